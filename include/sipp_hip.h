@@ -1,0 +1,136 @@
+/*
+ * sipp_hip.h -- C ABI of the MI355X-native SIPP STARK sub-prover (libsipp_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of qope/SIPP: the three starky
+ * sub-proofs that reference src/verifier_circuit.rs:133-135 delegates to
+ * starky-bn254 (g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit).  At proving
+ * time each of those runs, inside a plonky2 witness generator,
+ *     stark.generate_trace(&ios); stark.generate_public_inputs(&ios);
+ *     starky::prover::prove::<F, C, S, D>(stark, &config, trace, public_inputs, &mut timing)
+ * (starky-bn254 @ 2d46f9e and starky @ InternetMaximalism/plonky2 541e127,
+ * reference Cargo.toml:24,26 -- not vendored under /root/reference).  The three
+ * sipp_*_exp_prove entry points below replace exactly that body: native IO
+ * records in, flat StarkProofWithPublicInputs buffer out.  Trace fill happens
+ * on the device; the caller never materialises the N x W table.
+ *
+ * Conventions
+ *  - plain C, no callbacks, no exceptions; every function returns a sipp_status.
+ *  - field elements are canonical little-endian uint64_t (< 2^64 - 2^32 + 1);
+ *    extension elements are two consecutive uint64_t (c0, c1).
+ *  - BN254 integers are 8 x uint32_t little-endian limbs, exactly the limb
+ *    stream of reference src/transcript_native.rs:68-77 and src/statements.rs:90-131.
+ *  - `d_` parameters are DEVICE pointers (HBM of the ctx's GPU); everything else
+ *    is host memory owned by the caller.
+ *  - a sipp_ctx is bound to one GPU and is not thread-safe; distinct contexts on
+ *    distinct GPUs may be used concurrently (one process per GPU in bench.py).
+ */
+#ifndef SIPP_HIP_H
+#define SIPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sipp_ctx sipp_ctx;
+
+typedef enum {
+    SIPP_OK = 0,
+    SIPP_E_BADARG = -1,      /* null pointer, non power of two, size out of range */
+    SIPP_E_HIP = -2,         /* a HIP runtime call failed; see sipp_last_error */
+    SIPP_E_NOMEM = -3,       /* workspace arena exhausted */
+    SIPP_E_BUFSZ = -4,       /* caller's output buffer too small */
+    SIPP_E_SUBGROUP = -5,    /* zeta landed in the trace subgroup (starky prover.rs ensure!) */
+    SIPP_E_QUOTIENT = -6,    /* constraints not satisfied: quotient has too high degree */
+    SIPP_E_UNSUPPORTED = -7, /* configuration not supported by this build */
+    SIPP_E_WITNESS = -8      /* IO record not provable (point at infinity / not on curve) */
+} sipp_status;
+
+/* starky StarkConfig::standard_fast_config() */
+typedef struct {
+    uint32_t rate_bits;       /* 1 */
+    uint32_t cap_height;      /* 4 */
+    uint32_t pow_bits;        /* 16 */
+    uint32_t arity_bits;      /* 4 */
+    uint32_t final_poly_bits; /* 5 */
+    uint32_t num_queries;     /* 84 */
+    uint32_t num_challenges;  /* 2 */
+} sipp_stark_config;
+
+void sipp_default_config(sipp_stark_config *cfg);
+
+/* Which STARK (reference src/verifier_circuit.rs:133 / :134 / :135) */
+typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2 } sipp_kind;
+
+/* u32 words per IO record, (x, offset, exp_val, output) order:
+ * G1 7*8 = 56, G2 13*8 = 104, Fq12 37*8 = 296. */
+#define SIPP_G1_IO_WORDS 56
+#define SIPP_G2_IO_WORDS 104
+#define SIPP_FQ12_IO_WORDS 296
+
+/* ---- context ---------------------------------------------------------------- */
+/* `workspace_bytes` of HBM are reserved once; nothing is hipMalloc'ed afterwards.
+ * Pass 0 to size the arena for n = 128 (about 24 GiB). */
+int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t workspace_bytes);
+void sipp_ctx_destroy(sipp_ctx *ctx);
+const char *sipp_last_error(const sipp_ctx *ctx);
+int sipp_sync(sipp_ctx *ctx);
+/* the hipStream_t every launch of this ctx goes to (as void*) */
+void *sipp_stream(sipp_ctx *ctx);
+
+/* ---- the three provers (replace the body of starky-bn254's *ProofGenerator::run_once) */
+/* ios: num_io records of SIPP_*_IO_WORDS u32 each, outputs included (they are
+ * checked against the device-computed result).  num_io is padded internally to
+ * the next power of two by repeating the last record, as upstream does.
+ * On success *proof_len u64 words of proof_out are written (layout: INTEGRATION.md). */
+int sipp_g1_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+                      size_t *proof_len);
+int sipp_g2_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+                      size_t *proof_len);
+int sipp_fq12_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+                        size_t *proof_len);
+/* upper bound (u64 words) of the flat proof for `num_io` records of `kind` */
+size_t sipp_proof_size(const sipp_ctx *ctx, int kind, size_t num_io);
+/* trace shape the prover will use: rows (log2), main columns, permutation-Z columns, quotient chunks */
+int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
+                     uint32_t *perm_cols, uint32_t *quotient_cols);
+
+/* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
+/* plonky2 fft()/ifft(): natural order in, natural order out, in place.
+ * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */
+int sipp_ntt_batch(sipp_ctx *ctx, uint64_t *d_cols, size_t col_stride, size_t ncols, uint32_t log_n, int inverse);
+/* PolynomialBatch::from_values, column-major and transpose-free:
+ *   d_values [ncols][N] natural order  ->  d_coeffs [ncols][N] (natural, may alias d_values)
+ *   d_lde [ncols][N << rate_bits] in LEAF order (position j = natural LDE row bitrev(j)). */
+int sipp_lde_batch(sipp_ctx *ctx, const uint64_t *d_values, uint64_t *d_coeffs, uint64_t *d_lde, size_t ncols,
+                   uint32_t log_n);
+/* hash_or_noop of every leaf: d_lde [ncols][n_leaves] leaf order -> d_digests [n_leaves][4] */
+int sipp_poseidon_leaves(sipp_ctx *ctx, const uint64_t *d_lde, size_t ncols, uint32_t log_leaves,
+                         uint64_t *d_digests);
+/* Merkle levels above the leaf digests; d_tree holds every level back to back
+ * (level l at digest offset sum_{i<l} n_leaves >> i), level 0 = leaf digests (input).
+ * cap_out (host, 2^cap_height * 4 u64) receives the cap. */
+int sipp_merkle_cap(sipp_ctx *ctx, uint64_t *d_tree, uint32_t log_leaves, uint64_t *cap_out);
+/* values -> (coeffs, lde, tree, cap) in one call; d_tree sized 2 * n_leaves * 4 u64 */
+int sipp_commit_batch(sipp_ctx *ctx, const uint64_t *d_values, uint64_t *d_coeffs, uint64_t *d_lde,
+                      uint64_t *d_tree, size_t ncols, uint32_t log_n, uint64_t *cap_out);
+/* batched Poseidon permutation of n states, d_states [n][12] in place (KAT surface) */
+int sipp_poseidon_permute(sipp_ctx *ctx, uint64_t *d_states, size_t n);
+
+/* ---- measurement ------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the ctx stream (the stream the kernels run on).
+ * enable != 0 starts bracketing every launch with an event pair. */
+int sipp_profile_enable(sipp_ctx *ctx, int enable);
+int sipp_profile_reset(sipp_ctx *ctx);
+/* writes a JSON object {"kernel": {"calls": n, "ms": total}, ...} into buf */
+int sipp_profile_report(sipp_ctx *ctx, char *buf, size_t cap);
+/* wall-clock bracket on the ctx stream */
+int sipp_timer_start(sipp_ctx *ctx);
+int sipp_timer_stop(sipp_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

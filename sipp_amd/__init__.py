@@ -1,0 +1,8 @@
+"""sipp_amd -- MI355X-native STARK sub-prover for the SIPP hot path (reference
+src/verifier_circuit.rs:133-135).  The product is the C-ABI library libsipp_hip.so
+(include/sipp_hip.h); this package is the thin Python harness tests and bench.py use
+to drive it.  There is no CPU fallback: if the HIP library is missing or no GPU is
+present the calls fail loudly."""
+from ._lib import lib, Ctx, SippError, default_config, StarkConfig  # noqa: F401
+
+__all__ = ["lib", "Ctx", "SippError", "default_config", "StarkConfig"]

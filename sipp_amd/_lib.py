@@ -1,0 +1,201 @@
+"""ctypes binding of include/sipp_hip.h -- the same surface a Rust `extern "C"` block would bind
+(INTEGRATION.md).  Device memory is plain torch tensors (dtype int64 viewed as u64)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libsipp_hip.so")
+
+P = 2**64 - 2**32 + 1
+
+STATUS = {
+    0: "SIPP_OK", -1: "SIPP_E_BADARG", -2: "SIPP_E_HIP", -3: "SIPP_E_NOMEM", -4: "SIPP_E_BUFSZ",
+    -5: "SIPP_E_SUBGROUP", -6: "SIPP_E_QUOTIENT", -7: "SIPP_E_UNSUPPORTED", -8: "SIPP_E_WITNESS",
+}
+
+
+class SippError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class StarkConfig(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "arity_bits", "final_poly_bits",
+                                          "num_queries", "num_challenges")]
+
+
+# every symbol include/sipp_hip.h declares: name -> (restype, argtypes)
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+vp = C.c_void_p
+SIGNATURES = {
+    "sipp_default_config": (None, [C.POINTER(StarkConfig)]),
+    "sipp_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(StarkConfig), C.c_size_t]),
+    "sipp_ctx_destroy": (None, [vp]),
+    "sipp_last_error": (C.c_char_p, [vp]),
+    "sipp_sync": (C.c_int, [vp]),
+    "sipp_stream": (vp, [vp]),
+    "sipp_g1_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_g2_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
+    "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
+    "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
+    "sipp_lde_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
+    "sipp_poseidon_leaves": (C.c_int, [vp, vp, C.c_size_t, C.c_uint32, vp]),
+    "sipp_merkle_cap": (C.c_int, [vp, vp, C.c_uint32, vp]),
+    "sipp_commit_batch": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp]),
+    "sipp_poseidon_permute": (C.c_int, [vp, vp, C.c_size_t]),
+    "sipp_profile_enable": (C.c_int, [vp, C.c_int]),
+    "sipp_profile_reset": (C.c_int, [vp]),
+    "sipp_profile_report": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "sipp_timer_start": (C.c_int, [vp]),
+    "sipp_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsipp_hip.so.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise SippError(-7, "libsipp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(SO)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def default_config():
+    cfg = StarkConfig()
+    lib().sipp_default_config(C.byref(cfg))
+    return cfg
+
+
+def to_device(arr):
+    """host uint64 ndarray -> device tensor (int64 bit pattern)"""
+    import torch
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy(a.view(np.int64)).to("cuda")
+
+
+def to_host(t):
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Ctx:
+    """One GPU, one stream, one workspace arena (sipp_ctx)."""
+
+    def __init__(self, device=0, cfg=None, workspace_bytes=1 << 30):
+        import torch
+        if not torch.cuda.is_available():
+            raise SippError(-2, "no GPU visible: the SIPP HIP path has no CPU fallback")
+        self.L = lib()
+        self.device = device
+        torch.cuda.set_device(device)
+        h = vp()
+        rc = self.L.sipp_ctx_create(C.byref(h), device, C.byref(cfg) if cfg is not None else None, workspace_bytes)
+        if rc != 0:
+            raise SippError(rc, "sipp_ctx_create")
+        self.h = h
+        self.cfg = cfg if cfg is not None else default_config()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sipp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise SippError(rc, "%s: %s" % (what, self.L.sipp_last_error(self.h).decode()))
+
+    def sync(self):
+        self._ck(self.L.sipp_sync(self.h), "sync")
+
+    # ---- building blocks (device tensors) ----
+    def ntt(self, t, log_n, inverse=False):
+        """in place, natural -> natural; t is [ncols, stride] int64"""
+        assert t.is_cuda and t.dim() == 2 and t.is_contiguous()
+        self._ck(self.L.sipp_ntt_batch(self.h, t.data_ptr(), t.shape[1], t.shape[0], log_n, int(inverse)), "ntt_batch")
+        return t
+
+    def lde(self, values, log_n):
+        import torch
+        ncols = values.shape[0]
+        rb = self.cfg.rate_bits
+        coeffs = torch.empty_like(values)
+        lde = torch.empty((ncols, values.shape[1] << rb), dtype=torch.int64, device=values.device)
+        self._ck(self.L.sipp_lde_batch(self.h, values.data_ptr(), coeffs.data_ptr(), lde.data_ptr(), ncols, log_n),
+                 "lde_batch")
+        return coeffs, lde
+
+    def poseidon_leaves(self, lde, log_leaves):
+        import torch
+        dig = torch.empty(((1 << log_leaves), 4), dtype=torch.int64, device=lde.device)
+        self._ck(self.L.sipp_poseidon_leaves(self.h, lde.data_ptr(), lde.shape[0], log_leaves, dig.data_ptr()),
+                 "poseidon_leaves")
+        return dig
+
+    def merkle_cap(self, tree, log_leaves):
+        ch = min(self.cfg.cap_height, log_leaves)
+        cap = np.zeros((1 << ch, 4), dtype=np.uint64)
+        self._ck(self.L.sipp_merkle_cap(self.h, tree.data_ptr(), log_leaves, cap.ctypes.data), "merkle_cap")
+        return cap
+
+    def commit(self, values, log_n, bufs=None):
+        """PolynomialBatch::from_values on device.  Returns (coeffs, lde, tree, cap)."""
+        import torch
+        ncols = values.shape[0]
+        rb = self.cfg.rate_bits
+        log_m = log_n + rb
+        if bufs is None:
+            coeffs = torch.empty_like(values)
+            lde = torch.empty((ncols, 1 << log_m), dtype=torch.int64, device=values.device)
+            tree = torch.empty((2 << log_m, 4), dtype=torch.int64, device=values.device)
+        else:
+            coeffs, lde, tree = bufs
+        ch = min(self.cfg.cap_height, log_m)
+        cap = np.zeros((1 << ch, 4), dtype=np.uint64)
+        self._ck(self.L.sipp_commit_batch(self.h, values.data_ptr(), coeffs.data_ptr(), lde.data_ptr(),
+                                          tree.data_ptr(), ncols, log_n, cap.ctypes.data), "commit_batch")
+        return coeffs, lde, tree, cap
+
+    def poseidon_permute(self, states):
+        self._ck(self.L.sipp_poseidon_permute(self.h, states.data_ptr(), states.shape[0]), "poseidon_permute")
+        return states
+
+    # ---- measurement ----
+    def profile(self, enable=True):
+        self._ck(self.L.sipp_profile_enable(self.h, int(enable)), "profile_enable")
+
+    def profile_reset(self):
+        self._ck(self.L.sipp_profile_reset(self.h), "profile_reset")
+
+    def profile_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._ck(self.L.sipp_profile_report(self.h, buf, len(buf)), "profile_report")
+        return json.loads(buf.value.decode())
+
+    def timer_start(self):
+        self._ck(self.L.sipp_timer_start(self.h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.L.sipp_timer_stop(self.h, C.byref(ms)), "timer_stop")
+        return ms.value

@@ -1,0 +1,249 @@
+// sipp_amd/csrc/api.hip -- C-ABI entry points of include/sipp_hip.h: context, arena, tables,
+// profiling and the building-block calls (NTT / LDE / Poseidon leaves / Merkle / commit).
+#include <algorithm>
+#include <string>
+
+#include "ctx.hpp"
+
+int sipp_poseidon_init_constants(sipp_ctx* ctx);  // poseidon.hip
+
+extern "C" {
+
+void sipp_default_config(sipp_stark_config* cfg) {
+    if (!cfg) return;
+    cfg->rate_bits = 1;
+    cfg->cap_height = 4;
+    cfg->pow_bits = 16;
+    cfg->arity_bits = 4;
+    cfg->final_poly_bits = 5;
+    cfg->num_queries = 84;
+    cfg->num_challenges = 2;
+}
+
+int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, size_t workspace_bytes) {
+    if (!out) return SIPP_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SIPP_E_HIP;
+    sipp_ctx* ctx = new sipp_ctx();
+    ctx->device = device;
+    if (cfg)
+        ctx->cfg = *cfg;
+    else
+        sipp_default_config(&ctx->cfg);
+    if (ctx->cfg.rate_bits != 1 || ctx->cfg.num_challenges != 2 || ctx->cfg.arity_bits != 4 ||
+        ctx->cfg.cap_height > 8) {
+        delete ctx;
+        return SIPP_E_UNSUPPORTED;
+    }
+    auto bail = [&](int rc) {
+        sipp_ctx_destroy(ctx);
+        return rc;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(SIPP_E_HIP);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(SIPP_E_HIP);
+    if (workspace_bytes == 0) workspace_bytes = (size_t)24 << 30;
+    ctx->arena_size = workspace_bytes;
+    if (hipMalloc((void**)&ctx->arena, workspace_bytes) != hipSuccess) return bail(SIPP_E_NOMEM);
+    if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) return bail(SIPP_E_HIP);
+    ctx->h_pinned_words = (size_t)1 << 20;  // 8 MiB of pinned staging for caps / openings / query rows
+    if (hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_words * 8) != hipSuccess) return bail(SIPP_E_NOMEM);
+    int rc = sipp_poseidon_init_constants(ctx);
+    if (rc != SIPP_OK) return bail(rc);
+    *out = ctx;
+    return SIPP_OK;
+}
+
+void sipp_ctx_destroy(sipp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->tables) (void)hipFree(kv.second);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sipp_last_error(const sipp_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int sipp_sync(sipp_ctx* ctx) {
+    if (!ctx) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SIPP_OK;
+}
+
+void* sipp_stream(sipp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---- profiling ------------------------------------------------------------------
+static void prof_drain(sipp_ctx* ctx) {
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[std::get<1>(p)], ctx->ev_pool[std::get<2>(p)]) == hipSuccess) {
+            auto& e = ctx->prof_acc[std::get<0>(p)];
+            e.calls++;
+            e.ms += ms;
+        }
+    }
+    ctx->pending.clear();
+    ctx->ev_used = 0;
+}
+
+int sipp_profile_enable(sipp_ctx* ctx, int enable) {
+    if (!ctx) return SIPP_E_BADARG;
+    if (!enable) prof_drain(ctx);
+    ctx->prof = enable != 0;
+    return SIPP_OK;
+}
+
+int sipp_profile_reset(sipp_ctx* ctx) {
+    if (!ctx) return SIPP_E_BADARG;
+    prof_drain(ctx);
+    ctx->prof_acc.clear();
+    return SIPP_OK;
+}
+
+int sipp_profile_report(sipp_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap < 3) return SIPP_E_BADARG;
+    prof_drain(ctx);
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : ctx->prof_acc) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\"%s\": {\"calls\": %d, \"ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+                 kv.second.calls, kv.second.ms);
+        s += line;
+        first = false;
+    }
+    s += "}";
+    if (s.size() + 1 > cap) return SIPP_E_BUFSZ;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return SIPP_OK;
+}
+
+int sipp_timer_start(sipp_ctx* ctx) {
+    if (!ctx) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return SIPP_OK;
+}
+
+int sipp_timer_stop(sipp_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipEventSynchronize(ctx->t1));
+    SIPP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return SIPP_OK;
+}
+
+// ---- building blocks --------------------------------------------------------------
+int sipp_ntt_batch(sipp_ctx* ctx, uint64_t* d_cols, size_t col_stride, size_t ncols, uint32_t log_n, int inverse) {
+    if (!ctx || !d_cols) return SIPP_E_BADARG;
+    size_t n = (size_t)1 << log_n;
+    if (col_stride < n) return sipp_fail(ctx, SIPP_E_BADARG, "ntt_batch: col_stride < n");
+    ArenaMark m = arena_mark(ctx);
+    uint64_t* tmp = arena_alloc_t<uint64_t>(ctx, n * ncols);
+    if (!tmp) return SIPP_E_NOMEM;
+    // natural -> (DIF) bit-reversed -> permuted back to natural
+    int rc = sipp_ntt_dif(ctx, d_cols, col_stride, log_n, tmp, n, log_n, ncols, inverse != 0, NttDiag{});
+    if (rc == SIPP_OK) rc = sipp_bitrev_cols(ctx, tmp, n, d_cols, col_stride, log_n, ncols);
+    if (rc == SIPP_OK) rc = sipp_sync(ctx);
+    arena_release(ctx, m);
+    return rc;
+}
+
+// values (natural) -> coeffs (natural) + LDE (leaf order)
+static int lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
+                           uint32_t log_n) {
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t rb = ctx->cfg.rate_bits;
+    ArenaMark m = arena_mark(ctx);
+    uint64_t* src = const_cast<uint64_t*>(d_values);
+    int rc = SIPP_OK;
+    if (d_values == d_coeffs) {
+        uint64_t* tmp = arena_alloc_t<uint64_t>(ctx, n * ncols);
+        if (!tmp) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(tmp, d_values, n * ncols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        src = tmp;
+    }
+    rc = sipp_bitrev_cols(ctx, src, n, d_coeffs, n, log_n, ncols);
+    if (rc == SIPP_OK) rc = sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, /*inverse=*/true, NttDiag{});
+    if (rc == SIPP_OK)
+        rc = sipp_ntt_dif(ctx, d_coeffs, n, log_n, d_lde, n << rb, log_n + rb, ncols, false, NttDiag{gl::GEN, 0});
+    arena_release(ctx, m);
+    return rc;
+}
+
+int sipp_lde_batch(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
+                   uint32_t log_n) {
+    if (!ctx || !d_values || !d_coeffs || !d_lde) return SIPP_E_BADARG;
+    SIPP_TRY(lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n));
+    return sipp_sync(ctx);
+}
+
+int sipp_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t ncols, uint32_t log_leaves,
+                         uint64_t* d_digests) {
+    if (!ctx || !d_lde || !d_digests) return SIPP_E_BADARG;
+    SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_leaves, ncols, log_leaves, d_digests));
+    return sipp_sync(ctx);
+}
+
+static int read_cap(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, uint64_t* cap_out) {
+    uint32_t ch = std::min(ctx->cfg.cap_height, log_leaves);
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < log_leaves - ch; l++) off += (uint64_t)1 << (log_leaves - l);
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(cap_out, d_tree + 4 * off, ((size_t)4 << ch) * 8, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+    return sipp_sync(ctx);
+}
+
+int sipp_merkle_cap(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint64_t* cap_out) {
+    if (!ctx || !d_tree || !cap_out) return SIPP_E_BADARG;
+    SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_leaves, ctx->cfg.cap_height));
+    return read_cap(ctx, d_tree, log_leaves, cap_out);
+}
+
+int sipp_commit_batch(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, uint64_t* d_tree,
+                      size_t ncols, uint32_t log_n, uint64_t* cap_out) {
+    if (!ctx || !d_values || !d_coeffs || !d_lde || !d_tree || !cap_out) return SIPP_E_BADARG;
+    const uint32_t log_m = log_n + ctx->cfg.rate_bits;
+    SIPP_TRY(lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n));
+    SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
+    SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
+    return read_cap(ctx, d_tree, log_m, cap_out);
+}
+
+int sipp_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n) {
+    if (!ctx || !d_states) return SIPP_E_BADARG;
+    SIPP_TRY(sipp_k_poseidon_permute(ctx, d_states, n));
+    return sipp_sync(ctx);
+}
+
+// ---- provers: implemented in stark.hip -----------------------------------------------
+}  // extern "C"
+
+// ---- persistent tables ------------------------------------------------------------------
+uint64_t* sipp_table_get(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b) {
+    auto it = ctx->tables.find(std::make_tuple(kind, a, b));
+    return it == ctx->tables.end() ? nullptr : it->second;
+}
+
+int sipp_table_put(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b, const std::vector<uint64_t>& host,
+                   uint64_t** out) {
+    uint64_t* d = nullptr;
+    // tables are created once per (kind, size) and live as long as the ctx: the only hipMalloc outside
+    // sipp_ctx_create, and only on the first use of a new transform size.
+    SIPP_CHECK_HIP(ctx, hipMalloc((void**)&d, host.size() * 8));
+    hipError_t e = hipMemcpy(d, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        SIPP_CHECK_HIP(ctx, e);
+    }
+    ctx->tables[std::make_tuple(kind, a, b)] = d;
+    *out = d;
+    return SIPP_OK;
+}

@@ -1,0 +1,154 @@
+// sipp_amd/csrc/ctx.hpp -- internal state behind the opaque sipp_ctx of include/sipp_hip.h.
+//
+// One ctx == one GPU == one HIP stream.  All device memory comes from a bump arena that is
+// reserved once at sipp_ctx_create (no hipMalloc in the steady state, SURVEY.md section 8b
+// "threading" row); twiddle / power tables are cached per (kind, size) for the ctx lifetime.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/sipp_hip.h"
+#include "gl.hpp"
+
+struct sipp_prof_entry {
+    int calls = 0;
+    double ms = 0.0;
+};
+
+struct sipp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    sipp_stark_config cfg{};
+    char err[512] = {0};
+
+    // bump arena (device)
+    char* arena = nullptr;
+    size_t arena_size = 0;
+    size_t arena_off = 0;
+    size_t arena_peak = 0;
+
+    // persistent small tables (device), keyed by (kind, a, b)
+    std::map<std::tuple<int, uint64_t, uint64_t>, uint64_t*> tables;
+
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::tuple<std::string, size_t, size_t>> pending;  // name, ev index a, b
+    std::map<std::string, sipp_prof_entry> prof_acc;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    // pinned host staging
+    uint64_t* h_pinned = nullptr;
+    size_t h_pinned_words = 0;
+};
+
+#define SIPP_CHECK_HIP(ctx, expr)                                                                   \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,  \
+                     hipGetErrorString(e__));                                                       \
+            return SIPP_E_HIP;                                                                      \
+        }                                                                                           \
+    } while (0)
+
+#define SIPP_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != SIPP_OK) return rc__; \
+    } while (0)
+
+static inline int sipp_fail(sipp_ctx* ctx, int code, const char* msg) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+    return code;
+}
+
+// ---- arena -------------------------------------------------------------------
+struct ArenaMark {
+    size_t off;
+};
+static inline ArenaMark arena_mark(sipp_ctx* ctx) { return ArenaMark{ctx->arena_off}; }
+static inline void arena_release(sipp_ctx* ctx, ArenaMark m) { ctx->arena_off = m.off; }
+// returns nullptr when exhausted
+static inline void* arena_alloc(sipp_ctx* ctx, size_t bytes) {
+    size_t off = (ctx->arena_off + 255) & ~(size_t)255;
+    if (off + bytes > ctx->arena_size) {
+        snprintf(ctx->err, sizeof(ctx->err), "workspace arena exhausted: need %zu more bytes (size %zu, used %zu)",
+                 bytes, ctx->arena_size, off);
+        return nullptr;
+    }
+    ctx->arena_off = off + bytes;
+    if (ctx->arena_off > ctx->arena_peak) ctx->arena_peak = ctx->arena_off;
+    return ctx->arena + off;
+}
+template <typename T>
+static inline T* arena_alloc_t(sipp_ctx* ctx, size_t count) {
+    return reinterpret_cast<T*>(arena_alloc(ctx, count * sizeof(T)));
+}
+
+// ---- profiling-aware launch bracket ------------------------------------------
+struct ProfScope {
+    sipp_ctx* ctx;
+    const char* name;
+    size_t ia = 0, ib = 0;
+    bool on;
+    ProfScope(sipp_ctx* c, const char* n) : ctx(c), name(n), on(c->prof) {
+        if (!on) return;
+        if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+            size_t old = ctx->ev_pool.size();
+            ctx->ev_pool.resize(old + 256);
+            for (size_t i = old; i < ctx->ev_pool.size(); i++) (void)hipEventCreate(&ctx->ev_pool[i]);
+        }
+        ia = ctx->ev_used++;
+        ib = ctx->ev_used++;
+        (void)hipEventRecord(ctx->ev_pool[ia], ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(ctx->ev_pool[ib], ctx->stream);
+        ctx->pending.emplace_back(name, ia, ib);
+    }
+};
+
+// ---- persistent tables ---------------------------------------------------------
+enum TableKind {
+    TAB_WR = 1,       // w_R^x, x < R/2            key (logR, inverse)
+    TAB_TW_LO = 2,    // w_m^x, x < 2^L            key (logm, inverse)
+    TAB_TW_HI = 3,    // w_m^(x * 2^L)             key (logm, inverse)
+    TAB_POW_LO = 4,   // base^x * c                key (id, L)
+    TAB_POW_HI = 5,   // base^(x * 2^L)            key (id, L)
+};
+
+uint64_t* sipp_table_get(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b);
+int sipp_table_put(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b, const std::vector<uint64_t>& host, uint64_t** out);
+
+// ---- internal kernels' host entry points (ntt.hip / poseidon.hip) ---------------
+// Direction of an in-place radix-2 transform over a column-major batch.
+//   DIF: natural order in  -> bit-reversed order out
+//   DIT: bit-reversed in   -> natural order out
+struct NttDiag {
+    // optional per-element scaling by base^(natural index) * c, applied on the natural-order side
+    // (DIF: input, DIT: output).  base == 0 disables; c == 0 means 1.
+    uint64_t base = 0;
+    uint64_t c = 0;
+};
+int sipp_ntt_dif(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint32_t log_n_in, uint64_t* d_out,
+                 size_t out_stride, uint32_t log_n, size_t ncols, bool inverse, NttDiag diag);
+int sipp_ntt_dit(sipp_ctx* ctx, uint64_t* d_io, size_t stride, uint32_t log_n, size_t ncols, bool inverse,
+                 NttDiag diag);
+// out[c][j] = in[c][bitrev(j)]  (out != in)
+int sipp_bitrev_cols(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_out, size_t out_stride,
+                     uint32_t log_n, size_t ncols);
+
+int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stride, size_t ncols, uint32_t log_leaves,
+                           uint64_t* d_digests);
+int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height);
+int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n);

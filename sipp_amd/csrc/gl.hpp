@@ -1,0 +1,160 @@
+// sipp_amd/csrc/gl.hpp -- Goldilocks field (p = 2^64 - 2^32 + 1) and its quadratic extension
+// F_p[X]/(X^2 - 7) for gfx950 device code and the host-side driver.
+//
+// All values that cross a kernel boundary are canonical (< p).  64-bit integer modular
+// arithmetic on a 32-bit VALU: a mulmod is four 32x32->64 multiply-adds plus a
+// shift/add reduction (2^64 = 2^32 - 1, 2^96 = -1 mod p) -- no MFMA anywhere.
+//
+// Replaces (on the GPU side) plonky2's GoldilocksField @ InternetMaximalism/plonky2 541e127
+// (reference Cargo.toml:21; used as `F` at reference src/prover_native.rs:7,12).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace gl {
+
+constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
+constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
+constexpr uint64_t GEN = 7;              // multiplicative generator == coset shift
+constexpr uint64_t TWO_ADIC_ROOT = 1753635133440165772ULL;  // order 2^32
+constexpr uint64_t EXT_W = 7;            // X^2 = 7
+
+GL_HD uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
+
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    uint64_t t = s - P;  // == s + EPS mod 2^64
+    return (s < a || s >= P) ? t : s;
+}
+
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return a < b ? d + P : d;
+}
+
+GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+
+GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
+
+// (hi, lo) -> canonical.  hi:lo is any 128-bit value.
+GL_HD uint64_t reduce128(uint64_t hi, uint64_t lo) {
+    uint64_t hi_hi = hi >> 32;
+    uint64_t hi_lo = hi & EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;
+    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
+    uint64_t r = t0 + t1;
+    if (r < t0) r += EPS;
+    return canon(r);
+}
+
+// value = lo + 2^64 * hi32 with hi32 < 2^32 (a "96-bit" accumulator)
+GL_HD uint64_t reduce96(uint32_t hi32, uint64_t lo) {
+    uint64_t t1 = ((uint64_t)hi32 << 32) - hi32;
+    uint64_t r = lo + t1;
+    if (r < lo) r += EPS;
+    return canon(r);
+}
+
+GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (uint64_t)p;
+    hi = (uint64_t)(p >> 64);
+#endif
+}
+
+GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+    uint64_t hi, lo;
+    mul_wide(a, b, hi, lo);
+    return reduce128(hi, lo);
+}
+
+GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+// a * b + c
+GL_HD uint64_t mad(uint64_t a, uint64_t b, uint64_t c) {
+    uint64_t hi, lo;
+    mul_wide(a, b, hi, lo);
+    lo += c;
+    hi += (lo < c);
+    return reduce128(hi, lo);
+}
+
+GL_HD uint64_t pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+GL_HD uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+
+GL_HD uint64_t root_of_unity(unsigned k) {
+    uint64_t r = TWO_ADIC_ROOT;
+    for (unsigned i = k; i < 32; i++) r = sqr(r);
+    return r;
+}
+
+// signed small integer -> field
+GL_HD uint64_t from_i64(int64_t v) { return v >= 0 ? (uint64_t)v : P - (uint64_t)(-v); }
+
+// ---- quadratic extension ----
+struct E2 {
+    uint64_t c0, c1;
+};
+
+GL_HD E2 e2(uint64_t c0, uint64_t c1 = 0) { return E2{c0, c1}; }
+GL_HD E2 add(E2 a, E2 b) { return E2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+GL_HD E2 sub(E2 a, E2 b) { return E2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+GL_HD E2 neg(E2 a) { return E2{neg(a.c0), neg(a.c1)}; }
+GL_HD E2 mul(E2 a, E2 b) {
+    uint64_t t = mul(a.c1, b.c1);
+    uint64_t c0 = mad(a.c0, b.c0, mul(t, EXT_W));
+    uint64_t c1 = mad(a.c0, b.c1, mul(a.c1, b.c0));
+    return E2{c0, c1};
+}
+GL_HD E2 scale(E2 a, uint64_t s) { return E2{mul(a.c0, s), mul(a.c1, s)}; }
+GL_HD E2 sqr(E2 a) { return mul(a, a); }
+GL_HD bool eq(E2 a, E2 b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+GL_HD E2 inv(E2 a) {
+    uint64_t n = sub(sqr(a.c0), mul(EXT_W, sqr(a.c1)));
+    uint64_t ni = inv(n);
+    return E2{mul(a.c0, ni), mul(neg(a.c1), ni)};
+}
+GL_HD E2 pow(E2 a, uint64_t e) {
+    E2 r{1, 0};
+    while (e) {
+        if (e & 1) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+GL_HD uint32_t bitrev(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1);
+        x >>= 1;
+    }
+    return r;
+#endif
+}
+
+}  // namespace gl

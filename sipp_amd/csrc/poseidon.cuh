@@ -1,0 +1,130 @@
+// sipp_amd/csrc/poseidon.cuh -- Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds),
+// one state per lane, for gfx950.
+//
+// Replaces plonky2's PoseidonPermutation / PoseidonHash (hash/poseidon.rs @ 541e127; selected by the
+// reference at src/verifier_circuit.rs:196 `PoseidonGoldilocksConfig` and used natively at
+// src/transcript_native.rs:27,57).
+//
+// Mapping to the hardware (DESIGN.md "Poseidon"):
+//  * 12 x u64 state lives in 24 VGPRs of ONE lane; a wave hashes 64 independent leaves/nodes, so there
+//    is no cross-lane traffic at all and every global access is lane-contiguous.
+//  * round constants / sparse-matrix tables are wave-uniform: they sit in __constant__ memory and are
+//    fetched with scalar loads (s_load), costing no VGPRs and no VALU issue slots.
+//  * full-round MDS (circulant, entries <= 41): state split into 32-bit halves, each output is two
+//    chains of 12 v_mad_u64_u32 (32 x 32 + 64) and ONE 96-bit reduction.
+//  * the 22 partial rounds use the equivalent sparse factorisation (tables derived and verified in
+//    tools/gen_poseidon_header.py): 1 dense 11x11 pre-multiplication, then per round one 160-bit
+//    dot product and 11 multiply-adds instead of a dense MDS.
+//  * the round loops are NOT unrolled (code stays inside the instruction cache); the per-lane loops are.
+#pragma once
+#include "gl.hpp"
+#include "poseidon_constants.h"
+
+namespace poseidon {
+
+__constant__ uint64_t c_rc[360];
+__constant__ uint64_t c_fast_first[12];
+__constant__ uint64_t c_fast_scalar[22];
+__constant__ uint64_t c_fast_mi[121];
+__constant__ uint64_t c_fast_vs[22 * 11];
+__constant__ uint64_t c_fast_what[22 * 11];
+
+__device__ __forceinline__ uint64_t sbox(uint64_t x) {
+    uint64_t x2 = gl::sqr(x);
+    uint64_t x3 = gl::mul(x2, x);
+    uint64_t x4 = gl::sqr(x2);
+    return gl::mul(x3, x4);
+}
+
+// out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  CIRC = 17 15 41 16 2 28 13 13 39 18 34 20, DIAG[0] = 8
+__device__ __forceinline__ void mds_full(uint64_t s[12]) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (uint64_t)lo[(i + r) % 12] * CIRC[i];
+            ah += (uint64_t)hi[(i + r) % 12] * CIRC[i];
+        }
+        if (r == 0) {
+            al += (uint64_t)lo[0] * 8u;
+            ah += (uint64_t)hi[0] * 8u;
+        }
+        // value = al + ah * 2^32, al, ah < 2^42
+        uint64_t l = al + (ah << 32);
+        uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
+        s[r] = gl::reduce96(h, l);
+    }
+}
+
+struct Acc160 {
+    uint64_t lo = 0, hi = 0;
+    uint32_t c = 0;
+    __device__ __forceinline__ void mac(uint64_t a, uint64_t b) {
+        uint64_t ph, pl;
+        gl::mul_wide(a, b, ph, pl);
+        lo += pl;
+        ph += (lo < pl);  // ph <= 2^64 - 2, cannot wrap
+        hi += ph;
+        c += (hi < ph);
+    }
+    // 2^128 = -2^32 (mod p)
+    __device__ __forceinline__ uint64_t reduce() const {
+        return gl::sub(gl::reduce128(hi, lo), (uint64_t)c << 32);
+    }
+};
+
+__device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], c_rc[12 * rnd + i]));
+    mds_full(s);
+}
+
+__device__ __forceinline__ void partial_rounds_fast(uint64_t s[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], c_fast_first[i]);
+    {
+        uint64_t t[11];
+#pragma unroll 1
+        for (int i = 0; i < 11; i++) {
+            Acc160 acc;
+#pragma unroll
+            for (int j = 0; j < 11; j++) acc.mac(s[j + 1], c_fast_mi[i * 11 + j]);
+            uint64_t v = acc.reduce();
+            // static register indices: write through a switch the compiler turns into v_cndmask/moves
+#pragma unroll
+            for (int q = 0; q < 11; q++)
+                if (q == i) t[q] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 11; i++) s[i + 1] = t[i];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        uint64_t x = gl::add(sbox(s[0]), c_fast_scalar[r]);
+        Acc160 acc;
+        acc.mac(x, 25);  // M[0][0] = CIRC[0] + DIAG[0]
+#pragma unroll
+        for (int i = 0; i < 11; i++) acc.mac(s[i + 1], c_fast_what[r * 11 + i]);
+#pragma unroll
+        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad(x, c_fast_vs[r * 11 + i], s[i + 1]);
+        s[0] = acc.reduce();
+    }
+}
+
+__device__ __forceinline__ void permute(uint64_t s[12]) {
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) full_round(s, r);
+    partial_rounds_fast(s);
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) full_round(s, r);
+}
+
+}  // namespace poseidon

@@ -1,0 +1,135 @@
+// sipp_amd/csrc/poseidon.hip -- batched Poseidon leaf hashing and Merkle levels (one leaf / node per lane).
+//
+// Replaces plonky2's MerkleTree::new over PoseidonHash (hash/merkle_tree.rs, hashing.rs @ 541e127),
+// reached from the reference through starky::prover::prove behind src/verifier_circuit.rs:133-135.
+//
+// Layout: the LDE is column-major [col][leaf] in LEAF order, so the 64 lanes of a wave read 64
+// consecutive u64 of one column per load (512 B, fully coalesced) and no transpose ever exists.
+// Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
+#include "ctx.hpp"
+#include "poseidon.cuh"
+
+namespace {
+
+// hash_or_noop(leaf): ncols <= 4 -> the zero-padded elements are the digest; otherwise the
+// overwrite-mode sponge with rate 8 (hash_n_to_hash_no_pad).
+__global__ void __launch_bounds__(256) poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
+                                                             uint32_t ncols, uint64_t n_leaves,
+                                                             uint64_t* __restrict__ digests) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const uint64_t* p = lde + j;
+    if (ncols <= 4) {
+        for (uint32_t c = 0; c < ncols; c++) {
+            uint64_t v = p[(size_t)c * col_stride];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (q == (int)c) s[q] = v;
+        }
+    } else {
+        uint32_t c = 0;
+        for (; c + 8 <= ncols; c += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * col_stride];
+            poseidon::permute(s);
+        }
+        if (c < ncols) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c + i < ncols) s[i] = p[(size_t)(c + i) * col_stride];
+            poseidon::permute(s);
+        }
+    }
+    uint64_t* d = digests + 4 * j;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+    d[3] = s[3];
+}
+
+// parent[i] = two_to_one(child[2i], child[2i+1])
+__global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __restrict__ child,
+                                                          uint64_t* __restrict__ parent, uint64_t n_parents) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    uint64_t s[12];
+    const uint64_t* c = child + 8 * i;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s[q] = c[q];
+#pragma unroll
+    for (int q = 8; q < 12; q++) s[q] = 0;
+    poseidon::permute(s);
+    uint64_t* d = parent + 4 * i;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+    d[3] = s[3];
+}
+
+__global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) s[q] = states[12 * i + q];
+    poseidon::permute(s);
+#pragma unroll
+    for (int q = 0; q < 12; q++) states[12 * i + q] = s[q];
+}
+
+}  // namespace
+
+int sipp_poseidon_init_constants(sipp_ctx* ctx) {
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_rc), SIPP_POSEIDON_RC, sizeof(SIPP_POSEIDON_RC)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_first), SIPP_POSEIDON_FAST_FIRST,
+                                          sizeof(SIPP_POSEIDON_FAST_FIRST)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_scalar), SIPP_POSEIDON_FAST_SCALAR,
+                                          sizeof(SIPP_POSEIDON_FAST_SCALAR)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_mi), SIPP_POSEIDON_FAST_MI,
+                                          sizeof(SIPP_POSEIDON_FAST_MI)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_vs), SIPP_POSEIDON_FAST_VS,
+                                          sizeof(SIPP_POSEIDON_FAST_VS)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_what), SIPP_POSEIDON_FAST_WHAT,
+                                          sizeof(SIPP_POSEIDON_FAST_WHAT)));
+    return SIPP_OK;
+}
+
+int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stride, size_t ncols, uint32_t log_leaves,
+                           uint64_t* d_digests) {
+    if (ncols == 0 || ncols > 0xffffffffull) return sipp_fail(ctx, SIPP_E_BADARG, "poseidon_leaves: bad ncols");
+    uint64_t n = (uint64_t)1 << log_leaves;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    ProfScope ps(ctx, "poseidon_leaves");
+    hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                       (uint32_t)ncols, n, d_digests);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height) {
+    if (cap_height > log_leaves) cap_height = log_leaves;
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < log_leaves - cap_height; l++) {
+        uint64_t n_child = (uint64_t)1 << (log_leaves - l);
+        uint64_t n_par = n_child >> 1;
+        unsigned grid = (unsigned)((n_par + 255) / 256);
+        ProfScope ps(ctx, "merkle_level");
+        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
+                           d_tree + 4 * (off + n_child), n_par);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        off += n_child;
+    }
+    return SIPP_OK;
+}
+
+int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n) {
+    if (!n) return SIPP_OK;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    ProfScope ps(ctx, "poseidon_permute");
+    hipLaunchKernelGGL(poseidon_permute_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_states, (uint64_t)n);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}

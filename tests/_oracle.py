@@ -1,0 +1,121 @@
+"""ctypes loader for oracle/liboracle.so (the CPU restatement).  Test infrastructure:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+P = 2**64 - 2**32 + 1
+
+u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(ODIR, "liboracle.so")
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ODIR, "-s"])
+    return so
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    sig = {
+        "orc_poseidon_permute": (None, [u64p]),
+        "orc_hash_no_pad": (None, [u64p, C.c_size_t, u64p]),
+        "orc_two_to_one": (None, [u64p, u64p, u64p]),
+        "orc_fft": (None, [u64p, C.c_uint]),
+        "orc_ifft": (None, [u64p, C.c_uint]),
+        "orc_naive_dft": (None, [u64p, u64p, C.c_uint]),
+        "orc_coset_lde": (None, [u64p, C.c_uint, C.c_uint, C.c_uint64, u64p]),
+        "orc_batch_from_values": (C.c_void_p, [u64p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]),
+        "orc_batch_from_coeffs": (C.c_void_p, [u64p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint]),
+        "orc_batch_free": (None, [C.c_void_p]),
+        "orc_batch_cap": (C.POINTER(C.c_uint64), [C.c_void_p]),
+        "orc_batch_leaves": (C.POINTER(C.c_uint64), [C.c_void_p]),
+        "orc_batch_coeffs": (C.POINTER(C.c_uint64), [C.c_void_p]),
+        "orc_batch_level": (C.POINTER(C.c_uint64), [C.c_void_p, C.c_uint, C.POINTER(C.c_size_t)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def rand_field(rng, shape):
+    """uniform canonical Goldilocks elements"""
+    a = rng.integers(0, P, size=shape, dtype=np.uint64, endpoint=False)
+    return np.ascontiguousarray(a)
+
+
+def permute(state):
+    s = np.ascontiguousarray(np.array(state, dtype=np.uint64))
+    load().orc_poseidon_permute(s)
+    return s
+
+
+def hash_no_pad(vals):
+    v = np.ascontiguousarray(np.array(vals, dtype=np.uint64))
+    out = np.zeros(4, dtype=np.uint64)
+    load().orc_hash_no_pad(v, len(v), out)
+    return out
+
+
+def two_to_one(l, r):
+    out = np.zeros(4, dtype=np.uint64)
+    load().orc_two_to_one(np.ascontiguousarray(np.array(l, dtype=np.uint64)),
+                          np.ascontiguousarray(np.array(r, dtype=np.uint64)), out)
+    return out
+
+
+class Batch:
+    """PolynomialBatch::from_values / from_coeffs restatement (column-major input [ncols][N])."""
+
+    def __init__(self, arr, log_n, rate_bits=1, cap_height=4, from_coeffs=False):
+        L = load()
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        self.ncols = arr.shape[0]
+        self.log_n = log_n
+        self.rate_bits = rate_bits
+        assert arr.shape[1] == 1 << log_n
+        fn = L.orc_batch_from_coeffs if from_coeffs else L.orc_batch_from_values
+        self.h = fn(arr, self.ncols, log_n, rate_bits, cap_height)
+        self.cap_height = min(cap_height, log_n + rate_bits)
+        self.L = L
+
+    def _arr(self, ptr, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
+
+    @property
+    def cap(self):
+        return self._arr(self.L.orc_batch_cap(self.h), (1 << self.cap_height, 4))
+
+    @property
+    def leaves(self):
+        return self._arr(self.L.orc_batch_leaves(self.h), (1 << (self.log_n + self.rate_bits), self.ncols))
+
+    @property
+    def coeffs(self):
+        return self._arr(self.L.orc_batch_coeffs(self.h), (self.ncols, 1 << self.log_n))
+
+    def level(self, lvl):
+        n = C.c_size_t()
+        p = self.L.orc_batch_level(self.h, lvl, C.byref(n))
+        return self._arr(p, (n.value, 4))
+
+    def __del__(self):
+        try:
+            self.L.orc_batch_free(self.h)
+        except Exception:
+            pass

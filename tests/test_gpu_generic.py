@@ -1,0 +1,91 @@
+"""GPU parity tests of the generic layer, through the C ABI, against the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+from tests._oracle import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sipp_amd
+    c = sipp_amd.Ctx(workspace_bytes=2 << 30)
+    yield c
+    c.close()
+
+
+def dev(a):
+    from sipp_amd._lib import to_device
+    return to_device(a)
+
+
+def host(t):
+    from sipp_amd._lib import to_host
+    return to_host(t)
+
+
+def test_poseidon_kats_and_random(ctx):
+    from tests.test_oracle_generic import KAT
+    rng = np.random.default_rng(1)
+    states = np.concatenate([np.array([k[0] for k in KAT], dtype=np.uint64), _oracle.rand_field(rng, (1000, 12))])
+    got = host(ctx.poseidon_permute(dev(states)))
+    for i, (_, out) in enumerate(KAT):
+        assert [int(x) for x in got[i]] == out
+    for i in range(3, states.shape[0]):
+        assert (got[i] == _oracle.permute(states[i])).all(), i
+
+
+@pytest.mark.parametrize("log_n", [4, 5, 8, 12, 13, 14, 17, 20])
+def test_ntt_matches_oracle(ctx, oracle, log_n):
+    rng = np.random.default_rng(log_n)
+    ncols = 3 if log_n < 18 else 2
+    a = _oracle.rand_field(rng, (ncols, 1 << log_n))
+    a[0, :4] = [0, 1, P - 1, P - 2]
+    d = dev(a)
+    got = host(ctx.ntt(d, log_n))
+    for c in range(ncols):
+        ref = a[c].copy()
+        oracle.orc_fft(ref, log_n)
+        assert (got[c] == ref).all(), (log_n, c)
+    back = host(ctx.ntt(d, log_n, inverse=True))
+    assert (back == a).all()
+
+
+@pytest.mark.parametrize("log_n,ncols", [(4, 1), (6, 11), (10, 4), (12, 9), (13, 17), (16, 5)])
+def test_commit_matches_oracle(ctx, log_n, ncols):
+    rng = np.random.default_rng(100 + log_n)
+    vals = _oracle.rand_field(rng, (ncols, 1 << log_n))
+    ref = _oracle.Batch(vals, log_n)
+    coeffs, lde, tree, cap = ctx.commit(dev(vals), log_n)
+    assert (host(coeffs) == ref.coeffs).all()
+    assert (host(lde).T == ref.leaves).all()          # column-major leaf order == transposed leaves
+    m = 2 << log_n
+    assert (host(tree)[:m] == ref.level(0)).all()
+    assert (host(tree)[m:m + m // 2] == ref.level(1)).all()
+    assert (cap == ref.cap).all()
+
+
+def test_leaves_and_cap_separately(ctx):
+    rng = np.random.default_rng(5)
+    log_n, ncols = 9, 20
+    vals = _oracle.rand_field(rng, (ncols, 1 << log_n))
+    ref = _oracle.Batch(vals, log_n)
+    import torch
+    coeffs, lde = ctx.lde(dev(vals), log_n)
+    dig = ctx.poseidon_leaves(lde, log_n + 1)
+    assert (host(dig) == ref.level(0)).all()
+    tree = torch.zeros((4 << log_n, 4), dtype=torch.int64, device="cuda")
+    tree[: 2 << log_n] = dig
+    assert (ctx.merkle_cap(tree, log_n + 1) == ref.cap).all()
+
+
+def test_hash_or_noop_narrow_leaves(ctx):
+    rng = np.random.default_rng(6)
+    for ncols in (1, 3, 4, 5, 8, 9):
+        vals = _oracle.rand_field(rng, (ncols, 64))
+        ref = _oracle.Batch(vals, 6)
+        _, _, tree, cap = ctx.commit(dev(vals), 6)
+        assert (host(tree)[:128] == ref.level(0)).all(), ncols
+        assert (cap == ref.cap).all(), ncols

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate the Poseidon-Goldilocks constant headers from data/poseidon_goldilocks_rc.txt.
+
+Writes two independent copies (the product never includes anything from oracle/):
+  oracle/poseidon_constants.h            (plain C, naive round constants only)
+  sipp_amd/csrc/poseidon_constants.h     (HIP side: naive constants + the derived
+                                          "fast partial round" tables)
+
+The fast-partial-round tables are derived here from the MDS matrix and the round
+constants with the standard Poseidon equivalent-matrix factorisation (Poseidon paper,
+App. B; the same algebra plonky2 uses for FAST_PARTIAL_* upstream).  The HIP kernels
+that use them are checked bit for bit against the naive oracle permutation.
+"""
+import os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2**64 - 2**32 + 1
+CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+DIAG = [8] + [0] * 11
+W = 12
+N_FULL_HALF = 4
+N_PARTIAL = 22
+
+
+def load_rc():
+    txt = open(os.path.join(ROOT, "data", "poseidon_goldilocks_rc.txt")).read()
+    vals = [int(v, 16) for v in re.findall(r"0x[0-9a-f]{16}", txt)]
+    assert len(vals) == 360
+    return vals
+
+
+def mds_matrix():
+    # out[r] = sum_i in[(i + r) % 12] * CIRC[i] + in[r] * DIAG[r]
+    M = [[0] * W for _ in range(W)]
+    for r in range(W):
+        for i in range(W):
+            M[r][(i + r) % W] = (M[r][(i + r) % W] + CIRC[i]) % P
+        M[r][r] = (M[r][r] + DIAG[r]) % P
+    return M
+
+
+def mat_mul(A, B):
+    n, m, k = len(A), len(B[0]), len(B)
+    return [[sum(A[i][t] * B[t][j] for t in range(k)) % P for j in range(m)] for i in range(n)]
+
+
+def mat_vec(A, v):
+    return [sum(A[i][j] * v[j] for j in range(len(v))) % P for i in range(len(A))]
+
+
+def mat_inv(A):
+    n = len(A)
+    M = [row[:] + [1 if i == j else 0 for j in range(n)] for i, row in enumerate(A)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if M[r][c] % P)
+        M[c], M[piv] = M[piv], M[c]
+        inv = pow(M[c][c], P - 2, P)
+        M[c] = [x * inv % P for x in M[c]]
+        for r in range(n):
+            if r != c and M[r][c]:
+                f = M[r][c]
+                M[r] = [(x - f * y) % P for x, y in zip(M[r], M[c])]
+    return [row[n:] for row in M]
+
+
+def transpose(A):
+    return [list(r) for r in zip(*A)]
+
+
+def derive_fast_partial(rc):
+    """Returns (first_round_constants[12], initial_matrix[11][11], round_constants[22],
+    vs[22][11], w_hats[22][11]) such that
+
+      state += first_round_constants
+      state  = [state[0]] ++ initial_matrix applied to state[1..]   (row-vector form below)
+      for r in 0..22:
+          state[0] = sbox(state[0]); state[0] += round_constants[r]   (r < 21; last adds 0)
+          d = state[0]*M00 + sum_i state[i+1]*w_hats[r][i]
+          state[i+1] += state[0]*vs[r][i];  state[0] = d
+
+    is equal to the 22 naive partial rounds (add full constant vector, sbox lane 0, dense MDS).
+    Verified numerically at the bottom of this script before any header is written.
+    """
+    M = mds_matrix()
+    # --- constants: push all-lane constants backwards through the linear layers ---
+    # naive partial round i: s -> M * sbox0(s + c_i).  Work from the last round to the first,
+    # keeping only lane-0 constants inside the rounds and an initial full vector.
+    Minv = mat_inv(M)
+    partial_rc = [rc[12 * (N_FULL_HALF + r):12 * (N_FULL_HALF + r) + 12] for r in range(N_PARTIAL)]
+    # opt constants: c'_r (scalar for lane 0), first_vec
+    acc = partial_rc[N_PARTIAL - 1][:]
+    scalars = [0] * N_PARTIAL
+    for r in range(N_PARTIAL - 1, 0, -1):
+        inv_acc = mat_vec(Minv, acc)
+        scalars[r] = inv_acc[0]
+        inv_acc[0] = 0
+        acc = [(a + b) % P for a, b in zip(inv_acc, partial_rc[r - 1])]
+    first = acc
+    # after the transformation: round r (r = 0..21): sbox lane 0, then add scalars[r+1] to lane 0
+    # *after* the MDS of round r ... we instead restate: state += first; for r: sbox0; (if r<21)
+    # the constant scalars[r+1] is added to lane 0 after multiplying by M.  Because constants
+    # on lane 0 commute with nothing, apply them as: s -> M*sbox0(s) then lane0 += M-pushed...
+    # To keep this simple and exactly checkable we use the direct formulation below.
+    return first, scalars
+
+
+def naive_perm(state, rc):
+    M = mds_matrix()
+    s = state[:]
+    rnd = 0
+    def full():
+        nonlocal s, rnd
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    def partial():
+        nonlocal s, rnd
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s[0] = pow(s[0], 7, P)
+        s = mat_vec(M, s)
+        rnd += 1
+    for _ in range(4): full()
+    for _ in range(22): partial()
+    for _ in range(4): full()
+    return s
+
+
+def sparse_factor():
+    """Factor the partial-round linear layers: M = M' * M'' style, iterated (Poseidon paper B).
+    Returns initial 12x12 matrix `Mi` (with Mi[0][0]=1 border) and per-round (v[11], w_hat[11])."""
+    M = mds_matrix()
+    MT = transpose(M)
+    # Follow the hadeshash reference: work with M^T (row-vector convention), M_mul accumulates.
+    m_mul = [r[:] for r in MT]
+    m_i = [[0] * W for _ in range(W)]
+    vs, ws = [], []
+    for _ in range(N_PARTIAL):
+        # split m_mul = M' * M''
+        m_hat = [row[1:] for row in m_mul[1:]]
+        w = [m_mul[i][0] for i in range(1, W)]
+        v = m_mul[0][1:]
+        m_hat_inv = mat_inv(m_hat)
+        w_hat = mat_vec(m_hat_inv, w)
+        vs.append(v)
+        ws.append(w_hat)
+        # M' = [[1,0],[0,m_hat]]
+        m_i = [[1] + [0] * (W - 1)] + [[0] + row for row in m_hat]
+        m_mul = mat_mul(MT, m_i)
+    return transpose(m_i), vs[::-1], ws[::-1]
+
+
+def fast_perm(state, rc, tables):
+    first, scalars, Mi, vs, ws = tables
+    M = mds_matrix()
+    s = state[:]
+    rnd = 0
+    for _ in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    # partial rounds, fast form
+    s = [(x + c) % P for x, c in zip(s, first)]
+    s = mat_vec(Mi, s)
+    m00 = M[0][0]
+    for r in range(N_PARTIAL):
+        s[0] = pow(s[0], 7, P)
+        if r < N_PARTIAL - 1:
+            s[0] = (s[0] + scalars[r + 1]) % P
+        d = (s[0] * m00 + sum(s[i + 1] * ws[r][i] for i in range(W - 1))) % P
+        for i in range(W - 1):
+            s[i + 1] = (s[i + 1] + s[0] * vs[r][i]) % P
+        s[0] = d
+    rnd += N_PARTIAL
+    for _ in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    return s
+
+
+def fmt(vals, per=4):
+    out = []
+    for i in range(0, len(vals), per):
+        out.append("    " + ", ".join("0x%016xULL" % v for v in vals[i:i + per]) + ",")
+    return "\n".join(out)
+
+
+def main():
+    rc = load_rc()
+    first, scalars = derive_fast_partial(rc)
+    Mi, vs, ws = sparse_factor()
+    tables = (first, scalars, Mi, vs, ws)
+    import random
+    rnd = random.Random(1)
+    for t in range(8):
+        st = [rnd.randrange(P) for _ in range(12)] if t else [0] * 12
+        a, b = naive_perm(st, rc), fast_perm(st, rc, tables)
+        assert a == b, ("fast partial rounds mismatch", t)
+    kat0 = naive_perm([0] * 12, rc)
+    assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
+
+    hdr = "/* GENERATED by tools/gen_poseidon_header.py from data/poseidon_goldilocks_rc.txt -- do not edit. */\n"
+    with open(os.path.join(ROOT, "oracle", "poseidon_constants.h"), "w") as f:
+        f.write(hdr)
+        f.write("#ifndef ORACLE_POSEIDON_CONSTANTS_H\n#define ORACLE_POSEIDON_CONSTANTS_H\n#include <stdint.h>\n")
+        f.write("static const uint64_t POSEIDON_RC[360] = {\n" + fmt(rc) + "\n};\n")
+        f.write("static const uint64_t POSEIDON_CIRC[12] = {%s};\n" % ", ".join(map(str, CIRC)))
+        f.write("static const uint64_t POSEIDON_DIAG[12] = {%s};\n" % ", ".join(map(str, DIAG)))
+        f.write("#endif\n")
+    with open(os.path.join(ROOT, "sipp_amd", "csrc", "poseidon_constants.h"), "w") as f:
+        f.write(hdr)
+        f.write("#pragma once\n#include <stdint.h>\n")
+        f.write("// index = 12*round + lane, rounds 0..29 (4 full, 22 partial, 4 full)\n")
+        f.write("static const uint64_t SIPP_POSEIDON_RC[360] = {\n" + fmt(rc) + "\n};\n")
+        f.write("// fast partial rounds: state += FIRST; state = MI * state; 22 x (sbox0, +SCALAR, sparse)\n")
+        f.write("static const uint64_t SIPP_POSEIDON_FAST_FIRST[12] = {\n" + fmt(first) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_FAST_SCALAR[22] = {\n" + fmt(scalars[1:] + [0]) + "\n};\n")
+        mi_flat = [Mi[i][j] for i in range(1, 12) for j in range(1, 12)]
+        f.write("// 11x11 block of the initial matrix (row-major, out[i+1] = sum_j MI[i][j]*in[j+1]); lane 0 passes through\n")
+        f.write("static const uint64_t SIPP_POSEIDON_FAST_MI[121] = {\n" + fmt(mi_flat) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_FAST_VS[22*11] = {\n" + fmt([x for r in vs for x in r]) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_FAST_WHAT[22*11] = {\n" + fmt([x for r in ws for x in r]) + "\n};\n")
+    assert all(Mi[0][j] == (1 if j == 0 else 0) for j in range(12)) and all(Mi[i][0] == 0 for i in range(1, 12))
+    print("ok: headers written; fast-partial tables verified against naive permutation")
+
+
+if __name__ == "__main__":
+    main()
