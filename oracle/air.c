@@ -1,0 +1,479 @@
+/*
+ * oracle/air.c -- CPU restatement of the three SIPP AIRs: trace generation (native BN254 arithmetic +
+ * generic gadget witnesses from the AIR program) and constraint evaluation (air_eval.inc).
+ *
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED.  The reference reaches this code's upstream counterpart
+ * (starky-bn254 @ 2d46f9e `generate_trace` / `eval_packed_generic`, not vendored) only through
+ * src/verifier_circuit.rs:133-135.  Semantics follow src/verifier_circuit.rs:92-124:
+ *   G1/G2: out = offset + [exp_val] x ;  Fq12: out = offset * x^exp_val ; exp_val = 8 x u32 LE limbs.
+ * The AIR layout itself is this repository's specification (tools/air_gen.py).
+ */
+#include "air.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+const orc_air_t *orc_air_get(int kind, unsigned log_n) {
+    int mode_u16 = log_n >= 16;
+    for (size_t i = 0; i < sizeof(ORC_AIRS) / sizeof(ORC_AIRS[0]); i++)
+        if (ORC_AIRS[i].kind == kind && (ORC_AIRS[i].table_bits == 16) == mode_u16) return &ORC_AIRS[i];
+    return NULL;
+}
+
+int orc_air_width(const orc_air_t *a) { return a->n_main + 2 * a->n_checked; }
+
+/* ---- column name lookup is positional: the generator allocates in a fixed order ---- */
+typedef struct {
+    int ext;           /* curve: 1 or 2 */
+    int Rx, Ry, Px, Py, bit, e, lam, X3, Y3;
+    int acc, pw, C;    /* fq12 */
+    int gad0;          /* first gadget's unchecked sign column / checked q column are found from the program */
+} layout_t;
+
+static layout_t layout_of(const orc_air_t *a) {
+    layout_t L;
+    memset(&L, 0, sizeof L);
+    int cpl = a->cells_per_limb;
+    if (a->kind == 2) {
+        L.acc = 1; L.pw = 1 + 192; L.bit = 1 + 384; L.e = L.bit + 1;
+        L.C = a->checked_base;
+    } else {
+        int ext = a->kind == 0 ? 1 : 2, nc = 16 * ext;
+        L.ext = ext;
+        L.Rx = 1; L.Ry = 1 + nc; L.Px = 1 + 2 * nc; L.Py = 1 + 3 * nc; L.bit = 1 + 4 * nc; L.e = L.bit + 1;
+        L.lam = a->checked_base; L.X3 = L.lam + nc * cpl; L.Y3 = L.X3 + nc * cpl;
+    }
+    return L;
+}
+
+static inline void put(uint64_t *tr, size_t n, int col, size_t row, uint64_t v) { tr[(size_t)col * n + row] = v; }
+
+static void put_fq_u16(uint64_t *tr, size_t n, int col, size_t row, fq v) {
+    uint16_t l[16];
+    fq_to_limbs16(v, l);
+    for (int i = 0; i < 16; i++) put(tr, n, col + i, row, l[i]);
+}
+
+static void put_fq_checked(uint64_t *tr, size_t n, int col, size_t row, fq v, int cpl) {
+    uint16_t l[16];
+    fq_to_limbs16(v, l);
+    for (int i = 0; i < 16; i++) {
+        if (cpl == 1) put(tr, n, col + i, row, l[i]);
+        else { put(tr, n, col + 2 * i, row, l[i] & 0xff); put(tr, n, col + 2 * i + 1, row, l[i] >> 8); }
+    }
+}
+
+/* ---- primary witness: the native chain ---- */
+static int fill_exponent(uint64_t *tr, size_t n, const layout_t *L, size_t row0, const uint32_t exp[8], int *bits_out) {
+    uint32_t e[8];
+    memcpy(e, exp, sizeof e);
+    for (int r = 0; r < 512; r++) {
+        size_t row = row0 + r;
+        int is_add = (r & 1) == 0;
+        int bit = is_add ? (int)(e[0] & 1) : 0;
+        put(tr, n, L->bit, row, bit);
+        for (int i = 0; i < 8; i++) put(tr, n, L->e + i, row, e[i]);
+        if (is_add) {
+            bits_out[r >> 1] = bit;
+            e[0] = (e[0] - bit) >> 1;
+        }
+        if ((r & 63) == 63) { /* limb end: rotate */
+            for (int i = 0; i < 7; i++) e[i] = e[i + 1];
+            e[7] = 0;
+        }
+    }
+    return 0;
+}
+
+typedef struct { fq2 x, y; } pt2; /* Fq points use c1 = 0 */
+
+static fq2 mk2(fq a) { fq2 r = {a, fq_zero()}; return r; }
+
+static fq2 f2_mul(fq2 a, fq2 b, int ext) { return ext == 2 ? fq2_mul(a, b) : mk2(fq_mul(a.c0, b.c0)); }
+static int f2_inv(fq2 a, int ext, fq2 *out) {
+    if (ext == 2) { if (fq2_is_zero(a)) return -1; *out = fq2_inv(a); return 0; }
+    if (fq_is_zero(a.c0)) return -1;
+    *out = mk2(fq_inv(a.c0));
+    return 0;
+}
+
+static void put_f2_u16(uint64_t *tr, size_t n, int col, size_t row, fq2 v, int ext) {
+    put_fq_u16(tr, n, col, row, v.c0);
+    if (ext == 2) put_fq_u16(tr, n, col + 16, row, v.c1);
+}
+static void put_f2_chk(uint64_t *tr, size_t n, int col, size_t row, fq2 v, int ext, int cpl) {
+    put_fq_checked(tr, n, col, row, v.c0, cpl);
+    if (ext == 2) put_fq_checked(tr, n, col + 16 * cpl, row, v.c1, cpl);
+}
+
+static fq2 read_f2(const uint32_t *w, int ext) {
+    fq2 r;
+    r.c0 = fq_from_u32(w);
+    r.c1 = ext == 2 ? fq_from_u32(w + 8) : fq_zero();
+    return r;
+}
+
+static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+    layout_t L = layout_of(a);
+    int ext = L.ext, cpl = a->cells_per_limb, w = 8 * ext;
+    pt2 P = {read_f2(rec, ext), read_f2(rec + w, ext)};
+    pt2 R = {read_f2(rec + 2 * w, ext), read_f2(rec + 3 * w, ext)};
+    const uint32_t *exp = rec + 4 * w;
+    int bits[256];
+    size_t row0 = io * 512;
+    fill_exponent(tr, n, &L, row0, exp, bits);
+    fq2 three = mk2(fq_from_u64(3)), two = mk2(fq_from_u64(2));
+    for (int r = 0; r < 512; r++) {
+        size_t row = row0 + r;
+        int is_add = (r & 1) == 0;
+        put_f2_u16(tr, n, L.Rx, row, R.x, ext); put_f2_u16(tr, n, L.Ry, row, R.y, ext);
+        put_f2_u16(tr, n, L.Px, row, P.x, ext); put_f2_u16(tr, n, L.Py, row, P.y, ext);
+        fq2 lam, num, den, deninv, xa, ya, xb;
+        if (is_add) {
+            num = fq2_sub(P.y, R.y); den = fq2_sub(P.x, R.x);
+            xa = R.x; ya = R.y; xb = P.x;
+        } else {
+            num = f2_mul(three, f2_mul(P.x, P.x, ext), ext); den = f2_mul(two, P.y, ext);
+            xa = P.x; ya = P.y; xb = P.x;
+        }
+        if (f2_inv(den, ext, &deninv)) return -1; /* R = +-P or 2-torsion: not provable */
+        lam = f2_mul(num, deninv, ext);
+        fq2 x3 = fq2_sub(fq2_sub(f2_mul(lam, lam, ext), xa), xb);
+        fq2 y3 = fq2_sub(f2_mul(lam, fq2_sub(xa, x3), ext), ya);
+        put_f2_chk(tr, n, L.lam, row, lam, ext, cpl);
+        put_f2_chk(tr, n, L.X3, row, x3, ext, cpl);
+        put_f2_chk(tr, n, L.Y3, row, y3, ext, cpl);
+        if (is_add) { if (bits[r >> 1]) { R.x = x3; R.y = y3; } }
+        else if (r != 511) { P.x = x3; P.y = y3; }
+    }
+    /* output words */
+    fq_to_u32(R.x.c0, out_words);
+    if (ext == 2) { fq_to_u32(R.x.c1, out_words + 8); fq_to_u32(R.y.c0, out_words + 16); fq_to_u32(R.y.c1, out_words + 24); }
+    else fq_to_u32(R.y.c0, out_words + 8);
+    return 0;
+}
+
+static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+    layout_t L = layout_of(a);
+    int cpl = a->cells_per_limb;
+    fq12 pw, acc;
+    for (int k = 0; k < 12; k++) { pw.c[k] = fq_from_u32(rec + 8 * k); acc.c[k] = fq_from_u32(rec + 96 + 8 * k); }
+    int bits[256];
+    size_t row0 = io * 512;
+    fill_exponent(tr, n, &L, row0, rec + 192, bits);
+    for (int r = 0; r < 512; r++) {
+        size_t row = row0 + r;
+        int is_add = (r & 1) == 0;
+        for (int k = 0; k < 12; k++) { put_fq_u16(tr, n, L.acc + 16 * k, row, acc.c[k]); put_fq_u16(tr, n, L.pw + 16 * k, row, pw.c[k]); }
+        fq12 c = is_add ? fq12_mul(&acc, &pw) : fq12_mul(&pw, &pw);
+        for (int k = 0; k < 12; k++) put_fq_checked(tr, n, L.C + 16 * cpl * k, row, c.c[k], cpl);
+        if (is_add) { if (bits[r >> 1]) acc = c; }
+        else if (r != 511) pw = c;
+    }
+    for (int k = 0; k < 12; k++) fq_to_u32(acc.c[k], out_words + 8 * k);
+    return 0;
+}
+
+/* ---- generic gadget witnesses (integers) ---- */
+static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, const int per[ORC_N_PERIODIC],
+                   int64_t *out, int *n_out) {
+    int nl = (int)w[0], nt = (int)w[1];
+    for (int i = 0; i < nl; i++) out[i] = 0;
+    for (int t = 0; t < nt; t++) {
+        const int64_t *tm = w + 2 + 5 * t;
+        int64_t f = tm[0];
+        int base = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
+        if (flag >= 0) f *= neg ? 1 - per[flag] : per[flag];
+        if (f == 0) continue;
+        for (int i = 0; i < nl; i++) out[i] += f * (int64_t)tr[(size_t)(base + i * stride) * n + row];
+    }
+    *n_out = nl;
+    return 2 + 5 * (size_t)nt;
+}
+
+static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t row) {
+    int per[ORC_N_PERIODIC];
+    for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = (int)(row % (size_t)ORC_PERIODIC[k][0]) == ORC_PERIODIC[k][1];
+    const int64_t *w = a->prog, *end = a->prog + a->prog_len;
+    int cpl = a->cells_per_limb;
+    /* p^-1 mod 2^16 */
+    uint32_t pinv = 1;
+    for (int i = 0; i < 5; i++) pinv = (pinv * (2 - ORC_BN_P_LIMBS[0] * pinv)) & 0xffff;
+    while (w < end) {
+        if (w[0] != 1) break; /* gadgets come first */
+        int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
+        int64_t coffset = w[5];
+        w += 6;
+        /* q vector descriptor: remember where its cells live */
+        int q_base = (int)w[3]; /* first term's base */
+        w += 2 + 5 * (size_t)w[1];
+        int64_t e[34], va[17], vb[17];
+        memset(e, 0, sizeof e);
+        int na, nb;
+        int np = (int)*w++;
+        for (int p = 0; p < np; p++) {
+            int64_t coef = *w++;
+            w += ivec(w, tr, n, row, per, va, &na);
+            w += ivec(w, tr, n, row, per, vb, &nb);
+            for (int i = 0; i < na; i++) {
+                if (!va[i]) continue;
+                int64_t ai = coef * va[i];
+                for (int j = 0; j < nb; j++) e[i + j] += ai * vb[j];
+            }
+        }
+        int nl = (int)*w++;
+        for (int p = 0; p < nl; p++) {
+            int64_t coef = *w++;
+            w += ivec(w, tr, n, row, per, va, &na);
+            for (int i = 0; i < na; i++) e[i] += coef * va[i];
+        }
+        /* E = sum e_k 2^(16k) as a signed big integer in 16-bit limbs */
+        int64_t limbs[40];
+        int sign = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            int64_t carry = 0;
+            for (int k = 0; k < 40; k++) {
+                int64_t t = (k < 31 ? (sign ? -e[k] : e[k]) : 0) + carry;
+                limbs[k] = t & 0xffff;
+                carry = t >> 16;
+            }
+            if (carry == 0) break;
+            if (carry == -1 && pass == 0) { sign = 1; continue; }
+            return -2;
+        }
+        /* exact division by p: q_i = limbs[i] * p^-1 mod 2^16 */
+        uint32_t q[17];
+        for (int i = 0; i < 17; i++) {
+            q[i] = ((uint32_t)limbs[i] * pinv) & 0xffff;
+            int64_t carry = 0;
+            for (int j = 0; i + j < 40; j++) {
+                int64_t t = limbs[i + j] - (j < 16 ? (int64_t)q[i] * ORC_BN_P_LIMBS[j] : 0) + carry;
+                limbs[i + j] = t & 0xffff;
+                carry = t >> 16;
+                if (j >= 16 && carry == 0) break;
+            }
+        }
+        for (int k = 0; k < 40; k++) if (limbs[k]) return -3; /* E not divisible by p: primary witness wrong */
+        put(tr, n, sign_col, row, (uint64_t)sign);
+        for (int i = 0; i < 17; i++) {
+            if (cpl == 1) put(tr, n, q_base + i, row, q[i]);
+            else { put(tr, n, q_base + 2 * i, row, q[i] & 0xff); put(tr, n, q_base + 2 * i + 1, row, q[i] >> 8); }
+        }
+        /* carries: e_k - sgn (q*p)_k - c_{k-1} + 2^16 c_k = 0 */
+        int64_t sgn = sign ? -1 : 1, cprev = 0;
+        for (int k = 0; k < 32; k++) {
+            int64_t qp = 0;
+            for (int i = 0; i < 17; i++) { int j = k - i; if (j >= 0 && j < 16) qp += (int64_t)q[i] * ORC_BN_P_LIMBS[j]; }
+            int64_t dk = (k < 31 ? e[k] : 0) - sgn * qp - cprev; /* = -2^16 c_k */
+            if (dk & 0xffff) return -4;
+            int64_t ck = -(dk >> 16);
+            if (k == 31) { if (ck != 0) return -5; break; }
+            int64_t v = ck + coffset;
+            if (v < 0 || (v >> (ncl * lb)) != 0) return -6;
+            for (int l = 0; l < ncl; l++) put(tr, n, cbase + k * ncl + l, row, (uint64_t)((v >> (lb * l)) & (((int64_t)1 << lb) - 1)));
+            cprev = ck;
+        }
+    }
+    return 0;
+}
+
+/* ---- permuted lookup columns (this repository's deterministic fill rule, DESIGN.md "lookups") ----
+ * perm_in  = the column sorted ascending
+ * perm_tab[i] = perm_in[i] where perm_in[i] is the first occurrence of its value; the remaining positions
+ *               receive, in ascending position order, the table entries not matched that way, ascending. */
+static void permuted_cols(const uint64_t *col, size_t n, unsigned tbits, uint64_t *pin, uint64_t *ptab) {
+    size_t T = (size_t)1 << tbits;
+    uint32_t *hist = (uint32_t *)calloc(T, sizeof(uint32_t));
+    for (size_t i = 0; i < n; i++) hist[col[i]]++;
+    /* unused table entries ascending: values with hist == 0, then the extra copies of T-1 */
+    size_t pos = 0;
+    size_t uz = 0; /* cursor over unused values */
+    for (size_t v = 0; v < T; v++) {
+        for (uint32_t k = 0; k < hist[v]; k++) {
+            pin[pos] = v;
+            if (k == 0) ptab[pos] = v;
+            else {
+                while (uz < T && hist[uz] != 0) uz++;
+                if (uz < T) ptab[pos] = uz++;
+                else ptab[pos] = T - 1;
+            }
+            pos++;
+        }
+    }
+    free(hist);
+}
+
+orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *err) {
+    fq_init();
+    *err = 0;
+    if (num_io == 0) { *err = -1; return NULL; }
+    size_t nio = 1;
+    while (nio < num_io) nio <<= 1;
+    unsigned log_n = 9;
+    while (((size_t)1 << (log_n - 9)) < nio) log_n++;
+    const orc_air_t *a = orc_air_get(kind, log_n);
+    size_t n = (size_t)1 << log_n;
+    if (n < ((size_t)1 << a->table_bits)) { *err = -7; return NULL; }
+    int W = orc_air_width(a);
+    orc_trace *t = (orc_trace *)calloc(1, sizeof *t);
+    t->air = a; t->log_n = log_n; t->num_io = nio; t->width = W;
+    t->trace = (uint64_t *)calloc((size_t)W * n, sizeof(uint64_t));
+    t->pis = (uint32_t *)calloc(nio * a->pi_per_io, sizeof(uint32_t));
+    int ppi = a->pi_per_io, out_words = kind == 0 ? 16 : kind == 1 ? 32 : 96;
+    int rc_all = 0;
+#pragma omp parallel for schedule(dynamic)
+    for (size_t io = 0; io < nio; io++) {
+        const uint32_t *rec = ios + (io < num_io ? io : num_io - 1) * ppi;
+        uint32_t *pi = t->pis + io * ppi;
+        memcpy(pi, rec, ppi * sizeof(uint32_t));
+        uint32_t outw[96];
+        int rc = kind == 2 ? fill_fq12_io(a, t->trace, n, io, rec, outw) : fill_curve_io(a, t->trace, n, io, rec, outw);
+        if (rc == 0 && memcmp(outw, rec + ppi - out_words, out_words * sizeof(uint32_t)) != 0) rc = -8; /* claimed output wrong */
+        if (rc) {
+#pragma omp critical
+            rc_all = rc;
+        }
+    }
+    if (rc_all) { *err = rc_all; orc_trace_free(t); return NULL; }
+    size_t T = (size_t)1 << a->table_bits;
+    for (size_t r = 0; r < n; r++) t->trace[r] = r < T ? r : T - 1;
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n; r++) {
+        int rc = fill_gadgets_row(a, t->trace, n, r);
+        if (rc) {
+#pragma omp critical
+            rc_all = rc;
+        }
+    }
+    if (rc_all) { *err = rc_all; orc_trace_free(t); return NULL; }
+#pragma omp parallel for schedule(dynamic)
+    for (int j = 0; j < a->n_checked; j++)
+        permuted_cols(t->trace + (size_t)(a->checked_base + j) * n, n, a->table_bits,
+                      t->trace + (size_t)(a->n_main + j) * n, t->trace + (size_t)(a->n_main + a->n_checked + j) * n);
+    return t;
+}
+
+void orc_trace_free(orc_trace *t) {
+    if (!t) return;
+    free(t->trace); free(t->pis); free(t);
+}
+
+/* ---- periodic selectors and public-input polynomials ---- */
+/* S_{m,r0}(x) = (K/N) ((x g^-r0)^N - 1) / ((x g^-r0)^K - 1),  K = N/m  (1 on rows r = r0 mod m) */
+uint64_t orc_periodic_base(unsigned log_n, int which, uint64_t x) {
+    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)ORC_PERIODIC[which][0], r0 = (uint64_t)ORC_PERIODIC[which][1];
+    uint64_t K = N / m, g = gl_root_of_unity(log_n);
+    uint64_t y = gl_mul(x, gl_inv(gl_pow(g, r0)));
+    uint64_t num = gl_sub(gl_pow(y, N), 1), den = gl_sub(gl_pow(y, K), 1);
+    return gl_mul(gl_mul(num, gl_inv(den)), gl_mul(K % GL_P, gl_inv(N % GL_P)));
+}
+gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x) {
+    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)ORC_PERIODIC[which][0], r0 = (uint64_t)ORC_PERIODIC[which][1];
+    uint64_t K = N / m, g = gl_root_of_unity(log_n);
+    gl2 y = gl2_scale(x, gl_inv(gl_pow(g, r0)));
+    gl2 num = gl2_sub(gl2_pow(y, N), gl2_from(1)), den = gl2_sub(gl2_pow(y, K), gl2_from(1));
+    return gl2_scale(gl2_mul(num, gl2_inv(den)), gl_mul(K % GL_P, gl_inv(N % GL_P)));
+}
+
+/* value of aux column `ai` for IO `io`: the lo/hi half or the whole of a public u32 word */
+uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int ai) {
+    int word = a->aux[3 * ai], part = a->aux[3 * ai + 1];
+    uint32_t w = pis[io * a->pi_per_io + word];
+    return part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
+}
+
+/* coefficients (length num_io) of the aux polynomial A with A(g^(512 io + shift)) = value(io):
+ * interpolate over the order-num_io subgroup, then substitute x -> x g^-shift. */
+void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs) {
+    unsigned log_io = log_n - 9;
+    for (size_t io = 0; io < num_io; io++) coeffs[io] = orc_aux_value(a, pis, io, ai);
+    orc_ifft(coeffs, log_io);
+    int shift = a->aux[3 * ai + 2];
+    if (shift) {
+        uint64_t s = gl_inv(gl_pow(gl_root_of_unity(log_n), (uint64_t)shift)), f = 1;
+        for (size_t j = 0; j < num_io; j++) { coeffs[j] = gl_mul(coeffs[j], f); f = gl_mul(f, s); }
+    }
+}
+
+/* ---- evaluators ---- */
+#define FT uint64_t
+#define F_ADD gl_add
+#define F_SUB gl_sub
+#define F_MUL gl_mul
+#define F_SCALE(a, s) gl_mul((a), (s) % GL_P)
+#define F_FROM_I64(v) gl_from_i64(v)
+#define SUFFIX(n) n##_base
+#include "air_eval.inc"
+#undef FT
+#undef F_ADD
+#undef F_SUB
+#undef F_MUL
+#undef F_SCALE
+#undef F_FROM_I64
+#undef SUFFIX
+
+#define FT gl2
+#define F_ADD gl2_add
+#define F_SUB gl2_sub
+#define F_MUL gl2_mul
+#define F_SCALE(a, s) gl2_scale((a), (s) % GL_P)
+#define F_FROM_I64(v) gl2_from(gl_from_i64(v))
+#define SUFFIX(n) n##_ext
+#include "air_eval.inc"
+
+void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
+                   const uint64_t per[ORC_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
+                   uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
+                   const uint64_t gamma[2], uint64_t out[2]) {
+    evalctx_base c;
+    c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
+    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
+    c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
+    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
+    eval_all_base(air, &c);
+    out[0] = c.acc[0]; out[1] = c.acc[1];
+}
+
+void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
+                  const gl2 per[ORC_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
+                  gl2 z_last, const uint64_t alpha[2], const uint64_t gamma[2], gl2 out[2]) {
+    evalctx_ext c;
+    c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
+    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
+    c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
+    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
+    eval_all_ext(air, &c);
+    out[0] = c.acc[0]; out[1] = c.acc[1];
+}
+
+size_t orc_air_num_constraints(const orc_air_t *a) { return (size_t)a->n_constraints + 3 + 6 * (size_t)a->n_checked; }
+
+/* Debug aid used by the tests: evaluate every constraint on trace row `row` (selectors in {0,1}); returns
+ * the index of the first non-zero constraint or -1.  Z columns are not checked here (pass zeros -> skipped). */
+long orc_trace_check_row(const orc_trace *t, size_t row) {
+    const orc_air_t *a = t->air;
+    size_t n = (size_t)1 << t->log_n;
+    int W = t->width;
+    uint64_t *local = (uint64_t *)malloc(sizeof(uint64_t) * W), *next = (uint64_t *)malloc(sizeof(uint64_t) * W);
+    uint64_t *aux = (uint64_t *)calloc(a->n_aux ? a->n_aux : 1, sizeof(uint64_t));
+    for (int c = 0; c < W; c++) { local[c] = t->trace[(size_t)c * n + row]; next[c] = t->trace[(size_t)c * n + (row + 1) % n]; }
+    evalctx_base c;
+    memset(&c, 0, sizeof c);
+    c.local = local; c.next = next; c.aux = aux;
+    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = (row % (size_t)ORC_PERIODIC[k][0]) == (size_t)ORC_PERIODIC[k][1];
+    size_t io = row / 512;
+    for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = orc_aux_value(a, t->pis, io, ai);
+    /* alpha = 0 turns acc into "the last emitted constraint": walk constraint by constraint instead */
+    c.alpha[0] = c.alpha[1] = 0;
+    /* run the program with a probing consumer: use alpha = 0 and stop at first non-zero by re-running prefix */
+    long bad = -1;
+    {
+        /* cheap trick: evaluate with two random-ish alphas; if the combination is zero all constraints are (whp) zero */
+        c.alpha[0] = 0x123456789abcdefULL % GL_P; c.alpha[1] = 0xfedcba987654321ULL % GL_P;
+        c.acc[0] = c.acc[1] = 0; c.n_emitted = 0;
+        eval_program_base(a, &c);
+        if (c.acc[0] != 0 || c.acc[1] != 0) bad = (long)c.n_emitted;
+    }
+    free(local); free(next); free(aux);
+    return bad;
+}

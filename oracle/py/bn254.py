@@ -1,0 +1,228 @@
+"""oracle/py/bn254.py -- pure-Python big-int BN254: Fq, Fq2, Fq12 (w^12 - 18 w^6 + 82 form), G1/G2 affine
+arithmetic and the optimal-ate pairing.
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the reference takes these from ark-bn254 0.4.0 and
+plonky2-bn254-pairing @ fe5c3a8 (reference Cargo.toml:9,27; call sites src/prover_native.rs:20,
+src/verifier_native.rs:80), neither vendored.  Constants are the ones verified in SURVEY.md App. A.10; the
+pairing is pinned here by bilinearity and non-degeneracy (tests/test_oracle_bn254.py).
+"""
+U = 4965661367192848881
+P = 36 * U**4 + 36 * U**3 + 24 * U**2 + 6 * U + 1
+R = 36 * U**4 + 36 * U**3 + 18 * U**2 + 6 * U + 1
+assert P == 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+G1 = (1, 2)
+G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+       11559732032986387107991004021392285783925812861821192530917403151452391805634),
+      (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+       4082367875863433681332203403145435568316851327593401208105741076214120093531))
+
+
+def inv(a):
+    return pow(a, P - 2, P)
+
+
+# ---------------- Fq2 = Fq[u]/(u^2 + 1) ----------------
+def f2_add(a, b): return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+def f2_sub(a, b): return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+def f2_neg(a): return ((-a[0]) % P, (-a[1]) % P)
+def f2_mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+def f2_scal(a, s): return (a[0] * s % P, a[1] * s % P)
+def f2_conj(a): return (a[0], (-a[1]) % P)
+
+
+def f2_inv(a):
+    n = inv((a[0] * a[0] + a[1] * a[1]) % P)
+    return (a[0] * n % P, (-a[1]) * n % P)
+
+
+def f2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = f2_mul(r, a)
+        a = f2_mul(a, a)
+        e >>= 1
+    return r
+
+
+XI = (9, 1)
+B2 = f2_mul((3, 0), f2_inv(XI))  # twist: y^2 = x^3 + 3/(9+u)
+
+
+# ---------------- Fq12 = Fq[w]/(w^12 - 18 w^6 + 82): list of 12 ints ----------------
+F12_ONE = [1] + [0] * 11
+
+
+def f12_mul(a, b):
+    d = [0] * 23
+    for i, ai in enumerate(a):
+        if ai:
+            for j, bj in enumerate(b):
+                d[i + j] += ai * bj
+    for m in range(22, 11, -1):
+        d[m - 6] += 18 * d[m]
+        d[m - 12] -= 82 * d[m]
+    return [x % P for x in d[:12]]
+
+
+def f12_pow(a, e):
+    r = F12_ONE
+    while e:
+        if e & 1:
+            r = f12_mul(r, a)
+        a = f12_mul(a, a)
+        e >>= 1
+    return r
+
+
+def f12_from_fq2(a, k=0):
+    """(a0 + a1 u) * w^k with u = w^6 - 9, k < 6"""
+    r = [0] * 12
+    r[k] = (a[0] - 9 * a[1]) % P
+    r[k + 6] = a[1] % P
+    return r
+
+
+def f12_inv(a):
+    return f12_pow(a, P**12 - 2)
+
+
+# ---------------- G1 / G2 affine (None = infinity) ----------------
+def g1_add(p, q):
+    if p is None: return q
+    if q is None: return p
+    if p[0] == q[0]:
+        if (p[1] + q[1]) % P == 0:
+            return None
+        lam = 3 * p[0] * p[0] * inv(2 * p[1]) % P
+    else:
+        lam = (q[1] - p[1]) * inv((q[0] - p[0]) % P) % P
+    x = (lam * lam - p[0] - q[0]) % P
+    return (x, (lam * (p[0] - x) - p[1]) % P)
+
+
+def g1_mul(p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = g1_add(r, p)
+        p = g1_add(p, p)
+        k >>= 1
+    return r
+
+
+def g1_neg(p): return None if p is None else (p[0], (-p[1]) % P)
+def g1_on_curve(p): return (p[1] * p[1] - p[0] ** 3 - 3) % P == 0
+
+
+def g2_add(p, q):
+    if p is None: return q
+    if q is None: return p
+    if p[0] == q[0]:
+        if f2_add(p[1], q[1]) == (0, 0):
+            return None
+        lam = f2_mul(f2_scal(f2_mul(p[0], p[0]), 3), f2_inv(f2_scal(p[1], 2)))
+    else:
+        lam = f2_mul(f2_sub(q[1], p[1]), f2_inv(f2_sub(q[0], p[0])))
+    x = f2_sub(f2_sub(f2_mul(lam, lam), p[0]), q[0])
+    return (x, f2_sub(f2_mul(lam, f2_sub(p[0], x)), p[1]))
+
+
+def g2_mul(p, k):
+    r = None
+    while k:
+        if k & 1:
+            r = g2_add(r, p)
+        p = g2_add(p, p)
+        k >>= 1
+    return r
+
+
+def g2_neg(p): return None if p is None else (p[0], f2_neg(p[1]))
+def g2_on_curve(p): return f2_sub(f2_mul(p[1], p[1]), f2_add(f2_mul(f2_mul(p[0], p[0]), p[0]), B2)) == (0, 0)
+
+
+# ---------------- optimal ate pairing ----------------
+ATE = 6 * U + 2
+FROB_X = f2_pow(XI, (P - 1) // 3)   # pi(x', y') = (conj(x') * xi^((p-1)/3), conj(y') * xi^((p-1)/2))
+FROB_Y = f2_pow(XI, (P - 1) // 2)
+
+
+def _line(T, Q, Pt):
+    """Line through twist points T, Q (or tangent at T when T == Q) evaluated at the G1 point Pt,
+    as a sparse Fq12 element.  With the untwist (x', y') -> (x' w^2, y' w^3):
+        l(P) = y_P - lam' x_P w + (lam' x_T - y_T) w^3     (lam' = slope on the twist)."""
+    if T[0] == Q[0] and T[1] == Q[1]:
+        lam = f2_mul(f2_scal(f2_mul(T[0], T[0]), 3), f2_inv(f2_scal(T[1], 2)))
+    else:
+        lam = f2_mul(f2_sub(Q[1], T[1]), f2_inv(f2_sub(Q[0], T[0])))
+    xp, yp = Pt
+    out = [0] * 12
+    out[0] = yp % P
+    a = f12_from_fq2(f2_scal(lam, (-xp) % P), 1)
+    b = f12_from_fq2(f2_sub(f2_mul(lam, T[0]), T[1]), 3)
+    return [(out[i] + a[i] + b[i]) % P for i in range(12)], lam
+
+
+def _step(T, Q, lam):
+    x = f2_sub(f2_sub(f2_mul(lam, lam), T[0]), Q[0])
+    return (x, f2_sub(f2_mul(lam, f2_sub(T[0], x)), T[1]))
+
+
+def miller_loop(Pt, Q):
+    if Pt is None or Q is None:
+        return F12_ONE
+    f = F12_ONE
+    T = Q
+    for bit in bin(ATE)[3:]:
+        l, lam = _line(T, T, Pt)
+        f = f12_mul(f12_mul(f, f), l)
+        T = _step(T, T, lam)
+        if bit == "1":
+            l, lam = _line(T, Q, Pt)
+            f = f12_mul(f, l)
+            T = _step(T, Q, lam)
+    Q1 = (f2_mul(f2_conj(Q[0]), FROB_X), f2_mul(f2_conj(Q[1]), FROB_Y))
+    Q2 = (f2_mul(f2_conj(Q1[0]), FROB_X), f2_mul(f2_conj(Q1[1]), FROB_Y))
+    Q2n = (Q2[0], f2_neg(Q2[1]))
+    l, lam = _line(T, Q1, Pt)
+    f = f12_mul(f, l)
+    T = _step(T, Q1, lam)
+    l, lam = _line(T, Q2n, Pt)
+    f = f12_mul(f, l)
+    return f
+
+
+FINAL_EXP = (P**12 - 1) // R
+
+
+def final_exp(f):
+    return f12_pow(f, FINAL_EXP)
+
+
+def pairing(Pt, Q):
+    return final_exp(miller_loop(Pt, Q))
+
+
+def multi_pairing(ps, qs):
+    """prod_i e(P_i, Q_i) with one shared final exponentiation (equal, as a field element, to the product
+    of individual pairings that reference src/prover_native.rs:15-23 computes)."""
+    f = F12_ONE
+    for a, b in zip(ps, qs):
+        f = f12_mul(f, miller_loop(a, b))
+    return final_exp(f)
+
+
+# ---------------- limb (de)serialisation: 8 x u32 little-endian per Fq ----------------
+def fq_to_u32(a):
+    return [(a >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def u32_to_fq(w):
+    return sum(int(x) << (32 * i) for i, x in enumerate(w))
+
+
+def g1_to_u32(p): return fq_to_u32(p[0]) + fq_to_u32(p[1])
+def g2_to_u32(p): return fq_to_u32(p[0][0]) + fq_to_u32(p[0][1]) + fq_to_u32(p[1][0]) + fq_to_u32(p[1][1])
+def f12_to_u32(a): return [w for c in a for w in fq_to_u32(c)]

@@ -119,3 +119,52 @@ class Batch:
             self.L.orc_batch_free(self.h)
         except Exception:
             pass
+
+
+# ---------------- AIR / trace (oracle/air.c) ----------------
+class OrcAir(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("kind", C.c_int), ("table_bits", C.c_int), ("cells_per_limb", C.c_int),
+                ("n_main", C.c_int), ("checked_base", C.c_int), ("n_checked", C.c_int), ("n_ops", C.c_int),
+                ("n_constraints", C.c_int), ("n_aux", C.c_int), ("pi_per_io", C.c_int), ("n_gadgets", C.c_int),
+                ("carry_limbs", C.c_int), ("prog", C.POINTER(C.c_int64)), ("prog_len", C.c_int),
+                ("aux", C.POINTER(C.c_int32))]
+
+
+class OrcTrace(C.Structure):
+    _fields_ = [("air", C.POINTER(OrcAir)), ("log_n", C.c_uint), ("num_io", C.c_size_t), ("width", C.c_int),
+                ("trace", C.POINTER(C.c_uint64)), ("pis", C.POINTER(C.c_uint32))]
+
+
+class Trace:
+    def __init__(self, kind, ios):
+        L = load()
+        L.orc_trace_build.restype = C.POINTER(OrcTrace)
+        L.orc_trace_build.argtypes = [C.c_int, u32p, C.c_size_t, C.POINTER(C.c_int)]
+        L.orc_trace_free.argtypes = [C.POINTER(OrcTrace)]
+        L.orc_trace_check_row.restype = C.c_long
+        L.orc_trace_check_row.argtypes = [C.POINTER(OrcTrace), C.c_size_t]
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        err = C.c_int()
+        self.L = L
+        self.p = L.orc_trace_build(kind, ios, ios.shape[0], C.byref(err))
+        self.err = err.value
+        if not self.p:
+            raise RuntimeError("orc_trace_build failed: %d" % err.value)
+        t = self.p.contents
+        self.log_n, self.width, self.num_io = t.log_n, t.width, t.num_io
+        self.air = t.air.contents
+
+    def array(self):
+        """view [width][N] (no copy)"""
+        n = 1 << self.log_n
+        return np.ctypeslib.as_array(self.p.contents.trace, shape=(self.width * n,)).reshape(self.width, n)
+
+    def check_row(self, r):
+        return self.L.orc_trace_check_row(self.p, r)
+
+    def __del__(self):
+        try:
+            if self.p:
+                self.L.orc_trace_free(self.p)
+        except Exception:
+            pass

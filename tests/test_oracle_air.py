@@ -1,0 +1,59 @@
+"""The AIRs (tools/air_gen.py specification) on the CPU oracle: traces built from native SIPP obligations
+satisfy every program constraint on every row; tampering is detected; wrong claimed outputs are refused."""
+import numpy as np
+import pytest
+
+from oracle.py import sipp_native as sn
+from tests import _oracle
+
+
+@pytest.fixture(scope="module")
+def ios4():
+    A, B = sn.synthetic_inputs(4, 7)
+    proof = sn.sipp_prove_native(A, B)
+    ok, st, obl = sn.sipp_verify_native(A, B, proof, check_final_pairing=False)
+    return sn.io_records(obl)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_trace_satisfies_constraints(ios4, kind):
+    ios = ios4[kind]
+    t = _oracle.Trace(kind, ios)
+    n = 1 << t.log_n
+    assert t.air.table_bits == 8 and n == 512 * t.num_io
+    rows = list(range(0, 70)) + list(range(500, 530)) + list(range(n - 3, n)) + [1023, 1024, 1087, 1088]
+    for r in rows:
+        if r < n:
+            assert t.check_row(r) == -1, (kind, r)
+    arr = t.array()
+    # range table and lookups
+    tb = 1 << t.air.table_bits
+    assert (arr[0] == np.minimum(np.arange(n), tb - 1)).all()
+    nm, nc, cb = t.air.n_main, t.air.n_checked, t.air.checked_base
+    for j in (0, nc // 2, nc - 1):
+        col, pin, ptab = arr[cb + j], arr[nm + j], arr[nm + nc + j]
+        assert col.max() < tb
+        assert (np.sort(col) == pin).all()
+        assert (np.sort(ptab) == np.sort(arr[0])).all()
+        first = np.concatenate([[True], pin[1:] != pin[:-1]])
+        assert (ptab[first] == pin[first]).all()
+
+
+def test_tamper_detected(ios4):
+    t = _oracle.Trace(0, ios4[0])
+    arr = t.array()
+    r = 37
+    assert t.check_row(r) == -1
+    col = t.air.checked_base + 5          # a limb of lambda
+    arr[col, r] ^= 1
+    assert t.check_row(r) != -1
+    arr[col, r] ^= 1
+    arr[1, r] += 1                         # accumulator limb: breaks the transition from row r-1 / gadgets of r
+    assert t.check_row(r) != -1 or t.check_row(r - 1) != -1
+
+
+def test_wrong_output_refused(ios4):
+    ios = ios4[0].copy()
+    ios[1, 55] ^= 1                        # last word of the claimed output of IO 1
+    with pytest.raises(RuntimeError):
+        _oracle.Trace(0, ios)

@@ -1,0 +1,459 @@
+#!/usr/bin/env python3
+"""AIR specification generator for the three SIPP STARKs (G1 exp, G2 exp, Fq12 exp).
+
+The reference delegates these AIRs to starky-bn254 @ 2d46f9e (reference src/verifier_circuit.rs:133-135;
+Cargo.toml:26), whose source is NOT under /root/reference.  PARITY UNPINNED: the column layout below is this
+repository's own specification, written to follow what SURVEY.md App. A.9 records about upstream
+(16 x 16-bit limbs, schoolbook products with quotient + carry witnesses, u16 range checks through
+permuted-column lookups, LSB-first double-and-add with 2 rows per exponent bit = 512 rows per IO,
+semantics out = offset + [exp] x  /  out = offset * x^exp from src/verifier_circuit.rs:92-124).
+
+An AIR is emitted as DATA (a flat int64 "program" + a header) consumed by two independent interpreters:
+oracle/air.c (CPU restatement: witness fill, constraint evaluation for prover and verifier) and
+sipp_amd/csrc/air.cuh (HIP: witness fill and quotient kernels).  Both copies of the tables are written
+by this script: oracle/air_tables.h and sipp_amd/csrc/air_tables.h.
+
+Column model
+  main columns  = [TABLE] + unchecked cells + checked cells (range-checked against the TABLE column)
+  trace columns = main | perm_in[n_checked] | perm_tab[n_checked]        (Halo2-style permuted lookup)
+  Z columns     = one per checked column per challenge:  Z' (pi+g)(pt+g) = Z (c+g)(table+g)
+  aux columns   = public-input polynomials (NOT committed; both sides derive them from the public inputs)
+  mode "u16": table = 0..65535 (needs N >= 2^16); a 16-bit limb is ONE checked cell
+  mode "u8" : table = 0..255; a 16-bit limb is TWO checked cells (lo, hi), value lo + 256*hi
+
+Program encoding (int64 words), see `Prog` below:
+  VEC   := n_limbs, n_terms, (coef, base, stride, flag_per, flag_neg)*     limb_i = sum coef*F*cell[base+i*stride]
+           F = 1 | per[flag_per] | 1 - per[flag_per]        (flag_per = -1: none)
+  GADGET:= OP_GADGET, sign_col, carry_base, carry_limbs, carry_bits, carry_offset, VEC(q),
+           n_prod, (coef, VEC a, VEC b)*, n_lin, (coef, VEC a)*
+           constraints k = 0..n_e:  e_k - (1-2s)(q*p)_k - c_{k-1} + 2^16 c_k = 0,  plus  s(s-1) = 0
+  POLY  := OP_POLY, n_mono, (coef, n_factors, (kind, index)*)*             kind: 0 local 1 next 2 aux 3 periodic
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BN_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+NL = 16          # 16-bit limbs per Fq element
+NQ = 17          # quotient limbs
+ROWS_PER_IO = 512
+OP_GADGET, OP_POLY = 1, 2
+K_LOCAL, K_NEXT, K_AUX, K_PER = 0, 1, 2, 3
+
+P_LIMBS = [(BN_P >> (16 * i)) & 0xFFFF for i in range(NL)]
+
+# periodic functions: index -> (m, r0): 1 on rows r = r0 (mod m), 0 on the other rows
+PER_FIRST, PER_LAST, PER_ADD, PER_LIMB_END = 0, 1, 2, 3
+PERIODICS = [(ROWS_PER_IO, 0), (ROWS_PER_IO, ROWS_PER_IO - 1), (2, 0), (64, 63)]
+
+
+class Air:
+    def __init__(self, name, mode):
+        self.name, self.mode = name, mode
+        self.cpl = 1 if mode == "u16" else 2       # checked cells per 16-bit limb
+        self.tbits = 16 if mode == "u16" else 8
+        self.unchecked = 1                          # column 0 = TABLE
+        self.checked = 0
+        self.names = {"TABLE": 0}
+        self._defer = []                            # (name, ncells) checked allocations
+        self.prog = []
+        self.n_ops = 0
+        self.n_constraints = 0
+        self.aux = []                               # (pi_word_index, part, shift_rows): part 0 = lo16, 1 = hi16, 2 = u32
+        self.pi_per_io = 0
+        self.max_e = 0
+
+    # ---- column allocation: all unchecked first, then all checked ----
+    def alloc(self, name, n):
+        base = self.unchecked
+        self.names[name] = base
+        self.unchecked += n
+        return base
+
+    def alloc_checked(self, name, ncells):
+        self._defer.append((name, ncells))
+
+    def finalize_columns(self):
+        self.checked_base = self.unchecked
+        off = self.checked_base
+        for name, n in self._defer:
+            self.names[name] = off
+            off += n
+        self.n_checked = off - self.checked_base
+        self.n_main = off
+
+    def col(self, name):
+        return self.names[name]
+
+    # ---- vectors ----
+    def vec_u16(self, name, n=NL, coef=1, flag=-1, neg=0):
+        """unchecked vector: one cell per limb"""
+        return [(coef, self.col(name), 1, flag, neg)], n
+
+    def vec_chk(self, name, n=NL, coef=1, flag=-1, neg=0):
+        """checked limb vector: 1 or 2 cells per limb"""
+        b = self.col(name)
+        if self.cpl == 1:
+            return [(coef, b, 1, flag, neg)], n
+        return [(coef, b, 2, flag, neg), (coef * 256, b + 1, 2, flag, neg)], n
+
+    @staticmethod
+    def vsum(*vs):
+        terms, n = [], vs[0][1]
+        for t, m in vs:
+            assert m == n
+            terms += t
+        return terms, n
+
+    def _emit_vec(self, v):
+        terms, n = v
+        out = [n, len(terms)]
+        for t in terms:
+            out += list(t)
+        return out
+
+    # ---- gadget: E(2^16) == 0 mod p ----
+    def gadget(self, gname, prods, lins, bound_bits):
+        """prods: [(coef, vecA, vecB)], lins: [(coef, vecA)].  bound_bits: log2 bound of |e_k|."""
+        # carry magnitude: |c_k| <= (|c_{k-1}| + |d_k|) / 2^16 with |d_k| < 2^bound_bits + 2^37
+        cbits_needed = max(bound_bits, 38) - 16 + 2      # signed, with slack
+        total_bits = cbits_needed + 1
+        if self.mode == "u16":
+            ncl, lb = (total_bits + 15) // 16, 16
+        else:
+            ncl, lb = (total_bits + 7) // 8, 8
+        coffset = 1 << (ncl * lb - 1)
+        n_e = 2 * NL - 1                                  # e_0 .. e_30, plus k = 31 from q*p
+        self.gadgets.append(dict(name=gname, prods=prods, lins=lins, ncl=ncl, lb=lb, coffset=coffset, n_e=n_e))
+
+    def emit_gadgets(self):
+        for g in self.gadgets:
+            nm = g["name"]
+            sign = self.col(nm + "_s")
+            cbase = self.col(nm + "_c")
+            q = self.vec_chk(nm + "_q", NQ)
+            w = [OP_GADGET, sign, cbase, g["ncl"], g["lb"], g["coffset"]] + self._emit_vec(q)
+            w += [len(g["prods"])]
+            for coef, a, b in g["prods"]:
+                w += [coef] + self._emit_vec(a) + self._emit_vec(b)
+            w += [len(g["lins"])]
+            for coef, a in g["lins"]:
+                w += [coef] + self._emit_vec(a)
+            self.prog += w
+            self.n_ops += 1
+            self.n_constraints += 2 * NL + 1              # 32 coefficient equations + sign booleanity
+
+    def declare_gadget_cols(self, gname, bound_bits):
+        cbits_needed = max(bound_bits, 38) - 16 + 2
+        total_bits = cbits_needed + 1
+        if self.mode == "u16":
+            ncl = (total_bits + 15) // 16
+        else:
+            ncl = (total_bits + 7) // 8
+        self.alloc(gname + "_s", 1)
+        self.alloc_checked(gname + "_q", NQ * self.cpl)
+        self.alloc_checked(gname + "_c", (2 * NL - 1) * ncl)
+
+    # ---- generic polynomial constraints ----
+    def poly(self, monos):
+        """monos: [(coef, [(kind, index), ...])]; one constraint"""
+        w = [OP_POLY, len(monos)]
+        for coef, factors in monos:
+            assert len(factors) <= 3
+            w += [coef, len(factors)]
+            for k, i in factors:
+                w += [k, i]
+        self.prog += w
+        self.n_ops += 1
+        self.n_constraints += 1
+
+    def limb_expr(self, name, i, checked):
+        """[(coef, (kind,col))] for limb i of a 16-bit-limb vector in the local row"""
+        b = self.col(name)
+        if not checked or self.cpl == 1:
+            return [(1, b + i)]
+        return [(1, b + 2 * i), (256, b + 2 * i + 1)]
+
+
+def L(c):
+    return (K_LOCAL, c)
+
+
+def X(c):
+    return (K_NEXT, c)
+
+
+def PER(i):
+    return (K_PER, i)
+
+
+def AUX(i):
+    return (K_AUX, i)
+
+
+def exponent_logic(a):
+    """bit / remaining-exponent-limb machinery shared by the three AIRs (2 rows per bit, LSB first)."""
+    bit, e = a.col("bit"), a.col("e")
+    a.poly([(1, [L(bit), L(bit)]), (-1, [L(bit)])])                                   # bit boolean
+    a.poly([(2, [PER(PER_ADD), X(e)]), (1, [PER(PER_ADD), L(bit)]), (-1, [PER(PER_ADD), L(e)])])  # add rows: e0 = 2 e0' + bit
+    # double rows that are not a limb end: e0' = e0          (1 - per_add - per_limb_end)
+    a.poly([(1, [X(e)]), (-1, [L(e)]), (-1, [PER(PER_ADD), X(e)]), (1, [PER(PER_ADD), L(e)]),
+            (-1, [PER(PER_LIMB_END), X(e)]), (1, [PER(PER_LIMB_END), L(e)])])
+    a.poly([(1, [PER(PER_LIMB_END), L(e)])])                                          # limb consumed at its end
+    for i in range(7):                                                                # rotate at limb ends (not block end)
+        a.poly([(1, [PER(PER_LIMB_END), X(e + i)]), (-1, [PER(PER_LIMB_END), L(e + i + 1)]),
+                (-1, [PER(PER_LAST), X(e + i)]), (1, [PER(PER_LAST), L(e + i + 1)])])
+    for i in range(1, 8):                                                             # otherwise limbs 1..7 are copied
+        a.poly([(1, [X(e + i)]), (-1, [L(e + i)]), (-1, [PER(PER_LIMB_END), X(e + i)]), (1, [PER(PER_LIMB_END), L(e + i)])])
+
+
+def state_transition(a, state, result, upd_on_add, nl):
+    """state/result: column names of nl 16-bit limbs (state unchecked, result checked).
+    upd_on_add: True  -> accumulator: add rows: s' = bit ? res : s ; double rows (not last): s' = s
+                False -> running power: add rows: s' = s ; double rows (not last): s' = res"""
+    bit = a.col("bit")
+    for i in range(nl):
+        s = a.col(state) + i
+        res = a.limb_expr(result, i, True)
+        if upd_on_add:
+            # per_add * (s' - s - bit*(res - s)) = 0
+            m = [(1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_ADD), L(s)]), (1, [PER(PER_ADD), L(bit), L(s)])]
+            m += [(-c, [PER(PER_ADD), L(bit), L(cc)]) for c, cc in res]
+            a.poly(m)
+            # (1 - per_add - per_last) * (s' - s) = 0     (double rows except the block's last row)
+            a.poly([(1, [X(s)]), (-1, [L(s)]), (-1, [PER(PER_ADD), X(s)]), (1, [PER(PER_ADD), L(s)]),
+                    (-1, [PER(PER_LAST), X(s)]), (1, [PER(PER_LAST), L(s)])])
+        else:
+            a.poly([(1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_ADD), L(s)])])
+            m = [(1, [X(s)]), (-1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_LAST), X(s)])]
+            for c, cc in res:
+                m += [(-c, [L(cc)]), (c, [PER(PER_ADD), L(cc)]), (c, [PER(PER_LAST), L(cc)])]
+            a.poly(m)
+
+
+def bind_pi(a, layout):
+    """layout: [(state_name, n_u32_words, row)] in PI order; row 'first' or 'last'.
+    Every 16-bit limb cell of the state is bound to the matching half of the public u32 word."""
+    word = 0
+    for name, nwords, row in layout:
+        per = PER_FIRST if row == "first" else PER_LAST
+        shift = 0 if row == "first" else ROWS_PER_IO - 1
+        base = a.col(name)
+        if name == "e":
+            for j in range(nwords):
+                ai = len(a.aux)
+                a.aux.append((word + j, 2, shift))
+                a.poly([(1, [PER(per), L(base + j)]), (-1, [PER(per), AUX(ai)])])
+        else:
+            for j in range(nwords):
+                for part in (0, 1):
+                    ai = len(a.aux)
+                    a.aux.append((word + j, part, shift))
+                    a.poly([(1, [PER(per), L(base + 2 * j + part)]), (-1, [PER(per), AUX(ai)])])
+        word += nwords
+    a.pi_per_io = word
+
+
+# ------------------------------------------------------------------------------------------------
+def build_curve(name, mode, ext):
+    """G1 (ext = 1, coordinates in Fq) or G2 (ext = 2, coordinates in Fq2 = Fq[u]/(u^2+1)).
+    Row: one affine group operation  (x3, y3) = A (+) B  with slope lam:
+       add rows  (even): A = R (accumulator), B = P (running power);  lam (xB - xA) = yB - yA
+       double rows (odd): A = B = P;                                   2 lam yA = 3 xA^2
+       lam^2 = xA + xB + x3 ;  lam (xA - x3) = yA + y3
+    """
+    a = Air(name, mode)
+    a.gadgets = []
+    nc = NL * ext                      # limbs per coordinate
+    a.alloc("Rx", nc); a.alloc("Ry", nc); a.alloc("Px", nc); a.alloc("Py", nc)
+    a.alloc("bit", 1); a.alloc("e", 8)
+    for nm in ("lam", "X3", "Y3"):
+        a.alloc_checked(nm, nc * a.cpl)
+    gad = []
+    for eq in ("slope", "x3", "y3"):
+        for c in range(ext):
+            gad.append("%s%d" % (eq, c))
+    bound = 42 if ext == 1 else 43
+    for g in gad:
+        a.declare_gadget_cols(g, bound)
+    a.finalize_columns()
+
+    def comp_u(nm, c, **kw):   # component c (0/1) of an unchecked Fq2/Fq value
+        t, n = a.vec_u16(nm, **kw)
+        return [(co, b + NL * c, st, f, ng) for (co, b, st, f, ng) in t], n
+
+    def comp_c(nm, c, **kw):   # component c of a checked value
+        t, n = a.vec_chk(nm, **kw)
+        return [(co, b + NL * a.cpl * c, st, f, ng) for (co, b, st, f, ng) in t], n
+
+    def fq2_mul_terms(va, vb):
+        """va, vb: functions c -> vector for component c.  Returns {0: prods, 1: prods} of (coef, A, B)."""
+        if ext == 1:
+            return {0: [(1, va(0), vb(0))]}
+        return {0: [(1, va(0), vb(0)), (-1, va(1), vb(1))], 1: [(1, va(0), vb(1)), (1, va(1), vb(0))]}
+
+    lam = lambda c: comp_c("lam", c)
+    # slope:  per_add * [lam*(Px - Rx) - (Py - Ry)] + (1 - per_add) * [2 lam Py - 3 Px^2] = 0
+    dx = lambda c: Air.vsum(comp_u("Px", c, flag=PER_ADD), comp_u("Rx", c, coef=-1, flag=PER_ADD),
+                            comp_u("Py", c, coef=2, flag=PER_ADD, neg=1))
+    px_d = lambda c: comp_u("Px", c, flag=PER_ADD, neg=1)
+    px = lambda c: comp_u("Px", c)
+    t1 = fq2_mul_terms(lam, dx)
+    t2 = fq2_mul_terms(px_d, px)
+    for c in range(ext):
+        prods = t1[c] + [(-3 * co, A, B) for (co, A, B) in t2[c]]
+        lins = [(-1, comp_u("Py", c, flag=PER_ADD)), (1, comp_u("Ry", c, flag=PER_ADD))]
+        a.gadget("slope%d" % c, prods, lins, bound)
+    # x3:  lam^2 - xA - xB - x3 = 0 ;  xA + xB = per_add*(Rx + Px) + (1-per_add)*2Px
+    t = fq2_mul_terms(lam, lam)
+    for c in range(ext):
+        lins = [(-1, comp_u("Rx", c, flag=PER_ADD)), (-1, comp_u("Px", c, flag=PER_ADD)),
+                (-2, comp_u("Px", c, flag=PER_ADD, neg=1)), (-1, comp_c("X3", c))]
+        a.gadget("x3%d" % c, t[c], lins, bound)
+    # y3:  lam*(xA - x3) - yA - y3 = 0 ;  xA = per_add*Rx + (1-per_add)*Px
+    xa_m = lambda c: Air.vsum(comp_u("Rx", c, flag=PER_ADD), comp_u("Px", c, flag=PER_ADD, neg=1), comp_c("X3", c, coef=-1))
+    t = fq2_mul_terms(lam, xa_m)
+    for c in range(ext):
+        lins = [(-1, comp_u("Ry", c, flag=PER_ADD)), (-1, comp_u("Py", c, flag=PER_ADD, neg=1)), (-1, comp_c("Y3", c))]
+        a.gadget("y3%d" % c, t[c], lins, bound)
+    a.emit_gadgets()
+    exponent_logic(a)
+    state_transition(a, "Rx", "X3", True, nc)
+    state_transition(a, "Ry", "Y3", True, nc)
+    state_transition(a, "Px", "X3", False, nc)
+    state_transition(a, "Py", "Y3", False, nc)
+    w = 8 * ext
+    # IO record order (x, offset, exp_val, output): reference src/verifier_circuit.rs:92-105
+    bind_pi(a, [("Px", w, "first"), ("Py", w, "first"), ("Rx", w, "first"), ("Ry", w, "first"), ("e", 8, "first"),
+                ("Rx", w, "last"), ("Ry", w, "last")])
+    a.primary = dict(kind="curve", ext=ext)
+    return a
+
+
+def build_fq12(mode):
+    """out = offset * x^exp in Fq12 = Fq[w]/(w^12 - 18 w^6 + 82) (MyFq12 coefficient order).
+    Row: one Fq12 product C = A * B;  mul rows (even): A = acc, B = pw;  square rows (odd): A = B = pw."""
+    a = Air("fq12", mode)
+    a.gadgets = []
+    a.alloc("acc", 12 * NL); a.alloc("pw", 12 * NL); a.alloc("bit", 1); a.alloc("e", 8)
+    a.alloc_checked("C", 12 * NL * a.cpl)
+    bound = 50
+    for k in range(12):
+        a.declare_gadget_cols("c%d" % k, bound)
+    a.finalize_columns()
+
+    def coef_u(nm, i, **kw):
+        t, n = a.vec_u16(nm, **kw)
+        return [(co, b + NL * i, st, f, ng) for (co, b, st, f, ng) in t], n
+
+    def coef_c(nm, i, **kw):
+        t, n = a.vec_chk(nm, **kw)
+        return [(co, b + NL * a.cpl * i, st, f, ng) for (co, b, st, f, ng) in t], n
+
+    A = lambda i: Air.vsum(coef_u("acc", i, flag=PER_ADD), coef_u("pw", i, flag=PER_ADD, neg=1))
+    B = lambda j: coef_u("pw", j)
+    # w^m for m >= 12 in terms of w^0..w^11:   w^12 = 18 w^6 - 82
+    red = {}
+    for m in range(23):
+        if m < 12:
+            red[m] = {m: 1}
+        elif m < 18:
+            red[m] = {m - 6: 18, m - 12: -82}
+        else:
+            red[m] = {m - 12: 242, m - 18: -1476}
+    for k in range(12):
+        prods = []
+        for i in range(12):
+            for j in range(12):
+                c = red[i + j].get(k, 0)
+                if c:
+                    prods.append((c, A(i), B(j)))
+        a.gadget("c%d" % k, prods, [(-1, coef_c("C", k))], bound)
+    a.emit_gadgets()
+    exponent_logic(a)
+    state_transition(a, "acc", "C", True, 12 * NL)
+    state_transition(a, "pw", "C", False, 12 * NL)
+    # IO record order (x, offset, exp_val, output): reference src/verifier_circuit.rs:111-123
+    bind_pi(a, [("pw", 96, "first"), ("acc", 96, "first"), ("e", 8, "first"), ("acc", 96, "last")])
+    a.primary = dict(kind="fq12")
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+def emit(a, f, prefix):
+    tag = "%s_%s_%s" % (prefix, a.name, a.mode)
+    f.write("static const int64_t %s_PROG[] = {\n" % tag)
+    for i in range(0, len(a.prog), 16):
+        f.write("    " + ", ".join("%dLL" % v for v in a.prog[i:i + 16]) + ",\n")
+    f.write("};\n")
+    f.write("static const int32_t %s_AUX[] = {\n" % tag)
+    for i in range(0, len(a.aux), 8):
+        f.write("    " + ", ".join("%d, %d, %d" % t for t in a.aux[i:i + 8]) + ",\n")
+    f.write("};\n")
+
+
+def header_entry(a, prefix):
+    tag = "%s_%s_%s" % (prefix, a.name, a.mode)
+    g0 = a.gadgets[0]
+    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX},\n" % (
+        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
+        a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag))
+
+
+STRUCT = """typedef struct {
+    const char *name;
+    int kind;            /* 0 g1, 1 g2, 2 fq12 */
+    int table_bits;      /* 16 or 8 */
+    int cells_per_limb;  /* checked cells per 16-bit limb: 1 (u16 table) or 2 (u8 table) */
+    int n_main;          /* TABLE + unchecked + checked cells */
+    int checked_base;    /* first checked column; checked columns are [checked_base, n_main) */
+    int n_checked;
+    int n_ops;
+    int n_constraints;   /* constraints produced by the program (gadgets + polys) */
+    int n_aux;           /* public-input polynomials */
+    int pi_per_io;       /* u32 words per IO record */
+    int n_gadgets;
+    int carry_limbs;
+    const int64_t *prog;
+    int prog_len;
+    const int32_t *aux;  /* (pi word, part 0 lo16 / 1 hi16 / 2 u32, row shift) per aux column */
+} %s_air_t;
+"""
+
+
+def column_map(a):
+    rows = sorted(a.names.items(), key=lambda kv: kv[1])
+    return ", ".join("%s@%d" % kv for kv in rows)
+
+
+def main():
+    airs = []
+    for mode in ("u16", "u8"):
+        airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode)]
+    for path, prefix, guard in ((os.path.join(ROOT, "oracle", "air_tables.h"), "ORC", "ORACLE_AIR_TABLES_H"),
+                                (os.path.join(ROOT, "sipp_amd", "csrc", "air_tables.h"), "SIPP", "SIPP_AIR_TABLES_H")):
+        with open(path, "w") as f:
+            f.write("/* GENERATED by tools/air_gen.py -- the AIR specification as data; do not edit. */\n")
+            f.write("#ifndef %s\n#define %s\n#include <stdint.h>\n" % (guard, guard))
+            f.write(STRUCT % prefix.lower())
+            f.write("#define %s_N_PERIODIC %d\n" % (prefix, len(PERIODICS)))
+            f.write("static const int32_t %s_PERIODIC[%d][2] = {%s};\n" % (
+                prefix, len(PERIODICS), ", ".join("{%d, %d}" % p for p in PERIODICS)))
+            f.write("static const uint32_t %s_BN_P_LIMBS[16] = {%s};\n" % (prefix, ", ".join(map(str, P_LIMBS))))
+            for a in airs:
+                f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
+                emit(a, f, prefix)
+            f.write("static const %s_air_t %s_AIRS[%d] = {\n" % (prefix.lower(), prefix, len(airs)))
+            for a in airs:
+                f.write(header_entry(a, prefix))
+            f.write("};\n#endif\n")
+    for a in airs:
+        W = a.n_main + 2 * a.n_checked
+        print("%-10s n_main %5d checked %5d  W %6d  Z %6d  aux %4d  constraints %6d  prog %7d words  carry limbs %d" % (
+            a.name + "_" + a.mode, a.n_main, a.n_checked, W, 2 * a.n_checked, len(a.aux), a.n_constraints, len(a.prog),
+            a.gadgets[0]["ncl"]))
+
+
+if __name__ == "__main__":
+    main()
