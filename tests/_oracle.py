@@ -168,3 +168,41 @@ class Trace:
                 self.L.orc_trace_free(self.p)
         except Exception:
             pass
+
+
+# ---------------- STARK prover / verifier (oracle/stark.c) ----------------
+class OrcConfig(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "arity_bits", "final_poly_bits",
+                                          "num_queries", "num_challenges")]
+
+
+def default_config():
+    cfg = OrcConfig()
+    load().orc_default_config(C.byref(cfg))
+    return cfg
+
+
+def stark_prove(kind, ios, cfg=None):
+    L = load()
+    cfg = cfg or default_config()
+    ios = np.ascontiguousarray(ios, dtype=np.uint32)
+    L.orc_stark_prove.argtypes = [C.c_int, u32p, C.c_size_t, C.POINTER(OrcConfig), C.POINTER(C.POINTER(C.c_uint64)),
+                                  C.POINTER(C.c_size_t)]
+    L.orc_free.argtypes = [C.c_void_p]
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    rc = L.orc_stark_prove(kind, ios, ios.shape[0], C.byref(cfg), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("orc_stark_prove failed: %d" % rc)
+    proof = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free(out)
+    return proof
+
+
+def stark_verify(proof, cfg=None):
+    L = load()
+    cfg = cfg or default_config()
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    L.orc_stark_verify.argtypes = [u64p, C.c_size_t, C.POINTER(OrcConfig)]
+    L.orc_stark_verify.restype = C.c_int
+    return L.orc_stark_verify(proof, len(proof), C.byref(cfg))
