@@ -116,6 +116,10 @@ int sipp_merkle_cap(sipp_ctx *ctx, uint64_t *d_tree, uint32_t log_leaves, uint64
 /* values -> (coeffs, lde, tree, cap) in one call; d_tree sized 2 * n_leaves * 4 u64 */
 int sipp_commit_batch(sipp_ctx *ctx, const uint64_t *d_values, uint64_t *d_coeffs, uint64_t *d_lde,
                       uint64_t *d_tree, size_t ncols, uint32_t log_n, uint64_t *cap_out);
+/* Trace generation only (test surface for the trace-fill kernels): ios as for sipp_*_exp_prove;
+ * d_trace receives the column-major trace [width][2^log_rows] in natural row order, where
+ * width = main_cols of sipp_stark_shape.  d_trace must hold width * 2^log_rows u64. */
+int sipp_trace_build(sipp_ctx *ctx, int kind, const uint32_t *ios, size_t num_io, uint64_t *d_trace);
 /* batched Poseidon permutation of n states, d_states [n][12] in place (KAT surface) */
 int sipp_poseidon_permute(sipp_ctx *ctx, uint64_t *d_states, size_t n);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "sipp_merkle_cap": (C.c_int, [vp, vp, C.c_uint32, vp]),
     "sipp_commit_batch": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp]),
     "sipp_poseidon_permute": (C.c_int, [vp, vp, C.c_size_t]),
+    "sipp_trace_build": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp]),
     "sipp_profile_enable": (C.c_int, [vp, C.c_int]),
     "sipp_profile_reset": (C.c_int, [vp]),
     "sipp_profile_report": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
@@ -175,6 +176,20 @@ class Ctx:
         self._ck(self.L.sipp_commit_batch(self.h, values.data_ptr(), coeffs.data_ptr(), lde.data_ptr(),
                                           tree.data_ptr(), ncols, log_n, cap.ctypes.data), "commit_batch")
         return coeffs, lde, tree, cap
+
+    def shape(self, kind, num_io):
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._ck(self.L.sipp_stark_shape(self.h, kind, num_io, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "stark_shape")
+        return a.value, b.value, c.value, d.value
+
+    def trace_build(self, kind, ios):
+        """device trace [W][N] (natural row order) for the IO records (host uint32 [num_io][words])"""
+        import torch
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        log_n, W, _, _ = self.shape(kind, ios.shape[0])
+        t = torch.empty((W, 1 << log_n), dtype=torch.int64, device="cuda")
+        self._ck(self.L.sipp_trace_build(self.h, kind, ios.ctypes.data, ios.shape[0], t.data_ptr()), "trace_build")
+        return t
 
     def poseidon_permute(self, states):
         self._ck(self.L.sipp_poseidon_permute(self.h, states.data_ptr(), states.shape[0]), "poseidon_permute")

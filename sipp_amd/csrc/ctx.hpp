@@ -152,3 +152,10 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
                            uint64_t* d_digests);
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height);
 int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n);
+
+// ---- AIR layer (trace.hip / quotient.hip / stark.hip) -----------------------------------------
+#include "air_tables.h"
+const sipp_air_t* sipp_air_get(int kind, uint32_t log_n);
+const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a);
+int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
+                    uint64_t* d_trace, int* d_err);
