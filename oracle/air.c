@@ -307,7 +307,7 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
     fq_init();
     *err = 0;
     if (num_io == 0) { *err = -1; return NULL; }
-    size_t nio = 1;
+    size_t nio = 2; /* at least two IO blocks (1024 rows) */
     while (nio < num_io) nio <<= 1;
     unsigned log_n = 9;
     while (((size_t)1 << (log_n - 9)) < nio) log_n++;

@@ -191,6 +191,18 @@ class Ctx:
         self._ck(self.L.sipp_trace_build(self.h, kind, ios.ctypes.data, ios.shape[0], t.data_ptr()), "trace_build")
         return t
 
+    def prove(self, kind, ios):
+        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12) for host IO records -> flat proof (uint64 ndarray)"""
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        cap = self.L.sipp_proof_size(self.h, kind, ios.shape[0])
+        if cap == 0:
+            raise SippError(-1, "sipp_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        fn = (self.L.sipp_g1_exp_prove, self.L.sipp_g2_exp_prove, self.L.sipp_fq12_exp_prove)[kind]
+        self._ck(fn(self.h, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
+        return out[: n.value]
+
     def poseidon_permute(self, states):
         self._ck(self.L.sipp_poseidon_permute(self.h, states.data_ptr(), states.shape[0]), "poseidon_permute")
         return states

@@ -46,7 +46,7 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
     ctx->arena_size = workspace_bytes;
     if (hipMalloc((void**)&ctx->arena, workspace_bytes) != hipSuccess) return bail(SIPP_E_NOMEM);
     if (hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) return bail(SIPP_E_HIP);
-    ctx->h_pinned_words = (size_t)1 << 20;  // 8 MiB of pinned staging for caps / openings / query rows
+    ctx->h_pinned_words = (size_t)1 << 23;  // 64 MiB of pinned staging for IO records / query rows
     if (hipHostMalloc((void**)&ctx->h_pinned, ctx->h_pinned_words * 8) != hipSuccess) return bail(SIPP_E_NOMEM);
     int rc = sipp_poseidon_init_constants(ctx);
     if (rc != SIPP_OK) return bail(rc);

