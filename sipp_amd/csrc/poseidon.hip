@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
 int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests) {
     uint64_t nl = len >> 4;
     ProfScope ps(ctx, "fri_leaves");
-    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals, (uint64_t)len,
+    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
                        d_digests);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
@@ -185,9 +185,12 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
                            uint64_t* d_digests) {
     if (ncols == 0 || ncols > 0xffffffffull) return sipp_fail(ctx, SIPP_E_BADARG, "poseidon_leaves: bad ncols");
     uint64_t n = (uint64_t)1 << log_leaves;
-    unsigned grid = (unsigned)((n + 255) / 256);
+    // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
+    // park 4 waves on one CU and leave three quarters of the CUs idle
+    const unsigned bs = n <= 65536 ? 64 : 256;
+    unsigned grid = (unsigned)((n + bs - 1) / bs);
     ProfScope ps(ctx, "poseidon_leaves");
-    hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+    hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
                        (uint32_t)ncols, n, d_digests);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
@@ -199,9 +202,10 @@ int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, u
     for (uint32_t l = 0; l < log_leaves - cap_height; l++) {
         uint64_t n_child = (uint64_t)1 << (log_leaves - l);
         uint64_t n_par = n_child >> 1;
-        unsigned grid = (unsigned)((n_par + 255) / 256);
+        const unsigned bs = n_par <= 65536 ? 64 : 256;
+        unsigned grid = (unsigned)((n_par + bs - 1) / bs);
         ProfScope ps(ctx, "merkle_level");
-        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
+        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_tree + 4 * off,
                            d_tree + 4 * (off + n_child), n_par);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         off += n_child;

@@ -144,6 +144,7 @@ struct Oracle3 {
 static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io_in, uint64_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     if (!ctx || !ios || !proof_out || !proof_len) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread may be new (one host thread per ctx)
     const sipp_stark_config& cfg = ctx->cfg;
     Shape s;
     SIPP_TRY(shape_of(kind, num_io_in, &s));
@@ -454,6 +455,7 @@ size_t sipp_proof_size(const sipp_ctx* ctx, int kind, size_t num_io) {
 
 int sipp_trace_build(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* d_trace) {
     if (!ctx || !ios || !d_trace) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
     ArenaMark m = arena_mark(ctx);

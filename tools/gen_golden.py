@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/ with the CPU restatements (oracle/py):
+native SIPP obligations (STARK IO records) for seeded synthetic inputs A_i = [s_i]G1, B_i = [t_i]G2
+(SplitMix64).  SELF-GOLDEN: produced by this repository's restatement of
+reference src/prover_native.rs / src/verifier_native.rs / src/transcript_native.rs, not by the reference
+binary (no cargo in this image).
+
+    python tools/gen_golden.py 4 8 128
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.py import sipp_native as sn  # noqa: E402
+
+SEEDS = {4: 7, 8: 0x51515050, 128: 0x51515050 + 1, 1024: 0x51515050 + 2}
+
+
+def main():
+    for n in [int(x) for x in sys.argv[1:]]:
+        t = time.time()
+        A, B = sn.synthetic_inputs(n, SEEDS.get(n, n))
+        proof = sn.sipp_prove_native(A, B)
+        ok, st, obl = sn.sipp_verify_native(A, B, proof)
+        assert ok, "native SIPP verification failed"
+        g1, g2, f12 = sn.io_records(obl)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % n), g1=g1, g2=g2, fq12=f12,
+                            statement=np.array(sn.statement_to_u32(st), dtype=np.uint32))
+        print("n=%d: %s %s %s in %.1fs" % (n, g1.shape, g2.shape, f12.shape, time.time() - t))
+
+
+if __name__ == "__main__":
+    main()
