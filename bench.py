@@ -126,14 +126,12 @@ def main():
             e["calls"] += v["calls"]
             e["ms"] += v["ms"]
         c.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from sipp_amd import dist_util
+    elapsed = dist_util.max_over_ranks(elapsed, device="cuda")
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.n / (elapsed / args.steps)
+        value = dist_util.whole_job_rate(args.n, world, elapsed / args.steps)
         # dominant kernel: Poseidon leaf hashing.  Algorithmic bytes per step: every LDE cell of the three
         # committed batches of each STARK is read once (8 B) and one 32-B digest per leaf is written.
         leaf_bytes = 0.0

@@ -1,0 +1,40 @@
+"""world_size-2 gloo test of bench.py's N > 1 plumbing (instance sharding, barrier, max-over-ranks timing)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from sipp_amd import dist_util as du
+rank, local_rank, world = du.rank_world()
+dist.init_process_group("gloo")
+mine = du.shard_instances(5, rank, world)
+assert mine == list(range(rank, 5, world))
+dist.barrier()
+t = du.max_over_ranks(1.0 + rank)          # rank 1 is the slow one
+assert t == float(world), t
+rate = du.whole_job_rate(128, world, t)
+assert abs(rate - 128.0 * world / world) < 1e-9
+# every instance is owned exactly once
+import torch
+owned = torch.zeros(5, dtype=torch.int64); owned[mine] = 1
+dist.all_reduce(owned)
+assert owned.tolist() == [1] * 5
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                         capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
