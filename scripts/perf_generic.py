@@ -1,7 +1,7 @@
 """Quick per-kernel timing of the commitment pipeline at n=128-like shapes (GPU box)."""
 import sys, json
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sipp_amd
 from sipp_amd._lib import to_device
 

@@ -42,30 +42,46 @@ GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
 
 GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
 
-// (hi, lo) -> canonical.  hi:lo is any 128-bit value.
-GL_HD uint64_t reduce128(uint64_t hi, uint64_t lo) {
-    uint64_t hi_hi = hi >> 32;
-    uint64_t hi_lo = hi & EPS;
-    uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= EPS;
-    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
-    uint64_t r = t0 + t1;
-    if (r < t0) r += EPS;
-    return canon(r);
+// (hi, lo) -> [0, 2^64), congruent mod p but NOT necessarily canonical.  hi:lo is any 128-bit value.
+// x = lo + 2^64 hl + 2^96 hh  ==  lo - (hh + hl) + (hl << 32)      (2^64 = 2^32 - 1, 2^96 = -1)
+// The borrow of the subtraction and the carry of the addition are netted into ONE correction of +-(2^32 - 1).
+GL_HD uint64_t reduce128_nc(uint64_t hi, uint64_t lo) {
+    const uint32_t hl = (uint32_t)hi, hh = (uint32_t)(hi >> 32);
+    const uint32_t l0 = (uint32_t)lo, l1 = (uint32_t)(lo >> 32);
+    uint32_t s0 = hh + hl;
+    const uint32_t s1 = s0 < hh;
+    const uint32_t a0 = l0 - s0;
+    const uint32_t bw0 = l0 < s0;
+    const uint32_t a1a = l1 - s1;
+    const uint32_t a1 = a1a - bw0;
+    const uint32_t b1 = (l1 < s1) | (a1a < bw0);
+    const uint32_t b1h = a1 + hl;
+    const uint32_t c1 = b1h < a1;
+    const int32_t corr = (int32_t)c1 - (int32_t)b1;  // -1, 0, +1
+    const uint64_t b = ((uint64_t)b1h << 32) | a0;
+    return b + (uint64_t)((int64_t)corr * (int64_t)EPS);
 }
 
-// value = lo + 2^64 * hi32 with hi32 < 2^32 (a "96-bit" accumulator)
-GL_HD uint64_t reduce96(uint32_t hi32, uint64_t lo) {
+GL_HD uint64_t reduce128(uint64_t hi, uint64_t lo) { return canon(reduce128_nc(hi, lo)); }
+
+// value = lo + 2^64 * hi32 with hi32 < 2^32 (a "96-bit" accumulator) -> [0, 2^64), not canonical
+GL_HD uint64_t reduce96_nc(uint32_t hi32, uint64_t lo) {
     uint64_t t1 = ((uint64_t)hi32 << 32) - hi32;
     uint64_t r = lo + t1;
     if (r < lo) r += EPS;
-    return canon(r);
+    return r;
 }
+GL_HD uint64_t reduce96(uint32_t hi32, uint64_t lo) { return canon(reduce96_nc(hi32, lo)); }
 
+// 64 x 64 -> 128: four 32 x 32 + 64 multiply-adds (v_mad_u64_u32), no separate low product
 GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    lo = a * b;
-    hi = __umul64hi(a, b);
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
+    const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t1;
+    hi = (uint64_t)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+    lo = (t2 << 32) | (uint32_t)t0;
 #else
     unsigned __int128 p = (unsigned __int128)a * b;
     lo = (uint64_t)p;
@@ -73,21 +89,30 @@ GL_HD void mul_wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
 #endif
 }
 
-GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+// product in [0, 2^64), not canonical; inputs may be any u64
+GL_HD uint64_t mul_nc(uint64_t a, uint64_t b) {
     uint64_t hi, lo;
     mul_wide(a, b, hi, lo);
-    return reduce128(hi, lo);
+    return reduce128_nc(hi, lo);
 }
+
+GL_HD uint64_t mul(uint64_t a, uint64_t b) { return canon(mul_nc(a, b)); }
 
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 
 // a * b + c
-GL_HD uint64_t mad(uint64_t a, uint64_t b, uint64_t c) {
+GL_HD uint64_t mad_nc(uint64_t a, uint64_t b, uint64_t c) {
     uint64_t hi, lo;
     mul_wide(a, b, hi, lo);
     lo += c;
     hi += (lo < c);
-    return reduce128(hi, lo);
+    return reduce128_nc(hi, lo);
+}
+GL_HD uint64_t mad(uint64_t a, uint64_t b, uint64_t c) { return canon(mad_nc(a, b, c)); }
+// a (any u64) + c (canonical) -> [0, 2^64)
+GL_HD uint64_t add_nc(uint64_t a, uint64_t c) {
+    uint64_t s = a + c;
+    return s < a ? s + EPS : s;
 }
 
 GL_HD uint64_t pow(uint64_t a, uint64_t e) {

@@ -30,10 +30,11 @@ __constant__ uint64_t c_fast_vs[22 * 11];
 __constant__ uint64_t c_fast_what[22 * 11];
 
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
-    uint64_t x2 = gl::sqr(x);
-    uint64_t x3 = gl::mul(x2, x);
-    uint64_t x4 = gl::sqr(x2);
-    return gl::mul(x3, x4);
+    // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
+    uint64_t x2 = gl::mul_nc(x, x);
+    uint64_t x3 = gl::mul_nc(x2, x);
+    uint64_t x4 = gl::mul_nc(x2, x2);
+    return gl::mul_nc(x3, x4);
 }
 
 // out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  CIRC = 17 15 41 16 2 28 13 13 39 18 34 20, DIAG[0] = 8
@@ -60,7 +61,7 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
         // value = al + ah * 2^32, al, ah < 2^42
         uint64_t l = al + (ah << 32);
         uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[r] = gl::reduce96(h, l);
+        s[r] = gl::reduce96_nc(h, l);
     }
 }
 
@@ -75,21 +76,23 @@ struct Acc160 {
         hi += ph;
         c += (hi < ph);
     }
-    // 2^128 = -2^32 (mod p)
+    // 2^128 = -2^32 (mod p); result in [0, 2^64), not canonical
     __device__ __forceinline__ uint64_t reduce() const {
-        return gl::sub(gl::reduce128(hi, lo), (uint64_t)c << 32);
+        const uint64_t r = gl::reduce128_nc(hi, lo), t = (uint64_t)c << 32;
+        const uint64_t d = r - t;
+        return r < t ? d - gl::EPS : d;  // r < t < 2^37: d wrapped is >= 2^64 - 2^37 > EPS
     }
 };
 
 __device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add(s[i], c_rc[12 * rnd + i]));
+    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_nc(s[i], c_rc[12 * rnd + i]));
     mds_full(s);
 }
 
 __device__ __forceinline__ void partial_rounds_fast(uint64_t s[12]) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], c_fast_first[i]);
+    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_fast_first[i]);
     {
         uint64_t t[11];
 #pragma unroll 1
@@ -108,13 +111,13 @@ __device__ __forceinline__ void partial_rounds_fast(uint64_t s[12]) {
     }
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
-        uint64_t x = gl::add(sbox(s[0]), c_fast_scalar[r]);
+        uint64_t x = gl::add_nc(sbox(s[0]), c_fast_scalar[r]);
         Acc160 acc;
         acc.mac(x, 25);  // M[0][0] = CIRC[0] + DIAG[0]
 #pragma unroll
         for (int i = 0; i < 11; i++) acc.mac(s[i + 1], c_fast_what[r * 11 + i]);
 #pragma unroll
-        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad(x, c_fast_vs[r * 11 + i], s[i + 1]);
+        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad_nc(x, c_fast_vs[r * 11 + i], s[i + 1]);
         s[0] = acc.reduce();
     }
 }
@@ -125,6 +128,8 @@ __device__ __forceinline__ void permute(uint64_t s[12]) {
     partial_rounds_fast(s);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) full_round(s, r);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }
 
 }  // namespace poseidon
