@@ -8,6 +8,7 @@
 // Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
 #include "ctx.hpp"
 #include "poseidon.cuh"
+#include "poseidon_quad.cuh"
 #include "prover.hpp"
 
 namespace {
@@ -49,6 +50,65 @@ __global__ void __launch_bounds__(256) poseidon_leaves_kernel(const uint64_t* __
     d[1] = s[1];
     d[2] = s[2];
     d[3] = s[3];
+}
+
+// ---- four lanes per state (poseidon_quad.cuh): thin launches ----
+__global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
+                                                                  uint32_t ncols, uint64_t n_leaves,
+                                                                  uint64_t* __restrict__ digests) {
+    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
+    poseidon_quad::load_tables(tab);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t leaf = tid >> 2;
+    const uint32_t q = (uint32_t)tid & 3;
+    if (leaf >= n_leaves) return;  // n_leaves is a multiple of 16: whole quads / waves leave together
+    uint64_t s[3] = {0, 0, 0};
+    const uint64_t* p = lde + leaf;
+    for (uint32_t c = 0; c < ncols; c += 8) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t e = 3 * q + j;
+            if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
+        }
+        poseidon_quad::permute(s, q, tab);
+    }
+    uint64_t* d = digests + 4 * leaf;
+    if (q == 0) {
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+    } else if (q == 1) {
+        d[3] = s[0];
+    }
+}
+
+__global__ void __launch_bounds__(256) merkle_level_quad_kernel(const uint64_t* __restrict__ child,
+                                                               uint64_t* __restrict__ parent, uint64_t n_parents) {
+    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
+    poseidon_quad::load_tables(tab);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = tid >> 2;
+    const uint32_t q = (uint32_t)tid & 3;
+    // every lane of the wave runs the permutation (DPP needs whole quads); out-of-range quads work on zeros
+    const bool live = i < n_parents;
+    uint64_t s[3] = {0, 0, 0};
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t e = 3 * q + j;
+            if (e < 8) s[j] = child[8 * i + e];
+        }
+    }
+    poseidon_quad::permute(s, q, tab);
+    if (!live) return;
+    uint64_t* d = parent + 4 * i;
+    if (q == 0) {
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+    } else if (q == 1) {
+        d[3] = s[0];
+    }
 }
 
 // parent[i] = two_to_one(child[2i], child[2i+1])
@@ -123,6 +183,15 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
     if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
 }
 
+uint64_t quad_threshold() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("SIPP_QUAD_MAX_LEAVES");
+        v = e ? atol(e) : 65536;
+    }
+    return (uint64_t)v;
+}
+
 }  // namespace
 
 int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests) {
@@ -187,11 +256,18 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     uint64_t n = (uint64_t)1 << log_leaves;
     // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
     // park 4 waves on one CU and leave three quarters of the CUs idle
-    const unsigned bs = n <= 65536 ? 64 : 256;
-    unsigned grid = (unsigned)((n + bs - 1) / bs);
     ProfScope ps(ctx, "poseidon_leaves");
-    hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
-                       (uint32_t)ncols, n, d_digests);
+    if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
+        // thin launch: four lanes per state -> 4x the waves
+        unsigned grid = (unsigned)((4 * n + 255) / 256);
+        hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
+    } else {
+        const unsigned bs = n <= 65536 ? 64 : 256;
+        unsigned grid = (unsigned)((n + bs - 1) / bs);
+        hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
+    }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
@@ -202,11 +278,16 @@ int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, u
     for (uint32_t l = 0; l < log_leaves - cap_height; l++) {
         uint64_t n_child = (uint64_t)1 << (log_leaves - l);
         uint64_t n_par = n_child >> 1;
-        const unsigned bs = n_par <= 65536 ? 64 : 256;
-        unsigned grid = (unsigned)((n_par + bs - 1) / bs);
         ProfScope ps(ctx, "merkle_level");
-        hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_tree + 4 * off,
-                           d_tree + 4 * (off + n_child), n_par);
+        if (n_par <= quad_threshold()) {
+            unsigned grid = (unsigned)((4 * n_par + 255) / 256);
+            hipLaunchKernelGGL(merkle_level_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
+                               d_tree + 4 * (off + n_child), n_par);
+        } else {
+            unsigned grid = (unsigned)((n_par + 255) / 256);
+            hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
+                               d_tree + 4 * (off + n_child), n_par);
+        }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         off += n_child;
     }
