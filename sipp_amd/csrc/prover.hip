@@ -107,10 +107,16 @@ __global__ void __launch_bounds__(256) z_phase_c(uint64_t* __restrict__ zv, size
 }
 
 // =====================================================================================================
-// quotient: one lane per LDE point (leaf order), AIR program interpreted over the base field.
-// per-lane work arrays live in LDS as arr[slot][lane] (lane fastest: conflict-free).
+// quotient: one lane per LDE point (leaf order).
+//   quotient_prog_kernel : the AIR program (gadgets + polynomial constraints) interpreted over the base field.
+//                          Limb vectors, the 31-coefficient accumulator and the quotient limbs live in REGISTERS:
+//                          the limb loops are static (16 / 17 limbs, fixed by tools/air_gen.py) and fully unrolled,
+//                          only the walk over terms / products is data driven (wave-uniform, no divergence).
+//   quotient_rest_kernel : range table, permuted lookups and permutation-Z constraints (no program, no arrays,
+//                          high occupancy, loads batched four columns at a time), then
+//                          total = acc_prog * alpha^(#rest) + acc_rest, divided by Z_H.
+// Constraint order == alpha-power order, identical to oracle/air_eval.inc.
 // =====================================================================================================
-constexpr int QT = 64;  // lanes per block
 struct QuotArgs {
     const uint64_t* lde;   // [W][m]
     const uint64_t* zlde;  // [P][m]
@@ -120,6 +126,7 @@ struct QuotArgs {
     int W, nm, nc, cbase, tbits;
     uint32_t log_n, log_m;
     uint64_t alpha[2], gamma[2];
+    uint64_t alpha_rest[2];                    // alpha^(3 + 6 nc)
     const uint64_t* per_tab[SIPP_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
     uint32_t per_mask[SIPP_N_PERIODIC];
     uint64_t zh_inv[2];   // 1 / (x^N - 1) for even / odd natural index
@@ -130,8 +137,6 @@ struct QuotArgs {
     uint32_t p_limbs[16];
     uint64_t* out;        // [2][m] leaf order
 };
-
-#define LDSA(base, slot) lds[((base) + (slot)) * QT + threadIdx.x]
 
 struct QCtx {
     const QuotArgs* a;
@@ -146,10 +151,12 @@ struct QCtx {
     }
 };
 
-// evaluates a VEC into lds slots [base, base + n); returns words consumed
-__device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t* lds, int base, int* n_out) {
-    const int n = (int)w[0], nt = (int)w[1];
-    for (int i = 0; i < n; i++) LDSA(base, i) = 0;
+// evaluates a VEC with exactly N limbs into registers; returns words consumed
+template <int N>
+__device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t (&out)[N]) {
+    const int nt = (int)w[1];
+#pragma unroll
+    for (int i = 0; i < N; i++) out[i] = 0;
     for (int t = 0; t < nt; t++) {
         const int64_t* tm = w + 2 + 5 * t;
         const int cbase = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
@@ -159,18 +166,18 @@ __device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t* l
             if (neg) pv = gl::sub(1, pv);
             f = gl::mul(f, pv);
         }
-        for (int i = 0; i < n; i++) LDSA(base, i) = gl::mad(f, c.local(cbase + i * stride), LDSA(base, i));
+        uint64_t v[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = c.local(cbase + i * stride);
+#pragma unroll
+        for (int i = 0; i < N; i++) out[i] = gl::mad(f, v[i], out[i]);
     }
-    *n_out = n;
     return 2 + 5 * nt;
 }
 
-__global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
-    // slots: e[0..33), va[33..50), vb[50..67), q[67..84)
-    __shared__ uint64_t lds[84 * QT];
-    constexpr int E0 = 0, VA = 33, VB = 50, Q0 = 67;
+__global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
     const size_t m = (size_t)1 << a.log_m;
-    const size_t j = (size_t)blockIdx.x * QT + threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
     const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);  // natural LDE index
     QCtx c;
     c.a = &a;
@@ -179,7 +186,6 @@ __global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
     for (int k = 0; k < SIPP_N_PERIODIC; k++) c.per[k] = a.per_tab[k][i & a.per_mask[k]];
-    const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_m, i));
 
     const int64_t* w = a.prog;
     const int64_t* end = a.prog + a.prog_len;
@@ -188,34 +194,45 @@ __global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
             const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
             const int64_t coffset = w[5];
             w += 6;
-            int nq, na, nb;
-            w += qvec(w, c, lds, Q0, &nq);
-            for (int k = 0; k < 33; k++) LDSA(E0, k) = 0;
+            const int64_t* qdesc = w;
+            w += 2 + 5 * (int)w[1];
+            uint64_t e[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) e[k] = 0;
             const int np = (int)*w++;
             for (int p = 0; p < np; p++) {
                 const uint64_t coef = gl::from_i64(*w++);
-                w += qvec(w, c, lds, VA, &na);
-                w += qvec(w, c, lds, VB, &nb);
-                for (int ii = 0; ii < na; ii++) {
-                    const uint64_t ai = gl::mul(coef, LDSA(VA, ii));
-                    for (int jj = 0; jj < nb; jj++) LDSA(E0, ii + jj) = gl::mad(ai, LDSA(VB, jj), LDSA(E0, ii + jj));
+                uint64_t va[16], vb[16];
+                w += qvec<16>(w, c, va);
+                w += qvec<16>(w, c, vb);
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) {
+                    const uint64_t ai = gl::mul(coef, va[ii]);
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj++) e[ii + jj] = gl::mad(ai, vb[jj], e[ii + jj]);
                 }
             }
             const int nl = (int)*w++;
             for (int p = 0; p < nl; p++) {
                 const uint64_t coef = gl::from_i64(*w++);
-                w += qvec(w, c, lds, VA, &na);
-                for (int ii = 0; ii < na; ii++) LDSA(E0, ii) = gl::mad(coef, LDSA(VA, ii), LDSA(E0, ii));
+                uint64_t va[16];
+                w += qvec<16>(w, c, va);
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) e[ii] = gl::mad(coef, va[ii], e[ii]);
             }
+            uint64_t q[17];
+            (void)qvec<17>(qdesc, c, q);
             const uint64_t s = c.local(sign_col);
             const uint64_t sgn = gl::sub(1, gl::add(s, s));
             uint64_t cprev = 0;
             const uint64_t coff = gl::from_i64(coffset);
+#pragma unroll
             for (int k = 0; k < 32; k++) {
                 uint64_t qp = 0;
-                for (int ii = 0; ii < nq; ii++) {
-                    int jj = k - ii;
-                    if (jj >= 0 && jj < 16) qp = gl::mad(LDSA(Q0, ii), (uint64_t)a.p_limbs[jj], qp);
+#pragma unroll
+                for (int ii = 0; ii < 17; ii++) {
+                    const int jj = k - ii;
+                    if (jj >= 0 && jj < 16) qp = gl::mad(q[ii], (uint64_t)a.p_limbs[jj], qp);
                 }
                 uint64_t ck = 0;
                 if (k < 31) {
@@ -223,7 +240,7 @@ __global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
                         ck = gl::mad(c.local(cbase + k * ncl + l), (uint64_t)1 << (lb * l), ck);
                     ck = gl::sub(ck, coff);
                 }
-                uint64_t v = gl::sub(LDSA(E0, k), gl::mul(sgn, qp));
+                uint64_t v = gl::sub(e[k], gl::mul(sgn, qp));
                 v = gl::sub(v, cprev);
                 v = gl::mad(ck, 65536, v);
                 c.emit(v);
@@ -249,7 +266,21 @@ __global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
             c.emit(sum);
         }
     }
-    // selectors at x
+    a.out[j] = c.acc0;
+    a.out[m + j] = c.acc1;
+}
+
+__global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
+    const size_t m = (size_t)1 << a.log_m;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);
+    QCtx c;
+    c.a = &a;
+    c.m = m;
+    c.j = j;
+    c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
+    c.acc0 = c.acc1 = 0;
+    const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_m, i));
     const uint64_t zh = a.zh[i & 1];
     const uint64_t zl = gl::sub(x, a.g_inv);
     const uint64_t lf = gl::mul(gl::mul(zh, a.ninv), gl::inv(gl::sub(x, 1)));
@@ -263,24 +294,54 @@ __global__ void __launch_bounds__(QT) quotient_kernel(QuotArgs a) {
         c.emit(gl::mul(ll, gl::sub(tl, ((uint64_t)1 << a.tbits) - 1)));
     }
     const int nm = a.nm, nc = a.nc;
-    for (int k = 0; k < nc; k++) {
-        const uint64_t pin = c.local(nm + k), ptab = c.local(nm + nc + k);
-        const uint64_t npin = c.next(nm + k), nptab = c.next(nm + nc + k);
-        c.emit(gl::mul(lf, gl::sub(pin, ptab)));
-        c.emit(gl::mul(zl, gl::mul(gl::sub(npin, pin), gl::sub(npin, nptab))));
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < nc; k0 += U) {
+        uint64_t pin[U], ptab[U], npin[U], nptab[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = min(k0 + u, nc - 1);
+            pin[u] = c.local(nm + k);
+            ptab[u] = c.local(nm + nc + k);
+            npin[u] = c.next(nm + k);
+            nptab[u] = c.next(nm + nc + k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (k0 + u < nc) {
+                c.emit(gl::mul(lf, gl::sub(pin[u], ptab[u])));
+                c.emit(gl::mul(zl, gl::mul(gl::sub(npin[u], pin[u]), gl::sub(npin[u], nptab[u]))));
+            }
+        }
     }
     for (int ch = 0; ch < 2; ch++) {
         const uint64_t g = a.gamma[ch];
-        for (int k = 0; k < nc; k++) {
-            const uint64_t z = a.zlde[(size_t)(ch * nc + k) * m + j], zn = a.zlde[(size_t)(ch * nc + k) * m + c.jn];
-            const uint64_t lhs = gl::mul(gl::add(c.local(a.cbase + k), g), gl::add(tl, g));
-            const uint64_t rhs = gl::mul(gl::add(c.local(nm + k), g), gl::add(c.local(nm + nc + k), g));
-            c.emit(gl::mul(lf, gl::sub(z, 1)));
-            c.emit(gl::sub(gl::mul(zn, rhs), gl::mul(z, lhs)));
+        const uint64_t tg = gl::add(tl, g);
+        for (int k0 = 0; k0 < nc; k0 += U) {
+            uint64_t z[U], zn[U], col[U], pin[U], ptab[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = min(k0 + u, nc - 1);
+                z[u] = a.zlde[(size_t)(ch * nc + k) * m + j];
+                zn[u] = a.zlde[(size_t)(ch * nc + k) * m + c.jn];
+                col[u] = c.local(a.cbase + k);
+                pin[u] = c.local(nm + k);
+                ptab[u] = c.local(nm + nc + k);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (k0 + u < nc) {
+                    const uint64_t lhs = gl::mul(gl::add(col[u], g), tg);
+                    const uint64_t rhs = gl::mul(gl::add(pin[u], g), gl::add(ptab[u], g));
+                    c.emit(gl::mul(lf, gl::sub(z[u], 1)));
+                    c.emit(gl::sub(gl::mul(zn[u], rhs), gl::mul(z[u], lhs)));
+                }
+            }
         }
     }
-    a.out[j] = gl::mul(c.acc0, a.zh_inv[i & 1]);
-    a.out[m + j] = gl::mul(c.acc1, a.zh_inv[i & 1]);
+    const uint64_t t0 = gl::mad(a.out[j], a.alpha_rest[0], c.acc0);
+    const uint64_t t1 = gl::mad(a.out[m + j], a.alpha_rest[1], c.acc1);
+    a.out[j] = gl::mul(t0, a.zh_inv[i & 1]);
+    a.out[m + j] = gl::mul(t1, a.zh_inv[i & 1]);
 }
 
 // =====================================================================================================
@@ -535,8 +596,17 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.w_m = wm;
     for (int i = 0; i < 16; i++) q.p_limbs[i] = SIPP_BN_P_LIMBS[i];
     q.out = d_out;
-    ProfScope ps(ctx, "quotient");
-    hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)(m / QT)), dim3(QT), 0, ctx->stream, q);
+    const uint64_t n_rest = 3 + 6 * (uint64_t)a->n_checked;
+    q.alpha_rest[0] = gl::pow(alpha[0], n_rest);
+    q.alpha_rest[1] = gl::pow(alpha[1], n_rest);
+    {
+        ProfScope ps(ctx, "quotient_prog");
+        hipLaunchKernelGGL(quotient_prog_kernel, dim3((unsigned)(m / 64)), dim3(64), 0, ctx->stream, q);
+    }
+    {
+        ProfScope ps(ctx, "quotient_rest");
+        hipLaunchKernelGGL(quotient_rest_kernel, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
+    }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
