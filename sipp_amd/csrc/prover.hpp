@@ -28,31 +28,58 @@ int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* i
 // ---- host Poseidon + duplex challenger (plonky2 iop/challenger.rs) ----
 namespace host {
 
+// Same algorithm as the device permutation (poseidon.cuh): dense circulant MDS in the 8 full rounds, the sparse
+// "fast" form in the 22 partial rounds -- about 0.5 us on a host core, so that observing ~27 k opening words of
+// the widest STARK costs a few ms instead of tens.  Checked against the device kernel by every proof parity test.
 inline void poseidon_permute(uint64_t s[12]) {
+    typedef unsigned __int128 u128;
     static const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     auto sbox = [](uint64_t x) {
         uint64_t x2 = gl::sqr(x), x3 = gl::mul(x2, x), x4 = gl::sqr(x2);
         return gl::mul(x3, x4);
     };
-    auto mds = [&](uint64_t* st) {
-        uint64_t out[12];
+    auto red = [](u128 v) { return gl::reduce128((uint64_t)(v >> 64), (uint64_t)v); };
+    auto full = [&](int rnd) {
+        uint64_t t[12], out[12];
+        for (int i = 0; i < 12; i++) t[i] = sbox(gl::add(s[i], SIPP_POSEIDON_RC[12 * rnd + i]));
         for (int r = 0; r < 12; r++) {
-            unsigned __int128 acc = 0;
-            for (int i = 0; i < 12; i++) acc += (unsigned __int128)st[(i + r) % 12] * CIRC[i];
-            if (r == 0) acc += (unsigned __int128)st[0] * 8;
-            out[r] = gl::reduce128((uint64_t)(acc >> 64), (uint64_t)acc);
+            u128 acc = 0;
+            for (int i = 0; i < 12; i++) acc += (u128)t[(i + r) % 12] * CIRC[i];
+            if (r == 0) acc += (u128)t[0] * 8;
+            out[r] = red(acc);
         }
-        for (int r = 0; r < 12; r++) st[r] = out[r];
+        for (int r = 0; r < 12; r++) s[r] = out[r];
     };
-    for (int rnd = 0; rnd < 30; rnd++) {
-        const bool full = rnd < 4 || rnd >= 26;
-        for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], SIPP_POSEIDON_RC[12 * rnd + i]);
-        if (full)
-            for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-        else
-            s[0] = sbox(s[0]);
-        mds(s);
+    for (int r = 0; r < 4; r++) full(r);
+    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], SIPP_POSEIDON_FAST_FIRST[i]);
+    {
+        uint64_t t[11];
+        for (int i = 0; i < 11; i++) {
+            // 11 products < 2^128 each: accumulate in 192 bits as (hi carry count, u128)
+            u128 acc = 0;
+            uint32_t c = 0;
+            for (int j = 0; j < 11; j++) {
+                u128 pr = (u128)s[j + 1] * SIPP_POSEIDON_FAST_MI[i * 11 + j];
+                acc += pr;
+                c += acc < pr;
+            }
+            t[i] = gl::sub(red(acc), (uint64_t)c << 32);  // 2^128 = -2^32
+        }
+        for (int i = 0; i < 11; i++) s[i + 1] = t[i];
     }
+    for (int r = 0; r < 22; r++) {
+        const uint64_t x = gl::add(sbox(s[0]), SIPP_POSEIDON_FAST_SCALAR[r]);
+        u128 acc = (u128)x * 25;
+        uint32_t c = 0;
+        for (int i = 0; i < 11; i++) {
+            u128 pr = (u128)s[i + 1] * SIPP_POSEIDON_FAST_WHAT[r * 11 + i];
+            acc += pr;
+            c += acc < pr;
+        }
+        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad(x, SIPP_POSEIDON_FAST_VS[r * 11 + i], s[i + 1]);
+        s[0] = gl::sub(red(acc), (uint64_t)c << 32);
+    }
+    for (int r = 26; r < 30; r++) full(r);
 }
 
 struct Challenger {
