@@ -8,7 +8,7 @@
 //   curve_chain      one 256-lane workgroup per IO: sequential doublings on one lane, then a parallel prefix
 //                    scan of the selected powers (Jacobian, no inversions); stores (R_k, P_k) per row.
 //   curve_rows       one lane per row: Jacobian -> affine, slope, x3, y3 (2 Fermat inversions), limbs
-//   fq12_chain       24 lanes per IO: acc*pw and pw^2 per exponent bit, one output coefficient per lane
+//   fq12_chain       one 288-lane workgroup per IO: the 2 x 144 limb products of acc*pw and pw^2 per bit in parallel
 //   exp_rows         one lane per row: bit / remaining-exponent-limb cells (closed form)
 //   gadget_rows      one lane per row: quotient / sign / carry witnesses of every modular gadget,
 //                    interpreted from the AIR program (integer arithmetic)
@@ -276,64 +276,70 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
     store_f_chk<EXT>(tr, n, c.Y3, row, y3, c.cpl);
 }
 
-// ---- Fq12 chain: 24 lanes per IO (lanes 0..11: coefficient k of acc*pw, 12..23: of pw*pw) ----
+// ---- Fq12 chain: one 288-lane workgroup per IO ----
+// per exponent bit: lanes 0..143 form the 144 limb products acc_i * pw_j, lanes 144..287 pw_i * pw_j (ONE
+// Montgomery product each); 24 lanes fold them into the 12 + 12 output coefficients of
+// Fq[w]/(w^12 - 18 w^6 + 82); 72 lanes convert and store the trace cells of the two rows.
 struct Fq12Cols {
     int acc, pw, C, cpl;
 };
 
-__global__ void __launch_bounds__(64) fq12_chain_kernel(const uint32_t* __restrict__ ios, uint32_t num_io,
-                                                       uint64_t* __restrict__ tr, size_t n, Fq12Cols c) {
-    __shared__ Fq s_acc[2][12], s_pw[2][12], s_mul[2][12], s_sqr[2][12];
-    const int slot = threadIdx.x / 24;        // 2 IOs per 64-lane block (48 lanes used)
-    const int lane = threadIdx.x % 24;
-    const uint32_t io = blockIdx.x * 2 + slot;
-    const bool active = slot < 2 && io < num_io;
-    const int k = lane % 12;
-    const bool sq = lane >= 12;
-    const uint32_t* rec = ios + (size_t)(active ? io : 0) * SIPP_FQ12_IO_WORDS;
-    if (active && !sq) {
-        s_pw[slot][k] = Fld<1>::load(rec + 8 * k);
-        s_acc[slot][k] = Fld<1>::load(rec + 96 + 8 * k);
+__global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restrict__ ios, uint32_t num_io,
+                                                        uint64_t* __restrict__ tr, size_t n, Fq12Cols c) {
+    __shared__ Fq s_acc[12], s_pw[12], s_res[2][12], s_prod[2][144];
+    const uint32_t io = blockIdx.x;
+    const int t = threadIdx.x;
+    const uint32_t* rec = ios + (size_t)io * SIPP_FQ12_IO_WORDS;
+    if (t < 12) {
+        s_pw[t] = Fld<1>::load(rec + 8 * t);
+        s_acc[t] = Fld<1>::load(rec + 96 + 8 * t);
     }
     __syncthreads();
     const Fq m18 = fq::small_m(18), m82 = fq::small_m(82), m242 = fq::small_m(242), m1476 = fq::small_m(1476);
     const uint32_t* ex = rec + 192;
+    const int which = t >= 144, pi = (t % 144) / 12, pj = t % 12;
     for (int b = 0; b < 256; b++) {
-        const int bit = active ? (int)((ex[b >> 5] >> (b & 31)) & 1) : 0;
-        if (active) {
-            const Fq* A = sq ? s_pw[slot] : s_acc[slot];
-            const Fq* B = s_pw[slot];
-            // d-sums feeding coefficient k:  k < 6: d_k - 82 d_{k+12} - 1476 d_{k+18}
-            //                                k >= 6: d_k + 18 d_{k+6} + 242 d_{k+12}
+        const int bit = (int)((ex[b >> 5] >> (b & 31)) & 1);
+        s_prod[which][pi * 12 + pj] = fq::mul(which ? s_pw[pi] : s_acc[pi], s_pw[pj]);
+        __syncthreads();
+        if (t < 24) {
+            const int sq = t >= 12, k = t % 12;
+            const Fq* pr = s_prod[sq];
+            // k < 6: d_k - 82 d_{k+12} - 1476 d_{k+18} ;  k >= 6: d_k + 18 d_{k+6} + 242 d_{k+12}
             Fq s0 = fq::zero(), s1 = fq::zero(), s2 = fq::zero();
             const int m1 = k < 6 ? k + 12 : k + 6, m2 = k < 6 ? k + 18 : k + 12;
             for (int i = 0; i < 12; i++) {
-                int j0 = k - i, j1 = m1 - i, j2 = m2 - i;
-                if (j0 >= 0 && j0 < 12) s0 = fq::add(s0, fq::mul(A[i], B[j0]));
-                if (j1 >= 0 && j1 < 12) s1 = fq::add(s1, fq::mul(A[i], B[j1]));
-                if (j2 >= 0 && j2 < 12) s2 = fq::add(s2, fq::mul(A[i], B[j2]));
+                const int j0 = k - i, j1 = m1 - i, j2 = m2 - i;
+                if (j0 >= 0 && j0 < 12) s0 = fq::add(s0, pr[i * 12 + j0]);
+                if (j1 >= 0 && j1 < 12) s1 = fq::add(s1, pr[i * 12 + j1]);
+                if (j2 >= 0 && j2 < 12) s2 = fq::add(s2, pr[i * 12 + j2]);
             }
             Fq r;
             if (k < 6)
                 r = fq::sub(fq::sub(s0, fq::mul(m82, s1)), fq::mul(m1476, s2));
             else
                 r = fq::add(fq::add(s0, fq::mul(m18, s1)), fq::mul(m242, s2));
-            (sq ? s_sqr[slot] : s_mul[slot])[k] = r;
+            s_res[sq][k] = r;
         }
         __syncthreads();
-        if (active) {
-            // rows 2b (mul row) and 2b+1 (square row); lanes 0..11 write the mul row, 12..23 the square row
-            const size_t row = (size_t)io * 512 + 2 * b + (sq ? 1 : 0);
-            Fq accv = s_acc[slot][k];
-            if (sq && bit) accv = s_mul[slot][k];  // the square row already sees the updated accumulator
-            store_limbs16(tr, n, c.acc + 16 * k, row, fq::from_mont(accv));
-            store_limbs16(tr, n, c.pw + 16 * k, row, fq::from_mont(s_pw[slot][k]));
-            store_checked(tr, n, c.C + 16 * c.cpl * k, row, fq::from_mont(sq ? s_sqr[slot][k] : s_mul[slot][k]), c.cpl);
+        if (t < 72) {
+            // task = (row 0/1, array 0 acc / 1 pw / 2 C, coefficient k)
+            const int rowsel = t / 36, arr = (t % 36) / 12, k = t % 12;
+            const size_t row = (size_t)io * 512 + 2 * b + rowsel;
+            if (arr == 0) {
+                Fq v = s_acc[k];
+                if (rowsel && bit) v = s_res[0][k];  // the square row already sees the updated accumulator
+                store_limbs16(tr, n, c.acc + 16 * k, row, fq::from_mont(v));
+            } else if (arr == 1) {
+                store_limbs16(tr, n, c.pw + 16 * k, row, fq::from_mont(s_pw[k]));
+            } else {
+                store_checked(tr, n, c.C + 16 * c.cpl * k, row, fq::from_mont(s_res[rowsel][k]), c.cpl);
+            }
         }
         __syncthreads();
-        if (active) {
-            if (!sq && bit) s_acc[slot][k] = s_mul[slot][k];
-            if (sq && b != 255) s_pw[slot][k] = s_sqr[slot][k];
+        if (t < 12) {
+            if (bit) s_acc[t] = s_res[0][t];
+            if (b != 255) s_pw[t] = s_res[1][t];
         }
         __syncthreads();
     }
@@ -363,6 +369,7 @@ __global__ void table_kernel(uint64_t* __restrict__ tr, size_t n, uint32_t tbits
 // ---- generic gadget witnesses: one lane per row, integer interpreter over the AIR program ----
 struct GadgetArgs {
     const int64_t* prog;
+    const uint32_t* gadget_off;  // word offset of every gadget in prog
     int prog_len;
     int cpl;
     uint32_t p_limbs[16];
@@ -390,11 +397,11 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
     if (row >= n) return;
     int per[SIPP_N_PERIODIC];
     for (int k = 0; k < SIPP_N_PERIODIC; k++) per[k] = (int)(row % (size_t)SIPP_PERIODIC[k][0]) == SIPP_PERIODIC[k][1];
-    const int64_t* w = g.prog;
-    const int64_t* end = g.prog + g.prog_len;
+    // one lane per (row, gadget): blockIdx.y selects the gadget
+    const int64_t* w = g.prog + g.gadget_off[blockIdx.y];
     int64_t e[34], va[17], vb[17], limbs[40];
     uint32_t q[17];
-    while (w < end && w[0] == 1) {
+    {
         const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
         const int64_t coffset = w[5];
         w += 6;
@@ -608,7 +615,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         col_e = col_bit + 1;
         exp_off = 192;
         ProfScope ps(ctx, "trace_fq12_chain");
-        hipLaunchKernelGGL(fq12_chain_kernel, dim3((num_io + 1) / 2), dim3(64), 0, ctx->stream, d_ios, num_io, d_trace, n, c);
+        hipLaunchKernelGGL(fq12_chain_kernel, dim3(num_io), dim3(288), 0, ctx->stream, d_ios, num_io, d_trace, n, c);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     } else {
         const int ext = a->kind == 0 ? 1 : 2, ncl = 16 * ext;
@@ -657,6 +664,36 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         GadgetArgs g;
         g.prog = prog_on_device(ctx, a);
         if (!g.prog) return SIPP_E_HIP;
+        {
+            uint64_t* t = sipp_table_get(ctx, 101, (uint64_t)a->kind, (uint64_t)a->table_bits);
+            if (!t) {
+                // gadgets come first in the program: record where each one starts
+                std::vector<uint32_t> off;
+                const int64_t* w = a->prog;
+                const int64_t* end = a->prog + a->prog_len;
+                while (w < end && w[0] == 1) {
+                    off.push_back((uint32_t)(w - a->prog));
+                    w += 6;
+                    w += 2 + 5 * w[1];
+                    int64_t np = *w++;
+                    for (int64_t p = 0; p < np; p++) {
+                        w += 1;
+                        w += 2 + 5 * w[1];
+                        w += 2 + 5 * w[1];
+                    }
+                    int64_t nl = *w++;
+                    for (int64_t p = 0; p < nl; p++) {
+                        w += 1;
+                        w += 2 + 5 * w[1];
+                    }
+                }
+                if ((int)off.size() != a->n_gadgets) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "AIR program: gadget count mismatch");
+                std::vector<uint64_t> packed((off.size() + 1) / 2 + 1, 0);
+                memcpy(packed.data(), off.data(), off.size() * 4);
+                SIPP_TRY(sipp_table_put(ctx, 101, (uint64_t)a->kind, (uint64_t)a->table_bits, packed, &t));
+            }
+            g.gadget_off = reinterpret_cast<const uint32_t*>(t);
+        }
         g.prog_len = a->prog_len;
         g.cpl = cpl;
         for (int i = 0; i < 16; i++) g.p_limbs[i] = SIPP_BN_P_LIMBS[i];
@@ -664,7 +701,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         for (int i = 0; i < 5; i++) pinv = (pinv * (2 - SIPP_BN_P_LIMBS[0] * pinv)) & 0xffff;
         g.pinv16 = pinv;
         ProfScope ps(ctx, "trace_gadgets");
-        hipLaunchKernelGGL(gadget_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);
+        hipLaunchKernelGGL(gadget_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)a->n_gadgets), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
     {
