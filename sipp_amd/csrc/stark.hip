@@ -10,6 +10,7 @@
 // The Fiat-Shamir challenger runs on the host (a few hundred Poseidon permutations per proof); every
 // array of size O(N) stays in HBM.  One HIP stream per ctx; three ctxs give the three-stream overlap.
 #include <algorithm>
+#include <chrono>
 
 #include "prover.hpp"
 
@@ -159,6 +160,16 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     if (n < ((size_t)1 << a->table_bits)) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "trace shorter than the range table");
     if (R > 8) return SIPP_E_UNSUPPORTED;
 
+    // optional host-side phase timing (SIPP_HOST_TIMING=1): wall clock at each Fiat-Shamir synchronisation point
+    static const bool host_timing = getenv("SIPP_HOST_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!host_timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sipp kind %d] %-18s %8.3f ms\n", kind, what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     ArenaMark mark = arena_mark(ctx);
     struct Release {
         sipp_ctx* c;
@@ -207,6 +218,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     // the claimed outputs must equal the device-computed ones: compare the last row of every IO block
     // (bound to the public inputs by the AIR anyway; checked here so a wrong record fails fast)
 
+    tick("trace fill");
     host::Challenger ch;
     uint64_t cap_host[4 << 8];
 
@@ -214,6 +226,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     SIPP_TRY(commit_values(ctx, d_trace, (size_t)W, log_n, T.coeffs, T.lde, T.tree, cap_host));
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
+    tick("trace commit");
 
     // ---- 2. permutation challenges, Z columns ----
     uint64_t beta[2], gamma[2];
@@ -233,6 +246,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
 
+    tick("Z + commit");
     // ---- 3. alphas ----
     uint64_t alpha[2];
     alpha[0] = ch.get();
@@ -280,6 +294,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
 
+    tick("quotient + commit");
     // ---- 5. zeta, openings ----
     const gl::E2 zeta = ch.get_ext();
     if (gl::eq(gl::pow(zeta, (uint64_t)n), gl::e2(1))) return sipp_fail(ctx, SIPP_E_SUBGROUP, "zeta in the trace subgroup");
@@ -313,6 +328,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         for (int c = 0; c < P; c++) ch.observe_many(&hop[(size_t)(W + c) * 4 + 2], 2);
     }
 
+    tick("openings+observe");
     // ---- 6. FRI ----
     const gl::E2 fa = ch.get_ext();
     uint64_t* d_final = arena_alloc_t<uint64_t>(ctx, 2 * n);
@@ -369,6 +385,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
             push(e, 2);
         }
     }
+    tick("fri commit phase");
     // proof of work: smallest valid nonce (deterministic; upstream's rayon find_any may return another one)
     uint64_t pow_witness = 0;
     SIPP_TRY(sipp_k_pow_search(ctx, ch.state, ch.in_buf, ch.n_in, cfg.pow_bits, &pow_witness));
@@ -376,6 +393,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     (void)ch.get();
     push(&pow_witness, 1);
 
+    tick("pow");
     // ---- queries ----
     std::vector<uint32_t> qidx(nq);
     for (uint32_t i = 0; i < nq; i++) qidx[i] = (uint32_t)(ch.get() % m);
@@ -428,6 +446,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         }
     }
     for (size_t k = 0; k < pis.size(); k++) pf[pos++] = pis[k];
+    tick("queries+assemble");
     if (pos != total_words) return sipp_fail(ctx, SIPP_E_BUFSZ, "internal: proof length mismatch");
     *proof_len = pos;
     return SIPP_OK;
