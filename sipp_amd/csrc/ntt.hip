@@ -185,6 +185,30 @@ __global__ void bitrev_cols_kernel(const uint64_t* in, size_t in_stride, uint64_
     }
 }
 
+// tiled bit-reversal: index = (a | b | c) with a, c of TB bits each; bitrev = (rev c | rev b | rev a).
+// One block moves the 2^TB x 2^TB tile of a fixed (column, b) through LDS so that both the global reads
+// (runs over c) and the global writes (runs over rev a) are contiguous 2^TB * 8 B segments.
+constexpr int TB = 5;
+__global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* __restrict__ in, size_t in_stride,
+                                                          uint64_t* __restrict__ out, size_t out_stride, uint32_t log_n) {
+    __shared__ uint64_t tile[1 << TB][(1 << TB) + 1];
+    const uint32_t lb = log_n - 2 * TB;
+    const uint32_t b = blockIdx.x, col = blockIdx.y;
+    const uint32_t rb = gl::bitrev(b, lb);
+    const uint64_t* src = in + (size_t)col * in_stride;
+    uint64_t* dst = out + (size_t)col * out_stride;
+    // out[j] = in[bitrev(j)]:  j = (c' | b' | a')  reads  i = (rev a' | rev b' | rev c')
+    for (uint32_t e = threadIdx.x; e < (1u << (2 * TB)); e += 256) {
+        const uint32_t a = e >> TB, c = e & ((1u << TB) - 1);
+        tile[a][c] = src[((size_t)a << (lb + TB)) | ((size_t)b << TB) | c];
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < (1u << (2 * TB)); e += 256) {
+        const uint32_t cp = e >> TB, ap = e & ((1u << TB) - 1);
+        dst[((size_t)cp << (lb + TB)) | ((size_t)rb << TB) | ap] = tile[gl::bitrev(ap, TB)][gl::bitrev(cp, TB)];
+    }
+}
+
 // ---- host side: tables + pass planning -----------------------------------------------------
 
 int ntt_ltile() {
@@ -370,6 +394,12 @@ int sipp_bitrev_cols(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint
     unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (!grid) return SIPP_OK;
     ProfScope ps(ctx, "bitrev_cols");
+    if (log_n >= 2 * TB && ncols <= 65535) {
+        hipLaunchKernelGGL(bitrev_tiled_kernel, dim3(1u << (log_n - 2 * TB), (unsigned)ncols), dim3(256), 0, ctx->stream, d_in,
+                           in_stride, d_out, out_stride, log_n);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        return SIPP_OK;
+    }
     hipLaunchKernelGGL(bitrev_cols_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, in_stride, d_out, out_stride,
                        log_n, ncols);
     SIPP_CHECK_HIP(ctx, hipGetLastError());

@@ -143,6 +143,11 @@ struct QCtx {
     size_t j, jn, m;
     uint64_t per[SIPP_N_PERIODIC];
     uint64_t acc0, acc1;
+    // select instead of a dynamically indexed private array (which would live in scratch memory)
+    __device__ __forceinline__ uint64_t periodic(int k) const {
+        static_assert(SIPP_N_PERIODIC == 4, "periodic(): update the select chain");
+        return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
+    }
     __device__ __forceinline__ uint64_t local(int c) const { return a->lde[(size_t)c * m + j]; }
     __device__ __forceinline__ uint64_t next(int c) const { return a->lde[(size_t)c * m + jn]; }
     __device__ __forceinline__ void emit(uint64_t v) {
@@ -162,7 +167,7 @@ __device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t (&
         const int cbase = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
         uint64_t f = gl::from_i64(tm[0]);
         if (flag >= 0) {
-            uint64_t pv = c.per[flag];
+            uint64_t pv = c.periodic(flag);
             if (neg) pv = gl::sub(1, pv);
             f = gl::mul(f, pv);
         }
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
                     const int kind = (int)w[0], idx = (int)w[1];
                     w += 2;
                     uint64_t v = kind == 0 ? c.local(idx) : kind == 1 ? c.next(idx)
-                                 : kind == 2 ? a.aux[(size_t)idx * m + j] : c.per[idx];
+                                 : kind == 2 ? a.aux[(size_t)idx * m + j] : c.periodic(idx);
                     t = gl::mul(t, v);
                 }
                 sum = gl::add(sum, t);

@@ -13,6 +13,8 @@
 //   gadget_rows      one lane per row: quotient / sign / carry witnesses of every modular gadget,
 //                    interpreted from the AIR program (integer arithmetic)
 //   table / lookups  range table column; per checked column histogram -> scan -> permuted columns
+#include <algorithm>
+
 #include "air_tables.h"
 #include "ctx.hpp"
 #include "fq.cuh"
@@ -501,6 +503,19 @@ __global__ void hist_kernel(const uint64_t* __restrict__ cols, size_t n, uint32_
     }
 }
 
+// u8 table: LDS-privatised histogram, one block per (column, chunk of rows)
+__global__ void __launch_bounds__(256) hist_u8_kernel(const uint64_t* __restrict__ cols, size_t n, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t c = blockIdx.y;
+    const uint64_t* col = cols + c * n;
+    const size_t chunk = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[col[i] & 0xff], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[(c << 8) + threadIdx.x], h[threadIdx.x]);
+}
+
 // one block per column: start[v] = #values < v ; dist[v] = #distinct values <= v ; zlist = values with hist == 0 ascending
 __global__ void __launch_bounds__(256) lookup_scan_kernel(const uint32_t* __restrict__ hist, uint32_t tbits,
                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ dist,
@@ -718,7 +733,12 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         const uint64_t* cols = d_trace + (size_t)a->checked_base * n;
         {
             ProfScope ps(ctx, "lookup_hist");
-            hipLaunchKernelGGL(hist_kernel, dim3(4096), dim3(256), 0, ctx->stream, cols, n, (uint32_t)nc, tb, hist);
+            if (tb == 8) {
+                const unsigned chunks = (unsigned)std::max<size_t>(1, std::min<size_t>(16, n / 2048));
+                hipLaunchKernelGGL(hist_u8_kernel, dim3(chunks, (unsigned)nc), dim3(256), 0, ctx->stream, cols, n, hist);
+            } else {
+                hipLaunchKernelGGL(hist_kernel, dim3(4096), dim3(256), 0, ctx->stream, cols, n, (uint32_t)nc, tb, hist);
+            }
         }
         {
             ProfScope ps(ctx, "lookup_scan");
