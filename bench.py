@@ -80,7 +80,15 @@ def main():
     # independent, so their thin kernels and Fiat-Shamir round trips overlap
     from concurrent.futures import ThreadPoolExecutor
     ws = [(8 << 30), (16 << 30), (12 << 30)] if args.n <= 256 else [(60 << 30), (120 << 30), (20 << 30)]
-    ctxs = [sipp_amd.Ctx(device=local_rank, workspace_bytes=ws[k]) for k in range(3)]
+    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,,high").split(",")   # G1, G2, Fq12
+    ctxs = []
+    for k in range(3):
+        if prios[k]:
+            os.environ["SIPP_STREAM_PRIORITY"] = prios[k]
+        else:
+            os.environ.pop("SIPP_STREAM_PRIORITY", None)
+        ctxs.append(sipp_amd.Ctx(device=local_rank, workspace_bytes=ws[k]))
+    os.environ.pop("SIPP_STREAM_PRIORITY", None)
     ctx = ctxs[0]
     shapes = [ctx.shape(k, ios[k].shape[0]) for k in range(3)]
     pool = ThreadPoolExecutor(max_workers=3)

@@ -41,7 +41,16 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
         return rc;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(SIPP_E_HIP);
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(SIPP_E_HIP);
+    {
+        // SIPP_STREAM_PRIORITY (read at ctx creation): "high" / "low" / unset.  With one ctx per STARK the thin,
+        // latency-bound proof should be scheduled ahead of the fat ones.
+        int lo = 0, hi = 0, prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least, hi = greatest priority (numerically lower)
+        const char* e = getenv("SIPP_STREAM_PRIORITY");
+        if (e && !strcmp(e, "high")) prio = hi;
+        if (e && !strcmp(e, "low")) prio = lo;
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess) return bail(SIPP_E_HIP);
+    }
     if (workspace_bytes == 0) workspace_bytes = (size_t)24 << 30;
     ctx->arena_size = workspace_bytes;
     if (hipMalloc((void**)&ctx->arena, workspace_bytes) != hipSuccess) return bail(SIPP_E_NOMEM);
