@@ -203,7 +203,8 @@ static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t r
         if (w[0] != 1) break; /* gadgets come first */
         int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
         int64_t coffset = w[5];
-        w += 6;
+        int grp = (int)w[6];
+        w += 7;
         /* q vector descriptor: remember where its cells live */
         int q_base = (int)w[3]; /* first term's base */
         w += 2 + 5 * (size_t)w[1];
@@ -259,18 +260,26 @@ static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t r
             if (cpl == 1) put(tr, n, q_base + i, row, q[i]);
             else { put(tr, n, q_base + 2 * i, row, q[i] & 0xff); put(tr, n, q_base + 2 * i + 1, row, q[i] >> 8); }
         }
-        /* carries: e_k - sgn (q*p)_k - c_{k-1} + 2^16 c_k = 0 */
-        int64_t sgn = sign ? -1 : 1, cprev = 0;
-        for (int k = 0; k < 32; k++) {
-            int64_t qp = 0;
-            for (int i = 0; i < 17; i++) { int j = k - i; if (j >= 0 && j < 16) qp += (int64_t)q[i] * ORC_BN_P_LIMBS[j]; }
-            int64_t dk = (k < 31 ? e[k] : 0) - sgn * qp - cprev; /* = -2^16 c_k */
-            if (dk & 0xffff) return -4;
-            int64_t ck = -(dk >> 16);
-            if (k == 31) { if (ck != 0) return -5; break; }
-            int64_t v = ck + coffset;
+        /* carries: sum_t 2^(16t) d_{g m + t} - c_{m-1} + 2^(16 g) c_m = 0,  d_k = e_k - sgn (q*p)_k */
+        int64_t sgn = sign ? -1 : 1;
+        __int128 cprev = 0;
+        int nm_ = 32 / grp;
+        for (int m = 0; m < nm_; m++) {
+            __int128 dm = 0;
+            for (int t = grp - 1; t >= 0; t--) {
+                int k = grp * m + t;
+                int64_t qp = 0;
+                for (int i = 0; i < 17; i++) { int j = k - i; if (j >= 0 && j < 16) qp += (int64_t)q[i] * ORC_BN_P_LIMBS[j]; }
+                dm = dm * 65536 + ((k < 31 ? e[k] : 0) - sgn * qp);
+            }
+            dm -= cprev; /* = -2^(16 g) c_m */
+            __int128 mask = (((__int128)1) << (16 * grp)) - 1;
+            if (dm & mask) return -4;
+            __int128 ck = -(dm >> (16 * grp));
+            if (m == nm_ - 1) { if (ck != 0) return -5; break; }
+            __int128 v = ck + coffset;
             if (v < 0 || (v >> (ncl * lb)) != 0) return -6;
-            for (int l = 0; l < ncl; l++) put(tr, n, cbase + k * ncl + l, row, (uint64_t)((v >> (lb * l)) & (((int64_t)1 << lb) - 1)));
+            for (int l = 0; l < ncl; l++) put(tr, n, cbase + m * ncl + l, row, (uint64_t)((v >> (lb * l)) & (((int64_t)1 << lb) - 1)));
             cprev = ck;
         }
     }

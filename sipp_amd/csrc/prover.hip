@@ -198,7 +198,8 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
         if (w[0] == 1) {
             const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
             const int64_t coffset = w[5];
-            w += 6;
+            const int grp = (int)w[6];
+            w += 7;
             const int64_t* qdesc = w;
             w += 2 + 5 * (int)w[1];
             uint64_t e[32];
@@ -231,6 +232,8 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
             const uint64_t sgn = gl::sub(1, gl::add(s, s));
             uint64_t cprev = 0;
             const uint64_t coff = gl::from_i64(coffset);
+            // d_k = e_k - sgn (q * p)_k, all 32 of them in registers; then 32 / grp equations in base 2^(16 grp)
+            uint64_t d[32];
 #pragma unroll
             for (int k = 0; k < 32; k++) {
                 uint64_t qp = 0;
@@ -239,17 +242,26 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
                     const int jj = k - ii;
                     if (jj >= 0 && jj < 16) qp = gl::mad(q[ii], (uint64_t)a.p_limbs[jj], qp);
                 }
-                uint64_t ck = 0;
-                if (k < 31) {
-                    for (int l = 0; l < ncl; l++)
-                        ck = gl::mad(c.local(cbase + k * ncl + l), (uint64_t)1 << (lb * l), ck);
-                    ck = gl::sub(ck, coff);
+                d[k] = gl::sub(e[k], gl::mul(sgn, qp));
+            }
+            const uint64_t wgt = (uint64_t)1 << (16 * grp);
+#pragma unroll
+            for (int m = 0; m < 32; m++) {
+                if (m < 32 / grp) {
+                    uint64_t v;
+                    if (grp == 2) v = gl::mad(d[(2 * m + 1) & 31], 65536, d[(2 * m) & 31]);
+                    else v = d[m];
+                    uint64_t ck = 0;
+                    if (m < 32 / grp - 1) {
+                        for (int l = 0; l < ncl; l++)
+                            ck = gl::mad(c.local(cbase + m * ncl + l), (uint64_t)1 << (lb * l), ck);
+                        ck = gl::sub(ck, coff);
+                    }
+                    v = gl::sub(v, cprev);
+                    v = gl::mad(ck, wgt, v);
+                    c.emit(v);
+                    cprev = ck;
                 }
-                uint64_t v = gl::sub(e[k], gl::mul(sgn, qp));
-                v = gl::sub(v, cprev);
-                v = gl::mad(ck, 65536, v);
-                c.emit(v);
-                cprev = ck;
             }
             c.emit(gl::mul(s, gl::sub(s, 1)));
         } else {

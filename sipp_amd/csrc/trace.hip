@@ -406,7 +406,8 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
     {
         const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
         const int64_t coffset = w[5];
-        w += 6;
+        const int grp = (int)w[6];
+        w += 7;
         const int q_base = (int)w[3];
         w += 2 + 5 * (int)w[1];
         for (int i = 0; i < 34; i++) e[i] = 0;
@@ -467,25 +468,34 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
                 tr[(size_t)(q_base + 2 * i + 1) * n + row] = q[i] >> 8;
             }
         }
+        // carries in base 2^(16 grp): sum_t 2^(16t) d_{grp m + t} - c_{m-1} + 2^(16 grp) c_m = 0
         const int64_t sgn = sign ? -1 : 1;
-        int64_t cprev = 0;
-        for (int k = 0; k < 32; k++) {
-            int64_t qp = 0;
-            for (int i = 0; i < 17; i++) {
-                int j = k - i;
-                if (j >= 0 && j < 16) qp += (int64_t)q[i] * g.p_limbs[j];
+        __int128 cprev = 0;
+        const int nmm = 32 / grp;
+        for (int m = 0; m < nmm; m++) {
+            __int128 dm = 0;
+            for (int t = grp - 1; t >= 0; t--) {
+                const int k = grp * m + t;
+                int64_t qp = 0;
+                for (int i = 0; i < 17; i++) {
+                    int j = k - i;
+                    if (j >= 0 && j < 16) qp += (int64_t)q[i] * g.p_limbs[j];
+                }
+                dm = dm * 65536 + ((k < 31 ? e[k] : 0) - sgn * qp);
             }
-            const int64_t dk = (k < 31 ? e[k] : 0) - sgn * qp - cprev;
-            bad |= (dk & 0xffff) != 0;
-            const int64_t ck = -(dk >> 16);
-            if (k == 31) {
+            dm -= cprev;
+            const __int128 mask = (((__int128)1) << (16 * grp)) - 1;
+            bad |= (dm & mask) != 0;
+            const __int128 ck = -(dm >> (16 * grp));
+            if (m == nmm - 1) {
                 bad |= ck != 0;
                 break;
             }
-            const int64_t v = ck + coffset;
+            const __int128 v = ck + coffset;
             bad |= v < 0 || (v >> (ncl * lb)) != 0;
+            const uint64_t vv = (uint64_t)v;
             for (int l = 0; l < ncl; l++)
-                tr[(size_t)(cbase + k * ncl + l) * n + row] = (uint64_t)((v >> (lb * l)) & (((int64_t)1 << lb) - 1));
+                tr[(size_t)(cbase + m * ncl + l) * n + row] = (vv >> (lb * l)) & (((uint64_t)1 << lb) - 1);
             cprev = ck;
         }
         if (bad) atomicExch(err, SIPP_E_WITNESS);
@@ -688,7 +698,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                 const int64_t* end = a->prog + a->prog_len;
                 while (w < end && w[0] == 1) {
                     off.push_back((uint32_t)(w - a->prog));
-                    w += 6;
+                    w += 7;
                     w += 2 + 5 * w[1];
                     int64_t np = *w++;
                     for (int64_t p = 0; p < np; p++) {

@@ -34,6 +34,8 @@ def test_trace_matches_oracle(ctx, ios4, kind):
     assert bad.size == 0, "first mismatches (col,row): %s" % bad[:8].tolist()
 
 
-def test_wrong_output_is_not_checked_by_trace_build_but_shape_is(ctx, ios4):
-    log_n, W, P, Q = ctx.shape(0, 3)
-    assert (log_n, Q) == (11, 4) and P == 2 * 570
+def test_shape_matches_oracle_air(ctx, ios4):
+    for kind in (0, 1, 2):
+        ref = _oracle.Trace(kind, ios4[kind])
+        log_n, W, P, Q = ctx.shape(kind, ios4[kind].shape[0])
+        assert (log_n, W, P, Q) == (ref.log_n, ref.width, 2 * ref.air.n_checked, 4)

@@ -24,9 +24,11 @@ Column model
 Program encoding (int64 words), see `Prog` below:
   VEC   := n_limbs, n_terms, (coef, base, stride, flag_per, flag_neg)*     limb_i = sum coef*F*cell[base+i*stride]
            F = 1 | per[flag_per] | 1 - per[flag_per]        (flag_per = -1: none)
-  GADGET:= OP_GADGET, sign_col, carry_base, carry_limbs, carry_bits, carry_offset, VEC(q),
+  GADGET:= OP_GADGET, sign_col, carry_base, carry_limbs, carry_bits, carry_offset, group, VEC(q),
            n_prod, (coef, VEC a, VEC b)*, n_lin, (coef, VEC a)*
-           constraints k = 0..n_e:  e_k - (1-2s)(q*p)_k - c_{k-1} + 2^16 c_k = 0,  plus  s(s-1) = 0
+           with d_k = e_k - (1-2s)(q*p)_k (k = 0..31) and group g in {1, 2}: the 32/g constraints
+               sum_{t<g} 2^(16 t) d_{g m + t} - c_{m-1} + 2^(16 g) c_m = 0      (c_{-1} = c_{32/g - 1} = 0)
+           i.e. the limb identity is checked in base 2^(16 g); g = 2 halves the carry cells.  Plus s(s-1) = 0.
   POLY  := OP_POLY, n_mono, (coef, n_factors, (kind, index)*)*             kind: 0 local 1 next 2 aux 3 periodic
 """
 import os
@@ -116,7 +118,7 @@ class Air:
     # ---- gadget: E(2^16) == 0 mod p ----
     def gadget(self, gname, prods, lins, bound_bits):
         """prods: [(coef, vecA, vecB)], lins: [(coef, vecA)].  bound_bits: log2 bound of |e_k|."""
-        # carry magnitude: |c_k| <= (|c_{k-1}| + |d_k|) / 2^16 with |d_k| < 2^bound_bits + 2^37
+        # carry magnitude (any group g): |c_m| <= (|c_{m-1}| + 2^(16(g-1)) |d|) / 2^(16 g) ~ |d| / 2^16
         cbits_needed = max(bound_bits, 38) - 16 + 2      # signed, with slack
         total_bits = cbits_needed + 1
         if self.mode == "u16":
@@ -124,8 +126,12 @@ class Air:
         else:
             ncl, lb = (total_bits + 7) // 8, 8
         coffset = 1 << (ncl * lb - 1)
-        n_e = 2 * NL - 1                                  # e_0 .. e_30, plus k = 31 from q*p
-        self.gadgets.append(dict(name=gname, prods=prods, lins=lins, ncl=ncl, lb=lb, coffset=coffset, n_e=n_e))
+        group = self.group
+        # soundness: |D_m - c_{m-1} + 2^(16g) c_m| must stay below the Goldilocks prime for EVERY range-checked
+        # assignment, so that the field identity forces the integer identity (0 is the only multiple of p there)
+        worst = (1 << (ncl * lb - 1 + 16 * group)) + (1 << (bound_bits + 16 * (group - 1) + 1)) + (1 << (ncl * lb))
+        assert worst < (1 << 64) - (1 << 32), (bound_bits, group, ncl, lb)
+        self.gadgets.append(dict(name=gname, prods=prods, lins=lins, ncl=ncl, lb=lb, coffset=coffset, group=group))
 
     def emit_gadgets(self):
         for g in self.gadgets:
@@ -133,7 +139,7 @@ class Air:
             sign = self.col(nm + "_s")
             cbase = self.col(nm + "_c")
             q = self.vec_chk(nm + "_q", NQ)
-            w = [OP_GADGET, sign, cbase, g["ncl"], g["lb"], g["coffset"]] + self._emit_vec(q)
+            w = [OP_GADGET, sign, cbase, g["ncl"], g["lb"], g["coffset"], g["group"]] + self._emit_vec(q)
             w += [len(g["prods"])]
             for coef, a, b in g["prods"]:
                 w += [coef] + self._emit_vec(a) + self._emit_vec(b)
@@ -142,7 +148,7 @@ class Air:
                 w += [coef] + self._emit_vec(a)
             self.prog += w
             self.n_ops += 1
-            self.n_constraints += 2 * NL + 1              # 32 coefficient equations + sign booleanity
+            self.n_constraints += 2 * NL // g["group"] + 1  # 32 / group coefficient equations + sign booleanity
 
     def declare_gadget_cols(self, gname, bound_bits):
         cbits_needed = max(bound_bits, 38) - 16 + 2
@@ -153,7 +159,7 @@ class Air:
             ncl = (total_bits + 7) // 8
         self.alloc(gname + "_s", 1)
         self.alloc_checked(gname + "_q", NQ * self.cpl)
-        self.alloc_checked(gname + "_c", (2 * NL - 1) * ncl)
+        self.alloc_checked(gname + "_c", (2 * NL // self.group - 1) * ncl)
 
     # ---- generic polynomial constraints ----
     def poly(self, monos):
@@ -265,6 +271,7 @@ def build_curve(name, mode, ext):
     """
     a = Air(name, mode)
     a.gadgets = []
+    a.group = 2                        # limb identity checked in base 2^32: 15 carries per gadget instead of 31
     nc = NL * ext                      # limbs per coordinate
     a.alloc("Rx", nc); a.alloc("Ry", nc); a.alloc("Px", nc); a.alloc("Py", nc)
     a.alloc("bit", 1); a.alloc("e", 8)
@@ -336,6 +343,7 @@ def build_fq12(mode):
     Row: one Fq12 product C = A * B;  mul rows (even): A = acc, B = pw;  square rows (odd): A = B = pw."""
     a = Air("fq12", mode)
     a.gadgets = []
+    a.group = 1                        # |e_k| ~ 2^50: pairing limbs would overflow the 2^63 integrality margin
     a.alloc("acc", 12 * NL); a.alloc("pw", 12 * NL); a.alloc("bit", 1); a.alloc("e", 8)
     a.alloc_checked("C", 12 * NL * a.cpl)
     bound = 50
