@@ -153,6 +153,12 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
     return 0;
 }
 
+static fq fq12_tower(const fq12 *x, int t) {
+    int i = t >> 1;
+    if (t & 1) return x->c[i + 6];
+    return fq_add(x->c[i], fq_mul(fq_from_u64(9), x->c[i + 6]));
+}
+
 static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     layout_t L = layout_of(a);
     int cpl = a->cells_per_limb;
@@ -164,9 +170,13 @@ static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, c
     for (int r = 0; r < 512; r++) {
         size_t row = row0 + r;
         int is_add = (r & 1) == 0;
-        for (int k = 0; k < 12; k++) { put_fq_u16(tr, n, L.acc + 16 * k, row, acc.c[k]); put_fq_u16(tr, n, L.pw + 16 * k, row, pw.c[k]); }
         fq12 c = is_add ? fq12_mul(&acc, &pw) : fq12_mul(&pw, &pw);
-        for (int k = 0; k < 12; k++) put_fq_checked(tr, n, L.C + 16 * cpl * k, row, c.c[k], cpl);
+        /* cells hold the tower basis: component t = 2i: c_i + 9 c_{i+6}, t = 2i+1: c_{i+6} */
+        for (int t = 0; t < 12; t++) {
+            put_fq_u16(tr, n, L.acc + 16 * t, row, fq12_tower(&acc, t));
+            put_fq_u16(tr, n, L.pw + 16 * t, row, fq12_tower(&pw, t));
+            put_fq_checked(tr, n, L.C + 16 * cpl * t, row, fq12_tower(&c, t), cpl);
+        }
         if (is_add) { if (bits[r >> 1]) acc = c; }
         else if (r != 511) pw = c;
     }
@@ -386,8 +396,17 @@ gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x) {
 
 /* value of aux column `ai` for IO `io`: the lo/hi half or the whole of a public u32 word */
 uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int ai) {
-    int word = a->aux[3 * ai], part = a->aux[3 * ai + 1];
-    uint32_t w = pis[io * a->pi_per_io + word];
+    int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], sub = a->aux[4 * ai + 3];
+    const uint32_t *rec = pis + io * a->pi_per_io;
+    if (part == 3) { /* tower-basis limb of the MyFq12 value at words [word, word + 96) */
+        fq12 x;
+        fq_init();
+        for (int k = 0; k < 12; k++) x.c[k] = fq_from_u32(rec + word + 8 * k);
+        uint16_t l[16];
+        fq_to_limbs16(fq12_tower(&x, sub / 16), l);
+        return l[sub % 16];
+    }
+    uint32_t w = rec[word];
     return part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
 }
 
@@ -397,7 +416,7 @@ void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsi
     unsigned log_io = log_n - 9;
     for (size_t io = 0; io < num_io; io++) coeffs[io] = orc_aux_value(a, pis, io, ai);
     orc_ifft(coeffs, log_io);
-    int shift = a->aux[3 * ai + 2];
+    int shift = a->aux[4 * ai + 2];
     if (shift) {
         uint64_t s = gl_inv(gl_pow(gl_root_of_unity(log_n), (uint64_t)shift)), f = 1;
         for (size_t j = 0; j < num_io; j++) { coeffs[j] = gl_mul(coeffs[j], f); f = gl_mul(f, s); }

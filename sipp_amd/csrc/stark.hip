@@ -137,6 +137,53 @@ static void host_ifft(std::vector<uint64_t>& a, uint32_t log_n) {
     for (auto& v : a) v = gl::mul(v, ninv);
 }
 
+// ---- BN254 Fq on the host, only for the public basis change of Fq12 public inputs (tools/air_gen.py build_fq12):
+// tower component t of the MyFq12 value c[0..11] (8 x u32 LE each): t = 2i -> (c_i + 9 c_{i+6}) mod p, t = 2i+1 -> c_{i+6}
+static void fq12_tower_limbs(const uint32_t* c96, int t, uint16_t limbs[16]) {
+    static const uint64_t P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    typedef unsigned __int128 u128;
+    const int i = t >> 1;
+    uint64_t r[5] = {0, 0, 0, 0, 0};
+    auto load = [&](int k, uint64_t out[4]) {
+        for (int q = 0; q < 4; q++) out[q] = (uint64_t)c96[8 * k + 2 * q] | ((uint64_t)c96[8 * k + 2 * q + 1] << 32);
+    };
+    uint64_t hi[4];
+    load(i + 6, hi);
+    if (t & 1) {
+        memcpy(r, hi, 32);
+    } else {
+        uint64_t lo[4];
+        load(i, lo);
+        u128 carry = 0;
+        for (int q = 0; q < 4; q++) {
+            carry += (u128)hi[q] * 9 + lo[q];
+            r[q] = (uint64_t)carry;
+            carry >>= 64;
+        }
+        r[4] = (uint64_t)carry;
+        // reduce: r < 10 p, subtract p while r >= p
+        for (;;) {
+            bool ge = r[4] != 0;
+            if (!ge) {
+                ge = true;
+                for (int q = 3; q >= 0; q--) {
+                    if (r[q] > P[q]) break;
+                    if (r[q] < P[q]) { ge = false; break; }
+                }
+            }
+            if (!ge) break;
+            u128 borrow = 0;
+            for (int q = 0; q < 4; q++) {
+                u128 d = (u128)r[q] - P[q] - borrow;
+                r[q] = (uint64_t)d;
+                borrow = (d >> 64) & 1;
+            }
+            r[4] -= (uint64_t)borrow;
+        }
+    }
+    for (int l = 0; l < 16; l++) limbs[l] = (uint16_t)(r[l / 4] >> (16 * (l % 4)));
+}
+
 struct Oracle3 {
     uint64_t *coeffs, *lde, *tree;
     int ncols;
@@ -262,10 +309,17 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         std::vector<uint64_t> auxc((size_t)n_aux * nio), col(nio);
         const uint64_t g = gl::root_of_unity(log_n);
         for (int ai = 0; ai < n_aux; ai++) {
-            const int word = a->aux[3 * ai], part = a->aux[3 * ai + 1], shift = a->aux[3 * ai + 2];
+            const int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], shift = a->aux[4 * ai + 2], sub = a->aux[4 * ai + 3];
             for (size_t io = 0; io < nio; io++) {
-                uint32_t w = pis[io * a->pi_per_io + word];
-                col[io] = part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
+                const uint32_t* rec = &pis[io * a->pi_per_io];
+                if (part == 3) {
+                    uint16_t limbs[16];
+                    fq12_tower_limbs(rec + word, sub / 16, limbs);
+                    col[io] = limbs[sub % 16];
+                } else {
+                    uint32_t w = rec[word];
+                    col[io] = part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
+                }
             }
             host_ifft(col, log_io);
             if (shift) {

@@ -298,6 +298,7 @@ __global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restr
     }
     __syncthreads();
     const Fq m18 = fq::small_m(18), m82 = fq::small_m(82), m242 = fq::small_m(242), m1476 = fq::small_m(1476);
+    const Fq m9 = fq::small_m(9);
     const uint32_t* ex = rec + 192;
     const int which = t >= 144, pi = (t % 144) / 12, pj = t % 12;
     for (int b = 0; b < 256; b++) {
@@ -325,18 +326,18 @@ __global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restr
         }
         __syncthreads();
         if (t < 72) {
-            // task = (row 0/1, array 0 acc / 1 pw / 2 C, coefficient k)
-            const int rowsel = t / 36, arr = (t % 36) / 12, k = t % 12;
+            // task = (row 0/1, array 0 acc / 1 pw / 2 C, tower component tc); the cells hold the tower basis
+            // Fq2[w]/(w^6 - (9 + u)): tc = 2i -> c_i + 9 c_{i+6}, tc = 2i + 1 -> c_{i+6}   (tools/air_gen.py build_fq12)
+            const int rowsel = t / 36, arr = (t % 36) / 12, tc = t % 12;
             const size_t row = (size_t)io * 512 + 2 * b + rowsel;
-            if (arr == 0) {
-                Fq v = s_acc[k];
-                if (rowsel && bit) v = s_res[0][k];  // the square row already sees the updated accumulator
-                store_limbs16(tr, n, c.acc + 16 * k, row, fq::from_mont(v));
-            } else if (arr == 1) {
-                store_limbs16(tr, n, c.pw + 16 * k, row, fq::from_mont(s_pw[k]));
-            } else {
-                store_checked(tr, n, c.C + 16 * c.cpl * k, row, fq::from_mont(s_res[rowsel][k]), c.cpl);
-            }
+            const Fq* src = arr == 0 ? ((rowsel && bit) ? s_res[0] : s_acc) : arr == 1 ? s_pw : s_res[rowsel];
+            const int i = tc >> 1;
+            Fq v = src[i + 6];
+            if (!(tc & 1)) v = fq::add(src[i], fq::mul(m9, v));
+            v = fq::from_mont(v);
+            if (arr == 0) store_limbs16(tr, n, c.acc + 16 * tc, row, v);
+            else if (arr == 1) store_limbs16(tr, n, c.pw + 16 * tc, row, v);
+            else store_checked(tr, n, c.C + 16 * c.cpl * tc, row, v, c.cpl);
         }
         __syncthreads();
         if (t < 12) {

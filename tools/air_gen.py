@@ -238,9 +238,13 @@ def state_transition(a, state, result, upd_on_add, nl):
             a.poly(m)
 
 
-def bind_pi(a, layout):
+def bind_pi(a, layout, tower=False):
     """layout: [(state_name, n_u32_words, row)] in PI order; row 'first' or 'last'.
-    Every 16-bit limb cell of the state is bound to the matching half of the public u32 word."""
+    Every 16-bit limb cell of the state is bound to a value both sides derive from the public u32 words.
+    aux descriptor = (word, part, shift_rows, sub):
+       part 0 / 1: low / high 16 bits of public word `word`;  part 2: the whole u32 word
+       part 3 (tower=True, 96-word Fq12 blocks): 16-bit limb `sub % 16` of tower component t = sub // 16 of the
+               MyFq12 value stored at words [word, word + 96):  t = 2i: (c_i + 9 c_{i+6}) mod p,  t = 2i+1: c_{i+6}"""
     word = 0
     for name, nwords, row in layout:
         per = PER_FIRST if row == "first" else PER_LAST
@@ -249,13 +253,19 @@ def bind_pi(a, layout):
         if name == "e":
             for j in range(nwords):
                 ai = len(a.aux)
-                a.aux.append((word + j, 2, shift))
+                a.aux.append((word + j, 2, shift, 0))
                 a.poly([(1, [PER(per), L(base + j)]), (-1, [PER(per), AUX(ai)])])
+        elif tower:
+            assert nwords == 96
+            for sub in range(12 * NL):
+                ai = len(a.aux)
+                a.aux.append((word, 3, shift, sub))
+                a.poly([(1, [PER(per), L(base + sub)]), (-1, [PER(per), AUX(ai)])])
         else:
             for j in range(nwords):
                 for part in (0, 1):
                     ai = len(a.aux)
-                    a.aux.append((word + j, part, shift))
+                    a.aux.append((word + j, part, shift, 0))
                     a.poly([(1, [PER(per), L(base + 2 * j + part)]), (-1, [PER(per), AUX(ai)])])
         word += nwords
     a.pi_per_io = word
@@ -339,51 +349,59 @@ def build_curve(name, mode, ext):
 
 
 def build_fq12(mode):
-    """out = offset * x^exp in Fq12 = Fq[w]/(w^12 - 18 w^6 + 82) (MyFq12 coefficient order).
-    Row: one Fq12 product C = A * B;  mul rows (even): A = acc, B = pw;  square rows (odd): A = B = pw."""
+    """out = offset * x^exp in Fq12.  The IO records carry MyFq12 coefficients c_0..c_11 over w with
+    w^12 - 18 w^6 + 82 = 0; the TRACE works in the isomorphic tower basis
+        Fq2[w] / (w^6 - xi),  xi = 9 + u,  u^2 = -1:     A_i = a_i + b_i u,  a_i = c_i + 9 c_{i+6},  b_i = c_{i+6}
+    because its reduction constants are 1 and 9 instead of 18 / 82 / 242 / 1476: |e_k| < 2^44, which lets the
+    gadgets pair limbs (group 2) and use 15 four-byte carries instead of 31 five-byte ones (-42 % columns).
+    The basis change of the public inputs is a public computation (done natively by prover and verifier when they
+    derive the public-input polynomials), so no conversion constraints exist.
+    Row: one Fq12 product C = A * B;  mul rows (even): A = acc, B = pw;  square rows (odd): A = B = pw.
+    Cell order of acc / pw / C: tower component t = 2 i + (0 for a_i, 1 for b_i), 16 limbs each."""
     a = Air("fq12", mode)
     a.gadgets = []
-    a.group = 1                        # |e_k| ~ 2^50: pairing limbs would overflow the 2^63 integrality margin
+    a.group = 2
     a.alloc("acc", 12 * NL); a.alloc("pw", 12 * NL); a.alloc("bit", 1); a.alloc("e", 8)
     a.alloc_checked("C", 12 * NL * a.cpl)
-    bound = 50
+    bound = 44
     for k in range(12):
         a.declare_gadget_cols("c%d" % k, bound)
     a.finalize_columns()
 
-    def coef_u(nm, i, **kw):
-        t, n = a.vec_u16(nm, **kw)
-        return [(co, b + NL * i, st, f, ng) for (co, b, st, f, ng) in t], n
+    def coef_u(nm, t, **kw):
+        tm, n = a.vec_u16(nm, **kw)
+        return [(co, b + NL * t, st, f, ng) for (co, b, st, f, ng) in tm], n
 
-    def coef_c(nm, i, **kw):
-        t, n = a.vec_chk(nm, **kw)
-        return [(co, b + NL * a.cpl * i, st, f, ng) for (co, b, st, f, ng) in t], n
+    def coef_c(nm, t, **kw):
+        tm, n = a.vec_chk(nm, **kw)
+        return [(co, b + NL * a.cpl * t, st, f, ng) for (co, b, st, f, ng) in tm], n
 
-    A = lambda i: Air.vsum(coef_u("acc", i, flag=PER_ADD), coef_u("pw", i, flag=PER_ADD, neg=1))
-    B = lambda j: coef_u("pw", j)
-    # w^m for m >= 12 in terms of w^0..w^11:   w^12 = 18 w^6 - 82
-    red = {}
-    for m in range(23):
-        if m < 12:
-            red[m] = {m: 1}
-        elif m < 18:
-            red[m] = {m - 6: 18, m - 12: -82}
-        else:
-            red[m] = {m - 12: 242, m - 18: -1476}
-    for k in range(12):
-        prods = []
-        for i in range(12):
-            for j in range(12):
-                c = red[i + j].get(k, 0)
-                if c:
-                    prods.append((c, A(i), B(j)))
-        a.gadget("c%d" % k, prods, [(-1, coef_c("C", k))], bound)
+    A = lambda i, c: Air.vsum(coef_u("acc", 2 * i + c, flag=PER_ADD), coef_u("pw", 2 * i + c, flag=PER_ADD, neg=1))
+    B = lambda j, c: coef_u("pw", 2 * j + c)
+    for k in range(6):
+        for comp in range(2):
+            prods = []
+            for i in range(6):
+                for j in range(6):
+                    if i + j == k:
+                        # (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u
+                        if comp == 0:
+                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1))]
+                        else:
+                            prods += [(1, A(i, 0), B(j, 1)), (1, A(i, 1), B(j, 0))]
+                    elif i + j == k + 6:
+                        # times xi = 9 + u:  (x + y u)(9 + u) = (9x - y) + (x + 9y) u
+                        if comp == 0:
+                            prods += [(9, A(i, 0), B(j, 0)), (-9, A(i, 1), B(j, 1)), (-1, A(i, 0), B(j, 1)), (-1, A(i, 1), B(j, 0))]
+                        else:
+                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1)), (9, A(i, 0), B(j, 1)), (9, A(i, 1), B(j, 0))]
+            a.gadget("c%d" % (2 * k + comp), prods, [(-1, coef_c("C", 2 * k + comp))], bound)
     a.emit_gadgets()
     exponent_logic(a)
     state_transition(a, "acc", "C", True, 12 * NL)
     state_transition(a, "pw", "C", False, 12 * NL)
     # IO record order (x, offset, exp_val, output): reference src/verifier_circuit.rs:111-123
-    bind_pi(a, [("pw", 96, "first"), ("acc", 96, "first"), ("e", 8, "first"), ("acc", 96, "last")])
+    bind_pi(a, [("pw", 96, "first"), ("acc", 96, "first"), ("e", 8, "first"), ("acc", 96, "last")], tower=True)
     a.primary = dict(kind="fq12")
     return a
 
@@ -397,7 +415,7 @@ def emit(a, f, prefix):
     f.write("};\n")
     f.write("static const int32_t %s_AUX[] = {\n" % tag)
     for i in range(0, len(a.aux), 8):
-        f.write("    " + ", ".join("%d, %d, %d" % t for t in a.aux[i:i + 8]) + ",\n")
+        f.write("    " + ", ".join("%d, %d, %d, %d" % t for t in a.aux[i:i + 8]) + ",\n")
     f.write("};\n")
 
 
@@ -425,7 +443,7 @@ STRUCT = """typedef struct {
     int carry_limbs;
     const int64_t *prog;
     int prog_len;
-    const int32_t *aux;  /* (pi word, part 0 lo16 / 1 hi16 / 2 u32, row shift) per aux column */
+    const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
 } %s_air_t;
 """
 
