@@ -126,7 +126,12 @@ struct QuotArgs {
     int W, nm, nc, cbase, tbits;
     uint32_t log_n, log_m;
     uint64_t alpha[2], gamma[2];
-    uint64_t alpha_rest[2];                    // alpha^(3 + 6 nc)
+    // program segments: one gadget, or a run of up to 64 POLY ops; each is folded with alpha from zero by one lane
+    const uint32_t* seg_off;                   // word offset of the segment in prog
+    const uint32_t* seg_cnt;                   // 0 = gadget, else number of POLY ops in the run
+    const uint64_t* seg_pow;                   // [n_seg][2]: alpha_c^(#program constraints after the segment)
+    int n_seg;
+    uint64_t* part;                            // [n_seg][2][m] partial Horner sums
     const uint64_t* per_tab[SIPP_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
     uint32_t per_mask[SIPP_N_PERIODIC];
     uint64_t zh_inv[2];   // 1 / (x^N - 1) for even / odd natural index
@@ -180,9 +185,12 @@ __device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t (&
     return 2 + 5 * nt;
 }
 
+// one lane per (LDE point, gadget): the gadget's 32/grp + 1 constraints folded with alpha from zero, then scaled by
+// alpha^(number of gadget constraints that follow), so that the sum over gadgets equals the sequential Horner value.
 __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
     const size_t m = (size_t)1 << a.log_m;
     const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int g = blockIdx.y;
     const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);  // natural LDE index
     QCtx c;
     c.a = &a;
@@ -191,80 +199,10 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
     for (int k = 0; k < SIPP_N_PERIODIC; k++) c.per[k] = a.per_tab[k][i & a.per_mask[k]];
-
-    const int64_t* w = a.prog;
-    const int64_t* end = a.prog + a.prog_len;
-    while (w < end) {
-        if (w[0] == 1) {
-            const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
-            const int64_t coffset = w[5];
-            const int grp = (int)w[6];
-            w += 7;
-            const int64_t* qdesc = w;
-            w += 2 + 5 * (int)w[1];
-            uint64_t e[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) e[k] = 0;
-            const int np = (int)*w++;
-            for (int p = 0; p < np; p++) {
-                const uint64_t coef = gl::from_i64(*w++);
-                uint64_t va[16], vb[16];
-                w += qvec<16>(w, c, va);
-                w += qvec<16>(w, c, vb);
-#pragma unroll
-                for (int ii = 0; ii < 16; ii++) {
-                    const uint64_t ai = gl::mul(coef, va[ii]);
-#pragma unroll
-                    for (int jj = 0; jj < 16; jj++) e[ii + jj] = gl::mad(ai, vb[jj], e[ii + jj]);
-                }
-            }
-            const int nl = (int)*w++;
-            for (int p = 0; p < nl; p++) {
-                const uint64_t coef = gl::from_i64(*w++);
-                uint64_t va[16];
-                w += qvec<16>(w, c, va);
-#pragma unroll
-                for (int ii = 0; ii < 16; ii++) e[ii] = gl::mad(coef, va[ii], e[ii]);
-            }
-            uint64_t q[17];
-            (void)qvec<17>(qdesc, c, q);
-            const uint64_t s = c.local(sign_col);
-            const uint64_t sgn = gl::sub(1, gl::add(s, s));
-            uint64_t cprev = 0;
-            const uint64_t coff = gl::from_i64(coffset);
-            // d_k = e_k - sgn (q * p)_k, all 32 of them in registers; then 32 / grp equations in base 2^(16 grp)
-            uint64_t d[32];
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                uint64_t qp = 0;
-#pragma unroll
-                for (int ii = 0; ii < 17; ii++) {
-                    const int jj = k - ii;
-                    if (jj >= 0 && jj < 16) qp = gl::mad(q[ii], (uint64_t)a.p_limbs[jj], qp);
-                }
-                d[k] = gl::sub(e[k], gl::mul(sgn, qp));
-            }
-            const uint64_t wgt = (uint64_t)1 << (16 * grp);
-#pragma unroll
-            for (int m = 0; m < 32; m++) {
-                if (m < 32 / grp) {
-                    uint64_t v;
-                    if (grp == 2) v = gl::mad(d[(2 * m + 1) & 31], 65536, d[(2 * m) & 31]);
-                    else v = d[m];
-                    uint64_t ck = 0;
-                    if (m < 32 / grp - 1) {
-                        for (int l = 0; l < ncl; l++)
-                            ck = gl::mad(c.local(cbase + m * ncl + l), (uint64_t)1 << (lb * l), ck);
-                        ck = gl::sub(ck, coff);
-                    }
-                    v = gl::sub(v, cprev);
-                    v = gl::mad(ck, wgt, v);
-                    c.emit(v);
-                    cprev = ck;
-                }
-            }
-            c.emit(gl::mul(s, gl::sub(s, 1)));
-        } else {
+    const int64_t* w = a.prog + a.seg_off[g];
+    const uint32_t n_poly = a.seg_cnt[g];
+    if (n_poly) {
+        for (uint32_t op = 0; op < n_poly; op++) {
             const int nmono = (int)w[1];
             w += 2;
             uint64_t sum = 0;
@@ -282,9 +220,77 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
             }
             c.emit(sum);
         }
+    } else {
+        const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
+        const int64_t coffset = w[5];
+        const int grp = (int)w[6];
+        w += 7;
+        const int64_t* qdesc = w;
+        w += 2 + 5 * (int)w[1];
+        uint64_t e[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) e[k] = 0;
+        const int np = (int)*w++;
+        for (int p = 0; p < np; p++) {
+            const uint64_t coef = gl::from_i64(*w++);
+            uint64_t va[16], vb[16];
+            w += qvec<16>(w, c, va);
+            w += qvec<16>(w, c, vb);
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) {
+                const uint64_t ai = gl::mul(coef, va[ii]);
+#pragma unroll
+                for (int jj = 0; jj < 16; jj++) e[ii + jj] = gl::mad(ai, vb[jj], e[ii + jj]);
+            }
+        }
+        const int nl = (int)*w++;
+        for (int p = 0; p < nl; p++) {
+            const uint64_t coef = gl::from_i64(*w++);
+            uint64_t va[16];
+            w += qvec<16>(w, c, va);
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) e[ii] = gl::mad(coef, va[ii], e[ii]);
+        }
+        uint64_t q[17];
+        (void)qvec<17>(qdesc, c, q);
+        const uint64_t s = c.local(sign_col);
+        const uint64_t sgn = gl::sub(1, gl::add(s, s));
+        uint64_t cprev = 0;
+        const uint64_t coff = gl::from_i64(coffset);
+        uint64_t d[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            uint64_t qp = 0;
+#pragma unroll
+            for (int ii = 0; ii < 17; ii++) {
+                const int jj = k - ii;
+                if (jj >= 0 && jj < 16) qp = gl::mad(q[ii], (uint64_t)a.p_limbs[jj], qp);
+            }
+            d[k] = gl::sub(e[k], gl::mul(sgn, qp));
+        }
+        const uint64_t wgt = (uint64_t)1 << (16 * grp);
+#pragma unroll
+        for (int mm = 0; mm < 32; mm++) {
+            if (mm < 32 / grp) {
+                uint64_t v;
+                if (grp == 2) v = gl::mad(d[(2 * mm + 1) & 31], 65536, d[(2 * mm) & 31]);
+                else v = d[mm];
+                uint64_t ck = 0;
+                if (mm < 32 / grp - 1) {
+                    for (int l = 0; l < ncl; l++)
+                        ck = gl::mad(c.local(cbase + mm * ncl + l), (uint64_t)1 << (lb * l), ck);
+                    ck = gl::sub(ck, coff);
+                }
+                v = gl::sub(v, cprev);
+                v = gl::mad(ck, wgt, v);
+                c.emit(v);
+                cprev = ck;
+            }
+        }
+        c.emit(gl::mul(s, gl::sub(s, 1)));
     }
-    a.out[j] = c.acc0;
-    a.out[m + j] = c.acc1;
+    a.part[((size_t)g * 2 + 0) * m + j] = gl::mul(c.acc0, a.seg_pow[2 * g]);
+    a.part[((size_t)g * 2 + 1) * m + j] = gl::mul(c.acc1, a.seg_pow[2 * g + 1]);
 }
 
 __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
@@ -297,6 +303,10 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
+    for (int g = 0; g < a.n_seg; g++) {
+        c.acc0 = gl::add(c.acc0, a.part[((size_t)g * 2 + 0) * m + j]);
+        c.acc1 = gl::add(c.acc1, a.part[((size_t)g * 2 + 1) * m + j]);
+    }
     const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_m, i));
     const uint64_t zh = a.zh[i & 1];
     const uint64_t zl = gl::sub(x, a.g_inv);
@@ -355,10 +365,8 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
             }
         }
     }
-    const uint64_t t0 = gl::mad(a.out[j], a.alpha_rest[0], c.acc0);
-    const uint64_t t1 = gl::mad(a.out[m + j], a.alpha_rest[1], c.acc1);
-    a.out[j] = gl::mul(t0, a.zh_inv[i & 1]);
-    a.out[m + j] = gl::mul(t1, a.zh_inv[i & 1]);
+    a.out[j] = gl::mul(c.acc0, a.zh_inv[i & 1]);
+    a.out[m + j] = gl::mul(c.acc1, a.zh_inv[i & 1]);
 }
 
 // =====================================================================================================
@@ -613,18 +621,74 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.w_m = wm;
     for (int i = 0; i < 16; i++) q.p_limbs[i] = SIPP_BN_P_LIMBS[i];
     q.out = d_out;
-    const uint64_t n_rest = 3 + 6 * (uint64_t)a->n_checked;
-    q.alpha_rest[0] = gl::pow(alpha[0], n_rest);
-    q.alpha_rest[1] = gl::pow(alpha[1], n_rest);
+    // segment table: offsets, kinds, alpha powers (tiny; rebuilt per proof because alpha changes)
+    ArenaMark mk = arena_mark(ctx);
+    {
+        std::vector<uint32_t> off, cnt;
+        std::vector<int> ncons;
+        const int64_t* w = a->prog;
+        const int64_t* end = a->prog + a->prog_len;
+        while (w < end && w[0] == 1) {
+            off.push_back((uint32_t)(w - a->prog));
+            cnt.push_back(0);
+            ncons.push_back(32 / (int)w[6] + 1);
+            w += 7;
+            w += 2 + 5 * w[1];
+            int64_t np = *w++;
+            for (int64_t p = 0; p < np; p++) {
+                w += 1;
+                w += 2 + 5 * w[1];
+                w += 2 + 5 * w[1];
+            }
+            int64_t nl = *w++;
+            for (int64_t p = 0; p < nl; p++) {
+                w += 1;
+                w += 2 + 5 * w[1];
+            }
+        }
+        while (w < end) {  // runs of POLY ops
+            off.push_back((uint32_t)(w - a->prog));
+            uint32_t k = 0;
+            while (w < end && k < 64) {
+                int64_t nmono = w[1];
+                w += 2;
+                for (int64_t mo = 0; mo < nmono; mo++) w += 2 + 2 * w[1];
+                k++;
+            }
+            cnt.push_back(k);
+            ncons.push_back((int)k);
+        }
+        const int ns = (int)off.size();
+        q.n_seg = ns;
+        std::vector<uint64_t> host((size_t)ns * 2 + ns + 2, 0);
+        int after = 0;
+        for (int g = ns - 1; g >= 0; g--) {
+            host[2 * g] = gl::pow(alpha[0], (uint64_t)after);
+            host[2 * g + 1] = gl::pow(alpha[1], (uint64_t)after);
+            after += ncons[g];
+        }
+        uint32_t* h32 = reinterpret_cast<uint32_t*>(&host[2 * ns]);
+        memcpy(h32, off.data(), (size_t)ns * 4);
+        memcpy(h32 + ns, cnt.data(), (size_t)ns * 4);
+        uint64_t* d_tab = arena_alloc_t<uint64_t>(ctx, host.size());
+        q.part = arena_alloc_t<uint64_t>(ctx, (size_t)ns * 2 * m);
+        if (!d_tab || !q.part) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_tab, host.data(), host.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `host` goes out of scope
+        q.seg_pow = d_tab;
+        q.seg_off = reinterpret_cast<const uint32_t*>(d_tab + 2 * ns);
+        q.seg_cnt = q.seg_off + ns;
+    }
     {
         ProfScope ps(ctx, "quotient_prog");
-        hipLaunchKernelGGL(quotient_prog_kernel, dim3((unsigned)(m / 64)), dim3(64), 0, ctx->stream, q);
+        hipLaunchKernelGGL(quotient_prog_kernel, dim3((unsigned)(m / 64), (unsigned)q.n_seg), dim3(64), 0, ctx->stream, q);
     }
     {
         ProfScope ps(ctx, "quotient_rest");
         hipLaunchKernelGGL(quotient_rest_kernel, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
+    arena_release(ctx, mk);
     return SIPP_OK;
 }
 
