@@ -132,9 +132,52 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     bool cs_done = a.cscale == 0;
     if (a.tw_mode == 1 || a.pw_mode == 1) diag(a.tw_mode == 1, a.pw_mode == 1, 0);
 
-    // ---- butterflies: k stages over the r dimension (element stride T) ----
+    // ---- butterflies: k stages over the r dimension (element stride T), two stages per LDS round trip ----
+    // radix-2^2: a lane loads the 4 elements of a quad, applies both stages in registers and writes them back:
+    // half the LDS traffic, index arithmetic and barriers of stage-by-stage radix 2 (same 4 twiddle products).
+    uint32_t s = 0;
+    const uint32_t quarter = E >> 2;
+    for (; s + 1 < k; s += 2) {
+        // DIF: distances 2q then q with q = R >> (s + 2);  DIT: distances h then 2h with h = 1 << s
+        const uint32_t log_q = a.dit ? s : (k - 2 - s);
+        for (uint32_t idx = threadIdx.x; idx < quarter; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 2) - 1);
+            const uint32_t g = rest >> (k - 2);
+            const uint32_t j = b & ((1u << log_q) - 1);
+            const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t st = (1u << log_q) << lt;
+            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e0 + st), l2 = lds_idx(e0 + 2 * st), l3 = lds_idx(e0 + 3 * st);
+            uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
+            if (a.dit) {
+                // stage s: (x0, x1), (x2, x3) with w_{2h}^j ; stage s+1: (a0, a2) with w_{4h}^j, (a1, a3) with w_{4h}^(j+h)
+                const uint64_t w1 = wr_s[j << (k - 1 - s)];
+                const uint64_t w20 = wr_s[j << (k - 2 - s)], w21 = wr_s[(j + (1u << s)) << (k - 2 - s)];
+                const uint64_t v1 = gl::mul(x1, w1), v3 = gl::mul(x3, w1);
+                const uint64_t a0 = gl::add(x0, v1), a1 = gl::sub(x0, v1), a2 = gl::add(x2, v3), a3 = gl::sub(x2, v3);
+                const uint64_t u2 = gl::mul(a2, w20), u3 = gl::mul(a3, w21);
+                tile[l0] = gl::add(a0, u2);
+                tile[l2] = gl::sub(a0, u2);
+                tile[l1] = gl::add(a1, u3);
+                tile[l3] = gl::sub(a1, u3);
+            } else {
+                // stage s: (x0, x2) with w^(j 2^s), (x1, x3) with w^((j+q) 2^s) ; stage s+1: (a0, a1), (a2, a3) with w^(j 2^(s+1))
+                const uint64_t w10 = wr_s[j << s], w11 = wr_s[(j + (1u << log_q)) << s];
+                const uint64_t w2 = wr_s[j << (s + 1)];
+                const uint64_t a0 = gl::add(x0, x2), a2 = gl::mul(gl::sub(x0, x2), w10);
+                const uint64_t a1 = gl::add(x1, x3), a3 = gl::mul(gl::sub(x1, x3), w11);
+                tile[l0] = gl::add(a0, a1);
+                tile[l1] = gl::mul(gl::sub(a0, a1), w2);
+                tile[l2] = gl::add(a2, a3);
+                tile[l3] = gl::mul(gl::sub(a2, a3), w2);
+            }
+        }
+        __syncthreads();
+    }
     const uint32_t half = E >> 1;
-    for (uint32_t s = 0; s < k; s++) {
+    for (; s < k; s++) {
         const uint32_t log_hd = a.dit ? s : (k - 1 - s);
         const uint32_t tw_shift = k - 1 - log_hd;
         for (uint32_t idx = threadIdx.x; idx < half; idx += blockDim.x) {
