@@ -215,7 +215,9 @@ int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* i
     memset(a.in_buf, 0, sizeof a.in_buf);
     memcpy(a.in_buf, in_buf, n_in * sizeof(uint64_t));
     a.n_in = n_in; a.pow_bits = pow_bits; a.result = d_res;
-    const uint64_t batch = (uint64_t)1 << 20;
+    // expected 2^pow_bits trials: a batch of 2^(pow_bits + 1) succeeds with probability 1 - e^-2; batches go in
+    // ascending order and atomicMin keeps the smallest valid nonce, so the witness is the global minimum
+    const uint64_t batch = (uint64_t)1 << (pow_bits + 1 < 12 ? 12 : pow_bits + 1);
     unsigned long long h_res = ~0ull;
     SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_res, 0xff, sizeof(unsigned long long), ctx->stream));
     for (uint64_t base = 0; base < ((uint64_t)1 << 44); base += batch) {

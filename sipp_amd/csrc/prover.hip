@@ -454,49 +454,58 @@ struct DivArgs {
     uint64_t* qout;  // [2 batches][2][n]
 };
 __global__ void __launch_bounds__(1024) fri_divide_kernel(DivArgs a) {
+    // one block per batch; tiles of 1024 consecutive coefficients from the top down (coalesced), suffix scan in LDS
     __shared__ uint64_t s0[1024], s1[1024];
-    const int b = blockIdx.x;
-    const size_t n = a.n, chunk = (n + 1023) / 1024;
-    const size_t lo = (size_t)threadIdx.x * chunk, hi = min(n, lo + chunk);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const size_t n = a.n;
     const uint64_t* zp = a.zp[b];
     const uint64_t* zip = a.zip[b];
     uint64_t* q0 = a.qout + (size_t)b * 2 * n;
     uint64_t* q1 = q0 + n;
-    auto F = [&](size_t k) -> E2 {
-        uint64_t c0 = 0, c1 = 0;
-        for (int sl = 0; sl < a.slices; sl++) {
-            const uint64_t* p = a.partial + (size_t)sl * 4 * n + (size_t)b * 2 * n;
-            c0 = gl::add(c0, p[k]);
-            c1 = gl::add(c1, p[n + k]);
+    E2 carry{0, 0};  // sum over all higher tiles
+    for (size_t base = n; base > 0;) {
+        const size_t tile = base >= 1024 ? 1024 : base;
+        base -= tile;
+        const size_t k = base + t;
+        E2 v{0, 0};
+        if ((size_t)t < tile) {
+            uint64_t c0 = 0, c1 = 0;
+            for (int sl = 0; sl < a.slices; sl++) {
+                const uint64_t* p = a.partial + (size_t)sl * 4 * n + (size_t)b * 2 * n;
+                c0 = gl::add(c0, p[k]);
+                c1 = gl::add(c1, p[n + k]);
+            }
+            v = gl::mul(E2{c0, c1}, E2{zp[k], zp[n + k]});
         }
-        return E2{c0, c1};
-    };
-    // local suffix sums (descending k) of F_k z^k
-    E2 acc{0, 0};
-    for (size_t k = hi; k-- > lo;) acc = gl::add(acc, gl::mul(F(k), E2{zp[k], zp[n + k]}));
-    s0[threadIdx.x] = acc.c0;
-    s1[threadIdx.x] = acc.c1;
-    __syncthreads();
-    // suffix scan over the 1024 chunk sums: after[t] = sum_{t' > t}
-    if (threadIdx.x == 0) {
-        uint64_t a0 = 0, a1 = 0;
-        for (int t = 1023; t >= 0; t--) {
-            uint64_t t0 = s0[t], t1 = s1[t];
-            s0[t] = a0; s1[t] = a1;
-            a0 = gl::add(a0, t0); a1 = gl::add(a1, t1);
+        // inclusive suffix scan over the tile: S[t] = sum_{t' >= t} v[t']
+        s0[t] = v.c0;
+        s1[t] = v.c1;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            E2 o{0, 0};
+            if (t + off < 1024) o = E2{s0[t + off], s1[t + off]};
+            __syncthreads();
+            v = gl::add(v, o);
+            s0[t] = v.c0;
+            s1[t] = v.c1;
+            __syncthreads();
         }
+        const E2 total{s0[0], s1[0]};
+        if ((size_t)t < tile) {
+            const E2 S = gl::add(v, carry);  // S_k = sum_{j >= k} F_j z^j
+            if (k >= 1) {
+                const E2 q = gl::mul(S, E2{zip[k], zip[n + k]});
+                q0[k - 1] = q.c0;
+                q1[k - 1] = q.c1;
+            }
+        }
+        carry = gl::add(carry, total);
+        __syncthreads();
     }
-    __syncthreads();
-    acc = E2{s0[threadIdx.x], s1[threadIdx.x]};
-    for (size_t k = hi; k-- > lo;) {
-        acc = gl::add(acc, gl::mul(F(k), E2{zp[k], zp[n + k]}));  // S_k
-        if (k >= 1) {
-            E2 q = gl::mul(acc, E2{zip[k], zip[n + k]});
-            q0[k - 1] = q.c0;
-            q1[k - 1] = q.c1;
-        }
+    if (t == 0) {
+        q0[n - 1] = 0;
+        q1[n - 1] = 0;
     }
-    if (threadIdx.x == 0) { q0[n - 1] = 0; q1[n - 1] = 0; }
 }
 
 // final[0] = 0 ; final[k+1] = q0[k] * shift + q1[k]   (multiplication by X)
