@@ -56,3 +56,21 @@ def test_wrong_claimed_output_fails_verification_or_prove(ctx, ios4):
     except sipp_amd.SippError:
         return
     assert _oracle.stark_verify(pf) != 0
+
+
+def test_full_size_n128_proofs_verify(ctx):
+    """BASELINE config n = 128 (127 / 127 / 14 IO records; N = 2^16, 2^16, 2^13): too large for the CPU prover in a test,
+    so parity is checked through size-independent properties: the oracle's verifier accepts each GPU proof (all
+    constraints at zeta, FRI, 84 query openings against the caps) and the public inputs are exactly the IO records."""
+    d = np.load("tests/golden/sipp_n128_ios.npz")
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        ios = d[key]
+        pf = ctx.prove(kind, ios)
+        assert _oracle.stark_verify(pf) == 0, key
+        nio = int(pf[3])
+        pis = pf[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])
+        assert (pis[: ios.shape[0]] == ios).all()
+        assert (pis[ios.shape[0]:] == ios[-1]).all()      # padding repeats the last record
+        bad = pf.copy()
+        bad[16 + 3] ^= 1                                   # one bit of the trace cap
+        assert _oracle.stark_verify(bad) != 0
