@@ -5,8 +5,8 @@
 // the column-major trace [W][N] (natural row order) is produced in HBM.
 //
 // Kernels
-//   curve_chain      one 256-lane workgroup per IO: sequential doublings on one lane, then a parallel prefix
-//                    scan of the selected powers (Jacobian, no inversions); stores (R_k, P_k) per row.
+//   curve_dbl/scan   one lane per IO for the 255 serial doublings, then one 256-lane workgroup per IO for a parallel
+//                    prefix scan of the selected powers (Jacobian, no inversions); stores (R_k, P_k) per row.
 //   curve_rows       one lane per row: Jacobian -> affine, slope, x3, y3 (2 Fermat inversions), limbs
 //   fq12_chain       one 288-lane workgroup per IO: the 2 x 144 limb products of acc*pw and pw^2 per bit in parallel
 //   exp_rows         one lane per row: bit / remaining-exponent-limb cells (closed form)
@@ -124,16 +124,33 @@ __device__ __forceinline__ Jac<EXT> jac_add_id(const Jac<EXT>& p, const Jac<EXT>
     return jac_add<EXT>(p, q);
 }
 
-// One 256-lane workgroup per IO record (lane k <-> exponent bit k).  rows[512 io + 2k] = (R_k, P_k) for the
-// add row of bit k, rows[.. + 2k + 1] = (R_{k+1}, P_k) for its double row, where P_k = 2^k x and
-// R_k = offset + sum_{j<k} bit_j P_j.
-//   phase 1  lane 0: the 255 sequential doublings (the only inherently serial part)
-//   phase 2  all lanes: inclusive Hillis-Steele scan of T_k = bit_k ? P_k : inf  (8 point additions deep)
-//   phase 3  all lanes: R_{k+1} = offset + scan_k
-// 2,200 field-multiplication times on the critical path instead of 6,100 for the one-lane-per-IO chain.
+// rows[512 io + 2k] = (R_k, P_k) for the add row of bit k, rows[.. + 2k + 1] = (R_{k+1}, P_k) for its double row,
+// where P_k = 2^k x and R_k = offset + sum_{j<k} bit_j P_j.
+//   curve_dbl_kernel   one LANE per IO: the 255 sequential doublings (the only inherently serial part; its time
+//                      does not grow with the number of IOs until there are more IOs than lanes on the chip)
+//   curve_scan_kernel  one 256-lane workgroup per IO (lane k <-> bit k): inclusive Hillis-Steele scan of
+//                      T_k = bit_k ? P_k : inf (8 point additions deep), then R_{k+1} = offset + scan_k
+// 2,200 field-multiplication times on the critical path instead of 6,100 for a one-lane-per-IO double-and-add.
 template <int EXT>
-__global__ void __launch_bounds__(256) curve_chain_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi,
-                                                         RowPts<EXT>* __restrict__ rows) {
+__global__ void __launch_bounds__(64) curve_dbl_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi,
+                                                      RowPts<EXT>* __restrict__ rows) {
+    using F = Fld<EXT>;
+    using T = typename F::T;
+    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
+    if (io >= num_io) return;
+    const uint32_t* rec = ios + (size_t)io * ppi;
+    const int w = 8 * EXT;
+    RowPts<EXT>* out = rows + (size_t)io * 512;
+    Jac<EXT> P{F::load(rec), F::load(rec + w), one_of((T*)nullptr)};
+    for (int b = 0; b < 256; b++) {
+        out[2 * b].P = P;
+        if (b != 255) P = jac_dbl<EXT>(P);
+    }
+}
+
+template <int EXT>
+__global__ void __launch_bounds__(256) curve_scan_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi,
+                                                        RowPts<EXT>* __restrict__ rows) {
     using F = Fld<EXT>;
     using T = typename F::T;
     __shared__ Jac<EXT> pts[256];
@@ -141,15 +158,7 @@ __global__ void __launch_bounds__(256) curve_chain_kernel(const uint32_t* __rest
     const uint32_t* rec = ios + (size_t)io * ppi;
     const int w = 8 * EXT;
     RowPts<EXT>* out = rows + (size_t)io * 512;
-    if (k == 0) {
-        Jac<EXT> P{F::load(rec), F::load(rec + w), one_of((T*)nullptr)};
-        for (int b = 0; b < 256; b++) {
-            pts[b] = P;
-            if (b != 255) P = jac_dbl<EXT>(P);
-        }
-    }
-    __syncthreads();
-    const Jac<EXT> Pk = pts[k];
+    const Jac<EXT> Pk = out[2 * k].P;
     const uint32_t* ex = rec + 4 * w;
     const int bit = (ex[k >> 5] >> (k & 31)) & 1;
     Jac<EXT> inf;
@@ -157,7 +166,6 @@ __global__ void __launch_bounds__(256) curve_chain_kernel(const uint32_t* __rest
     inf.y = one_of((T*)nullptr);
     inf.z = F::sub(inf.x, inf.x);
     Jac<EXT> v = bit ? Pk : inf;
-    __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
         pts[k] = v;
         __syncthreads();
@@ -172,7 +180,6 @@ __global__ void __launch_bounds__(256) curve_chain_kernel(const uint32_t* __rest
     __syncthreads();
     const Jac<EXT> Rk = k ? pts[k - 1] : offs;
     out[2 * k].R = Rk;
-    out[2 * k].P = Pk;
     out[2 * k + 1].R = A;
     out[2 * k + 1].P = Pk;
 }
@@ -655,7 +662,9 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             if (!rows) return SIPP_E_NOMEM;
             {
                 ProfScope ps(ctx, "trace_curve_chain");
-                hipLaunchKernelGGL(curve_chain_kernel<1>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
+                hipLaunchKernelGGL(curve_dbl_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
+                                   (uint32_t)a->pi_per_io, rows);
+                hipLaunchKernelGGL(curve_scan_kernel<1>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
@@ -668,7 +677,9 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             if (!rows) return SIPP_E_NOMEM;
             {
                 ProfScope ps(ctx, "trace_curve_chain");
-                hipLaunchKernelGGL(curve_chain_kernel<2>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
+                hipLaunchKernelGGL(curve_dbl_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
+                                   (uint32_t)a->pi_per_io, rows);
+                hipLaunchKernelGGL(curve_scan_kernel<2>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
