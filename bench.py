@@ -155,6 +155,12 @@ def main():
         avg_ms = lk["ms"] / launches
         bytes_per_launch = leaf_bytes * args.steps / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected with
+        # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.n == 128 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         out = {
             "metric": "SIPP proof-gen (3 STARK sub-proofs) pairings-aggregated/sec, n=%d" % args.n,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +174,8 @@ def main():
                        "stark_config": "rate_bits=1 cap_height=4 pow_bits=16 arity=16 queries=84 challenges=2",
                        "parallelism": "%d independent SIPP instance(s), one per GPU, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "poseidon_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": launches, "avg_launch_ms": avg_ms,
                          "note": "integer-VALU-bound kernel (Poseidon x^7 + MDS, ~%.2f G permutations/s); HBM fraction "
                                  "is small by construction, see DESIGN.md" % (leaf_perms * args.steps / (lk["ms"] * 1e-3) / 1e9
