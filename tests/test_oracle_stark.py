@@ -52,3 +52,15 @@ def test_g2_and_fq12_verify(case):
     for kind in (1, 2):
         pf = _oracle.stark_prove(kind, case[kind])
         assert _oracle.stark_verify(pf) == 0
+
+
+def test_proof_digests_match_committed_self_golden():
+    """tests/golden/proof_digests_n4.json (tools/gen_golden.py digests): regenerate deliberately when the AIR changes."""
+    import hashlib
+    import json
+    gold = json.load(open("tests/golden/proof_digests_n4.json"))
+    d = np.load("tests/golden/sipp_n4_ios.npz")
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        pf = _oracle.stark_prove(kind, d[key])
+        assert len(pf) == gold[key]["words"] and int(pf[4]) == gold[key]["W"]
+        assert hashlib.sha256(pf.tobytes()).hexdigest() == gold[key]["sha256"], key

@@ -20,7 +20,26 @@ from oracle.py import sipp_native as sn  # noqa: E402
 SEEDS = {4: 7, 8: 0x51515050, 128: 0x51515050 + 1, 1024: 0x51515050 + 2}
 
 
+def proof_digests():
+    """SELF-GOLDEN digests of the CPU oracle's three sub-proofs for the n = 4 fixture (sha256 over the u64 words):
+    pins the oracle -- AIR tables, lookup fill rule, Fiat-Shamir order, FRI -- against silent drift.  The GPU path is
+    compared with the oracle word for word in tests/test_gpu_stark.py, so these digests pin it too."""
+    import hashlib
+    import json
+    from tests import _oracle
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n4_ios.npz"))
+    out = {}
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        pf = _oracle.stark_prove(kind, d[key])
+        out[key] = {"words": int(len(pf)), "log_n": int(pf[2]), "W": int(pf[4]), "P": int(pf[5]),
+                    "pow_witness_index": None, "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "proof_digests_n4.json"), "w"), indent=1)
+    print("proof digests:", {k: v["sha256"][:16] for k, v in out.items()})
+
+
 def main():
+    if sys.argv[1:] == ["digests"]:
+        return proof_digests()
     for n in [int(x) for x in sys.argv[1:]]:
         t = time.time()
         A, B = sn.synthetic_inputs(n, SEEDS.get(n, n))
