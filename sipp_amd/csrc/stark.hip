@@ -260,10 +260,8 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         int h_err = 0;
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (h_err) return sipp_fail(ctx, h_err, "trace fill: IO record not provable (degenerate point or inconsistent limbs)");
+        if (h_err) return sipp_fail(ctx, h_err, "trace fill: IO record not provable (claimed output wrong, degenerate point or non-canonical limbs)");
     }
-    // the claimed outputs must equal the device-computed ones: compare the last row of every IO block
-    // (bound to the public inputs by the AIR anyway; checked here so a wrong record fails fast)
 
     tick("trace fill");
     host::Challenger ch;

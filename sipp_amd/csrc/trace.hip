@@ -355,6 +355,39 @@ __global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restr
     }
 }
 
+// ---- claimed outputs: the last row of every IO block must hold the output the record claims (the AIR binds those
+// cells to the public inputs anyway; checking here makes a wrong record fail fast, like the CPU restatement) ----
+__global__ void check_outputs_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi, int kind,
+                                     const uint64_t* __restrict__ tr, size_t n, int col_state, int* __restrict__ err) {
+    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
+    if (io >= num_io) return;
+    const size_t row = (size_t)io * 512 + 511;
+    const uint32_t* rec = ios + (size_t)io * ppi;
+    bool bad = false;
+    if (kind == 2) {
+        const uint32_t* outw = rec + ppi - 96;   // MyFq12 coefficients; the cells hold the tower basis
+        const Fq m9 = fq::small_m(9);
+        for (int tc = 0; tc < 12; tc++) {
+            const int i = tc >> 1;
+            Fq v = Fld<1>::load(outw + 8 * (i + 6));
+            if (!(tc & 1)) v = fq::add(Fld<1>::load(outw + 8 * i), fq::mul(m9, v));
+            v = fq::from_mont(v);
+            for (int l = 0; l < 16; l++) {
+                const uint64_t want = (v.l[l >> 1] >> (16 * (l & 1))) & 0xffffu;
+                bad |= tr[(size_t)(col_state + 16 * tc + l) * n + row] != want;
+            }
+        }
+    } else {
+        const int words = kind == 0 ? 16 : 32;   // (x, y) or (x.c0, x.c1, y.c0, y.c1): the Rx | Ry cells in order
+        const uint32_t* outw = rec + ppi - words;
+        for (int wd = 0; wd < words; wd++) {
+            bad |= tr[(size_t)(col_state + 2 * wd) * n + row] != (outw[wd] & 0xffffu);
+            bad |= tr[(size_t)(col_state + 2 * wd + 1) * n + row] != (outw[wd] >> 16);
+        }
+    }
+    if (bad) atomicExch(err, SIPP_E_WITNESS);
+}
+
 // ---- exponent cells: closed form per row ----
 __global__ void exp_rows_kernel(const uint32_t* __restrict__ ios, uint32_t ppi, uint32_t exp_off, uint64_t* __restrict__ tr,
                                 size_t n, int col_bit, int col_e) {
@@ -688,6 +721,13 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                d_trace, n, c, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         }
+    }
+    {
+        // accumulator state columns: R (curves, column 1) or acc (Fq12, column 1)
+        ProfScope ps(ctx, "trace_check_outputs");
+        hipLaunchKernelGGL(check_outputs_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
+                           (uint32_t)a->pi_per_io, a->kind, d_trace, n, 1, d_err);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
     {
         ProfScope ps(ctx, "trace_exp_table");
