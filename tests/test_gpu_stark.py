@@ -87,3 +87,18 @@ def test_error_behaviour(ctx, ios4):
     assert L.sipp_g1_exp_prove(ctx.h, ios.ctypes.data, 0, out.ctypes.data, 16, C.byref(n)) == -1
     assert L.sipp_proof_size(ctx.h, 7, 3) == 0
     assert _oracle.stark_verify(ctx.prove(0, ios4[0])) == 0     # still works afterwards
+
+
+def test_large_n1024_g1_proof_verifies():
+    """deep trace (BASELINE config 3): G1ExpStark for n = 1024 -> 1023 IO records, N = 2^19 rows, 2^20-leaf trees,
+    2-pass NTTs of size 2^19 / 2^20.  Checked through the oracle's verifier and the public inputs."""
+    import sipp_amd
+    ios = np.load("tests/golden/sipp_n1024_ios.npz")["g1"]
+    c = sipp_amd.Ctx(workspace_bytes=30 << 30)
+    try:
+        pf = c.prove(0, ios)
+    finally:
+        c.close()
+    assert int(pf[2]) == 19 and int(pf[3]) == 1024
+    assert _oracle.stark_verify(pf) == 0
+    assert (pf[-1024 * 56:].reshape(1024, 56)[:1023] == ios).all()
