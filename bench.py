@@ -79,7 +79,7 @@ def main():
     # one ctx (= one HIP stream + workspace arena) and one host thread per STARK: the three sub-proofs are
     # independent, so their thin kernels and Fiat-Shamir round trips overlap
     from concurrent.futures import ThreadPoolExecutor
-    ws = [(8 << 30), (16 << 30), (12 << 30)] if args.n <= 256 else [(60 << 30), (120 << 30), (20 << 30)]
+    ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
     prios = os.environ.get("SIPP_BENCH_PRIOS", "low,,high").split(",")   # G1, G2, Fq12
     ctxs = []
     for k in range(3):
@@ -96,7 +96,11 @@ def main():
 
     proof_ms = [0.0, 0.0, 0.0]
 
+    delays = [float(x or 0) * 1e-3 for x in os.environ.get("SIPP_BENCH_DELAYS", ",,").split(",")]   # ms, per proof
+
     def one(k):
+        if delays[k] > 0 and not serial:
+            time.sleep(delays[k])
         t = time.perf_counter()
         p = ctxs[k].prove(k, ios[k])
         proof_ms[k] += 1e3 * (time.perf_counter() - t)

@@ -93,6 +93,8 @@ int sipp_fq12_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint6
                         size_t *proof_len);
 /* upper bound (u64 words) of the flat proof for `num_io` records of `kind` */
 size_t sipp_proof_size(const sipp_ctx *ctx, int kind, size_t num_io);
+/* HBM workspace (bytes) one proof of `kind` with `num_io` records needs; pass it (or more) to sipp_ctx_create */
+size_t sipp_workspace_bytes(int kind, size_t num_io);
 /* trace shape the prover will use: rows (log2), main columns, permutation-Z columns, quotient chunks */
 int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
                      uint32_t *perm_cols, uint32_t *quotient_cols);

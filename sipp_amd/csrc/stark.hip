@@ -518,6 +518,22 @@ int sipp_stark_shape(const sipp_ctx* ctx, int kind, size_t num_io, uint32_t* log
     return SIPP_OK;
 }
 
+size_t sipp_workspace_bytes(int kind, size_t num_io) {
+    Shape s;
+    if (shape_of(kind, num_io, &s) != SIPP_OK) return 0;
+    const size_t n = (size_t)1 << s.log_n, m = 2 * n;
+    const size_t W = (size_t)s.W, P = (size_t)s.P, Q = (size_t)s.Q, nc = (size_t)s.air->n_checked;
+    size_t words = n * (2 * W + 3 * P)                                  // trace values + coefficients, Z values (x2) + coefficients
+                   + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
+                   + 3 * 8 * m                                          // three Merkle trees
+                   + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
+                   + 80 * n;                                            // power tables, FRI layers, combine partials
+    size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
+                   + n * 400                                            // Jacobian row scratch of the curve chains
+                   + ((size_t)64 << 20);
+    return bytes + bytes / 16;
+}
+
 size_t sipp_proof_size(const sipp_ctx* ctx, int kind, size_t num_io) {
     Shape s;
     if (!ctx || shape_of(kind, num_io, &s) != SIPP_OK) return 0;
