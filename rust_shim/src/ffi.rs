@@ -1,0 +1,36 @@
+//! Raw bindings of include/sipp_hip.h (never compiled here: no Rust toolchain in the image).
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)]
+pub struct SippCtxOpaque {
+    _p: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippStarkConfig {
+    pub rate_bits: u32,
+    pub cap_height: u32,
+    pub pow_bits: u32,
+    pub arity_bits: u32,
+    pub final_poly_bits: u32,
+    pub num_queries: u32,
+    pub num_challenges: u32,
+}
+
+pub const SIPP_G1_EXP: c_int = 0;
+pub const SIPP_G2_EXP: c_int = 1;
+pub const SIPP_FQ12_EXP: c_int = 2;
+
+#[link(name = "sipp_hip")]
+extern "C" {
+    pub fn sipp_default_config(cfg: *mut SippStarkConfig);
+    pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
+    pub fn sipp_ctx_create(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, workspace_bytes: usize) -> c_int;
+    pub fn sipp_ctx_destroy(ctx: *mut SippCtxOpaque);
+    pub fn sipp_last_error(ctx: *const SippCtxOpaque) -> *const c_char;
+    pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
+    pub fn sipp_g1_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
+    pub fn sipp_g2_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
+    pub fn sipp_fq12_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
+}

@@ -1,0 +1,110 @@
+//! Safe wrapper around libsipp_hip.so for the three starky sub-provers of qope/SIPP
+//! (reference src/verifier_circuit.rs:133-135).  Source only; see README.md.
+pub mod ffi;
+
+use anyhow::{anyhow, Result};
+use std::ffi::CStr;
+
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Kind {
+    G1Exp = 0,   // 56 u32 per IO:  x.x x.y offset.x offset.y exp_val out.x out.y          (8 LE limbs each)
+    G2Exp = 1,   // 104 u32 per IO: Fq2 coordinates as (c0, c1)
+    Fq12Exp = 2, // 296 u32 per IO: 12 MyFq12 coefficients for x, offset; exp_val; out
+}
+
+impl Kind {
+    pub fn io_words(self) -> usize {
+        match self {
+            Kind::G1Exp => 56,
+            Kind::G2Exp => 104,
+            Kind::Fq12Exp => 296,
+        }
+    }
+}
+
+/// One GPU, one HIP stream, one workspace arena.  Not Sync: use one per thread (three of them give the
+/// three-stream overlap bench.py uses).
+pub struct SippCtx {
+    raw: *mut ffi::SippCtxOpaque,
+}
+
+unsafe impl Send for SippCtx {}
+
+impl SippCtx {
+    pub fn new(device: i32, kind: Kind, max_num_io: usize) -> Result<Self> {
+        let mut raw = std::ptr::null_mut();
+        let ws = unsafe { ffi::sipp_workspace_bytes(kind as i32, max_num_io) };
+        let rc = unsafe { ffi::sipp_ctx_create(&mut raw, device, std::ptr::null(), ws) };
+        if rc != 0 {
+            return Err(anyhow!("sipp_ctx_create failed: status {rc}"));
+        }
+        Ok(Self { raw })
+    }
+
+    fn last_error(&self) -> String {
+        unsafe { CStr::from_ptr(ffi::sipp_last_error(self.raw)) }.to_string_lossy().into_owned()
+    }
+
+    /// `ios`: `num_io * kind.io_words()` little-endian u32 limbs, outputs included.
+    /// Returns the flat StarkProofWithPublicInputs buffer (layout: INTEGRATION.md section 2).
+    pub fn prove(&mut self, kind: Kind, ios: &[u32]) -> Result<Vec<u64>> {
+        let num_io = ios.len() / kind.io_words();
+        anyhow::ensure!(num_io * kind.io_words() == ios.len() && num_io > 0, "ragged IO list");
+        let cap = unsafe { ffi::sipp_proof_size(self.raw, kind as i32, num_io) };
+        let mut buf = vec![0u64; cap];
+        let mut len = 0usize;
+        let rc = unsafe {
+            match kind {
+                Kind::G1Exp => ffi::sipp_g1_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+                Kind::G2Exp => ffi::sipp_g2_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+                Kind::Fq12Exp => ffi::sipp_fq12_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+            }
+        };
+        if rc != 0 {
+            // the reference's call sites `.unwrap()` (src/verifier_circuit.rs:253): surface the same way
+            return Err(anyhow!("sipp prove failed: status {rc}: {}", self.last_error()));
+        }
+        buf.truncate(len);
+        Ok(buf)
+    }
+}
+
+impl Drop for SippCtx {
+    fn drop(&mut self) {
+        unsafe { ffi::sipp_ctx_destroy(self.raw) }
+    }
+}
+
+/// Section offsets of the flat proof (u64 words), mirroring StarkProofWithPublicInputs.
+pub struct FlatProof<'a> {
+    pub words: &'a [u64],
+}
+
+impl<'a> FlatProof<'a> {
+    pub fn header(&self) -> &[u64] { &self.words[..16] }
+    pub fn log_n(&self) -> usize { self.words[2] as usize }
+    pub fn widths(&self) -> (usize, usize, usize) { (self.words[4] as usize, self.words[5] as usize, self.words[6] as usize) }
+    pub fn cap_words(&self) -> usize { 4usize << self.words[7] }
+    pub fn trace_cap(&self) -> &[u64] { &self.words[16..16 + self.cap_words()] }
+    pub fn permutation_zs_cap(&self) -> &[u64] { let c = self.cap_words(); &self.words[16 + c..16 + 2 * c] }
+    pub fn quotient_polys_cap(&self) -> &[u64] { let c = self.cap_words(); &self.words[16 + 2 * c..16 + 3 * c] }
+    /// local_values | next_values | permutation_zs | permutation_zs_next | quotient_polys, 2 words per element
+    pub fn openings(&self) -> &[u64] {
+        let (w, p, q) = self.widths();
+        let start = 16 + 3 * self.cap_words();
+        &self.words[start..start + 2 * (2 * w + 2 * p + q)]
+    }
+    pub fn public_inputs(&self) -> &[u64] {
+        let n = (self.words[3] * self.words[11]) as usize;
+        &self.words[self.words.len() - n..]
+    }
+}
+
+// In starky-bn254 (G1ExpStarkyProofGenerator::run_once and its G2 / Fq12 twins) the body
+//     let trace = stark.generate_trace(&ios);
+//     let pi = stark.generate_public_inputs(&ios);
+//     let proof = starky::prover::prove::<F, C, _, D>(stark, &config, trace, pi, &mut TimingTree::default())?;
+// becomes
+//     let flat = ctx.prove(Kind::G1Exp, &ios_as_u32_limbs)?;
+//     let proof = StarkProofWithPublicInputs::<F, C, D>::from_flat(&FlatProof { words: &flat });
+// followed, unchanged, by set_stark_proof_with_pis_target(out_buffer, &self.proof_target, &proof).
