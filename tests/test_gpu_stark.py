@@ -102,3 +102,21 @@ def test_large_n1024_g1_proof_verifies():
     assert int(pf[2]) == 19 and int(pf[3]) == 1024
     assert _oracle.stark_verify(pf) == 0
     assert (pf[-1024 * 56:].reshape(1024, 56)[:1023] == ios).all()
+
+
+def test_edge_exponents_and_degenerate_inputs(ctx):
+    """exp = 0 / 1 / r - 1 / high-bit patterns prove and match the oracle word for word; a degenerate record
+    (x == offset, odd exponent: the first addition would be a doubling) fails loudly with SIPP_E_WITNESS."""
+    import sipp_amd
+    from tests.test_oracle_air import crafted_g1_records
+    recs = crafted_g1_records()
+    got = ctx.prove(0, recs)
+    assert (got == _oracle.stark_prove(0, recs)).all()
+    assert _oracle.stark_verify(got) == 0
+    from oracle.py import bn254 as bn
+    from oracle.py import sipp_native as sn
+    x = bn.g1_mul(bn.G1, 77)
+    bad = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(x) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 4))], dtype=np.uint32)
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.prove(0, bad)
+    assert e.value.code == -8

@@ -57,3 +57,30 @@ def test_wrong_output_refused(ios4):
     ios[1, 55] ^= 1                        # last word of the claimed output of IO 1
     with pytest.raises(RuntimeError):
         _oracle.Trace(0, ios)
+
+
+def crafted_g1_records():
+    """edge-case obligations: exp = 0 (out = offset), exp = 1, exp = r - 1, exp = 2^255-ish bit patterns"""
+    from oracle.py import bn254 as bn
+    from oracle.py import sipp_native as sn
+    x = bn.g1_mul(bn.G1, 0x1234567)
+    off = bn.g1_mul(bn.G1, 0x89abcdef)
+    recs = []
+    for e in (0, 1, bn.R - 1, (1 << 253) + 5):
+        out = bn.g1_add(off, bn.g1_mul(x, e)) if e else off
+        recs.append(bn.g1_to_u32(x) + bn.g1_to_u32(off) + sn.exp_to_u32(e) + bn.g1_to_u32(out))
+    return np.array(recs, dtype=np.uint32)
+
+
+def test_edge_exponents_and_degenerate_inputs():
+    recs = crafted_g1_records()
+    t = _oracle.Trace(0, recs)
+    for r in list(range(0, 4)) + [510, 511, 512, 1023, 1024, 1535, 2047]:
+        assert t.check_row(r) == -1, r
+    # x == offset with an odd exponent: the very first addition is R + P with R == P -> not provable, loudly
+    from oracle.py import bn254 as bn
+    from oracle.py import sipp_native as sn
+    x = bn.g1_mul(bn.G1, 77)
+    bad = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(x) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 4))], dtype=np.uint32)
+    with pytest.raises(RuntimeError):
+        _oracle.Trace(0, bad)
