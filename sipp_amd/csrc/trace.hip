@@ -33,6 +33,7 @@ struct Fld<1> {
     static __device__ __forceinline__ T add(const T& a, const T& b) { return fq::add(a, b); }
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return fq::sub(a, b); }
     static __device__ __forceinline__ T mul(const T& a, const T& b) { return fq::mul(a, b); }
+    static __device__ __forceinline__ T sqr(const T& a) { return fq::sqr(a); }
     static __device__ __forceinline__ T inv(const T& a) { return fq::inv(a); }
     static __device__ __forceinline__ bool is_zero(const T& a) { return fq::is_zero(a); }
     static __device__ __forceinline__ T load(const uint32_t* w) {  // 8 u32 standard form -> Montgomery
@@ -48,6 +49,7 @@ struct Fld<2> {
     static __device__ __forceinline__ T add(const T& a, const T& b) { return fq::add(a, b); }
     static __device__ __forceinline__ T sub(const T& a, const T& b) { return fq::sub(a, b); }
     static __device__ __forceinline__ T mul(const T& a, const T& b) { return fq::mul(a, b); }
+    static __device__ __forceinline__ T sqr(const T& a) { return fq::sqr(a); }
     static __device__ __forceinline__ T inv(const T& a) { return fq::inv(a); }
     static __device__ __forceinline__ bool is_zero(const T& a) { return fq::is_zero(a); }
     static __device__ __forceinline__ T load(const uint32_t* w) {
@@ -63,12 +65,12 @@ struct Jac {
 template <int EXT>
 __device__ __forceinline__ Jac<EXT> jac_dbl(const Jac<EXT>& p) {
     using F = Fld<EXT>;
-    auto A = F::mul(p.x, p.x), B = F::mul(p.y, p.y), C = F::mul(B, B);
+    auto A = F::sqr(p.x), B = F::sqr(p.y), C = F::sqr(B);
     auto t = F::add(p.x, B);
-    auto D = F::sub(F::sub(F::mul(t, t), A), C);
+    auto D = F::sub(F::sub(F::sqr(t), A), C);
     D = F::add(D, D);
     auto E = F::add(F::add(A, A), A);
-    auto Fv = F::mul(E, E);
+    auto Fv = F::sqr(E);
     Jac<EXT> r;
     r.x = F::sub(Fv, F::add(D, D));
     auto C8 = F::add(C, C);
@@ -83,22 +85,22 @@ __device__ __forceinline__ Jac<EXT> jac_dbl(const Jac<EXT>& p) {
 template <int EXT>
 __device__ __forceinline__ Jac<EXT> jac_add(const Jac<EXT>& p, const Jac<EXT>& q) {
     using F = Fld<EXT>;
-    auto z1z1 = F::mul(p.z, p.z), z2z2 = F::mul(q.z, q.z);
+    auto z1z1 = F::sqr(p.z), z2z2 = F::sqr(q.z);
     auto u1 = F::mul(p.x, z2z2), u2 = F::mul(q.x, z1z1);
     auto s1 = F::mul(F::mul(p.y, q.z), z2z2), s2 = F::mul(F::mul(q.y, p.z), z1z1);
     auto h = F::sub(u2, u1);
     auto i = F::add(h, h);
-    i = F::mul(i, i);
+    i = F::sqr(i);
     auto j = F::mul(h, i);
     auto rr = F::sub(s2, s1);
     rr = F::add(rr, rr);
     auto v = F::mul(u1, i);
     Jac<EXT> r;
-    r.x = F::sub(F::sub(F::mul(rr, rr), j), F::add(v, v));
+    r.x = F::sub(F::sub(F::sqr(rr), j), F::add(v, v));
     auto s1j = F::mul(s1, j);
     r.y = F::sub(F::mul(rr, F::sub(v, r.x)), F::add(s1j, s1j));
     auto zz = F::add(p.z, q.z);
-    r.z = F::mul(F::sub(F::sub(F::mul(zz, zz), z1z1), z2z2), h);
+    r.z = F::mul(F::sub(F::sub(F::sqr(zz), z1z1), z2z2), h);
     return r;
 }
 
