@@ -69,6 +69,12 @@ def lib():
         return _lib
     if not os.path.exists(SO):
         raise SippError(-7, "libsipp_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch ships its own libamdhip64: load torch FIRST so that libsipp_hip.so binds to the same HIP runtime
+    # (two runtimes in one process make hipGetDeviceCount fail in whichever comes second)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(SO)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)

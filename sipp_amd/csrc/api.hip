@@ -37,6 +37,10 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
         return SIPP_E_UNSUPPORTED;
     }
     auto bail = [&](int rc) {
+        // no ctx survives to carry the message: say it on stderr (creation failures are configuration errors)
+        hipError_t last = hipGetLastError();
+        fprintf(stderr, "sipp_ctx_create(device %d, workspace %zu bytes) failed with status %d (last HIP error: %s)\n", device,
+                workspace_bytes, rc, hipGetErrorString(last));
         sipp_ctx_destroy(ctx);
         return rc;
     };

@@ -120,3 +120,17 @@ def test_edge_exponents_and_degenerate_inputs(ctx):
     with pytest.raises(sipp_amd.SippError) as e:
         ctx.prove(0, bad)
     assert e.value.code == -8
+
+
+def test_max_size_n4096_g1_proof_verifies():
+    """largest BASELINE config: n = 4096 -> 4095 G1 IO records, N = 2^21 rows, LDE 2^22 rows (three-pass NTT),
+    82 GB arena.  The oracle's verifier must accept the proof."""
+    import sipp_amd
+    ios = np.load("tests/golden/sipp_n4096_ios.npz")["g1"]
+    c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(0, ios.shape[0]))
+    try:
+        pf = c.prove(0, ios)
+    finally:
+        c.close()
+    assert int(pf[2]) == 21 and int(pf[3]) == 4096
+    assert _oracle.stark_verify(pf) == 0
