@@ -453,37 +453,60 @@ struct DivArgs {
     const uint64_t* zip[2];
     uint64_t* qout;  // [2 batches][2][n]
 };
-__global__ void __launch_bounds__(1024) fri_divide_kernel(DivArgs a) {
-    // one block per batch; tiles of 1024 consecutive coefficients from the top down (coalesced), suffix scan in LDS
+// three launches so that the division scales with n:
+//   fri_divide_tiles   one block per (1024-coefficient tile, batch): v_k = F_k z^k, inclusive suffix scan inside the
+//                      tile (LDS), tile total
+//   fri_divide_carry   one block per batch: exclusive suffix scan of the tile totals
+//   fri_divide_finish  q_{k-1} = (tile scan + carry) z^-k
+__global__ void __launch_bounds__(1024) fri_divide_tiles(DivArgs a, uint64_t* __restrict__ scan, uint64_t* __restrict__ totals) {
     __shared__ uint64_t s0[1024], s1[1024];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const size_t n = a.n;
+    const int b = blockIdx.y, t = threadIdx.x;
+    const size_t n = a.n, k = (size_t)blockIdx.x * 1024 + t;
     const uint64_t* zp = a.zp[b];
-    const uint64_t* zip = a.zip[b];
-    uint64_t* q0 = a.qout + (size_t)b * 2 * n;
-    uint64_t* q1 = q0 + n;
-    E2 carry{0, 0};  // sum over all higher tiles
-    for (size_t base = n; base > 0;) {
-        const size_t tile = base >= 1024 ? 1024 : base;
-        base -= tile;
-        const size_t k = base + t;
-        E2 v{0, 0};
-        if ((size_t)t < tile) {
-            uint64_t c0 = 0, c1 = 0;
-            for (int sl = 0; sl < a.slices; sl++) {
-                const uint64_t* p = a.partial + (size_t)sl * 4 * n + (size_t)b * 2 * n;
-                c0 = gl::add(c0, p[k]);
-                c1 = gl::add(c1, p[n + k]);
-            }
-            v = gl::mul(E2{c0, c1}, E2{zp[k], zp[n + k]});
-        }
-        // inclusive suffix scan over the tile: S[t] = sum_{t' >= t} v[t']
+    uint64_t c0 = 0, c1 = 0;
+    for (int sl = 0; sl < a.slices; sl++) {
+        const uint64_t* p = a.partial + (size_t)sl * 4 * n + (size_t)b * 2 * n;
+        c0 = gl::add(c0, p[k]);
+        c1 = gl::add(c1, p[n + k]);
+    }
+    E2 v = gl::mul(E2{c0, c1}, E2{zp[k], zp[n + k]});
+    s0[t] = v.c0;
+    s1[t] = v.c1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        E2 o{0, 0};
+        if (t + off < 1024) o = E2{s0[t + off], s1[t + off]};
+        __syncthreads();
+        v = gl::add(v, o);
         s0[t] = v.c0;
         s1[t] = v.c1;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
+    }
+    uint64_t* sc = scan + (size_t)b * 2 * n;
+    sc[k] = v.c0;
+    sc[n + k] = v.c1;
+    if (t == 0) {
+        totals[((size_t)b * gridDim.x + blockIdx.x) * 2] = v.c0;
+        totals[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = v.c1;
+    }
+}
+
+__global__ void __launch_bounds__(256) fri_divide_carry(uint64_t* __restrict__ totals, int ntiles) {
+    // exclusive suffix sums over the tile totals of one batch (ntiles <= 2^14): serial chunks of a block-wide scan
+    __shared__ uint64_t s0[256], s1[256];
+    uint64_t* tt = totals + (size_t)blockIdx.x * ntiles * 2;
+    const int t = threadIdx.x;
+    E2 carry{0, 0};
+    for (int base = ((ntiles + 255) / 256 - 1) * 256; base >= 0; base -= 256) {
+        const int idx = base + t;
+        E2 v{0, 0};
+        if (idx < ntiles) v = E2{tt[2 * idx], tt[2 * idx + 1]};
+        s0[t] = v.c0;
+        s1[t] = v.c1;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
             E2 o{0, 0};
-            if (t + off < 1024) o = E2{s0[t + off], s1[t + off]};
+            if (t + off < 256) o = E2{s0[t + off], s1[t + off]};
             __syncthreads();
             v = gl::add(v, o);
             s0[t] = v.c0;
@@ -491,18 +514,34 @@ __global__ void __launch_bounds__(1024) fri_divide_kernel(DivArgs a) {
             __syncthreads();
         }
         const E2 total{s0[0], s1[0]};
-        if ((size_t)t < tile) {
-            const E2 S = gl::add(v, carry);  // S_k = sum_{j >= k} F_j z^j
-            if (k >= 1) {
-                const E2 q = gl::mul(S, E2{zip[k], zip[n + k]});
-                q0[k - 1] = q.c0;
-                q1[k - 1] = q.c1;
-            }
+        const E2 after = t + 1 < 256 ? E2{s0[t + 1], s1[t + 1]} : E2{0, 0};
+        __syncthreads();
+        if (idx < ntiles) {
+            const E2 ex = gl::add(after, carry);  // sum over all tiles after idx
+            tt[2 * idx] = ex.c0;
+            tt[2 * idx + 1] = ex.c1;
         }
         carry = gl::add(carry, total);
         __syncthreads();
     }
-    if (t == 0) {
+}
+
+__global__ void __launch_bounds__(1024) fri_divide_finish(DivArgs a, const uint64_t* __restrict__ scan,
+                                                         const uint64_t* __restrict__ totals) {
+    const int b = blockIdx.y;
+    const size_t n = a.n, k = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint64_t* zip = a.zip[b];
+    const uint64_t* sc = scan + (size_t)b * 2 * n;
+    uint64_t* q0 = a.qout + (size_t)b * 2 * n;
+    uint64_t* q1 = q0 + n;
+    const E2 carry{totals[((size_t)b * gridDim.x + blockIdx.x) * 2], totals[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1]};
+    const E2 S = gl::add(E2{sc[k], sc[n + k]}, carry);  // S_k = sum_{j >= k} F_j z^j
+    if (k >= 1) {
+        const E2 q = gl::mul(S, E2{zip[k], zip[n + k]});
+        q0[k - 1] = q.c0;
+        q1[k - 1] = q.c1;
+    }
+    if (k == n - 1) {
         q0[n - 1] = 0;
         q1[n - 1] = 0;
     }
@@ -735,9 +774,16 @@ int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[
     d.partial = partial; d.slices = slices; d.n = n;
     d.zp[0] = d_zp[0]; d.zp[1] = d_zp[1]; d.zip[0] = d_zip[0]; d.zip[1] = d_zip[1];
     d.qout = q;
+    const unsigned ntiles = (unsigned)(n / 1024);
+    uint64_t* scan = arena_alloc_t<uint64_t>(ctx, 4 * n);
+    uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)4 * ntiles);
+    if (!scan || !totals) return SIPP_E_NOMEM;
+    if (n % 1024) return sipp_fail(ctx, SIPP_E_BADARG, "fri_divide: n must be a multiple of 1024");
     {
         ProfScope ps(ctx, "fri_divide");
-        hipLaunchKernelGGL(fri_divide_kernel, dim3(2), dim3(1024), 0, ctx->stream, d);
+        hipLaunchKernelGGL(fri_divide_tiles, dim3(ntiles, 2), dim3(1024), 0, ctx->stream, d, scan, totals);
+        hipLaunchKernelGGL(fri_divide_carry, dim3(2), dim3(256), 0, ctx->stream, totals, (int)ntiles);
+        hipLaunchKernelGGL(fri_divide_finish, dim3(ntiles, 2), dim3(1024), 0, ctx->stream, d, scan, totals);
         hipLaunchKernelGGL(fri_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, q, n, shift1, d_final);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
