@@ -1,8 +1,10 @@
-// sipp_amd/csrc/fq.cuh -- BN254 base field Fq on gfx950: 8 x u32 limbs, Montgomery form (R = 2^256).
+// sipp_amd/csrc/fq.cuh -- BN254 base field Fq on gfx950: 8 x u32 limbs, Montgomery form (R = 2^261).
 //
 // Used only by the trace-fill kernels (the native double-and-add / square-and-multiply chains whose
 // intermediate values become trace cells).  Replaces ark-bn254's Fq (reference Cargo.toml:9) on the device.
-// 32-bit limbs because the VALU is 32-bit: one limb product is ONE v_mad_u64_u32.
+// Values live in registers as 8 x 32-bit words; a product re-cuts its operands into 9 x 29-bit limbs so that every
+// column of the schoolbook product AND of the Montgomery reduction is a plain chain of v_mad_u64_u32 into one 64-bit
+// accumulator (18 terms < 2^58 never overflow): one instruction per limb product, no carry bookkeeping.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,14 +18,17 @@ struct Fq {
 // p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 __device__ __constant__ const uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
                                                0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-// -p^-1 mod 2^32
-constexpr uint32_t NINV = 0xe4866389u;
-// R^2 mod p (R = 2^256): to Montgomery form
-__device__ __constant__ const uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
-                                                0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+// p in 9 limbs of 29 bits, and -p^-1 mod 2^29
+constexpr uint32_t P29[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                             0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+constexpr uint32_t NINV29 = 0x04866389u;
+constexpr uint32_t M29 = (1u << 29) - 1;
+// R^2 mod p (R = 2^261): to Montgomery form
+__device__ __constant__ const uint32_t R2[8] = {0x659bac10u, 0xe1a2a074u, 0x5406005au, 0x63985586u,
+                                                0x2d3e2632u, 0xff54c580u, 0x34ea65a6u, 0x2a11a68cu};
 // R mod p: one in Montgomery form
-__device__ __constant__ const uint32_t ONE_M[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
-                                                   0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+__device__ __constant__ const uint32_t ONE_M[8] = {0x157ccc21u, 0x4e8384ebu, 0x0ce148c3u, 0xfb90a602u,
+                                                   0x819caa36u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};
 
 __device__ __forceinline__ Fq zero() {
     Fq r;
@@ -43,93 +48,105 @@ __device__ __forceinline__ bool is_zero(const Fq& a) {
     for (int i = 0; i < 8; i++) t |= a.l[i];
     return t == 0;
 }
+// All branch-free: carry chains (v_add_co / v_addc_co) and selects, so the compiler never emits exec-mask branches.
+// r = a - p and the final borrow (1 when a < p)
+__device__ __forceinline__ uint32_t sub_p_borrow(Fq& r, const Fq& a) {
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __builtin_subc(a.l[i], P[i], bw, &bw);
+    return bw;
+}
 __device__ __forceinline__ bool geq_p(const Fq& a) {
-#pragma unroll
-    for (int i = 7; i >= 0; i--) {
-        if (a.l[i] > P[i]) return true;
-        if (a.l[i] < P[i]) return false;
-    }
-    return true;
+    Fq d;
+    return sub_p_borrow(d, a) == 0;
 }
-__device__ __forceinline__ void sub_p(Fq& a) {
-    uint64_t borrow = 0;
+// a mod p for a < 2p
+__device__ __forceinline__ Fq reduce_once(const Fq& a, uint32_t carry = 0) {
+    Fq d, r;
+    const uint32_t bw = sub_p_borrow(d, a);
+    const bool take = carry || !bw;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] - P[i] - borrow;
-        a.l[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-}
-__device__ __forceinline__ Fq add(const Fq& a, const Fq& b) {
-    Fq r;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.l[i] + b.l[i];
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    if (c || geq_p(r)) sub_p(r);
+    for (int i = 0; i < 8; i++) r.l[i] = take ? d.l[i] : a.l[i];
     return r;
 }
+__device__ __forceinline__ void sub_p(Fq& a) {
+    Fq d;
+    sub_p_borrow(d, a);
+    a = d;
+}
+__device__ __forceinline__ Fq add(const Fq& a, const Fq& b) {
+    Fq s;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
+    return reduce_once(s, c);
+}
 __device__ __forceinline__ Fq sub(const Fq& a, const Fq& b) {
-    Fq r;
-    uint64_t borrow = 0;
+    Fq d, e, r;
+    uint32_t bw = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
-        r.l[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    if (borrow) {
-        uint64_t c = 0;
+    for (int i = 0; i < 8; i++) d.l[i] = __builtin_subc(a.l[i], b.l[i], bw, &bw);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)r.l[i] + P[i];
-            r.l[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
+    for (int i = 0; i < 8; i++) e.l[i] = __builtin_addc(d.l[i], P[i], c, &c);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = bw ? e.l[i] : d.l[i];
     return r;
 }
 __device__ __forceinline__ Fq neg(const Fq& a) { return sub(zero(), a); }
 __device__ __forceinline__ Fq dbl(const Fq& a) { return add(a, a); }
 
-// Montgomery product a * b * R^-1 mod p (CIOS, 32-bit words)
-__device__ __forceinline__ Fq mul(const Fq& a, const Fq& b) {
-    uint32_t t[10];
+// 8 x 32 -> 9 x 29 bits
+__device__ __forceinline__ void cut29(uint32_t (&o)[9], const Fq& a) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.l[j] * b.l[i] + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (uint32_t)c;
-        t[9] = (uint32_t)(c >> 32);
-        uint32_t m = t[0] * NINV;
-        c = (uint64_t)m * P[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c += (uint64_t)m * P[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = t[9] + (uint32_t)(c >> 32);
+    for (int k = 0; k < 9; k++) {
+        const int w = (29 * k) >> 5, sh = (29 * k) & 31;
+        uint32_t v = a.l[w] >> sh;
+        if (sh > 3 && w < 7) v |= a.l[w + 1] << (32 - sh);
+        o[k] = v & M29;
     }
-    Fq r;
+}
+// 9 x 29 (each limb < 2^29) -> 8 x 32; bits above 256 are dropped (callers guarantee the value is < 2p < 2^255)
+__device__ __forceinline__ Fq join29(const uint32_t (&r)[9]) {
+    Fq o;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = t[i];
-    if (t[8] || geq_p(r)) sub_p(r);
-    return r;
+    for (int j = 0; j < 8; j++) {
+        const int k = (32 * j) / 29, sh = 32 * j - 29 * k;  // word j starts at bit sh of limb k
+        uint32_t v = r[k] >> sh;
+        v |= r[k + 1] << (29 - sh);
+        if (58 - sh < 32 && k + 2 < 9) v |= r[k + 2] << (58 - sh);
+        o.l[j] = v;
+    }
+    return o;
+}
+
+// Montgomery product a * b * R^-1 mod p, column-wise (Comba) in radix 2^29
+__device__ __forceinline__ Fq mul(const Fq& a, const Fq& b) {
+    uint32_t x[9], y[9], m[9], r[9];
+    cut29(x, a);
+    cut29(y, b);
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) acc += (uint64_t)x[i] * y[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (i < k && j >= 0 && j < 9) acc += (uint64_t)m[i] * P29[j];
+        }
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * NINV29) & M29;
+            acc += (uint64_t)m[k] * P29[0];
+        } else {
+            r[k - 9] = (uint32_t)acc & M29;
+        }
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+    return reduce_once(join29(r));
 }
 __device__ __forceinline__ Fq sqr(const Fq& a) { return mul(a, a); }
 
