@@ -29,57 +29,82 @@ int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* i
 namespace host {
 
 // Same algorithm as the device permutation (poseidon.cuh): dense circulant MDS in the 8 full rounds, the sparse
-// "fast" form in the 22 partial rounds -- about 0.5 us on a host core, so that observing ~27 k opening words of
-// the widest STARK costs a few ms instead of tens.  Checked against the device kernel by every proof parity test.
-inline void poseidon_permute(uint64_t s[12]) {
-    typedef unsigned __int128 u128;
+// "fast" form in the 22 partial rounds, written for a 64-bit host core: u128 products, a three-instruction-deep
+// reduction, values kept as any u64 congruent to the state word until the end, MDS on the 32-bit halves so its sums
+// stay in u64.  Observing the ~27 k opening words of the widest STARK is ~3.4 k sequential permutations on the
+// proof's critical path.  Checked against the device kernel by every proof parity test.
+typedef unsigned __int128 u128;
+inline uint64_t red128(u128 v) {  // -> [0, 2^64), congruent, not canonical
+    const uint64_t lo = (uint64_t)v, hi = (uint64_t)(v >> 64);
+    const uint64_t hh = hi >> 32, hl = hi & gl::EPS;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= gl::EPS;
+    const uint64_t t1 = (hl << 32) - hl;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += gl::EPS;
+    return r;
+}
+// v - c * 2^32 for any u64 v (2^128 = -2^32 mod p: c lost carries of a u128 accumulator)
+inline uint64_t sub_carries(uint64_t v, uint32_t c) {
+    const uint64_t k = (uint64_t)c << 32, d = v - k;
+    return v < k ? d - gl::EPS : d;
+}
+inline uint64_t sbox7(uint64_t x) {
+    const uint64_t x2 = red128((u128)x * x), x3 = red128((u128)x2 * x), x4 = red128((u128)x2 * x2);
+    return red128((u128)x3 * x4);
+}
+inline void full_round(uint64_t s[12], int rnd) {
     static const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    auto sbox = [](uint64_t x) {
-        uint64_t x2 = gl::sqr(x), x3 = gl::mul(x2, x), x4 = gl::sqr(x2);
-        return gl::mul(x3, x4);
-    };
-    auto red = [](u128 v) { return gl::reduce128((uint64_t)(v >> 64), (uint64_t)v); };
-    auto full = [&](int rnd) {
-        uint64_t t[12], out[12];
-        for (int i = 0; i < 12; i++) t[i] = sbox(gl::add(s[i], SIPP_POSEIDON_RC[12 * rnd + i]));
-        for (int r = 0; r < 12; r++) {
-            u128 acc = 0;
-            for (int i = 0; i < 12; i++) acc += (u128)t[(i + r) % 12] * CIRC[i];
-            if (r == 0) acc += (u128)t[0] * 8;
-            out[r] = red(acc);
+    uint64_t lo[24], hi[24];
+    for (int i = 0; i < 12; i++) {
+        const uint64_t t = sbox7(gl::add_nc(s[i], SIPP_POSEIDON_RC[12 * rnd + i]));
+        lo[i] = lo[i + 12] = t & gl::EPS;
+        hi[i] = hi[i + 12] = t >> 32;
+    }
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+        for (int i = 0; i < 12; i++) {
+            al += lo[i + r] * CIRC[i];
+            ah += hi[i + r] * CIRC[i];
         }
-        for (int r = 0; r < 12; r++) s[r] = out[r];
-    };
-    for (int r = 0; r < 4; r++) full(r);
-    for (int i = 0; i < 12; i++) s[i] = gl::add(s[i], SIPP_POSEIDON_FAST_FIRST[i]);
+        if (r == 0) {
+            al += lo[0] * 8;
+            ah += hi[0] * 8;
+        }
+        s[r] = red128((u128)al + ((u128)ah << 32));
+    }
+}
+inline void poseidon_permute(uint64_t s[12]) {
+    for (int r = 0; r < 4; r++) full_round(s, r);
+    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], SIPP_POSEIDON_FAST_FIRST[i]);
     {
         uint64_t t[11];
         for (int i = 0; i < 11; i++) {
-            // 11 products < 2^128 each: accumulate in 192 bits as (hi carry count, u128)
             u128 acc = 0;
             uint32_t c = 0;
             for (int j = 0; j < 11; j++) {
-                u128 pr = (u128)s[j + 1] * SIPP_POSEIDON_FAST_MI[i * 11 + j];
+                const u128 pr = (u128)s[j + 1] * SIPP_POSEIDON_FAST_MI[i * 11 + j];
                 acc += pr;
                 c += acc < pr;
             }
-            t[i] = gl::sub(red(acc), (uint64_t)c << 32);  // 2^128 = -2^32
+            t[i] = sub_carries(red128(acc), c);
         }
         for (int i = 0; i < 11; i++) s[i + 1] = t[i];
     }
     for (int r = 0; r < 22; r++) {
-        const uint64_t x = gl::add(sbox(s[0]), SIPP_POSEIDON_FAST_SCALAR[r]);
+        const uint64_t x = gl::add_nc(sbox7(s[0]), SIPP_POSEIDON_FAST_SCALAR[r]);
         u128 acc = (u128)x * 25;
         uint32_t c = 0;
         for (int i = 0; i < 11; i++) {
-            u128 pr = (u128)s[i + 1] * SIPP_POSEIDON_FAST_WHAT[r * 11 + i];
+            const u128 pr = (u128)s[i + 1] * SIPP_POSEIDON_FAST_WHAT[r * 11 + i];
             acc += pr;
             c += acc < pr;
         }
-        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad(x, SIPP_POSEIDON_FAST_VS[r * 11 + i], s[i + 1]);
-        s[0] = gl::sub(red(acc), (uint64_t)c << 32);
+        for (int i = 0; i < 11; i++) s[i + 1] = red128((u128)x * SIPP_POSEIDON_FAST_VS[r * 11 + i] + s[i + 1]);
+        s[0] = sub_carries(red128(acc), c);
     }
-    for (int r = 26; r < 30; r++) full(r);
+    for (int r = 26; r < 30; r++) full_round(s, r);
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }
 
 struct Challenger {
