@@ -13,8 +13,12 @@
 //  * full-round MDS (circulant, entries <= 41): state split into 32-bit halves, each output is two
 //    chains of 12 v_mad_u64_u32 (32 x 32 + 64) and ONE 96-bit reduction.
 //  * the 22 partial rounds use the equivalent sparse factorisation (tables derived and verified in
-//    tools/gen_poseidon_header.py): 1 dense 11x11 pre-multiplication, then per round one 160-bit
-//    dot product and 11 multiply-adds instead of a dense MDS.
+//    tools/gen_poseidon_header.py): 1 dense 11x11 pre-multiplication, then per round a dot product and
+//    11 multiply-adds instead of a dense MDS -- evaluated LAZILY in two blocks of 11 rounds: lanes 1..11 are
+//    linear in the block's lane-0 values x_t, so inside a block nothing but lane 0 is reduced mod p and every
+//    term is (per-lane u32 half) x (22-bit limb of a wave-uniform constant) accumulated by ONE v_mad_u64_u32
+//    into a 64-bit accumulator that cannot overflow (Acc6).  594 + 121 such six-instruction MACs and 55
+//    reductions replace 242 mulmods, 242 160-bit MACs and 264 reductions.
 //  * the round loops are NOT unrolled (code stays inside the instruction cache); the per-lane loops are.
 #pragma once
 #include "gl.hpp"
@@ -28,6 +32,8 @@ __constant__ uint64_t c_fast_scalar[22];
 __constant__ uint64_t c_fast_mi[121];
 __constant__ uint64_t c_fast_vs[22 * 11];
 __constant__ uint64_t c_fast_what[22 * 11];
+__constant__ uint32_t c_blk3[2 * SIPP_POSEIDON_BLK_WORDS];
+__constant__ uint32_t c_mi3[363];
 
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
@@ -122,10 +128,120 @@ __device__ __forceinline__ void partial_rounds_fast(uint64_t s[12]) {
     }
 }
 
+// sum of (64-bit value) x (64-bit constant) products with the constant cut into limbs c0 + c1 2^22 + c2 2^44:
+// value = a[0] + a[1] 2^22 + a[2] 2^44 + 2^32 (a[3] + a[4] 2^22 + a[5] 2^44).  Each product is < 2^54, so a[] holds
+// 1024 of them.
+struct Acc6 {
+    uint64_t a[6];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] = 0;
+    }
+    __device__ __forceinline__ void set(uint32_t lo, uint32_t hi) {
+        zero();
+        a[0] = lo;
+        a[3] = hi;
+    }
+    __device__ __forceinline__ void mac(uint32_t xl, uint32_t xh, const uint32_t* __restrict__ c) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            a[j] += (uint64_t)xl * c[j];
+            a[3 + j] += (uint64_t)xh * c[j];
+        }
+    }
+    // t[0..3] = a0 + a1 2^22 + a2 2^44 (a's < 2^60: the sum is < 2^105)
+    static __device__ __forceinline__ void fold3(uint32_t (&t)[4], uint64_t a0, uint64_t a1, uint64_t a2) {
+        const uint32_t a1l = (uint32_t)a1, a1h = (uint32_t)(a1 >> 32), a2l = (uint32_t)a2, a2h = (uint32_t)(a2 >> 32);
+        uint32_t c = 0;
+        t[0] = __builtin_addc((uint32_t)a0, a1l << 22, c, &c);
+        t[1] = __builtin_addc((uint32_t)(a0 >> 32), (uint32_t)(a1 >> 10), c, &c);
+        t[2] = (a1h >> 10) + c;
+        c = 0;
+        t[1] = __builtin_addc(t[1], a2l << 12, c, &c);
+        t[2] = __builtin_addc(t[2], (uint32_t)(a2 >> 20), c, &c);
+        t[3] = (a2h >> 20) + c;
+    }
+    // -> [0, 2^64), congruent to the value, not canonical
+    __device__ __forceinline__ uint64_t reduce() const {
+        uint32_t l[4], h[4], v[5];
+        fold3(l, a[0], a[1], a[2]);
+        fold3(h, a[3], a[4], a[5]);
+        uint32_t c = 0;
+        v[0] = l[0];
+        v[1] = __builtin_addc(l[1], h[0], c, &c);
+        v[2] = __builtin_addc(l[2], h[1], c, &c);
+        v[3] = __builtin_addc(l[3], h[2], c, &c);
+        v[4] = h[3] + c;
+        const uint64_t r = gl::reduce128_nc(((uint64_t)v[3] << 32) | v[2], ((uint64_t)v[1] << 32) | v[0]);
+        const uint64_t t = (uint64_t)v[4] << 32;  // 2^128 = -2^32 (mod p)
+        const uint64_t d = r - t;
+        return r < t ? d - gl::EPS : d;
+    }
+};
+
+__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
+    constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_fast_first[i]);
+    {
+        uint32_t sl[11], sh[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) {
+            sl[j] = (uint32_t)s[j + 1];
+            sh[j] = (uint32_t)(s[j + 1] >> 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            Acc6 acc;
+            acc.zero();
+#pragma unroll
+            for (int j = 0; j < 11; j++) acc.mac(sl[j], sh[j], c_mi3 + 3 * (i * 11 + j));
+            s[i + 1] = acc.reduce();
+        }
+    }
+#pragma unroll 1
+    for (int b = 0; b < 22 / B; b++) {
+        const uint32_t* __restrict__ T = c_blk3 + SIPP_POSEIDON_BLK_WORDS * b;
+        uint32_t sl[11], sh[11], xl[B], xh[B];
+#pragma unroll
+        for (int j = 0; j < 11; j++) {
+            sl[j] = (uint32_t)s[j + 1];
+            sh[j] = (uint32_t)(s[j + 1] >> 32);
+        }
+        uint64_t s0 = s[0];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const uint64_t x = gl::add_nc(sbox(s0), c_fast_scalar[B * b + k]);
+            xl[k] = (uint32_t)x;
+            xh[k] = (uint32_t)(x >> 32);
+            const uint32_t* __restrict__ Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
+            Acc6 acc;
+            acc.zero();
+            acc.a[0] = (uint64_t)xl[k] * 25u;  // M[0][0] = CIRC[0] + DIAG[0]
+            acc.a[3] = (uint64_t)xh[k] * 25u;
+#pragma unroll
+            for (int i = 0; i < 11; i++) acc.mac(sl[i], sh[i], Wt + 3 * i);
+#pragma unroll
+            for (int j = 0; j < k; j++) acc.mac(xl[j], xh[j], Wt + 33 + 3 * j);
+            s0 = acc.reduce();
+        }
+        s[0] = s0;
+        const uint32_t* __restrict__ V = T + 33 * B + 3 * (B * (B - 1) / 2);
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            Acc6 acc;
+            acc.set(sl[i], sh[i]);
+#pragma unroll
+            for (int k = 0; k < B; k++) acc.mac(xl[k], xh[k], V + 3 * (i * B + k));
+            s[i + 1] = acc.reduce();
+        }
+    }
+}
+
 __device__ __forceinline__ void permute(uint64_t s[12]) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) full_round(s, r);
-    partial_rounds_fast(s);
+    partial_rounds_blocked(s);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) full_round(s, r);
 #pragma unroll

@@ -15,7 +15,11 @@ namespace {
 
 // hash_or_noop(leaf): ncols <= 4 -> the zero-padded elements are the digest; otherwise the
 // overwrite-mode sponge with rate 8 (hash_n_to_hash_no_pad).
-__global__ void __launch_bounds__(256) poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
+#ifndef SIPP_LEAVES_WPE
+#define SIPP_LEAVES_WPE 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIPP_LEAVES_WPE, SIPP_LEAVES_WPE)))
+poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                              uint32_t ncols, uint64_t n_leaves,
                                                              uint64_t* __restrict__ digests) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,16 +36,13 @@ __global__ void __launch_bounds__(256) poseidon_leaves_kernel(const uint64_t* __
                 if (q == (int)c) s[q] = v;
         }
     } else {
-        uint32_t c = 0;
-        for (; c + 8 <= ncols; c += 8) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * col_stride];
-            poseidon::permute(s);
-        }
-        if (c < ncols) {
+        // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
+#pragma unroll 1
+        for (uint32_t c = 0; c < ncols; c += 8) {
+            const uint32_t m = ncols - c;  // wave-uniform
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                if (c + i < ncols) s[i] = p[(size_t)(c + i) * col_stride];
+                if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
             poseidon::permute(s);
         }
     }
@@ -249,6 +250,8 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
                                           sizeof(SIPP_POSEIDON_FAST_VS)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_what), SIPP_POSEIDON_FAST_WHAT,
                                           sizeof(SIPP_POSEIDON_FAST_WHAT)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_blk3), SIPP_POSEIDON_BLK3, sizeof(SIPP_POSEIDON_BLK3)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_mi3), SIPP_POSEIDON_MI3, sizeof(SIPP_POSEIDON_MI3)));
     return SIPP_OK;
 }
 

@@ -180,6 +180,96 @@ def fast_perm(state, rc, tables):
     return s
 
 
+BLK = 11  # partial rounds per lazy block (22 = 2 x 11)
+
+
+def blocked_tables(vs, ws):
+    """Lazy ("blocked") evaluation of the sparse partial rounds.  Inside a block starting at round r0 with
+    S_i = state[i+1] and x_t = lane 0 after sbox + constant in round t:
+        state[i+1] before round r = S_i + sum_{r0 <= t < r} x_t * vs[t][i]
+        d_r = M00 * x_r + sum_i ws[r][i] * S_i + sum_{r0 <= t < r} x_t * CC[r][t],   CC[r][t] = sum_i ws[r][i] * vs[t][i]
+    so no lane is reduced mod p inside the block: every term is a multiply-accumulate with a CONSTANT, and the
+    kernel cuts constants into 22-bit limbs so that 64-bit accumulators never overflow (poseidon.cuh Acc6).
+    Returns CC as a dict (r, t) -> value."""
+    cc = {}
+    for r in range(N_PARTIAL):
+        r0 = r - r % BLK
+        for t in range(r0, r):
+            cc[(r, t)] = sum(ws[r][i] * vs[t][i] for i in range(W - 1)) % P
+    return cc
+
+
+def blocked_partial(s, scalars, vs, ws, cc):
+    """the 22 sparse rounds in blocked form (python model of the kernel); s is after FIRST and MI"""
+    m00 = mds_matrix()[0][0]
+    s = s[:]
+    for r0 in range(0, N_PARTIAL, BLK):
+        S = s[1:]
+        xs = []
+        s0 = s[0]
+        for r in range(r0, r0 + BLK):
+            x = pow(s0, 7, P)
+            if r < N_PARTIAL - 1:
+                x = (x + scalars[r + 1]) % P
+            s0 = (m00 * x + sum(ws[r][i] * S[i] for i in range(W - 1)) + sum(xs[t - r0] * cc[(r, t)] for t in range(r0, r))) % P
+            xs.append(x)
+        s = [s0] + [(S[i] + sum(xs[k] * vs[r0 + k][i] for k in range(BLK))) % P for i in range(W - 1)]
+    return s
+
+
+def blocked_perm(state, rc, tables, cc):
+    first, scalars, Mi, vs, ws = tables
+    M = mds_matrix()
+    s = state[:]
+    rnd = 0
+    for _ in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    s = [(x + c) % P for x, c in zip(s, first)]
+    s = mat_vec(Mi, s)
+    s = blocked_partial(s, scalars, vs, ws, cc)
+    rnd += N_PARTIAL
+    for _ in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    return s
+
+
+def limbs3(c):
+    """22 + 22 + 20 bits"""
+    assert 0 <= c < P
+    return [c & 0x3FFFFF, (c >> 22) & 0x3FFFFF, c >> 44]
+
+
+def blocked_words(vs, ws, cc):
+    """u32 table read by poseidon.cuh partial_rounds_blocked: per block [ per local round k: ws[r][0..10] then
+    CC[r][r0..r0+k-1] ] then vs transposed [i][k]; every constant as 3 limbs."""
+    out = []
+    for r0 in range(0, N_PARTIAL, BLK):
+        for k in range(BLK):
+            r = r0 + k
+            for i in range(W - 1):
+                out += limbs3(ws[r][i])
+            for t in range(r0, r):
+                out += limbs3(cc[(r, t)])
+        for i in range(W - 1):
+            for k in range(BLK):
+                out += limbs3(vs[r0 + k][i])
+    assert len(out) == (N_PARTIAL // BLK) * (33 * BLK + 3 * (BLK * (BLK - 1) // 2) + 33 * BLK)
+    return out
+
+
+def fmt32(vals, per=8):
+    out = []
+    for i in range(0, len(vals), per):
+        out.append("    " + ", ".join("0x%06xu" % v for v in vals[i:i + per]) + ",")
+    return "\n".join(out)
+
+
 def fmt(vals, per=4):
     out = []
     for i in range(0, len(vals), per):
@@ -192,12 +282,14 @@ def main():
     first, scalars = derive_fast_partial(rc)
     Mi, vs, ws = sparse_factor()
     tables = (first, scalars, Mi, vs, ws)
+    cc = blocked_tables(vs, ws)
     import random
     rnd = random.Random(1)
     for t in range(8):
         st = [rnd.randrange(P) for _ in range(12)] if t else [0] * 12
         a, b = naive_perm(st, rc), fast_perm(st, rc, tables)
         assert a == b, ("fast partial rounds mismatch", t)
+        assert a == blocked_perm(st, rc, tables, cc), ("blocked partial rounds mismatch", t)
     kat0 = naive_perm([0] * 12, rc)
     assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
 
@@ -222,6 +314,12 @@ def main():
         f.write("static const uint64_t SIPP_POSEIDON_FAST_MI[121] = {\n" + fmt(mi_flat) + "\n};\n")
         f.write("static const uint64_t SIPP_POSEIDON_FAST_VS[22*11] = {\n" + fmt([x for r in vs for x in r]) + "\n};\n")
         f.write("static const uint64_t SIPP_POSEIDON_FAST_WHAT[22*11] = {\n" + fmt([x for r in ws for x in r]) + "\n};\n")
+        f.write("// blocked (lazy) partial rounds, constants in 22/22/20-bit limbs: see blocked_words() in tools/gen_poseidon_header.py\n")
+        bw = blocked_words(vs, ws, cc)
+        f.write("#define SIPP_POSEIDON_BLK_ROUNDS %d\n#define SIPP_POSEIDON_BLK_WORDS %d\n" % (BLK, len(bw) // (N_PARTIAL // BLK)))
+        f.write("static const uint32_t SIPP_POSEIDON_BLK3[%d] = {\n" % len(bw) + fmt32(bw) + "\n};\n")
+        mi3 = [w for v in mi_flat for w in limbs3(v)]
+        f.write("static const uint32_t SIPP_POSEIDON_MI3[363] = {\n" + fmt32(mi3) + "\n};\n")
     assert all(Mi[0][j] == (1 if j == 0 else 0) for j in range(12)) and all(Mi[i][0] == 0 for i in range(1, 12))
     print("ok: headers written; fast-partial tables verified against naive permutation")
 
