@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=128, help="pairings per SIPP instance (fixture must exist)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="instances proved concurrently for the secondary `pipelined` figure (1 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -139,7 +141,47 @@ def main():
             e["ms"] += v["ms"]
         c.profile(False)
     from sipp_amd import dist_util
-    elapsed = dist_util.max_over_ranks(elapsed, device="cuda")
+
+    def dist_util_max(x):
+        return dist_util.max_over_ranks(x, device="cuda")
+
+    elapsed = dist_util_max(elapsed)
+
+    # secondary figure, outside the timed region: `inflight` independent instances proved concurrently on this GPU
+    # (3 streams each).  One instance leaves issue slots idle in its latency-bound phases (chains, Fiat-Shamir round
+    # trips, FRI tail); a server with a queue of proofs fills them.  `value` above stays the single-instance number.
+    pipelined = None
+    if args.inflight > 1 and not serial and sum(ws) * args.inflight < (200 << 30):
+        extra = []
+        for _ in range(args.inflight - 1):
+            row = []
+            for k in range(3):
+                if prios[k]:
+                    os.environ["SIPP_STREAM_PRIORITY"] = prios[k]
+                else:
+                    os.environ.pop("SIPP_STREAM_PRIORITY", None)
+                row.append(sipp_amd.Ctx(device=local_rank, workspace_bytes=ws[k]))
+            extra.append(row)
+        os.environ.pop("SIPP_STREAM_PRIORITY", None)
+        groups = [ctxs] + extra
+        pool2 = ThreadPoolExecutor(max_workers=3 * args.inflight)
+        jobs = [(g, k) for k in (1, 0, 2) for g in range(args.inflight)]
+
+        def pstep():
+            return list(pool2.map(lambda gk: groups[gk[0]][gk[1]].prove(gk[1], ios[gk[1]]), jobs))
+
+        pstep()
+        barrier()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            pstep()
+        barrier()
+        dtp = dist_util_max(time.perf_counter() - tp)
+        pipelined = {"instances_in_flight": args.inflight, "ms_per_instance": 1e3 * dtp / (args.steps * args.inflight),
+                     "value": args.n * world * args.inflight * args.steps / dtp, "unit": "pairings/s"}
+        for row in extra:
+            for c in row:
+                c.close()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -162,7 +204,7 @@ def main():
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected with
         # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_d_pmc.json")
         if args.n == 128 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         out = {
@@ -189,6 +231,7 @@ def main():
             "stark_bytes_alg_GBs": sum(8.0 * (1 << s[0]) * (12 * s[1] + 12 * s[2] + 7 * s[3]) for s in shapes) / (ms_per_step * 1e-3) / 1e9,
             "proof_words": [int(len(p)) for p in proofs],
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms],
+            "pipelined": pipelined,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ios, shapes)

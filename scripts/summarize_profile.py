@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of scripts/profile_round.sh into the small summaries committed under profiles/.
+usage: summarize_profile.py gpurun_out/prof_<tag> profiles/<prefix>"""
+import collections, csv, json, re, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def kname(s):
+    s = s.replace("(anonymous namespace)::", "")
+    s = re.sub(r"^void ", "", s)
+    return re.split(r"[<(]", s)[0]
+
+
+def counters(tag):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open("%s/%s/run_counter_collection.csv" % (src, tag))):
+        k = kname(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in disp.items()}
+
+
+shutil.copy("%s/stats/run_kernel_stats.csv" % src, dst + "_bench_n128_kernel_stats.csv")
+shutil.copy("%s/bench_line.json" % src, dst + "_bench_n128_bench_line.json")
+f, nf = counters("pmc_f")
+w, nw = counters("pmc_w")
+leaf = ("poseidon_leaves_kernel", "poseidon_leaves_quad_kernel")
+fetch_kb = sum(f[k]["FETCH_SIZE"] for k in leaf)
+write_kb = sum(w[k]["WRITE_SIZE"] for k in leaf)
+launches = sum(nf[k] for k in leaf)
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "kernel": "poseidon_leaves (one-state-per-lane + four-lanes-per-state kernels)",
+    "launches": launches,
+    "FETCH_SIZE_kb_sum": fetch_kb,
+    "WRITE_SIZE_kb_sum": write_kb,
+    "calibration": "scripts/ubench/fetch_calib.hip: 1 GiB read with this kernel's 8-B-per-lane column pattern reports FETCH_SIZE = 524,293.5 KB (exactly 1/2, as MI355X_MICROARCH.md section HBM says for wide coalesced reads); 1 GiB written reports WRITE_SIZE = 1,048,576 KB (exact)",
+    "fetch_correction": 2.0,
+    "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0 / launches,
+    "ntt_pass": {"launches": nf.get("ntt_pass_kernel", 0), "FETCH_SIZE_kb_sum": f["ntt_pass_kernel"]["FETCH_SIZE"],
+                 "WRITE_SIZE_kb_sum": w["ntt_pass_kernel"]["WRITE_SIZE"]},
+}
+i, ni = counters("pmc_i")
+out["valu"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -- python3 scripts/perf_generic.py 16 1024",
+               "per_kernel": {k: {"SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_WAVES": v["SQ_WAVES"], "dispatches": ni[k],
+                                  "valu_insts_per_wave": v["SQ_INSTS_VALU"] / max(1.0, v["SQ_WAVES"])}
+                              for k, v in i.items() if v["SQ_WAVES"] > 0 and not k.startswith("at::") and not k.startswith("__amd")}}
+json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
