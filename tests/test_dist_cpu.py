@@ -29,12 +29,19 @@ print("rank", rank, "ok")
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_rank_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=180, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
