@@ -136,6 +136,68 @@ GL_HD uint64_t root_of_unity(unsigned k) {
 // signed small integer -> field
 GL_HD uint64_t from_i64(int64_t v) { return v >= 0 ? (uint64_t)v : P - (uint64_t)(-v); }
 
+#if defined(__HIPCC__)
+#define GL_D __device__ __forceinline__
+// ---- lazy dot products on the 32-bit VALU ----
+// sum of (64-bit value x) x (64-bit value c) products with c cut into limbs c0 + c1 2^22 + c2 2^44 (22 + 22 + 20 bits):
+// value = a[0] + a[1] 2^22 + a[2] 2^44 + 2^32 (a[3] + a[4] 2^22 + a[5] 2^44).  Each product is < 2^54, so a[] holds
+// 1024 of them.
+struct Acc6 {
+    uint64_t a[6];
+    GL_D void zero() {
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[j] = 0;
+    }
+    GL_D void set(uint32_t lo, uint32_t hi) {
+        zero();
+        a[0] = lo;
+        a[3] = hi;
+    }
+    GL_D void mac(uint32_t xl, uint32_t xh, const uint32_t* __restrict__ c) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            a[j] += (uint64_t)xl * c[j];
+            a[3 + j] += (uint64_t)xh * c[j];
+        }
+    }
+    // t[0..3] = a0 + a1 2^22 + a2 2^44 (a's < 2^60: the sum is < 2^105)
+    static GL_D void fold3(uint32_t (&t)[4], uint64_t a0, uint64_t a1, uint64_t a2) {
+        const uint32_t a1l = (uint32_t)a1, a1h = (uint32_t)(a1 >> 32), a2l = (uint32_t)a2, a2h = (uint32_t)(a2 >> 32);
+        uint32_t c = 0;
+        t[0] = __builtin_addc((uint32_t)a0, a1l << 22, c, &c);
+        t[1] = __builtin_addc((uint32_t)(a0 >> 32), (uint32_t)(a1 >> 10), c, &c);
+        t[2] = (a1h >> 10) + c;
+        c = 0;
+        t[1] = __builtin_addc(t[1], a2l << 12, c, &c);
+        t[2] = __builtin_addc(t[2], (uint32_t)(a2 >> 20), c, &c);
+        t[3] = (a2h >> 20) + c;
+    }
+    // -> [0, 2^64), congruent to the value, not canonical
+    GL_D uint64_t reduce() const {
+        uint32_t l[4], h[4], v[5];
+        fold3(l, a[0], a[1], a[2]);
+        fold3(h, a[3], a[4], a[5]);
+        uint32_t c = 0;
+        v[0] = l[0];
+        v[1] = __builtin_addc(l[1], h[0], c, &c);
+        v[2] = __builtin_addc(l[2], h[1], c, &c);
+        v[3] = __builtin_addc(l[3], h[2], c, &c);
+        v[4] = h[3] + c;
+        const uint64_t r = reduce128_nc(((uint64_t)v[3] << 32) | v[2], ((uint64_t)v[1] << 32) | v[0]);
+        const uint64_t t = (uint64_t)v[4] << 32;  // 2^128 = -2^32 (mod p)
+        const uint64_t d = r - t;
+        return r < t ? d - EPS : d;
+    }
+};
+
+// c -> limbs for Acc6::mac
+GL_D void limbs3(uint32_t (&o)[3], uint64_t c) {
+    o[0] = (uint32_t)c & 0x3FFFFFu;
+    o[1] = (uint32_t)(c >> 22) & 0x3FFFFFu;
+    o[2] = (uint32_t)(c >> 44);
+}
+#endif
+
 // ---- quadratic extension ----
 struct E2 {
     uint64_t c0, c1;

@@ -236,11 +236,25 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
             uint64_t va[16], vb[16];
             w += qvec<16>(w, c, va);
             w += qvec<16>(w, c, vb);
+            // 256 limb products: each output coefficient is ONE lazy dot product (gl::Acc6: six v_mad_u64_u32 per
+            // term, one reduction per coefficient) instead of 16 multiply-reduce-add steps
+            uint32_t a3[16][3], bl[16], bh[16];
 #pragma unroll
             for (int ii = 0; ii < 16; ii++) {
-                const uint64_t ai = gl::mul(coef, va[ii]);
+                gl::limbs3(a3[ii], va[ii]);
+                bl[ii] = (uint32_t)vb[ii];
+                bh[ii] = (uint32_t)(vb[ii] >> 32);
+            }
 #pragma unroll
-                for (int jj = 0; jj < 16; jj++) e[ii + jj] = gl::mad(ai, vb[jj], e[ii + jj]);
+            for (int k = 0; k < 31; k++) {
+                gl::Acc6 acc;
+                acc.zero();
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) {
+                    const int jj = k - ii;
+                    if (jj >= 0 && jj < 16) acc.mac(bl[jj], bh[jj], a3[ii]);
+                }
+                e[k] = gl::mad(coef, gl::canon(acc.reduce()), e[k]);
             }
         }
         const int nl = (int)*w++;
@@ -260,12 +274,19 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
         uint64_t d[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) {
-            uint64_t qp = 0;
+            // q * p limbs: the p limbs are 16-bit constants, so the two 32-bit halves of q accumulate in plain u64
+            uint64_t al = 0, ah = 0;
 #pragma unroll
             for (int ii = 0; ii < 17; ii++) {
                 const int jj = k - ii;
-                if (jj >= 0 && jj < 16) qp = gl::mad(q[ii], (uint64_t)a.p_limbs[jj], qp);
+                if (jj >= 0 && jj < 16) {
+                    al += (uint64_t)(uint32_t)q[ii] * a.p_limbs[jj];
+                    ah += (uint64_t)(uint32_t)(q[ii] >> 32) * a.p_limbs[jj];
+                }
             }
+            const uint64_t l = al + (ah << 32);
+            const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
+            const uint64_t qp = gl::reduce96(h, l);
             d[k] = gl::sub(e[k], gl::mul(sgn, qp));
         }
         const uint64_t wgt = (uint64_t)1 << (16 * grp);
