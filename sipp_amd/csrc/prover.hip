@@ -141,6 +141,10 @@ struct QuotArgs {
     uint64_t w_m;         // 2N-th root of unity
     uint32_t p_limbs[16];
     uint64_t* out;        // [2][m] leaf order
+    // quotient_rest: K constraints after the program; apow3 = their alpha-power weights (alpha_pow3_kernel layout)
+    int K;
+    const uint32_t* apow3;
+    uint64_t alphaK[2];   // alpha_c^K
 };
 
 struct QCtx {
@@ -314,6 +318,65 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
     a.part[((size_t)g * 2 + 1) * m + j] = gl::mul(c.acc1, a.seg_pow[2 * g + 1]);
 }
 
+// limbs (gl::limbs3) of the alpha powers the constraints after the program are weighted with, laid out in the order
+// quotient_rest_kernel consumes them so that one checked column is ONE contiguous 36-dword scalar fetch:
+//   head  [c][t][3]        t = 0..2  : range-table constraints, exponent K-1-t
+//   body  [k][c][slot][3]  slot 0..5 : lookup (first row, transition), permutation challenge 0 (first row, running
+//                                      product), challenge 1 (same) of checked column k
+__global__ void alpha_pow3_kernel(uint64_t a0, uint64_t a1, int K, int nc, uint32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = 2 * 3 + nc * 2 * 6;
+    if (t >= total) return;
+    int c, e;
+    if (t < 6) {
+        c = t / 3;
+        e = K - 1 - t % 3;
+    } else {
+        const int k = (t - 6) / 12, r = (t - 6) % 12, slot = r % 6;
+        c = r / 6;
+        e = K - 1 - (3 + 2 * k) - (slot >> 1) * 2 * nc - (slot & 1);
+    }
+    uint32_t l[3];
+    gl::limbs3(l, gl::pow(c ? a1 : a0, (uint64_t)e));
+    for (int q = 0; q < 3; q++) out[3 * t + q] = l[q];
+}
+
+// The K constraints after the program are a random linear combination with WAVE-UNIFORM coefficients:
+//   acc_c = acc_prog * alpha_c^K + sum_i v_i * alpha_c^(K-1-i).
+// The sum is taken lazily (gl::Acc6, six v_mad_u64_u32 per term and challenge, limbs of alpha^e from scalar loads)
+// in three groups that share a multiplier -- first-row constraints (x lagrange_first), transition constraints that
+// vanish on the last row (x z_last), and the rest -- so the per-constraint multiplications by lagrange_first / z_last
+// and the two Horner mulmods per constraint disappear.
+struct RestAcc {
+    gl::Acc6 a[2];
+    int terms;
+    uint64_t folded[2];
+    __device__ __forceinline__ void init() {
+        a[0].zero();
+        a[1].zero();
+        terms = 0;
+        folded[0] = folded[1] = 0;
+    }
+    // p0 / p1: limbs of the constraint's weight for challenge 0 / 1
+    __device__ __forceinline__ void mac(uint64_t v, const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1) {
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        a[0].mac(lo, hi, p0);
+        a[1].mac(lo, hi, p1);
+    }
+    // an accumulator holds 1024 terms: fold long before that (wave-uniform condition)
+    __device__ __forceinline__ void maybe_fold(int added) {
+        terms += added;
+        if (terms >= 960) {
+            for (int c = 0; c < 2; c++) {
+                folded[c] = gl::add(folded[c], gl::canon(a[c].reduce()));
+                a[c].zero();
+            }
+            terms = 0;
+        }
+    }
+    __device__ __forceinline__ uint64_t value(int c) const { return gl::add(folded[c], gl::canon(a[c].reduce())); }
+};
+
 __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const size_t m = (size_t)1 << a.log_m;
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -333,18 +396,28 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const uint64_t zl = gl::sub(x, a.g_inv);
     const uint64_t lf = gl::mul(gl::mul(zh, a.ninv), gl::inv(gl::sub(x, 1)));
     const uint64_t ll = gl::mul(gl::mul(gl::mul(zh, a.ninv), a.g_inv), gl::inv(zl));
+    const uint32_t* __restrict__ ap = a.apow3;
+    RestAcc F, T, R;  // x lagrange_first, x z_last, plain
+    F.init();
+    T.init();
+    R.init();
     // range table
     const uint64_t tl = c.local(0), tn = c.next(0);
     {
         const uint64_t d = gl::sub(tn, tl);
-        c.emit(gl::mul(lf, tl));
-        c.emit(gl::mul(zl, gl::mul(d, gl::sub(d, 1))));
-        c.emit(gl::mul(ll, gl::sub(tl, ((uint64_t)1 << a.tbits) - 1)));
+        F.mac(tl, ap, ap + 9);
+        T.mac(gl::mul(d, gl::sub(d, 1)), ap + 3, ap + 12);
+        R.mac(gl::mul(ll, gl::sub(tl, ((uint64_t)1 << a.tbits) - 1)), ap + 6, ap + 15);
     }
+    // One pass over the checked columns evaluates the lookup constraints AND the permutation constraints of both
+    // challenges (nine loads per column instead of fourteen); the exponent of each constraint follows from its
+    // position in the oracle's order: lookups 3 + 2k (+1), then per challenge 3 + 2 nc + 2 nc ch + 2k (+1).
     const int nm = a.nm, nc = a.nc;
-    constexpr int U = 4;
+    const uint64_t g0 = a.gamma[0], g1 = a.gamma[1];
+    const uint64_t tg0 = gl::add(tl, g0), tg1 = gl::add(tl, g1);
+    constexpr int U = 2;
     for (int k0 = 0; k0 < nc; k0 += U) {
-        uint64_t pin[U], ptab[U], npin[U], nptab[U];
+        uint64_t pin[U], ptab[U], npin[U], nptab[U], col[U], z0[U], zn0[U], z1[U], zn1[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int k = min(k0 + u, nc - 1);
@@ -352,42 +425,42 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
             ptab[u] = c.local(nm + nc + k);
             npin[u] = c.next(nm + k);
             nptab[u] = c.next(nm + nc + k);
+            col[u] = c.local(a.cbase + k);
+            z0[u] = a.zlde[(size_t)k * m + j];
+            zn0[u] = a.zlde[(size_t)k * m + c.jn];
+            z1[u] = a.zlde[(size_t)(nc + k) * m + j];
+            zn1[u] = a.zlde[(size_t)(nc + k) * m + c.jn];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (k0 + u < nc) {
-                c.emit(gl::mul(lf, gl::sub(pin[u], ptab[u])));
-                c.emit(gl::mul(zl, gl::mul(gl::sub(npin[u], pin[u]), gl::sub(npin[u], nptab[u]))));
+            const int k = k0 + u;
+            if (k < nc) {
+                const uint32_t* __restrict__ w0 = ap + 18 + 36 * k;  // [c][slot][3]
+                const uint32_t* __restrict__ w1 = w0 + 18;
+                F.mac(gl::sub(pin[u], ptab[u]), w0, w1);
+                T.mac(gl::mul_nc(gl::sub(npin[u], pin[u]), gl::sub(npin[u], nptab[u])), w0 + 3, w1 + 3);
+                const uint64_t cg0 = gl::add(col[u], g0), cg1 = gl::add(col[u], g1);
+                const uint64_t rhs0 = gl::mul_nc(gl::add(pin[u], g0), gl::add(ptab[u], g0));
+                const uint64_t rhs1 = gl::mul_nc(gl::add(pin[u], g1), gl::add(ptab[u], g1));
+                F.mac(gl::sub(z0[u], 1), w0 + 6, w1 + 6);
+                R.mac(gl::sub(gl::mul(zn0[u], rhs0), gl::mul(z0[u], gl::mul_nc(cg0, tg0))), w0 + 9, w1 + 9);
+                F.mac(gl::sub(z1[u], 1), w0 + 12, w1 + 12);
+                R.mac(gl::sub(gl::mul(zn1[u], rhs1), gl::mul(z1[u], gl::mul_nc(cg1, tg1))), w0 + 15, w1 + 15);
             }
         }
+        F.maybe_fold(3 * U);
+        T.maybe_fold(U);
+        R.maybe_fold(2 * U);
     }
-    for (int ch = 0; ch < 2; ch++) {
-        const uint64_t g = a.gamma[ch];
-        const uint64_t tg = gl::add(tl, g);
-        for (int k0 = 0; k0 < nc; k0 += U) {
-            uint64_t z[U], zn[U], col[U], pin[U], ptab[U];
+    uint64_t acc[2] = {c.acc0, c.acc1};
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int k = min(k0 + u, nc - 1);
-                z[u] = a.zlde[(size_t)(ch * nc + k) * m + j];
-                zn[u] = a.zlde[(size_t)(ch * nc + k) * m + c.jn];
-                col[u] = c.local(a.cbase + k);
-                pin[u] = c.local(nm + k);
-                ptab[u] = c.local(nm + nc + k);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (k0 + u < nc) {
-                    const uint64_t lhs = gl::mul(gl::add(col[u], g), tg);
-                    const uint64_t rhs = gl::mul(gl::add(pin[u], g), gl::add(ptab[u], g));
-                    c.emit(gl::mul(lf, gl::sub(z[u], 1)));
-                    c.emit(gl::sub(gl::mul(zn[u], rhs), gl::mul(z[u], lhs)));
-                }
-            }
-        }
+    for (int q = 0; q < 2; q++) {
+        uint64_t v = gl::mul(acc[q], a.alphaK[q]);
+        v = gl::add(v, R.value(q));
+        v = gl::mad(lf, F.value(q), v);
+        v = gl::mad(zl, T.value(q), v);
+        a.out[(size_t)q * m + j] = gl::mul(v, a.zh_inv[i & 1]);
     }
-    a.out[j] = gl::mul(c.acc0, a.zh_inv[i & 1]);
-    a.out[m + j] = gl::mul(c.acc1, a.zh_inv[i & 1]);
 }
 
 // =====================================================================================================
@@ -747,6 +820,18 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
         q.seg_pow = d_tab;
         q.seg_off = reinterpret_cast<const uint32_t*>(d_tab + 2 * ns);
         q.seg_cnt = q.seg_off + ns;
+    }
+    {
+        // alpha powers of the K constraints that follow the program (range table 3, lookups 2 nc, permutation 4 nc)
+        q.K = 3 + 6 * a->n_checked;
+        const int nw = 6 + 12 * a->n_checked;  // weights: one limb triple each
+        uint32_t* d_ap = arena_alloc_t<uint32_t>(ctx, (size_t)3 * nw);
+        if (!d_ap) return SIPP_E_NOMEM;
+        hipLaunchKernelGGL(alpha_pow3_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, alpha[0], alpha[1],
+                           q.K, a->n_checked, d_ap);
+        q.apow3 = d_ap;
+        q.alphaK[0] = gl::pow(alpha[0], (uint64_t)q.K);
+        q.alphaK[1] = gl::pow(alpha[1], (uint64_t)q.K);
     }
     {
         ProfScope ps(ctx, "quotient_prog");
