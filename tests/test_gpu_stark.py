@@ -134,3 +134,28 @@ def test_max_size_n4096_g1_proof_verifies():
         c.close()
     assert int(pf[2]) == 21 and int(pf[3]) == 4096
     assert _oracle.stark_verify(pf) == 0
+
+
+def test_concurrent_streams_are_deterministic():
+    """bench.py drives one ctx (= HIP stream + arena) per sub-proof from its own host thread, and several instances in
+    flight for the `pipelined` figure.  The proofs must not depend on that: two instances x three sub-proofs proved
+    concurrently, twice, equal the proofs of a single ctx run serially, word for word."""
+    from concurrent.futures import ThreadPoolExecutor
+    import sipp_amd
+    d = np.load("tests/golden/sipp_n8_ios.npz")
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    L = sipp_amd.lib()
+    serial_ctx = sipp_amd.Ctx(workspace_bytes=max(L.sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)))
+    want = [serial_ctx.prove(k, ios[k]) for k in range(3)]
+    serial_ctx.close()
+    groups = [[sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(k, ios[k].shape[0])) for k in range(3)] for _ in range(2)]
+    jobs = [(g, k) for g in range(2) for k in range(3)]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        for _ in range(2):
+            got = list(pool.map(lambda gk: groups[gk[0]][gk[1]].prove(gk[1], ios[gk[1]]), jobs))
+            for (g, k), pf in zip(jobs, got):
+                assert len(pf) == len(want[k]) and (pf == want[k]).all(), (g, k)
+    for row in groups:
+        for c in row:
+            c.close()
+    assert _oracle.stark_verify(want[0]) == 0
