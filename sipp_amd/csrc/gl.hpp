@@ -125,7 +125,23 @@ GL_HD uint64_t pow(uint64_t a, uint64_t e) {
     return r;
 }
 
-GL_HD uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+// a^(p - 2) with the addition chain for p - 2 = 2^64 - 2^32 - 1 = (31 ones) 0 (32 ones): 63 squarings + 9 products
+// instead of the 126 of square-and-multiply.  inv(0) = 0.
+GL_HD uint64_t sqr_n(uint64_t a, int n) {
+    for (int i = 0; i < n; i++) a = mul_nc(a, a);
+    return a;
+}
+GL_HD uint64_t inv(uint64_t a) {
+    const uint64_t t2 = mul_nc(mul_nc(a, a), a);            // 2 ones
+    const uint64_t t3 = mul_nc(mul_nc(t2, t2), a);          // 3 ones
+    const uint64_t t6 = mul_nc(sqr_n(t3, 3), t3);
+    const uint64_t t12 = mul_nc(sqr_n(t6, 6), t6);
+    const uint64_t t24 = mul_nc(sqr_n(t12, 12), t12);
+    const uint64_t t30 = mul_nc(sqr_n(t24, 6), t6);
+    const uint64_t t31 = mul_nc(mul_nc(t30, t30), a);       // 31 ones
+    const uint64_t t63 = mul_nc(sqr_n(t31, 32), t31);       // (31 ones)(0)(31 ones)
+    return mul(mul_nc(t63, t63), a);                        // (31 ones)(0)(32 ones)
+}
 
 GL_HD uint64_t root_of_unity(unsigned k) {
     uint64_t r = TWO_ADIC_ROOT;

@@ -14,13 +14,10 @@ using gl::E2;
 
 // =====================================================================================================
 // permutation Z:  Z[r] = prod_{r' < r} (c + g)(t + g) / ((pin + g)(ptab + g))
-// phase A: 256 lanes x 4 rows per block: batch-inverted ratios, block-local inclusive products
+// phase A: 256 lanes x ZR rows per block: batch-inverted ratios, block-local inclusive products
 // phase B: one block per Z column: exclusive scan of the block totals
 // phase C: Z = total_before_block * local_inclusive[r - 1]
 // =====================================================================================================
-constexpr int ZROWS = 4;
-constexpr int ZBLOCK = 256 * ZROWS;
-
 __device__ __forceinline__ uint64_t block_scan_mul_256(uint64_t v, uint64_t* s) {
     // inclusive multiplicative scan across 256 lanes (Hillis-Steele in LDS)
     const int t = threadIdx.x;
@@ -36,43 +33,55 @@ __device__ __forceinline__ uint64_t block_scan_mul_256(uint64_t v, uint64_t* s) 
     return v;
 }
 
+// ZR rows per lane: the lane's batch inversion (72 products) is shared by ZR rows -- 16 when the trace is long enough
+template <int ZR>
 __global__ void __launch_bounds__(256) z_phase_a(const uint64_t* __restrict__ trace, size_t n, int nm, int nc, int cbase,
                                                 uint64_t gamma0, uint64_t gamma1, uint64_t* __restrict__ zv,
                                                 uint64_t* __restrict__ totals) {
     __shared__ uint64_t s[256];
     const int zi = blockIdx.y, i = zi / nc, j = zi % nc;
     const uint64_t g = i ? gamma1 : gamma0;
-    const size_t r0 = (size_t)blockIdx.x * ZBLOCK + (size_t)threadIdx.x * ZROWS;
-    const uint64_t* col = trace + (size_t)(cbase + j) * n;
-    const uint64_t* tab = trace;
-    const uint64_t* pin = trace + (size_t)(nm + j) * n;
-    const uint64_t* ptab = trace + (size_t)(nm + nc + j) * n;
-    uint64_t num[ZROWS], den[ZROWS], pre[ZROWS];
+    const size_t r0 = (size_t)blockIdx.x * (256 * ZR) + (size_t)threadIdx.x * ZR;
+    // a lane owns ZR consecutive rows = ZR * 8 contiguous bytes of each column: 16-byte vector accesses
+    const ulonglong2* col = reinterpret_cast<const ulonglong2*>(trace + (size_t)(cbase + j) * n + r0);
+    const ulonglong2* tab = reinterpret_cast<const ulonglong2*>(trace + r0);
+    const ulonglong2* pin = reinterpret_cast<const ulonglong2*>(trace + (size_t)(nm + j) * n + r0);
+    const ulonglong2* ptab = reinterpret_cast<const ulonglong2*>(trace + (size_t)(nm + nc + j) * n + r0);
+    uint64_t num[ZR], den[ZR], pre[ZR];
+#pragma unroll
+    for (int k = 0; k < ZR; k += 2) {
+        const ulonglong2 c2 = col[k >> 1], t2 = tab[k >> 1], p2 = pin[k >> 1], q2 = ptab[k >> 1];
+        num[k] = gl::mul(gl::add(c2.x, g), gl::add(t2.x, g));
+        den[k] = gl::mul(gl::add(p2.x, g), gl::add(q2.x, g));
+        num[k + 1] = gl::mul(gl::add(c2.y, g), gl::add(t2.y, g));
+        den[k + 1] = gl::mul(gl::add(p2.y, g), gl::add(q2.y, g));
+    }
     uint64_t acc = 1;
 #pragma unroll
-    for (int k = 0; k < ZROWS; k++) {
-        size_t r = r0 + k;
-        num[k] = gl::mul(gl::add(col[r], g), gl::add(tab[r], g));
-        den[k] = gl::mul(gl::add(pin[r], g), gl::add(ptab[r], g));
+    for (int k = 0; k < ZR; k++) {
         pre[k] = acc;
         acc = gl::mul(acc, den[k]);
     }
     uint64_t inv = gl::inv(acc);
-    uint64_t loc[ZROWS];
+    // num[k] becomes the ratio, then the lane-local inclusive product
 #pragma unroll
-    for (int k = ZROWS - 1; k >= 0; k--) {
-        uint64_t di = gl::mul(inv, pre[k]);
+    for (int k = ZR - 1; k >= 0; k--) {
+        const uint64_t di = gl::mul(inv, pre[k]);
         inv = gl::mul(inv, den[k]);
-        loc[k] = gl::mul(num[k], di);
+        num[k] = gl::mul(num[k], di);
     }
-    // thread-local inclusive products
 #pragma unroll
-    for (int k = 1; k < ZROWS; k++) loc[k] = gl::mul(loc[k], loc[k - 1]);
-    uint64_t incl = block_scan_mul_256(loc[ZROWS - 1], s);
-    uint64_t before = threadIdx.x ? s[threadIdx.x - 1] : 1;
-    uint64_t* out = zv + (size_t)zi * n + r0;
+    for (int k = 1; k < ZR; k++) num[k] = gl::mul(num[k], num[k - 1]);
+    const uint64_t incl = block_scan_mul_256(num[ZR - 1], s);
+    const uint64_t before = threadIdx.x ? s[threadIdx.x - 1] : 1;
+    ulonglong2* out = reinterpret_cast<ulonglong2*>(zv + (size_t)zi * n + r0);
 #pragma unroll
-    for (int k = 0; k < ZROWS; k++) out[k] = gl::mul(before, loc[k]);
+    for (int k = 0; k < ZR; k += 2) {
+        ulonglong2 o;
+        o.x = gl::mul(before, num[k]);
+        o.y = gl::mul(before, num[k + 1]);
+        out[k >> 1] = o;
+    }
     if (threadIdx.x == 255) totals[(size_t)zi * gridDim.x + blockIdx.x] = incl;
 }
 
@@ -95,8 +104,10 @@ __global__ void __launch_bounds__(256) z_phase_b(uint64_t* __restrict__ totals, 
     }
 }
 
+template <int ZR>
 __global__ void __launch_bounds__(256) z_phase_c(uint64_t* __restrict__ zv, size_t n, const uint64_t* __restrict__ totals) {
     // in: block-local inclusive products L[r]; out: Z[r] = T_blk * L[r-1] (exclusive)
+    constexpr int ZBLOCK = 256 * ZR;
     __shared__ uint64_t s[ZBLOCK];
     const int zi = blockIdx.y;
     uint64_t* z = zv + (size_t)zi * n + (size_t)blockIdx.x * ZBLOCK;
@@ -701,20 +712,30 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
                      uint64_t* d_zv) {
     const size_t n = (size_t)1 << log_n;
     const int P = 2 * a->n_checked;
-    const unsigned nblk = (unsigned)(n / ZBLOCK);
-    if (n % ZBLOCK) return sipp_fail(ctx, SIPP_E_BADARG, "z_columns: n must be a multiple of 1024");
+    // rows per lane: 16 on long traces (the lane's inversion is amortised over 16 rows), 4 otherwise
+    const int zr = (n >= 16384) ? 16 : 4;
+    const size_t zblock = (size_t)256 * zr;
+    const unsigned nblk = (unsigned)(n / zblock);
+    if (n % zblock) return sipp_fail(ctx, SIPP_E_BADARG, "z_columns: n must be a multiple of 1024");
     ArenaMark mk = arena_mark(ctx);
     uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)P * nblk);
     if (!totals) return SIPP_E_NOMEM;
     {
         ProfScope ps(ctx, "z_phase_a");
-        hipLaunchKernelGGL(z_phase_a, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
-                           a->checked_base, gamma[0], gamma[1], d_zv, totals);
+        if (zr == 16)
+            hipLaunchKernelGGL(z_phase_a<16>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
+                               a->checked_base, gamma[0], gamma[1], d_zv, totals);
+        else
+            hipLaunchKernelGGL(z_phase_a<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
+                               a->checked_base, gamma[0], gamma[1], d_zv, totals);
     }
     {
         ProfScope ps(ctx, "z_phase_bc");
         hipLaunchKernelGGL(z_phase_b, dim3(P), dim3(256), 0, ctx->stream, totals, (int)nblk);
-        hipLaunchKernelGGL(z_phase_c, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
+        if (zr == 16)
+            hipLaunchKernelGGL(z_phase_c<16>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
+        else
+            hipLaunchKernelGGL(z_phase_c<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     arena_release(ctx, mk);
