@@ -89,19 +89,43 @@ def test_error_behaviour(ctx, ios4):
     assert _oracle.stark_verify(ctx.prove(0, ios4[0])) == 0     # still works afterwards
 
 
-def test_large_n1024_g1_proof_verifies():
-    """deep trace (BASELINE config 3): G1ExpStark for n = 1024 -> 1023 IO records, N = 2^19 rows, 2^20-leaf trees,
-    2-pass NTTs of size 2^19 / 2^20.  Checked through the oracle's verifier and the public inputs."""
+def test_large_n1024_proofs_verify():
+    """deep traces (BASELINE config 3): n = 1024 -> 1023 G1 / 1023 G2 / 20 Fq12 IO records, N = 2^19 / 2^19 / 2^14 rows,
+    2^20-leaf trees, 2-pass NTTs of size 2^19 / 2^20.  Checked through the oracle's verifier and the public inputs."""
     import sipp_amd
-    ios = np.load("tests/golden/sipp_n1024_ios.npz")["g1"]
-    c = sipp_amd.Ctx(workspace_bytes=30 << 30)
+    d = np.load("tests/golden/sipp_n1024_ios.npz")
+    L = sipp_amd.lib()
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        ios = d[key]
+        c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(kind, ios.shape[0]))
+        try:
+            pf = c.prove(kind, ios)
+        finally:
+            c.close()
+        nio = int(pf[3])
+        assert nio >= ios.shape[0] and (nio & (nio - 1)) == 0
+        if kind < 2:
+            assert int(pf[2]) == 19 and nio == 1024
+        assert _oracle.stark_verify(pf) == 0, key
+        assert (pf[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])[: ios.shape[0]] == ios).all()
+
+
+def test_workspace_too_small_fails_cleanly(ios4):
+    """a ctx whose arena cannot hold the proof's buffers returns SIPP_E_NOMEM (no fault, no partial proof) and a
+    properly sized ctx created afterwards still works"""
+    import sipp_amd
+    small = sipp_amd.Ctx(workspace_bytes=8 << 20)
     try:
-        pf = c.prove(0, ios)
+        with pytest.raises(sipp_amd.SippError) as e:
+            small.prove(1, ios4[1])
+        assert e.value.code == -3      # SIPP_E_NOMEM
     finally:
-        c.close()
-    assert int(pf[2]) == 19 and int(pf[3]) == 1024
-    assert _oracle.stark_verify(pf) == 0
-    assert (pf[-1024 * 56:].reshape(1024, 56)[:1023] == ios).all()
+        small.close()
+    ok = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(1, ios4[1].shape[0]))
+    try:
+        assert _oracle.stark_verify(ok.prove(1, ios4[1])) == 0
+    finally:
+        ok.close()
 
 
 def test_edge_exponents_and_degenerate_inputs(ctx):
