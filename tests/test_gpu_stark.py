@@ -146,18 +146,22 @@ def test_edge_exponents_and_degenerate_inputs(ctx):
     assert e.value.code == -8
 
 
-def test_max_size_n4096_g1_proof_verifies():
-    """largest BASELINE config: n = 4096 -> 4095 G1 IO records, N = 2^21 rows, LDE 2^22 rows (three-pass NTT),
-    82 GB arena.  The oracle's verifier must accept the proof."""
+def test_max_size_n4096_proofs_verify():
+    """largest BASELINE config: n = 4096 -> 4095 G1 / 4095 G2 / 24 Fq12 IO records, N = 2^21 rows, LDE 2^22 rows
+    (three-pass NTT), 82 GB / 160 GB arenas.  The oracle's verifier must accept every proof."""
     import sipp_amd
-    ios = np.load("tests/golden/sipp_n4096_ios.npz")["g1"]
-    c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(0, ios.shape[0]))
-    try:
-        pf = c.prove(0, ios)
-    finally:
-        c.close()
-    assert int(pf[2]) == 21 and int(pf[3]) == 4096
-    assert _oracle.stark_verify(pf) == 0
+    d = np.load("tests/golden/sipp_n4096_ios.npz")
+    L = sipp_amd.lib()
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        ios = d[key]
+        c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(kind, ios.shape[0]))
+        try:
+            pf = c.prove(kind, ios)
+        finally:
+            c.close()
+        if kind < 2:
+            assert int(pf[2]) == 21 and int(pf[3]) == 4096
+        assert _oracle.stark_verify(pf) == 0, key
 
 
 def test_concurrent_streams_are_deterministic():
