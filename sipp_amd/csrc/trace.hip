@@ -421,128 +421,156 @@ struct GadgetArgs {
     uint32_t pinv16;
 };
 
+// limb vector with a STATIC number of limbs (16 for operands, 17 for the quotient: fixed by tools/air_gen.py): the limbs
+// stay in registers.  Every limb of the specification is a small combination of 16-bit cells, far below 2^31; `ovf`
+// is set if that ever fails, and the row is then reported as SIPP_E_WITNESS instead of being computed wrongly.
+template <int NLV>
 __device__ __forceinline__ int ivec_dev(const int64_t* w, const uint64_t* tr, size_t n, size_t row, const int* per,
-                                        int64_t* out) {
-    const int nl = (int)w[0], nt = (int)w[1];
-    for (int i = 0; i < nl; i++) out[i] = 0;
+                                        int32_t (&out)[NLV], bool& ovf) {
+    const int nt = (int)w[1];
+    int64_t acc[NLV];
+#pragma unroll
+    for (int i = 0; i < NLV; i++) acc[i] = 0;
     for (int t = 0; t < nt; t++) {
         const int64_t* tm = w + 2 + 5 * t;
-        int64_t f = tm[0];
+        int32_t f = (int32_t)tm[0];
         const int base = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
         if (flag >= 0) f *= neg ? 1 - per[flag] : per[flag];
-        if (f == 0) continue;
-        for (int i = 0; i < nl; i++) out[i] += f * (int64_t)tr[(size_t)(base + i * stride) * n + row];
+#pragma unroll
+        for (int i = 0; i < NLV; i++) acc[i] += (int64_t)f * (int32_t)(uint32_t)tr[(size_t)(base + i * stride) * n + row];
+    }
+#pragma unroll
+    for (int i = 0; i < NLV; i++) {
+        out[i] = (int32_t)acc[i];
+        ovf |= acc[i] != (int64_t)out[i];
     }
     return 2 + 5 * nt;
 }
 
+// one lane per (row, gadget): blockIdx.y selects the gadget.  All limb loops are static and unrolled (registers, no
+// scratch); 16 x 16-bit operands keep every product inside one v_mad_i64_i32 / v_mad_u64_u32.
 __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t* __restrict__ tr, size_t n,
                                                         int* __restrict__ err) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     int per[SIPP_N_PERIODIC];
     for (int k = 0; k < SIPP_N_PERIODIC; k++) per[k] = (int)(row % (size_t)SIPP_PERIODIC[k][0]) == SIPP_PERIODIC[k][1];
-    // one lane per (row, gadget): blockIdx.y selects the gadget
     const int64_t* w = g.prog + g.gadget_off[blockIdx.y];
-    int64_t e[34], va[17], vb[17], limbs[40];
+    bool bad = false;
+    const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
+    const int64_t coffset = w[5];
+    const int grp = (int)w[6];
+    w += 7;
+    const int q_base = (int)w[3];
+    w += 2 + 5 * (int)w[1];
+    int64_t e[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) e[i] = 0;
+    const int np = (int)*w++;
+    for (int p = 0; p < np; p++) {
+        const int64_t coef = *w++;
+        int32_t va[16], vb[16];
+        w += ivec_dev<16>(w, tr, n, row, per, va, bad);
+        w += ivec_dev<16>(w, tr, n, row, per, vb, bad);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int64_t a64 = coef * va[i];
+            const int32_t ai = (int32_t)a64;
+            bad |= a64 != (int64_t)ai;
+#pragma unroll
+            for (int j = 0; j < 16; j++) e[i + j] += (int64_t)ai * vb[j];
+        }
+    }
+    const int nl = (int)*w++;
+    for (int p = 0; p < nl; p++) {
+        const int64_t coef = *w++;
+        int32_t va[16];
+        w += ivec_dev<16>(w, tr, n, row, per, va, bad);
+#pragma unroll
+        for (int i = 0; i < 16; i++) e[i] += coef * va[i];
+    }
+    // sign of E = sum e_k 2^(16 k) and the 16-bit limbs of |E| (E < 2^(16*40))
+    int32_t limbs[40];
+    int sign = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 40; k++) {
+            const int64_t t = (k < 31 ? (sign ? -e[k] : e[k]) : 0) + carry;
+            limbs[k] = (int32_t)(t & 0xffff);
+            carry = t >> 16;
+        }
+        if (carry == 0) break;
+        if (carry == -1 && pass == 0) {
+            sign = 1;
+            continue;
+        }
+        bad = true;
+        break;
+    }
+    // q = |E| / p by exact division from the low end (p odd: q_i = limb_i * p^-1 mod 2^16)
     uint32_t q[17];
-    {
-        const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
-        const int64_t coffset = w[5];
-        const int grp = (int)w[6];
-        w += 7;
-        const int q_base = (int)w[3];
-        w += 2 + 5 * (int)w[1];
-        for (int i = 0; i < 34; i++) e[i] = 0;
-        const int np = (int)*w++;
-        for (int p = 0; p < np; p++) {
-            const int64_t coef = *w++;
-            const int na = (int)w[0];
-            w += ivec_dev(w, tr, n, row, per, va);
-            const int nb = (int)w[0];
-            w += ivec_dev(w, tr, n, row, per, vb);
-            for (int i = 0; i < na; i++) {
-                if (!va[i]) continue;
-                const int64_t ai = coef * va[i];
-                for (int j = 0; j < nb; j++) e[i + j] += ai * vb[j];
-            }
-        }
-        const int nl = (int)*w++;
-        for (int p = 0; p < nl; p++) {
-            const int64_t coef = *w++;
-            const int na = (int)w[0];
-            w += ivec_dev(w, tr, n, row, per, va);
-            for (int i = 0; i < na; i++) e[i] += coef * va[i];
-        }
-        int sign = 0;
-        bool bad = false;
-        for (int pass = 0; pass < 2; pass++) {
-            int64_t carry = 0;
-            for (int k = 0; k < 40; k++) {
-                int64_t t = (k < 31 ? (sign ? -e[k] : e[k]) : 0) + carry;
-                limbs[k] = t & 0xffff;
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        q[i] = ((uint32_t)limbs[i] * g.pinv16) & 0xffffu;
+        int64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 40; j++) {
+            if (i + j < 40) {
+                const int64_t t = (int64_t)limbs[i + j] - (j < 16 ? (int64_t)((uint64_t)q[i] * g.p_limbs[j]) : 0) + carry;
+                limbs[i + j] = (int32_t)(t & 0xffff);
                 carry = t >> 16;
             }
-            if (carry == 0) break;
-            if (carry == -1 && pass == 0) {
-                sign = 1;
-                continue;
-            }
-            bad = true;
-            break;
         }
+    }
+#pragma unroll
+    for (int k = 0; k < 40; k++) bad |= limbs[k] != 0;
+    tr[(size_t)sign_col * n + row] = (uint64_t)sign;
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        if (g.cpl == 1) {
+            tr[(size_t)(q_base + i) * n + row] = q[i];
+        } else {
+            tr[(size_t)(q_base + 2 * i) * n + row] = q[i] & 0xffu;
+            tr[(size_t)(q_base + 2 * i + 1) * n + row] = q[i] >> 8;
+        }
+    }
+    // d_k = e_k -+ (q * p)_k
+    int64_t d[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        uint64_t qp = 0;
+#pragma unroll
         for (int i = 0; i < 17; i++) {
-            q[i] = ((uint32_t)limbs[i] * g.pinv16) & 0xffffu;
-            int64_t carry = 0;
-            for (int j = 0; i + j < 40; j++) {
-                int64_t t = limbs[i + j] - (j < 16 ? (int64_t)q[i] * g.p_limbs[j] : 0) + carry;
-                limbs[i + j] = t & 0xffff;
-                carry = t >> 16;
-                if (j >= 16 && carry == 0) break;
-            }
+            const int j = k - i;
+            if (j >= 0 && j < 16) qp += (uint64_t)q[i] * g.p_limbs[j];
         }
-        for (int k = 0; k < 40; k++) bad |= limbs[k] != 0;
-        tr[(size_t)sign_col * n + row] = (uint64_t)sign;
-        for (int i = 0; i < 17; i++) {
-            if (g.cpl == 1) {
-                tr[(size_t)(q_base + i) * n + row] = q[i];
-            } else {
-                tr[(size_t)(q_base + 2 * i) * n + row] = q[i] & 0xffu;
-                tr[(size_t)(q_base + 2 * i + 1) * n + row] = q[i] >> 8;
-            }
-        }
-        // carries in base 2^(16 grp): sum_t 2^(16t) d_{grp m + t} - c_{m-1} + 2^(16 grp) c_m = 0
-        const int64_t sgn = sign ? -1 : 1;
-        __int128 cprev = 0;
-        const int nmm = 32 / grp;
-        for (int m = 0; m < nmm; m++) {
-            __int128 dm = 0;
-            for (int t = grp - 1; t >= 0; t--) {
-                const int k = grp * m + t;
-                int64_t qp = 0;
-                for (int i = 0; i < 17; i++) {
-                    int j = k - i;
-                    if (j >= 0 && j < 16) qp += (int64_t)q[i] * g.p_limbs[j];
-                }
-                dm = dm * 65536 + ((k < 31 ? e[k] : 0) - sgn * qp);
-            }
+        d[k] = (k < 31 ? e[k] : 0) - (sign ? -(int64_t)qp : (int64_t)qp);
+    }
+    // carries in base 2^(16 grp): sum_t 2^(16t) d_{grp m + t} - c_{m-1} + 2^(16 grp) c_m = 0
+    __int128 cprev = 0;
+    const int nmm = 32 / grp;
+#pragma unroll
+    for (int m = 0; m < 32; m++) {
+        if (m < nmm) {
+            __int128 dm = grp == 2 ? (__int128)d[(2 * m + 1) & 31] * 65536 + d[(2 * m) & 31] : (__int128)d[m];
             dm -= cprev;
             const __int128 mask = (((__int128)1) << (16 * grp)) - 1;
             bad |= (dm & mask) != 0;
             const __int128 ck = -(dm >> (16 * grp));
             if (m == nmm - 1) {
                 bad |= ck != 0;
-                break;
+            } else {
+                const __int128 v = ck + coffset;
+                bad |= v < 0 || (v >> (ncl * lb)) != 0;
+                const uint64_t vv = (uint64_t)v;
+                for (int l = 0; l < ncl; l++)
+                    tr[(size_t)(cbase + m * ncl + l) * n + row] = (vv >> (lb * l)) & (((uint64_t)1 << lb) - 1);
+                cprev = ck;
             }
-            const __int128 v = ck + coffset;
-            bad |= v < 0 || (v >> (ncl * lb)) != 0;
-            const uint64_t vv = (uint64_t)v;
-            for (int l = 0; l < ncl; l++)
-                tr[(size_t)(cbase + m * ncl + l) * n + row] = (vv >> (lb * l)) & (((uint64_t)1 << lb) - 1);
-            cprev = ck;
         }
-        if (bad) atomicExch(err, SIPP_E_WITNESS);
     }
+    if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
 
 // ---- permuted lookup columns ----
