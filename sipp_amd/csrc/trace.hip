@@ -643,11 +643,24 @@ __global__ void __launch_bounds__(256) lookup_scan_kernel(const uint32_t* __rest
     uint32_t* zl = zlist + (c << tbits);
     const uint32_t v0 = threadIdx.x * per;
     uint32_t cnt = 0, dst = 0, zer = 0;
-    for (uint32_t v = v0; v < v0 + per; v++) {
-        uint32_t x = h[v];
-        cnt += x;
-        dst += x != 0;
-        zer += x == 0;
+    // a lane owns `per` consecutive bins (256 for the u16 table): 16-byte vector accesses, four bins at a time
+    if (per % 4 == 0) {
+        const uint4* h4 = reinterpret_cast<const uint4*>(h + v0);
+#pragma unroll 8
+        for (uint32_t k = 0; k < per / 4; k++) {
+            const uint4 x = h4[k];
+            cnt += x.x + x.y + x.z + x.w;
+            const uint32_t nz = (x.x != 0) + (x.y != 0) + (x.z != 0) + (x.w != 0);
+            dst += nz;
+            zer += 4 - nz;
+        }
+    } else {
+        for (uint32_t v = v0; v < v0 + per; v++) {
+            uint32_t x = h[v];
+            cnt += x;
+            dst += x != 0;
+            zer += x == 0;
+        }
     }
     s_cnt[threadIdx.x] = cnt;
     s_dst[threadIdx.x] = dst;
@@ -670,13 +683,31 @@ __global__ void __launch_bounds__(256) lookup_scan_kernel(const uint32_t* __rest
     cnt = s_cnt[threadIdx.x];
     dst = s_dst[threadIdx.x];
     zer = s_zer[threadIdx.x];
-    for (uint32_t v = v0; v < v0 + per; v++) {
-        uint32_t x = h[v];
-        st[v] = cnt;
-        cnt += x;
-        dst += x != 0;
-        ds[v] = dst;
-        if (x == 0) zl[zer++] = v;
+    if (per % 4 == 0) {
+        const uint4* h4 = reinterpret_cast<const uint4*>(h + v0);
+        uint4* st4 = reinterpret_cast<uint4*>(st + v0);
+        uint4* ds4 = reinterpret_cast<uint4*>(ds + v0);
+#pragma unroll 4
+        for (uint32_t k = 0; k < per / 4; k++) {
+            const uint4 x = h4[k];
+            const uint32_t v = v0 + 4 * k;
+            uint4 so, dd;
+            so.x = cnt; cnt += x.x; dst += x.x != 0; dd.x = dst; if (x.x == 0) zl[zer++] = v;
+            so.y = cnt; cnt += x.y; dst += x.y != 0; dd.y = dst; if (x.y == 0) zl[zer++] = v + 1;
+            so.z = cnt; cnt += x.z; dst += x.z != 0; dd.z = dst; if (x.z == 0) zl[zer++] = v + 2;
+            so.w = cnt; cnt += x.w; dst += x.w != 0; dd.w = dst; if (x.w == 0) zl[zer++] = v + 3;
+            st4[k] = so;
+            ds4[k] = dd;
+        }
+    } else {
+        for (uint32_t v = v0; v < v0 + per; v++) {
+            uint32_t x = h[v];
+            st[v] = cnt;
+            cnt += x;
+            dst += x != 0;
+            ds[v] = dst;
+            if (x == 0) zl[zer++] = v;
+        }
     }
 }
 
