@@ -128,25 +128,133 @@ __device__ __forceinline__ Jac<EXT> jac_add_id(const Jac<EXT>& p, const Jac<EXT>
 
 // rows[512 io + 2k] = (R_k, P_k) for the add row of bit k, rows[.. + 2k + 1] = (R_{k+1}, P_k) for its double row,
 // where P_k = 2^k x and R_k = offset + sum_{j<k} bit_j P_j.
-//   curve_dbl_kernel   one LANE per IO: the 255 sequential doublings (the only inherently serial part; its time
-//                      does not grow with the number of IOs until there are more IOs than lanes on the chip)
+//   curve_dbl_par_kernel  4 (Fq) / 8 (Fq2) lanes per IO: the 255 sequential doublings, the base-field products of one
+//                      doubling spread over the lanes (three dependency levels, exchanged through LDS)
 //   curve_scan_kernel  one 256-lane workgroup per IO (lane k <-> bit k): inclusive Hillis-Steele scan of
 //                      T_k = bit_k ? P_k : inf (8 point additions deep), then R_{k+1} = offset + scan_k
 // 2,200 field-multiplication times on the critical path instead of 6,100 for a one-lane-per-IO double-and-add.
-template <int EXT>
-__global__ void __launch_bounds__(64) curve_dbl_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi,
-                                                      RowPts<EXT>* __restrict__ rows) {
+// ---- the doubling chain with several lanes per IO ----
+// The 255 doublings are serial, but the 16 (Fq2) / 7 (Fq) base-field products inside one doubling are not: they fall
+// into three dependency levels of 7 + 6 + 3 (Fq2) or 3 + 3 + 1 (Fq) independent products.  G lanes share an IO: every
+// lane keeps the whole point, all lanes form the level's operand pairs (cheap additions, done redundantly), lane t
+// multiplies pair t, the products are exchanged through LDS, and every lane finishes the level's additions.  One
+// doubling then costs 3 product latencies instead of 16 / 7.
+__device__ __forceinline__ void lds_put(Fq* dst, const Fq& v) {
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ Fq lds_get(const Fq* src) {
+    const uint4* d = reinterpret_cast<const uint4*>(src);
+    const uint4 a = d[0], b = d[1];
+    Fq v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
+}
+
+// one level: NT operand pairs (identical in every lane of the group) -> NT products, visible to every lane
+template <int NT>
+__device__ __forceinline__ void par_level(Fq* s_op, Fq* s_pr, int sub, const Fq (&a)[NT], const Fq (&b)[NT], Fq (&p)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        lds_put(s_op + 2 * t, a[t]);
+        lds_put(s_op + 2 * t + 1, b[t]);
+    }
+    __syncthreads();
+    const int task = sub < NT ? sub : NT - 1;
+    const Fq x = lds_get(s_op + 2 * task), y = lds_get(s_op + 2 * task + 1);
+    lds_put(s_pr + sub, fq::mul(x, y));
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; t++) p[t] = lds_get(s_pr + t);
+}
+
+__device__ __forceinline__ Jac<1> jac_dbl_par(const Jac<1>& P, Fq* s_op, Fq* s_pr, int sub) {
+    Fq p1[3], p2[3], p3[1];
+    {
+        const Fq a[3] = {P.x, P.y, P.y}, b[3] = {P.x, P.y, P.z};
+        par_level<3>(s_op, s_pr, sub, a, b, p1);  // A = X^2, B = Y^2, YZ
+    }
+    const Fq A = p1[0], B = p1[1];
+    const Fq U = fq::add(P.x, B), E = fq::add(fq::add(A, A), A);
+    {
+        const Fq a[3] = {B, U, E};
+        par_level<3>(s_op, s_pr, sub, a, a, p2);  // C = B^2, (X + B)^2, F = E^2
+    }
+    const Fq C = p2[0];
+    Fq D = fq::sub(fq::sub(p2[1], A), C);
+    D = fq::add(D, D);
+    Jac<1> r;
+    r.x = fq::sub(p2[2], fq::add(D, D));
+    {
+        const Fq a[1] = {E}, b[1] = {fq::sub(D, r.x)};
+        par_level<1>(s_op, s_pr, sub, a, b, p3);
+    }
+    Fq C8 = fq::add(C, C);
+    C8 = fq::add(C8, C8);
+    C8 = fq::add(C8, C8);
+    r.y = fq::sub(p3[0], C8);
+    r.z = fq::add(p1[2], p1[2]);
+    return r;
+}
+
+__device__ __forceinline__ Jac<2> jac_dbl_par(const Jac<2>& P, Fq* s_op, Fq* s_pr, int sub) {
+    Fq p1[7], p2[6], p3[3];
+    {
+        // X^2 = (x0+x1)(x0-x1) + 2 x0 x1 u ; Y^2 likewise ; Y Z by Karatsuba
+        const Fq a[7] = {fq::add(P.x.c0, P.x.c1), P.x.c0, fq::add(P.y.c0, P.y.c1), P.y.c0, P.y.c0, P.y.c1,
+                         fq::add(P.y.c0, P.y.c1)};
+        const Fq b[7] = {fq::sub(P.x.c0, P.x.c1), P.x.c1, fq::sub(P.y.c0, P.y.c1), P.y.c1, P.z.c0, P.z.c1,
+                         fq::add(P.z.c0, P.z.c1)};
+        par_level<7>(s_op, s_pr, sub, a, b, p1);
+    }
+    const Fq2 A{p1[0], fq::add(p1[1], p1[1])}, B{p1[2], fq::add(p1[3], p1[3])};
+    const Fq2 YZ{fq::sub(p1[4], p1[5]), fq::sub(fq::sub(p1[6], p1[4]), p1[5])};
+    const Fq2 U = fq::add(P.x, B), E = fq::add(fq::add(A, A), A);
+    {
+        const Fq a[6] = {fq::add(B.c0, B.c1), B.c0, fq::add(U.c0, U.c1), U.c0, fq::add(E.c0, E.c1), E.c0};
+        const Fq b[6] = {fq::sub(B.c0, B.c1), B.c1, fq::sub(U.c0, U.c1), U.c1, fq::sub(E.c0, E.c1), E.c1};
+        par_level<6>(s_op, s_pr, sub, a, b, p2);
+    }
+    const Fq2 C{p2[0], fq::add(p2[1], p2[1])}, S{p2[2], fq::add(p2[3], p2[3])}, Fv{p2[4], fq::add(p2[5], p2[5])};
+    Fq2 D = fq::sub(fq::sub(S, A), C);
+    D = fq::add(D, D);
+    Jac<2> r;
+    r.x = fq::sub(Fv, fq::add(D, D));
+    const Fq2 Wd = fq::sub(D, r.x);
+    {
+        const Fq a[3] = {E.c0, E.c1, fq::add(E.c0, E.c1)}, b[3] = {Wd.c0, Wd.c1, fq::add(Wd.c0, Wd.c1)};
+        par_level<3>(s_op, s_pr, sub, a, b, p3);
+    }
+    const Fq2 EW{fq::sub(p3[0], p3[1]), fq::sub(fq::sub(p3[2], p3[0]), p3[1])};
+    Fq2 C8 = fq::add(C, C);
+    C8 = fq::add(C8, C8);
+    C8 = fq::add(C8, C8);
+    r.y = fq::sub(EW, C8);
+    r.z = fq::add(YZ, YZ);
+    return r;
+}
+
+// G lanes per IO, one 64-lane block = 64 / G IOs
+template <int EXT, int G>
+__global__ void __launch_bounds__(64) curve_dbl_par_kernel(const uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi,
+                                                          RowPts<EXT>* __restrict__ rows) {
     using F = Fld<EXT>;
     using T = typename F::T;
-    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
-    if (io >= num_io) return;
+    constexpr int GPB = 64 / G;
+    __shared__ Fq s_op[GPB][14], s_pr[GPB][G];
+    const int grp = threadIdx.x / G, sub = threadIdx.x % G;
+    uint32_t io = blockIdx.x * GPB + grp;
+    const bool live = io < num_io && sub == 0;
+    if (io >= num_io) io = num_io - 1;  // spare groups redo the last IO (uniform control flow for the barriers)
     const uint32_t* rec = ios + (size_t)io * ppi;
     const int w = 8 * EXT;
     RowPts<EXT>* out = rows + (size_t)io * 512;
     Jac<EXT> P{F::load(rec), F::load(rec + w), one_of((T*)nullptr)};
     for (int b = 0; b < 256; b++) {
-        out[2 * b].P = P;
-        if (b != 255) P = jac_dbl<EXT>(P);
+        if (live) out[2 * b].P = P;
+        if (b != 255) P = jac_dbl_par(P, s_op[grp], s_pr[grp], sub);
     }
 }
 
@@ -789,7 +897,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             if (!rows) return SIPP_E_NOMEM;
             {
                 ProfScope ps(ctx, "trace_curve_chain");
-                hipLaunchKernelGGL(curve_dbl_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
+                hipLaunchKernelGGL((curve_dbl_par_kernel<1, 4>), dim3((num_io + 15) / 16), dim3(64), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
                 hipLaunchKernelGGL(curve_scan_kernel<1>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
@@ -804,7 +912,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             if (!rows) return SIPP_E_NOMEM;
             {
                 ProfScope ps(ctx, "trace_curve_chain");
-                hipLaunchKernelGGL(curve_dbl_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
+                hipLaunchKernelGGL((curve_dbl_par_kernel<2, 8>), dim3((num_io + 7) / 8), dim3(64), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
                 hipLaunchKernelGGL(curve_scan_kernel<2>, dim3(num_io), dim3(256), 0, ctx->stream, d_ios, num_io,
                                    (uint32_t)a->pi_per_io, rows);
