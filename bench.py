@@ -82,7 +82,7 @@ def main():
     # independent, so their thin kernels and Fiat-Shamir round trips overlap
     from concurrent.futures import ThreadPoolExecutor
     ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
-    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,,high").split(",")   # G1, G2, Fq12
+    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,high,high").split(",")   # G1, G2, Fq12
     ctxs = []
     for k in range(3):
         if prios[k]:

@@ -9,7 +9,7 @@ L = sipp_amd.lib()
 for ninst in (1, 2, 3):
     ctxs = []
     for i in range(ninst):
-        for k, pr in enumerate(("low", "", "high")):
+        for k, pr in enumerate(("low", "high", "high")):
             if pr: os.environ["SIPP_STREAM_PRIORITY"] = pr
             else: os.environ.pop("SIPP_STREAM_PRIORITY", None)
             ctxs.append((k, sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(k, ios[k].shape[0]))))
