@@ -204,7 +204,7 @@ def main():
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected with
         # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_d_pmc.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_e_pmc.json")
         if args.n == 128 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         out = {

@@ -31,7 +31,7 @@ fetch_kb = sum(f[k]["FETCH_SIZE"] for k in leaf)
 write_kb = sum(w[k]["WRITE_SIZE"] for k in leaf)
 launches = sum(nf[k] for k in leaf)
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
     "kernel": "poseidon_leaves (one-state-per-lane + four-lanes-per-state kernels)",
     "launches": launches,
     "FETCH_SIZE_kb_sum": fetch_kb,
