@@ -206,6 +206,26 @@ struct Acc6 {
     }
 };
 
+// sum of full 64 x 64 products (both factors per-lane values) in 160 bits, one reduction at the end
+struct Acc160 {
+    uint64_t lo = 0, hi = 0;
+    uint32_t c = 0;
+    GL_D void mac(uint64_t a, uint64_t b) {
+        uint64_t ph, pl;
+        mul_wide(a, b, ph, pl);
+        lo += pl;
+        ph += (lo < pl);  // ph <= 2^64 - 2, cannot wrap
+        hi += ph;
+        c += (hi < ph);
+    }
+    // 2^128 = -2^32 (mod p); result in [0, 2^64), not canonical
+    GL_D uint64_t reduce() const {
+        const uint64_t r = reduce128_nc(hi, lo), t = (uint64_t)c << 32;
+        const uint64_t d = r - t;
+        return r < t ? d - EPS : d;  // r < t < 2^37: d wrapped is >= 2^64 - 2^37 > EPS
+    }
+};
+
 // c -> limbs for Acc6::mac
 GL_D void limbs3(uint32_t (&o)[3], uint64_t c) {
     o[0] = (uint32_t)c & 0x3FFFFFu;

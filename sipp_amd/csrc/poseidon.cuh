@@ -71,24 +71,7 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
     }
 }
 
-struct Acc160 {
-    uint64_t lo = 0, hi = 0;
-    uint32_t c = 0;
-    __device__ __forceinline__ void mac(uint64_t a, uint64_t b) {
-        uint64_t ph, pl;
-        gl::mul_wide(a, b, ph, pl);
-        lo += pl;
-        ph += (lo < pl);  // ph <= 2^64 - 2, cannot wrap
-        hi += ph;
-        c += (hi < ph);
-    }
-    // 2^128 = -2^32 (mod p); result in [0, 2^64), not canonical
-    __device__ __forceinline__ uint64_t reduce() const {
-        const uint64_t r = gl::reduce128_nc(hi, lo), t = (uint64_t)c << 32;
-        const uint64_t d = r - t;
-        return r < t ? d - gl::EPS : d;  // r < t < 2^37: d wrapped is >= 2^64 - 2^37 > EPS
-    }
-};
+using gl::Acc160;
 
 __device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
 #pragma unroll

@@ -486,30 +486,44 @@ __global__ void pow_table_kernel(E2 base, size_t n, uint64_t* __restrict__ tab) 
     tab[n + k] = r.c1;
 }
 
-// one block per column: sum_k c[k] * t0[k] and sum_k c[k] * t1[k]; out[col] = (e0.c0, e0.c1, e1.c0, e1.c1)
-__global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restrict__ coeffs, size_t n,
+// one block per OCOLS columns: sum_k c[k] * t0[k] and sum_k c[k] * t1[k]; out[col] = (e0.c0, e0.c1, e1.c0, e1.c1).
+// The power tables are read once per block and k, i.e. once per OCOLS coefficients; the products are summed lazily in
+// 160 bits (gl::Acc160) and reduced once per lane.
+constexpr int OCOLS = 1;  // more columns per block re-use the tables but leave too few waves in flight (measured)
+__global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restrict__ coeffs, size_t n, uint32_t ncols,
                                                       const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
                                                       uint64_t* __restrict__ out) {
     __shared__ uint64_t s[4][256];
-    const uint64_t* c = coeffs + (size_t)blockIdx.x * n;
-    uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    const uint32_t col0 = blockIdx.x * OCOLS;
+    gl::Acc160 acc[OCOLS][4];
     for (size_t k = threadIdx.x; k < n; k += 256) {
-        uint64_t v = c[k];
-        a0 = gl::mad(v, t0[k], a0);
-        a1 = gl::mad(v, t0[n + k], a1);
-        if (t1) {
-            b0 = gl::mad(v, t1[k], b0);
-            b1 = gl::mad(v, t1[n + k], b1);
+        const uint64_t p0 = t0[k], p1 = t0[n + k];
+        const uint64_t q0 = t1 ? t1[k] : 0, q1 = t1 ? t1[n + k] : 0;
+#pragma unroll
+        for (int u = 0; u < OCOLS; u++) {
+            const uint32_t col = min(col0 + u, ncols - 1);
+            const uint64_t v = coeffs[(size_t)col * n + k];
+            acc[u][0].mac(v, p0);
+            acc[u][1].mac(v, p1);
+            if (t1) {
+                acc[u][2].mac(v, q0);
+                acc[u][3].mac(v, q1);
+            }
         }
     }
-    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1; s[2][threadIdx.x] = b0; s[3][threadIdx.x] = b1;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::add(s[q][threadIdx.x], s[q][threadIdx.x + off]);
+    for (int u = 0; u < OCOLS; u++) {
+        if (col0 + u >= ncols) break;   // block-uniform
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::canon(acc[u][q].reduce());
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::add(s[q][threadIdx.x], s[q][threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x < 4) out[(size_t)(col0 + u) * 4 + threadIdx.x] = s[threadIdx.x][0];
     }
-    if (threadIdx.x < 4) out[(size_t)blockIdx.x * 4 + threadIdx.x] = s[threadIdx.x][0];
 }
 
 // partial[slice][{0,1}][{c0,c1}][k]: acc over the columns of this slice of alpha^c * coef_c[k];
@@ -518,33 +532,42 @@ struct CombArgs {
     const uint64_t* src[3];
     int cnt[3];
     size_t n;
-    const uint64_t* apow;  // [total][2]: alpha^c as (c0, c1)
+    const uint32_t* apow3; // [total][2][3]: limbs (gl::limbs3) of alpha^c as (c0, c1)
     int n1;                // columns in batch 1 (W + P)
     int slices;
     uint64_t* partial;     // [slices][4][n]
 };
+// the weights alpha^c are wave-uniform (lanes run over the coefficient index k): lazy multiply-accumulate with the limbs
+// of alpha^c (gl::Acc6, six v_mad_u64_u32 per extension component), one reduction per slice.  A column belongs either
+// to batch 1 (c < n1) or not, so g (batch 1) and h (the rest) are accumulated separately and f = g + h.
 __global__ void __launch_bounds__(256) fri_combine_kernel(CombArgs a) {
     const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int total = a.cnt[0] + a.cnt[1] + a.cnt[2];
-    const int per = (total + a.slices - 1) / a.slices;
+    const int per = (total + a.slices - 1) / a.slices;   // <= 1024 terms per accumulator (host checks)
     const int c_lo = blockIdx.y * per, c_hi = min(total, c_lo + per);
-    uint64_t f0 = 0, f1 = 0, g0 = 0, g1 = 0;  // f: all columns of the slice, g: those with c < n1
+    gl::Acc6 G0, G1, H0, H1;
+    G0.zero(); G1.zero(); H0.zero(); H1.zero();
     for (int c = c_lo; c < c_hi; c++) {
         const uint64_t* col = c < a.cnt[0] ? a.src[0] + (size_t)c * a.n
                               : c < a.cnt[0] + a.cnt[1] ? a.src[1] + (size_t)(c - a.cnt[0]) * a.n
                                                         : a.src[2] + (size_t)(c - a.cnt[0] - a.cnt[1]) * a.n;
         const uint64_t v = col[k];
-        const uint64_t p0 = a.apow[2 * c], p1 = a.apow[2 * c + 1];
-        const uint64_t t0 = gl::mul(v, p0), t1 = gl::mul(v, p1);
-        f0 = gl::add(f0, t0);
-        f1 = gl::add(f1, t1);
-        if (c < a.n1) {
-            g0 = gl::add(g0, t0);
-            g1 = gl::add(g1, t1);
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        const uint32_t* __restrict__ w = a.apow3 + 6 * c;
+        if (c < a.n1) {   // wave-uniform
+            G0.mac(lo, hi, w);
+            G1.mac(lo, hi, w + 3);
+        } else {
+            H0.mac(lo, hi, w);
+            H1.mac(lo, hi, w + 3);
         }
     }
+    const uint64_t g0 = gl::canon(G0.reduce()), g1 = gl::canon(G1.reduce());
     uint64_t* p = a.partial + (size_t)blockIdx.y * 4 * a.n;
-    p[k] = f0; p[a.n + k] = f1; p[2 * a.n + k] = g0; p[3 * a.n + k] = g1;
+    p[k] = gl::add(g0, gl::canon(H0.reduce()));
+    p[a.n + k] = gl::add(g1, gl::canon(H1.reduce()));
+    p[2 * a.n + k] = g0;
+    p[3 * a.n + k] = g1;
 }
 
 // one block per batch b (0: point zeta, 1: point g zeta):
@@ -878,21 +901,25 @@ int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_
                     const uint64_t* d_t1, uint64_t* d_out) {
     if (!ncols) return SIPP_OK;
     ProfScope ps(ctx, "openings");
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, d_coeffs, n, d_t0, d_t1, d_out);
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)((ncols + OCOLS - 1) / OCOLS)), dim3(256), 0, ctx->stream, d_coeffs, n,
+                       (uint32_t)ncols, d_t0, d_t1, d_out);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
 
-int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint64_t* d_apow,
+int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,
                      int n1, gl::E2 shift1, const uint64_t* d_zp[2], const uint64_t* d_zip[2], uint64_t* d_final) {
     ArenaMark mk = arena_mark(ctx);
-    const int slices = 8;
+    // enough (block, slice) pairs to fill the chip: short traces with many columns (Fq12) get more slices
+    int slices = 8;
+    while (slices < 64 && (n / 256) * (size_t)slices < 2048) slices *= 2;
     uint64_t* partial = arena_alloc_t<uint64_t>(ctx, (size_t)slices * 4 * n);
     uint64_t* q = arena_alloc_t<uint64_t>(ctx, 4 * n);
     if (!partial || !q) return SIPP_E_NOMEM;
     CombArgs c{};
     for (int i = 0; i < 3; i++) { c.src[i] = src[i]; c.cnt[i] = cnt[i]; }
-    c.n = n; c.apow = d_apow; c.n1 = n1; c.slices = slices; c.partial = partial;
+    c.n = n; c.apow3 = d_apow3; c.n1 = n1; c.slices = slices; c.partial = partial;
+    if ((cnt[0] + cnt[1] + cnt[2] + slices - 1) / slices > 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri_combine: more than 1024 columns per slice");
     {
         ProfScope ps(ctx, "fri_combine");
         hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)(n / 256), slices), dim3(256), 0, ctx->stream, c);

@@ -385,16 +385,21 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     const gl::E2 fa = ch.get_ext();
     uint64_t* d_final = arena_alloc_t<uint64_t>(ctx, 2 * n);
     {
-        std::vector<uint64_t> apow((size_t)(W + P + Q) * 2);
+        // limbs of alpha^c (c0, c1) for the lazy combination (prover.hip::fri_combine_kernel)
+        std::vector<uint32_t> apow((size_t)(W + P + Q) * 6);
         gl::E2 ap = gl::e2(1);
         for (int c = 0; c < W + P + Q; c++) {
-            apow[2 * c] = ap.c0;
-            apow[2 * c + 1] = ap.c1;
+            const uint64_t comp[2] = {ap.c0, ap.c1};
+            for (int q = 0; q < 2; q++) {
+                apow[6 * c + 3 * q] = (uint32_t)comp[q] & 0x3FFFFFu;
+                apow[6 * c + 3 * q + 1] = (uint32_t)(comp[q] >> 22) & 0x3FFFFFu;
+                apow[6 * c + 3 * q + 2] = (uint32_t)(comp[q] >> 44);
+            }
             ap = gl::mul(ap, fa);
         }
-        uint64_t* d_apow = arena_alloc_t<uint64_t>(ctx, apow.size());
+        uint32_t* d_apow = arena_alloc_t<uint32_t>(ctx, apow.size());
         if (!d_final || !d_apow) return SIPP_E_NOMEM;
-        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), apow.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), apow.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const uint64_t* src[3] = {T.coeffs, Z.coeffs, Qo.coeffs};
         const int cnt[3] = {W, P, Q};
