@@ -162,6 +162,40 @@ __global__ void __launch_bounds__(256) fri_leaves_kernel(const uint64_t* __restr
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
+// the same with four lanes per leaf (poseidon_quad.cuh): FRI trees are small (2^13, 2^9, 2^5 leaves at n = 128) and sit
+// on the latency-bound tail of a proof, where a lone wave per SIMD takes 50 us per permutation and a quad 18 us
+__global__ void __launch_bounds__(256) fri_leaves_quad_kernel(const uint64_t* __restrict__ vals, uint64_t len,
+                                                             uint64_t* __restrict__ digests) {
+    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
+    poseidon_quad::load_tables(tab);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = tid >> 2;
+    const uint32_t q = (uint32_t)tid & 3;
+    const bool live = k < (len >> 4);   // every lane runs the permutation (DPP needs whole quads)
+    const uint64_t kk = live ? k : 0;
+    const uint64_t* c0 = vals + 16 * kk;
+    const uint64_t* c1 = vals + len + 16 * kk;
+    uint64_t s[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; chunk++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t e = 3 * q + j;
+            if (e < 8) s[j] = (e & 1) ? c1[4 * chunk + (e >> 1)] : c0[4 * chunk + (e >> 1)];
+        }
+        poseidon_quad::permute(s, q, tab);
+    }
+    if (!live) return;
+    uint64_t* d = digests + 4 * k;
+    if (q == 0) {
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+    } else if (q == 1) {
+        d[3] = s[0];
+    }
+}
+
 // proof-of-work grind: candidate nonce w = base + lane; response = state[7] after absorbing (in_buf, w)
 struct PowArgs {
     uint64_t state[12];
@@ -198,8 +232,12 @@ uint64_t quad_threshold() {
 int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests) {
     uint64_t nl = len >> 4;
     ProfScope ps(ctx, "fri_leaves");
-    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
-                       d_digests);
+    if (nl <= quad_threshold())
+        hipLaunchKernelGGL(fri_leaves_quad_kernel, dim3((unsigned)((4 * nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals,
+                           (uint64_t)len, d_digests);
+    else
+        hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
+                           d_digests);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
