@@ -39,7 +39,7 @@ def cpu_baseline(ios, shapes, budget_s=30.0):
     from tests import _oracle
     ncores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
-    sample_io = 16                                    # 16 G1 IO records -> N = 2^13 rows (u8-table AIR variant)
+    sample_io = 32                                    # 32 G1 IO records -> N = 2^14 rows (u8-table AIR variant), ~10 s
     sub = ios[0][:sample_io]
     t = time.time()
     pf = _oracle.stark_prove(0, sub)
