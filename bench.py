@@ -204,9 +204,21 @@ def main():
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected with
         # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "r01_e_pmc.json")
         if args.n == 128 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            pmc = json.load(open(tpath))
+            traffic = pmc.get("traffic_bytes_per_launch")
+            # the kernel's real bound: wave-level VALU instructions per launch (PMC SQ_INSTS_VALU, same command) over the
+            # live launch time, against the issue peak of 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+            # (MI355X_MICROARCH.md, wave scheduling).  39 % of the instructions are v_mad_u64_u32 (~5.4 cycles each), and
+            # the launches share the SIMDs with the two other proofs, so 1.0 is not reachable for this instruction mix.
+            vi = pmc.get("leaf_valu_insts_per_launch")
+            if vi and avg_ms > 0:
+                peak = 256 * 4 * 2.4e9 / 2 / 1e9
+                ach = vi / (avg_ms * 1e-3) / 1e9
+                valu = {"unit": "G wave-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak,
+                        "insts_per_launch": vi}
         out = {
             "metric": "SIPP proof-gen wall-clock + pairings-aggregated/sec, n=%d (the 3 STARK sub-proofs; outer plonky2 proof not included)" % args.n,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,7 +234,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "poseidon_leaves", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launches": launches, "avg_launch_ms": avg_ms,
+                         "launches": launches, "avg_launch_ms": avg_ms, "valu": valu,
                          "note": "integer-VALU-bound kernel (Poseidon x^7 + MDS, ~%.2f G permutations/s); HBM fraction "
                                  "is small by construction, see DESIGN.md" % (leaf_perms * args.steps / (lk["ms"] * 1e-3) / 1e9
                                                                               if lk["ms"] > 0 else 0.0)},

@@ -42,6 +42,11 @@ out = {
     "ntt_pass": {"launches": nf.get("ntt_pass_kernel", 0), "FETCH_SIZE_kb_sum": f["ntt_pass_kernel"]["FETCH_SIZE"],
                  "WRITE_SIZE_kb_sum": w["ntt_pass_kernel"]["WRITE_SIZE"]},
 }
+import os
+if os.path.exists("%s/pmc_v/run_counter_collection.csv" % src):
+    v, nv = counters("pmc_v")
+    out["leaf_valu_insts_per_launch"] = sum(v[k]["SQ_INSTS_VALU"] for k in leaf) / max(1, sum(nv[k] for k in leaf))
+    out["leaf_valu_note"] = "SQ_INSTS_VALU (wave-level VALU instructions) of both leaf-hash kernels, bench.py --steps 2 --warmup 1, per launch"
 i, ni = counters("pmc_i")
 out["valu"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -- python3 scripts/perf_generic.py 16 1024",
                "per_kernel": {k: {"SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_WAVES": v["SQ_WAVES"], "dispatches": ni[k],
