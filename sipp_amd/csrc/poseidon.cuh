@@ -79,38 +79,6 @@ __device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
     mds_full(s);
 }
 
-__device__ __forceinline__ void partial_rounds_fast(uint64_t s[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_fast_first[i]);
-    {
-        uint64_t t[11];
-#pragma unroll 1
-        for (int i = 0; i < 11; i++) {
-            Acc160 acc;
-#pragma unroll
-            for (int j = 0; j < 11; j++) acc.mac(s[j + 1], c_fast_mi[i * 11 + j]);
-            uint64_t v = acc.reduce();
-            // static register indices: write through a switch the compiler turns into v_cndmask/moves
-#pragma unroll
-            for (int q = 0; q < 11; q++)
-                if (q == i) t[q] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 11; i++) s[i + 1] = t[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        uint64_t x = gl::add_nc(sbox(s[0]), c_fast_scalar[r]);
-        Acc160 acc;
-        acc.mac(x, 25);  // M[0][0] = CIRC[0] + DIAG[0]
-#pragma unroll
-        for (int i = 0; i < 11; i++) acc.mac(s[i + 1], c_fast_what[r * 11 + i]);
-#pragma unroll
-        for (int i = 0; i < 11; i++) s[i + 1] = gl::mad_nc(x, c_fast_vs[r * 11 + i], s[i + 1]);
-        s[0] = acc.reduce();
-    }
-}
-
 using gl::Acc6;
 
 __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
