@@ -65,6 +65,19 @@ def test_full_size_n128_proofs_verify(ctx):
         assert _oracle.stark_verify(bad) != 0
 
 
+def test_full_size_n128_proofs_equal_the_oracle_digests(ctx):
+    """word-for-word parity at the BASELINE size: the oracle's n = 128 proofs take minutes of CPU, so their sha256
+    digests are committed (tools/gen_golden.py digests128) and the GPU proofs must hash to the same values."""
+    import hashlib
+    import json
+    gold = json.load(open("tests/golden/proof_digests_n128.json"))
+    d = np.load("tests/golden/sipp_n128_ios.npz")
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        pf = ctx.prove(kind, d[key])
+        assert len(pf) == gold[key]["words"], key
+        assert hashlib.sha256(pf.tobytes()).hexdigest() == gold[key]["sha256"], key
+
+
 def test_error_behaviour(ctx, ios4):
     """the C ABI's error contract (include/sipp_hip.h): wrong claimed output -> SIPP_E_WITNESS (the CPU restatement
     refuses the same record), short buffer -> SIPP_E_BUFSZ, bad arguments -> SIPP_E_BADARG; the ctx stays usable."""

@@ -37,9 +37,30 @@ def proof_digests():
     print("proof digests:", {k: v["sha256"][:16] for k, v in out.items()})
 
 
+def proof_digests_n128():
+    """Digests of the CPU oracle's three sub-proofs at the BASELINE size n = 128 (about ten minutes of CPU on 8 cores):
+    tests/test_gpu_stark.py compares the GPU proofs' digests with them, i.e. full-size word-for-word parity without
+    running the CPU prover inside the test."""
+    import hashlib
+    import json
+    from tests import _oracle
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n128_ios.npz"))
+    out = {}
+    for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
+        t = time.time()
+        pf = _oracle.stark_prove(kind, d[key])
+        assert _oracle.stark_verify(pf) == 0
+        out[key] = {"words": int(len(pf)), "log_n": int(pf[2]), "W": int(pf[4]), "P": int(pf[5]),
+                    "sha256": hashlib.sha256(pf.tobytes()).hexdigest(), "oracle_seconds": round(time.time() - t, 1)}
+        print(key, out[key], flush=True)
+        json.dump(out, open(os.path.join(ROOT, "tests", "golden", "proof_digests_n128.json"), "w"), indent=1)
+
+
 def main():
     if sys.argv[1:] == ["digests"]:
         return proof_digests()
+    if sys.argv[1:] == ["digests128"]:
+        return proof_digests_n128()
     for n in [int(x) for x in sys.argv[1:]]:
         t = time.time()
         A, B = sn.synthetic_inputs(n, SEEDS.get(n, n))
