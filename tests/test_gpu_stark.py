@@ -150,6 +150,10 @@ def test_edge_exponents_and_degenerate_inputs(ctx):
     got = ctx.prove(0, recs)
     assert (got == _oracle.stark_prove(0, recs)).all()
     assert _oracle.stark_verify(got) == 0
+    from tests.test_oracle_air import crafted_g2_records, crafted_fq12_records
+    for kind, r2 in ((1, crafted_g2_records()), (2, crafted_fq12_records())):
+        got2 = ctx.prove(kind, r2)
+        assert (got2 == _oracle.stark_prove(kind, r2)).all(), kind
     from oracle.py import bn254 as bn
     from oracle.py import sipp_native as sn
     x = bn.g1_mul(bn.G1, 77)

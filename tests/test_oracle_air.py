@@ -72,6 +72,40 @@ def crafted_g1_records():
     return np.array(recs, dtype=np.uint32)
 
 
+def crafted_g2_records():
+    """the same edge exponents for G2ExpStark"""
+    from oracle.py import bn254 as bn
+    from oracle.py import sipp_native as sn
+    x = bn.g2_mul(bn.G2, 0x7654321)
+    off = bn.g2_mul(bn.G2, 0xfedcba98)
+    recs = []
+    for e in (0, 1, bn.R - 1, (1 << 253) + 5):
+        out = bn.g2_add(off, bn.g2_mul(x, e)) if e else off
+        recs.append(bn.g2_to_u32(x) + bn.g2_to_u32(off) + sn.exp_to_u32(e) + bn.g2_to_u32(out))
+    return np.array(recs, dtype=np.uint32)
+
+
+def crafted_fq12_records():
+    """edge exponents for Fq12ExpStark: out = offset * x^exp in the pairing target group"""
+    from oracle.py import bn254 as bn
+    from oracle.py import sipp_native as sn
+    g = bn.pairing(bn.G1, bn.G2)
+    x = bn.f12_pow(g, 0x1357)
+    off = bn.f12_pow(g, 0x2468)
+    recs = []
+    for e in (0, 1, bn.R - 1, (1 << 253) + 5):
+        out = bn.f12_mul(off, bn.f12_pow(x, e)) if e else off
+        recs.append(bn.f12_to_u32(x) + bn.f12_to_u32(off) + sn.exp_to_u32(e) + bn.f12_to_u32(out))
+    return np.array(recs, dtype=np.uint32)
+
+
+def test_edge_exponents_g2_fq12_traces_satisfy_the_air():
+    for kind, recs in ((1, crafted_g2_records()), (2, crafted_fq12_records())):
+        t = _oracle.Trace(kind, recs)
+        for r in list(range(0, 4)) + [510, 511, 512, 1023, 1024, 1535, 2047]:
+            assert t.check_row(r) == -1, (kind, r)
+
+
 def test_edge_exponents_and_degenerate_inputs():
     recs = crafted_g1_records()
     t = _oracle.Trace(0, recs)
