@@ -17,8 +17,9 @@
 //    11 multiply-adds instead of a dense MDS -- evaluated LAZILY in two blocks of 11 rounds: lanes 1..11 are
 //    linear in the block's lane-0 values x_t, so inside a block nothing but lane 0 is reduced mod p and every
 //    term is (per-lane u32 half) x (22-bit limb of a wave-uniform constant) accumulated by ONE v_mad_u64_u32
-//    into a 64-bit accumulator that cannot overflow (Acc6).  594 + 121 such six-instruction MACs and 55
-//    reductions replace 242 mulmods, 242 160-bit MACs and 264 reductions.
+//    into a 64-bit accumulator that cannot overflow (Acc6).  594 + 132 such six-instruction MACs and 55
+//    reductions replace 242 mulmods, 242 160-bit MACs and 264 reductions; the dense pre-multiplication is merged
+//    with the linear layer of the full round before it (full_round3_combined).
 //  * the round loops are NOT unrolled (code stays inside the instruction cache); the per-lane loops are.
 #pragma once
 #include "gl.hpp"
@@ -33,7 +34,8 @@ __constant__ uint64_t c_fast_mi[121];
 __constant__ uint64_t c_fast_vs[22 * 11];
 __constant__ uint64_t c_fast_what[22 * 11];
 __constant__ uint32_t c_blk3[2 * SIPP_POSEIDON_BLK_WORDS];
-__constant__ uint32_t c_mi3[363];
+__constant__ uint32_t c_comb3[396];
+__constant__ uint64_t c_comb_c[12];
 
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
@@ -81,26 +83,41 @@ __device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
 
 using gl::Acc6;
 
+// full round 3 without its own MDS: its linear layer, the FIRST constants of the sparse form and the dense 11 x 11
+// pre-multiplication are ONE affine map s -> C s + c (tools/gen_poseidon_header.py combined_layer).  Row 0 of C is row 0 of
+// the MDS (small constants); rows 1..11 are 12 lazy MACs each, with c as the accumulators' start value.
+__device__ __forceinline__ void full_round3_combined(uint64_t s[12]) {
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const uint64_t v = sbox(gl::add_nc(s[i], c_rc[12 * 3 + i]));
+        lo[i] = (uint32_t)v;
+        hi[i] = (uint32_t)(v >> 32);
+    }
+    {
+        constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        uint64_t al = (uint64_t)lo[0] * 8u, ah = (uint64_t)hi[0] * 8u;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (uint64_t)lo[i] * CIRC[i];
+            ah += (uint64_t)hi[i] * CIRC[i];
+        }
+        const uint64_t l = al + (ah << 32);
+        const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
+        s[0] = gl::add_nc(gl::reduce96_nc(h, l), c_comb_c[0]);
+    }
+#pragma unroll
+    for (int i = 1; i < 12; i++) {
+        Acc6 acc;
+        acc.set((uint32_t)c_comb_c[i], (uint32_t)(c_comb_c[i] >> 32));
+#pragma unroll
+        for (int j = 0; j < 12; j++) acc.mac(lo[j], hi[j], c_comb3 + 3 * ((i - 1) * 12 + j));
+        s[i] = acc.reduce();
+    }
+}
+
 __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
     constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_fast_first[i]);
-    {
-        uint32_t sl[11], sh[11];
-#pragma unroll
-        for (int j = 0; j < 11; j++) {
-            sl[j] = (uint32_t)s[j + 1];
-            sh[j] = (uint32_t)(s[j + 1] >> 32);
-        }
-#pragma unroll
-        for (int i = 0; i < 11; i++) {
-            Acc6 acc;
-            acc.zero();
-#pragma unroll
-            for (int j = 0; j < 11; j++) acc.mac(sl[j], sh[j], c_mi3 + 3 * (i * 11 + j));
-            s[i + 1] = acc.reduce();
-        }
-    }
 #pragma unroll 1
     for (int b = 0; b < 22 / B; b++) {
         const uint32_t* __restrict__ T = c_blk3 + SIPP_POSEIDON_BLK_WORDS * b;
@@ -142,7 +159,8 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
 
 __device__ __forceinline__ void permute(uint64_t s[12]) {
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) full_round(s, r);
+    for (int r = 0; r < 3; r++) full_round(s, r);
+    full_round3_combined(s);
     partial_rounds_blocked(s);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) full_round(s, r);

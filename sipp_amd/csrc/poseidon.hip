@@ -289,7 +289,8 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_fast_what), SIPP_POSEIDON_FAST_WHAT,
                                           sizeof(SIPP_POSEIDON_FAST_WHAT)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_blk3), SIPP_POSEIDON_BLK3, sizeof(SIPP_POSEIDON_BLK3)));
-    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_mi3), SIPP_POSEIDON_MI3, sizeof(SIPP_POSEIDON_MI3)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb3), SIPP_POSEIDON_COMB3, sizeof(SIPP_POSEIDON_COMB3)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb_c), SIPP_POSEIDON_COMB_C, sizeof(SIPP_POSEIDON_COMB_C)));
     return SIPP_OK;
 }
 

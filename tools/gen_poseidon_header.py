@@ -239,6 +239,38 @@ def blocked_perm(state, rc, tables, cc):
     return s
 
 
+def combined_layer(first, Mi):
+    """The MDS of the 4th full round, the FIRST constants and the dense pre-multiplication MI' = diag(1, MI) are one
+    affine map s -> C s + c:  C = MI' * MDS (row 0 = row 0 of the MDS: small constants), c = MI' * first."""
+    M = mds_matrix()
+    C = mat_mul(Mi, M)
+    c = mat_vec(Mi, first)
+    assert C[0] == M[0] and c[0] == first[0]
+    return C, c
+
+
+def blocked_perm_combined(state, rc, tables, cc):
+    """blocked_perm with the combined layer (python model of poseidon.cuh::permute)"""
+    first, scalars, Mi, vs, ws = tables
+    M = mds_matrix()
+    C, c = combined_layer(first, Mi)
+    s = state[:]
+    rnd = 0
+    for r in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s) if r < 3 else [(a + b) % P for a, b in zip(mat_vec(C, s), c)]
+        rnd += 1
+    s = blocked_partial(s, scalars, vs, ws, cc)
+    rnd += N_PARTIAL
+    for _ in range(4):
+        s = [(x + rc[12 * rnd + i]) % P for i, x in enumerate(s)]
+        s = [pow(x, 7, P) for x in s]
+        s = mat_vec(M, s)
+        rnd += 1
+    return s
+
+
 def limbs3(c):
     """22 + 22 + 20 bits"""
     assert 0 <= c < P
@@ -290,6 +322,7 @@ def main():
         a, b = naive_perm(st, rc), fast_perm(st, rc, tables)
         assert a == b, ("fast partial rounds mismatch", t)
         assert a == blocked_perm(st, rc, tables, cc), ("blocked partial rounds mismatch", t)
+        assert a == blocked_perm_combined(st, rc, tables, cc), ("combined layer mismatch", t)
     kat0 = naive_perm([0] * 12, rc)
     assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
 
@@ -320,6 +353,12 @@ def main():
         f.write("static const uint32_t SIPP_POSEIDON_BLK3[%d] = {\n" % len(bw) + fmt32(bw) + "\n};\n")
         mi3 = [w for v in mi_flat for w in limbs3(v)]
         f.write("static const uint32_t SIPP_POSEIDON_MI3[363] = {\n" + fmt32(mi3) + "\n};\n")
+        f.write("// rows 1..11 of C = diag(1, MI) * MDS (12 limb triples each) and c = diag(1, MI) * FIRST: the linear layer of\n"
+                "// full round 3, the FIRST constants and the dense pre-multiplication as ONE affine map (row 0 is MDS row 0 + FIRST[0])\n")
+        Cm, cv = combined_layer(first, Mi)
+        comb3 = [w for i in range(1, 12) for j in range(12) for w in limbs3(Cm[i][j])]
+        f.write("static const uint32_t SIPP_POSEIDON_COMB3[396] = {\n" + fmt32(comb3) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_COMB_C[12] = {\n" + fmt(cv) + "\n};\n")
     assert all(Mi[0][j] == (1 if j == 0 else 0) for j in range(12)) and all(Mi[i][0] == 0 for i in range(1, 12))
     print("ok: headers written; fast-partial tables verified against naive permutation")
 
