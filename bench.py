@@ -241,6 +241,16 @@ def main():
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             # compulsory HBM traffic of a whole STARK, 8 N (12 W + 12 P + 7 Q) bytes, over the step time
             "stark_bytes_alg_GBs": sum(8.0 * (1 << s[0]) * (12 * s[1] + 12 * s[2] + 7 * s[3]) for s in shapes) / (ms_per_step * 1e-3) / 1e9,
+            # companion figures of SURVEY.md section 8(d): leaf permutations and NTT butterflies per second of kernel time
+            # (HIP-event time of those kernels, which run concurrently with the other proofs' kernels)
+            "rates": {
+                "poseidon_leaf_perms_per_s": leaf_perms * args.steps / (lk["ms"] * 1e-3) if lk["ms"] > 0 else None,
+                "ntt_butterflies_per_s": (
+                    sum((s[1] + s[2]) * ((1 << s[0]) / 2 * s[0] + (1 << s[0]) * (s[0] + 1))
+                        + (2 + s[3]) * (1 << s[0]) * (s[0] + 1) for s in shapes) * args.steps
+                    / ((prof.get("ntt_dif_pass", {"ms": 0})["ms"] + prof.get("ntt_dit_pass", {"ms": 0})["ms"]) * 1e-3)
+                    if prof.get("ntt_dif_pass", {"ms": 0})["ms"] > 0 else None),
+            },
             "proof_words": [int(len(p)) for p in proofs],
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms],
             "pipelined": pipelined,
