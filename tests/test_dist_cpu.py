@@ -25,7 +25,7 @@ owned = torch.zeros(5, dtype=torch.int64); owned[mine] = 1
 dist.all_reduce(owned)
 assert owned.tolist() == [1] * 5
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rank) + ".ok"), "w").write("ok")
 '''
 
 
@@ -44,4 +44,5 @@ def test_two_rank_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
                          capture_output=True, text=True, timeout=180, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    # per-rank files, not stdout: the two ranks' prints interleave character by character
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), out.stdout + out.stderr
