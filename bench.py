@@ -79,40 +79,27 @@ def main():
     import sipp_amd
     ios = load_ios(args.n)
     # one ctx (= one HIP stream + workspace arena) and one host thread per STARK: the three sub-proofs are
-    # independent, so their thin kernels and Fiat-Shamir round trips overlap
-    from concurrent.futures import ThreadPoolExecutor
-    ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
+    # independent, so their thin kernels and Fiat-Shamir round trips overlap.
+    # The threads are the library's own (sipp_instance_prove = 3 x sipp_prove_async + sipp_wait).
     prios = os.environ.get("SIPP_BENCH_PRIOS", "low,high,high").split(",")   # G1, G2, Fq12
-    ctxs = []
-    for k in range(3):
-        if prios[k]:
-            os.environ["SIPP_STREAM_PRIORITY"] = prios[k]
-        else:
-            os.environ.pop("SIPP_STREAM_PRIORITY", None)
-        ctxs.append(sipp_amd.Ctx(device=local_rank, workspace_bytes=ws[k]))
-    os.environ.pop("SIPP_STREAM_PRIORITY", None)
+    ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios)
+    ctxs = inst.ctxs
     ctx = ctxs[0]
     shapes = [ctx.shape(k, ios[k].shape[0]) for k in range(3)]
-    pool = ThreadPoolExecutor(max_workers=3)
     serial = bool(int(os.environ.get("SIPP_BENCH_SERIAL", "0")))
 
     proof_ms = [0.0, 0.0, 0.0]
 
-    delays = [float(x or 0) * 1e-3 for x in os.environ.get("SIPP_BENCH_DELAYS", ",,").split(",")]   # ms, per proof
-
-    def one(k):
-        if delays[k] > 0 and not serial:
-            time.sleep(delays[k])
-        t = time.perf_counter()
-        p = ctxs[k].prove(k, ios[k])
-        proof_ms[k] += 1e3 * (time.perf_counter() - t)
-        return p
-
     def step():
         if serial:
-            return [one(k) for k in range(3)]
-        res = dict(zip((1, 0, 2), pool.map(one, (1, 0, 2))))  # largest first
-        return [res[0], res[1], res[2]]
+            res = []
+            for k in range(3):
+                t = time.perf_counter()
+                res.append(ctxs[k].prove(k, ios[k]))
+                proof_ms[k] += 1e3 * (time.perf_counter() - t)
+            return res
+        return inst.prove(ios)
 
     def barrier():
         if world > 1:
@@ -152,23 +139,14 @@ def main():
     # trips, FRI tail); a server with a queue of proofs fills them.  `value` above stays the single-instance number.
     pipelined = None
     if args.inflight > 1 and not serial and sum(ws) * args.inflight < (200 << 30):
-        extra = []
-        for _ in range(args.inflight - 1):
-            row = []
-            for k in range(3):
-                if prios[k]:
-                    os.environ["SIPP_STREAM_PRIORITY"] = prios[k]
-                else:
-                    os.environ.pop("SIPP_STREAM_PRIORITY", None)
-                row.append(sipp_amd.Ctx(device=local_rank, workspace_bytes=ws[k]))
-            extra.append(row)
-        os.environ.pop("SIPP_STREAM_PRIORITY", None)
-        groups = [ctxs] + extra
-        pool2 = ThreadPoolExecutor(max_workers=3 * args.inflight)
-        jobs = [(g, k) for k in (1, 0, 2) for g in range(args.inflight)]
+        from concurrent.futures import ThreadPoolExecutor
+        extra = [sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios)
+                 for _ in range(args.inflight - 1)]
+        groups = [inst] + extra
+        pool2 = ThreadPoolExecutor(max_workers=args.inflight)
 
         def pstep():
-            return list(pool2.map(lambda gk: groups[gk[0]][gk[1]].prove(gk[1], ios[gk[1]]), jobs))
+            return list(pool2.map(lambda g: g.prove(ios), groups))
 
         pstep()
         barrier()
@@ -179,9 +157,8 @@ def main():
         dtp = dist_util_max(time.perf_counter() - tp)
         pipelined = {"instances_in_flight": args.inflight, "ms_per_instance": 1e3 * dtp / (args.steps * args.inflight),
                      "value": args.n * world * args.inflight * args.steps / dtp, "unit": "pairings/s"}
-        for row in extra:
-            for c in row:
-                c.close()
+        for g in extra:
+            g.close()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -252,7 +229,7 @@ def main():
                     if prof.get("ntt_dif_pass", {"ms": 0})["ms"] > 0 else None),
             },
             "proof_words": [int(len(p)) for p in proofs],
-            "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms],
+            "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms] if serial else None,
             "pipelined": pipelined,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -262,8 +239,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
+    inst.close()
 
 
 if __name__ == "__main__":

@@ -91,6 +91,26 @@ int sipp_g2_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_
                       size_t *proof_len);
 int sipp_fq12_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
                         size_t *proof_len);
+/* Asynchronous form ("who calls it"): plonky2 runs the three witness generators behind
+ * reference src/verifier_circuit.rs:133-135 serially on one thread, so a patched caller starts each proof as soon as
+ * its IO values exist and collects the three afterwards.  sipp_prove_async hands the job to the ctx's own worker
+ * thread and returns at once; `ios` and `proof_out` must stay valid until sipp_wait returns.  One proof in flight
+ * per ctx (a second sipp_prove_async before sipp_wait fails with SIPP_E_BADARG).  sipp_wait blocks until the
+ * proof is complete and returns ITS status; *proof_len as for the synchronous calls. */
+int sipp_prove_async(sipp_ctx *ctx, int kind, const uint32_t *ios, size_t num_io, uint64_t *proof_out,
+                     size_t proof_cap);
+int sipp_wait(sipp_ctx *ctx, size_t *proof_len);
+/* One SIPP instance = the three sub-proofs, concurrently on three DISTINCT ctxs (one HIP stream each; they may sit
+ * on one GPU or on up to three GPUs, SURVEY.md section 8e level L-B).  Arrays are indexed by sipp_kind.  Returns the
+ * first failing status; every proof that was started is waited for in any case. */
+int sipp_instance_prove(sipp_ctx *const ctxs[3], const uint32_t *const ios[3], const size_t num_io[3],
+                        uint64_t *const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]);
+/* The outputs alone: what the generators behind g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit assign to the
+ * returned output targets (reference src/verifier_circuit.rs:133-135 `*_exp_outputs`): out = offset + [exp_val] x
+ * (G1, G2) or offset * x^exp_val (Fq12), computed on the device by the trace kernels' accumulator chains.  `ios` are
+ * full-size records as for the provers; their (x, offset, exp_val) words are read and their output words are
+ * OVERWRITTEN.  Unprovable inputs (a point at infinity on the way) return SIPP_E_WITNESS as in the provers. */
+int sipp_exp_outputs(sipp_ctx *ctx, int kind, uint32_t *ios, size_t num_io);
 /* upper bound (u64 words) of the flat proof for `num_io` records of `kind` */
 size_t sipp_proof_size(const sipp_ctx *ctx, int kind, size_t num_io);
 /* HBM workspace (bytes) one proof of `kind` with `num_io` records needs; pass it (or more) to sipp_ctx_create */

@@ -1,0 +1,361 @@
+// sipp_host.hpp -- C++ host side above the C ABI of sipp_hip.h.
+//
+// The reference is Rust (no toolchain in this image), so the host layer a maintainer would write in Rust is written
+// here in C++ with the reference's own names and argument meaning:
+//
+//   reference (src/verifier_circuit.rs)                              here
+//   -------------------------------------------------------------    ------------------------------------------------
+//   G1ExpInputTarget  { x, offset, exp_val }            :92-96       sipp::G1ExpInput   { x, offset, exp_val }
+//   G2ExpInputTarget  { x, offset, exp_val }            :101-105     sipp::G2ExpInput
+//   Fq12ExpInputTarget{ x, offset, exp_val }            :111-115     sipp::Fq12ExpInput
+//   g1_exp_circuit(builder, &inputs)  -> Vec<G1Target>  :133         sipp::Prover::g1_exp_circuit(inputs)  -> outputs + proof
+//   g2_exp_circuit / fq12_exp_circuit                   :134-135     sipp::Prover::g2_exp_circuit / fq12_exp_circuit
+//   StarkProofWithPublicInputs<F, C, D> (starky)                     sipp::StarkProofWithPublicInputs (same field names)
+//   anyhow::Error at the .unwrap() of :253                           sipp::Error (carries the sipp_status)
+//
+// In the reference the three calls add a recursive verifier gadget and register a witness generator; at proving time the
+// generator computes the outputs natively, fills the trace and runs starky::prover::prove.  Prover::*_exp_circuit is that
+// proving-time body: outputs (sipp_exp_outputs) and proof (sipp_*_exp_prove) both come from the GPU.
+// Header-only; link with -lsipp_hip.  No torch, no HIP types.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "sipp_hip.h"
+
+namespace sipp {
+
+// ---- BN254 values as the reference serialises them: 8 x u32 little-endian limbs (transcript_native.rs:68-77) ----
+using U256 = std::array<uint32_t, 8>;
+struct Fq2 {
+    U256 c0, c1;  // statements.rs:102-119 order
+};
+struct G1Affine {
+    U256 x, y;
+};
+struct G2Affine {
+    Fq2 x, y;
+};
+struct Fq12 {
+    std::array<U256, 12> c;  // MyFq12 coefficient order (verifier_circuit.rs:111-124)
+};
+
+struct G1ExpInput {
+    G1Affine x, offset;
+    U256 exp_val;
+};
+struct G2ExpInput {
+    G2Affine x, offset;
+    U256 exp_val;
+};
+struct Fq12ExpInput {
+    Fq12 x, offset;
+    U256 exp_val;
+};
+
+// one IO record of the C ABI = input followed by the output
+template <class In, class Out>
+struct ExpIO {
+    In in;
+    Out out;
+};
+using G1ExpIO = ExpIO<G1ExpInput, G1Affine>;
+using G2ExpIO = ExpIO<G2ExpInput, G2Affine>;
+using Fq12ExpIO = ExpIO<Fq12ExpInput, Fq12>;
+static_assert(sizeof(G1ExpIO) == 4 * SIPP_G1_IO_WORDS, "G1 IO record layout");
+static_assert(sizeof(G2ExpIO) == 4 * SIPP_G2_IO_WORDS, "G2 IO record layout");
+static_assert(sizeof(Fq12ExpIO) == 4 * SIPP_FQ12_IO_WORDS, "Fq12 IO record layout");
+
+// ---- errors: the reference's call sites unwrap an anyhow::Result; here a failing status throws ----
+class Error : public std::runtime_error {
+   public:
+    Error(int status, const std::string& what) : std::runtime_error(what), status_(status) {}
+    int status() const { return status_; }
+
+   private:
+    int status_;
+};
+
+// ---- starky's proof structs (field names of starky::proof / plonky2::fri::proof) ----
+using F = uint64_t;  // canonical Goldilocks
+struct Ext {
+    F c0, c1;
+    bool operator==(const Ext& o) const { return c0 == o.c0 && c1 == o.c1; }
+};
+using HashOut = std::array<F, 4>;
+using MerkleCap = std::vector<HashOut>;
+struct MerkleProof {
+    std::vector<HashOut> siblings;
+};
+struct StarkOpeningSet {
+    std::vector<Ext> local_values, next_values, permutation_zs, permutation_zs_next, quotient_polys;
+};
+struct FriInitialTreeProof {
+    std::vector<std::pair<std::vector<F>, MerkleProof>> evals_proofs;  // trace, permutation Zs, quotient
+};
+struct FriQueryStep {
+    std::vector<Ext> evals;
+    MerkleProof merkle_proof;
+};
+struct FriQueryRound {
+    FriInitialTreeProof initial_trees_proof;
+    std::vector<FriQueryStep> steps;
+};
+struct FriProof {
+    std::vector<MerkleCap> commit_phase_merkle_caps;
+    std::vector<FriQueryRound> query_round_proofs;
+    std::vector<Ext> final_poly;
+    F pow_witness = 0;
+};
+struct StarkProof {
+    MerkleCap trace_cap, permutation_zs_cap, quotient_polys_cap;
+    StarkOpeningSet openings;
+    FriProof opening_proof;
+};
+
+struct StarkProofWithPublicInputs {
+    // shape (the flat buffer's header)
+    uint32_t kind = 0, degree_bits = 0, num_io = 0, main_cols = 0, perm_cols = 0, quotient_cols = 0, cap_height = 0,
+             pi_per_io = 0;
+    StarkProof proof;
+    std::vector<F> public_inputs;  // the (padded) IO records, one field element per u32 word
+
+    static constexpr uint64_t MAGIC = 0x5349505053544b31ULL;  // "SIPPSTK1"
+
+    static StarkProofWithPublicInputs from_flat(const uint64_t* w, size_t len) {
+        if (len < 16 || w[0] != MAGIC || w[12] != len) throw Error(SIPP_E_BADARG, "from_flat: not a SIPP STARK proof buffer");
+        StarkProofWithPublicInputs p;
+        p.kind = (uint32_t)w[1];
+        p.degree_bits = (uint32_t)w[2];
+        p.num_io = (uint32_t)w[3];
+        p.main_cols = (uint32_t)w[4];
+        p.perm_cols = (uint32_t)w[5];
+        p.quotient_cols = (uint32_t)w[6];
+        p.cap_height = (uint32_t)w[7];
+        p.pi_per_io = (uint32_t)w[11];
+        const uint32_t rounds = (uint32_t)w[8], final_len = (uint32_t)w[9], nq = (uint32_t)w[10];
+        const uint32_t log_m = p.degree_bits + 1, ncap = 1u << p.cap_height;
+        size_t pos = 16;
+        auto need = [&](size_t cnt) {
+            if (pos + cnt > len) throw Error(SIPP_E_BUFSZ, "from_flat: truncated proof");
+        };
+        auto hashes = [&](size_t cnt) {
+            need(4 * cnt);
+            std::vector<HashOut> v(cnt);
+            for (size_t i = 0; i < cnt; i++, pos += 4) v[i] = HashOut{w[pos], w[pos + 1], w[pos + 2], w[pos + 3]};
+            return v;
+        };
+        auto exts = [&](size_t cnt) {
+            need(2 * cnt);
+            std::vector<Ext> v(cnt);
+            for (size_t i = 0; i < cnt; i++, pos += 2) v[i] = Ext{w[pos], w[pos + 1]};
+            return v;
+        };
+        auto bases = [&](size_t cnt) {
+            need(cnt);
+            std::vector<F> v(w + pos, w + pos + cnt);
+            pos += cnt;
+            return v;
+        };
+        StarkProof& s = p.proof;
+        s.trace_cap = hashes(ncap);
+        s.permutation_zs_cap = hashes(ncap);
+        s.quotient_polys_cap = hashes(ncap);
+        s.openings.local_values = exts(p.main_cols);
+        s.openings.next_values = exts(p.main_cols);
+        s.openings.permutation_zs = exts(p.perm_cols);
+        s.openings.permutation_zs_next = exts(p.perm_cols);
+        s.openings.quotient_polys = exts(p.quotient_cols);
+        FriProof& f = s.opening_proof;
+        for (uint32_t r = 0; r < rounds; r++) f.commit_phase_merkle_caps.push_back(hashes(ncap));
+        f.final_poly = exts(final_len);
+        need(1);
+        f.pow_witness = w[pos++];
+        const uint32_t cols[3] = {p.main_cols, p.perm_cols, p.quotient_cols};
+        f.query_round_proofs.resize(nq);
+        for (uint32_t q = 0; q < nq; q++) {
+            FriQueryRound& qr = f.query_round_proofs[q];
+            for (int o = 0; o < 3; o++) {
+                std::vector<F> row = bases(cols[o]);
+                qr.initial_trees_proof.evals_proofs.emplace_back(std::move(row), MerkleProof{hashes(log_m - p.cap_height)});
+            }
+            for (uint32_t r = 0; r < rounds; r++) {
+                const uint32_t lt = log_m - 4 * (r + 1);
+                FriQueryStep st;
+                st.evals = exts(16);
+                st.merkle_proof.siblings = hashes(lt > p.cap_height ? lt - p.cap_height : 0);
+                qr.steps.push_back(std::move(st));
+            }
+        }
+        p.public_inputs = bases((size_t)p.num_io * p.pi_per_io);
+        if (pos != len) throw Error(SIPP_E_BUFSZ, "from_flat: trailing words");
+        return p;
+    }
+
+    std::vector<uint64_t> to_flat() const {
+        std::vector<uint64_t> w(16, 0);
+        const StarkProof& s = proof;
+        const FriProof& f = s.opening_proof;
+        auto hashes = [&](const std::vector<HashOut>& v) {
+            for (const HashOut& h : v) w.insert(w.end(), h.begin(), h.end());
+        };
+        auto exts = [&](const std::vector<Ext>& v) {
+            for (const Ext& e : v) {
+                w.push_back(e.c0);
+                w.push_back(e.c1);
+            }
+        };
+        hashes(s.trace_cap);
+        hashes(s.permutation_zs_cap);
+        hashes(s.quotient_polys_cap);
+        exts(s.openings.local_values);
+        exts(s.openings.next_values);
+        exts(s.openings.permutation_zs);
+        exts(s.openings.permutation_zs_next);
+        exts(s.openings.quotient_polys);
+        for (const MerkleCap& c : f.commit_phase_merkle_caps) hashes(c);
+        exts(f.final_poly);
+        w.push_back(f.pow_witness);
+        for (const FriQueryRound& qr : f.query_round_proofs) {
+            for (const auto& ep : qr.initial_trees_proof.evals_proofs) {
+                w.insert(w.end(), ep.first.begin(), ep.first.end());
+                hashes(ep.second.siblings);
+            }
+            for (const FriQueryStep& st : qr.steps) {
+                exts(st.evals);
+                hashes(st.merkle_proof.siblings);
+            }
+        }
+        w.insert(w.end(), public_inputs.begin(), public_inputs.end());
+        const uint64_t hdr[13] = {MAGIC, kind, degree_bits, num_io, main_cols, perm_cols, quotient_cols, cap_height,
+                                  (uint64_t)f.commit_phase_merkle_caps.size(), (uint64_t)f.final_poly.size(),
+                                  (uint64_t)f.query_round_proofs.size(), pi_per_io, (uint64_t)w.size()};
+        std::memcpy(w.data(), hdr, sizeof hdr);
+        return w;
+    }
+};
+
+template <class Out>
+struct ExpCircuitResult {
+    std::vector<Out> outputs;          // what g*_exp_circuit returns as targets, as values
+    StarkProofWithPublicInputs proof;  // what the generator writes into the recursive verifier's proof target
+    std::vector<uint64_t> flat;        // the same proof as the C ABI returned it
+};
+
+// One GPU, three sub-provers (three ctxs = three HIP streams), sized for the IO counts given at construction
+// (no device allocation afterwards, SURVEY.md section 8b "threading").
+class Prover {
+   public:
+    Prover(int device, size_t max_g1_io, size_t max_g2_io, size_t max_fq12_io) {
+        const size_t mx[3] = {max_g1_io, max_g2_io, max_fq12_io};
+        for (int k = 0; k < 3; k++) {
+            max_io_[k] = mx[k];
+            const int rc = sipp_ctx_create(&ctx_[k], device, nullptr, sipp_workspace_bytes(k, mx[k]));
+            if (rc != SIPP_OK) {
+                for (int j = 0; j < k; j++) sipp_ctx_destroy(ctx_[j]);
+                throw Error(rc, "sipp_ctx_create failed (see stderr)");
+            }
+        }
+    }
+    ~Prover() {
+        for (sipp_ctx* c : ctx_) sipp_ctx_destroy(c);
+    }
+    Prover(const Prover&) = delete;
+    Prover& operator=(const Prover&) = delete;
+
+    ExpCircuitResult<G1Affine> g1_exp_circuit(const std::vector<G1ExpInput>& inputs) {
+        return run<G1ExpInput, G1Affine>(SIPP_G1_EXP, inputs);
+    }
+    ExpCircuitResult<G2Affine> g2_exp_circuit(const std::vector<G2ExpInput>& inputs) {
+        return run<G2ExpInput, G2Affine>(SIPP_G2_EXP, inputs);
+    }
+    ExpCircuitResult<Fq12> fq12_exp_circuit(const std::vector<Fq12ExpInput>& inputs) {
+        return run<Fq12ExpInput, Fq12>(SIPP_FQ12_EXP, inputs);
+    }
+
+    // the three calls of verifier_circuit.rs:133-135 together: outputs first, then the three proofs concurrently
+    void exp_circuits(const std::vector<G1ExpInput>& g1, const std::vector<G2ExpInput>& g2, const std::vector<Fq12ExpInput>& fq12,
+                      ExpCircuitResult<G1Affine>* r1, ExpCircuitResult<G2Affine>* r2, ExpCircuitResult<Fq12>* r12) {
+        std::vector<G1ExpIO> io1 = outputs<G1ExpInput, G1Affine>(SIPP_G1_EXP, g1);
+        std::vector<G2ExpIO> io2 = outputs<G2ExpInput, G2Affine>(SIPP_G2_EXP, g2);
+        std::vector<Fq12ExpIO> io12 = outputs<Fq12ExpInput, Fq12>(SIPP_FQ12_EXP, fq12);
+        const uint32_t* ios[3] = {words(io1), words(io2), words(io12)};
+        const size_t num[3] = {io1.size(), io2.size(), io12.size()};
+        size_t cap[3], len[3] = {0, 0, 0};
+        std::vector<uint64_t>* flat[3] = {&r1->flat, &r2->flat, &r12->flat};
+        uint64_t* out[3];
+        for (int k = 0; k < 3; k++) {
+            cap[k] = sipp_proof_size(ctx_[k], k, num[k]);
+            flat[k]->assign(cap[k], 0);
+            out[k] = flat[k]->data();
+        }
+        const int rc = sipp_instance_prove(ctx_, ios, num, out, cap, len);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_instance_prove: ") + first_error());
+        for (int k = 0; k < 3; k++) flat[k]->resize(len[k]);
+        finish(io1, r1);
+        finish(io2, r2);
+        finish(io12, r12);
+    }
+
+    sipp_ctx* ctx(int kind) { return ctx_[kind]; }
+
+   private:
+    sipp_ctx* ctx_[3] = {nullptr, nullptr, nullptr};
+    size_t max_io_[3] = {0, 0, 0};
+
+    template <class IO>
+    static const uint32_t* words(const std::vector<IO>& v) {
+        return reinterpret_cast<const uint32_t*>(v.data());
+    }
+    std::string first_error() const {
+        for (sipp_ctx* c : ctx_) {
+            const char* e = sipp_last_error(c);
+            if (e && *e) return e;
+        }
+        return "";
+    }
+    template <class In, class Out>
+    std::vector<ExpIO<In, Out>> outputs(int kind, const std::vector<In>& inputs) {
+        if (inputs.empty() || inputs.size() > max_io_[kind]) throw Error(SIPP_E_BADARG, "exp_circuit: IO count out of range");
+        std::vector<ExpIO<In, Out>> io(inputs.size());
+        for (size_t i = 0; i < inputs.size(); i++) {
+            io[i].in = inputs[i];
+            std::memset(&io[i].out, 0, sizeof(Out));
+        }
+        const int rc = sipp_exp_outputs(ctx_[kind], kind, reinterpret_cast<uint32_t*>(io.data()), io.size());
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_exp_outputs: ") + sipp_last_error(ctx_[kind]));
+        return io;
+    }
+    template <class In, class Out>
+    static void finish(const std::vector<ExpIO<In, Out>>& io, ExpCircuitResult<Out>* r) {
+        r->outputs.resize(io.size());
+        for (size_t i = 0; i < io.size(); i++) r->outputs[i] = io[i].out;
+        r->proof = StarkProofWithPublicInputs::from_flat(r->flat.data(), r->flat.size());
+    }
+    template <class In, class Out>
+    ExpCircuitResult<Out> run(int kind, const std::vector<In>& inputs) {
+        std::vector<ExpIO<In, Out>> io = outputs<In, Out>(kind, inputs);
+        ExpCircuitResult<Out> r;
+        const size_t cap = sipp_proof_size(ctx_[kind], kind, io.size());
+        r.flat.assign(cap, 0);
+        size_t len = 0;
+        int rc;
+        if (kind == SIPP_G1_EXP)
+            rc = sipp_g1_exp_prove(ctx_[kind], words(io), io.size(), r.flat.data(), cap, &len);
+        else if (kind == SIPP_G2_EXP)
+            rc = sipp_g2_exp_prove(ctx_[kind], words(io), io.size(), r.flat.data(), cap, &len);
+        else
+            rc = sipp_fq12_exp_prove(ctx_[kind], words(io), io.size(), r.flat.data(), cap, &len);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_exp_prove: ") + sipp_last_error(ctx_[kind]));
+        r.flat.resize(len);
+        finish(io, &r);
+        return r;
+    }
+};
+
+}  // namespace sipp

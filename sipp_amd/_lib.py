@@ -42,6 +42,11 @@ SIGNATURES = {
     "sipp_g1_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_g2_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
+    "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "sipp_instance_prove": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "sipp_exp_outputs": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
@@ -210,6 +215,31 @@ class Ctx:
         self._ck(fn(self.h, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
         return out[: n.value]
 
+    def exp_outputs(self, kind, ios):
+        """copy of the records with the output words computed on the device (sipp_exp_outputs)"""
+        rec = np.array(ios, dtype=np.uint32, order="C", copy=True)
+        self._ck(self.L.sipp_exp_outputs(self.h, kind, rec.ctypes.data, rec.shape[0]), "exp_outputs")
+        return rec
+
+    def prove_async(self, kind, ios):
+        """start one sub-proof on the ctx's worker thread (sipp_prove_async); collect it with wait()"""
+        ios = np.ascontiguousarray(ios, dtype=np.uint32)
+        cap = self.L.sipp_proof_size(self.h, kind, ios.shape[0])
+        if cap == 0:
+            raise SippError(-1, "sipp_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        self._ck(self.L.sipp_prove_async(self.h, kind, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap), "prove_async")
+        self._inflight = (ios, out)      # both buffers stay alive until wait()
+        return self
+
+    def wait(self):
+        n = C.c_size_t()
+        rc = self.L.sipp_wait(self.h, C.byref(n))
+        ios, out = getattr(self, "_inflight", None) or (None, None)
+        self._inflight = None
+        self._ck(rc, "wait")
+        return out[: n.value]
+
     def poseidon_permute(self, states):
         self._ck(self.L.sipp_poseidon_permute(self.h, states.data_ptr(), states.shape[0]), "poseidon_permute")
         return states
@@ -233,3 +263,50 @@ class Ctx:
         ms = C.c_float()
         self._ck(self.L.sipp_timer_stop(self.h, C.byref(ms)), "timer_stop")
         return ms.value
+
+
+class Instance:
+    """The three sub-proofs of one SIPP instance (reference src/verifier_circuit.rs:133-135) on three ctxs = three HIP
+    streams, started together through sipp_instance_prove.  `devices` may name one GPU (default) or three
+    (level L-B).  `priorities`: stream priority per kind ("high" / "low" / "")."""
+
+    def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "high", "high")):
+        self.L = lib()
+        self.num_io = tuple(int(x) for x in num_io)
+        self.ctxs = []
+        for k in range(3):
+            if priorities[k]:
+                os.environ["SIPP_STREAM_PRIORITY"] = priorities[k]
+            else:
+                os.environ.pop("SIPP_STREAM_PRIORITY", None)
+            try:
+                self.ctxs.append(Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, self.num_io[k])))
+            finally:
+                os.environ.pop("SIPP_STREAM_PRIORITY", None)
+        self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) for k in range(3)]
+        self.out = [np.zeros(c, dtype=np.uint64) for c in self.caps]
+
+    def prove(self, ios):
+        """ios: [g1, g2, fq12] host uint32 arrays -> three flat proofs (views of this object's output buffers)"""
+        ios = [np.ascontiguousarray(a, dtype=np.uint32) for a in ios]
+        assert tuple(a.shape[0] for a in ios) == self.num_io
+        h = (vp * 3)(*[c.h for c in self.ctxs])
+        pi = (vp * 3)(*[a.ctypes.data for a in ios])
+        ni = (C.c_size_t * 3)(*self.num_io)
+        po = (vp * 3)(*[o.ctypes.data for o in self.out])
+        pc = (C.c_size_t * 3)(*self.caps)
+        pl = (C.c_size_t * 3)()
+        rc = self.L.sipp_instance_prove(h, pi, ni, po, pc, pl)
+        if rc != 0:
+            msgs = "; ".join(self.L.sipp_last_error(c.h).decode() for c in self.ctxs)
+            raise SippError(rc, "instance_prove: " + msgs)
+        return [self.out[k][: pl[k]] for k in range(3)]
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []

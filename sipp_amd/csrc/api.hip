@@ -69,6 +69,16 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
 
 void sipp_ctx_destroy(sipp_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->async.started) {
+        // a proof still in flight runs to its end (its buffers belong to the caller until then), then the worker exits
+        {
+            std::unique_lock<std::mutex> lk(ctx->async.mu);
+            ctx->async.cv.wait(lk, [&] { return !ctx->async.has_job || ctx->async.done; });
+            ctx->async.quit = true;
+        }
+        ctx->async.cv.notify_all();
+        ctx->async.th.join();
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second);

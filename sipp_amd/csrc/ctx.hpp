@@ -9,8 +9,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -48,6 +51,22 @@ struct sipp_ctx {
     // pinned host staging
     uint64_t* h_pinned = nullptr;
     size_t h_pinned_words = 0;
+
+    // sipp_exp_outputs: sipp_trace_fill stops after the accumulator chains and writes the outputs into the records
+    bool outputs_only = false;
+
+    // sipp_prove_async / sipp_wait: one worker thread per ctx, started on first use, one job at a time
+    struct Async {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool started = false, has_job = false, done = false, quit = false;
+        int kind = 0;
+        const uint32_t* ios = nullptr;
+        size_t num_io = 0, cap = 0, len = 0;
+        uint64_t* out = nullptr;
+        int rc = 0;
+    } async;
 };
 
 #define SIPP_CHECK_HIP(ctx, expr)                                                                   \

@@ -569,6 +569,39 @@ int sipp_trace_build(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io
     return rc;
 }
 
+int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
+    if (!ctx || !ios) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    Shape s;
+    SIPP_TRY(shape_of(kind, num_io, &s));
+    const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : kind == SIPP_G2_EXP ? 32 : 96;
+    ArenaMark m = arena_mark(ctx);
+    uint32_t* d_ios = nullptr;
+    int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
+    int* d_err = arena_alloc_t<int>(ctx, 1);
+    uint64_t* d_trace = arena_alloc_t<uint64_t>(ctx, (size_t)s.W << s.log_n);
+    if (rc == SIPP_OK && (!d_err || !d_trace)) rc = SIPP_E_NOMEM;
+    if (rc == SIPP_OK) {
+        SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+        ctx->outputs_only = true;
+        rc = sipp_trace_fill(ctx, s.air, d_ios, s.num_io, s.log_n, d_trace, d_err);
+        ctx->outputs_only = false;
+    }
+    if (rc == SIPP_OK) {
+        int h_err = 0;
+        uint32_t* h = reinterpret_cast<uint32_t*>(ctx->h_pinned);
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(h, d_ios, num_io * ppi * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        rc = sipp_sync(ctx);
+        if (rc == SIPP_OK && h_err) rc = sipp_fail(ctx, h_err, "exp_outputs: IO record not provable");
+        if (rc == SIPP_OK)
+            for (size_t io = 0; io < num_io; io++)
+                memcpy(ios + io * ppi + (ppi - out_words), h + io * ppi + (ppi - out_words), out_words * 4);
+    }
+    arena_release(ctx, m);
+    return rc;
+}
+
 int sipp_g1_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     return prove_impl(ctx, SIPP_G1_EXP, ios, num_io, proof_out, proof_cap, proof_len);
@@ -580,5 +613,88 @@ int sipp_g2_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_
 int sipp_fq12_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
                         size_t* proof_len) {
     return prove_impl(ctx, SIPP_FQ12_EXP, ios, num_io, proof_out, proof_cap, proof_len);
+}
+
+// ---- asynchronous form -------------------------------------------------------------------------------------
+// plonky2 runs its witness generators serially on one thread (SURVEY.md section 8b "who calls it"): a patched caller
+// starts the three proofs on three ctxs as soon as the IO values exist and collects them afterwards.  The prover
+// needs a host thread of its own (Fiat-Shamir challenges are derived on the host between phases), so every ctx
+// owns one worker, created on the first sipp_prove_async and joined by sipp_ctx_destroy.
+static void async_worker(sipp_ctx* ctx) {
+    sipp_ctx::Async& a = ctx->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    for (;;) {
+        a.cv.wait(lk, [&] { return a.quit || (a.has_job && !a.done); });
+        if (a.quit) return;
+        lk.unlock();
+        size_t len = 0;
+        const int rc = prove_impl(ctx, a.kind, a.ios, a.num_io, a.out, a.cap, &len);
+        lk.lock();
+        a.rc = rc;
+        a.len = len;
+        a.done = true;
+        a.cv.notify_all();
+    }
+}
+
+int sipp_prove_async(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap) {
+    if (!ctx || !ios || !proof_out) return SIPP_E_BADARG;
+    if (kind < SIPP_G1_EXP || kind > SIPP_FQ12_EXP) return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: unknown kind");
+    sipp_ctx::Async& a = ctx->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    if (a.has_job) {
+        lk.unlock();
+        return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: a proof is already in flight on this ctx (call sipp_wait first)");
+    }
+    a.kind = kind;
+    a.ios = ios;
+    a.num_io = num_io;
+    a.out = proof_out;
+    a.cap = proof_cap;
+    a.len = 0;
+    a.rc = SIPP_OK;
+    a.done = false;
+    a.has_job = true;
+    if (!a.started) {
+        a.started = true;
+        a.th = std::thread(async_worker, ctx);
+    }
+    a.cv.notify_all();
+    return SIPP_OK;
+}
+
+int sipp_wait(sipp_ctx* ctx, size_t* proof_len) {
+    if (!ctx) return SIPP_E_BADARG;
+    sipp_ctx::Async& a = ctx->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    if (!a.has_job) {
+        lk.unlock();
+        return sipp_fail(ctx, SIPP_E_BADARG, "wait: no proof in flight on this ctx");
+    }
+    a.cv.wait(lk, [&] { return a.done; });
+    a.has_job = false;
+    if (proof_len) *proof_len = a.len;
+    return a.rc;
+}
+
+int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], const size_t num_io[3],
+                        uint64_t* const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]) {
+    if (!ctxs || !ios || !num_io || !proof_out || !proof_cap || !proof_len) return SIPP_E_BADARG;
+    for (int k = 0; k < 3; k++)
+        if (!ctxs[k]) return SIPP_E_BADARG;
+    if (ctxs[0] == ctxs[1] || ctxs[0] == ctxs[2] || ctxs[1] == ctxs[2]) return SIPP_E_BADARG;
+    static const int order[3] = {SIPP_G2_EXP, SIPP_G1_EXP, SIPP_FQ12_EXP};  // the largest proof first
+    int started[3] = {0, 0, 0}, rc = SIPP_OK;
+    for (int i = 0; i < 3 && rc == SIPP_OK; i++) {
+        const int k = order[i];
+        rc = sipp_prove_async(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k]);
+        started[k] = rc == SIPP_OK;
+    }
+    for (int k = 0; k < 3; k++) {
+        if (!started[k]) continue;
+        const int r = sipp_wait(ctxs[k], &proof_len[k]);  // every started proof is collected, also after a failure
+        if (rc == SIPP_OK) rc = r;
+    }
+    return rc;
 }
 }

@@ -498,6 +498,41 @@ __global__ void check_outputs_kernel(const uint32_t* __restrict__ ios, uint32_t 
     if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
 
+// the same cells read back INTO the records (sipp_exp_outputs): the inverse of check_outputs_kernel
+__global__ void write_outputs_kernel(uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi, int kind,
+                                     const uint64_t* __restrict__ tr, size_t n, int col_state) {
+    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
+    if (io >= num_io) return;
+    const size_t row = (size_t)io * 512 + 511;
+    uint32_t* rec = ios + (size_t)io * ppi;
+    if (kind == 2) {
+        // cells: tower basis (a_i = c_i + 9 c_{i+6}, b_i = c_{i+6}) as 16-bit limbs -> MyFq12 coefficients c_i = a_i - 9 b_i
+        uint32_t* outw = rec + ppi - 96;
+        const Fq m9 = fq::small_m(9);
+        for (int i = 0; i < 6; i++) {
+            Fq ab[2];
+            for (int h = 0; h < 2; h++) {
+                uint32_t w[8];
+                for (int l = 0; l < 8; l++)
+                    w[l] = (uint32_t)tr[(size_t)(col_state + 16 * (2 * i + h) + 2 * l) * n + row] |
+                           ((uint32_t)tr[(size_t)(col_state + 16 * (2 * i + h) + 2 * l + 1) * n + row] << 16);
+                ab[h] = Fld<1>::load(w);
+            }
+            const Fq lo = fq::from_mont(fq::sub(ab[0], fq::mul(m9, ab[1]))), hi = fq::from_mont(ab[1]);
+            for (int l = 0; l < 8; l++) {
+                outw[8 * i + l] = lo.l[l];
+                outw[8 * (i + 6) + l] = hi.l[l];
+            }
+        }
+    } else {
+        const int words = kind == 0 ? 16 : 32;
+        uint32_t* outw = rec + ppi - words;
+        for (int wd = 0; wd < words; wd++)
+            outw[wd] = (uint32_t)tr[(size_t)(col_state + 2 * wd) * n + row] |
+                       ((uint32_t)tr[(size_t)(col_state + 2 * wd + 1) * n + row] << 16);
+    }
+}
+
 // ---- exponent cells: closed form per row ----
 __global__ void exp_rows_kernel(const uint32_t* __restrict__ ios, uint32_t ppi, uint32_t exp_off, uint64_t* __restrict__ tr,
                                 size_t n, int col_bit, int col_e) {
@@ -923,6 +958,14 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                d_trace, n, c, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         }
+    }
+    if (ctx->outputs_only) {
+        // sipp_exp_outputs: the accumulator cells of every block's last row are the outputs; nothing else is needed
+        hipLaunchKernelGGL(write_outputs_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios),
+                           num_io, (uint32_t)a->pi_per_io, a->kind, d_trace, n, 1);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        arena_release(ctx, mark);
+        return SIPP_OK;
     }
     {
         // accumulator state columns: R (curves, column 1) or acc (Fq12, column 1)

@@ -1,0 +1,147 @@
+// tests/host/test_sipp_circuit.cpp -- the C++ host layer (include/sipp_host.hpp) driven the way the reference's own
+// test drives the path (src/verifier_circuit.rs:192-269 `test_sipp_circuit`): build the three obligation lists, run
+// g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit, check the outputs against the native chain, verify the proofs.
+//
+//   test_sipp_circuit layout                      CPU only: record layouts, from_flat / to_flat round trip of <proof.bin>
+//   test_sipp_circuit layout <proof.bin>
+//   test_sipp_circuit prove <ios.bin> <out_prefix>   GPU: <ios.bin> = 3 x (u64 count, records); writes <out_prefix>{0,1,2}.bin
+//
+// The verifier is the CPU oracle's (test infrastructure), linked only into this test binary.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+
+#include "sipp_host.hpp"
+
+struct orc_config {
+    uint32_t rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries, num_challenges;
+};
+extern "C" void orc_default_config(orc_config* c);
+extern "C" int orc_stark_verify(const uint64_t* proof, size_t len, const orc_config* cfg);
+
+static std::vector<uint64_t> read_u64(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) {
+        fprintf(stderr, "cannot open %s\n", path);
+        exit(2);
+    }
+    const size_t bytes = (size_t)f.tellg();
+    std::vector<uint64_t> v(bytes / 8);
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * 8));
+    return v;
+}
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+static int layout(const char* proof_path) {
+    CHECK(sizeof(sipp::G1ExpInput) == 4 * (SIPP_G1_IO_WORDS - 16));
+    CHECK(sizeof(sipp::G2ExpInput) == 4 * (SIPP_G2_IO_WORDS - 32));
+    CHECK(sizeof(sipp::Fq12ExpInput) == 4 * (SIPP_FQ12_IO_WORDS - 96));
+    CHECK(offsetof(sipp::G1ExpIO, out) == 4 * 40 && offsetof(sipp::G2ExpIO, out) == 4 * 72 && offsetof(sipp::Fq12ExpIO, out) == 4 * 200);
+    if (!proof_path) return 0;
+    const std::vector<uint64_t> flat = read_u64(proof_path);
+    const auto p = sipp::StarkProofWithPublicInputs::from_flat(flat.data(), flat.size());
+    CHECK(p.proof.trace_cap.size() == (size_t)1 << p.cap_height);
+    CHECK(p.proof.openings.local_values.size() == p.main_cols && p.proof.openings.permutation_zs_next.size() == p.perm_cols);
+    CHECK(p.proof.opening_proof.query_round_proofs.size() == 84);
+    CHECK(p.proof.opening_proof.query_round_proofs[0].initial_trees_proof.evals_proofs.size() == 3);
+    CHECK(p.public_inputs.size() == (size_t)p.num_io * p.pi_per_io);
+    CHECK(p.to_flat() == flat);
+    // a truncated or foreign buffer is refused with an Error, not undefined behaviour
+    try {
+        (void)sipp::StarkProofWithPublicInputs::from_flat(flat.data(), flat.size() - 1);
+        CHECK(!"truncated buffer accepted");
+    } catch (const sipp::Error& e) {
+        CHECK(e.status() == SIPP_E_BADARG || e.status() == SIPP_E_BUFSZ);
+    }
+    printf("layout ok: %zu words, %u main / %u Z / %u quotient columns\n", flat.size(), p.main_cols, p.perm_cols, p.quotient_cols);
+    return 0;
+}
+
+template <class IO, class In>
+static std::vector<In> inputs_of(const std::vector<IO>& io) {
+    std::vector<In> v(io.size());
+    for (size_t i = 0; i < io.size(); i++) v[i] = io[i].in;
+    return v;
+}
+
+template <class IO>
+static std::vector<IO> take(const std::vector<uint64_t>& w, size_t* pos) {
+    const size_t cnt = (size_t)w[(*pos)++];
+    std::vector<IO> v(cnt);
+    std::memcpy(v.data(), w.data() + *pos, cnt * sizeof(IO));
+    *pos += (cnt * sizeof(IO) + 7) / 8;
+    return v;
+}
+
+static int prove(const char* ios_path, const char* out_prefix) {
+    const std::vector<uint64_t> w = read_u64(ios_path);
+    size_t pos = 0;
+    const auto io1 = take<sipp::G1ExpIO>(w, &pos);
+    const auto io2 = take<sipp::G2ExpIO>(w, &pos);
+    const auto io12 = take<sipp::Fq12ExpIO>(w, &pos);
+    sipp::Prover prover(0, io1.size(), io2.size(), io12.size());
+
+    // the three calls of verifier_circuit.rs:133-135
+    sipp::ExpCircuitResult<sipp::G1Affine> r1;
+    sipp::ExpCircuitResult<sipp::G2Affine> r2;
+    sipp::ExpCircuitResult<sipp::Fq12> r12;
+    prover.exp_circuits(inputs_of<sipp::G1ExpIO, sipp::G1ExpInput>(io1), inputs_of<sipp::G2ExpIO, sipp::G2ExpInput>(io2),
+                        inputs_of<sipp::Fq12ExpIO, sipp::Fq12ExpInput>(io12), &r1, &r2, &r12);
+    // outputs == the native chain's values (the fixture's output words, oracle/py/sipp_native.py)
+    for (size_t i = 0; i < io1.size(); i++) CHECK(std::memcmp(&r1.outputs[i], &io1[i].out, sizeof(sipp::G1Affine)) == 0);
+    for (size_t i = 0; i < io2.size(); i++) CHECK(std::memcmp(&r2.outputs[i], &io2[i].out, sizeof(sipp::G2Affine)) == 0);
+    for (size_t i = 0; i < io12.size(); i++) CHECK(std::memcmp(&r12.outputs[i], &io12[i].out, sizeof(sipp::Fq12)) == 0);
+    // data.verify(proof) of verifier_circuit.rs:254, per sub-proof
+    orc_config ocfg;
+    orc_default_config(&ocfg);
+    const std::vector<uint64_t>* flats[3] = {&r1.flat, &r2.flat, &r12.flat};
+    const sipp::StarkProofWithPublicInputs* proofs[3] = {&r1.proof, &r2.proof, &r12.proof};
+    for (int k = 0; k < 3; k++) {
+        CHECK(orc_stark_verify(flats[k]->data(), flats[k]->size(), &ocfg) == 0);
+        CHECK(proofs[k]->to_flat() == *flats[k]);
+        CHECK(proofs[k]->kind == (uint32_t)k);
+        std::ofstream f(std::string(out_prefix) + char('0' + k) + ".bin", std::ios::binary);
+        f.write(reinterpret_cast<const char*>(flats[k]->data()), (std::streamsize)(flats[k]->size() * 8));
+    }
+    // the single-call form gives the same proof, and public inputs are exactly the records
+    const auto again = prover.g1_exp_circuit(inputs_of<sipp::G1ExpIO, sipp::G1ExpInput>(io1));
+    CHECK(again.flat == r1.flat);
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(io1.data());
+    for (size_t i = 0; i < io1.size() * SIPP_G1_IO_WORDS; i++) CHECK(r1.proof.public_inputs[i] == rec[i]);
+    // error behaviour: an unprovable obligation (x = offset, odd exponent) throws with SIPP_E_WITNESS; the prover survives
+    {
+        auto bad = inputs_of<sipp::G1ExpIO, sipp::G1ExpInput>(io1);
+        bad[0].offset = bad[0].x;
+        bad[0].exp_val[0] |= 1;
+        try {
+            (void)prover.g1_exp_circuit(bad);
+            CHECK(!"degenerate obligation accepted");
+        } catch (const sipp::Error& e) {
+            CHECK(e.status() == SIPP_E_WITNESS);
+        }
+        CHECK(prover.g1_exp_circuit(inputs_of<sipp::G1ExpIO, sipp::G1ExpInput>(io1)).flat == r1.flat);
+    }
+    printf("test_sipp_circuit ok: %zu / %zu / %zu obligations, proofs of %zu / %zu / %zu words verified\n", io1.size(), io2.size(),
+           io12.size(), r1.flat.size(), r2.flat.size(), r12.flat.size());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc >= 2 && std::string(argv[1]) == "layout") return layout(argc >= 3 ? argv[2] : nullptr);
+        if (argc == 4 && std::string(argv[1]) == "prove") return prove(argv[2], argv[3]);
+    } catch (const sipp::Error& e) {
+        fprintf(stderr, "sipp::Error %d: %s\n", e.status(), e.what());
+        return 1;
+    }
+    fprintf(stderr, "usage: %s layout [proof.bin] | prove <ios.bin> <out_prefix>\n", argv[0]);
+    return 2;
+}

@@ -204,3 +204,40 @@ def test_concurrent_streams_are_deterministic():
         for c in row:
             c.close()
     assert _oracle.stark_verify(want[0]) == 0
+
+
+def test_async_and_instance_calls_give_the_same_proofs(ctx, ios4):
+    """sipp_prove_async + sipp_wait and sipp_instance_prove (three ctxs, three streams, the library's own worker threads)
+    return exactly the proofs of the synchronous calls; a second job on a busy ctx and a wait without a job are refused."""
+    import sipp_amd
+    want = [ctx.prove(k, ios4[k]) for k in range(3)]
+    got = ctx.prove_async(0, ios4[0]).wait()
+    assert (got == want[0]).all()
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.wait()
+    assert e.value.code == -1
+    ctx.prove_async(1, ios4[1])
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.prove_async(0, ios4[0])
+    assert e.value.code == -1
+    assert (ctx.wait() == want[1]).all()
+    inst = sipp_amd.Instance([a.shape[0] for a in ios4])
+    try:
+        for _ in range(2):
+            proofs = inst.prove(ios4)
+            for k in range(3):
+                assert len(proofs[k]) == len(want[k]) and (proofs[k] == want[k]).all(), k
+    finally:
+        inst.close()
+
+
+def test_async_error_is_reported_by_wait(ctx, ios4):
+    """an unprovable IO record (claimed output off by one) surfaces as SIPP_E_WITNESS from sipp_wait, like the synchronous call"""
+    import sipp_amd
+    bad = ios4[0].copy()
+    bad[0, -1] ^= 1
+    ctx.prove_async(0, bad)
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.wait()
+    assert e.value.code == -8
+    assert (ctx.prove(0, ios4[0])[:16] == _oracle.stark_prove(0, ios4[0])[:16]).all()   # the ctx is usable afterwards

@@ -39,3 +39,22 @@ def test_shape_matches_oracle_air(ctx, ios4):
         ref = _oracle.Trace(kind, ios4[kind])
         log_n, W, P, Q = ctx.shape(kind, ios4[kind].shape[0])
         assert (log_n, W, P, Q) == (ref.log_n, ref.width, 2 * ref.air.n_checked, 4)
+
+
+@pytest.mark.parametrize("fixture", ["sipp_n4_ios.npz", "sipp_n128_ios.npz"])
+def test_exp_outputs_match_the_native_chain(fixture):
+    """sipp_exp_outputs (what the reference's generators assign to the targets g*_exp_circuit returns,
+    src/verifier_circuit.rs:133-135): the device's accumulator chains reproduce the output words of every IO record, which
+    the fixture took from the CPU restatement of sipp_prove_native / sipp_verify_native (oracle/py/sipp_native.py)."""
+    import sipp_amd
+    d = np.load("tests/golden/" + fixture)
+    ctx = sipp_amd.Ctx(workspace_bytes=4 << 30)
+    try:
+        for kind, key, out_words in ((0, "g1", 16), (1, "g2", 32), (2, "fq12", 96)):
+            ios = d[key]
+            blank = ios.copy()
+            blank[:, -out_words:] = 0xDEADBEEF
+            got = ctx.exp_outputs(kind, blank)
+            assert (got == ios).all(), key
+    finally:
+        ctx.close()
