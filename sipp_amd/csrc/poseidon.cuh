@@ -75,9 +75,9 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
 
 using gl::Acc160;
 
-__device__ __forceinline__ void full_round(uint64_t s[12], int rnd) {
+__device__ __forceinline__ void full_round(uint64_t s[12], int rnd, uint32_t z) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_nc(s[i], c_rc[12 * rnd + i]));
+    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_nc(s[i], c_rc[12 * rnd + i + z]));
     mds_full(s);
 }
 
@@ -86,11 +86,11 @@ using gl::Acc6;
 // full round 3 without its own MDS: its linear layer, the FIRST constants of the sparse form and the dense 11 x 11
 // pre-multiplication are ONE affine map s -> C s + c (tools/gen_poseidon_header.py combined_layer).  Row 0 of C is row 0 of
 // the MDS (small constants); rows 1..11 are 12 lazy MACs each, with c as the accumulators' start value.
-__device__ __forceinline__ void full_round3_combined(uint64_t s[12]) {
+__device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z) {
     uint32_t lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        const uint64_t v = sbox(gl::add_nc(s[i], c_rc[12 * 3 + i]));
+        const uint64_t v = sbox(gl::add_nc(s[i], c_rc[12 * 3 + i + z]));
         lo[i] = (uint32_t)v;
         hi[i] = (uint32_t)(v >> 32);
     }
@@ -104,23 +104,23 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[12]) {
         }
         const uint64_t l = al + (ah << 32);
         const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[0] = gl::add_nc(gl::reduce96_nc(h, l), c_comb_c[0]);
+        s[0] = gl::add_nc(gl::reduce96_nc(h, l), c_comb_c[z]);
     }
 #pragma unroll
     for (int i = 1; i < 12; i++) {
         Acc6 acc;
-        acc.set((uint32_t)c_comb_c[i], (uint32_t)(c_comb_c[i] >> 32));
+        acc.set((uint32_t)c_comb_c[i + z], (uint32_t)(c_comb_c[i + z] >> 32));
 #pragma unroll
-        for (int j = 0; j < 12; j++) acc.mac(lo[j], hi[j], c_comb3 + 3 * ((i - 1) * 12 + j));
+        for (int j = 0; j < 12; j++) acc.mac(lo[j], hi[j], c_comb3 + z + 3 * ((i - 1) * 12 + j));
         s[i] = acc.reduce();
     }
 }
 
-__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
+__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t z) {
     constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
 #pragma unroll 1
     for (int b = 0; b < 22 / B; b++) {
-        const uint32_t* __restrict__ T = c_blk3 + SIPP_POSEIDON_BLK_WORDS * b;
+        const uint32_t* __restrict__ T = c_blk3 + z + SIPP_POSEIDON_BLK_WORDS * b;
         uint32_t sl[11], sh[11], xl[B], xh[B];
 #pragma unroll
         for (int j = 0; j < 11; j++) {
@@ -130,7 +130,7 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
         uint64_t s0 = s[0];
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const uint64_t x = gl::add_nc(sbox(s0), c_fast_scalar[B * b + k]);
+            const uint64_t x = gl::add_nc(sbox(s0), c_fast_scalar[B * b + k + z]);
             xl[k] = (uint32_t)x;
             xh[k] = (uint32_t)(x >> 32);
             const uint32_t* __restrict__ Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
@@ -158,12 +158,17 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12]) {
 }
 
 __device__ __forceinline__ void permute(uint64_t s[12]) {
+    // an opaque zero added to every table index: the tables are wave-uniform and loop-invariant, and without this the
+    // compiler hoists ~650 scalar loads out of the caller's column loop, runs out of SGPRs and parks the constants in
+    // VGPR lanes (v_writelane once, then a v_readlane + wait states per constant per permutation)
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
 #pragma unroll 1
-    for (int r = 0; r < 3; r++) full_round(s, r);
-    full_round3_combined(s);
-    partial_rounds_blocked(s);
+    for (int r = 0; r < 3; r++) full_round(s, r, z);
+    full_round3_combined(s, z);
+    partial_rounds_blocked(s, z);
 #pragma unroll 1
-    for (int r = 26; r < 30; r++) full_round(s, r);
+    for (int r = 26; r < 30; r++) full_round(s, r, z);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }
