@@ -20,6 +20,25 @@
 #include "../../include/sipp_hip.h"
 #include "gl.hpp"
 
+// one-shot host-side gate between the proofs of one SIPP instance (sipp_instance_prove): the shortest proof starts once
+// the longest has its trace filled, so that the long proof's latency-bound first phase is not crowded out
+struct sipp_gate {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool open = false;
+    void release() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            open = true;
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return open; });
+    }
+};
+
 struct sipp_prof_entry {
     int calls = 0;
     double ms = 0.0;
@@ -51,6 +70,10 @@ struct sipp_ctx {
     // pinned host staging
     uint64_t* h_pinned = nullptr;
     size_t h_pinned_words = 0;
+
+    // set by sipp_instance_prove for the duration of one proof (see sipp_gate)
+    sipp_gate* gate_wait = nullptr;     // wait for it before the first launch
+    sipp_gate* gate_release = nullptr;  // released after the trace fill (and on every exit path)
 
     // sipp_exp_outputs: sipp_trace_fill stops after the accumulator chains and writes the outputs into the records
     bool outputs_only = false;

@@ -192,6 +192,17 @@ struct Oracle3 {
 static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io_in, uint64_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     if (!ctx || !ios || !proof_out || !proof_len) return SIPP_E_BADARG;
+    struct GateGuard {  // whatever happens below, a proof waiting on this one is let go
+        sipp_ctx* c;
+        ~GateGuard() {
+            if (c->gate_release) c->gate_release->release();
+            c->gate_release = nullptr;
+        }
+    } gate_guard{ctx};
+    if (ctx->gate_wait) {
+        ctx->gate_wait->wait();
+        ctx->gate_wait = nullptr;
+    }
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread may be new (one host thread per ctx)
     const sipp_stark_config& cfg = ctx->cfg;
     Shape s;
@@ -264,6 +275,10 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     }
 
     tick("trace fill");
+    if (ctx->gate_release) {
+        ctx->gate_release->release();
+        ctx->gate_release = nullptr;
+    }
     host::Challenger ch;
     uint64_t cap_host[4 << 8];
 
@@ -683,18 +698,33 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     for (int k = 0; k < 3; k++)
         if (!ctxs[k]) return SIPP_E_BADARG;
     if (ctxs[0] == ctxs[1] || ctxs[0] == ctxs[2] || ctxs[1] == ctxs[2]) return SIPP_E_BADARG;
-    static const int order[3] = {SIPP_G2_EXP, SIPP_G1_EXP, SIPP_FQ12_EXP};  // the largest proof first
+    static const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
+    // The other two proofs start once the longest (G2) has its trace filled: its latency-bound chains and lookup kernels
+    // are otherwise crowded out by the others' long-running hash workgroups and G2 ends last by ~10 ms (n = 128: 73.3 ->
+    // 70.2 ms per instance; n = 1024: neutral; releasing after G2's trace COMMIT instead: 75-81 ms).
+    // SIPP_INSTANCE_GATE overrides which proofs wait: bit 0 = G1, bit 1 = Fq12, 0 = none.
+    static int gate_mask = -1;
+    if (gate_mask < 0) {
+        const char* e = getenv("SIPP_INSTANCE_GATE");
+        gate_mask = e ? atoi(e) : 3;
+    }
+    sipp_gate gate;
     int started[3] = {0, 0, 0}, rc = SIPP_OK;
+    ctxs[SIPP_G2_EXP]->gate_release = gate_mask ? &gate : nullptr;
+    ctxs[SIPP_G1_EXP]->gate_wait = (gate_mask & 1) ? &gate : nullptr;
+    ctxs[SIPP_FQ12_EXP]->gate_wait = (gate_mask & 2) ? &gate : nullptr;
     for (int i = 0; i < 3 && rc == SIPP_OK; i++) {
         const int k = order[i];
         rc = sipp_prove_async(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k]);
         started[k] = rc == SIPP_OK;
     }
+    if (!started[SIPP_G2_EXP]) gate.release();  // nobody is left to open it
     for (int k = 0; k < 3; k++) {
         if (!started[k]) continue;
         const int r = sipp_wait(ctxs[k], &proof_len[k]);  // every started proof is collected, also after a failure
         if (rc == SIPP_OK) rc = r;
     }
+    for (int k = 0; k < 3; k++) ctxs[k]->gate_wait = ctxs[k]->gate_release = nullptr;
     return rc;
 }
 }
