@@ -33,4 +33,9 @@ extern "C" {
     pub fn sipp_g1_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
     pub fn sipp_g2_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
     pub fn sipp_fq12_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
+    pub fn sipp_prove_async(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, out: *mut u64, cap: usize) -> c_int;
+    pub fn sipp_wait(ctx: *mut SippCtxOpaque, len: *mut usize) -> c_int;
+    pub fn sipp_instance_prove(ctxs: *const *mut SippCtxOpaque, ios: *const *const u32, num_io: *const usize, out: *const *mut u64,
+                               cap: *const usize, len: *mut usize) -> c_int;
+    pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
 }
