@@ -182,7 +182,7 @@ def main():
         # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
         traffic = None
         valu = None
-        tpath = os.path.join(ROOT, "profiles", "r01_e_pmc.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_f_pmc.json")
         if args.n == 128 and os.path.exists(tpath):
             pmc = json.load(open(tpath))
             traffic = pmc.get("traffic_bytes_per_launch")
