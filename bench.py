@@ -72,9 +72,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SIPP HIP path has no CPU fallback")
+    # SIPP_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- only to rehearse the N > 1 code path on a one-GPU box
+    # (the driver's scaling runs use one GPU per rank over RCCL, the default)
+    rehearsal = bool(int(os.environ.get("SIPP_BENCH_REHEARSAL", "0")))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import sipp_amd
     ios = load_ios(args.n)
@@ -130,7 +138,7 @@ def main():
     from sipp_amd import dist_util
 
     def dist_util_max(x):
-        return dist_util.max_over_ranks(x, device="cuda")
+        return dist_util.max_over_ranks(x, device="cpu" if rehearsal else "cuda")
 
     elapsed = dist_util_max(elapsed)
 
