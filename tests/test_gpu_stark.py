@@ -241,3 +241,20 @@ def test_async_error_is_reported_by_wait(ctx, ios4):
         ctx.wait()
     assert e.value.code == -8
     assert (ctx.prove(0, ios4[0])[:16] == _oracle.stark_prove(0, ios4[0])[:16]).all()   # the ctx is usable afterwards
+
+
+@pytest.mark.parametrize("kind,num", [(0, 1), (0, 5), (1, 2), (1, 7), (2, 1), (2, 3)])
+def test_ragged_io_counts_match_the_oracle(ctx, kind, num):
+    """IO lists that are not a power of two (and a single record) are padded with copies of the last record on both sides:
+    same proof word for word, and the public inputs show the padding."""
+    d = np.load("tests/golden/sipp_n8_ios.npz")
+    ios = d[("g1", "g2", "fq12")[kind]][:num]
+    ref = _oracle.stark_prove(kind, ios)
+    got = ctx.prove(kind, ios)
+    assert len(got) == len(ref)
+    diff = np.nonzero(got != ref)[0]
+    assert diff.size == 0, "first mismatch at word %d (%s)" % (diff[0], locate(ref, int(diff[0])))
+    nio = int(got[3])
+    assert nio >= max(2, num) and nio & (nio - 1) == 0
+    pis = got[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])
+    assert (pis[:num] == ios).all() and (pis[num:] == ios[-1]).all()
