@@ -89,7 +89,7 @@ def main():
     # one ctx (= one HIP stream + workspace arena) and one host thread per STARK: the three sub-proofs are
     # independent, so their thin kernels and Fiat-Shamir round trips overlap.
     # The threads are the library's own (sipp_instance_prove = 3 x sipp_prove_async + sipp_wait).
-    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,high,high").split(",")   # G1, G2, Fq12
+    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,,high").split(",")   # G1, G2, Fq12
     ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
     inst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios)
     ctxs = inst.ctxs

@@ -75,6 +75,10 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2 } sipp_kind;
  * Pass 0 to size the arena for n = 128 (about 24 GiB). */
 int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t workspace_bytes);
 void sipp_ctx_destroy(sipp_ctx *ctx);
+/* Priority of the ctx's HIP stream: level < 0 lowest, 0 normal, > 0 highest the device offers.  With the three proofs of
+ * an instance on three ctxs, G1 low / G2 normal / Fq12 high measured best.  Only while no proof is
+ * in flight on the ctx.  (SIPP_STREAM_PRIORITY=high|low in the environment sets the initial priority at sipp_ctx_create.) */
+int sipp_ctx_set_stream_priority(sipp_ctx *ctx, int level);
 const char *sipp_last_error(const sipp_ctx *ctx);
 int sipp_sync(sipp_ctx *ctx);
 /* the hipStream_t every launch of this ctx goes to (as void*) */

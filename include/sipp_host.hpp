@@ -260,6 +260,8 @@ class Prover {
                 for (int j = 0; j < k; j++) sipp_ctx_destroy(ctx_[j]);
                 throw Error(rc, "sipp_ctx_create failed (see stderr)");
             }
+            static const int level[3] = {-1, 0, 1};  // G1 low, G2 normal, Fq12 high
+            (void)sipp_ctx_set_stream_priority(ctx_[k], level[k]);
         }
     }
     ~Prover() {

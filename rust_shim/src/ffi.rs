@@ -28,6 +28,7 @@ extern "C" {
     pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
     pub fn sipp_ctx_create(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, workspace_bytes: usize) -> c_int;
     pub fn sipp_ctx_destroy(ctx: *mut SippCtxOpaque);
+    pub fn sipp_ctx_set_stream_priority(ctx: *mut SippCtxOpaque, level: c_int) -> c_int;
     pub fn sipp_last_error(ctx: *const SippCtxOpaque) -> *const c_char;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
     pub fn sipp_g1_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;

@@ -36,6 +36,7 @@ SIGNATURES = {
     "sipp_default_config": (None, [C.POINTER(StarkConfig)]),
     "sipp_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(StarkConfig), C.c_size_t]),
     "sipp_ctx_destroy": (None, [vp]),
+    "sipp_ctx_set_stream_priority": (C.c_int, [vp, C.c_int]),
     "sipp_last_error": (C.c_char_p, [vp]),
     "sipp_sync": (C.c_int, [vp]),
     "sipp_stream": (vp, [vp]),
@@ -268,21 +269,18 @@ class Ctx:
 class Instance:
     """The three sub-proofs of one SIPP instance (reference src/verifier_circuit.rs:133-135) on three ctxs = three HIP
     streams, started together through sipp_instance_prove.  `devices` may name one GPU (default) or three
-    (level L-B).  `priorities`: stream priority per kind ("high" / "low" / "")."""
+    (level L-B).  `priorities`: stream priority per kind ("high" / "low" / "" = normal); G1 low / G2 normal / Fq12 high
+    measured best with the start gate of sipp_instance_prove (69.3 vs 71.2 ms per n = 128 instance for low / high / high)."""
 
-    def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "high", "high")):
+    def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "", "high")):
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
         self.ctxs = []
+        level = {"low": -1, "": 0, "normal": 0, "high": 1}
         for k in range(3):
-            if priorities[k]:
-                os.environ["SIPP_STREAM_PRIORITY"] = priorities[k]
-            else:
-                os.environ.pop("SIPP_STREAM_PRIORITY", None)
-            try:
-                self.ctxs.append(Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, self.num_io[k])))
-            finally:
-                os.environ.pop("SIPP_STREAM_PRIORITY", None)
+            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, self.num_io[k]))
+            c._ck(self.L.sipp_ctx_set_stream_priority(c.h, level[priorities[k]]), "set_stream_priority")
+            self.ctxs.append(c)
         self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) for k in range(3)]
         self.out = [np.zeros(c, dtype=np.uint64) for c in self.caps]
 

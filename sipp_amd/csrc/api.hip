@@ -91,6 +91,33 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     delete ctx;
 }
 
+int sipp_ctx_set_stream_priority(sipp_ctx* ctx, int level) {
+    if (!ctx) return SIPP_E_BADARG;
+    {
+        std::unique_lock<std::mutex> lk(ctx->async.mu);
+        if (ctx->async.has_job) {
+            lk.unlock();
+            return sipp_fail(ctx, SIPP_E_BADARG, "set_stream_priority: a proof is in flight on this ctx");
+        }
+    }
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int lo = 0, hi = 0;
+    SIPP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest (numerically lower)
+    const int prio = level > 0 ? hi : level < 0 ? lo : 0;  // 0 is the default (normal) priority of a HIP stream
+    hipStream_t ns = nullptr;
+    SIPP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio));
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->prof) {  // pending event pairs belong to the old stream: fold them into the totals first
+            (void)sipp_profile_enable(ctx, 0);
+            ctx->prof = true;
+        }
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = ns;
+    return SIPP_OK;
+}
+
 const char* sipp_last_error(const sipp_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
 int sipp_sync(sipp_ctx* ctx) {

@@ -698,27 +698,29 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     for (int k = 0; k < 3; k++)
         if (!ctxs[k]) return SIPP_E_BADARG;
     if (ctxs[0] == ctxs[1] || ctxs[0] == ctxs[2] || ctxs[1] == ctxs[2]) return SIPP_E_BADARG;
-    static const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     // The other two proofs start once the longest (G2) has its trace filled: its latency-bound chains and lookup kernels
     // are otherwise crowded out by the others' long-running hash workgroups and G2 ends last by ~10 ms (n = 128: 73.3 ->
-    // 70.2 ms per instance; n = 1024: neutral; releasing after G2's trace COMMIT instead: 75-81 ms).
-    // SIPP_INSTANCE_GATE overrides which proofs wait: bit 0 = G1, bit 1 = Fq12, 0 = none.
+    // 70.2 ms per instance; n = 1024: neutral; releasing after G2's trace COMMIT instead: 75-81 ms; Fq12 first: 71-72 ms).
+    // SIPP_INSTANCE_GATE overrides which kinds wait (bit k = sipp_kind k; 0 = none).
+    const int first = SIPP_G2_EXP;
     static int gate_mask = -1;
     if (gate_mask < 0) {
         const char* e = getenv("SIPP_INSTANCE_GATE");
-        gate_mask = e ? atoi(e) : 3;
+        gate_mask = (e ? atoi(e) : ((1 << SIPP_G1_EXP) | (1 << SIPP_FQ12_EXP))) & ~(1 << first);
     }
+    const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     sipp_gate gate;
     int started[3] = {0, 0, 0}, rc = SIPP_OK;
-    ctxs[SIPP_G2_EXP]->gate_release = gate_mask ? &gate : nullptr;
-    ctxs[SIPP_G1_EXP]->gate_wait = (gate_mask & 1) ? &gate : nullptr;
-    ctxs[SIPP_FQ12_EXP]->gate_wait = (gate_mask & 2) ? &gate : nullptr;
+    for (int k = 0; k < 3; k++) {
+        ctxs[k]->gate_release = (k == first && gate_mask) ? &gate : nullptr;
+        ctxs[k]->gate_wait = (gate_mask >> k & 1) ? &gate : nullptr;
+    }
     for (int i = 0; i < 3 && rc == SIPP_OK; i++) {
         const int k = order[i];
         rc = sipp_prove_async(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k]);
         started[k] = rc == SIPP_OK;
     }
-    if (!started[SIPP_G2_EXP]) gate.release();  // nobody is left to open it
+    if (!started[first]) gate.release();  // nobody is left to open it
     for (int k = 0; k < 3; k++) {
         if (!started[k]) continue;
         const int r = sipp_wait(ctxs[k], &proof_len[k]);  // every started proof is collected, also after a failure
