@@ -258,3 +258,23 @@ def test_ragged_io_counts_match_the_oracle(ctx, kind, num):
     assert nio >= max(2, num) and nio & (nio - 1) == 0
     pis = got[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])
     assert (pis[:num] == ios).all() and (pis[num:] == ios[-1]).all()
+
+
+def test_config0_n8_instance_matches_the_oracle():
+    """BASELINE configs[0] (n = 8, the reference's CPU-runnable plumbing case: 7 / 7 / 6 obligations): the whole instance through
+    sipp_instance_prove equals the CPU oracle's three proofs word for word and verifies."""
+    import sipp_amd
+    d = np.load("tests/golden/sipp_n8_ios.npz")
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    assert [a.shape[0] for a in ios] == [7, 7, 6]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios])
+    try:
+        proofs = [p.copy() for p in inst.prove(ios)]
+    finally:
+        inst.close()
+    for kind in range(3):
+        ref = _oracle.stark_prove(kind, ios[kind])
+        assert len(proofs[kind]) == len(ref), kind
+        diff = np.nonzero(proofs[kind] != ref)[0]
+        assert diff.size == 0, "kind %d: first mismatch at word %d (%s)" % (kind, diff[0], locate(ref, int(diff[0])))
+        assert _oracle.stark_verify(proofs[kind]) == 0
