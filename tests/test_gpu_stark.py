@@ -278,3 +278,21 @@ def test_config0_n8_instance_matches_the_oracle():
         diff = np.nonzero(proofs[kind] != ref)[0]
         assert diff.size == 0, "kind %d: first mismatch at word %d (%s)" % (kind, diff[0], locate(ref, int(diff[0])))
         assert _oracle.stark_verify(proofs[kind]) == 0
+
+
+@pytest.mark.timeout(300)
+def test_instance_with_an_unprovable_g2_record_fails_without_hanging(ios4):
+    """G1 and Fq12 wait for G2's trace fill (the start gate of sipp_instance_prove): a G2 proof that fails before that
+    point must still let them go.  The call reports SIPP_E_WITNESS and the instance stays usable."""
+    import sipp_amd
+    inst = sipp_amd.Instance([a.shape[0] for a in ios4])
+    try:
+        bad = [a.copy() for a in ios4]
+        bad[1][0, -1] ^= 1
+        with pytest.raises(sipp_amd.SippError) as e:
+            inst.prove(bad)
+        assert e.value.code == -8
+        good = inst.prove(ios4)
+        assert _oracle.stark_verify(good[1]) == 0
+    finally:
+        inst.close()
