@@ -296,3 +296,31 @@ def test_instance_with_an_unprovable_g2_record_fails_without_hanging(ios4):
         assert _oracle.stark_verify(good[1]) == 0
     finally:
         inst.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_obligations_match_the_oracle(ctx, seed):
+    """fresh obligations per seed (random points, random Fq12 elements, random exponents; nothing from the fixtures): outputs
+    from sipp_exp_outputs, then every proof word for word against the oracle (which recomputes and checks the outputs itself)."""
+    from oracle.py import bn254 as bn
+    rng = np.random.default_rng(seed)
+
+    def scalar():
+        return int.from_bytes(rng.bytes(32), "little") % bn.R or 1
+
+    def fq():
+        return int.from_bytes(rng.bytes(32), "little") % bn.P
+
+    g1 = [bn.g1_to_u32(bn.g1_mul(bn.G1, scalar())) + bn.g1_to_u32(bn.g1_mul(bn.G1, scalar())) +
+          [(e >> (32 * i)) & 0xFFFFFFFF for e in [scalar()] for i in range(8)] + [0] * 16 for _ in range(3)]
+    g2 = [bn.g2_to_u32(bn.g2_mul(bn.G2, scalar())) + bn.g2_to_u32(bn.g2_mul(bn.G2, scalar())) +
+          [(e >> (32 * i)) & 0xFFFFFFFF for e in [scalar()] for i in range(8)] + [0] * 32 for _ in range(2)]
+    f12 = [bn.f12_to_u32([fq() for _ in range(12)]) + bn.f12_to_u32([fq() for _ in range(12)]) +
+           [(e >> (32 * i)) & 0xFFFFFFFF for e in [scalar()] for i in range(8)] + [0] * 96 for _ in range(2)]
+    for kind, recs in ((0, g1), (1, g2), (2, f12)):
+        ios = ctx.exp_outputs(kind, np.array(recs, dtype=np.uint32))
+        ref = _oracle.stark_prove(kind, ios)          # raises if an output were wrong
+        got = ctx.prove(kind, ios)
+        assert len(got) == len(ref)
+        diff = np.nonzero(got != ref)[0]
+        assert diff.size == 0, "kind %d: first mismatch at word %d (%s)" % (kind, diff[0], locate(ref, int(diff[0])))
