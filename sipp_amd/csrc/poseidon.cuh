@@ -27,7 +27,7 @@
 
 namespace poseidon {
 
-__constant__ uint64_t c_rc[360];
+__constant__ uint64_t c_rc[360 + 12];  // 30 rounds x 12, then 12 zeros: the "next round" constants of round 29
 __constant__ uint64_t c_fast_first[12];
 __constant__ uint64_t c_fast_scalar[22];
 __constant__ uint64_t c_fast_mi[121];
@@ -45,8 +45,11 @@ __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     return gl::mul_nc(x3, x4);
 }
 
-// out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r],  CIRC = 17 15 41 16 2 28 13 13 39 18 34 20, DIAG[0] = 8
-__device__ __forceinline__ void mds_full(uint64_t s[12]) {
+// out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r] (+ add[r]),  CIRC = 17 15 41 16 2 28 13 13 39 18 34 20, DIAG[0] = 8.
+// `add` (wave-uniform, may be null at compile time) = the NEXT round's constants: they start the two multiply-add chains
+// instead of costing a modular addition per element in front of the next S-box layer.
+template <bool ADD>
+__device__ __forceinline__ void mds_full(uint64_t s[12], const uint64_t* __restrict__ add) {
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     uint32_t lo[12], hi[12];
 #pragma unroll
@@ -57,6 +60,10 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         uint64_t al = 0, ah = 0;
+        if (ADD) {
+            al = (uint32_t)add[r];
+            ah = add[r] >> 32;
+        }
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             al += (uint64_t)lo[(i + r) % 12] * CIRC[i];
@@ -66,7 +73,7 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
             al += (uint64_t)lo[0] * 8u;
             ah += (uint64_t)hi[0] * 8u;
         }
-        // value = al + ah * 2^32, al, ah < 2^42
+        // value = al + ah * 2^32, al, ah < 2^43
         uint64_t l = al + (ah << 32);
         uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
         s[r] = gl::reduce96_nc(h, l);
@@ -75,10 +82,12 @@ __device__ __forceinline__ void mds_full(uint64_t s[12]) {
 
 using gl::Acc160;
 
+// S-box layer + MDS of round `rnd`; the state already carries the round's constants, and leaves with those of round rnd + 1
+// folded into the MDS sums (zeros after round 29: c_rc carries 12 trailing zeros)
 __device__ __forceinline__ void full_round(uint64_t s[12], int rnd, uint32_t z) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox(gl::add_nc(s[i], c_rc[12 * rnd + i + z]));
-    mds_full(s);
+    for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
+    mds_full<true>(s, c_rc + 12 * (rnd + 1) + z);
 }
 
 using gl::Acc6;
@@ -90,7 +99,7 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z)
     uint32_t lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        const uint64_t v = sbox(gl::add_nc(s[i], c_rc[12 * 3 + i + z]));
+        const uint64_t v = sbox(s[i]);  // the constants of round 3 came with round 2's MDS
         lo[i] = (uint32_t)v;
         hi[i] = (uint32_t)(v >> 32);
     }
@@ -163,10 +172,14 @@ __device__ __forceinline__ void permute(uint64_t s[12]) {
     // VGPR lanes (v_writelane once, then a v_readlane + wait states per constant per permutation)
     uint32_t z = 0;
     asm volatile("" : "+s"(z));
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[i + z]);
 #pragma unroll 1
     for (int r = 0; r < 3; r++) full_round(s, r, z);
     full_round3_combined(s, z);
     partial_rounds_blocked(s, z);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[12 * 26 + i + z]);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) full_round(s, r, z);
 #pragma unroll
