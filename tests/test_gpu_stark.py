@@ -324,3 +324,26 @@ def test_random_obligations_match_the_oracle(ctx, seed):
         assert len(got) == len(ref)
         diff = np.nonzero(got != ref)[0]
         assert diff.size == 0, "kind %d: first mismatch at word %d (%s)" % (kind, diff[0], locate(ref, int(diff[0])))
+
+
+@pytest.mark.parametrize("cap_height,pow_bits,final_poly_bits,num_queries", [(2, 10, 4, 20), (5, 18, 6, 30), (0, 4, 5, 3)])
+def test_non_default_stark_config_matches_the_oracle(ios4, cap_height, pow_bits, final_poly_bits, num_queries):
+    """sipp_stark_config other than standard_fast_config (cap height, proof-of-work bits, final polynomial size, query
+    count): the proof shape changes with it, and stays word for word the oracle's for the same config."""
+    import sipp_amd
+    cfg = sipp_amd.default_config()
+    ocfg = _oracle.default_config()
+    for c in (cfg, ocfg):
+        c.cap_height, c.pow_bits, c.final_poly_bits, c.num_queries = cap_height, pow_bits, final_poly_bits, num_queries
+    ctx = sipp_amd.Ctx(cfg=cfg, workspace_bytes=4 << 30)
+    try:
+        for kind in (0, 2):
+            ref = _oracle.stark_prove(kind, ios4[kind], ocfg)
+            got = ctx.prove(kind, ios4[kind])
+            assert len(got) == len(ref), (kind, len(got), len(ref))
+            diff = np.nonzero(got != ref)[0]
+            assert diff.size == 0, "kind %d: first mismatch at word %d" % (kind, diff[0])
+            assert _oracle.stark_verify(got, ocfg) == 0
+            assert int(got[7]) == cap_height and int(got[10]) == num_queries
+    finally:
+        ctx.close()
