@@ -123,6 +123,15 @@ size_t sipp_workspace_bytes(int kind, size_t num_io);
 int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
                      uint32_t *perm_cols, uint32_t *quotient_cols);
 
+/* ---- next row: the native prover's pairing products ------------------------- */
+/* inner_product of reference src/prover_native.rs:15-23: prod_i pairing(A_i, B_i) for n pairs, on the device.
+ * g1: n x 16 u32 (x, y), g2: n x 32 u32 (x.c0, x.c1, y.c0, y.c1) -- the limb stream of src/transcript_native.rs:42-54;
+ * all-zero coordinates stand for the point at infinity.  out: the 12 MyFq12 coefficients, 96 u32 (src/transcript_native.rs:32-40).
+ * sipp_inner_products computes `count` independent products (pairs [k n, (k + 1) n) -> out[k]) in one pass, e.g. the Z_L and
+ * Z_R of one SIPP round (src/prover_native.rs:51-52).  Uses the ctx's workspace (about 500 bytes per pair). */
+int sipp_inner_product(sipp_ctx *ctx, const uint32_t *g1, const uint32_t *g2, size_t n, uint32_t *out);
+int sipp_inner_products(sipp_ctx *ctx, const uint32_t *g1, const uint32_t *g2, size_t n, size_t count, uint32_t *out);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

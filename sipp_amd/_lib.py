@@ -48,6 +48,8 @@ SIGNATURES = {
     "sipp_instance_prove": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_exp_outputs": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "sipp_inner_product": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "sipp_inner_products": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, vp]),
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
@@ -221,6 +223,16 @@ class Ctx:
         rec = np.array(ios, dtype=np.uint32, order="C", copy=True)
         self._ck(self.L.sipp_exp_outputs(self.h, kind, rec.ctypes.data, rec.shape[0]), "exp_outputs")
         return rec
+
+    def inner_products(self, g1, g2, count=1):
+        """prod_i pairing(A_i, B_i) (sipp_inner_products): g1 [count * n, 16], g2 [count * n, 32] uint32 limbs -> [count, 96]"""
+        g1 = np.ascontiguousarray(g1, dtype=np.uint32).reshape(-1, 16)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint32).reshape(-1, 32)
+        assert g1.shape[0] == g2.shape[0] and g1.shape[0] % count == 0
+        out = np.zeros((count, 96), dtype=np.uint32)
+        self._ck(self.L.sipp_inner_products(self.h, g1.ctypes.data, g2.ctypes.data, g1.shape[0] // count, count,
+                                            out.ctypes.data), "inner_products")
+        return out
 
     def prove_async(self, kind, ios):
         """start one sub-proof on the ctx's worker thread (sipp_prove_async); collect it with wait()"""

@@ -1,0 +1,63 @@
+"""sipp_inner_product(s) -- the pairing products of the native SIPP prover (reference src/prover_native.rs:15-23), SURVEY.md
+section 8(f) rank 3 -- against the CPU restatement oracle/py/bn254.py (optimal ate Miller loop + plain (p^12 - 1)/r power)."""
+import numpy as np
+import pytest
+
+from oracle.py import bn254 as bn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sipp_amd
+    c = sipp_amd.Ctx(workspace_bytes=1 << 30)
+    yield c
+    c.close()
+
+
+def points(rng, n):
+    def scalar():
+        return int.from_bytes(rng.bytes(32), "little") % bn.R or 1
+    A = [bn.g1_mul(bn.G1, scalar()) for _ in range(n)]
+    B = [bn.g2_mul(bn.G2, scalar()) for _ in range(n)]
+    return A, B
+
+
+def limbs(A, B):
+    return (np.array([bn.g1_to_u32(a) for a in A], dtype=np.uint32), np.array([bn.g2_to_u32(b) for b in B], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_inner_product_matches_the_oracle(ctx, n):
+    rng = np.random.default_rng(100 + n)
+    A, B = points(rng, n)
+    g1, g2 = limbs(A, B)
+    got = ctx.inner_products(g1, g2)[0]
+    want = np.array(bn.f12_to_u32(bn.multi_pairing(A, B)), dtype=np.uint32)
+    assert (got == want).all()
+
+
+def test_generator_pairing_and_bilinearity(ctx):
+    g1, g2 = limbs([bn.G1], [bn.G2])
+    e = ctx.inner_products(g1, g2)[0]
+    assert (e == np.array(bn.f12_to_u32(bn.pairing(bn.G1, bn.G2)), dtype=np.uint32)).all()
+    # e([a] G1, [b] G2) == e([ab] G1, G2): two products of one pair each in ONE call
+    a, b = 0x1234567890ABCDEF1234567, 0xFEDCBA09876543211234
+    g1, g2 = limbs([bn.g1_mul(bn.G1, a), bn.g1_mul(bn.G1, a * b % bn.R)], [bn.g2_mul(bn.G2, b), bn.G2])
+    both = ctx.inner_products(g1, g2, count=2)
+    assert (both[0] == both[1]).all() and not (both[0] == e).all()
+
+
+def test_round_shaped_call_and_infinity(ctx):
+    """Z_L and Z_R of one SIPP round (src/prover_native.rs:51-52) in one call; a pair with the point at infinity contributes 1"""
+    rng = np.random.default_rng(7)
+    A, B = points(rng, 4)
+    g1, g2 = limbs(A[2:] + A[:2], B[:2] + B[2:])           # (A2, B1) then (A1, B2)
+    z = ctx.inner_products(g1, g2, count=2)
+    assert (z[0] == np.array(bn.f12_to_u32(bn.multi_pairing(A[2:], B[:2])), dtype=np.uint32)).all()
+    assert (z[1] == np.array(bn.f12_to_u32(bn.multi_pairing(A[:2], B[2:])), dtype=np.uint32)).all()
+    g1, g2 = limbs(A[:2], B[:2])
+    g1[1] = 0
+    one_pair = ctx.inner_products(g1, g2)[0]
+    assert (one_pair == np.array(bn.f12_to_u32(bn.pairing(A[0], B[0])), dtype=np.uint32)).all()
