@@ -132,6 +132,19 @@ int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log
 int sipp_inner_product(sipp_ctx *ctx, const uint32_t *g1, const uint32_t *g2, size_t n, uint32_t *out);
 int sipp_inner_products(sipp_ctx *ctx, const uint32_t *g1, const uint32_t *g2, size_t n, size_t count, uint32_t *out);
 
+/* The native chain around those products (host code over the device routines; the transcript stays on the host):
+ * sipp_prove_native = reference src/prover_native.rs:26-80: A (n x 16 u32), B (n x 32 u32), n a power of two ->
+ *   proof = 2 log2 n + 1 Fq12 messages of 96 u32 each, in the reference's (reversed) order; sipp_native_proof_words(n) u32.
+ * sipp_verify_native = reference src/verifier_native.rs:14-85: replays the transcript, folds A, B, Z and returns
+ *   statement (16n + 32n + 96 + 16 + 32 + 96 u32: A | B | Z | final_A | final_B | final_Z, src/statements.rs:24-39),
+ *   the three obligation lists as complete IO records for sipp_*_exp_prove (src/verifier_circuit.rs:68-131:
+ *   (n - 1) x 56, (n - 1) x 104 and 2 log2 n x 296 u32, round-major), and *accepted = (pairing(final_A, final_B) == final_Z).
+ *   Any output pointer may be NULL.  The ctx's workspace must hold the widest fold (sipp_workspace_bytes(SIPP_G2_EXP, n / 2)). */
+size_t sipp_native_proof_words(size_t n);
+int sipp_prove_native(sipp_ctx *ctx, const uint32_t *A, const uint32_t *B, size_t n, uint32_t *proof);
+int sipp_verify_native(sipp_ctx *ctx, const uint32_t *A, const uint32_t *B, size_t n, const uint32_t *proof,
+                       uint32_t *statement, uint32_t *g1_ios, uint32_t *g2_ios, uint32_t *fq12_ios, int *accepted);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

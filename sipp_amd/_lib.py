@@ -50,6 +50,9 @@ SIGNATURES = {
     "sipp_exp_outputs": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
     "sipp_inner_product": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "sipp_inner_products": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, vp]),
+    "sipp_native_proof_words": (C.c_size_t, [C.c_size_t]),
+    "sipp_prove_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+    "sipp_verify_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]),
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
@@ -233,6 +236,34 @@ class Ctx:
         self._ck(self.L.sipp_inner_products(self.h, g1.ctypes.data, g2.ctypes.data, g1.shape[0] // count, count,
                                             out.ctypes.data), "inner_products")
         return out
+
+    def prove_native(self, A, B):
+        """sipp_prove_native: A [n, 16], B [n, 32] uint32 limbs -> proof [2 log2 n + 1, 96]"""
+        A = np.ascontiguousarray(A, dtype=np.uint32).reshape(-1, 16)
+        B = np.ascontiguousarray(B, dtype=np.uint32).reshape(-1, 32)
+        n = A.shape[0]
+        words = self.L.sipp_native_proof_words(n)
+        if words == 0 or B.shape[0] != n:
+            raise SippError(-1, "prove_native: n must be a power of two")
+        proof = np.zeros((words // 96, 96), dtype=np.uint32)
+        self._ck(self.L.sipp_prove_native(self.h, A.ctypes.data, B.ctypes.data, n, proof.ctypes.data), "prove_native")
+        return proof
+
+    def verify_native(self, A, B, proof):
+        """sipp_verify_native -> (accepted, statement, [g1_ios, g2_ios, fq12_ios])"""
+        A = np.ascontiguousarray(A, dtype=np.uint32).reshape(-1, 16)
+        B = np.ascontiguousarray(B, dtype=np.uint32).reshape(-1, 32)
+        proof = np.ascontiguousarray(proof, dtype=np.uint32)
+        n = A.shape[0]
+        lg = n.bit_length() - 1
+        st = np.zeros(48 * n + 240, dtype=np.uint32)
+        ios = [np.zeros((max(n - 1, 0), 56), dtype=np.uint32), np.zeros((max(n - 1, 0), 104), dtype=np.uint32),
+               np.zeros((2 * lg, 296), dtype=np.uint32)]
+        ok = C.c_int(0)
+        self._ck(self.L.sipp_verify_native(self.h, A.ctypes.data, B.ctypes.data, n, proof.ctypes.data, st.ctypes.data,
+                                           ios[0].ctypes.data, ios[1].ctypes.data, ios[2].ctypes.data, C.byref(ok)),
+                 "verify_native")
+        return bool(ok.value), st, ios
 
     def prove_async(self, kind, ios):
         """start one sub-proof on the ctx's worker thread (sipp_prove_async); collect it with wait()"""
