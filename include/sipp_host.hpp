@@ -304,6 +304,60 @@ class Prover {
         finish(io12, r12);
     }
 
+    // ---- the native chain in front of the circuit ----
+    // reference src/prover_native.rs:26-80: the 2 log2 n + 1 proof messages, in the reference's (reversed) order
+    std::vector<Fq12> sipp_prove_native(const std::vector<G1Affine>& A, const std::vector<G2Affine>& B) {
+        if (A.size() != B.size() || sipp_native_proof_words(A.size()) == 0) throw Error(SIPP_E_BADARG, "sipp_prove_native: |A| = |B| = 2^k");
+        std::vector<Fq12> proof(sipp_native_proof_words(A.size()) / 96);
+        const int rc = ::sipp_prove_native(ctx_[SIPP_G2_EXP], reinterpret_cast<const uint32_t*>(A.data()),
+                                           reinterpret_cast<const uint32_t*>(B.data()), A.size(), reinterpret_cast<uint32_t*>(proof.data()));
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_prove_native: ") + sipp_last_error(ctx_[SIPP_G2_EXP]));
+        return proof;
+    }
+    // reference src/statements.rs:14-22
+    struct SIPPStatement {
+        std::vector<G1Affine> A;
+        std::vector<G2Affine> B;
+        Fq12 Z;
+        G1Affine final_A;
+        G2Affine final_B;
+        Fq12 final_Z;
+    };
+    struct NativeVerification {
+        SIPPStatement statement;
+        std::vector<G1ExpIO> g1_obligations;      // verifier_circuit.rs:92-98, outputs included
+        std::vector<G2ExpIO> g2_obligations;      // :101-107
+        std::vector<Fq12ExpIO> fq12_obligations;  // :111-124
+    };
+    // reference src/verifier_native.rs:14-85; throws Error(SIPP_E_WITNESS) where the reference returns Err("Verification failed")
+    NativeVerification sipp_verify_native(const std::vector<G1Affine>& A, const std::vector<G2Affine>& B, const std::vector<Fq12>& proof) {
+        const size_t n = A.size();
+        if (n != B.size() || proof.size() * 96 != sipp_native_proof_words(n)) throw Error(SIPP_E_BADARG, "sipp_verify_native: sizes");
+        size_t lg = 0;
+        while (((size_t)1 << lg) < n) lg++;
+        NativeVerification v;
+        v.g1_obligations.resize(n - 1);
+        v.g2_obligations.resize(n - 1);
+        v.fq12_obligations.resize(2 * lg);
+        std::vector<uint32_t> st(48 * n + 240);
+        int ok = 0;
+        const int rc = ::sipp_verify_native(ctx_[SIPP_G2_EXP], reinterpret_cast<const uint32_t*>(A.data()),
+                                            reinterpret_cast<const uint32_t*>(B.data()), n, reinterpret_cast<const uint32_t*>(proof.data()),
+                                            st.data(), reinterpret_cast<uint32_t*>(v.g1_obligations.data()),
+                                            reinterpret_cast<uint32_t*>(v.g2_obligations.data()),
+                                            reinterpret_cast<uint32_t*>(v.fq12_obligations.data()), &ok);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_verify_native: ") + sipp_last_error(ctx_[SIPP_G2_EXP]));
+        if (!ok) throw Error(SIPP_E_WITNESS, "Verification failed");
+        v.statement.A = A;
+        v.statement.B = B;
+        const uint32_t* s = st.data() + 48 * n;
+        std::memcpy(&v.statement.Z, s, sizeof(Fq12));
+        std::memcpy(&v.statement.final_A, s + 96, sizeof(G1Affine));
+        std::memcpy(&v.statement.final_B, s + 112, sizeof(G2Affine));
+        std::memcpy(&v.statement.final_Z, s + 144, sizeof(Fq12));
+        return v;
+    }
+
     sipp_ctx* ctx(int kind) { return ctx_[kind]; }
 
    private:

@@ -4,7 +4,8 @@
 //
 //   test_sipp_circuit layout                      CPU only: record layouts, from_flat / to_flat round trip of <proof.bin>
 //   test_sipp_circuit layout <proof.bin>
-//   test_sipp_circuit prove <ios.bin> <out_prefix>   GPU: <ios.bin> = 3 x (u64 count, records); writes <out_prefix>{0,1,2}.bin
+//   test_sipp_circuit prove <ios.bin> <out_prefix>   GPU: <ios.bin> = 3 x (u64 count, records) [+ (count, A), (count, B)];
+//                                                    writes <out_prefix>{0,1,2}.bin
 //
 // The verifier is the CPU oracle's (test infrastructure), linked only into this test binary.
 #include <cstdio>
@@ -88,6 +89,29 @@ static int prove(const char* ios_path, const char* out_prefix) {
     const auto io2 = take<sipp::G2ExpIO>(w, &pos);
     const auto io12 = take<sipp::Fq12ExpIO>(w, &pos);
     sipp::Prover prover(0, io1.size(), io2.size(), io12.size());
+
+    // optional fourth section: the points A, B themselves -> the native chain in front of the circuit
+    // (verifier_circuit.rs:202-211: sipp_prove_native, then sipp_verify_native gives the statement and the obligations)
+    if (pos < w.size()) {
+        const auto A = take<sipp::G1Affine>(w, &pos);
+        const auto B = take<sipp::G2Affine>(w, &pos);
+        const std::vector<sipp::Fq12> sipp_proof = prover.sipp_prove_native(A, B);
+        const auto v = prover.sipp_verify_native(A, B, sipp_proof);
+        CHECK(v.g1_obligations.size() == io1.size() && v.g2_obligations.size() == io2.size() && v.fq12_obligations.size() == io12.size());
+        CHECK(std::memcmp(v.g1_obligations.data(), io1.data(), io1.size() * sizeof(sipp::G1ExpIO)) == 0);
+        CHECK(std::memcmp(v.g2_obligations.data(), io2.data(), io2.size() * sizeof(sipp::G2ExpIO)) == 0);
+        CHECK(std::memcmp(v.fq12_obligations.data(), io12.data(), io12.size() * sizeof(sipp::Fq12ExpIO)) == 0);
+        CHECK(std::memcmp(&v.statement.final_Z, &io12.back().out, sizeof(sipp::Fq12)) == 0);
+        auto bad = sipp_proof;
+        bad[0].c[0][0] ^= 1;  // final message Z_R of the last round
+        try {
+            (void)prover.sipp_verify_native(A, B, bad);
+            CHECK(!"tampered SIPP proof accepted");
+        } catch (const sipp::Error& e) {
+            CHECK(e.status() == SIPP_E_WITNESS);
+        }
+        printf("native chain ok: %zu pairs, %zu proof messages\n", A.size(), sipp_proof.size());
+    }
 
     // the three calls of verifier_circuit.rs:133-135
     sipp::ExpCircuitResult<sipp::G1Affine> r1;

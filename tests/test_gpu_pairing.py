@@ -87,3 +87,31 @@ def test_native_chain_reproduces_the_fixtures(n):
         assert not ctx.verify_native(A, B, bad)[0]
     finally:
         ctx.close()
+
+
+def test_whole_pipeline_from_points_to_three_proofs():
+    """The flow of the reference's test_sipp_circuit (src/verifier_circuit.rs:192-269) with every heavy step in the product:
+    A, B -> sipp_prove_native -> sipp_verify_native (statement + obligation lists) -> sipp_instance_prove -> three STARK
+    proofs whose public inputs are exactly those obligations; each proof is checked by the oracle's verifier."""
+    import sipp_amd
+    from tests import _oracle
+    n = 8
+    d = np.load("tests/golden/sipp_n%d_ios.npz" % n)
+    A, B = d["statement"][: 16 * n].reshape(n, 16), d["statement"][16 * n: 48 * n].reshape(n, 32)
+    ctx = sipp_amd.Ctx(workspace_bytes=1 << 30)
+    try:
+        ok, st, ios = ctx.verify_native(A, B, ctx.prove_native(A, B))
+        assert ok and (st == d["statement"]).all()
+    finally:
+        ctx.close()
+    inst = sipp_amd.Instance([a.shape[0] for a in ios])
+    try:
+        proofs = inst.prove(ios)
+        for kind in range(3):
+            pf = proofs[kind]
+            assert _oracle.stark_verify(pf) == 0
+            nio = int(pf[3])
+            pis = pf[-nio * ios[kind].shape[1]:].reshape(nio, ios[kind].shape[1])
+            assert (pis[: ios[kind].shape[0]] == ios[kind]).all()
+    finally:
+        inst.close()

@@ -47,14 +47,17 @@ def test_sipp_circuit_cpp(tmp_path):
     exe = build_host_test()
     d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n4_ios.npz"))
     ios = [np.ascontiguousarray(d[k], dtype=np.uint32) for k in ("g1", "g2", "fq12")]
+    st = d["statement"]
+    pts = [np.ascontiguousarray(st[:64].reshape(4, 16)), np.ascontiguousarray(st[64:192].reshape(4, 32))]   # A, B of the n = 4 fixture
     with open(tmp_path / "ios.bin", "wb") as f:
-        for a in ios:
+        for a in ios + pts:
             f.write(np.uint64(a.shape[0]).tobytes())
             f.write(a.tobytes())
             f.write(b"\0" * (-a.nbytes % 8))
     out = subprocess.run([exe, "prove", str(tmp_path / "ios.bin"), str(tmp_path / "proof")], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+    assert "native chain ok" in out.stdout
     ctx = sipp_amd.Ctx(workspace_bytes=8 << 30)
     try:
         for k in range(3):
