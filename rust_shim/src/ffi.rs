@@ -38,5 +38,10 @@ extern "C" {
     pub fn sipp_wait(ctx: *mut SippCtxOpaque, len: *mut usize) -> c_int;
     pub fn sipp_instance_prove(ctxs: *const *mut SippCtxOpaque, ios: *const *const u32, num_io: *const usize, out: *const *mut u64,
                                cap: *const usize, len: *mut usize) -> c_int;
+    pub fn sipp_inner_products(ctx: *mut SippCtxOpaque, g1: *const u32, g2: *const u32, n: usize, count: usize, out: *mut u32) -> c_int;
+    pub fn sipp_native_proof_words(n: usize) -> usize;
+    pub fn sipp_prove_native(ctx: *mut SippCtxOpaque, a: *const u32, b: *const u32, n: usize, proof: *mut u32) -> c_int;
+    pub fn sipp_verify_native(ctx: *mut SippCtxOpaque, a: *const u32, b: *const u32, n: usize, proof: *const u32, statement: *mut u32,
+                              g1_ios: *mut u32, g2_ios: *mut u32, fq12_ios: *mut u32, accepted: *mut c_int) -> c_int;
     pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
 }
