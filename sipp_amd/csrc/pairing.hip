@@ -1,17 +1,16 @@
 // sipp_amd/csrc/pairing.hip -- BN254 optimal ate pairing products on gfx950: the inner_product of the native SIPP prover
 // (reference src/prover_native.rs:15-23: prod_i pairing(A_i, B_i), called 2 log2 n + 1 times per proof at :43,:51,:52; the
 // reference takes `pairing` from plonky2-bn254-pairing @ fe5c3a8, not vendored).  SURVEY.md section 8(f) rank 3: first step
-// of the widening beyond the STARK sub-provers -- a correct, oracle-checked path; not yet tuned.
+// of the widening beyond the STARK sub-provers.
 //
-// Mapping: one lane per (A_i, B_i) runs the Miller loop (affine twist arithmetic with one Fq2 inversion per step, the same
-// algorithm step for step as oracle/py/bn254.py::miller_loop, so intermediate values can be compared), values in
-// Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six Fq2 coefficients in Montgomery form (fq.cuh).  One workgroup then multiplies
-// the n Miller values (strided partial products + a tree) and lane 0 applies the final exponentiation: easy part
+// Mapping: one WAVE per (A_i, B_i) runs the Miller loop (homogeneous projective twist arithmetic on lane 0, no inversion; the
+// 36 / 18 Fq2 products of every Fq12 product spread over the lanes), values in Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six
+// Fq2 coefficients in Montgomery form (fq.cuh), resident in LDS.  One workgroup then multiplies
+// the n Miller values (strided partial products + a tree) and one wave applies the final exponentiation: easy part
 // (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers by u); the result is
 // exactly f^((p^12 - 1)/r).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
 // (c_i = a_i - 9 b_i, c_{i+6} = b_i for the Fq2 coefficient a_i + b_i u of w^i), 8 x u32 limbs each.
-// The field routines are deliberately NOT inlined (one copy each, operands through pointers): the whole file is ~4 k
-// Montgomery products per lane-step and would not fit the instruction cache otherwise.
+// The field routines are deliberately NOT inlined (one copy each, operands through pointers) to keep the code small.
 #include "ctx.hpp"
 #include "fq.cuh"
 #include "pairing_constants.h"
@@ -46,11 +45,6 @@ __device__ __forceinline__ void f2_scale(Fq2& r, const Fq2& a, const Fq& s) {
     fq_mul(r.c1, a.c1, s);
 }
 
-__device__ __noinline__ void t6_one(T6& r) {
-    r.c[0] = f2_one();
-    for (int i = 1; i < 6; i++) r.c[i] = f2_zero();
-}
-
 // r = a * b in Fq2[w]/(w^6 - xi); r may alias a or b
 __device__ __noinline__ void t6_mul(T6& r, const T6& a, const T6& b) {
     Fq2 d[11];
@@ -67,39 +61,6 @@ __device__ __noinline__ void t6_mul(T6& r, const T6& a, const T6& b) {
         r.c[k] = fq::add(d[k], t);
     }
     r.c[5] = d[5];
-}
-
-// f *= l0 + l1 w + l3 w^3 with l0 in Fq (the line through twist points evaluated at a G1 point)
-__device__ __noinline__ void t6_mul_line(T6& f, const Fq& l0, const Fq2& l1, const Fq2& l3) {
-    Fq2 d[9];
-    for (int k = 0; k < 9; k++) d[k] = f2_zero();
-    for (int i = 0; i < 6; i++) {
-        Fq2 t;
-        f2_scale(t, f.c[i], l0);
-        d[i] = fq::add(d[i], t);
-        f2_mul(t, f.c[i], l1);
-        d[i + 1] = fq::add(d[i + 1], t);
-        f2_mul(t, f.c[i], l3);
-        d[i + 3] = fq::add(d[i + 3], t);
-    }
-    for (int k = 0; k < 3; k++) {
-        Fq2 t;
-        f2_mul_xi(t, d[k + 6]);
-        f.c[k] = fq::add(d[k], t);
-    }
-    for (int k = 3; k < 6; k++) f.c[k] = d[k];
-}
-
-// x -> x^(p^6): w -> -w
-__device__ __noinline__ void t6_conj(T6& r, const T6& a) {
-    for (int i = 0; i < 6; i++) r.c[i] = (i & 1) ? f2_neg(a.c[i]) : a.c[i];
-}
-// x -> x^(p^k), k = 1..3
-__device__ __noinline__ void t6_frob(T6& r, const T6& a, int k) {
-    for (int i = 0; i < 6; i++) {
-        const Fq2 c = (k & 1) ? f2_conj(a.c[i]) : a.c[i];
-        f2_mul(r.c[i], c, pairing_k::GAMMA[k - 1][i]);
-    }
 }
 
 // ---- Fq6 = Fq2[v]/(v^3 - xi), v = w^2: only for the inversion ----
@@ -167,92 +128,218 @@ __device__ __noinline__ void t6_inv(T6& r, const T6& a) {
     }
 }
 
-// r = a^u (u = 4965661367192848881, 63 bits), most significant bit first
-__device__ __noinline__ void t6_pow_u(T6& r, const T6& a) {
-    T6 acc = a;
-    for (int i = pairing_k::U_BITS - 2; i >= 0; i--) {
-        t6_mul(acc, acc, acc);
-        if ((pairing_k::U >> i) & 1) t6_mul(acc, acc, a);
+// ---- final exponentiation f^((p^12 - 1)/r) by ONE WAVE (oracle/py/bn254.py::final_exp computes the same value by plain
+// square-and-multiply): easy part (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers
+// by u).  Every Fq12 value lives in LDS, the 36 Fq2 products of an Fq12 product are
+// taken by 36 lanes (then 11 lanes sum the anti-diagonals and 6 fold w^6 = xi), conjugations and Frobenius maps by 6 lanes;
+// only the single inversion of the easy part runs on one lane.  ~290 Fq12 products: 33 ms on one lane, ~1 ms this way.
+struct CoopScratch {
+    Fq2 prod[36];
+    Fq2 dsum[11];
+};
+__device__ __forceinline__ void coop_mul(T6& r, const T6& a, const T6& b, CoopScratch& sc) {  // r may alias a or b
+    const uint32_t l = threadIdx.x;
+    if (l < 36) f2_mul(sc.prod[l], a.c[l / 6], b.c[l % 6]);
+    __syncthreads();
+    if (l < 11) {
+        Fq2 d = f2_zero();
+        for (int i = 0; i < 6; i++) {
+            const int j = (int)l - i;
+            if (j >= 0 && j < 6) d = fq::add(d, sc.prod[i * 6 + j]);
+        }
+        sc.dsum[l] = d;
     }
-    r = acc;
+    __syncthreads();
+    if (l < 6) {
+        if (l < 5) {
+            Fq2 t;
+            f2_mul_xi(t, sc.dsum[l + 6]);
+            r.c[l] = fq::add(sc.dsum[l], t);
+        } else {
+            r.c[5] = sc.dsum[5];
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_conj(T6& r, const T6& a) {
+    const uint32_t l = threadIdx.x;
+    if (l < 6) r.c[l] = (l & 1) ? f2_neg(a.c[l]) : a.c[l];
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_frob(T6& r, const T6& a, int k) {
+    const uint32_t l = threadIdx.x;
+    if (l < 6) {
+        const Fq2 c = (k & 1) ? f2_conj(a.c[l]) : a.c[l];
+        f2_mul(r.c[l], c, pairing_k::GAMMA[k - 1][l]);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_copy(T6& r, const T6& a) {
+    const uint32_t l = threadIdx.x;
+    if (l < 6) r.c[l] = a.c[l];
+    __syncthreads();
+}
+__device__ __forceinline__ void coop_pow_u(T6& r, const T6& a, CoopScratch& sc) {  // r != a
+    coop_copy(r, a);
+    for (int i = pairing_k::U_BITS - 2; i >= 0; i--) {
+        coop_mul(r, r, r, sc);
+        if ((pairing_k::U >> i) & 1) coop_mul(r, r, a, sc);
+    }
+}
+struct FinalExpLds {
+    T6 f, g, t, u, fx, fx2, fx3, y0, y1, y2, y3, y4, y5, y6, t0, t1;
+    CoopScratch sc;
+};
+// L.f in: the Miller product; L.f out: f^((p^12 - 1)/r).  Called by all 64 lanes of a one-wave workgroup.
+__device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
+    CoopScratch& sc = L.sc;
+    coop_conj(L.t, L.f);
+    if (threadIdx.x == 0) {  // the one inversion: ~40 Fq2 products and an Fq inversion, on one lane
+        T6 a = L.f, b;
+        t6_inv(b, a);
+        L.u = b;
+    }
+    __syncthreads();
+    coop_mul(L.g, L.t, L.u, sc);  // f^(p^6 - 1)
+    coop_frob(L.t, L.g, 2);
+    coop_mul(L.g, L.t, L.g, sc);  // ^(p^2 + 1)
+    coop_pow_u(L.fx, L.g, sc);
+    coop_pow_u(L.fx2, L.fx, sc);
+    coop_pow_u(L.fx3, L.fx2, sc);
+    coop_frob(L.y0, L.g, 1);
+    coop_frob(L.t, L.g, 2);
+    coop_mul(L.y0, L.y0, L.t, sc);
+    coop_frob(L.t, L.g, 3);
+    coop_mul(L.y0, L.y0, L.t, sc);
+    coop_conj(L.y1, L.g);
+    coop_frob(L.y2, L.fx2, 2);
+    coop_frob(L.t, L.fx, 1);
+    coop_conj(L.y3, L.t);
+    coop_frob(L.t, L.fx2, 1);
+    coop_mul(L.t, L.fx, L.t, sc);
+    coop_conj(L.y4, L.t);
+    coop_conj(L.y5, L.fx2);
+    coop_frob(L.t, L.fx3, 1);
+    coop_mul(L.t, L.fx3, L.t, sc);
+    coop_conj(L.y6, L.t);
+    coop_mul(L.t0, L.y6, L.y6, sc);
+    coop_mul(L.t0, L.t0, L.y4, sc);
+    coop_mul(L.t0, L.t0, L.y5, sc);
+    coop_mul(L.t1, L.y3, L.y5, sc);
+    coop_mul(L.t1, L.t1, L.t0, sc);
+    coop_mul(L.t0, L.t0, L.y2, sc);
+    coop_mul(L.t1, L.t1, L.t1, sc);
+    coop_mul(L.t1, L.t1, L.t0, sc);
+    coop_mul(L.t1, L.t1, L.t1, sc);
+    coop_mul(L.t0, L.t1, L.y1, sc);
+    coop_mul(L.t1, L.t1, L.y0, sc);
+    coop_mul(L.t0, L.t0, L.t0, sc);
+    coop_mul(L.f, L.t0, L.t1, sc);
 }
 
-// f^((p^12 - 1)/r): oracle/py/bn254.py::final_exp computes the same value by plain square-and-multiply
-__device__ __noinline__ void final_exp(T6& f) {
-    T6 g, t, u;
-    t6_conj(t, f);
-    t6_inv(u, f);
-    t6_mul(g, t, u);  // f^(p^6 - 1)
-    t6_frob(t, g, 2);
-    t6_mul(g, t, g);  // ^(p^2 + 1)
-    // hard part, Devegili-Scott-Dahab
-    T6 fx, fx2, fx3, y0, y1, y2, y3, y4, y5, y6, t0, t1;
-    t6_pow_u(fx, g);
-    t6_pow_u(fx2, fx);
-    t6_pow_u(fx3, fx2);
-    t6_frob(y0, g, 1);
-    t6_frob(t, g, 2);
-    t6_mul(y0, y0, t);
-    t6_frob(t, g, 3);
-    t6_mul(y0, y0, t);
-    t6_conj(y1, g);
-    t6_frob(y2, fx2, 2);
-    t6_frob(t, fx, 1);
-    t6_conj(y3, t);
-    t6_frob(t, fx2, 1);
-    t6_mul(t, fx, t);
-    t6_conj(y4, t);
-    t6_conj(y5, fx2);
-    t6_frob(t, fx3, 1);
-    t6_mul(t, fx3, t);
-    t6_conj(y6, t);
-    t6_mul(t0, y6, y6);
-    t6_mul(t0, t0, y4);
-    t6_mul(t0, t0, y5);
-    t6_mul(t1, y3, y5);
-    t6_mul(t1, t1, t0);
-    t6_mul(t0, t0, y2);
-    t6_mul(t1, t1, t1);
-    t6_mul(t1, t1, t0);
-    t6_mul(t1, t1, t1);
-    t6_mul(t0, t1, y1);
-    t6_mul(t1, t1, y0);
-    t6_mul(t0, t0, t0);
-    t6_mul(f, t0, t1);
-}
-
-// ---- Miller loop (oracle/py/bn254.py::_line, _step, miller_loop) ----
+// ---- Miller loop: one WAVE per pair.  f lives in LDS and its products are spread over the lanes like in the final
+// exponentiation; the twist point T = (X, Y, Z) is homogeneous projective and advanced by lane 0 without any inversion.
+// Lines are scaled by Fq2 factors (2 Y Z^2 for a tangent, x_Q Z - X for a chord) that the final exponentiation removes:
+//   tangent: N = 3 X^2, D = 2 Y Z:  l = D Z y_P - N Z x_P w + (N X - D Y) w^3
+//            W = N^2 Z - 2 X D^2:   T <- (D W, N (X D^2 - W) - Y D^3, D^3 Z)
+//   chord:   N = y_Q Z - Y, D = x_Q Z - X:  l = D y_P - N x_P w + (N x_Q - D y_Q) w^3
+//            E = D^2 Z, W = N^2 Z - X D^2 - x_Q E:  T <- (D W, N (x_Q E - W) - y_Q D^3 Z, D^3 Z)
+// (tools/pairing_prototype.py::miller_proj is the same algorithm in Python, checked against the oracle's affine loop.)
 struct G2A {
     Fq2 x, y;
 };
-// line through T and Q (tangent when `tangent`) evaluated at (xp, yp), f *= line, T <- T + Q
-__device__ __noinline__ void line_step(T6& f, G2A& T, const G2A& Q, bool tangent, const Fq& xp_neg, const Fq& yp, bool advance) {
-    Fq2 lam, num, den, deni;
-    if (tangent) {
-        Fq2 x2;
-        f2_sqr(x2, T.x);
-        num = fq::add(f2_dbl(x2), x2);  // 3 x^2
-        den = f2_dbl(T.y);
-    } else {
-        num = fq::sub(Q.y, T.y);
-        den = fq::sub(Q.x, T.x);
+struct G2P {
+    Fq2 X, Y, Z;
+};
+struct LineLds {
+    Fq2 l[3];       // coefficients of w^0, w^1, w^3
+    Fq2 prod[18];
+    Fq2 dsum[9];
+};
+__device__ __noinline__ void proj_double(G2P& T, Fq2 (&l)[3], const Fq& xp_neg, const Fq& yp) {
+    Fq2 N, D, D2, D3, XD2, N2, W, t, u;
+    f2_sqr(t, T.X);
+    N = fq::add(f2_dbl(t), t);
+    f2_mul(t, T.Y, T.Z);
+    D = f2_dbl(t);
+    f2_sqr(D2, D);
+    f2_mul(D3, D2, D);
+    f2_mul(XD2, T.X, D2);
+    f2_sqr(N2, N);
+    f2_mul(t, N2, T.Z);
+    W = fq::sub(t, f2_dbl(XD2));
+    f2_mul(t, D, T.Z);
+    f2_scale(l[0], t, yp);
+    f2_mul(t, N, T.Z);
+    f2_scale(l[1], t, xp_neg);
+    f2_mul(t, N, T.X);
+    f2_mul(u, D, T.Y);
+    l[2] = fq::sub(t, u);
+    Fq2 X3, Y3;
+    f2_mul(X3, D, W);
+    f2_mul(t, N, fq::sub(XD2, W));
+    f2_mul(u, T.Y, D3);
+    Y3 = fq::sub(t, u);
+    f2_mul(t, D3, T.Z);
+    T.X = X3;
+    T.Y = Y3;
+    T.Z = t;
+}
+__device__ __noinline__ void proj_add(G2P& T, const G2A& Q, Fq2 (&l)[3], const Fq& xp_neg, const Fq& yp, bool advance) {
+    Fq2 N, D, t, u;
+    f2_mul(t, Q.y, T.Z);
+    N = fq::sub(t, T.Y);
+    f2_mul(t, Q.x, T.Z);
+    D = fq::sub(t, T.X);
+    f2_scale(l[0], D, yp);
+    f2_scale(l[1], N, xp_neg);
+    f2_mul(t, N, Q.x);
+    f2_mul(u, D, Q.y);
+    l[2] = fq::sub(t, u);
+    if (!advance) return;
+    Fq2 D2, D3, E, xqE, N2, W, Z3, X3, Y3;
+    f2_sqr(D2, D);
+    f2_mul(D3, D2, D);
+    f2_mul(E, D2, T.Z);
+    f2_mul(xqE, Q.x, E);
+    f2_sqr(N2, N);
+    f2_mul(t, N2, T.Z);
+    f2_mul(u, T.X, D2);
+    W = fq::sub(fq::sub(t, u), xqE);
+    f2_mul(Z3, D3, T.Z);
+    f2_mul(X3, D, W);
+    f2_mul(t, N, fq::sub(xqE, W));
+    f2_mul(u, Q.y, Z3);
+    Y3 = fq::sub(t, u);
+    T.X = X3;
+    T.Y = Y3;
+    T.Z = Z3;
+}
+// f *= l[0] + l[1] w + l[2] w^3, the 18 products on 18 lanes
+__device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L) {
+    const uint32_t t = threadIdx.x;
+    if (t < 18) f2_mul(L.prod[t], f.c[t / 3], L.l[t % 3]);
+    __syncthreads();
+    if (t < 9) {
+        Fq2 d = f2_zero();
+        for (int i = 0; i < 6; i++) {
+            const int off = (int)t - i;  // exponent of the line term: 0, 1 or 3
+            if (off == 0 || off == 1) d = fq::add(d, L.prod[3 * i + off]);
+            else if (off == 3) d = fq::add(d, L.prod[3 * i + 2]);
+        }
+        L.dsum[t] = d;
     }
-    f2_inv(deni, den);
-    f2_mul(lam, num, deni);
-    Fq2 l1, l3;
-    f2_scale(l1, lam, xp_neg);  // -lam x_P
-    f2_mul(l3, lam, T.x);
-    l3 = fq::sub(l3, T.y);      // lam x_T - y_T
-    t6_mul_line(f, yp, l1, l3);
-    if (advance) {
-        Fq2 l2, x3, y3;
-        f2_sqr(l2, lam);
-        x3 = fq::sub(fq::sub(l2, T.x), tangent ? T.x : Q.x);
-        f2_mul(y3, lam, fq::sub(T.x, x3));
-        y3 = fq::sub(y3, T.y);
-        T.x = x3;
-        T.y = y3;
+    __syncthreads();
+    if (t < 6) {
+        if (t < 3) {
+            Fq2 x;
+            f2_mul_xi(x, L.dsum[t + 6]);
+            f.c[t] = fq::add(L.dsum[t], x);
+        } else {
+            f.c[t] = L.dsum[t];
+        }
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ Fq load_fq(const uint32_t* w) {
@@ -261,46 +348,65 @@ __device__ __forceinline__ Fq load_fq(const uint32_t* w) {
     return fq::to_mont(r);
 }
 
-// one lane per pair; g1 [n][16] = (x, y), g2 [n][32] = (x.c0, x.c1, y.c0, y.c1) (reference src/transcript_native.rs:42-54 order);
+struct MillerLds {
+    T6 f;
+    CoopScratch sc;
+    LineLds line;
+};
+// one wave per pair; g1 [n][16] = (x, y), g2 [n][32] = (x.c0, x.c1, y.c0, y.c1) (reference src/transcript_native.rs:42-54 order);
 // all-zero coordinates stand for the point at infinity (Miller value 1)
 __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                     T6* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    __shared__ MillerLds S;
+    const uint32_t i = blockIdx.x, t = threadIdx.x;
     const uint32_t* pw = g1 + (size_t)i * 16;
     const uint32_t* qw = g2 + (size_t)i * 32;
-    T6 f;
-    t6_one(f);
-    uint32_t nzp = 0, nzq = 0;
+    if (t < 6) S.f.c[t] = t == 0 ? f2_one() : f2_zero();
+    uint32_t nzp = 0, nzq = 0;  // wave-uniform
     for (int k = 0; k < 16; k++) nzp |= pw[k];
     for (int k = 0; k < 32; k++) nzq |= qw[k];
+    __syncthreads();
     if (nzp != 0 && nzq != 0) {
-        const Fq xp = load_fq(pw), yp = load_fq(pw + 8);
-        const Fq xpn = fq::neg(xp);
-        G2A Q{Fq2{load_fq(qw), load_fq(qw + 8)}, Fq2{load_fq(qw + 16), load_fq(qw + 24)}};
-        G2A T = Q;
-        for (int b = pairing_k::ATE_BITS - 2; b >= 0; b--) {
-            t6_mul(f, f, f);
-            line_step(f, T, T, true, xpn, yp, true);
-            const uint32_t bit = b >= 64 ? (pairing_k::ATE_HI >> (b - 64)) & 1u : (uint32_t)(pairing_k::ATE_LO >> b) & 1u;
-            if (bit) line_step(f, T, Q, false, xpn, yp, true);
+        // lane 0 owns the point arithmetic; the other lanes only help with the products of f
+        Fq xpn = fq::zero(), yp = fq::zero();
+        G2A Q{f2_zero(), f2_zero()}, Q1 = Q, Q2 = Q;
+        G2P T{f2_zero(), f2_zero(), f2_zero()};
+        if (t == 0) {
+            xpn = fq::neg(load_fq(pw));
+            yp = load_fq(pw + 8);
+            Q = G2A{Fq2{load_fq(qw), load_fq(qw + 8)}, Fq2{load_fq(qw + 16), load_fq(qw + 24)}};
+            T = G2P{Q.x, Q.y, f2_one()};
+            // Q1 = pi(Q), Q2 = -pi^2(Q): pi(x, y) = (conj(x) gamma_1,2, conj(y) gamma_1,3)
+            f2_mul(Q1.x, f2_conj(Q.x), pairing_k::GAMMA[0][2]);
+            f2_mul(Q1.y, f2_conj(Q.y), pairing_k::GAMMA[0][3]);
+            f2_mul(Q2.x, f2_conj(Q1.x), pairing_k::GAMMA[0][2]);
+            f2_mul(Q2.y, f2_conj(Q1.y), pairing_k::GAMMA[0][3]);
+            Q2.y = f2_neg(Q2.y);
         }
-        // Q1 = pi(Q), Q2 = -pi^2(Q): pi(x, y) = (conj(x) gamma_1,2, conj(y) gamma_1,3)
-        G2A Q1, Q2;
-        f2_mul(Q1.x, f2_conj(Q.x), pairing_k::GAMMA[0][2]);
-        f2_mul(Q1.y, f2_conj(Q.y), pairing_k::GAMMA[0][3]);
-        f2_mul(Q2.x, f2_conj(Q1.x), pairing_k::GAMMA[0][2]);
-        f2_mul(Q2.y, f2_conj(Q1.y), pairing_k::GAMMA[0][3]);
-        Q2.y = f2_neg(Q2.y);
-        line_step(f, T, Q1, false, xpn, yp, true);
-        line_step(f, T, Q2, false, xpn, yp, false);
+        for (int b = pairing_k::ATE_BITS - 2; b >= 0; b--) {
+            coop_mul(S.f, S.f, S.f, S.sc);
+            if (t == 0) proj_double(T, S.line.l, xpn, yp);
+            __syncthreads();
+            coop_mul_line(S.f, S.line);
+            const uint32_t bit = b >= 64 ? (pairing_k::ATE_HI >> (b - 64)) & 1u : (uint32_t)(pairing_k::ATE_LO >> b) & 1u;
+            if (bit) {
+                if (t == 0) proj_add(T, Q, S.line.l, xpn, yp, true);
+                __syncthreads();
+                coop_mul_line(S.f, S.line);
+            }
+        }
+        if (t == 0) proj_add(T, Q1, S.line.l, xpn, yp, true);
+        __syncthreads();
+        coop_mul_line(S.f, S.line);
+        if (t == 0) proj_add(T, Q2, S.line.l, xpn, yp, false);
+        __syncthreads();
+        coop_mul_line(S.f, S.line);
     }
-    out[i] = f;
+    if (t < 6) out[i].c[t] = S.f.c[t];
 }
 
-// one workgroup: product of the n Miller values, final exponentiation, MyFq12 coefficients out.  `count` independent
-// products (blockIdx.x): product k covers values [k * n, (k + 1) * n)
-__global__ void __launch_bounds__(256) product_final_kernel(T6* __restrict__ vals, uint32_t n, uint32_t* __restrict__ out) {
+// one workgroup per product (blockIdx.x): the product of the Miller values [k * n, (k + 1) * n) is left in vals[k * n]
+__global__ void __launch_bounds__(256) product_kernel(T6* __restrict__ vals, uint32_t n) {
     T6* v = vals + (size_t)blockIdx.x * n;
     const uint32_t t = threadIdx.x;
     // strided partial products into v[t]
@@ -319,19 +425,25 @@ __global__ void __launch_bounds__(256) product_final_kernel(T6* __restrict__ val
         }
         __syncthreads();
     }
-    if (t == 0) {
-        T6 f = v[0];
-        final_exp(f);
+}
+
+// one wave per product: final exponentiation of vals[k * n] (the product left there by product_kernel), MyFq12 coefficients out
+__global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ vals, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ FinalExpLds L;
+    const uint32_t l = threadIdx.x;
+    if (l < 6) L.f.c[l] = vals[(size_t)blockIdx.x * n].c[l];
+    __syncthreads();
+    final_exp_coop(L);
+    if (l < 6) {
+        // MyFq12 coefficients c_i = a_i - 9 b_i, c_{i+6} = b_i of the Fq2 coefficient a_i + b_i u of w^i
         uint32_t* o = out + (size_t)blockIdx.x * 96;
         const Fq nine = fq::small_m(9);
-        for (int i = 0; i < 6; i++) {
-            Fq nb;
-            fq_mul(nb, nine, f.c[i].c1);
-            const Fq lo = fq::from_mont(fq::sub(f.c[i].c0, nb)), hi = fq::from_mont(f.c[i].c1);
-            for (int l = 0; l < 8; l++) {
-                o[8 * i + l] = lo.l[l];
-                o[8 * (i + 6) + l] = hi.l[l];
-            }
+        Fq nb;
+        fq_mul(nb, nine, L.f.c[l].c1);
+        const Fq lo = fq::from_mont(fq::sub(L.f.c[l].c0, nb)), hi = fq::from_mont(L.f.c[l].c1);
+        for (int k = 0; k < 8; k++) {
+            o[8 * l + k] = lo.l[k];
+            o[8 * (l + 6) + k] = hi.l[k];
         }
     }
 }
@@ -355,13 +467,13 @@ extern "C" int sipp_inner_products(sipp_ctx* ctx, const uint32_t* g1, const uint
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_g2, g2, total * 128, hipMemcpyHostToDevice, ctx->stream));
         {
             ProfScope ps(ctx, "pairing_miller");
-            hipLaunchKernelGGL(miller_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, ctx->stream, d_g1, d_g2,
-                               (uint32_t)total, d_f);
+            hipLaunchKernelGGL(miller_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, d_g1, d_g2, (uint32_t)total, d_f);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         {
             ProfScope ps(ctx, "pairing_product_final");
-            hipLaunchKernelGGL(product_final_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_f, (uint32_t)n, d_out);
+            hipLaunchKernelGGL(product_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_f, (uint32_t)n);
+            hipLaunchKernelGGL(final_exp_kernel, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_f, (uint32_t)n, d_out);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, count * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -136,3 +136,50 @@ if __name__ == "__main__":
     e = final_exp(m)
     assert t_to_c(e) == bn.pairing(Pt, Q), "final exp"
     print("prototype ok")
+
+
+# ---- projective Miller loop (no inversion per step): what miller_coop_kernel in pairing.hip runs ----
+# T = (X, Y, Z) homogeneous, x = X/Z, y = Y/Z.  Lines are scaled by Fq2 factors (2 Y Z^2 for a tangent, x_Q Z - X for a chord),
+# which the final exponentiation removes; the Miller VALUE therefore differs from the affine one, the pairing does not.
+def f2sq(a): return f2m(a, a)
+def f2sc(a, s): return bn.f2_scal(a, s % P)
+def proj_double(T, Pt):
+    X, Y, Z = T
+    N = f2sc(f2sq(X), 3); D = f2sc(f2m(Y, Z), 2)
+    D2 = f2sq(D); D3 = f2m(D2, D); XD2 = f2m(X, D2)
+    W = f2s(f2m(f2sq(N), Z), f2sc(XD2, 2))
+    l0 = f2sc(f2m(D, Z), Pt[1]); l1 = f2sc(f2m(N, Z), -Pt[0]); l3 = f2s(f2m(N, X), f2m(D, Y))
+    T3 = (f2m(D, W), f2s(f2m(N, f2s(XD2, W)), f2m(Y, D3)), f2m(D3, Z))
+    return T3, (l0, l1, l3)
+def proj_add(T, Q, Pt):
+    X, Y, Z = T; xq, yq = Q
+    N = f2s(f2m(yq, Z), Y); D = f2s(f2m(xq, Z), X)
+    D2 = f2sq(D); D3 = f2m(D2, D); E = f2m(D2, Z); xqE = f2m(xq, E)
+    W = f2s(f2s(f2m(f2sq(N), Z), f2m(X, D2)), xqE)
+    Z3 = f2m(D3, Z)
+    l0 = f2sc(D, Pt[1]); l1 = f2sc(N, -Pt[0]); l3 = f2s(f2m(N, xq), f2m(D, yq))
+    T3 = (f2m(D, W), f2s(f2m(N, f2s(xqE, W)), f2m(yq, Z3)), Z3)
+    return T3, (l0, l1, l3)
+def mul_line(f, l):
+    L = [l[0], l[1], Z2, l[2], Z2, Z2]
+    return t_mul(f, L)
+def miller_proj(Pt, Q):
+    f = t_one(); T = (Q[0], Q[1], O2)
+    for bit in bin(ATE)[3:]:
+        T, l = proj_double(T, Pt); f = mul_line(t_sqr(f), l)
+        if bit == "1":
+            T, l = proj_add(T, Q, Pt); f = mul_line(f, l)
+    Q1 = (f2m(f2conj(Q[0]), bn.FROB_X), f2m(f2conj(Q[1]), bn.FROB_Y))
+    Q2 = (f2m(f2conj(Q1[0]), bn.FROB_X), f2m(f2conj(Q1[1]), bn.FROB_Y))
+    T, l = proj_add(T, Q1, Pt); f = mul_line(f, l)
+    T, l = proj_add(T, (Q2[0], f2neg(Q2[1])), Pt); f = mul_line(f, l)
+    return f
+
+
+if __name__ == "__main__":
+    rnd = random.Random(9)
+    for _ in range(2):
+        s, t = rnd.randrange(1, bn.R), rnd.randrange(1, bn.R)
+        Pt, Q = bn.g1_mul(bn.G1, s), bn.g2_mul(bn.G2, t)
+        assert t_to_c(final_exp(miller_proj(Pt, Q))) == bn.pairing(Pt, Q), "projective Miller loop"
+    print("projective prototype ok")
