@@ -240,6 +240,25 @@ def main():
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms] if serial else None,
             "pipelined": pipelined,
         }
+        # secondary, outside the timed region: the native SIPP chain in front of the circuit
+        # on this GPU -- sipp_prove_native = 3n - 2 pairings + the folds, sipp_verify_native = the obligation lists the timed
+        # region consumes.  Never allowed to break the main line.
+        try:
+            st = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % args.n))["statement"]
+            An, Bn = st[: 16 * args.n].reshape(args.n, 16), st[16 * args.n: 48 * args.n].reshape(args.n, 32)
+            nctx = ctxs[1]                      # the G2 ctx: its arena holds the widest fold
+            nctx.prove_native(An, Bn)
+            t = time.perf_counter()
+            npf = nctx.prove_native(An, Bn)
+            t_np = time.perf_counter() - t
+            t = time.perf_counter()
+            okn, _, nios = nctx.verify_native(An, Bn, npf)
+            t_nv = time.perf_counter() - t
+            out["native_chain"] = {"prove_native_ms": 1e3 * t_np, "verify_native_ms": 1e3 * t_nv, "pairings": 3 * args.n - 2,
+                                   "pairings_per_s": (3 * args.n - 2) / t_np, "accepted": bool(okn),
+                                   "obligations_equal_bench_input": bool(all((a == b).all() for a, b in zip(nios, ios)))}
+        except Exception as e:                  # noqa: BLE001
+            out["native_chain"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ios, shapes)
         else:
