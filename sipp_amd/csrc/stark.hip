@@ -594,8 +594,9 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
     uint32_t* d_ios = nullptr;
     int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
     int* d_err = arena_alloc_t<int>(ctx, 1);
-    uint64_t* d_trace = arena_alloc_t<uint64_t>(ctx, (size_t)s.W << s.log_n);
-    if (rc == SIPP_OK && (!d_err || !d_trace)) rc = SIPP_E_NOMEM;
+    // the curves' outputs come straight from the accumulator chains (no trace rows); the Fq12 chain writes its cells
+    uint64_t* d_trace = kind == SIPP_FQ12_EXP ? arena_alloc_t<uint64_t>(ctx, (size_t)s.W << s.log_n) : nullptr;
+    if (rc == SIPP_OK && (!d_err || (kind == SIPP_FQ12_EXP && !d_trace))) rc = SIPP_E_NOMEM;
     if (rc == SIPP_OK) {
         SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
         ctx->outputs_only = true;

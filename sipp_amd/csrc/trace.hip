@@ -340,6 +340,35 @@ __device__ __forceinline__ void store_f_chk<2>(uint64_t* tr, size_t n, int col, 
     store_checked(tr, n, col + 16 * cpl, row, fq::from_mont(v.c1), cpl);
 }
 
+// sipp_exp_outputs for the curves: the accumulator after the last bit (R_256 = offset + [exp] x, Jacobian) of every IO goes
+// straight into the record's output words -- one inversion per IO, no trace rows.  A result at infinity is SIPP_E_WITNESS.
+template <int EXT>
+__global__ void __launch_bounds__(64) curve_outputs_kernel(const RowPts<EXT>* __restrict__ rows, uint32_t* __restrict__ ios,
+                                                         uint32_t num_io, uint32_t ppi, int* __restrict__ err) {
+    using F = Fld<EXT>;
+    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
+    if (io >= num_io) return;
+    const Jac<EXT> J = rows[(size_t)io * 512 + 511].R;
+    if (jac_is_inf<EXT>(J)) {
+        atomicExch(err, SIPP_E_WITNESS);
+        return;
+    }
+    const auto zi = F::inv(J.z), zi2 = F::sqr(zi);
+    const auto x = F::mul(J.x, zi2), y = F::mul(J.y, F::mul(zi2, zi));
+    uint32_t* outw = ios + (size_t)io * ppi + ppi - 16 * EXT;
+    if constexpr (EXT == 1) {
+        const Fq xs = fq::from_mont(x), ys = fq::from_mont(y);
+        for (int l = 0; l < 8; l++) {
+            outw[l] = xs.l[l];
+            outw[8 + l] = ys.l[l];
+        }
+    } else {
+        const Fq c[4] = {fq::from_mont(x.c0), fq::from_mont(x.c1), fq::from_mont(y.c0), fq::from_mont(y.c1)};
+        for (int k = 0; k < 4; k++)
+            for (int l = 0; l < 8; l++) outw[8 * k + l] = c[k].l[l];
+    }
+}
+
 struct CurveCols {
     int Rx, Ry, Px, Py, lam, X3, Y3, cpl;
 };
@@ -938,6 +967,13 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
+            if (ctx->outputs_only) {
+                hipLaunchKernelGGL(curve_outputs_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
+                                   const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
+                SIPP_CHECK_HIP(ctx, hipGetLastError());
+                arena_release(ctx, mark);
+                return SIPP_OK;
+            }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<1>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
                                d_trace, n, c, d_err);
@@ -953,6 +989,13 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
+            if (ctx->outputs_only) {
+                hipLaunchKernelGGL(curve_outputs_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
+                                   const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
+                SIPP_CHECK_HIP(ctx, hipGetLastError());
+                arena_release(ctx, mark);
+                return SIPP_OK;
+            }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<2>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
                                d_trace, n, c, d_err);
