@@ -238,87 +238,122 @@ __device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
 }
 
 // ---- Miller loop: one WAVE per pair.  f lives in LDS and its products are spread over the lanes like in the final
-// exponentiation; the twist point T = (X, Y, Z) is homogeneous projective and advanced by lane 0 without any inversion.
+// exponentiation; the twist point T = (X, Y, Z) is homogeneous projective and advanced without any inversion, the Fq2 products of
+// one dependency level of a step on as many lanes (four levels for a tangent, five for a chord).
 // Lines are scaled by Fq2 factors (2 Y Z^2 for a tangent, x_Q Z - X for a chord) that the final exponentiation removes:
 //   tangent: N = 3 X^2, D = 2 Y Z:  l = D Z y_P - N Z x_P w + (N X - D Y) w^3
 //            W = N^2 Z - 2 X D^2:   T <- (D W, N (X D^2 - W) - Y D^3, D^3 Z)
 //   chord:   N = y_Q Z - Y, D = x_Q Z - X:  l = D y_P - N x_P w + (N x_Q - D y_Q) w^3
 //            E = D^2 Z, W = N^2 Z - X D^2 - x_Q E:  T <- (D W, N (x_Q E - W) - y_Q D^3 Z, D^3 Z)
 // (tools/pairing_prototype.py::miller_proj is the same algorithm in Python, checked against the oracle's affine loop.)
-struct G2A {
-    Fq2 x, y;
+// The point arithmetic of a step is a short program of Fq2 products whose operands and results sit in LDS (PointLds::v);
+// the products of one dependency level run on as many lanes, the additions between levels on lane 0.
+enum PV : uint8_t {
+    vX, vY, vZ, vXQ, vYQ,           // T = (X, Y, Z); the affine point of a chord step
+    vN, vD, vD2, vN2, vD3, vXD2, vNZ, vNX, vDZ, vDY, vN2Z, vW, vU, vT0, vT1, vT2, vT3, vE, vXQE, vZ3,
+    vL0, vL1, vL3,                  // the line: coefficients of w^0, w^1, w^3
+    PV_COUNT
 };
-struct G2P {
-    Fq2 X, Y, Z;
+struct PointLds {
+    Fq2 v[PV_COUNT];
+    Fq xpn, yp;                     // -x_P, y_P (Montgomery)
 };
+struct POp {
+    uint8_t out, a, b;              // v[out] = v[a] * v[b];  b == 0xFE: v[a] * yp, b == 0xFF: v[a] * xpn (Fq scalars)
+};
+template <int M>
+__device__ __forceinline__ void run_level(PointLds& P, const POp (&ops)[M]) {
+    const uint32_t t = threadIdx.x;
+    if (t < M) {
+        // the table is indexed by the lane: keep it out of a private array
+        uint8_t o = 0, a = 0, b = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++)
+            if (t == (uint32_t)k) {
+                o = ops[k].out;
+                a = ops[k].a;
+                b = ops[k].b;
+            }
+        if (b >= 0xFE) {
+            Fq2 r;
+            f2_scale(r, P.v[a], b == 0xFE ? P.yp : P.xpn);
+            P.v[o] = r;
+        } else {
+            f2_mul(P.v[o], P.v[a], P.v[b]);
+        }
+    }
+    __syncthreads();
+}
+// tangent step: line into vL0 / vL1 / vL3, T <- 2 T
+__device__ __forceinline__ void proj_double(PointLds& P) {
+    const uint32_t t = threadIdx.x;
+    constexpr POp L1[2] = {{vT0, vX, vX}, {vT1, vY, vZ}};
+    run_level(P, L1);
+    if (t == 0) {
+        P.v[vN] = fq::add(f2_dbl(P.v[vT0]), P.v[vT0]);  // N = 3 X^2
+        P.v[vD] = f2_dbl(P.v[vT1]);                     // D = 2 Y Z
+    }
+    __syncthreads();
+    constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNZ, vN, vZ}, {vNX, vN, vX}, {vDZ, vD, vZ}, {vDY, vD, vY}};
+    run_level(P, L2);
+    constexpr POp L3[5] = {{vD3, vD2, vD}, {vXD2, vX, vD2}, {vN2Z, vN2, vZ}, {vL0, vDZ, 0xFE}, {vL1, vNZ, 0xFF}};
+    run_level(P, L3);
+    if (t == 0) {
+        P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
+        P.v[vW] = fq::sub(P.v[vN2Z], f2_dbl(P.v[vXD2]));
+        P.v[vU] = fq::sub(P.v[vXD2], P.v[vW]);
+    }
+    __syncthreads();
+    constexpr POp L4[4] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vY, vD3}, {vT3, vD3, vZ}};
+    run_level(P, L4);
+    if (t == 0) {
+        P.v[vX] = P.v[vT0];
+        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
+        P.v[vZ] = P.v[vT3];
+    }
+    __syncthreads();
+}
+// chord step through the affine point (vXQ, vYQ): line into vL0 / vL1 / vL3, T <- T + Q unless it is the last line
+__device__ __forceinline__ void proj_add(PointLds& P, bool advance) {
+    const uint32_t t = threadIdx.x;
+    constexpr POp L1[2] = {{vT0, vYQ, vZ}, {vT1, vXQ, vZ}};
+    run_level(P, L1);
+    if (t == 0) {
+        P.v[vN] = fq::sub(P.v[vT0], P.v[vY]);  // N = y_Q Z - Y
+        P.v[vD] = fq::sub(P.v[vT1], P.v[vX]);  // D = x_Q Z - X
+    }
+    __syncthreads();
+    constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNX, vN, vXQ}, {vDY, vD, vYQ}, {vL0, vD, 0xFE}, {vL1, vN, 0xFF}};
+    run_level(P, L2);
+    if (t == 0) P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
+    __syncthreads();
+    if (!advance) return;
+    constexpr POp L3[4] = {{vD3, vD2, vD}, {vE, vD2, vZ}, {vN2Z, vN2, vZ}, {vXD2, vX, vD2}};
+    run_level(P, L3);
+    constexpr POp L4[2] = {{vXQE, vXQ, vE}, {vZ3, vD3, vZ}};
+    run_level(P, L4);
+    if (t == 0) {
+        P.v[vW] = fq::sub(fq::sub(P.v[vN2Z], P.v[vXD2]), P.v[vXQE]);
+        P.v[vU] = fq::sub(P.v[vXQE], P.v[vW]);
+    }
+    __syncthreads();
+    constexpr POp L5[3] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vYQ, vZ3}};
+    run_level(P, L5);
+    if (t == 0) {
+        P.v[vX] = P.v[vT0];
+        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
+        P.v[vZ] = P.v[vZ3];
+    }
+    __syncthreads();
+}
 struct LineLds {
-    Fq2 l[3];       // coefficients of w^0, w^1, w^3
     Fq2 prod[18];
     Fq2 dsum[9];
 };
-__device__ __noinline__ void proj_double(G2P& T, Fq2 (&l)[3], const Fq& xp_neg, const Fq& yp) {
-    Fq2 N, D, D2, D3, XD2, N2, W, t, u;
-    f2_sqr(t, T.X);
-    N = fq::add(f2_dbl(t), t);
-    f2_mul(t, T.Y, T.Z);
-    D = f2_dbl(t);
-    f2_sqr(D2, D);
-    f2_mul(D3, D2, D);
-    f2_mul(XD2, T.X, D2);
-    f2_sqr(N2, N);
-    f2_mul(t, N2, T.Z);
-    W = fq::sub(t, f2_dbl(XD2));
-    f2_mul(t, D, T.Z);
-    f2_scale(l[0], t, yp);
-    f2_mul(t, N, T.Z);
-    f2_scale(l[1], t, xp_neg);
-    f2_mul(t, N, T.X);
-    f2_mul(u, D, T.Y);
-    l[2] = fq::sub(t, u);
-    Fq2 X3, Y3;
-    f2_mul(X3, D, W);
-    f2_mul(t, N, fq::sub(XD2, W));
-    f2_mul(u, T.Y, D3);
-    Y3 = fq::sub(t, u);
-    f2_mul(t, D3, T.Z);
-    T.X = X3;
-    T.Y = Y3;
-    T.Z = t;
-}
-__device__ __noinline__ void proj_add(G2P& T, const G2A& Q, Fq2 (&l)[3], const Fq& xp_neg, const Fq& yp, bool advance) {
-    Fq2 N, D, t, u;
-    f2_mul(t, Q.y, T.Z);
-    N = fq::sub(t, T.Y);
-    f2_mul(t, Q.x, T.Z);
-    D = fq::sub(t, T.X);
-    f2_scale(l[0], D, yp);
-    f2_scale(l[1], N, xp_neg);
-    f2_mul(t, N, Q.x);
-    f2_mul(u, D, Q.y);
-    l[2] = fq::sub(t, u);
-    if (!advance) return;
-    Fq2 D2, D3, E, xqE, N2, W, Z3, X3, Y3;
-    f2_sqr(D2, D);
-    f2_mul(D3, D2, D);
-    f2_mul(E, D2, T.Z);
-    f2_mul(xqE, Q.x, E);
-    f2_sqr(N2, N);
-    f2_mul(t, N2, T.Z);
-    f2_mul(u, T.X, D2);
-    W = fq::sub(fq::sub(t, u), xqE);
-    f2_mul(Z3, D3, T.Z);
-    f2_mul(X3, D, W);
-    f2_mul(t, N, fq::sub(xqE, W));
-    f2_mul(u, Q.y, Z3);
-    Y3 = fq::sub(t, u);
-    T.X = X3;
-    T.Y = Y3;
-    T.Z = Z3;
-}
 // f *= l[0] + l[1] w + l[2] w^3, the 18 products on 18 lanes
-__device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L) {
+__device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L, const PointLds& P) {
     const uint32_t t = threadIdx.x;
-    if (t < 18) f2_mul(L.prod[t], f.c[t / 3], L.l[t % 3]);
+    if (t < 18) f2_mul(L.prod[t], f.c[t / 3], P.v[vL0 + t % 3]);
     __syncthreads();
     if (t < 9) {
         Fq2 d = f2_zero();
@@ -352,6 +387,8 @@ struct MillerLds {
     T6 f;
     CoopScratch sc;
     LineLds line;
+    PointLds pt;
+    Fq2 q[6];  // Q, pi(Q), -pi^2(Q): (x, y) each
 };
 // one wave per pair; g1 [n][16] = (x, y), g2 [n][32] = (x.c0, x.c1, y.c0, y.c1) (reference src/transcript_native.rs:42-54 order);
 // all-zero coordinates stand for the point at infinity (Miller value 1)
@@ -365,43 +402,52 @@ __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__
     uint32_t nzp = 0, nzq = 0;  // wave-uniform
     for (int k = 0; k < 16; k++) nzp |= pw[k];
     for (int k = 0; k < 32; k++) nzq |= qw[k];
-    __syncthreads();
     if (nzp != 0 && nzq != 0) {
-        // lane 0 owns the point arithmetic; the other lanes only help with the products of f
-        Fq xpn = fq::zero(), yp = fq::zero();
-        G2A Q{f2_zero(), f2_zero()}, Q1 = Q, Q2 = Q;
-        G2P T{f2_zero(), f2_zero(), f2_zero()};
         if (t == 0) {
-            xpn = fq::neg(load_fq(pw));
-            yp = load_fq(pw + 8);
-            Q = G2A{Fq2{load_fq(qw), load_fq(qw + 8)}, Fq2{load_fq(qw + 16), load_fq(qw + 24)}};
-            T = G2P{Q.x, Q.y, f2_one()};
-            // Q1 = pi(Q), Q2 = -pi^2(Q): pi(x, y) = (conj(x) gamma_1,2, conj(y) gamma_1,3)
-            f2_mul(Q1.x, f2_conj(Q.x), pairing_k::GAMMA[0][2]);
-            f2_mul(Q1.y, f2_conj(Q.y), pairing_k::GAMMA[0][3]);
-            f2_mul(Q2.x, f2_conj(Q1.x), pairing_k::GAMMA[0][2]);
-            f2_mul(Q2.y, f2_conj(Q1.y), pairing_k::GAMMA[0][3]);
-            Q2.y = f2_neg(Q2.y);
+            S.pt.xpn = fq::neg(load_fq(pw));
+            S.pt.yp = load_fq(pw + 8);
         }
+        if (t < 2) {  // Q
+            S.q[t] = Fq2{load_fq(qw + 16 * t), load_fq(qw + 16 * t + 8)};
+        }
+        __syncthreads();
+        if (t < 2) {  // Q1 = pi(Q): pi(x, y) = (conj(x) gamma_1,2, conj(y) gamma_1,3)
+            f2_mul(S.q[2 + t], f2_conj(S.q[t]), pairing_k::GAMMA[0][2 + t]);
+        }
+        __syncthreads();
+        if (t < 2) {  // Q2 = -pi^2(Q)
+            Fq2 r;
+            f2_mul(r, f2_conj(S.q[2 + t]), pairing_k::GAMMA[0][2 + t]);
+            S.q[4 + t] = t ? f2_neg(r) : r;
+        }
+        if (t == 0) {
+            S.pt.v[vX] = S.q[0];
+            S.pt.v[vY] = S.q[1];
+            S.pt.v[vZ] = f2_one();
+            S.pt.v[vXQ] = S.q[0];
+            S.pt.v[vYQ] = S.q[1];
+        }
+        __syncthreads();
         for (int b = pairing_k::ATE_BITS - 2; b >= 0; b--) {
             coop_mul(S.f, S.f, S.f, S.sc);
-            if (t == 0) proj_double(T, S.line.l, xpn, yp);
-            __syncthreads();
-            coop_mul_line(S.f, S.line);
+            proj_double(S.pt);
+            coop_mul_line(S.f, S.line, S.pt);
             const uint32_t bit = b >= 64 ? (pairing_k::ATE_HI >> (b - 64)) & 1u : (uint32_t)(pairing_k::ATE_LO >> b) & 1u;
             if (bit) {
-                if (t == 0) proj_add(T, Q, S.line.l, xpn, yp, true);
-                __syncthreads();
-                coop_mul_line(S.f, S.line);
+                proj_add(S.pt, true);
+                coop_mul_line(S.f, S.line, S.pt);
             }
         }
-        if (t == 0) proj_add(T, Q1, S.line.l, xpn, yp, true);
+        if (t < 2) S.pt.v[vXQ + t] = S.q[2 + t];
         __syncthreads();
-        coop_mul_line(S.f, S.line);
-        if (t == 0) proj_add(T, Q2, S.line.l, xpn, yp, false);
+        proj_add(S.pt, true);
+        coop_mul_line(S.f, S.line, S.pt);
+        if (t < 2) S.pt.v[vXQ + t] = S.q[4 + t];
         __syncthreads();
-        coop_mul_line(S.f, S.line);
+        proj_add(S.pt, false);
+        coop_mul_line(S.f, S.line, S.pt);
     }
+    __syncthreads();
     if (t < 6) out[i].c[t] = S.f.c[t];
 }
 
