@@ -16,6 +16,9 @@
 #include "ctx.hpp"
 #include "prover.hpp"
 
+int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, const uint32_t* off, size_t count,
+                               uint32_t* out);  // pairing.hip
+
 namespace {
 
 // ---- hash_n_to_hash_no_pad: overwrite-mode sponge, rate 8 ----
@@ -192,13 +195,33 @@ int sipp_prove_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in,
         t.append(&B[i * G2W], G2W);
     }
     std::vector<uint32_t> msgs;  // in sending order; reversed at the end (prover_native.rs:78)
-    uint32_t z[96];
-    SIPP_TRY(sipp_inner_product(ctx, A.data(), B.data(), n, z));
+    uint32_t z[96], zl[96], zr[96];
+    bool have_first = false;
+    if (n > 1) {
+        // Z = <A, B> and the first round's Z_L = <A2, B1>, Z_R = <A1, B2> depend on no challenge: ONE device pass
+        const size_t h = n / 2;
+        std::vector<uint32_t> g1(2 * n * G1W), g2(2 * n * G2W);
+        memcpy(&g1[0], A.data(), n * G1W * 4);
+        memcpy(&g2[0], B.data(), n * G2W * 4);
+        memcpy(&g1[n * G1W], &A[h * G1W], h * G1W * 4);            // A2
+        memcpy(&g2[n * G2W], &B[0], h * G2W * 4);                  // B1
+        memcpy(&g1[(n + h) * G1W], &A[0], h * G1W * 4);            // A1
+        memcpy(&g2[(n + h) * G2W], &B[h * G2W], h * G2W * 4);      // B2
+        const uint32_t off[4] = {0, (uint32_t)n, (uint32_t)(n + h), (uint32_t)(2 * n)};
+        uint32_t out[3 * 96];
+        SIPP_TRY(sipp_inner_products_groups(ctx, g1.data(), g2.data(), off, 3, out));
+        memcpy(z, out, 96 * 4);
+        memcpy(zl, out + 96, 96 * 4);
+        memcpy(zr, out + 192, 96 * 4);
+        have_first = true;
+    } else {
+        SIPP_TRY(sipp_inner_product(ctx, A.data(), B.data(), n, z));
+    }
     msgs.insert(msgs.end(), z, z + 96);
     t.append(z, 96);
     while (n > 1) {
-        uint32_t zl[96], zr[96];
-        SIPP_TRY(cross_products(ctx, A, B, n, zl, zr));
+        if (!have_first) SIPP_TRY(cross_products(ctx, A, B, n, zl, zr));
+        have_first = false;
         msgs.insert(msgs.end(), zl, zl + 96);
         t.append(zl, 96);
         msgs.insert(msgs.end(), zr, zr + 96);

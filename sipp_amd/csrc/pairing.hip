@@ -11,6 +11,8 @@
 // exactly f^((p^12 - 1)/r).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
 // (c_i = a_i - 9 b_i, c_{i+6} = b_i for the Fq2 coefficient a_i + b_i u of w^i), 8 x u32 limbs each.
 // The field routines are deliberately NOT inlined (one copy each, operands through pointers) to keep the code small.
+#include <vector>
+
 #include "ctx.hpp"
 #include "fq.cuh"
 #include "pairing_constants.h"
@@ -451,9 +453,10 @@ __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__
     if (t < 6) out[i].c[t] = S.f.c[t];
 }
 
-// one workgroup per product (blockIdx.x): the product of the Miller values [k * n, (k + 1) * n) is left in vals[k * n]
-__global__ void __launch_bounds__(256) product_kernel(T6* __restrict__ vals, uint32_t n) {
-    T6* v = vals + (size_t)blockIdx.x * n;
+// one workgroup per product (blockIdx.x = k): the product of the Miller values [off[k], off[k + 1]) is left in vals[off[k]]
+__global__ void __launch_bounds__(256) product_kernel(T6* __restrict__ vals, const uint32_t* __restrict__ off) {
+    T6* v = vals + off[blockIdx.x];
+    const uint32_t n = off[blockIdx.x + 1] - off[blockIdx.x];
     const uint32_t t = threadIdx.x;
     // strided partial products into v[t]
     if (t < n) {
@@ -473,11 +476,12 @@ __global__ void __launch_bounds__(256) product_kernel(T6* __restrict__ vals, uin
     }
 }
 
-// one wave per product: final exponentiation of vals[k * n] (the product left there by product_kernel), MyFq12 coefficients out
-__global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ vals, uint32_t n, uint32_t* __restrict__ out) {
+// one wave per product: final exponentiation of vals[off[k]] (the product left there by product_kernel), MyFq12 coefficients out
+__global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ vals, const uint32_t* __restrict__ off,
+                                                       uint32_t* __restrict__ out) {
     __shared__ FinalExpLds L;
     const uint32_t l = threadIdx.x;
-    if (l < 6) L.f.c[l] = vals[(size_t)blockIdx.x * n].c[l];
+    if (l < 6) L.f.c[l] = vals[off[blockIdx.x]].c[l];
     __syncthreads();
     final_exp_coop(L);
     if (l < 6) {
@@ -496,21 +500,26 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ va
 
 }  // namespace
 
-extern "C" int sipp_inner_products(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, size_t n, size_t count, uint32_t* out) {
-    if (!ctx || !g1 || !g2 || !out || n == 0 || count == 0) return SIPP_E_BADARG;
-    const size_t total = n * count;
-    if (total > ((size_t)1 << 24)) return sipp_fail(ctx, SIPP_E_BADARG, "inner_products: too many pairs");
+// `count` products over consecutive groups of pairs: group k = pairs [off[k], off[k + 1])
+int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, const uint32_t* off, size_t count, uint32_t* out) {
+    if (!ctx || !g1 || !g2 || !off || !out || count == 0) return SIPP_E_BADARG;
+    const size_t total = off[count];
+    for (size_t k = 0; k < count; k++)
+        if (off[k + 1] <= off[k]) return sipp_fail(ctx, SIPP_E_BADARG, "inner_products: empty group");
+    if (off[0] != 0 || total > ((size_t)1 << 24)) return sipp_fail(ctx, SIPP_E_BADARG, "inner_products: bad group offsets");
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     ArenaMark mk = arena_mark(ctx);
     uint32_t* d_g1 = arena_alloc_t<uint32_t>(ctx, total * 16);
     uint32_t* d_g2 = arena_alloc_t<uint32_t>(ctx, total * 32);
     T6* d_f = arena_alloc_t<T6>(ctx, total);
     uint32_t* d_out = arena_alloc_t<uint32_t>(ctx, count * 96);
+    uint32_t* d_off = arena_alloc_t<uint32_t>(ctx, count + 1);
     int rc = SIPP_OK;
-    if (!d_g1 || !d_g2 || !d_f || !d_out) rc = SIPP_E_NOMEM;
+    if (!d_g1 || !d_g2 || !d_f || !d_out || !d_off) rc = SIPP_E_NOMEM;
     if (rc == SIPP_OK) {
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_g1, g1, total * 64, hipMemcpyHostToDevice, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_g2, g2, total * 128, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_off, off, (count + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         {
             ProfScope ps(ctx, "pairing_miller");
             hipLaunchKernelGGL(miller_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, d_g1, d_g2, (uint32_t)total, d_f);
@@ -518,8 +527,8 @@ extern "C" int sipp_inner_products(sipp_ctx* ctx, const uint32_t* g1, const uint
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         {
             ProfScope ps(ctx, "pairing_product_final");
-            hipLaunchKernelGGL(product_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_f, (uint32_t)n);
-            hipLaunchKernelGGL(final_exp_kernel, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_f, (uint32_t)n, d_out);
+            hipLaunchKernelGGL(product_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, d_f, d_off);
+            hipLaunchKernelGGL(final_exp_kernel, dim3((unsigned)count), dim3(64), 0, ctx->stream, d_f, d_off, d_out);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, count * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -527,6 +536,13 @@ extern "C" int sipp_inner_products(sipp_ctx* ctx, const uint32_t* g1, const uint
     }
     arena_release(ctx, mk);
     return rc;
+}
+
+extern "C" int sipp_inner_products(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, size_t n, size_t count, uint32_t* out) {
+    if (!ctx || n == 0 || count == 0 || n * count > ((size_t)1 << 24)) return SIPP_E_BADARG;
+    std::vector<uint32_t> off(count + 1);
+    for (size_t k = 0; k <= count; k++) off[k] = (uint32_t)(k * n);
+    return sipp_inner_products_groups(ctx, g1, g2, off.data(), count, out);
 }
 
 extern "C" int sipp_inner_product(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, size_t n, uint32_t* out) {
