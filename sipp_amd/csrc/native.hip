@@ -52,18 +52,20 @@ uint64_t sub_in_place(U256& a, const U256& b) {
     }
     return (uint64_t)bw;
 }
-// (a * b) mod r by shift-and-add over the bits of b (a < r): 256 doublings, no wide product
-U256 mulmod(const U256& a, const U256& b) {
+const U256 FQ = {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};  // the base field
+
+// (a * b) mod m by shift-and-add over the bits of b (a < m, m = r or p): 256 doublings, no wide product
+U256 mulmod(const U256& a, const U256& b, const U256& m) {
     U256 acc = {{0, 0, 0, 0}};
     for (int i = 255; i >= 0; i--) {
-        // acc = 2 acc mod r   (acc < r < 2^254, so 2 acc < 2^255 never overflows)
+        // acc = 2 acc mod m   (acc < m < 2^254, so 2 acc < 2^255 never overflows)
         uint64_t c = 0;
         for (int k = 0; k < 4; k++) {
             const uint64_t nc = acc.w[k] >> 63;
             acc.w[k] = (acc.w[k] << 1) | c;
             c = nc;
         }
-        if (cmp(acc, FR) >= 0) sub_in_place(acc, FR);
+        if (cmp(acc, m) >= 0) sub_in_place(acc, m);
         if ((b.w[i >> 6] >> (i & 63)) & 1) {
             unsigned __int128 cy = 0;
             for (int k = 0; k < 4; k++) {
@@ -71,7 +73,7 @@ U256 mulmod(const U256& a, const U256& b) {
                 acc.w[k] = (uint64_t)cy;
                 cy >>= 64;
             }
-            if (cmp(acc, FR) >= 0) sub_in_place(acc, FR);
+            if (cmp(acc, m) >= 0) sub_in_place(acc, m);
         }
     }
     return acc;
@@ -82,8 +84,8 @@ U256 inv_mod_r(const U256& x) {  // x^(r - 2)
     sub_in_place(e, two);
     U256 r = {{1, 0, 0, 0}};
     for (int i = 253; i >= 0; i--) {
-        r = mulmod(r, r);
-        if ((e.w[i >> 6] >> (i & 63)) & 1) r = mulmod(r, x);
+        r = mulmod(r, r, FR);
+        if ((e.w[i >> 6] >> (i & 63)) & 1) r = mulmod(r, x, FR);
     }
     return r;
 }
@@ -92,6 +94,55 @@ void to_u32(const U256& a, uint32_t out[8]) {
         out[2 * i] = (uint32_t)a.w[i];
         out[2 * i + 1] = (uint32_t)(a.w[i] >> 32);
     }
+}
+
+U256 from_u32(const uint32_t* w) {
+    U256 a;
+    for (int i = 0; i < 4; i++) a.w[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    return a;
+}
+U256 addmod(const U256& a, const U256& b, const U256& m) {
+    U256 s;
+    unsigned __int128 cy = 0;
+    for (int k = 0; k < 4; k++) {
+        cy += (unsigned __int128)a.w[k] + b.w[k];
+        s.w[k] = (uint64_t)cy;
+        cy >>= 64;
+    }
+    if (cmp(s, m) >= 0) sub_in_place(s, m);
+    return s;
+}
+U256 submod(const U256& a, const U256& b, const U256& m) {
+    U256 d = a;
+    if (sub_in_place(d, b)) {  // borrowed: add m back
+        unsigned __int128 cy = 0;
+        for (int k = 0; k < 4; k++) {
+            cy += (unsigned __int128)d.w[k] + m.w[k];
+            d.w[k] = (uint64_t)cy;
+            cy >>= 64;
+        }
+    }
+    return d;
+}
+// product in the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82), 12 x 8 u32 limbs: the few products the verifier needs
+// to chain the per-round powers (everything heavier runs on the device)
+void f12_mul_host(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    U256 x[12], y[12], d[23];
+    for (int i = 0; i < 12; i++) {
+        x[i] = from_u32(a + 8 * i);
+        y[i] = from_u32(b + 8 * i);
+        while (cmp(x[i], FQ) >= 0) sub_in_place(x[i], FQ);  // a tampered message may carry non-canonical limbs
+        while (cmp(y[i], FQ) >= 0) sub_in_place(y[i], FQ);
+    }
+    for (auto& v : d) v = U256{{0, 0, 0, 0}};
+    for (int i = 0; i < 12; i++)
+        for (int j = 0; j < 12; j++) d[i + j] = addmod(d[i + j], mulmod(x[i], y[j], FQ), FQ);
+    const U256 c18 = {{18, 0, 0, 0}}, c82 = {{82, 0, 0, 0}};
+    for (int m = 22; m >= 12; m--) {
+        d[m - 6] = addmod(d[m - 6], mulmod(d[m], c18, FQ), FQ);
+        d[m - 12] = submod(d[m - 12], mulmod(d[m], c82, FQ), FQ);
+    }
+    for (int i = 0; i < 12; i++) to_u32(d[i], out + 8 * i);
 }
 
 struct Transcript {
@@ -257,38 +308,55 @@ int sipp_verify_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in
     memcpy(orig_Z, proof + (--left) * 96, 96 * 4);
     memcpy(Z, orig_Z, 96 * 4);
     t.append(Z, 96);
-    size_t o1 = 0, o2 = 0, o12 = 0;
-    while (n > 1) {
-        const uint32_t* zl = proof + (--left) * 96;
-        t.append(zl, 96);
-        const uint32_t* zr = proof + (--left) * 96;
-        t.append(zr, 96);
+    // every challenge follows from the messages alone: replay the transcript first ...
+    size_t rounds = 0;
+    while (((size_t)1 << rounds) < n) rounds++;
+    std::vector<uint32_t> xs(rounds * 8), ixs(rounds * 8);
+    std::vector<const uint32_t*> zls(rounds), zrs(rounds);
+    for (size_t r = 0; r < rounds; r++) {
+        zls[r] = proof + (--left) * 96;
+        t.append(zls[r], 96);
+        zrs[r] = proof + (--left) * 96;
+        t.append(zrs[r], 96);
         const U256 x = t.get_challenge();
-        const U256 ix = inv_mod_r(x);
-        uint32_t xw[8], ixw[8];
-        to_u32(x, xw);
-        to_u32(ix, ixw);
+        to_u32(x, &xs[r * 8]);
+        to_u32(inv_mod_r(x), &ixs[r * 8]);
+    }
+    // ... then all 2 log2 n powers Z_L^x, Z_R^(1/x) in ONE pass through the Fq12 chain kernel (offset 1), and the running
+    // product Z <- Z Z_L^x Z_R^(1/x) on the host.  The obligations are {x: Z_L, offset: Z, exp_val: x} and
+    // {x: Z_R, offset: Z Z_L^x, exp_val: 1/x} (verifier_circuit.rs:111-124).
+    std::vector<uint32_t> f12rec(2 * rounds * SIPP_FQ12_IO_WORDS, 0);
+    if (rounds) {
+        std::vector<uint32_t> pw(2 * rounds * SIPP_FQ12_IO_WORDS, 0);
+        for (size_t r = 0; r < rounds; r++)
+            for (int h = 0; h < 2; h++) {
+                uint32_t* p = &pw[(2 * r + h) * SIPP_FQ12_IO_WORDS];
+                memcpy(p, h ? zrs[r] : zls[r], 96 * 4);
+                p[96] = 1;  // offset = 1
+                memcpy(p + 192, h ? &ixs[r * 8] : &xs[r * 8], 32);
+            }
+        SIPP_TRY(sipp_exp_outputs(ctx, SIPP_FQ12_EXP, pw.data(), 2 * rounds));
+        for (size_t r = 0; r < rounds; r++)
+            for (int h = 0; h < 2; h++) {
+                uint32_t* rec = &f12rec[(2 * r + h) * SIPP_FQ12_IO_WORDS];
+                const uint32_t* p = &pw[(2 * r + h) * SIPP_FQ12_IO_WORDS];
+                memcpy(rec, p, 96 * 4);
+                memcpy(rec + 96, Z, 96 * 4);
+                memcpy(rec + 192, p + 192, 32);
+                f12_mul_host(Z, p + 200, rec + 200);
+                memcpy(Z, rec + 200, 96 * 4);
+            }
+        if (fq12_ios) memcpy(fq12_ios, f12rec.data(), f12rec.size() * 4);
+    }
+    size_t o1 = 0, o2 = 0;
+    for (size_t r = 0; r < rounds; r++) {
         std::vector<uint32_t> rec1, rec2;
-        SIPP_TRY(fold_round(ctx, A, B, n, xw, ixw, rec1, rec2));
+        SIPP_TRY(fold_round(ctx, A, B, n, &xs[r * 8], &ixs[r * 8], rec1, rec2));
         if (g1_ios) memcpy(g1_ios + o1, rec1.data(), rec1.size() * 4);
         if (g2_ios) memcpy(g2_ios + o2, rec2.data(), rec2.size() * 4);
         o1 += rec1.size();
         o2 += rec2.size();
         take_outputs(rec1, rec2, n / 2, A, B);
-        // Z <- Z Z_L^x Z_R^(1/x): two Fq12 obligations {x: Z_L, offset: Z, exp_val: x}, {x: Z_R, offset: Z Z_L^x, exp_val: 1/x}
-        // (verifier_circuit.rs:111-124)
-        uint32_t rec[2][SIPP_FQ12_IO_WORDS];
-        memcpy(rec[0], zl, 96 * 4);
-        memcpy(rec[0] + 96, Z, 96 * 4);
-        memcpy(rec[0] + 192, xw, 32);
-        SIPP_TRY(sipp_exp_outputs(ctx, SIPP_FQ12_EXP, rec[0], 1));
-        memcpy(rec[1], zr, 96 * 4);
-        memcpy(rec[1] + 96, rec[0] + 200, 96 * 4);
-        memcpy(rec[1] + 192, ixw, 32);
-        SIPP_TRY(sipp_exp_outputs(ctx, SIPP_FQ12_EXP, rec[1], 1));
-        memcpy(Z, rec[1] + 200, 96 * 4);
-        if (fq12_ios) memcpy(fq12_ios + o12, rec, sizeof rec);
-        o12 += 2 * SIPP_FQ12_IO_WORDS;
         n /= 2;
     }
     if (statement) {  // A | B | Z | final_A | final_B | final_Z (statements.rs:24-39)
