@@ -115,3 +115,18 @@ def test_whole_pipeline_from_points_to_three_proofs():
             assert (pis[: ios[kind].shape[0]] == ios[kind]).all()
     finally:
         inst.close()
+
+
+@pytest.mark.parametrize("n", [300, 513])
+def test_large_products_by_bilinearity(ctx, n):
+    """more pairs than one workgroup has lanes (strided partial products + tree): prod_i e([a_i] G1, [b_i] G2) must equal
+    e([sum a_i b_i] G1, G2) -- a size-independent property, both sides computed on the device"""
+    rng = np.random.default_rng(n)
+    a = [int.from_bytes(rng.bytes(16), "little") + 1 for _ in range(n)]
+    b = [int.from_bytes(rng.bytes(16), "little") + 1 for _ in range(n)]
+    g1, g2 = limbs([bn.g1_mul(bn.G1, x) for x in a], [bn.g2_mul(bn.G2, y) for y in b])
+    lhs = ctx.inner_products(g1, g2)[0]
+    s = sum(x * y for x, y in zip(a, b)) % bn.R
+    h1, h2 = limbs([bn.g1_mul(bn.G1, s)], [bn.G2])
+    rhs = ctx.inner_products(h1, h2)[0]
+    assert (lhs == rhs).all()
