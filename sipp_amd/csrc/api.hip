@@ -87,6 +87,7 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

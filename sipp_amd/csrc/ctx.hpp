@@ -75,6 +75,9 @@ struct sipp_ctx {
     sipp_gate* gate_wait = nullptr;     // wait for it before the first launch
     sipp_gate* gate_release = nullptr;  // released after the trace fill (and on every exit path)
 
+    // second stream for the G1 half of sipp_fold_outputs (created on first use)
+    hipStream_t aux_stream = nullptr;
+
     // sipp_exp_outputs: sipp_trace_fill stops after the accumulator chains and writes the outputs into the records
     bool outputs_only = false;
 
@@ -201,3 +204,6 @@ const sipp_air_t* sipp_air_get(int kind, uint32_t log_n);
 const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a);
 int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
                     uint64_t* d_trace, int* d_err);
+size_t sipp_curve_rows_bytes(int kind, uint32_t log_n);
+// outputs of n1 G1 and n2 G2 obligations, the two accumulator chains on two streams (native.hip's fold of a SIPP round)
+int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2);

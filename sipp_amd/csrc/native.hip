@@ -194,9 +194,7 @@ int fold_round(sipp_ctx* ctx, const std::vector<uint32_t>& A, const std::vector<
         memcpy(s + 32, &B[i * G2W], G2W * 4);
         memcpy(s + 64, ix, 32);
     }
-    SIPP_TRY(sipp_exp_outputs(ctx, SIPP_G1_EXP, rec1.data(), h));
-    SIPP_TRY(sipp_exp_outputs(ctx, SIPP_G2_EXP, rec2.data(), h));
-    return SIPP_OK;
+    return sipp_fold_outputs(ctx, rec1.data(), h, rec2.data(), h);
 }
 
 void take_outputs(const std::vector<uint32_t>& rec1, const std::vector<uint32_t>& rec2, size_t h, std::vector<uint32_t>& A,

@@ -618,6 +618,63 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
     return rc;
 }
 
+}  // extern "C"
+
+// A' = A1 + [x] A2 and B' = B1 + [1/x] B2 of one SIPP round: both are latency-bound chains of 255 doublings on a few
+// workgroups, so the G1 chain runs on a second stream beside the G2 chain.
+int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2) {
+    if (!ctx || !g1_ios || !g2_ios) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->aux_stream) SIPP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    Shape s[2];
+    SIPP_TRY(shape_of(SIPP_G1_EXP, n1, &s[0]));
+    SIPP_TRY(shape_of(SIPP_G2_EXP, n2, &s[1]));
+    uint32_t* ios[2] = {g1_ios, g2_ios};
+    const size_t num[2] = {n1, n2}, ppi[2] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS}, outw[2] = {16, 32};
+    ArenaMark m = arena_mark(ctx);
+    uint32_t* d_ios[2] = {nullptr, nullptr};
+    int* d_err = arena_alloc_t<int>(ctx, 2);
+    if (!d_err) return SIPP_E_NOMEM;
+    int rc = SIPP_OK;
+    for (int k = 0; k < 2 && rc == SIPP_OK; k++) rc = upload_ios(ctx, k, ios[k], num[k], s[k], &d_ios[k], nullptr);
+    hipStream_t main_stream = ctx->stream;
+    uint32_t* h = reinterpret_cast<uint32_t*>(ctx->h_pinned);
+    const size_t h_off[2] = {0, ctx->h_pinned_words};  // u32 offsets: the two halves of the pinned buffer
+    // the error words land in pinned memory too: a device-to-host copy into pageable memory would block the host until the
+    // first chain is done, i.e. before the second one is even launched
+    volatile int* h_err = reinterpret_cast<volatile int*>(h + 2 * ctx->h_pinned_words - 2);
+    h_err[0] = h_err[1] = 0;
+    if (rc == SIPP_OK) {
+        SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, 2 * sizeof(int), main_stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(main_stream));
+        ctx->outputs_only = true;
+        for (int k = 0; k < 2 && rc == SIPP_OK; k++) {
+            ctx->stream = k == 0 ? ctx->aux_stream : main_stream;
+            rc = sipp_trace_fill(ctx, s[k].air, d_ios[k], s[k].num_io, s[k].log_n, nullptr, d_err + k);
+            // sipp_trace_fill has handed its row scratch back, but on another stream the kernels are still using it:
+            // take exactly that block again so that the next chain gets its own
+            if (rc == SIPP_OK && !arena_alloc(ctx, sipp_curve_rows_bytes(k, s[k].log_n))) rc = SIPP_E_NOMEM;
+            if (rc == SIPP_OK) {
+                (void)hipMemcpyAsync(h + h_off[k], d_ios[k], num[k] * ppi[k] * 4, hipMemcpyDeviceToHost, ctx->stream);
+                (void)hipMemcpyAsync(const_cast<int*>(h_err) + k, d_err + k, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+            }
+        }
+        ctx->outputs_only = false;
+        ctx->stream = main_stream;
+        const hipError_t e0 = hipStreamSynchronize(ctx->aux_stream), e1 = hipStreamSynchronize(main_stream);
+        if (rc == SIPP_OK && (e0 != hipSuccess || e1 != hipSuccess)) rc = sipp_fail(ctx, SIPP_E_HIP, "fold_outputs: stream synchronisation failed");
+    }
+    if (rc == SIPP_OK && (h_err[0] || h_err[1])) rc = sipp_fail(ctx, h_err[0] ? h_err[0] : h_err[1], "fold_outputs: obligation not provable");
+    if (rc == SIPP_OK)
+        for (int k = 0; k < 2; k++)
+            for (size_t io = 0; io < num[k]; io++)
+                memcpy(ios[k] + io * ppi[k] + (ppi[k] - outw[k]), h + h_off[k] + io * ppi[k] + (ppi[k] - outw[k]), outw[k] * 4);
+    arena_release(ctx, m);
+    return rc;
+}
+
+extern "C" {
+
 int sipp_g1_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     return prove_impl(ctx, SIPP_G1_EXP, ios, num_io, proof_out, proof_cap, proof_len);

@@ -933,6 +933,11 @@ static int64_t* prog_on_device(sipp_ctx* ctx, const sipp_air_t* a) {
 }
 const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a) { return prog_on_device(ctx, a); }
 
+// bytes of the Jacobian row scratch sipp_trace_fill takes from the arena FIRST for a curve AIR (kind 0 / 1) of 2^log_n rows
+size_t sipp_curve_rows_bytes(int kind, uint32_t log_n) {
+    return ((size_t)1 << log_n) * (kind == 0 ? sizeof(RowPts<1>) : sizeof(RowPts<2>));
+}
+
 // d_ios: [num_io][pi_per_io] u32 on the device (padded); d_trace: [W][n] zero-initialised by the caller is NOT
 // required: every main column is written here.  d_err: device int, 0 on entry.
 int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
