@@ -54,40 +54,73 @@ uint64_t sub_in_place(U256& a, const U256& b) {
 }
 const U256 FQ = {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};  // the base field
 
-// (a * b) mod m by shift-and-add over the bits of b (a < m, m = r or p): 256 doublings, no wide product
-U256 mulmod(const U256& a, const U256& b, const U256& m) {
-    U256 acc = {{0, 0, 0, 0}};
-    for (int i = 255; i >= 0; i--) {
-        // acc = 2 acc mod m   (acc < m < 2^254, so 2 acc < 2^255 never overflows)
-        uint64_t c = 0;
-        for (int k = 0; k < 4; k++) {
-            const uint64_t nc = acc.w[k] >> 63;
-            acc.w[k] = (acc.w[k] << 1) | c;
-            c = nc;
-        }
-        if (cmp(acc, m) >= 0) sub_in_place(acc, m);
-        if ((b.w[i >> 6] >> (i & 63)) & 1) {
-            unsigned __int128 cy = 0;
+// ---- Montgomery arithmetic mod an odd 254-bit modulus (r or p), four 64-bit limbs, CIOS ----
+struct Mont {
+    U256 m;
+    uint64_t ninv;  // -m^-1 mod 2^64
+    U256 r2;        // 2^512 mod m
+    explicit Mont(const U256& mod) : m(mod) {
+        uint64_t x = mod.w[0];  // Newton: x <- x (2 - m x), correct to 3 bits at the start for odd m
+        for (int i = 0; i < 6; i++) x *= 2 - mod.w[0] * x;
+        ninv = (uint64_t)0 - x;
+        // 2^512 mod m by 512 modular doublings of 1
+        U256 t = {{1, 0, 0, 0}};
+        for (int i = 0; i < 512; i++) {
+            uint64_t c = 0;
             for (int k = 0; k < 4; k++) {
-                cy += (unsigned __int128)acc.w[k] + a.w[k];
-                acc.w[k] = (uint64_t)cy;
-                cy >>= 64;
+                const uint64_t nc = t.w[k] >> 63;
+                t.w[k] = (t.w[k] << 1) | c;
+                c = nc;
             }
-            if (cmp(acc, m) >= 0) sub_in_place(acc, m);
+            if (cmp(t, m) >= 0) sub_in_place(t, m);
         }
+        r2 = t;
     }
-    return acc;
-}
+    // a b 2^-256 mod m (a, b < m)
+    U256 mul(const U256& a, const U256& b) const {
+        uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            unsigned __int128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (unsigned __int128)a.w[j] * b.w[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[4] = (uint64_t)c;
+            t[5] = (uint64_t)(c >> 64);
+            const uint64_t q = t[0] * ninv;
+            c = (unsigned __int128)q * m.w[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; j++) {
+                c += (unsigned __int128)q * m.w[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[3] = (uint64_t)c;
+            t[4] = t[5] + (uint64_t)(c >> 64);
+        }
+        U256 r = {{t[0], t[1], t[2], t[3]}};
+        if (t[4] || cmp(r, m) >= 0) sub_in_place(r, m);
+        return r;
+    }
+    U256 to(const U256& a) const { return mul(a, r2); }
+    U256 from(const U256& a) const { return mul(a, U256{{1, 0, 0, 0}}); }
+};
+const Mont MONT_R(FR), MONT_P(FQ);
+
 U256 inv_mod_r(const U256& x) {  // x^(r - 2)
     U256 e = FR;
     const U256 two = {{2, 0, 0, 0}};
     sub_in_place(e, two);
-    U256 r = {{1, 0, 0, 0}};
+    const U256 xm = MONT_R.to(x);
+    U256 r = MONT_R.to(U256{{1, 0, 0, 0}});
     for (int i = 253; i >= 0; i--) {
-        r = mulmod(r, r, FR);
-        if ((e.w[i >> 6] >> (i & 63)) & 1) r = mulmod(r, x, FR);
+        r = MONT_R.mul(r, r);
+        if ((e.w[i >> 6] >> (i & 63)) & 1) r = MONT_R.mul(r, xm);
     }
-    return r;
+    return MONT_R.from(r);
 }
 void to_u32(const U256& a, uint32_t out[8]) {
     for (int i = 0; i < 4; i++) {
@@ -133,16 +166,18 @@ void f12_mul_host(const uint32_t* a, const uint32_t* b, uint32_t* out) {
         y[i] = from_u32(b + 8 * i);
         while (cmp(x[i], FQ) >= 0) sub_in_place(x[i], FQ);  // a tampered message may carry non-canonical limbs
         while (cmp(y[i], FQ) >= 0) sub_in_place(y[i], FQ);
+        x[i] = MONT_P.to(x[i]);  // x 2^256, y 2^256: the Montgomery products below then give (x y) 2^256 ...
+        y[i] = MONT_P.to(y[i]);
     }
     for (auto& v : d) v = U256{{0, 0, 0, 0}};
     for (int i = 0; i < 12; i++)
-        for (int j = 0; j < 12; j++) d[i + j] = addmod(d[i + j], mulmod(x[i], y[j], FQ), FQ);
-    const U256 c18 = {{18, 0, 0, 0}}, c82 = {{82, 0, 0, 0}};
+        for (int j = 0; j < 12; j++) d[i + j] = addmod(d[i + j], MONT_P.mul(x[i], y[j]), FQ);
+    const U256 c18 = MONT_P.to(U256{{18, 0, 0, 0}}), c82 = MONT_P.to(U256{{82, 0, 0, 0}});
     for (int m = 22; m >= 12; m--) {
-        d[m - 6] = addmod(d[m - 6], mulmod(d[m], c18, FQ), FQ);
-        d[m - 12] = submod(d[m - 12], mulmod(d[m], c82, FQ), FQ);
+        d[m - 6] = addmod(d[m - 6], MONT_P.mul(d[m], c18), FQ);
+        d[m - 12] = submod(d[m - 12], MONT_P.mul(d[m], c82), FQ);
     }
-    for (int i = 0; i < 12; i++) to_u32(d[i], out + 8 * i);
+    for (int i = 0; i < 12; i++) to_u32(MONT_P.from(d[i]), out + 8 * i);  // ... and this takes the 2^256 off again
 }
 
 struct Transcript {
