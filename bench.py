@@ -254,7 +254,16 @@ def main():
             t = time.perf_counter()
             okn, _, nios = nctx.verify_native(An, Bn, npf)
             t_nv = time.perf_counter() - t
-            out["native_chain"] = {"prove_native_ms": 1e3 * t_np, "verify_native_ms": 1e3 * t_nv, "pairings": 3 * args.n - 2,
+            cpu_pair = None
+            if not args.no_cpu_baseline:
+                # the CPU restatement of the pairing (oracle/py, big-int Python: a port, not the reference's Rust) on 3 pairs
+                from oracle.py import bn254 as obn
+                t = time.perf_counter()
+                for k in (3, 5, 7):
+                    obn.pairing(obn.g1_mul(obn.G1, k), obn.g2_mul(obn.G2, k + 1))
+                cpu_pair = {"pairings_per_s": 3 / (time.perf_counter() - t), "cores": 1, "kind": "port",
+                            "sample": "oracle/py/bn254.py pairing (pure Python big integers) on 3 pairs"}
+            out["native_chain"] = {"cpu_baseline": cpu_pair, "prove_native_ms": 1e3 * t_np, "verify_native_ms": 1e3 * t_nv, "pairings": 3 * args.n - 2,
                                    "pairings_per_s": (3 * args.n - 2) / t_np, "accepted": bool(okn),
                                    "obligations_equal_bench_input": bool(all((a == b).all() for a, b in zip(nios, ios)))}
         except Exception as e:                  # noqa: BLE001
