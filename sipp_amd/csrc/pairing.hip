@@ -3,8 +3,8 @@
 // reference takes `pairing` from plonky2-bn254-pairing @ fe5c3a8, not vendored).  SURVEY.md section 8(f) rank 3: first step
 // of the widening beyond the STARK sub-provers.
 //
-// Mapping: one WAVE per (A_i, B_i) runs the Miller loop (homogeneous projective twist arithmetic on lane 0, no inversion; the
-// 36 / 18 Fq2 products of every Fq12 product spread over the lanes), values in Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six
+// Mapping: one WAVE per (A_i, B_i) runs the Miller loop (homogeneous projective twist arithmetic, no inversion; the 36 / 18 Fq2
+// products of every Fq12 product and the products of one dependency level of a point step spread over the lanes), values in Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six
 // Fq2 coefficients in Montgomery form (fq.cuh), resident in LDS.  One workgroup then multiplies
 // the n Miller values (strided partial products + a tree) and one wave applies the final exponentiation: easy part
 // (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers by u); the result is
