@@ -130,3 +130,31 @@ def test_large_products_by_bilinearity(ctx, n):
     h1, h2 = limbs([bn.g1_mul(bn.G1, s)], [bn.G2])
     rhs = ctx.inner_products(h1, h2)[0]
     assert (lhs == rhs).all()
+
+
+def test_native_chain_edge_sizes_and_errors(ctx):
+    """n = 1 (no round: the proof is Z alone) and n = 2 against the CPU restatement of the chain; sizes that are not a power
+    of two are refused with SIPP_E_BADARG"""
+    import sipp_amd
+    from oracle.py import sipp_native as sn
+    rng = np.random.default_rng(21)
+    for n in (1, 2):
+        A, B = points(rng, n)
+        g1, g2 = limbs(A, B)
+        proof = ctx.prove_native(g1, g2)
+        want = sn.sipp_prove_native(A, B)
+        assert proof.shape[0] == len(want) == 2 * (n.bit_length() - 1) + 1
+        for got, w in zip(proof, want):
+            assert (got == np.array(bn.f12_to_u32(w), dtype=np.uint32)).all()
+        ok, st, ios = ctx.verify_native(g1, g2, proof)
+        ok2, st2, obl = sn.sipp_verify_native(A, B, want)
+        assert ok and ok2
+        assert (st == np.array(sn.statement_to_u32(st2), dtype=np.uint32)).all()
+        if n > 1:
+            for got, w in zip(ios, sn.io_records(obl)):
+                assert (got == w).all()
+    A, B = points(rng, 3)
+    g1, g2 = limbs(A, B)
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.prove_native(g1, g2)
+    assert e.value.code == -1
