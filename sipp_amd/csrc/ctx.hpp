@@ -134,6 +134,15 @@ static inline void* arena_alloc(sipp_ctx* ctx, size_t bytes) {
     if (ctx->arena_off > ctx->arena_peak) ctx->arena_peak = ctx->arena_off;
     return ctx->arena + off;
 }
+// releases everything allocated after its construction on EVERY exit path (error returns included)
+struct ArenaScope {
+    sipp_ctx* ctx;
+    ArenaMark mark;
+    explicit ArenaScope(sipp_ctx* c) : ctx(c), mark(arena_mark(c)) {}
+    ~ArenaScope() { arena_release(ctx, mark); }
+    ArenaScope(const ArenaScope&) = delete;
+    ArenaScope& operator=(const ArenaScope&) = delete;
+};
 template <typename T>
 static inline T* arena_alloc_t(sipp_ctx* ctx, size_t count) {
     return reinterpret_cast<T*>(arena_alloc(ctx, count * sizeof(T)));

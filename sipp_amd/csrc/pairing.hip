@@ -508,7 +508,7 @@ int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t
         if (off[k + 1] <= off[k]) return sipp_fail(ctx, SIPP_E_BADARG, "inner_products: empty group");
     if (off[0] != 0 || total > ((size_t)1 << 24)) return sipp_fail(ctx, SIPP_E_BADARG, "inner_products: bad group offsets");
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    ArenaMark mk = arena_mark(ctx);
+    ArenaScope scope(ctx);
     uint32_t* d_g1 = arena_alloc_t<uint32_t>(ctx, total * 16);
     uint32_t* d_g2 = arena_alloc_t<uint32_t>(ctx, total * 32);
     T6* d_f = arena_alloc_t<T6>(ctx, total);
@@ -534,7 +534,6 @@ int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, count * 96 * 4, hipMemcpyDeviceToHost, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    arena_release(ctx, mk);
     return rc;
 }
 

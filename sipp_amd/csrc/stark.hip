@@ -590,7 +590,7 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
     const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : kind == SIPP_G2_EXP ? 32 : 96;
-    ArenaMark m = arena_mark(ctx);
+    ArenaScope scope(ctx);
     uint32_t* d_ios = nullptr;
     int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
     int* d_err = arena_alloc_t<int>(ctx, 1);
@@ -614,7 +614,6 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
             for (size_t io = 0; io < num_io; io++)
                 memcpy(ios + io * ppi + (ppi - out_words), h + io * ppi + (ppi - out_words), out_words * 4);
     }
-    arena_release(ctx, m);
     return rc;
 }
 
@@ -631,7 +630,7 @@ int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_i
     SIPP_TRY(shape_of(SIPP_G2_EXP, n2, &s[1]));
     uint32_t* ios[2] = {g1_ios, g2_ios};
     const size_t num[2] = {n1, n2}, ppi[2] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS}, outw[2] = {16, 32};
-    ArenaMark m = arena_mark(ctx);
+    ArenaScope scope(ctx);
     uint32_t* d_ios[2] = {nullptr, nullptr};
     int* d_err = arena_alloc_t<int>(ctx, 2);
     if (!d_err) return SIPP_E_NOMEM;
@@ -669,7 +668,6 @@ int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_i
         for (int k = 0; k < 2; k++)
             for (size_t io = 0; io < num[k]; io++)
                 memcpy(ios[k] + io * ppi[k] + (ppi[k] - outw[k]), h + h_off[k] + io * ppi[k] + (ppi[k] - outw[k]), outw[k] * 4);
-    arena_release(ctx, m);
     return rc;
 }
 
