@@ -263,100 +263,49 @@ struct PointLds {
 struct POp {
     uint8_t out, a, b;              // v[out] = v[a] * v[b];  b == 0xFE: v[a] * yp, b == 0xFF: v[a] * xpn (Fq scalars)
 };
-template <int M>
-__device__ __forceinline__ void run_level(PointLds& P, const POp (&ops)[M]) {
-    const uint32_t t = threadIdx.x;
-    if (t < M) {
-        // the table is indexed by the lane: keep it out of a private array
-        uint8_t o = 0, a = 0, b = 0;
-#pragma unroll
-        for (int k = 0; k < M; k++)
-            if (t == (uint32_t)k) {
-                o = ops[k].out;
-                a = ops[k].a;
-                b = ops[k].b;
-            }
-        if (b >= 0xFE) {
-            Fq2 r;
-            f2_scale(r, P.v[a], b == 0xFE ? P.yp : P.xpn);
-            P.v[o] = r;
-        } else {
-            f2_mul(P.v[o], P.v[a], P.v[b]);
-        }
-    }
-    __syncthreads();
-}
-// tangent step: line into vL0 / vL1 / vL3, T <- 2 T
-__device__ __forceinline__ void proj_double(PointLds& P) {
-    const uint32_t t = threadIdx.x;
-    constexpr POp L1[2] = {{vT0, vX, vX}, {vT1, vY, vZ}};
-    run_level(P, L1);
-    if (t == 0) {
-        P.v[vN] = fq::add(f2_dbl(P.v[vT0]), P.v[vT0]);  // N = 3 X^2
-        P.v[vD] = f2_dbl(P.v[vT1]);                     // D = 2 Y Z
-    }
-    __syncthreads();
-    constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNZ, vN, vZ}, {vNX, vN, vX}, {vDZ, vD, vZ}, {vDY, vD, vY}};
-    run_level(P, L2);
-    constexpr POp L3[5] = {{vD3, vD2, vD}, {vXD2, vX, vD2}, {vN2Z, vN2, vZ}, {vL0, vDZ, 0xFE}, {vL1, vNZ, 0xFF}};
-    run_level(P, L3);
-    if (t == 0) {
-        P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
-        P.v[vW] = fq::sub(P.v[vN2Z], f2_dbl(P.v[vXD2]));
-        P.v[vU] = fq::sub(P.v[vXD2], P.v[vW]);
-    }
-    __syncthreads();
-    constexpr POp L4[4] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vY, vD3}, {vT3, vD3, vZ}};
-    run_level(P, L4);
-    if (t == 0) {
-        P.v[vX] = P.v[vT0];
-        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
-        P.v[vZ] = P.v[vT3];
-    }
-    __syncthreads();
-}
-// chord step through the affine point (vXQ, vYQ): line into vL0 / vL1 / vL3, T <- T + Q unless it is the last line
-__device__ __forceinline__ void proj_add(PointLds& P, bool advance) {
-    const uint32_t t = threadIdx.x;
-    constexpr POp L1[2] = {{vT0, vYQ, vZ}, {vT1, vXQ, vZ}};
-    run_level(P, L1);
-    if (t == 0) {
-        P.v[vN] = fq::sub(P.v[vT0], P.v[vY]);  // N = y_Q Z - Y
-        P.v[vD] = fq::sub(P.v[vT1], P.v[vX]);  // D = x_Q Z - X
-    }
-    __syncthreads();
-    constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNX, vN, vXQ}, {vDY, vD, vYQ}, {vL0, vD, 0xFE}, {vL1, vN, 0xFF}};
-    run_level(P, L2);
-    if (t == 0) P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
-    __syncthreads();
-    if (!advance) return;
-    constexpr POp L3[4] = {{vD3, vD2, vD}, {vE, vD2, vZ}, {vN2Z, vN2, vZ}, {vXD2, vX, vD2}};
-    run_level(P, L3);
-    constexpr POp L4[2] = {{vXQE, vXQ, vE}, {vZ3, vD3, vZ}};
-    run_level(P, L4);
-    if (t == 0) {
-        P.v[vW] = fq::sub(fq::sub(P.v[vN2Z], P.v[vXD2]), P.v[vXQE]);
-        P.v[vU] = fq::sub(P.v[vXQE], P.v[vW]);
-    }
-    __syncthreads();
-    constexpr POp L5[3] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vYQ, vZ3}};
-    run_level(P, L5);
-    if (t == 0) {
-        P.v[vX] = P.v[vT0];
-        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
-        P.v[vZ] = P.v[vZ3];
-    }
-    __syncthreads();
-}
 struct LineLds {
     Fq2 prod[18];
     Fq2 dsum[9];
 };
-// f *= l[0] + l[1] w + l[2] w^3, the 18 products on 18 lanes
-__device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L, const PointLds& P) {
+struct MillerLds {
+    T6 f;
+    CoopScratch sc;
+    LineLds line;
+    PointLds pt;
+    Fq2 q[6];  // Q, pi(Q), -pi^2(Q): (x, y) each
+};
+constexpr uint32_t PL = 36;  // first lane of the point arithmetic (lanes 0..35 belong to the products of f)
+
+// the Fq2 products of lanes PL.. for one level of a point step
+template <int M>
+__device__ __forceinline__ void level_ops(PointLds& P, const POp (&ops)[M], const Fq2*& pa, const Fq2*& pb, Fq2*& po, int& scale) {
     const uint32_t t = threadIdx.x;
-    if (t < 18) f2_mul(L.prod[t], f.c[t / 3], P.v[vL0 + t % 3]);
+#pragma unroll
+    for (int k = 0; k < M; k++)
+        if (t == PL + (uint32_t)k) {
+            po = &P.v[ops[k].out];
+            pa = &P.v[ops[k].a];
+            if (ops[k].b >= 0xFE) scale = ops[k].b == 0xFE ? 1 : 2;
+            else pb = &P.v[ops[k].b];
+        }
+}
+// ONE call site of f2_mul for every lane that has a product in this phase (operands through per-lane pointers), so that
+// products of f and products of the point step issue together instead of one group after the other
+__device__ __forceinline__ void phase(const PointLds& P, const Fq2* pa, const Fq2* pb, Fq2* po, int scale) {
+    if (po) {
+        if (scale) {
+            Fq2 r;
+            f2_scale(r, *pa, scale == 1 ? P.yp : P.xpn);
+            *po = r;
+        } else {
+            f2_mul(*po, *pa, *pb);
+        }
+    }
     __syncthreads();
+}
+// sums of the 18 line products into the 9 anti-diagonals (lanes 0..8)
+__device__ __forceinline__ void line_sums(LineLds& L) {
+    const uint32_t t = threadIdx.x;
     if (t < 9) {
         Fq2 d = f2_zero();
         for (int i = 0; i < 6; i++) {
@@ -366,7 +315,9 @@ __device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L, const PointLds&
         }
         L.dsum[t] = d;
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void line_fold(T6& f, const LineLds& L) {
+    const uint32_t t = threadIdx.x;
     if (t < 6) {
         if (t < 3) {
             Fq2 x;
@@ -375,6 +326,170 @@ __device__ __forceinline__ void coop_mul_line(T6& f, LineLds& L, const PointLds&
         } else {
             f.c[t] = L.dsum[t];
         }
+    }
+}
+
+// tangent step, fused: f <- f^2 * l_{T,T}(P), T <- 2 T in FOUR product phases
+//   1: the 36 products of f^2 | X^2, Y Z          2: N^2, D^2, N Z, N X, D Z, D Y (f's anti-diagonals are summed and folded beside)
+//   3: D^3, X D^2, N^2 Z, l0, l1                  4: the 18 products f * line | D W, N U, Y D^3, D^3 Z
+__device__ __forceinline__ void step_double(MillerLds& S) {
+    const uint32_t t = threadIdx.x;
+    PointLds& P = S.pt;
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        if (t < 36) {
+            pa = &S.f.c[t / 6];
+            pb = &S.f.c[t % 6];
+            po = &S.sc.prod[t];
+        }
+        constexpr POp L1[2] = {{vT0, vX, vX}, {vT1, vY, vZ}};
+        level_ops(P, L1, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t < 11) {
+        Fq2 d = f2_zero();
+        for (int i = 0; i < 6; i++) {
+            const int j = (int)t - i;
+            if (j >= 0 && j < 6) d = fq::add(d, S.sc.prod[i * 6 + j]);
+        }
+        S.sc.dsum[t] = d;
+    } else if (t == PL) {
+        P.v[vN] = fq::add(f2_dbl(P.v[vT0]), P.v[vT0]);  // N = 3 X^2
+        P.v[vD] = f2_dbl(P.v[vT1]);                     // D = 2 Y Z
+    }
+    __syncthreads();
+    {
+        if (t < 6) {  // fold w^6 = xi into f (additions only)
+            if (t < 5) {
+                Fq2 x;
+                f2_mul_xi(x, S.sc.dsum[t + 6]);
+                S.f.c[t] = fq::add(S.sc.dsum[t], x);
+            } else {
+                S.f.c[5] = S.sc.dsum[5];
+            }
+        }
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNZ, vN, vZ}, {vNX, vN, vX}, {vDZ, vD, vZ}, {vDY, vD, vY}};
+        level_ops(P, L2, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L3[5] = {{vD3, vD2, vD}, {vXD2, vX, vD2}, {vN2Z, vN2, vZ}, {vL0, vDZ, 0xFE}, {vL1, vNZ, 0xFF}};
+        level_ops(P, L3, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t == PL) {
+        P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
+        P.v[vW] = fq::sub(P.v[vN2Z], f2_dbl(P.v[vXD2]));
+        P.v[vU] = fq::sub(P.v[vXD2], P.v[vW]);
+    }
+    __syncthreads();
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        if (t < 18) {
+            pa = &S.f.c[t / 3];
+            pb = &P.v[vL0 + t % 3];
+            po = &S.line.prod[t];
+        }
+        constexpr POp L4[4] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vY, vD3}, {vT3, vD3, vZ}};
+        level_ops(P, L4, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    line_sums(S.line);
+    if (t == PL) {
+        P.v[vX] = P.v[vT0];
+        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
+        P.v[vZ] = P.v[vT3];
+    }
+    __syncthreads();
+    line_fold(S.f, S.line);
+    __syncthreads();
+}
+// chord step through the affine point (vXQ, vYQ), fused: f <- f * l_{T,Q}(P), T <- T + Q (unless it is the last line)
+//   1: y_Q Z, x_Q Z        2: D^2, N^2, N x_Q, D y_Q, l0, l1        3: the 18 products f * line | D^3, D^2 Z, N^2 Z, X D^2
+//   4: x_Q E, D^3 Z        5: D W, N U, y_Q Z3
+__device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
+    const uint32_t t = threadIdx.x;
+    PointLds& P = S.pt;
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L1[2] = {{vT0, vYQ, vZ}, {vT1, vXQ, vZ}};
+        level_ops(P, L1, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t == PL) {
+        P.v[vN] = fq::sub(P.v[vT0], P.v[vY]);  // N = y_Q Z - Y
+        P.v[vD] = fq::sub(P.v[vT1], P.v[vX]);  // D = x_Q Z - X
+    }
+    __syncthreads();
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNX, vN, vXQ}, {vDY, vD, vYQ}, {vL0, vD, 0xFE}, {vL1, vN, 0xFF}};
+        level_ops(P, L2, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t == PL) P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
+    __syncthreads();
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        if (t < 18) {
+            pa = &S.f.c[t / 3];
+            pb = &P.v[vL0 + t % 3];
+            po = &S.line.prod[t];
+        }
+        if (advance) {
+            constexpr POp L3[4] = {{vD3, vD2, vD}, {vE, vD2, vZ}, {vN2Z, vN2, vZ}, {vXD2, vX, vD2}};
+            level_ops(P, L3, pa, pb, po, sc);
+        }
+        phase(P, pa, pb, po, sc);
+    }
+    line_sums(S.line);
+    __syncthreads();
+    line_fold(S.f, S.line);
+    if (!advance) {
+        __syncthreads();
+        return;
+    }
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L4[2] = {{vXQE, vXQ, vE}, {vZ3, vD3, vZ}};
+        level_ops(P, L4, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t == PL) {
+        P.v[vW] = fq::sub(fq::sub(P.v[vN2Z], P.v[vXD2]), P.v[vXQE]);
+        P.v[vU] = fq::sub(P.v[vXQE], P.v[vW]);
+    }
+    __syncthreads();
+    {
+        const Fq2 *pa = nullptr, *pb = nullptr;
+        Fq2* po = nullptr;
+        int sc = 0;
+        constexpr POp L5[3] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vYQ, vZ3}};
+        level_ops(P, L5, pa, pb, po, sc);
+        phase(P, pa, pb, po, sc);
+    }
+    if (t == PL) {
+        P.v[vX] = P.v[vT0];
+        P.v[vY] = fq::sub(P.v[vT1], P.v[vT2]);
+        P.v[vZ] = P.v[vZ3];
     }
     __syncthreads();
 }
@@ -385,13 +500,6 @@ __device__ __forceinline__ Fq load_fq(const uint32_t* w) {
     return fq::to_mont(r);
 }
 
-struct MillerLds {
-    T6 f;
-    CoopScratch sc;
-    LineLds line;
-    PointLds pt;
-    Fq2 q[6];  // Q, pi(Q), -pi^2(Q): (x, y) each
-};
 // one wave per pair; g1 [n][16] = (x, y), g2 [n][32] = (x.c0, x.c1, y.c0, y.c1) (reference src/transcript_native.rs:42-54 order);
 // all-zero coordinates stand for the point at infinity (Miller value 1)
 __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
@@ -431,23 +539,16 @@ __global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__
         }
         __syncthreads();
         for (int b = pairing_k::ATE_BITS - 2; b >= 0; b--) {
-            coop_mul(S.f, S.f, S.f, S.sc);
-            proj_double(S.pt);
-            coop_mul_line(S.f, S.line, S.pt);
+            step_double(S);
             const uint32_t bit = b >= 64 ? (pairing_k::ATE_HI >> (b - 64)) & 1u : (uint32_t)(pairing_k::ATE_LO >> b) & 1u;
-            if (bit) {
-                proj_add(S.pt, true);
-                coop_mul_line(S.f, S.line, S.pt);
-            }
+            if (bit) step_add(S, true);
         }
         if (t < 2) S.pt.v[vXQ + t] = S.q[2 + t];
         __syncthreads();
-        proj_add(S.pt, true);
-        coop_mul_line(S.f, S.line, S.pt);
+        step_add(S, true);
         if (t < 2) S.pt.v[vXQ + t] = S.q[4 + t];
         __syncthreads();
-        proj_add(S.pt, false);
-        coop_mul_line(S.f, S.line, S.pt);
+        step_add(S, false);
     }
     __syncthreads();
     if (t < 6) out[i].c[t] = S.f.c[t];
