@@ -70,6 +70,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # one process per GPU: the launcher provides the ranks (no GPU call has happened yet, nothing is re-executed here)
+        raise SystemExit("bench.py --gpus %d needs %d ranks but WORLD_SIZE is %d: launch it as `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`"
+                         % (args.gpus, args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SIPP HIP path has no CPU fallback")
     # SIPP_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- only to rehearse the N > 1 code path on a one-GPU box
@@ -78,11 +83,8 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from sipp_amd import dist_util
+    red_device = dist_util.init_process_group(world, local_rank, rehearsal)   # "cuda" over RCCL, "cpu" over gloo / alone
 
     import sipp_amd
     ios = load_ios(args.n)
@@ -109,25 +111,23 @@ def main():
             return res
         return inst.prove(ios)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def device_sync():
         torch.cuda.synchronize()
         for c in ctxs:
             c.sync()
 
-    for _ in range(args.warmup):
-        step()
-    for c in ctxs:
-        c.profile(True)
-        c.profile_reset()
-    barrier()
-    proof_ms[:] = [0.0, 0.0, 0.0]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proofs = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def barrier():
+        dist_util.barrier(device_sync)
+
+    def start_profiling():
+        for c in ctxs:
+            c.profile(True)
+            c.profile_reset()
+        proof_ms[:] = [0.0, 0.0, 0.0]
+
+    # W untimed warm-up steps, then exactly K steps between barrier + synchronize, max over ranks
+    elapsed, proofs = dist_util.timed_steps(step, args.steps, args.warmup, sync=device_sync, device=red_device,
+                                            before_timing=start_profiling)
     prof = {}
     for c in ctxs:
         for k, v in c.profile_report().items():
@@ -135,12 +135,9 @@ def main():
             e["calls"] += v["calls"]
             e["ms"] += v["ms"]
         c.profile(False)
-    from sipp_amd import dist_util
 
     def dist_util_max(x):
-        return dist_util.max_over_ranks(x, device="cpu" if rehearsal else "cuda")
-
-    elapsed = dist_util_max(elapsed)
+        return dist_util.max_over_ranks(x, device=red_device)
 
     # secondary figure, outside the timed region: `inflight` independent instances proved concurrently on this GPU
     # (3 streams each).  One instance leaves issue slots idle in its latency-bound phases (chains, Fiat-Shamir round

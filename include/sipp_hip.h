@@ -57,7 +57,12 @@ typedef struct {
     uint32_t final_poly_bits; /* 5 */
     uint32_t num_queries;     /* 84 */
     uint32_t num_challenges;  /* 2 */
+    uint32_t pow_rule;        /* SIPP_POW_DUPLEX (0): observe the witness, response = next challenge (plonky2 fri/prover.rs
+                                 of 2023); SIPP_POW_HASH (1): response = hash_no_pad(challenger.get_hash() || witness)[0]
+                                 (the earlier rule).  Kept as data until upstream's pinned revision can be read. */
 } sipp_stark_config;
+#define SIPP_POW_DUPLEX 0
+#define SIPP_POW_HASH 1
 
 void sipp_default_config(sipp_stark_config *cfg);
 

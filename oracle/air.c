@@ -452,24 +452,26 @@ void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsi
 void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
                    const uint64_t per[ORC_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
                    uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
-                   const uint64_t gamma[2], uint64_t out[2]) {
+                   const uint64_t beta[2], const uint64_t gamma[2], uint64_t out[2]) {
     evalctx_base c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
     for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
-    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
+    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
+    c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
     eval_all_base(air, &c);
     out[0] = c.acc[0]; out[1] = c.acc[1];
 }
 
 void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
                   const gl2 per[ORC_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
-                  gl2 z_last, const uint64_t alpha[2], const uint64_t gamma[2], gl2 out[2]) {
+                  gl2 z_last, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2], gl2 out[2]) {
     evalctx_ext c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
     for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
-    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
+    c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
+    c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
     eval_all_ext(air, &c);
     out[0] = c.acc[0]; out[1] = c.acc[1];
 }

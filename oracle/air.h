@@ -32,8 +32,8 @@ void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsi
 void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
                    const uint64_t per[ORC_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
                    uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
-                   const uint64_t gamma[2], uint64_t out[2]);
+                   const uint64_t beta[2], const uint64_t gamma[2], uint64_t out[2]);
 void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
                   const gl2 per[ORC_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
-                  gl2 z_last, const uint64_t alpha[2], const uint64_t gamma[2], gl2 out[2]);
+                  gl2 z_last, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2], gl2 out[2]);
 #endif

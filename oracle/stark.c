@@ -7,6 +7,14 @@
  * and A.11.  Reached from the reference only through src/verifier_circuit.rs:133-135.
  * Deterministic: the proof-of-work witness is the SMALLEST valid nonce.
  *
+ * Fiat-Shamir binds the STATEMENT first (this repository's proof format, not upstream's starky of mid-2023, which
+ * started from the trace cap): before the trace cap the challenger observes
+ *   kind, log_n, num_io, W, P, Q, rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries,
+ *   num_challenges, pow_rule, pi_per_io, 0                                      (16 elements)
+ *   pi_root[4] = Merkle root (two_to_one) over d_io = hash_no_pad(the pi_per_io u32 words of IO record io)
+ * Public inputs must be canonical: every Fq element of a record < p (checked by prover and verifier), so the
+ * result cells, which the AIR only range-checks to < 2^256, cannot smuggle a non-canonical output into the statement.
+ *
  * Flat proof layout (u64 words; shared with the HIP prover):
  *   header[16]: magic, kind, log_n, num_io, W, P, Q, cap_height, n_fri_rounds, final_poly_len, num_queries,
  *               pi_per_io, total_len, 0, 0, 0
@@ -26,7 +34,79 @@
 
 void orc_default_config(orc_config *c) {
     c->rate_bits = 1; c->cap_height = 4; c->pow_bits = 16; c->arity_bits = 4; c->final_poly_bits = 5;
-    c->num_queries = 84; c->num_challenges = 2;
+    c->num_queries = 84; c->num_challenges = 2; c->pow_rule = ORC_POW_DUPLEX;
+}
+
+/* ---------------- statement binding ---------------- */
+static const uint64_t BN_P64[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static int fq_words_canonical(const uint32_t *w) {
+    for (int q = 3; q >= 0; q--) {
+        uint64_t v = (uint64_t)w[2 * q] | ((uint64_t)w[2 * q + 1] << 32);
+        if (v < BN_P64[q]) return 1;
+        if (v > BN_P64[q]) return 0;
+    }
+    return 0; /* == p */
+}
+/* every Fq element of every record < p; the exponent (8 words) may be any 256-bit value.
+ * Record layouts (reference src/verifier_circuit.rs:92-124): (x, offset, exp_val, output). */
+int orc_pis_canonical(int kind, const uint32_t *pis, size_t num_io) {
+    const int fe = kind == 0 ? 2 : kind == 1 ? 4 : 12;       /* Fq elements per group element */
+    const int ppi = 8 * (3 * fe + 1);
+    for (size_t io = 0; io < num_io; io++) {
+        const uint32_t *rec = pis + io * ppi;
+        for (int k = 0; k < 3 * fe + 1; k++) {
+            if (k >= 2 * fe && k < 2 * fe + 1) continue;     /* exp_val */
+            if (!fq_words_canonical(rec + 8 * k)) return 0;
+        }
+    }
+    return 1;
+}
+
+void orc_pi_root(const uint32_t *pis, size_t num_io, int ppi, uint64_t root[4]) {
+    uint64_t *d = (uint64_t *)malloc(num_io * 4 * sizeof(uint64_t));
+#pragma omp parallel
+    {
+        uint64_t *tmp = (uint64_t *)malloc((size_t)ppi * sizeof(uint64_t));
+#pragma omp for schedule(static)
+        for (size_t io = 0; io < num_io; io++) {
+            for (int k = 0; k < ppi; k++) tmp[k] = pis[io * ppi + k];
+            orc_hash_no_pad(tmp, (size_t)ppi, d + 4 * io);
+        }
+        free(tmp);
+    }
+    for (size_t cnt = num_io; cnt > 1; cnt >>= 1)
+        for (size_t i = 0; i < cnt / 2; i++) {
+            uint64_t out[4];
+            orc_two_to_one(d + 8 * i, d + 8 * i + 4, out);
+            memcpy(d + 4 * i, out, 32);
+        }
+    memcpy(root, d, 32);
+    free(d);
+}
+
+static void observe_statement(orc_challenger *ch, int kind, unsigned log_n, size_t num_io, int W, int P, int Q,
+                              const orc_config *cfg, int ppi, const uint32_t *pis) {
+    uint64_t st[16] = {(uint64_t)kind, log_n, num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg->rate_bits, cfg->cap_height,
+                       cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits, cfg->num_queries, cfg->num_challenges,
+                       cfg->pow_rule, (uint64_t)ppi, 0};
+    uint64_t root[4];
+    orc_chal_observe_many(ch, st, 16);
+    orc_pi_root(pis, num_io, ppi, root);
+    orc_chal_observe_many(ch, root, 4);
+}
+
+/* proof-of-work response for candidate w (two recollections of upstream kept as data):
+ *   ORC_POW_DUPLEX: observe w, response = next challenge                    (plonky2 fri/prover.rs, 2023)
+ *   ORC_POW_HASH  : response = hash_no_pad(challenger.get_hash() || w)[0]   (plonky2 before the duplex grind) */
+static uint64_t pow_response(const orc_challenger *ch, const uint64_t cur_hash[4], unsigned rule, uint64_t w) {
+    if (rule == ORC_POW_HASH) {
+        uint64_t in[5] = {cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], w}, out[4];
+        orc_hash_no_pad(in, 5, out);
+        return out[0];
+    }
+    orc_challenger c2 = *ch;
+    orc_chal_observe(&c2, w);
+    return orc_chal_get(&c2);
 }
 
 static unsigned fri_rounds(const orc_config *c, unsigned degree_bits) {
@@ -141,17 +221,31 @@ static void fri_commit(const orc_config *cfg, unsigned log_n, const gl2 *final_c
     free(coeffs);
     for (size_t i = 0; i < out->final_len; i++) { orc_chal_observe_ext(ch, out->final_poly[i]); wb_push_ext(proof, out->final_poly[i]); }
     /* proof of work: smallest witness */
-    uint64_t w = 0;
+    uint64_t w = 0, cur_hash[4] = {0, 0, 0, 0};
+    if (cfg->pow_rule == ORC_POW_HASH) for (int i = 0; i < 4; i++) cur_hash[i] = orc_chal_get(ch);
     for (;; w++) {
-        orc_challenger c2 = *ch;
-        orc_chal_observe(&c2, w);
-        uint64_t resp = orc_chal_get(&c2);
+        uint64_t resp = pow_response(ch, cur_hash, cfg->pow_rule, w);
         if (cfg->pow_bits == 0 || (resp >> (64 - cfg->pow_bits)) == 0) break;
     }
     out->pow_witness = w;
-    orc_chal_observe(ch, w);
-    (void)orc_chal_get(ch);
+    if (cfg->pow_rule != ORC_POW_HASH) {
+        orc_chal_observe(ch, w);
+        (void)orc_chal_get(ch);
+    }
     wb_push1(proof, w);
+}
+
+/* ---------------- test hook: one-shot tampering with a committed oracle the caller cannot reach ----------------
+ * stage 1: Z column values (before their commitment), stage 2: quotient chunk coefficients.  tests/test_oracle_soundness.py */
+static struct { int stage, col; size_t row; uint64_t delta; } g_tamper;
+void orc_test_tamper(int stage, int col, size_t row, uint64_t delta) {
+    g_tamper.stage = stage; g_tamper.col = col; g_tamper.row = row; g_tamper.delta = delta;
+}
+static void apply_tamper(int stage, uint64_t *cols, size_t n) {
+    if (g_tamper.stage != stage) return;
+    uint64_t *c = cols + (size_t)g_tamper.col * n + g_tamper.row;
+    *c = gl_add(*c, g_tamper.delta % GL_P);
+    g_tamper.stage = 0;
 }
 
 /* ---------------- prover ---------------- */
@@ -160,6 +254,17 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
     int err = 0;
     orc_trace *t = orc_trace_build(kind, ios, num_io, &err);
     if (!t) return err ? err : -1;
+    if (!orc_pis_canonical(kind, t->pis, t->num_io)) { orc_trace_free(t); return -9; }
+    err = orc_stark_prove_trace(t, cfg, proof_out, proof_len);
+    orc_trace_free(t);
+    return err;
+}
+
+/* the prover proper, from a filled trace (tests tamper with the trace between orc_trace_build and this call:
+ * whatever the cells hold is committed and proved as is; the verifier must then refuse) */
+int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **proof_out, size_t *proof_len) {
+    int err = 0;
+    const int kind = t->air->kind;
     const orc_air_t *a = t->air;
     const unsigned log_n = t->log_n, log_m = log_n + cfg->rate_bits;
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
@@ -173,6 +278,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
 
     orc_challenger ch;
     orc_chal_init(&ch);
+    observe_statement(&ch, kind, log_n, t->num_io, W, P, Q, cfg, a->pi_per_io, t->pis);
     /* 1. trace commitment */
     orc_batch *bt = orc_batch_from_values(t->trace, (size_t)W, log_n, cfg->rate_bits, cfg->cap_height);
     orc_chal_observe_cap(&ch, orc_batch_cap(bt), cap_n);
@@ -180,7 +286,6 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
     /* 2. permutation challenges and Z polys */
     uint64_t beta[2], gamma[2];
     for (int i = 0; i < 2; i++) { beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch); }
-    (void)beta;
     uint64_t *zv = (uint64_t *)malloc((size_t)P * n * sizeof(uint64_t));
 #pragma omp parallel
     {
@@ -192,8 +297,8 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
             const uint64_t *col = t->trace + (size_t)(a->checked_base + j) * n, *tab = t->trace;
             const uint64_t *pin = t->trace + (size_t)(nm + j) * n, *ptab = t->trace + (size_t)(nm + nc + j) * n;
             for (size_t r = 0; r < n; r++) {
-                num[r] = gl_mul(gl_add(col[r], gamma[i]), gl_add(tab[r], gamma[i]));
-                den[r] = gl_mul(gl_add(pin[r], gamma[i]), gl_add(ptab[r], gamma[i]));
+                num[r] = gl_mul(gl_add(col[r], gamma[i]), gl_add(tab[r], beta[i]));
+                den[r] = gl_mul(gl_add(pin[r], gamma[i]), gl_add(ptab[r], beta[i]));
             }
             /* batch inversion of den */
             uint64_t acc = 1;
@@ -206,6 +311,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
         }
         free(num); free(den); free(pre);
     }
+    apply_tamper(1, zv, n);
     orc_batch *bz = orc_batch_from_values(zv, (size_t)P, log_n, cfg->rate_bits, cfg->cap_height);
     free(zv);
     orc_chal_observe_cap(&ch, orc_batch_cap(bz), cap_n);
@@ -244,7 +350,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
                 for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = orc_periodic_base(log_n, k, x);
                 selectors_base(log_n, x, &lf, &ll, &zlast);
                 for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = aux_lde[(size_t)ai * m + i];
-                orc_eval_base(a, tl + j * W, tl + jn * W, aux, per, zl + j * P, zl + jn * P, lf, ll, zlast, alpha, gamma, out);
+                orc_eval_base(a, tl + j * W, tl + jn * W, aux, per, zl + j * P, zl + jn * P, lf, ll, zlast, alpha, beta, gamma, out);
                 qv[i] = gl_mul(out[0], zh_inv[i & 1]);
                 qv[m + i] = gl_mul(out[1], zh_inv[i & 1]);
             }
@@ -266,6 +372,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
         }
     }
     free(qv);
+    apply_tamper(2, qc, n);
     orc_batch *bq = orc_batch_from_coeffs(qc, (size_t)Q, log_n, cfg->rate_bits, cfg->cap_height);
     free(qc);
     orc_chal_observe_cap(&ch, orc_batch_cap(bq), cap_n);
@@ -352,7 +459,6 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
     free(op);
 done:
     orc_batch_free(bt); orc_batch_free(bz); orc_batch_free(bq);
-    orc_trace_free(t);
     if (err) { free(pf.w); return err; }
     *proof_out = pf.w;
     *proof_len = pf.len;
@@ -400,13 +506,14 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     }
     int rc = 0;
     gl2 *op = NULL, *auxz = NULL;
+    if (!orc_pis_canonical(kind, pis, num_io)) { free(pis); return -108; }
     orc_challenger ch;
     orc_chal_init(&ch);
+    observe_statement(&ch, kind, log_n, num_io, W, P, Q, cfg, a->pi_per_io, pis);
     const uint64_t *trace_cap = rb_take(&rb, cap_n * 4);
     orc_chal_observe_cap(&ch, trace_cap, cap_n);
     uint64_t beta[2], gamma[2], alpha[2];
     for (int i = 0; i < 2; i++) { beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch); }
-    (void)beta;
     const uint64_t *z_cap = rb_take(&rb, cap_n * 4);
     orc_chal_observe_cap(&ch, z_cap, cap_n);
     alpha[0] = orc_chal_get(&ch); alpha[1] = orc_chal_get(&ch);
@@ -434,7 +541,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
             auxz[ai] = eval_poly_base(co, num_io, zeta);
         }
         free(co);
-        orc_eval_ext(a, op, op + W, auxz, per, op + 2 * W, op + 2 * W + P, lf, ll, zlast, alpha, gamma, out);
+        orc_eval_ext(a, op, op + W, auxz, per, op + 2 * W, op + 2 * W + P, lf, ll, zlast, alpha, beta, gamma, out);
         gl2 zh = gl2_sub(gl2_pow(zeta, n), gl2_from(1));
         if (gl2_eq(zh, gl2_from(0))) { rc = -107; goto out; }
         gl2 zn = gl2_pow(zeta, n);
@@ -457,9 +564,15 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
         if (flen != ((n >> (4 * rounds)))) { rc = -120; goto out; }
         gl2 *fpoly = (gl2 *)malloc(flen * sizeof(gl2));
         for (size_t i = 0; i < flen; i++) { fpoly[i] = rb_ext(&rb); orc_chal_observe_ext(&ch, fpoly[i]); }
-        uint64_t pw = *rb_take(&rb, 1);
-        orc_chal_observe(&ch, pw);
-        uint64_t resp = orc_chal_get(&ch);
+        uint64_t pw = *rb_take(&rb, 1), resp;
+        if (cfg->pow_rule == ORC_POW_HASH) {
+            uint64_t cur_hash[4];
+            for (int i = 0; i < 4; i++) cur_hash[i] = orc_chal_get(&ch);
+            resp = pow_response(&ch, cur_hash, ORC_POW_HASH, pw);
+        } else {
+            orc_chal_observe(&ch, pw);
+            resp = orc_chal_get(&ch);
+        }
         if (cfg->pow_bits && (resp >> (64 - cfg->pow_bits)) != 0) { free(fpoly); rc = -121; goto out; }
         /* precomputed reduced openings */
         gl2 red0 = gl2_from(0), red1 = gl2_from(0);

@@ -18,6 +18,7 @@ void sipp_default_config(sipp_stark_config* cfg) {
     cfg->final_poly_bits = 5;
     cfg->num_queries = 84;
     cfg->num_challenges = 2;
+    cfg->pow_rule = SIPP_POW_DUPLEX;
 }
 
 int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, size_t workspace_bytes) {
@@ -32,7 +33,8 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
     else
         sipp_default_config(&ctx->cfg);
     if (ctx->cfg.rate_bits != 1 || ctx->cfg.num_challenges != 2 || ctx->cfg.arity_bits != 4 ||
-        ctx->cfg.cap_height > 8) {
+        ctx->cfg.cap_height > 8 || ctx->cfg.pow_bits > 32 || ctx->cfg.pow_rule > SIPP_POW_HASH ||
+        ctx->cfg.num_queries == 0 || ctx->cfg.num_queries > 1024 || ctx->cfg.final_poly_bits > 12) {
         delete ctx;
         return SIPP_E_UNSUPPORTED;
     }
@@ -123,6 +125,7 @@ const char* sipp_last_error(const sipp_ctx* ctx) { return ctx ? ctx->err : "null
 
 int sipp_sync(sipp_ctx* ctx) {
     if (!ctx) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SIPP_OK;
 }
@@ -132,6 +135,7 @@ void* sipp_stream(sipp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 // ---- profiling ------------------------------------------------------------------
 static void prof_drain(sipp_ctx* ctx) {
     if (ctx->pending.empty()) return;
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& p : ctx->pending) {
         float ms = 0.f;
@@ -179,12 +183,14 @@ int sipp_profile_report(sipp_ctx* ctx, char* buf, size_t cap) {
 
 int sipp_timer_start(sipp_ctx* ctx) {
     if (!ctx) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_CHECK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
     return SIPP_OK;
 }
 
 int sipp_timer_stop(sipp_ctx* ctx, float* ms) {
     if (!ctx || !ms) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_CHECK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
     SIPP_CHECK_HIP(ctx, hipEventSynchronize(ctx->t1));
     SIPP_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
@@ -194,17 +200,17 @@ int sipp_timer_stop(sipp_ctx* ctx, float* ms) {
 // ---- building blocks --------------------------------------------------------------
 int sipp_ntt_batch(sipp_ctx* ctx, uint64_t* d_cols, size_t col_stride, size_t ncols, uint32_t log_n, int inverse) {
     if (!ctx || !d_cols) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     size_t n = (size_t)1 << log_n;
     if (col_stride < n) return sipp_fail(ctx, SIPP_E_BADARG, "ntt_batch: col_stride < n");
-    ArenaMark m = arena_mark(ctx);
+    ArenaScope scope(ctx);
     uint64_t* tmp = arena_alloc_t<uint64_t>(ctx, n * ncols);
     if (!tmp) return SIPP_E_NOMEM;
     // natural -> (DIF) bit-reversed -> permuted back to natural
     int rc = sipp_ntt_dif(ctx, d_cols, col_stride, log_n, tmp, n, log_n, ncols, inverse != 0, NttDiag{});
     if (rc == SIPP_OK) rc = sipp_bitrev_cols(ctx, tmp, n, d_cols, col_stride, log_n, ncols);
-    if (rc == SIPP_OK) rc = sipp_sync(ctx);
-    arena_release(ctx, m);
-    return rc;
+    const int rs = sipp_sync(ctx);   // the scratch is handed back only after the kernels are done with it
+    return rc == SIPP_OK ? rs : rc;
 }
 
 // values (natural) -> coeffs (natural) + LDE (leaf order)
@@ -212,7 +218,8 @@ static int lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_
                            uint32_t log_n) {
     const size_t n = (size_t)1 << log_n;
     const uint32_t rb = ctx->cfg.rate_bits;
-    ArenaMark m = arena_mark(ctx);
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    ArenaScope scope(ctx);   // released on every exit path; the stream is ordered, so later users of the block wait
     uint64_t* src = const_cast<uint64_t*>(d_values);
     int rc = SIPP_OK;
     if (d_values == d_coeffs) {
@@ -225,7 +232,6 @@ static int lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_
     if (rc == SIPP_OK) rc = sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, /*inverse=*/true, NttDiag{});
     if (rc == SIPP_OK)
         rc = sipp_ntt_dif(ctx, d_coeffs, n, log_n, d_lde, n << rb, log_n + rb, ncols, false, NttDiag{gl::GEN, 0});
-    arena_release(ctx, m);
     return rc;
 }
 
@@ -239,6 +245,7 @@ int sipp_lde_batch(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, 
 int sipp_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t ncols, uint32_t log_leaves,
                          uint64_t* d_digests) {
     if (!ctx || !d_lde || !d_digests) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_leaves, ncols, log_leaves, d_digests));
     return sipp_sync(ctx);
 }
@@ -254,6 +261,7 @@ static int read_cap(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, 
 
 int sipp_merkle_cap(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint64_t* cap_out) {
     if (!ctx || !d_tree || !cap_out) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_leaves, ctx->cfg.cap_height));
     return read_cap(ctx, d_tree, log_leaves, cap_out);
 }
@@ -270,6 +278,7 @@ int sipp_commit_batch(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeff
 
 int sipp_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n) {
     if (!ctx || !d_states) return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     SIPP_TRY(sipp_k_poseidon_permute(ctx, d_states, n));
     return sipp_sync(ctx);
 }
@@ -286,6 +295,7 @@ uint64_t* sipp_table_get(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b) {
 int sipp_table_put(sipp_ctx* ctx, int kind, uint64_t a, uint64_t b, const std::vector<uint64_t>& host,
                    uint64_t** out) {
     uint64_t* d = nullptr;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));   // the table must live on the ctx's GPU whatever the thread last used
     // tables are created once per (kind, size) and live as long as the ctx: the only hipMalloc outside
     // sipp_ctx_create, and only on the first use of a new transform size.
     SIPP_CHECK_HIP(ctx, hipMalloc((void**)&d, host.size() * 8));

@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) fri_leaves_quad_kernel(const uint64_t* __
 struct PowArgs {
     uint64_t state[12];
     uint64_t in_buf[8];
-    uint32_t n_in, pow_bits;
+    uint32_t n_in, pow_bits, resp_word;
     uint64_t base;
     unsigned long long* result;
 };
@@ -215,7 +215,8 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
         if ((uint32_t)i == a.n_in) s[i] = w;
     }
     poseidon::permute(s);
-    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
+    const uint64_t resp = a.resp_word == 7 ? s[7] : s[0];
+    if ((resp >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
 }
 
 uint64_t quad_threshold() {
@@ -242,10 +243,11 @@ int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_
     return SIPP_OK;
 }
 
-int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t pow_bits,
-                      uint64_t* witness) {
+int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t resp_word,
+                      uint32_t pow_bits, uint64_t* witness) {
     if (pow_bits == 0) { *witness = 0; return SIPP_OK; }
-    if (pow_bits > 40 || n_in > 7) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pow_search: unsupported parameters");
+    if (pow_bits > 32 || n_in > 7 || (resp_word != 0 && resp_word != 7))
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pow_search: unsupported parameters");
     ArenaMark mk = arena_mark(ctx);
     unsigned long long* d_res = arena_alloc_t<unsigned long long>(ctx, 1);
     if (!d_res) return SIPP_E_NOMEM;
@@ -253,10 +255,12 @@ int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* i
     memcpy(a.state, state, sizeof a.state);
     memset(a.in_buf, 0, sizeof a.in_buf);
     memcpy(a.in_buf, in_buf, n_in * sizeof(uint64_t));
-    a.n_in = n_in; a.pow_bits = pow_bits; a.result = d_res;
+    a.n_in = n_in; a.pow_bits = pow_bits; a.resp_word = resp_word; a.result = d_res;
     // expected 2^pow_bits trials: a batch of 2^(pow_bits + 1) succeeds with probability 1 - e^-2; batches go in
     // ascending order and atomicMin keeps the smallest valid nonce, so the witness is the global minimum
-    const uint64_t batch = (uint64_t)1 << (pow_bits + 1 < 12 ? 12 : pow_bits + 1);
+    // (at most 2^28 nonces per launch: the grid stays far inside what a launch accepts for every allowed pow_bits)
+    const uint32_t log_batch = pow_bits + 1 < 12 ? 12 : pow_bits + 1 > 28 ? 28 : pow_bits + 1;
+    const uint64_t batch = (uint64_t)1 << log_batch;
     unsigned long long h_res = ~0ull;
     SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_res, 0xff, sizeof(unsigned long long), ctx->stream));
     for (uint64_t base = 0; base < ((uint64_t)1 << 44); base += batch) {

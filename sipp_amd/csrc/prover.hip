@@ -13,7 +13,8 @@ namespace {
 using gl::E2;
 
 // =====================================================================================================
-// permutation Z:  Z[r] = prod_{r' < r} (c + g)(t + g) / ((pin + g)(ptab + g))
+// permutation Z:  Z[r] = prod_{r' < r} (c + g)(t + b) / ((pin + g)(ptab + b))   (g = gamma_i, b = beta_i: independent
+// challenges for the column factor and the table factor, so the two multisets are permuted separately)
 // phase A: 256 lanes x ZR rows per block: batch-inverted ratios, block-local inclusive products
 // phase B: one block per Z column: exclusive scan of the block totals
 // phase C: Z = total_before_block * local_inclusive[r - 1]
@@ -36,11 +37,11 @@ __device__ __forceinline__ uint64_t block_scan_mul_256(uint64_t v, uint64_t* s) 
 // ZR rows per lane: the lane's batch inversion (72 products) is shared by ZR rows -- 16 when the trace is long enough
 template <int ZR>
 __global__ void __launch_bounds__(256) z_phase_a(const uint64_t* __restrict__ trace, size_t n, int nm, int nc, int cbase,
-                                                uint64_t gamma0, uint64_t gamma1, uint64_t* __restrict__ zv,
-                                                uint64_t* __restrict__ totals) {
+                                                uint64_t gamma0, uint64_t gamma1, uint64_t beta0, uint64_t beta1,
+                                                uint64_t* __restrict__ zv, uint64_t* __restrict__ totals) {
     __shared__ uint64_t s[256];
     const int zi = blockIdx.y, i = zi / nc, j = zi % nc;
-    const uint64_t g = i ? gamma1 : gamma0;
+    const uint64_t g = i ? gamma1 : gamma0, b = i ? beta1 : beta0;
     const size_t r0 = (size_t)blockIdx.x * (256 * ZR) + (size_t)threadIdx.x * ZR;
     // a lane owns ZR consecutive rows = ZR * 8 contiguous bytes of each column: 16-byte vector accesses
     const ulonglong2* col = reinterpret_cast<const ulonglong2*>(trace + (size_t)(cbase + j) * n + r0);
@@ -51,10 +52,10 @@ __global__ void __launch_bounds__(256) z_phase_a(const uint64_t* __restrict__ tr
 #pragma unroll
     for (int k = 0; k < ZR; k += 2) {
         const ulonglong2 c2 = col[k >> 1], t2 = tab[k >> 1], p2 = pin[k >> 1], q2 = ptab[k >> 1];
-        num[k] = gl::mul(gl::add(c2.x, g), gl::add(t2.x, g));
-        den[k] = gl::mul(gl::add(p2.x, g), gl::add(q2.x, g));
-        num[k + 1] = gl::mul(gl::add(c2.y, g), gl::add(t2.y, g));
-        den[k + 1] = gl::mul(gl::add(p2.y, g), gl::add(q2.y, g));
+        num[k] = gl::mul(gl::add(c2.x, g), gl::add(t2.x, b));
+        den[k] = gl::mul(gl::add(p2.x, g), gl::add(q2.x, b));
+        num[k + 1] = gl::mul(gl::add(c2.y, g), gl::add(t2.y, b));
+        den[k + 1] = gl::mul(gl::add(p2.y, g), gl::add(q2.y, b));
     }
     uint64_t acc = 1;
 #pragma unroll
@@ -136,7 +137,7 @@ struct QuotArgs {
     int prog_len;
     int W, nm, nc, cbase, tbits;
     uint32_t log_n, log_m;
-    uint64_t alpha[2], gamma[2];
+    uint64_t alpha[2], beta[2], gamma[2];
     // program segments: one gadget, or a run of up to 64 POLY ops; each is folded with alpha from zero by one lane
     const uint32_t* seg_off;                   // word offset of the segment in prog
     const uint32_t* seg_cnt;                   // 0 = gadget, else number of POLY ops in the run
@@ -425,7 +426,8 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     // position in the oracle's order: lookups 3 + 2k (+1), then per challenge 3 + 2 nc + 2 nc ch + 2k (+1).
     const int nm = a.nm, nc = a.nc;
     const uint64_t g0 = a.gamma[0], g1 = a.gamma[1];
-    const uint64_t tg0 = gl::add(tl, g0), tg1 = gl::add(tl, g1);
+    const uint64_t b0 = a.beta[0], b1 = a.beta[1];
+    const uint64_t tg0 = gl::add(tl, b0), tg1 = gl::add(tl, b1);
     constexpr int U = 2;
     for (int k0 = 0; k0 < nc; k0 += U) {
         uint64_t pin[U], ptab[U], npin[U], nptab[U], col[U], z0[U], zn0[U], z1[U], zn1[U];
@@ -451,8 +453,8 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
                 F.mac(gl::sub(pin[u], ptab[u]), w0, w1);
                 T.mac(gl::mul_nc(gl::sub(npin[u], pin[u]), gl::sub(npin[u], nptab[u])), w0 + 3, w1 + 3);
                 const uint64_t cg0 = gl::add(col[u], g0), cg1 = gl::add(col[u], g1);
-                const uint64_t rhs0 = gl::mul_nc(gl::add(pin[u], g0), gl::add(ptab[u], g0));
-                const uint64_t rhs1 = gl::mul_nc(gl::add(pin[u], g1), gl::add(ptab[u], g1));
+                const uint64_t rhs0 = gl::mul_nc(gl::add(pin[u], g0), gl::add(ptab[u], b0));
+                const uint64_t rhs1 = gl::mul_nc(gl::add(pin[u], g1), gl::add(ptab[u], b1));
                 F.mac(gl::sub(z0[u], 1), w0 + 6, w1 + 6);
                 R.mac(gl::sub(gl::mul(zn0[u], rhs0), gl::mul(z0[u], gl::mul_nc(cg0, tg0))), w0 + 9, w1 + 9);
                 F.mac(gl::sub(z1[u], 1), w0 + 12, w1 + 12);
@@ -731,8 +733,8 @@ __global__ void gather_fri_leaf_kernel(const uint64_t* __restrict__ vals, size_t
 }  // namespace
 
 // ---- host wrappers -----------------------------------------------------------------------------------
-int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t gamma[2],
-                     uint64_t* d_zv) {
+int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
+                     const uint64_t gamma[2], uint64_t* d_zv) {
     const size_t n = (size_t)1 << log_n;
     const int P = 2 * a->n_checked;
     // rows per lane: 16 on long traces (the lane's inversion is amortised over 16 rows), 4 otherwise
@@ -747,10 +749,10 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
         ProfScope ps(ctx, "z_phase_a");
         if (zr == 16)
             hipLaunchKernelGGL(z_phase_a<16>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
-                               a->checked_base, gamma[0], gamma[1], d_zv, totals);
+                               a->checked_base, gamma[0], gamma[1], beta[0], beta[1], d_zv, totals);
         else
             hipLaunchKernelGGL(z_phase_a<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
-                               a->checked_base, gamma[0], gamma[1], d_zv, totals);
+                               a->checked_base, gamma[0], gamma[1], beta[0], beta[1], d_zv, totals);
     }
     {
         ProfScope ps(ctx, "z_phase_bc");
@@ -766,7 +768,8 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
 }
 
 int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
-                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t gamma[2], uint64_t* d_out) {
+                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2],
+                    uint64_t* d_out) {
     const uint32_t log_m = log_n + 1;
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
     QuotArgs q{};
@@ -777,6 +780,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.W = a->n_main + 2 * a->n_checked; q.nm = a->n_main; q.nc = a->n_checked; q.cbase = a->checked_base;
     q.tbits = a->table_bits; q.log_n = log_n; q.log_m = log_m;
     q.alpha[0] = alpha[0]; q.alpha[1] = alpha[1]; q.gamma[0] = gamma[0]; q.gamma[1] = gamma[1];
+    q.beta[0] = beta[0]; q.beta[1] = beta[1];
     const uint64_t g = gl::root_of_unity(log_n), wm = gl::root_of_unity(log_m);
     // periodic tables over natural LDE index i mod 2 m_k
     for (int k = 0; k < SIPP_N_PERIODIC; k++) {

@@ -4,10 +4,11 @@
 #include "ctx.hpp"
 #include "poseidon_constants.h"
 
-int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t gamma[2],
-                     uint64_t* d_zv);
+int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
+                     const uint64_t gamma[2], uint64_t* d_zv);
 int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
-                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t gamma[2], uint64_t* d_out);
+                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2],
+                    uint64_t* d_out);
 int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab);
 int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_t n, const uint64_t* d_t0,
                     const uint64_t* d_t1, uint64_t* d_out);
@@ -22,8 +23,10 @@ int sipp_k_gather_fri_leaf(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, ui
                            uint32_t nq, uint64_t* d_out);
 // poseidon.hip
 int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests);
-int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t pow_bits,
-                      uint64_t* witness);
+// smallest w whose response has pow_bits leading zeros; response = word `resp_word` of permute(state with in_buf[0..n_in)
+// and w at position n_in overwritten)
+int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t resp_word,
+                      uint32_t pow_bits, uint64_t* witness);
 
 // ---- host Poseidon + duplex challenger (plonky2 iop/challenger.rs) ----
 namespace host {
@@ -131,6 +134,20 @@ struct Challenger {
     uint64_t get() {
         if (n_in != 0 || n_out == 0) duplex();
         return out_buf[--n_out];
+    }
+    // hash_n_to_hash_no_pad (overwrite-mode sponge, rate 8) and two_to_one, for the statement binding of stark.hip
+    static void hash_no_pad(const uint64_t* in, size_t n, uint64_t out[4]) {
+        uint64_t s[12] = {0};
+        for (size_t i = 0; i < n; i += 8) {
+            for (size_t k = 0; k < 8 && i + k < n; k++) s[k] = in[i + k];
+            poseidon_permute(s);
+        }
+        for (int k = 0; k < 4; k++) out[k] = s[k];
+    }
+    static void two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
+        uint64_t s[12] = {l[0], l[1], l[2], l[3], r[0], r[1], r[2], r[3], 0, 0, 0, 0};
+        poseidon_permute(s);
+        for (int k = 0; k < 4; k++) out[k] = s[k];
     }
     gl::E2 get_ext() {
         gl::E2 r;

@@ -184,6 +184,40 @@ static void fq12_tower_limbs(const uint32_t* c96, int t, uint16_t limbs[16]) {
     for (int l = 0; l < 16; l++) limbs[l] = (uint16_t)(r[l / 4] >> (16 * (l % 4)));
 }
 
+// ---- statement binding (oracle/stark.c header): canonical public inputs, pi_root, the 16 statement words ----------
+static bool fq_words_canonical(const uint32_t* w) {
+    static const uint64_t P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    for (int q = 3; q >= 0; q--) {
+        const uint64_t v = (uint64_t)w[2 * q] | ((uint64_t)w[2 * q + 1] << 32);
+        if (v < P[q]) return true;
+        if (v > P[q]) return false;
+    }
+    return false;
+}
+// every Fq element of every record < p (the exponent may be any 256-bit value): (x, offset, exp_val, output)
+static bool pis_canonical(int kind, const uint32_t* pis, size_t num_io) {
+    const int fe = kind == SIPP_G1_EXP ? 2 : kind == SIPP_G2_EXP ? 4 : 12, ppi = 8 * (3 * fe + 1);
+    for (size_t io = 0; io < num_io; io++)
+        for (int k = 0; k < 3 * fe + 1; k++)
+            if (k != 2 * fe && !fq_words_canonical(pis + io * ppi + 8 * k)) return false;
+    return true;
+}
+// Merkle root (two_to_one) over hash_no_pad(record words); num_io is a power of two >= 2
+static void pi_root(const uint32_t* pis, size_t num_io, int ppi, uint64_t root[4]) {
+    std::vector<uint64_t> d(num_io * 4), tmp((size_t)ppi);
+    for (size_t io = 0; io < num_io; io++) {
+        for (int k = 0; k < ppi; k++) tmp[k] = pis[io * ppi + k];
+        host::Challenger::hash_no_pad(tmp.data(), (size_t)ppi, &d[4 * io]);
+    }
+    for (size_t cnt = num_io; cnt > 1; cnt >>= 1)
+        for (size_t i = 0; i < cnt / 2; i++) {
+            uint64_t out[4];
+            host::Challenger::two_to_one(&d[8 * i], &d[8 * i + 4], out);
+            memcpy(&d[4 * i], out, 32);
+        }
+    memcpy(root, d.data(), 32);
+}
+
 struct Oracle3 {
     uint64_t *coeffs, *lde, *tree;
     int ncols;
@@ -265,8 +299,21 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     if (!d_err || !d_trace || !T.coeffs || !T.lde || !T.tree || !Z.coeffs || !Z.lde || !Z.tree || !Qo.coeffs || !Qo.lde ||
         !Qo.tree)
         return SIPP_E_NOMEM;
+    if (!pis_canonical(kind, pis.data(), s.num_io))
+        return sipp_fail(ctx, SIPP_E_WITNESS, "IO record holds a non-canonical field element (>= p)");
     SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
     SIPP_TRY(sipp_trace_fill(ctx, a, d_ios, s.num_io, log_n, d_trace, d_err));
+    // Fiat-Shamir starts from the statement (hashed on the host while the trace-fill kernels run)
+    host::Challenger ch;
+    {
+        const uint64_t st[16] = {(uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.rate_bits,
+                                 cfg.cap_height, cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries,
+                                 cfg.num_challenges, cfg.pow_rule, (uint64_t)a->pi_per_io, 0};
+        uint64_t root[4];
+        ch.observe_many(st, 16);
+        pi_root(pis.data(), s.num_io, a->pi_per_io, root);
+        ch.observe_many(root, 4);
+    }
     {
         int h_err = 0;
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -279,7 +326,6 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         ctx->gate_release->release();
         ctx->gate_release = nullptr;
     }
-    host::Challenger ch;
     uint64_t cap_host[4 << 8];
 
     // ---- 1. trace commitment ----
@@ -294,12 +340,11 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         beta[i] = ch.get();
         gamma[i] = ch.get();
     }
-    (void)beta;
     {
         ArenaMark mz = arena_mark(ctx);
         uint64_t* d_zv = arena_alloc_t<uint64_t>(ctx, (size_t)P * n);
         if (!d_zv) return SIPP_E_NOMEM;
-        SIPP_TRY(sipp_k_z_columns(ctx, a, d_trace, log_n, gamma, d_zv));
+        SIPP_TRY(sipp_k_z_columns(ctx, a, d_trace, log_n, beta, gamma, d_zv));
         SIPP_TRY(commit_values(ctx, d_zv, (size_t)P, log_n, Z.coeffs, Z.lde, Z.tree, cap_host));
         arena_release(ctx, mz);
     }
@@ -351,7 +396,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_auxc, auxc.data(), auxc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (n_aux) SIPP_TRY(sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, m, log_m, (size_t)n_aux, false, NttDiag{gl::GEN, 0}));
-        SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, d_aux, alpha, gamma, Qo.coeffs));
+        SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, d_aux, alpha, beta, gamma, Qo.coeffs));
         // coset iNTT: leaf-order values -> natural coefficients of q(x) (undo the shift 7)
         SIPP_TRY(sipp_ntt_dit(ctx, Qo.coeffs, m, log_m, 2, true, NttDiag{gl::inv(gl::GEN), 0}));
         // [2][m] natural == 4 chunks of N coefficients, contiguous
@@ -460,9 +505,17 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     tick("fri commit phase");
     // proof of work: smallest valid nonce (deterministic; upstream's rayon find_any may return another one)
     uint64_t pow_witness = 0;
-    SIPP_TRY(sipp_k_pow_search(ctx, ch.state, ch.in_buf, ch.n_in, cfg.pow_bits, &pow_witness));
-    ch.observe(pow_witness);
-    (void)ch.get();
+    if (cfg.pow_rule == SIPP_POW_HASH) {
+        // response = hash_no_pad(challenger.get_hash() || w)[0]: one permutation of (h0..h3, w, 0, ...)
+        uint64_t zero[12] = {0}, cur[4];
+        for (int i = 0; i < 4; i++) cur[i] = ch.get();
+        SIPP_TRY(sipp_k_pow_search(ctx, zero, cur, 4, 0, cfg.pow_bits, &pow_witness));
+    } else {
+        // observe w, response = next challenge = word 7 of the duplexed state
+        SIPP_TRY(sipp_k_pow_search(ctx, ch.state, ch.in_buf, ch.n_in, 7, cfg.pow_bits, &pow_witness));
+        ch.observe(pow_witness);
+        (void)ch.get();
+    }
     push(&pow_witness, 1);
 
     tick("pow");
@@ -630,6 +683,11 @@ int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_i
     SIPP_TRY(shape_of(SIPP_G2_EXP, n2, &s[1]));
     uint32_t* ios[2] = {g1_ios, g2_ios};
     const size_t num[2] = {n1, n2}, ppi[2] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS}, outw[2] = {16, 32};
+    // each list is read back into its own HALF of the pinned buffer (h_pinned_words u32 each); the last two u32 of the
+    // buffer hold the error words
+    for (int k = 0; k < 2; k++)
+        if (num[k] * ppi[k] + 2 > ctx->h_pinned_words)
+            return sipp_fail(ctx, SIPP_E_NOMEM, "fold_outputs: obligation list larger than half of the pinned staging buffer");
     ArenaScope scope(ctx);
     uint32_t* d_ios[2] = {nullptr, nullptr};
     int* d_err = arena_alloc_t<int>(ctx, 2);

@@ -26,3 +26,44 @@ def max_over_ranks(value, device="cpu"):
 def whole_job_rate(units_per_rank, world, max_step_seconds):
     """aggregate throughput: every rank processed `units_per_rank` units in (at most) max_step_seconds"""
     return world * units_per_rank / max_step_seconds
+
+
+def init_process_group(world, local_rank, rehearsal=False):
+    """one process per GPU over RCCL (backend "nccl" on ROCm); rehearsal = every rank on one GPU over gloo, the only
+    difference being the backend and the device of the timing tensor.  No-op for a single rank."""
+    if world <= 1:
+        return "cpu"
+    import torch
+    import torch.distributed as dist
+    if rehearsal:
+        dist.init_process_group("gloo")
+        return "cpu"
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return "cuda"
+
+
+def barrier(sync=None):
+    """rank barrier (when initialised) followed by the caller's device synchronisation"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if sync is not None:
+        sync()
+
+
+def timed_steps(step, steps, warmup, sync=None, device="cpu", before_timing=None):
+    """bench.py's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on
+    both sides; returns (max-over-ranks elapsed seconds, result of the last step)."""
+    import time
+    last = None
+    for _ in range(warmup):
+        last = step()
+    if before_timing is not None:
+        before_timing()
+    barrier(sync)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    barrier(sync)
+    elapsed = time.perf_counter() - t0
+    return max_over_ranks(elapsed, device=device), last

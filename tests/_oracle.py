@@ -173,7 +173,7 @@ class Trace:
 # ---------------- STARK prover / verifier (oracle/stark.c) ----------------
 class OrcConfig(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "arity_bits", "final_poly_bits",
-                                          "num_queries", "num_challenges")]
+                                          "num_queries", "num_challenges", "pow_rule")]
 
 
 def default_config():
@@ -194,6 +194,23 @@ def stark_prove(kind, ios, cfg=None):
     rc = L.orc_stark_prove(kind, ios, ios.shape[0], C.byref(cfg), C.byref(out), C.byref(n))
     if rc != 0:
         raise RuntimeError("orc_stark_prove failed: %d" % rc)
+    proof = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free(out)
+    return proof
+
+
+def stark_prove_trace(trace, cfg=None):
+    """prove from a filled `Trace` (possibly tampered through Trace.array()): whatever the cells hold is committed"""
+    L = load()
+    cfg = cfg or default_config()
+    L.orc_stark_prove_trace.argtypes = [C.POINTER(OrcTrace), C.POINTER(OrcConfig), C.POINTER(C.POINTER(C.c_uint64)),
+                                        C.POINTER(C.c_size_t)]
+    L.orc_free.argtypes = [C.c_void_p]
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    rc = L.orc_stark_prove_trace(trace.p, C.byref(cfg), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("orc_stark_prove_trace failed: %d" % rc)
     proof = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
     L.orc_free(out)
     return proof

@@ -24,6 +24,22 @@ import torch
 owned = torch.zeros(5, dtype=torch.int64); owned[mine] = 1
 dist.all_reduce(owned)
 assert owned.tolist() == [1] * 5
+# bench.py's timing contract (dist_util.timed_steps): W untimed + exactly K timed steps between barriers, MAX over ranks,
+# whole-job value = world * units / max step time -- with a fake step whose cost depends on the rank
+calls = []
+def fake_step():
+    calls.append(1)
+    time.sleep(0.02 * (1 + rank))
+    return len(calls)
+marks = []
+elapsed, last = du.timed_steps(fake_step, steps=3, warmup=2, sync=lambda: marks.append("sync"), device="cpu",
+                               before_timing=lambda: marks.append("prof"))
+assert len(calls) == 5 and last == 5, calls
+assert marks == ["prof", "sync", "sync"], marks
+assert 3 * 0.02 * world <= elapsed < 3 * 0.02 * world + 0.5, elapsed      # the slow rank's time on every rank
+value = du.whole_job_rate(128, world, elapsed / 3)
+assert abs(value - world * 128 / (elapsed / 3)) < 1e-6
+assert du.init_process_group(1, 0) == "cpu"                                 # single rank: nothing to initialise
 dist.destroy_process_group()
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rank) + ".ok"), "w").write("ok")
 '''

@@ -1,0 +1,83 @@
+"""The N > 1 legs of bench.py and multi-device instances (L-A replicas, L-B one ctx per sub-proof).
+
+The driver's 8-GPU scaling run is not ours to launch; what can be exercised on a one-GPU box is exercised here:
+ * bench.py --gpus 2 under torch.distributed.run in rehearsal mode (both ranks on GPU 0, gloo instead of RCCL -- the
+   only two differences from the driver's launch, see sipp_amd/dist_util.init_process_group);
+ * Instance(devices=...) over every visible device (skipped on a one-GPU box): per-device constant tables, arenas,
+   streams; proofs must equal the single-device ones word for word."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(extra_env, nproc, args, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_rehearsal_prints_one_whole_job_line():
+    out = _run_bench({"SIPP_BENCH_REHEARSAL": "1"}, 2,
+                     ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--inflight", "1"])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["unit"] == "pairings/s" and r["higher_is_better"] is True
+    # whole-job aggregate: both ranks proved one n = 128 instance per step, timed by the slower rank
+    assert abs(r["value"] - 2 * 128 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    assert r["proof_words"] and all(w > 0 for w in r["proof_words"])
+    assert "independent SIPP instance" in r["config"]["parallelism"]
+
+
+def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
+    """`python bench.py --gpus 2` without a launcher must not report a one-GPU number as the 2-GPU leg"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode != 0
+    assert "torch.distributed.run" in (out.stdout + out.stderr)
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_instance_over_all_visible_devices_matches_single_device():
+    import torch
+    import sipp_amd
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("one visible GPU: multi-device ctxs cannot be exercised on this box")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    ref = sipp_amd.Instance([a.shape[0] for a in ios], devices=(0, 0, 0))
+    try:
+        want = [p.copy() for p in ref.prove(ios)]
+    finally:
+        ref.close()
+    # every rotation of the visible devices over the three sub-proofs: each device gets each kind at least once
+    for start in range(nd):
+        devs = tuple((start + k) % nd for k in range(3))
+        inst = sipp_amd.Instance([a.shape[0] for a in ios], devices=devs)
+        try:
+            for _ in range(2):
+                got = inst.prove(ios)
+                for k in range(3):
+                    assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), (devs, k)
+        finally:
+            inst.close()

@@ -1,0 +1,236 @@
+"""Soundness of this repository's AIRs on the CPU oracle (tools/air_gen.py is the specification; PARITY UNPINNED, so
+these tests are what stands between the specification and an unsound one):
+
+ * AIR mutation suite: one cell of every column class is changed on an add row, a double row, a limb-end row and at
+   a block boundary; the constraints of that row (or of the row before it) must fail.
+ * committed-oracle mutations the row checker cannot see (permuted lookup columns, the range table, Z, quotient chunks):
+   a complete proof is produced from the tampered data and the verifier must refuse it.
+ * the lookup attack of ADVICE.md round 1 (an out-of-range limb hidden in permuted_table): accepted by a permutation
+   argument that uses ONE challenge for both factors, refused with independent challenges (the current form).
+ * statement binding: public inputs, header words and the configuration all enter Fiat-Shamir; non-canonical public
+   inputs are refused."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+
+P = _oracle.P
+
+
+@pytest.fixture(scope="module")
+def ios4():
+    d = np.load("tests/golden/sipp_n4_ios.npz")
+    return d["g1"], d["g2"], d["fq12"]
+
+
+def column_classes(t, kind):
+    """name -> one representative column of every class the generator allocates (tools/air_gen.py build_curve / build_fq12)"""
+    a = t.air
+    cb, cpl = a.checked_base, a.cells_per_limb
+    prog = np.ctypeslib.as_array(a.prog, shape=(a.prog_len,))
+    assert prog[0] == 1                                     # first op is a gadget: sign col, carry base, q base
+    sign0, carry0, q0 = int(prog[1]), int(prog[2]), int(prog[7 + 3])
+    if kind == 2:
+        cls = {"acc": 1 + 16 * 3 + 2, "pw": 1 + 192 + 16 * 5 + 1, "bit": 1 + 384, "e0": 1 + 385, "e3": 1 + 388,
+               "C": cb + 16 * cpl * 4 + 3}
+    else:
+        nc = 16 * (kind + 1)
+        cls = {"Rx": 1 + 2, "Ry": 1 + nc + 5, "Px": 1 + 2 * nc + 1, "Py": 1 + 3 * nc + 7, "bit": 1 + 4 * nc,
+               "e0": 1 + 4 * nc + 1, "e3": 1 + 4 * nc + 4, "lam": cb + 3, "X3": cb + nc * cpl + 2, "Y3": cb + 2 * nc * cpl + 9}
+    cls.update({"sign": sign0, "carry": carry0 + 1, "q": q0 + 4})
+    # the last gadget's cells too (different offsets in the program)
+    cls["carry_last"] = a.n_main - 1
+    return cls
+
+
+ROWS = {"add": 36, "double": 37, "limb_end": 63, "block_last": 511, "block_first": 512}
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_every_column_class_mutation_breaks_a_row_constraint(ios4, kind):
+    t = _oracle.Trace(kind, ios4[kind])
+    arr = t.array()
+    n = 1 << t.log_n
+    assert n >= 1024
+    undetected = []
+    for name, col in column_classes(t, kind).items():
+        assert 0 < col < t.air.n_main, (name, col)
+        for rname, r in ROWS.items():
+            assert t.check_row(r) == -1 and t.check_row(r - 1) == -1
+            old = int(arr[col, r])
+            # a different value that still passes the range check where one applies; `bit` is only boolean on double rows
+            # (by design: the exponent and state transitions read it on add rows only), so leave {0, 1} there
+            new = old ^ 1
+            if name == "bit" and (r & 1):
+                new = 2
+            arr[col, r] = new
+            if t.check_row(r) == -1 and t.check_row(r - 1) == -1:
+                undetected.append((name, col, rname))
+            arr[col, r] = old
+    assert not undetected, undetected
+
+
+def _prove_verify(t):
+    pf = _oracle.stark_prove_trace(t)
+    return _oracle.stark_verify(pf)
+
+
+def test_untampered_trace_proves_and_verifies(ios4):
+    t = _oracle.Trace(0, ios4[0])
+    assert _prove_verify(t) == 0
+
+
+@pytest.mark.parametrize("what", ["perm_in", "perm_tab_first", "perm_tab_filler", "table", "z", "quotient"])
+def test_committed_column_mutations_are_refused_by_the_verifier(ios4, what):
+    t = _oracle.Trace(0, ios4[0])
+    arr = t.array()
+    a = t.air
+    nm, nc = a.n_main, a.n_checked
+    n = 1 << t.log_n
+    j = 7
+    pin, ptab = arr[nm + j], arr[nm + nc + j]
+    first = np.concatenate([[True], pin[1:] != pin[:-1]])
+    if what == "perm_in":
+        arr[nm + j, 300] = (int(pin[300]) + 1) % 256
+    elif what == "perm_tab_first":
+        r = int(np.nonzero(first)[0][3])
+        arr[nm + nc + j, r] = (int(ptab[r]) + 1) % 256
+    elif what == "perm_tab_filler":
+        r = int(np.nonzero(~first)[0][5])
+        arr[nm + nc + j, r] = (int(ptab[r]) + 1) % 256          # lookup constraints still hold; only the multiset changes
+    elif what == "table":
+        arr[0, 100] = 99                                        # range table must count 0, 1, ..., T-1, T-1, ...
+    elif what == "z":
+        _oracle.load().orc_test_tamper(1, j, 123, 5)
+    elif what == "quotient":
+        _oracle.load().orc_test_tamper(2, 1, 17, 1)
+    rc = _prove_verify(t)
+    assert rc != 0, what
+    assert -119 < rc <= -110 or rc <= -120, rc                  # a constraint at zeta, or FRI / Merkle consistency
+
+
+def _lookup_constraints_hold(pin, ptab):
+    ok_first = pin[0] == ptab[0]
+    d1 = (pin[1:].astype(object) - pin[:-1].astype(object))
+    d2 = (pin[1:].astype(object) - ptab[1:].astype(object))
+    return ok_first and all((x * y) % P == 0 for x, y in zip(d1, d2))
+
+
+def _grand_products(col, tab, pin, ptab, gamma, beta):
+    lhs = rhs = 1
+    for c, t_, p_, q_ in zip(col, tab, pin, ptab):
+        lhs = lhs * ((int(c) + gamma) % P) * ((int(t_) + beta) % P) % P
+        rhs = rhs * ((int(p_) + gamma) % P) * ((int(q_) + beta) % P) % P
+    return lhs, rhs
+
+
+def test_out_of_range_limb_hidden_in_the_permuted_table_is_refused(ios4):
+    """split a u8-table limb cell lo -> lo + 256, hi -> hi - 1 (same 16-bit limb value, so every
+    gadget still holds), then hide the out-of-range value v = lo + 256 in permuted_table and give permuted_input a spare
+    table value instead.  All lookup constraints hold; with ONE challenge for both factors the grand products agree
+    (the unsound form), with independent challenges they do not, and the verifier refuses the proof."""
+    t = _oracle.Trace(0, ios4[0])
+    arr = t.array()
+    a = t.air
+    assert a.table_bits == 8 and a.cells_per_limb == 2
+    nm, nc, cb = a.n_main, a.n_checked, a.checked_base
+    n = 1 << t.log_n
+    # a lambda limb whose high byte is non-zero: cells (cb + 2 i, cb + 2 i + 1) = (lo, hi)
+    r = 36
+    i = next(i for i in range(16) if arr[cb + 2 * i + 1, r] > 0)
+    jl, jh = 2 * i, 2 * i + 1
+    lo, hi = int(arr[cb + jl, r]), int(arr[cb + jh, r])
+    v = lo + 256
+    arr[cb + jl, r] = v
+    arr[cb + jh, r] = hi - 1
+    for rr in (r - 1, r):
+        assert t.check_row(rr) == -1                            # gadgets and transitions cannot see it
+    # hi column: re-derive its permuted columns honestly (its multiset changed)
+    tab = arr[0].copy()
+
+    def honest_fill(col):
+        hist = np.bincount(col.astype(np.int64), minlength=256)
+        pin = np.sort(col)
+        unused = [x for x in range(256) if hist[x] == 0]
+        ptab = np.empty_like(pin)
+        first = np.concatenate([[True], pin[1:] != pin[:-1]])
+        k = 0
+        for pos in range(len(pin)):
+            if first[pos]:
+                ptab[pos] = pin[pos]
+            else:
+                ptab[pos] = unused[k] if k < len(unused) else 255
+                k += 1
+        return pin, ptab, first
+    pin_h, ptab_h, _ = honest_fill(arr[cb + jh])
+    arr[nm + jh], arr[nm + nc + jh] = pin_h, ptab_h
+    # lo column: the attack.  Pretend the bad cell holds 255 (x0 = T - 1, of which the table column has many copies) ...
+    fake = arr[cb + jl].copy()
+    fake[r] = 255
+    pin_l, ptab_l, first = honest_fill(fake)
+    fill255 = [p for p in range(n) if not first[p] and ptab_l[p] == 255]
+    assert fill255, "no spare copy of T - 1 among the fillers"
+    ptab_l[fill255[0]] = v                                      # ... and park v in a filler position of permuted_table
+    arr[nm + jl], arr[nm + nc + jl] = pin_l, ptab_l
+    assert _lookup_constraints_hold(pin_l, ptab_l)              # every lookup constraint is satisfied
+    assert sorted(ptab_l.tolist()) != sorted(tab.tolist())      # although permuted_table is NOT a permutation of the table
+    col = arr[cb + jl]
+    g = 0x1234567890abcdef % P
+    lhs, rhs = _grand_products(col, tab, pin_l, ptab_l, g, g)
+    assert lhs == rhs                                           # one shared challenge: the cheat goes through
+    lhs, rhs = _grand_products(col, tab, pin_l, ptab_l, g, 0xfedcba0987654321 % P)
+    assert lhs != rhs                                           # independent challenges: it does not
+    rc = _prove_verify(t)
+    assert rc in (-110, -111), rc                               # the verifier's constraint check at zeta fails
+
+
+def test_statement_is_bound_by_fiat_shamir(ios4):
+    """public inputs, header and configuration enter the transcript before the trace cap: changing any of them after
+    the fact changes every challenge, so the proof no longer verifies"""
+    pf = _oracle.stark_prove(0, ios4[0])
+    assert _oracle.stark_verify(pf) == 0
+    nio, ppi = int(pf[3]), int(pf[11])
+    bad = pf.copy()
+    bad[len(pf) - nio * ppi + 40] ^= 1                          # one bit of the exponent of IO record 0
+    assert _oracle.stark_verify(bad) != 0
+    # the same proof under another configuration (query count unchanged, proof-of-work bits lower: every structural
+    # check still passes, only the transcript differs)
+    cfg = _oracle.default_config()
+    cfg.pow_bits = 15
+    assert _oracle.stark_verify(pf, cfg) != 0
+
+
+def test_non_canonical_public_inputs_are_refused(ios4):
+    """the AIR range-checks result cells to < 2^256 only; canonicity (< p) of every public Fq element is checked by the
+    prover and by the verifier instead, so x + p cannot stand in for x in the statement"""
+    p_bn = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    ios = ios4[0].copy()
+    x = sum(int(w) << (32 * k) for k, w in enumerate(ios[0, :8]))
+    xp = x + p_bn
+    assert xp < 1 << 256
+    ios[0, :8] = [(xp >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+    with pytest.raises(RuntimeError):
+        _oracle.stark_prove(0, ios)
+    pf = _oracle.stark_prove(0, ios4[0])
+    bad = pf.copy()
+    nio, ppi = int(pf[3]), int(pf[11])
+    base = len(pf) - nio * ppi
+    out = sum(int(bad[base + ppi - 16 + k]) << (32 * k) for k in range(8)) + p_bn
+    if out < 1 << 256:
+        for k in range(8):
+            bad[base + ppi - 16 + k] = (out >> (32 * k)) & 0xFFFFFFFF
+        assert _oracle.stark_verify(bad) == -108
+
+
+def test_pow_rule_is_data(ios4):
+    """both recollections of upstream's proof-of-work rule are implemented; a proof made under one
+    verifies under it and not under the other"""
+    for rule in (0, 1):
+        cfg = _oracle.default_config()
+        cfg.pow_rule = rule
+        cfg.pow_bits = 10
+        pf = _oracle.stark_prove(0, ios4[0], cfg)
+        assert _oracle.stark_verify(pf, cfg) == 0
+        other = _oracle.default_config()
+        other.pow_rule, other.pow_bits = 1 - rule, 10
+        assert _oracle.stark_verify(pf, other) != 0
