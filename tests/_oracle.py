@@ -16,6 +16,9 @@ _lib = None
 
 
 def build(force=False):
+    if os.environ.get("SIPP_ORACLE_ASAN"):      # scripts/run_asan.sh: the AddressSanitizer + UBSan build of the same sources
+        subprocess.check_call(["make", "-C", ODIR, "-s", "asan"])
+        return os.path.join(ODIR, "liboracle_asan.so")
     so = os.path.join(ODIR, "liboracle.so")
     srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
