@@ -221,7 +221,9 @@ static int lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     ArenaScope scope(ctx);   // released on every exit path; the stream is ordered, so later users of the block wait
     uint64_t* src = const_cast<uint64_t*>(d_values);
-    int rc = SIPP_OK;
+    int rc = sipp_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rb);
+    if (rc != SIPP_E_UNSUPPORTED) return rc;
+    rc = SIPP_OK;
     if (d_values == d_coeffs) {
         uint64_t* tmp = arena_alloc_t<uint64_t>(ctx, n * ncols);
         if (!tmp) return SIPP_E_NOMEM;

@@ -217,6 +217,161 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// Fused commitment transforms (PolynomialBatch::from_values without intermediate sweeps over HBM)
+//
+//   lde_column_kernel   2^10 <= N <= 2^14: the WHOLE column lives in LDS.  values (natural) are scattered into LDS in
+//                       bit-reversed position, the inverse DIT yields natural coefficients (x 1/N folded into the
+//                       twiddle table), which are stored once; then for each of the 2^rate_bits cosets the coefficients
+//                       are scaled by the coset's power table, a forward DIF runs in LDS and the half is stored in leaf
+//                       order.  HBM per column: 8 N read + 8 N (coefficients) + 8 N 2^rate_bits (LDE) written
+//                       (+ 8 N re-read of the just-written coefficients per extra coset: cache hits) instead of
+//                       104 N for bitrev copy + 2 iNTT passes + 2 LDE passes.
+//   per-element tables  twiddle / coset-power factors come from tables laid out like the data (one coalesced 8-B load
+//                       and ONE product per element) instead of a running product per 16-element segment (two products).
+// Tile layout = the pass kernel's: position p at LDS index p + p / 16; k1 high bits (rows r = p >> k2, strided stages),
+// k2 low bits (contiguous blocks); conventions identical to ntt_pass_kernel (tested bit-exact against it and the oracle).
+// =====================================================================================================================
+
+// all butterfly stages of one bit group on an LDS tile of E elements: k stages over rows (element stride T = 2^lt)
+__device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit) {
+    const uint32_t R = 1u << k, T = 1u << lt;
+    uint32_t s = 0;
+    const uint32_t quarter = E >> 2;
+    for (; s + 1 < k; s += 2) {
+        const uint32_t log_q = dit ? s : (k - 2 - s);
+        for (uint32_t idx = threadIdx.x; idx < quarter; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 2) - 1);
+            const uint32_t g = rest >> (k - 2);
+            const uint32_t j = b & ((1u << log_q) - 1);
+            const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t st = (1u << log_q) << lt;
+            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e0 + st), l2 = lds_idx(e0 + 2 * st), l3 = lds_idx(e0 + 3 * st);
+            uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
+            if (dit) {
+                const uint64_t w1 = wr_s[j << (k - 1 - s)];
+                const uint64_t w20 = wr_s[j << (k - 2 - s)], w21 = wr_s[(j + (1u << s)) << (k - 2 - s)];
+                const uint64_t v1 = gl::mul(x1, w1), v3 = gl::mul(x3, w1);
+                const uint64_t a0 = gl::add(x0, v1), a1 = gl::sub(x0, v1), a2 = gl::add(x2, v3), a3 = gl::sub(x2, v3);
+                const uint64_t u2 = gl::mul(a2, w20), u3 = gl::mul(a3, w21);
+                tile[l0] = gl::add(a0, u2);
+                tile[l2] = gl::sub(a0, u2);
+                tile[l1] = gl::add(a1, u3);
+                tile[l3] = gl::sub(a1, u3);
+            } else {
+                const uint64_t w10 = wr_s[j << s], w11 = wr_s[(j + (1u << log_q)) << s];
+                const uint64_t w2 = wr_s[j << (s + 1)];
+                const uint64_t a0 = gl::add(x0, x2), a2 = gl::mul(gl::sub(x0, x2), w10);
+                const uint64_t a1 = gl::add(x1, x3), a3 = gl::mul(gl::sub(x1, x3), w11);
+                tile[l0] = gl::add(a0, a1);
+                tile[l1] = gl::mul(gl::sub(a0, a1), w2);
+                tile[l2] = gl::add(a2, a3);
+                tile[l3] = gl::mul(gl::sub(a2, a3), w2);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t half = E >> 1;
+    for (; s < k; s++) {
+        const uint32_t log_hd = dit ? s : (k - 1 - s);
+        const uint32_t tw_shift = k - 1 - log_hd;
+        for (uint32_t idx = threadIdx.x; idx < half; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 1) - 1);
+            const uint32_t g = rest >> (k - 1);
+            const uint32_t j = b & ((1u << log_hd) - 1);
+            const uint32_t r0 = ((b >> log_hd) << (log_hd + 1)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t e1 = e0 + ((1u << log_hd) << lt);
+            const uint64_t w = wr_s[j << tw_shift];
+            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e1);
+            uint64_t u = tile[l0], v = tile[l1];
+            if (dit) {
+                v = gl::mul(v, w);
+                tile[l0] = gl::add(u, v);
+                tile[l1] = gl::sub(u, v);
+            } else {
+                tile[l0] = gl::add(u, v);
+                tile[l1] = gl::mul(gl::sub(u, v), w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct ColArgs {
+    const uint64_t* in;       // [ncols][in_stride]: values (natural rows) or, with from_coeffs, coefficients
+    uint64_t* coeffs;         // [ncols][n] natural order (written unless from_coeffs)
+    uint64_t* lde;            // [ncols][lde_stride] leaf order
+    size_t in_stride, lde_stride;
+    uint32_t log_n, rate_bits, k1, k2, from_coeffs;
+    const uint64_t* wr1_inv;  // w_R1^-x, x < R1 / 2
+    const uint64_t* wr2_inv;
+    const uint64_t* wr1_fwd;
+    const uint64_t* wr2_fwd;
+    const uint64_t* tw_inv;   // [n]: w_n^-(t bitrev_k1(r)) / n   at position p = r 2^k2 + t
+    const uint64_t* tw_fwd;   // [n]: w_n^(t bitrev_k1(r))
+    const uint64_t* pw;       // [2^rate_bits][n]: (7 w_m^h)^p, half h = natural LDE index mod 2^rate_bits
+};
+
+__global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t n = 1u << a.log_n, k1 = a.k1, k2 = a.k2;
+    const uint32_t R1 = 1u << k1, R2 = 1u << k2;
+    uint64_t* tile = smem;
+    uint64_t* w1i = smem + (n + (n >> LOG_SEG));
+    uint64_t* w2i = w1i + (R1 >> 1);
+    uint64_t* w1f = w2i + (R2 >> 1);
+    uint64_t* w2f = w1f + (R1 >> 1);
+    const uint32_t col = blockIdx.x;
+    const uint64_t* in = a.in + (size_t)col * a.in_stride;
+    for (uint32_t i = threadIdx.x; i < (R1 >> 1); i += blockDim.x) {
+        w1i[i] = a.wr1_inv[i];
+        w1f[i] = a.wr1_fwd[i];
+    }
+    for (uint32_t i = threadIdx.x; i < (R2 >> 1); i += blockDim.x) {
+        w2i[i] = a.wr2_inv[i];
+        w2f[i] = a.wr2_fwd[i];
+    }
+    const uint64_t* cf = in;   // where the coefficients of this column can be (re)read from
+    if (!a.from_coeffs) {
+        // values -> coefficients: scatter into bit-reversed position, DIT low bits, twiddle (x 1/n), DIT high bits
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tile[lds_idx(gl::bitrev(i, a.log_n))] = in[i];
+        __syncthreads();
+        tile_stages(tile, w2i, n, k2, 0, true);
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_inv[p]);
+        __syncthreads();
+        tile_stages(tile, w1i, n, k1, k2, true);
+        uint64_t* co = a.coeffs + (size_t)col * n;
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) co[p] = tile[lds_idx(p)];
+        cf = co;
+    }
+    const uint32_t halves = 1u << a.rate_bits;
+    for (uint32_t h = 0; h < halves; h++) {
+        // coefficients x coset powers -> LDS (the first coset of from_values takes them from LDS, the others re-read them)
+        const uint64_t* pw = a.pw + (size_t)h * n;
+        if (h == 0 && !a.from_coeffs) {
+            for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], pw[p]);
+        } else {
+            __syncthreads();   // the previous half's stores read the tile
+            for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(cf[p], pw[p]);
+        }
+        __syncthreads();
+        tile_stages(tile, w1f, n, k1, k2, false);
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_fwd[p]);
+        __syncthreads();
+        tile_stages(tile, w2f, n, k2, 0, false);
+        // natural LDE index i = i' 2^rate_bits + h sits at leaf position bitrev(h) n + bitrev(i'): the DIF's own order
+        uint64_t* out = a.lde + (size_t)col * a.lde_stride + (size_t)gl::bitrev(h, a.rate_bits) * n;
+        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) out[p] = tile[lds_idx(p)];
+    }
+}
+
 __global__ void bitrev_cols_kernel(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride,
                                    uint32_t log_n, size_t ncols) {
     size_t n = (size_t)1 << log_n;
@@ -419,7 +574,96 @@ int ntt_run(sipp_ctx* ctx, bool dit, const uint64_t* d_in, size_t in_stride, uin
     return SIPP_OK;
 }
 
+
+// ---- fused commitment transforms: host side ----------------------------------------------------------------------
+enum { TAB_COL_TW = 20, TAB_COL_PW = 21 };
+
+// per-element twiddle table of the whole-column kernel: tab[p] = w^(t bitrev_k1(r)) c, p = r 2^k2 + t
+uint64_t* col_tw_table(sipp_ctx* ctx, uint32_t log_n, uint32_t k1, bool inverse) {
+    uint64_t* t = sipp_table_get(ctx, TAB_COL_TW, ((uint64_t)log_n << 8) | k1, inverse);
+    if (t) return t;
+    const uint32_t k2 = log_n - k1;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> v(n);
+    uint64_t w = gl::root_of_unity(log_n);
+    if (inverse) w = gl::inv(w);
+    const uint64_t c = inverse ? gl::inv((uint64_t)n) : 1;
+    for (uint32_t r = 0; r < (1u << k1); r++) {
+        const uint64_t step = gl::pow(w, (uint64_t)gl::bitrev(r, k1));
+        uint64_t x = c;
+        for (uint32_t tt = 0; tt < (1u << k2); tt++) {
+            v[((size_t)r << k2) | tt] = x;
+            x = gl::mul(x, step);
+        }
+    }
+    if (sipp_table_put(ctx, TAB_COL_TW, ((uint64_t)log_n << 8) | k1, inverse, v, &t) != SIPP_OK) return nullptr;
+    return t;
+}
+
+// coset power tables: tab[h][p] = (7 w_m^h)^p, m = n << rate_bits
+uint64_t* col_pw_table(sipp_ctx* ctx, uint32_t log_n, uint32_t rate_bits) {
+    uint64_t* t = sipp_table_get(ctx, TAB_COL_PW, log_n, rate_bits);
+    if (t) return t;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<uint64_t> v(n << rate_bits);
+    const uint64_t wm = gl::root_of_unity(log_n + rate_bits);
+    for (uint32_t h = 0; h < (1u << rate_bits); h++) {
+        const uint64_t base = gl::mul(gl::GEN, gl::pow(wm, (uint64_t)h));
+        uint64_t x = 1;
+        for (size_t p = 0; p < n; p++) {
+            v[(size_t)h * n + p] = x;
+            x = gl::mul(x, base);
+        }
+    }
+    if (sipp_table_put(ctx, TAB_COL_PW, log_n, rate_bits, v, &t) != SIPP_OK) return nullptr;
+    return t;
+}
+
+bool fused_lde_enabled() {
+    static int v = -1;
+    if (v < 0) v = getenv("SIPP_NTT_UNFUSED") ? 0 : 1;
+    return v == 1;
+}
+
+int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_coeffs, uint64_t* d_lde, size_t lde_stride,
+               size_t ncols, uint32_t log_n, uint32_t rate_bits, bool from_coeffs) {
+    ColArgs a{};
+    a.in = d_in; a.coeffs = d_coeffs; a.lde = d_lde; a.in_stride = in_stride; a.lde_stride = lde_stride;
+    a.log_n = log_n; a.rate_bits = rate_bits; a.from_coeffs = from_coeffs ? 1 : 0;
+    a.k2 = 7; a.k1 = log_n - 7;
+    a.wr1_inv = wr_table(ctx, a.k1, true); a.wr2_inv = wr_table(ctx, a.k2, true);
+    a.wr1_fwd = wr_table(ctx, a.k1, false); a.wr2_fwd = wr_table(ctx, a.k2, false);
+    a.tw_inv = col_tw_table(ctx, log_n, a.k1, true);
+    a.tw_fwd = col_tw_table(ctx, log_n, a.k1, false);
+    a.pw = col_pw_table(ctx, log_n, rate_bits);
+    if (!a.wr1_inv || !a.wr2_inv || !a.wr1_fwd || !a.wr2_fwd || !a.tw_inv || !a.tw_fwd || !a.pw) return SIPP_E_HIP;
+    const size_t n = (size_t)1 << log_n;
+    const size_t shmem = (n + (n >> LOG_SEG) + ((size_t)1 << a.k1) + ((size_t)1 << a.k2)) * sizeof(uint64_t);
+    if (shmem > 160 * 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "lde_column: column does not fit LDS");
+    if (shmem > 64 * 1024)
+        SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const unsigned threads = n >= 16384 ? 1024 : n >= 8192 ? 512 : 256;
+    ProfScope ps(ctx, "lde_column");
+    hipLaunchKernelGGL(lde_column_kernel, dim3((unsigned)ncols), dim3(threads), shmem, ctx->stream, a);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
 }  // namespace
+
+// values [ncols][n] natural -> coefficients [ncols][n] natural + LDE [ncols][n << rate_bits] in leaf order; d_coeffs may
+// alias d_values only on the unfused path (the fused kernels read a column completely before they write it: aliasing is fine there too)
+int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
+                         uint32_t rate_bits) {
+    if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
+        return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
+    return SIPP_E_UNSUPPORTED;   // caller falls back to the pass-by-pass path
+}
+int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {
+    if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
+        return lde_column(ctx, d_coeffs, (size_t)1 << log_n, nullptr, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, true);
+    return SIPP_E_UNSUPPORTED;
+}
 
 int sipp_ntt_dif(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint32_t log_n_in, uint64_t* d_out,
                  size_t out_stride, uint32_t log_n, size_t ncols, bool inverse, NttDiag diag) {

@@ -21,12 +21,21 @@ namespace {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIPP_LEAVES_WPE, SIPP_LEAVES_WPE)))
 poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                              uint32_t ncols, uint64_t n_leaves,
-                                                             uint64_t* __restrict__ digests) {
+                                                             uint64_t* __restrict__ digests,
+                                                             uint32_t c_begin, uint32_t c_end, uint64_t* __restrict__ carry) {
+    // columns [c_begin, c_end) of the sponge (c_begin a multiple of 8); a launch that does not start at column 0 resumes from
+    // `carry` ([12][n_leaves] sponge states), one that does not reach ncols leaves its states there (column-chunked launches
+    // keep the waves short-lived so that other streams' kernels get placed; sipp_k_poseidon_leaves)
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     uint64_t s[12];
+    if (c_begin) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
+        for (int i = 0; i < 12; i++) s[i] = carry[(uint64_t)i * n_leaves + j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = 0;
+    }
     const uint64_t* p = lde + j;
     if (ncols <= 4) {
         for (uint32_t c = 0; c < ncols; c++) {
@@ -38,13 +47,18 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
     } else {
         // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
 #pragma unroll 1
-        for (uint32_t c = 0; c < ncols; c += 8) {
+        for (uint32_t c = c_begin; c < c_end; c += 8) {
             const uint32_t m = ncols - c;  // wave-uniform
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
             poseidon::permute(s);
         }
+    }
+    if (c_end < ncols) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) carry[(uint64_t)i * n_leaves + j] = s[i];
+        return;
     }
     uint64_t* d = digests + 4 * j;
     d[0] = s[0];
@@ -56,7 +70,8 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 // ---- four lanes per state (poseidon_quad.cuh): thin launches ----
 __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
-                                                                  uint64_t* __restrict__ digests) {
+                                                                  uint64_t* __restrict__ digests,
+                                                                  uint32_t c_begin, uint32_t c_end, uint64_t* __restrict__ carry) {
     __shared__ uint64_t tab[poseidon_quad::T_WORDS];
     poseidon_quad::load_tables(tab);
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,14 +79,23 @@ __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_
     const uint32_t q = (uint32_t)tid & 3;
     if (leaf >= n_leaves) return;  // n_leaves is a multiple of 16: whole quads / waves leave together
     uint64_t s[3] = {0, 0, 0};
+    if (c_begin) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[j] = carry[(uint64_t)(3 * q + j) * n_leaves + leaf];
+    }
     const uint64_t* p = lde + leaf;
-    for (uint32_t c = 0; c < ncols; c += 8) {
+    for (uint32_t c = c_begin; c < c_end; c += 8) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint32_t e = 3 * q + j;
             if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
         }
         poseidon_quad::permute(s, q, tab);
+    }
+    if (c_end < ncols) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) carry[(uint64_t)(3 * q + j) * n_leaves + leaf] = s[j];
+        return;
     }
     uint64_t* d = digests + 4 * leaf;
     if (q == 0) {
@@ -129,6 +153,77 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __res
     d[1] = s[1];
     d[2] = s[2];
     d[3] = s[3];
+}
+
+// ---- one launch per SUBTREE instead of one per level ------------------------------------------------------------------
+// Block b owns the 2^lw consecutive nodes [b 2^lw, (b + 1) 2^lw) of level `level0` and climbs `nlev` <= lw levels: every
+// level it produces is written to the tree buffer (queries need the siblings of every level) and read back by the same
+// block after a barrier (__syncthreads orders the block's global writes).  A 2^17-leaf tree takes 2 launches instead of 13,
+// a 2^22-leaf tree 2 instead of 18; the wide levels run with all lanes busy, only the tip of a subtree (< 64 / < 16 parents)
+// leaves lanes idle.  tree: levels back to back, level l at digest offset sum_{i<l} (n_leaves >> i).
+template <bool QUAD>
+__global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uint32_t log_leaves,
+                                                            uint32_t level0, uint32_t lw, uint32_t nlev) {
+    __shared__ uint64_t tab[QUAD ? poseidon_quad::T_WORDS : 1];
+    if (QUAD) poseidon_quad::load_tables(tab);
+    uint64_t off = 0;
+    for (uint32_t l = 0; l < level0; l++) off += (uint64_t)1 << (log_leaves - l);
+    uint64_t n_level = (uint64_t)1 << (log_leaves - level0);       // nodes of the current level in the whole tree
+    uint64_t first = (uint64_t)blockIdx.x << lw;                  // this block's first node on the current level
+    uint32_t cnt = 1u << lw;                                       // this block's nodes on the current level
+    for (uint32_t s = 0; s < nlev; s++) {
+        const uint64_t* child = tree + 4 * (off + first);
+        uint64_t* parent = tree + 4 * (off + n_level + (first >> 1));
+        cnt >>= 1;
+        if (QUAD) {
+            const uint32_t q = threadIdx.x & 3;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                // whole waves run the permutation together (DPP needs complete quads); a wave past the end skips it
+                if (base + ((threadIdx.x & ~63u) >> 2) >= cnt) continue;
+                const uint32_t i = base + (threadIdx.x >> 2);
+                const bool live = i < cnt;
+                uint64_t st[3] = {0, 0, 0};
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const uint32_t e = 3 * q + j;
+                        if (e < 8) st[j] = child[8 * (uint64_t)i + e];
+                    }
+                }
+                poseidon_quad::permute(st, q, tab);
+                if (live) {
+                    uint64_t* d = parent + 4 * (uint64_t)i;
+                    if (q == 0) {
+                        d[0] = st[0];
+                        d[1] = st[1];
+                        d[2] = st[2];
+                    } else if (q == 1) {
+                        d[3] = st[0];
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                uint64_t st[12];
+                const uint64_t* c = child + 8 * (uint64_t)i;
+#pragma unroll
+                for (int k = 0; k < 8; k++) st[k] = c[k];
+#pragma unroll
+                for (int k = 8; k < 12; k++) st[k] = 0;
+                poseidon::permute(st);
+                uint64_t* d = parent + 4 * (uint64_t)i;
+                d[0] = st[0];
+                d[1] = st[1];
+                d[2] = st[2];
+                d[3] = st[3];
+            }
+        }
+        __syncthreads();
+        off += n_level;
+        n_level >>= 1;
+        first >>= 1;
+    }
 }
 
 __global__ void __launch_bounds__(256) poseidon_permute_kernel(uint64_t* states, uint64_t n) {
@@ -298,32 +393,85 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     return SIPP_OK;
 }
 
+// columns per leaf-hash launch (multiple of 8; 0 = one launch over all columns).  A sponge over W columns is sequential per
+// leaf, so a single launch keeps its waves resident for W / 8 permutations (milliseconds) and, at three waves per SIMD, holds
+// nearly every VGPR of the chip: the other proofs' thin kernels (lookups, Z, Merkle, Fiat-Shamir round trips) cannot be
+// placed until those waves retire.  Chunked launches hand the SIMDs back every `chunk / 8` permutations; the sponge states
+// travel through a [12][n_leaves] scratch (96 B per leaf per boundary against chunk * 8 B of column data read).
+static uint32_t leaf_chunk_cols() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("SIPP_LEAF_CHUNK");
+        v = e ? atol(e) : 0;
+        v &= ~7L;
+    }
+    return (uint32_t)v;
+}
+
 int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stride, size_t ncols, uint32_t log_leaves,
                            uint64_t* d_digests) {
     if (ncols == 0 || ncols > 0xffffffffull) return sipp_fail(ctx, SIPP_E_BADARG, "poseidon_leaves: bad ncols");
     uint64_t n = (uint64_t)1 << log_leaves;
-    // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
-    // park 4 waves on one CU and leave three quarters of the CUs idle
-    ProfScope ps(ctx, "poseidon_leaves");
-    if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
-        // thin launch: four lanes per state -> 4x the waves
-        unsigned grid = (unsigned)((4 * n + 255) / 256);
-        hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
-                           (uint32_t)ncols, n, d_digests);
-    } else {
-        // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
-        // at 2^17 leaves), 512 is slightly slower
-        const unsigned bs = n <= 65536 ? 64 : 256;
-        unsigned grid = (unsigned)((n + bs - 1) / bs);
-        hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
-                           (uint32_t)ncols, n, d_digests);
+    const bool quad = ncols > 4 && n >= 16 && n <= quad_threshold();
+    uint32_t chunk = leaf_chunk_cols();
+    if (chunk == 0 || ncols <= 4 || chunk >= ncols) chunk = (uint32_t)ncols;
+    ArenaScope scope(ctx);
+    uint64_t* carry = nullptr;
+    if (chunk < ncols) {
+        carry = arena_alloc_t<uint64_t>(ctx, 12 * n);
+        if (!carry) return SIPP_E_NOMEM;
     }
-    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    for (uint32_t c0 = 0; c0 < ncols; c0 += chunk) {
+        const uint32_t c1 = c0 + chunk < ncols ? c0 + chunk : (uint32_t)ncols;
+        ProfScope ps(ctx, "poseidon_leaves");
+        if (quad) {
+            // thin launch: four lanes per state -> 4x the waves
+            unsigned grid = (unsigned)((4 * n + 255) / 256);
+            hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                               (uint32_t)ncols, n, d_digests, c0, c1, carry);
+        } else {
+            // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
+            // at 2^17 leaves), 512 is slightly slower
+            const unsigned bs = n <= 65536 ? 64 : 256;
+            unsigned grid = (unsigned)((n + bs - 1) / bs);
+            hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
+                               (uint32_t)ncols, n, d_digests, c0, c1, carry);
+        }
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
     return SIPP_OK;
+}
+
+// SIPP_MERKLE_PER_LEVEL=1: the one-launch-per-level form (kept for A/B measurements)
+static bool merkle_per_level() {
+    static int v = -1;
+    if (v < 0) v = getenv("SIPP_MERKLE_PER_LEVEL") ? 1 : 0;
+    return v == 1;
 }
 
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height) {
     if (cap_height > log_leaves) cap_height = log_leaves;
+    if (!merkle_per_level()) {
+        uint32_t level = 0;
+        const uint32_t top = log_leaves - cap_height;     // levels to produce
+        while (level < top) {
+            const uint32_t log_nodes = log_leaves - level;
+            // subtree size: as many blocks as the level allows while a block still has >= 2^8 nodes (full lanes on its
+            // wide levels); the last launch is a single block over <= 2^10 nodes that climbs to the cap
+            uint32_t lw = log_nodes <= 10 ? log_nodes : log_nodes >= 18 ? 10 : 8;
+            uint32_t nlev = lw < top - level ? lw : top - level;
+            const unsigned blocks = 1u << (log_nodes - lw);
+            const uint64_t widest_parents = (uint64_t)1 << (log_nodes - 1);
+            ProfScope ps(ctx, "merkle_subtree");
+            if (widest_parents <= quad_threshold())
+                hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, d_tree, log_leaves, level, lw, nlev);
+            else
+                hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, d_tree, log_leaves, level, lw, nlev);
+            SIPP_CHECK_HIP(ctx, hipGetLastError());
+            level += nlev;
+        }
+        return SIPP_OK;
+    }
     uint64_t off = 0;
     for (uint32_t l = 0; l < log_leaves - cap_height; l++) {
         uint64_t n_child = (uint64_t)1 << (log_leaves - l);

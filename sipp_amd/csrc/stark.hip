@@ -95,8 +95,11 @@ static int read_cap(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, 
 static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, uint32_t log_n, uint64_t* d_lde,
                          uint64_t* d_tree, uint64_t* cap_host) {
     const uint32_t log_m = log_n + ctx->cfg.rate_bits;
-    SIPP_TRY(sipp_ntt_dif(ctx, d_coeffs, (size_t)1 << log_n, log_n, d_lde, (size_t)1 << log_m, log_m, ncols, false,
-                          NttDiag{gl::GEN, 0}));
+    int rc = sipp_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, ctx->cfg.rate_bits);
+    if (rc == SIPP_E_UNSUPPORTED)
+        rc = sipp_ntt_dif(ctx, d_coeffs, (size_t)1 << log_n, log_n, d_lde, (size_t)1 << log_m, log_m, ncols, false,
+                          NttDiag{gl::GEN, 0});
+    SIPP_TRY(rc);
     SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
     SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
     return read_cap(ctx, d_tree, log_m, cap_host);
@@ -106,6 +109,14 @@ static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, 
 static int commit_values(sipp_ctx* ctx, const uint64_t* d_values, size_t ncols, uint32_t log_n, uint64_t* d_coeffs,
                          uint64_t* d_lde, uint64_t* d_tree, uint64_t* cap_host) {
     const size_t n = (size_t)1 << log_n;
+    const uint32_t log_m = log_n + ctx->cfg.rate_bits;
+    const int rc = sipp_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, ctx->cfg.rate_bits);
+    if (rc == SIPP_OK) {   // fused: coefficients and LDE are both in place
+        SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
+        SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
+        return read_cap(ctx, d_tree, log_m, cap_host);
+    }
+    if (rc != SIPP_E_UNSUPPORTED) return rc;
     SIPP_TRY(sipp_bitrev_cols(ctx, d_values, n, d_coeffs, n, log_n, ncols));
     SIPP_TRY(sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, true, NttDiag{}));
     return commit_coeffs(ctx, d_coeffs, ncols, log_n, d_lde, d_tree, cap_host);
@@ -600,7 +611,8 @@ size_t sipp_workspace_bytes(int kind, size_t num_io) {
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
                    + 3 * 8 * m                                          // three Merkle trees
                    + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
-                   + 80 * n;                                            // power tables, FRI layers, combine partials
+                   + 80 * n                                             // power tables, FRI layers, combine partials
+                   + 12 * m;                                            // sponge states between column-chunked leaf-hash launches
     size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
                    + n * 400                                            // Jacobian row scratch of the curve chains
                    + ((size_t)64 << 20);
