@@ -234,8 +234,20 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
 // k2 low bits (contiguous blocks); conventions identical to ntt_pass_kernel (tested bit-exact against it and the oracle).
 // =====================================================================================================================
 
+// LDS placement of tile element e: one u64 of padding per 16 (lds_idx), optionally one more per 2^BLK elements so that a
+// scatter over blocks (the bit-reversed gather of lde_gather_kernel) is conflict-free as well
+struct IdxPlain {
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
+};
+struct IdxBlocked {
+    uint32_t blk;   // log2 block size
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
+};
+
 // all butterfly stages of one bit group on an LDS tile of E elements: k stages over rows (element stride T = 2^lt)
-__device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit) {
+template <class Idx>
+__device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit,
+                                            Idx lidx) {
     const uint32_t R = 1u << k, T = 1u << lt;
     uint32_t s = 0;
     const uint32_t quarter = E >> 2;
@@ -250,7 +262,7 @@ __device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s
             const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
             const uint32_t e0 = (((g << k) | r0) << lt) | t;
             const uint32_t st = (1u << log_q) << lt;
-            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e0 + st), l2 = lds_idx(e0 + 2 * st), l3 = lds_idx(e0 + 3 * st);
+            const uint32_t l0 = lidx(e0), l1 = lidx(e0 + st), l2 = lidx(e0 + 2 * st), l3 = lidx(e0 + 3 * st);
             uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
             if (dit) {
                 const uint64_t w1 = wr_s[j << (k - 1 - s)];
@@ -289,7 +301,7 @@ __device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s
             const uint32_t e0 = (((g << k) | r0) << lt) | t;
             const uint32_t e1 = e0 + ((1u << log_hd) << lt);
             const uint64_t w = wr_s[j << tw_shift];
-            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e1);
+            const uint32_t l0 = lidx(e0), l1 = lidx(e1);
             uint64_t u = tile[l0], v = tile[l1];
             if (dit) {
                 v = gl::mul(v, w);
@@ -343,10 +355,10 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
         // values -> coefficients: scatter into bit-reversed position, DIT low bits, twiddle (x 1/n), DIT high bits
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tile[lds_idx(gl::bitrev(i, a.log_n))] = in[i];
         __syncthreads();
-        tile_stages(tile, w2i, n, k2, 0, true);
+        tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{});
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_inv[p]);
         __syncthreads();
-        tile_stages(tile, w1i, n, k1, k2, true);
+        tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{});
         uint64_t* co = a.coeffs + (size_t)col * n;
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) co[p] = tile[lds_idx(p)];
         cf = co;
@@ -362,13 +374,103 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
             for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(cf[p], pw[p]);
         }
         __syncthreads();
-        tile_stages(tile, w1f, n, k1, k2, false);
+        tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{});
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_fwd[p]);
         __syncthreads();
-        tile_stages(tile, w2f, n, k2, 0, false);
+        tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{});
         // natural LDE index i = i' 2^rate_bits + h sits at leaf position bitrev(h) n + bitrev(i'): the DIF's own order
         uint64_t* out = a.lde + (size_t)col * a.lde_stride + (size_t)gl::bitrev(h, a.rate_bits) * n;
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) out[p] = tile[lds_idx(p)];
+    }
+}
+
+// ---- 2^15 <= N <= 2^17: three sweeps instead of five ------------------------------------------------------------------
+//   lde_gather_kernel  inverse DIT over the LOW k2 position bits, reading the natural-order values directly: a tile is 16
+//                      blocks of 2^k2 positions that differ in their top four position bits, i.e. in the low four bits of
+//                      the natural index, so every global read is a full 128-byte line (no bit-reversal copy).
+//   lde_mid_kernel     tile = 2^k1 rows x 16 positions: twiddle (x 1/N), inverse DIT over the HIGH k1 bits -> natural
+//                      coefficients (stored); x 7^p; rows [2^k1, 2^(k1+1)) = 0; forward DIF over the top k1 + 1 bits of the
+//                      2N-point coset transform; twiddle; stored into the LDE buffer.  (The last iNTT pass and the first LDE
+//                      pass work on the same strided set of coefficients.)
+//   ntt_pass_kernel    the remaining low k2 bits of the 2N-point DIF, contiguous blocks (unchanged).
+struct GatherArgs {
+    const uint64_t* in;    // [ncols][n] values, natural order
+    uint64_t* out;         // [ncols][n] positions after the low-bit DIT
+    uint32_t log_n, k2;
+    const uint64_t* wr;    // w_R2^-x
+};
+
+__global__ void __launch_bounds__(256) lde_gather_kernel(GatherArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k2 = a.k2, R2 = 1u << k2, E = 16u << k2;
+    const IdxBlocked lidx{k2};
+    uint64_t* tile = smem;
+    uint64_t* wr_s = smem + (E + (E >> LOG_SEG) + 16);
+    const uint32_t mid_bits = a.log_n - 4 - k2;
+    const uint32_t tiles_per_col = 1u << mid_bits;
+    const uint32_t col = blockIdx.x >> mid_bits, mid = blockIdx.x & (tiles_per_col - 1);
+    const uint64_t* in = a.in + ((size_t)col << a.log_n);
+    uint64_t* out = a.out + ((size_t)col << a.log_n);
+    for (uint32_t i = threadIdx.x; i < (R2 >> 1); i += blockDim.x) wr_s[i] = a.wr[i];
+    // natural index = bitrev(position): [bitrev(r) | bitrev(mid) | bitrev4(g)]
+    const uint32_t nat_mid = gl::bitrev(mid, mid_bits) << 4;
+    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
+        const uint32_t gq = e & 15, r = e >> 4;
+        const uint32_t nat = (gl::bitrev(r, k2) << (a.log_n - k2)) | nat_mid | gq;
+        tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = in[nat];
+    }
+    __syncthreads();
+    tile_stages(tile, wr_s, E, k2, 0, true, lidx);
+    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
+        const uint32_t g = e >> k2, r = e & (R2 - 1);
+        out[((size_t)g << (a.log_n - 4)) | ((size_t)mid << k2) | r] = tile[lidx(e)];
+    }
+}
+
+struct MidArgs {
+    uint64_t* coeffs;        // [ncols][n]: in = positions after lde_gather_kernel, out = natural coefficients (in place)
+    uint64_t* lde;           // [ncols][2n]: positions of the 2n-point DIF after its top k1 + 1 bits
+    uint32_t log_n, k1;
+    const uint64_t* wr_inv;  // w_R1^-x, x < R1 / 2
+    const uint64_t* wr_fwd;  // w_(2 R1)^x, x < R1
+    const uint64_t* tw_inv;  // [n]   w_n^-(t bitrev_k1(r)) / n         at position r 2^k2 + t
+    const uint64_t* pw;      // [n]   7^p
+    const uint64_t* tw_fwd;  // [2n]  w_2n^(t bitrev_(k1+1)(r'))         at position r' 2^k2 + t
+};
+
+__global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k1 = a.k1, R1 = 1u << k1, k2 = a.log_n - k1;
+    const uint32_t E1 = R1 << 4, E2 = E1 << 1;          // T = 16
+    uint64_t* tile = smem;
+    uint64_t* wi = smem + (E2 + (E2 >> LOG_SEG));
+    uint64_t* wf = wi + (R1 >> 1);
+    const uint32_t tiles_per_col = 1u << (k2 - 4);
+    const uint32_t col = blockIdx.x / tiles_per_col;
+    const uint32_t i0 = (blockIdx.x - col * tiles_per_col) << 4;
+    uint64_t* co = a.coeffs + ((size_t)col << a.log_n);
+    uint64_t* lde = a.lde + ((size_t)col << (a.log_n + 1));
+    for (uint32_t i = threadIdx.x; i < (R1 >> 1); i += blockDim.x) wi[i] = a.wr_inv[i];
+    for (uint32_t i = threadIdx.x; i < R1; i += blockDim.x) wf[i] = a.wr_fwd[i];
+    // element e = r 16 + t  <->  position p = r 2^k2 + i0 + t
+    for (uint32_t e = threadIdx.x; e < E1; e += blockDim.x) {
+        const size_t p = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
+        tile[lds_idx(e)] = gl::mul(co[p], a.tw_inv[p]);
+    }
+    __syncthreads();
+    tile_stages(tile, wi, E1, k1, 4, true, IdxPlain{});
+    for (uint32_t e = threadIdx.x; e < E1; e += blockDim.x) {
+        const size_t p = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
+        const uint64_t c = tile[lds_idx(e)];
+        co[p] = c;
+        tile[lds_idx(e)] = gl::mul(c, a.pw[p]);          // coset shift 7^p
+        tile[lds_idx(e + E1)] = 0;                        // zero padding of the LDE: rows R1 .. 2 R1 - 1
+    }
+    __syncthreads();
+    tile_stages(tile, wf, E2, k1 + 1, 4, false, IdxPlain{});
+    for (uint32_t e = threadIdx.x; e < E2; e += blockDim.x) {
+        const size_t q = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
+        lde[q] = gl::mul(tile[lds_idx(e)], a.tw_fwd[q]);
     }
 }
 
@@ -642,10 +744,75 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
     if (shmem > 160 * 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "lde_column: column does not fit LDS");
     if (shmem > 64 * 1024)
         SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    const unsigned threads = n >= 16384 ? 1024 : n >= 8192 ? 512 : 256;
+    // threads per block (SIPP_LDE_COL_THREADS overrides): big blocks hide LDS latency when the kernel runs alone, small ones
+    // are placed sooner beside the other proofs' resident hash waves
+    static int thr_env = -1;
+    if (thr_env < 0) {
+        const char* e = getenv("SIPP_LDE_COL_THREADS");
+        thr_env = e ? atoi(e) : 0;
+    }
+    // measured at n = 128 (3 proofs concurrent): 256 threads 71.2 ms, 512 72.2, 1024 75.1, 128 72.1 per instance
+    const unsigned threads = thr_env ? (unsigned)thr_env : n >= 16384 ? 512 : 256;
     ProfScope ps(ctx, "lde_column");
     hipLaunchKernelGGL(lde_column_kernel, dim3((unsigned)ncols), dim3(threads), shmem, ctx->stream, a);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+// 2^15 <= n <= 2^17, blowup 2: gather + low-bit DIT | fused middle | low-bit DIF of the 2n-point transform
+int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n) {
+    const uint32_t k1 = 8, k2 = log_n - k1;
+    const size_t n = (size_t)1 << log_n;
+    {
+        GatherArgs g{};
+        g.in = d_values; g.out = d_coeffs; g.log_n = log_n; g.k2 = k2;
+        g.wr = wr_table(ctx, k2, true);
+        if (!g.wr) return SIPP_E_HIP;
+        const size_t E = (size_t)16 << k2;
+        const size_t shmem = (E + (E >> LOG_SEG) + 16 + ((size_t)1 << (k2 - 1))) * sizeof(uint64_t);
+        const size_t tiles = (n / E) * ncols;
+        if (tiles > 0x7fffffffull) return SIPP_E_UNSUPPORTED;
+        if (shmem > 64 * 1024)
+            SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        ProfScope ps(ctx, "lde_gather");
+        hipLaunchKernelGGL(lde_gather_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, g);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    {
+        MidArgs m{};
+        m.coeffs = d_coeffs; m.lde = d_lde; m.log_n = log_n; m.k1 = k1;
+        m.wr_inv = wr_table(ctx, k1, true);
+        m.wr_fwd = wr_table(ctx, k1 + 1, false);
+        m.tw_inv = col_tw_table(ctx, log_n, k1, true);
+        m.pw = col_pw_table(ctx, log_n, 1);               // first coset half = 7^p
+        m.tw_fwd = col_tw_table(ctx, log_n + 1, k1 + 1, false);
+        if (!m.wr_inv || !m.wr_fwd || !m.tw_inv || !m.pw || !m.tw_fwd) return SIPP_E_HIP;
+        const size_t E2 = (size_t)32 << k1;
+        const size_t shmem = (E2 + (E2 >> LOG_SEG) + ((size_t)1 << (k1 - 1)) + ((size_t)1 << k1)) * sizeof(uint64_t);
+        const size_t tiles = (n >> (k1 + 4)) * ncols;
+        if (tiles > 0x7fffffffull) return SIPP_E_UNSUPPORTED;
+        SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        ProfScope ps(ctx, "lde_mid");
+        static int mid_thr = -1;
+        if (mid_thr < 0) {
+            const char* e = getenv("SIPP_LDE_MID_THREADS");
+            mid_thr = e ? atoi(e) : 256;
+        }
+        hipLaunchKernelGGL(lde_mid_kernel, dim3((unsigned)tiles), dim3((unsigned)mid_thr), shmem, ctx->stream, m);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    {
+        // low k2 bits of the 2n-point DIF: contiguous blocks of 2^k2 positions, in place
+        PassArgs a{};
+        a.in = d_lde; a.out = d_lde; a.in_stride = a.out_stride = 2 * n;
+        a.log_n = log_n + 1; a.k = k2; a.log_m = k2; a.dit = 0; a.n_in = 2 * n;
+        const uint32_t LT = (uint32_t)ntt_ltile();
+        a.lt = 0;
+        a.lg = LT > k2 ? LT - k2 : 0;
+        a.wr = wr_table(ctx, k2, false);
+        if (!a.wr) return SIPP_E_HIP;
+        SIPP_TRY(run_pass(ctx, "ntt_dif_pass", a, ncols));
+    }
     return SIPP_OK;
 }
 
@@ -657,6 +824,8 @@ int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_co
                          uint32_t rate_bits) {
     if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
+    if (fused_lde_enabled() && log_n >= 15 && log_n <= 17 && rate_bits == 1 && d_values != d_coeffs)
+        return lde_three_sweeps(ctx, d_values, d_coeffs, d_lde, ncols, log_n);
     return SIPP_E_UNSUPPORTED;   // caller falls back to the pass-by-pass path
 }
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {

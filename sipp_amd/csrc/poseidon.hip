@@ -21,21 +21,12 @@ namespace {
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIPP_LEAVES_WPE, SIPP_LEAVES_WPE)))
 poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                              uint32_t ncols, uint64_t n_leaves,
-                                                             uint64_t* __restrict__ digests,
-                                                             uint32_t c_begin, uint32_t c_end, uint64_t* __restrict__ carry) {
-    // columns [c_begin, c_end) of the sponge (c_begin a multiple of 8); a launch that does not start at column 0 resumes from
-    // `carry` ([12][n_leaves] sponge states), one that does not reach ncols leaves its states there (column-chunked launches
-    // keep the waves short-lived so that other streams' kernels get placed; sipp_k_poseidon_leaves)
+                                                             uint64_t* __restrict__ digests) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
     uint64_t s[12];
-    if (c_begin) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = carry[(uint64_t)i * n_leaves + j];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = 0;
-    }
+    for (int i = 0; i < 12; i++) s[i] = 0;
     const uint64_t* p = lde + j;
     if (ncols <= 4) {
         for (uint32_t c = 0; c < ncols; c++) {
@@ -47,18 +38,13 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
     } else {
         // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
 #pragma unroll 1
-        for (uint32_t c = c_begin; c < c_end; c += 8) {
+        for (uint32_t c = 0; c < ncols; c += 8) {
             const uint32_t m = ncols - c;  // wave-uniform
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
             poseidon::permute(s);
         }
-    }
-    if (c_end < ncols) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) carry[(uint64_t)i * n_leaves + j] = s[i];
-        return;
     }
     uint64_t* d = digests + 4 * j;
     d[0] = s[0];
@@ -70,8 +56,7 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 // ---- four lanes per state (poseidon_quad.cuh): thin launches ----
 __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
-                                                                  uint64_t* __restrict__ digests,
-                                                                  uint32_t c_begin, uint32_t c_end, uint64_t* __restrict__ carry) {
+                                                                  uint64_t* __restrict__ digests) {
     __shared__ uint64_t tab[poseidon_quad::T_WORDS];
     poseidon_quad::load_tables(tab);
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,23 +64,14 @@ __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_
     const uint32_t q = (uint32_t)tid & 3;
     if (leaf >= n_leaves) return;  // n_leaves is a multiple of 16: whole quads / waves leave together
     uint64_t s[3] = {0, 0, 0};
-    if (c_begin) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) s[j] = carry[(uint64_t)(3 * q + j) * n_leaves + leaf];
-    }
     const uint64_t* p = lde + leaf;
-    for (uint32_t c = c_begin; c < c_end; c += 8) {
+    for (uint32_t c = 0; c < ncols; c += 8) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const uint32_t e = 3 * q + j;
             if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
         }
         poseidon_quad::permute(s, q, tab);
-    }
-    if (c_end < ncols) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) carry[(uint64_t)(3 * q + j) * n_leaves + leaf] = s[j];
-        return;
     }
     uint64_t* d = digests + 4 * leaf;
     if (q == 0) {
@@ -393,52 +369,27 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     return SIPP_OK;
 }
 
-// columns per leaf-hash launch (multiple of 8; 0 = one launch over all columns).  A sponge over W columns is sequential per
-// leaf, so a single launch keeps its waves resident for W / 8 permutations (milliseconds) and, at three waves per SIMD, holds
-// nearly every VGPR of the chip: the other proofs' thin kernels (lookups, Z, Merkle, Fiat-Shamir round trips) cannot be
-// placed until those waves retire.  Chunked launches hand the SIMDs back every `chunk / 8` permutations; the sponge states
-// travel through a [12][n_leaves] scratch (96 B per leaf per boundary against chunk * 8 B of column data read).
-static uint32_t leaf_chunk_cols() {
-    static long v = -1;
-    if (v < 0) {
-        const char* e = getenv("SIPP_LEAF_CHUNK");
-        v = e ? atol(e) : 0;
-        v &= ~7L;
-    }
-    return (uint32_t)v;
-}
-
 int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stride, size_t ncols, uint32_t log_leaves,
                            uint64_t* d_digests) {
     if (ncols == 0 || ncols > 0xffffffffull) return sipp_fail(ctx, SIPP_E_BADARG, "poseidon_leaves: bad ncols");
     uint64_t n = (uint64_t)1 << log_leaves;
-    const bool quad = ncols > 4 && n >= 16 && n <= quad_threshold();
-    uint32_t chunk = leaf_chunk_cols();
-    if (chunk == 0 || ncols <= 4 || chunk >= ncols) chunk = (uint32_t)ncols;
-    ArenaScope scope(ctx);
-    uint64_t* carry = nullptr;
-    if (chunk < ncols) {
-        carry = arena_alloc_t<uint64_t>(ctx, 12 * n);
-        if (!carry) return SIPP_E_NOMEM;
+    // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
+    // park 4 waves on one CU and leave three quarters of the CUs idle
+    ProfScope ps(ctx, "poseidon_leaves");
+    if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
+        // thin launch: four lanes per state -> 4x the waves
+        unsigned grid = (unsigned)((4 * n + 255) / 256);
+        hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
+    } else {
+        // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
+        // at 2^17 leaves), 512 is slightly slower
+        const unsigned bs = n <= 65536 ? 64 : 256;
+        unsigned grid = (unsigned)((n + bs - 1) / bs);
+        hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
     }
-    for (uint32_t c0 = 0; c0 < ncols; c0 += chunk) {
-        const uint32_t c1 = c0 + chunk < ncols ? c0 + chunk : (uint32_t)ncols;
-        ProfScope ps(ctx, "poseidon_leaves");
-        if (quad) {
-            // thin launch: four lanes per state -> 4x the waves
-            unsigned grid = (unsigned)((4 * n + 255) / 256);
-            hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
-                               (uint32_t)ncols, n, d_digests, c0, c1, carry);
-        } else {
-            // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
-            // at 2^17 leaves), 512 is slightly slower
-            const unsigned bs = n <= 65536 ? 64 : 256;
-            unsigned grid = (unsigned)((n + bs - 1) / bs);
-            hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
-                               (uint32_t)ncols, n, d_digests, c0, c1, carry);
-        }
-        SIPP_CHECK_HIP(ctx, hipGetLastError());
-    }
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
 

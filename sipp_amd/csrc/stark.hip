@@ -91,9 +91,9 @@ static int read_cap(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, 
     return SIPP_OK;
 }
 
-// coeffs [ncols][n] natural -> lde [ncols][m] leaf order -> tree -> cap
-static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, uint32_t log_n, uint64_t* d_lde,
-                         uint64_t* d_tree, uint64_t* cap_host) {
+// coeffs [ncols][n] natural -> lde [ncols][m] leaf order -> tree (launches only; read_cap collects the cap)
+static int commit_coeffs_launch(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, uint32_t log_n, uint64_t* d_lde,
+                                uint64_t* d_tree) {
     const uint32_t log_m = log_n + ctx->cfg.rate_bits;
     int rc = sipp_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, ctx->cfg.rate_bits);
     if (rc == SIPP_E_UNSUPPORTED)
@@ -101,25 +101,33 @@ static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, 
                           NttDiag{gl::GEN, 0});
     SIPP_TRY(rc);
     SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
-    SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
-    return read_cap(ctx, d_tree, log_m, cap_host);
+    return sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height);
+}
+static int commit_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, uint32_t log_n, uint64_t* d_lde,
+                         uint64_t* d_tree, uint64_t* cap_host) {
+    SIPP_TRY(commit_coeffs_launch(ctx, d_coeffs, ncols, log_n, d_lde, d_tree));
+    return read_cap(ctx, d_tree, log_n + ctx->cfg.rate_bits, cap_host);
 }
 
-// values [ncols][n] natural -> coeffs -> lde -> tree -> cap
-static int commit_values(sipp_ctx* ctx, const uint64_t* d_values, size_t ncols, uint32_t log_n, uint64_t* d_coeffs,
-                         uint64_t* d_lde, uint64_t* d_tree, uint64_t* cap_host) {
+// values [ncols][n] natural -> coeffs -> lde -> tree (launches only)
+static int commit_values_launch(sipp_ctx* ctx, const uint64_t* d_values, size_t ncols, uint32_t log_n, uint64_t* d_coeffs,
+                                uint64_t* d_lde, uint64_t* d_tree) {
     const size_t n = (size_t)1 << log_n;
     const uint32_t log_m = log_n + ctx->cfg.rate_bits;
     const int rc = sipp_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, ctx->cfg.rate_bits);
     if (rc == SIPP_OK) {   // fused: coefficients and LDE are both in place
         SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
-        SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
-        return read_cap(ctx, d_tree, log_m, cap_host);
+        return sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height);
     }
     if (rc != SIPP_E_UNSUPPORTED) return rc;
     SIPP_TRY(sipp_bitrev_cols(ctx, d_values, n, d_coeffs, n, log_n, ncols));
     SIPP_TRY(sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, true, NttDiag{}));
-    return commit_coeffs(ctx, d_coeffs, ncols, log_n, d_lde, d_tree, cap_host);
+    return commit_coeffs_launch(ctx, d_coeffs, ncols, log_n, d_lde, d_tree);
+}
+static int commit_values(sipp_ctx* ctx, const uint64_t* d_values, size_t ncols, uint32_t log_n, uint64_t* d_coeffs,
+                         uint64_t* d_lde, uint64_t* d_tree, uint64_t* cap_host) {
+    SIPP_TRY(commit_values_launch(ctx, d_values, ncols, log_n, d_coeffs, d_lde, d_tree));
+    return read_cap(ctx, d_tree, log_n + ctx->cfg.rate_bits, cap_host);
 }
 
 // ---- small host FFT for the public-input polynomials (size = number of IOs) ----------------------------
@@ -314,17 +322,6 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         return sipp_fail(ctx, SIPP_E_WITNESS, "IO record holds a non-canonical field element (>= p)");
     SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
     SIPP_TRY(sipp_trace_fill(ctx, a, d_ios, s.num_io, log_n, d_trace, d_err));
-    // Fiat-Shamir starts from the statement (hashed on the host while the trace-fill kernels run)
-    host::Challenger ch;
-    {
-        const uint64_t st[16] = {(uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.rate_bits,
-                                 cfg.cap_height, cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries,
-                                 cfg.num_challenges, cfg.pow_rule, (uint64_t)a->pi_per_io, 0};
-        uint64_t root[4];
-        ch.observe_many(st, 16);
-        pi_root(pis.data(), s.num_io, a->pi_per_io, root);
-        ch.observe_many(root, 4);
-    }
     {
         int h_err = 0;
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -340,7 +337,19 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     uint64_t cap_host[4 << 8];
 
     // ---- 1. trace commitment ----
-    SIPP_TRY(commit_values(ctx, d_trace, (size_t)W, log_n, T.coeffs, T.lde, T.tree, cap_host));
+    SIPP_TRY(commit_values_launch(ctx, d_trace, (size_t)W, log_n, T.coeffs, T.lde, T.tree));
+    // Fiat-Shamir starts from the statement (hashed on the host while the commitment kernels run)
+    host::Challenger ch;
+    {
+        const uint64_t st[16] = {(uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.rate_bits,
+                                 cfg.cap_height, cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries,
+                                 cfg.num_challenges, cfg.pow_rule, (uint64_t)a->pi_per_io, 0};
+        uint64_t root[4];
+        ch.observe_many(st, 16);
+        pi_root(pis.data(), s.num_io, a->pi_per_io, root);
+        ch.observe_many(root, 4);
+    }
+    SIPP_TRY(read_cap(ctx, T.tree, log_m, cap_host));
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
     tick("trace commit");
@@ -611,8 +620,7 @@ size_t sipp_workspace_bytes(int kind, size_t num_io) {
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
                    + 3 * 8 * m                                          // three Merkle trees
                    + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
-                   + 80 * n                                             // power tables, FRI layers, combine partials
-                   + 12 * m;                                            // sponge states between column-chunked leaf-hash launches
+                   + 80 * n;                                            // power tables, FRI layers, combine partials
     size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
                    + n * 400                                            // Jacobian row scratch of the curve chains
                    + ((size_t)64 << 20);
@@ -832,7 +840,8 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     static int gate_mask = -1;
     if (gate_mask < 0) {
         const char* e = getenv("SIPP_INSTANCE_GATE");
-        gate_mask = (e ? atoi(e) : ((1 << SIPP_G1_EXP) | (1 << SIPP_FQ12_EXP))) & ~(1 << first);
+        // round 2 (fused LDE kernels): only G1 waits -- 69.0-69.6 ms per n = 128 instance against 70.0-70.6 with Fq12 gated too
+        gate_mask = (e ? atoi(e) : (1 << SIPP_G1_EXP)) & ~(1 << first);
     }
     const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     sipp_gate gate;
