@@ -39,12 +39,24 @@ out = {
     "calibration": "scripts/ubench/fetch_calib.hip: 1 GiB read with this kernel's 8-B-per-lane column pattern reports FETCH_SIZE = 524,293.5 KB (exactly 1/2, as MI355X_MICROARCH.md section HBM says for wide coalesced reads); 1 GiB written reports WRITE_SIZE = 1,048,576 KB (exact)",
     "fetch_correction": 2.0,
     "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0 / launches,
-    "ntt_pass": {"launches": nf.get("ntt_pass_kernel", 0), "FETCH_SIZE_kb_sum": f["ntt_pass_kernel"]["FETCH_SIZE"],
-                 "WRITE_SIZE_kb_sum": w["ntt_pass_kernel"]["WRITE_SIZE"]},
 }
+NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel")
+steps_profiled = 3   # --steps 2 --warmup 1
+out["ntt"] = {"kernels": {k: {"launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"]}
+                          for k in NTT if nf.get(k, 0)},
+              "traffic_bytes_per_instance": sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / steps_profiled,
+              "note": "all NTT / LDE kernels of one n = 128 instance (3 instances profiled: 1 warm-up + 2 steps); FETCH_SIZE x2"}
+out["merkle"] = {k: nf.get(k, 0) // steps_profiled for k in ("merkle_subtree_kernel", "merkle_level_kernel", "merkle_level_quad_kernel") if nf.get(k, 0)}
 import os
 if os.path.exists("%s/pmc_v/run_counter_collection.csv" % src):
     v, nv = counters("pmc_v")
+    tot = sum(x["SQ_INSTS_VALU"] for x in v.values())
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
+               "instances_profiled": steps_profiled, "valu_insts_per_instance": tot / steps_profiled,
+               "per_kernel": {k: {"SQ_INSTS_VALU_per_instance": x["SQ_INSTS_VALU"] / steps_profiled, "share": x["SQ_INSTS_VALU"] / tot,
+                                  "launches_per_instance": nv[k] / steps_profiled}
+                              for k, x in sorted(v.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]) if x["SQ_INSTS_VALU"] > 0}},
+              open(dst + "_valu_by_kernel.json", "w"), indent=1)
     out["leaf_valu_insts_per_launch"] = sum(v[k]["SQ_INSTS_VALU"] for k in leaf) / max(1, sum(nv[k] for k in leaf))
     out["leaf_valu_note"] = "SQ_INSTS_VALU (wave-level VALU instructions) of both leaf-hash kernels, bench.py --steps 2 --warmup 1, per launch"
 i, ni = counters("pmc_i")
