@@ -26,6 +26,7 @@
  *   public_inputs[num_io x pi_per_io]
  */
 #include "stark.h"
+#include "fri.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,50 +96,27 @@ static void observe_statement(orc_challenger *ch, int kind, unsigned log_n, size
     orc_chal_observe_many(ch, root, 4);
 }
 
-/* proof-of-work response for candidate w (two recollections of upstream kept as data):
- *   ORC_POW_DUPLEX: observe w, response = next challenge                    (plonky2 fri/prover.rs, 2023)
- *   ORC_POW_HASH  : response = hash_no_pad(challenger.get_hash() || w)[0]   (plonky2 before the duplex grind) */
-static uint64_t pow_response(const orc_challenger *ch, const uint64_t cur_hash[4], unsigned rule, uint64_t w) {
-    if (rule == ORC_POW_HASH) {
-        uint64_t in[5] = {cur_hash[0], cur_hash[1], cur_hash[2], cur_hash[3], w}, out[4];
-        orc_hash_no_pad(in, 5, out);
-        return out[0];
-    }
-    orc_challenger c2 = *ch;
-    orc_chal_observe(&c2, w);
-    return orc_chal_get(&c2);
-}
-
-static unsigned fri_rounds(const orc_config *c, unsigned degree_bits) {
-    unsigned r = 0;
-    while (degree_bits > c->final_poly_bits && degree_bits + c->rate_bits - c->arity_bits >= c->cap_height) {
-        r++;
-        degree_bits -= c->arity_bits;
-    }
-    return r;
-}
-
 /* ---------------- small helpers ---------------- */
-typedef struct { uint64_t *w; size_t len, cap; } wbuf;
-static void wb_push(wbuf *b, const uint64_t *v, size_t n) {
-    if (b->len + n > b->cap) {
-        while (b->len + n > b->cap) b->cap = b->cap ? b->cap * 2 : 4096;
-        b->w = (uint64_t *)realloc(b->w, b->cap * sizeof(uint64_t));
-    }
-    memcpy(b->w + b->len, v, n * sizeof(uint64_t));
-    b->len += n;
-}
+typedef orc_wbuf wbuf;
+#define wb_push orc_wb_push
 static void wb_push1(wbuf *b, uint64_t v) { wb_push(b, &v, 1); }
+
+static void fri_params_of(const orc_config *c, unsigned log_n, orc_fri_params *p) {
+    memset(p, 0, sizeof *p);
+    p->rate_bits = c->rate_bits; p->cap_height = c->cap_height; p->pow_bits = c->pow_bits; p->num_queries = c->num_queries;
+    p->pow_rule = c->pow_rule; p->hiding = 0;
+    orc_fri_const_arity(p, c->arity_bits, c->final_poly_bits, log_n);
+}
 static void wb_push_ext(wbuf *b, gl2 v) { wb_push1(b, v.c0); wb_push1(b, v.c1); }
+static unsigned fri_rounds(const orc_config *c, unsigned degree_bits) {
+    orc_fri_params p;
+    fri_params_of(c, degree_bits, &p);
+    return p.n_rounds;
+}
 
 static gl2 eval_poly_base(const uint64_t *c, size_t n, gl2 x) {
     gl2 acc = gl2_from(0);
     for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, x), gl2_from(c[i]));
-    return acc;
-}
-static gl2 eval_poly_ext(const gl2 *c, size_t n, gl2 x) {
-    gl2 acc = gl2_from(0);
-    for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, x), c[i]);
     return acc;
 }
 
@@ -157,82 +135,6 @@ static void selectors_ext(unsigned log_n, gl2 x, gl2 *lf, gl2 *ll, gl2 *zl) {
     *lf = gl2_mul(gl2_scale(zh, ninv), gl2_inv(gl2_sub(x, gl2_from(1))));
     *ll = gl2_mul(gl2_scale(zh, gl_mul(ninv, gi)), gl2_inv(gl2_sub(x, gl2_from(gi))));
     *zl = gl2_sub(x, gl2_from(gi));
-}
-
-/* ---------------- FRI prover ---------------- */
-typedef struct {
-    unsigned n_rounds;
-    orc_merkle **trees;
-    gl2 *final_poly;
-    size_t final_len;
-    uint64_t pow_witness;
-} fri_state;
-
-static void fri_free(fri_state *f) {
-    for (unsigned r = 0; r < f->n_rounds; r++) orc_merkle_free(f->trees[r]);
-    free(f->trees); free(f->final_poly);
-}
-
-/* final: N ext coefficients (already multiplied by X) */
-static void fri_commit(const orc_config *cfg, unsigned log_n, const gl2 *final_coeffs, orc_challenger *ch, fri_state *out,
-                       wbuf *proof) {
-    unsigned log_m = log_n + cfg->rate_bits;
-    size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
-    unsigned rounds = fri_rounds(cfg, log_n);
-    out->n_rounds = rounds;
-    out->trees = (orc_merkle **)calloc(rounds ? rounds : 1, sizeof(orc_merkle *));
-    gl2 *coeffs = (gl2 *)calloc(m, sizeof(gl2));
-    memcpy(coeffs, final_coeffs, n * sizeof(gl2));
-    size_t len = m;
-    unsigned log_len = log_m;
-    uint64_t shift = GL_GEN;
-    gl2 *values = (gl2 *)malloc(m * sizeof(gl2));
-    for (unsigned r = 0; r <= rounds; r++) {
-        /* values = coset_fft(coeffs, shift) */
-        uint64_t s = 1;
-        for (size_t i = 0; i < len; i++) { values[i] = gl2_scale(coeffs[i], s); s = gl_mul(s, shift); }
-        orc_fft_ext(values, log_len);
-        if (r == rounds) break;
-        /* bit-reverse, chunk by 16, flatten, commit */
-        size_t n_leaves = len >> 4;
-        uint64_t *leaves = (uint64_t *)malloc(len * 2 * sizeof(uint64_t));
-        for (size_t j = 0; j < len; j++) {
-            gl2 v = values[bitrev32((uint32_t)j, log_len)];
-            leaves[2 * j] = v.c0; leaves[2 * j + 1] = v.c1;
-        }
-        out->trees[r] = orc_merkle_new(leaves, log_len - 4, 32, cfg->cap_height);
-        free(leaves);
-        size_t cap_n = (size_t)1 << out->trees[r]->cap_height;
-        orc_chal_observe_cap(ch, out->trees[r]->cap, cap_n);
-        wb_push(proof, out->trees[r]->cap, cap_n * 4);
-        gl2 beta = orc_chal_get_ext(ch);
-        for (size_t k = 0; k < n_leaves; k++) {
-            gl2 acc = gl2_from(0);
-            for (int i = 15; i >= 0; i--) acc = gl2_add(gl2_mul(acc, beta), coeffs[16 * k + i]);
-            coeffs[k] = acc;
-        }
-        len = n_leaves; log_len -= 4;
-        shift = gl_pow(shift, 16);
-    }
-    free(values);
-    out->final_len = len >> cfg->rate_bits;
-    out->final_poly = (gl2 *)malloc(out->final_len * sizeof(gl2));
-    memcpy(out->final_poly, coeffs, out->final_len * sizeof(gl2));
-    free(coeffs);
-    for (size_t i = 0; i < out->final_len; i++) { orc_chal_observe_ext(ch, out->final_poly[i]); wb_push_ext(proof, out->final_poly[i]); }
-    /* proof of work: smallest witness */
-    uint64_t w = 0, cur_hash[4] = {0, 0, 0, 0};
-    if (cfg->pow_rule == ORC_POW_HASH) for (int i = 0; i < 4; i++) cur_hash[i] = orc_chal_get(ch);
-    for (;; w++) {
-        uint64_t resp = pow_response(ch, cur_hash, cfg->pow_rule, w);
-        if (cfg->pow_bits == 0 || (resp >> (64 - cfg->pow_bits)) == 0) break;
-    }
-    out->pow_witness = w;
-    if (cfg->pow_rule != ORC_POW_HASH) {
-        orc_chal_observe(ch, w);
-        (void)orc_chal_get(ch);
-    }
-    wb_push1(proof, w);
 }
 
 /* ---------------- test hook: one-shot tampering with a committed oracle the caller cannot reach ----------------
@@ -267,7 +169,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     const int kind = t->air->kind;
     const orc_air_t *a = t->air;
     const unsigned log_n = t->log_n, log_m = log_n + cfg->rate_bits;
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
+    const size_t n = (size_t)1 << log_n;
     const int W = t->width, nc = a->n_checked, P = 2 * nc, Q = 4, nm = a->n_main;
     const uint64_t g = gl_root_of_unity(log_n);
     wbuf pf = {0, 0, 0};
@@ -321,21 +223,26 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     alpha[0] = orc_chal_get(&ch); alpha[1] = orc_chal_get(&ch);
     /* 4. quotient: evaluate all constraints on the 2N coset */
     const uint64_t *tl = orc_batch_leaves(bt), *zl = orc_batch_leaves(bz);
-    /* aux LDE, natural order: [n_aux][m] */
-    uint64_t *aux_lde = (uint64_t *)malloc((size_t)(a->n_aux ? a->n_aux : 1) * m * sizeof(uint64_t));
+    /* The quotient is evaluated on the coset 7 <w_2N> whatever the blowup: its points are the natural LDE indices that are
+     * multiples of 2^(rate_bits - 1), i.e. exactly the FIRST 2N leaves in leaf order (bit-reversal moves the zero low bits
+     * to the top), at leaf position bitrev_(log_n + 1)(iq) for quotient-domain index iq. */
+    const unsigned log_mq = log_n + 1;
+    const size_t mq = (size_t)1 << log_mq;
+    /* aux LDE, natural order: [n_aux][mq] */
+    uint64_t *aux_lde = (uint64_t *)malloc((size_t)(a->n_aux ? a->n_aux : 1) * mq * sizeof(uint64_t));
     {
         size_t nio = t->num_io;
 #pragma omp parallel for schedule(dynamic)
         for (int ai = 0; ai < a->n_aux; ai++) {
             uint64_t *co = (uint64_t *)calloc(n, sizeof(uint64_t));
             orc_aux_coeffs(a, t->pis, nio, log_n, ai, co);
-            orc_coset_lde(co, log_n, cfg->rate_bits, GL_GEN, aux_lde + (size_t)ai * m);
+            orc_coset_lde(co, log_n, 1, GL_GEN, aux_lde + (size_t)ai * mq);
             free(co);
         }
     }
-    uint64_t *qv = (uint64_t *)malloc(2 * m * sizeof(uint64_t)); /* [2][m] natural order */
+    uint64_t *qv = (uint64_t *)malloc(2 * mq * sizeof(uint64_t)); /* [2][mq] natural order */
     {
-        uint64_t wm = gl_root_of_unity(log_m);
+        uint64_t wm = gl_root_of_unity(log_mq);
         /* x^N on the coset takes 2 values */
         uint64_t sN = gl_pow(GL_GEN, n);
         uint64_t zh_inv[2] = {gl_inv(gl_sub(sN, 1)), gl_inv(gl_sub(gl_neg(sN), 1))};
@@ -343,16 +250,16 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
         {
             uint64_t *aux = (uint64_t *)malloc(sizeof(uint64_t) * (a->n_aux ? a->n_aux : 1));
 #pragma omp for schedule(static)
-            for (size_t i = 0; i < m; i++) {
+            for (size_t i = 0; i < mq; i++) {
                 uint64_t x = gl_mul(GL_GEN, gl_pow(wm, i));
-                size_t j = bitrev32((uint32_t)i, log_m), jn = bitrev32((uint32_t)((i + 2) & (m - 1)), log_m);
+                size_t j = bitrev32((uint32_t)i, log_mq), jn = bitrev32((uint32_t)((i + 2) & (mq - 1)), log_mq);
                 uint64_t per[ORC_N_PERIODIC], lf, ll, zlast, out[2];
                 for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = orc_periodic_base(log_n, k, x);
                 selectors_base(log_n, x, &lf, &ll, &zlast);
-                for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = aux_lde[(size_t)ai * m + i];
+                for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = aux_lde[(size_t)ai * mq + i];
                 orc_eval_base(a, tl + j * W, tl + jn * W, aux, per, zl + j * P, zl + jn * P, lf, ll, zlast, alpha, beta, gamma, out);
                 qv[i] = gl_mul(out[0], zh_inv[i & 1]);
-                qv[m + i] = gl_mul(out[1], zh_inv[i & 1]);
+                qv[mq + i] = gl_mul(out[1], zh_inv[i & 1]);
             }
             free(aux);
         }
@@ -363,10 +270,10 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     {
         uint64_t si = gl_inv(GL_GEN);
         for (int i = 0; i < 2; i++) {
-            uint64_t *p = qv + (size_t)i * m;
-            orc_ifft(p, log_m);
+            uint64_t *p = qv + (size_t)i * mq;
+            orc_ifft(p, log_mq);
             uint64_t s = 1;
-            for (size_t k = 0; k < m; k++) { p[k] = gl_mul(p[k], s); s = gl_mul(s, si); }
+            for (size_t k = 0; k < mq; k++) { p[k] = gl_mul(p[k], s); s = gl_mul(s, si); }
             memcpy(qc + (size_t)(2 * i) * n, p, n * sizeof(uint64_t));
             memcpy(qc + (size_t)(2 * i + 1) * n, p + n, n * sizeof(uint64_t));
         }
@@ -396,66 +303,23 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     for (int c = 0; c < Q; c++) orc_chal_observe_ext(&ch, op[2 * W + 2 * P + c]);
     for (int c = 0; c < W; c++) orc_chal_observe_ext(&ch, op[W + c]);
     for (int c = 0; c < P; c++) orc_chal_observe_ext(&ch, op[2 * W + P + c]);
-    /* 6. FRI: final = alpha^len1 * q0 + q1, then * X */
+    /* 6. FRI (oracle/fri.c, the generic PolynomialBatch::prove_openings): batch 0 = everything at zeta, batch 1 = trace | Z at g zeta */
     gl2 fa = orc_chal_get_ext(&ch);
-    gl2 *fin = (gl2 *)calloc(n, sizeof(gl2));
     {
-        gl2 *comp0 = (gl2 *)calloc(n, sizeof(gl2)), *comp1 = (gl2 *)calloc(n, sizeof(gl2));
-        gl2 ap = gl2_from(1);
-        /* batch 0: trace, z, quotient ; batch 1: trace, z  (powers restart per batch) */
-        gl2 ap1 = gl2_from(1);
-        for (int c = 0; c < W + P + Q; c++) {
-            const uint64_t *co = c < W ? ct + (size_t)c * n : c < W + P ? cz + (size_t)(c - W) * n : cq + (size_t)(c - W - P) * n;
-            for (size_t k = 0; k < n; k++) comp0[k] = gl2_add(comp0[k], gl2_scale(ap, co[k]));
-            if (c < W + P) {
-                for (size_t k = 0; k < n; k++) comp1[k] = gl2_add(comp1[k], gl2_scale(ap1, co[k]));
-                ap1 = gl2_mul(ap1, fa);
-            }
-            ap = gl2_mul(ap, fa);
-        }
-        /* divide_by_linear: q_{k-1} = F_k + z q_k */
-        gl2 *q0 = (gl2 *)calloc(n, sizeof(gl2)), *q1 = (gl2 *)calloc(n, sizeof(gl2));
-        gl2 acc = gl2_from(0);
-        for (size_t k = n; k-- > 1;) { acc = gl2_add(comp0[k], gl2_mul(acc, zeta)); q0[k - 1] = acc; }
-        acc = gl2_from(0);
-        for (size_t k = n; k-- > 1;) { acc = gl2_add(comp1[k], gl2_mul(acc, gzeta)); q1[k - 1] = acc; }
-        gl2 shift1 = gl2_pow(fa, (uint64_t)(W + P)); /* alpha^len(batch1) */
-        /* final = (q0 * alpha^len1 + q1) * X */
-        for (size_t k = 0; k + 1 < n; k++) fin[k + 1] = gl2_add(gl2_mul(q0[k], shift1), q1[k]);
-        free(comp0); free(comp1); free(q0); free(q1);
-    }
-    fri_state fs;
-    size_t fri_off = pf.len;
-    (void)fri_off;
-    fri_commit(cfg, log_n, fin, &ch, &fs, &pf);
-    free(fin);
-    pf.w[9] = fs.final_len;
-    /* queries */
-    {
-        orc_merkle *or3[3] = {bt->tree, bz->tree, bq->tree};
-        unsigned nsib0 = log_m - bt->tree->cap_height;
-        uint64_t *sib = (uint64_t *)malloc((size_t)(log_m + 1) * 4 * sizeof(uint64_t));
-        for (unsigned qi = 0; qi < cfg->num_queries; qi++) {
-            size_t x = (size_t)(orc_chal_get(&ch) % m);
-            for (int o = 0; o < 3; o++) {
-                wb_push(&pf, or3[o]->leaves + x * or3[o]->leaf_len, or3[o]->leaf_len);
-                size_t ns = orc_merkle_prove(or3[o], x, sib);
-                if (ns != nsib0) { err = -21; }
-                wb_push(&pf, sib, ns * 4);
-            }
-            size_t xi = x;
-            for (unsigned r = 0; r < fs.n_rounds; r++) {
-                xi >>= 4;
-                wb_push(&pf, fs.trees[r]->leaves + xi * 32, 32);
-                size_t ns = orc_merkle_prove(fs.trees[r], xi, sib);
-                wb_push(&pf, sib, ns * 4);
-            }
-        }
-        free(sib);
+        const orc_batch *oracles[3] = {bt, bz, bq};
+        const orc_poly_range r0[3] = {{0, 0, (uint32_t)W}, {1, 0, (uint32_t)P}, {2, 0, (uint32_t)Q}};
+        const orc_fri_batch batches[2] = {{zeta, 3, r0}, {gzeta, 2, r0}};
+        orc_fri_params fp;
+        fri_params_of(cfg, log_n, &fp);
+        gl2 *fin = orc_fri_final_poly(oracles, batches, 2, log_n, fa);
+        size_t flen = 0;
+        int frc = orc_fri_prove_core(oracles, 3, log_n, &fp, fin, &ch, &pf, &flen);
+        free(fin);
+        if (frc) err = frc;
+        pf.w[9] = flen;
     }
     for (size_t k = 0; k < t->num_io * (size_t)a->pi_per_io; k++) wb_push1(&pf, t->pis[k]);
     pf.w[12] = pf.len;
-    fri_free(&fs);
     free(op);
 done:
     orc_batch_free(bt); orc_batch_free(bz); orc_batch_free(bq);
@@ -490,8 +354,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len)
         return -102;
-    const unsigned log_m = log_n + cfg->rate_bits;
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
+    const size_t n = (size_t)1 << log_n;
     const unsigned rounds = fri_rounds(cfg, log_n);
     if (h[8] != rounds) return -103;
     const size_t cap_n = (size_t)1 << cfg->cap_height;
@@ -550,108 +413,25 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
             if (!gl2_eq(out[i], gl2_mul(zh, qz))) { rc = -110 - i; goto out; }
         }
     }
-    /* FRI */
+    /* FRI (oracle/fri.c) */
     {
         gl2 fa = orc_chal_get_ext(&ch);
-        const uint64_t *caps[16];
-        gl2 betas[16];
-        for (unsigned r = 0; r < rounds; r++) {
-            caps[r] = rb_take(&rb, cap_n * 4);
-            orc_chal_observe_cap(&ch, caps[r], cap_n);
-            betas[r] = orc_chal_get_ext(&ch);
-        }
-        size_t flen = (size_t)h[9];
-        if (flen != ((n >> (4 * rounds)))) { rc = -120; goto out; }
-        gl2 *fpoly = (gl2 *)malloc(flen * sizeof(gl2));
-        for (size_t i = 0; i < flen; i++) { fpoly[i] = rb_ext(&rb); orc_chal_observe_ext(&ch, fpoly[i]); }
-        uint64_t pw = *rb_take(&rb, 1), resp;
-        if (cfg->pow_rule == ORC_POW_HASH) {
-            uint64_t cur_hash[4];
-            for (int i = 0; i < 4; i++) cur_hash[i] = orc_chal_get(&ch);
-            resp = pow_response(&ch, cur_hash, ORC_POW_HASH, pw);
-        } else {
-            orc_chal_observe(&ch, pw);
-            resp = orc_chal_get(&ch);
-        }
-        if (cfg->pow_bits && (resp >> (64 - cfg->pow_bits)) != 0) { free(fpoly); rc = -121; goto out; }
-        /* precomputed reduced openings */
-        gl2 red0 = gl2_from(0), red1 = gl2_from(0);
-        {
-            gl2 ap = gl2_from(1);
-            for (int c = 0; c < W; c++) { red0 = gl2_add(red0, gl2_mul(ap, op[c])); ap = gl2_mul(ap, fa); }
-            for (int c = 0; c < P; c++) { red0 = gl2_add(red0, gl2_mul(ap, op[2 * W + c])); ap = gl2_mul(ap, fa); }
-            for (int c = 0; c < Q; c++) { red0 = gl2_add(red0, gl2_mul(ap, op[2 * W + 2 * P + c])); ap = gl2_mul(ap, fa); }
-            ap = gl2_from(1);
-            for (int c = 0; c < W; c++) { red1 = gl2_add(red1, gl2_mul(ap, op[W + c])); ap = gl2_mul(ap, fa); }
-            for (int c = 0; c < P; c++) { red1 = gl2_add(red1, gl2_mul(ap, op[2 * W + P + c])); ap = gl2_mul(ap, fa); }
-        }
-        gl2 shift1 = gl2_pow(fa, (uint64_t)(W + P));
         gl2 gzeta = gl2_scale(zeta, gl_root_of_unity(log_n));
-        unsigned nsib0 = log_m - cfg->cap_height;
-        uint64_t wm = gl_root_of_unity(log_m);
-        int ncols3[3] = {W, P, Q};
         const uint64_t *caps3[3] = {trace_cap, z_cap, q_cap};
-        for (unsigned qi = 0; qi < cfg->num_queries && !rc; qi++) {
-            size_t x = (size_t)(orc_chal_get(&ch) % m);
-            const uint64_t *rows[3];
-            for (int o = 0; o < 3; o++) {
-                rows[o] = rb_take(&rb, (size_t)ncols3[o]);
-                const uint64_t *sib = rb_take(&rb, (size_t)nsib0 * 4);
-                if (rb.bad) { rc = -122; break; }
-                if (!orc_merkle_verify(rows[o], (size_t)ncols3[o], x, sib, nsib0, caps3[o], cfg->cap_height)) { rc = -123 - o; break; }
-            }
-            if (rc) break;
-            uint64_t sx = gl_mul(GL_GEN, gl_pow(wm, bitrev32((uint32_t)x, log_m)));
-            /* fri_combine_initial */
-            gl2 e0 = gl2_from(0), e1 = gl2_from(0), ap = gl2_from(1), ap1 = gl2_from(1);
-            for (int c = 0; c < W + P + Q; c++) {
-                uint64_t v = c < W ? rows[0][c] : c < W + P ? rows[1][c - W] : rows[2][c - W - P];
-                e0 = gl2_add(e0, gl2_scale(ap, v));
-                ap = gl2_mul(ap, fa);
-                if (c < W + P) { e1 = gl2_add(e1, gl2_scale(ap1, v)); ap1 = gl2_mul(ap1, fa); }
-            }
-            gl2 sxe = gl2_from(sx);
-            gl2 t0 = gl2_mul(gl2_sub(e0, red0), gl2_inv(gl2_sub(sxe, zeta)));
-            gl2 t1 = gl2_mul(gl2_sub(e1, red1), gl2_inv(gl2_sub(sxe, gzeta)));
-            gl2 old = gl2_scale(gl2_add(gl2_mul(t0, shift1), t1), sx); /* final poly was multiplied by X */
-            size_t xi = x;
-            uint64_t sub_x = sx;
-            for (unsigned r = 0; r < rounds; r++) {
-                const uint64_t *ev = rb_take(&rb, 32);
-                unsigned log_tree = log_m - 4 * (r + 1);
-                unsigned ns = log_tree > cfg->cap_height ? log_tree - cfg->cap_height : 0;
-                const uint64_t *sib = rb_take(&rb, (size_t)ns * 4);
-                if (rb.bad) { rc = -130; break; }
-                size_t within = xi & 15;
-                gl2 evs[16];
-                for (int k = 0; k < 16; k++) evs[k] = gl2_make(ev[2 * k], ev[2 * k + 1]);
-                if (!gl2_eq(evs[within], old)) { rc = -131; break; }
-                /* interpolate the coset {coset_start * g16^i} with values evs[bitrev4(i)] and evaluate at beta */
-                uint64_t g16 = gl_root_of_unity(4);
-                uint64_t rev_within = bitrev32((uint32_t)within, 4);
-                uint64_t coset_start = gl_mul(sub_x, gl_pow(g16, 16 - rev_within));
-                gl2 acc = gl2_from(0);
-                uint64_t pts[16];
-                for (int i = 0; i < 16; i++) pts[i] = gl_mul(coset_start, gl_pow(g16, (uint64_t)i));
-                for (int i = 0; i < 16; i++) {
-                    gl2 numr = evs[bitrev32((uint32_t)i, 4)];
-                    uint64_t den = 1;
-                    for (int k = 0; k < 16; k++) {
-                        if (k == i) continue;
-                        numr = gl2_mul(numr, gl2_sub(betas[r], gl2_from(pts[k])));
-                        den = gl_mul(den, gl_sub(pts[i], pts[k]));
-                    }
-                    acc = gl2_add(acc, gl2_scale(numr, gl_inv(den)));
-                }
-                old = acc;
-                xi >>= 4;
-                if (!orc_merkle_verify(ev, 32, xi, sib, ns, caps[r], cfg->cap_height)) { rc = -132; break; }
-                sub_x = gl_pow(sub_x, 16);
-            }
-            if (rc) break;
-            if (!gl2_eq(eval_poly_ext(fpoly, flen, gl2_from(sub_x)), old)) { rc = -133; break; }
-        }
-        free(fpoly);
+        const int ncols3[3] = {W, P, Q}, salt3[3] = {0, 0, 0};
+        const orc_poly_range r0[3] = {{0, 0, (uint32_t)W}, {1, 0, (uint32_t)P}, {2, 0, (uint32_t)Q}};
+        const orc_fri_batch batches[2] = {{zeta, 3, r0}, {gzeta, 2, r0}};
+        /* opened values in batch order: local | z | quotient, then next | z_next */
+        gl2 *o0 = (gl2 *)malloc((size_t)(W + P + Q) * sizeof(gl2)), *o1 = (gl2 *)malloc((size_t)(W + P) * sizeof(gl2));
+        for (int c = 0; c < W; c++) { o0[c] = op[c]; o1[c] = op[W + c]; }
+        for (int c = 0; c < P; c++) { o0[W + c] = op[2 * W + c]; o1[W + c] = op[2 * W + P + c]; }
+        for (int c = 0; c < Q; c++) o0[W + P + c] = op[2 * W + 2 * P + c];
+        const gl2 *opened[2] = {o0, o1};
+        orc_fri_params fp;
+        fri_params_of(cfg, log_n, &fp);
+        if ((size_t)h[9] != (n >> (fp.n_rounds * cfg->arity_bits))) rc = -120;
+        if (!rc) rc = orc_fri_verify_core(proof, len, &rb.pos, caps3, ncols3, salt3, 3, batches, opened, 2, log_n, &fp, fa, &ch);
+        free(o0); free(o1);
     }
     if (!rc && rb.pos + n_pi != len) rc = -140;
 out:

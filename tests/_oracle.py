@@ -226,3 +226,133 @@ def stark_verify(proof, cfg=None):
     L.orc_stark_verify.argtypes = [u64p, C.c_size_t, C.POINTER(OrcConfig)]
     L.orc_stark_verify.restype = C.c_int
     return L.orc_stark_verify(proof, len(proof), C.byref(cfg))
+
+
+# ---------------- generic opening proofs (oracle/fri.c) ----------------
+class OrcFriParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "num_queries", "pow_rule", "hiding", "n_rounds")] + \
+               [("arity_bits", C.c_uint32 * 32)]
+
+
+def fri_params(rate_bits=1, cap_height=4, pow_bits=16, num_queries=84, pow_rule=0, hiding=0, arity_bits=4, final_poly_bits=5,
+               degree_bits=None, arities=None):
+    """FriParams: ConstantArityBits(arity_bits, final_poly_bits) for `degree_bits`, or an explicit list `arities`"""
+    p = OrcFriParams()
+    p.rate_bits, p.cap_height, p.pow_bits, p.num_queries, p.pow_rule, p.hiding = rate_bits, cap_height, pow_bits, num_queries, pow_rule, hiding
+    if arities is not None:
+        p.n_rounds = len(arities)
+        for i, a in enumerate(arities):
+            p.arity_bits[i] = a
+    else:
+        L = load()
+        L.orc_fri_const_arity.argtypes = [C.POINTER(OrcFriParams), C.c_uint, C.c_uint, C.c_uint]
+        L.orc_fri_const_arity(C.byref(p), arity_bits, final_poly_bits, degree_bits)
+    return p
+
+
+class OrcPolyRange(C.Structure):
+    _fields_ = [("oracle", C.c_uint32), ("col_begin", C.c_uint32), ("col_end", C.c_uint32)]
+
+
+class OrcFriBatch(C.Structure):
+    _fields_ = [("point", C.c_uint64 * 2), ("n_ranges", C.c_uint32), ("ranges", C.POINTER(OrcPolyRange))]
+
+
+class OrcChallenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_size_t), ("out_buf", C.c_uint64 * 8),
+                ("n_out", C.c_size_t)]
+
+
+def challenger(observe=()):
+    L = load()
+    ch = OrcChallenger()
+    L.orc_chal_init(C.byref(ch))
+    L.orc_chal_observe.argtypes = [C.POINTER(OrcChallenger), C.c_uint64]
+    for e in observe:
+        L.orc_chal_observe(C.byref(ch), int(e))
+    return ch
+
+
+def make_batches(batches):
+    """[(point (c0, c1), [(oracle, col_begin, col_end), ...]), ...] -> ctypes array (keeps the range arrays alive)"""
+    arr = (OrcFriBatch * len(batches))()
+    keep = []
+    for i, (pt, ranges) in enumerate(batches):
+        r = (OrcPolyRange * len(ranges))(*[OrcPolyRange(*x) for x in ranges])
+        keep.append(r)
+        arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+        arr[i].n_ranges = len(ranges)
+        arr[i].ranges = r
+    arr._keep = keep
+    return arr
+
+
+class SaltedBatch:
+    """orc_batch_salted: PolynomialBatch with `blinding` -- SALT_SIZE extra words per leaf, supplied by the caller"""
+
+    def __init__(self, data, log_n, rate_bits, cap_height, from_values=True, salt=None):
+        L = load()
+        L.orc_batch_salted.restype = C.c_void_p
+        L.orc_batch_salted.argtypes = [u64p, C.c_int, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_size_t]
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        self.ncols, self.log_n, self.rate_bits = data.shape[0], log_n, rate_bits
+        self.n_salt = 0 if salt is None else salt.shape[0]
+        self.salt = None if salt is None else np.ascontiguousarray(salt, dtype=np.uint64)
+        self.h = L.orc_batch_salted(data, int(from_values), self.ncols, log_n, rate_bits, cap_height,
+                                    None if salt is None else self.salt.ctypes.data, self.n_salt)
+        self.cap_height = min(cap_height, log_n + rate_bits)
+        self.L = L
+
+    @property
+    def cap(self):
+        return np.ctypeslib.as_array(self.L.orc_batch_cap(self.h), shape=((1 << self.cap_height) * 4,)).reshape(-1, 4).copy()
+
+    @property
+    def leaves(self):
+        ll = self.ncols + self.n_salt
+        m = 1 << (self.log_n + self.rate_bits)
+        return np.ctypeslib.as_array(self.L.orc_batch_leaves(self.h), shape=(m * ll,)).reshape(m, ll).copy()
+
+    @property
+    def coeffs(self):
+        n = 1 << self.log_n
+        return np.ctypeslib.as_array(self.L.orc_batch_coeffs(self.h), shape=(self.ncols * n,)).reshape(self.ncols, n).copy()
+
+    def __del__(self):
+        try:
+            self.L.orc_batch_free(self.h)
+        except Exception:
+            pass
+
+
+def fri_prove_openings(oracles, batches, log_n, params, ch):
+    L = load()
+    L.orc_fri_prove_openings.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(OrcFriBatch), C.c_size_t, C.c_uint,
+                                         C.POINTER(OrcFriParams), C.POINTER(OrcChallenger), C.POINTER(C.POINTER(C.c_uint64)),
+                                         C.POINTER(C.c_size_t)]
+    L.orc_free.argtypes = [C.c_void_p]
+    hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
+    barr = make_batches(batches)
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    rc = L.orc_fri_prove_openings(hs, len(oracles), barr, len(batches), log_n, C.byref(params), C.byref(ch), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("orc_fri_prove_openings failed: %d" % rc)
+    proof = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free(out)
+    return proof
+
+
+def fri_verify_openings(proof, caps, ncols, n_salt, batches, log_n, params, ch):
+    L = load()
+    L.orc_fri_verify_openings.argtypes = [u64p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_size_t,
+                                          C.POINTER(OrcFriBatch), C.c_size_t, C.c_uint, C.POINTER(OrcFriParams),
+                                          C.POINTER(OrcChallenger)]
+    L.orc_fri_verify_openings.restype = C.c_int
+    caps = [np.ascontiguousarray(c, dtype=np.uint64) for c in caps]
+    cp = (C.c_void_p * len(caps))(*[c.ctypes.data for c in caps])
+    nc = (C.c_int * len(caps))(*ncols)
+    ns = (C.c_int * len(caps))(*n_salt)
+    barr = make_batches(batches)
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    return L.orc_fri_verify_openings(proof, len(proof), cp, nc, ns, len(caps), barr, len(batches), log_n, C.byref(params), C.byref(ch))
