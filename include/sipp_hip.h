@@ -48,15 +48,15 @@ typedef enum {
     SIPP_E_WITNESS = -8      /* IO record not provable (point at infinity / not on curve) */
 } sipp_status;
 
-/* starky StarkConfig::standard_fast_config() */
+/* starky StarkConfig::standard_fast_config(); supported ranges in brackets */
 typedef struct {
-    uint32_t rate_bits;       /* 1 */
-    uint32_t cap_height;      /* 4 */
-    uint32_t pow_bits;        /* 16 */
-    uint32_t arity_bits;      /* 4 */
-    uint32_t final_poly_bits; /* 5 */
-    uint32_t num_queries;     /* 84 */
-    uint32_t num_challenges;  /* 2 */
+    uint32_t rate_bits;       /* 1   [1 .. 3: blowup 2, 4, 8; the quotient stays on the 2N coset]   */
+    uint32_t cap_height;      /* 4   [0 .. 8]                                                        */
+    uint32_t pow_bits;        /* 16  [0 .. 32]                                                       */
+    uint32_t arity_bits;      /* 4   [1 .. 4: FriReductionStrategy::ConstantArityBits, arity 2 .. 16] */
+    uint32_t final_poly_bits; /* 5   [0 .. 12]                                                       */
+    uint32_t num_queries;     /* 84  [1 .. 1024]                                                     */
+    uint32_t num_challenges;  /* 2   [2]                                                             */
     uint32_t pow_rule;        /* SIPP_POW_DUPLEX (0): observe the witness, response = next challenge (plonky2 fri/prover.rs
                                  of 2023); SIPP_POW_HASH (1): response = hash_no_pad(challenger.get_hash() || witness)[0]
                                  (the earlier rule).  Kept as data until upstream's pinned revision can be read. */
@@ -124,6 +124,8 @@ int sipp_exp_outputs(sipp_ctx *ctx, int kind, uint32_t *ios, size_t num_io);
 size_t sipp_proof_size(const sipp_ctx *ctx, int kind, size_t num_io);
 /* HBM workspace (bytes) one proof of `kind` with `num_io` records needs; pass it (or more) to sipp_ctx_create */
 size_t sipp_workspace_bytes(int kind, size_t num_io);
+/* the same for a non-default configuration (the LDEs grow with the blowup 2^rate_bits); cfg == NULL = default */
+size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config *cfg);
 /* trace shape the prover will use: rows (log2), main columns, permutation-Z columns, quotient chunks */
 int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
                      uint32_t *perm_cols, uint32_t *quotient_cols);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
+    "sipp_workspace_bytes_cfg": (C.c_size_t, [C.c_int, C.c_size_t, C.POINTER(StarkConfig)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
     "sipp_lde_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
     "sipp_poseidon_leaves": (C.c_int, [vp, vp, C.c_size_t, C.c_uint32, vp]),

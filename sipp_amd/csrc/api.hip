@@ -32,8 +32,9 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
         ctx->cfg = *cfg;
     else
         sipp_default_config(&ctx->cfg);
-    if (ctx->cfg.rate_bits != 1 || ctx->cfg.num_challenges != 2 || ctx->cfg.arity_bits != 4 ||
-        ctx->cfg.cap_height > 8 || ctx->cfg.pow_bits > 32 || ctx->cfg.pow_rule > SIPP_POW_HASH ||
+    // blowup 2 / 4 / 8, reduction arity 2 / 4 / 8 / 16 (constant), two challenges (the AIRs' quotient kernels fold exactly two)
+    if (ctx->cfg.rate_bits < 1 || ctx->cfg.rate_bits > 3 || ctx->cfg.num_challenges != 2 || ctx->cfg.arity_bits < 1 ||
+        ctx->cfg.arity_bits > 4 || ctx->cfg.cap_height > 8 || ctx->cfg.pow_bits > 32 || ctx->cfg.pow_rule > SIPP_POW_HASH ||
         ctx->cfg.num_queries == 0 || ctx->cfg.num_queries > 1024 || ctx->cfg.final_poly_bits > 12) {
         delete ctx;
         return SIPP_E_UNSUPPORTED;

@@ -267,6 +267,36 @@ __global__ void __launch_bounds__(256) fri_leaves_quad_kernel(const uint64_t* __
     }
 }
 
+// any arity: leaf k = 2^ab extension values = 2^(ab + 1) words; <= 4 words are the digest themselves (hash_or_noop)
+__global__ void __launch_bounds__(64) fri_leaves_any_kernel(const uint64_t* __restrict__ vals, uint64_t len, uint32_t ab,
+                                                           uint64_t* __restrict__ digests) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (len >> ab)) return;
+    const uint32_t words = 2u << ab;
+    const uint64_t* c0 = vals + (k << ab);
+    const uint64_t* c1 = vals + len + (k << ab);
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    if (words <= 4) {
+        s[0] = c0[0];
+        s[1] = c1[0];
+        if (words == 4) {
+            s[2] = c0[1];
+            s[3] = c1[1];
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t chunk = 0; chunk < words / 8; chunk++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] = (e & 1) ? c1[4 * chunk + (e >> 1)] : c0[4 * chunk + (e >> 1)];
+            poseidon::permute(s);
+        }
+    }
+    uint64_t* d = digests + 4 * k;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+}
+
 // proof-of-work grind: candidate nonce w = base + lane; response = state[7] after absorbing (in_buf, w)
 struct PowArgs {
     uint64_t state[12];
@@ -301,10 +331,14 @@ uint64_t quad_threshold() {
 
 }  // namespace
 
-int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests) {
-    uint64_t nl = len >> 4;
+int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t arity_bits, uint64_t* d_digests) {
+    uint64_t nl = len >> arity_bits;
     ProfScope ps(ctx, "fri_leaves");
-    if (nl <= quad_threshold())
+    if (arity_bits != 4) {
+        if (arity_bits < 1 || arity_bits > 4) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri_leaves: arity must be 2, 4, 8 or 16");
+        hipLaunchKernelGGL(fri_leaves_any_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
+                           arity_bits, d_digests);
+    } else if (nl <= quad_threshold())
         hipLaunchKernelGGL(fri_leaves_quad_kernel, dim3((unsigned)((4 * nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals,
                            (uint64_t)len, d_digests);
     else

@@ -136,7 +136,8 @@ struct QuotArgs {
     const int64_t* prog;
     int prog_len;
     int W, nm, nc, cbase, tbits;
-    uint32_t log_n, log_m;
+    uint32_t log_n, log_m;   // log_m = log_n + 1: the quotient domain (coset 7 <w_2N>) = the first 2N leaves of any larger LDE
+    size_t lde_stride;       // column stride of lde / zlde (n << rate_bits)
     uint64_t alpha[2], beta[2], gamma[2];
     // program segments: one gadget, or a run of up to 64 POLY ops; each is folded with alpha from zero by one lane
     const uint32_t* seg_off;                   // word offset of the segment in prog
@@ -169,8 +170,8 @@ struct QCtx {
         static_assert(SIPP_N_PERIODIC == 4, "periodic(): update the select chain");
         return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
     }
-    __device__ __forceinline__ uint64_t local(int c) const { return a->lde[(size_t)c * m + j]; }
-    __device__ __forceinline__ uint64_t next(int c) const { return a->lde[(size_t)c * m + jn]; }
+    __device__ __forceinline__ uint64_t local(int c) const { return a->lde[(size_t)c * a->lde_stride + j]; }
+    __device__ __forceinline__ uint64_t next(int c) const { return a->lde[(size_t)c * a->lde_stride + jn]; }
     __device__ __forceinline__ void emit(uint64_t v) {
         acc0 = gl::mad(acc0, a->alpha[0], v);
         acc1 = gl::mad(acc1, a->alpha[1], v);
@@ -439,10 +440,10 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
             npin[u] = c.next(nm + k);
             nptab[u] = c.next(nm + nc + k);
             col[u] = c.local(a.cbase + k);
-            z0[u] = a.zlde[(size_t)k * m + j];
-            zn0[u] = a.zlde[(size_t)k * m + c.jn];
-            z1[u] = a.zlde[(size_t)(nc + k) * m + j];
-            zn1[u] = a.zlde[(size_t)(nc + k) * m + c.jn];
+            z0[u] = a.zlde[(size_t)k * a.lde_stride + j];
+            zn0[u] = a.zlde[(size_t)k * a.lde_stride + c.jn];
+            z1[u] = a.zlde[(size_t)(nc + k) * a.lde_stride + j];
+            zn1[u] = a.zlde[(size_t)(nc + k) * a.lde_stride + c.jn];
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -688,13 +689,15 @@ __global__ void fri_final_kernel(const uint64_t* __restrict__ q, size_t n, E2 sh
     fin[n + k] = r.c1;
 }
 
-// coeffs'[k] = sum_{i < 16} beta^i coeffs[16 k + i]; in: [2][len_in] SoA, out: [2][len_in / 16]
-__global__ void fri_fold_kernel(const uint64_t* __restrict__ in, size_t len_in, E2 beta, uint64_t* __restrict__ out) {
+// coeffs'[k] = sum_{i < arity} beta^i coeffs[arity k + i]; in: [2][len_in] SoA, out: [2][len_in / arity]
+__global__ void fri_fold_kernel(const uint64_t* __restrict__ in, size_t len_in, uint32_t ab, E2 beta, uint64_t* __restrict__ out) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t len_out = len_in >> 4;
+    size_t len_out = len_in >> ab;
     if (k >= len_out) return;
+    const int arity = 1 << ab;
     E2 acc{0, 0};
-    for (int i = 15; i >= 0; i--) acc = gl::add(gl::mul(acc, beta), E2{in[16 * k + i], in[len_in + 16 * k + i]});
+    for (int i = arity - 1; i >= 0; i--)
+        acc = gl::add(gl::mul(acc, beta), E2{in[((size_t)k << ab) + i], in[len_in + ((size_t)k << ab) + i]});
     out[k] = acc.c0;
     out[len_out + k] = acc.c1;
 }
@@ -722,12 +725,12 @@ __global__ void gather_siblings_kernel(const uint64_t* __restrict__ tree, uint32
     out[((size_t)q * nsib + l) * 4 + w] = tree[(off + node) * 4 + w];
 }
 
-// FRI round leaf: 16 ext values (interleaved c0, c1) at leaf index idx[q] >> shift; vals: [2][len] leaf order
-__global__ void gather_fri_leaf_kernel(const uint64_t* __restrict__ vals, size_t len, uint32_t shift,
+// FRI round leaf: 2^ab ext values (interleaved c0, c1) at leaf index idx[q] >> shift; vals: [2][len] leaf order
+__global__ void gather_fri_leaf_kernel(const uint64_t* __restrict__ vals, size_t len, uint32_t shift, uint32_t ab,
                                        const uint32_t* __restrict__ idx, uint64_t* __restrict__ out) {
-    const uint32_t q = blockIdx.x, t = threadIdx.x;  // 32 threads
+    const uint32_t q = blockIdx.x, t = threadIdx.x;  // 2 * arity threads
     const size_t leaf = (size_t)idx[q] >> shift;
-    out[(size_t)q * 32 + t] = vals[(size_t)(t & 1) * len + 16 * leaf + (t >> 1)];
+    out[((size_t)q << (ab + 1)) + t] = vals[(size_t)(t & 1) * len + (leaf << ab) + (t >> 1)];
 }
 
 }  // namespace
@@ -768,12 +771,12 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
 }
 
 int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
-                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2],
-                    uint64_t* d_out) {
+                    size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
+                    const uint64_t gamma[2], uint64_t* d_out) {
     const uint32_t log_m = log_n + 1;
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
     QuotArgs q{};
-    q.lde = d_lde; q.zlde = d_zlde; q.aux = d_aux;
+    q.lde = d_lde; q.zlde = d_zlde; q.aux = d_aux; q.lde_stride = lde_stride;
     q.prog = sipp_air_prog_device(ctx, a);
     if (!q.prog) return SIPP_E_HIP;
     q.prog_len = a->prog_len;
@@ -949,10 +952,11 @@ int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[
     return SIPP_OK;
 }
 
-int sipp_k_fri_fold(sipp_ctx* ctx, const uint64_t* d_in, size_t len_in, gl::E2 beta, uint64_t* d_out) {
-    size_t len_out = len_in >> 4;
+int sipp_k_fri_fold(sipp_ctx* ctx, const uint64_t* d_in, size_t len_in, uint32_t arity_bits, gl::E2 beta, uint64_t* d_out) {
+    size_t len_out = len_in >> arity_bits;
     ProfScope ps(ctx, "fri_fold");
-    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((len_out + 255) / 256)), dim3(256), 0, ctx->stream, d_in, len_in, beta, d_out);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((len_out + 255) / 256)), dim3(256), 0, ctx->stream, d_in, len_in, arity_bits,
+                       beta, d_out);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
@@ -975,10 +979,11 @@ int sipp_k_gather_siblings(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_l
     return SIPP_OK;
 }
 
-int sipp_k_gather_fri_leaf(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t shift, const uint32_t* d_idx,
-                           uint32_t nq, uint64_t* d_out) {
+int sipp_k_gather_fri_leaf(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t shift, uint32_t arity_bits,
+                           const uint32_t* d_idx, uint32_t nq, uint64_t* d_out) {
     ProfScope ps(ctx, "query_gather");
-    hipLaunchKernelGGL(gather_fri_leaf_kernel, dim3(nq), dim3(32), 0, ctx->stream, d_vals, len, shift, d_idx, d_out);
+    hipLaunchKernelGGL(gather_fri_leaf_kernel, dim3(nq), dim3(2u << arity_bits), 0, ctx->stream, d_vals, len, shift, arity_bits, d_idx,
+                       d_out);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }

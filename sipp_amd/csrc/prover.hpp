@@ -1,28 +1,33 @@
 // sipp_amd/csrc/prover.hpp -- host entry points of the prover kernels (prover.hip, poseidon.hip) and the
 // host-side Fiat-Shamir challenger.
 #pragma once
+#include <functional>
+
 #include "ctx.hpp"
 #include "poseidon_constants.h"
 
 int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
                      const uint64_t gamma[2], uint64_t* d_zv);
+// quotient on the coset 7 <w_2N> (the first 2N leaves of the LDEs, whose columns are lde_stride apart); d_aux [n_aux][2N],
+// d_out [2][2N] in leaf order
 int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
-                    const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2],
-                    uint64_t* d_out);
+                    size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
+                    const uint64_t gamma[2], uint64_t* d_out);
 int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab);
 int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_t n, const uint64_t* d_t0,
                     const uint64_t* d_t1, uint64_t* d_out);
 int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,
                      int n1, gl::E2 shift1, const uint64_t* d_zp[2], const uint64_t* d_zip[2], uint64_t* d_final);
-int sipp_k_fri_fold(sipp_ctx* ctx, const uint64_t* d_in, size_t len_in, gl::E2 beta, uint64_t* d_out);
+int sipp_k_fri_fold(sipp_ctx* ctx, const uint64_t* d_in, size_t len_in, uint32_t arity_bits, gl::E2 beta, uint64_t* d_out);
 int sipp_k_gather_rows(sipp_ctx* ctx, const uint64_t* d_lde, size_t m, uint32_t ncols, const uint32_t* d_idx, uint32_t nq,
                        uint64_t* d_out);
 int sipp_k_gather_siblings(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, uint32_t nsib, uint32_t shift,
                            const uint32_t* d_idx, uint32_t nq, uint64_t* d_out);
-int sipp_k_gather_fri_leaf(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t shift, const uint32_t* d_idx,
-                           uint32_t nq, uint64_t* d_out);
+int sipp_k_gather_fri_leaf(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t shift, uint32_t arity_bits,
+                           const uint32_t* d_idx, uint32_t nq, uint64_t* d_out);
 // poseidon.hip
-int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint64_t* d_digests);
+// leaf k = the 2^arity_bits consecutive (leaf-order) extension values [k 2^ab, (k + 1) 2^ab), flattened (c0, c1); hash_or_noop
+int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_t arity_bits, uint64_t* d_digests);
 // smallest w whose response has pow_bits leading zeros; response = word `resp_word` of permute(state with in_buf[0..n_in)
 // and w at position n_in overwritten)
 int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* in_buf, uint32_t n_in, uint32_t resp_word,
@@ -158,3 +163,21 @@ struct Challenger {
 };
 
 }  // namespace host
+
+// ---- the FRI core (fri.hip) ------------------------------------------------------------------------------------
+struct FriOracleDev {
+    const uint64_t* lde;    // [ncols][stride] leaf order (salt columns, if any, are the last ones)
+    size_t stride;          // n << rate_bits
+    uint32_t ncols;         // words per leaf
+    const uint64_t* tree;   // levels back to back
+};
+struct FriParamsDev {
+    uint32_t rate_bits = 1, cap_height = 4, pow_bits = 16, num_queries = 84, pow_rule = 0;
+    std::vector<uint32_t> arity_bits;   // FriParams::reduction_arity_bits
+};
+// u64 words of the section sipp_fri_prove_core appends (caps, final polynomial, witness, query rounds)
+size_t sipp_fri_core_words(const FriParamsDev& p, uint32_t log_n, const uint32_t* leaf_words, int n_oracles);
+// d_final: [2][n] extension coefficients (SoA) of the final polynomial, already multiplied by X
+int sipp_fri_prove_core(sipp_ctx* ctx, const FriOracleDev* ors, int n_oracles, uint32_t log_n, const FriParamsDev& p,
+                        uint64_t* d_final, host::Challenger& ch, uint64_t* pf, size_t& pos, size_t cap_total, size_t* final_len,
+                        const std::function<void(const char*)>& tick);

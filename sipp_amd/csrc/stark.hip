@@ -40,25 +40,28 @@ static int shape_of(int kind, size_t num_io, Shape* s) {
     return SIPP_OK;
 }
 
-static uint32_t fri_rounds(const sipp_stark_config& c, uint32_t degree_bits) {
-    uint32_t r = 0;
-    while (degree_bits > c.final_poly_bits && degree_bits + c.rate_bits - c.arity_bits >= c.cap_height) {
-        r++;
+// FriParams of a STARK: FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits)
+static FriParamsDev fri_params_of(const sipp_stark_config& c, uint32_t degree_bits) {
+    FriParamsDev p;
+    p.rate_bits = c.rate_bits; p.cap_height = c.cap_height; p.pow_bits = c.pow_bits; p.num_queries = c.num_queries;
+    p.pow_rule = c.pow_rule;
+    while (degree_bits > c.final_poly_bits && degree_bits + c.rate_bits - c.arity_bits >= c.cap_height &&
+           degree_bits >= c.arity_bits && p.arity_bits.size() < 32) {
+        p.arity_bits.push_back(c.arity_bits);
         degree_bits -= c.arity_bits;
     }
-    return r;
+    return p;
 }
 
 static size_t proof_words(const sipp_stark_config& cfg, const Shape& s) {
-    const uint32_t log_m = s.log_n + cfg.rate_bits, R = fri_rounds(cfg, s.log_n);
+    const FriParamsDev fp = fri_params_of(cfg, s.log_n);
+    const uint32_t log_m = s.log_n + cfg.rate_bits;
     const size_t cap = (size_t)4 << cfg.cap_height;
-    size_t w = 16 + 3 * cap + 2 * (size_t)(2 * s.W + 2 * s.P + s.Q) + R * cap + 2 * ((size_t)1 << (s.log_n - 4 * R)) + 1;
-    size_t per_q = (size_t)(s.W + s.P + s.Q) + 3 * (size_t)(log_m - cfg.cap_height) * 4;
-    for (uint32_t r = 0; r < R; r++) {
-        uint32_t lt = log_m - 4 * (r + 1);
-        per_q += 32 + (size_t)(lt > cfg.cap_height ? lt - cfg.cap_height : 0) * 4;
-    }
-    w += cfg.num_queries * per_q + (size_t)s.num_io * s.air->pi_per_io;
+    size_t w = 16 + 3 * cap + 2 * (size_t)(2 * s.W + 2 * s.P + s.Q);
+    const uint32_t leaf_words[3] = {(uint32_t)s.W, (uint32_t)s.P, (uint32_t)s.Q};
+    w += sipp_fri_core_words(fp, s.log_n, leaf_words, 3);
+    w += (size_t)s.num_io * s.air->pi_per_io;
+    (void)log_m;
     return w;
 }
 
@@ -261,15 +264,18 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     Shape s;
     SIPP_TRY(shape_of(kind, num_io_in, &s));
     const sipp_air_t* a = s.air;
-    const uint32_t log_n = s.log_n, log_m = log_n + cfg.rate_bits, R = fri_rounds(cfg, log_n);
-    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
+    const FriParamsDev fp = fri_params_of(cfg, s.log_n);
+    const uint32_t log_n = s.log_n, log_m = log_n + cfg.rate_bits, R = (uint32_t)fp.arity_bits.size();
+    const uint32_t log_mq = log_n + 1;                    // the quotient domain: coset 7 <w_2N> = the first 2N leaves of the LDE
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m, mq = (size_t)1 << log_mq;
+    const size_t final_len = n >> (R * cfg.arity_bits);
     const int W = s.W, P = s.P, Q = s.Q;
     const uint32_t nq = cfg.num_queries;
+    (void)nq;
     const size_t cap_words = (size_t)4 << cfg.cap_height;
     const size_t total_words = proof_words(cfg, s);
     if (proof_cap < total_words) return sipp_fail(ctx, SIPP_E_BUFSZ, "proof buffer too small (see sipp_proof_size)");
     if (n < ((size_t)1 << a->table_bits)) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "trace shorter than the range table");
-    if (R > 8) return SIPP_E_UNSUPPORTED;
 
     // optional host-side phase timing (SIPP_HOST_TIMING=1): wall clock at each Fiat-Shamir synchronisation point
     static const bool host_timing = getenv("SIPP_HOST_TIMING") != nullptr;
@@ -299,7 +305,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     };
     {
         uint64_t hdr[16] = {SIPP_MAGIC, (uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.cap_height,
-                            R, (uint64_t)(n >> (4 * R)), nq, (uint64_t)a->pi_per_io, total_words, 0, 0, 0};
+                            R, (uint64_t)final_len, nq, (uint64_t)a->pi_per_io, total_words, 0, 0, 0};
         push(hdr, 16);
     }
 
@@ -313,7 +319,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
               arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), W};
     Oracle3 Z{arena_alloc_t<uint64_t>(ctx, (size_t)P * n), arena_alloc_t<uint64_t>(ctx, (size_t)P * m),
               arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), P};
-    Oracle3 Qo{arena_alloc_t<uint64_t>(ctx, (size_t)2 * m), arena_alloc_t<uint64_t>(ctx, (size_t)Q * m),
+    Oracle3 Qo{arena_alloc_t<uint64_t>(ctx, (size_t)2 * mq), arena_alloc_t<uint64_t>(ctx, (size_t)Q * m),
                arena_alloc_t<uint64_t>(ctx, tree_words(log_m)), Q};
     if (!d_err || !d_trace || !T.coeffs || !T.lde || !T.tree || !Z.coeffs || !Z.lde || !Z.tree || !Qo.coeffs || !Qo.lde ||
         !Qo.tree)
@@ -379,7 +385,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
 
     // ---- 4. quotient ----
     {
-        ArenaMark mq = arena_mark(ctx);
+        ArenaMark mark_q = arena_mark(ctx);
         const int n_aux = a->n_aux;
         const uint32_t log_io = log_n - 9;
         const size_t nio = s.num_io;
@@ -411,17 +417,17 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
             memcpy(&auxc[(size_t)ai * nio], col.data(), nio * 8);
         }
         uint64_t* d_auxc = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * nio + 1);
-        uint64_t* d_aux = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * m + 1);
+        uint64_t* d_aux = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * mq + 1);
         if (!d_auxc || !d_aux) return SIPP_E_NOMEM;
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_auxc, auxc.data(), auxc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (n_aux) SIPP_TRY(sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, m, log_m, (size_t)n_aux, false, NttDiag{gl::GEN, 0}));
-        SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, d_aux, alpha, beta, gamma, Qo.coeffs));
+        if (n_aux) SIPP_TRY(sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, mq, log_mq, (size_t)n_aux, false, NttDiag{gl::GEN, 0}));
+        SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, m, d_aux, alpha, beta, gamma, Qo.coeffs));
         // coset iNTT: leaf-order values -> natural coefficients of q(x) (undo the shift 7)
-        SIPP_TRY(sipp_ntt_dit(ctx, Qo.coeffs, m, log_m, 2, true, NttDiag{gl::inv(gl::GEN), 0}));
-        // [2][m] natural == 4 chunks of N coefficients, contiguous
+        SIPP_TRY(sipp_ntt_dit(ctx, Qo.coeffs, mq, log_mq, 2, true, NttDiag{gl::inv(gl::GEN), 0}));
+        // [2][2N] natural == 4 chunks of N coefficients, contiguous
         SIPP_TRY(commit_coeffs(ctx, Qo.coeffs, (size_t)Q, log_n, Qo.lde, Qo.tree, cap_host));
-        arena_release(ctx, mq);
+        arena_release(ctx, mark_q);
     }
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
@@ -487,108 +493,12 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         const uint64_t* zip[2] = {d_zip[0], d_zip[1]};
         SIPP_TRY(sipp_k_fri_final(ctx, src, cnt, n, d_apow, W + P, gl::pow(fa, (uint64_t)(W + P)), zp, zip, d_final));
     }
-    // commit phase
-    uint64_t* r_vals[8];
-    uint64_t* r_tree[8];
-    uint64_t* cur = d_final;   // [2][len_c] coefficients with len_c non-zero entries
-    size_t len_c = n;
-    uint64_t shift = gl::GEN;
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t log_len = log_m - 4 * r;       // values this round
-        const size_t len = (size_t)1 << log_len;
-        r_vals[r] = arena_alloc_t<uint64_t>(ctx, 2 * len);
-        r_tree[r] = arena_alloc_t<uint64_t>(ctx, tree_words(log_len - 4));
-        uint64_t* nxt = arena_alloc_t<uint64_t>(ctx, 2 * (len_c >> 4) + 2);
-        if (!r_vals[r] || !r_tree[r] || !nxt) return SIPP_E_NOMEM;
-        SIPP_TRY(sipp_ntt_dif(ctx, cur, len_c, log_len - 1, r_vals[r], len, log_len, 2, false, NttDiag{shift, 0}));
-        SIPP_TRY(sipp_k_fri_leaves(ctx, r_vals[r], len, r_tree[r]));
-        SIPP_TRY(sipp_k_merkle_levels(ctx, r_tree[r], log_len - 4, cfg.cap_height));
-        SIPP_TRY(read_cap(ctx, r_tree[r], log_len - 4, cap_host));
-        ch.observe_many(cap_host, cap_words);
-        push(cap_host, cap_words);
-        const gl::E2 fb = ch.get_ext();
-        SIPP_TRY(sipp_k_fri_fold(ctx, cur, len_c, fb, nxt));
-        cur = nxt;
-        len_c >>= 4;
-        shift = gl::pow(shift, 16);
-    }
+    // commit phase, proof of work, query rounds: the generic FRI core (fri.hip)
     {
-        std::vector<uint64_t> fp(2 * len_c);
-        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(fp.data(), cur, fp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < len_c; i++) {
-            uint64_t e[2] = {fp[i], fp[len_c + i]};
-            ch.observe_many(e, 2);
-            push(e, 2);
-        }
-    }
-    tick("fri commit phase");
-    // proof of work: smallest valid nonce (deterministic; upstream's rayon find_any may return another one)
-    uint64_t pow_witness = 0;
-    if (cfg.pow_rule == SIPP_POW_HASH) {
-        // response = hash_no_pad(challenger.get_hash() || w)[0]: one permutation of (h0..h3, w, 0, ...)
-        uint64_t zero[12] = {0}, cur[4];
-        for (int i = 0; i < 4; i++) cur[i] = ch.get();
-        SIPP_TRY(sipp_k_pow_search(ctx, zero, cur, 4, 0, cfg.pow_bits, &pow_witness));
-    } else {
-        // observe w, response = next challenge = word 7 of the duplexed state
-        SIPP_TRY(sipp_k_pow_search(ctx, ch.state, ch.in_buf, ch.n_in, 7, cfg.pow_bits, &pow_witness));
-        ch.observe(pow_witness);
-        (void)ch.get();
-    }
-    push(&pow_witness, 1);
-
-    tick("pow");
-    // ---- queries ----
-    std::vector<uint32_t> qidx(nq);
-    for (uint32_t i = 0; i < nq; i++) qidx[i] = (uint32_t)(ch.get() % m);
-    uint32_t* d_idx = arena_alloc_t<uint32_t>(ctx, nq);
-    if (!d_idx) return SIPP_E_NOMEM;
-    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_idx, qidx.data(), nq * 4, hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t nsib0 = log_m - cfg.cap_height;
-    Oracle3* ors[3] = {&T, &Z, &Qo};
-    // staging layout on the device, then one D2H
-    size_t st_words = 0;
-    size_t off_rows[3], off_sib[3], off_leaf[8], off_rsib[8];
-    uint32_t rsib[8];
-    for (int o = 0; o < 3; o++) {
-        off_rows[o] = st_words;
-        st_words += (size_t)nq * ors[o]->ncols;
-        off_sib[o] = st_words;
-        st_words += (size_t)nq * nsib0 * 4;
-    }
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t lt = log_m - 4 * (r + 1);
-        rsib[r] = lt > cfg.cap_height ? lt - cfg.cap_height : 0;
-        off_leaf[r] = st_words;
-        st_words += (size_t)nq * 32;
-        off_rsib[r] = st_words;
-        st_words += (size_t)nq * rsib[r] * 4;
-    }
-    if (st_words > ctx->h_pinned_words) return sipp_fail(ctx, SIPP_E_NOMEM, "query staging exceeds the pinned buffer");
-    uint64_t* d_st = arena_alloc_t<uint64_t>(ctx, st_words);
-    if (!d_st) return SIPP_E_NOMEM;
-    for (int o = 0; o < 3; o++) {
-        SIPP_TRY(sipp_k_gather_rows(ctx, ors[o]->lde, m, (uint32_t)ors[o]->ncols, d_idx, nq, d_st + off_rows[o]));
-        SIPP_TRY(sipp_k_gather_siblings(ctx, ors[o]->tree, log_m, nsib0, 0, d_idx, nq, d_st + off_sib[o]));
-    }
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t log_len = log_m - 4 * r;
-        SIPP_TRY(sipp_k_gather_fri_leaf(ctx, r_vals[r], (size_t)1 << log_len, 4 * (r + 1), d_idx, nq, d_st + off_leaf[r]));
-        SIPP_TRY(sipp_k_gather_siblings(ctx, r_tree[r], log_len - 4, rsib[r], 4 * (r + 1), d_idx, nq, d_st + off_rsib[r]));
-    }
-    uint64_t* hst = ctx->h_pinned;
-    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hst, d_st, st_words * 8, hipMemcpyDeviceToHost, ctx->stream));
-    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint32_t qi = 0; qi < nq; qi++) {
-        for (int o = 0; o < 3; o++) {
-            push(hst + off_rows[o] + (size_t)qi * ors[o]->ncols, (size_t)ors[o]->ncols);
-            push(hst + off_sib[o] + (size_t)qi * nsib0 * 4, (size_t)nsib0 * 4);
-        }
-        for (uint32_t r = 0; r < R; r++) {
-            push(hst + off_leaf[r] + (size_t)qi * 32, 32);
-            push(hst + off_rsib[r] + (size_t)qi * rsib[r] * 4, (size_t)rsib[r] * 4);
-        }
+        const FriOracleDev ors[3] = {{T.lde, m, (uint32_t)W, T.tree}, {Z.lde, m, (uint32_t)P, Z.tree}, {Qo.lde, m, (uint32_t)Q, Qo.tree}};
+        size_t flen = 0;
+        SIPP_TRY(sipp_fri_prove_core(ctx, ors, 3, log_n, fp, d_final, ch, pf, pos, total_words, &flen, tick));
+        if (flen != final_len) return sipp_fail(ctx, SIPP_E_BUFSZ, "internal: final polynomial length mismatch");
     }
     for (size_t k = 0; k < pis.size(); k++) pf[pos++] = pis[k];
     tick("queries+assemble");
@@ -611,10 +521,14 @@ int sipp_stark_shape(const sipp_ctx* ctx, int kind, size_t num_io, uint32_t* log
     return SIPP_OK;
 }
 
-size_t sipp_workspace_bytes(int kind, size_t num_io) {
+size_t sipp_workspace_bytes(int kind, size_t num_io) { return sipp_workspace_bytes_cfg(kind, num_io, nullptr); }
+
+size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config* cfg) {
     Shape s;
     if (shape_of(kind, num_io, &s) != SIPP_OK) return 0;
-    const size_t n = (size_t)1 << s.log_n, m = 2 * n;
+    const uint32_t rate_bits = cfg ? cfg->rate_bits : 1;
+    if (rate_bits < 1 || rate_bits > 3) return 0;
+    const size_t n = (size_t)1 << s.log_n, m = n << rate_bits;
     const size_t W = (size_t)s.W, P = (size_t)s.P, Q = (size_t)s.Q, nc = (size_t)s.air->n_checked;
     size_t words = n * (2 * W + 3 * P)                                  // trace values + coefficients, Z values (x2) + coefficients
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs

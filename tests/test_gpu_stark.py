@@ -347,3 +347,29 @@ def test_non_default_stark_config_matches_the_oracle(ios4, cap_height, pow_bits,
             assert int(got[7]) == cap_height and int(got[10]) == num_queries
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("rate_bits,arity_bits,final_poly_bits,pow_rule", [(2, 4, 5, 0), (3, 3, 4, 0), (1, 2, 3, 1), (2, 1, 6, 0), (3, 4, 5, 1)])
+def test_other_blowups_arities_and_pow_rules_match_the_oracle(ios4, rate_bits, arity_bits, final_poly_bits, pow_rule):
+    """blowup 4 / 8 (plonky2's outer circuit uses 8), reduction arity 2 / 4 / 8 and the second proof-of-work rule: the proof
+    shape changes (LDE size, FRI layers, leaf widths) and stays word for word the oracle's"""
+    import ctypes as C
+    import sipp_amd
+    cfg = sipp_amd.default_config()
+    ocfg = _oracle.default_config()
+    for c in (cfg, ocfg):
+        c.rate_bits, c.arity_bits, c.final_poly_bits, c.pow_rule, c.num_queries, c.pow_bits = rate_bits, arity_bits, final_poly_bits, pow_rule, 11, 9
+    L = sipp_amd.lib()
+    for kind in (0, 2):
+        ws = L.sipp_workspace_bytes_cfg(kind, ios4[kind].shape[0], C.byref(cfg))
+        assert ws > L.sipp_workspace_bytes(kind, ios4[kind].shape[0]) or rate_bits == 1
+        ctx = sipp_amd.Ctx(cfg=cfg, workspace_bytes=ws)
+        try:
+            ref = _oracle.stark_prove(kind, ios4[kind], ocfg)
+            got = ctx.prove(kind, ios4[kind])
+            assert len(got) == len(ref), (kind, len(got), len(ref))
+            diff = np.nonzero(got != ref)[0]
+            assert diff.size == 0, "kind %d: first mismatch at word %d of %d" % (kind, diff[0], len(ref))
+            assert _oracle.stark_verify(got, ocfg) == 0
+        finally:
+            ctx.close()
