@@ -152,6 +152,61 @@ int sipp_prove_native(sipp_ctx *ctx, const uint32_t *A, const uint32_t *B, size_
 int sipp_verify_native(sipp_ctx *ctx, const uint32_t *A, const uint32_t *B, size_t n, const uint32_t *proof,
                        uint32_t *statement, uint32_t *g1_ios, uint32_t *g2_ios, uint32_t *fq12_ios, int *accepted);
 
+/* ---- next row (SURVEY.md section 8f, rank 2 -- the generic half of the outer plonky2 prover) ---------------------------
+ * PolynomialBatch commitments and FRI opening proofs for ARBITRARY FriParams: what reference src/verifier_circuit.rs:225
+ * (`builder.build`) fixes and :253 (`data.prove`) runs four times per proof in plonky2 (constants/sigmas, wires,
+ * zs/partial products, quotient; blowup 8, arity 16, 28 queries in `standard_recursion_config`, salted wires when zero
+ * knowledge is on).  The gate constraints of the outer circuit are NOT part of this (upstream's circuit is not vendored). */
+#define SIPP_SALT_SIZE 4
+#define SIPP_FRI_MAX_ROUNDS 32
+typedef struct {
+    uint32_t rate_bits, cap_height, pow_bits, num_queries, pow_rule;
+    uint32_t hiding;                           /* FriParams::hiding: salted oracles open their salt words too */
+    uint32_t n_rounds;
+    uint32_t arity_bits[SIPP_FRI_MAX_ROUNDS];  /* FriParams::reduction_arity_bits, each 1 .. 4 */
+} sipp_fri_params;
+/* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) for polynomials of 2^degree_bits coefficients;
+ * rate_bits and cap_height of *p must be set before the call */
+void sipp_fri_const_arity(sipp_fri_params *p, uint32_t arity_bits, uint32_t final_poly_bits, uint32_t degree_bits);
+/* a committed oracle, all pointers DEVICE memory owned by the caller:
+ *   d_coeffs [n_polys][N] natural, d_lde [n_polys + n_salt][N << rate_bits] leaf order, d_tree (2 leaves x 4 u64, levels back to back) */
+typedef struct {
+    const uint64_t *d_coeffs;
+    const uint64_t *d_lde;
+    const uint64_t *d_tree;
+    uint32_t n_polys, n_salt;
+} sipp_oracle;
+/* PolynomialBatch::from_values (from_coeffs != 0: from_coeffs) with explicit blowup / cap height and optional blinding:
+ * d_salt = n_salt (0 or SIPP_SALT_SIZE) columns of N << rate_bits words in NATURAL LDE order (plonky2 draws them at random;
+ * here the caller supplies them so that proofs are reproducible), appended to every leaf.  d_lde must hold ncols + n_salt
+ * columns.  cap_out (host): 2^min(cap_height, log leaves) x 4 u64. */
+int sipp_commit_batch_ex(sipp_ctx *ctx, const uint64_t *d_in, int from_coeffs, uint64_t *d_coeffs, uint64_t *d_lde,
+                         uint64_t *d_tree, size_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
+                         const uint64_t *d_salt, uint32_t n_salt, uint64_t *cap_out);
+typedef struct { uint32_t oracle, col_begin, col_end; } sipp_poly_range;
+typedef struct {
+    uint64_t point[2];              /* extension element (c0, c1), not in the trace subgroup */
+    uint32_t n_ranges;
+    const sipp_poly_range *ranges;  /* FriBatchInfo::polynomials as ranges of oracle columns, in opening order */
+} sipp_fri_batch;
+/* plonky2 Challenger state as plain data: the caller's transcript goes in and comes out */
+typedef struct {
+    uint64_t state[12];
+    uint64_t in_buf[8];
+    uint64_t n_in;
+    uint64_t out_buf[8];
+    uint64_t n_out;
+} sipp_challenger;
+/* PolynomialBatch::prove_openings: the opened values are computed, written and observed batch by batch, then alpha, the
+ * final polynomial, the commit phase, the proof of work and the query rounds.  Flat proof (u64 words):
+ *   header[8]: "SIPPFRI1", n_rounds, final_len, num_queries, n_oracles, n_batches, total_len, log_n
+ *   opened values (ext) per batch | commit caps | final_poly | pow_witness | query rounds */
+size_t sipp_fri_proof_size(const sipp_oracle *oracles, size_t n_oracles, const sipp_fri_batch *batches, size_t n_batches,
+                           uint32_t log_n, const sipp_fri_params *p);
+int sipp_fri_prove_openings(sipp_ctx *ctx, const sipp_oracle *oracles, size_t n_oracles, const sipp_fri_batch *batches,
+                            size_t n_batches, uint32_t log_n, const sipp_fri_params *p, sipp_challenger *ch,
+                            uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

@@ -28,6 +28,28 @@ class StarkConfig(C.Structure):
                                           "num_queries", "num_challenges", "pow_rule")]
 
 
+class FriParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "num_queries", "pow_rule", "hiding", "n_rounds")] + \
+               [("arity_bits", C.c_uint32 * 32)]
+
+
+class Oracle(C.Structure):
+    _fields_ = [("d_coeffs", C.c_void_p), ("d_lde", C.c_void_p), ("d_tree", C.c_void_p), ("n_polys", C.c_uint32), ("n_salt", C.c_uint32)]
+
+
+class PolyRange(C.Structure):
+    _fields_ = [("oracle", C.c_uint32), ("col_begin", C.c_uint32), ("col_end", C.c_uint32)]
+
+
+class FriBatch(C.Structure):
+    _fields_ = [("point", C.c_uint64 * 2), ("n_ranges", C.c_uint32), ("ranges", C.POINTER(PolyRange))]
+
+
+class Challenger(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
+                ("n_out", C.c_uint64)]
+
+
 # every symbol include/sipp_hip.h declares: name -> (restype, argtypes)
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
@@ -57,6 +79,11 @@ SIGNATURES = {
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
     "sipp_workspace_bytes_cfg": (C.c_size_t, [C.c_int, C.c_size_t, C.POINTER(StarkConfig)]),
+    "sipp_fri_const_arity": (None, [C.POINTER(FriParams), C.c_uint32, C.c_uint32, C.c_uint32]),
+    "sipp_commit_batch_ex": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]),
+    "sipp_fri_proof_size": (C.c_size_t, [C.POINTER(Oracle), C.c_size_t, C.POINTER(FriBatch), C.c_size_t, C.c_uint32, C.POINTER(FriParams)]),
+    "sipp_fri_prove_openings": (C.c_int, [vp, C.POINTER(Oracle), C.c_size_t, C.POINTER(FriBatch), C.c_size_t, C.c_uint32,
+                                          C.POINTER(FriParams), C.POINTER(Challenger), vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
     "sipp_lde_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
     "sipp_poseidon_leaves": (C.c_int, [vp, vp, C.c_size_t, C.c_uint32, vp]),
@@ -195,6 +222,45 @@ class Ctx:
         self._ck(self.L.sipp_commit_batch(self.h, values.data_ptr(), coeffs.data_ptr(), lde.data_ptr(),
                                           tree.data_ptr(), ncols, log_n, cap.ctypes.data), "commit_batch")
         return coeffs, lde, tree, cap
+
+    # ---- generic PolynomialBatch / FRI opening proofs ----
+    def commit_ex(self, data, log_n, rate_bits, cap_height, from_coeffs=False, salt=None):
+        """sipp_commit_batch_ex: data [ncols, N] device int64 (values or coefficients), salt [4, N << rate_bits] or None.
+        Returns (Oracle struct, cap ndarray, (coeffs, lde, tree) tensors kept alive by the caller)."""
+        import torch
+        ncols = data.shape[0]
+        n_salt = 0 if salt is None else salt.shape[0]
+        m = 1 << (log_n + rate_bits)
+        coeffs = torch.empty_like(data)
+        lde = torch.empty((ncols + n_salt, m), dtype=torch.int64, device=data.device)
+        tree = torch.empty((2 * m, 4), dtype=torch.int64, device=data.device)
+        ch = min(cap_height, log_n + rate_bits)
+        cap = np.zeros((1 << ch, 4), dtype=np.uint64)
+        self._ck(self.L.sipp_commit_batch_ex(self.h, data.data_ptr(), int(from_coeffs), coeffs.data_ptr(), lde.data_ptr(), tree.data_ptr(),
+                                             ncols, log_n, rate_bits, cap_height, None if salt is None else salt.data_ptr(), n_salt,
+                                             cap.ctypes.data), "commit_batch_ex")
+        return Oracle(coeffs.data_ptr(), lde.data_ptr(), tree.data_ptr(), ncols, n_salt), cap, (coeffs, lde, tree)
+
+    def fri_prove_openings(self, oracles, batches, log_n, params, challenger):
+        """sipp_fri_prove_openings.  oracles: [Oracle], batches: [((c0, c1), [(oracle, col_begin, col_end), ...])];
+        `challenger` (Challenger struct) is advanced in place.  Returns the flat proof."""
+        oa = (Oracle * len(oracles))(*oracles)
+        ba = (FriBatch * len(batches))()
+        keep = []
+        for i, (pt, ranges) in enumerate(batches):
+            r = (PolyRange * len(ranges))(*[PolyRange(*x) for x in ranges])
+            keep.append(r)
+            ba[i].point[0], ba[i].point[1] = int(pt[0]), int(pt[1])
+            ba[i].n_ranges = len(ranges)
+            ba[i].ranges = r
+        cap = self.L.sipp_fri_proof_size(oa, len(oracles), ba, len(batches), log_n, C.byref(params))
+        if cap == 0:
+            raise SippError(-1, "sipp_fri_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        self._ck(self.L.sipp_fri_prove_openings(self.h, oa, len(oracles), ba, len(batches), log_n, C.byref(params),
+                                                C.byref(challenger), out.ctypes.data, cap, C.byref(n)), "fri_prove_openings")
+        return out[: n.value]
 
     def shape(self, kind, num_io):
         a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

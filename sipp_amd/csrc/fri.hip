@@ -169,3 +169,229 @@ int sipp_fri_prove_core(sipp_ctx* ctx, const FriOracleDev* ors, int n_oracles, u
     }
     return SIPP_OK;
 }
+
+
+// =====================================================================================================================
+// generic opening proofs: the C ABI of include/sipp_hip.h (PolynomialBatch::from_values / prove_openings for any FriParams)
+// =====================================================================================================================
+#define SIPP_FRI_MAGIC 0x5349505046524931ULL /* "SIPPFRI1" */
+
+static size_t batch_len(const sipp_fri_batch& b) {
+    size_t k = 0;
+    for (uint32_t r = 0; r < b.n_ranges; r++) k += b.ranges[r].col_end - b.ranges[r].col_begin;
+    return k;
+}
+
+static int check_params(sipp_ctx* ctx, const sipp_fri_params* p, uint32_t log_n) {
+    if (!p || p->rate_bits < 1 || p->rate_bits > 3 || p->cap_height > 8 || p->pow_bits > 32 || p->pow_rule > SIPP_POW_HASH ||
+        p->num_queries == 0 || p->num_queries > 1024 || p->n_rounds > SIPP_FRI_MAX_ROUNDS)
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: parameters out of the supported range");
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < p->n_rounds; r++) {
+        if (p->arity_bits[r] < 1 || p->arity_bits[r] > 4) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: arity must be 2, 4, 8 or 16");
+        sum += p->arity_bits[r];
+        // every committed layer keeps at least 2^cap_height leaves and 16 values (plonky2 asserts the former)
+        if (log_n + p->rate_bits < sum + p->cap_height || log_n + p->rate_bits - sum + p->arity_bits[r] < 4)
+            return sipp_fail(ctx, SIPP_E_BADARG, "fri: reduction arities leave a layer smaller than its cap");
+    }
+    if (sum > log_n || log_n < 10 || log_n > 24) return sipp_fail(ctx, SIPP_E_BADARG, "fri: degree bits out of range [10, 24]");
+    return SIPP_OK;
+}
+
+extern "C" {
+
+void sipp_fri_const_arity(sipp_fri_params* p, uint32_t arity_bits, uint32_t final_poly_bits, uint32_t degree_bits) {
+    if (!p) return;
+    p->n_rounds = 0;
+    while (degree_bits > final_poly_bits && degree_bits + p->rate_bits - arity_bits >= p->cap_height && degree_bits >= arity_bits &&
+           p->n_rounds < SIPP_FRI_MAX_ROUNDS) {
+        p->arity_bits[p->n_rounds++] = arity_bits;
+        degree_bits -= arity_bits;
+    }
+}
+
+int sipp_commit_batch_ex(sipp_ctx* ctx, const uint64_t* d_in, int from_coeffs, uint64_t* d_coeffs, uint64_t* d_lde, uint64_t* d_tree,
+                         size_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, const uint64_t* d_salt,
+                         uint32_t n_salt, uint64_t* cap_out) {
+    if (!ctx || !d_in || !d_coeffs || !d_lde || !d_tree || !cap_out || ncols == 0) return SIPP_E_BADARG;
+    if (rate_bits < 1 || rate_bits > 3 || cap_height > 8 || (n_salt != 0 && (n_salt != SIPP_SALT_SIZE || !d_salt)))
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "commit_batch_ex: blowup 2 / 4 / 8, cap height <= 8, salt 0 or 4 columns");
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t log_m = log_n + rate_bits;
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m;
+    ArenaScope scope(ctx);
+    int rc;
+    if (from_coeffs) {
+        if (d_in != d_coeffs) SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_coeffs, d_in, ncols * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        rc = sipp_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+        if (rc == SIPP_E_UNSUPPORTED) rc = sipp_ntt_dif(ctx, d_coeffs, n, log_n, d_lde, m, log_m, ncols, false, NttDiag{gl::GEN, 0});
+    } else {
+        rc = d_in != d_coeffs ? sipp_lde_from_values(ctx, d_in, d_coeffs, d_lde, ncols, log_n, rate_bits) : SIPP_E_UNSUPPORTED;
+        if (rc == SIPP_E_UNSUPPORTED) {
+            const uint64_t* src = d_in;
+            if (d_in == d_coeffs) {
+                uint64_t* tmp = arena_alloc_t<uint64_t>(ctx, n * ncols);
+                if (!tmp) return SIPP_E_NOMEM;
+                SIPP_CHECK_HIP(ctx, hipMemcpyAsync(tmp, d_in, n * ncols * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                src = tmp;
+            }
+            rc = sipp_bitrev_cols(ctx, src, n, d_coeffs, n, log_n, ncols);
+            if (rc == SIPP_OK) rc = sipp_ntt_dit(ctx, d_coeffs, n, log_n, ncols, true, NttDiag{});
+            if (rc == SIPP_OK) rc = sipp_ntt_dif(ctx, d_coeffs, n, log_n, d_lde, m, log_m, ncols, false, NttDiag{gl::GEN, 0});
+        }
+    }
+    // salt columns: natural LDE order in, leaf order (= bit-reversed rows) behind the polynomial columns
+    if (rc == SIPP_OK && n_salt) rc = sipp_bitrev_cols(ctx, d_salt, m, d_lde + ncols * m, m, log_m, n_salt);
+    if (rc == SIPP_OK) rc = sipp_k_poseidon_leaves(ctx, d_lde, m, ncols + n_salt, log_m, d_tree);
+    if (rc == SIPP_OK) rc = sipp_k_merkle_levels(ctx, d_tree, log_m, cap_height);
+    if (rc == SIPP_OK) rc = read_cap(ctx, d_tree, log_m, cap_height, cap_out);
+    else (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+size_t sipp_fri_proof_size(const sipp_oracle* oracles, size_t n_oracles, const sipp_fri_batch* batches, size_t n_batches,
+                           uint32_t log_n, const sipp_fri_params* p) {
+    if (!oracles || !batches || !p || n_oracles == 0 || n_oracles > 8 || n_batches == 0) return 0;
+    FriParamsDev fp;
+    fp.rate_bits = p->rate_bits; fp.cap_height = p->cap_height; fp.pow_bits = p->pow_bits; fp.num_queries = p->num_queries;
+    fp.pow_rule = p->pow_rule;
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < p->n_rounds && r < SIPP_FRI_MAX_ROUNDS; r++) {
+        fp.arity_bits.push_back(p->arity_bits[r]);
+        sum += p->arity_bits[r];
+    }
+    if (sum > log_n) return 0;
+    uint32_t lw[8];
+    for (size_t o = 0; o < n_oracles; o++) lw[o] = oracles[o].n_polys + oracles[o].n_salt;
+    size_t w = 8 + sipp_fri_core_words(fp, log_n, lw, (int)n_oracles);
+    for (size_t b = 0; b < n_batches; b++) w += 2 * batch_len(batches[b]);
+    return w;
+}
+
+int sipp_fri_prove_openings(sipp_ctx* ctx, const sipp_oracle* oracles, size_t n_oracles, const sipp_fri_batch* batches,
+                            size_t n_batches, uint32_t log_n, const sipp_fri_params* p, sipp_challenger* chs, uint64_t* proof_out,
+                            size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !oracles || !batches || !p || !chs || !proof_out || !proof_len || n_oracles == 0 || n_oracles > 8 || n_batches == 0)
+        return SIPP_E_BADARG;
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    SIPP_TRY(check_params(ctx, p, log_n));
+    if (chs->n_in > 7 || chs->n_out > 8) return sipp_fail(ctx, SIPP_E_BADARG, "fri: malformed challenger state");
+    const size_t total = sipp_fri_proof_size(oracles, n_oracles, batches, n_batches, log_n, p);
+    if (total == 0) return SIPP_E_BADARG;
+    if (proof_cap < total) return sipp_fail(ctx, SIPP_E_BUFSZ, "fri: proof buffer too small (see sipp_fri_proof_size)");
+    for (size_t b = 0; b < n_batches; b++)
+        for (uint32_t r = 0; r < batches[b].n_ranges; r++) {
+            const sipp_poly_range& rg = batches[b].ranges[r];
+            if (rg.oracle >= n_oracles || rg.col_begin > rg.col_end || rg.col_end > oracles[rg.oracle].n_polys)
+                return sipp_fail(ctx, SIPP_E_BADARG, "fri: polynomial range outside its oracle");
+        }
+    const size_t n = (size_t)1 << log_n, m = n << p->rate_bits;
+    FriParamsDev fp;
+    fp.rate_bits = p->rate_bits; fp.cap_height = p->cap_height; fp.pow_bits = p->pow_bits; fp.num_queries = p->num_queries;
+    fp.pow_rule = p->pow_rule;
+    for (uint32_t r = 0; r < p->n_rounds; r++) fp.arity_bits.push_back(p->arity_bits[r]);
+    host::Challenger ch;
+    memcpy(ch.state, chs->state, sizeof ch.state);
+    memcpy(ch.in_buf, chs->in_buf, sizeof ch.in_buf);
+    memcpy(ch.out_buf, chs->out_buf, sizeof ch.out_buf);
+    ch.n_in = (uint32_t)chs->n_in;
+    ch.n_out = (uint32_t)chs->n_out;
+    struct Release {
+        sipp_ctx* c;
+        ArenaMark mk;
+        ~Release() {
+            (void)hipStreamSynchronize(c->stream);
+            arena_release(c, mk);
+        }
+    } release{ctx, arena_mark(ctx)};
+    size_t pos = 0;
+    uint64_t* pf = proof_out;
+    {
+        uint64_t hdr[8] = {SIPP_FRI_MAGIC, p->n_rounds, 0, p->num_queries, (uint64_t)n_oracles, (uint64_t)n_batches, total, log_n};
+        memcpy(pf, hdr, sizeof hdr);
+        pos = 8;
+    }
+    // ---- opened values: per batch a power table of its point, one dot product per polynomial ----
+    std::vector<uint64_t*> d_zp(n_batches), d_zip(n_batches);
+    std::vector<gl::E2> points(n_batches);
+    for (size_t b = 0; b < n_batches; b++) {
+        points[b] = gl::E2{batches[b].point[0], batches[b].point[1]};
+        if (gl::eq(gl::pow(points[b], (uint64_t)n), gl::e2(1))) return sipp_fail(ctx, SIPP_E_SUBGROUP, "fri: opening point in the subgroup");
+        d_zp[b] = arena_alloc_t<uint64_t>(ctx, 2 * n);
+        d_zip[b] = arena_alloc_t<uint64_t>(ctx, 2 * n);
+        if (!d_zp[b] || !d_zip[b]) return SIPP_E_NOMEM;
+        SIPP_TRY(sipp_k_pow_table(ctx, points[b], n, d_zp[b]));
+        SIPP_TRY(sipp_k_pow_table(ctx, gl::inv(points[b]), n, d_zip[b]));
+    }
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t k = batch_len(batches[b]);
+        uint64_t* d_open = arena_alloc_t<uint64_t>(ctx, 4 * k + 4);
+        if (!d_open) return SIPP_E_NOMEM;
+        size_t at = 0;
+        for (uint32_t r = 0; r < batches[b].n_ranges; r++) {
+            const sipp_poly_range& rg = batches[b].ranges[r];
+            const size_t cnt = rg.col_end - rg.col_begin;
+            SIPP_TRY(sipp_k_openings(ctx, oracles[rg.oracle].d_coeffs + (size_t)rg.col_begin * n, cnt, n, d_zp[b], nullptr, d_open + 4 * at));
+            at += cnt;
+        }
+        std::vector<uint64_t> hop(4 * k + 4);
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hop.data(), d_open, (4 * k) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t j = 0; j < k; j++) {
+            memcpy(pf + pos, &hop[4 * j], 16);
+            pos += 2;
+            ch.observe_many(&hop[4 * j], 2);
+        }
+    }
+    // ---- final polynomial: sum over batches of alpha-shifted quotients, times X ----
+    const gl::E2 alpha = ch.get_ext();
+    uint64_t* d_acc = arena_alloc_t<uint64_t>(ctx, 2 * n);
+    uint64_t* d_final = arena_alloc_t<uint64_t>(ctx, 2 * n);
+    if (!d_acc || !d_final) return SIPP_E_NOMEM;
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t k = batch_len(batches[b]);
+        std::vector<const uint64_t*> cols;
+        cols.reserve(k);
+        for (uint32_t r = 0; r < batches[b].n_ranges; r++) {
+            const sipp_poly_range& rg = batches[b].ranges[r];
+            for (uint32_t c = rg.col_begin; c < rg.col_end; c++) cols.push_back(oracles[rg.oracle].d_coeffs + (size_t)c * n);
+        }
+        std::vector<uint32_t> apow(6 * k + 6);
+        gl::E2 ap = gl::e2(1);
+        for (size_t c = 0; c < k; c++) {
+            const uint64_t comp[2] = {ap.c0, ap.c1};
+            for (int q = 0; q < 2; q++) {
+                apow[6 * c + 3 * q] = (uint32_t)comp[q] & 0x3FFFFFu;
+                apow[6 * c + 3 * q + 1] = (uint32_t)(comp[q] >> 22) & 0x3FFFFFu;
+                apow[6 * c + 3 * q + 2] = (uint32_t)(comp[q] >> 44);
+            }
+            ap = gl::mul(ap, alpha);
+        }
+        const uint64_t** d_cols = reinterpret_cast<const uint64_t**>(arena_alloc(ctx, (k + 1) * sizeof(uint64_t*)));
+        uint32_t* d_apow = arena_alloc_t<uint32_t>(ctx, apow.size());
+        if (!d_cols || !d_apow) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_cols, cols.data(), k * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_apow, apow.data(), apow.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope
+        // alpha.shift_poly: final = final * alpha^(len of THIS batch) + quotient; `ap` is alpha^k here
+        SIPP_TRY(sipp_k_fri_batch_quotient(ctx, d_cols, (int)k, n, d_apow, d_zp[b], d_zip[b], ap, b == 0, d_acc));
+    }
+    SIPP_TRY(sipp_k_fri_mulx(ctx, d_acc, n, d_final));
+    // ---- commit phase, proof of work, queries ----
+    FriOracleDev ors[8];
+    for (size_t o = 0; o < n_oracles; o++)
+        ors[o] = FriOracleDev{oracles[o].d_lde, m, oracles[o].n_polys + oracles[o].n_salt, oracles[o].d_tree};
+    size_t flen = 0;
+    SIPP_TRY(sipp_fri_prove_core(ctx, ors, (int)n_oracles, log_n, fp, d_final, ch, pf, pos, total, &flen, nullptr));
+    pf[2] = flen;
+    if (pos != total) return sipp_fail(ctx, SIPP_E_BUFSZ, "internal: opening proof length mismatch");
+    *proof_len = pos;
+    memcpy(chs->state, ch.state, sizeof ch.state);
+    memcpy(chs->in_buf, ch.in_buf, sizeof ch.in_buf);
+    memcpy(chs->out_buf, ch.out_buf, sizeof ch.out_buf);
+    chs->n_in = ch.n_in;
+    chs->n_out = ch.n_out;
+    return SIPP_OK;
+}
+
+}  // extern "C"

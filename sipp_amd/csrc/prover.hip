@@ -573,6 +573,51 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(CombArgs a) {
     p[3 * a.n + k] = g1;
 }
 
+// generic batch composition F[k] = sum_j alpha^j col_j[k] for an arbitrary list of coefficient columns (pointer table):
+// the same lazy accumulation, written in the [slices][4][n] layout the division kernels read (batch slot 0)
+struct GCombArgs {
+    const uint64_t* const* cols;
+    int total;
+    size_t n;
+    const uint32_t* apow3;  // [total][2][3]
+    int slices;
+    uint64_t* partial;      // [slices][4][n]
+};
+__global__ void __launch_bounds__(256) fri_gcombine_kernel(GCombArgs a) {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int per = (a.total + a.slices - 1) / a.slices;
+    const int c_lo = blockIdx.y * per, c_hi = min(a.total, c_lo + per);
+    gl::Acc6 G0, G1;
+    G0.zero(); G1.zero();
+    for (int c = c_lo; c < c_hi; c++) {
+        const uint64_t v = a.cols[c][k];
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        const uint32_t* __restrict__ w = a.apow3 + 6 * c;
+        G0.mac(lo, hi, w);
+        G1.mac(lo, hi, w + 3);
+    }
+    uint64_t* p = a.partial + (size_t)blockIdx.y * 4 * a.n;
+    p[k] = gl::canon(G0.reduce());
+    p[a.n + k] = gl::canon(G1.reduce());
+}
+
+// acc = acc * shift + q   (ext, SoA [2][n])
+__global__ void fri_accum_kernel(uint64_t* __restrict__ acc, const uint64_t* __restrict__ q, size_t n, E2 shift, int first) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    E2 r{q[k], q[n + k]};
+    if (!first) r = gl::add(gl::mul(E2{acc[k], acc[n + k]}, shift), r);
+    acc[k] = r.c0;
+    acc[n + k] = r.c1;
+}
+// fin[0] = 0, fin[k + 1] = acc[k]   (multiplication by X; acc[n - 1] is zero by construction)
+__global__ void fri_mulx_kernel(const uint64_t* __restrict__ acc, size_t n, uint64_t* __restrict__ fin) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    fin[k] = k ? acc[k - 1] : 0;
+    fin[n + k] = k ? acc[n + k - 1] : 0;
+}
+
 // one block per batch b (0: point zeta, 1: point g zeta):
 //   F = sum over slices of partial;  S_k = sum_{j >= k} F_j z^j ;  q_{k-1} = S_k z^-k
 // zp = z^k table, zip = z^-k table (ext SoA).  qout: [2][n] (c0 | c1) per batch.
@@ -949,6 +994,47 @@ int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     arena_release(ctx, mk);
+    return SIPP_OK;
+}
+
+// (F(X) - F(z)) / (X - z) of the composition F = sum_j alpha^j col_j of one generic batch, then acc = acc * shift + quotient
+int sipp_k_fri_batch_quotient(sipp_ctx* ctx, const uint64_t* const* d_cols, int total, size_t n, const uint32_t* d_apow3,
+                              const uint64_t* d_zp, const uint64_t* d_zip, gl::E2 shift, bool first, uint64_t* d_acc) {
+    ArenaMark mk = arena_mark(ctx);
+    int slices = 1;
+    while (slices < 64 && ((n / 256) * (size_t)slices < 1024 || (total + slices - 1) / slices > 1024)) slices *= 2;
+    if ((total + slices - 1) / slices > 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: more than 65536 polynomials in one batch");
+    if (n % 1024) return sipp_fail(ctx, SIPP_E_BADARG, "fri: degree must be a multiple of 1024");
+    uint64_t* partial = arena_alloc_t<uint64_t>(ctx, (size_t)slices * 4 * n);
+    uint64_t* q = arena_alloc_t<uint64_t>(ctx, 4 * n);
+    uint64_t* scan = arena_alloc_t<uint64_t>(ctx, 4 * n);
+    const unsigned ntiles = (unsigned)(n / 1024);
+    uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)4 * ntiles);
+    if (!partial || !q || !scan || !totals) return SIPP_E_NOMEM;
+    GCombArgs c{};
+    c.cols = d_cols; c.total = total; c.n = n; c.apow3 = d_apow3; c.slices = slices; c.partial = partial;
+    DivArgs d{};
+    d.partial = partial; d.slices = slices; d.n = n;
+    d.zp[0] = d_zp; d.zp[1] = d_zp; d.zip[0] = d_zip; d.zip[1] = d_zip;
+    d.qout = q;
+    {
+        ProfScope ps(ctx, "fri_combine");
+        hipLaunchKernelGGL(fri_gcombine_kernel, dim3((unsigned)(n / 256), slices), dim3(256), 0, ctx->stream, c);
+    }
+    {
+        ProfScope ps(ctx, "fri_divide");
+        hipLaunchKernelGGL(fri_divide_tiles, dim3(ntiles, 1), dim3(1024), 0, ctx->stream, d, scan, totals);
+        hipLaunchKernelGGL(fri_divide_carry, dim3(1), dim3(256), 0, ctx->stream, totals, (int)ntiles);
+        hipLaunchKernelGGL(fri_divide_finish, dim3(ntiles, 1), dim3(1024), 0, ctx->stream, d, scan, totals);
+        hipLaunchKernelGGL(fri_accum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_acc, q, n, shift, first ? 1 : 0);
+    }
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    arena_release(ctx, mk);
+    return SIPP_OK;
+}
+int sipp_k_fri_mulx(sipp_ctx* ctx, const uint64_t* d_acc, size_t n, uint64_t* d_final) {
+    hipLaunchKernelGGL(fri_mulx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_acc, n, d_final);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
 
