@@ -91,6 +91,7 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

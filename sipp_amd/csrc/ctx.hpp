@@ -77,6 +77,17 @@ struct sipp_ctx {
 
     // second stream for the G1 half of sipp_fold_outputs (created on first use)
     hipStream_t aux_stream = nullptr;
+    // sipp_fold_begin / sipp_fold_finish: a third stream (G2 chain) and the state that lives between the two calls
+    hipStream_t aux2_stream = nullptr;
+    struct Fold {
+        bool active = false;
+        size_t mark = 0;
+        uint32_t* d_ios[2] = {nullptr, nullptr};
+        void* rows[2] = {nullptr, nullptr};
+        int* d_err = nullptr;
+        uint32_t num_io[2] = {0, 0};   // padded
+        size_t n_in[2] = {0, 0};
+    } fold;
 
     // sipp_exp_outputs: sipp_trace_fill stops after the accumulator chains and writes the outputs into the records
     bool outputs_only = false;
@@ -220,3 +231,13 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
 size_t sipp_curve_rows_bytes(int kind, uint32_t log_n);
 // outputs of n1 G1 and n2 G2 obligations, the two accumulator chains on two streams (native.hip's fold of a SIPP round)
 int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2);
+// the same in two phases: begin starts the 255 doublings of every record's point x on two side streams (the exponent and
+// output words of the records are ignored), finish uploads the complete records, selects and sums the powers, and writes the
+// outputs into the records.  Between the two calls the ctx's main stream is free (native.hip computes the round's pairing
+// products there); nothing else may allocate BELOW the arena mark taken by begin.
+int sipp_fold_begin(sipp_ctx* ctx, const uint32_t* g1_ios, size_t n1, const uint32_t* g2_ios, size_t n2);
+int sipp_fold_finish(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2);
+size_t sipp_fold_rows_bytes(int kind, uint32_t num_io);
+int sipp_fold_chain_begin(sipp_ctx* ctx, int kind, const uint32_t* d_ios, uint32_t num_io, uint32_t ppi, void* rows, hipStream_t st);
+int sipp_fold_chain_finish(sipp_ctx* ctx, int kind, uint32_t* d_ios, uint32_t num_io, uint32_t ppi, void* rows, int* d_err,
+                           hipStream_t st);

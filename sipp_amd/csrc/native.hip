@@ -212,6 +212,25 @@ constexpr size_t G1W = 16, G2W = 32, F12W = 96;
 
 bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
+// the obligation records of one round: {x: A2, offset: A1, exp_val: x} (verifier_circuit.rs:92-96), {x: B2, offset: B1, exp_val: 1/x};
+// x == nullptr leaves the exponent words zero (sipp_fold_begin does not read them)
+void fold_records(const std::vector<uint32_t>& A, const std::vector<uint32_t>& B, size_t n, const uint32_t* x, const uint32_t* ix,
+                  std::vector<uint32_t>& rec1, std::vector<uint32_t>& rec2) {
+    const size_t h = n / 2;
+    rec1.assign(h * SIPP_G1_IO_WORDS, 0);
+    rec2.assign(h * SIPP_G2_IO_WORDS, 0);
+    for (size_t i = 0; i < h; i++) {
+        uint32_t* r = &rec1[i * SIPP_G1_IO_WORDS];
+        memcpy(r, &A[(h + i) * G1W], G1W * 4);
+        memcpy(r + 16, &A[i * G1W], G1W * 4);
+        if (x) memcpy(r + 32, x, 32);
+        uint32_t* s = &rec2[i * SIPP_G2_IO_WORDS];
+        memcpy(s, &B[(h + i) * G2W], G2W * 4);
+        memcpy(s + 32, &B[i * G2W], G2W * 4);
+        if (ix) memcpy(s + 64, ix, 32);
+    }
+}
+
 // one round's folds on the device: A' = A1 + [x] A2 (G1 obligations {x: A2, offset: A1, exp_val: x}, verifier_circuit.rs:92-96)
 // and B' = B1 + [1/x] B2; the complete IO records (outputs included) are left in rec1 / rec2
 int fold_round(sipp_ctx* ctx, const std::vector<uint32_t>& A, const std::vector<uint32_t>& B, size_t n, const uint32_t x[8],
@@ -280,8 +299,22 @@ int sipp_prove_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in,
     }
     std::vector<uint32_t> msgs;  // in sending order; reversed at the end (prover_native.rs:78)
     uint32_t z[96], zl[96], zr[96];
-    bool have_first = false;
+    bool have_first = false, fold_started = false;
+    std::vector<uint32_t> rec1, rec2;
+    // the 255 doublings of A2_i / B2_i of a round do not depend on its challenge: they run on side streams while the pairing
+    // products that determine the challenge are computed on the main stream
+    auto begin_fold = [&]() -> int {
+        fold_records(A, B, n, nullptr, nullptr, rec1, rec2);
+        const int rc = sipp_fold_begin(ctx, rec1.data(), n / 2, rec2.data(), n / 2);
+        fold_started = rc == SIPP_OK;
+        return rc;
+    };
+    auto abandon_fold = [&]() {   // drain the side streams and hand the arena back on an error path
+        if (fold_started) (void)sipp_fold_finish(ctx, rec1.data(), rec1.size() / SIPP_G1_IO_WORDS, rec2.data(), rec2.size() / SIPP_G2_IO_WORDS);
+        fold_started = false;
+    };
     if (n > 1) {
+        SIPP_TRY(begin_fold());
         // Z = <A, B> and the first round's Z_L = <A2, B1>, Z_R = <A1, B2> depend on no challenge: ONE device pass
         const size_t h = n / 2;
         std::vector<uint32_t> g1(2 * n * G1W), g2(2 * n * G2W);
@@ -293,7 +326,13 @@ int sipp_prove_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in,
         memcpy(&g2[(n + h) * G2W], &B[h * G2W], h * G2W * 4);      // B2
         const uint32_t off[4] = {0, (uint32_t)n, (uint32_t)(n + h), (uint32_t)(2 * n)};
         uint32_t out[3 * 96];
-        SIPP_TRY(sipp_inner_products_groups(ctx, g1.data(), g2.data(), off, 3, out));
+        {
+            const int rc = sipp_inner_products_groups(ctx, g1.data(), g2.data(), off, 3, out);
+            if (rc != SIPP_OK) {
+                abandon_fold();
+                return rc;
+            }
+        }
         memcpy(z, out, 96 * 4);
         memcpy(zl, out + 96, 96 * 4);
         memcpy(zr, out + 192, 96 * 4);
@@ -304,7 +343,14 @@ int sipp_prove_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in,
     msgs.insert(msgs.end(), z, z + 96);
     t.append(z, 96);
     while (n > 1) {
-        if (!have_first) SIPP_TRY(cross_products(ctx, A, B, n, zl, zr));
+        if (!fold_started) SIPP_TRY(begin_fold());
+        if (!have_first) {
+            const int rc = cross_products(ctx, A, B, n, zl, zr);
+            if (rc != SIPP_OK) {
+                abandon_fold();
+                return rc;
+            }
+        }
         have_first = false;
         msgs.insert(msgs.end(), zl, zl + 96);
         t.append(zl, 96);
@@ -315,8 +361,9 @@ int sipp_prove_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in,
         uint32_t xw[8], ixw[8];
         to_u32(x, xw);
         to_u32(ix, ixw);
-        std::vector<uint32_t> rec1, rec2;
-        SIPP_TRY(fold_round(ctx, A, B, n, xw, ixw, rec1, rec2));
+        fold_records(A, B, n, xw, ixw, rec1, rec2);
+        fold_started = false;
+        SIPP_TRY(sipp_fold_finish(ctx, rec1.data(), n / 2, rec2.data(), n / 2));
         take_outputs(rec1, rec2, n / 2, A, B);
         n /= 2;
     }
@@ -359,7 +406,13 @@ int sipp_verify_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in
     // product Z <- Z Z_L^x Z_R^(1/x) on the host.  The obligations are {x: Z_L, offset: Z, exp_val: x} and
     // {x: Z_R, offset: Z Z_L^x, exp_val: 1/x} (verifier_circuit.rs:111-124).
     std::vector<uint32_t> f12rec(2 * rounds * SIPP_FQ12_IO_WORDS, 0);
+    // the first round's doubling chains (side streams) run beside the Fq12 powers (main stream)
+    std::vector<uint32_t> rec1_0, rec2_0;
+    bool fold0 = false;
     if (rounds) {
+        fold_records(A, B, n, &xs[0], &ixs[0], rec1_0, rec2_0);
+        SIPP_TRY(sipp_fold_begin(ctx, rec1_0.data(), n / 2, rec2_0.data(), n / 2));
+        fold0 = true;
         std::vector<uint32_t> pw(2 * rounds * SIPP_FQ12_IO_WORDS, 0);
         for (size_t r = 0; r < rounds; r++)
             for (int h = 0; h < 2; h++) {
@@ -368,7 +421,13 @@ int sipp_verify_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in
                 p[96] = 1;  // offset = 1
                 memcpy(p + 192, h ? &ixs[r * 8] : &xs[r * 8], 32);
             }
-        SIPP_TRY(sipp_exp_outputs(ctx, SIPP_FQ12_EXP, pw.data(), 2 * rounds));
+        {
+            const int rc = sipp_exp_outputs(ctx, SIPP_FQ12_EXP, pw.data(), 2 * rounds);
+            if (rc != SIPP_OK) {
+                (void)sipp_fold_finish(ctx, rec1_0.data(), n / 2, rec2_0.data(), n / 2);
+                return rc;
+            }
+        }
         for (size_t r = 0; r < rounds; r++)
             for (int h = 0; h < 2; h++) {
                 uint32_t* rec = &f12rec[(2 * r + h) * SIPP_FQ12_IO_WORDS];
@@ -384,7 +443,13 @@ int sipp_verify_native(sipp_ctx* ctx, const uint32_t* A_in, const uint32_t* B_in
     size_t o1 = 0, o2 = 0;
     for (size_t r = 0; r < rounds; r++) {
         std::vector<uint32_t> rec1, rec2;
-        SIPP_TRY(fold_round(ctx, A, B, n, &xs[r * 8], &ixs[r * 8], rec1, rec2));
+        if (r == 0 && fold0) {
+            rec1.swap(rec1_0);
+            rec2.swap(rec2_0);
+            SIPP_TRY(sipp_fold_finish(ctx, rec1.data(), n / 2, rec2.data(), n / 2));
+        } else {
+            SIPP_TRY(fold_round(ctx, A, B, n, &xs[r * 8], &ixs[r * 8], rec1, rec2));
+        }
         if (g1_ios) memcpy(g1_ios + o1, rec1.data(), rec1.size() * 4);
         if (g2_ios) memcpy(g2_ios + o2, rec2.data(), rec2.size() * 4);
         o1 += rec1.size();

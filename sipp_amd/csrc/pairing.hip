@@ -28,7 +28,8 @@ struct T6 {
 
 __device__ __noinline__ void f2_mul(Fq2& r, const Fq2& a, const Fq2& b) { r = fq::mul(a, b); }
 __device__ __noinline__ void f2_sqr(Fq2& r, const Fq2& a) { r = fq::sqr(a); }
-__device__ __noinline__ void f2_inv(Fq2& r, const Fq2& a) { r = fq::inv(a); }
+// one lane inverts one value (the easy part of a final exponentiation): binary extended Euclid instead of a^(p-2)
+__device__ __noinline__ void f2_inv(Fq2& r, const Fq2& a) { r = fq::inv_gcd(a); }
 __device__ __noinline__ void fq_mul(Fq& r, const Fq& a, const Fq& b) { r = fq::mul(a, b); }
 
 __device__ __forceinline__ Fq2 f2_zero() { return Fq2{fq::zero(), fq::zero()}; }
@@ -135,11 +136,69 @@ __device__ __noinline__ void t6_inv(T6& r, const T6& a) {
 // by u).  Every Fq12 value lives in LDS, the 36 Fq2 products of an Fq12 product are
 // taken by 36 lanes (then 11 lanes sum the anti-diagonals and 6 fold w^6 = xi), conjugations and Frobenius maps by 6 lanes;
 // only the single inversion of the easy part runs on one lane.  ~290 Fq12 products: 33 ms on one lane, ~1 ms this way.
+// The base-field products are the latency of everything here (one wave, dependent multiply-add chains): every Fq2 product is
+// therefore split into its three Karatsuba parts a0 b0, a1 b1, (a0 + a1)(b0 + b1) on THREE lanes (two waves per Fq12 value:
+// 36 products = 108 lanes), assembled by two lanes per product, summed along the anti-diagonals by one lane per component.
+constexpr uint32_t NT = 128;   // threads of a pairing workgroup
 struct CoopScratch {
+    Fq part[126];
     Fq2 prod[36];
     Fq2 dsum[11];
 };
+// the Karatsuba part `part` of a * b
+__device__ __forceinline__ void karatsuba_part(Fq& r, const Fq2& a, const Fq2& b, uint32_t part) {
+    // inlined product: the operands are register values (a call through pointers would park them in scratch memory)
+    const Fq x = part == 0 ? a.c0 : part == 1 ? a.c1 : fq::add(a.c0, a.c1);
+    const Fq y = part == 0 ? b.c0 : part == 1 ? b.c1 : fq::add(b.c0, b.c1);
+    r = fq::mul(x, y);
+}
+// component `comp` of the product whose three parts start at p[0]
+__device__ __forceinline__ Fq karatsuba_join(const Fq* p, uint32_t comp) {
+    return comp == 0 ? fq::sub(p[0], p[1]) : fq::sub(fq::sub(p[2], p[0]), p[1]);
+}
+// component `comp` of a * (9 + u) + b
+__device__ __forceinline__ Fq xi_add_comp(const Fq2& a, const Fq2& b, uint32_t comp) {
+    const Fq& m = comp ? a.c1 : a.c0;
+    const Fq m2 = fq::dbl(m), m4 = fq::dbl(m2), m9 = fq::add(fq::dbl(m4), m);
+    return comp ? fq::add(fq::add(m9, a.c0), b.c1) : fq::add(fq::sub(m9, a.c1), b.c0);
+}
+__device__ __forceinline__ void coop_sums_and_fold(T6& r, CoopScratch& sc) {
+    const uint32_t l = threadIdx.x;
+    if (l < 22) {   // anti-diagonal k, component comp
+        const uint32_t k = l >> 1, comp = l & 1;
+        Fq d = fq::zero();
+        for (int i = 0; i < 6; i++) {
+            const int j = (int)k - i;
+            if (j >= 0 && j < 6) d = fq::add(d, comp ? sc.prod[i * 6 + j].c1 : sc.prod[i * 6 + j].c0);
+        }
+        (comp ? sc.dsum[k].c1 : sc.dsum[k].c0) = d;
+    }
+    __syncthreads();
+    if (l < 12) {   // w^6 = xi
+        const uint32_t k = l >> 1, comp = l & 1;
+        const Fq v = k < 5 ? xi_add_comp(sc.dsum[k + 6], sc.dsum[k], comp) : (comp ? sc.dsum[5].c1 : sc.dsum[5].c0);
+        (comp ? r.c[k].c1 : r.c[k].c0) = v;
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void coop_mul(T6& r, const T6& a, const T6& b, CoopScratch& sc) {  // r may alias a or b
+    const uint32_t l = threadIdx.x;
+    if (l < 108) karatsuba_part(sc.part[l], a.c[(l / 3) / 6], b.c[(l / 3) % 6], l % 3);
+    __syncthreads();
+    if (l < 72) {
+        const uint32_t k = l >> 1, comp = l & 1;
+        (comp ? sc.prod[k].c1 : sc.prod[k].c0) = karatsuba_join(&sc.part[3 * k], comp);
+    }
+    __syncthreads();
+    coop_sums_and_fold(r, sc);
+}
+// the final exponentiation runs as ONE wave (its barriers cost nothing then; measured 1.93 ms against 2.19 ms with the
+// 128-thread products and cyclotomic squarings, whose additions on six lanes outweigh the saved products)
+struct CoopScratch64 {
+    Fq2 prod[36];
+    Fq2 dsum[11];
+};
+__device__ __forceinline__ void coop_mul64(T6& r, const T6& a, const T6& b, CoopScratch64& sc) {  // r may alias a or b
     const uint32_t l = threadIdx.x;
     if (l < 36) f2_mul(sc.prod[l], a.c[l / 6], b.c[l % 6]);
     __syncthreads();
@@ -163,6 +222,62 @@ __device__ __forceinline__ void coop_mul(T6& r, const T6& a, const T6& b, CoopSc
     }
     __syncthreads();
 }
+// Granger-Scott squaring of an element of the cyclotomic subgroup (everything after the easy part of the final exponentiation):
+// with a = sum a_i w^i the pairs (x, y) = (a0, a3), (a2, a5), (a1, a4) are squared as elements of Fq4 = Fq2[Y]/(Y^2 - xi):
+//   (x + y Y)^2 = A + B Y,  A = x^2 + xi y^2,  B = 2 x y
+//   a0' = 3 A(a0, a3) - 2 a0    a3' = 3 B(a0, a3) + 2 a3
+//   a4' = 3 A(a2, a5) - 2 a4    a1' = 3 xi B(a2, a5) + 2 a1
+//   a2' = 3 A(a1, a4) - 2 a2    a5' = 3 B(a1, a4) + 2 a5
+// (arkworks' Fp12::cyclotomic_square in the w-power basis).  One wave: the TEN base-field products of a pair -- x0^2, x1^2, x0 x1,
+// y0^2, y1^2, y0 y1, x0 y0, x1 y1, x0 y1, x1 y0 -- take raw components as operands (no additions in front of the products), 30
+// lanes in one phase; then one lane per output component adds them up.  30 base-field products instead of 108.
+struct CycloScratch {
+    Fq part[30];
+};
+__device__ __forceinline__ Fq fq_x9(const Fq& a) {
+    const Fq a2 = fq::dbl(a), a4 = fq::dbl(a2);
+    return fq::add(fq::dbl(a4), a);
+}
+__device__ __forceinline__ void coop_cyclo_sqr64(T6& r, const T6& a, CycloScratch& cs) {  // r may alias a
+    const uint32_t l = threadIdx.x;
+    if (l < 30) {
+        const uint32_t q = l / 10, m = l % 10;
+        const Fq2& x = a.c[q == 0 ? 0 : q == 1 ? 2 : 1];
+        const Fq2& y = a.c[q == 0 ? 3 : q == 1 ? 5 : 4];
+        // operand table: (x0 x0) (x1 x1) (x0 x1) (y0 y0) (y1 y1) (y0 y1) (x0 y0) (x1 y1) (x0 y1) (x1 y0)
+        const Fq& u = (m == 0 || m == 2 || m == 6 || m == 8) ? x.c0 : (m == 1 || m == 7 || m == 9) ? x.c1 : m == 3 || m == 5 ? y.c0 : y.c1;
+        const Fq& v = m == 0 ? x.c0 : (m == 1 || m == 2) ? x.c1 : (m == 3 || m == 6) ? y.c0 : (m == 4 || m == 5 || m == 7 || m == 8) ? y.c1 : y.c0;
+        cs.part[l] = fq::mul(u, v);
+    }
+    __syncthreads();
+    if (l < 12) {
+        const uint32_t q = l >> 2, c = l & 3;
+        const Fq* p = &cs.part[10 * q];
+        Fq out;
+        if (c < 2) {
+            const Fq dy = fq::sub(p[3], p[4]), ey = fq::dbl(p[5]);                       // y^2 = dy + ey u
+            const Fq A = c == 0 ? fq::sub(fq::add(fq::sub(p[0], p[1]), fq_x9(dy)), ey)    // x0^2 - x1^2 + 9 dy - ey
+                                : fq::add(fq::add(fq::dbl(p[2]), fq_x9(ey)), dy);         // 2 x0 x1 + 9 ey + dy
+            const Fq2& z = a.c[q == 0 ? 0 : q == 1 ? 4 : 2];
+            const Fq d = fq::sub(A, c ? z.c1 : z.c0);
+            out = fq::add(fq::dbl(d), A);                                                // 3 A - 2 z
+            Fq2& dst = r.c[q == 0 ? 0 : q == 1 ? 4 : 2];
+            (c ? dst.c1 : dst.c0) = out;
+        } else {
+            const Fq B0 = fq::dbl(fq::sub(p[6], p[7])), B1 = fq::dbl(fq::add(p[8], p[9]));
+            const uint32_t comp = c - 2;
+            Fq t;                                                                         // component of B, or of xi B for the pair (a2, a5)
+            if (q == 1) t = comp ? fq::add(fq_x9(B1), B0) : fq::sub(fq_x9(B0), B1);
+            else t = comp ? B1 : B0;
+            const Fq2& z = a.c[q == 0 ? 3 : q == 1 ? 1 : 5];
+            const Fq s2 = fq::add(t, comp ? z.c1 : z.c0);
+            out = fq::add(fq::dbl(s2), t);                                               // 3 t + 2 z
+            Fq2& dst = r.c[q == 0 ? 3 : q == 1 ? 1 : 5];
+            (comp ? dst.c1 : dst.c0) = out;
+        }
+    }
+    __syncthreads();
+}
 __device__ __forceinline__ void coop_conj(T6& r, const T6& a) {
     const uint32_t l = threadIdx.x;
     if (l < 6) r.c[l] = (l & 1) ? f2_neg(a.c[l]) : a.c[l];
@@ -181,20 +296,21 @@ __device__ __forceinline__ void coop_copy(T6& r, const T6& a) {
     if (l < 6) r.c[l] = a.c[l];
     __syncthreads();
 }
-__device__ __forceinline__ void coop_pow_u(T6& r, const T6& a, CoopScratch& sc) {  // r != a
+__device__ __forceinline__ void coop_pow_u(T6& r, const T6& a, CoopScratch64& sc, CycloScratch& cs) {  // r != a, a cyclotomic
     coop_copy(r, a);
     for (int i = pairing_k::U_BITS - 2; i >= 0; i--) {
-        coop_mul(r, r, r, sc);
-        if ((pairing_k::U >> i) & 1) coop_mul(r, r, a, sc);
+        coop_cyclo_sqr64(r, r, cs);
+        if ((pairing_k::U >> i) & 1) coop_mul64(r, r, a, sc);
     }
 }
 struct FinalExpLds {
     T6 f, g, t, u, fx, fx2, fx3, y0, y1, y2, y3, y4, y5, y6, t0, t1;
-    CoopScratch sc;
+    CoopScratch64 sc;
+    CycloScratch cs;
 };
 // L.f in: the Miller product; L.f out: f^((p^12 - 1)/r).  Called by all 64 lanes of a one-wave workgroup.
 __device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
-    CoopScratch& sc = L.sc;
+    CoopScratch64& sc = L.sc;
     coop_conj(L.t, L.f);
     if (threadIdx.x == 0) {  // the one inversion: ~40 Fq2 products and an Fq inversion, on one lane
         T6 a = L.f, b;
@@ -202,41 +318,41 @@ __device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
         L.u = b;
     }
     __syncthreads();
-    coop_mul(L.g, L.t, L.u, sc);  // f^(p^6 - 1)
+    coop_mul64(L.g, L.t, L.u, sc);  // f^(p^6 - 1)
     coop_frob(L.t, L.g, 2);
-    coop_mul(L.g, L.t, L.g, sc);  // ^(p^2 + 1)
-    coop_pow_u(L.fx, L.g, sc);
-    coop_pow_u(L.fx2, L.fx, sc);
-    coop_pow_u(L.fx3, L.fx2, sc);
+    coop_mul64(L.g, L.t, L.g, sc);  // ^(p^2 + 1)
+    coop_pow_u(L.fx, L.g, sc, L.cs);
+    coop_pow_u(L.fx2, L.fx, sc, L.cs);
+    coop_pow_u(L.fx3, L.fx2, sc, L.cs);
     coop_frob(L.y0, L.g, 1);
     coop_frob(L.t, L.g, 2);
-    coop_mul(L.y0, L.y0, L.t, sc);
+    coop_mul64(L.y0, L.y0, L.t, sc);
     coop_frob(L.t, L.g, 3);
-    coop_mul(L.y0, L.y0, L.t, sc);
+    coop_mul64(L.y0, L.y0, L.t, sc);
     coop_conj(L.y1, L.g);
     coop_frob(L.y2, L.fx2, 2);
     coop_frob(L.t, L.fx, 1);
     coop_conj(L.y3, L.t);
     coop_frob(L.t, L.fx2, 1);
-    coop_mul(L.t, L.fx, L.t, sc);
+    coop_mul64(L.t, L.fx, L.t, sc);
     coop_conj(L.y4, L.t);
     coop_conj(L.y5, L.fx2);
     coop_frob(L.t, L.fx3, 1);
-    coop_mul(L.t, L.fx3, L.t, sc);
+    coop_mul64(L.t, L.fx3, L.t, sc);
     coop_conj(L.y6, L.t);
-    coop_mul(L.t0, L.y6, L.y6, sc);
-    coop_mul(L.t0, L.t0, L.y4, sc);
-    coop_mul(L.t0, L.t0, L.y5, sc);
-    coop_mul(L.t1, L.y3, L.y5, sc);
-    coop_mul(L.t1, L.t1, L.t0, sc);
-    coop_mul(L.t0, L.t0, L.y2, sc);
-    coop_mul(L.t1, L.t1, L.t1, sc);
-    coop_mul(L.t1, L.t1, L.t0, sc);
-    coop_mul(L.t1, L.t1, L.t1, sc);
-    coop_mul(L.t0, L.t1, L.y1, sc);
-    coop_mul(L.t1, L.t1, L.y0, sc);
-    coop_mul(L.t0, L.t0, L.t0, sc);
-    coop_mul(L.f, L.t0, L.t1, sc);
+    coop_mul64(L.t0, L.y6, L.y6, sc);
+    coop_mul64(L.t0, L.t0, L.y4, sc);
+    coop_mul64(L.t0, L.t0, L.y5, sc);
+    coop_mul64(L.t1, L.y3, L.y5, sc);
+    coop_mul64(L.t1, L.t1, L.t0, sc);
+    coop_mul64(L.t0, L.t0, L.y2, sc);
+    coop_mul64(L.t1, L.t1, L.t1, sc);
+    coop_mul64(L.t1, L.t1, L.t0, sc);
+    coop_mul64(L.t1, L.t1, L.t1, sc);
+    coop_mul64(L.t0, L.t1, L.y1, sc);
+    coop_mul64(L.t1, L.t1, L.y0, sc);
+    coop_mul64(L.t0, L.t0, L.t0, sc);
+    coop_mul64(L.f, L.t0, L.t1, sc);
 }
 
 // ---- Miller loop: one WAVE per pair.  f lives in LDS and its products are spread over the lanes like in the final
@@ -274,12 +390,13 @@ struct MillerLds {
     PointLds pt;
     Fq2 q[6];  // Q, pi(Q), -pi^2(Q): (x, y) each
 };
-constexpr uint32_t PL = 36;  // first lane of the point arithmetic (lanes 0..35 belong to the products of f)
+constexpr uint32_t PL = 36;  // first PRODUCT SLOT of the point arithmetic (slots 0..35 belong to the products of f); slot k is
+                             // worked by the three threads 3 k .. 3 k + 2 (Karatsuba parts); thread PL also does the point's additions
 
 // the Fq2 products of lanes PL.. for one level of a point step
 template <int M>
 __device__ __forceinline__ void level_ops(PointLds& P, const POp (&ops)[M], const Fq2*& pa, const Fq2*& pb, Fq2*& po, int& scale) {
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x / 3;
 #pragma unroll
     for (int k = 0; k < M; k++)
         if (t == PL + (uint32_t)k) {
@@ -289,17 +406,27 @@ __device__ __forceinline__ void level_ops(PointLds& P, const POp (&ops)[M], cons
             else pb = &P.v[ops[k].b];
         }
 }
-// ONE call site of f2_mul for every lane that has a product in this phase (operands through per-lane pointers), so that
-// products of f and products of the point step issue together instead of one group after the other
-__device__ __forceinline__ void phase(const PointLds& P, const Fq2* pa, const Fq2* pb, Fq2* po, int scale) {
+// ONE call site of the base-field product for every thread that has a part in this phase (operands through per-thread pointers),
+// so that products of f and products of the point step issue together; then two threads per slot assemble the components
+__device__ __forceinline__ void phase(const PointLds& P, Fq* part_buf, const Fq2* pa, const Fq2* pb, Fq2* po, int scale) {
+    const uint32_t t = threadIdx.x, part = t % 3;
     if (po) {
+        // Fq2 times an Fq scalar s = the parts (a0 s, a1 s, unused) of a product with b = (s, s): one call site for both kinds
+        Fq2 bb;
+        uint32_t pt = part;
         if (scale) {
-            Fq2 r;
-            f2_scale(r, *pa, scale == 1 ? P.yp : P.xpn);
-            *po = r;
+            const Fq& sv = scale == 1 ? P.yp : P.xpn;
+            bb = Fq2{sv, sv};
+            if (part == 2) pt = 0;
         } else {
-            f2_mul(*po, *pa, *pb);
+            bb = *pb;
         }
+        karatsuba_part(part_buf[t], *pa, bb, pt);
+    }
+    __syncthreads();
+    if (po && part < 2) {
+        const Fq v = scale ? part_buf[t] : karatsuba_join(&part_buf[t - part], part);
+        (part ? po->c1 : po->c0) = v;
     }
     __syncthreads();
 }
@@ -333,20 +460,20 @@ __device__ __forceinline__ void line_fold(T6& f, const LineLds& L) {
 //   1: the 36 products of f^2 | X^2, Y Z          2: N^2, D^2, N Z, N X, D Z, D Y (f's anti-diagonals are summed and folded beside)
 //   3: D^3, X D^2, N^2 Z, l0, l1                  4: the 18 products f * line | D W, N U, Y D^3, D^3 Z
 __device__ __forceinline__ void step_double(MillerLds& S) {
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, slot = t / 3;
     PointLds& P = S.pt;
     {
         const Fq2 *pa = nullptr, *pb = nullptr;
         Fq2* po = nullptr;
         int sc = 0;
-        if (t < 36) {
-            pa = &S.f.c[t / 6];
-            pb = &S.f.c[t % 6];
-            po = &S.sc.prod[t];
+        if (slot < 36) {
+            pa = &S.f.c[slot / 6];
+            pb = &S.f.c[slot % 6];
+            po = &S.sc.prod[slot];
         }
         constexpr POp L1[2] = {{vT0, vX, vX}, {vT1, vY, vZ}};
         level_ops(P, L1, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t < 11) {
         Fq2 d = f2_zero();
@@ -375,7 +502,7 @@ __device__ __forceinline__ void step_double(MillerLds& S) {
         int sc = 0;
         constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNZ, vN, vZ}, {vNX, vN, vX}, {vDZ, vD, vZ}, {vDY, vD, vY}};
         level_ops(P, L2, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     {
         const Fq2 *pa = nullptr, *pb = nullptr;
@@ -383,7 +510,7 @@ __device__ __forceinline__ void step_double(MillerLds& S) {
         int sc = 0;
         constexpr POp L3[5] = {{vD3, vD2, vD}, {vXD2, vX, vD2}, {vN2Z, vN2, vZ}, {vL0, vDZ, 0xFE}, {vL1, vNZ, 0xFF}};
         level_ops(P, L3, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t == PL) {
         P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
@@ -395,14 +522,14 @@ __device__ __forceinline__ void step_double(MillerLds& S) {
         const Fq2 *pa = nullptr, *pb = nullptr;
         Fq2* po = nullptr;
         int sc = 0;
-        if (t < 18) {
-            pa = &S.f.c[t / 3];
-            pb = &P.v[vL0 + t % 3];
-            po = &S.line.prod[t];
+        if (slot < 18) {
+            pa = &S.f.c[slot / 3];
+            pb = &P.v[vL0 + slot % 3];
+            po = &S.line.prod[slot];
         }
         constexpr POp L4[4] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vY, vD3}, {vT3, vD3, vZ}};
         level_ops(P, L4, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     line_sums(S.line);
     if (t == PL) {
@@ -418,7 +545,7 @@ __device__ __forceinline__ void step_double(MillerLds& S) {
 //   1: y_Q Z, x_Q Z        2: D^2, N^2, N x_Q, D y_Q, l0, l1        3: the 18 products f * line | D^3, D^2 Z, N^2 Z, X D^2
 //   4: x_Q E, D^3 Z        5: D W, N U, y_Q Z3
 __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, slot = t / 3;
     PointLds& P = S.pt;
     {
         const Fq2 *pa = nullptr, *pb = nullptr;
@@ -426,7 +553,7 @@ __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
         int sc = 0;
         constexpr POp L1[2] = {{vT0, vYQ, vZ}, {vT1, vXQ, vZ}};
         level_ops(P, L1, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t == PL) {
         P.v[vN] = fq::sub(P.v[vT0], P.v[vY]);  // N = y_Q Z - Y
@@ -439,7 +566,7 @@ __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
         int sc = 0;
         constexpr POp L2[6] = {{vD2, vD, vD}, {vN2, vN, vN}, {vNX, vN, vXQ}, {vDY, vD, vYQ}, {vL0, vD, 0xFE}, {vL1, vN, 0xFF}};
         level_ops(P, L2, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t == PL) P.v[vL3] = fq::sub(P.v[vNX], P.v[vDY]);
     __syncthreads();
@@ -447,16 +574,16 @@ __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
         const Fq2 *pa = nullptr, *pb = nullptr;
         Fq2* po = nullptr;
         int sc = 0;
-        if (t < 18) {
-            pa = &S.f.c[t / 3];
-            pb = &P.v[vL0 + t % 3];
-            po = &S.line.prod[t];
+        if (slot < 18) {
+            pa = &S.f.c[slot / 3];
+            pb = &P.v[vL0 + slot % 3];
+            po = &S.line.prod[slot];
         }
         if (advance) {
             constexpr POp L3[4] = {{vD3, vD2, vD}, {vE, vD2, vZ}, {vN2Z, vN2, vZ}, {vXD2, vX, vD2}};
             level_ops(P, L3, pa, pb, po, sc);
         }
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     line_sums(S.line);
     __syncthreads();
@@ -471,7 +598,7 @@ __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
         int sc = 0;
         constexpr POp L4[2] = {{vXQE, vXQ, vE}, {vZ3, vD3, vZ}};
         level_ops(P, L4, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t == PL) {
         P.v[vW] = fq::sub(fq::sub(P.v[vN2Z], P.v[vXD2]), P.v[vXQE]);
@@ -484,7 +611,7 @@ __device__ __forceinline__ void step_add(MillerLds& S, bool advance) {
         int sc = 0;
         constexpr POp L5[3] = {{vT0, vD, vW}, {vT1, vN, vU}, {vT2, vYQ, vZ3}};
         level_ops(P, L5, pa, pb, po, sc);
-        phase(P, pa, pb, po, sc);
+        phase(P, S.sc.part, pa, pb, po, sc);
     }
     if (t == PL) {
         P.v[vX] = P.v[vT0];
@@ -502,7 +629,7 @@ __device__ __forceinline__ Fq load_fq(const uint32_t* w) {
 
 // one wave per pair; g1 [n][16] = (x, y), g2 [n][32] = (x.c0, x.c1, y.c0, y.c1) (reference src/transcript_native.rs:42-54 order);
 // all-zero coordinates stand for the point at infinity (Miller value 1)
-__global__ void __launch_bounds__(64) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
+__global__ void __launch_bounds__(NT) miller_kernel(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ g2, uint32_t n,
                                                     T6* __restrict__ out) {
     __shared__ MillerLds S;
     const uint32_t i = blockIdx.x, t = threadIdx.x;
@@ -623,7 +750,7 @@ int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_off, off, (count + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         {
             ProfScope ps(ctx, "pairing_miller");
-            hipLaunchKernelGGL(miller_kernel, dim3((unsigned)total), dim3(64), 0, ctx->stream, d_g1, d_g2, (uint32_t)total, d_f);
+            hipLaunchKernelGGL(miller_kernel, dim3((unsigned)total), dim3(NT), 0, ctx->stream, d_g1, d_g2, (uint32_t)total, d_f);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         {

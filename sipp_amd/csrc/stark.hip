@@ -663,6 +663,104 @@ int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_i
     return rc;
 }
 
+// ---- two-phase folds (see ctx.hpp) ----
+static int fold_upload(sipp_ctx* ctx, int k, const uint32_t* ios, size_t num, uint32_t padded, uint32_t* d_dst, hipStream_t st) {
+    const size_t ppi = IO_WORDS[k], words = (size_t)padded * ppi;
+    uint32_t* h = reinterpret_cast<uint32_t*>(ctx->h_pinned) + (k ? ctx->h_pinned_words : 0);   // each list has its own half
+    for (size_t io = 0; io < padded; io++) memcpy(h + io * ppi, ios + (io < num ? io : num - 1) * ppi, ppi * 4);
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_dst, h, words * 4, hipMemcpyHostToDevice, st));
+    return SIPP_OK;
+}
+
+int sipp_fold_begin(sipp_ctx* ctx, const uint32_t* g1_ios, size_t n1, const uint32_t* g2_ios, size_t n2) {
+    if (!ctx || !g1_ios || !g2_ios) return SIPP_E_BADARG;
+    if (ctx->fold.active) return sipp_fail(ctx, SIPP_E_BADARG, "fold_begin: a fold is already in flight");
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->aux_stream) SIPP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux2_stream) SIPP_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking));
+    Shape s[2];
+    SIPP_TRY(shape_of(SIPP_G1_EXP, n1, &s[0]));
+    SIPP_TRY(shape_of(SIPP_G2_EXP, n2, &s[1]));
+    const uint32_t* ios[2] = {g1_ios, g2_ios};
+    const size_t num[2] = {n1, n2};
+    for (int k = 0; k < 2; k++)
+        if ((size_t)s[k].num_io * IO_WORDS[k] + 2 > ctx->h_pinned_words)
+            return sipp_fail(ctx, SIPP_E_NOMEM, "fold: obligation list larger than half of the pinned staging buffer");
+    sipp_ctx::Fold& f = ctx->fold;
+    f.mark = ctx->arena_off;
+    f.d_err = arena_alloc_t<int>(ctx, 2);
+    for (int k = 0; k < 2; k++) {
+        f.num_io[k] = s[k].num_io;
+        f.n_in[k] = num[k];
+        f.d_ios[k] = arena_alloc_t<uint32_t>(ctx, (size_t)s[k].num_io * IO_WORDS[k]);
+        f.rows[k] = arena_alloc(ctx, sipp_fold_rows_bytes(k, s[k].num_io));
+    }
+    if (!f.d_err || !f.d_ios[0] || !f.d_ios[1] || !f.rows[0] || !f.rows[1]) {
+        ctx->arena_off = f.mark;
+        return SIPP_E_NOMEM;
+    }
+    hipStream_t st[2] = {ctx->aux_stream, ctx->aux2_stream};
+    int rc = SIPP_OK;
+    // earlier work on the main stream may still be using the arena block handed out here: order the side streams behind it
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 2 && rc == SIPP_OK; k++) {
+        rc = fold_upload(ctx, k, ios[k], num[k], s[k].num_io, f.d_ios[k], st[k]);
+        // the staging buffer belongs to the caller again when begin returns (sipp_exp_outputs and the provers stage through it)
+        if (rc == SIPP_OK && hipStreamSynchronize(st[k]) != hipSuccess) rc = sipp_fail(ctx, SIPP_E_HIP, "fold_begin: upload failed");
+        if (rc == SIPP_OK) rc = sipp_fold_chain_begin(ctx, k, f.d_ios[k], s[k].num_io, IO_WORDS[k], f.rows[k], st[k]);
+    }
+    if (rc != SIPP_OK) {
+        (void)hipStreamSynchronize(st[0]);
+        (void)hipStreamSynchronize(st[1]);
+        ctx->arena_off = f.mark;
+        return rc;
+    }
+    f.active = true;
+    return SIPP_OK;
+}
+
+int sipp_fold_finish(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2) {
+    if (!ctx || !g1_ios || !g2_ios) return SIPP_E_BADARG;
+    sipp_ctx::Fold& f = ctx->fold;
+    if (!f.active || f.n_in[0] != n1 || f.n_in[1] != n2) return sipp_fail(ctx, SIPP_E_BADARG, "fold_finish: no matching fold_begin");
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st[2] = {ctx->aux_stream, ctx->aux2_stream};
+    uint32_t* ios[2] = {g1_ios, g2_ios};
+    const size_t num[2] = {n1, n2}, outw[2] = {16, 32};
+    uint32_t* h = reinterpret_cast<uint32_t*>(ctx->h_pinned);
+    volatile int* h_err = reinterpret_cast<volatile int*>(h + 2 * ctx->h_pinned_words - 2);
+    int rc = SIPP_OK;
+    // the staging halves are free again only when the uploads of begin have completed: the chains are long done by now
+    for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(st[k]);
+    h_err[0] = h_err[1] = 0;
+    for (int k = 0; k < 2 && rc == SIPP_OK; k++) {
+        const size_t ppi = IO_WORDS[k];
+        (void)hipMemsetAsync(f.d_err + k, 0, sizeof(int), st[k]);
+        rc = fold_upload(ctx, k, ios[k], num[k], f.num_io[k], f.d_ios[k], st[k]);     // the complete records (exponents now known)
+        if (rc == SIPP_OK) rc = sipp_fold_chain_finish(ctx, k, f.d_ios[k], f.num_io[k], (uint32_t)ppi, f.rows[k], f.d_err + k, st[k]);
+    }
+    for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(st[k]);   // uploads read the staging halves the downloads write
+    if (rc == SIPP_OK)
+        for (int k = 0; k < 2; k++) {
+            const size_t ppi = IO_WORDS[k];
+            (void)hipMemcpyAsync(h + (k ? ctx->h_pinned_words : 0), f.d_ios[k], num[k] * ppi * 4, hipMemcpyDeviceToHost, st[k]);
+            (void)hipMemcpyAsync(const_cast<int*>(h_err) + k, f.d_err + k, sizeof(int), hipMemcpyDeviceToHost, st[k]);
+        }
+    const hipError_t e0 = hipStreamSynchronize(st[0]), e1 = hipStreamSynchronize(st[1]);
+    if (rc == SIPP_OK && (e0 != hipSuccess || e1 != hipSuccess)) rc = sipp_fail(ctx, SIPP_E_HIP, "fold_finish: stream synchronisation failed");
+    if (rc == SIPP_OK && (h_err[0] || h_err[1])) rc = sipp_fail(ctx, h_err[0] ? h_err[0] : h_err[1], "fold: obligation not provable");
+    if (rc == SIPP_OK)
+        for (int k = 0; k < 2; k++) {
+            const size_t ppi = IO_WORDS[k];
+            const uint32_t* src = h + (k ? ctx->h_pinned_words : 0);
+            for (size_t io = 0; io < num[k]; io++)
+                memcpy(ios[k] + io * ppi + (ppi - outw[k]), src + io * ppi + (ppi - outw[k]), outw[k] * 4);
+        }
+    ctx->arena_off = f.mark;
+    f.active = false;
+    return rc;
+}
+
 extern "C" {
 
 int sipp_g1_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,

@@ -938,6 +938,39 @@ size_t sipp_curve_rows_bytes(int kind, uint32_t log_n) {
     return ((size_t)1 << log_n) * (kind == 0 ? sizeof(RowPts<1>) : sizeof(RowPts<2>));
 }
 
+// ---- the folds of a native SIPP round in two phases (native.hip) ----------------------------------------------------------
+// A' = A1 + [x] A2 and B' = B1 + [1/x] B2 need the challenge x only for the SELECTION of the powers 2^k A2 / 2^k B2, not for
+// the 255 doublings that produce them: phase A (the doubling chains, 1.8 ms of pure latency) therefore runs while the round's
+// pairing products -- which determine x -- are still being computed; phase B (scan over the exponent bits, outputs) follows.
+size_t sipp_fold_rows_bytes(int kind, uint32_t num_io) {
+    return (size_t)num_io * 512 * (kind == 0 ? sizeof(RowPts<1>) : sizeof(RowPts<2>));
+}
+int sipp_fold_chain_begin(sipp_ctx* ctx, int kind, const uint32_t* d_ios, uint32_t num_io, uint32_t ppi, void* rows, hipStream_t st) {
+    // (no ProfScope: these launches go to a side stream, the event brackets belong to the main one)
+    if (kind == 0)
+        hipLaunchKernelGGL((curve_dbl_par_kernel<1, 4>), dim3((num_io + 15) / 16), dim3(64), 0, st, d_ios, num_io, ppi,
+                           reinterpret_cast<RowPts<1>*>(rows));
+    else
+        hipLaunchKernelGGL((curve_dbl_par_kernel<2, 8>), dim3((num_io + 7) / 8), dim3(64), 0, st, d_ios, num_io, ppi,
+                           reinterpret_cast<RowPts<2>*>(rows));
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+int sipp_fold_chain_finish(sipp_ctx* ctx, int kind, uint32_t* d_ios, uint32_t num_io, uint32_t ppi, void* rows, int* d_err,
+                           hipStream_t st) {
+    if (kind == 0) {
+        hipLaunchKernelGGL(curve_scan_kernel<1>, dim3(num_io), dim3(256), 0, st, d_ios, num_io, ppi, reinterpret_cast<RowPts<1>*>(rows));
+        hipLaunchKernelGGL(curve_outputs_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, st, reinterpret_cast<RowPts<1>*>(rows), d_ios,
+                           num_io, ppi, d_err);
+    } else {
+        hipLaunchKernelGGL(curve_scan_kernel<2>, dim3(num_io), dim3(256), 0, st, d_ios, num_io, ppi, reinterpret_cast<RowPts<2>*>(rows));
+        hipLaunchKernelGGL(curve_outputs_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, st, reinterpret_cast<RowPts<2>*>(rows), d_ios,
+                           num_io, ppi, d_err);
+    }
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
 // d_ios: [num_io][pi_per_io] u32 on the device (padded); d_trace: [W][n] zero-initialised by the caller is NOT
 // required: every main column is written here.  d_err: device int, 0 on entry.
 int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
