@@ -16,6 +16,8 @@ pub struct SippStarkConfig {
     pub final_poly_bits: u32,
     pub num_queries: u32,
     pub num_challenges: u32,
+    /// 0 = duplex grind (plonky2 fri/prover.rs of 2023), 1 = hash grind (the earlier rule)
+    pub pow_rule: u32,
 }
 
 pub const SIPP_G1_EXP: c_int = 0;

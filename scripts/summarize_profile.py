@@ -41,11 +41,11 @@ out = {
     "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0 / launches,
 }
 NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel")
-steps_profiled = 3   # --steps 2 --warmup 1
+steps_profiled = 4   # --steps 2 --warmup 1, plus the serial step bench.py appends for kernel_ms_serial
 out["ntt"] = {"kernels": {k: {"launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"]}
                           for k in NTT if nf.get(k, 0)},
               "traffic_bytes_per_instance": sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / steps_profiled,
-              "note": "all NTT / LDE kernels of one n = 128 instance (3 instances profiled: 1 warm-up + 2 steps); FETCH_SIZE x2"}
+              "note": "all NTT / LDE kernels of one n = 128 instance (4 instances profiled: 1 warm-up + 2 timed steps + the serial step); FETCH_SIZE x2"}
 out["merkle"] = {k: nf.get(k, 0) // steps_profiled for k in ("merkle_subtree_kernel", "merkle_level_kernel", "merkle_level_quad_kernel") if nf.get(k, 0)}
 import os
 if os.path.exists("%s/pmc_v/run_counter_collection.csv" % src):

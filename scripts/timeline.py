@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Concurrency analysis of a rocprofv3 kernel trace of bench.py: for the last timed step, how much wall-clock has
 0 / 1 / 2 / 3 streams busy, and which kernels run while fewer than all three streams are busy.
-usage: timeline.py <run_kernel_trace.csv>"""
+usage: timeline.py <run_kernel_trace.csv> [step index, default -3: bench.py appends a serial step and the native chain after the timed steps]"""
 import collections, csv, re, sys
 
 rows = []
@@ -23,9 +23,15 @@ for m in marks:
     cuts.append(i)
 steps = [rows[a:b] for a, b in zip(cuts, cuts[1:] + [len(rows)])]
 print("steps found:", len(steps), [len(s) for s in steps])
-st = steps[-1]
+# bench.py appends a serial step and the native chain after the timed steps: analyse the last step that looks like a timed
+# one (the most common launch count), or the index given on the command line
+if len(sys.argv) > 2:
+    st = steps[int(sys.argv[2])]
+else:
+    cnt = collections.Counter(len(x) for x in steps[1:]).most_common(1)[0][0]
+    st = [x for x in steps if abs(len(x) - cnt) <= 2][-1]
 t0, t1 = min(s for s, _, _, _ in st), max(e for _, e, _, _ in st)
-print("last step: %.2f ms, %d launches" % ((t1 - t0) / 1e6, len(st)))
+print("analysed step: %.2f ms, %d launches" % ((t1 - t0) / 1e6, len(st)))
 ev = []
 for s, e, q, n in st:
     ev.append((s, 1, q, n))
