@@ -759,7 +759,10 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
     return SIPP_OK;
 }
 
-// 2^15 <= n <= 2^17, blowup 2: gather + low-bit DIT | fused middle | low-bit DIF of the 2n-point transform
+// 2^15 <= n <= 2^17, blowup 2: gather + low-bit DIT | fused middle | low-bit DIF of the 2n-point transform.
+// (Tried for 2^18 .. 2^21 as well -- 8 / 4 blocks per gather tile, one extra strided pass, 8- or 9-bit fused top: no gain, 7.1-7.8 ms
+// against 7.1-7.3 ms for 134 M elements.  The three per-element tables (16 + 8 + 8 B per input element) no longer fit the 4 MB L2
+// of an XCD there, and the 16384-element tile of a 9-bit top runs one block per CU; the pass-by-pass path keeps those sizes.)
 int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n) {
     const uint32_t k1 = 8, k2 = log_n - k1;
     const size_t n = (size_t)1 << log_n;
