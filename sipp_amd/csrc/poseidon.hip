@@ -9,6 +9,7 @@
 #include "ctx.hpp"
 #include "poseidon.cuh"
 #include "poseidon_quad.cuh"
+#include "poseidon_pair.cuh"
 #include "prover.hpp"
 
 namespace {
@@ -80,6 +81,35 @@ __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_
         d[2] = s[2];
     } else if (q == 1) {
         d[3] = s[0];
+    }
+}
+
+// ---- two lanes per state (poseidon_pair.cuh): the middle ground for thin launches ----
+__global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
+                                                                  uint32_t ncols, uint64_t n_leaves,
+                                                                  uint64_t* __restrict__ digests) {
+    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
+    poseidon_quad::load_tables(tab);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t leaf = tid >> 1;
+    const uint32_t h = (uint32_t)tid & 1;
+    if (leaf >= n_leaves) return;  // n_leaves is a multiple of 32: whole pairs / waves leave together
+    uint64_t s[6] = {0, 0, 0, 0, 0, 0};
+    const uint64_t* p = lde + leaf;
+    for (uint32_t c = 0; c < ncols; c += 8) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t e = 6 * h + j;
+            if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
+        }
+        poseidon_pair::permute(s, h, tab);
+    }
+    if (h == 0) {
+        uint64_t* d = digests + 4 * leaf;
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+        d[3] = s[3];
     }
 }
 
@@ -410,7 +440,18 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
     // park 4 waves on one CU and leave three quarters of the CUs idle
     ProfScope ps(ctx, "poseidon_leaves");
-    if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
+    // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.cuh, the default since round 2) costs
+    // 33.1 k lane-instructions per permutation against 39.5 k for four and is SLOWER alone (2^13 x 4096 columns: 19.1 ms against
+    // 12.0 ms: 37 us per sequential permutation instead of 23 us) but FASTER where it matters, beside the other two proofs: the
+    // instance is bound by total instruction issue (68.5 ms against 70.5-70.8 ms single, 61.1 against 63.6-63.9 ms with three
+    // instances in flight).  SIPP_THIN_LANES=4 restores the four-lane kernel.
+    static int thin_lanes = -1;
+    if (thin_lanes < 0) thin_lanes = getenv("SIPP_THIN_LANES") ? atoi(getenv("SIPP_THIN_LANES")) : 2;
+    if (thin_lanes == 2 && ncols > 4 && n >= 32 && n <= quad_threshold()) {
+        unsigned grid = (unsigned)((2 * n + 255) / 256);
+        hipLaunchKernelGGL(poseidon_leaves_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
+    } else if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
         // thin launch: four lanes per state -> 4x the waves
         unsigned grid = (unsigned)((4 * n + 255) / 256);
         hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
