@@ -26,13 +26,14 @@ shutil.copy("%s/stats/run_kernel_stats.csv" % src, dst + "_bench_n128_kernel_sta
 shutil.copy("%s/bench_line.json" % src, dst + "_bench_n128_bench_line.json")
 f, nf = counters("pmc_f")
 w, nw = counters("pmc_w")
-leaf = ("poseidon_leaves_kernel", "poseidon_leaves_quad_kernel")
+leaf = ("poseidon_leaves_kernel", "poseidon_leaves_quad_kernel", "poseidon_leaves_pair_kernel")
+leaf = tuple(k for k in leaf if k in nf)
 fetch_kb = sum(f[k]["FETCH_SIZE"] for k in leaf)
 write_kb = sum(w[k]["WRITE_SIZE"] for k in leaf)
 launches = sum(nf[k] for k in leaf)
 out = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
-    "kernel": "poseidon_leaves (one-state-per-lane + four-lanes-per-state kernels)",
+    "kernel": "poseidon_leaves (one-state-per-lane kernel for the 2^17-leaf trees + two-lanes-per-state kernel for the thin Fq12 trees)",
     "launches": launches,
     "FETCH_SIZE_kb_sum": fetch_kb,
     "WRITE_SIZE_kb_sum": write_kb,
@@ -57,7 +58,7 @@ if os.path.exists("%s/pmc_v/run_counter_collection.csv" % src):
                                   "launches_per_instance": nv[k] / steps_profiled}
                               for k, x in sorted(v.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]) if x["SQ_INSTS_VALU"] > 0}},
               open(dst + "_valu_by_kernel.json", "w"), indent=1)
-    out["leaf_valu_insts_per_launch"] = sum(v[k]["SQ_INSTS_VALU"] for k in leaf) / max(1, sum(nv[k] for k in leaf))
+    out["leaf_valu_insts_per_launch"] = sum(v[k]["SQ_INSTS_VALU"] for k in leaf) / max(1, sum(nv.get(k, 0) for k in leaf))
     out["leaf_valu_note"] = "SQ_INSTS_VALU (wave-level VALU instructions) of both leaf-hash kernels, bench.py --steps 2 --warmup 1, per launch"
 i, ni = counters("pmc_i")
 out["valu"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -- python3 scripts/perf_generic.py 16 1024",
