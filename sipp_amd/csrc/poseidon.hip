@@ -89,7 +89,9 @@ __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_
                                                                   uint32_t ncols, uint64_t n_leaves,
                                                                   uint64_t* __restrict__ digests) {
     __shared__ uint64_t tab[poseidon_quad::T_WORDS];
+    __shared__ uint32_t blk[poseidon_pair::B_WORDS];
     poseidon_quad::load_tables(tab);
+    poseidon_pair::load_block_tables(blk);
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t leaf = tid >> 1;
     const uint32_t h = (uint32_t)tid & 1;
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_
             const uint32_t e = 6 * h + j;
             if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
         }
-        poseidon_pair::permute(s, h, tab);
+        poseidon_pair::permute(s, h, tab, blk);
     }
     if (h == 0) {
         uint64_t* d = digests + 4 * leaf;

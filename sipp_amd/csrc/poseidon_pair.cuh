@@ -66,8 +66,78 @@ __device__ __forceinline__ void mds_full(uint64_t s[6], uint32_t diag0 /* 8 in t
     }
 }
 
+// LDS copy of the lazy-block tables of the one-lane kernel (poseidon.cuh::partial_rounds_blocked), plus the limbs of 25 = M[0][0]
+constexpr int B_WORDS = 2 * SIPP_POSEIDON_BLK_WORDS + 3;
+__device__ __forceinline__ void load_block_tables(uint32_t* blk) {
+    for (int i = threadIdx.x; i < B_WORDS; i += blockDim.x)
+        blk[i] = i < 2 * SIPP_POSEIDON_BLK_WORDS ? poseidon::c_blk3[i] : (i == 2 * SIPP_POSEIDON_BLK_WORDS ? 25u : 0u);
+    __syncthreads();
+}
+
+// The 22 partial rounds, lazily in two blocks of 11 like the one-lane kernel: inside a block only element 0 is reduced mod p,
+// everything else is (u32 half of a start-of-block value or of an x_k) x (22-bit limb of a constant) accumulated into 64-bit sums
+// (gl::Acc6).  Split over the pair: a lane multiplies its OWN six start values and the x_j of its parity, the two partial sums
+// meet through one DPP swap; both lanes then hold element 0 and evaluate x^7 together -- x^2 on both, x^3 on the even and x^4
+// on the odd lane, swapped, x^3 x^4 on both: three products deep instead of four.  Constants are per lane (they depend on
+// which six elements the lane owns), hence from LDS.
+__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
+    constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
+    const uint32_t* C25 = blk + 2 * SIPP_POSEIDON_BLK_WORDS;
+#pragma unroll 1
+    for (int b = 0; b < 22 / B; b++) {
+        const uint32_t* T = blk + SIPP_POSEIDON_BLK_WORDS * b;
+        uint32_t sl[6], sh[6], xl[B], xh[B];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            sl[j] = (uint32_t)s[j];
+            sh[j] = (uint32_t)(s[j] >> 32);
+        }
+        uint64_t s0 = pair_bcast0(s[0]);
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            const uint64_t x2 = gl::mul_nc(s0, s0);
+            const uint64_t y = gl::mul_nc(x2, h ? x2 : s0);
+            const uint64_t x = gl::add_nc(gl::mul_nc(y, pair_swap(y)), tab[T_SCALAR + B * b + k]);
+            xl[k] = (uint32_t)x;
+            xh[k] = (uint32_t)(x >> 32);
+            const uint32_t* Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
+            gl::Acc6 acc;
+            acc.zero();
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                // element e = 6 h + j carries weight e - 1; the even lane's j = 0 IS element 0: it contributes 25 x_k
+                const bool is0 = j == 0 && h == 0;
+                const uint32_t* w = is0 ? C25 : Wt + 3 * (6 * h + j - 1);
+                acc.mac(is0 ? xl[k] : sl[j], is0 ? xh[k] : sh[j], w);
+            }
+#pragma unroll
+            for (int m = 0; 2 * m < k; m++) {
+                // x_j, j < k: j = 2 m on the even lane, 2 m + 1 (if it exists) on the odd one
+                const bool odd_ok = 2 * m + 1 < k;
+                const uint32_t lo = h ? (odd_ok ? xl[odd_ok ? 2 * m + 1 : 0] : 0u) : xl[2 * m];
+                const uint32_t hi = h ? (odd_ok ? xh[odd_ok ? 2 * m + 1 : 0] : 0u) : xh[2 * m];
+                acc.mac(lo, hi, Wt + 33 + 3 * (2 * m + (odd_ok ? h : 0)));
+            }
+            const uint64_t part = gl::canon(acc.reduce());
+            s0 = gl::add(part, pair_swap(part));
+        }
+        const uint32_t* V = T + 33 * B + 3 * (B * (B - 1) / 2);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const bool is0 = j == 0 && h == 0;
+            gl::Acc6 acc;
+            acc.set(sl[j], sh[j]);
+            const uint32_t* v = V + 3 * ((is0 ? 0 : 6 * h + j - 1) * B);
+#pragma unroll
+            for (int k = 0; k < B; k++) acc.mac(xl[k], xh[k], v + 3 * k);
+            const uint64_t r = acc.reduce();
+            s[j] = is0 ? s0 : r;
+        }
+    }
+}
+
 // s: this lane's six elements (6 h + j); h = lane & 1; tab = LDS tables
-__device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const uint64_t* tab) {
+__device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
     const uint32_t diag0 = h == 0 ? 8u : 0u;
     const uint32_t e0 = 6 * h;
 #pragma unroll 1
@@ -102,28 +172,7 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const u
 #pragma unroll
         for (int j = 1; j < 6; j++) s[j] = t[j];
     }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        // x = sbox(element 0) + scalar, evaluated by both lanes on their s[0], taken from the even lane
-        uint64_t x = gl::add_nc(poseidon::sbox(s[0]), tab[T_SCALAR + r]);
-        x = pair_bcast0(x);
-        poseidon::Acc160 acc;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const uint32_t e = e0 + j;
-            const uint64_t wv = tab[T_WHAT + r * 11 + (e ? e - 1 : 0)];
-            acc.mac(e ? s[j] : x, e ? wv : 25);  // element 0 contributes x * M00
-        }
-        uint64_t part = gl::canon(acc.reduce());
-        part = gl::add(part, pair_swap(part));   // sum over the pair
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const uint32_t e = e0 + j;
-            const uint64_t v = tab[T_VS + r * 11 + (e ? e - 1 : 0)];
-            const uint64_t upd = gl::mad_nc(x, v, s[j]);
-            s[j] = e ? upd : part;
-        }
-    }
+    partial_rounds_blocked(s, h, tab, blk);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
