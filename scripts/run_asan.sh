@@ -14,7 +14,7 @@ LD_PRELOAD="$ASAN_LIB" python -m pytest tests -q -m "not gpu" -x \
     --deselect tests/test_host_cpp.py --deselect tests/test_abi.py "$@"
 # the C++ host layer (include/sipp_host.hpp): flat-proof parsing / record layouts under the sanitizers
 make -C tests/host -s asan
-python - <<'PY'
+env -u SIPP_ORACLE_ASAN python - <<'PY'
 import numpy as np
 from tests import _oracle
 _oracle.stark_prove(0, np.load("tests/golden/sipp_n4_ios.npz")["g1"]).tofile("/tmp/sipp_asan_proof.bin")
