@@ -67,11 +67,62 @@ __device__ __forceinline__ void mds_full(uint64_t s[6], uint32_t diag0 /* 8 in t
 }
 
 // LDS copy of the lazy-block tables of the one-lane kernel (poseidon.cuh::partial_rounds_blocked), plus the limbs of 25 = M[0][0]
-constexpr int B_WORDS = 2 * SIPP_POSEIDON_BLK_WORDS + 3;
+// then the limbs of the merged affine layer of round 3 (poseidon.cuh::full_round3_combined): C3[11][12][3] and its constants
+constexpr int B_C25 = 2 * SIPP_POSEIDON_BLK_WORDS, B_COMB3 = B_C25 + 3, B_COMBC = B_COMB3 + 396, B_WORDS = B_COMBC + 24;
 __device__ __forceinline__ void load_block_tables(uint32_t* blk) {
-    for (int i = threadIdx.x; i < B_WORDS; i += blockDim.x)
-        blk[i] = i < 2 * SIPP_POSEIDON_BLK_WORDS ? poseidon::c_blk3[i] : (i == 2 * SIPP_POSEIDON_BLK_WORDS ? 25u : 0u);
+    for (int i = threadIdx.x; i < B_WORDS; i += blockDim.x) {
+        uint32_t v;
+        if (i < B_C25) v = poseidon::c_blk3[i];
+        else if (i < B_COMB3) v = i == B_C25 ? 25u : 0u;
+        else if (i < B_COMBC) v = poseidon::c_comb3[i - B_COMB3];
+        else v = (uint32_t)(poseidon::c_comb_c[(i - B_COMBC) >> 1] >> (32 * ((i - B_COMBC) & 1)));
+        blk[i] = v;
+    }
     __syncthreads();
+}
+
+// Full round 3 without its own MDS: its linear layer, the first constants of the sparse form and the dense 11 x 11
+// pre-multiplication are ONE affine map s -> C s + c (tools/gen_poseidon_header.py combined_layer): row 0 is the MDS row with
+// its small constants, rows 1..11 are twelve lazy multiply-accumulates each, started from c.
+__device__ __forceinline__ void full_round3_combined(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t e0 = 6 * h;
+#pragma unroll
+    for (int j = 0; j < 6; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * 3 + e0 + j]));
+    Gathered g;
+    gather(s, g);
+    const uint32_t* C3 = blk + B_COMB3;
+    const uint32_t* CC = blk + B_COMBC;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const uint32_t e = e0 + j;
+        // rows 1..11 (for the even lane's j = 0 the row index is clamped and the result replaced below)
+        const uint32_t row = e ? e - 1 : 0;
+        gl::Acc6 acc;
+        acc.set(CC[2 * e], CC[2 * e + 1]);
+#pragma unroll
+        for (int d = 0; d < 12; d++) {
+            const uint32_t ie = d < 6 ? e0 + d : e0 + d - 12 + (h ? 0 : 12);   // (6 h + d) mod 12
+            acc.mac(g.lo[d], g.hi[d], C3 + 3 * (row * 12 + ie));
+        }
+        uint64_t r = acc.reduce();
+        if (j == 0) {
+            // element 0: row 0 of the MDS (+ DIAG[0] = 8) on the even lane, with gathered index d = element d there
+            uint64_t al = (uint64_t)g.lo[0] * 8u, ah = (uint64_t)g.hi[0] * 8u;
+#pragma unroll
+            for (int d = 0; d < 12; d++) {
+                al += (uint64_t)g.lo[d] * CIRC[d];
+                ah += (uint64_t)g.hi[d] * CIRC[d];
+            }
+            const uint64_t l = al + (ah << 32);
+            const uint32_t hh = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
+            const uint64_t c0 = ((uint64_t)CC[1] << 32) | CC[0];
+            const uint64_t m0 = gl::add_nc(gl::reduce96_nc(hh, l), c0);
+            r = h ? r : m0;
+        }
+        s[j] = r;
+        asm volatile("" ::: "memory");   // keep the next row's table loads behind this one (register pressure)
+    }
 }
 
 // The 22 partial rounds, lazily in two blocks of 11 like the one-lane kernel: inside a block only element 0 is reduced mod p,
@@ -141,37 +192,12 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const u
     const uint32_t diag0 = h == 0 ? 8u : 0u;
     const uint32_t e0 = 6 * h;
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
         for (int j = 0; j < 6; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
         mds_full(s, diag0);
     }
-    // ---- partial rounds, sparse form ----
-#pragma unroll
-    for (int j = 0; j < 6; j++) s[j] = gl::add_nc(s[j], tab[T_FIRST + e0 + j]);
-    {
-        // dense pre-multiplication of elements 1..11 (element 0 passes through)
-        Gathered g;
-        gather(s, g);
-        uint64_t t[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const uint32_t e = e0 + j;                // output element
-            const uint32_t row = e == 0 ? 0 : e - 1;  // row of the 11 x 11 block (the even lane's j = 0 is discarded)
-            poseidon::Acc160 acc;
-#pragma unroll
-            for (int d = 0; d < 12; d++) {
-                const uint32_t ie = (e0 + d) % 12;    // input element; element 0 has coefficient 0
-                const uint64_t cv = tab[T_MI + row * 11 + (ie ? ie - 1 : 0)];
-                acc.mac(((uint64_t)g.hi[d] << 32) | g.lo[d], ie ? cv : 0);
-            }
-            t[j] = acc.reduce();
-            asm volatile("" ::: "memory");   // keep the next output's table loads behind this one (register pressure)
-        }
-        if (h != 0) s[0] = t[0];
-#pragma unroll
-        for (int j = 1; j < 6; j++) s[j] = t[j];
-    }
+    full_round3_combined(s, h, tab, blk);
     partial_rounds_blocked(s, h, tab, blk);
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
