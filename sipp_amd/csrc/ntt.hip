@@ -49,9 +49,144 @@ struct PassArgs {
     const uint64_t* pw_hi;
     uint64_t pw_step;
     uint64_t cscale;  // 0 = none; multiplied in after the butterflies
+    uint32_t r16;     // radix-2^4 register rounds (see tile_stages)
 };
 
 __device__ __forceinline__ uint32_t lds_idx(uint32_t e) { return e + (e >> LOG_SEG); }
+
+// LDS placement of tile element e: one u64 of padding per 16 (lds_idx), optionally one more per 2^BLK elements so that a
+// scatter over blocks (the bit-reversed gather of lde_gather_kernel) is conflict-free as well
+struct IdxPlain {
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
+};
+struct IdxBlocked {
+    uint32_t blk;   // log2 block size
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
+};
+
+// all butterfly stages of one bit group on an LDS tile of E elements: k stages over rows (element stride T = 2^lt)
+template <class Idx>
+__device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit,
+                                            Idx lidx, bool r16) {
+    const uint32_t R = 1u << k, T = 1u << lt;
+    uint32_t s = 0;
+    // radix-2^4 in registers: a lane loads the 16 elements of a hexadecuple, applies FOUR stages and writes them back -- a quarter
+    // of the LDS round trips, index arithmetic and barriers of radix 2^2, 15 twiddle loads instead of 24 (same 32 products)
+    const uint32_t sixteenth = E >> 4;
+    for (; r16 && s + 3 < k; s += 4) {
+        const uint32_t log_q = dit ? s : (k - 4 - s);
+        const uint32_t q = 1u << log_q;
+        for (uint32_t idx = threadIdx.x; idx < sixteenth; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 4) - 1);
+            const uint32_t g = rest >> (k - 4);
+            const uint32_t j = b & (q - 1);
+            const uint32_t r0 = ((b >> log_q) << (log_q + 4)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t st = q << lt;
+            uint64_t x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] = tile[lidx(e0 + i * st)];
+            if (dit) {
+                // distances h, 2h, 4h, 8h (h = q): stage s + d pairs offsets (i, i + 2^d) with twiddle w^((j + (i mod 2^d) h) << (k - 1 - s - d))
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int half = 1 << d;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (i & half) continue;
+                        const uint64_t w = wr_s[(j + (uint32_t)(i & (half - 1)) * q) << (k - 1 - s - d)];
+                        const uint64_t v = gl::mul(x[i + half], w), u = x[i];
+                        x[i] = gl::add(u, v);
+                        x[i + half] = gl::sub(u, v);
+                    }
+                }
+            } else {
+                // distances 8q, 4q, 2q, q: stage s + d pairs offsets (i, i + 2^(3 - d)) with twiddle w^((j + (i mod 2^(3 - d)) q) << (s + d))
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int half = 8 >> d;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (i & half) continue;
+                        const uint64_t w = wr_s[(j + (uint32_t)(i & (half - 1)) * q) << (s + d)];
+                        const uint64_t u = x[i], v = x[i + half];
+                        x[i] = gl::add(u, v);
+                        x[i + half] = gl::mul(gl::sub(u, v), w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) tile[lidx(e0 + i * st)] = x[i];
+        }
+        __syncthreads();
+    }
+    const uint32_t quarter = E >> 2;
+    for (; s + 1 < k; s += 2) {
+        const uint32_t log_q = dit ? s : (k - 2 - s);
+        for (uint32_t idx = threadIdx.x; idx < quarter; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 2) - 1);
+            const uint32_t g = rest >> (k - 2);
+            const uint32_t j = b & ((1u << log_q) - 1);
+            const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t st = (1u << log_q) << lt;
+            const uint32_t l0 = lidx(e0), l1 = lidx(e0 + st), l2 = lidx(e0 + 2 * st), l3 = lidx(e0 + 3 * st);
+            uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
+            if (dit) {
+                const uint64_t w1 = wr_s[j << (k - 1 - s)];
+                const uint64_t w20 = wr_s[j << (k - 2 - s)], w21 = wr_s[(j + (1u << s)) << (k - 2 - s)];
+                const uint64_t v1 = gl::mul(x1, w1), v3 = gl::mul(x3, w1);
+                const uint64_t a0 = gl::add(x0, v1), a1 = gl::sub(x0, v1), a2 = gl::add(x2, v3), a3 = gl::sub(x2, v3);
+                const uint64_t u2 = gl::mul(a2, w20), u3 = gl::mul(a3, w21);
+                tile[l0] = gl::add(a0, u2);
+                tile[l2] = gl::sub(a0, u2);
+                tile[l1] = gl::add(a1, u3);
+                tile[l3] = gl::sub(a1, u3);
+            } else {
+                const uint64_t w10 = wr_s[j << s], w11 = wr_s[(j + (1u << log_q)) << s];
+                const uint64_t w2 = wr_s[j << (s + 1)];
+                const uint64_t a0 = gl::add(x0, x2), a2 = gl::mul(gl::sub(x0, x2), w10);
+                const uint64_t a1 = gl::add(x1, x3), a3 = gl::mul(gl::sub(x1, x3), w11);
+                tile[l0] = gl::add(a0, a1);
+                tile[l1] = gl::mul(gl::sub(a0, a1), w2);
+                tile[l2] = gl::add(a2, a3);
+                tile[l3] = gl::mul(gl::sub(a2, a3), w2);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t half = E >> 1;
+    for (; s < k; s++) {
+        const uint32_t log_hd = dit ? s : (k - 1 - s);
+        const uint32_t tw_shift = k - 1 - log_hd;
+        for (uint32_t idx = threadIdx.x; idx < half; idx += blockDim.x) {
+            const uint32_t t = idx & (T - 1);
+            const uint32_t rest = idx >> lt;
+            const uint32_t b = rest & ((R >> 1) - 1);
+            const uint32_t g = rest >> (k - 1);
+            const uint32_t j = b & ((1u << log_hd) - 1);
+            const uint32_t r0 = ((b >> log_hd) << (log_hd + 1)) | j;
+            const uint32_t e0 = (((g << k) | r0) << lt) | t;
+            const uint32_t e1 = e0 + ((1u << log_hd) << lt);
+            const uint64_t w = wr_s[j << tw_shift];
+            const uint32_t l0 = lidx(e0), l1 = lidx(e1);
+            uint64_t u = tile[l0], v = tile[l1];
+            if (dit) {
+                v = gl::mul(v, w);
+                tile[l0] = gl::add(u, v);
+                tile[l1] = gl::sub(u, v);
+            } else {
+                tile[l0] = gl::add(u, v);
+                tile[l1] = gl::mul(gl::sub(u, v), w);
+            }
+        }
+        __syncthreads();
+    }
+}
 
 __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     extern __shared__ uint64_t smem[];
@@ -132,77 +267,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     bool cs_done = a.cscale == 0;
     if (a.tw_mode == 1 || a.pw_mode == 1) diag(a.tw_mode == 1, a.pw_mode == 1, 0);
 
-    // ---- butterflies: k stages over the r dimension (element stride T), two stages per LDS round trip ----
-    // radix-2^2: a lane loads the 4 elements of a quad, applies both stages in registers and writes them back:
-    // half the LDS traffic, index arithmetic and barriers of stage-by-stage radix 2 (same 4 twiddle products).
-    uint32_t s = 0;
-    const uint32_t quarter = E >> 2;
-    for (; s + 1 < k; s += 2) {
-        // DIF: distances 2q then q with q = R >> (s + 2);  DIT: distances h then 2h with h = 1 << s
-        const uint32_t log_q = a.dit ? s : (k - 2 - s);
-        for (uint32_t idx = threadIdx.x; idx < quarter; idx += blockDim.x) {
-            const uint32_t t = idx & (T - 1);
-            const uint32_t rest = idx >> lt;
-            const uint32_t b = rest & ((R >> 2) - 1);
-            const uint32_t g = rest >> (k - 2);
-            const uint32_t j = b & ((1u << log_q) - 1);
-            const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
-            const uint32_t e0 = (((g << k) | r0) << lt) | t;
-            const uint32_t st = (1u << log_q) << lt;
-            const uint32_t l0 = lds_idx(e0), l1 = lds_idx(e0 + st), l2 = lds_idx(e0 + 2 * st), l3 = lds_idx(e0 + 3 * st);
-            uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
-            if (a.dit) {
-                // stage s: (x0, x1), (x2, x3) with w_{2h}^j ; stage s+1: (a0, a2) with w_{4h}^j, (a1, a3) with w_{4h}^(j+h)
-                const uint64_t w1 = wr_s[j << (k - 1 - s)];
-                const uint64_t w20 = wr_s[j << (k - 2 - s)], w21 = wr_s[(j + (1u << s)) << (k - 2 - s)];
-                const uint64_t v1 = gl::mul(x1, w1), v3 = gl::mul(x3, w1);
-                const uint64_t a0 = gl::add(x0, v1), a1 = gl::sub(x0, v1), a2 = gl::add(x2, v3), a3 = gl::sub(x2, v3);
-                const uint64_t u2 = gl::mul(a2, w20), u3 = gl::mul(a3, w21);
-                tile[l0] = gl::add(a0, u2);
-                tile[l2] = gl::sub(a0, u2);
-                tile[l1] = gl::add(a1, u3);
-                tile[l3] = gl::sub(a1, u3);
-            } else {
-                // stage s: (x0, x2) with w^(j 2^s), (x1, x3) with w^((j+q) 2^s) ; stage s+1: (a0, a1), (a2, a3) with w^(j 2^(s+1))
-                const uint64_t w10 = wr_s[j << s], w11 = wr_s[(j + (1u << log_q)) << s];
-                const uint64_t w2 = wr_s[j << (s + 1)];
-                const uint64_t a0 = gl::add(x0, x2), a2 = gl::mul(gl::sub(x0, x2), w10);
-                const uint64_t a1 = gl::add(x1, x3), a3 = gl::mul(gl::sub(x1, x3), w11);
-                tile[l0] = gl::add(a0, a1);
-                tile[l1] = gl::mul(gl::sub(a0, a1), w2);
-                tile[l2] = gl::add(a2, a3);
-                tile[l3] = gl::mul(gl::sub(a2, a3), w2);
-            }
-        }
-        __syncthreads();
-    }
-    const uint32_t half = E >> 1;
-    for (; s < k; s++) {
-        const uint32_t log_hd = a.dit ? s : (k - 1 - s);
-        const uint32_t tw_shift = k - 1 - log_hd;
-        for (uint32_t idx = threadIdx.x; idx < half; idx += blockDim.x) {
-            uint32_t t = idx & (T - 1);
-            uint32_t rest = idx >> lt;
-            uint32_t b = rest & ((R >> 1) - 1);
-            uint32_t g = rest >> (k - 1);
-            uint32_t j = b & ((1u << log_hd) - 1);
-            uint32_t r0 = ((b >> log_hd) << (log_hd + 1)) | j;
-            uint32_t e0 = (((g << k) | r0) << lt) | t;
-            uint32_t e1 = e0 + ((1u << log_hd) << lt);
-            uint64_t w = wr_s[j << tw_shift];
-            uint32_t l0 = lds_idx(e0), l1 = lds_idx(e1);
-            uint64_t u = tile[l0], v = tile[l1];
-            if (a.dit) {
-                v = gl::mul(v, w);
-                tile[l0] = gl::add(u, v);
-                tile[l1] = gl::sub(u, v);
-            } else {
-                tile[l0] = gl::add(u, v);
-                tile[l1] = gl::mul(gl::sub(u, v), w);
-            }
-        }
-        __syncthreads();
-    }
+    // ---- butterflies: k stages over the r dimension (element stride T), four (two, one) stages per LDS round trip ----
+    tile_stages(tile, wr_s, E, k, lt, a.dit != 0, IdxPlain{}, a.r16 != 0);
 
     if (a.tw_mode == 2 || a.pw_mode == 2) {
         diag(a.tw_mode == 2, a.pw_mode == 2, a.cscale);
@@ -234,88 +300,6 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
 // k2 low bits (contiguous blocks); conventions identical to ntt_pass_kernel (tested bit-exact against it and the oracle).
 // =====================================================================================================================
 
-// LDS placement of tile element e: one u64 of padding per 16 (lds_idx), optionally one more per 2^BLK elements so that a
-// scatter over blocks (the bit-reversed gather of lde_gather_kernel) is conflict-free as well
-struct IdxPlain {
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
-};
-struct IdxBlocked {
-    uint32_t blk;   // log2 block size
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
-};
-
-// all butterfly stages of one bit group on an LDS tile of E elements: k stages over rows (element stride T = 2^lt)
-template <class Idx>
-__device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit,
-                                            Idx lidx) {
-    const uint32_t R = 1u << k, T = 1u << lt;
-    uint32_t s = 0;
-    const uint32_t quarter = E >> 2;
-    for (; s + 1 < k; s += 2) {
-        const uint32_t log_q = dit ? s : (k - 2 - s);
-        for (uint32_t idx = threadIdx.x; idx < quarter; idx += blockDim.x) {
-            const uint32_t t = idx & (T - 1);
-            const uint32_t rest = idx >> lt;
-            const uint32_t b = rest & ((R >> 2) - 1);
-            const uint32_t g = rest >> (k - 2);
-            const uint32_t j = b & ((1u << log_q) - 1);
-            const uint32_t r0 = ((b >> log_q) << (log_q + 2)) | j;
-            const uint32_t e0 = (((g << k) | r0) << lt) | t;
-            const uint32_t st = (1u << log_q) << lt;
-            const uint32_t l0 = lidx(e0), l1 = lidx(e0 + st), l2 = lidx(e0 + 2 * st), l3 = lidx(e0 + 3 * st);
-            uint64_t x0 = tile[l0], x1 = tile[l1], x2 = tile[l2], x3 = tile[l3];
-            if (dit) {
-                const uint64_t w1 = wr_s[j << (k - 1 - s)];
-                const uint64_t w20 = wr_s[j << (k - 2 - s)], w21 = wr_s[(j + (1u << s)) << (k - 2 - s)];
-                const uint64_t v1 = gl::mul(x1, w1), v3 = gl::mul(x3, w1);
-                const uint64_t a0 = gl::add(x0, v1), a1 = gl::sub(x0, v1), a2 = gl::add(x2, v3), a3 = gl::sub(x2, v3);
-                const uint64_t u2 = gl::mul(a2, w20), u3 = gl::mul(a3, w21);
-                tile[l0] = gl::add(a0, u2);
-                tile[l2] = gl::sub(a0, u2);
-                tile[l1] = gl::add(a1, u3);
-                tile[l3] = gl::sub(a1, u3);
-            } else {
-                const uint64_t w10 = wr_s[j << s], w11 = wr_s[(j + (1u << log_q)) << s];
-                const uint64_t w2 = wr_s[j << (s + 1)];
-                const uint64_t a0 = gl::add(x0, x2), a2 = gl::mul(gl::sub(x0, x2), w10);
-                const uint64_t a1 = gl::add(x1, x3), a3 = gl::mul(gl::sub(x1, x3), w11);
-                tile[l0] = gl::add(a0, a1);
-                tile[l1] = gl::mul(gl::sub(a0, a1), w2);
-                tile[l2] = gl::add(a2, a3);
-                tile[l3] = gl::mul(gl::sub(a2, a3), w2);
-            }
-        }
-        __syncthreads();
-    }
-    const uint32_t half = E >> 1;
-    for (; s < k; s++) {
-        const uint32_t log_hd = dit ? s : (k - 1 - s);
-        const uint32_t tw_shift = k - 1 - log_hd;
-        for (uint32_t idx = threadIdx.x; idx < half; idx += blockDim.x) {
-            const uint32_t t = idx & (T - 1);
-            const uint32_t rest = idx >> lt;
-            const uint32_t b = rest & ((R >> 1) - 1);
-            const uint32_t g = rest >> (k - 1);
-            const uint32_t j = b & ((1u << log_hd) - 1);
-            const uint32_t r0 = ((b >> log_hd) << (log_hd + 1)) | j;
-            const uint32_t e0 = (((g << k) | r0) << lt) | t;
-            const uint32_t e1 = e0 + ((1u << log_hd) << lt);
-            const uint64_t w = wr_s[j << tw_shift];
-            const uint32_t l0 = lidx(e0), l1 = lidx(e1);
-            uint64_t u = tile[l0], v = tile[l1];
-            if (dit) {
-                v = gl::mul(v, w);
-                tile[l0] = gl::add(u, v);
-                tile[l1] = gl::sub(u, v);
-            } else {
-                tile[l0] = gl::add(u, v);
-                tile[l1] = gl::mul(gl::sub(u, v), w);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 struct ColArgs {
     const uint64_t* in;       // [ncols][in_stride]: values (natural rows) or, with from_coeffs, coefficients
     uint64_t* coeffs;         // [ncols][n] natural order (written unless from_coeffs)
@@ -329,6 +313,7 @@ struct ColArgs {
     const uint64_t* tw_inv;   // [n]: w_n^-(t bitrev_k1(r)) / n   at position p = r 2^k2 + t
     const uint64_t* tw_fwd;   // [n]: w_n^(t bitrev_k1(r))
     const uint64_t* pw;       // [2^rate_bits][n]: (7 w_m^h)^p, half h = natural LDE index mod 2^rate_bits
+    uint32_t r16;
 };
 
 __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
@@ -355,10 +340,10 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
         // values -> coefficients: scatter into bit-reversed position, DIT low bits, twiddle (x 1/n), DIT high bits
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tile[lds_idx(gl::bitrev(i, a.log_n))] = in[i];
         __syncthreads();
-        tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{});
+        tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{}, a.r16 != 0);
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_inv[p]);
         __syncthreads();
-        tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{});
+        tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{}, a.r16 != 0);
         uint64_t* co = a.coeffs + (size_t)col * n;
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) co[p] = tile[lds_idx(p)];
         cf = co;
@@ -374,10 +359,10 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
             for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(cf[p], pw[p]);
         }
         __syncthreads();
-        tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{});
+        tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{}, a.r16 != 0);
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_fwd[p]);
         __syncthreads();
-        tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{});
+        tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{}, a.r16 != 0);
         // natural LDE index i = i' 2^rate_bits + h sits at leaf position bitrev(h) n + bitrev(i'): the DIF's own order
         uint64_t* out = a.lde + (size_t)col * a.lde_stride + (size_t)gl::bitrev(h, a.rate_bits) * n;
         for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) out[p] = tile[lds_idx(p)];
@@ -398,6 +383,7 @@ struct GatherArgs {
     uint64_t* out;         // [ncols][n] positions after the low-bit DIT
     uint32_t log_n, k2;
     const uint64_t* wr;    // w_R2^-x
+    uint32_t r16;
 };
 
 __global__ void __launch_bounds__(256) lde_gather_kernel(GatherArgs a) {
@@ -420,7 +406,7 @@ __global__ void __launch_bounds__(256) lde_gather_kernel(GatherArgs a) {
         tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = in[nat];
     }
     __syncthreads();
-    tile_stages(tile, wr_s, E, k2, 0, true, lidx);
+    tile_stages(tile, wr_s, E, k2, 0, true, lidx, a.r16 != 0);
     for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
         const uint32_t g = e >> k2, r = e & (R2 - 1);
         out[((size_t)g << (a.log_n - 4)) | ((size_t)mid << k2) | r] = tile[lidx(e)];
@@ -436,6 +422,7 @@ struct MidArgs {
     const uint64_t* tw_inv;  // [n]   w_n^-(t bitrev_k1(r)) / n         at position r 2^k2 + t
     const uint64_t* pw;      // [n]   7^p
     const uint64_t* tw_fwd;  // [2n]  w_2n^(t bitrev_(k1+1)(r'))         at position r' 2^k2 + t
+    uint32_t r16;
 };
 
 __global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
@@ -458,7 +445,7 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
         tile[lds_idx(e)] = gl::mul(co[p], a.tw_inv[p]);
     }
     __syncthreads();
-    tile_stages(tile, wi, E1, k1, 4, true, IdxPlain{});
+    tile_stages(tile, wi, E1, k1, 4, true, IdxPlain{}, a.r16 != 0);
     for (uint32_t e = threadIdx.x; e < E1; e += blockDim.x) {
         const size_t p = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
         const uint64_t c = tile[lds_idx(e)];
@@ -467,7 +454,7 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
         tile[lds_idx(e + E1)] = 0;                        // zero padding of the LDE: rows R1 .. 2 R1 - 1
     }
     __syncthreads();
-    tile_stages(tile, wf, E2, k1 + 1, 4, false, IdxPlain{});
+    tile_stages(tile, wf, E2, k1 + 1, 4, false, IdxPlain{}, a.r16 != 0);
     for (uint32_t e = threadIdx.x; e < E2; e += blockDim.x) {
         const size_t q = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
         lde[q] = gl::mul(tile[lds_idx(e)], a.tw_fwd[q]);
@@ -510,6 +497,19 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* __res
 }
 
 // ---- host side: tables + pass planning -----------------------------------------------------
+
+// SIPP_NTT_RADIX16: bit 0 pass kernel, bit 1 whole-column, bit 2 gather, bit 3 fused middle.  Default all on: the radix-2^4
+// rounds need ~100 VGPRs instead of 38 and are NOT faster alone (lde_mid 1.74 vs 1.50 ms, lde_column 1.33 vs 1.09 ms for 67 M
+// elements; the pass kernel 5-10 % faster), but they execute fewer instructions, and the instance is bound by instruction issue:
+// 66.5-67.1 ms per n = 128 instance against 67.8-67.9 ms (25-step runs, same box, alternating).
+int ntt_r16_mask() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SIPP_NTT_RADIX16");
+        v = e ? atoi(e) : 15;
+    }
+    return v;
+}
 
 int ntt_ltile() {
     static int v = -1;
@@ -582,6 +582,7 @@ int pow_tables(sipp_ctx* ctx, int kind_lo, int kind_hi, uint64_t key_a, uint64_t
 }
 
 int run_pass(sipp_ctx* ctx, const char* name, PassArgs& a, size_t ncols) {
+    a.r16 = ntt_r16_mask() & 1;
     const uint32_t log_e = a.k + a.lt + a.lg;
     const size_t E = (size_t)1 << log_e;
     size_t shmem = (E + (E >> LOG_SEG) + ((size_t)1 << (a.k ? a.k - 1 : 0))) * sizeof(uint64_t);
@@ -738,6 +739,7 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
     a.tw_inv = col_tw_table(ctx, log_n, a.k1, true);
     a.tw_fwd = col_tw_table(ctx, log_n, a.k1, false);
     a.pw = col_pw_table(ctx, log_n, rate_bits);
+    a.r16 = (ntt_r16_mask() >> 1) & 1;
     if (!a.wr1_inv || !a.wr2_inv || !a.wr1_fwd || !a.wr2_fwd || !a.tw_inv || !a.tw_fwd || !a.pw) return SIPP_E_HIP;
     const size_t n = (size_t)1 << log_n;
     const size_t shmem = (n + (n >> LOG_SEG) + ((size_t)1 << a.k1) + ((size_t)1 << a.k2)) * sizeof(uint64_t);
@@ -770,6 +772,7 @@ int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs
         GatherArgs g{};
         g.in = d_values; g.out = d_coeffs; g.log_n = log_n; g.k2 = k2;
         g.wr = wr_table(ctx, k2, true);
+        g.r16 = (ntt_r16_mask() >> 2) & 1;
         if (!g.wr) return SIPP_E_HIP;
         const size_t E = (size_t)16 << k2;
         const size_t shmem = (E + (E >> LOG_SEG) + 16 + ((size_t)1 << (k2 - 1))) * sizeof(uint64_t);
@@ -789,6 +792,7 @@ int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs
         m.tw_inv = col_tw_table(ctx, log_n, k1, true);
         m.pw = col_pw_table(ctx, log_n, 1);               // first coset half = 7^p
         m.tw_fwd = col_tw_table(ctx, log_n + 1, k1 + 1, false);
+        m.r16 = (ntt_r16_mask() >> 3) & 1;
         if (!m.wr_inv || !m.wr_fwd || !m.tw_inv || !m.pw || !m.tw_fwd) return SIPP_E_HIP;
         const size_t E2 = (size_t)32 << k1;
         const size_t shmem = (E2 + (E2 >> LOG_SEG) + ((size_t)1 << (k1 - 1)) + ((size_t)1 << k1)) * sizeof(uint64_t);
