@@ -158,6 +158,9 @@ struct QuotArgs {
     int K;
     const uint32_t* apow3;
     uint64_t alphaK[2];   // alpha_c^K
+    // products of a gadget (group 2): limbs of gamma_c^i, i < 8, gamma_c = 1 / alpha_c; gamma_c; alpha_c^16 (see quotient_prog_kernel)
+    uint32_t ginv3[2][8][3];
+    uint64_t gamma_inv[2], alpha16[2];
 };
 
 struct QCtx {
@@ -247,31 +250,37 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
         uint64_t e[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) e[k] = 0;
+        // The 16 x 16 limb products are never expanded into their 31 coefficients: the 16 coefficient equations of a gadget are
+        // folded with powers of alpha anyway (acc = sum_m alpha^(16 - m) v_m + ...), and the product part of that fold factorises.
+        // With gamma = 1 / alpha, e_k = sum_{i + j = k} a_i b_j and the pairing of limbs in base 2^32 (group 2):
+        //   sum_m alpha^(16 - m) (e_2m + 2^16 e_2m+1) = alpha^16 [A_e B_e + 2^16 (A_e B_o + A_o B_e) + gamma A_o B_o],
+        //   A_e = sum_i a_2i gamma^i, A_o = sum_i a_2i+1 gamma^i (likewise B): four 8-term linear forms with WAVE-UNIFORM weights
+        // (lazy limb MACs) and four products per challenge instead of 256 limb products and 31 reductions.  Exact field
+        // arithmetic: the value is the one the coefficient-wise Horner fold of oracle/air_eval.inc produces.
+        uint64_t psum[2] = {0, 0};
         const int np = (int)*w++;
         for (int p = 0; p < np; p++) {
             const uint64_t coef = gl::from_i64(*w++);
             uint64_t va[16], vb[16];
             w += qvec<16>(w, c, va);
             w += qvec<16>(w, c, vb);
-            // 256 limb products: each output coefficient is ONE lazy dot product (gl::Acc6: six v_mad_u64_u32 per
-            // term, one reduction per coefficient) instead of 16 multiply-reduce-add steps
-            uint32_t a3[16][3], bl[16], bh[16];
 #pragma unroll
-            for (int ii = 0; ii < 16; ii++) {
-                gl::limbs3(a3[ii], va[ii]);
-                bl[ii] = (uint32_t)vb[ii];
-                bh[ii] = (uint32_t)(vb[ii] >> 32);
-            }
+            for (int ch = 0; ch < 2; ch++) {
+                gl::Acc6 Ae, Ao, Be, Bo;
+                Ae.zero(); Ao.zero(); Be.zero(); Bo.zero();
 #pragma unroll
-            for (int k = 0; k < 31; k++) {
-                gl::Acc6 acc;
-                acc.zero();
-#pragma unroll
-                for (int ii = 0; ii < 16; ii++) {
-                    const int jj = k - ii;
-                    if (jj >= 0 && jj < 16) acc.mac(bl[jj], bh[jj], a3[ii]);
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t* g3 = a.ginv3[ch][i];
+                    Ae.mac((uint32_t)va[2 * i], (uint32_t)(va[2 * i] >> 32), g3);
+                    Ao.mac((uint32_t)va[2 * i + 1], (uint32_t)(va[2 * i + 1] >> 32), g3);
+                    Be.mac((uint32_t)vb[2 * i], (uint32_t)(vb[2 * i] >> 32), g3);
+                    Bo.mac((uint32_t)vb[2 * i + 1], (uint32_t)(vb[2 * i + 1] >> 32), g3);
                 }
-                e[k] = gl::mad(coef, gl::canon(acc.reduce()), e[k]);
+                const uint64_t ae = Ae.reduce(), ao = Ao.reduce(), be = Be.reduce(), bo = Bo.reduce();
+                const uint64_t cross = gl::add(gl::mul(ae, bo), gl::mul(ao, be));
+                uint64_t t = gl::mad(gl::mul(ao, bo), a.gamma_inv[ch], gl::mul(ae, be));
+                t = gl::mad(cross, 65536, t);
+                psum[ch] = gl::mad(coef, t, psum[ch]);
             }
         }
         const int nl = (int)*w++;
@@ -326,6 +335,9 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
             }
         }
         c.emit(gl::mul(s, gl::sub(s, 1)));
+        // the product part of the fold (grp == 2: the generator's only setting, checked on the host)
+        c.acc0 = gl::mad(a.alpha16[0], psum[0], c.acc0);
+        c.acc1 = gl::mad(a.alpha16[1], psum[1], c.acc1);
     }
     a.part[((size_t)g * 2 + 0) * m + j] = gl::mul(c.acc0, a.seg_pow[2 * g]);
     a.part[((size_t)g * 2 + 1) * m + j] = gl::mul(c.acc1, a.seg_pow[2 * g + 1]);
@@ -859,6 +871,20 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.w_m = wm;
     for (int i = 0; i < 16; i++) q.p_limbs[i] = SIPP_BN_P_LIMBS[i];
     q.out = d_out;
+    for (int ch = 0; ch < 2; ch++) {
+        // (alpha = 0 has probability 2^-64 per challenge; the factorised fold divides by alpha, so refuse it loudly)
+        if (alpha[ch] == 0) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "quotient: a zero constraint challenge");
+        const uint64_t gi = gl::inv(alpha[ch]);
+        q.gamma_inv[ch] = gi;
+        q.alpha16[ch] = gl::pow(alpha[ch], 16);
+        uint64_t x = 1;
+        for (int i = 0; i < 8; i++) {
+            q.ginv3[ch][i][0] = (uint32_t)x & 0x3FFFFFu;
+            q.ginv3[ch][i][1] = (uint32_t)(x >> 22) & 0x3FFFFFu;
+            q.ginv3[ch][i][2] = (uint32_t)(x >> 44);
+            x = gl::mul(x, gi);
+        }
+    }
     // segment table: offsets, kinds, alpha powers (tiny; rebuilt per proof because alpha changes)
     ArenaMark mk = arena_mark(ctx);
     {
@@ -869,6 +895,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
         while (w < end && w[0] == 1) {
             off.push_back((uint32_t)(w - a->prog));
             cnt.push_back(0);
+            if (w[6] != 2) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "quotient: gadgets must pair their limbs (group 2)");
             ncons.push_back(32 / (int)w[6] + 1);
             w += 7;
             w += 2 + 5 * w[1];
