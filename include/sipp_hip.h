@@ -111,9 +111,16 @@ int sipp_prove_async(sipp_ctx *ctx, int kind, const uint32_t *ios, size_t num_io
 int sipp_wait(sipp_ctx *ctx, size_t *proof_len);
 /* One SIPP instance = the three sub-proofs, concurrently on three DISTINCT ctxs (one HIP stream each; they may sit
  * on one GPU or on up to three GPUs, SURVEY.md section 8e level L-B).  Arrays are indexed by sipp_kind.  Returns the
- * first failing status; every proof that was started is waited for in any case. */
+ * first failing status; every proof that was started is waited for in any case.  num_io[k] == 0 skips kind k
+ * (proof_len[k] = 0). */
 int sipp_instance_prove(sipp_ctx *const ctxs[3], const uint32_t *const ios[3], const size_t num_io[3],
                         uint64_t *const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]);
+/* IO-sharded sub-proofs (level L-D): the obligation list of one kind is cut into
+ * `world` contiguous, balanced ranges and every rank proves ITS range as a STARK of its own -- on the reference side one
+ * g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit call per range instead of one per list (src/verifier_circuit.rs:133-135
+ * take any slice of obligations).  No data is exchanged between ranks.  Range of `rank`: records [*first, *first + *count);
+ * *count may be 0 when num_io < world (sipp_instance_prove skips a kind whose num_io is 0 and reports proof_len 0). */
+int sipp_io_shard(size_t num_io, uint32_t world, uint32_t rank, size_t *first, size_t *count);
 /* The outputs alone: what the generators behind g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit assign to the
  * returned output targets (reference src/verifier_circuit.rs:133-135 `*_exp_outputs`): out = offset + [exp_val] x
  * (G1, G2) or offset * x^exp_val (Fq12), computed on the device by the trace kernels' accumulator chains.  `ios` are

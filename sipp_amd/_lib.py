@@ -67,6 +67,7 @@ SIGNATURES = {
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "sipp_io_shard": (C.c_int, [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_instance_prove": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_exp_outputs": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
@@ -388,14 +389,15 @@ class Instance:
         self.ctxs = []
         level = {"low": -1, "": 0, "normal": 0, "high": 1}
         for k in range(3):
-            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, self.num_io[k]))
+            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, max(1, self.num_io[k])))
             c._ck(self.L.sipp_ctx_set_stream_priority(c.h, level[priorities[k]]), "set_stream_priority")
             self.ctxs.append(c)
-        self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) for k in range(3)]
-        self.out = [np.zeros(c, dtype=np.uint64) for c in self.caps]
+        self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) if self.num_io[k] else 0 for k in range(3)]
+        self.out = [np.zeros(max(c, 1), dtype=np.uint64) for c in self.caps]
 
     def prove(self, ios):
-        """ios: [g1, g2, fq12] host uint32 arrays -> three flat proofs (views of this object's output buffers)"""
+        """ios: [g1, g2, fq12] host uint32 arrays -> three flat proofs (views of this object's output buffers); a kind with
+        no record (an IO shard may have none) yields an empty proof"""
         ios = [np.ascontiguousarray(a, dtype=np.uint32) for a in ios]
         assert tuple(a.shape[0] for a in ios) == self.num_io
         h = (vp * 3)(*[c.h for c in self.ctxs])
@@ -418,3 +420,22 @@ class Instance:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+
+
+def io_shard(num_io, world, rank):
+    """sipp_io_shard: the contiguous range (first, count) of an obligation list that `rank` of `world` proves"""
+    first, count = C.c_size_t(), C.c_size_t()
+    rc = lib().sipp_io_shard(int(num_io), int(world), int(rank), C.byref(first), C.byref(count))
+    if rc != 0:
+        raise SippError(rc, "io_shard")
+    return first.value, count.value
+
+
+def shard_ios(ios, world, rank):
+    """IO-sharded sub-proofs (level L-D): the slices of the three obligation lists of ONE SIPP instance
+    that `rank` proves as STARKs of their own; no data is exchanged between the ranks"""
+    out = []
+    for a in ios:
+        first, count = io_shard(a.shape[0], world, rank)
+        out.append(a[first: first + count])
+    return out

@@ -521,6 +521,15 @@ int sipp_stark_shape(const sipp_ctx* ctx, int kind, size_t num_io, uint32_t* log
     return SIPP_OK;
 }
 
+int sipp_io_shard(size_t num_io, uint32_t world, uint32_t rank, size_t* first, size_t* count) {
+    if (!first || !count || world == 0 || rank >= world || num_io > SIZE_MAX / world) return SIPP_E_BADARG;
+    // balanced contiguous ranges: floor(rank n / world) .. floor((rank + 1) n / world); the ranges tile [0, n) exactly
+    const size_t lo = num_io * rank / world, hi = num_io * ((size_t)rank + 1) / world;
+    *first = lo;
+    *count = hi - lo;
+    return SIPP_OK;
+}
+
 size_t sipp_workspace_bytes(int kind, size_t num_io) { return sipp_workspace_bytes_cfg(kind, num_io, nullptr); }
 
 size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config* cfg) {
@@ -862,8 +871,10 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
         ctxs[k]->gate_release = (k == first && gate_mask) ? &gate : nullptr;
         ctxs[k]->gate_wait = (gate_mask >> k & 1) ? &gate : nullptr;
     }
+    for (int k = 0; k < 3; k++) proof_len[k] = 0;
     for (int i = 0; i < 3 && rc == SIPP_OK; i++) {
         const int k = order[i];
+        if (num_io[k] == 0) continue;  // an IO shard (sipp_io_shard) may hold no record of a kind: no proof of that kind
         rc = sipp_prove_async(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k]);
         started[k] = rc == SIPP_OK;
     }

@@ -40,3 +40,20 @@ def test_no_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(sipp_amd.SippError):
         sipp_amd.Ctx()
+
+
+def test_io_shard_ranges_tile_the_list_and_reject_bad_ranks():
+    """sipp_io_shard (IO-sharded sub-proofs, DESIGN.md section 5 level L-D) is host arithmetic: callable without a GPU"""
+    import pytest
+    for n in (0, 1, 6, 7, 14, 127, 1023, 4095):
+        for world in (1, 2, 3, 4, 8):
+            nxt = 0
+            for rank in range(world):
+                first, count = sipp_amd.io_shard(n, world, rank)
+                assert first == nxt and n // world <= count <= -(-n // world)
+                nxt = first + count
+            assert nxt == n
+    with pytest.raises(sipp_amd.SippError):
+        sipp_amd.io_shard(10, 4, 4)
+    with pytest.raises(sipp_amd.SippError):
+        sipp_amd.io_shard(10, 0, 0)

@@ -40,6 +40,20 @@ assert 3 * 0.02 * world <= elapsed < 3 * 0.02 * world + 0.5, elapsed      # the 
 value = du.whole_job_rate(128, world, elapsed / 3)
 assert abs(value - world * 128 / (elapsed / 3)) < 1e-6
 assert du.init_process_group(1, 0) == "cpu"                                 # single rank: nothing to initialise
+# IO-sharded sub-proofs (sipp_io_shard through the C ABI, no GPU needed): the ranks' ranges tile every obligation list exactly once
+import numpy as np, sipp_amd
+for n_io in (127, 14, 6, 1, 4095):
+    first, count = sipp_amd.io_shard(n_io, world, rank)
+    cover = torch.zeros(n_io, dtype=torch.int64); cover[first: first + count] = 1
+    dist.all_reduce(cover)
+    assert cover.tolist() == [1] * n_io, (n_io, cover)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([count]))
+    assert max(int(x) for x in sizes) - min(int(x) for x in sizes) <= 1      # balanced
+lists = [np.arange(7 * 56, dtype=np.uint32).reshape(7, 56), np.arange(7 * 104, dtype=np.uint32).reshape(7, 104),
+         np.arange(6 * 296, dtype=np.uint32).reshape(6, 296)]
+mine_io = sipp_amd.shard_ios(lists, world, rank)
+assert [a.shape[1] for a in mine_io] == [56, 104, 296] and sum(a.shape[0] for a in mine_io) in (9, 11)
 dist.destroy_process_group()
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rank) + ".ok"), "w").write("ok")
 '''

@@ -33,7 +33,7 @@ def _run_bench(extra_env, nproc, args, timeout=900):
 
 @pytest.mark.timeout(1200)
 def test_bench_two_ranks_rehearsal_prints_one_whole_job_line():
-    out = _run_bench({"SIPP_BENCH_REHEARSAL": "1"}, 2,
+    out = _run_bench({"SIPP_BENCH_REHEARSAL": "1", "SIPP_BENCH_IO_SHARD_N": "128"}, 2,
                      ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--inflight", "1"])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -45,6 +45,10 @@ def test_bench_two_ranks_rehearsal_prints_one_whole_job_line():
     assert abs(r["value"] - 2 * 128 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
     assert r["proof_words"] and all(w > 0 for w in r["proof_words"])
     assert "independent SIPP instance" in r["config"]["parallelism"]
+    # the IO-sharded leg: one n = 128 instance cut into two ranges of obligations (63 + 64 G1 / G2 records, 7 + 7 Fq12)
+    sh = r["io_sharded"]["n=128"]
+    assert sh["ranks"] == 2 and sh["scaling"] == "strong" and sh["records_of_rank0"] == [63, 63, 7]
+    assert abs(sh["value"] - 128 / (sh["ms_per_instance"] * 1e-3)) / sh["value"] < 1e-6
 
 
 def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
@@ -81,3 +85,38 @@ def test_instance_over_all_visible_devices_matches_single_device():
                     assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), (devs, k)
         finally:
             inst.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_io_sharded_sub_proofs_cover_the_instance_and_verify(world):
+    """Level L-D: the obligation lists of ONE instance cut into `world` ranges, every range proved as STARKs of its own
+    (reference side: one g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit call per range, src/verifier_circuit.rs:133-135).
+    Every shard's proofs are what a single ctx produces for the same slice, the CPU verifier accepts them, their public
+    inputs are exactly the slice, and the slices tile the lists.  world = 8 leaves ranks without any Fq12 record."""
+    import sipp_amd
+    from tests import _oracle
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    seen = [0, 0, 0]
+    ctx = sipp_amd.Ctx(workspace_bytes=max(sipp_amd.lib().sipp_workspace_bytes(k, 8) for k in range(3)))
+    try:
+        for rank in range(world):
+            mine = sipp_amd.shard_ios(ios, world, rank)
+            inst = sipp_amd.Instance([a.shape[0] for a in mine])
+            try:
+                proofs = [p.copy() for p in inst.prove(mine)]
+            finally:
+                inst.close()
+            for k in range(3):
+                if mine[k].shape[0] == 0:
+                    assert len(proofs[k]) == 0
+                    continue
+                first, count = sipp_amd.io_shard(ios[k].shape[0], world, rank)
+                assert first == seen[k] and (mine[k] == ios[k][first: first + count]).all()
+                seen[k] += count
+                alone = ctx.prove(k, mine[k])
+                assert len(alone) == len(proofs[k]) and (alone == proofs[k]).all(), (rank, k)
+                assert _oracle.stark_verify(proofs[k]) == 0, (rank, k)
+    finally:
+        ctx.close()
+    assert seen == [a.shape[0] for a in ios]
