@@ -239,6 +239,10 @@ int sipp_commit_batch(sipp_ctx *ctx, const uint64_t *d_values, uint64_t *d_coeff
 int sipp_trace_build(sipp_ctx *ctx, int kind, const uint32_t *ios, size_t num_io, uint64_t *d_trace);
 /* batched Poseidon permutation of n states, d_states [n][12] in place (KAT surface) */
 int sipp_poseidon_permute(sipp_ctx *ctx, uint64_t *d_states, size_t n);
+/* the HOST permutation of the Fiat-Shamir challenger (no GPU involved): n states [n][12] in host memory, in place.
+ * impl: -1 = the implementation the provers use on this CPU, 0 = portable scalar, 1 = scalar with look-ahead partial
+ * rounds, 2 / 3 = AVX-512 (SIPP_E_UNSUPPORTED when the CPU lacks it).  All are bit-identical. */
+int sipp_host_poseidon_permute(uint64_t *states, size_t n, int impl);
 
 /* ---- measurement ------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the ctx stream (the stream the kernels run on).

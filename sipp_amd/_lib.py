@@ -67,6 +67,7 @@ SIGNATURES = {
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "sipp_host_poseidon_permute": (C.c_int, [vp, C.c_size_t, C.c_int]),
     "sipp_io_shard": (C.c_int, [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_instance_prove": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -4,6 +4,7 @@
 #include <string>
 
 #include "ctx.hpp"
+#include "host_poseidon.hpp"
 
 int sipp_poseidon_init_constants(sipp_ctx* ctx);  // poseidon.hip
 
@@ -278,6 +279,20 @@ int sipp_commit_batch(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeff
     SIPP_TRY(sipp_k_poseidon_leaves(ctx, d_lde, (size_t)1 << log_m, ncols, log_m, d_tree));
     SIPP_TRY(sipp_k_merkle_levels(ctx, d_tree, log_m, ctx->cfg.cap_height));
     return read_cap(ctx, d_tree, log_m, cap_out);
+}
+
+int sipp_host_poseidon_permute(uint64_t* states, size_t n, int impl) {
+    if (!states && n) return SIPP_E_BADARG;
+    for (size_t i = 0; i < n; i++) {
+        if (impl < 0) {
+            host::poseidon_permute(states + 12 * i);
+            continue;
+        }
+        const int r = host::poseidon_permute_impl(states + 12 * i, impl);
+        if (r == -1) return SIPP_E_UNSUPPORTED;
+        if (r != 0 || impl >= 10) return SIPP_E_BADARG;
+    }
+    return SIPP_OK;
 }
 
 int sipp_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n) {

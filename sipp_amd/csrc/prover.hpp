@@ -4,6 +4,7 @@
 #include <functional>
 
 #include "ctx.hpp"
+#include "host_poseidon.hpp"
 #include "poseidon_constants.h"
 
 int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
@@ -39,84 +40,9 @@ int sipp_k_pow_search(sipp_ctx* ctx, const uint64_t state[12], const uint64_t* i
 // ---- host Poseidon + duplex challenger (plonky2 iop/challenger.rs) ----
 namespace host {
 
-// Same algorithm as the device permutation (poseidon.cuh): dense circulant MDS in the 8 full rounds, the sparse
-// "fast" form in the 22 partial rounds, written for a 64-bit host core: u128 products, a three-instruction-deep
-// reduction, values kept as any u64 congruent to the state word until the end, MDS on the 32-bit halves so its sums
-// stay in u64.  Observing the ~27 k opening words of the widest STARK is ~3.4 k sequential permutations on the
-// proof's critical path.  Checked against the device kernel by every proof parity test.
-typedef unsigned __int128 u128;
-inline uint64_t red128(u128 v) {  // -> [0, 2^64), congruent, not canonical
-    const uint64_t lo = (uint64_t)v, hi = (uint64_t)(v >> 64);
-    const uint64_t hh = hi >> 32, hl = hi & gl::EPS;
-    uint64_t t0 = lo - hh;
-    if (lo < hh) t0 -= gl::EPS;
-    const uint64_t t1 = (hl << 32) - hl;
-    uint64_t r = t0 + t1;
-    if (r < t1) r += gl::EPS;
-    return r;
-}
-// v - c * 2^32 for any u64 v (2^128 = -2^32 mod p: c lost carries of a u128 accumulator)
-inline uint64_t sub_carries(uint64_t v, uint32_t c) {
-    const uint64_t k = (uint64_t)c << 32, d = v - k;
-    return v < k ? d - gl::EPS : d;
-}
-inline uint64_t sbox7(uint64_t x) {
-    const uint64_t x2 = red128((u128)x * x), x3 = red128((u128)x2 * x), x4 = red128((u128)x2 * x2);
-    return red128((u128)x3 * x4);
-}
-inline void full_round(uint64_t s[12], int rnd) {
-    static const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    uint64_t lo[24], hi[24];
-    for (int i = 0; i < 12; i++) {
-        const uint64_t t = sbox7(gl::add_nc(s[i], SIPP_POSEIDON_RC[12 * rnd + i]));
-        lo[i] = lo[i + 12] = t & gl::EPS;
-        hi[i] = hi[i + 12] = t >> 32;
-    }
-    for (int r = 0; r < 12; r++) {
-        uint64_t al = 0, ah = 0;
-        for (int i = 0; i < 12; i++) {
-            al += lo[i + r] * CIRC[i];
-            ah += hi[i + r] * CIRC[i];
-        }
-        if (r == 0) {
-            al += lo[0] * 8;
-            ah += hi[0] * 8;
-        }
-        s[r] = red128((u128)al + ((u128)ah << 32));
-    }
-}
-inline void poseidon_permute(uint64_t s[12]) {
-    for (int r = 0; r < 4; r++) full_round(s, r);
-    for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], SIPP_POSEIDON_FAST_FIRST[i]);
-    {
-        uint64_t t[11];
-        for (int i = 0; i < 11; i++) {
-            u128 acc = 0;
-            uint32_t c = 0;
-            for (int j = 0; j < 11; j++) {
-                const u128 pr = (u128)s[j + 1] * SIPP_POSEIDON_FAST_MI[i * 11 + j];
-                acc += pr;
-                c += acc < pr;
-            }
-            t[i] = sub_carries(red128(acc), c);
-        }
-        for (int i = 0; i < 11; i++) s[i + 1] = t[i];
-    }
-    for (int r = 0; r < 22; r++) {
-        const uint64_t x = gl::add_nc(sbox7(s[0]), SIPP_POSEIDON_FAST_SCALAR[r]);
-        u128 acc = (u128)x * 25;
-        uint32_t c = 0;
-        for (int i = 0; i < 11; i++) {
-            const u128 pr = (u128)s[i + 1] * SIPP_POSEIDON_FAST_WHAT[r * 11 + i];
-            acc += pr;
-            c += acc < pr;
-        }
-        for (int i = 0; i < 11; i++) s[i + 1] = red128((u128)x * SIPP_POSEIDON_FAST_VS[r * 11 + i] + s[i + 1]);
-        s[0] = sub_carries(red128(acc), c);
-    }
-    for (int r = 26; r < 30; r++) full_round(s, r);
-    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
-}
+// The permutation itself lives in host_poseidon.cpp (portable scalar and AVX-512 forms, bit-identical, chosen at load time):
+// observing the ~32 k opening words of the widest STARK is ~4 k sequential permutations on the proof's critical path.
+// Checked against the device kernel by every proof parity test and against the CPU oracle by tests/test_abi.py.
 
 struct Challenger {
     uint64_t state[12] = {0};
