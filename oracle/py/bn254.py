@@ -143,6 +143,44 @@ def g2_neg(p): return None if p is None else (p[0], f2_neg(p[1]))
 def g2_on_curve(p): return f2_sub(f2_mul(p[1], p[1]), f2_add(f2_mul(f2_mul(p[0], p[0]), p[0]), B2)) == (0, 0)
 
 
+# ---------------- points of the twist outside the r-torsion, cofactor clearing ----------------
+# What the reference's BLS example needs in front of SIPP (src/bin/bls_aggregation.rs:65,103-106): messages are mapped to
+# E'(Fp2) and multiplied by the cofactor.  The map itself (plonky2_bn254::curves::map_to_g2) is not in the reference tree;
+# the cofactor multiplication is plain arithmetic: #E'(Fp2) = r (2p - r).
+G2_COFACTOR = 2 * P - R
+
+
+def f2_sqrt(a):
+    """a square root of a in Fp2 = Fp[u]/(u^2 + 1), or None (p = 3 mod 4; Adj & Rodriguez-Henriquez, algorithm 9)"""
+    if a == (0, 0):
+        return (0, 0)
+    a1 = f2_pow(a, (P - 3) // 4)
+    x0 = f2_mul(a1, a)
+    alpha = f2_mul(a1, x0)
+    if f2_mul(f2_conj(alpha), alpha) == (P - 1, 0):      # alpha^(p+1) = -1: a is not a square
+        return None
+    if alpha == (P - 1, 0):
+        x = f2_mul((0, 1), x0)
+    else:
+        x = f2_mul(f2_pow(f2_add((1, 0), alpha), (P - 1) // 2), x0)
+    return x if f2_mul(x, x) == a else None
+
+
+def g2_twist_point(seed):
+    """a point of E'(Fp2): y^2 = x^3 + 3/(9+u), by try-and-increment from x = (seed, seed^2 + 1); almost surely NOT of order r"""
+    x0 = seed % P
+    while True:
+        x = (x0, (x0 * x0 + 1) % P)
+        y = f2_sqrt(f2_add(f2_mul(f2_mul(x, x), x), B2))
+        if y is not None:
+            return (x, y)
+        x0 = (x0 + 1) % P
+
+
+def g2_clear_cofactor(p):
+    return g2_mul(p, G2_COFACTOR)
+
+
 # ---------------- optimal ate pairing ----------------
 ATE = 6 * U + 2
 FROB_X = f2_pow(XI, (P - 1) // 3)   # pi(x', y') = (conj(x') * xi^((p-1)/3), conj(y') * xi^((p-1)/2))

@@ -424,17 +424,28 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
     store_f_chk<EXT>(tr, n, c.Y3, row, y3, c.cpl);
 }
 
-// ---- Fq12 chain: one 288-lane workgroup per IO ----
-// per exponent bit: lanes 0..143 form the 144 limb products acc_i * pw_j, lanes 144..287 pw_i * pw_j (ONE
-// Montgomery product each); 24 lanes fold them into the 12 + 12 output coefficients of
-// Fq[w]/(w^12 - 18 w^6 + 82); 72 lanes convert and store the trace cells of the two rows.
+// ---- Fq12 chain: one 384-lane workgroup per IO ----
+// Per exponent bit, on the critical path: (A) 144 products acc_i * pw_j + the 78 distinct products pw_i * pw_j (i <= j), ONE
+// Montgomery product per lane on waves 0..3 (one wave per SIMD); (B) 46 lanes sum them into the 23 + 23 coefficients d_m of
+// the two plain polynomial products; (C) 72 lanes form the three terms of every folded coefficient of
+// Fq[w]/(w^12 - 18 w^6 + 82) (one small-constant product each); (D) 24 lanes combine them; (E) state update + snapshot.
+// Beside the path: waves 4..5 convert and store the trace cells of the PREVIOUS bit's two rows from the snapshot while
+// waves 0..3 are in (A).  Round 1's kernel (288 lanes, 24-lane fold with 36 additions and two products in sequence,
+// conversion on the path) took 2.97 ms for the 14 records of n = 128, this one the time in DESIGN.md section 6b.
 struct Fq12Cols {
     int acc, pw, C, cpl;
 };
 
-__global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restrict__ ios, uint32_t num_io,
+struct Fq12Snap {
+    Fq acc[12], pw[12], res[2][12];
+};
+
+__device__ __forceinline__ int sq_index(int i, int j) { return i * 12 - i * (i - 1) / 2 + (j - i); }  // i <= j, 0..77
+
+__global__ void __launch_bounds__(384) fq12_chain_kernel(const uint32_t* __restrict__ ios, uint32_t num_io,
                                                         uint64_t* __restrict__ tr, size_t n, Fq12Cols c) {
-    __shared__ Fq s_acc[12], s_pw[12], s_res[2][12], s_prod[2][144];
+    __shared__ Fq s_acc[12], s_pw[12], s_res[2][12], s_mul[144], s_sq[78], s_d[2][23], s_t[2][12][3];
+    __shared__ Fq12Snap s_snap[2];
     const uint32_t io = blockIdx.x;
     const int t = threadIdx.x;
     const uint32_t* rec = ios + (size_t)io * SIPP_FQ12_IO_WORDS;
@@ -443,50 +454,96 @@ __global__ void __launch_bounds__(288) fq12_chain_kernel(const uint32_t* __restr
         s_acc[t] = Fld<1>::load(rec + 96 + 8 * t);
     }
     __syncthreads();
-    const Fq m18 = fq::small_m(18), m82 = fq::small_m(82), m242 = fq::small_m(242), m1476 = fq::small_m(1476);
-    const Fq m9 = fq::small_m(9);
     const uint32_t* ex = rec + 192;
-    const int which = t >= 144, pi = (t % 144) / 12, pj = t % 12;
-    for (int b = 0; b < 256; b++) {
-        const int bit = (int)((ex[b >> 5] >> (b & 31)) & 1);
-        s_prod[which][pi * 12 + pj] = fq::mul(which ? s_pw[pi] : s_acc[pi], s_pw[pj]);
-        __syncthreads();
-        if (t < 24) {
-            const int sq = t >= 12, k = t % 12;
-            const Fq* pr = s_prod[sq];
-            // k < 6: d_k - 82 d_{k+12} - 1476 d_{k+18} ;  k >= 6: d_k + 18 d_{k+6} + 242 d_{k+12}
-            Fq s0 = fq::zero(), s1 = fq::zero(), s2 = fq::zero();
-            const int m1 = k < 6 ? k + 12 : k + 6, m2 = k < 6 ? k + 18 : k + 12;
-            for (int i = 0; i < 12; i++) {
-                const int j0 = k - i, j1 = m1 - i, j2 = m2 - i;
-                if (j0 >= 0 && j0 < 12) s0 = fq::add(s0, pr[i * 12 + j0]);
-                if (j1 >= 0 && j1 < 12) s1 = fq::add(s1, pr[i * 12 + j1]);
-                if (j2 >= 0 && j2 < 12) s2 = fq::add(s2, pr[i * 12 + j2]);
-            }
-            Fq r;
-            if (k < 6)
-                r = fq::sub(fq::sub(s0, fq::mul(m82, s1)), fq::mul(m1476, s2));
-            else
-                r = fq::add(fq::add(s0, fq::mul(m18, s1)), fq::mul(m242, s2));
-            s_res[sq][k] = r;
+    // product lanes: t < 144 -> acc_i pw_j; 144 <= t < 222 -> pw_i pw_j with i <= j
+    int pi = 0, pj = 0;
+    if (t < 144) {
+        pi = t / 12;
+        pj = t % 12;
+    } else if (t < 222) {
+        int r = t - 144;
+        while (r >= 12 - pi) {
+            r -= 12 - pi;
+            pi++;
         }
-        __syncthreads();
-        if (t < 72) {
+        pj = pi + r;
+    }
+    const int ct = t - 256;  // conversion lanes 0..71 on waves 4..5
+    // fold lanes (C): lane t < 72 = (product sq, coefficient k, term); terms 1, 2 carry one small constant and one source index
+    const int f_sq = t / 36, f_k = (t % 36) / 3, f_term = t % 3;
+    const int f_m = f_term == 0 ? f_k : f_k < 6 ? (f_term == 1 ? f_k + 12 : f_k + 18) : (f_term == 1 ? f_k + 6 : f_k + 12);
+    const Fq f_c = fq::small_m(f_k < 6 ? (f_term == 1 ? 82u : 1476u) : (f_term == 1 ? 18u : 242u));
+    for (int b = 0; b <= 256; b++) {
+        // (A) products of bit b | cells of bit b - 1
+        if (t < 144) {
+            if (b < 256) s_mul[t] = fq::mul(s_acc[pi], s_pw[pj]);
+        } else if (t < 222) {
+            if (b < 256) s_sq[t - 144] = fq::mul(s_pw[pi], s_pw[pj]);
+        } else if (ct >= 0 && ct < 72 && b > 0) {
             // task = (row 0/1, array 0 acc / 1 pw / 2 C, tower component tc); the cells hold the tower basis
             // Fq2[w]/(w^6 - (9 + u)): tc = 2i -> c_i + 9 c_{i+6}, tc = 2i + 1 -> c_{i+6}   (tools/air_gen.py build_fq12)
-            const int rowsel = t / 36, arr = (t % 36) / 12, tc = t % 12;
-            const size_t row = (size_t)io * 512 + 2 * b + rowsel;
-            const Fq* src = arr == 0 ? ((rowsel && bit) ? s_res[0] : s_acc) : arr == 1 ? s_pw : s_res[rowsel];
+            const int pb = b - 1;
+            const int bit = (int)((ex[pb >> 5] >> (pb & 31)) & 1);
+            const Fq12Snap& sn = s_snap[pb & 1];
+            const int rowsel = ct / 36, arr = (ct % 36) / 12, tc = ct % 12;
+            const size_t row = (size_t)io * 512 + 2 * pb + rowsel;
+            const Fq* src = arr == 0 ? ((rowsel && bit) ? sn.res[0] : sn.acc) : arr == 1 ? sn.pw : sn.res[rowsel];
             const int i = tc >> 1;
             Fq v = src[i + 6];
-            if (!(tc & 1)) v = fq::add(src[i], fq::mul(m9, v));
+            if (!(tc & 1)) {
+                // c_i + 9 c_{i+6}: 9 v = 8 v + v (three doublings and an addition are shorter than a Montgomery product)
+                Fq v2 = fq::add(v, v);
+                v2 = fq::add(v2, v2);
+                v2 = fq::add(v2, v2);
+                v = fq::add(src[i], fq::add(v2, v));
+            }
             v = fq::from_mont(v);
             if (arr == 0) store_limbs16(tr, n, c.acc + 16 * tc, row, v);
             else if (arr == 1) store_limbs16(tr, n, c.pw + 16 * tc, row, v);
             else store_checked(tr, n, c.C + 16 * c.cpl * tc, row, v, c.cpl);
         }
+        if (b == 256) break;
         __syncthreads();
+        // (B) d_m = sum_{i + j = m} of the products, m = 0..22, for acc * pw (lanes 0..22) and pw * pw (lanes 23..45)
+        if (t < 46) {
+            const int sq = t >= 23, m = t % 23;
+            const int lo = m > 11 ? m - 11 : 0, hi = m < 11 ? m : 11;  // i range with 0 <= m - i <= 11
+            Fq d = fq::zero();
+            if (!sq) {
+                for (int i = lo; i <= hi; i++) d = fq::add(d, s_mul[i * 12 + (m - i)]);
+            } else {
+                for (int i = lo; 2 * i < m; i++) d = fq::add(d, s_sq[sq_index(i, m - i)]);
+                d = fq::add(d, d);
+                if (!(m & 1)) d = fq::add(d, s_sq[sq_index(m >> 1, m >> 1)]);
+            }
+            s_d[sq][m] = d;
+        }
+        __syncthreads();
+        // (C) k < 6: d_k, 82 d_{k+12}, 1476 d_{k+18} (0 for k = 5: d_23 does not exist);  k >= 6: d_k, 18 d_{k+6}, 242 d_{k+12}
+        if (t < 72) {
+            Fq v = fq::zero();
+            if (f_term == 0)
+                v = s_d[f_sq][f_k];
+            else if (f_m < 23)
+                v = fq::mul(f_c, s_d[f_sq][f_m]);
+            s_t[f_sq][f_k][f_term] = v;
+        }
+        __syncthreads();
+        // (D) r_k = t0 -/+ t1 -/+ t2
+        if (t < 24) {
+            const int sq = t >= 12, k = t % 12;
+            const Fq* tt = s_t[sq][k];
+            s_res[sq][k] = k < 6 ? fq::sub(fq::sub(tt[0], tt[1]), tt[2]) : fq::add(fq::add(tt[0], tt[1]), tt[2]);
+        }
+        __syncthreads();
+        // (E) snapshot for the conversion lanes, then the state of the next bit
         if (t < 12) {
+            const int bit = (int)((ex[b >> 5] >> (b & 31)) & 1);
+            Fq12Snap& sn = s_snap[b & 1];
+            sn.acc[t] = s_acc[t];
+            sn.pw[t] = s_pw[t];
+            sn.res[0][t] = s_res[0][t];
+            sn.res[1][t] = s_res[1][t];
             if (bit) s_acc[t] = s_res[0][t];
             if (b != 255) s_pw[t] = s_res[1][t];
         }
@@ -985,7 +1042,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         col_e = col_bit + 1;
         exp_off = 192;
         ProfScope ps(ctx, "trace_fq12_chain");
-        hipLaunchKernelGGL(fq12_chain_kernel, dim3(num_io), dim3(288), 0, ctx->stream, d_ios, num_io, d_trace, n, c);
+        hipLaunchKernelGGL(fq12_chain_kernel, dim3(num_io), dim3(384), 0, ctx->stream, d_ios, num_io, d_trace, n, c);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     } else {
         const int ext = a->kind == 0 ? 1 : 2, ncl = 16 * ext;

@@ -373,3 +373,27 @@ def test_other_blowups_arities_and_pow_rules_match_the_oracle(ios4, rate_bits, a
             assert _oracle.stark_verify(got, ocfg) == 0
         finally:
             ctx.close()
+
+
+def test_g2_cofactor_clearing_runs_through_the_g2_exp_stark(ctx):
+    """SURVEY 8f rank 4 (reference src/bin/bls_aggregation.rs:65,103-106), the arithmetic half: messages mapped to E'(Fp2) are
+    multiplied by the cofactor 2p - r.  That is a G2 obligation out = offset + [exp] x with exp = cofactor (254 bits) on points
+    OUTSIDE the r-torsion -- the same records, AIR and prover as the SIPP G2 list.  Outputs from sipp_exp_outputs are checked
+    against the Python restatement (and land in the r-torsion once the offset is removed); the proof equals the oracle's word
+    for word.  The map to the curve itself is not in the reference tree and is not restated."""
+    from oracle.py import bn254 as bn
+    h = bn.G2_COFACTOR
+    offset = bn.g2_mul(bn.G2, 0x5151)
+    pts = [bn.g2_twist_point(seed) for seed in (11, 12, 13)]
+    recs = [bn.g2_to_u32(p) + bn.g2_to_u32(offset) + [(h >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [0] * 32 for p in pts]
+    ios = ctx.exp_outputs(1, np.array(recs, dtype=np.uint32))
+    for p, rec in zip(pts, ios):
+        w = [int(x) for x in rec[72:104]]
+        out = ((bn.u32_to_fq(w[0:8]), bn.u32_to_fq(w[8:16])), (bn.u32_to_fq(w[16:24]), bn.u32_to_fq(w[24:32])))
+        cleared = bn.g2_add(out, bn.g2_neg(offset))
+        assert cleared == bn.g2_clear_cofactor(p)
+        assert bn.g2_mul(p, bn.R) is not None and bn.g2_mul(cleared, bn.R) is None
+    ref = _oracle.stark_prove(1, ios)
+    got = ctx.prove(1, ios)
+    assert len(got) == len(ref) and (got == ref).all()
+    assert _oracle.stark_verify(got) == 0

@@ -69,3 +69,21 @@ def test_c_fq_and_fq12_match_python(oracle):
         fy.c[k] = mk(y[k])
     r = oracle.fq12_mul(C.byref(fx), C.byref(fy))
     assert [val(r.c[k]) for k in range(12)] == bn.f12_mul(x, y)
+
+
+def test_fq2_sqrt_and_cofactor_clearing():
+    """E'(Fp2) has r (2p - r) points: a twist point found by try-and-increment is (almost surely) outside the r-torsion, its
+    cofactor multiple is inside (what bls_aggregation.rs:103-106 does with mapped messages)"""
+    from oracle.py import bn254 as bn
+    for a in [(4, 0), (5, 7), (123456789, 987654321), (0, 1)]:
+        sq = bn.f2_mul(a, a)
+        r = bn.f2_sqrt(sq)
+        assert r is not None and bn.f2_mul(r, r) == sq
+    assert sum(bn.f2_sqrt((k, 1)) is None for k in range(40)) > 5          # about half of the elements are non-squares
+    for seed in (1, 2, 3):
+        pt = bn.g2_twist_point(seed)
+        assert bn.g2_on_curve(pt)
+        assert bn.g2_mul(pt, bn.R) is not None                               # not in the r-torsion
+        assert bn.g2_mul(pt, bn.R * bn.G2_COFACTOR) is None                  # the group order kills it
+        cleared = bn.g2_clear_cofactor(pt)
+        assert cleared is not None and bn.g2_on_curve(cleared) and bn.g2_mul(cleared, bn.R) is None
