@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$1
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export SIPP_BENCH_IO_SHARD_N=0   # the profiled command is the n = 128 line alone (no io_sharded leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_w.log"

@@ -511,6 +511,10 @@ int ntt_r16_mask() {
     return v;
 }
 
+// Tile size per transform size, measured (round 2): a 2^13-element tile would turn the THREE passes of log_n = 21, 22 (N = 2^21
+// traces, n = 4096) into two, but every pass on it is slower than the saved sweep is worth -- with 256 threads (32 elements per
+// lane) twice as slow (n = 4096: 1697 vs 1464 ms per instance), with 512 threads (two 72-KB blocks per CU) 315 + 143 ms of
+// transform time against 285 + 128 ms.  The light strided passes (4-5 stages) already run at 2.5-3 TB/s; 2^12 stays.
 int ntt_ltile() {
     static int v = -1;
     if (v < 0) {
