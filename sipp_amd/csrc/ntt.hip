@@ -54,6 +54,30 @@ struct PassArgs {
 
 __device__ __forceinline__ uint32_t lds_idx(uint32_t e) { return e + (e >> LOG_SEG); }
 
+// for e = threadIdx.x; e < E; e += blockDim.x:  use(e, load(e)) -- with U loads in flight per lane.  The trip counts of the tile
+// loops are run-time values, so the compiler keeps them rolled and waits for every load before it issues the next
+// (global_load; s_waitcnt vmcnt(0); ds_write in the ISA): one 8-byte load in flight per lane caps a sweep at 2.5-3 TB/s
+// (256 CUs x 16 waves x 512 B over ~0.8 us).  Batches of U keep U loads in flight.
+struct Two {
+    uint64_t a, b;
+};
+template <int U, class T, class Load, class Use>
+__device__ __forceinline__ void tile_loop(uint32_t E, Load load, Use use) {
+    const uint32_t step = blockDim.x;
+    uint32_t e = threadIdx.x;
+    for (; e + (U - 1) * step < E; e += U * step) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = load(e + u * step);
+#pragma unroll
+        for (int u = 0; u < U; u++) use(e + u * step, v[u]);
+    }
+    for (; e < E; e += step) use(e, load(e));
+}
+#ifndef SIPP_NTT_MLP
+#define SIPP_NTT_MLP 8
+#endif
+
 // LDS placement of tile element e: one u64 of padding per 16 (lds_idx), optionally one more per 2^BLK elements so that a
 // scatter over blocks (the bit-reversed gather of lde_gather_kernel) is conflict-free as well
 struct IdxPlain {
@@ -223,10 +247,13 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     };
 
     // ---- load ----
-    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
-        uint64_t p = pos_of(e);
-        tile[lds_idx(e)] = p < a.n_in ? in[p] : 0;
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E,
+        [&](uint32_t e) -> uint64_t {
+            const uint64_t p = pos_of(e);
+            return p < a.n_in ? in[p] : 0;
+        },
+        [&](uint32_t e, uint64_t v) { tile[lds_idx(e)] = v; });
     for (uint32_t i = threadIdx.x; i < (R >> 1); i += blockDim.x) wr_s[i] = a.wr[i];
     __syncthreads();
 
@@ -276,11 +303,12 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     }
 
     // ---- store ----
-    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
-        uint64_t v = tile[lds_idx(e)];
-        if (!cs_done) v = gl::mul(v, a.cscale);
-        out[pos_of(e)] = v;
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; },
+        [&](uint32_t e, uint64_t v) {
+            if (!cs_done) v = gl::mul(v, a.cscale);
+            out[pos_of(e)] = v;
+        });
 }
 
 
@@ -338,14 +366,19 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
     const uint64_t* cf = in;   // where the coefficients of this column can be (re)read from
     if (!a.from_coeffs) {
         // values -> coefficients: scatter into bit-reversed position, DIT low bits, twiddle (x 1/n), DIT high bits
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tile[lds_idx(gl::bitrev(i, a.log_n))] = in[i];
+        tile_loop<SIPP_NTT_MLP, uint64_t>(
+            n, [&](uint32_t i) -> uint64_t { return in[i]; },
+            [&](uint32_t i, uint64_t v) { tile[lds_idx(gl::bitrev(i, a.log_n))] = v; });
         __syncthreads();
         tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{}, a.r16 != 0);
-        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_inv[p]);
+        tile_loop<SIPP_NTT_MLP, uint64_t>(
+            n, [&](uint32_t p) -> uint64_t { return a.tw_inv[p]; },
+            [&](uint32_t p, uint64_t w) { tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], w); });
         __syncthreads();
         tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{}, a.r16 != 0);
         uint64_t* co = a.coeffs + (size_t)col * n;
-        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) co[p] = tile[lds_idx(p)];
+        tile_loop<SIPP_NTT_MLP, uint64_t>(
+            n, [&](uint32_t p) -> uint64_t { return tile[lds_idx(p)]; }, [&](uint32_t p, uint64_t v) { co[p] = v; });
         cf = co;
     }
     const uint32_t halves = 1u << a.rate_bits;
@@ -353,19 +386,26 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
         // coefficients x coset powers -> LDS (the first coset of from_values takes them from LDS, the others re-read them)
         const uint64_t* pw = a.pw + (size_t)h * n;
         if (h == 0 && !a.from_coeffs) {
-            for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], pw[p]);
+            tile_loop<SIPP_NTT_MLP, uint64_t>(
+                n, [&](uint32_t p) -> uint64_t { return pw[p]; },
+                [&](uint32_t p, uint64_t w) { tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], w); });
         } else {
             __syncthreads();   // the previous half's stores read the tile
-            for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(cf[p], pw[p]);
+            tile_loop<SIPP_NTT_MLP, Two>(
+                n, [&](uint32_t p) -> Two { return Two{cf[p], pw[p]}; },
+                [&](uint32_t p, Two v) { tile[lds_idx(p)] = gl::mul(v.a, v.b); });
         }
         __syncthreads();
         tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{}, a.r16 != 0);
-        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], a.tw_fwd[p]);
+        tile_loop<SIPP_NTT_MLP, uint64_t>(
+            n, [&](uint32_t p) -> uint64_t { return a.tw_fwd[p]; },
+            [&](uint32_t p, uint64_t w) { tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], w); });
         __syncthreads();
         tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{}, a.r16 != 0);
         // natural LDE index i = i' 2^rate_bits + h sits at leaf position bitrev(h) n + bitrev(i'): the DIF's own order
         uint64_t* out = a.lde + (size_t)col * a.lde_stride + (size_t)gl::bitrev(h, a.rate_bits) * n;
-        for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) out[p] = tile[lds_idx(p)];
+        tile_loop<SIPP_NTT_MLP, uint64_t>(
+            n, [&](uint32_t p) -> uint64_t { return tile[lds_idx(p)]; }, [&](uint32_t p, uint64_t v) { out[p] = v; });
     }
 }
 
@@ -400,17 +440,24 @@ __global__ void __launch_bounds__(256) lde_gather_kernel(GatherArgs a) {
     for (uint32_t i = threadIdx.x; i < (R2 >> 1); i += blockDim.x) wr_s[i] = a.wr[i];
     // natural index = bitrev(position): [bitrev(r) | bitrev(mid) | bitrev4(g)]
     const uint32_t nat_mid = gl::bitrev(mid, mid_bits) << 4;
-    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
-        const uint32_t gq = e & 15, r = e >> 4;
-        const uint32_t nat = (gl::bitrev(r, k2) << (a.log_n - k2)) | nat_mid | gq;
-        tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = in[nat];
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E,
+        [&](uint32_t e) -> uint64_t {
+            const uint32_t gq = e & 15, r = e >> 4;
+            return in[(gl::bitrev(r, k2) << (a.log_n - k2)) | nat_mid | gq];
+        },
+        [&](uint32_t e, uint64_t v) {
+            const uint32_t gq = e & 15, r = e >> 4;
+            tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = v;
+        });
     __syncthreads();
     tile_stages(tile, wr_s, E, k2, 0, true, lidx, a.r16 != 0);
-    for (uint32_t e = threadIdx.x; e < E; e += blockDim.x) {
-        const uint32_t g = e >> k2, r = e & (R2 - 1);
-        out[((size_t)g << (a.log_n - 4)) | ((size_t)mid << k2) | r] = tile[lidx(e)];
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E, [&](uint32_t e) -> uint64_t { return tile[lidx(e)]; },
+        [&](uint32_t e, uint64_t v) {
+            const uint32_t g = e >> k2, r = e & (R2 - 1);
+            out[((size_t)g << (a.log_n - 4)) | ((size_t)mid << k2) | r] = v;
+        });
 }
 
 struct MidArgs {
@@ -440,25 +487,29 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
     for (uint32_t i = threadIdx.x; i < (R1 >> 1); i += blockDim.x) wi[i] = a.wr_inv[i];
     for (uint32_t i = threadIdx.x; i < R1; i += blockDim.x) wf[i] = a.wr_fwd[i];
     // element e = r 16 + t  <->  position p = r 2^k2 + i0 + t
-    for (uint32_t e = threadIdx.x; e < E1; e += blockDim.x) {
-        const size_t p = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
-        tile[lds_idx(e)] = gl::mul(co[p], a.tw_inv[p]);
-    }
+    auto pos = [&](uint32_t e) -> size_t { return ((size_t)(e >> 4) << k2) + i0 + (e & 15); };
+    tile_loop<SIPP_NTT_MLP, Two>(
+        E1,
+        [&](uint32_t e) -> Two {
+            const size_t p = pos(e);
+            return Two{co[p], a.tw_inv[p]};
+        },
+        [&](uint32_t e, Two v) { tile[lds_idx(e)] = gl::mul(v.a, v.b); });
     __syncthreads();
     tile_stages(tile, wi, E1, k1, 4, true, IdxPlain{}, a.r16 != 0);
-    for (uint32_t e = threadIdx.x; e < E1; e += blockDim.x) {
-        const size_t p = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
-        const uint64_t c = tile[lds_idx(e)];
-        co[p] = c;
-        tile[lds_idx(e)] = gl::mul(c, a.pw[p]);          // coset shift 7^p
-        tile[lds_idx(e + E1)] = 0;                        // zero padding of the LDE: rows R1 .. 2 R1 - 1
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E1, [&](uint32_t e) -> uint64_t { return a.pw[pos(e)]; },
+        [&](uint32_t e, uint64_t w) {
+            const uint64_t c = tile[lds_idx(e)];
+            co[pos(e)] = c;
+            tile[lds_idx(e)] = gl::mul(c, w);                 // coset shift 7^p
+            tile[lds_idx(e + E1)] = 0;                        // zero padding of the LDE: rows R1 .. 2 R1 - 1
+        });
     __syncthreads();
     tile_stages(tile, wf, E2, k1 + 1, 4, false, IdxPlain{}, a.r16 != 0);
-    for (uint32_t e = threadIdx.x; e < E2; e += blockDim.x) {
-        const size_t q = ((size_t)(e >> 4) << k2) + i0 + (e & 15);
-        lde[q] = gl::mul(tile[lds_idx(e)], a.tw_fwd[q]);
-    }
+    tile_loop<SIPP_NTT_MLP, uint64_t>(
+        E2, [&](uint32_t e) -> uint64_t { return a.tw_fwd[pos(e)]; },
+        [&](uint32_t e, uint64_t w) { lde[pos(e)] = gl::mul(tile[lds_idx(e)], w); });
 }
 
 __global__ void bitrev_cols_kernel(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride,
