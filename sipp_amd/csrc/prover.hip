@@ -511,7 +511,36 @@ __global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restric
     __shared__ uint64_t s[4][256];
     const uint32_t col0 = blockIdx.x * OCOLS;
     gl::Acc160 acc[OCOLS][4];
-    for (size_t k = threadIdx.x; k < n; k += 256) {
+    // OB coefficient indices per trip: all their loads are issued before the first product (the rolled loop waited for five
+    // loads per 32 products; n / 256 trips of load latency were the kernel's run time)
+    constexpr int OB = 4;
+    size_t k = threadIdx.x;
+    for (; k + (OB - 1) * 256 < n; k += OB * 256) {
+        uint64_t p0[OB], p1[OB], q0[OB], q1[OB], v[OCOLS][OB];
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+            const size_t kb = k + (size_t)b * 256;
+            p0[b] = t0[kb];
+            p1[b] = t0[n + kb];
+            q0[b] = t1 ? t1[kb] : 0;
+            q1[b] = t1 ? t1[n + kb] : 0;
+#pragma unroll
+            for (int u = 0; u < OCOLS; u++) v[u][b] = coeffs[(size_t)min(col0 + u, ncols - 1) * n + kb];
+        }
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+#pragma unroll
+            for (int u = 0; u < OCOLS; u++) {
+                acc[u][0].mac(v[u][b], p0[b]);
+                acc[u][1].mac(v[u][b], p1[b]);
+                if (t1) {
+                    acc[u][2].mac(v[u][b], q0[b]);
+                    acc[u][3].mac(v[u][b], q1[b]);
+                }
+            }
+        }
+    }
+    for (; k < n; k += 256) {
         const uint64_t p0 = t0[k], p1 = t0[n + k];
         const uint64_t q0 = t1 ? t1[k] : 0, q1 = t1 ? t1[n + k] : 0;
 #pragma unroll
@@ -562,21 +591,39 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(CombArgs a) {
     const int c_lo = blockIdx.y * per, c_hi = min(total, c_lo + per);
     gl::Acc6 G0, G1, H0, H1;
     G0.zero(); G1.zero(); H0.zero(); H1.zero();
-    for (int c = c_lo; c < c_hi; c++) {
-        const uint64_t* col = c < a.cnt[0] ? a.src[0] + (size_t)c * a.n
-                              : c < a.cnt[0] + a.cnt[1] ? a.src[1] + (size_t)(c - a.cnt[0]) * a.n
-                                                        : a.src[2] + (size_t)(c - a.cnt[0] - a.cnt[1]) * a.n;
-        const uint64_t v = col[k];
-        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-        const uint32_t* __restrict__ w = a.apow3 + 6 * c;
-        if (c < a.n1) {   // wave-uniform
-            G0.mac(lo, hi, w);
-            G1.mac(lo, hi, w + 3);
-        } else {
-            H0.mac(lo, hi, w);
-            H1.mac(lo, hi, w + 3);
-        }
+    const uint64_t *src0 = a.src[0], *src1 = a.src[1], *src2 = a.src[2];
+    const int cnt0 = a.cnt[0], cnt01 = a.cnt[0] + a.cnt[1], n1 = a.n1;
+    const size_t nn = a.n;
+    const uint32_t* __restrict__ apow3 = a.apow3;
+    auto col_of = [=](int c) -> const uint64_t* {
+        return c < cnt0 ? src0 + (size_t)c * nn : c < cnt01 ? src1 + (size_t)(c - cnt0) * nn : src2 + (size_t)(c - cnt01) * nn;
+    };
+#define SIPP_COMB_TERM(cc, vv)                                             \
+    do {                                                                   \
+        const uint64_t v_ = (vv);                                          \
+        const uint32_t lo_ = (uint32_t)v_, hi_ = (uint32_t)(v_ >> 32);     \
+        const uint32_t* __restrict__ w_ = apow3 + 6 * (cc);                \
+        if ((cc) < n1) { /* wave-uniform */                                \
+            G0.mac(lo_, hi_, w_);                                          \
+            G1.mac(lo_, hi_, w_ + 3);                                      \
+        } else {                                                           \
+            H0.mac(lo_, hi_, w_);                                          \
+            H1.mac(lo_, hi_, w_ + 3);                                      \
+        }                                                                  \
+    } while (0)
+    // eight columns per trip: their coefficients are loaded before the first multiply-add (one load per trip of a rolled
+    // loop made the kernel wait out a memory latency per column)
+    constexpr int CB = 8;
+    int c = c_lo;
+    for (; c + CB <= c_hi; c += CB) {
+        uint64_t v[CB];
+#pragma unroll
+        for (int b = 0; b < CB; b++) v[b] = col_of(c + b)[k];
+#pragma unroll
+        for (int b = 0; b < CB; b++) SIPP_COMB_TERM(c + b, v[b]);
     }
+    for (; c < c_hi; c++) SIPP_COMB_TERM(c, col_of(c)[k]);
+#undef SIPP_COMB_TERM
     const uint64_t g0 = gl::canon(G0.reduce()), g1 = gl::canon(G1.reduce());
     uint64_t* p = a.partial + (size_t)blockIdx.y * 4 * a.n;
     p[k] = gl::add(g0, gl::canon(H0.reduce()));
