@@ -382,6 +382,7 @@ permute_fn pick() {
     // "mixed" (AVX-512 full rounds + scalar look-ahead partial rounds, the default where AVX-512 exists) overrides the choice.
     // One dependent permutation on an EPYC 9575F (scripts/ubench/host_poseidon_bench.cpp): 1.17 / 1.08 / 0.77 / 0.76 us.
     const char* e = getenv("SIPP_HOST_POSEIDON");
+    __builtin_cpu_init();  // this runs from a static initialiser of the shared library
     const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
     if (e && e[0] == 's') return permute_scalar;
     if (e && e[0] == 'l') return permute_scalar_lookahead;
