@@ -61,16 +61,8 @@ GL_HD uint64_t reduce128_nc(uint64_t hi, uint64_t lo) {
     const uint32_t b1h = a1 + hl;
     const bool c1 = b1h < a1;
     const uint64_t b = ((uint64_t)b1h << 32) | a0;
-#if defined(SIPP_REDUCE_MAD)
     const int32_t corr = (int32_t)c1 - (int32_t)b1;  // -1, 0, +1
     return b + (uint64_t)((int64_t)corr * (int64_t)EPS);
-#else
-    // + EPS for a lone carry, - EPS (= + P mod 2^64) for a lone borrow: two selects on scalar masks and one 64-bit addition
-    // instead of a fifth v_mad_u64_u32 with its sign fix-up (round 2)
-    const uint64_t up = (c1 && !b1) ? EPS : 0;
-    const uint64_t dn = (b1 && !c1) ? P : 0;
-    return b + (up | dn);
-#endif
 }
 
 GL_HD uint64_t reduce128(uint64_t hi, uint64_t lo) { return canon(reduce128_nc(hi, lo)); }
