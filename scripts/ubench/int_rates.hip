@@ -19,6 +19,13 @@ __global__ void k(uint64_t* out, uint32_t a0, uint32_t b0) {
             if (OP == 4) acc[i] = (uint32_t)acc[i] + a;                                 // v_add_u32
             if (OP == 5) acc[i] = __umul64hi(acc[i], ((uint64_t)a << 32) | b) + acc[i] * b;  // full 64x64 hi+lo
             if (OP == 6) acc[i] = __mul24((int)acc[i], (int)a) + b;                     // v_mul_u32_u24
+            if (OP == 7) {                                                              // v_dot2_u32_u16
+                typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+                const uint32_t x = (uint32_t)acc[i];
+                acc[i] = __builtin_amdgcn_udot2(*(const v2u16*)&x, *(const v2u16*)&a, b, false);
+            }
+            if (OP == 8) acc[i] = __builtin_amdgcn_udot4((uint32_t)acc[i], a, b, false); // v_dot4_u32_u8
+            if (OP == 9) acc[i] = __builtin_amdgcn_perm((uint32_t)acc[i], a, 0x05040100u) + 0; // v_perm_b32
         }
     }
     uint64_t s = 0;
@@ -55,5 +62,8 @@ int main() {
     run<2>("v_mul_hi_u32+add", 1);
     run<6>("v_mul_u32_u24+add", 1);
     run<5>("u64 mulhi + mullo", 1);
+    run<7>("v_dot2_u32_u16", 1);
+    run<8>("v_dot4_u32_u8", 1);
+    run<9>("v_perm_b32", 1);
     return 0;
 }
