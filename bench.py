@@ -204,24 +204,6 @@ def main():
         for g in extra:
             g.close()
 
-    # secondary figure, outside the timed region: ONE instance whose obligation lists are cut into `world` contiguous ranges,
-    # every rank proving its range as STARKs of its own (sipp_io_shard; DESIGN.md section 5, level L-D; BASELINE configs[3] /
-    # configs[4]: "per-round starky sub-proofs sharded across 8 MI355X").  Strong scaling, no data-path collective: the time
-    # of the instance is the slowest rank's.  Sizes: n = 1024 on one rank, n = 1024 and n = 4096 on several.
-    io_sharded = None
-    shard_sizes = os.environ.get("SIPP_BENCH_IO_SHARD_N", "1024" if world == 1 else "1024,4096")
-    if shard_sizes not in ("", "0") and not serial:
-        io_sharded = {}
-        for n_s in [int(x) for x in shard_sizes.split(",")]:
-            mine = sipp_amd.shard_ios(load_ios(n_s), world, rank)
-            si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios)
-            k_s = 2
-            dts, _ = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=device_sync, device=red_device)
-            si.close()
-            io_sharded["n=%d" % n_s] = {"ms_per_instance": 1e3 * dts / k_s, "value": n_s * k_s / dts, "unit": "pairings/s",
-                                        "scaling": "strong", "ranks": world, "steps": k_s,
-                                        "records_of_rank0": [int(a.shape[0]) for a in mine]}
-
     # one extra step with the three proofs run one after the other (outside the timed region): per-kernel times without the
     # other proofs' kernels competing for the SIMDs
     kernel_ms_serial = None
@@ -325,7 +307,6 @@ def main():
             "proof_words": [int(len(p)) for p in proofs],
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms] if serial else None,
             "pipelined": pipelined,
-            "io_sharded": io_sharded,
         }
         # secondary, outside the timed region: the native SIPP chain in front of the circuit
         # on this GPU -- sipp_prove_native = 3n - 2 pairings + the folds, sipp_verify_native = the obligation lists the timed
@@ -360,10 +341,32 @@ def main():
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
+    # secondary figure, outside the timed region and after everything else (this process's other arenas are released first: at
+    # n = 4096 one rank needs 246 GB): ONE instance whose obligation lists are cut into `world` contiguous ranges, every rank
+    # proving its range as STARKs of its own (sipp_io_shard; DESIGN.md section 5, level L-D; BASELINE configs[3] / configs[4]:
+    # "per-round starky sub-proofs sharded across 8 MI355X").  Strong scaling, no data-path collective: the time of the
+    # instance is the slowest rank's.  Sizes: n = 1024 and n = 4096 on any number of ranks (one rank = the whole instance on one
+    # GPU, the figure the sharded runs are divided into).
+    inst.close()
+    io_sharded = None
+    shard_sizes = os.environ.get("SIPP_BENCH_IO_SHARD_N", "1024,4096")
+    if shard_sizes not in ("", "0") and not serial:
+        io_sharded = {}
+        for n_s in [int(x) for x in shard_sizes.split(",")]:
+            mine = sipp_amd.shard_ios(load_ios(n_s), world, rank)
+            si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios)
+            k_s = 2
+            dts, _ = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
+                                           device=red_device)
+            si.close()
+            io_sharded["n=%d" % n_s] = {"ms_per_instance": 1e3 * dts / k_s, "value": n_s * k_s / dts, "unit": "pairings/s",
+                                        "scaling": "strong", "ranks": world, "steps": k_s,
+                                        "records_of_rank0": [int(a.shape[0]) for a in mine]}
+    if rank == 0:
+        out["io_sharded"] = io_sharded
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    inst.close()
 
 
 if __name__ == "__main__":
