@@ -182,27 +182,19 @@ def main():
     # (3 streams each).  One instance leaves issue slots idle in its latency-bound phases (chains, Fiat-Shamir round
     # trips, FRI tail); a server with a queue of proofs fills them.  `value` above stays the single-instance number.
     pipelined = None
-    if args.inflight > 1 and not serial and sum(ws) * args.inflight < (200 << 30):
-        from concurrent.futures import ThreadPoolExecutor
-        extra = [sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios)
-                 for _ in range(args.inflight - 1)]
-        groups = [inst] + extra
-        pool2 = ThreadPoolExecutor(max_workers=args.inflight)
-
-        def pstep():
-            return list(pool2.map(lambda g: g.prove(ios), groups))
-
-        pstep()
+    if args.inflight > 1 and not serial and sum(ws) * (args.inflight + 1) < (240 << 30):
+        # sipp_instances_prove: `inflight` slots of three ctxs take the instances of a queue from a shared counter
+        queue = sipp_amd.InstanceQueue([a.shape[0] for a in ios], in_flight=args.inflight, device=local_rank, priorities=prios)
+        queue.prove([ios] * args.inflight)
         barrier()
         tp = time.perf_counter()
-        for _ in range(args.steps):
-            pstep()
+        queue.prove([ios] * (args.inflight * args.steps))
         barrier()
         dtp = dist_util_max(time.perf_counter() - tp)
         pipelined = {"instances_in_flight": args.inflight, "ms_per_instance": 1e3 * dtp / (args.steps * args.inflight),
-                     "value": args.n * world * args.inflight * args.steps / dtp, "unit": "pairings/s"}
-        for g in extra:
-            g.close()
+                     "value": args.n * world * args.inflight * args.steps / dtp, "unit": "pairings/s",
+                     "entry_point": "sipp_instances_prove (queue of %d instances)" % (args.inflight * args.steps)}
+        queue.close()
 
     # one extra step with the three proofs run one after the other (outside the timed region): per-kernel times without the
     # other proofs' kernels competing for the SIMDs

@@ -115,6 +115,14 @@ int sipp_wait(sipp_ctx *ctx, size_t *proof_len);
  * (proof_len[k] = 0). */
 int sipp_instance_prove(sipp_ctx *const ctxs[3], const uint32_t *const ios[3], const size_t num_io[3],
                         uint64_t *const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]);
+/* A queue of `count` independent instances on one GPU (or several): `in_flight` slots of three distinct ctxs each
+ * (ctxs[3 * slot + kind]) take the instances from a shared counter, so the latency-bound head and tail of one instance
+ * overlap the hashing of the others.  Arrays of instance i: ios[3 i + kind], num_io[3 i + kind], proof_out / proof_cap /
+ * proof_len likewise; status[i] (may be NULL) receives sipp_instance_prove's result for instance i.  Returns the first
+ * failing status; every instance is attempted.  Every ctx's workspace must hold the largest proof of its kind. */
+int sipp_instances_prove(sipp_ctx *const *ctxs, size_t in_flight, size_t count, const uint32_t *const *ios,
+                         const size_t *num_io, uint64_t *const *proof_out, const size_t *proof_cap, size_t *proof_len,
+                         int *status);
 /* IO-sharded sub-proofs (level L-D): the obligation list of one kind is cut into
  * `world` contiguous, balanced ranges and every rank proves ITS range as a STARK of its own -- on the reference side one
  * g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit call per range instead of one per list (src/verifier_circuit.rs:133-135

@@ -46,6 +46,9 @@ extern "C" {
     pub fn sipp_verify_native(ctx: *mut SippCtxOpaque, a: *const u32, b: *const u32, n: usize, proof: *const u32, statement: *mut u32,
                               g1_ios: *mut u32, g2_ios: *mut u32, fq12_ios: *mut u32, accepted: *mut c_int) -> c_int;
     pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
+    /// a queue of `count` instances through `in_flight` slots of three ctxs (arrays indexed 3 * i + kind)
+    pub fn sipp_instances_prove(ctxs: *const *mut SippCtxOpaque, in_flight: usize, count: usize, ios: *const *const u32,
+                                num_io: *const usize, out: *const *mut u64, cap: *const usize, len: *mut usize, status: *mut c_int) -> c_int;
     /// range of an obligation list that GPU `rank` of `world` proves as a STARK of its own (level L-D)
     pub fn sipp_io_shard(num_io: usize, world: u32, rank: u32, first: *mut usize, count: *mut usize) -> c_int;
 }

@@ -68,6 +68,8 @@ SIGNATURES = {
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "sipp_host_poseidon_permute": (C.c_int, [vp, C.c_size_t, C.c_int]),
+    "sipp_instances_prove": (C.c_int, [C.POINTER(vp), C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "sipp_io_shard": (C.c_int, [C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_instance_prove": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -421,6 +423,41 @@ class Instance:
         for c in self.ctxs:
             c.close()
         self.ctxs = []
+
+
+class InstanceQueue:
+    """sipp_instances_prove: `in_flight` slots of three ctxs on one device; prove(list of [g1, g2, fq12]) proves every instance of
+    the list, `in_flight` at a time, and returns their proofs (copies)."""
+
+    def __init__(self, num_io, in_flight=3, device=0, priorities=("low", "", "high")):
+        self.L = lib()
+        self.num_io = tuple(int(x) for x in num_io)
+        self.slots = [Instance(self.num_io, devices=(device,) * 3, priorities=priorities) for _ in range(in_flight)]
+
+    def prove(self, instances):
+        count, F = len(instances), len(self.slots)
+        keep = [[np.ascontiguousarray(a, dtype=np.uint32) for a in inst] for inst in instances]
+        for inst in keep:
+            assert tuple(a.shape[0] for a in inst) == self.num_io
+        caps = self.slots[0].caps
+        outs = [[np.zeros(max(c, 1), dtype=np.uint64) for c in caps] for _ in range(count)]
+        h = (vp * (3 * F))(*[c.h for s in self.slots for c in s.ctxs])
+        pi = (vp * (3 * count))(*[a.ctypes.data for inst in keep for a in inst])
+        ni = (C.c_size_t * (3 * count))(*[n for _ in range(count) for n in self.num_io])
+        po = (vp * (3 * count))(*[o.ctypes.data for inst in outs for o in inst])
+        pc = (C.c_size_t * (3 * count))(*[c for _ in range(count) for c in caps])
+        pl = (C.c_size_t * (3 * count))()
+        st = (C.c_int * count)()
+        rc = self.L.sipp_instances_prove(h, F, count, pi, ni, po, pc, pl, st)
+        if rc != 0:
+            msgs = "; ".join(self.L.sipp_last_error(c.h).decode() for s in self.slots for c in s.ctxs)
+            raise SippError(rc, "instances_prove: " + msgs)
+        return [[outs[i][k][: pl[3 * i + k]] for k in range(3)] for i in range(count)]
+
+    def close(self):
+        for s in self.slots:
+            s.close()
+        self.slots = []
 
 
 def io_shard(num_io, world, rank):

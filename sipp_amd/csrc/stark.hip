@@ -9,6 +9,8 @@
 //      proof-of-work (smallest nonce), 84 query openings.
 // The Fiat-Shamir challenger runs on the host (a few hundred Poseidon permutations per proof); every
 // array of size O(N) stays in HBM.  One HIP stream per ctx; three ctxs give the three-stream overlap.
+#include <atomic>
+#include <thread>
 #include <algorithm>
 #include <chrono>
 
@@ -894,5 +896,37 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     }
     for (int k = 0; k < 3; k++) ctxs[k]->gate_wait = ctxs[k]->gate_release = nullptr;
     return rc;
+}
+
+int sipp_instances_prove(sipp_ctx* const* ctxs, size_t in_flight, size_t count, const uint32_t* const* ios, const size_t* num_io,
+                         uint64_t* const* proof_out, const size_t* proof_cap, size_t* proof_len, int* status) {
+    if (!ctxs || !in_flight || !ios || !num_io || !proof_out || !proof_cap || !proof_len) return SIPP_E_BADARG;
+    for (size_t i = 0; i < 3 * in_flight; i++) {
+        if (!ctxs[i]) return SIPP_E_BADARG;
+        for (size_t j = 0; j < i; j++)
+            if (ctxs[i] == ctxs[j]) return SIPP_E_BADARG;
+    }
+    // one host thread per slot of three ctxs; the slots take the instances from a shared counter, so that the latency-bound
+    // head and tail of one instance overlap the hashing of the others (n = 128 on one MI355X: 57 ms per instance with three
+    // slots against 62 ms one at a time)
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{SIPP_OK};
+    auto worker = [&](size_t slot) {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= count) return;
+            const int rc = sipp_instance_prove(ctxs + 3 * slot, ios + 3 * i, num_io + 3 * i, proof_out + 3 * i, proof_cap + 3 * i,
+                                               proof_len + 3 * i);
+            if (status) status[i] = rc;
+            int ok = SIPP_OK;
+            if (rc != SIPP_OK) first_rc.compare_exchange_strong(ok, rc);
+        }
+    };
+    std::vector<std::thread> pool;
+    const size_t slots = in_flight < count ? in_flight : count;
+    for (size_t sl = 1; sl < slots; sl++) pool.emplace_back(worker, sl);
+    if (slots) worker(0);
+    for (auto& t : pool) t.join();
+    return first_rc.load();
 }
 }

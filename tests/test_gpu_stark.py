@@ -397,3 +397,30 @@ def test_g2_cofactor_clearing_runs_through_the_g2_exp_stark(ctx):
     got = ctx.prove(1, ios)
     assert len(got) == len(ref) and (got == ref).all()
     assert _oracle.stark_verify(got) == 0
+
+
+def test_instance_queue_gives_the_single_instance_proofs(ios4):
+    """sipp_instances_prove: five instances (alternating the n = 4 and a permuted copy of its obligation lists) through two slots
+    of three ctxs -- every proof equals what one Instance produces for the same lists; a bad record fails only its instance."""
+    import sipp_amd
+    other = [np.ascontiguousarray(a[::-1]) for a in ios4]
+    single = sipp_amd.Instance([a.shape[0] for a in ios4])
+    try:
+        want = {0: [p.copy() for p in single.prove(ios4)], 1: [p.copy() for p in single.prove(other)]}
+    finally:
+        single.close()
+    q = sipp_amd.InstanceQueue([a.shape[0] for a in ios4], in_flight=2)
+    try:
+        got = q.prove([ios4, other, ios4, other, ios4])
+        assert len(got) == 5
+        for i, proofs in enumerate(got):
+            for k in range(3):
+                assert len(proofs[k]) == len(want[i % 2][k]) and (proofs[k] == want[i % 2][k]).all(), (i, k)
+        bad = [a.copy() for a in ios4]
+        bad[0][0, -1] ^= 1                       # a wrong claimed output in the G1 list of the second instance
+        with pytest.raises(sipp_amd.SippError):
+            q.prove([ios4, bad, ios4])
+        again = q.prove([ios4])                   # the slots are usable afterwards
+        assert all((again[0][k] == want[0][k]).all() for k in range(3))
+    finally:
+        q.close()
