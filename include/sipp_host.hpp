@@ -304,6 +304,16 @@ class Prover {
         finish(io12, r12);
     }
 
+    // Several GPUs for ONE instance without any exchange (level L-D): the slice of an obligation list that
+    // GPU `rank` of `world` hands to its own g1_exp_circuit / g2_exp_circuit / fq12_exp_circuit call (sipp_io_shard)
+    template <class In>
+    static std::vector<In> io_shard(const std::vector<In>& all, unsigned world, unsigned rank) {
+        size_t first = 0, count = 0;
+        const int rc = sipp_io_shard(all.size(), world, rank, &first, &count);
+        if (rc != SIPP_OK) throw Error(rc, "sipp_io_shard: rank >= world or world == 0");
+        return std::vector<In>(all.begin() + (ptrdiff_t)first, all.begin() + (ptrdiff_t)(first + count));
+    }
+
     // ---- the native chain in front of the circuit ----
     // reference src/prover_native.rs:26-80: the 2 log2 n + 1 proof messages, in the reference's (reversed) order
     std::vector<Fq12> sipp_prove_native(const std::vector<G1Affine>& A, const std::vector<G2Affine>& B) {

@@ -8,6 +8,7 @@
 //                                                    writes <out_prefix>{0,1,2}.bin
 //
 // The verifier is the CPU oracle's (test infrastructure), linked only into this test binary.
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -46,6 +47,27 @@ static int layout(const char* proof_path) {
     CHECK(sizeof(sipp::G2ExpInput) == 4 * (SIPP_G2_IO_WORDS - 32));
     CHECK(sizeof(sipp::Fq12ExpInput) == 4 * (SIPP_FQ12_IO_WORDS - 96));
     CHECK(offsetof(sipp::G1ExpIO, out) == 4 * 40 && offsetof(sipp::G2ExpIO, out) == 4 * 72 && offsetof(sipp::Fq12ExpIO, out) == 4 * 200);
+    {
+        // level L-D: the per-GPU slices of an obligation list tile it (host arithmetic of the C ABI, no GPU)
+        std::vector<sipp::G1ExpInput> all(127);
+        for (size_t i = 0; i < all.size(); i++) memset(&all[i], (int)i, sizeof(all[i]));
+        for (unsigned world : {1u, 2u, 8u, 200u}) {
+            size_t seen = 0;
+            for (unsigned rank = 0; rank < world; rank++) {
+                const auto mine = sipp::Prover::io_shard(all, world, rank);
+                CHECK(mine.size() <= (all.size() + world - 1) / world);
+                for (size_t j = 0; j < mine.size(); j++) CHECK(memcmp(&mine[j], &all[seen + j], sizeof(all[0])) == 0);
+                seen += mine.size();
+            }
+            CHECK(seen == all.size());
+        }
+        try {
+            (void)sipp::Prover::io_shard(all, 4, 4);
+            CHECK(!"rank == world accepted");
+        } catch (const sipp::Error& e) {
+            CHECK(e.status() == SIPP_E_BADARG);
+        }
+    }
     if (!proof_path) return 0;
     const std::vector<uint64_t> flat = read_u64(proof_path);
     const auto p = sipp::StarkProofWithPublicInputs::from_flat(flat.data(), flat.size());
