@@ -57,6 +57,9 @@ struct Fld<2> {
     }
 };
 
+__device__ __forceinline__ Fq one_of(Fq*) { return fq::one_m(); }
+__device__ __forceinline__ Fq2 one_of(Fq2*) { return Fq2{fq::one_m(), fq::zero()}; }
+
 template <int EXT>
 struct Jac {
     typename Fld<EXT>::T x, y, z;
@@ -89,10 +92,21 @@ __device__ __forceinline__ Jac<EXT> jac_add(const Jac<EXT>& p, const Jac<EXT>& q
     auto u1 = F::mul(p.x, z2z2), u2 = F::mul(q.x, z1z1);
     auto s1 = F::mul(F::mul(p.y, q.z), z2z2), s2 = F::mul(F::mul(q.y, p.z), z1z1);
     auto h = F::sub(u2, u1);
+    auto rr = F::sub(s2, s1);
+    if (F::is_zero(h)) {
+        // the same x: p == q (the chord formula would divide zero by zero: double instead) or p == -q (the sum is the point
+        // at infinity).  The operands of the scan are sums of disjoint sets of 2^j x and the offset: equal whenever the
+        // offset is a small multiple of x (offset = 3 x, bits 0 and 1 set) -- records the AIR's sequential chain proves.
+        if (F::is_zero(rr)) return jac_dbl<EXT>(p);
+        Jac<EXT> inf;
+        inf.x = one_of((typename F::T*)nullptr);
+        inf.y = inf.x;
+        inf.z = F::sub(inf.x, inf.x);
+        return inf;
+    }
     auto i = F::add(h, h);
     i = F::sqr(i);
     auto j = F::mul(h, i);
-    auto rr = F::sub(s2, s1);
     rr = F::add(rr, rr);
     auto v = F::mul(u1, i);
     Jac<EXT> r;
@@ -104,8 +118,6 @@ __device__ __forceinline__ Jac<EXT> jac_add(const Jac<EXT>& p, const Jac<EXT>& q
     return r;
 }
 
-__device__ __forceinline__ Fq one_of(Fq*) { return fq::one_m(); }
-__device__ __forceinline__ Fq2 one_of(Fq2*) { return Fq2{fq::one_m(), fq::zero()}; }
 
 // scratch per row: Jacobian R_k and P_k (the values the row's constraints see)
 template <int EXT>
@@ -116,9 +128,9 @@ struct RowPts {
 template <int EXT>
 __device__ __forceinline__ bool jac_is_inf(const Jac<EXT>& p) { return Fld<EXT>::is_zero(p.z); }
 
-// group addition with the point at infinity (z == 0) as identity.  p == q never happens here: the operands
-// are sums of DISJOINT sets of 2^j x (and the offset), equal only with negligible probability -- that case
-// produces z == 0 garbage and is reported as SIPP_E_WITNESS by curve_rows.
+// group addition with the point at infinity (z == 0) as identity; jac_add is complete (p == q doubles, p == -q gives
+// infinity), so the scan below is right for EVERY record and the records refused are exactly those whose rows have no
+// witness (curve_rows: the AIR's own chain meets R = +-P), as in the CPU restatement.
 template <int EXT>
 __device__ __forceinline__ Jac<EXT> jac_add_id(const Jac<EXT>& p, const Jac<EXT>& q) {
     if (jac_is_inf<EXT>(p)) return q;

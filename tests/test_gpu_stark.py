@@ -424,3 +424,37 @@ def test_instance_queue_gives_the_single_instance_proofs(ios4):
         assert all((again[0][k] == want[0][k]).all() for k in range(3))
     finally:
         q.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_offset_a_small_multiple_of_the_base_point(ctx, kind):
+    """Found by scripts/stress_parity.py (round 2): with offset = 3 x and exponent bits 0 and 1 set, the parallel scan of the
+    trace generator adds two EQUAL partial sums (x + 2 x and the offset) although the AIR's sequential chain 3x -> 4x -> 6x
+    never meets R = +-P.  The Jacobian addition of the scan is complete now; what is refused is exactly what the CPU
+    restatement refuses (rows without a witness), and everything else is proved word for word."""
+    import sipp_amd
+    from oracle.py import bn254 as bn
+    mul, G, to_u32 = (bn.g1_mul, bn.G1, bn.g1_to_u32) if kind == 0 else (bn.g2_mul, bn.G2, bn.g2_to_u32)
+    neg = bn.g1_neg if kind == 0 else bn.g2_neg
+    pad = 16 if kind == 0 else 32
+
+    def rec(xk, offk, e):
+        off = mul(G, abs(offk))
+        if offk < 0:
+            off = neg(off)
+        return to_u32(mul(G, xk)) + to_u32(off) + [(e >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [0] * pad
+
+    allones = (1 << 256) - 1
+    provable = [rec(1, 3, allones - 0x330e4), rec(1, 3, 0b1011), rec(1, 5, 0b10111), rec(2, 6, 0x3), rec(1, 7, allones)]
+    for r in provable:                      # one record per proof: a refusal cannot hide behind another record
+        ios = ctx.exp_outputs(kind, np.array([r], dtype=np.uint32))
+        ref = _oracle.stark_prove(kind, ios)
+        got = ctx.prove(kind, ios)
+        assert len(got) == len(ref) and (got == ref).all()
+    # rows without a witness: both sides refuse (2x + [2] x doubles on an add row; -3x + x + 2x passes through infinity)
+    for r in (rec(1, 2, 0b10), rec(1, -3, 0b11)):
+        arr = np.array([r], dtype=np.uint32)
+        with pytest.raises(RuntimeError):
+            _oracle.stark_prove(kind, arr)
+        with pytest.raises(sipp_amd.SippError):
+            ctx.prove(kind, ctx.exp_outputs(kind, arr))
