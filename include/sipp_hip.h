@@ -215,7 +215,10 @@ typedef struct {
 /* PolynomialBatch::prove_openings: the opened values are computed, written and observed batch by batch, then alpha, the
  * final polynomial, the commit phase, the proof of work and the query rounds.  Flat proof (u64 words):
  *   header[8]: "SIPPFRI1", n_rounds, final_len, num_queries, n_oracles, n_batches, total_len, log_n
- *   opened values (ext) per batch | commit caps | final_poly | pow_witness | query rounds */
+ *   opened values (ext) per batch | commit caps | final_poly | pow_witness | query rounds
+ * Supported range (SIPP_E_UNSUPPORTED outside it): log_n 10 .. 24, rate_bits 1 .. 3, arity_bits 1 .. 4 per round, cap_height
+ * <= 8, and every committed layer holds at least 16 values; SIPP_E_BADARG for parameters the protocol itself forbids (a layer
+ * with fewer leaves than its cap, arities that exceed the degree). */
 size_t sipp_fri_proof_size(const sipp_oracle *oracles, size_t n_oracles, const sipp_fri_batch *batches, size_t n_batches,
                            uint32_t log_n, const sipp_fri_params *p);
 int sipp_fri_prove_openings(sipp_ctx *ctx, const sipp_oracle *oracles, size_t n_oracles, const sipp_fri_batch *batches,

@@ -32,20 +32,36 @@ for seed in range(first, first + count):
             return 1 << int(rng.integers(1, 254))               # one bit
         if mode == 3:
             return (1 << 256) - 1 - int(rng.integers(0, 1 << 20))  # 256-bit exponents are legal (U256Target)
+        if mode == 4:
+            return [0, 1, bn.R, bn.R + 1, (1 << 256) - 1, 1 << 255][int(rng.integers(0, 6))]
         return int.from_bytes(rng.bytes(32), "little") % bn.R or 1
 
     def fq():
         return int.from_bytes(rng.bytes(32), "little") % bn.P
 
+    def rand_f12():
+        mode = rng.integers(0, 8)
+        if mode == 0:
+            return [1] + [0] * 11                               # one
+        if mode == 1:
+            return [0] * 12                                     # zero
+        if mode == 2:
+            return [bn.P - 1] + [0] * 11                        # minus one
+        if mode == 3:
+            return [fq()] + [0] * 11                            # a base-field element
+        if mode == 4:
+            return [0] * 6 + [1] + [0] * 5                      # w^6
+        return [fq() for _ in range(12)]
+
     def words(e):
         return [(e >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
 
     n1, n2, n12 = (int(rng.integers(1, 10)) for _ in range(3))
-    g1 = [bn.g1_to_u32(bn.g1_mul(bn.G1, scalar() % bn.R or 1)) + bn.g1_to_u32(bn.g1_mul(bn.G1, scalar() % bn.R or 2)) + words(scalar()) + [0] * 16
+    g1 = [bn.g1_to_u32(bn.g1_mul(bn.G1, scalar() % bn.R or 1)) + bn.g1_to_u32(bn.g1_mul(bn.G1, scalar() % bn.R or 2)) + words(scalar() % (1 << 256)) + [0] * 16
           for _ in range(n1)]
-    g2 = [bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 1)) + bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 2)) + words(scalar()) + [0] * 32
+    g2 = [bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 1)) + bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 2)) + words(scalar() % (1 << 256)) + [0] * 32
           for _ in range(n2)]
-    f12 = [bn.f12_to_u32([fq() for _ in range(12)]) + bn.f12_to_u32([fq() for _ in range(12)]) + words(scalar()) + [0] * 96 for _ in range(n12)]
+    f12 = [bn.f12_to_u32(rand_f12()) + bn.f12_to_u32(rand_f12()) + words(scalar()) + [0] * 96 for _ in range(n12)]
     for kind, recs in ((0, g1), (1, g2), (2, f12)):
         try:
             ios = ctx.exp_outputs(kind, np.array(recs, dtype=np.uint32))

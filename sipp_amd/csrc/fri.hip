@@ -190,11 +190,15 @@ static int check_params(sipp_ctx* ctx, const sipp_fri_params* p, uint32_t log_n)
     for (uint32_t r = 0; r < p->n_rounds; r++) {
         if (p->arity_bits[r] < 1 || p->arity_bits[r] > 4) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: arity must be 2, 4, 8 or 16");
         sum += p->arity_bits[r];
-        // every committed layer keeps at least 2^cap_height leaves and 16 values (plonky2 asserts the former)
-        if (log_n + p->rate_bits < sum + p->cap_height || log_n + p->rate_bits - sum + p->arity_bits[r] < 4)
+        // every committed layer keeps at least 2^cap_height leaves (plonky2 asserts this) ...
+        if (log_n + p->rate_bits < sum + p->cap_height)
             return sipp_fail(ctx, SIPP_E_BADARG, "fri: reduction arities leave a layer smaller than its cap");
+        // ... and at least 16 values (a limit of this implementation's layer kernels, not of the protocol)
+        if (log_n + p->rate_bits - sum + p->arity_bits[r] < 4)
+            return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: a committed layer of fewer than 16 values is not supported");
     }
-    if (sum > log_n || log_n < 10 || log_n > 24) return sipp_fail(ctx, SIPP_E_BADARG, "fri: degree bits out of range [10, 24]");
+    if (sum > log_n) return sipp_fail(ctx, SIPP_E_BADARG, "fri: the reduction arities exceed the degree bits");
+    if (log_n < 10 || log_n > 24) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: degree bits outside the supported range [10, 24]");
     return SIPP_OK;
 }
 
