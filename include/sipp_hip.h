@@ -54,7 +54,8 @@ typedef struct {
     uint32_t cap_height;      /* 4   [0 .. 8]                                                        */
     uint32_t pow_bits;        /* 16  [0 .. 32]                                                       */
     uint32_t arity_bits;      /* 4   [1 .. 4: FriReductionStrategy::ConstantArityBits, arity 2 .. 16] */
-    uint32_t final_poly_bits; /* 5   [0 .. 12]                                                       */
+    uint32_t final_poly_bits; /* 5   [0 .. 12]; together with arity_bits it must leave every committed FRI layer at least 16
+                                 values for the trace length proved (else SIPP_E_UNSUPPORTED from the prove call)   */
     uint32_t num_queries;     /* 84  [1 .. 1024]                                                     */
     uint32_t num_challenges;  /* 2   [2]                                                             */
     uint32_t pow_rule;        /* SIPP_POW_DUPLEX (0): observe the witness, response = next challenge (plonky2 fri/prover.rs

@@ -272,6 +272,10 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     const sipp_air_t* a = s.air;
     const FriParamsDev fp = fri_params_of(cfg, s.log_n);
     const uint32_t log_n = s.log_n, log_m = log_n + cfg.rate_bits, R = (uint32_t)fp.arity_bits.size();
+    // the layer kernels (transforms, leaf hashing) work on at least 16 values: a limit of this implementation, not of FRI --
+    // refused here, before any work, instead of by a kernel wrapper in the middle of the proof
+    if (R > 0 && log_m < (R - 1) * cfg.arity_bits + 4)   // the values of the last committed layer
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "stark: arity_bits / final_poly_bits fold the FRI layers below 16 values for this trace length");
     const uint32_t log_mq = log_n + 1;                    // the quotient domain: coset 7 <w_2N> = the first 2N leaves of the LDE
     const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m, mq = (size_t)1 << log_mq;
     const size_t final_len = n >> (R * cfg.arity_bits);
