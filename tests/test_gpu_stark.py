@@ -461,12 +461,12 @@ def test_offset_a_small_multiple_of_the_base_point(ctx, kind):
 
 
 def test_config_that_folds_below_sixteen_values_is_declined_before_any_work(ios4):
-    """Found by scripts/stress_stark_cfg.py (round 2): arity 2 with final_poly_bits 0 folds the last committed FRI layers below
+    """Found by scripts/stress_stark_cfg.py (round 2): arity 2 with final_poly_bits 0 and a low cap folds the last committed FRI layers below
     the 16 values the layer kernels work on; the prove call used to fail in a transform wrapper in the middle of the proof
     (SIPP_E_BADARG "ntt: log_n out of range").  It is declined up front with SIPP_E_UNSUPPORTED now, and the ctx stays usable."""
     import sipp_amd
     cfg = sipp_amd.default_config()
-    cfg.arity_bits, cfg.final_poly_bits, cfg.rate_bits = 1, 0, 2
+    cfg.arity_bits, cfg.final_poly_bits, cfg.rate_bits, cfg.cap_height = 1, 0, 2, 0
     ctx = sipp_amd.Ctx(cfg=cfg, workspace_bytes=4 << 30)
     try:
         with pytest.raises(sipp_amd.SippError) as e:
@@ -475,5 +475,5 @@ def test_config_that_folds_below_sixteen_values_is_declined_before_any_work(ios4
     finally:
         ctx.close()
     ocfg = _oracle.default_config()
-    ocfg.arity_bits, ocfg.final_poly_bits, ocfg.rate_bits = 1, 0, 2
+    ocfg.arity_bits, ocfg.final_poly_bits, ocfg.rate_bits, ocfg.cap_height = 1, 0, 2, 0
     assert _oracle.stark_verify(_oracle.stark_prove(0, ios4[0], ocfg), ocfg) == 0     # the protocol itself allows it
