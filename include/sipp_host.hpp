@@ -121,7 +121,7 @@ struct StarkProof {
 struct StarkProofWithPublicInputs {
     // shape (the flat buffer's header)
     uint32_t kind = 0, degree_bits = 0, num_io = 0, main_cols = 0, perm_cols = 0, quotient_cols = 0, cap_height = 0,
-             pi_per_io = 0;
+             pi_per_io = 0, rate_bits = 1, arity_bits = 4;
     StarkProof proof;
     std::vector<F> public_inputs;  // the (padded) IO records, one field element per u32 word
 
@@ -129,6 +129,13 @@ struct StarkProofWithPublicInputs {
 
     static StarkProofWithPublicInputs from_flat(const uint64_t* w, size_t len) {
         if (len < 16 || w[0] != MAGIC || w[12] != len) throw Error(SIPP_E_BADARG, "from_flat: not a SIPP STARK proof buffer");
+        // the header of a buffer from anywhere is untrusted: every field that sizes an allocation or a shift is bounded first
+        // (each of the counts below is also at most `len`, or the section checks would have to refuse the buffer anyway)
+        for (int i = 1; i < 16; i++)
+            if (w[i] >> 32) throw Error(SIPP_E_BADARG, "from_flat: header field out of range");
+        if (w[2] > 30 || w[7] > 16 || w[13] < 1 || w[13] > 3 || w[14] < 1 || w[14] > 4 || w[15] != 0 || w[8] > 32 || w[9] > len ||
+            w[10] > len || w[4] > len || w[5] > len || w[6] > len)
+            throw Error(SIPP_E_BADARG, "from_flat: header field out of range");
         StarkProofWithPublicInputs p;
         p.kind = (uint32_t)w[1];
         p.degree_bits = (uint32_t)w[2];
@@ -138,11 +145,14 @@ struct StarkProofWithPublicInputs {
         p.quotient_cols = (uint32_t)w[6];
         p.cap_height = (uint32_t)w[7];
         p.pi_per_io = (uint32_t)w[11];
+        p.rate_bits = (uint32_t)w[13];
+        p.arity_bits = (uint32_t)w[14];
         const uint32_t rounds = (uint32_t)w[8], final_len = (uint32_t)w[9], nq = (uint32_t)w[10];
-        const uint32_t log_m = p.degree_bits + 1, ncap = 1u << p.cap_height;
+        const uint32_t log_m = p.degree_bits + p.rate_bits, ncap = 1u << p.cap_height;
+        if (p.cap_height > log_m) throw Error(SIPP_E_BADARG, "from_flat: cap higher than the tree");
         size_t pos = 16;
         auto need = [&](size_t cnt) {
-            if (pos + cnt > len) throw Error(SIPP_E_BUFSZ, "from_flat: truncated proof");
+            if (cnt > len - pos) throw Error(SIPP_E_BUFSZ, "from_flat: truncated proof");
         };
         auto hashes = [&](size_t cnt) {
             need(4 * cnt);
@@ -172,7 +182,11 @@ struct StarkProofWithPublicInputs {
         s.openings.permutation_zs_next = exts(p.perm_cols);
         s.openings.quotient_polys = exts(p.quotient_cols);
         FriProof& f = s.opening_proof;
-        for (uint32_t r = 0; r < rounds; r++) f.commit_phase_merkle_caps.push_back(hashes(ncap));
+        for (uint32_t r = 0; r < rounds; r++) {
+            if (p.arity_bits * (r + 1) > log_m) throw Error(SIPP_E_BADARG, "from_flat: more FRI rounds than the domain has bits");
+            const uint32_t lt = log_m - p.arity_bits * (r + 1);          // leaves of round r's tree (log2)
+            f.commit_phase_merkle_caps.push_back(hashes((size_t)1 << (lt < p.cap_height ? lt : p.cap_height)));
+        }
         f.final_poly = exts(final_len);
         need(1);
         f.pow_witness = w[pos++];
@@ -185,13 +199,15 @@ struct StarkProofWithPublicInputs {
                 qr.initial_trees_proof.evals_proofs.emplace_back(std::move(row), MerkleProof{hashes(log_m - p.cap_height)});
             }
             for (uint32_t r = 0; r < rounds; r++) {
-                const uint32_t lt = log_m - 4 * (r + 1);
+                if (p.arity_bits * (r + 1) > log_m) throw Error(SIPP_E_BADARG, "from_flat: more FRI rounds than the domain has bits");
+                const uint32_t lt = log_m - p.arity_bits * (r + 1);      // leaves of round r's tree (log2)
                 FriQueryStep st;
-                st.evals = exts(16);
+                st.evals = exts((size_t)1 << p.arity_bits);
                 st.merkle_proof.siblings = hashes(lt > p.cap_height ? lt - p.cap_height : 0);
                 qr.steps.push_back(std::move(st));
             }
         }
+        if ((uint64_t)p.num_io * p.pi_per_io > len) throw Error(SIPP_E_BUFSZ, "from_flat: truncated proof");
         p.public_inputs = bases((size_t)p.num_io * p.pi_per_io);
         if (pos != len) throw Error(SIPP_E_BUFSZ, "from_flat: trailing words");
         return p;
@@ -232,9 +248,9 @@ struct StarkProofWithPublicInputs {
             }
         }
         w.insert(w.end(), public_inputs.begin(), public_inputs.end());
-        const uint64_t hdr[13] = {MAGIC, kind, degree_bits, num_io, main_cols, perm_cols, quotient_cols, cap_height,
+        const uint64_t hdr[15] = {MAGIC, kind, degree_bits, num_io, main_cols, perm_cols, quotient_cols, cap_height,
                                   (uint64_t)f.commit_phase_merkle_caps.size(), (uint64_t)f.final_poly.size(),
-                                  (uint64_t)f.query_round_proofs.size(), pi_per_io, (uint64_t)w.size()};
+                                  (uint64_t)f.query_round_proofs.size(), pi_per_io, (uint64_t)w.size(), rate_bits, arity_bits};
         std::memcpy(w.data(), hdr, sizeof hdr);
         return w;
     }

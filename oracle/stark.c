@@ -174,7 +174,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     const uint64_t g = gl_root_of_unity(log_n);
     wbuf pf = {0, 0, 0};
     uint64_t hdr[16] = {MAGIC, (uint64_t)kind, log_n, t->num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg->cap_height,
-                        fri_rounds(cfg, log_n), 0, cfg->num_queries, (uint64_t)a->pi_per_io, 0, 0, 0, 0};
+                        fri_rounds(cfg, log_n), 0, cfg->num_queries, (uint64_t)a->pi_per_io, 0, cfg->rate_bits, cfg->arity_bits, 0};
     wb_push(&pf, hdr, 16);
     const size_t cap_n = (size_t)1 << (cfg->cap_height < log_m ? cfg->cap_height : log_m);
 
@@ -352,7 +352,8 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     if (kind < 0 || kind > 2 || log_n < 9 || log_n > 26 || num_io != ((size_t)1 << (log_n - 9))) return -101;
     const orc_air_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
-        h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len)
+        h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||
+        h[14] != cfg->arity_bits || h[15] != 0)
         return -102;
     const size_t n = (size_t)1 << log_n;
     const unsigned rounds = fri_rounds(cfg, log_n);

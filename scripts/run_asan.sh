@@ -20,3 +20,5 @@ from tests import _oracle
 _oracle.stark_prove(0, np.load("tests/golden/sipp_n4_ios.npz")["g1"]).tofile("/tmp/sipp_asan_proof.bin")
 PY
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 tests/host/test_sipp_circuit_asan layout /tmp/sipp_asan_proof.bin
+# ... and from_flat on 20,000 damaged copies of that buffer: an Error or a round trip, never undefined behaviour
+ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 tests/host/test_sipp_circuit_asan fuzz /tmp/sipp_asan_proof.bin 20000

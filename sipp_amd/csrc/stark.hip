@@ -315,7 +315,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     };
     {
         uint64_t hdr[16] = {SIPP_MAGIC, (uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.cap_height,
-                            R, (uint64_t)final_len, nq, (uint64_t)a->pi_per_io, total_words, 0, 0, 0};
+                            R, (uint64_t)final_len, nq, (uint64_t)a->pi_per_io, total_words, cfg.rate_bits, cfg.arity_bits, 0};
         push(hdr, 16);
     }
 

@@ -4,6 +4,7 @@
 //
 //   test_sipp_circuit layout                      CPU only: record layouts, from_flat / to_flat round trip of <proof.bin>
 //   test_sipp_circuit layout <proof.bin>
+//   test_sipp_circuit fuzz <proof.bin> [n]        CPU only: from_flat on n damaged copies of the buffer (Error or round trip, never UB)
 //   test_sipp_circuit prove <ios.bin> <out_prefix>   GPU: <ios.bin> = 3 x (u64 count, records) [+ (count, A), (count, B)];
 //                                                    writes <out_prefix>{0,1,2}.bin
 //
@@ -104,6 +105,49 @@ static std::vector<IO> take(const std::vector<uint64_t>& w, size_t* pos) {
     return v;
 }
 
+// from_flat on damaged buffers: a proof buffer may come from anywhere, so the parser must answer every mutation with an
+// Error (or a successful parse that round-trips), never with undefined behaviour -- run under AddressSanitizer + UBSan by
+// scripts/run_asan.sh.  Mutations: header fields set to extreme values, random words flipped, truncations, extensions.
+static int fuzz(const char* proof_path, int iterations) {
+    const std::vector<uint64_t> flat = read_u64(proof_path);
+    uint64_t x = 0x9E3779B97F4A7C15ULL;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    const uint64_t extreme[] = {0, 1, 2, 31, 32, 33, 63, 64, 255, 65535, 0x7fffffffULL, 0xffffffffULL, 0x100000000ULL, ~0ULL, ~0ULL >> 1};
+    size_t parsed = 0, refused = 0;
+    for (int it = 0; it < iterations; it++) {
+        std::vector<uint64_t> b = flat;
+        const int mode = (int)(rnd() % 5);
+        if (mode == 0) {
+            b[1 + rnd() % 15] = extreme[rnd() % (sizeof extreme / sizeof extreme[0])];
+        } else if (mode == 1) {
+            for (int k = 0; k < 1 + (int)(rnd() % 4); k++) b[1 + rnd() % 15] = extreme[rnd() % (sizeof extreme / sizeof extreme[0])];
+            b[12] = b.size();
+        } else if (mode == 2) {
+            b[rnd() % b.size()] ^= 1ULL << (rnd() % 64);
+        } else if (mode == 3) {
+            b.resize(rnd() % b.size());
+            if (b.size() > 12 && (rnd() & 1)) b[12] = b.size();
+        } else {
+            b.resize(b.size() + 1 + rnd() % 64, rnd());
+            if (rnd() & 1) b[12] = b.size();
+        }
+        try {
+            const auto p = sipp::StarkProofWithPublicInputs::from_flat(b.data(), b.size());
+            CHECK(p.to_flat() == b);     // whatever parses must re-serialise to the same words
+            parsed++;
+        } catch (const sipp::Error&) {
+            refused++;
+        }
+    }
+    printf("fuzz ok: %d mutations, %zu refused, %zu parsed and round-tripped\n", iterations, refused, parsed);
+    return 0;
+}
+
 static int prove(const char* ios_path, const char* out_prefix) {
     const std::vector<uint64_t> w = read_u64(ios_path);
     size_t pos = 0;
@@ -184,10 +228,11 @@ int main(int argc, char** argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "layout") return layout(argc >= 3 ? argv[2] : nullptr);
         if (argc == 4 && std::string(argv[1]) == "prove") return prove(argv[2], argv[3]);
+        if (argc >= 3 && std::string(argv[1]) == "fuzz") return fuzz(argv[2], argc >= 4 ? atoi(argv[3]) : 20000);
     } catch (const sipp::Error& e) {
         fprintf(stderr, "sipp::Error %d: %s\n", e.status(), e.what());
         return 1;
     }
-    fprintf(stderr, "usage: %s layout [proof.bin] | prove <ios.bin> <out_prefix>\n", argv[0]);
+    fprintf(stderr, "usage: %s layout [proof.bin] | fuzz <proof.bin> [iterations] | prove <ios.bin> <out_prefix>\n", argv[0]);
     return 2;
 }
