@@ -136,6 +136,8 @@ struct StarkProofWithPublicInputs {
         if (w[2] > 30 || w[7] > 16 || w[13] < 1 || w[13] > 3 || w[14] < 1 || w[14] > 4 || w[15] != 0 || w[8] > 32 || w[9] > len ||
             w[10] > len || w[4] > len || w[5] > len || w[6] > len)
             throw Error(SIPP_E_BADARG, "from_flat: header field out of range");
+        for (size_t i = 16; i < len; i++)   // canonical field elements only: x + p would be a second encoding of x
+            if (w[i] >= 0xFFFFFFFF00000001ULL) throw Error(SIPP_E_BADARG, "from_flat: non-canonical field element");
         StarkProofWithPublicInputs p;
         p.kind = (uint32_t)w[1];
         p.degree_bits = (uint32_t)w[2];

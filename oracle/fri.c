@@ -353,6 +353,8 @@ int orc_fri_verify_openings(const uint64_t *proof, size_t len, const uint64_t *c
     if (len < 8 || proof[0] != FRI_MAGIC || proof[1] != p->n_rounds || proof[3] != p->num_queries || proof[4] != n_oracles ||
         proof[5] != n_batches || proof[6] != len || proof[7] != log_n)
         return -100;
+    for (size_t i = 8; i < len; i++)
+        if (proof[i] >= GL_P) return -141; /* canonical field elements only: x + p would be a second encoding of x */
     size_t pos = 8;
     int bad = 0;
     gl2 **opened = (gl2 **)calloc(n_batches, sizeof(gl2 *));

@@ -345,6 +345,12 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     rbuf rb = {proof, 0, len, 0};
     const uint64_t *h = rb_take(&rb, 16);
     if (rb.bad || h[0] != MAGIC) return -100;
+    for (int i = 1; i < 16; i++)
+        if (h[i] >> 32) return -100; /* every header word is a small integer: no high bits to hide a second encoding in */
+    /* every body word is a field element in canonical form: x + p hashes and computes like x, so a non-canonical word would be
+     * a second encoding of the same proof */
+    for (size_t i = 16; i < len; i++)
+        if (proof[i] >= GL_P) return -141;
     int kind = (int)h[1];
     unsigned log_n = (unsigned)h[2];
     size_t num_io = (size_t)h[3];

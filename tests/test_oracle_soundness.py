@@ -234,3 +234,45 @@ def test_pow_rule_is_data(ios4):
         other = _oracle.default_config()
         other.pow_rule, other.pow_bits = 1 - rule, 10
         assert _oracle.stark_verify(pf, other) != 0
+
+
+def test_header_words_have_one_encoding():
+    """Found by fuzzing the verifier (round 2): header word 1 (kind) = 2^32 was read as kind 0 and the proof accepted -- a second
+    encoding of the same proof.  Every header word must be a small integer now; any set high bit is refused."""
+    import numpy as np
+    ios = np.load("tests/golden/sipp_n4_ios.npz")["g1"]
+    pf = _oracle.stark_prove(0, ios)
+    assert _oracle.stark_verify(pf) == 0
+    for i in range(1, 16):
+        for bit in (32, 40, 63):
+            bad = pf.copy()
+            bad[i] |= np.uint64(1) << np.uint64(bit)
+            assert _oracle.stark_verify(bad) != 0, (i, bit)
+
+
+def test_non_canonical_field_elements_are_refused():
+    """Found with the same fuzz run: a body word x may be replaced by x + p (when that fits 64 bits) -- the hash and all field
+    arithmetic see the same element, so the twin verified.  Zero words (c1 of base-field openings) always have the twin p.
+    Verifiers refuse every word >= p now (STARK proofs and generic opening proofs)."""
+    import numpy as np
+    P = _oracle.P
+    ios = np.load("tests/golden/sipp_n4_ios.npz")["g1"]
+    pf = _oracle.stark_prove(0, ios)
+    small = [i for i in range(16, len(pf)) if int(pf[i]) < (1 << 32) - 1]
+    assert len(small) > 10
+    for i in small[:5] + small[-3:]:
+        twin = pf.copy()
+        twin[i] = np.uint64(int(pf[i]) + P)
+        assert _oracle.stark_verify(twin) != 0, i
+    # generic opening proof
+    from tests.test_oracle_fri_generic import random_instance
+    oracles, batches = random_instance(3, 7, 1, 2)
+    fp = _oracle.fri_params(rate_bits=1, cap_height=2, pow_bits=5, num_queries=4, hiding=1, arity_bits=3, final_poly_bits=2, degree_bits=7)
+    gpf = _oracle.fri_prove_openings(oracles, batches, 7, fp, _oracle.challenger([1]))
+    args = ([o.cap for o in oracles], [o.ncols for o in oracles], [o.n_salt for o in oracles], batches, 7, fp)
+    assert _oracle.fri_verify_openings(gpf, *args, _oracle.challenger([1])) == 0
+    small = [i for i in range(8, len(gpf)) if int(gpf[i]) < (1 << 32) - 1]
+    assert small                                   # the proof-of-work witness at least
+    twin = gpf.copy()
+    twin[small[0]] = np.uint64(int(gpf[small[0]]) + P)
+    assert _oracle.fri_verify_openings(twin, *args, _oracle.challenger([1])) != 0
