@@ -113,11 +113,24 @@ static fq2 read_f2(const uint32_t *w, int ext) {
     return r;
 }
 
+/* y^2 = x^3 + 3 on E(Fp), (9 + u)(y^2 - x^3) = 3 on the twist E'(Fp2): y^2 = x^3 + 3 / (9 + u) */
+static int on_curve(pt2 p, int ext) {
+    fq2 d = fq2_sub(f2_mul(p.y, p.y, ext), f2_mul(f2_mul(p.x, p.x, ext), p.x, ext));
+    fq three = fq_from_u64(3);
+    if (ext == 1) return fq_is_zero(fq_sub(d.c0, three));
+    fq nine = fq_from_u64(9);
+    fq re = fq_sub(fq_mul(nine, d.c0), d.c1), im = fq_add(d.c0, fq_mul(nine, d.c1));
+    return fq_is_zero(fq_sub(re, three)) && fq_is_zero(im);
+}
+
 static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     layout_t L = layout_of(a);
     int ext = L.ext, cpl = a->cells_per_limb, w = 8 * ext;
     pt2 P = {read_f2(rec, ext), read_f2(rec + w, ext)};
     pt2 R = {read_f2(rec + 2 * w, ext), read_f2(rec + 3 * w, ext)};
+    /* both points on the curve: the chord / tangent rules are a group law only there (a generator that sums in another order
+     * than this chain -- the GPU's scan -- agrees with it only there), and the statement is about group elements */
+    if (!on_curve(P, ext) || !on_curve(R, ext)) return -1;
     const uint32_t *exp = rec + 4 * w;
     int bits[256];
     size_t row0 = io * 512;

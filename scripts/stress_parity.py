@@ -62,6 +62,12 @@ for seed in range(first, first + count):
     g2 = [bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 1)) + bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 2)) + words(scalar() % (1 << 256)) + [0] * 32
           for _ in range(n2)]
     f12 = [bn.f12_to_u32(rand_f12()) + bn.f12_to_u32(rand_f12()) + words(scalar()) + [0] * 96 for _ in range(n12)]
+    if rng.integers(0, 4) == 0:      # a point off its curve in one record: both sides must refuse
+        k = int(rng.integers(0, n1))
+        g1[k] = g1[k][:8] + words(fq()) + g1[k][16:]
+    if rng.integers(0, 4) == 0:
+        k = int(rng.integers(0, n2))
+        g2[k] = g2[k][:32 + 16] + words(fq()) + g2[k][32 + 24:]
     for kind, recs in ((0, g1), (1, g2), (2, f12)):
         try:
             ios = ctx.exp_outputs(kind, np.array(recs, dtype=np.uint32))

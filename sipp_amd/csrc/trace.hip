@@ -60,6 +60,25 @@ struct Fld<2> {
 __device__ __forceinline__ Fq one_of(Fq*) { return fq::one_m(); }
 __device__ __forceinline__ Fq2 one_of(Fq2*) { return Fq2{fq::one_m(), fq::zero()}; }
 
+// the affine point at `w` (x, y as 8-limb words) lies on E(Fp): y^2 = x^3 + 3, or on the twist E'(Fp2): (9 + u)(y^2 - x^3) = 3.
+// Records with a point off its curve are not provable (SIPP_E_WITNESS, as in the CPU restatement): the chord / tangent rules are
+// a group law only on ONE curve, and the accumulator scan of the generator sums in another order than the AIR's chain.
+template <int EXT>
+__device__ __forceinline__ bool point_on_curve(const uint32_t* w) {
+    using F = Fld<EXT>;
+    const auto x = F::load(w), y = F::load(w + 8 * EXT);
+    const auto d = F::sub(F::sqr(y), F::mul(F::sqr(x), x));
+    const Fq three = fq::small_m(3);
+    if constexpr (EXT == 1) {
+        return fq::is_zero(fq::sub(d, three));
+    } else {
+        const Fq nine = fq::small_m(9);
+        const Fq re = fq::sub(fq::mul(nine, d.c0), d.c1), im = fq::add(d.c0, fq::mul(nine, d.c1));
+        return fq::is_zero(fq::sub(re, three)) && fq::is_zero(im);
+    }
+}
+
+
 template <int EXT>
 struct Jac {
     typename Fld<EXT>::T x, y, z;
@@ -361,7 +380,8 @@ __global__ void __launch_bounds__(64) curve_outputs_kernel(const RowPts<EXT>* __
     const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
     if (io >= num_io) return;
     const Jac<EXT> J = rows[(size_t)io * 512 + 511].R;
-    if (jac_is_inf<EXT>(J)) {
+    const uint32_t* rec = ios + (size_t)io * ppi;
+    if (jac_is_inf<EXT>(J) || !point_on_curve<EXT>(rec) || !point_on_curve<EXT>(rec + 16 * EXT)) {
         atomicExch(err, SIPP_E_WITNESS);
         return;
     }
@@ -588,6 +608,7 @@ __global__ void check_outputs_kernel(const uint32_t* __restrict__ ios, uint32_t 
     } else {
         const int words = kind == 0 ? 16 : 32;   // (x, y) or (x.c0, x.c1, y.c0, y.c1): the Rx | Ry cells in order
         const uint32_t* outw = rec + ppi - words;
+        bad |= kind == 0 ? !(point_on_curve<1>(rec) && point_on_curve<1>(rec + 16)) : !(point_on_curve<2>(rec) && point_on_curve<2>(rec + 32));
         for (int wd = 0; wd < words; wd++) {
             bad |= tr[(size_t)(col_state + 2 * wd) * n + row] != (outw[wd] & 0xffffu);
             bad |= tr[(size_t)(col_state + 2 * wd + 1) * n + row] != (outw[wd] >> 16);

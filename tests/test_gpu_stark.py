@@ -477,3 +477,28 @@ def test_config_that_folds_below_sixteen_values_is_declined_before_any_work(ios4
     ocfg = _oracle.default_config()
     ocfg.arity_bits, ocfg.final_poly_bits, ocfg.rate_bits, ocfg.cap_height = 1, 0, 2, 0
     assert _oracle.stark_verify(_oracle.stark_prove(0, ios4[0], ocfg), ocfg) == 0     # the protocol itself allows it
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_points_off_the_curve_are_refused_by_both_sides(ctx, kind):
+    """The chord / tangent rules are a group law only on one curve; the GPU generator sums the selected powers in another order
+    than the AIR's sequential chain, so for a base point and an offset on DIFFERENT curves y^2 = x^3 + b the two would disagree.
+    Both sides refuse any record whose x or offset is not on E(Fp) / E'(Fp2) (SIPP_E_WITNESS / a failed trace build)."""
+    import sipp_amd
+    from oracle.py import bn254 as bn
+    if kind == 0:
+        good, off, pad = bn.g1_to_u32(bn.g1_mul(bn.G1, 77)), bn.fq_to_u32(5) + bn.fq_to_u32(7), 16
+    else:
+        good, pad = bn.g2_to_u32(bn.g2_mul(bn.G2, 77)), 32
+        off = bn.fq_to_u32(5) + bn.fq_to_u32(1) + bn.fq_to_u32(7) + bn.fq_to_u32(2)
+    e = [(0b1011 >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    for rec in (off + good + e + [0] * pad, good + off + e + [0] * pad):
+        arr = np.array([rec], dtype=np.uint32)
+        with pytest.raises(RuntimeError):
+            _oracle.stark_prove(kind, arr)
+        with pytest.raises(sipp_amd.SippError) as err:
+            ctx.exp_outputs(kind, arr)
+        assert err.value.code == -8
+        with pytest.raises(sipp_amd.SippError) as err:
+            ctx.prove(kind, arr)
+        assert err.value.code == -8
