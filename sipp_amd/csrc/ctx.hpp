@@ -4,6 +4,7 @@
 // reserved once at sipp_ctx_create (no hipMalloc in the steady state, SURVEY.md section 8b
 // "threading" row); twiddle / power tables are cached per (kind, size) for the ctx lifetime.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -160,6 +161,13 @@ static inline T* arena_alloc_t(sipp_ctx* ctx, size_t count) {
 }
 
 // ---- profiling-aware launch bracket ------------------------------------------
+// measurement knob from the environment, read once (a function-local `static const int v = sipp_env_int(...)` is
+// initialised thread-safely: the three host threads of an instance reach these at the same time)
+inline int sipp_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 struct ProfScope {
     sipp_ctx* ctx;
     const char* name;

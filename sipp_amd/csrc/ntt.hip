@@ -554,11 +554,7 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* __res
 // elements; the pass kernel 5-10 % faster), but they execute fewer instructions, and the instance is bound by instruction issue:
 // 66.5-67.1 ms per n = 128 instance against 67.8-67.9 ms (25-step runs, same box, alternating).
 int ntt_r16_mask() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SIPP_NTT_RADIX16");
-        v = e ? atoi(e) : 15;
-    }
+    static const int v = sipp_env_int("SIPP_NTT_RADIX16", 15);
     return v;
 }
 
@@ -567,13 +563,10 @@ int ntt_r16_mask() {
 // lane) twice as slow (n = 4096: 1697 vs 1464 ms per instance), with 512 threads (two 72-KB blocks per CU) 315 + 143 ms of
 // transform time against 285 + 128 ms.  The light strided passes (4-5 stages) already run at 2.5-3 TB/s; 2^12 stays.
 int ntt_ltile() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SIPP_NTT_LTILE");
-        v = e ? atoi(e) : 12;
-        if (v < 8) v = 8;
-        if (v > 13) v = 13;
-    }
+    static const int v = [] {
+        const int t = sipp_env_int("SIPP_NTT_LTILE", 12);
+        return t < 8 ? 8 : t > 13 ? 13 : t;
+    }();
     return v;
 }
 
@@ -778,9 +771,8 @@ uint64_t* col_pw_table(sipp_ctx* ctx, uint32_t log_n, uint32_t rate_bits) {
 }
 
 bool fused_lde_enabled() {
-    static int v = -1;
-    if (v < 0) v = getenv("SIPP_NTT_UNFUSED") ? 0 : 1;
-    return v == 1;
+    static const bool v = getenv("SIPP_NTT_UNFUSED") == nullptr;
+    return v;
 }
 
 int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_coeffs, uint64_t* d_lde, size_t lde_stride,
@@ -803,11 +795,7 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
         SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // threads per block (SIPP_LDE_COL_THREADS overrides): big blocks hide LDS latency when the kernel runs alone, small ones
     // are placed sooner beside the other proofs' resident hash waves
-    static int thr_env = -1;
-    if (thr_env < 0) {
-        const char* e = getenv("SIPP_LDE_COL_THREADS");
-        thr_env = e ? atoi(e) : 0;
-    }
+    static const int thr_env = sipp_env_int("SIPP_LDE_COL_THREADS", 0);
     // measured at n = 128 (3 proofs concurrent): 256 threads 71.2 ms, 512 72.2, 1024 75.1, 128 72.1 per instance
     const unsigned threads = thr_env ? (unsigned)thr_env : n >= 16384 ? 512 : 256;
     ProfScope ps(ctx, "lde_column");
@@ -855,11 +843,7 @@ int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs
         if (tiles > 0x7fffffffull) return SIPP_E_UNSUPPORTED;
         SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         ProfScope ps(ctx, "lde_mid");
-        static int mid_thr = -1;
-        if (mid_thr < 0) {
-            const char* e = getenv("SIPP_LDE_MID_THREADS");
-            mid_thr = e ? atoi(e) : 256;
-        }
+        static const int mid_thr = sipp_env_int("SIPP_LDE_MID_THREADS", 256);
         hipLaunchKernelGGL(lde_mid_kernel, dim3((unsigned)tiles), dim3((unsigned)mid_thr), shmem, ctx->stream, m);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }

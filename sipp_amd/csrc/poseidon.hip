@@ -353,12 +353,11 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
 }
 
 uint64_t quad_threshold() {
-    static long v = -1;
-    if (v < 0) {
+    static const uint64_t v = [] {
         const char* e = getenv("SIPP_QUAD_MAX_LEAVES");
-        v = e ? atol(e) : 65536;
-    }
-    return (uint64_t)v;
+        return e ? (uint64_t)atol(e) : (uint64_t)65536;
+    }();
+    return v;
 }
 
 }  // namespace
@@ -447,8 +446,7 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // 12.0 ms: 37 us per sequential permutation instead of 23 us) but FASTER where it matters, beside the other two proofs: the
     // instance is bound by total instruction issue (68.5 ms against 70.5-70.8 ms single, 61.1 against 63.6-63.9 ms with three
     // instances in flight).  SIPP_THIN_LANES=4 restores the four-lane kernel.
-    static int thin_lanes = -1;
-    if (thin_lanes < 0) thin_lanes = getenv("SIPP_THIN_LANES") ? atoi(getenv("SIPP_THIN_LANES")) : 2;
+    static const int thin_lanes = sipp_env_int("SIPP_THIN_LANES", 2);
     if (thin_lanes == 2 && ncols > 4 && n >= 32 && n <= quad_threshold()) {
         unsigned grid = (unsigned)((2 * n + 255) / 256);
         hipLaunchKernelGGL(poseidon_leaves_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
@@ -472,9 +470,8 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
 
 // SIPP_MERKLE_PER_LEVEL=1: the one-launch-per-level form (kept for A/B measurements)
 static bool merkle_per_level() {
-    static int v = -1;
-    if (v < 0) v = getenv("SIPP_MERKLE_PER_LEVEL") ? 1 : 0;
-    return v == 1;
+    static const bool v = getenv("SIPP_MERKLE_PER_LEVEL") != nullptr;
+    return v;
 }
 
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height) {

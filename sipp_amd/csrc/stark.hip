@@ -259,8 +259,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     } gate_guard{ctx};
     // where a gated proof waits: before its first launch (0, the default) or after its own trace fill, in front of its first
     // fat kernel (SIPP_GATE_POINT=1: measured 63.1 against 61.9-62.6 ms per n = 128 instance -- G1's early chains disturb G2's)
-    static int gate_point = -1;
-    if (gate_point < 0) gate_point = getenv("SIPP_GATE_POINT") ? atoi(getenv("SIPP_GATE_POINT")) : 0;
+    static const int gate_point = [] { const char* e = getenv("SIPP_GATE_POINT"); return e ? atoi(e) : 0; }();   // three host threads get here at once
     if (ctx->gate_wait && gate_point == 0) {
         ctx->gate_wait->wait();
         ctx->gate_wait = nullptr;
@@ -872,12 +871,11 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     // 70.2 ms per instance; n = 1024: neutral; releasing after G2's trace COMMIT instead: 75-81 ms; Fq12 first: 71-72 ms).
     // SIPP_INSTANCE_GATE overrides which kinds wait (bit k = sipp_kind k; 0 = none).
     const int first = SIPP_G2_EXP;
-    static int gate_mask = -1;
-    if (gate_mask < 0) {
+    // round 2 (fused LDE kernels): only G1 waits -- 69.0-69.6 ms per n = 128 instance against 70.0-70.6 with Fq12 gated too
+    static const int gate_mask = [] {
         const char* e = getenv("SIPP_INSTANCE_GATE");
-        // round 2 (fused LDE kernels): only G1 waits -- 69.0-69.6 ms per n = 128 instance against 70.0-70.6 with Fq12 gated too
-        gate_mask = (e ? atoi(e) : (1 << SIPP_G1_EXP)) & ~(1 << first);
-    }
+        return (e ? atoi(e) : (1 << SIPP_G1_EXP)) & ~(1 << SIPP_G2_EXP);
+    }();   // several queue slots (sipp_instances_prove) get here at once
     const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     sipp_gate gate;
     int started[3] = {0, 0, 0}, rc = SIPP_OK;
