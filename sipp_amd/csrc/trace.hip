@@ -385,6 +385,8 @@ __global__ void __launch_bounds__(64) curve_outputs_kernel(const RowPts<EXT>* __
         atomicExch(err, SIPP_E_WITNESS);
         return;
     }
+    // z^(p-2): the binary extended Euclid (fq::inv_gcd) was tried here -- with 64 different values per wave its lanes diverge
+    // and the kernel takes 0.25-0.26 ms instead of 0.23 ms (round 2)
     const auto zi = F::inv(J.z), zi2 = F::sqr(zi);
     const auto x = F::mul(J.x, zi2), y = F::mul(J.y, F::mul(zi2, zi));
     uint32_t* outw = ios + (size_t)io * ppi + ppi - 16 * EXT;
