@@ -144,14 +144,23 @@ int sipp_fri_prove_core(sipp_ctx* ctx, const FriOracleDev* ors, int n_oracles, u
     if (st_words > ctx->h_pinned_words) return sipp_fail(ctx, SIPP_E_NOMEM, "query staging exceeds the pinned buffer");
     uint64_t* d_st = arena_alloc_t<uint64_t>(ctx, st_words);
     if (!d_st) return SIPP_E_NOMEM;
-    for (int o = 0; o < n_oracles; o++) {
-        SIPP_TRY(sipp_k_gather_rows(ctx, ors[o].lde, ors[o].stride, ors[o].ncols, d_idx, nq, d_st + off_rows[o]));
-        SIPP_TRY(sipp_k_gather_siblings(ctx, ors[o].tree, log_m, nsib0, 0, d_idx, nq, d_st + off_sib[o]));
-    }
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t ab = p.arity_bits[r];
-        SIPP_TRY(sipp_k_gather_fri_leaf(ctx, r_vals[r], (size_t)1 << r_loglen[r], rshift[r], ab, d_idx, nq, d_st + off_leaf[r]));
-        SIPP_TRY(sipp_k_gather_siblings(ctx, r_tree[r], r_loglen[r] - ab, rsib[r], rshift[r], d_idx, nq, d_st + off_rsib[r]));
+    // one launch for all of them (sipp_k_gather_tasks): the task table goes up with one small copy (`tasks` stays alive until
+    // the stream has been synchronised for the read-back below)
+    std::vector<QueryGatherTask> tasks;
+    {
+        for (int o = 0; o < n_oracles; o++) {
+            tasks.push_back(QueryGatherTask{ors[o].lde, d_st + off_rows[o], (uint64_t)ors[o].stride, 0, ors[o].ncols, 0, 0});
+            if (nsib0) tasks.push_back(QueryGatherTask{ors[o].tree, d_st + off_sib[o], 0, 1, log_m, nsib0, 0});
+        }
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t ab = p.arity_bits[r];
+            tasks.push_back(QueryGatherTask{r_vals[r], d_st + off_leaf[r], (uint64_t)1 << r_loglen[r], 2, rshift[r], ab, 0});
+            if (rsib[r]) tasks.push_back(QueryGatherTask{r_tree[r], d_st + off_rsib[r], 0, 1, r_loglen[r] - ab, rsib[r], rshift[r]});
+        }
+        QueryGatherTask* d_tasks = arena_alloc_t<QueryGatherTask>(ctx, tasks.size());
+        if (!d_tasks) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(QueryGatherTask), hipMemcpyHostToDevice, ctx->stream));
+        SIPP_TRY(sipp_k_gather_tasks(ctx, d_tasks, (uint32_t)tasks.size(), d_idx, nq));
     }
     uint64_t* hst = ctx->h_pinned;
     SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hst, d_st, st_words * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -501,6 +501,24 @@ __global__ void pow_table_kernel(E2 base, size_t n, uint64_t* __restrict__ tab) 
     tab[n + k] = r.c1;
 }
 
+// the four tables of an opening (zeta, g zeta and their inverses) in ONE launch: blockIdx.y selects the base
+struct Pow4Args {
+    E2 base[4];
+    uint64_t* tab[4];
+    size_t n;
+};
+__global__ void pow_table4_kernel(Pow4Args a) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    const int b = blockIdx.y;
+    // select instead of a dynamically indexed kernel argument (which would be copied to scratch memory)
+    const E2 base = b == 0 ? a.base[0] : b == 1 ? a.base[1] : b == 2 ? a.base[2] : a.base[3];
+    uint64_t* tab = b == 0 ? a.tab[0] : b == 1 ? a.tab[1] : b == 2 ? a.tab[2] : a.tab[3];
+    const E2 r = gl::pow(base, (uint64_t)k);
+    tab[k] = r.c0;
+    tab[a.n + k] = r.c1;
+}
+
 // one block per OCOLS columns: sum_k c[k] * t0[k] and sum_k c[k] * t1[k]; out[col] = (e0.c0, e0.c1, e1.c0, e1.c1).
 // The power tables are read once per block and k, i.e. once per OCOLS coefficients; the products are summed lazily in
 // 160 bits (gl::Acc160) and reduced once per lane.
@@ -837,9 +855,40 @@ __global__ void gather_fri_leaf_kernel(const uint64_t* __restrict__ vals, size_t
     out[((size_t)q << (ab + 1)) + t] = vals[(size_t)(t & 1) * len + (leaf << ab) + (t >> 1)];
 }
 
+// every gather of a query phase in ONE launch: block (q, task) copies what one of the three kernels above copies for query q
+// (a dozen launches of a few microseconds each were 0.2 ms of launch gaps in every proof's FRI tail)
+__global__ void __launch_bounds__(256) gather_tasks_kernel(const QueryGatherTask* __restrict__ tasks, const uint32_t* __restrict__ idx) {
+    const QueryGatherTask t = tasks[blockIdx.y];
+    const uint32_t q = blockIdx.x;
+    const size_t x = idx[q];
+    if (t.type == 0) {                       // a row of an oracle: ncols = b, column stride = a
+        for (uint32_t c = threadIdx.x; c < t.b; c += blockDim.x) t.out[(size_t)q * t.b + c] = t.src[(size_t)c * t.a + x];
+    } else if (t.type == 1) {                // Merkle siblings: log_leaves = b, nsib = c, shift = d
+        for (uint32_t e = threadIdx.x; e < 4 * t.c; e += blockDim.x) {
+            const uint32_t l = e >> 2, w = e & 3;
+            size_t off = 0;
+            for (uint32_t k = 0; k < l; k++) off += (size_t)1 << (t.b - k);
+            const size_t node = ((x >> t.d) >> l) ^ 1;
+            t.out[((size_t)q * t.c + l) * 4 + w] = t.src[(off + node) * 4 + w];
+        }
+    } else {                                 // a FRI leaf: len = a, shift = b, arity bits = c
+        const size_t leaf = x >> t.b;
+        for (uint32_t e = threadIdx.x; e < (2u << t.c); e += blockDim.x)
+            t.out[((size_t)q << (t.c + 1)) + e] = t.src[(size_t)(e & 1) * t.a + (leaf << t.c) + (e >> 1)];
+    }
+}
+
 }  // namespace
 
 // ---- host wrappers -----------------------------------------------------------------------------------
+int sipp_k_gather_tasks(sipp_ctx* ctx, const QueryGatherTask* d_tasks, uint32_t n_tasks, const uint32_t* d_idx, uint32_t nq) {
+    if (!n_tasks || !nq) return SIPP_OK;
+    ProfScope ps(ctx, "query_gather");
+    hipLaunchKernelGGL(gather_tasks_kernel, dim3(nq, n_tasks), dim3(256), 0, ctx->stream, d_tasks, d_idx);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
 int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
                      const uint64_t gamma[2], uint64_t* d_zv) {
     const size_t n = (size_t)1 << log_n;
@@ -1019,6 +1068,19 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
 int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab) {
     ProfScope ps(ctx, "pow_table");
     hipLaunchKernelGGL(pow_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, base, n, d_tab);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+int sipp_k_pow_table4(sipp_ctx* ctx, const gl::E2 base[4], size_t n, uint64_t* const d_tab[4]) {
+    ProfScope ps(ctx, "pow_table");
+    Pow4Args a;
+    for (int i = 0; i < 4; i++) {
+        a.base[i] = base[i];
+        a.tab[i] = d_tab[i];
+    }
+    a.n = n;
+    hipLaunchKernelGGL(pow_table4_kernel, dim3((unsigned)((n + 255) / 256), 4), dim3(256), 0, ctx->stream, a);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }

@@ -15,6 +15,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
                     size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
                     const uint64_t gamma[2], uint64_t* d_out);
 int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab);
+int sipp_k_pow_table4(sipp_ctx* ctx, const gl::E2 base[4], size_t n, uint64_t* const d_tab[4]);
 int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_t n, const uint64_t* d_t0,
                     const uint64_t* d_t1, uint64_t* d_out);
 int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,
@@ -23,6 +24,15 @@ int sipp_k_fri_batch_quotient(sipp_ctx* ctx, const uint64_t* const* d_cols, int 
                               const uint64_t* d_zp, const uint64_t* d_zip, gl::E2 shift, bool first, uint64_t* d_acc);
 int sipp_k_fri_mulx(sipp_ctx* ctx, const uint64_t* d_acc, size_t n, uint64_t* d_final);
 int sipp_k_fri_fold(sipp_ctx* ctx, const uint64_t* d_in, size_t len_in, uint32_t arity_bits, gl::E2 beta, uint64_t* d_out);
+// one entry of the fused query-phase gather (sipp_k_gather_tasks): type 0 = oracle row (a = column stride, b = columns),
+// 1 = Merkle siblings (b = log2 leaves, c = siblings, d = index shift), 2 = FRI leaf (a = values per component, b = shift, c = arity bits)
+struct QueryGatherTask {
+    const uint64_t* src;
+    uint64_t* out;
+    uint64_t a;
+    uint32_t type, b, c, d;
+};
+int sipp_k_gather_tasks(sipp_ctx* ctx, const QueryGatherTask* d_tasks, uint32_t n_tasks, const uint32_t* d_idx, uint32_t nq);
 int sipp_k_gather_rows(sipp_ctx* ctx, const uint64_t* d_lde, size_t m, uint32_t ncols, const uint32_t* d_idx, uint32_t nq,
                        uint64_t* d_out);
 int sipp_k_gather_siblings(sipp_ctx* ctx, const uint64_t* d_tree, uint32_t log_leaves, uint32_t nsib, uint32_t shift,

@@ -454,10 +454,11 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     uint64_t* d_zip[2] = {arena_alloc_t<uint64_t>(ctx, 2 * n), arena_alloc_t<uint64_t>(ctx, 2 * n)};
     uint64_t* d_open = arena_alloc_t<uint64_t>(ctx, (size_t)(W + P + Q) * 4);
     if (!d_zp[0] || !d_zp[1] || !d_zip[0] || !d_zip[1] || !d_open) return SIPP_E_NOMEM;
-    SIPP_TRY(sipp_k_pow_table(ctx, zeta, n, d_zp[0]));
-    SIPP_TRY(sipp_k_pow_table(ctx, gzeta, n, d_zp[1]));
-    SIPP_TRY(sipp_k_pow_table(ctx, gl::inv(zeta), n, d_zip[0]));
-    SIPP_TRY(sipp_k_pow_table(ctx, gl::inv(gzeta), n, d_zip[1]));
+    {
+        const gl::E2 bases[4] = {zeta, gzeta, gl::inv(zeta), gl::inv(gzeta)};
+        uint64_t* const tabs[4] = {d_zp[0], d_zp[1], d_zip[0], d_zip[1]};
+        SIPP_TRY(sipp_k_pow_table4(ctx, bases, n, tabs));
+    }
     SIPP_TRY(sipp_k_openings(ctx, T.coeffs, (size_t)W, n, d_zp[0], d_zp[1], d_open));
     SIPP_TRY(sipp_k_openings(ctx, Z.coeffs, (size_t)P, n, d_zp[0], d_zp[1], d_open + (size_t)W * 4));
     SIPP_TRY(sipp_k_openings(ctx, Qo.coeffs, (size_t)Q, n, d_zp[0], nullptr, d_open + (size_t)(W + P) * 4));
