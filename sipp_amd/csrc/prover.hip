@@ -522,19 +522,17 @@ __global__ void pow_table4_kernel(Pow4Args a) {
 // one block per OCOLS columns: sum_k c[k] * t0[k] and sum_k c[k] * t1[k]; out[col] = (e0.c0, e0.c1, e1.c0, e1.c1).
 // The power tables are read once per block and k, i.e. once per OCOLS coefficients; the products are summed lazily in
 // 160 bits (gl::Acc160) and reduced once per lane.
-constexpr int OCOLS = 1;  // more columns per block re-use the tables but leave too few waves in flight (measured)
-__global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restrict__ coeffs, size_t n, uint32_t ncols,
-                                                      const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
-                                                      uint64_t* __restrict__ out) {
+// (more columns per block would re-use the tables but leave too few waves in flight: measured)
+__device__ __forceinline__ void openings_column(const uint64_t* __restrict__ col, size_t n, const uint64_t* __restrict__ t0,
+                                                const uint64_t* __restrict__ t1, uint64_t* __restrict__ out4) {
     __shared__ uint64_t s[4][256];
-    const uint32_t col0 = blockIdx.x * OCOLS;
-    gl::Acc160 acc[OCOLS][4];
+    gl::Acc160 acc[4];
     // OB coefficient indices per trip: all their loads are issued before the first product (the rolled loop waited for five
     // loads per 32 products; n / 256 trips of load latency were the kernel's run time)
     constexpr int OB = 4;
     size_t k = threadIdx.x;
     for (; k + (OB - 1) * 256 < n; k += OB * 256) {
-        uint64_t p0[OB], p1[OB], q0[OB], q1[OB], v[OCOLS][OB];
+        uint64_t p0[OB], p1[OB], q0[OB], q1[OB], v[OB];
 #pragma unroll
         for (int b = 0; b < OB; b++) {
             const size_t kb = k + (size_t)b * 256;
@@ -542,50 +540,66 @@ __global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restric
             p1[b] = t0[n + kb];
             q0[b] = t1 ? t1[kb] : 0;
             q1[b] = t1 ? t1[n + kb] : 0;
-#pragma unroll
-            for (int u = 0; u < OCOLS; u++) v[u][b] = coeffs[(size_t)min(col0 + u, ncols - 1) * n + kb];
+            v[b] = col[kb];
         }
 #pragma unroll
         for (int b = 0; b < OB; b++) {
-#pragma unroll
-            for (int u = 0; u < OCOLS; u++) {
-                acc[u][0].mac(v[u][b], p0[b]);
-                acc[u][1].mac(v[u][b], p1[b]);
-                if (t1) {
-                    acc[u][2].mac(v[u][b], q0[b]);
-                    acc[u][3].mac(v[u][b], q1[b]);
-                }
+            acc[0].mac(v[b], p0[b]);
+            acc[1].mac(v[b], p1[b]);
+            if (t1) {
+                acc[2].mac(v[b], q0[b]);
+                acc[3].mac(v[b], q1[b]);
             }
         }
     }
     for (; k < n; k += 256) {
-        const uint64_t p0 = t0[k], p1 = t0[n + k];
-        const uint64_t q0 = t1 ? t1[k] : 0, q1 = t1 ? t1[n + k] : 0;
-#pragma unroll
-        for (int u = 0; u < OCOLS; u++) {
-            const uint32_t col = min(col0 + u, ncols - 1);
-            const uint64_t v = coeffs[(size_t)col * n + k];
-            acc[u][0].mac(v, p0);
-            acc[u][1].mac(v, p1);
-            if (t1) {
-                acc[u][2].mac(v, q0);
-                acc[u][3].mac(v, q1);
-            }
+        const uint64_t v = col[k];
+        acc[0].mac(v, t0[k]);
+        acc[1].mac(v, t0[n + k]);
+        if (t1) {
+            acc[2].mac(v, t1[k]);
+            acc[3].mac(v, t1[n + k]);
         }
     }
-    for (int u = 0; u < OCOLS; u++) {
-        if (col0 + u >= ncols) break;   // block-uniform
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::canon(acc[u][q].reduce());
+    for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::canon(acc[q].reduce());
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::add(s[q][threadIdx.x], s[q][threadIdx.x + off]);
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off)
-                for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::add(s[q][threadIdx.x], s[q][threadIdx.x + off]);
-            __syncthreads();
-        }
-        if (threadIdx.x < 4) out[(size_t)(col0 + u) * 4 + threadIdx.x] = s[threadIdx.x][0];
     }
+    if (threadIdx.x < 4) out4[threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restrict__ coeffs, size_t n, uint32_t ncols,
+                                                      const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
+                                                      uint64_t* __restrict__ out) {
+    openings_column(coeffs + (size_t)blockIdx.x * n, n, t0, t1, out + (size_t)blockIdx.x * 4);
+}
+
+// the three oracles of a STARK (trace, Z, quotient chunks) in ONE launch: block b opens column b of their concatenation; the
+// quotient chunks are opened at the first point only
+struct Open3Args {
+    const uint64_t* coeffs[3];
+    uint32_t ncols[3];
+    size_t n;
+    const uint64_t *t0, *t1;
+    uint64_t* out;
+};
+__global__ void __launch_bounds__(256) openings3_kernel(Open3Args a) {
+    const uint32_t b = blockIdx.x;
+    const uint64_t* col;
+    const uint64_t* t1 = a.t1;
+    if (b < a.ncols[0]) {
+        col = a.coeffs[0] + (size_t)b * a.n;
+    } else if (b < a.ncols[0] + a.ncols[1]) {
+        col = a.coeffs[1] + (size_t)(b - a.ncols[0]) * a.n;
+    } else {
+        col = a.coeffs[2] + (size_t)(b - a.ncols[0] - a.ncols[1]) * a.n;
+        t1 = nullptr;
+    }
+    openings_column(col, a.n, a.t0, t1, a.out + (size_t)b * 4);
 }
 
 // partial[slice][{0,1}][{c0,c1}][k]: acc over the columns of this slice of alpha^c * coef_c[k];
@@ -1089,8 +1103,24 @@ int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_
                     const uint64_t* d_t1, uint64_t* d_out) {
     if (!ncols) return SIPP_OK;
     ProfScope ps(ctx, "openings");
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)((ncols + OCOLS - 1) / OCOLS)), dim3(256), 0, ctx->stream, d_coeffs, n,
-                       (uint32_t)ncols, d_t0, d_t1, d_out);
+    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, d_coeffs, n, (uint32_t)ncols, d_t0, d_t1,
+                       d_out);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uint32_t ncols[3], size_t n, const uint64_t* d_t0,
+                     const uint64_t* d_t1, uint64_t* d_out) {
+    const unsigned total = ncols[0] + ncols[1] + ncols[2];
+    if (!total) return SIPP_OK;
+    ProfScope ps(ctx, "openings");
+    Open3Args a;
+    for (int i = 0; i < 3; i++) {
+        a.coeffs[i] = d_coeffs[i];
+        a.ncols[i] = ncols[i];
+    }
+    a.n = n; a.t0 = d_t0; a.t1 = d_t1; a.out = d_out;
+    hipLaunchKernelGGL(openings3_kernel, dim3(total), dim3(256), 0, ctx->stream, a);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }

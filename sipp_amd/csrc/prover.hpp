@@ -18,6 +18,8 @@ int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab);
 int sipp_k_pow_table4(sipp_ctx* ctx, const gl::E2 base[4], size_t n, uint64_t* const d_tab[4]);
 int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_t n, const uint64_t* d_t0,
                     const uint64_t* d_t1, uint64_t* d_out);
+int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uint32_t ncols[3], size_t n, const uint64_t* d_t0,
+                     const uint64_t* d_t1, uint64_t* d_out);
 int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,
                      int n1, gl::E2 shift1, const uint64_t* d_zp[2], const uint64_t* d_zip[2], uint64_t* d_final);
 int sipp_k_fri_batch_quotient(sipp_ctx* ctx, const uint64_t* const* d_cols, int total, size_t n, const uint32_t* d_apow3,

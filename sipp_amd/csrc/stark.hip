@@ -459,9 +459,11 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         uint64_t* const tabs[4] = {d_zp[0], d_zp[1], d_zip[0], d_zip[1]};
         SIPP_TRY(sipp_k_pow_table4(ctx, bases, n, tabs));
     }
-    SIPP_TRY(sipp_k_openings(ctx, T.coeffs, (size_t)W, n, d_zp[0], d_zp[1], d_open));
-    SIPP_TRY(sipp_k_openings(ctx, Z.coeffs, (size_t)P, n, d_zp[0], d_zp[1], d_open + (size_t)W * 4));
-    SIPP_TRY(sipp_k_openings(ctx, Qo.coeffs, (size_t)Q, n, d_zp[0], nullptr, d_open + (size_t)(W + P) * 4));
+    {
+        const uint64_t* const cf[3] = {T.coeffs, Z.coeffs, Qo.coeffs};
+        const uint32_t nc3[3] = {(uint32_t)W, (uint32_t)P, (uint32_t)Q};
+        SIPP_TRY(sipp_k_openings3(ctx, cf, nc3, n, d_zp[0], d_zp[1], d_open));
+    }
     std::vector<uint64_t> hop((size_t)(W + P + Q) * 4);
     SIPP_CHECK_HIP(ctx, hipMemcpyAsync(hop.data(), d_open, hop.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
