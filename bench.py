@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=128, help="pairings per SIPP instance (fixture must exist)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=5,
                     help="instances proved concurrently for the secondary `pipelined` figure (1 = skip)")
     args = ap.parse_args()
 
