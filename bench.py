@@ -100,9 +100,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=128, help="pairings per SIPP instance (fixture must exist)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=5,
-                    help="instances proved concurrently for the secondary `pipelined` figure (1 = skip)")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="instances proved concurrently for the secondary `pipelined` figure (1 = skip); default 5 on one "
+                         "rank, 1 (skipped) when launched with more: 8 ranks x 5 slots x 3 worker threads would put 120 host "
+                         "threads on one node for a secondary figure")
     args = ap.parse_args()
+    if args.inflight is None:
+        args.inflight = 5 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 1
 
     import torch
     import torch.distributed as dist
@@ -348,11 +352,17 @@ def main():
             mine = sipp_amd.shard_ios(load_ios(n_s), world, rank)
             si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios)
             k_s = 2
+            own = []
             dts, _ = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
-                                           device=red_device)
+                                           device=red_device, local_out=own)
             si.close()
+            lo, hi = dist_util.min_max_over_ranks(own[0], device=red_device)
             io_sharded["n=%d" % n_s] = {"ms_per_instance": 1e3 * dts / k_s, "value": n_s * k_s / dts, "unit": "pairings/s",
-                                        "scaling": "strong", "ranks": world, "steps": k_s,
+                                        # one rank proves the whole instance on one GPU: the figure the sharded runs are divided into
+                                        "scaling": "strong" if world > 1 else "baseline (whole instance on one GPU)",
+                                        "ranks": world, "steps": k_s,
+                                        "rank_ms_per_instance_min_max": [1e3 * lo / k_s, 1e3 * hi / k_s],
+                                        "host_threads_per_rank": 4,
                                         "records_of_rank0": [int(a.shape[0]) for a in mine]}
     if rank == 0:
         out["io_sharded"] = io_sharded

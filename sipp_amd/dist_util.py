@@ -23,6 +23,17 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def min_max_over_ranks(value, device="cpu"):
+    """(min, max) of a python float over all ranks: the spread of the ranks' own step times"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value), float(value)
+    t = torch.tensor([value, -value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return -float(t[1].item()), float(t[0].item())
+
+
 def whole_job_rate(units_per_rank, world, max_step_seconds):
     """aggregate throughput: every rank processed `units_per_rank` units in (at most) max_step_seconds"""
     return world * units_per_rank / max_step_seconds
@@ -51,9 +62,10 @@ def barrier(sync=None):
         sync()
 
 
-def timed_steps(step, steps, warmup, sync=None, device="cpu", before_timing=None):
+def timed_steps(step, steps, warmup, sync=None, device="cpu", before_timing=None, local_out=None):
     """bench.py's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on
-    both sides; returns (max-over-ranks elapsed seconds, result of the last step)."""
+    both sides; returns (max-over-ranks elapsed seconds, result of the last step).  `local_out` (a list) receives this rank's
+    own time for its `steps` steps WITHOUT the closing barrier (the spread of the ranks, reported beside the contract's figure)."""
     import time
     last = None
     for _ in range(warmup):
@@ -64,6 +76,10 @@ def timed_steps(step, steps, warmup, sync=None, device="cpu", before_timing=None
     t0 = time.perf_counter()
     for _ in range(steps):
         last = step()
+    if local_out is not None:
+        if sync is not None:
+            sync()
+        local_out.append(time.perf_counter() - t0)
     barrier(sync)
     elapsed = time.perf_counter() - t0
     return max_over_ranks(elapsed, device=device), last

@@ -59,6 +59,42 @@ open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rank)
 '''
 
 
+WORKER8 = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sipp_amd import dist_util as du
+import sipp_amd
+rank, local_rank, world = du.rank_world()
+assert world == 8
+dist.init_process_group("gloo")
+# the obligation lists of BASELINE configs[3] / configs[4] cut across 8 ranks: n = 1024 -> 1023 / 1023 / 20, n = 4096 -> 4095 / 4095 / 24
+for n, lists in ((1024, (1023, 1023, 20)), (4096, (4095, 4095, 24))):
+    counts = []
+    for n_io in lists:
+        first, count = sipp_amd.io_shard(n_io, world, rank)
+        cover = torch.zeros(n_io, dtype=torch.int64); cover[first: first + count] = 1
+        dist.all_reduce(cover)
+        assert cover.tolist() == [1] * n_io
+        counts.append(count)
+    allc = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, torch.tensor(counts))
+    allc = [c.tolist() for c in allc]
+    if n == 1024:
+        assert allc[0] == [127, 127, 2] and all(c[0] in (127, 128) and c[2] in (2, 3) for c in allc), allc
+    else:
+        assert allc[0] == [511, 511, 3] and all(c[0] in (511, 512) and c[2] == 3 for c in allc), allc
+# the io_sharded leg's timing: max over ranks by the contract, (min, max) of the ranks' own times beside it
+own = []
+elapsed, _ = du.timed_steps(lambda: time.sleep(0.01 * (1 + rank)), steps=2, warmup=1, device="cpu", local_out=own)
+lo, hi = du.min_max_over_ranks(own[0])
+assert 2 * 0.01 <= lo < 2 * 0.01 + 0.2 and 2 * 0.08 <= hi <= elapsed + 1e-9, (lo, hi, elapsed)
+assert du.min_max_over_ranks(float(rank)) == (0.0, 7.0)
+dist.destroy_process_group()
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank" + str(rank) + ".ok"), "w").write("ok")
+'''
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -76,3 +112,16 @@ def test_two_rank_gloo(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     # per-rank files, not stdout: the two ranks' prints interleave character by character
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), out.stdout + out.stderr
+
+
+def test_eight_rank_gloo_shards_of_the_large_configs(tmp_path):
+    """the 8-rank launch of bench.py's io_sharded leg without the GPU: tiling and balance of the n = 1024 / n = 4096 lists over
+    8 ranks and the (min, max) spread of the ranks' step times (the GPU side of the same shards: tests/test_gpu_multi.py)"""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert all((tmp_path / ("rank%d.ok" % r)).exists() for r in range(8)), out.stdout + out.stderr

@@ -49,6 +49,73 @@ def test_bench_two_ranks_rehearsal_prints_one_whole_job_line():
     sh = r["io_sharded"]["n=128"]
     assert sh["ranks"] == 2 and sh["scaling"] == "strong" and sh["records_of_rank0"] == [63, 63, 7]
     assert abs(sh["value"] - 128 / (sh["ms_per_instance"] * 1e-3)) / sh["value"] < 1e-6
+    lo, hi = sh["rank_ms_per_instance_min_max"]
+    assert 0 < lo <= hi <= sh["ms_per_instance"] * 1.001
+    assert r["pipelined"] is None              # more than one rank: the queue leg (5 x 3 worker threads per rank) is off by default
+
+
+@pytest.mark.timeout(1500)
+def test_bench_four_ranks_rehearsal_shards_the_n1024_instance():
+    """BASELINE configs[3] (n = 1024 sharded across GPUs) through the driver's own command line, as far as a one-GPU box
+    allows: four ranks on GPU 0 over gloo (the pool's process guard allows at most 6 processes on a card, so the 8-rank
+    launch itself cannot be rehearsed here; the 8-rank SHARDS are proved one by one in
+    test_world8_shards_of_the_large_configs and the 8-rank tiling / timing contract runs on the CPU in tests/test_dist_cpu.py).
+    No --inflight flag: the default must switch the queue leg off for world > 1."""
+    out = _run_bench({"SIPP_BENCH_REHEARSAL": "1", "SIPP_BENCH_IO_SHARD_N": "1024"}, 4,
+                     ["--gpus", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=1400)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 4 and r["steps"] == 2 and r["scaling"] == "weak" and r["pipelined"] is None
+    assert abs(r["value"] - 4 * 128 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    sh = r["io_sharded"]["n=1024"]
+    assert sh["ranks"] == 4 and sh["scaling"] == "strong" and sh["records_of_rank0"] == [255, 255, 5]
+    assert abs(sh["value"] - 1024 / (sh["ms_per_instance"] * 1e-3)) / sh["value"] < 1e-6
+    lo, hi = sh["rank_ms_per_instance_min_max"]
+    assert 0 < lo <= hi <= sh["ms_per_instance"] * 1.001
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("n,log_n,records", [(1024, 16, {0: [127, 127, 2], 3: [128, 128, 3], 7: [128, 128, 3]}),
+                                             (4096, 18, {0: [511, 511, 3], 3: [512, 512, 3], 7: [512, 512, 3]})])
+def test_world8_shards_of_the_large_configs(n, log_n, records):
+    """BASELINE configs[3] / configs[4]: the shards an 8-rank run proves -- n = 1024: 127 / 128 G1 and G2 records (N = 2^16)
+    and 2 / 3 Fq12 records (the two-IO-block minimum and a padded block); n = 4096: 511 / 512 records, N = 2^18, the first
+    size outside the fused LDE kernels' range, with ragged 511-record lists padded by one copy.  Ranks 0, 3 and 7 through
+    sipp_instance_prove exactly as bench.py's io_sharded leg does: the oracle's verifier accepts every proof, the public
+    inputs are the rank's slice (padding = copies of its last record), and a single ctx gives the same words."""
+    import sipp_amd
+    from tests import _oracle
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % n))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    L = sipp_amd.lib()
+    for rank, want_counts in records.items():
+        mine = sipp_amd.shard_ios(ios, 8, rank)
+        assert [int(a.shape[0]) for a in mine] == want_counts, rank
+        inst = sipp_amd.Instance([a.shape[0] for a in mine])
+        try:
+            proofs = [p.copy() for p in inst.prove(mine)]
+        finally:
+            inst.close()
+        for k in range(3):
+            first, count = sipp_amd.io_shard(ios[k].shape[0], 8, rank)
+            assert (mine[k] == ios[k][first: first + count]).all()
+            pf = proofs[k]
+            nio = int(pf[3])
+            assert nio >= max(2, count) and nio & (nio - 1) == 0
+            if k < 2:
+                assert int(pf[2]) == log_n and nio == (1 << (log_n - 9))
+            assert _oracle.stark_verify(pf) == 0, (rank, k)
+            pis = pf[-nio * mine[k].shape[1]:].reshape(nio, mine[k].shape[1])
+            assert (pis[:count] == mine[k]).all() and (pis[count:] == mine[k][-1]).all(), (rank, k)
+            if rank == 3:
+                c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(k, count))
+                try:
+                    alone = c.prove(k, mine[k])
+                finally:
+                    c.close()
+                assert len(alone) == len(pf) and (alone == pf).all(), (rank, k)
 
 
 def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
