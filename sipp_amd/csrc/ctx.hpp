@@ -237,6 +237,12 @@ int sipp_ntt_dit(sipp_ctx* ctx, uint64_t* d_io, size_t stride, uint32_t log_n, s
 int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                          uint32_t rate_bits);
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits);
+// the same two for long columns (ntt_tree.hip: tree-of-rings transforms, no diagonals, no bit-reversal copy)
+bool sipp_tree_ntt_enabled(uint32_t log_n);
+int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
+                              uint32_t log_n, uint32_t rate_bits);
+int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
+                              uint32_t rate_bits);
 // out[c][j] = in[c][bitrev(j)]  (out != in)
 int sipp_bitrev_cols(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_out, size_t out_stride,
                      uint32_t log_n, size_t ncols);

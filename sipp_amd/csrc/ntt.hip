@@ -870,6 +870,9 @@ int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_co
                          uint32_t rate_bits) {
     if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
+    // long columns: the tree-of-rings sweeps of ntt_tree.hip (SIPP_TREE_MIN_LOG, default 18; never below the whole-column range)
+    if (fused_lde_enabled() && log_n >= 15 && sipp_tree_ntt_enabled(log_n) && d_values != d_coeffs)
+        return sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
     if (fused_lde_enabled() && log_n >= 15 && log_n <= 17 && rate_bits == 1 && d_values != d_coeffs)
         return lde_three_sweeps(ctx, d_values, d_coeffs, d_lde, ncols, log_n);
     return SIPP_E_UNSUPPORTED;   // caller falls back to the pass-by-pass path
@@ -877,6 +880,7 @@ int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_co
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {
     if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_coeffs, (size_t)1 << log_n, nullptr, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, true);
+    if (fused_lde_enabled() && log_n >= 15 && sipp_tree_ntt_enabled(log_n)) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
     return SIPP_E_UNSUPPORTED;
 }
 

@@ -1,0 +1,456 @@
+// sipp_amd/csrc/ntt_tree.hip -- commitment transforms for LONG columns (N >= 2^18) as a tree of polynomial rings, gfx950.
+//
+// What it replaces: plonky2's PolynomialBatch::from_values (ifft, then coset LDE; field/src/fft.rs, fri/oracle.rs @ 541e127,
+// reached from the reference through starky::prover::prove behind src/verifier_circuit.rs:133-135) for the sizes where a column
+// fits neither LDS (ntt.hip lde_column) nor the three-sweep kernels -- the n = 1024 / n = 4096 configurations of BASELINE.json
+// and every IO shard of an 8-GPU run at n = 4096 (N = 2^18).
+//
+// Why another formulation: the pass-by-pass path of ntt.hip is a four-step FFT -- every sweep over HBM ends
+// (or starts) with a diagonal of twiddles w^(i0 o1) that costs TWO modular products per element (one to advance the running
+// power, one to apply it), the coset shift 7^j is a third diagonal, and the inverse needs a bit-reversal copy first.  At
+// N = 2^21 that is 9 sweeps, 7 diagonals and 152 N bytes per column, and the kernels are bound by VALU issue, not by HBM.
+// Here the transform is the tree of rings  F[x]/(x^n - r)  ->  F[x]/(x^(n/2) - s) x F[x]/(x^(n/2) + s),  s^2 = r:
+//   forward   (u, v) -> (u + s v, u - s v)         one product per butterfly, the twiddle belongs to the BLOCK (tree node),
+//   inverse   (a, b) -> (a + b, (a - b) / s)       not to the position inside it: no diagonal between sweeps at all.
+// The leaves come out in bit-reversed order, i.e. directly in the leaf order of the LDE buffer.  Evaluating on
+// the coset 7 <w> is the same tree with root r = 7^n: the shift lives in the node constants and costs nothing.  With blowup 2^b
+// the top b levels see a zero upper half and are plain copies: the LDE is 2^b INDEPENDENT size-N trees over the same
+// coefficients, written to the 2^b halves of the LDE column.  The inverse reads natural-order values through a tile that is
+// 16 blocks apart in the top four position bits (= the low four bits of the natural index: full 128-byte lines), so the
+// bit-reversal copy disappears as well.
+//
+// Node constants: node (level l, block i) of a size-2^L tree with root constant g^(2^L) has  s = g^(2^(L-1-l)) T[i],
+// T[i] = w_(2^(l+1))^bitrev(i, l)  -- T does not depend on l (prefix property), so the plain tree (g = 1, the inverse) needs one flat
+// table of n/2 entries, and a coset tree a heap-ordered table (index (Q << l) + i under the subtree root Q).  Tables are shared by
+// every column; the grid is ordered column-fastest so that the blocks in flight work on the same few KB of them.
+#include "ctx.hpp"
+#include "gl_lazy.cuh"
+
+namespace {
+
+#ifndef SIPP_TREE_LAZY
+#define SIPP_TREE_LAZY 1
+#endif
+// forward butterfly (u, v) -> (u + s v, u - s v): u may be ANY u64 congruent to its value, the product is made canonical, the
+// sum and the difference take one conditional correction each and stay in [0, 2^64) (gl_lazy.cuh); what leaves the last sweep is
+// canonicalised at the store
+__device__ __forceinline__ void bfly_fwd(uint64_t& u, uint64_t& v, uint64_t s) {
+#if SIPP_TREE_LAZY
+    const uint64_t w = gll::canon(gl::mul_nc(v, s)), a = u;
+    u = gll::add_nc(a, w);
+    v = gll::sub_nc(a, w);
+#else
+    const uint64_t w = gl::mul(v, s), a = u;
+    u = gl::add(a, w);
+    v = gl::sub(a, w);
+#endif
+}
+// inverse butterfly (a, b) -> (a + b, (a - b) / s) on canonical values
+__device__ __forceinline__ void bfly_inv(uint64_t& a, uint64_t& b, uint64_t sinv) {
+#if SIPP_TREE_LAZY
+    const uint64_t u = a, v = b;
+    a = gl::add(u, v);
+    b = gll::canon(gl::mul_nc(gll::sub_nc(u, v), sinv));
+#else
+    const uint64_t u = a, v = b;
+    a = gl::add(u, v);
+    b = gl::mul(gl::sub(u, v), sinv);
+#endif
+}
+
+constexpr int LOG_SEG = 4;
+__device__ __forceinline__ uint32_t lds_idx(uint32_t e) { return e + (e >> LOG_SEG); }
+
+struct IdxPlain {
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
+};
+struct IdxBlocked {
+    uint32_t blk;
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
+};
+
+#ifndef SIPP_NTT_MLP
+#define SIPP_NTT_MLP 8
+#endif
+template <int U, class Load, class Use>
+__device__ __forceinline__ void tile_loop(uint32_t E, Load load, Use use) {
+    const uint32_t step = blockDim.x;
+    uint32_t e = threadIdx.x;
+    for (; e + (U - 1) * step < E; e += U * step) {
+        uint64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = load(e + u * step);
+#pragma unroll
+        for (int u = 0; u < U; u++) use(e + u * step, v[u]);
+    }
+    for (; e < E; e += step) use(e, load(e));
+}
+
+// node constants of the tile's levels: level `lev` below the tile's root (lev = 0: one block per group), block `blk` of group g
+struct TwLds {          // staged in LDS: [G][R] local heaps (entry 0 of a heap unused)
+    const uint64_t* tws;
+    uint32_t k;
+    __device__ __forceinline__ uint64_t operator()(uint32_t g, uint32_t lev, uint32_t blk) const {
+        return tws[(g << k) + (1u << lev) + blk];
+    }
+};
+struct TwGlobal {       // straight from the table (L2): the deep levels use every constant once or twice
+    const uint64_t* tw;
+    uint32_t z0, zstride;
+    __device__ __forceinline__ uint64_t operator()(uint32_t g, uint32_t lev, uint32_t blk) const {
+        return tw[((z0 + g * zstride) << lev) + blk];
+    }
+};
+
+// one round of S levels (row strides 2^D .. 2^(D+S-1)) in registers: a lane owns the 2^S rows r0 + i 2^D of one column
+template <bool FWD, int S, class Idx, class Tw>
+__device__ __forceinline__ void tree_round(uint64_t* tile, uint32_t E, uint32_t k, uint32_t lt, uint32_t D, Idx lidx, Tw tw) {
+    constexpr int M = 1 << S;
+    const uint32_t T = 1u << lt, R = 1u << k, q = 1u << D;
+    const uint32_t items = E >> S;
+    for (uint32_t idx = threadIdx.x; idx < items; idx += blockDim.x) {
+        const uint32_t t = idx & (T - 1);
+        const uint32_t rest = idx >> lt;
+        const uint32_t b = rest & ((R >> S) - 1);
+        const uint32_t g = rest >> (k - S);
+        const uint32_t j = b & (q - 1);
+        const uint32_t r0 = ((b >> D) << (D + S)) | j;
+        const uint32_t e0 = (((g << k) | r0) << lt) | t;
+        const uint32_t st = q << lt;
+        const uint32_t top = r0 >> (D + S);      // block index of the round's highest level, before the lane's own bits
+        uint64_t x[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) x[i] = tile[lidx(e0 + i * st)];
+        if (FWD) {
+#pragma unroll
+            for (int sg = S - 1; sg >= 0; sg--) {
+                const uint32_t lev = k - 1 - (D + sg);
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    if (i & (1 << sg)) continue;
+                    const uint64_t w = tw(g, lev, (top << (S - 1 - sg)) + (uint32_t)(i >> (sg + 1)));
+                    bfly_fwd(x[i], x[i + (1 << sg)], w);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < S; sg++) {
+                const uint32_t lev = k - 1 - (D + sg);
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    if (i & (1 << sg)) continue;
+                    const uint64_t w = tw(g, lev, (top << (S - 1 - sg)) + (uint32_t)(i >> (sg + 1)));
+                    bfly_inv(x[i], x[i + (1 << sg)], w);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) tile[lidx(e0 + i * st)] = x[i];
+    }
+    __syncthreads();
+}
+
+// all k levels of a pass on an LDS tile of E = G R T elements, element e = ((g << k | r) << lt) | t
+template <bool FWD, class Idx, class Tw>
+__device__ __forceinline__ void tree_stages(uint64_t* tile, uint32_t E, uint32_t k, uint32_t lt, Idx lidx, Tw tw) {
+    if (FWD) {
+        uint32_t top = k;
+        for (; top >= 4; top -= 4) tree_round<true, 4>(tile, E, k, lt, top - 4, lidx, tw);
+        if (top >= 2) {
+            tree_round<true, 2>(tile, E, k, lt, top - 2, lidx, tw);
+            top -= 2;
+        }
+        if (top) tree_round<true, 1>(tile, E, k, lt, 0, lidx, tw);
+    } else {
+        uint32_t bot = 0, rem = k;
+        for (; rem >= 4; rem -= 4, bot += 4) tree_round<false, 4>(tile, E, k, lt, bot, lidx, tw);
+        if (rem >= 2) {
+            tree_round<false, 2>(tile, E, k, lt, bot, lidx, tw);
+            bot += 2;
+            rem -= 2;
+        }
+        if (rem) tree_round<false, 1>(tile, E, k, lt, bot, lidx, tw);
+    }
+}
+
+struct TreeArgs {
+    const uint64_t* in;
+    uint64_t* out;
+    size_t in_stride, out_stride;         // per column (elements)
+    size_t in_half, out_half;             // per subtree of blockIdx.y (elements)
+    uint32_t L;                           // log2 positions of one (sub)tree
+    uint32_t lo, k;                       // the pass owns position bits [lo, lo + k)
+    uint32_t lt, lg;                      // tile = 2^k rows x 2^lt columns (lo > 0)  or  2^lg groups of 2^k positions (lo == 0)
+    uint32_t q0;                          // root of subtree blockIdx.y in the table: q0 + blockIdx.y (0 = flat table of the plain tree)
+    const uint64_t* tw;
+    uint64_t scale;                       // 0 = none; applied to every element at the store
+    uint32_t ncols, colfast;
+};
+
+template <bool FWD, bool TWLDS>
+__global__ void __launch_bounds__(256) tree_pass_kernel(TreeArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k = a.k, lt = a.lt, lg = a.lg, lo = a.lo;
+    const uint32_t log_e = k + lt + lg;
+    const uint32_t E = 1u << log_e, T = 1u << lt;
+    uint64_t* tile = smem;
+    uint64_t* tws = smem + (E + (E >> LOG_SEG));
+    const uint32_t tiles_per_col = 1u << (a.L - log_e);
+    uint32_t col, tix;
+    if (a.colfast) {
+        tix = blockIdx.x / a.ncols;
+        col = blockIdx.x - tix * a.ncols;
+    } else {
+        col = blockIdx.x / tiles_per_col;
+        tix = blockIdx.x - col * tiles_per_col;
+    }
+    const uint64_t* in = a.in + (size_t)col * a.in_stride + (size_t)blockIdx.y * a.in_half;
+    uint64_t* out = a.out + (size_t)col * a.out_stride + (size_t)blockIdx.y * a.out_half;
+    const uint32_t Q = a.q0 ? a.q0 + blockIdx.y : 0;
+    // tile -> positions.  strided (lo > 0): tix = hi 2^(lo - lt) + c,  p(r, t) = hi 2^(lo + k) + r 2^lo + c T + t
+    //                     contiguous:       p(e) = tix E + e
+    uint32_t base, hi;
+    if (lo) {
+        hi = tix >> (lo - lt);
+        base = (hi << (lo + k)) + ((tix & ((1u << (lo - lt)) - 1)) << lt);
+    } else {
+        base = tix << log_e;
+        hi = tix << lg;
+    }
+    auto pos_of = [&](uint32_t e) -> uint32_t { return lo ? base + ((e >> lt) << lo) + (e & (T - 1)) : base + e; };
+    const uint32_t z0 = (Q << (a.L - lo - k)) + hi;   // the tile's (first group's) root node
+    tile_loop<SIPP_NTT_MLP>(
+        E, [&](uint32_t e) -> uint64_t { return in[pos_of(e)]; }, [&](uint32_t e, uint64_t v) { tile[lds_idx(e)] = v; });
+    if (TWLDS) {
+        const uint32_t R = 1u << k;
+        for (uint32_t i = threadIdx.x; i < (R << lg); i += blockDim.x) {
+            const uint32_t g = i >> k, J = i & (R - 1);
+            if (!J) continue;
+            const uint32_t lev = 31 - __clz(J);
+            tws[i] = a.tw[((z0 + g) << lev) + (J - (1u << lev))];
+        }
+    }
+    __syncthreads();
+    if (TWLDS)
+        tree_stages<FWD>(tile, E, k, lt, IdxPlain{}, TwLds{tws, k});
+    else
+        tree_stages<FWD>(tile, E, k, lt, IdxPlain{}, TwGlobal{a.tw, z0, 1});
+    const uint64_t sc = a.scale;
+    tile_loop<SIPP_NTT_MLP>(
+        E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; },
+        [&](uint32_t e, uint64_t v) { out[pos_of(e)] = sc ? gl::mul(v, sc) : FWD ? gl::canon(v) : v; });
+}
+
+// inverse, first sweep: natural-order values -> the k2 leaf-most levels.  Tile = 16 groups of 2^k2 positions that differ in their
+// top four position bits, i.e. in the low four bits of the natural index: every global read is a full 128-byte line.
+struct GatherArgs {
+    const uint64_t* in;     // [ncols][n] values, natural order
+    uint64_t* out;          // [ncols][n] positions (leaf order) after the k2 lowest levels
+    uint32_t L, k2;
+    const uint64_t* tw;     // flat inverse table
+    uint32_t ncols, colfast;
+};
+
+__global__ void __launch_bounds__(256) tree_gather_kernel(GatherArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k2 = a.k2, R2 = 1u << k2, E = 16u << k2;
+    const IdxBlocked lidx{k2};
+    uint64_t* tile = smem;
+    const uint32_t mid_bits = a.L - 4 - k2;
+    uint32_t col, mid;
+    if (a.colfast) {
+        mid = blockIdx.x / a.ncols;
+        col = blockIdx.x - mid * a.ncols;
+    } else {
+        col = blockIdx.x >> mid_bits;
+        mid = blockIdx.x & ((1u << mid_bits) - 1);
+    }
+    const uint64_t* in = a.in + ((size_t)col << a.L);
+    uint64_t* out = a.out + ((size_t)col << a.L);
+    const uint32_t nat_mid = gl::bitrev(mid, mid_bits) << 4;
+    tile_loop<SIPP_NTT_MLP>(
+        E,
+        [&](uint32_t e) -> uint64_t {
+            const uint32_t gq = e & 15, r = e >> 4;
+            return in[(gl::bitrev(r, k2) << (a.L - k2)) | nat_mid | gq];
+        },
+        [&](uint32_t e, uint64_t v) {
+            const uint32_t gq = e & 15, r = e >> 4;
+            tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = v;
+        });
+    __syncthreads();
+    // group g = top four position bits: its blocks hang under node (g << mid_bits) + mid of level L - k2
+    tree_stages<false>(tile, E, k2, 0, lidx, TwGlobal{a.tw, mid, 1u << mid_bits});
+    tile_loop<SIPP_NTT_MLP>(
+        E, [&](uint32_t e) -> uint64_t { return tile[lidx(e)]; },
+        [&](uint32_t e, uint64_t v) {
+            const uint32_t g = e >> k2, r = e & (R2 - 1);
+            out[((size_t)g << (a.L - 4)) | ((size_t)mid << k2) | r] = v;
+        });
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+enum { TAB_TREE_FLAT = 30, TAB_TREE_COSET = 31 };
+
+// T[i] = w^(+-bitrev(i, L - 1)), w = w_(2^L), i < 2^(L-1)
+uint64_t* tree_flat_table(sipp_ctx* ctx, uint32_t L, bool inverse) {
+    uint64_t* t = sipp_table_get(ctx, TAB_TREE_FLAT, L, inverse);
+    if (t) return t;
+    const size_t h = (size_t)1 << (L - 1);
+    std::vector<uint64_t> pw(h), v(h);
+    uint64_t w = gl::root_of_unity(L);
+    if (inverse) w = gl::inv(w);
+    uint64_t x = 1;
+    for (size_t i = 0; i < h; i++) {
+        pw[i] = x;
+        x = gl::mul(x, w);
+    }
+    for (size_t i = 0; i < h; i++) v[i] = pw[gl::bitrev((uint32_t)i, L - 1)];
+    if (sipp_table_put(ctx, TAB_TREE_FLAT, L, inverse, v, &t) != SIPP_OK) return nullptr;
+    return t;
+}
+
+// heap table of the coset tree of size m = 2^(L + rate_bits), shift g = 7: C[2^l + i] = 7^(m / 2^(l+1)) T[i]; the levels above
+// rate_bits are never read (zero upper halves: copies)
+uint64_t* tree_coset_table(sipp_ctx* ctx, uint32_t L, uint32_t rate_bits) {
+    uint64_t* t = sipp_table_get(ctx, TAB_TREE_COSET, L, rate_bits);
+    if (t) return t;
+    const uint32_t LM = L + rate_bits;
+    const size_t m = (size_t)1 << LM, h = m >> 1;
+    std::vector<uint64_t> pw(h), v(m, 0);
+    const uint64_t w = gl::root_of_unity(LM);
+    uint64_t x = 1;
+    for (size_t i = 0; i < h; i++) {
+        pw[i] = x;
+        x = gl::mul(x, w);
+    }
+    for (uint32_t l = rate_bits; l < LM; l++) {
+        const uint64_t gs = gl::pow(gl::GEN, (uint64_t)1 << (LM - 1 - l));
+        for (size_t i = 0; i < ((size_t)1 << l); i++)
+            v[((size_t)1 << l) + i] = gl::mul(gs, pw[gl::bitrev((uint32_t)i, LM - 1)]);
+    }
+    if (sipp_table_put(ctx, TAB_TREE_COSET, L, rate_bits, v, &t) != SIPP_OK) return nullptr;
+    return t;
+}
+
+int tree_colfast() {
+    static const int v = sipp_env_int("SIPP_TREE_COLFAST", 1);
+    return v;
+}
+
+// bits of the strided sweeps above the first `low` position bits, highest first, at most 8 each
+std::vector<uint32_t> split_bits(uint32_t rem) {
+    std::vector<uint32_t> ks;
+    if (!rem) return ks;
+    uint32_t q = (rem + 7) / 8;
+    for (uint32_t i = 0; i < q; i++) {
+        const uint32_t ki = rem / (q - i) + ((rem % (q - i)) ? 1 : 0);
+        ks.push_back(ki);
+        rem -= ki;
+    }
+    return ks;
+}
+
+template <bool FWD, bool TWLDS>
+int launch_pass(sipp_ctx* ctx, const char* name, TreeArgs& a, unsigned halves) {
+    const uint32_t log_e = a.k + a.lt + a.lg;
+    const size_t E = (size_t)1 << log_e;
+    const size_t shmem = (E + (E >> LOG_SEG) + (TWLDS ? ((size_t)1 << (a.k + a.lg)) : 0)) * sizeof(uint64_t);
+    const size_t tiles = ((size_t)1 << (a.L - log_e)) * a.ncols;
+    if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
+    auto kern = tree_pass_kernel<FWD, TWLDS>;
+    if (shmem > 64 * 1024)
+        SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    a.colfast = (uint32_t)tree_colfast();
+    ProfScope ps(ctx, name);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, halves), dim3(256), shmem, ctx->stream, a);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
+constexpr uint32_t LTILE = 12;
+
+// coefficients [ncols][n] natural -> the 2^rate_bits halves of the leaf-order LDE
+int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t L, uint32_t rate_bits) {
+    const size_t n = (size_t)1 << L;
+    const uint64_t* tw = tree_coset_table(ctx, L, rate_bits);
+    if (!tw) return SIPP_E_HIP;
+    const uint32_t kc = L < LTILE ? L : LTILE;
+    const std::vector<uint32_t> ks = split_bits(L - kc);
+    const unsigned halves = 1u << rate_bits;
+    uint32_t top = L;
+    bool first = true;
+    for (uint32_t k : ks) {
+        TreeArgs a{};
+        a.in = first ? d_coeffs : d_lde;
+        a.in_stride = first ? n : (n << rate_bits);
+        a.in_half = first ? 0 : n;
+        a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
+        a.L = L; a.k = k; a.lo = top - k;
+        a.lt = LTILE - k < a.lo ? LTILE - k : a.lo;
+        a.lg = 0; a.q0 = halves; a.tw = tw; a.scale = 0; a.ncols = (uint32_t)ncols;
+        SIPP_TRY((launch_pass<true, true>(ctx, "ntt_tree_fwd", a, halves)));
+        top -= k;
+        first = false;
+    }
+    TreeArgs a{};
+    a.in = first ? d_coeffs : d_lde;
+    a.in_stride = first ? n : (n << rate_bits);
+    a.in_half = first ? 0 : n;
+    a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
+    a.L = L; a.k = kc; a.lo = 0; a.lt = 0; a.lg = 0; a.q0 = halves; a.tw = tw; a.scale = 0; a.ncols = (uint32_t)ncols;
+    return launch_pass<true, false>(ctx, "ntt_tree_fwd", a, halves);
+}
+
+// values [ncols][n] natural -> coefficients [ncols][n] natural (d_values != d_coeffs)
+int tree_inverse(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, size_t ncols, uint32_t L) {
+    const uint64_t* tw = tree_flat_table(ctx, L, true);
+    if (!tw) return SIPP_E_HIP;
+    const uint32_t k2 = 8;
+    {
+        GatherArgs g{};
+        g.in = d_values; g.out = d_coeffs; g.L = L; g.k2 = k2; g.tw = tw; g.ncols = (uint32_t)ncols;
+        g.colfast = (uint32_t)tree_colfast();
+        const size_t E = (size_t)16 << k2;
+        const size_t shmem = (E + (E >> LOG_SEG) + 16) * sizeof(uint64_t);
+        const size_t tiles = ((size_t)1 << (L - 4 - k2)) * ncols;
+        if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
+        ProfScope ps(ctx, "ntt_tree_gather");
+        hipLaunchKernelGGL(tree_gather_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, g);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    std::vector<uint32_t> ks = split_bits(L - k2);   // highest first: run them from the back
+    uint32_t lo = k2;
+    for (size_t i = ks.size(); i-- > 0;) {
+        const uint32_t k = ks[i];
+        TreeArgs a{};
+        a.in = d_coeffs; a.out = d_coeffs; a.in_stride = a.out_stride = (size_t)1 << L;
+        a.L = L; a.k = k; a.lo = lo;
+        a.lt = LTILE - k < lo ? LTILE - k : lo;
+        a.lg = 0; a.q0 = 0; a.tw = tw; a.ncols = (uint32_t)ncols;
+        a.scale = i == 0 ? gl::inv((uint64_t)1 << L) : 0;
+        SIPP_TRY((launch_pass<false, true>(ctx, "ntt_tree_inv", a, 1)));
+        lo += k;
+    }
+    return SIPP_OK;
+}
+
+}  // namespace
+
+bool sipp_tree_ntt_enabled(uint32_t log_n) {
+    static const int lo = sipp_env_int("SIPP_TREE_MIN_LOG", 18);
+    return log_n >= (uint32_t)lo && log_n >= 12 && log_n <= 25;
+}
+
+int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
+                              uint32_t log_n, uint32_t rate_bits) {
+    if (d_values == d_coeffs || ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
+    SIPP_TRY(tree_inverse(ctx, d_values, d_coeffs, ncols, log_n));
+    return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+}
+
+int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
+                              uint32_t rate_bits) {
+    if (ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
+    return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+}

@@ -74,6 +74,22 @@ def test_commit_matches_oracle(ctx, log_n, ncols):
     assert (cap == ref.cap).all()
 
 
+@pytest.mark.parametrize("log_n,rate_bits,from_coeffs", [(18, 2, False), (18, 3, True), (19, 1, True), (18, 1, False)])
+def test_long_column_batches_at_other_blowups_match_the_oracle(ctx, log_n, rate_bits, from_coeffs):
+    """the tree-of-rings transforms of ntt_tree.hip (N >= 2^18) through sipp_commit_batch_ex: blowup 4 and 8 (2^rate_bits
+    independent subtrees over the same coefficients), from values and from coefficients -- coefficients, every LDE cell in leaf
+    order and the cap equal the oracle's PolynomialBatch"""
+    rng = np.random.default_rng(500 + log_n + rate_bits)
+    ncols = 2
+    data = _oracle.rand_field(rng, (ncols, 1 << log_n))
+    ref = _oracle.Batch(data, log_n, rate_bits=rate_bits, cap_height=4, from_coeffs=from_coeffs)
+    od, cap, (coeffs, lde, tree) = ctx.commit_ex(dev(data), log_n, rate_bits, 4, from_coeffs=from_coeffs)
+    if not from_coeffs:
+        assert (host(coeffs) == ref.coeffs).all()
+    assert (host(lde).T == ref.leaves).all()
+    assert (cap == ref.cap).all()
+
+
 def test_leaves_and_cap_separately(ctx):
     rng = np.random.default_rng(5)
     log_n, ncols = 9, 20
