@@ -243,6 +243,7 @@ int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t*
                               uint32_t log_n, uint32_t rate_bits);
 int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                               uint32_t rate_bits);
+int sipp_tree_coset_eval(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_out, size_t ncols, uint32_t log_n, uint32_t log_m);
 // out[c][j] = in[c][bitrev(j)]  (out != in)
 int sipp_bitrev_cols(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_out, size_t out_stride,
                      uint32_t log_n, size_t ncols);

@@ -310,12 +310,11 @@ uint64_t* tree_flat_table(sipp_ctx* ctx, uint32_t L, bool inverse) {
     return t;
 }
 
-// heap table of the coset tree of size m = 2^(L + rate_bits), shift g = 7: C[2^l + i] = 7^(m / 2^(l+1)) T[i]; the levels above
-// rate_bits are never read (zero upper halves: copies)
-uint64_t* tree_coset_table(sipp_ctx* ctx, uint32_t L, uint32_t rate_bits) {
-    uint64_t* t = sipp_table_get(ctx, TAB_TREE_COSET, L, rate_bits);
+// heap table of the coset tree of size m = 2^LM, shift g = 7: C[2^l + i] = 7^(m / 2^(l+1)) T[i].  One table serves every split of LM
+// into (column length, blowup): the levels above the blowup are simply never read (zero upper halves: copies)
+uint64_t* tree_coset_table(sipp_ctx* ctx, uint32_t LM) {
+    uint64_t* t = sipp_table_get(ctx, TAB_TREE_COSET, LM, 0);
     if (t) return t;
-    const uint32_t LM = L + rate_bits;
     const size_t m = (size_t)1 << LM, h = m >> 1;
     std::vector<uint64_t> pw(h), v(m, 0);
     const uint64_t w = gl::root_of_unity(LM);
@@ -324,12 +323,12 @@ uint64_t* tree_coset_table(sipp_ctx* ctx, uint32_t L, uint32_t rate_bits) {
         pw[i] = x;
         x = gl::mul(x, w);
     }
-    for (uint32_t l = rate_bits; l < LM; l++) {
+    for (uint32_t l = 0; l < LM; l++) {
         const uint64_t gs = gl::pow(gl::GEN, (uint64_t)1 << (LM - 1 - l));
         for (size_t i = 0; i < ((size_t)1 << l); i++)
             v[((size_t)1 << l) + i] = gl::mul(gs, pw[gl::bitrev((uint32_t)i, LM - 1)]);
     }
-    if (sipp_table_put(ctx, TAB_TREE_COSET, L, rate_bits, v, &t) != SIPP_OK) return nullptr;
+    if (sipp_table_put(ctx, TAB_TREE_COSET, LM, 0, v, &t) != SIPP_OK) return nullptr;
     return t;
 }
 
@@ -373,7 +372,7 @@ constexpr uint32_t LTILE = 12;
 // coefficients [ncols][n] natural -> the 2^rate_bits halves of the leaf-order LDE
 int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t L, uint32_t rate_bits) {
     const size_t n = (size_t)1 << L;
-    const uint64_t* tw = tree_coset_table(ctx, L, rate_bits);
+    const uint64_t* tw = tree_coset_table(ctx, L + rate_bits);
     if (!tw) return SIPP_E_HIP;
     const uint32_t kc = L < LTILE ? L : LTILE;
     const std::vector<uint32_t> ks = split_bits(L - kc);
@@ -437,6 +436,11 @@ int tree_inverse(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, si
 
 }  // namespace
 
+static bool fused_tree_ok() {
+    static const bool v = getenv("SIPP_NTT_UNFUSED") == nullptr;
+    return v;
+}
+
 bool sipp_tree_ntt_enabled(uint32_t log_n) {
     static const int lo = sipp_env_int("SIPP_TREE_MIN_LOG", 18);
     return log_n >= (uint32_t)lo && log_n >= 12 && log_n <= 25;
@@ -453,4 +457,14 @@ int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t*
                               uint32_t rate_bits) {
     if (ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
     return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+}
+
+// SHORT polynomials on a LONG coset (the public-input polynomials of the quotient: 2^log_n coefficients, 2^log_m points of 7 <w_m>,
+// leaf order): the same trees with log_m - log_n copy levels -- 2^(log_m - log_n) independent size-2^log_n transforms, ONE sweep
+// that reads the coefficients from L2 and writes every point once, instead of a zero-padded 2^log_m transform in three (shorter
+// polynomials would make one tiny block per subtree: they stay with the pass-by-pass path)
+int sipp_tree_coset_eval(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_out, size_t ncols, uint32_t log_n, uint32_t log_m) {
+    if (!fused_tree_ok() || ncols == 0 || ncols > 0xffffffu || log_n < 10 || log_m < log_n || log_m - log_n > 15 || log_m > 25)
+        return SIPP_E_UNSUPPORTED;
+    return tree_forward(ctx, d_coeffs, d_out, ncols, log_n, log_m - log_n);
 }

@@ -434,7 +434,12 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         if (!d_auxc || !d_aux) return SIPP_E_NOMEM;
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_auxc, auxc.data(), auxc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (n_aux) SIPP_TRY(sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, mq, log_mq, (size_t)n_aux, false, NttDiag{gl::GEN, 0}));
+        if (n_aux) {
+            int rc_aux = sipp_tree_coset_eval(ctx, d_auxc, d_aux, (size_t)n_aux, log_io, log_mq);
+            if (rc_aux == SIPP_E_UNSUPPORTED)
+                rc_aux = sipp_ntt_dif(ctx, d_auxc, nio, log_io, d_aux, mq, log_mq, (size_t)n_aux, false, NttDiag{gl::GEN, 0});
+            SIPP_TRY(rc_aux);
+        }
         SIPP_TRY(sipp_k_quotient(ctx, a, log_n, T.lde, Z.lde, m, d_aux, alpha, beta, gamma, Qo.coeffs));
         // coset iNTT: leaf-order values -> natural coefficients of q(x) (undo the shift 7)
         SIPP_TRY(sipp_ntt_dit(ctx, Qo.coeffs, mq, log_mq, 2, true, NttDiag{gl::inv(gl::GEN), 0}));
