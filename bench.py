@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (spec)
 NTT_KERNELS = ("lde_column", "lde_gather", "lde_mid", "ntt_dif_pass", "ntt_dit_pass", "bitrev_cols", "ntt_tree_gather", "ntt_tree_inv",
                "ntt_tree_fwd")
-PMC_FILE = "r02_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
+PMC_FILE = "r03_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
 
 
 def load_ios(n):
@@ -46,8 +46,10 @@ def cpu_baseline(ios, shapes, budget_s=150.0):
     takes 7.8 s on 16 threads, 8.6 s on 64, 21 s on 256 -- scripts/omp_scaling.py).  If the first proof shows that the three
     would not fit `budget_s`, the other two are extrapolated by committed LDE cells and the object says so."""
     from tests import _oracle
-    threads = int(os.environ.get("SIPP_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(threads)
+    want = int(os.environ.get("SIPP_CPU_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # omp_set_num_threads through the oracle: OMP_NUM_THREADS is read when the OpenMP runtime loads (with `import torch`, long
+    # ago); `threads` is what omp_get_max_threads() reports afterwards, i.e. the team size the proofs below really run with
+    threads = _oracle.set_num_threads(want)
     cells = [2.0 * (1 << s[0]) * (s[1] + s[2] + s[3]) for s in shapes]
     secs, measured = [], True
     for k in range(3):
@@ -219,39 +221,63 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = dist_util.whole_job_rate(args.n, world, elapsed / args.steps)
-        # dominant kernel: Poseidon leaf hashing.  Algorithmic bytes per step: every LDE cell of the three
-        # committed batches of each STARK is read once (8 B) and one 32-B digest per leaf is written.
-        leaf_bytes = 0.0
-        leaf_perms = 0.0
+        # dominant kernel: Poseidon leaf hashing, ONE STATE PER LANE (poseidon_leaves_kernel: every tree of more than 2^16 leaves).
+        # Algorithmic bytes per launch: every LDE cell of the batch is read once (8 B), one 32-B digest per leaf is written.  The
+        # thin trees' two-lane kernel (the Fq12 STARK) is a different kernel and has its own entry; batches of <= 4 columns are
+        # not hashed at all (hash_or_noop: a copy) and are in neither.
+        leaf = {"one": {"bytes": 0.0, "perms": 0.0, "batches": 0}, "pair": {"bytes": 0.0, "perms": 0.0, "batches": 0}}
         for (log_n, W, P, Q) in shapes:
             m = 2 << log_n
             for cols in (W, P, Q):
-                leaf_bytes += 8.0 * m * cols + 32.0 * m
-                if cols > 4:
-                    leaf_perms += m * ((cols + 7) // 8)
-        lk = prof.get("poseidon_leaves", {"calls": 0, "ms": 0.0})
-        launches = max(1, lk["calls"])
-        avg_ms = lk["ms"] / launches
-        bytes_per_launch = leaf_bytes * args.steps / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected with
-        # rocprofv3 in separate runs of this same command and committed under profiles/ (n = 128 only)
-        traffic = None
-        valu = None
+                if cols <= 4:
+                    continue
+                e = leaf["one" if m > 65536 else "pair"]
+                e["bytes"] += 8.0 * m * cols + 32.0 * m
+                e["perms"] += m * ((cols + 7) // 8)
+                e["batches"] += 1
+        leaf_perms = leaf["one"]["perms"] + leaf["pair"]["perms"]
+        pmc = {}
         tpath = os.path.join(ROOT, "profiles", PMC_FILE)
         if args.n == 128 and os.path.exists(tpath):
             pmc = json.load(open(tpath))
-            traffic = pmc.get("traffic_bytes_per_launch")
-            # the kernel's real bound: wave-level VALU instructions per launch (PMC SQ_INSTS_VALU, same command) over the
-            # live launch time, against the issue peak of 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
-            # (MI355X_MICROARCH.md, wave scheduling).  39 % of the instructions are v_mad_u64_u32 (~5.4 cycles each), and
-            # the launches share the SIMDs with the two other proofs, so 1.0 is not reachable for this instruction mix.
-            vi = pmc.get("leaf_valu_insts_per_launch")
-            if vi and avg_ms > 0:
-                peak = 256 * 4 * 2.4e9 / 2 / 1e9
-                ach = vi / (avg_ms * 1e-3) / 1e9
-                valu = {"unit": "G wave-instructions/s", "achieved": ach, "peak": peak, "frac": ach / peak,
-                        "insts_per_launch": vi}
+        issue_peak = 256 * 4 * 2.4e9 / 2 / 1e9    # G wave-instructions/s: 1024 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz
+
+        def leaf_entry(kind, prof_name):
+            lk_ = prof.get(prof_name, {"calls": 0, "ms": 0.0})
+            n_l = lk_["calls"]
+            if not n_l or lk_["ms"] <= 0:
+                return None, lk_
+            avg = lk_["ms"] / n_l
+            bpl = leaf[kind]["bytes"] * args.steps / n_l
+            ach = bpl / (avg * 1e-3) / 1e9
+            st = pmc.get("leaf_" + kind, {})
+            vi = st.get("valu_insts_per_launch")
+            return {"kernel": prof_name, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl,
+                    "launches": n_l, "avg_launch_ms": avg, "traffic": st.get("traffic_bytes_per_launch"),
+                    "perms_per_s": leaf[kind]["perms"] * args.steps / (lk_["ms"] * 1e-3),
+                    # the kernel's real bound: wave-level VALU instructions per launch (PMC SQ_INSTS_VALU of this same command,
+                    # static) over the live launch time, against the issue peak (MI355X_MICROARCH.md, wave scheduling)
+                    "valu": ({"unit": "G wave-instructions/s", "achieved": vi / (avg * 1e-3) / 1e9, "peak": issue_peak,
+                              "frac": vi / (avg * 1e-3) / 1e9 / issue_peak, "insts_per_launch": vi} if vi else None)}, lk_
+
+        one, lk = leaf_entry("one", "poseidon_leaves")
+        pair, lkp = leaf_entry("pair", "poseidon_leaves_pair")
+        if one is None:          # a size without fat trees (n < 128): the thin kernel is the dominant one
+            one, lk = pair, lkp
+        achieved, launches, avg_ms = (one["achieved"], one["launches"], one["avg_launch_ms"]) if one else (0.0, 0, 0.0)
+        bytes_per_launch = one["algorithmic_bytes_per_launch"] if one else 0.0
+        traffic = one["traffic"] if one else None
+        valu = one["valu"] if one else None
+        # the INSTANCE-level bound: all wave-level VALU instructions of one instance (PMC, static) over the step time, against the
+        # issue peak and against what this instruction mix can reach (scripts/ubench/enc_rates.hip: carry / 64-bit / multiply
+        # forms issue at ~1.7x the time of a plain 32-bit add; the mix of the leaf kernel averages ~1.5x)
+        valu_instance = None
+        if pmc.get("valu_insts_per_instance"):
+            vi = pmc["valu_insts_per_instance"]
+            ach = vi / (ms_per_step * 1e-3) / 1e9
+            valu_instance = {"unit": "G wave-instructions/s", "insts_per_instance": vi, "achieved": ach, "peak": issue_peak,
+                             "frac": ach / issue_peak, "mix_ceiling": issue_peak / 1.5, "frac_of_mix_ceiling": ach / (issue_peak / 1.5),
+                             "source": "profiles/%s (static: rocprofv3 --pmc SQ_INSTS_VALU of this command)" % PMC_FILE}
         out = {
             "metric": "SIPP proof-gen wall-clock + pairings-aggregated/sec, n=%d (the 3 STARK sub-proofs; outer plonky2 proof not included)" % args.n,
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,10 +300,11 @@ def main():
                                             "command, FETCH_SIZE x2 gfx950 correction; not re-measured in this run)" % PMC_FILE)
                                            if traffic is not None else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launches": launches, "avg_launch_ms": avg_ms, "valu": valu,
-                         "note": "integer-VALU-bound kernel (Poseidon x^7 + MDS, ~%.2f G permutations/s); HBM fraction "
-                                 "is small by construction, see DESIGN.md" % (leaf_perms * args.steps / (lk["ms"] * 1e-3) / 1e9
-                                                                              if lk["ms"] > 0 else 0.0)},
+                         "launches": launches, "avg_launch_ms": avg_ms, "valu": valu, "valu_instance": valu_instance,
+                         "two_lane_kernel": pair if pair is not one else None,
+                         "note": "one-state-per-lane launches only (%d per step); integer-VALU-bound kernel (Poseidon x^7 + MDS, "
+                                 "~%.2f G permutations/s); HBM fraction is small by construction, see DESIGN.md"
+                                 % (launches // max(1, args.steps), (one["perms_per_s"] / 1e9) if one else 0.0)},
             # HIP-event brackets on each proof's own stream, summed over the three CONCURRENT streams: upper bounds on a kernel's
             # cost (its waves share the SIMDs with the other proofs' kernels), their sum exceeds ms_per_step
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
@@ -293,7 +320,8 @@ def main():
             # companion figures of SURVEY.md section 8(d): leaf permutations and NTT butterflies per second of kernel time
             # (HIP-event time of those kernels, which run concurrently with the other proofs' kernels)
             "rates": {
-                "poseidon_leaf_perms_per_s": leaf_perms * args.steps / (lk["ms"] * 1e-3) if lk["ms"] > 0 else None,
+                "poseidon_leaf_perms_per_s": (leaf_perms * args.steps / ((lk["ms"] + (lkp["ms"] if pair is not one else 0.0)) * 1e-3)
+                                              if lk["ms"] > 0 else None),
                 # butterflies of all committed transforms over the event time of every NTT / LDE kernel (3 streams concurrent)
                 "ntt_butterflies_per_s": (
                     sum((s[1] + s[2]) * ((1 << s[0]) / 2 * s[0] + (1 << s[0]) * (s[0] + 1))

@@ -7,6 +7,24 @@
 #include "oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 orc_merkle *orc_merkle_new(const uint64_t *leaves, unsigned log_leaves, size_t leaf_len, unsigned cap_height) {
     orc_merkle *t = (orc_merkle *)calloc(1, sizeof *t);

@@ -25,6 +25,11 @@ void orc_poseidon_permute(uint64_t state[12]);
  * reference at src/transcript_native.rs:27,57. */
 void orc_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);
 void orc_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
+/* OpenMP team size of every parallel region of the oracle.  The environment variable OMP_NUM_THREADS is read when the runtime is
+ * first loaded -- in a Python process that has imported torch that was long ago -- so a caller that wants a thread count sets it
+ * here; orc_get_max_threads() is what the next parallel region will really use (1 in a build without OpenMP). */
+void orc_set_num_threads(int n);
+int orc_get_max_threads(void);
 /* hash_or_noop: len <= 4 -> zero padded elements ARE the digest */
 void orc_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);
 

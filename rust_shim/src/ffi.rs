@@ -1,5 +1,7 @@
-//! Raw bindings of include/sipp_hip.h (never compiled here: no Rust toolchain in the image).
-use std::os::raw::{c_char, c_int};
+//! Raw bindings of include/sipp_hip.h -- every function and every struct of the header, in the header's order.
+//! Never compiled here (no Rust toolchain in the image); tests/test_abi.py::test_rust_bindings_match_the_header parses this
+//! file and the header and compares every function (name, argument types, return type) and every struct field.
+use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
 pub struct SippCtxOpaque {
@@ -23,32 +25,114 @@ pub struct SippStarkConfig {
 pub const SIPP_G1_EXP: c_int = 0;
 pub const SIPP_G2_EXP: c_int = 1;
 pub const SIPP_FQ12_EXP: c_int = 2;
+pub const SIPP_SALT_SIZE: usize = 4;
+pub const SIPP_FRI_MAX_ROUNDS: usize = 32;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippFriParams {
+    pub rate_bits: u32,
+    pub cap_height: u32,
+    pub pow_bits: u32,
+    pub num_queries: u32,
+    pub pow_rule: u32,
+    pub hiding: u32,
+    pub n_rounds: u32,
+    pub arity_bits: [u32; SIPP_FRI_MAX_ROUNDS],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippOracle {
+    pub d_coeffs: *const u64,
+    pub d_lde: *const u64,
+    pub d_tree: *const u64,
+    pub n_polys: u32,
+    pub n_salt: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPolyRange {
+    pub oracle: u32,
+    pub col_begin: u32,
+    pub col_end: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippFriBatch {
+    pub point: [u64; 2],
+    pub n_ranges: u32,
+    pub ranges: *const SippPolyRange,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippChallenger {
+    pub state: [u64; 12],
+    pub in_buf: [u64; 8],
+    pub n_in: u64,
+    pub out_buf: [u64; 8],
+    pub n_out: u64,
+}
 
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
-    pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
     pub fn sipp_ctx_create(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, workspace_bytes: usize) -> c_int;
     pub fn sipp_ctx_destroy(ctx: *mut SippCtxOpaque);
     pub fn sipp_ctx_set_stream_priority(ctx: *mut SippCtxOpaque, level: c_int) -> c_int;
     pub fn sipp_last_error(ctx: *const SippCtxOpaque) -> *const c_char;
-    pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
-    pub fn sipp_g1_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
-    pub fn sipp_g2_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
-    pub fn sipp_fq12_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, out: *mut u64, cap: usize, len: *mut usize) -> c_int;
-    pub fn sipp_prove_async(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, out: *mut u64, cap: usize) -> c_int;
-    pub fn sipp_wait(ctx: *mut SippCtxOpaque, len: *mut usize) -> c_int;
-    pub fn sipp_instance_prove(ctxs: *const *mut SippCtxOpaque, ios: *const *const u32, num_io: *const usize, out: *const *mut u64,
-                               cap: *const usize, len: *mut usize) -> c_int;
-    pub fn sipp_inner_products(ctx: *mut SippCtxOpaque, g1: *const u32, g2: *const u32, n: usize, count: usize, out: *mut u32) -> c_int;
-    pub fn sipp_native_proof_words(n: usize) -> usize;
-    pub fn sipp_prove_native(ctx: *mut SippCtxOpaque, a: *const u32, b: *const u32, n: usize, proof: *mut u32) -> c_int;
-    pub fn sipp_verify_native(ctx: *mut SippCtxOpaque, a: *const u32, b: *const u32, n: usize, proof: *const u32, statement: *mut u32,
-                              g1_ios: *mut u32, g2_ios: *mut u32, fq12_ios: *mut u32, accepted: *mut c_int) -> c_int;
-    pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
+    pub fn sipp_sync(ctx: *mut SippCtxOpaque) -> c_int;
+    pub fn sipp_stream(ctx: *mut SippCtxOpaque) -> *mut c_void;
+    pub fn sipp_g1_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_g2_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_fq12_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_prove_async(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize) -> c_int;
+    pub fn sipp_wait(ctx: *mut SippCtxOpaque, proof_len: *mut usize) -> c_int;
+    /// arrays of three, indexed by kind
+    pub fn sipp_instance_prove(ctxs: *const *mut SippCtxOpaque, ios: *const *const u32, num_io: *const usize, proof_out: *const *mut u64,
+                               proof_cap: *const usize, proof_len: *mut usize) -> c_int;
     /// a queue of `count` instances through `in_flight` slots of three ctxs (arrays indexed 3 * i + kind)
     pub fn sipp_instances_prove(ctxs: *const *mut SippCtxOpaque, in_flight: usize, count: usize, ios: *const *const u32,
-                                num_io: *const usize, out: *const *mut u64, cap: *const usize, len: *mut usize, status: *mut c_int) -> c_int;
+                                num_io: *const usize, proof_out: *const *mut u64, proof_cap: *const usize, proof_len: *mut usize,
+                                status: *mut c_int) -> c_int;
     /// range of an obligation list that GPU `rank` of `world` proves as a STARK of its own (level L-D)
     pub fn sipp_io_shard(num_io: usize, world: u32, rank: u32, first: *mut usize, count: *mut usize) -> c_int;
+    pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
+    pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
+    pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
+    pub fn sipp_workspace_bytes_cfg(kind: c_int, num_io: usize, cfg: *const SippStarkConfig) -> usize;
+    pub fn sipp_stark_shape(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize, log_rows: *mut u32, main_cols: *mut u32,
+                            perm_cols: *mut u32, quotient_cols: *mut u32) -> c_int;
+    pub fn sipp_inner_product(ctx: *mut SippCtxOpaque, g1: *const u32, g2: *const u32, n: usize, out: *mut u32) -> c_int;
+    pub fn sipp_inner_products(ctx: *mut SippCtxOpaque, g1: *const u32, g2: *const u32, n: usize, count: usize, out: *mut u32) -> c_int;
+    pub fn sipp_native_proof_words(n: usize) -> usize;
+    pub fn sipp_prove_native(ctx: *mut SippCtxOpaque, A: *const u32, B: *const u32, n: usize, proof: *mut u32) -> c_int;
+    pub fn sipp_verify_native(ctx: *mut SippCtxOpaque, A: *const u32, B: *const u32, n: usize, proof: *const u32, statement: *mut u32,
+                              g1_ios: *mut u32, g2_ios: *mut u32, fq12_ios: *mut u32, accepted: *mut c_int) -> c_int;
+    pub fn sipp_fri_const_arity(p: *mut SippFriParams, arity_bits: u32, final_poly_bits: u32, degree_bits: u32);
+    pub fn sipp_commit_batch_ex(ctx: *mut SippCtxOpaque, d_in: *const u64, from_coeffs: c_int, d_coeffs: *mut u64, d_lde: *mut u64,
+                                d_tree: *mut u64, ncols: usize, log_n: u32, rate_bits: u32, cap_height: u32, d_salt: *const u64,
+                                n_salt: u32, cap_out: *mut u64) -> c_int;
+    pub fn sipp_fri_proof_size(oracles: *const SippOracle, n_oracles: usize, batches: *const SippFriBatch, n_batches: usize, log_n: u32,
+                               p: *const SippFriParams) -> usize;
+    pub fn sipp_fri_prove_openings(ctx: *mut SippCtxOpaque, oracles: *const SippOracle, n_oracles: usize, batches: *const SippFriBatch,
+                                   n_batches: usize, log_n: u32, p: *const SippFriParams, ch: *mut SippChallenger, proof_out: *mut u64,
+                                   proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_ntt_batch(ctx: *mut SippCtxOpaque, d_cols: *mut u64, col_stride: usize, ncols: usize, log_n: u32, inverse: c_int) -> c_int;
+    pub fn sipp_lde_batch(ctx: *mut SippCtxOpaque, d_values: *const u64, d_coeffs: *mut u64, d_lde: *mut u64, ncols: usize, log_n: u32) -> c_int;
+    pub fn sipp_poseidon_leaves(ctx: *mut SippCtxOpaque, d_lde: *const u64, ncols: usize, log_leaves: u32, d_digests: *mut u64) -> c_int;
+    pub fn sipp_merkle_cap(ctx: *mut SippCtxOpaque, d_tree: *mut u64, log_leaves: u32, cap_out: *mut u64) -> c_int;
+    pub fn sipp_commit_batch(ctx: *mut SippCtxOpaque, d_values: *const u64, d_coeffs: *mut u64, d_lde: *mut u64, d_tree: *mut u64,
+                             ncols: usize, log_n: u32, cap_out: *mut u64) -> c_int;
+    pub fn sipp_trace_build(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, d_trace: *mut u64) -> c_int;
+    pub fn sipp_poseidon_permute(ctx: *mut SippCtxOpaque, d_states: *mut u64, n: usize) -> c_int;
+    pub fn sipp_host_poseidon_permute(states: *mut u64, n: usize, r#impl: c_int) -> c_int;
+    pub fn sipp_profile_enable(ctx: *mut SippCtxOpaque, enable: c_int) -> c_int;
+    pub fn sipp_profile_reset(ctx: *mut SippCtxOpaque) -> c_int;
+    pub fn sipp_profile_report(ctx: *mut SippCtxOpaque, buf: *mut c_char, cap: usize) -> c_int;
+    pub fn sipp_timer_start(ctx: *mut SippCtxOpaque) -> c_int;
+    pub fn sipp_timer_stop(ctx: *mut SippCtxOpaque, ms: *mut f32) -> c_int;
 }

@@ -69,6 +69,46 @@ impl SippCtx {
     }
 }
 
+/// Level L-D: the slice of an obligation list that GPU `rank` of `world` proves as a STARK
+/// of its own.  On the circuit side `g1_exp_circuit` / `g2_exp_circuit` / `fq12_exp_circuit` (reference
+/// src/verifier_circuit.rs:133-135) are then called once per range, each generator proving its slice on its own GPU.
+pub fn io_shard(num_io: usize, world: u32, rank: u32) -> Result<std::ops::Range<usize>> {
+    let (mut first, mut count) = (0usize, 0usize);
+    let rc = unsafe { ffi::sipp_io_shard(num_io, world, rank, &mut first, &mut count) };
+    anyhow::ensure!(rc == 0, "sipp_io_shard failed: status {rc}");
+    Ok(first..first + count)
+}
+
+/// The three sub-proofs of ONE rank's slices, concurrently on three ctxs of that rank's GPU (`sipp_instance_prove`): what the
+/// patched generators of rank `rank` run.  `ios[k]` is the WHOLE list of kind k; an empty slice yields an empty proof.
+pub fn prove_rank_shards(ctxs: &mut [SippCtx; 3], ios: [&[u32]; 3], world: u32, rank: u32) -> Result<[Vec<u64>; 3]> {
+    let kinds = [Kind::G1Exp, Kind::G2Exp, Kind::Fq12Exp];
+    let mut ptr = [std::ptr::null::<u32>(); 3];
+    let mut num = [0usize; 3];
+    let mut out: [Vec<u64>; 3] = [Vec::new(), Vec::new(), Vec::new()];
+    for k in 0..3 {
+        let w = kinds[k].io_words();
+        anyhow::ensure!(ios[k].len() % w == 0, "ragged IO list");
+        let r = io_shard(ios[k].len() / w, world, rank)?;
+        num[k] = r.len();
+        ptr[k] = ios[k][r.start * w..].as_ptr();
+        let cap = if num[k] > 0 { unsafe { ffi::sipp_proof_size(ctxs[k].raw, k as i32, num[k]) } } else { 0 };
+        out[k] = vec![0u64; cap.max(1)];
+    }
+    let raw = [ctxs[0].raw, ctxs[1].raw, ctxs[2].raw];
+    let bufs = [out[0].as_mut_ptr(), out[1].as_mut_ptr(), out[2].as_mut_ptr()];
+    let caps = [out[0].len(), out[1].len(), out[2].len()];
+    let mut lens = [0usize; 3];
+    let rc = unsafe { ffi::sipp_instance_prove(raw.as_ptr(), ptr.as_ptr(), num.as_ptr(), bufs.as_ptr(), caps.as_ptr(), lens.as_mut_ptr()) };
+    if rc != 0 {
+        return Err(anyhow!("sipp_instance_prove failed: status {rc}: {}", ctxs.iter().map(|c| c.last_error()).collect::<Vec<_>>().join("; ")));
+    }
+    for k in 0..3 {
+        out[k].truncate(lens[k]);
+    }
+    Ok(out)
+}
+
 impl Drop for SippCtx {
     fn drop(&mut self) {
         unsafe { ffi::sipp_ctx_destroy(self.raw) }

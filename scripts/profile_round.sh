@@ -11,7 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- p
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_w.log"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_v" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_v.log"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d "$OUT/pmc_i" -o run -- python3 "$R/scripts/perf_generic.py" 16 1024 > "$OUT/pmc_i.txt" 2> "$OUT/pmc_i.log"
 # concurrency timeline of the same command (kernel trace only)
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tl" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/tl.log"
 # native chain

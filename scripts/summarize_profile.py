@@ -26,44 +26,39 @@ shutil.copy("%s/stats/run_kernel_stats.csv" % src, dst + "_bench_n128_kernel_sta
 shutil.copy("%s/bench_line.json" % src, dst + "_bench_n128_bench_line.json")
 f, nf = counters("pmc_f")
 w, nw = counters("pmc_w")
-leaf = ("poseidon_leaves_kernel", "poseidon_leaves_quad_kernel", "poseidon_leaves_pair_kernel")
-leaf = tuple(k for k in leaf if k in nf)
-fetch_kb = sum(f[k]["FETCH_SIZE"] for k in leaf)
-write_kb = sum(w[k]["WRITE_SIZE"] for k in leaf)
-launches = sum(nf[k] for k in leaf)
-out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
-    "kernel": "poseidon_leaves (one-state-per-lane kernel for the 2^17-leaf trees + two-lanes-per-state kernel for the thin Fq12 trees)",
-    "launches": launches,
-    "FETCH_SIZE_kb_sum": fetch_kb,
-    "WRITE_SIZE_kb_sum": write_kb,
-    "calibration": "scripts/ubench/fetch_calib.hip: 1 GiB read with this kernel's 8-B-per-lane column pattern reports FETCH_SIZE = 524,293.5 KB (exactly 1/2, as MI355X_MICROARCH.md section HBM says for wide coalesced reads); 1 GiB written reports WRITE_SIZE = 1,048,576 KB (exact)",
-    "fetch_correction": 2.0,
-    "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0 / launches,
-}
-NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel")
+v, nv = counters("pmc_v")
 steps_profiled = 4   # --steps 2 --warmup 1, plus the serial step bench.py appends for kernel_ms_serial
+tot = sum(x["SQ_INSTS_VALU"] for x in v.values())
+
+
+def leaf(k, what):
+    n = max(1, nf.get(k, 0))
+    return {"kernel": k, "what": what, "launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"],
+            "traffic_bytes_per_launch": (2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"]) * 1024.0 / n,
+            "valu_insts_per_launch": v[k]["SQ_INSTS_VALU"] / max(1, nv.get(k, 0))}
+
+
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
+    "calibration": "scripts/ubench/fetch_calib.hip: 1 GiB read with the leaf kernel's 8-B-per-lane column pattern reports FETCH_SIZE = 524,293.5 KB (exactly 1/2, as MI355X_MICROARCH.md section HBM says for wide coalesced reads); 1 GiB written reports WRITE_SIZE = 1,048,576 KB (exact)",
+    "fetch_correction": 2.0,
+    "instances_profiled": steps_profiled,
+    "leaf_one": leaf("poseidon_leaves_kernel", "one state per lane: the trees of more than 2^16 leaves (G1 / G2 at n = 128); launches with <= 4 columns are copies (hash_or_noop) and are counted in `launches` of this kernel name only if the kernel was launched for them"),
+    "leaf_pair": leaf("poseidon_leaves_pair_kernel", "two lanes per state: the thin Fq12 trees"),
+    "valu_insts_per_instance": tot / steps_profiled,
+}
+NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel",
+       "tree_gather_kernel", "tree_pass_kernel")
 out["ntt"] = {"kernels": {k: {"launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"]}
                           for k in NTT if nf.get(k, 0)},
               "traffic_bytes_per_instance": sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / steps_profiled,
               "note": "all NTT / LDE kernels of one n = 128 instance (4 instances profiled: 1 warm-up + 2 timed steps + the serial step); FETCH_SIZE x2"}
 out["merkle"] = {k: nf.get(k, 0) // steps_profiled for k in ("merkle_subtree_kernel", "merkle_level_kernel", "merkle_level_quad_kernel") if nf.get(k, 0)}
-import os
-if os.path.exists("%s/pmc_v/run_counter_collection.csv" % src):
-    v, nv = counters("pmc_v")
-    tot = sum(x["SQ_INSTS_VALU"] for x in v.values())
-    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
-               "instances_profiled": steps_profiled, "valu_insts_per_instance": tot / steps_profiled,
-               "per_kernel": {k: {"SQ_INSTS_VALU_per_instance": x["SQ_INSTS_VALU"] / steps_profiled, "share": x["SQ_INSTS_VALU"] / tot,
-                                  "launches_per_instance": nv[k] / steps_profiled}
-                              for k, x in sorted(v.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]) if x["SQ_INSTS_VALU"] > 0}},
-              open(dst + "_valu_by_kernel.json", "w"), indent=1)
-    out["leaf_valu_insts_per_launch"] = sum(v[k]["SQ_INSTS_VALU"] for k in leaf) / max(1, sum(nv.get(k, 0) for k in leaf))
-    out["leaf_valu_note"] = "SQ_INSTS_VALU (wave-level VALU instructions) of both leaf-hash kernels, bench.py --steps 2 --warmup 1, per launch"
-i, ni = counters("pmc_i")
-out["valu"] = {"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -- python3 scripts/perf_generic.py 16 1024",
-               "per_kernel": {k: {"SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "SQ_WAVES": v["SQ_WAVES"], "dispatches": ni[k],
-                                  "valu_insts_per_wave": v["SQ_INSTS_VALU"] / max(1.0, v["SQ_WAVES"])}
-                              for k, v in i.items() if v["SQ_WAVES"] > 0 and not k.startswith("at::") and not k.startswith("__amd")}}
+json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
+           "instances_profiled": steps_profiled, "valu_insts_per_instance": tot / steps_profiled,
+           "per_kernel": {k: {"SQ_INSTS_VALU_per_instance": x["SQ_INSTS_VALU"] / steps_profiled, "share": x["SQ_INSTS_VALU"] / tot,
+                              "launches_per_instance": nv[k] / steps_profiled}
+                          for k, x in sorted(v.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]) if x["SQ_INSTS_VALU"] > 0}},
+          open(dst + "_valu_by_kernel.json", "w"), indent=1)
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])

@@ -29,29 +29,31 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
     const uint64_t* p = lde + j;
-    if (ncols <= 4) {
-        for (uint32_t c = 0; c < ncols; c++) {
-            uint64_t v = p[(size_t)c * col_stride];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (q == (int)c) s[q] = v;
-        }
-    } else {
-        // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
+    // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
 #pragma unroll 1
-        for (uint32_t c = 0; c < ncols; c += 8) {
-            const uint32_t m = ncols - c;  // wave-uniform
+    for (uint32_t c = 0; c < ncols; c += 8) {
+        const uint32_t m = ncols - c;  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
-            poseidon::permute(s);
-        }
+        for (int i = 0; i < 8; i++)
+            if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
+        poseidon::permute(s);
     }
     uint64_t* d = digests + 4 * j;
     d[0] = s[0];
     d[1] = s[1];
     d[2] = s[2];
     d[3] = s[3];
+}
+
+// hash_or_noop: leaves of at most four elements are not hashed, the "digest" is the zero-padded leaf itself (the quotient chunks at
+// blowup 2).  A kernel of its own: a copy, in no launch count or launch average of the hash kernel
+__global__ void __launch_bounds__(256) poseidon_leaves_copy_kernel(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t ncols,
+                                                                  uint64_t n_leaves, uint64_t* __restrict__ digests) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    uint64_t* d = digests + 4 * j;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) d[q] = q < ncols ? lde[j + (size_t)q * col_stride] : 0;
 }
 
 // ---- four lanes per state (poseidon_quad.cuh): thin launches ----
@@ -440,14 +442,21 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     uint64_t n = (uint64_t)1 << log_leaves;
     // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
     // park 4 waves on one CU and leave three quarters of the CUs idle
-    ProfScope ps(ctx, "poseidon_leaves");
+    // profile names: "poseidon_leaves" = one state per lane (the dominant kernel: every tree of > 2^16 leaves); the thin trees'
+    // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
+    static const int thin_lanes_p = sipp_env_int("SIPP_THIN_LANES", 2);
+    const bool thin = ncols > 4 && n <= quad_threshold() && n >= (thin_lanes_p == 2 ? 32 : 16);
+    ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : !thin ? "poseidon_leaves" : thin_lanes_p == 2 ? "poseidon_leaves_pair" : "poseidon_leaves_quad");
     // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.cuh, the default since round 2) costs
     // 33.1 k lane-instructions per permutation against 39.5 k for four and is SLOWER alone (2^13 x 4096 columns: 19.1 ms against
     // 12.0 ms: 37 us per sequential permutation instead of 23 us) but FASTER where it matters, beside the other two proofs: the
     // instance is bound by total instruction issue (68.5 ms against 70.5-70.8 ms single, 61.1 against 63.6-63.9 ms with three
     // instances in flight).  SIPP_THIN_LANES=4 restores the four-lane kernel.
     static const int thin_lanes = sipp_env_int("SIPP_THIN_LANES", 2);
-    if (thin_lanes == 2 && ncols > 4 && n >= 32 && n <= quad_threshold()) {
+    if (ncols <= 4) {
+        hipLaunchKernelGGL(poseidon_leaves_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_lde, col_stride,
+                           (uint32_t)ncols, n, d_digests);
+    } else if (thin_lanes == 2 && ncols > 4 && n >= 32 && n <= quad_threshold()) {
         unsigned grid = (unsigned)((2 * n + 255) / 256);
         hipLaunchKernelGGL(poseidon_leaves_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
                            (uint32_t)ncols, n, d_digests);

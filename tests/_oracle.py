@@ -46,6 +46,8 @@ def load():
         "orc_batch_leaves": (C.POINTER(C.c_uint64), [C.c_void_p]),
         "orc_batch_coeffs": (C.POINTER(C.c_uint64), [C.c_void_p]),
         "orc_batch_level": (C.POINTER(C.c_uint64), [C.c_void_p, C.c_uint, C.POINTER(C.c_size_t)]),
+        "orc_set_num_threads": (None, [C.c_int]),
+        "orc_get_max_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -53,6 +55,14 @@ def load():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def set_num_threads(n):
+    """OpenMP threads of the oracle's parallel regions; returns what the runtime will really use (OMP_NUM_THREADS set after the
+    OpenMP runtime was loaded -- e.g. after `import torch` -- is ignored, this is not)"""
+    L = load()
+    L.orc_set_num_threads(int(n))
+    return int(L.orc_get_max_threads())
 
 
 def rand_field(rng, shape):

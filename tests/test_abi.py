@@ -95,3 +95,116 @@ def test_host_poseidon_implementations_agree_with_the_oracle():
         if L.sipp_host_poseidon_permute(got.ctypes.data, got.shape[0], impl) == 0:
             assert (got == want).all(), impl
     assert L.sipp_host_poseidon_permute(states.ctypes.data, 1, 7) != 0
+
+
+# ---- rust_shim/src/ffi.rs against include/sipp_hip.h (the shim cannot be compiled here: no Rust toolchain) ----------------------
+_STRUCTS = {"sipp_ctx": "SippCtxOpaque", "sipp_stark_config": "SippStarkConfig", "sipp_fri_params": "SippFriParams",
+            "sipp_oracle": "SippOracle", "sipp_poly_range": "SippPolyRange", "sipp_fri_batch": "SippFriBatch",
+            "sipp_challenger": "SippChallenger"}
+_SCALARS = {"int": "c_int", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "char": "c_char", "void": "c_void"}
+
+
+def _c_to_rust(ctype):
+    """one C parameter / field / return type (declarator stripped of its name) -> the Rust spelling ffi.rs must use"""
+    t = ctype.strip()
+    arr = re.search(r"\[\s*(\w*)\s*\]$", t)          # parameter arrays decay to pointers
+    if arr:
+        t = t[: arr.start()].strip() + " *"
+    toks = re.findall(r"\*|\w+", t)
+    base_const = False
+    base = None
+    i = 0
+    while i < len(toks) and toks[i] != "*":
+        if toks[i] == "const":
+            base_const = True
+        else:
+            base = toks[i]
+        i += 1
+    rust = _SCALARS.get(base) or _STRUCTS[base]
+    cur_const = base_const
+    while i < len(toks):                               # every '*' wraps what is left of it; a 'const' after it qualifies the pointer
+        assert toks[i] == "*"
+        rust = ("*const " if cur_const else "*mut ") + rust
+        cur_const = False
+        i += 1
+        while i < len(toks) and toks[i] == "const":
+            cur_const = True
+            i += 1
+    if rust == "c_void":
+        return "()"
+    return rust
+
+
+def _split_decl(decl):
+    """'const uint32_t *const ios[3]' -> (type, name)"""
+    decl = decl.strip()
+    m = re.match(r"^(.*?)(\w+)\s*(\[\s*\w*\s*\])?$", decl, flags=re.S)
+    return (m.group(1) + (m.group(3) or "")).strip(), m.group(2)
+
+
+def _header_api():
+    txt = open(os.path.join(ROOT, "include", "sipp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = "\n".join(l for l in txt.splitlines() if not l.strip().startswith("#"))
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", txt, flags=re.S):
+        fields = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            first_type, first_name = _split_decl(stmt.split(",")[0])
+            base = re.sub(r"\[.*\]$", "", first_type).strip()
+            for part in stmt.split(","):
+                part = part.strip()
+                t, n = (first_type, first_name) if part == stmt.split(",")[0].strip() else _split_decl(base + " " + part)
+                dim = re.search(r"\[\s*(\w+)\s*\]$", t)
+                if dim:
+                    fields.append((n, "[%s; %s]" % (_c_to_rust(t[: dim.start()]), dim.group(1))))
+                else:
+                    fields.append((n, _c_to_rust(t)))
+        structs[name] = fields
+    txt = re.sub(r"typedef\s+(struct|enum)\s*\{.*?\}\s*\w+\s*;", "", txt, flags=re.S)
+    txt = re.sub(r"typedef\s+struct\s+\w+\s+\w+\s*;", "", txt)
+    funcs = {}
+    for ret, name, args in re.findall(r"([\w\s\*]+?)\b(sipp_\w+)\s*\(([^)]*)\)\s*;", txt, flags=re.S):
+        params = [] if args.strip() in ("", "void") else [_split_decl(a) for a in args.split(",")]
+        funcs[name] = ([(n, _c_to_rust(t)) for t, n in params], _c_to_rust(ret))
+    return structs, funcs
+
+
+def _rust_api():
+    txt = open(os.path.join(ROOT, "rust_shim", "src", "ffi.rs")).read()
+    txt = re.sub(r"//[^\n]*", "", txt)
+    structs = {}
+    for name, body in re.findall(r"pub struct (\w+)\s*\{(.*?)\}", txt, flags=re.S):
+        structs[name] = [(n, " ".join(t.split())) for n, t in re.findall(r"pub\s+(\w+)\s*:\s*([^,\n]+),", body)]
+    ext = re.search(r'extern "C"\s*\{(.*)\}', txt, flags=re.S).group(1)
+    funcs = {}
+    for name, args, ret in re.findall(r"pub fn (\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", ext, flags=re.S):
+        params = []
+        for a in [x for x in args.split(",") if x.strip()]:
+            n, t = a.split(":", 1)
+            params.append((n.strip().replace("r#", ""), " ".join(t.split())))
+        funcs[name] = (params, " ".join(ret.split()) if ret else "()")
+    return structs, funcs
+
+
+def test_rust_bindings_match_the_header():
+    """every function of include/sipp_hip.h is bound in rust_shim/src/ffi.rs with the same parameter names, order and types and
+    the same return type; every struct has the same fields in the same order; nothing is bound that the header does not declare"""
+    c_structs, c_funcs = _header_api()
+    r_structs, r_funcs = _rust_api()
+    assert sorted(c_funcs) == declared_symbols()
+    assert sorted(r_funcs) == sorted(c_funcs), (sorted(set(c_funcs) - set(r_funcs)), sorted(set(r_funcs) - set(c_funcs)))
+    for name, (params, ret) in c_funcs.items():
+        assert r_funcs[name] == (params, ret), (name, r_funcs[name], (params, ret))
+    assert len(c_structs) == 6
+    for cname, fields in c_structs.items():
+        rfields = r_structs[_STRUCTS[cname]]
+        want = [(n, t.replace("SIPP_FRI_MAX_ROUNDS", "SIPP_FRI_MAX_ROUNDS")) for n, t in fields]
+        assert rfields == want, (cname, rfields, want)
+    # the shim's safe layer calls only what ffi.rs binds
+    lib_rs = open(os.path.join(ROOT, "rust_shim", "src", "lib.rs")).read()
+    used = set(re.findall(r"ffi::(sipp_\w+)", lib_rs))
+    assert used and used <= set(r_funcs), used - set(r_funcs)

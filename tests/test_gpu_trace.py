@@ -34,6 +34,29 @@ def test_trace_matches_oracle(ctx, ios4, kind):
     assert bad.size == 0, "first mismatches (col,row): %s" % bad[:8].tolist()
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_trace_matches_oracle_at_n128_cell_for_cell(kind):
+    """the BASELINE size: G1 / G2 at N = 2^16 use the u16-table variant of the AIR (one checked cell per limb), which carries 85 % of
+    the n = 128 work and is otherwise pinned only through whole-proof digests.  Every cell of the device trace against the oracle's
+    (644 / 1278 columns x 2^16 rows; Fq12: 4942 x 2^13, the u8 variant); a mismatch names its first (column, row) cells."""
+    import sipp_amd
+    from sipp_amd._lib import to_host
+    d = np.load("tests/golden/sipp_n128_ios.npz")
+    ios = d[("g1", "g2", "fq12")[kind]]
+    ref = _oracle.Trace(kind, ios)
+    assert ref.air.table_bits == (16 if kind < 2 else 8)
+    c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(kind, ios.shape[0]))
+    try:
+        got = to_host(c.trace_build(kind, ios))
+    finally:
+        c.close()
+    want = ref.array()
+    assert got.shape == want.shape == (ref.width, 1 << (16 if kind < 2 else 13))
+    if not (got == want).all():
+        bad = np.argwhere(got != want)
+        raise AssertionError("%d cells differ; first (col,row): %s" % (len(bad), bad[:8].tolist()))
+
+
 def test_shape_matches_oracle_air(ctx, ios4):
     for kind in (0, 1, 2):
         ref = _oracle.Trace(kind, ios4[kind])
