@@ -21,6 +21,8 @@ const orc_air_t *orc_air_get(int kind, unsigned log_n);
 int orc_air_width(const orc_air_t *a);
 size_t orc_air_num_constraints(const orc_air_t *a);
 orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *err);
+int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io);
+void orc_test_forge(int flags);   /* test hook, see air.c */
 void orc_trace_free(orc_trace *t);
 long orc_trace_check_row(const orc_trace *t, size_t row);
 

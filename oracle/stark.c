@@ -377,6 +377,9 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     int rc = 0;
     gl2 *op = NULL, *auxz = NULL;
     if (!orc_pis_canonical(kind, pis, num_io)) { free(pis); return -108; }
+    /* the statement is about group elements (src/verifier_circuit.rs:92-124): a prover that skipped its own curve check must not
+     * get a proof about points of another curve accepted (the row constraints alone are satisfiable for any two points) */
+    if (!orc_records_on_curve(kind, pis, num_io)) { free(pis); return -109; }
     orc_challenger ch;
     orc_chal_init(&ch);
     observe_statement(&ch, kind, log_n, num_io, W, P, Q, cfg, a->pi_per_io, pis);

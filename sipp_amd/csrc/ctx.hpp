@@ -168,22 +168,9 @@ inline int sipp_env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// Host wait for a stream.  The provers wait a dozen times per proof (caps, openings, FRI layers, queries) with the transcript
-// on the host in between; SIPP_SYNC_SPIN=1 polls hipStreamQuery instead of blocking in hipStreamSynchronize (the wake-up of a
-// blocked thread is tens of microseconds; every ctx has its own host thread, so spinning costs one core per proof in flight).
-// Measured (n = 128, same box, alternating): 61.5-61.7 ms against 61.8-62.0 ms single, 56.4-56.7 against 57.1-57.4 ms queued --
-// inside the box-to-box spread; off by default.
-inline hipError_t sipp_sync_stream(hipStream_t s) {
-    static const int spin = sipp_env_int("SIPP_SYNC_SPIN", 0);
-    if (!spin) return (hipStreamSynchronize)(s);
-    for (;;) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
-        __builtin_ia32_pause();
-    }
-}
-#define hipStreamSynchronize(s) sipp_sync_stream(s)
-
+// (Round 2 had a SIPP_SYNC_SPIN knob that replaced hipStreamSynchronize by a hipStreamQuery poll through a macro of the same name:
+// it measured inside the box-to-box spread -- 61.5-61.7 against 61.8-62.0 ms -- burned a core per ctx and shadowed a HIP API name;
+// removed.)
 struct ProfScope {
     sipp_ctx* ctx;
     const char* name;

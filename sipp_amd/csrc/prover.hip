@@ -912,7 +912,7 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
     const size_t zblock = (size_t)256 * zr;
     const unsigned nblk = (unsigned)(n / zblock);
     if (n % zblock) return sipp_fail(ctx, SIPP_E_BADARG, "z_columns: n must be a multiple of 1024");
-    ArenaMark mk = arena_mark(ctx);
+    ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)P * nblk);
     if (!totals) return SIPP_E_NOMEM;
     {
@@ -933,7 +933,6 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
             hipLaunchKernelGGL(z_phase_c<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
-    arena_release(ctx, mk);
     return SIPP_OK;
 }
 
@@ -996,7 +995,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
         }
     }
     // segment table: offsets, kinds, alpha powers (tiny; rebuilt per proof because alpha changes)
-    ArenaMark mk = arena_mark(ctx);
+    ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     {
         std::vector<uint32_t> off, cnt;
         std::vector<int> ncons;
@@ -1075,7 +1074,6 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
         hipLaunchKernelGGL(quotient_rest_kernel, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
-    arena_release(ctx, mk);
     return SIPP_OK;
 }
 
@@ -1127,7 +1125,7 @@ int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uin
 
 int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,
                      int n1, gl::E2 shift1, const uint64_t* d_zp[2], const uint64_t* d_zip[2], uint64_t* d_final) {
-    ArenaMark mk = arena_mark(ctx);
+    ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     // enough (block, slice) pairs to fill the chip: short traces with many columns (Fq12) get more slices
     int slices = 8;
     while (slices < 64 && (n / 256) * (size_t)slices < 2048) slices *= 2;
@@ -1159,14 +1157,13 @@ int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[
         hipLaunchKernelGGL(fri_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, q, n, shift1, d_final);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
-    arena_release(ctx, mk);
     return SIPP_OK;
 }
 
 // (F(X) - F(z)) / (X - z) of the composition F = sum_j alpha^j col_j of one generic batch, then acc = acc * shift + quotient
 int sipp_k_fri_batch_quotient(sipp_ctx* ctx, const uint64_t* const* d_cols, int total, size_t n, const uint32_t* d_apow3,
                               const uint64_t* d_zp, const uint64_t* d_zip, gl::E2 shift, bool first, uint64_t* d_acc) {
-    ArenaMark mk = arena_mark(ctx);
+    ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     int slices = 1;
     while (slices < 64 && ((n / 256) * (size_t)slices < 1024 || (total + slices - 1) / slices > 1024)) slices *= 2;
     if ((total + slices - 1) / slices > 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri: more than 65536 polynomials in one batch");
@@ -1195,7 +1192,6 @@ int sipp_k_fri_batch_quotient(sipp_ctx* ctx, const uint64_t* const* d_cols, int 
         hipLaunchKernelGGL(fri_accum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_acc, q, n, shift, first ? 1 : 0);
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
-    arena_release(ctx, mk);
     return SIPP_OK;
 }
 int sipp_k_fri_mulx(sipp_ctx* ctx, const uint64_t* d_acc, size_t n, uint64_t* d_final) {

@@ -911,6 +911,8 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
 int sipp_instances_prove(sipp_ctx* const* ctxs, size_t in_flight, size_t count, const uint32_t* const* ios, const size_t* num_io,
                          uint64_t* const* proof_out, const size_t* proof_cap, size_t* proof_len, int* status) {
     if (!ctxs || !in_flight || !ios || !num_io || !proof_out || !proof_cap || !proof_len) return SIPP_E_BADARG;
+    for (size_t i = 0; i < 3 * count; i++)
+        if (num_io[i] && (!ios[i] || !proof_out[i])) return SIPP_E_BADARG;   // a kind without records needs no buffers
     for (size_t i = 0; i < 3 * in_flight; i++) {
         if (!ctxs[i]) return SIPP_E_BADARG;
         for (size_t j = 0; j < i; j++)
@@ -932,9 +934,15 @@ int sipp_instances_prove(sipp_ctx* const* ctxs, size_t in_flight, size_t count, 
             if (rc != SIPP_OK) first_rc.compare_exchange_strong(ok, rc);
         }
     };
+    // no exception may cross the C ABI, and a joinable std::thread must not be destroyed: if a thread cannot be created (or the
+    // vector cannot grow), the threads that did start plus this one drain the queue -- fewer slots, same result
     std::vector<std::thread> pool;
     const size_t slots = in_flight < count ? in_flight : count;
-    for (size_t sl = 1; sl < slots; sl++) pool.emplace_back(worker, sl);
+    try {
+        pool.reserve(slots);
+        for (size_t sl = 1; sl < slots; sl++) pool.emplace_back(worker, sl);
+    } catch (...) {
+    }
     if (slots) worker(0);
     for (auto& t : pool) t.join();
     return first_rc.load();

@@ -276,3 +276,30 @@ def test_non_canonical_field_elements_are_refused():
     twin = gpf.copy()
     twin[small[0]] = np.uint64(int(gpf[small[0]]) + P)
     assert _oracle.fri_verify_openings(twin, *args, _oracle.challenger([1])) != 0
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_records_off_the_curve_are_refused_by_the_verifier_too(ios4, kind):
+    """the prover refuses records whose points are not on the curve, but the row constraints are the chord / tangent
+    FORMULAS, which any two points satisfy -- a prover that skips its own check can commit to a complete, constraint-satisfying
+    trace about points of another curve.  Through the oracle's test hook (orc_test_forge) such a trace is built and proved; every
+    row constraint holds; the verifier refuses the proof with its own curve check (-109) and accepts the same flow for points on
+    the curve."""
+    L = _oracle.load()
+    L.orc_test_forge.argtypes = [__import__("ctypes").c_int]
+    rec = ios4[kind][:1].copy()
+    w = 8 * (kind + 1)
+    try:
+        L.orc_test_forge(3)
+        good = _oracle.Trace(kind, rec)                       # outputs taken from the chain: the honest record again
+        assert (np.ctypeslib.as_array(good.p.contents.pis, shape=(rec.shape[1],)) == rec[0]).all()
+        assert _prove_verify(good) == 0
+        bad_rec = rec.copy()
+        bad_rec[0, w] ^= 2                                    # y of the base point: not on y^2 = x^3 + 3 any more
+        t = _oracle.Trace(kind, bad_rec)
+        assert all(t.check_row(r) == -1 for r in range(1024))                          # every row of the forged trace satisfies the AIR
+        assert _prove_verify(t) == -109
+    finally:
+        L.orc_test_forge(0)
+    with pytest.raises(RuntimeError):                         # without the hook the prover side refuses as before
+        _oracle.Trace(kind, bad_rec)
