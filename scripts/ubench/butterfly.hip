@@ -28,7 +28,7 @@ __device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v, uint64_t s) {
         u = gll::add_nc(a, w);
         v = gll::sub_nc(a, w);
     } else {
-        const uint64_t w = gll::canon(gll::mul_nc(v, s)), a = u;
+        const uint64_t w = gll::canon(gll::mul_nc_vop2(v, s)), a = u;
         u = gll::add_nc(a, w);
         v = gll::sub_nc(a, w);
     }

@@ -5,6 +5,9 @@
 //                                              ntt_tree.hip (6.65 against 6.66 ms): they are not bound by the product's instruction count
 //   two products interleaved per block (mul2_nc3)           1.60 T: the single block is not latency-bound
 #pragma once
+#ifndef GLL_T
+#define GLL_T 100
+#endif
 #include "gl_lazy.cuh"
 
 namespace gll {
@@ -14,7 +17,7 @@ namespace gll {
 //     lo + 2^64 hi  ==  lo - hh + hl (2^32 - 1)      (hi = hh 2^32 + hl;  2^64 = 2^32 - 1,  2^96 = -1  mod p)
 // are ONE chain of fourteen VOP2 instructions with the carry in VCC: a borrow of lo - hh is repaid by - (2^32 - 1), a carry of the
 // final addition by + (2^32 - 1); neither correction can wrap again (the bounds are plonky2's reduce128).
-__device__ __forceinline__ uint64_t mul_nc(uint64_t a, uint64_t b) {
+__device__ __forceinline__ uint64_t mul_nc_vop2(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t0 = (uint64_t)a0 * b0;
     const uint64_t t1 = (uint64_t)a0 * b1 + (t0 >> 32);
@@ -44,56 +47,6 @@ __device__ __forceinline__ uint64_t mul_nc(uint64_t a, uint64_t b) {
 // What the instructions cost on gfx950 (scripts/ubench/enc_rates.hip): everything with a carry-out, a third operand or 64 bits --
 // v_add_co, v_addc, v_cndmask, v_cmp_*_u64, v_lshl_add_u64 AND v_mad_u64_u32 -- takes ~1.7x the issue time of a plain 32-bit VOP2
 // (v_add_u32, v_sub_u32, shifts, logic, v_mov); the encoding (VOP2 with VCC against VOP3 with an SGPR pair) makes no difference.
-// ---- the product as ONE hand-scheduled block ------------------------------------------------------------------------------
-// The compiler's code for the sequences above carries ~31 instructions per product (it rebuilds every zero-extended 64-bit addend
-// of v_mad_u64_u32 with moves, splits 64-bit additions, and selects through SGPR pairs); the block below has 18.  Inline asm
-// cannot name the halves of a 64-bit operand, so the 64-bit temporaries are FIXED physical registers listed as clobbers
-// (GLL_T = first of ten consecutive VGPRs, even): v[T:T+1] .. v[T+6:T+7] are the four partial products, v[T+8:T+9] is the
-// zero-extended addend (its high half is zeroed in every block: the compiler may use the registers between two blocks).
-//   t0 = a0 b0;  t1 = a0 b1 + hi(t0);  t2 = a1 b0 + lo(t1);  hi = a1 b1 + hi(t1) + hi(t2);  lo = (lo(t0), lo(t2))
-//   T  = lo(hi) (2^32 - 1) + lo        carry c      (one multiply-add: 2^64 = 2^32 - 1 mod p)
-//   T += c (2^32 - 1)                  cannot wrap: T < (2^32 - 1)^2 after a carry
-//   T -= hi(hi)                        borrow b     (2^96 = -1 mod p; no borrow after a carry: T >= 2^32 - 1 >= hi(hi) then)
-//   T += b p                           = T - (2^32 - 1) mod 2^64, cannot wrap
-#ifndef GLL_T
-#define GLL_T 100
-#endif
-#define GLL_STR2(x) #x
-#define GLL_STR(x) GLL_STR2(x)
-#define GLL_V(i) "v" GLL_STR(GLL_T + i)
-#define GLL_P(i) "v[" GLL_STR(GLL_T + i) ":" GLL_STR(GLL_T + i + 1) "]"
-}  // namespace gll
-// the assembler evaluates "v100 + 1"-style expressions only inside brackets: spell the register numbers out with the preprocessor
-#include "gl_mul_regs.inc"
-namespace gll {
-
-__device__ __forceinline__ uint64_t mul_nc3(uint64_t a, uint64_t b) {
-    uint64_t r;
-    asm("v_mov_b32_e32 " GLL_R9 ", 0\n\t"
-        "v_mad_u64_u32 " GLL_P0 ", vcc, %1, %3, 0\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R1 "\n\t"
-        "v_mad_u64_u32 " GLL_P2 ", vcc, %1, %4, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R2 "\n\t"
-        "v_mad_u64_u32 " GLL_P4 ", vcc, %2, %3, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R3 "\n\t"
-        "v_mad_u64_u32 " GLL_P6 ", vcc, %2, %4, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R5 "\n\t"
-        "v_lshl_add_u64 " GLL_P6 ", " GLL_P6 ", 0, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R1 ", " GLL_R4 "\n\t"
-        "v_mad_u64_u32 " GLL_P2 ", vcc, " GLL_R6 ", -1, " GLL_P0 "\n\t"
-        "v_subb_co_u32_e32 " GLL_R8 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"     /* -c (carry-in reads of VCC need no wait states) */
-        "v_lshl_add_u64 " GLL_P2 ", " GLL_P2 ", 0, " GLL_P8 "\n\t"
-        "v_sub_co_u32_e32 " GLL_R2 ", vcc, " GLL_R2 ", " GLL_R7 "\n\t"
-        "v_subbrev_co_u32_e32 " GLL_R3 ", vcc, 0, " GLL_R3 ", vcc\n\t"
-        "v_subb_co_u32_e32 " GLL_R5 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"     /* -b */
-        "v_lshrrev_b32_e32 " GLL_R4 ", 31, " GLL_R5 "\n\t"
-        "v_lshl_add_u64 %0, " GLL_P2 ", 0, " GLL_P4
-        : "=v"(r)
-        : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32))
-        : "vcc", GLL_R0, GLL_R1, GLL_R2, GLL_R3, GLL_R4, GLL_R5, GLL_R6, GLL_R7, GLL_R8, GLL_R9);
-    return r;
-}
-
 // two independent products in one block, interleaved instruction by instruction (twenty fixed temporaries): one product alone is a
 // single dependent chain of 19 instructions, which a SIMD with three or four resident waves cannot hide
 __device__ __forceinline__ void mul2_nc3(uint64_t& r, uint64_t& q, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {

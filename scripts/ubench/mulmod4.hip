@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) k(const uint64_t* in, uint64_t* out, int 
             for (int q = 0; q < 8; q += 2) gll::mul2_nc3(x[q], x[q + 1], x[q], s, x[q + 1], s);
         } else
 #pragma unroll
-        for (int q = 0; q < 8; q++) x[q] = V == 0 ? gl::mul_nc(x[q], s) : V == 1 ? gll::mul_nc(x[q], s) : gll::mul_nc3(x[q], s);
+        for (int q = 0; q < 8; q++) x[q] = V == 0 ? gl::mul_nc(x[q], s) : V == 1 ? gll::mul_nc_vop2(x[q], s) : gll::mul_nc(x[q], s);
         s += 0x9E3779B97F4A7C15ull;
     }
     for (int q = 0; q < 8; q++) out[8 * i + q] = gl::canon(x[q]);

@@ -23,6 +23,7 @@
 //  * the round loops are NOT unrolled (code stays inside the instruction cache); the per-lane loops are.
 #pragma once
 #include "gl.hpp"
+#include "gl_lazy.cuh"
 #include "poseidon_constants.h"
 
 namespace poseidon {
@@ -37,12 +38,32 @@ __constant__ uint32_t c_blk3[2 * SIPP_POSEIDON_BLK_WORDS];
 __constant__ uint32_t c_comb3[396];
 __constant__ uint64_t c_comb_c[12];
 
+// S-box products: the hand-scheduled block of gl_lazy.cuh when the translation unit reserves its temporaries (GLL_T), the compiler's
+// sequence otherwise (-DSIPP_POSEIDON_C_MUL keeps the latter for A/B runs)
+#if defined(GLL_T) && !defined(SIPP_POSEIDON_C_MUL)
+#define SIPP_PMUL gll::mul_nc
+#else
+#define SIPP_PMUL gl::mul_nc
+#endif
+// the two- and four-lanes-per-state kernels (two waves per SIMD, latency-bound): the compiler's products interleave across the
+// state elements, the fixed-register blocks cannot -- measured slower there (pair kernel 35.5 against 32 ms per n = 128 instance)
+#ifdef SIPP_POSEIDON_THIN_ASM_MUL
+#define SIPP_PMUL_THIN SIPP_PMUL
+#else
+#define SIPP_PMUL_THIN gl::mul_nc
+#endif
+__device__ __forceinline__ uint64_t sbox_thin(uint64_t x) {
+    uint64_t x2 = SIPP_PMUL_THIN(x, x);
+    uint64_t x3 = SIPP_PMUL_THIN(x2, x);
+    uint64_t x4 = SIPP_PMUL_THIN(x2, x2);
+    return SIPP_PMUL_THIN(x3, x4);
+}
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
-    uint64_t x2 = gl::mul_nc(x, x);
-    uint64_t x3 = gl::mul_nc(x2, x);
-    uint64_t x4 = gl::mul_nc(x2, x2);
-    return gl::mul_nc(x3, x4);
+    uint64_t x2 = SIPP_PMUL(x, x);
+    uint64_t x3 = SIPP_PMUL(x2, x);
+    uint64_t x4 = SIPP_PMUL(x2, x2);
+    return SIPP_PMUL(x3, x4);
 }
 
 // out[r] = sum_i s[(i + r) % 12] * CIRC[i] + s[r] * DIAG[r] (+ add[r]),  CIRC = 17 15 41 16 2 28 13 13 39 18 34 20, DIAG[0] = 8.

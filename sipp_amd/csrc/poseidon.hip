@@ -7,6 +7,9 @@
 // consecutive u64 of one column per load (512 B, fully coalesced) and no transpose ever exists.
 // Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
 #include "ctx.hpp"
+// ten VGPRs for the 64-bit temporaries of the hand-scheduled Goldilocks product (gl_lazy.cuh): v140 .. v149 keep the one-state-per-lane
+// leaf kernel at 150 VGPRs (152 without; its budget is 168 = three waves per SIMD)
+#define GLL_T 140
 #include "poseidon.cuh"
 #include "poseidon_quad.cuh"
 #include "poseidon_pair.cuh"

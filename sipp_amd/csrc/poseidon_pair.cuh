@@ -88,7 +88,7 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[6], const uint32
     constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const uint32_t e0 = 6 * h;
 #pragma unroll
-    for (int j = 0; j < 6; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * 3 + e0 + j]));
+    for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * 3 + e0 + j]));
     Gathered g;
     gather(s, g);
     const uint32_t* C3 = blk + B_COMB3;
@@ -146,9 +146,9 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint
         uint64_t s0 = pair_bcast0(s[0]);
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const uint64_t x2 = gl::mul_nc(s0, s0);
-            const uint64_t y = gl::mul_nc(x2, h ? x2 : s0);
-            const uint64_t x = gl::add_nc(gl::mul_nc(y, pair_swap(y)), tab[T_SCALAR + B * b + k]);
+            const uint64_t x2 = SIPP_PMUL_THIN(s0, s0);
+            const uint64_t y = SIPP_PMUL_THIN(x2, h ? x2 : s0);
+            const uint64_t x = gl::add_nc(SIPP_PMUL_THIN(y, pair_swap(y)), tab[T_SCALAR + B * b + k]);
             xl[k] = (uint32_t)x;
             xh[k] = (uint32_t)(x >> 32);
             const uint32_t* Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
@@ -194,7 +194,7 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const u
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
+        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
         mds_full(s, diag0);
     }
     full_round3_combined(s, h, tab, blk);
@@ -202,7 +202,7 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const u
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
+        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
         mds_full(s, diag0);
     }
 #pragma unroll

@@ -107,7 +107,7 @@ __device__ __forceinline__ void permute(uint64_t s[3], const uint32_t q, const u
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
+        for (int j = 0; j < 3; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
         mds_full(s, diag0);
     }
     // ---- partial rounds, sparse form ----
@@ -139,7 +139,7 @@ __device__ __forceinline__ void permute(uint64_t s[3], const uint32_t q, const u
 #pragma unroll 1
     for (int r = 0; r < 22; r++) {
         // x = sbox(element 0) + scalar, computed by every lane on its s[0], taken from lane 0
-        uint64_t x = gl::add_nc(poseidon::sbox(s[0]), tab[T_SCALAR + r]);
+        uint64_t x = gl::add_nc(poseidon::sbox_thin(s[0]), tab[T_SCALAR + r]);
         x = quad_bcast0(x);
         poseidon::Acc160 acc;
 #pragma unroll
@@ -163,7 +163,7 @@ __device__ __forceinline__ void permute(uint64_t s[3], const uint32_t q, const u
 #pragma unroll 1
     for (int r = 26; r < 30; r++) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) s[j] = poseidon::sbox(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
+        for (int j = 0; j < 3; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
         mds_full(s, diag0);
     }
 #pragma unroll
