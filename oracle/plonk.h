@@ -1,0 +1,59 @@
+/*
+ * oracle/plonk.h -- CPU restatement of the WIRE PERMUTATION ARGUMENT of plonky2's outer prover: what `data.prove(pw)` at reference
+ * src/verifier_circuit.rs:253 runs between the wires commitment and the opening proof -- plonk/prover.rs
+ * `wires_permutation_partial_products_and_zs`, plonk/vanishing_poly.rs `eval_vanishing_poly_base_batch` (its Z(1) = 1 and
+ * partial-product terms), `compute_quotient_polys`, plonk/plonk_common.rs (`quotient_chunk_products`, `partial_products_and_z_gx`,
+ * `check_partial_products`, `reduce_with_powers`), plonk/verifier.rs' check of the quotient at zeta.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED: plonky2 @ InternetMaximalism/plonky2 541e127 is not vendored (reference Cargo.toml:21), the
+ * sequence is restated from its published structure; a second, independent reading lives in oracle/py/plonky2_generic.py.
+ * The GATE constraints of the reference's circuit are not part of this (the circuit is built by un-vendored crates): wires and sigmas
+ * are the caller's data, any `num_routed_wires`, chunk size (= quotient degree factor, a power of two) and `num_challenges`.
+ */
+#ifndef ORACLE_PLONK_H
+#define ORACLE_PLONK_H
+#include "fri.h"
+
+typedef struct {
+    uint32_t num_routed_wires;   /* CircuitConfig::num_routed_wires (80 in standard_recursion_config) */
+    uint32_t max_degree;         /* quotient_degree_factor = chunk size of the partial products (8); a power of two >= 2 */
+    uint32_t num_challenges;     /* CircuitConfig::num_challenges (2) */
+} orc_plonk_params;
+
+static inline uint32_t orc_plonk_num_prods(const orc_plonk_params *p) {   /* CommonCircuitData::num_partial_products */
+    return (p->num_routed_wires + p->max_degree - 1) / p->max_degree - 1;
+}
+static inline uint32_t orc_plonk_zs_cols(const orc_plonk_params *p) { return p->num_challenges * (1 + orc_plonk_num_prods(p)); }
+
+/* k_is = get_unique_coset_shifts: 7^j */
+uint64_t orc_plonk_k_i(uint32_t j);
+/* sigma polynomial VALUES for a wire permutation: sigma[j][i] = k_{col'} w^{row'} where (col', row') = perm[j * N + i] (index col' * N + row') */
+void orc_plonk_sigmas_from_perm(const uint32_t *perm, uint32_t num_routed, unsigned log_n, uint64_t *sigmas);
+
+/* wires [R][N], sigmas [R][N] values in natural order -> out [C (1 + num_prods)][N] values: Z_0 .. Z_{C-1}, then the partial products of
+ * challenge 0, of challenge 1, ... (the column order of the zs_partial_products commitment) */
+void orc_plonk_zs_partial_products(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p,
+                                   const uint64_t *betas, const uint64_t *gammas, uint64_t *out);
+
+/* compute_quotient_polys for the permutation terms: coefficient arrays in, [C max_degree][N] coefficient chunks out (chunk d of
+ * challenge c at row c max_degree + d).  Returns -1 if a quotient does not fit max_degree N coefficients (constraints violated). */
+int orc_plonk_quotient_chunks(const uint64_t *wires_c, const uint64_t *sigmas_c, const uint64_t *zs_c, unsigned log_n,
+                              const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                              uint64_t *out);
+
+/* the verifier's side: vanishing terms at an extension point from opened values, reduced with the powers of every alpha */
+void orc_plonk_eval_vanishing(gl2 x, const gl2 *wires, const gl2 *sigmas, const gl2 *zs, const gl2 *zs_next, const gl2 *pps,
+                              unsigned log_n, const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas,
+                              const uint64_t *alphas, gl2 *out);
+
+/* the whole flow as a flat proof:
+ *   header[8]: "SIPPPLK1", log_n, num_routed_wires, max_degree, num_challenges, total_len, 0, 0
+ *   wires cap | zs_partial_products cap | quotient cap | opening proof (orc_fri_prove_openings: zeta batch over the four oracles
+ *   sigmas, wires, zs_partial_products, quotient chunks; g zeta batch over the Z columns)
+ * Transcript: circuit_digest[4], public_inputs_hash[4], wires cap -> betas, gammas; zs cap -> alphas; quotient cap -> zeta. */
+int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p,
+                         const orc_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4],
+                         uint64_t **proof, size_t *len);
+/* sigmas_cap: the verifier's copy of the constants_sigmas commitment (part of the verifier data in plonky2) */
+int orc_plonk_perm_verify(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p,
+                          const orc_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4]);
+#endif

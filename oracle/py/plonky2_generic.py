@@ -421,3 +421,92 @@ def fri_verify_query(x_index, n_log, rate_bits, arities, alpha, batches, initial
     if eval_poly(final_poly, Ext(subgroup_x)) != old:
         return "final polynomial"
     return None
+
+
+# ---------------------------------------------------------------------------------------------------- PLONK wire permutation
+# Second reading of plonk/prover.rs (wires_permutation_partial_products_and_zs), plonk/plonk_common.rs (quotient_chunk_products,
+# partial_products_and_z_gx, check_partial_products, reduce_with_powers, eval_l_0, ZeroPolyOnCoset) and plonk/vanishing_poly.rs
+# (the Z(1) = 1 and partial-product terms of eval_vanishing_poly), in the shape of the Rust code: row-major lists, chunks, zips.
+def get_unique_coset_shifts(num_shifts):
+    return [pow(GEN, j, P) for j in range(num_shifts)]
+
+
+def quotient_chunk_products(quotient_values, max_degree):
+    out = []
+    for k in range(0, len(quotient_values), max_degree):
+        acc = 1
+        for q in quotient_values[k:k + max_degree]:
+            acc = acc * q % P
+        out.append(acc)
+    return out
+
+
+def partial_products_and_z_gx(z_x, chunk_products):
+    res, acc = [], z_x
+    for c in chunk_products:
+        acc = acc * c % P
+        res.append(acc)
+    return res
+
+
+def wires_permutation_partial_products_and_zs(wires, sigmas, beta, gamma, max_degree):
+    """wires, sigmas: [num_routed][N] value columns.  Returns the columns [partial products ..., Z] of ONE challenge (plonky2 pops the
+    last one and moves it to the front of the batch)."""
+    num_routed, n = len(wires), len(wires[0])
+    k_is = get_unique_coset_shifts(num_routed)
+    w = primitive_root_of_unity(n.bit_length() - 1)
+    rows, z_x, x = [], 1, 1
+    for i in range(n):
+        quotients = []
+        for j in range(num_routed):
+            num = (wires[j][i] + beta * k_is[j] % P * x + gamma) % P
+            den = (wires[j][i] + beta * sigmas[j][i] + gamma) % P
+            quotients.append(num * inv(den) % P)
+        row = partial_products_and_z_gx(z_x, quotient_chunk_products(quotients, max_degree))
+        z_x, row[-1] = row[-1], z_x                          # the last term is Z(g x): swapped for Z(x)
+        rows.append(row)
+        x = x * w % P
+    return [[r[c] for r in rows] for c in range(len(rows[0]))]
+
+
+def eval_l_0(n, x):
+    """L_0(x) = (x^n - 1) / (n (x - 1)) at an extension point"""
+    return (x ** n - ext(1)) * ((x - ext(1)) * ext(n % P)).inverse()
+
+
+def check_partial_products(numerators, denominators, partials, z_x, z_gx, max_degree):
+    accs = [z_x] + list(partials)
+    nexts = list(partials) + [z_gx]
+    out = []
+    for k, (prev, nxt) in enumerate(zip(accs, nexts)):
+        num = den = ext(1)
+        for v in numerators[k * max_degree:(k + 1) * max_degree]:
+            num = num * v
+        for v in denominators[k * max_degree:(k + 1) * max_degree]:
+            den = den * v
+        out.append(prev * num - nxt * den)
+    return out
+
+
+def eval_vanishing_poly_permutation(n_log, x, wires, sigmas, zs, zs_next, partial_products, betas, gammas, alphas, max_degree):
+    """the permutation terms of eval_vanishing_poly at the extension point x from opened values, reduced with the powers of every alpha:
+    vanishing_z_1_terms ++ vanishing_partial_products_terms (no gates: the circuit is not vendored)"""
+    num_routed, num_ch = len(wires), len(betas)
+    num_prods = len(partial_products) // num_ch
+    k_is = get_unique_coset_shifts(num_routed)
+    l_0 = eval_l_0(1 << n_log, x)
+    z1_terms, pp_terms = [], []
+    for i in range(num_ch):
+        z1_terms.append(l_0 * (zs[i] - ext(1)))
+        numerators = [wires[j] + x * ext(betas[i] * k_is[j] % P) + ext(gammas[i]) for j in range(num_routed)]
+        denominators = [wires[j] + sigmas[j] * ext(betas[i]) + ext(gammas[i]) for j in range(num_routed)]
+        pp_terms += check_partial_products(numerators, denominators, partial_products[i * num_prods:(i + 1) * num_prods], zs[i], zs_next[i],
+                                           max_degree)
+    terms = z1_terms + pp_terms
+    out = []
+    for a in alphas:                                             # reduce_with_powers
+        acc = ext(0)
+        for t in reversed(terms):
+            acc = acc * ext(a) + t
+        out.append(acc)
+    return out

@@ -366,3 +366,96 @@ def fri_verify_openings(proof, caps, ncols, n_salt, batches, log_n, params, ch):
     barr = make_batches(batches)
     proof = np.ascontiguousarray(proof, dtype=np.uint64)
     return L.orc_fri_verify_openings(proof, len(proof), cp, nc, ns, len(caps), barr, len(batches), log_n, C.byref(params), C.byref(ch))
+
+
+# ---------------- plonky2's wire permutation argument (oracle/plonk.c) ----------------
+class OrcPlonkParams(C.Structure):
+    _fields_ = [("num_routed_wires", C.c_uint32), ("max_degree", C.c_uint32), ("num_challenges", C.c_uint32)]
+
+
+def plonk_params(num_routed_wires=80, max_degree=8, num_challenges=2):
+    return OrcPlonkParams(num_routed_wires, max_degree, num_challenges)
+
+
+def plonk_num_prods(p):
+    return (p.num_routed_wires + p.max_degree - 1) // p.max_degree - 1
+
+
+def plonk_zs_cols(p):
+    return p.num_challenges * (1 + plonk_num_prods(p))
+
+
+def _plonk_lib():
+    L = load()
+    if not getattr(L, "_plonk_sigs", False):
+        pp = C.POINTER(OrcPlonkParams)
+        L.orc_plonk_sigmas_from_perm.argtypes = [u32p, C.c_uint32, C.c_uint, u64p]
+        L.orc_plonk_zs_partial_products.argtypes = [u64p, u64p, C.c_uint, pp, u64p, u64p, u64p]
+        L.orc_plonk_quotient_chunks.argtypes = [u64p, u64p, u64p, C.c_uint, pp, u64p, u64p, u64p, u64p]
+        L.orc_plonk_quotient_chunks.restype = C.c_int
+        L.orc_plonk_perm_prove.argtypes = [u64p, u64p, C.c_uint, pp, C.POINTER(OrcFriParams), u64p, u64p, C.POINTER(C.POINTER(C.c_uint64)),
+                                           C.POINTER(C.c_size_t)]
+        L.orc_plonk_perm_prove.restype = C.c_int
+        L.orc_plonk_perm_verify.argtypes = [u64p, C.c_size_t, u64p, pp, C.POINTER(OrcFriParams), u64p, u64p]
+        L.orc_plonk_perm_verify.restype = C.c_int
+        L._plonk_sigs = True
+    return L
+
+
+def plonk_random_instance(seed, log_n, num_routed, n_cycles=None):
+    """wires [R][N] that satisfy the copy constraints of a random wire permutation, and that permutation's sigma VALUES:
+    positions (column j, row i) <-> index j N + i; the permutation is a product of random cycles, wires are constant on cycles"""
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    total = num_routed * n
+    order = rng.permutation(total).astype(np.uint32)
+    n_cycles = n_cycles or max(1, total // 3)
+    cuts = np.sort(rng.choice(np.arange(1, total), size=min(n_cycles - 1, total - 1), replace=False)) if total > 1 else np.array([], dtype=int)
+    perm = np.empty(total, dtype=np.uint32)
+    vals = np.empty(total, dtype=np.uint64)
+    start = 0
+    for end in list(cuts) + [total]:
+        cyc = order[start:end]
+        perm[cyc] = np.roll(cyc, -1)                       # sigma maps each position to the next one of its cycle
+        vals[cyc] = rand_field(rng, (1,))[0]
+        start = end
+    sig = np.zeros((num_routed, n), dtype=np.uint64)
+    _plonk_lib().orc_plonk_sigmas_from_perm(perm, num_routed, log_n, sig.reshape(-1))
+    return vals.reshape(num_routed, n).copy(), sig, perm
+
+
+def plonk_zs(wires, sigmas, log_n, p, betas, gammas):
+    out = np.zeros((plonk_zs_cols(p), 1 << log_n), dtype=np.uint64)
+    _plonk_lib().orc_plonk_zs_partial_products(np.ascontiguousarray(wires).reshape(-1), np.ascontiguousarray(sigmas).reshape(-1), log_n, C.byref(p),
+                                               np.asarray(betas, dtype=np.uint64), np.asarray(gammas, dtype=np.uint64), out.reshape(-1))
+    return out
+
+
+def plonk_quotient_chunks(wires_c, sigmas_c, zs_c, log_n, p, betas, gammas, alphas):
+    out = np.zeros((p.num_challenges * p.max_degree, 1 << log_n), dtype=np.uint64)
+    rc = _plonk_lib().orc_plonk_quotient_chunks(np.ascontiguousarray(wires_c).reshape(-1), np.ascontiguousarray(sigmas_c).reshape(-1),
+                                                np.ascontiguousarray(zs_c).reshape(-1), log_n, C.byref(p), np.asarray(betas, dtype=np.uint64),
+                                                np.asarray(gammas, dtype=np.uint64), np.asarray(alphas, dtype=np.uint64), out.reshape(-1))
+    if rc:
+        raise RuntimeError("orc_plonk_quotient_chunks: %d" % rc)
+    return out
+
+
+def plonk_perm_prove(wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
+    L = _plonk_lib()
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    rc = L.orc_plonk_perm_prove(np.ascontiguousarray(wires).reshape(-1), np.ascontiguousarray(sigmas).reshape(-1), log_n, C.byref(p), C.byref(fp),
+                                np.asarray(digest, dtype=np.uint64), np.asarray(pih, dtype=np.uint64), C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError("orc_plonk_perm_prove: %d" % rc)
+    pf = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_free(out)
+    return pf
+
+
+def plonk_perm_verify(proof, sigmas_cap, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    return _plonk_lib().orc_plonk_perm_verify(proof, len(proof), np.ascontiguousarray(sigmas_cap, dtype=np.uint64).reshape(-1), C.byref(p), C.byref(fp),
+                                              np.asarray(digest, dtype=np.uint64), np.asarray(pih, dtype=np.uint64))

@@ -1,0 +1,118 @@
+"""plonky2's wire permutation argument (oracle/plonk.c: Z and partial products, the permutation terms of the vanishing polynomial,
+quotient chunks, the verifier's check at zeta) on synthetic wires / sigmas -- SURVEY.md section 8f rank 2, the protocol-generic part of
+`data.prove` (reference src/verifier_circuit.rs:253) that needs no circuit.  CPU only."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+
+P = _oracle.P
+
+
+def fri(log_n, rate_bits=3, cap_height=2, nq=6, arity=3, fpb=3):
+    return _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_height, pow_bits=6, num_queries=nq, pow_rule=0, hiding=0, arity_bits=arity,
+                              final_poly_bits=fpb, degree_bits=log_n)
+
+
+@pytest.mark.parametrize("log_n,R,D,C", [(6, 80, 8, 2), (5, 13, 4, 3), (7, 9, 2, 1), (6, 16, 8, 2)])
+def test_partial_products_close_and_the_proof_verifies(log_n, R, D, C):
+    """Z starts at 1 and every chunk relation holds on every row (the column order Z_0 .. Z_{C-1}, then the partial products per
+    challenge); the whole flow proves and verifies for 80 routed wires in chunks of 8 (standard_recursion_config: 9 partial products
+    per challenge, blowup 8), for a ragged last chunk (13 wires in chunks of 4), chunk size 2, and one or three challenges"""
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, perm = _oracle.plonk_random_instance(40 + log_n + R, log_n, R)
+    n = 1 << log_n
+    rng = np.random.default_rng(1)
+    betas, gammas = _oracle.rand_field(rng, (C,)), _oracle.rand_field(rng, (C,))
+    zs = _oracle.plonk_zs(wires, sig, log_n, p, betas, gammas)
+    npd = _oracle.plonk_num_prods(p)
+    assert zs.shape == (C * (1 + npd), n) and (zs[:C, 0] == 1).all()
+    # python big-int check of row 3 of challenge C - 1: prev * prod(num) == next * prod(den) chunk by chunk, Z(g x) closes the row
+    c, i = C - 1, 3
+    w = pow(7, (P - 1) >> log_n, P)
+    x = pow(w, i, P)
+    accs = [int(zs[c, i])] + [int(zs[C + c * npd + q, i]) for q in range(npd)] + [int(zs[c, (i + 1) % n])]
+    for q in range(npd + 1):
+        num = den = 1
+        for j in range(q * D, min((q + 1) * D, R)):
+            num = num * ((int(wires[j, i]) + int(betas[c]) * pow(7, j, P) * x + int(gammas[c])) % P) % P
+            den = den * ((int(wires[j, i]) + int(betas[c]) * int(sig[j, i]) + int(gammas[c])) % P) % P
+        assert accs[q] * num % P == accs[q + 1] * den % P, q
+    fp = fri(log_n, rate_bits=max(3, D.bit_length() - 1))
+    pf = _oracle.plonk_perm_prove(wires, sig, log_n, p, fp)
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=fp.rate_bits, cap_height=fp.cap_height).cap
+    assert _oracle.plonk_perm_verify(pf, sig_cap, p, fp) == 0
+    # tampering: an opened value, a cap word, another circuit digest
+    bad = pf.copy()
+    bad[8 + 3 * 4 * (1 << fp.cap_height) + 8 + 5] ^= 1
+    assert _oracle.plonk_perm_verify(bad, sig_cap, p, fp) != 0
+    bad = pf.copy()
+    bad[9] ^= 1
+    assert _oracle.plonk_perm_verify(bad, sig_cap, p, fp) != 0
+    assert _oracle.plonk_perm_verify(pf, sig_cap, p, fp, digest=(1, 2, 3, 5)) != 0
+
+
+def test_a_broken_copy_constraint_is_refused():
+    """one wire changed so that two positions of a cycle disagree: Z does not return to 1 and the verifier's identity at zeta fails"""
+    log_n, R, D, C = 6, 16, 8, 2
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, perm = _oracle.plonk_random_instance(7, log_n, R, n_cycles=40)
+    fp = fri(log_n)
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=fp.rate_bits, cap_height=fp.cap_height).cap
+    assert _oracle.plonk_perm_verify(_oracle.plonk_perm_prove(wires, sig, log_n, p, fp), sig_cap, p, fp) == 0
+    bad = wires.copy()
+    pos = int(np.nonzero(perm != np.arange(perm.size))[0][0])        # a position inside a cycle of length > 1
+    bad.reshape(-1)[pos] = (int(bad.reshape(-1)[pos]) + 1) % P
+    assert _oracle.plonk_perm_verify(_oracle.plonk_perm_prove(bad, sig, log_n, p, fp), sig_cap, p, fp) == -210
+
+
+def test_python_reading_replays_a_c_oracle_proof():
+    """the second, independent reading (oracle/py/plonky2_generic.py, written in the shape of the Rust code): from the same wires and
+    sigmas it derives the same challenges, the same Z / partial-product COLUMNS in the same order (its zs_partial_products cap equals
+    the one in the C oracle's proof), and the verifier's identity at zeta holds on the proof's opened values with ITS evaluation of
+    the vanishing terms"""
+    from oracle.py import plonky2_generic as g2
+    log_n, R, D, C = 4, 5, 2, 2
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, _ = _oracle.plonk_random_instance(11, log_n, R)
+    fp = fri(log_n, rate_bits=2, cap_height=1, nq=3, arity=1, fpb=2)
+    pf = [int(v) for v in _oracle.plonk_perm_prove(wires, sig, log_n, p, fp, digest=(9, 8, 7, 6))]
+    cap_words = 4 << fp.cap_height
+    wcap, zcap, qcap = pf[8:8 + cap_words], pf[8 + cap_words:8 + 2 * cap_words], pf[8 + 2 * cap_words:8 + 3 * cap_words]
+    W = [[int(v) for v in row] for row in wires]
+    S = [[int(v) for v in row] for row in sig]
+    wb = g2.PolynomialBatch.from_values(W, fp.rate_bits, fp.cap_height)
+    assert sum(wb.tree.cap, []) == wcap
+    ch = g2.Challenger()
+    ch.observe_many([9, 8, 7, 6])
+    ch.observe_many([0, 0, 0, 0])
+    ch.observe_cap(wb.tree.cap)
+    betas, gammas = ch.get_n(C), ch.get_n(C)
+    per_ch = [g2.wires_permutation_partial_products_and_zs(W, S, betas[i], gammas[i], D) for i in range(C)]
+    zs_cols = [cols[-1] for cols in per_ch] + [c for cols in per_ch for c in cols[:-1]]       # Z first, then the partial products
+    zb = g2.PolynomialBatch.from_values(zs_cols, fp.rate_bits, fp.cap_height)
+    assert sum(zb.tree.cap, []) == zcap
+    ch.observe_cap(zb.tree.cap)
+    alphas = ch.get_n(C)
+    ch.observe_cap([qcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    zeta = ch.get_ext()
+    npd = _oracle.plonk_num_prods(p)
+    op = pf[8 + 3 * cap_words + 8:]
+    take = iter(range(0, 10 ** 9, 2))
+    ext_at = lambda: (lambda k: g2.Ext(op[k], op[k + 1]))(next(take))
+    sg_o = [ext_at() for _ in range(R)]
+    w_o = [ext_at() for _ in range(R)]
+    zs_o = [ext_at() for _ in range(C)]
+    pp_o = [ext_at() for _ in range(C * npd)]
+    q_o = [ext_at() for _ in range(C * D)]
+    zn_o = [ext_at() for _ in range(C)]
+    # the opened values ARE the polynomials at zeta / g zeta (python evaluation of its own coefficient columns)
+    assert zs_o[1] == g2.eval_poly([g2.ext(c) for c in zb.polynomials[1]], zeta)
+    assert zn_o[0] == g2.eval_poly([g2.ext(c) for c in zb.polynomials[0]], zeta * g2.ext(g2.primitive_root_of_unity(log_n)))
+    van = g2.eval_vanishing_poly_permutation(log_n, zeta, w_o, sg_o, zs_o, zn_o, pp_o, betas, gammas, alphas, D)
+    zeta_n = zeta ** (1 << log_n)
+    for c in range(C):
+        acc = g2.ext(0)
+        for d in reversed(range(D)):
+            acc = acc * zeta_n + q_o[c * D + d]
+        assert van[c] == (zeta_n - g2.ext(1)) * acc, c
