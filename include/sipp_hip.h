@@ -226,6 +226,41 @@ int sipp_fri_prove_openings(sipp_ctx *ctx, const sipp_oracle *oracles, size_t n_
                             size_t n_batches, uint32_t log_n, const sipp_fri_params *p, sipp_challenger *ch,
                             uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
 
+/* ---- SURVEY.md section 8f, rank 2, continued: plonky2's WIRE PERMUTATION ARGUMENT -------------------------------------------------
+ * The protocol-generic part of `data.prove(pw)` (reference src/verifier_circuit.rs:253) between the wires commitment and the opening
+ * proof: plonk/prover.rs wires_permutation_partial_products_and_zs, the Z(1) = 1 and partial-product terms of
+ * plonk/vanishing_poly.rs, compute_quotient_polys -- for any number of routed wires, chunk size (= quotient degree factor, a power
+ * of two) and number of challenges, on the caller's wires and sigma polynomials.  The GATE constraints of the reference's circuit
+ * are not part of this (the circuit is built by un-vendored crates). */
+typedef struct {
+    uint32_t num_routed_wires;   /* CircuitConfig::num_routed_wires (80 in standard_recursion_config) */
+    uint32_t max_degree;         /* quotient_degree_factor = chunk size of the partial products (8); a power of two, 2 .. 64 */
+    uint32_t num_challenges;     /* CircuitConfig::num_challenges (2); 1 .. 8 */
+} sipp_plonk_params;
+/* CommonCircuitData::num_partial_products = ceil(num_routed_wires / max_degree) - 1 */
+uint32_t sipp_plonk_num_partial_products(const sipp_plonk_params *p);
+/* d_wires, d_sigmas: [num_routed_wires][N] VALUES in natural row order (sigma[j][i] = k_col' w^row' of the wire that (j, i) maps to,
+ * k_j = 7^j); betas, gammas: num_challenges host words.  d_out [num_challenges (1 + num_partial_products)][N] values in the column order
+ * of the zs_partial_products commitment: Z_0 .. Z_{C-1}, then the partial products of challenge 0, of challenge 1, ... */
+int sipp_plonk_zs_partial_products(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *d_sigmas, uint32_t log_n,
+                                   const sipp_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, uint64_t *d_out);
+/* compute_quotient_polys for the permutation terms, from the three committed oracles' LDEs (leaf order, blowup 2^rate_bits >=
+ * max_degree; column strides N << rate_bits): d_chunks [num_challenges max_degree][N] receives the coefficient chunks (chunk d of
+ * challenge c at row c max_degree + d) -- the input of sipp_commit_batch_ex(from_coeffs = 1). */
+int sipp_plonk_quotient_chunks(sipp_ctx *ctx, const uint64_t *d_wires_lde, const uint64_t *d_sigmas_lde, const uint64_t *d_zs_lde,
+                               uint32_t log_n, uint32_t rate_bits, const sipp_plonk_params *p, const uint64_t *betas,
+                               const uint64_t *gammas, const uint64_t *alphas, uint64_t *d_chunks);
+/* The whole argument as one call: commitments of sigmas, wires, zs_partial_products and quotient chunks, the transcript
+ * (circuit_digest[4], public_inputs_hash[4], wires cap -> betas, gammas; zs cap -> alphas; quotient cap -> zeta) and one opening proof
+ * (zeta: the four oracles; g zeta: the Z columns).  Flat proof (u64 words):
+ *   header[8]: "SIPPPLK1", log_n, num_routed_wires, max_degree, num_challenges, total_len, 0, 0
+ *   wires cap | zs_partial_products cap | quotient cap | sipp_fri_prove_openings' proof
+ * The workspace must hold the four oracles (coefficients, LDE, tree each). */
+size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params *p, const sipp_fri_params *fp);
+int sipp_plonk_perm_prove(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *d_sigmas, uint32_t log_n, const sipp_plonk_params *p,
+                          const sipp_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4],
+                          uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

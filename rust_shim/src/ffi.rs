@@ -77,6 +77,14 @@ pub struct SippChallenger {
     pub n_out: u64,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkParams {
+    pub num_routed_wires: u32,
+    pub max_degree: u32,
+    pub num_challenges: u32,
+}
+
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
@@ -121,6 +129,16 @@ extern "C" {
     pub fn sipp_fri_prove_openings(ctx: *mut SippCtxOpaque, oracles: *const SippOracle, n_oracles: usize, batches: *const SippFriBatch,
                                    n_batches: usize, log_n: u32, p: *const SippFriParams, ch: *mut SippChallenger, proof_out: *mut u64,
                                    proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_plonk_num_partial_products(p: *const SippPlonkParams) -> u32;
+    pub fn sipp_plonk_zs_partial_products(ctx: *mut SippCtxOpaque, d_wires: *const u64, d_sigmas: *const u64, log_n: u32, p: *const SippPlonkParams,
+                                          betas: *const u64, gammas: *const u64, d_out: *mut u64) -> c_int;
+    pub fn sipp_plonk_quotient_chunks(ctx: *mut SippCtxOpaque, d_wires_lde: *const u64, d_sigmas_lde: *const u64, d_zs_lde: *const u64, log_n: u32,
+                                      rate_bits: u32, p: *const SippPlonkParams, betas: *const u64, gammas: *const u64, alphas: *const u64,
+                                      d_chunks: *mut u64) -> c_int;
+    pub fn sipp_plonk_perm_proof_size(log_n: u32, p: *const SippPlonkParams, fp: *const SippFriParams) -> usize;
+    pub fn sipp_plonk_perm_prove(ctx: *mut SippCtxOpaque, d_wires: *const u64, d_sigmas: *const u64, log_n: u32, p: *const SippPlonkParams,
+                                 fp: *const SippFriParams, circuit_digest: *const u64, public_inputs_hash: *const u64, proof_out: *mut u64,
+                                 proof_cap: usize, proof_len: *mut usize) -> c_int;
     pub fn sipp_ntt_batch(ctx: *mut SippCtxOpaque, d_cols: *mut u64, col_stride: usize, ncols: usize, log_n: u32, inverse: c_int) -> c_int;
     pub fn sipp_lde_batch(ctx: *mut SippCtxOpaque, d_values: *const u64, d_coeffs: *mut u64, d_lde: *mut u64, ncols: usize, log_n: u32) -> c_int;
     pub fn sipp_poseidon_leaves(ctx: *mut SippCtxOpaque, d_lde: *const u64, ncols: usize, log_leaves: u32, d_digests: *mut u64) -> c_int;

@@ -45,6 +45,10 @@ class FriBatch(C.Structure):
     _fields_ = [("point", C.c_uint64 * 2), ("n_ranges", C.c_uint32), ("ranges", C.POINTER(PolyRange))]
 
 
+class PlonkParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("num_routed_wires", "max_degree", "num_challenges")]
+
+
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
                 ("n_out", C.c_uint64)]
@@ -88,6 +92,12 @@ SIGNATURES = {
     "sipp_fri_proof_size": (C.c_size_t, [C.POINTER(Oracle), C.c_size_t, C.POINTER(FriBatch), C.c_size_t, C.c_uint32, C.POINTER(FriParams)]),
     "sipp_fri_prove_openings": (C.c_int, [vp, C.POINTER(Oracle), C.c_size_t, C.POINTER(FriBatch), C.c_size_t, C.c_uint32,
                                           C.POINTER(FriParams), C.POINTER(Challenger), vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_plonk_num_partial_products": (C.c_uint32, [C.POINTER(PlonkParams)]),
+    "sipp_plonk_zs_partial_products": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), u64p, u64p, vp]),
+    "sipp_plonk_quotient_chunks": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(PlonkParams), u64p, u64p, u64p, vp]),
+    "sipp_plonk_perm_proof_size": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams)]),
+    "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
     "sipp_lde_batch": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32]),
     "sipp_poseidon_leaves": (C.c_int, [vp, vp, C.c_size_t, C.c_uint32, vp]),
@@ -264,6 +274,39 @@ class Ctx:
         n = C.c_size_t()
         self._ck(self.L.sipp_fri_prove_openings(self.h, oa, len(oracles), ba, len(batches), log_n, C.byref(params),
                                                 C.byref(challenger), out.ctypes.data, cap, C.byref(n)), "fri_prove_openings")
+        return out[: n.value]
+
+    # ---- plonky2's wire permutation argument ----
+    @staticmethod
+    def _u64(v):
+        a = (C.c_uint64 * len(v))(*[int(x) for x in v])
+        return a
+
+    def plonk_zs(self, wires, sigmas, log_n, p, betas, gammas):
+        """sipp_plonk_zs_partial_products: wires, sigmas [R, N] device int64 -> [C (1 + num_prods), N]"""
+        import torch
+        rows = p.num_challenges * (1 + self.L.sipp_plonk_num_partial_products(C.byref(p)))
+        out = torch.empty((rows, 1 << log_n), dtype=torch.int64, device=wires.device)
+        self._ck(self.L.sipp_plonk_zs_partial_products(self.h, wires.data_ptr(), sigmas.data_ptr(), log_n, C.byref(p), self._u64(betas),
+                                                       self._u64(gammas), out.data_ptr()), "plonk_zs_partial_products")
+        return out
+
+    def plonk_quotient_chunks(self, wires_lde, sigmas_lde, zs_lde, log_n, rate_bits, p, betas, gammas, alphas):
+        import torch
+        out = torch.empty((p.num_challenges * p.max_degree, 1 << log_n), dtype=torch.int64, device=wires_lde.device)
+        self._ck(self.L.sipp_plonk_quotient_chunks(self.h, wires_lde.data_ptr(), sigmas_lde.data_ptr(), zs_lde.data_ptr(), log_n, rate_bits,
+                                                   C.byref(p), self._u64(betas), self._u64(gammas), self._u64(alphas), out.data_ptr()),
+                 "plonk_quotient_chunks")
+        return out
+
+    def plonk_perm_prove(self, wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
+        cap = self.L.sipp_plonk_perm_proof_size(log_n, C.byref(p), C.byref(fp))
+        if cap == 0:
+            raise SippError(-1, "sipp_plonk_perm_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        self._ck(self.L.sipp_plonk_perm_prove(self.h, wires.data_ptr(), sigmas.data_ptr(), log_n, C.byref(p), C.byref(fp), self._u64(digest),
+                                              self._u64(pih), out.ctypes.data, cap, C.byref(n)), "plonk_perm_prove")
         return out[: n.value]
 
     def shape(self, kind, num_io):

@@ -1,0 +1,344 @@
+// sipp_amd/csrc/plonk.hip -- plonky2's WIRE PERMUTATION ARGUMENT on the device (the protocol-generic part of
+// `data.prove(pw)` at reference src/verifier_circuit.rs:253 that needs no circuit): Z and the partial products
+// (plonk/prover.rs wires_permutation_partial_products_and_zs), the permutation terms of the vanishing polynomial reduced with the
+// powers of every alpha and divided by Z_H on the quotient coset (plonk/vanishing_poly.rs eval_vanishing_poly_base_batch,
+// compute_quotient_polys), for any number of routed wires, chunk size (= quotient degree factor, a power of two) and challenges.
+// plonky2 @ InternetMaximalism/plonky2 541e127 is not vendored: the sequence follows oracle/plonk.c (and its second reading in
+// oracle/py/plonky2_generic.py); the GATE constraints of the reference's circuit are not part of this.
+//
+// Layout: everything column-major [column][row] like the rest of the library; LDEs in leaf order, so the quotient coset
+// 7 <w_(N D)> is simply the FIRST N D leaves of a blowup-2^rate_bits LDE (leaf t = coset index bitrev(t)), and the quotient values are
+// written in leaf order, which is what the coset iNTT (bit-reversed in, natural out) reads.
+// Kernels: one lane per row (chunk quotients with ONE inversion per row and challenge: Montgomery's trick over the <= 32 chunk
+// denominators), a two-level prefix product over the rows for Z, one lane per coset point for the quotient.  All HBM-streaming with
+// O(R) products per cell read -- integer VALU bound like the STARK quotient kernels.
+#include "ctx.hpp"
+#include "prover.hpp"
+
+namespace {
+
+constexpr uint32_t MAX_CHUNKS = 32, MAX_CH = 8;
+
+struct ZsArgs {
+    const uint64_t* wires;    // [R][n]
+    const uint64_t* sigmas;   // [R][n]
+    uint32_t log_n, R, D, m, C;
+    const uint64_t* bk;       // [C][R]  beta_c 7^j
+    uint64_t beta[MAX_CH], gamma[MAX_CH];
+    uint64_t w;               // primitive n-th root
+    uint64_t* chunk;          // [C][m][n]   quotient_chunk_products
+    uint64_t* tot;            // [C][n]      product of a row's chunks = Z(g x) / Z(x)
+};
+
+__global__ void __launch_bounds__(256) plonk_chunk_kernel(ZsArgs a) {
+    const uint32_t n = 1u << a.log_n, i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (i >= n) return;
+    const uint64_t x = gl::pow(a.w, i), beta = a.beta[c], gamma = a.gamma[c];
+    const uint64_t* bk = a.bk + (size_t)c * a.R;
+    uint64_t num[MAX_CHUNKS], pre[MAX_CHUNKS];   // chunk numerators; prefix products of the chunk denominators
+    uint64_t run = 1;
+#pragma unroll 1
+    for (uint32_t q = 0; q < a.m; q++) {
+        uint64_t nu = 1, de = 1;
+        const uint32_t j1 = min((q + 1) * a.D, a.R);
+        for (uint32_t j = q * a.D; j < j1; j++) {
+            const uint64_t wv = a.wires[(size_t)j * n + i];
+            nu = gl::mul(nu, gl::add(gl::add(wv, gl::mul(bk[j], x)), gamma));
+            de = gl::mul(de, gl::add(gl::add(wv, gl::mul(beta, a.sigmas[(size_t)j * n + i])), gamma));
+        }
+        num[q] = nu;
+        pre[q] = run;                 // product of the denominators before chunk q
+        run = gl::mul(run, de);
+        // keep the denominator itself in `chunk` for the backward sweep
+        a.chunk[((size_t)c * a.m + q) * n + i] = de;
+    }
+    uint64_t inv = gl::inv(run), t = 1;
+#pragma unroll 1
+    for (uint32_t q = a.m; q-- > 0;) {
+        uint64_t* cell = a.chunk + ((size_t)c * a.m + q) * n + i;
+        const uint64_t de = *cell;
+        const uint64_t qv = gl::mul(num[q], gl::mul(inv, pre[q]));   // num_q / den_q
+        inv = gl::mul(inv, de);
+        *cell = qv;
+        t = gl::mul(t, qv);
+    }
+    a.tot[(size_t)c * n + i] = t;
+}
+
+// exclusive prefix product over the rows: one block per challenge, every thread owns n / 1024 consecutive rows
+__global__ void __launch_bounds__(1024) plonk_scan_kernel(const uint64_t* tot, uint64_t* zs, uint32_t log_n) {
+    __shared__ uint64_t part[1024];
+    const uint32_t n = 1u << log_n, c = blockIdx.x, T = blockDim.x;
+    const uint32_t per = (n + T - 1) / T, lo = threadIdx.x * per, hi = min(lo + per, n);
+    const uint64_t* t = tot + (size_t)c * n;
+    uint64_t* z = zs + (size_t)c * n;
+    uint64_t acc = 1;
+    for (uint32_t i = lo; i < hi; i++) acc = gl::mul(acc, t[i]);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < T; d <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partial products
+        const uint64_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 1;
+        __syncthreads();
+        part[threadIdx.x] = gl::mul(part[threadIdx.x], v);
+        __syncthreads();
+    }
+    acc = threadIdx.x ? part[threadIdx.x - 1] : 1;
+    for (uint32_t i = lo; i < hi; i++) {
+        z[i] = acc;                                   // Z(w^i) = product of the rows before i; Z(1) = 1
+        acc = gl::mul(acc, t[i]);
+    }
+}
+
+__global__ void __launch_bounds__(256) plonk_pp_kernel(const uint64_t* chunk, uint64_t* out, uint32_t log_n, uint32_t m, uint32_t C) {
+    const uint32_t n = 1u << log_n, i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, np = m - 1;
+    if (i >= n) return;
+    uint64_t acc = out[(size_t)c * n + i];
+    for (uint32_t q = 0; q < np; q++) {
+        acc = gl::mul(acc, chunk[((size_t)c * m + q) * n + i]);
+        out[((size_t)C + (size_t)c * np + q) * n + i] = acc;
+    }
+}
+
+struct QuotArgs {
+    const uint64_t* wl;       // [R][stride]  leaf order
+    const uint64_t* sl;
+    const uint64_t* zl;       // [C (1 + np)][stride]
+    size_t stride;            // n << rate_bits
+    uint32_t log_n, rate_bits, log_d, R, D, m, C;
+    const uint64_t* bk;       // [C][R]
+    uint64_t beta[MAX_CH], gamma[MAX_CH], alpha[MAX_CH];
+    uint64_t w_nd;            // primitive (n D)-th root
+    uint64_t zh_inv[64];      // 1 / (x^n - 1) by coset index mod D
+    uint64_t zh[64];
+    uint64_t n_field;         // n as a field element
+    uint64_t* qv;             // [C][n D]  leaf order of the quotient coset
+};
+
+__global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
+    const uint32_t lq = a.log_n + a.log_d, nd = 1u << lq, pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= nd) return;
+    const uint32_t L = a.log_n + a.rate_bits;
+    const uint32_t i = gl::bitrev(pos, lq);                              // coset index: x = 7 w^i
+    const uint32_t nat = gl::bitrev(pos, L);                             // natural index in the blowup-2^rate_bits LDE
+    const uint32_t pos_next = gl::bitrev((nat + (1u << a.rate_bits)) & ((1u << L) - 1), L);   // g x: D steps on the coset
+    const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_nd, i));
+    const uint64_t zh = a.zh[i & (a.D - 1)], zhi = a.zh_inv[i & (a.D - 1)];
+    const uint64_t l0 = gl::mul(zh, gl::inv(gl::mul(a.n_field, gl::sub(x, 1))));
+    const uint32_t np = a.m - 1, C = a.C;
+    uint64_t acc[MAX_CH], apow[MAX_CH];
+#pragma unroll
+    for (uint32_t c = 0; c < MAX_CH; c++) acc[c] = 0, apow[c] = 1;
+    auto push = [&](uint64_t term) {                                     // reduce_with_powers: sum_k alpha^k term_k, for every alpha
+#pragma unroll
+        for (uint32_t c = 0; c < MAX_CH; c++)
+            if (c < C) {
+                acc[c] = gl::add(acc[c], gl::mul(apow[c], term));
+                apow[c] = gl::mul(apow[c], a.alpha[c]);
+            }
+    };
+    for (uint32_t c = 0; c < C; c++) push(gl::mul(l0, gl::sub(a.zl[(size_t)c * a.stride + pos], 1)));   // L_0(x) (Z(x) - 1)
+    for (uint32_t c = 0; c < C; c++) {
+        const uint64_t* bk = a.bk + (size_t)c * a.R;
+        uint64_t prev = a.zl[(size_t)c * a.stride + pos];
+        for (uint32_t q = 0; q < a.m; q++) {
+            uint64_t nu = 1, de = 1;
+            const uint32_t j1 = min((q + 1) * a.D, a.R);
+            for (uint32_t j = q * a.D; j < j1; j++) {
+                const uint64_t wv = a.wl[(size_t)j * a.stride + pos];
+                nu = gl::mul(nu, gl::add(gl::add(wv, gl::mul(bk[j], x)), a.gamma[c]));
+                de = gl::mul(de, gl::add(gl::add(wv, gl::mul(a.beta[c], a.sl[(size_t)j * a.stride + pos])), a.gamma[c]));
+            }
+            const uint64_t next = q == np ? a.zl[(size_t)c * a.stride + pos_next] : a.zl[((size_t)C + (size_t)c * np + q) * a.stride + pos];
+            push(gl::sub(gl::mul(prev, nu), gl::mul(next, de)));         // check_partial_products
+            prev = next;
+        }
+    }
+    for (uint32_t c = 0; c < C; c++) a.qv[(size_t)c * nd + pos] = gl::mul(acc[c], zhi);
+}
+
+int check(sipp_ctx* ctx, const sipp_plonk_params* p, uint32_t log_n, uint32_t* log_d, uint32_t* m) {
+    if (!p || p->num_routed_wires == 0 || p->num_challenges == 0 || log_n < 1 || log_n > 24) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: bad parameters");
+    uint32_t ld = 0;
+    while ((1u << ld) < p->max_degree) ld++;
+    if (p->max_degree < 2 || (1u << ld) != p->max_degree || ld > 6)
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: the chunk size (quotient degree factor) must be a power of two in 2 .. 64");
+    const uint32_t chunks = (p->num_routed_wires + p->max_degree - 1) / p->max_degree;
+    if (chunks > MAX_CHUNKS || p->num_challenges > MAX_CH)
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: at most 32 chunks of routed wires and 8 challenges");
+    *log_d = ld;
+    *m = chunks;
+    return SIPP_OK;
+}
+
+// beta_c 7^j on the device (released with the caller's arena scope)
+uint64_t* upload_bk(sipp_ctx* ctx, const sipp_plonk_params* p, const uint64_t* betas) {
+    const uint32_t R = p->num_routed_wires, C = p->num_challenges;
+    std::vector<uint64_t> h((size_t)C * R);
+    uint64_t k = 1;
+    for (uint32_t j = 0; j < R; j++) {
+        for (uint32_t c = 0; c < C; c++) h[(size_t)c * R + j] = gl::mul(gl::canon(betas[c]), k);
+        k = gl::mul(k, gl::GEN);
+    }
+    uint64_t* d = arena_alloc_t<uint64_t>(ctx, h.size());
+    if (!d) return nullptr;
+    if (hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)   // `h` goes out of scope
+        return nullptr;
+    return d;
+}
+
+}  // namespace
+
+uint32_t sipp_plonk_num_partial_products(const sipp_plonk_params* p) {
+    if (!p || p->max_degree == 0 || p->num_routed_wires == 0) return 0;
+    return (p->num_routed_wires + p->max_degree - 1) / p->max_degree - 1;
+}
+
+int sipp_plonk_zs_partial_products(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
+                                   const uint64_t* betas, const uint64_t* gammas, uint64_t* d_out) {
+    if (!ctx || !d_wires || !d_sigmas || !betas || !gammas || !d_out) return SIPP_E_BADARG;
+    uint32_t log_d, m;
+    SIPP_TRY(check(ctx, p, log_n, &log_d, &m));
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    ArenaScope scope(ctx);
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t C = p->num_challenges;
+    ZsArgs a{};
+    a.wires = d_wires; a.sigmas = d_sigmas; a.log_n = log_n; a.R = p->num_routed_wires; a.D = p->max_degree; a.m = m; a.C = C;
+    a.w = gl::root_of_unity(log_n);
+    for (uint32_t c = 0; c < C; c++) { a.beta[c] = gl::canon(betas[c]); a.gamma[c] = gl::canon(gammas[c]); }
+    a.bk = upload_bk(ctx, p, betas);
+    a.chunk = arena_alloc_t<uint64_t>(ctx, (size_t)C * m * n);
+    a.tot = arena_alloc_t<uint64_t>(ctx, (size_t)C * n);
+    if (!a.bk || !a.chunk || !a.tot) return SIPP_E_NOMEM;
+    {
+        ProfScope ps(ctx, "plonk_zs");
+        hipLaunchKernelGGL(plonk_chunk_kernel, dim3((unsigned)((n + 255) / 256), C), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(plonk_scan_kernel, dim3(C), dim3(1024), 0, ctx->stream, a.tot, d_out, log_n);
+        hipLaunchKernelGGL(plonk_pp_kernel, dim3((unsigned)((n + 255) / 256), C), dim3(256), 0, ctx->stream, a.chunk, d_out, log_n, m, C);
+    }
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return sipp_sync(ctx);   // the scratch goes back with the scope
+}
+
+int sipp_plonk_quotient_chunks(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
+                               uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas,
+                               const uint64_t* alphas, uint64_t* d_chunks) {
+    if (!ctx || !d_wires_lde || !d_sigmas_lde || !d_zs_lde || !betas || !gammas || !alphas || !d_chunks) return SIPP_E_BADARG;
+    uint32_t log_d, m;
+    SIPP_TRY(check(ctx, p, log_n, &log_d, &m));
+    if (rate_bits < log_d || rate_bits > 3) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: the blowup must cover the quotient degree factor (and be <= 8)");
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    ArenaScope scope(ctx);
+    const size_t n = (size_t)1 << log_n, nd = n << log_d;
+    const uint32_t C = p->num_challenges;
+    QuotArgs a{};
+    a.wl = d_wires_lde; a.sl = d_sigmas_lde; a.zl = d_zs_lde; a.stride = n << rate_bits;
+    a.log_n = log_n; a.rate_bits = rate_bits; a.log_d = log_d; a.R = p->num_routed_wires; a.D = p->max_degree; a.m = m; a.C = C;
+    for (uint32_t c = 0; c < C; c++) { a.beta[c] = gl::canon(betas[c]); a.gamma[c] = gl::canon(gammas[c]); a.alpha[c] = gl::canon(alphas[c]); }
+    a.w_nd = gl::root_of_unity(log_n + log_d);
+    a.n_field = (uint64_t)n;
+    {   // x^n = 7^n w_D^(i mod D) on the coset
+        const uint64_t g_n = gl::pow(gl::GEN, (uint64_t)n), w_d = gl::root_of_unity(log_d);
+        uint64_t f = g_n;
+        for (uint32_t d = 0; d < p->max_degree; d++) {
+            a.zh[d] = gl::sub(f, 1);
+            a.zh_inv[d] = gl::inv(a.zh[d]);
+            f = gl::mul(f, w_d);
+        }
+    }
+    a.bk = upload_bk(ctx, p, betas);
+    if (!a.bk) return SIPP_E_NOMEM;
+    a.qv = d_chunks;           // [C][n D]: values in leaf order, transformed in place
+    {
+        ProfScope ps(ctx, "plonk_quotient");
+        hipLaunchKernelGGL(plonk_quotient_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    }
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    // coset_ifft(7): leaf-order values -> natural coefficients; [C][n D] natural == [C D][n] chunks
+    SIPP_TRY(sipp_ntt_dit(ctx, d_chunks, nd, log_n + log_d, C, true, NttDiag{gl::inv(gl::GEN), 0}));
+    return sipp_sync(ctx);
+}
+
+// the flow of oracle/plonk.c::orc_plonk_perm_prove on the device: four PolynomialBatch commitments, the transcript on the host, one
+// opening proof at zeta / g zeta.  Flat proof: header[8] | wires cap | zs_partial_products cap | quotient cap | opening proof.
+int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
+                          const sipp_fri_params* fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4],
+                          uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !d_wires || !d_sigmas || !fp || !circuit_digest || !public_inputs_hash || !proof_out || !proof_len) return SIPP_E_BADARG;
+    uint32_t log_d, m;
+    SIPP_TRY(check(ctx, p, log_n, &log_d, &m));
+    if (fp->rate_bits < log_d || fp->rate_bits > 3 || fp->cap_height > 8 || fp->hiding)
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: blowup 2^rate_bits >= quotient degree factor, <= 8, unsalted oracles");
+    SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    ArenaScope scope(ctx);
+    const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = C * m;
+    const size_t n = (size_t)1 << log_n, M = n << fp->rate_bits, cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
+    const uint32_t ncols[4] = {R, R, nz, C * D};
+    uint64_t *co[4], *lde[4], *tree[4];
+    for (int o = 0; o < 4; o++) {
+        co[o] = arena_alloc_t<uint64_t>(ctx, (size_t)ncols[o] * n);
+        lde[o] = arena_alloc_t<uint64_t>(ctx, (size_t)ncols[o] * M);
+        tree[o] = arena_alloc_t<uint64_t>(ctx, 2 * M * 4);
+        if (!co[o] || !lde[o] || !tree[o]) return SIPP_E_NOMEM;
+    }
+    std::vector<uint64_t> caps(4 * cap_n * 4);
+    auto cap_of = [&](int o) { return caps.data() + (size_t)o * cap_n * 4; };
+    SIPP_TRY(sipp_commit_batch_ex(ctx, d_sigmas, 0, co[0], lde[0], tree[0], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(0)));
+    SIPP_TRY(sipp_commit_batch_ex(ctx, d_wires, 0, co[1], lde[1], tree[1], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(1)));
+    host::Challenger ch;
+    ch.observe_many(circuit_digest, 4);
+    ch.observe_many(public_inputs_hash, 4);
+    ch.observe_many(cap_of(1), cap_n * 4);
+    uint64_t betas[MAX_CH], gammas[MAX_CH], alphas[MAX_CH];
+    for (uint32_t c = 0; c < C; c++) betas[c] = ch.get();
+    for (uint32_t c = 0; c < C; c++) gammas[c] = ch.get();
+    {
+        uint64_t* zs = arena_alloc_t<uint64_t>(ctx, (size_t)nz * n);
+        if (!zs) return SIPP_E_NOMEM;
+        SIPP_TRY(sipp_plonk_zs_partial_products(ctx, d_wires, d_sigmas, log_n, p, betas, gammas, zs));
+        SIPP_TRY(sipp_commit_batch_ex(ctx, zs, 0, co[2], lde[2], tree[2], nz, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(2)));
+    }
+    ch.observe_many(cap_of(2), cap_n * 4);
+    for (uint32_t c = 0; c < C; c++) alphas[c] = ch.get();
+    SIPP_TRY(sipp_plonk_quotient_chunks(ctx, lde[1], lde[0], lde[2], log_n, fp->rate_bits, p, betas, gammas, alphas, co[3]));
+    SIPP_TRY(sipp_commit_batch_ex(ctx, co[3], 1, co[3], lde[3], tree[3], (size_t)C * D, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(3)));
+    ch.observe_many(cap_of(3), cap_n * 4);
+    const gl::E2 zeta = ch.get_ext();
+    sipp_oracle oracles[4];
+    for (int o = 0; o < 4; o++) oracles[o] = sipp_oracle{co[o], lde[o], tree[o], ncols[o], 0};
+    const sipp_poly_range r0[4] = {{0, 0, R}, {1, 0, R}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
+    const gl::E2 gz = gl::scale(zeta, gl::root_of_unity(log_n));
+    sipp_fri_batch batches[2] = {{{zeta.c0, zeta.c1}, 4, r0}, {{gz.c0, gz.c1}, 1, r1}};
+    const size_t op_cap = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
+    const size_t head = 8 + 3 * cap_n * 4;
+    if (op_cap == 0) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: FRI parameters do not fit the degree");
+    if (proof_cap < head + op_cap) return sipp_fail(ctx, SIPP_E_BUFSZ, "plonk: proof buffer too small (see sipp_plonk_perm_proof_size)");
+    sipp_challenger cs{};
+    memcpy(cs.state, ch.state, sizeof cs.state);
+    memcpy(cs.in_buf, ch.in_buf, sizeof cs.in_buf);
+    memcpy(cs.out_buf, ch.out_buf, sizeof cs.out_buf);
+    cs.n_in = ch.n_in;
+    cs.n_out = ch.n_out;
+    size_t op_len = 0;
+    SIPP_TRY(sipp_fri_prove_openings(ctx, oracles, 4, batches, 2, log_n, fp, &cs, proof_out + head, proof_cap - head, &op_len));
+    const uint64_t h[8] = {0x314b4c5050504953ULL /* "SIPPPLK1" */, log_n, R, D, C, head + op_len, 0, 0};
+    memcpy(proof_out, h, sizeof h);
+    memcpy(proof_out + 8, cap_of(1), cap_n * 32);
+    memcpy(proof_out + 8 + cap_n * 4, cap_of(2), cap_n * 32);
+    memcpy(proof_out + 8 + 2 * cap_n * 4, cap_of(3), cap_n * 32);
+    *proof_len = head + op_len;
+    return SIPP_OK;
+}
+
+size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params* p, const sipp_fri_params* fp) {
+    if (!p || !fp || p->max_degree == 0) return 0;
+    const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = C * ((R + D - 1) / D);
+    const size_t cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
+    sipp_oracle oracles[4] = {{nullptr, nullptr, nullptr, R, 0}, {nullptr, nullptr, nullptr, R, 0}, {nullptr, nullptr, nullptr, nz, 0},
+                              {nullptr, nullptr, nullptr, C * D, 0}};
+    const sipp_poly_range r0[4] = {{0, 0, R}, {1, 0, R}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
+    sipp_fri_batch batches[2] = {{{0, 0}, 4, r0}, {{0, 0}, 1, r1}};
+    const size_t op = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
+    return op ? 8 + 3 * cap_n * 4 + op : 0;
+}

@@ -1,0 +1,99 @@
+"""plonky2's wire permutation argument through the C ABI (sipp_plonk_zs_partial_products, sipp_plonk_quotient_chunks,
+sipp_plonk_perm_prove) against oracle/plonk.c: Z and partial-product columns, quotient coefficient chunks and the complete flat
+proof identical word for word; the oracle's verifier accepts the device's proof.  SURVEY.md section 8f rank 2, the protocol-generic part
+of `data.prove` (reference src/verifier_circuit.rs:253) that needs no circuit."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+from tests.test_gpu_fri_generic import to_params
+from tests.test_oracle_plonk import fri
+
+pytestmark = pytest.mark.gpu
+
+# log_n, routed wires, chunk size (quotient degree factor), challenges, rate_bits
+CONFIGS = [
+    (10, 80, 8, 2, 3),      # standard_recursion_config: 80 routed wires, 9 partial products per challenge, blowup 8
+    (12, 80, 8, 2, 3),
+    (10, 13, 4, 3, 2),      # ragged last chunk, three challenges, blowup 4
+    (11, 9, 2, 1, 1),       # chunk size 2, one challenge, blowup 2
+    (10, 135, 8, 2, 3),     # all 135 wires of the standard configuration routed: 17 chunks
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sipp_amd
+    c = sipp_amd.Ctx(workspace_bytes=3 << 30)
+    yield c
+    c.close()
+
+
+def dev(a):
+    from sipp_amd._lib import to_device
+    return to_device(a)
+
+
+def host(t):
+    from sipp_amd._lib import to_host
+    return to_host(t)
+
+
+@pytest.mark.parametrize("log_n,R,D,C,rate_bits", CONFIGS)
+def test_zs_quotient_and_whole_proof_match_the_oracle(ctx, log_n, R, D, C, rate_bits):
+    import sipp_amd
+    op = _oracle.plonk_params(R, D, C)
+    gp = sipp_amd.PlonkParams(R, D, C)
+    wires, sig, _ = _oracle.plonk_random_instance(900 + log_n + R, log_n, R)
+    rng = np.random.default_rng(3)
+    betas, gammas, alphas = (_oracle.rand_field(rng, (C,)) for _ in range(3))
+    d_w, d_s = dev(wires), dev(sig)
+    # Z and the partial products, every cell
+    ref_zs = _oracle.plonk_zs(wires, sig, log_n, op, betas, gammas)
+    got_zs = ctx.plonk_zs(d_w, d_s, log_n, gp, betas, gammas)
+    assert (host(got_zs) == ref_zs).all()
+    # quotient chunks from the committed LDEs against the oracle's from coefficients
+    cap_h = 2
+    _, _, (wc, wl, _) = ctx.commit_ex(d_w, log_n, rate_bits, cap_h)
+    _, _, (sc, sl, _) = ctx.commit_ex(d_s, log_n, rate_bits, cap_h)
+    _, _, (zc, zl, _) = ctx.commit_ex(got_zs, log_n, rate_bits, cap_h)
+    ref_q = _oracle.plonk_quotient_chunks(host(wc), host(sc), host(zc), log_n, op, betas, gammas, alphas)
+    got_q = host(ctx.plonk_quotient_chunks(wl, sl, zl, log_n, rate_bits, gp, betas, gammas, alphas))
+    bad = np.argwhere(got_q != ref_q)
+    assert bad.size == 0, "first mismatching (chunk, coefficient): %s" % bad[:4].tolist()
+    # the whole argument: flat proof word for word, and the oracle's verifier on the device's proof
+    fp = fri(log_n, rate_bits=rate_bits, cap_height=cap_h, nq=5, arity=3, fpb=3)
+    ref = _oracle.plonk_perm_prove(wires, sig, log_n, op, fp, digest=(11, 12, 13, 14))
+    got = ctx.plonk_perm_prove(d_w, d_s, log_n, gp, to_params(fp), digest=(11, 12, 13, 14))
+    assert len(got) == len(ref)
+    diff = np.nonzero(got != ref)[0]
+    assert diff.size == 0, "first mismatch at word %d of %d" % (diff[0], len(ref))
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=rate_bits, cap_height=cap_h).cap
+    assert _oracle.plonk_perm_verify(got, sig_cap, op, fp, digest=(11, 12, 13, 14)) == 0
+
+
+def test_broken_copy_constraint_gives_a_proof_the_verifier_refuses(ctx):
+    """the device proves whatever it is given (as plonky2's prover does); a wire that breaks a copy constraint yields a proof whose
+    identity at zeta fails in the verifier (-210), word for word the oracle's proof of the same broken witness"""
+    import sipp_amd
+    log_n, R, D, C, rate_bits = 10, 16, 8, 2, 3
+    op, gp = _oracle.plonk_params(R, D, C), sipp_amd.PlonkParams(R, D, C)
+    wires, sig, perm = _oracle.plonk_random_instance(5, log_n, R, n_cycles=300)
+    pos = int(np.nonzero(perm != np.arange(perm.size))[0][0])
+    wires.reshape(-1)[pos] = (int(wires.reshape(-1)[pos]) + 1) % _oracle.P
+    fp = fri(log_n, rate_bits=rate_bits, cap_height=1, nq=4, arity=4, fpb=2)
+    got = ctx.plonk_perm_prove(dev(wires), dev(sig), log_n, gp, to_params(fp))
+    assert (got == _oracle.plonk_perm_prove(wires, sig, log_n, op, fp)).all()
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=rate_bits, cap_height=1).cap
+    assert _oracle.plonk_perm_verify(got, sig_cap, op, fp) == -210
+
+
+def test_argument_errors(ctx):
+    import sipp_amd
+    w = dev(np.zeros((4, 1 << 10), dtype=np.uint64))
+    for bad in (sipp_amd.PlonkParams(4, 3, 2), sipp_amd.PlonkParams(4, 1, 2), sipp_amd.PlonkParams(4, 2, 9), sipp_amd.PlonkParams(0, 2, 1),
+                sipp_amd.PlonkParams(2 * 33, 2, 1)):
+        with pytest.raises(sipp_amd.SippError):
+            ctx.plonk_zs(w, w, 10, bad, [1] * 9, [2] * 9)
+    with pytest.raises(sipp_amd.SippError):                      # blowup 2 cannot carry a quotient degree factor of 4
+        ctx.plonk_quotient_chunks(w, w, w, 10, 1, sipp_amd.PlonkParams(4, 4, 1), [1], [2], [3])
