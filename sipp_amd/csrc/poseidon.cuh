@@ -42,8 +42,10 @@ __constant__ uint64_t c_comb_c[12];
 // sequence otherwise (-DSIPP_POSEIDON_C_MUL keeps the latter for A/B runs)
 #if defined(GLL_T) && !defined(SIPP_POSEIDON_C_MUL)
 #define SIPP_PMUL gll::mul_nc
+#define SIPP_PRED96 gll::reduce96_nc
 #else
 #define SIPP_PMUL gl::mul_nc
+#define SIPP_PRED96 gl::reduce96_nc
 #endif
 // the two- and four-lanes-per-state kernels (two waves per SIMD, latency-bound): the compiler's products interleave across the
 // state elements, the fixed-register blocks cannot -- measured slower there (pair kernel 35.5 against 32 ms per n = 128 instance)
@@ -97,7 +99,7 @@ __device__ __forceinline__ void mds_full(uint64_t s[12], const uint64_t* __restr
         // value = al + ah * 2^32, al, ah < 2^43
         uint64_t l = al + (ah << 32);
         uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[r] = gl::reduce96_nc(h, l);
+        s[r] = SIPP_PRED96(h, l);
     }
 }
 
@@ -134,7 +136,7 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z)
         }
         const uint64_t l = al + (ah << 32);
         const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[0] = gl::add_nc(gl::reduce96_nc(h, l), c_comb_c[z]);
+        s[0] = gl::add_nc(SIPP_PRED96(h, l), c_comb_c[z]);
     }
 #pragma unroll
     for (int i = 1; i < 12; i++) {
