@@ -103,14 +103,106 @@ __device__ __forceinline__ void mds_full(uint64_t s[12], const uint64_t* __restr
     }
 }
 
+// ---- the same layer on the MATRIX pipe (round 3; scripts/ubench/mfma_mds.hip: 1.33x the VALU form, the pipe is otherwise idle) ----
+// The 12 state words are cut into 8 byte planes (six 4 x 4 byte transposes = 48 v_perm_b32; the bytes are made signed by ^ 0x80: i8
+// operands are signed); per plane ONE v_mfma_i32_32x32x32_i8 with a block-diagonal A: lane l = (n = l & 31, h = l >> 5) supplies
+// B[k = 16 h + e][n] = byte of its element e, and A[(reg & 3) + 8 (reg >> 2) + 4 h][16 h + e] = M[reg][e], so the two wave halves are
+// two independent 12 x 12 products and every lane finds ITS twelve sums in accumulator registers 0 .. 11 (the C/D map of the 32 x 32
+// shapes) -- no lane exchange.  Recombination: sum_b D_b 2^(8 b) as two chains of four v_mad_i64_i32 (2^8, 2^16, 2^24 in SGPRs); the
+// +128 of every byte is repaid by the constant 128 rowsum(M) 0x01010101 that starts each chain together with the next round's
+// constant; then the same 96-bit reduction.  96 multiply-adds + 48 + 24 + 8 instead of 288 multiply-adds per layer.
+#if 1
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+
+// this lane's fragment of A (constant): row = lane & 31 of the block-diagonal matrix, columns k = 16 (lane >> 5) + j
+__device__ __forceinline__ mfma_v4i mds_a_fragment() {
+    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t lane = threadIdx.x & 63, row = lane & 31, h = lane >> 5;
+    const bool mine = row < 24 && ((row >> 2) & 1) == h;
+    const uint32_t reg = (row & 3) + 4 * (row >> 3);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t e = 0; e < 12; e++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 12; i++)            // M[reg][e] = CIRC[(e - reg) mod 12] (+ 8 on the diagonal of row 0)
+            if ((i + reg) % 12 == e) v = CIRC[i];
+        if (reg == 0 && e == 0) v += 8;
+        w[e >> 2] |= (mine ? v : 0u) << (8 * (e & 3));
+    }
+    return mfma_v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+}
+
+__device__ __forceinline__ void mds_transpose4(const uint32_t in[4], uint32_t out[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u), t1 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u), t3 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+
+template <bool ADD>
+__device__ __forceinline__ void mds_full_mfma(uint64_t s[12], const uint64_t* __restrict__ add, mfma_v4i afrag, uint32_t z) {
+    uint32_t lo[12], hi[12], plane[8][3];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        uint32_t o[4];
+        mds_transpose4(lo + 4 * g, o);
+#pragma unroll
+        for (int b = 0; b < 4; b++) plane[b][g] = o[b] ^ 0x80808080u;
+        mds_transpose4(hi + 4 * g, o);
+#pragma unroll
+        for (int b = 0; b < 4; b++) plane[4 + b][g] = o[b] ^ 0x80808080u;
+    }
+    // 2^8, 2^16, 2^24 as wave-uniform values the compiler cannot fold into literals (VOP3 has no literal operand on gfx9: SGPRs)
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    int64_t al[12], ah[12];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const mfma_v4i bfrag = {(int)plane[b][0], (int)plane[b][1], (int)plane[b][2], 0};
+        const mfma_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, bfrag, mfma_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            int64_t& acc = b < 4 ? al[r] : ah[r];
+            if ((b & 3) == 0) {
+                // chain start: the bias of the four planes of this chain, and the next round's constant
+                const uint64_t bias = (uint64_t)(128u * (256u + (r == 0 ? 8u : 0u))) * 0x01010101ull;
+                const uint64_t c = ADD ? (b < 4 ? (uint64_t)(uint32_t)add[r] : (add[r] >> 32)) : 0;
+                acc = (int64_t)d[r] + (int64_t)(bias + c);
+            } else {
+                acc = (int64_t)d[r] * (int64_t)((b & 3) == 1 ? p8 : (b & 3) == 2 ? p16 : p24) + acc;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        const uint64_t a = (uint64_t)al[r], hh = (uint64_t)ah[r];
+        const uint64_t l = a + (hh << 32);
+        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
+        s[r] = SIPP_PRED96(h, l);
+    }
+}
+#endif
+
 using gl::Acc160;
 
 // S-box layer + MDS of round `rnd`; the state already carries the round's constants, and leaves with those of round rnd + 1
 // folded into the MDS sums (zeros after round 29: c_rc carries 12 trailing zeros)
-__device__ __forceinline__ void full_round(uint64_t s[12], int rnd, uint32_t z) {
+template <bool MFMA>
+__device__ __forceinline__ void full_round(uint64_t s[12], int rnd, uint32_t z, mfma_v4i afrag) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = sbox(s[i]);
-    mds_full<true>(s, c_rc + 12 * (rnd + 1) + z);
+    if (MFMA)
+        mds_full_mfma<true>(s, c_rc + 12 * (rnd + 1) + z, afrag, z);
+    else
+        mds_full<true>(s, c_rc + 12 * (rnd + 1) + z);
 }
 
 using gl::Acc6;
@@ -189,6 +281,10 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t 
     }
 }
 
+// MFMA = the full-round linear layers on the matrix pipe (mds_full_mfma).  The matrix A of that product is spread over ALL 64 lanes
+// of the wave and MFMA ignores EXEC, so it may only be used where every lane of the wave is active and runs this function: the
+// leaf-hash kernel, whose launches are whole waves (-DSIPP_POSEIDON_VALU_MDS switches it off for A/B runs).
+template <bool MFMA = false>
 __device__ __forceinline__ void permute(uint64_t s[12]) {
     // an opaque zero added to every table index: the tables are wave-uniform and loop-invariant, and without this the
     // compiler hoists ~650 scalar loads out of the caller's column loop, runs out of SGPRs and parks the constants in
@@ -197,14 +293,15 @@ __device__ __forceinline__ void permute(uint64_t s[12]) {
     asm volatile("" : "+s"(z));
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[i + z]);
+    const mfma_v4i afrag = MFMA ? mds_a_fragment() : mfma_v4i{0, 0, 0, 0};
 #pragma unroll 1
-    for (int r = 0; r < 3; r++) full_round(s, r, z);
+    for (int r = 0; r < 3; r++) full_round<MFMA>(s, r, z, afrag);
     full_round3_combined(s, z);
     partial_rounds_blocked(s, z);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[12 * 26 + i + z]);
 #pragma unroll 1
-    for (int r = 26; r < 30; r++) full_round(s, r, z);
+    for (int r = 26; r < 30; r++) full_round<MFMA>(s, r, z, afrag);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }

@@ -26,8 +26,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIPP_L
 poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                              uint32_t ncols, uint64_t n_leaves,
                                                              uint64_t* __restrict__ digests) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_leaves) return;
+    // no early exit: the matrix-pipe form of the linear layers needs every lane of the wave (poseidon.cuh::permute<true>); a lane
+    // past the end hashes the last leaf again and skips the store
+    const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j = j0 < n_leaves ? j0 : n_leaves - 1;
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -39,8 +41,13 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
-        poseidon::permute(s);
+#ifdef SIPP_POSEIDON_VALU_MDS
+        poseidon::permute<false>(s);
+#else
+        poseidon::permute<true>(s);
+#endif
     }
+    if (j0 >= n_leaves) return;
     uint64_t* d = digests + 4 * j;
     d[0] = s[0];
     d[1] = s[1];

@@ -54,7 +54,7 @@ def test_ntt_matches_oracle(ctx, oracle, log_n):
 
 
 @pytest.mark.parametrize("log_n,ncols", [(4, 1), (6, 11), (9, 3), (10, 4), (11, 3), (12, 9), (13, 17), (14, 5), (15, 3), (16, 5),
-                                         (17, 2), (18, 2), (19, 2), (20, 1), (21, 1)])
+                                         (17, 2), (18, 2), (19, 2), (20, 1), (21, 1), (22, 1)])
 def test_commit_matches_oracle(ctx, log_n, ncols):
     """PolynomialBatch::from_values on the device -- whole-column fused kernel (2^10..2^14), gather / fused-top / low-pass sweeps (2^15..2^21), pass-by-pass path elsewhere --
     and the per-subtree Merkle kernels: coefficients, every LDE cell, EVERY tree level and the cap equal the oracle's"""
