@@ -479,6 +479,9 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
         // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
         // at 2^17 leaves), 512 is slightly slower
         const unsigned bs = n <= 65536 ? 64 : 256;
+        // (cutting this launch into k launches over leaf ranges, so that its waves retire in batches and the other proofs' thin kernels
+        // get placed in between, was measured in round 3: 58.8 -> 63.8 / 82.0 / 124.5 ms per instance for k = 2 / 4 / 8 -- a chunk has
+        // too few waves to hide its own latency; one launch stays)
         unsigned grid = (unsigned)((n + bs - 1) / bs);
         hipLaunchKernelGGL(poseidon_leaves_kernel, dim3(grid), dim3(bs), 0, ctx->stream, d_lde, col_stride,
                            (uint32_t)ncols, n, d_digests);
