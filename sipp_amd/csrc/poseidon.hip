@@ -9,7 +9,9 @@
 #include "ctx.hpp"
 // ten VGPRs for the 64-bit temporaries of the hand-scheduled Goldilocks product (gl_lazy.cuh): v140 .. v149 keep the one-state-per-lane
 // leaf kernel at 150 VGPRs (152 without; its budget is 168 = three waves per SIMD)
+#ifndef GLL_T
 #define GLL_T 140
+#endif
 #include "poseidon.cuh"
 #include "poseidon_quad.cuh"
 #include "poseidon_pair.cuh"
