@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (spec)
 NTT_KERNELS = ("lde_column", "lde_gather", "lde_mid", "ntt_dif_pass", "ntt_dit_pass", "bitrev_cols", "ntt_tree_gather", "ntt_tree_inv",
-               "ntt_tree_fwd")
+               "ntt_tree_mid", "ntt_tree_fwd")
 PMC_FILE = "r03_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
 
 

@@ -151,8 +151,10 @@ __device__ __forceinline__ void tree_round(uint64_t* tile, uint32_t E, uint32_t 
 }
 
 // all k levels of a pass on an LDS tile of E = G R T elements, element e = ((g << k | r) << lt) | t
+// d0: the INVERSE runs only the levels with row strides 2^d0 .. 2^(k-1) (the fused middle sweep: the lower row bits belong to
+// an earlier inverse sweep and act as extra columns)
 template <bool FWD, class Idx, class Tw>
-__device__ __forceinline__ void tree_stages(uint64_t* tile, uint32_t E, uint32_t k, uint32_t lt, Idx lidx, Tw tw) {
+__device__ __forceinline__ void tree_stages(uint64_t* tile, uint32_t E, uint32_t k, uint32_t lt, Idx lidx, Tw tw, uint32_t d0 = 0) {
     if (FWD) {
         uint32_t top = k;
         for (; top >= 4; top -= 4) tree_round<true, 4>(tile, E, k, lt, top - 4, lidx, tw);
@@ -162,7 +164,7 @@ __device__ __forceinline__ void tree_stages(uint64_t* tile, uint32_t E, uint32_t
         }
         if (top) tree_round<true, 1>(tile, E, k, lt, 0, lidx, tw);
     } else {
-        uint32_t bot = 0, rem = k;
+        uint32_t bot = d0, rem = k - d0;
         for (; rem >= 4; rem -= 4, bot += 4) tree_round<false, 4>(tile, E, k, lt, bot, lidx, tw);
         if (rem >= 2) {
             tree_round<false, 2>(tile, E, k, lt, bot, lidx, tw);
@@ -239,6 +241,86 @@ __global__ void __launch_bounds__(256) tree_pass_kernel(TreeArgs a) {
     tile_loop<SIPP_NTT_MLP>(
         E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; },
         [&](uint32_t e, uint64_t v) { out[pos_of(e)] = sc ? gl::mul(v, sc) : FWD ? gl::canon(v) : v; });
+}
+
+// Fused MIDDLE sweep: the inverse's top ki levels and, on the same tile, the top kf >= ki levels of every half's forward tree.
+// Tile = 2^kf rows (position bits [L - kf, L)) x 2^lt columns of a column of coefficients-to-be.  Reads N, writes N (coefficients,
+// scaled by 1/N) + 2^rate_bits N (first forward sweep of every half) -- instead of an inverse sweep (16 N) plus a forward sweep that
+// reads the coefficients once per half (16 N + 16 N at blowup 2).  The scaled coefficients wait in registers (16 per lane) while the
+// LDS tile runs one half after the other.
+struct MidArgs {
+    uint64_t* coeffs;                  // [ncols][n]  in: after the inverse's earlier sweeps; out: natural coefficients
+    uint64_t* lde;                     // [ncols][n << rate_bits]
+    uint32_t L, kf, ki, lt, rate_bits;
+    const uint64_t* tw_inv;            // flat inverse table
+    const uint64_t* tw_fwd;            // coset heap table of size 2^(L + rate_bits)
+    uint64_t scale;                    // 1 / n
+    uint32_t ncols, colfast;
+};
+
+__global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k = a.kf, lt = a.lt, lo = a.L - a.kf;
+    const uint32_t E = 1u << (k + lt), T = 1u << lt, R = 1u << k;
+    uint64_t* tile = smem;
+    uint64_t* twi = smem + (E + (E >> LOG_SEG));
+    uint64_t* twf = twi + R;
+    const uint32_t tiles_per_col = 1u << (lo - lt);
+    uint32_t col, tix;
+    if (a.colfast) {
+        tix = blockIdx.x / a.ncols;
+        col = blockIdx.x - tix * a.ncols;
+    } else {
+        col = blockIdx.x / tiles_per_col;
+        tix = blockIdx.x - col * tiles_per_col;
+    }
+    const size_t n = (size_t)1 << a.L;
+    uint64_t* co = a.coeffs + (size_t)col * n;
+    uint64_t* lde = a.lde + ((size_t)col << (a.L + a.rate_bits));
+    const uint32_t base = tix << lt;                       // the top pass: no bits above the tile's rows
+    auto pos_of = [&](uint32_t e) -> uint32_t { return base + ((e >> lt) << lo) + (e & (T - 1)); };
+    tile_loop<SIPP_NTT_MLP>(
+        E, [&](uint32_t e) -> uint64_t { return co[pos_of(e)]; }, [&](uint32_t e, uint64_t v) { tile[lds_idx(e)] = v; });
+    for (uint32_t J = threadIdx.x; J < R; J += blockDim.x) {
+        if (!J) continue;
+        const uint32_t lev = 31 - __clz(J);
+        twi[J] = a.tw_inv[J - (1u << lev)];                // root node 0 of the flat table
+    }
+    __syncthreads();
+    tree_stages<false>(tile, E, k, lt, IdxPlain{}, TwLds{twi, k}, k - a.ki);
+    // coefficients: scaled, stored, kept (E / 256 = 16 per lane)
+    constexpr int PER = 16;
+    uint64_t c[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t e = threadIdx.x + u * 256;
+        c[u] = e < E ? gl::mul(tile[lds_idx(e)], a.scale) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const uint32_t e = threadIdx.x + u * 256;
+        if (e < E) co[pos_of(e)] = c[u];
+    }
+    const uint32_t halves = 1u << a.rate_bits;
+    for (uint32_t h = 0; h < halves; h++) {
+        __syncthreads();                                   // the previous half's stores (and twf readers) are done with LDS
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t e = threadIdx.x + u * 256;
+            if (e < E) tile[lds_idx(e)] = c[u];
+        }
+        const uint32_t Q = halves + h;
+        for (uint32_t J = threadIdx.x; J < R; J += blockDim.x) {
+            if (!J) continue;
+            const uint32_t lev = 31 - __clz(J);
+            twf[J] = a.tw_fwd[(Q << lev) + (J - (1u << lev))];
+        }
+        __syncthreads();
+        tree_stages<true>(tile, E, k, lt, IdxPlain{}, TwLds{twf, k});
+        uint64_t* out = lde + (size_t)h * n;
+        tile_loop<SIPP_NTT_MLP>(
+            E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; }, [&](uint32_t e, uint64_t v) { out[pos_of(e)] = gl::canon(v); });
+    }
 }
 
 // inverse, first sweep: natural-order values -> the k2 leaf-most levels.  Tile = 16 groups of 2^k2 positions that differ in their
@@ -446,9 +528,80 @@ bool sipp_tree_ntt_enabled(uint32_t log_n) {
     return log_n >= (uint32_t)lo && log_n >= 12 && log_n <= 25;
 }
 
+// values -> coefficients + LDE with the fused middle sweep: gather (8 bits) | strided inverse sweeps | middle (inverse top ki bits +
+// forward top kf bits of every half) | the forward tree's remaining sweeps.  Needs L >= 13 (a strided top sweep exists).
+static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t L,
+                                  uint32_t rate_bits) {
+    const size_t n = (size_t)1 << L;
+    const uint64_t* twi = tree_flat_table(ctx, L, true);
+    const uint64_t* twf = tree_coset_table(ctx, L + rate_bits);
+    if (!twi || !twf) return SIPP_E_HIP;
+    const uint32_t k2 = 8;
+    const std::vector<uint32_t> fks = split_bits(L - LTILE);          // forward strided sweeps, top first
+    const uint32_t kf = fks[0];
+    const uint32_t ki = kf < L - k2 ? kf : L - k2;                    // inverse levels inside the middle sweep
+    const unsigned halves = 1u << rate_bits;
+    {
+        GatherArgs g{};
+        g.in = d_values; g.out = d_coeffs; g.L = L; g.k2 = k2; g.tw = twi; g.ncols = (uint32_t)ncols;
+        g.colfast = (uint32_t)tree_colfast();
+        const size_t E = (size_t)16 << k2;
+        const size_t shmem = (E + (E >> LOG_SEG) + 16) * sizeof(uint64_t);
+        const size_t tiles = ((size_t)1 << (L - 4 - k2)) * ncols;
+        if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
+        ProfScope ps(ctx, "ntt_tree_gather");
+        hipLaunchKernelGGL(tree_gather_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, g);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    {
+        const std::vector<uint32_t> iks = split_bits(L - k2 - ki);    // inverse strided sweeps between the gather and the middle
+        uint32_t lo = k2;
+        for (size_t i = iks.size(); i-- > 0;) {
+            TreeArgs a{};
+            a.in = d_coeffs; a.out = d_coeffs; a.in_stride = a.out_stride = n;
+            a.L = L; a.k = iks[i]; a.lo = lo;
+            a.lt = LTILE - a.k < lo ? LTILE - a.k : lo;
+            a.lg = 0; a.q0 = 0; a.tw = twi; a.ncols = (uint32_t)ncols; a.scale = 0;
+            SIPP_TRY((launch_pass<false, true>(ctx, "ntt_tree_inv", a, 1)));
+            lo += a.k;
+        }
+    }
+    {
+        MidArgs m{};
+        m.coeffs = d_coeffs; m.lde = d_lde; m.L = L; m.kf = kf; m.ki = ki; m.lt = LTILE - kf; m.rate_bits = rate_bits;
+        m.tw_inv = twi; m.tw_fwd = twf; m.scale = gl::inv((uint64_t)1 << L); m.ncols = (uint32_t)ncols;
+        m.colfast = (uint32_t)tree_colfast();
+        const size_t E = (size_t)1 << LTILE;
+        const size_t shmem = (E + (E >> LOG_SEG) + ((size_t)2 << kf)) * sizeof(uint64_t);
+        const size_t tiles = ((size_t)1 << (L - LTILE)) * ncols;
+        if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
+        ProfScope ps(ctx, "ntt_tree_mid");
+        hipLaunchKernelGGL(tree_mid_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, m);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    uint32_t top = L - kf;
+    for (size_t i = 1; i < fks.size(); i++) {
+        TreeArgs a{};
+        a.in = d_lde; a.in_stride = n << rate_bits; a.in_half = n;
+        a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
+        a.L = L; a.k = fks[i]; a.lo = top - a.k;
+        a.lt = LTILE - a.k < a.lo ? LTILE - a.k : a.lo;
+        a.lg = 0; a.q0 = halves; a.tw = twf; a.scale = 0; a.ncols = (uint32_t)ncols;
+        SIPP_TRY((launch_pass<true, true>(ctx, "ntt_tree_fwd", a, halves)));
+        top -= a.k;
+    }
+    TreeArgs a{};
+    a.in = d_lde; a.in_stride = n << rate_bits; a.in_half = n;
+    a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
+    a.L = L; a.k = LTILE; a.lo = 0; a.lt = 0; a.lg = 0; a.q0 = halves; a.tw = twf; a.scale = 0; a.ncols = (uint32_t)ncols;
+    return launch_pass<true, false>(ctx, "ntt_tree_fwd", a, halves);
+}
+
 int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
                               uint32_t log_n, uint32_t rate_bits) {
     if (d_values == d_coeffs || ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
+    static const int fused = sipp_env_int("SIPP_TREE_FUSED_MID", 1);
+    if (fused && log_n >= 13) return tree_from_values_fused(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
     SIPP_TRY(tree_inverse(ctx, d_values, d_coeffs, ncols, log_n));
     return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
 }
