@@ -153,16 +153,17 @@ __device__ __forceinline__ void tree_round(uint64_t* tile, uint32_t E, uint32_t 
 // all k levels of a pass on an LDS tile of E = G R T elements, element e = ((g << k | r) << lt) | t
 // d0: the INVERSE runs only the levels with row strides 2^d0 .. 2^(k-1) (the fused middle sweep: the lower row bits belong to
 // an earlier inverse sweep and act as extra columns)
+// and the FORWARD only the levels with row strides 2^(k-1) .. 2^d0 (the tile's lower row bits are left to the next sweep)
 template <bool FWD, class Idx, class Tw>
 __device__ __forceinline__ void tree_stages(uint64_t* tile, uint32_t E, uint32_t k, uint32_t lt, Idx lidx, Tw tw, uint32_t d0 = 0) {
     if (FWD) {
         uint32_t top = k;
-        for (; top >= 4; top -= 4) tree_round<true, 4>(tile, E, k, lt, top - 4, lidx, tw);
-        if (top >= 2) {
+        for (; top >= d0 + 4; top -= 4) tree_round<true, 4>(tile, E, k, lt, top - 4, lidx, tw);
+        if (top >= d0 + 2) {
             tree_round<true, 2>(tile, E, k, lt, top - 2, lidx, tw);
             top -= 2;
         }
-        if (top) tree_round<true, 1>(tile, E, k, lt, 0, lidx, tw);
+        if (top > d0) tree_round<true, 1>(tile, E, k, lt, d0, lidx, tw);
     } else {
         uint32_t bot = d0, rem = k - d0;
         for (; rem >= 4; rem -= 4, bot += 4) tree_round<false, 4>(tile, E, k, lt, bot, lidx, tw);
@@ -243,8 +244,8 @@ __global__ void __launch_bounds__(256) tree_pass_kernel(TreeArgs a) {
         [&](uint32_t e, uint64_t v) { out[pos_of(e)] = sc ? gl::mul(v, sc) : FWD ? gl::canon(v) : v; });
 }
 
-// Fused MIDDLE sweep: the inverse's top ki levels and, on the same tile, the top kf >= ki levels of every half's forward tree.
-// Tile = 2^kf rows (position bits [L - kf, L)) x 2^lt columns of a column of coefficients-to-be.  Reads N, writes N (coefficients,
+// Fused MIDDLE sweep: the inverse's top ki levels and, on the same tile, the top kf levels of every half's forward tree.
+// Tile = 2^max(ki, kf) rows (the top position bits) x 2^lt columns of a column of coefficients-to-be.  Reads N, writes N (coefficients,
 // scaled by 1/N) + 2^rate_bits N (first forward sweep of every half) -- instead of an inverse sweep (16 N) plus a forward sweep that
 // reads the coefficients once per half (16 N + 16 N at blowup 2).  The scaled coefficients wait in registers (16 per lane) while the
 // LDS tile runs one half after the other.
@@ -260,7 +261,7 @@ struct MidArgs {
 
 __global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
     extern __shared__ uint64_t smem[];
-    const uint32_t k = a.kf, lt = a.lt, lo = a.L - a.kf;
+    const uint32_t k = a.kf > a.ki ? a.kf : a.ki, lt = a.lt, lo = a.L - k;
     const uint32_t E = 1u << (k + lt), T = 1u << lt, R = 1u << k;
     uint64_t* tile = smem;
     uint64_t* twi = smem + (E + (E >> LOG_SEG));
@@ -316,7 +317,7 @@ __global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
             twf[J] = a.tw_fwd[(Q << lev) + (J - (1u << lev))];
         }
         __syncthreads();
-        tree_stages<true>(tile, E, k, lt, IdxPlain{}, TwLds{twf, k});
+        tree_stages<true>(tile, E, k, lt, IdxPlain{}, TwLds{twf, k}, k - a.kf);
         uint64_t* out = lde + (size_t)h * n;
         tile_loop<SIPP_NTT_MLP>(
             E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; }, [&](uint32_t e, uint64_t v) { out[pos_of(e)] = gl::canon(v); });
@@ -524,7 +525,7 @@ static bool fused_tree_ok() {
 }
 
 bool sipp_tree_ntt_enabled(uint32_t log_n) {
-    static const int lo = sipp_env_int("SIPP_TREE_MIN_LOG", 18);
+    static const int lo = sipp_env_int("SIPP_TREE_MIN_LOG", 15);
     return log_n >= (uint32_t)lo && log_n >= 12 && log_n <= 25;
 }
 
@@ -539,7 +540,10 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
     const uint32_t k2 = 8;
     const std::vector<uint32_t> fks = split_bits(L - LTILE);          // forward strided sweeps, top first
     const uint32_t kf = fks[0];
-    const uint32_t ki = kf < L - k2 ? kf : L - k2;                    // inverse levels inside the middle sweep
+    // inverse levels inside the middle sweep: all that is left above the gather when they fit a tile's rows (L <= 16: three sweeps in
+    // all), else as many as the forward's top sweep has
+    const uint32_t ki = L - k2 <= 8 ? L - k2 : kf;
+    const uint32_t km = kf > ki ? kf : ki;
     const unsigned halves = 1u << rate_bits;
     {
         GatherArgs g{};
@@ -568,11 +572,11 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
     }
     {
         MidArgs m{};
-        m.coeffs = d_coeffs; m.lde = d_lde; m.L = L; m.kf = kf; m.ki = ki; m.lt = LTILE - kf; m.rate_bits = rate_bits;
+        m.coeffs = d_coeffs; m.lde = d_lde; m.L = L; m.kf = kf; m.ki = ki; m.lt = LTILE - km; m.rate_bits = rate_bits;
         m.tw_inv = twi; m.tw_fwd = twf; m.scale = gl::inv((uint64_t)1 << L); m.ncols = (uint32_t)ncols;
         m.colfast = (uint32_t)tree_colfast();
         const size_t E = (size_t)1 << LTILE;
-        const size_t shmem = (E + (E >> LOG_SEG) + ((size_t)2 << kf)) * sizeof(uint64_t);
+        const size_t shmem = (E + (E >> LOG_SEG) + ((size_t)2 << km)) * sizeof(uint64_t);
         const size_t tiles = ((size_t)1 << (L - LTILE)) * ncols;
         if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
         ProfScope ps(ctx, "ntt_tree_mid");
