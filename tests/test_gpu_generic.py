@@ -74,13 +74,15 @@ def test_commit_matches_oracle(ctx, log_n, ncols):
     assert (cap == ref.cap).all()
 
 
-@pytest.mark.parametrize("log_n,rate_bits,from_coeffs", [(18, 2, False), (18, 3, True), (19, 1, True), (18, 1, False)])
+@pytest.mark.parametrize("log_n,rate_bits,from_coeffs", [(18, 2, False), (18, 3, True), (19, 1, True), (18, 1, False), (15, 3, False),
+                                                          (16, 2, False), (17, 3, False), (15, 1, True), (16, 3, True)])
 def test_long_column_batches_at_other_blowups_match_the_oracle(ctx, log_n, rate_bits, from_coeffs):
-    """the tree-of-rings transforms of ntt_tree.hip (N >= 2^18) through sipp_commit_batch_ex: blowup 4 and 8 (2^rate_bits
-    independent subtrees over the same coefficients), from values and from coefficients -- coefficients, every LDE cell in leaf
+    """the tree-of-rings transforms of ntt_tree.hip (N >= 2^15) through sipp_commit_batch_ex: blowup 2, 4 and 8 (2^rate_bits
+    independent subtrees over the same coefficients; the fused middle sweep runs one after the other on its tile), three- and
+    four-sweep plans (2^15 / 2^16 against 2^17 and above), from values and from coefficients -- coefficients, every LDE cell in leaf
     order and the cap equal the oracle's PolynomialBatch"""
     rng = np.random.default_rng(500 + log_n + rate_bits)
-    ncols = 2
+    ncols = 3 if log_n < 18 else 2
     data = _oracle.rand_field(rng, (ncols, 1 << log_n))
     ref = _oracle.Batch(data, log_n, rate_bits=rate_bits, cap_height=4, from_coeffs=from_coeffs)
     od, cap, (coeffs, lde, tree) = ctx.commit_ex(dev(data), log_n, rate_bits, 4, from_coeffs=from_coeffs)
