@@ -97,3 +97,25 @@ def test_argument_errors(ctx):
             ctx.plonk_zs(w, w, 10, bad, [1] * 9, [2] * 9)
     with pytest.raises(sipp_amd.SippError):                      # blowup 2 cannot carry a quotient degree factor of 4
         ctx.plonk_quotient_chunks(w, w, w, 10, 1, sipp_amd.PlonkParams(4, 4, 1), [1], [2], [3])
+
+
+def test_workspace_too_small_fails_cleanly_and_the_ctx_survives():
+    """the whole-argument call allocates its four oracles from the ctx's arena: an arena that cannot hold them gives SIPP_E_NOMEM
+    (no fault, no partial proof), and the same ctx proves a smaller instance afterwards"""
+    import sipp_amd
+    c = sipp_amd.Ctx(workspace_bytes=96 << 20)
+    try:
+        log_n, R, D, C = 13, 80, 8, 2
+        op, gp = _oracle.plonk_params(R, D, C), sipp_amd.PlonkParams(R, D, C)
+        wires, sig, _ = _oracle.plonk_random_instance(77, log_n, R)
+        fp = fri(log_n, rate_bits=3, cap_height=2, nq=4, arity=4, fpb=3)
+        with pytest.raises(sipp_amd.SippError) as e:
+            c.plonk_perm_prove(dev(wires), dev(sig), log_n, gp, to_params(fp))
+        assert e.value.code == -3
+        log_n = 10
+        wires, sig, _ = _oracle.plonk_random_instance(78, log_n, R)
+        fp = fri(log_n, rate_bits=3, cap_height=2, nq=4, arity=4, fpb=3)
+        got = c.plonk_perm_prove(dev(wires), dev(sig), log_n, gp, to_params(fp))
+        assert (got == _oracle.plonk_perm_prove(wires, sig, log_n, op, fp)).all()
+    finally:
+        c.close()
