@@ -68,13 +68,16 @@ typedef struct {
 void sipp_default_config(sipp_stark_config *cfg);
 
 /* Which STARK (reference src/verifier_circuit.rs:133 / :134 / :135) */
-typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2 } sipp_kind;
+typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
+               SIPP_MAP_G2 = 3 /* src/bin/bls_aggregation.rs:65, see sipp_map_to_g2_prove */ } sipp_kind;
 
 /* u32 words per IO record, (x, offset, exp_val, output) order:
  * G1 7*8 = 56, G2 13*8 = 104, Fq12 37*8 = 296. */
 #define SIPP_G1_IO_WORDS 56
 #define SIPP_G2_IO_WORDS 104
 #define SIPP_FQ12_IO_WORDS 296
+/* MapToG2 records (u, x, y): the message in Fp2 and its point on the twist, 6*8 = 48 */
+#define SIPP_MAP_G2_IO_WORDS 48
 
 /* ---- context ---------------------------------------------------------------- */
 /* `workspace_bytes` of HBM are reserved once; nothing is hipMalloc'ed afterwards.
@@ -145,6 +148,26 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
 /* trace shape the prover will use: rows (log2), main columns, permutation-Z columns, quotient chunks */
 int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
                      uint32_t *perm_cols, uint32_t *quotient_cols);
+
+/* ---- next row: messages -> G2 in front of SIPP's BLS example ----------------- */
+/* The STARK behind `batch_map_to_g2_circuit(builder, &messages)` (reference src/bin/bls_aggregation.rs:65): for every
+ * message u in Fp2 the point (x, y) = map_to_g2_without_cofactor_mul(u) on the twist y^2 = x^3 + 3/(9+u) (:102; the
+ * Shallue - van de Woestijne map of RFC 9380 F.1 with Z = 1, sgn0(y) = sgn0(u)).  ios: num_io records (u, x, y) of
+ * SIPP_MAP_G2_IO_WORDS u32, the point included (compared with the device-computed one; SIPP_E_WITNESS if it differs, if a
+ * word is >= p, or for the four u with u^2 g(1) = +-1).  One trace row per message, at least 1024 rows.  The cofactor
+ * multiplication that follows the map in the reference (`mul_by_cofactor`, :103) is a pair of ordinary G2ExpStark
+ * obligations: sipp_map_to_g2 below writes them.  Proof layout and the generic entry points (sipp_prove_async,
+ * sipp_proof_size, sipp_workspace_bytes, sipp_stark_shape, sipp_trace_build, sipp_exp_outputs) as for the other kinds
+ * with kind = SIPP_MAP_G2. */
+int sipp_map_to_g2_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+                         size_t *proof_len);
+/* What the reference computes natively per message (src/bin/bls_aggregation.rs:100-104), on the device:
+ *   map_ios [n][48]      (u, x, y) records for sipp_map_to_g2_prove;
+ *   g2_ios  [2n][104]    (may be NULL) the G2ExpStark obligations of the cofactor clearing, h = 2p - r:
+ *                        record i      : x = (x, y)_i, offset = G2 generator, exp_val = h, output = G + [h](x, y)_i
+ *                        record n + i  : x = -G,       offset = that output,  exp_val = 1, output = [h](x, y)_i
+ *   cleared [n][32]      (may be NULL) the points [h](x, y)_i of G2 (x.c0, x.c1, y.c0, y.c1), i.e. `ms` of :100-104. */
+int sipp_map_to_g2(sipp_ctx *ctx, const uint32_t *msgs, size_t n, uint32_t *map_ios, uint32_t *g2_ios, uint32_t *cleared);
 
 /* ---- next row: the native prover's pairing products ------------------------- */
 /* inner_product of reference src/prover_native.rs:15-23: prod_i pairing(A_i, B_i) for n pairs, on the device.

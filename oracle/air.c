@@ -9,6 +9,7 @@
  * The AIR layout itself is this repository's specification (tools/air_gen.py).
  */
 #include "air.h"
+#include "mapg2.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -131,6 +132,15 @@ void orc_test_forge(int flags) { g_forge = flags; }
 
 /* x and offset of every G1 / G2 record on E(Fp) / E'(Fp2) (the verifier's side of the refusal in fill_curve_io) */
 int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io) {
+    if (kind == 3) { /* (u, x, y): the point on E'(Fp2) and the map's sign rule sgn0(y) = sgn0(u) (public checks, not constraints) */
+        fq_init();
+        for (size_t io = 0; io < num_io; io++) {
+            const uint32_t *rec = pis + io * 48;
+            pt2 Q = {read_f2(rec + 16, 2), read_f2(rec + 32, 2)};
+            if (!on_curve(Q, 2) || !orc_mapg2_record_sign_ok(rec)) return 0;
+        }
+        return 1;
+    }
     if (kind != 0 && kind != 1) return 1;
     fq_init();
     const int ext = kind + 1, w = 8 * ext, ppi = 8 * (6 * ext + 1);
@@ -214,6 +224,31 @@ static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, c
         else if (r != 511) pw = c;
     }
     for (int k = 0; k < 12; k++) fq_to_u32(acc.c[k], out_words + 8 * k);
+    return 0;
+}
+
+/* MapToG2 (kind 3): one row per record (u, x, y); columns as tools/air_gen.py::build_map_g2 allocates them */
+enum { MGC_U = 1, MGC_ONE = 33, MGC_C1 = 65, MGC_C2 = 97, MGC_C3 = 129, MGC_C4 = 161, MGC_BB = 193, MGC_E1 = 225, MGC_E2 = 226,
+       MGC_M1 = 227, MGC_M2 = 259, MGC_XS = 291, MGC_GXS = 323, MGC_CHECKED = 397 };
+
+static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+    if (a->checked_base != MGC_CHECKED) return -20;
+    const int cpl = a->cells_per_limb;
+    orc_mapg2_consts k;
+    orc_mapg2_constants(&k);
+    orc_mapg2_wit w;
+    fq2 u = read_f2(rec, 2);
+    if (orc_mapg2_witness(u, &w)) return -1;       /* u^2 g(Z) = +-1 */
+    const size_t row = io;
+    put_f2_u16(tr, n, MGC_U, row, u, 2);
+    put_f2_u16(tr, n, MGC_ONE, row, k.one, 2); put_f2_u16(tr, n, MGC_C1, row, k.c1, 2); put_f2_u16(tr, n, MGC_C2, row, k.c2, 2);
+    put_f2_u16(tr, n, MGC_C3, row, k.c3, 2); put_f2_u16(tr, n, MGC_C4, row, k.c4, 2); put_f2_u16(tr, n, MGC_BB, row, k.b, 2);
+    put(tr, n, MGC_E1, row, (uint64_t)w.e1); put(tr, n, MGC_E2, row, (uint64_t)w.e2);
+    put_f2_u16(tr, n, MGC_M1, row, w.m1, 2); put_f2_u16(tr, n, MGC_M2, row, w.m2, 2);
+    put_f2_u16(tr, n, MGC_XS, row, w.xs, 2); put_f2_u16(tr, n, MGC_GXS, row, w.gxs, 2);
+    for (int i = 0; i < MG_NWIT; i++) put_f2_chk(tr, n, MGC_CHECKED + 32 * cpl * i, row, w.v[i], 2, cpl);
+    fq_to_u32(w.xs.c0, out_words); fq_to_u32(w.xs.c1, out_words + 8);
+    fq_to_u32(w.v[MG_Y].c0, out_words + 16); fq_to_u32(w.v[MG_Y].c1, out_words + 24);
     return 0;
 }
 
@@ -359,11 +394,13 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
     fq_init();
     *err = 0;
     if (num_io == 0) { *err = -1; return NULL; }
-    size_t nio = 2; /* at least two IO blocks (1024 rows) */
-    while (nio < num_io) nio <<= 1;
-    unsigned log_n = 9;
-    while (((size_t)1 << (log_n - 9)) < nio) log_n++;
+    const unsigned log_rows = kind == 3 ? 0 : 9;   /* rows per record: 512 (exponentiations), 1 (MapToG2); = air->log_rows */
+    size_t nio = 2; /* at least two IO blocks, at least 1024 rows */
+    while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
+    unsigned log_n = log_rows;
+    while (((size_t)1 << (log_n - log_rows)) < nio) log_n++;
     const orc_air_t *a = orc_air_get(kind, log_n);
+    if (!a || (unsigned)a->log_rows != log_rows) { *err = -1; return NULL; }
     size_t n = (size_t)1 << log_n;
     if (n < ((size_t)1 << a->table_bits)) { *err = -7; return NULL; }
     int W = orc_air_width(a);
@@ -371,7 +408,7 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
     t->air = a; t->log_n = log_n; t->num_io = nio; t->width = W;
     t->trace = (uint64_t *)calloc((size_t)W * n, sizeof(uint64_t));
     t->pis = (uint32_t *)calloc(nio * a->pi_per_io, sizeof(uint32_t));
-    int ppi = a->pi_per_io, out_words = kind == 0 ? 16 : kind == 1 ? 32 : 96;
+    int ppi = a->pi_per_io, out_words = kind == 0 ? 16 : kind == 2 ? 96 : 32;
     int rc_all = 0;
 #pragma omp parallel for schedule(dynamic)
     for (size_t io = 0; io < nio; io++) {
@@ -379,7 +416,8 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
         uint32_t *pi = t->pis + io * ppi;
         memcpy(pi, rec, ppi * sizeof(uint32_t));
         uint32_t outw[96];
-        int rc = kind == 2 ? fill_fq12_io(a, t->trace, n, io, rec, outw) : fill_curve_io(a, t->trace, n, io, rec, outw);
+        int rc = kind == 2 ? fill_fq12_io(a, t->trace, n, io, rec, outw) : kind == 3 ? fill_map_io(a, t->trace, n, io, rec, outw)
+                                                                          : fill_curve_io(a, t->trace, n, io, rec, outw);
         if (rc == 0 && (g_forge & 2)) memcpy(pi + ppi - out_words, outw, out_words * sizeof(uint32_t));
         else if (rc == 0 && memcmp(outw, rec + ppi - out_words, out_words * sizeof(uint32_t)) != 0) rc = -8; /* claimed output wrong */
         if (rc) {
@@ -444,10 +482,10 @@ uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int a
     return part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
 }
 
-/* coefficients (length num_io) of the aux polynomial A with A(g^(512 io + shift)) = value(io):
+/* coefficients (length num_io) of the aux polynomial A with A(g^(rows_per_io io + shift)) = value(io):
  * interpolate over the order-num_io subgroup, then substitute x -> x g^-shift. */
 void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs) {
-    unsigned log_io = log_n - 9;
+    unsigned log_io = log_n - (unsigned)a->log_rows;
     for (size_t io = 0; io < num_io; io++) coeffs[io] = orc_aux_value(a, pis, io, ai);
     orc_ifft(coeffs, log_io);
     int shift = a->aux[4 * ai + 2];
@@ -525,7 +563,7 @@ long orc_trace_check_row(const orc_trace *t, size_t row) {
     memset(&c, 0, sizeof c);
     c.local = local; c.next = next; c.aux = aux;
     for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = (row % (size_t)ORC_PERIODIC[k][0]) == (size_t)ORC_PERIODIC[k][1];
-    size_t io = row / 512;
+    size_t io = row >> a->log_rows;
     for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = orc_aux_value(a, t->pis, io, ai);
     /* alpha = 0 turns acc into "the last emitted constraint": walk constraint by constraint instead */
     c.alpha[0] = c.alpha[1] = 0;

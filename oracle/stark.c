@@ -51,6 +51,11 @@ static int fq_words_canonical(const uint32_t *w) {
 /* every Fq element of every record < p; the exponent (8 words) may be any 256-bit value.
  * Record layouts (reference src/verifier_circuit.rs:92-124): (x, offset, exp_val, output). */
 int orc_pis_canonical(int kind, const uint32_t *pis, size_t num_io) {
+    if (kind == 3) { /* MapToG2 records (u, x, y): six Fq elements, no exponent */
+        for (size_t k = 0; k < 6 * num_io; k++)
+            if (!fq_words_canonical(pis + 8 * k)) return 0;
+        return 1;
+    }
     const int fe = kind == 0 ? 2 : kind == 1 ? 4 : 12;       /* Fq elements per group element */
     const int ppi = 8 * (3 * fe + 1);
     for (size_t io = 0; io < num_io; io++) {
@@ -355,7 +360,8 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     unsigned log_n = (unsigned)h[2];
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
-    if (kind < 0 || kind > 2 || log_n < 9 || log_n > 26 || num_io != ((size_t)1 << (log_n - 9))) return -101;
+    const unsigned log_rows = kind == 3 ? 0 : 9;
+    if (kind < 0 || kind > 3 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const orc_air_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||

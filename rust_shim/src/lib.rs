@@ -10,6 +10,7 @@ pub enum Kind {
     G1Exp = 0,   // 56 u32 per IO:  x.x x.y offset.x offset.y exp_val out.x out.y          (8 LE limbs each)
     G2Exp = 1,   // 104 u32 per IO: Fq2 coordinates as (c0, c1)
     Fq12Exp = 2, // 296 u32 per IO: 12 MyFq12 coefficients for x, offset; exp_val; out
+    MapG2 = 3,   // 48 u32 per IO:  u, x, y in Fq2 (batch_map_to_g2_circuit, src/bin/bls_aggregation.rs:65)
 }
 
 impl Kind {
@@ -18,6 +19,7 @@ impl Kind {
             Kind::G1Exp => 56,
             Kind::G2Exp => 104,
             Kind::Fq12Exp => 296,
+            Kind::MapG2 => 48,
         }
     }
 }
@@ -58,6 +60,7 @@ impl SippCtx {
                 Kind::G1Exp => ffi::sipp_g1_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::G2Exp => ffi::sipp_g2_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::Fq12Exp => ffi::sipp_fq12_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+                Kind::MapG2 => ffi::sipp_map_to_g2_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
             }
         };
         if rc != 0 {

@@ -69,6 +69,8 @@ SIGNATURES = {
     "sipp_g1_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_g2_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_map_to_g2_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_map_to_g2": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "sipp_host_poseidon_permute": (C.c_int, [vp, C.c_size_t, C.c_int]),
@@ -324,14 +326,14 @@ class Ctx:
         return t
 
     def prove(self, kind, ios):
-        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12) for host IO records -> flat proof (uint64 ndarray)"""
+        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12 / 3 MapToG2) for host IO records -> flat proof (uint64 ndarray)"""
         ios = np.ascontiguousarray(ios, dtype=np.uint32)
         cap = self.L.sipp_proof_size(self.h, kind, ios.shape[0])
         if cap == 0:
             raise SippError(-1, "sipp_proof_size")
         out = np.zeros(cap, dtype=np.uint64)
         n = C.c_size_t()
-        fn = (self.L.sipp_g1_exp_prove, self.L.sipp_g2_exp_prove, self.L.sipp_fq12_exp_prove)[kind]
+        fn = (self.L.sipp_g1_exp_prove, self.L.sipp_g2_exp_prove, self.L.sipp_fq12_exp_prove, self.L.sipp_map_to_g2_prove)[kind]
         self._ck(fn(self.h, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
         return out[: n.value]
 
@@ -340,6 +342,20 @@ class Ctx:
         rec = np.array(ios, dtype=np.uint32, order="C", copy=True)
         self._ck(self.L.sipp_exp_outputs(self.h, kind, rec.ctypes.data, rec.shape[0]), "exp_outputs")
         return rec
+
+    def map_to_g2(self, msgs, cofactor=True):
+        """messages [n][16] (u in Fp2) -> (MapToG2 records [n][48], G2ExpStark records of the cofactor clearing [2n][104],
+        cleared points [n][32]) -- sipp_map_to_g2; without `cofactor` only the records"""
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint32).reshape(-1, 16)
+        n = msgs.shape[0]
+        recs = np.zeros((n, 48), dtype=np.uint32)
+        if not cofactor:
+            self._ck(self.L.sipp_map_to_g2(self.h, msgs.ctypes.data, n, recs.ctypes.data, None, None), "map_to_g2")
+            return recs
+        g2 = np.zeros((2 * n, 104), dtype=np.uint32)
+        pts = np.zeros((n, 32), dtype=np.uint32)
+        self._ck(self.L.sipp_map_to_g2(self.h, msgs.ctypes.data, n, recs.ctypes.data, g2.ctypes.data, pts.ctypes.data), "map_to_g2")
+        return recs, g2, pts
 
     def inner_products(self, g1, g2, count=1):
         """prod_i pairing(A_i, B_i) (sipp_inner_products): g1 [count * n, 16], g2 [count * n, 32] uint32 limbs -> [count, 96]"""

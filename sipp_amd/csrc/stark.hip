@@ -16,7 +16,7 @@
 
 #include "prover.hpp"
 
-static const int IO_WORDS[3] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS};
+static const int IO_WORDS[4] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS, SIPP_MAP_G2_IO_WORDS};
 #define SIPP_MAGIC 0x5349505053544b31ULL /* "SIPPSTK1" */
 
 struct Shape {
@@ -27,13 +27,14 @@ struct Shape {
 };
 
 static int shape_of(int kind, size_t num_io, Shape* s) {
-    if (kind < 0 || kind > 2 || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
-    uint32_t nio = 2;  // at least two IO blocks (1024 rows)
-    while (nio < num_io) nio <<= 1;
-    uint32_t log_n = 9;
-    while ((1u << (log_n - 9)) < nio) log_n++;
+    if (kind < 0 || kind > 3 || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
+    const uint32_t log_rows = kind == SIPP_MAP_G2 ? 0 : 9;   // rows per record: 512 (exponentiations), 1 (MapToG2)
+    uint32_t nio = 2;  // at least two IO blocks, at least 1024 rows
+    while (nio < num_io || ((size_t)nio << log_rows) < 1024) nio <<= 1;
+    uint32_t log_n = log_rows;
+    while ((1u << (log_n - log_rows)) < nio) log_n++;
     s->air = sipp_air_get(kind, log_n);
-    if (!s->air) return SIPP_E_UNSUPPORTED;
+    if (!s->air || (uint32_t)s->air->log_rows != log_rows) return SIPP_E_UNSUPPORTED;
     s->log_n = log_n;
     s->num_io = nio;
     s->W = s->air->n_main + 2 * s->air->n_checked;
@@ -220,6 +221,11 @@ static bool fq_words_canonical(const uint32_t* w) {
 }
 // every Fq element of every record < p (the exponent may be any 256-bit value): (x, offset, exp_val, output)
 static bool pis_canonical(int kind, const uint32_t* pis, size_t num_io) {
+    if (kind == SIPP_MAP_G2) {   // (u, x, y): six Fq elements, no exponent
+        for (size_t k = 0; k < 6 * num_io; k++)
+            if (!fq_words_canonical(pis + 8 * k)) return false;
+        return true;
+    }
     const int fe = kind == SIPP_G1_EXP ? 2 : kind == SIPP_G2_EXP ? 4 : 12, ppi = 8 * (3 * fe + 1);
     for (size_t io = 0; io < num_io; io++)
         for (int k = 0; k < 3 * fe + 1; k++)
@@ -400,7 +406,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     {
         ArenaMark mark_q = arena_mark(ctx);
         const int n_aux = a->n_aux;
-        const uint32_t log_io = log_n - 9;
+        const uint32_t log_io = log_n - (uint32_t)a->log_rows;
         const size_t nio = s.num_io;
         // public-input polynomials: interpolate over the order-nio subgroup, shift, LDE to the coset
         std::vector<uint64_t> auxc((size_t)n_aux * nio), col(nio);
@@ -606,7 +612,7 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
-    const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : kind == SIPP_G2_EXP ? 32 : 96;
+    const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : kind == SIPP_FQ12_EXP ? 96 : 32;
     ArenaScope scope(ctx);
     uint32_t* d_ios = nullptr;
     int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
@@ -805,6 +811,11 @@ int sipp_fq12_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint6
                         size_t* proof_len) {
     return prove_impl(ctx, SIPP_FQ12_EXP, ios, num_io, proof_out, proof_cap, proof_len);
 }
+// MapToG2 (kind 3, include/sipp_hip.h): the STARK behind batch_map_to_g2_circuit (reference src/bin/bls_aggregation.rs:65)
+int sipp_map_to_g2_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
+                         size_t* proof_len) {
+    return prove_impl(ctx, SIPP_MAP_G2, ios, num_io, proof_out, proof_cap, proof_len);
+}
 
 // ---- asynchronous form -------------------------------------------------------------------------------------
 // plonky2 runs its witness generators serially on one thread (SURVEY.md section 8b "who calls it"): a patched caller
@@ -830,7 +841,7 @@ static void async_worker(sipp_ctx* ctx) {
 
 int sipp_prove_async(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap) {
     if (!ctx || !ios || !proof_out) return SIPP_E_BADARG;
-    if (kind < SIPP_G1_EXP || kind > SIPP_FQ12_EXP) return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: unknown kind");
+    if (kind < SIPP_G1_EXP || kind > SIPP_MAP_G2) return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: unknown kind");
     sipp_ctx::Async& a = ctx->async;
     std::unique_lock<std::mutex> lk(a.mu);
     if (a.has_job) {

@@ -1070,8 +1070,16 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     const size_t n = (size_t)1 << log_n;
     const int cpl = a->cells_per_limb, nm = a->n_main, nc = a->n_checked;
     ArenaMark mark = arena_mark(ctx);
-    int col_bit, col_e, exp_off;
-    if (a->kind == 2) {
+    int col_bit = 0, col_e = 0, exp_off = 0;
+    if (a->kind == 3) {
+        // MapToG2: one row per message, no exponent / accumulator cells (mapg2.hip); the claimed point is compared there
+        if (ctx->outputs_only) {
+            SIPP_TRY(sipp_mapg2_outputs(ctx, const_cast<uint32_t*>(d_ios), num_io, d_err));
+            arena_release(ctx, mark);
+            return SIPP_OK;
+        }
+        SIPP_TRY(sipp_mapg2_fill(ctx, a, d_ios, num_io, log_n, d_trace, d_err));
+    } else if (a->kind == 2) {
         Fq12Cols c{1, 1 + 192, a->checked_base, cpl};
         col_bit = 1 + 384;
         col_e = col_bit + 1;
@@ -1140,7 +1148,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         arena_release(ctx, mark);
         return SIPP_OK;
     }
-    {
+    if (a->kind != 3) {
         // accumulator state columns: R (curves, column 1) or acc (Fq12, column 1)
         ProfScope ps(ctx, "trace_check_outputs");
         hipLaunchKernelGGL(check_outputs_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
@@ -1149,8 +1157,9 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     }
     {
         ProfScope ps(ctx, "trace_exp_table");
-        hipLaunchKernelGGL(exp_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ios,
-                           (uint32_t)a->pi_per_io, (uint32_t)exp_off, d_trace, n, col_bit, col_e);
+        if (a->kind != 3)
+            hipLaunchKernelGGL(exp_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ios,
+                               (uint32_t)a->pi_per_io, (uint32_t)exp_off, d_trace, n, col_bit, col_e);
         hipLaunchKernelGGL(table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n,
                            (uint32_t)a->table_bits);
         SIPP_CHECK_HIP(ctx, hipGetLastError());

@@ -140,7 +140,7 @@ class OrcAir(C.Structure):
                 ("n_main", C.c_int), ("checked_base", C.c_int), ("n_checked", C.c_int), ("n_ops", C.c_int),
                 ("n_constraints", C.c_int), ("n_aux", C.c_int), ("pi_per_io", C.c_int), ("n_gadgets", C.c_int),
                 ("carry_limbs", C.c_int), ("prog", C.POINTER(C.c_int64)), ("prog_len", C.c_int),
-                ("aux", C.POINTER(C.c_int32))]
+                ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int)]
 
 
 class OrcTrace(C.Structure):
@@ -181,6 +181,23 @@ class Trace:
                 self.L.orc_trace_free(self.p)
         except Exception:
             pass
+
+
+# ---------------- the map Fp2 -> E'(Fp2) in front of the BLS example (oracle/mapg2.c) ----------------
+def map_to_g2(u_words):
+    """u: [n][16] u32 -> MapToG2 records [n][48] = (u, x, y), x / y by the C reading of the Shallue - van de Woestijne map"""
+    L = load()
+    L.orc_map_to_g2.argtypes = [u32p, u32p]
+    u = np.ascontiguousarray(u_words, dtype=np.uint32).reshape(-1, 16)
+    out = np.zeros((u.shape[0], 48), dtype=np.uint32)
+    for i in range(u.shape[0]):
+        xy = np.zeros(32, dtype=np.uint32)
+        rc = L.orc_map_to_g2(np.ascontiguousarray(u[i]), xy)
+        if rc != 0:
+            raise RuntimeError("orc_map_to_g2 failed: %d" % rc)
+        out[i, :16] = u[i]
+        out[i, 16:] = xy
+    return out
 
 
 # ---------------- STARK prover / verifier (oracle/stark.c) ----------------

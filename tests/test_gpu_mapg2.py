@@ -1,0 +1,103 @@
+"""MapToG2 (kind 3; SURVEY.md section 8f rank 4, reference src/bin/bls_aggregation.rs:65, :100-104) on the GPU against the two
+CPU readings: the map's values, the trace cell for cell, the proof word for word, the cofactor clearing as G2ExpStark obligations."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle", "py"))
+
+pytestmark = pytest.mark.gpu
+
+
+def messages(n, seed=11):
+    import bn254
+    import random
+    rnd = random.Random(seed)
+    us = [(rnd.randrange(bn254.P), rnd.randrange(bn254.P)) for _ in range(n)]
+    us[0] = (0, 5)           # sgn0 decided by the second coordinate
+    if n > 2:
+        us[1] = (7, 0)
+        us[2] = (0, 0)       # u = 0: tv1 = 0, x1 = x2 = -Z/2 +- 0
+    return us, np.array([bn254.fq_to_u32(u[0]) + bn254.fq_to_u32(u[1]) for u in us], dtype=np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sipp_amd
+    c = sipp_amd.Ctx(workspace_bytes=max(sipp_amd.lib().sipp_workspace_bytes(3, 40), sipp_amd.lib().sipp_workspace_bytes(1, 80)))
+    yield c
+    c.close()
+
+
+def test_map_and_cofactor_clearing_match_the_python_reading(ctx):
+    import bn254
+    import map_to_g2 as M
+    us, words = messages(20)
+    recs, g2, pts = ctx.map_to_g2(words)
+    assert (recs == _oracle.map_to_g2(words)).all()          # C reading
+    branches = set()
+    for i, u in enumerate(us):
+        w = M.witness(u)
+        branches.add((w["e1"], w["e2"]))
+        q = (w["XS"], w["Y"])
+        assert list(recs[i, 16:]) == bn254.g2_to_u32(q)
+        cleared = bn254.g2_mul(q, bn254.G2_COFACTOR)
+        assert list(pts[i]) == bn254.g2_to_u32(cleared)
+        assert bn254.g2_mul(cleared, bn254.R) is None        # in the r-torsion
+        # the two obligations per message: G + [h] Q, then - G
+        assert list(g2[i, :32]) == bn254.g2_to_u32(q) and list(g2[i, 32:64]) == bn254.g2_to_u32(bn254.G2)
+        assert list(g2[20 + i, 72:]) == bn254.g2_to_u32(cleared) and list(g2[20 + i, 32:64]) == list(g2[i, 72:])
+    assert len(branches) == 3, branches                      # x1, x2 and x3 all taken
+    # the obligations are ordinary G2ExpStark records: the oracle's generator accepts them (claimed outputs checked)
+    t = _oracle.Trace(1, g2[[0, 1, 20, 21]])
+    assert t.check_row(0) == -1 and t.check_row(1023) == -1
+
+
+def test_trace_matches_oracle_cell_for_cell(ctx):
+    from sipp_amd._lib import to_host
+    _, words = messages(37)
+    recs = ctx.map_to_g2(words, cofactor=False)
+    ref = _oracle.Trace(3, recs)
+    assert ref.log_n == 10 and ref.air.table_bits == 8 and ref.air.log_rows == 0
+    assert ctx.shape(3, 37)[:2] == (10, ref.width)
+    got = to_host(ctx.trace_build(3, recs))
+    want = ref.array()
+    assert got.shape == want.shape
+    if not (got == want).all():
+        bad = np.argwhere(got != want)
+        raise AssertionError("%d cells differ; first (col,row): %s" % (len(bad), bad[:8].tolist()))
+
+
+def test_proof_matches_oracle_word_for_word_and_verifies(ctx):
+    _, words = messages(5, seed=3)
+    recs = ctx.map_to_g2(words, cofactor=False)
+    proof = ctx.prove(3, recs)
+    assert _oracle.stark_verify(proof) == 0
+    want = _oracle.stark_prove(3, recs)
+    assert proof.shape == want.shape and (proof == want).all()
+
+
+def test_wrong_or_unprovable_records_are_refused(ctx):
+    import sipp_amd
+    import bn254
+    _, words = messages(4, seed=5)
+    recs = ctx.map_to_g2(words, cofactor=False)
+    bad = recs.copy()
+    # the other root: on the curve, wrong sign
+    y = (bn254.u32_to_fq(list(bad[1, 32:40])), bn254.u32_to_fq(list(bad[1, 40:48])))
+    bad[1, 32:] = bn254.fq_to_u32((-y[0]) % bn254.P) + bn254.fq_to_u32((-y[1]) % bn254.P)
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.prove(3, bad)
+    assert e.value.code == -8                     # SIPP_E_WITNESS
+    bad = recs.copy()
+    bad[2, 0:8] = bn254.fq_to_u32(bn254.P - 1)
+    bad[2, 7] |= 0x80000000                      # u.c0 >= p
+    with pytest.raises(sipp_amd.SippError) as e:
+        ctx.prove(3, bad)
+    assert e.value.code == -8
+    # the ctx survives
+    assert _oracle.stark_verify(ctx.prove(3, recs)) == 0

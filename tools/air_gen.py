@@ -65,6 +65,7 @@ class Air:
         self.aux = []                               # (pi_word_index, part, shift_rows): part 0 = lo16, 1 = hi16, 2 = u32
         self.pi_per_io = 0
         self.max_e = 0
+        self.log_rows = 9                           # log2 of the rows per IO record
 
     # ---- column allocation: all unchecked first, then all checked ----
     def alloc(self, name, n):
@@ -407,6 +408,160 @@ def build_fq12(mode):
 
 
 # ------------------------------------------------------------------------------------------------
+def svdw_constants():
+    """constants of the Shallue - van de Woestijne map for E'(Fp2): y^2 = x^3 + 3/(9+u), Z = 1 (RFC 9380 appendix F.1);
+    the same values oracle/py/map_to_g2.py derives (tests compare)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import map_to_g2 as m
+    import bn254
+    return dict(C1=m.C1, C2=m.C2, C3=m.C3, C4=m.C4, BB=bn254.B2, ONE=(1, 0))
+
+
+def build_map_g2(mode):
+    """u in Fp2  ->  (x, y) on E'(Fp2) by the Shallue - van de Woestijne map (RFC 9380 F.1, Z = 1): the statement behind
+    `batch_map_to_g2_circuit` (reference src/bin/bls_aggregation.rs:65; the cofactor multiplication that follows the map
+    there is an ordinary G2ExpStark obligation).  ONE ROW PER MESSAGE, no transition constraints: 21 Fp2 witnesses, each
+    defined by one Fp2 identity = two limb gadgets; the three-way choice of x is by two boolean cells:
+        e1 = 1            : x = x1, y^2 = g(x1)
+        e1 = 0, e2 = 1    : N1^2 = (9+u) g(x1)  (g(x1) is NOT a square: 9+u is a non-residue),  x = x2, y^2 = g(x2)
+        e1 = 0, e2 = 0    : N1^2 = (9+u) g(x1), N2^2 = (9+u) g(x2),  x = x3, y^2 = g(x3)
+    The sign rule sgn0(y) = sgn0(u) and the canonicity of u, x, y are PUBLIC checks on the public inputs (both provers and the
+    verifier make them), not constraints.  IO record: u (16 u32), x (16), y (16)."""
+    a = Air("mapg2", mode)
+    a.gadgets = []
+    a.group = 2
+    a.log_rows = 0
+    consts = svdw_constants()
+    F2 = 2 * NL
+    a.alloc("U", F2)
+    for nm in ("ONE", "C1", "C2", "C3", "C4", "BB"):
+        a.alloc(nm, F2)
+    a.alloc("e1", 1); a.alloc("e2", 1)
+    for nm in ("M1", "M2", "XS", "GXS"):
+        a.alloc(nm, F2)
+    wit = ["T1", "TV1", "W", "TV3", "A4", "B4", "X2", "X1", "S1", "GX1", "S2", "GX2", "D", "E", "F", "X3", "S3", "GX3",
+           "N1", "N2", "Y"]
+    for nm in wit:
+        a.alloc_checked(nm, F2 * a.cpl)
+    gnames = ["t1", "tv1", "w", "inv", "a4", "b4", "x2", "x1", "s1", "gx1", "s2", "gx2", "d", "e", "f", "x3", "s3", "gx3",
+              "n1", "n2", "y"]
+    bound = 43
+    for g in gnames:
+        for c in range(2):
+            a.declare_gadget_cols("%s%d" % (g, c), bound)
+    a.finalize_columns()
+
+    def U(nm):      # unchecked Fp2 value: c -> vector
+        def f(c, coef=1):
+            t, n = a.vec_u16(nm, coef=coef)
+            return [(co, b + NL * c, st, fl, ng) for (co, b, st, fl, ng) in t], n
+        return f
+
+    def C(nm):      # checked Fp2 value
+        def f(c, coef=1):
+            t, n = a.vec_chk(nm, coef=coef)
+            return [(co, b + NL * a.cpl * c, st, fl, ng) for (co, b, st, fl, ng) in t], n
+        return f
+
+    def lc(*terms):  # linear combination of Fp2 values: (coef, fn)
+        def f(c, coef=1):
+            return Air.vsum(*[fn(c, coef * k) for k, fn in terms])
+        return f
+
+    def fp2_identity(name, prods, lins):
+        """sum coef A B + sum coef L = 0 in Fp2; prods: [(coef, fnA, fnB)], lins: [(coef, fn)]"""
+        for c in range(2):
+            pp = []
+            for coef, fa, fb in prods:
+                if c == 0:
+                    pp += [(coef, fa(0), fb(0)), (-coef, fa(1), fb(1))]
+                else:
+                    pp += [(coef, fa(0), fb(1)), (coef, fa(1), fb(0))]
+            a.gadget("%s%d" % (name, c), pp, [(coef, fn(c)) for coef, fn in lins], bound)
+
+    def times_xi(fn):
+        """(9 + u) v as two linear forms: component 0: 9 v0 - v1, component 1: v0 + 9 v1"""
+        def f(c, coef=1):
+            if c == 0:
+                return Air.vsum(fn(0, 9 * coef), fn(1, -coef))
+            return Air.vsum(fn(0, coef), fn(1, 9 * coef))
+        return f
+
+    u, one = U("U"), U("ONE")
+    tv1n = lc((1, one), (-1, C("TV1")))      # 1 - u^2 g(Z)
+    tv2 = lc((1, one), (1, C("TV1")))        # 1 + u^2 g(Z)
+    fp2_identity("t1", [(1, u, u)], [(-1, C("T1"))])
+    fp2_identity("tv1", [(1, U("C1"), C("T1"))], [(-1, C("TV1"))])
+    fp2_identity("w", [(1, tv1n, tv2)], [(-1, C("W"))])
+    fp2_identity("inv", [(1, C("TV3"), C("W"))], [(-1, one)])
+    fp2_identity("a4", [(1, u, tv1n)], [(-1, C("A4"))])
+    fp2_identity("b4", [(1, C("A4"), C("TV3"))], [(-1, C("B4"))])
+    fp2_identity("x2", [(1, C("B4"), U("C3"))], [(-1, C("X2")), (1, U("C2"))])          # x2 = -Z/2 + tv4
+    fp2_identity("x1", [], [(1, C("X1")), (1, C("X2")), (-2, U("C2"))])                 # x1 = -Z/2 - tv4
+    for k in ("1", "2", "3"):
+        fp2_identity("s" + k, [(1, C("X" + k), C("X" + k))], [(-1, C("S" + k))])
+        fp2_identity("gx" + k, [(1, C("S" + k), C("X" + k))], [(1, U("BB")), (-1, C("GX" + k))])
+        if k == "2":
+            fp2_identity("d", [(1, tv2, tv2)], [(-1, C("D"))])
+            fp2_identity("e", [(1, C("D"), C("TV3"))], [(-1, C("E"))])
+            fp2_identity("f", [(1, C("E"), C("E"))], [(-1, C("F"))])
+            fp2_identity("x3", [(1, C("F"), U("C4"))], [(1, one), (-1, C("X3"))])     # Z = 1
+    fp2_identity("n1", [(1, C("N1"), C("N1"))], [(-1, times_xi(U("M1")))])
+    fp2_identity("n2", [(1, C("N2"), C("N2"))], [(-1, times_xi(U("M2")))])
+    fp2_identity("y", [(1, C("Y"), C("Y"))], [(-1, U("GXS"))])
+    # gadgets are emitted in declaration order (the carry / quotient columns were allocated in that order)
+    order = {"%s%d" % (g, c): i for i, (g, c) in enumerate((g, c) for g in gnames for c in range(2))}
+    a.gadgets.sort(key=lambda g: order[g["name"]])
+    a.emit_gadgets()
+    # constants
+    for nm, v in consts.items():
+        for c in range(2):
+            for i in range(NL):
+                a.poly([(1, [L(a.col(nm) + NL * c + i)]), (-((v[c] >> (16 * i)) & 0xFFFF), [])])
+    e1, e2 = a.col("e1"), a.col("e2")
+    a.poly([(1, [L(e1), L(e1)]), (-1, [L(e1)])])
+    a.poly([(1, [L(e2), L(e2)]), (-1, [L(e2)])])
+
+    def chk_limb(nm, j):   # 16-bit limb j (0..31) of a checked Fp2 value as [(coef, col)]
+        b = a.col(nm)
+        return [(1, b + j)] if a.cpl == 1 else [(1, b + 2 * j), (256, b + 2 * j + 1)]
+
+    for j in range(F2):
+        # M1 = (1 - e1) g(x1)
+        m = [(1, [L(a.col("M1") + j)])]
+        for co, cc in chk_limb("GX1", j):
+            m += [(-co, [L(cc)]), (co, [L(e1), L(cc)])]
+        a.poly(m)
+        # M2 = (1 - e1)(1 - e2) g(x2)
+        m = [(1, [L(a.col("M2") + j)])]
+        for co, cc in chk_limb("GX2", j):
+            m += [(-co, [L(cc)]), (co, [L(e1), L(cc)]), (co, [L(e2), L(cc)]), (-co, [L(e1), L(e2), L(cc)])]
+        a.poly(m)
+        # selected = e1 v1 + (1 - e1) e2 v2 + (1 - e1)(1 - e2) v3
+        for dst, src in (("XS", "X"), ("GXS", "GX")):
+            m = [(1, [L(a.col(dst) + j)])]
+            for co, cc in chk_limb(src + "1", j):
+                m += [(-co, [L(e1), L(cc)])]
+            for co, cc in chk_limb(src + "2", j):
+                m += [(-co, [L(e2), L(cc)]), (co, [L(e1), L(e2), L(cc)])]
+            for co, cc in chk_limb(src + "3", j):
+                m += [(-co, [L(cc)]), (co, [L(e1), L(cc)]), (co, [L(e2), L(cc)]), (-co, [L(e1), L(e2), L(cc)])]
+            a.poly(m)
+    # public inputs: u, x, y as u32 words; every 16-bit limb is bound on EVERY row (one row per record)
+    word = 0
+    for nm, checked in (("U", False), ("XS", False), ("Y", True)):
+        for j in range(F2):
+            ai = len(a.aux)
+            a.aux.append((word + j // 2, j % 2, 0, 0))
+            cells = chk_limb(nm, j) if checked else [(1, a.col(nm) + j)]
+            a.poly([(co, [L(cc)]) for co, cc in cells] + [(-1, [AUX(ai)])])
+        word += NL
+    a.pi_per_io = word
+    a.primary = dict(kind="mapg2")
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
 def emit(a, f, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     f.write("static const int64_t %s_PROG[] = {\n" % tag)
@@ -422,14 +577,15 @@ def emit(a, f, prefix):
 def header_entry(a, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     g0 = a.gadgets[0]
-    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX},\n" % (
-        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
-        a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag))
+    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d},\n" % (
+        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
+        a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag,
+        a.log_rows))
 
 
 STRUCT = """typedef struct {
     const char *name;
-    int kind;            /* 0 g1, 1 g2, 2 fq12 */
+    int kind;            /* 0 g1, 1 g2, 2 fq12, 3 mapg2 */
     int table_bits;      /* 16 or 8 */
     int cells_per_limb;  /* checked cells per 16-bit limb: 1 (u16 table) or 2 (u8 table) */
     int n_main;          /* TABLE + unchecked + checked cells */
@@ -444,6 +600,7 @@ STRUCT = """typedef struct {
     const int64_t *prog;
     int prog_len;
     const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
+    int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 0 for mapg2 */
 } %s_air_t;
 """
 
@@ -456,7 +613,7 @@ def column_map(a):
 def main():
     airs = []
     for mode in ("u16", "u8"):
-        airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode)]
+        airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode), build_map_g2(mode)]
     for path, prefix, guard in ((os.path.join(ROOT, "oracle", "air_tables.h"), "ORC", "ORACLE_AIR_TABLES_H"),
                                 (os.path.join(ROOT, "sipp_amd", "csrc", "air_tables.h"), "SIPP", "SIPP_AIR_TABLES_H")):
         with open(path, "w") as f:
