@@ -101,3 +101,24 @@ def test_wrong_or_unprovable_records_are_refused(ctx):
     assert e.value.code == -8
     # the ctx survives
     assert _oracle.stark_verify(ctx.prove(3, recs)) == 0
+
+
+def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
+    """more than 2^15 messages: 2^16 rows, where the range table is the u16 one (one checked cell per limb: W = 8335, P = 5292).  The
+    oracle's verifier replays the proof (its own prover would need minutes for 2^16 x 13 631 cells)."""
+    import sipp_amd
+    _, words = messages(40, seed=9)
+    L = sipp_amd.lib()
+    n = 40000
+    c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(3, n))
+    try:
+        assert c.shape(3, n) == (16, 8335, 5292, 4)
+        recs40 = c.map_to_g2(words, cofactor=False)
+        recs = recs40[np.arange(n) % 40]
+        proof = c.prove(3, recs)
+    finally:
+        c.close()
+    assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 16, 65536)
+    assert _oracle.stark_verify(proof) == 0
+    proof[16 + 5] ^= 1
+    assert _oracle.stark_verify(proof) != 0
