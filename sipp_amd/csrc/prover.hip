@@ -1127,8 +1127,10 @@ int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[
                      int n1, gl::E2 shift1, const uint64_t* d_zp[2], const uint64_t* d_zip[2], uint64_t* d_final) {
     ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     // enough (block, slice) pairs to fill the chip: short traces with many columns (Fq12) get more slices
+    // (and no slice above the kernel's 1024 columns: MapToG2's 13 631 columns at 2^16 rows)
+    const int total_cols = cnt[0] + cnt[1] + cnt[2];
     int slices = 8;
-    while (slices < 64 && (n / 256) * (size_t)slices < 2048) slices *= 2;
+    while (slices < 64 && ((n / 256) * (size_t)slices < 2048 || (total_cols + slices - 1) / slices > 1024)) slices *= 2;
     uint64_t* partial = arena_alloc_t<uint64_t>(ctx, (size_t)slices * 4 * n);
     uint64_t* q = arena_alloc_t<uint64_t>(ctx, 4 * n);
     if (!partial || !q) return SIPP_E_NOMEM;
