@@ -227,26 +227,43 @@ static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, c
     return 0;
 }
 
-/* MapToG2 (kind 3): one row per record (u, x, y); columns as tools/air_gen.py::build_map_g2 allocates them */
-enum { MGC_U = 1, MGC_ONE = 33, MGC_C1 = 65, MGC_C2 = 97, MGC_C3 = 129, MGC_C4 = 161, MGC_BB = 193, MGC_E1 = 225, MGC_E2 = 226,
-       MGC_M1 = 227, MGC_M2 = 259, MGC_XS = 291, MGC_GXS = 323, MGC_CHECKED = 397 };
-
+/* MapToG2 (kind 3): eight rows per record (u, x, y); columns and schedule from the tables tools/air_gen.py::build_map_g2 emits:
+ * row t of the block holds the witnesses ORC_MAPG2_SLOT_WIT[t][0..2] in its three result slots and ORC_MAPG2_REG_WIT[t][0..5]
+ * in its six registers (zero where the table says -1); u, e1, e2 and the constants on every row; M1, M2, XS, GXS as the
+ * (ungated) selection constraints define them from the registers of THAT row. */
 static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
-    if (a->checked_base != MGC_CHECKED) return -20;
     const int cpl = a->cells_per_limb;
+    const int32_t *lay = cpl == 1 ? ORC_MAPG2_LAYOUT_U16 : ORC_MAPG2_LAYOUT_U8;
+    enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2, L_RG3 };
+    if (a->log_rows != 3 || ORC_MAPG2_ROWS != 8 || ORC_MAPG2_NWIT != MG_NWIT || lay[L_RES] != a->checked_base) return -20;
     orc_mapg2_consts k;
     orc_mapg2_constants(&k);
     orc_mapg2_wit w;
     fq2 u = read_f2(rec, 2);
     if (orc_mapg2_witness(u, &w)) return -1;       /* u^2 g(Z) = +-1 */
-    const size_t row = io;
-    put_f2_u16(tr, n, MGC_U, row, u, 2);
-    put_f2_u16(tr, n, MGC_ONE, row, k.one, 2); put_f2_u16(tr, n, MGC_C1, row, k.c1, 2); put_f2_u16(tr, n, MGC_C2, row, k.c2, 2);
-    put_f2_u16(tr, n, MGC_C3, row, k.c3, 2); put_f2_u16(tr, n, MGC_C4, row, k.c4, 2); put_f2_u16(tr, n, MGC_BB, row, k.b, 2);
-    put(tr, n, MGC_E1, row, (uint64_t)w.e1); put(tr, n, MGC_E2, row, (uint64_t)w.e2);
-    put_f2_u16(tr, n, MGC_M1, row, w.m1, 2); put_f2_u16(tr, n, MGC_M2, row, w.m2, 2);
-    put_f2_u16(tr, n, MGC_XS, row, w.xs, 2); put_f2_u16(tr, n, MGC_GXS, row, w.gxs, 2);
-    for (int i = 0; i < MG_NWIT; i++) put_f2_chk(tr, n, MGC_CHECKED + 32 * cpl * i, row, w.v[i], 2, cpl);
+    const fq2 zero = {fq_zero(), fq_zero()};
+    for (int t = 0; t < 8; t++) {
+        const size_t row = io * 8 + (size_t)t;
+        put_f2_u16(tr, n, lay[L_U], row, u, 2);
+        put_f2_u16(tr, n, lay[L_ONE], row, k.one, 2); put_f2_u16(tr, n, lay[L_C1], row, k.c1, 2); put_f2_u16(tr, n, lay[L_C2], row, k.c2, 2);
+        put_f2_u16(tr, n, lay[L_C3], row, k.c3, 2); put_f2_u16(tr, n, lay[L_C4], row, k.c4, 2); put_f2_u16(tr, n, lay[L_BB], row, k.b, 2);
+        put(tr, n, lay[L_E1], row, (uint64_t)w.e1); put(tr, n, lay[L_E2], row, (uint64_t)w.e2);
+        fq2 reg[6];
+        for (int r = 0; r < 6; r++) {
+            int wi = ORC_MAPG2_REG_WIT[t][r];
+            reg[r] = wi < 0 ? zero : w.v[wi];
+            put_f2_u16(tr, n, lay[L_REG] + 32 * r, row, reg[r], 2);
+        }
+        for (int sl = 0; sl < 3; sl++) {
+            int wi = ORC_MAPG2_SLOT_WIT[t][sl];
+            put_f2_chk(tr, n, lay[L_RES] + 32 * cpl * sl, row, wi < 0 ? zero : w.v[wi], 2, cpl);
+        }
+        const fq2 gx1 = reg[lay[L_RG1]], gx2 = reg[lay[L_RG2]], gx3 = reg[lay[L_RG3]];
+        put_f2_u16(tr, n, lay[L_M1], row, w.e1 ? zero : gx1, 2);
+        put_f2_u16(tr, n, lay[L_M2], row, (w.e1 || w.e2) ? zero : gx2, 2);
+        put_f2_u16(tr, n, lay[L_XS], row, w.e1 ? reg[lay[L_RX1]] : w.e2 ? reg[lay[L_RX2]] : reg[lay[L_RX3]], 2);
+        put_f2_u16(tr, n, lay[L_GXS], row, w.e1 ? gx1 : w.e2 ? gx2 : gx3, 2);
+    }
     fq_to_u32(w.xs.c0, out_words); fq_to_u32(w.xs.c1, out_words + 8);
     fq_to_u32(w.v[MG_Y].c0, out_words + 16); fq_to_u32(w.v[MG_Y].c1, out_words + 24);
     return 0;
@@ -394,7 +411,7 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
     fq_init();
     *err = 0;
     if (num_io == 0) { *err = -1; return NULL; }
-    const unsigned log_rows = kind == 3 ? 0 : 9;   /* rows per record: 512 (exponentiations), 1 (MapToG2); = air->log_rows */
+    const unsigned log_rows = kind == 3 ? 3 : 9;   /* rows per record: 512 (exponentiations), 8 (MapToG2); = air->log_rows */
     size_t nio = 2; /* at least two IO blocks, at least 1024 rows */
     while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
     unsigned log_n = log_rows;

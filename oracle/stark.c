@@ -360,7 +360,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     unsigned log_n = (unsigned)h[2];
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
-    const unsigned log_rows = kind == 3 ? 0 : 9;
+    const unsigned log_rows = kind == 3 ? 3 : 9;
     if (kind < 0 || kind > 3 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const orc_air_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||

@@ -1,5 +1,5 @@
 // sipp_amd/csrc/mapg2.hip -- the map Fp2 -> E'(Fp2) in front of SIPP's BLS example, on the device: native values and the
-// primary witness of the MapToG2 AIR (tools/air_gen.py::build_map_g2, one trace row per message).
+// primary witness of the MapToG2 AIR (tools/air_gen.py::build_map_g2, eight trace rows per message).
 //
 // Replaces plonky2_bn254::curves::map_to_g2::map_to_g2_without_cofactor_mul (reference src/bin/bls_aggregation.rs:21, :102) and
 // the trace generator behind starky_bn254's batch_map_to_g2_circuit (:31, :65); neither crate is under /root/reference, so
@@ -105,17 +105,20 @@ __device__ __forceinline__ void store_chk(uint64_t* tr, size_t n, int col, size_
         }
 }
 
-// column bases of the unchecked cells (tools/air_gen.py::build_map_g2 allocates in this order; the host checks checked_base)
-enum { MGC_U = 1, MGC_ONE = 33, MGC_C1 = 65, MGC_C2 = 97, MGC_C3 = 129, MGC_C4 = 161, MGC_BB = 193, MGC_E1 = 225, MGC_E2 = 226,
-       MGC_M1 = 227, MGC_M2 = 259, MGC_XS = 291, MGC_GXS = 323, MGC_CHECKED = 397 };
 enum { MG_T1, MG_TV1, MG_W, MG_TV3, MG_A4, MG_B4, MG_X2, MG_X1, MG_S1, MG_GX1, MG_S2, MG_GX2, MG_D, MG_E, MG_F, MG_X3, MG_S3,
        MG_GX3, MG_N1, MG_N2, MG_Y, MG_NWIT };
+static_assert(MG_NWIT == SIPP_MAPG2_NWIT && SIPP_MAPG2_ROWS == 8, "witness order / rows per message of tools/air_gen.py");
+// index into SIPP_MAPG2_LAYOUT_*: columns, then the registers that hold x1 x2 x3 g(x1) g(x2) g(x3) for the selections
+enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2,
+       L_RG3, L_N };
 
 struct MapConsts {
     uint32_t c1[16], c2[16], c3[16], c4[16], b[16];
+    // the schedule of tools/air_gen.py (MAP_SLOTS / MAP_REG_LOADS) and the column layout of the AIR variant in use
+    int32_t slot_wit[8][3], reg_wit[8][6], lay[L_N];
 };
 
-// mode 0: trace row `io` (= message io) + the claimed (x, y) of the record compared; mode 1: (x, y) written into the record
+// mode 0: the eight trace rows of message `io` + the claimed (x, y) of the record compared; mode 1: (x, y) written into the record
 __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi, MapConsts k,
                                                        uint64_t* __restrict__ tr, size_t n, int cpl, int checked_base, int mode,
                                                        int* __restrict__ err) {
@@ -184,44 +187,63 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
         atomicExch(err, SIPP_E_WITNESS);
         return;
     }
-    const size_t row = io;
-    store_u16(tr, n, MGC_U, row, u);
-    store_u16(tr, n, MGC_ONE, row, one);
-    store_u16(tr, n, MGC_C1, row, c1);
-    store_u16(tr, n, MGC_C2, row, c2);
-    store_u16(tr, n, MGC_C3, row, c3);
-    store_u16(tr, n, MGC_C4, row, c4);
-    store_u16(tr, n, MGC_BB, row, bb);
-    tr[(size_t)MGC_E1 * n + row] = e1 ? 1 : 0;
-    tr[(size_t)MGC_E2 * n + row] = e2 ? 1 : 0;
-    store_u16(tr, n, MGC_M1, row, m1);
-    store_u16(tr, n, MGC_M2, row, mm2);
-    store_u16(tr, n, MGC_XS, row, xs);
-    store_u16(tr, n, MGC_GXS, row, gxs);
-    for (int i = 0; i < MG_NWIT; i++) store_chk(tr, n, checked_base + 32 * cpl * i, row, v[i], cpl);
+    const Fq2 gx1 = v[MG_GX1], gx2 = v[MG_GX2];
+    (void)gx1; (void)gx2;
+    for (int t = 0; t < 8; t++) {
+        const size_t row = (size_t)io * 8 + t;
+        store_u16(tr, n, k.lay[L_U], row, u);
+        store_u16(tr, n, k.lay[L_ONE], row, one);
+        store_u16(tr, n, k.lay[L_C1], row, c1);
+        store_u16(tr, n, k.lay[L_C2], row, c2);
+        store_u16(tr, n, k.lay[L_C3], row, c3);
+        store_u16(tr, n, k.lay[L_C4], row, c4);
+        store_u16(tr, n, k.lay[L_BB], row, bb);
+        tr[(size_t)k.lay[L_E1] * n + row] = e1 ? 1 : 0;
+        tr[(size_t)k.lay[L_E2] * n + row] = e2 ? 1 : 0;
+        Fq2 reg[6];
+        for (int r = 0; r < 6; r++) {
+            const int wi = k.reg_wit[t][r];
+            reg[r] = wi < 0 ? zero : v[wi];
+            store_u16(tr, n, k.lay[L_REG] + 32 * r, row, reg[r]);
+        }
+        for (int sl = 0; sl < 3; sl++) {
+            const int wi = k.slot_wit[t][sl];
+            store_chk(tr, n, checked_base + 32 * cpl * sl, row, wi < 0 ? zero : v[wi], cpl);
+        }
+        // the selection cells as the (ungated) constraints define them from the registers of THIS row
+        const Fq2 rg1 = reg[k.lay[L_RG1]], rg2 = reg[k.lay[L_RG2]], rg3 = reg[k.lay[L_RG3]];
+        store_u16(tr, n, k.lay[L_M1], row, e1 ? zero : rg1);
+        store_u16(tr, n, k.lay[L_M2], row, (e1 || e2) ? zero : rg2);
+        store_u16(tr, n, k.lay[L_XS], row, e1 ? reg[k.lay[L_RX1]] : e2 ? reg[k.lay[L_RX2]] : reg[k.lay[L_RX3]]);
+        store_u16(tr, n, k.lay[L_GXS], row, e1 ? rg1 : e2 ? rg2 : rg3);
+    }
 }
 
-MapConsts map_consts() {
+MapConsts map_consts(const sipp_air_t* a) {
     MapConsts k;
     memcpy(k.c1, SIPP_MAPG2_C1, 64);
     memcpy(k.c2, SIPP_MAPG2_C2, 64);
     memcpy(k.c3, SIPP_MAPG2_C3, 64);
     memcpy(k.c4, SIPP_MAPG2_C4, 64);
     memcpy(k.b, SIPP_MAPG2_B, 64);
+    memcpy(k.slot_wit, SIPP_MAPG2_SLOT_WIT, sizeof k.slot_wit);
+    memcpy(k.reg_wit, SIPP_MAPG2_REG_WIT, sizeof k.reg_wit);
+    memcpy(k.lay, (a && a->cells_per_limb == 1) ? SIPP_MAPG2_LAYOUT_U16 : SIPP_MAPG2_LAYOUT_U8, sizeof k.lay);
     return k;
 }
 
 }  // namespace
 
-// primary witness of the MapToG2 AIR: d_ios [num_io][48] (padded: num_io == n rows), every main cell of row io written
+// primary witness of the MapToG2 AIR: d_ios [num_io][48] (padded: 8 num_io == n rows), every primary cell of rows 8 io .. 8 io + 7
 int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
                     int* d_err) {
     const size_t n = (size_t)1 << log_n;
-    if (a->kind != 3 || a->checked_base != MGC_CHECKED || a->pi_per_io != 48 || (size_t)num_io != n)
+    const MapConsts k = map_consts(a);
+    if (a->kind != 3 || a->log_rows != 3 || a->checked_base != k.lay[L_RES] || a->pi_per_io != 48 || (size_t)num_io * 8 != n)
         return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "MapToG2: AIR table / shape mismatch");
     ProfScope ps(ctx, "trace_mapg2");
     hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io, 48u,
-                       map_consts(), d_trace, n, a->cells_per_limb, a->checked_base, 0, d_err);
+                       k, d_trace, n, a->cells_per_limb, a->checked_base, 0, d_err);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
@@ -229,7 +251,7 @@ int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
 // (x, y) of every record computed from its u and written into the record (device buffer [num_io][48])
 int sipp_mapg2_outputs(sipp_ctx* ctx, uint32_t* d_ios, uint32_t num_io, int* d_err) {
     ProfScope ps(ctx, "mapg2_outputs");
-    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io, 48u, map_consts(),
+    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io, 48u, map_consts(nullptr),
                        (uint64_t*)nullptr, (size_t)0, 1, 0, 1, d_err);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;

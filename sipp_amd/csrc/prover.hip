@@ -168,10 +168,13 @@ struct QCtx {
     size_t j, jn, m;
     uint64_t per[SIPP_N_PERIODIC];
     uint64_t acc0, acc1;
-    // select instead of a dynamically indexed private array (which would live in scratch memory)
+    // selects instead of a dynamically indexed private array (which would live in scratch memory); k is wave-uniform.  Indices
+    // 0 .. 3: the exponentiation AIRs' selectors, 4 .. 11: MapToG2's eight row types
     __device__ __forceinline__ uint64_t periodic(int k) const {
-        static_assert(SIPP_N_PERIODIC == 4, "periodic(): update the select chain");
-        return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
+        static_assert(SIPP_N_PERIODIC == 12, "periodic(): update the select chain");
+        if (k < 4) return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
+        if (k < 8) return k == 4 ? per[4] : k == 5 ? per[5] : k == 6 ? per[6] : per[7];
+        return k == 8 ? per[8] : k == 9 ? per[9] : k == 10 ? per[10] : per[11];
     }
     __device__ __forceinline__ uint64_t local(int c) const { return a->lde[(size_t)c * a->lde_stride + j]; }
     __device__ __forceinline__ uint64_t next(int c) const { return a->lde[(size_t)c * a->lde_stride + jn]; }

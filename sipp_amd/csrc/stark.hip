@@ -28,7 +28,7 @@ struct Shape {
 
 static int shape_of(int kind, size_t num_io, Shape* s) {
     if (kind < 0 || kind > 3 || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
-    const uint32_t log_rows = kind == SIPP_MAP_G2 ? 0 : 9;   // rows per record: 512 (exponentiations), 1 (MapToG2)
+    const uint32_t log_rows = kind == SIPP_MAP_G2 ? 3 : 9;   // rows per record: 512 (exponentiations), 8 (MapToG2)
     uint32_t nio = 2;  // at least two IO blocks, at least 1024 rows
     while (nio < num_io || ((size_t)nio << log_rows) < 1024) nio <<= 1;
     uint32_t log_n = log_rows;

@@ -62,7 +62,7 @@ def test_trace_matches_oracle_cell_for_cell(ctx):
     _, words = messages(37)
     recs = ctx.map_to_g2(words, cofactor=False)
     ref = _oracle.Trace(3, recs)
-    assert ref.log_n == 10 and ref.air.table_bits == 8 and ref.air.log_rows == 0
+    assert ref.log_n == 10 and ref.air.table_bits == 8 and ref.air.log_rows == 3 and ref.num_io == 128
     assert ctx.shape(3, 37)[:2] == (10, ref.width)
     got = to_host(ctx.trace_build(3, recs))
     want = ref.array()
@@ -104,21 +104,21 @@ def test_wrong_or_unprovable_records_are_refused(ctx):
 
 
 def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
-    """more than 2^15 messages: 2^16 rows, where the range table is the u16 one (one checked cell per limb: W = 8335, P = 5292).  The
-    oracle's verifier replays the proof (its own prover would need minutes for 2^16 x 13 631 cells)."""
+    """more than 4096 messages: 2^16 rows and more, where the range table is the u16 one (one checked cell per limb: W = 1687,
+    P = 756).  The oracle's verifier replays the proof."""
     import sipp_amd
     _, words = messages(40, seed=9)
     L = sipp_amd.lib()
-    n = 40000
+    n = 5000
     c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(3, n))
     try:
-        assert c.shape(3, n) == (16, 8335, 5292, 4)
+        assert c.shape(3, n) == (16, 1687, 756, 4)
         recs40 = c.map_to_g2(words, cofactor=False)
         recs = recs40[np.arange(n) % 40]
         proof = c.prove(3, recs)
     finally:
         c.close()
-    assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 16, 65536)
+    assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 16, 8192)
     assert _oracle.stark_verify(proof) == 0
     proof[16 + 5] ^= 1
     assert _oracle.stark_verify(proof) != 0

@@ -68,6 +68,21 @@ def test_c_and_python_readings_of_the_map_agree():
     assert bn254.g2_on_curve(q) and bn254.g2_mul(q, bn254.R) is None
 
 
+def air_tables():
+    """the MapToG2 schedule and column layout as tools/air_gen.py emitted them (oracle/air_tables.h)"""
+    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
+    def ints(name):
+        m = re.search(r"%s(?:\[\d+\])+ = \{(.*?)\};" % name, txt, re.S)
+        return [int(x) for x in re.findall(r"-?\d+", m.group(1))]
+    slot = np.array(ints("ORC_MAPG2_SLOT_WIT")).reshape(8, 3)
+    reg = np.array(ints("ORC_MAPG2_REG_WIT")).reshape(8, 6)
+    lay = dict(zip("U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES RX1 RX2 RX3 RG1 RG2 RG3".split(), ints("ORC_MAPG2_LAYOUT_U8")))
+    return slot, reg, lay
+
+
+NAMES = ["T1", "TV1", "W", "TV3", "A4", "B4", "X2", "X1", "S1", "GX1", "S2", "GX2", "D", "E", "F", "X3", "S3", "GX3", "N1", "N2", "Y"]
+
+
 @pytest.fixture(scope="module")
 def trace():
     us = messages(9, 2)
@@ -77,50 +92,93 @@ def trace():
 
 def test_every_row_satisfies_the_air_and_the_cells_are_the_python_witness(trace):
     us, recs, t = trace
-    assert (t.log_n, t.num_io, t.air.log_rows, t.air.table_bits, t.air.pi_per_io) == (10, 1024, 0, 8, 48)
+    slot, reg, lay = air_tables()
+    assert (t.log_n, t.num_io, t.air.log_rows, t.air.table_bits, t.air.pi_per_io) == (10, 128, 3, 8, 48)
     assert all(t.check_row(r) == -1 for r in range(1 << t.log_n))
     arr = t.array()
-    cb = t.air.checked_base
-    names = ["T1", "TV1", "W", "TV3", "A4", "B4", "X2", "X1", "S1", "GX1", "S2", "GX2", "D", "E", "F", "X3", "S3", "GX3", "N1", "N2", "Y"]
-    for row, u in enumerate(us):
+    assert lay["RES"] == t.air.checked_base
+    # every witness sits in exactly one slot of its block, and is in a register wherever the schedule says so
+    assert sorted(int(x) for x in slot.ravel() if x >= 0) == list(range(21))
+    def fp2_u16(col, row):
+        return tuple(sum(int(arr[col + 16 * c + l, row]) << (16 * l) for l in range(16)) for c in range(2))
+    def fp2_chk(col, row):
+        return tuple(sum((int(arr[col + 32 * c + 2 * l, row]) + 256 * int(arr[col + 32 * c + 2 * l + 1, row])) << (16 * l) for l in range(16))
+                     for c in range(2))
+    for io, u in enumerate(us):
         w = M.witness(u)
-        assert (int(arr[225, row]), int(arr[226, row])) == (w["e1"], w["e2"])
-        for k, nm in enumerate(names):
-            for c in range(2):
-                limbs = [int(arr[cb + 64 * k + 32 * c + 2 * l, row]) + 256 * int(arr[cb + 64 * k + 32 * c + 2 * l + 1, row]) for l in range(16)]
-                assert sum(v << (16 * l) for l, v in enumerate(limbs)) == w[nm][c], (nm, c, row)
-    # padding rows repeat the last record
-    assert (arr[1:t.air.n_main, 8] == arr[1:t.air.n_main, 1023]).all()     # column 0 is the range table
+        for tt in range(8):
+            row = 8 * io + tt
+            assert (int(arr[lay["e1"], row]), int(arr[lay["e2"], row])) == (w["e1"], w["e2"])
+            assert fp2_u16(lay["U"], row) == u
+            for sl in range(3):
+                if slot[tt, sl] >= 0:
+                    assert fp2_chk(lay["RES"] + 64 * sl, row) == w[NAMES[slot[tt, sl]]], (tt, sl)
+            for k in range(6):
+                if reg[tt, k] >= 0:
+                    assert fp2_u16(lay["REG"] + 32 * k, row) == w[NAMES[reg[tt, k]]], (tt, k)
+        assert fp2_u16(lay["XS"], 8 * io + 7) == w["XS"] and fp2_chk(lay["RES"], 8 * io + 7) == w["Y"]
+    # padding blocks repeat the last record
+    assert (arr[1:t.air.n_main, 8 * 8:8 * 9] == arr[1:t.air.n_main, 1016:1024]).all()     # column 0 is the range table
 
 
 def test_mutations_break_a_row_constraint(trace):
+    """one cell of every column class changed on every row type: the constraints of that row or of the row before it (register and
+    block-constant transitions look at the next row) must fail"""
     _, _, t = trace
+    slot, reg, lay = air_tables()
     arr = t.array()
     a = t.air
-    cb = a.checked_base
-    cols = {"U": 1 + 3, "ONE": 33, "C3": 129 + 17, "BB": 193 + 2, "e1": 225, "e2": 226, "M1": 227 + 1, "M2": 259, "XS": 291 + 4,
-            "GXS": 323 + 20, "sign": 355 + 7, "TV3": cb + 64 * 3 + 5, "X1": cb + 64 * 7, "GX2": cb + 64 * 11 + 33, "N1": cb + 64 * 18 + 2,
-            "Y": cb + 64 * 20 + 9, "q": cb + 64 * 21 + 3, "carry_last": a.n_main - 1}
-    tested_e2 = 0
+    prog = np.ctypeslib.as_array(a.prog, shape=(a.prog_len,))
+    sign0, carry0, q0 = int(prog[1]), int(prog[2]), int(prog[7 + 3])
+    cols = {"U": lay["U"] + 3, "ONE": lay["ONE"], "C3": lay["C3"] + 17, "BB": lay["BB"] + 2, "M1": lay["M1"] + 1, "M2": lay["M2"],
+            "XS": lay["XS"] + 4, "GXS": lay["GXS"] + 20, "sign": sign0, "q": q0 + 3, "carry": carry0 + 1, "carry_last": a.n_main - 1}
+    for sl in range(3):
+        cols["RES%d" % sl] = lay["RES"] + 64 * sl + 7 + 32 * (sl & 1)
+    for k in range(6):
+        cols["REG%d" % k] = lay["REG"] + 32 * k + 5 + 16 * (k & 1)
+    free = []
     for name, col in cols.items():
-        for row in (0, 3, 700) if name != "e2" else range(9):
-            if name == "e2":
-                if int(arr[225, row]):      # e1 = 1: e2 multiplies (1 - e1) everywhere, a free cell (the provers write 0)
-                    continue
-                tested_e2 += 1
+        for tt in range(8):
+            row = 8 * 2 + tt
             old = int(arr[col, row])
             arr[col, row] = old ^ 1
-            assert t.check_row(row) != -1, (name, row)
+            caught = t.check_row(row) != -1 or t.check_row(row - 1) != -1
             arr[col, row] = old
-            assert t.check_row(row) == -1
-    assert tested_e2 >= 1
-    # taking another branch than the map's is refused too: row 0's (e1, e2) flipped together with a consistent selection is
-    # not checkable cell by cell, but the two obvious lies are: claim "square" for a non-square, "non-square" for a square
-    for row in range(9):
-        e1 = int(arr[225, row])
-        arr[225, row] = 1 - e1
-        assert t.check_row(row) != -1
-        arr[225, row] = e1
+            assert t.check_row(row) == -1 and t.check_row(row - 1) == -1
+            if not caught:
+                free.append((name, tt))
+    # what may be free: a register before its first load of the block and while nothing reads it again, an unused result slot --
+    # none of them is read by a constraint that matters; every cell the schedule USES must be caught
+    for name, tt in free:
+        if name == "sign":      # the sign of a quotient that is zero (E = 0 exactly, e.g. x1 + x2 = 2 c2 without a wrap) is meaningless
+            assert not arr[q0:q0 + 34, 8 * 2 + tt].any(), tt
+        elif name.startswith("RES"):
+            assert slot[tt, int(name[3:])] < 0, (name, tt)      # a slot without an identity on this row type
+        elif name.startswith("REG"):
+            assert reg[tt, int(name[3:])] < 0, (name, tt)       # a register before its first load of the block
+        else:
+            raise AssertionError("free cell %s on row type %d" % (name, tt))
+    # the branch bits: claiming "square" for a non-square / "non-square" for a square breaks the block (e1 is constant over it)
+    for io in range(9):
+        e1 = int(arr[lay["e1"], 8 * io])
+        arr[lay["e1"], 8 * io: 8 * io + 8] = 1 - e1
+        assert any(t.check_row(8 * io + tt) != -1 for tt in range(8))
+        arr[lay["e1"], 8 * io: 8 * io + 8] = e1
+    # e2 matters only where e1 = 0
+    tested = 0
+    for io in range(9):
+        if int(arr[lay["e1"], 8 * io]):
+            continue
+        tested += 1
+        e2 = int(arr[lay["e2"], 8 * io])
+        arr[lay["e2"], 8 * io: 8 * io + 8] = 1 - e2
+        assert any(t.check_row(8 * io + tt) != -1 for tt in range(8))
+        arr[lay["e2"], 8 * io: 8 * io + 8] = e2
+    assert tested >= 1
+    # a bit changed on ONE row of a block breaks the block-constant transition
+    arr[lay["e1"], 8 * 3 + 4] ^= 1
+    assert t.check_row(8 * 3 + 3) != -1 or t.check_row(8 * 3 + 4) != -1
+    arr[lay["e1"], 8 * 3 + 4] ^= 1
 
 
 def test_proof_verifies_and_public_checks_refuse_the_other_root():
@@ -128,8 +186,8 @@ def test_proof_verifies_and_public_checks_refuse_the_other_root():
     recs = _oracle.map_to_g2(words_of(us))
     proof = _oracle.stark_prove(3, recs)
     assert _oracle.stark_verify(proof) == 0
-    # header: kind 3, 2^10 rows, 1024 records
-    assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 10, 1024)
+    # header: kind 3, 2^10 rows, 128 records (8 rows each)
+    assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 10, 128)
     # a record that claims -y is refused by the generator ...
     bad = recs.copy()
     y = (bn254.u32_to_fq(list(bad[1, 32:40])), bn254.u32_to_fq(list(bad[1, 40:48])))
@@ -138,7 +196,7 @@ def test_proof_verifies_and_public_checks_refuse_the_other_root():
         _oracle.Trace(3, bad)
     # ... and a proof whose public inputs say so is refused by the verifier's public check (-109), whatever its body
     forged = proof.copy()
-    n_pi = 1024 * 48
+    n_pi = 128 * 48
     forged[len(forged) - n_pi + 48 + 32: len(forged) - n_pi + 2 * 48] = bad[1, 32:]
     assert _oracle.stark_verify(forged) == -109
     forged = proof.copy()

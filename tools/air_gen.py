@@ -48,6 +48,8 @@ P_LIMBS = [(BN_P >> (16 * i)) & 0xFFFF for i in range(NL)]
 # periodic functions: index -> (m, r0): 1 on rows r = r0 (mod m), 0 on the other rows
 PER_FIRST, PER_LAST, PER_ADD, PER_LIMB_END = 0, 1, 2, 3
 PERIODICS = [(ROWS_PER_IO, 0), (ROWS_PER_IO, ROWS_PER_IO - 1), (2, 0), (64, 63)]
+PER_MAP0 = len(PERIODICS)           # MapToG2: PER_MAP0 + t = 1 on rows = t (mod 8), t = 0 .. 7
+PERIODICS += [(8, t) for t in range(8)]
 
 
 class Air:
@@ -417,101 +419,146 @@ def svdw_constants():
     return dict(C1=m.C1, C2=m.C2, C3=m.C3, C4=m.C4, BB=bn254.B2, ONE=(1, 0))
 
 
+# MapToG2: eight rows per message, three Fp2 identities ("slots") per row; a value needed in a later row travels in one of six
+# register column groups.  The schedule is DATA shared with the two trace generators (emitted into air_tables.h).
+MAP_ROWS = 8
+MAP_WIT = ["T1", "TV1", "W", "TV3", "A4", "B4", "X2", "X1", "S1", "GX1", "S2", "GX2", "D", "E", "F", "X3", "S3", "GX3", "N1", "N2", "Y"]
+MAP_SLOTS = [["T1", "TV1", "W"], ["TV3", "A4", "D"], ["B4", "X2", "E"], ["X1", "F", "S2"], ["S1", "X3", "GX2"],
+             ["GX1", "S3", "N2"], ["GX3", "N1", None], ["Y", None, None]]
+# register k: {row t whose slot result it takes over for rows t+1 ..: witness}
+MAP_REG_LOADS = [{0: "TV1", 1: "TV3", 2: "E", 3: "F", 4: "S1", 5: "S3", 6: "GX3"}, {0: "W", 1: "A4", 3: "X1"}, {1: "D", 2: "X2"},
+                 {3: "S2", 5: "GX1"}, {4: "X3"}, {4: "GX2"}]
+
+
+def map_reg_holds(k, t):
+    """the witness register k holds AT row t of a block (None before its first load)"""
+    best = None
+    for lt, nm in MAP_REG_LOADS[k].items():
+        if lt < t and (best is None or lt > best[0]):
+            best = (lt, nm)
+    return best[1] if best else None
+
+
 def build_map_g2(mode):
     """u in Fp2  ->  (x, y) on E'(Fp2) by the Shallue - van de Woestijne map (RFC 9380 F.1, Z = 1): the statement behind
     `batch_map_to_g2_circuit` (reference src/bin/bls_aggregation.rs:65; the cofactor multiplication that follows the map
-    there is an ordinary G2ExpStark obligation).  ONE ROW PER MESSAGE, no transition constraints: 21 Fp2 witnesses, each
-    defined by one Fp2 identity = two limb gadgets; the three-way choice of x is by two boolean cells:
+    there is an ordinary G2ExpStark obligation).  EIGHT ROWS PER MESSAGE: row t of a block evaluates the (up to) three Fp2
+    identities MAP_SLOTS[t] in three gadget-pair slots whose operands are results of the same row, the message u, constants, or
+    one of six registers (unchecked column groups) that took a slot result over at the end of an earlier row:
+        next(REG_k) = RES_s on the rows MAP_REG_LOADS[k] names, = REG_k on the others (free across the block boundary).
+    Row-type selectors are the periodic functions PER_MAP0 + t (1 on rows = t mod 8).  The three-way choice of x:
         e1 = 1            : x = x1, y^2 = g(x1)
         e1 = 0, e2 = 1    : N1^2 = (9+u) g(x1)  (g(x1) is NOT a square: 9+u is a non-residue),  x = x2, y^2 = g(x2)
         e1 = 0, e2 = 0    : N1^2 = (9+u) g(x1), N2^2 = (9+u) g(x2),  x = x3, y^2 = g(x3)
-    The sign rule sgn0(y) = sgn0(u) and the canonicity of u, x, y are PUBLIC checks on the public inputs (both provers and the
-    verifier make them), not constraints.  IO record: u (16 u32), x (16), y (16)."""
+    with e1, e2 boolean and constant over the block.  The sign rule sgn0(y) = sgn0(u) and the canonicity of u, x, y are PUBLIC
+    checks on the public inputs (both provers and the verifier make them), not constraints.  IO record: u, x, y (16 u32 each):
+    u is bound on row 0 of the block, x and y on row 7."""
     a = Air("mapg2", mode)
     a.gadgets = []
     a.group = 2
-    a.log_rows = 0
+    a.log_rows = 3
     consts = svdw_constants()
     F2 = 2 * NL
+    NREG, NSLOT = len(MAP_REG_LOADS), 3
     a.alloc("U", F2)
     for nm in ("ONE", "C1", "C2", "C3", "C4", "BB"):
         a.alloc(nm, F2)
     a.alloc("e1", 1); a.alloc("e2", 1)
     for nm in ("M1", "M2", "XS", "GXS"):
         a.alloc(nm, F2)
-    wit = ["T1", "TV1", "W", "TV3", "A4", "B4", "X2", "X1", "S1", "GX1", "S2", "GX2", "D", "E", "F", "X3", "S3", "GX3",
-           "N1", "N2", "Y"]
-    for nm in wit:
-        a.alloc_checked(nm, F2 * a.cpl)
-    gnames = ["t1", "tv1", "w", "inv", "a4", "b4", "x2", "x1", "s1", "gx1", "s2", "gx2", "d", "e", "f", "x3", "s3", "gx3",
-              "n1", "n2", "y"]
+    a.alloc("REG", F2 * NREG)
+    a.alloc_checked("RES", F2 * a.cpl * NSLOT)
     bound = 43
-    for g in gnames:
+    for s in range(NSLOT):
         for c in range(2):
-            a.declare_gadget_cols("%s%d" % (g, c), bound)
+            a.declare_gadget_cols("slot%d_%d" % (s, c), bound)
     a.finalize_columns()
 
-    def U(nm):      # unchecked Fp2 value: c -> vector
-        def f(c, coef=1):
-            t, n = a.vec_u16(nm, coef=coef)
-            return [(co, b + NL * c, st, fl, ng) for (co, b, st, fl, ng) in t], n
+    def plain(nm):           # unchecked Fp2 value at a fixed column: (c, coef, flag) -> vector
+        def f(c, coef=1, flag=-1):
+            return [(coef, a.col(nm) + NL * c, 1, flag, 0)], NL
         return f
 
-    def C(nm):      # checked Fp2 value
-        def f(c, coef=1):
-            t, n = a.vec_chk(nm, coef=coef)
-            return [(co, b + NL * a.cpl * c, st, fl, ng) for (co, b, st, fl, ng) in t], n
+    def reg(k):
+        def f(c, coef=1, flag=-1):
+            return [(coef, a.col("REG") + F2 * k + NL * c, 1, flag, 0)], NL
         return f
 
-    def lc(*terms):  # linear combination of Fp2 values: (coef, fn)
-        def f(c, coef=1):
-            return Air.vsum(*[fn(c, coef * k) for k, fn in terms])
+    def res(sl):
+        def f(c, coef=1, flag=-1):
+            b = a.col("RES") + F2 * a.cpl * sl + NL * a.cpl * c
+            if a.cpl == 1:
+                return [(coef, b, 1, flag, 0)], NL
+            return [(coef, b, 2, flag, 0), (coef * 256, b + 1, 2, flag, 0)], NL
         return f
 
-    def fp2_identity(name, prods, lins):
-        """sum coef A B + sum coef L = 0 in Fp2; prods: [(coef, fnA, fnB)], lins: [(coef, fn)]"""
-        for c in range(2):
-            pp = []
-            for coef, fa, fb in prods:
-                if c == 0:
-                    pp += [(coef, fa(0), fb(0)), (-coef, fa(1), fb(1))]
-                else:
-                    pp += [(coef, fa(0), fb(1)), (coef, fa(1), fb(0))]
-            a.gadget("%s%d" % (name, c), pp, [(coef, fn(c)) for coef, fn in lins], bound)
+    def lc(*terms):          # linear combination of Fp2 values: (coef, fn)
+        def f(c, coef=1, flag=-1):
+            return Air.vsum(*[fn(c, coef * k, flag) for k, fn in terms])
+        return f
 
     def times_xi(fn):
         """(9 + u) v as two linear forms: component 0: 9 v0 - v1, component 1: v0 + 9 v1"""
-        def f(c, coef=1):
+        def f(c, coef=1, flag=-1):
             if c == 0:
-                return Air.vsum(fn(0, 9 * coef), fn(1, -coef))
-            return Air.vsum(fn(0, coef), fn(1, 9 * coef))
+                return Air.vsum(fn(0, 9 * coef, flag), fn(1, -coef, flag))
+            return Air.vsum(fn(0, coef, flag), fn(1, 9 * coef, flag))
         return f
 
-    u, one = U("U"), U("ONE")
-    tv1n = lc((1, one), (-1, C("TV1")))      # 1 - u^2 g(Z)
-    tv2 = lc((1, one), (1, C("TV1")))        # 1 + u^2 g(Z)
-    fp2_identity("t1", [(1, u, u)], [(-1, C("T1"))])
-    fp2_identity("tv1", [(1, U("C1"), C("T1"))], [(-1, C("TV1"))])
-    fp2_identity("w", [(1, tv1n, tv2)], [(-1, C("W"))])
-    fp2_identity("inv", [(1, C("TV3"), C("W"))], [(-1, one)])
-    fp2_identity("a4", [(1, u, tv1n)], [(-1, C("A4"))])
-    fp2_identity("b4", [(1, C("A4"), C("TV3"))], [(-1, C("B4"))])
-    fp2_identity("x2", [(1, C("B4"), U("C3"))], [(-1, C("X2")), (1, U("C2"))])          # x2 = -Z/2 + tv4
-    fp2_identity("x1", [], [(1, C("X1")), (1, C("X2")), (-2, U("C2"))])                 # x1 = -Z/2 - tv4
-    for k in ("1", "2", "3"):
-        fp2_identity("s" + k, [(1, C("X" + k), C("X" + k))], [(-1, C("S" + k))])
-        fp2_identity("gx" + k, [(1, C("S" + k), C("X" + k))], [(1, U("BB")), (-1, C("GX" + k))])
-        if k == "2":
-            fp2_identity("d", [(1, tv2, tv2)], [(-1, C("D"))])
-            fp2_identity("e", [(1, C("D"), C("TV3"))], [(-1, C("E"))])
-            fp2_identity("f", [(1, C("E"), C("E"))], [(-1, C("F"))])
-            fp2_identity("x3", [(1, C("F"), U("C4"))], [(1, one), (-1, C("X3"))])     # Z = 1
-    fp2_identity("n1", [(1, C("N1"), C("N1"))], [(-1, times_xi(U("M1")))])
-    fp2_identity("n2", [(1, C("N2"), C("N2"))], [(-1, times_xi(U("M2")))])
-    fp2_identity("y", [(1, C("Y"), C("Y"))], [(-1, U("GXS"))])
-    # gadgets are emitted in declaration order (the carry / quotient columns were allocated in that order)
-    order = {"%s%d" % (g, c): i for i, (g, c) in enumerate((g, c) for g in gnames for c in range(2))}
-    a.gadgets.sort(key=lambda g: order[g["name"]])
+    def src(nm, t):
+        """where the witness `nm` is read on row t: a slot of the same row or the register that holds it"""
+        if nm in MAP_SLOTS[t]:
+            return res(MAP_SLOTS[t].index(nm))
+        for k in range(NREG):
+            if map_reg_holds(k, t) == nm:
+                return reg(k)
+        raise AssertionError("%s is not available on row %d" % (nm, t))
+
+    u, one = plain("U"), plain("ONE")
+
+    def identity(nm, t):
+        """(prods, lins) of the Fp2 identity that defines witness nm, operands resolved for row t"""
+        g = lambda x: src(x, t)
+        me = g(nm)
+        if nm == "T1":  return [(1, u, u)], [(-1, me)]
+        if nm == "TV1": return [(1, plain("C1"), g("T1"))], [(-1, me)]
+        if nm == "W":   return [(1, lc((1, one), (-1, g("TV1"))), lc((1, one), (1, g("TV1"))))], [(-1, me)]
+        if nm == "TV3": return [(1, me, g("W"))], [(-1, one)]
+        if nm == "A4":  return [(1, u, lc((1, one), (-1, g("TV1"))))], [(-1, me)]
+        if nm == "D":   return [(1, lc((1, one), (1, g("TV1"))), lc((1, one), (1, g("TV1"))))], [(-1, me)]
+        if nm == "B4":  return [(1, g("A4"), g("TV3"))], [(-1, me)]
+        if nm == "X2":  return [(1, g("B4"), plain("C3"))], [(-1, me), (1, plain("C2"))]       # x2 = -Z/2 + tv4
+        if nm == "E":   return [(1, g("D"), g("TV3"))], [(-1, me)]
+        if nm == "X1":  return [], [(1, me), (1, g("X2")), (-2, plain("C2"))]                  # x1 = -Z/2 - tv4
+        if nm == "F":   return [(1, g("E"), g("E"))], [(-1, me)]
+        if nm in ("S1", "S2", "S3"):
+            x = g("X" + nm[1])
+            return [(1, x, x)], [(-1, me)]
+        if nm == "X3":  return [(1, g("F"), plain("C4"))], [(1, one), (-1, me)]                # Z = 1
+        if nm in ("GX1", "GX2", "GX3"):
+            return [(1, g("S" + nm[2]), g("X" + nm[2]))], [(1, plain("BB")), (-1, me)]
+        if nm == "N1":  return [(1, me, me)], [(-1, times_xi(plain("M1")))]
+        if nm == "N2":  return [(1, me, me)], [(-1, times_xi(plain("M2")))]
+        if nm == "Y":   return [(1, me, me)], [(-1, plain("GXS"))]
+        raise AssertionError(nm)
+
+    # one gadget pair per slot: the sum over the row types of (selector) x (identity of that row type)
+    for sl in range(NSLOT):
+        for c in range(2):
+            pp, ll = [], []
+            for t in range(MAP_ROWS):
+                nm = MAP_SLOTS[t][sl]
+                if nm is None:
+                    continue
+                fl = PER_MAP0 + t
+                prods, lins = identity(nm, t)
+                for coef, fa, fb in prods:
+                    if c == 0:
+                        pp += [(coef, fa(0, 1, fl), fb(0)), (-coef, fa(1, 1, fl), fb(1))]
+                    else:
+                        pp += [(coef, fa(0, 1, fl), fb(1)), (coef, fa(1, 1, fl), fb(0))]
+                ll += [(coef, fn(c, 1, fl)) for coef, fn in lins]
+            a.gadget("slot%d_%d" % (sl, c), pp, ll, bound)
     a.emit_gadgets()
     # constants
     for nm, v in consts.items():
@@ -521,44 +568,67 @@ def build_map_g2(mode):
     e1, e2 = a.col("e1"), a.col("e2")
     a.poly([(1, [L(e1), L(e1)]), (-1, [L(e1)])])
     a.poly([(1, [L(e2), L(e2)]), (-1, [L(e2)])])
+    last = PER_MAP0 + MAP_ROWS - 1
+    # u, e1, e2 are constant over a block: (1 - per_last) (next - local) = 0
+    for col in [a.col("U") + j for j in range(F2)] + [e1, e2]:
+        a.poly([(1, [X(col)]), (-1, [L(col)]), (-1, [PER(last), X(col)]), (1, [PER(last), L(col)])])
 
-    def chk_limb(nm, j):   # 16-bit limb j (0..31) of a checked Fp2 value as [(coef, col)]
-        b = a.col(nm)
+    def res_limb(sl, j):     # 16-bit limb j (0..31) of slot sl as [(coef, col)]
+        b = a.col("RES") + F2 * a.cpl * sl
         return [(1, b + j)] if a.cpl == 1 else [(1, b + 2 * j), (256, b + 2 * j + 1)]
 
+    # registers: (1 - per_last)(next - local) - sum_{t loads} per_t (res_s(t) - local) = 0
+    for k in range(NREG):
+        for j in range(F2):
+            col = a.col("REG") + F2 * k + j
+            m = [(1, [X(col)]), (-1, [L(col)]), (-1, [PER(last), X(col)]), (1, [PER(last), L(col)])]
+            for t, nm in sorted(MAP_REG_LOADS[k].items()):
+                sl = MAP_SLOTS[t].index(nm)
+                m += [(1, [PER(PER_MAP0 + t), L(col)])]
+                m += [(-co, [PER(PER_MAP0 + t), L(cc)]) for co, cc in res_limb(sl, j)]
+            a.poly(m)
+    # every value a later row reads sits in a register by then (checked when the identities were resolved); the selections read
+    # the registers that hold x1, x2, x3, g(x1), g(x2), g(x3) on the rows that use them
+    rk = {nm: [k for k in range(NREG) if map_reg_holds(k, MAP_ROWS - 1) == nm][0] for nm in ("X1", "X2", "X3", "GX1", "GX2", "GX3")}
+    assert map_reg_holds(rk["GX2"], 5) == "GX2" and map_reg_holds(rk["GX1"], 6) == "GX1"       # rows of N2, N1
+    R = lambda nm, j: a.col("REG") + F2 * rk[nm] + j
     for j in range(F2):
         # M1 = (1 - e1) g(x1)
-        m = [(1, [L(a.col("M1") + j)])]
-        for co, cc in chk_limb("GX1", j):
-            m += [(-co, [L(cc)]), (co, [L(e1), L(cc)])]
-        a.poly(m)
+        a.poly([(1, [L(a.col("M1") + j)]), (-1, [L(R("GX1", j))]), (1, [L(e1), L(R("GX1", j))])])
         # M2 = (1 - e1)(1 - e2) g(x2)
-        m = [(1, [L(a.col("M2") + j)])]
-        for co, cc in chk_limb("GX2", j):
-            m += [(-co, [L(cc)]), (co, [L(e1), L(cc)]), (co, [L(e2), L(cc)]), (-co, [L(e1), L(e2), L(cc)])]
-        a.poly(m)
+        c2_ = R("GX2", j)
+        a.poly([(1, [L(a.col("M2") + j)]), (-1, [L(c2_)]), (1, [L(e1), L(c2_)]), (1, [L(e2), L(c2_)]), (-1, [L(e1), L(e2), L(c2_)])])
         # selected = e1 v1 + (1 - e1) e2 v2 + (1 - e1)(1 - e2) v3
-        for dst, src in (("XS", "X"), ("GXS", "GX")):
-            m = [(1, [L(a.col(dst) + j)])]
-            for co, cc in chk_limb(src + "1", j):
-                m += [(-co, [L(e1), L(cc)])]
-            for co, cc in chk_limb(src + "2", j):
-                m += [(-co, [L(e2), L(cc)]), (co, [L(e1), L(e2), L(cc)])]
-            for co, cc in chk_limb(src + "3", j):
-                m += [(-co, [L(cc)]), (co, [L(e1), L(cc)]), (co, [L(e2), L(cc)]), (-co, [L(e1), L(e2), L(cc)])]
-            a.poly(m)
-    # public inputs: u, x, y as u32 words; every 16-bit limb is bound on EVERY row (one row per record)
+        for dst, pre in (("XS", "X"), ("GXS", "GX")):
+            v1, v2, v3 = R(pre + "1", j), R(pre + "2", j), R(pre + "3", j)
+            a.poly([(1, [L(a.col(dst) + j)]), (-1, [L(e1), L(v1)]), (-1, [L(e2), L(v2)]), (1, [L(e1), L(e2), L(v2)]),
+                    (-1, [L(v3)]), (1, [L(e1), L(v3)]), (1, [L(e2), L(v3)]), (-1, [L(e1), L(e2), L(v3)])])
+    # public inputs: u on row 0 of the block, x and y on its last row
     word = 0
-    for nm, checked in (("U", False), ("XS", False), ("Y", True)):
+    ysl = MAP_SLOTS[MAP_ROWS - 1].index("Y")
+    for nm, row in (("U", 0), ("XS", MAP_ROWS - 1), ("Y", MAP_ROWS - 1)):
         for j in range(F2):
             ai = len(a.aux)
-            a.aux.append((word + j // 2, j % 2, 0, 0))
-            cells = chk_limb(nm, j) if checked else [(1, a.col(nm) + j)]
-            a.poly([(co, [L(cc)]) for co, cc in cells] + [(-1, [AUX(ai)])])
+            a.aux.append((word + j // 2, j % 2, row, 0))
+            cells = res_limb(ysl, j) if nm == "Y" else [(1, a.col(nm) + j)]
+            a.poly([(co, [PER(PER_MAP0 + row), L(cc)]) for co, cc in cells] + [(-1, [PER(PER_MAP0 + row), AUX(ai)])])
         word += NL
     a.pi_per_io = word
     a.primary = dict(kind="mapg2")
+    a.layout = [a.col(nm) for nm in ("U", "ONE", "C1", "C2", "C3", "C4", "BB", "e1", "e2", "M1", "M2", "XS", "GXS", "REG", "RES")] + \
+               [rk[nm] for nm in ("X1", "X2", "X3", "GX1", "GX2", "GX3")]
     return a
+
+
+def emit_map_schedule(f, prefix):
+    wid = {nm: i for i, nm in enumerate(MAP_WIT)}
+    f.write("/* MapToG2 schedule (tools/air_gen.py MAP_SLOTS / MAP_REG_LOADS): witness index (order: %s) or -1 */\n" % " ".join(MAP_WIT))
+    f.write("#define %s_MAPG2_ROWS %d\n#define %s_MAPG2_NWIT %d\n" % (prefix, MAP_ROWS, prefix, len(MAP_WIT)))
+    f.write("static const int32_t %s_MAPG2_SLOT_WIT[%d][3] = {%s};\n" % (prefix, MAP_ROWS, ", ".join(
+        "{%s}" % ", ".join(str(wid[x]) if x else "-1" for x in row) for row in MAP_SLOTS)))
+    f.write("static const int32_t %s_MAPG2_REG_WIT[%d][%d] = {%s};\n" % (prefix, MAP_ROWS, len(MAP_REG_LOADS), ", ".join(
+        "{%s}" % ", ".join(str(wid[map_reg_holds(k, t)]) if map_reg_holds(k, t) else "-1" for k in range(len(MAP_REG_LOADS)))
+        for t in range(MAP_ROWS))))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -624,9 +694,13 @@ def main():
             f.write("static const int32_t %s_PERIODIC[%d][2] = {%s};\n" % (
                 prefix, len(PERIODICS), ", ".join("{%d, %d}" % p for p in PERIODICS)))
             f.write("static const uint32_t %s_BN_P_LIMBS[16] = {%s};\n" % (prefix, ", ".join(map(str, P_LIMBS))))
+            emit_map_schedule(f, prefix)
             for a in airs:
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
+                if a.name == "mapg2":
+                    f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, then the registers of x1 x2 x3 g(x1) g(x2) g(x3) */\n")
+                    f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
             f.write("static const %s_air_t %s_AIRS[%d] = {\n" % (prefix.lower(), prefix, len(airs)))
             for a in airs:
                 f.write(header_entry(a, prefix))
