@@ -363,7 +363,7 @@ def main():
             out["native_chain"] = {"error": repr(e)}
         # secondary, outside the timed region: the messages -> G2 step in front of SIPP's BLS example (reference
         # src/bin/bls_aggregation.rs:65, :100-104) for the n - 1 messages of this instance: the native map with
-        # its cofactor clearing, and the MapToG2 proof (one trace row per message).  The 2 (n - 1) cofactor obligations are ordinary
+        # its cofactor clearing, and the MapToG2 proof (eight trace rows per message).  The 2 (n - 1) cofactor obligations are ordinary
         # G2ExpStark records (the main line's path), not timed again here.
         try:
             mctx = ctxs[1]

@@ -7,10 +7,9 @@
 // (appendix F.1) with Z = 1, sgn0 of section 4.1, is_square(0) = true (PARITY UNPINNED; oracle/mapg2.c and
 // oracle/py/map_to_g2.py are the two CPU readings the tests compare with).
 //
-// One lane per message: ~20 Fp2 products, one Fp2 inversion and up to five Fp2 square roots (three Fp powers each, by the
-// norm).  Every witness root is THE root with sgn0 = 0, so the cells do not depend on how a root was found.  The kernel is
-// latency-bound scalar-style code on a few waves (1024 lanes for 1024 messages: ~2 ms); the field product is kept out of
-// line so that the five root computations share one copy.
+// Per message ~20 Fp2 products, one Fp2 inversion and five candidate Fp2 square roots (two or three Fp powers each, by the norm), on
+// eight lanes (mapg2_rows_kernel).  Every witness root is THE root with sgn0 = 0, so the cells do not depend on how a root was
+// found.  Latency-bound scalar-style code on few waves; the field product is kept out of line so that everything shares one copy.
 #include "air_tables.h"
 #include "ctx.hpp"
 #include "fq.cuh"
@@ -54,8 +53,9 @@ __device__ __forceinline__ int sgn0(const Fq2& a) {
     return (int)(s0.l[0] & 1u) | (z0 & (int)(s1.l[0] & 1u));
 }
 
-// THE root with sgn0 = 0; false for a non-square.  By the norm: x0^2 = (a0 +- sqrt(a0^2 + a1^2)) / 2, x1 = a1 / (2 x0).
-__device__ __noinline__ bool sqrt_even(const Fq2& a, Fq2& out) {
+// THE root with sgn0 = 0; false for a non-square.  By the norm: x0^2 = (a0 +- sqrt(a0^2 + a1^2)) / 2, x1 = a1 / (2 x0); the inverse of
+// x0 is the power the root came from: c^((p-3)/4) * c^((p+1)/4) = c^((p-1)/2) = 1 for a non-zero square c.  `half` = 1/2.
+__device__ __noinline__ bool sqrt_even(const Fq2& a, const Fq& half, Fq2& out) {
     Fq2 r;
     if (fq::is_zero(a.c1)) {
         Fq s;
@@ -65,11 +65,16 @@ __device__ __noinline__ bool sqrt_even(const Fq2& a, Fq2& out) {
     } else {
         Fq n;
         if (!fq_sqrt(fq::add(msqr(a.c0), msqr(a.c1)), n)) return false;
-        const Fq half = fq::inv(fq::small_m(2));
-        Fq x0;
-        if (!fq_sqrt(mmul(fq::add(a.c0, n), half), x0))
-            if (!fq_sqrt(mmul(fq::sub(a.c0, n), half), x0)) return false;
-        r = Fq2{x0, mmul(a.c1, fq::inv(fq::add(x0, x0)))};
+        Fq t = mmul(fq::add(a.c0, n), half);
+        Fq pw = pow_pm3d4(t);
+        Fq x0 = mmul(pw, t);
+        if (!feq(msqr(x0), t)) {
+            t = mmul(fq::sub(a.c0, n), half);
+            pw = pow_pm3d4(t);
+            x0 = mmul(pw, t);
+            if (!feq(msqr(x0), t)) return false;
+        }
+        r = Fq2{x0, mmul(mmul(a.c1, half), pw)};      // x0 != 0 here (a1 != 0), so pw = 1 / x0
     }
     const Fq2 rr = m2(r, r);
     if (!feq(rr.c0, a.c0) || !feq(rr.c1, a.c1)) return false;
@@ -118,26 +123,34 @@ struct MapConsts {
     int32_t slot_wit[8][3], reg_wit[8][6], lay[L_N];
 };
 
-// mode 0: the eight trace rows of message `io` + the claimed (x, y) of the record compared; mode 1: (x, y) written into the record
+// EIGHT LANES PER MESSAGE (a wave = eight messages).  (A) every lane of a group runs the chain u -> g(x1), g(x2), g(x3) (~450 field
+// products, the same values in all eight: no exchange); (B) lanes 0 .. 4 take ONE of the five candidate roots each -- of g(x1),
+// g(x2), g(x3), (9+u) g(x1), (9+u) g(x2): which of them exist decides the branch -- ~1150 products; (C) the roots meet in LDS, every lane
+// derives the branch bits and the witness vector, and lane t writes trace row t of the block (mode 0, after the record's claimed
+// point was compared) or lane 0 writes (x, y) into the record (mode 1).  One lane per message took 8.9 ms for 128 messages
+// (two waves of ~10 k dependent products); this form 1.6 ms.
 __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ ios, uint32_t num_io, uint32_t ppi, MapConsts k,
                                                        uint64_t* __restrict__ tr, size_t n, int cpl, int checked_base, int mode,
                                                        int* __restrict__ err) {
-    const uint32_t io = blockIdx.x * blockDim.x + threadIdx.x;
-    if (io >= num_io) return;
+    __shared__ Fq2 s_root[8][5];
+    __shared__ int s_ok[8][5];
+    __shared__ Fq2 s_v[8][MG_NWIT];
+    const uint32_t grp = threadIdx.x >> 3, ln = threadIdx.x & 7;
+    const uint32_t io0 = blockIdx.x * 8 + grp;
+    const bool live = io0 < num_io;
+    const uint32_t io = live ? io0 : num_io - 1;       // idle groups redo the last message and store nothing (barriers below)
     uint32_t* rec = ios + (size_t)io * ppi;
     const Fq2 one{fq::one_m(), fq::zero()}, zero{fq::zero(), fq::zero()};
     const Fq2 c1 = load2(k.c1), c2 = load2(k.c2), c3 = load2(k.c3), c4 = load2(k.c4), bb = load2(k.b);
     const Fq2 xi{fq::small_m(9), fq::one_m()};
+    const Fq half = fq::neg(c2.c0);                    // c2 = -Z/2 = -1/2
     const Fq2 u = load2(rec);
     Fq2 v[MG_NWIT];
     v[MG_T1] = m2(u, u);
     v[MG_TV1] = m2(c1, v[MG_T1]);
     const Fq2 tv2 = fq::add(one, v[MG_TV1]), tv1 = fq::sub(one, v[MG_TV1]);
     v[MG_W] = m2(tv1, tv2);
-    if (fq::is_zero(v[MG_W])) {   // u^2 g(Z) = +-1: the map's inv0(0) case has no witness
-        atomicExch(err, SIPP_E_WITNESS);
-        return;
-    }
+    const bool w_zero = fq::is_zero(v[MG_W]);          // u^2 g(Z) = +-1: the map's inv0(0) case has no witness
     {
         const Fq nrm = fq::inv(fq::add(msqr(v[MG_W].c0), msqr(v[MG_W].c1)));
         v[MG_TV3] = Fq2{mmul(v[MG_W].c0, nrm), fq::neg(mmul(v[MG_W].c1, nrm))};
@@ -157,39 +170,58 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
     v[MG_X3] = fq::add(m2(v[MG_F], c4), one);
     v[MG_S3] = m2(v[MG_X3], v[MG_X3]);
     v[MG_GX3] = fq::add(m2(v[MG_S3], v[MG_X3]), bb);
-    Fq2 r1, r2, y;
-    const bool e1 = sqrt_even(v[MG_GX1], r1);
-    const bool e2 = !e1 && sqrt_even(v[MG_GX2], r2);
-    const Fq2 m1 = e1 ? zero : v[MG_GX1], mm2 = (e1 || e2) ? zero : v[MG_GX2];
-    const Fq2 xs = e1 ? v[MG_X1] : e2 ? v[MG_X2] : v[MG_X3], gxs = e1 ? v[MG_GX1] : e2 ? v[MG_GX2] : v[MG_GX3];
-    bool ok = sqrt_even(m2(xi, m1), v[MG_N1]);
-    ok = sqrt_even(m2(xi, mm2), v[MG_N2]) && ok;
-    // the root of the selected g(x) is r1 / r2 when that branch was taken (both have sgn0 = 0 already)
-    if (e1) y = r1;
-    else if (e2) y = r2;
-    else ok = sqrt_even(gxs, y) && ok;
-    if (!ok) {
-        atomicExch(err, SIPP_E_WITNESS);
-        return;
+    // (B) candidate roots: 0: g(x1)  1: g(x2)  2: g(x3)  3: (9+u) g(x1)  4: (9+u) g(x2)
+    if (ln < 5) {
+        Fq2 arg = ln == 0 ? v[MG_GX1] : ln == 1 ? v[MG_GX2] : ln == 2 ? v[MG_GX3] : ln == 3 ? v[MG_GX1] : v[MG_GX2];
+        if (ln >= 3) arg = m2(xi, arg);
+        Fq2 r = zero;
+        const bool ok = sqrt_even(arg, half, r);
+        s_ok[grp][ln] = ok ? 1 : 0;
+        s_root[grp][ln] = r;
     }
+    __syncthreads();
+    // (C)
+    const bool e1 = s_ok[grp][0] != 0;
+    const bool e2 = !e1 && s_ok[grp][1] != 0;
+    bool ok = !w_zero;
+    v[MG_N1] = zero;
+    v[MG_N2] = zero;
+    if (!e1) {                       // g(x1) is not a square: (9+u) g(x1) is
+        ok = ok && s_ok[grp][3] != 0;
+        v[MG_N1] = s_root[grp][3];
+    }
+    if (!e1 && !e2) {
+        ok = ok && s_ok[grp][4] != 0;
+        v[MG_N2] = s_root[grp][4];
+    }
+    if (!e1 && !e2) ok = ok && s_ok[grp][2] != 0;
+    Fq2 y = e1 ? s_root[grp][0] : e2 ? s_root[grp][1] : s_root[grp][2];
+    const Fq2 xs = e1 ? v[MG_X1] : e2 ? v[MG_X2] : v[MG_X3];
     if (sgn0(u) != sgn0(y)) y = neg2(y);
     v[MG_Y] = y;
     const Fq o[4] = {fq::from_mont(xs.c0), fq::from_mont(xs.c1), fq::from_mont(y.c0), fq::from_mont(y.c1)};
     if (mode == 1) {
-        for (int q = 0; q < 4; q++)
-            for (int l = 0; l < 8; l++) rec[16 + 8 * q + l] = o[q].l[l];
-        return;
+        if (live && ln == 0) {
+            if (!ok) atomicExch(err, SIPP_E_WITNESS);
+            else
+                for (int q = 0; q < 4; q++)
+                    for (int l = 0; l < 8; l++) rec[16 + 8 * q + l] = o[q].l[l];
+        }
+        return;                      // no barrier below in this mode
     }
-    bool bad = false;
+    bool bad = !ok;
     for (int q = 0; q < 4; q++)
-        for (int l = 0; l < 8; l++) bad |= rec[16 + 8 * q + l] != o[q].l[l];
-    if (bad) {   // the record claims another point
-        atomicExch(err, SIPP_E_WITNESS);
-        return;
+        for (int l = 0; l < 8; l++) bad |= rec[16 + 8 * q + l] != o[q].l[l];   // the record claims another point
+    if (bad) {
+        if (live && ln == 0) atomicExch(err, SIPP_E_WITNESS);
     }
-    const Fq2 gx1 = v[MG_GX1], gx2 = v[MG_GX2];
-    (void)gx1; (void)gx2;
-    for (int t = 0; t < 8; t++) {
+    // the witness vector through LDS: the schedule indexes it dynamically (registers would spill)
+    if (ln == 0)
+        for (int i = 0; i < MG_NWIT; i++) s_v[grp][i] = v[i];
+    __syncthreads();
+    if (!live || bad) return;
+    {
+        const int t = (int)ln;
         const size_t row = (size_t)io * 8 + t;
         store_u16(tr, n, k.lay[L_U], row, u);
         store_u16(tr, n, k.lay[L_ONE], row, one);
@@ -203,12 +235,12 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
         Fq2 reg[6];
         for (int r = 0; r < 6; r++) {
             const int wi = k.reg_wit[t][r];
-            reg[r] = wi < 0 ? zero : v[wi];
+            reg[r] = wi < 0 ? zero : s_v[grp][wi];
             store_u16(tr, n, k.lay[L_REG] + 32 * r, row, reg[r]);
         }
         for (int sl = 0; sl < 3; sl++) {
             const int wi = k.slot_wit[t][sl];
-            store_chk(tr, n, checked_base + 32 * cpl * sl, row, wi < 0 ? zero : v[wi], cpl);
+            store_chk(tr, n, checked_base + 32 * cpl * sl, row, wi < 0 ? zero : s_v[grp][wi], cpl);
         }
         // the selection cells as the (ungated) constraints define them from the registers of THIS row
         const Fq2 rg1 = reg[k.lay[L_RG1]], rg2 = reg[k.lay[L_RG2]], rg3 = reg[k.lay[L_RG3]];
@@ -242,7 +274,7 @@ int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     if (a->kind != 3 || a->log_rows != 3 || a->checked_base != k.lay[L_RES] || a->pi_per_io != 48 || (size_t)num_io * 8 != n)
         return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "MapToG2: AIR table / shape mismatch");
     ProfScope ps(ctx, "trace_mapg2");
-    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io, 48u,
+    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 7) / 8), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io, 48u,
                        k, d_trace, n, a->cells_per_limb, a->checked_base, 0, d_err);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
@@ -251,7 +283,7 @@ int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
 // (x, y) of every record computed from its u and written into the record (device buffer [num_io][48])
 int sipp_mapg2_outputs(sipp_ctx* ctx, uint32_t* d_ios, uint32_t num_io, int* d_err) {
     ProfScope ps(ctx, "mapg2_outputs");
-    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io, 48u, map_consts(nullptr),
+    hipLaunchKernelGGL(mapg2_rows_kernel, dim3((num_io + 7) / 8), dim3(64), 0, ctx->stream, d_ios, num_io, 48u, map_consts(nullptr),
                        (uint64_t*)nullptr, (size_t)0, 1, 0, 1, d_err);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;

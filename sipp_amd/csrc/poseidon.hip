@@ -456,10 +456,10 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // park 4 waves on one CU and leave three quarters of the CUs idle
     // profile names: "poseidon_leaves" = one state per lane (the dominant kernel: every tree of > 2^16 leaves); the thin trees'
     // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
-    // (trees of at most 2^12 leaves with thousands of columns -- MapToG2's one-row-per-message trace: 2048 leaves x 16 k columns --
-    // are hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 78 against 102 ms)
+    // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2821 / 1512 columns -- are
+    // hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 23 against 30 us per dependent permutation)
     static const int thin_lanes_env = sipp_env_int("SIPP_THIN_LANES", 2);
-    const int thin_lanes_p = (n <= 4096 && ncols >= 2048) ? 4 : thin_lanes_env;
+    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : thin_lanes_env;
     const bool thin = ncols > 4 && n <= quad_threshold() && n >= (thin_lanes_p == 2 ? 32 : 16);
     ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : !thin ? "poseidon_leaves" : thin_lanes_p == 2 ? "poseidon_leaves_pair" : "poseidon_leaves_quad");
     // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.cuh, the default since round 2) costs

@@ -1072,7 +1072,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     ArenaMark mark = arena_mark(ctx);
     int col_bit = 0, col_e = 0, exp_off = 0;
     if (a->kind == 3) {
-        // MapToG2: one row per message, no exponent / accumulator cells (mapg2.hip); the claimed point is compared there
+        // MapToG2: eight rows per message, no exponent / accumulator cells (mapg2.hip); the claimed point is compared there
         if (ctx->outputs_only) {
             SIPP_TRY(sipp_mapg2_outputs(ctx, const_cast<uint32_t*>(d_ios), num_io, d_err));
             arena_release(ctx, mark);
