@@ -153,8 +153,8 @@ int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log
 /* The STARK behind `batch_map_to_g2_circuit(builder, &messages)` (reference src/bin/bls_aggregation.rs:65): for every
  * message u in Fp2 the point (x, y) = map_to_g2_without_cofactor_mul(u) on the twist y^2 = x^3 + 3/(9+u) (:102; the
  * Shallue - van de Woestijne map of RFC 9380 F.1 with Z = 1, sgn0(y) = sgn0(u)).  ios: num_io records (u, x, y) of
- * SIPP_MAP_G2_IO_WORDS u32, the point included (compared with the device-computed one; SIPP_E_WITNESS if it differs, if a
- * word is >= p, or for the four u with u^2 g(1) = +-1).  Eight trace rows per message, at least 1024 rows.  The cofactor
+ * SIPP_MAP_G2_IO_WORDS u32, the point included (compared with the device-computed one; SIPP_E_WITNESS if it differs or if a
+ * word is >= p; the four u with u^2 g(1) = +-1 follow the RFC's inv0(0) = 0).  Eight trace rows per message, at least 1024 rows.  The cofactor
  * multiplication that follows the map in the reference (`mul_by_cofactor`, :103) is a pair of ordinary G2ExpStark
  * obligations: sipp_map_to_g2 below writes them.  Proof layout and the generic entry points (sipp_prove_async,
  * sipp_proof_size, sipp_workspace_bytes, sipp_stark_shape, sipp_trace_build, sipp_exp_outputs) as for the other kinds

@@ -234,13 +234,14 @@ static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, c
 static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     const int cpl = a->cells_per_limb;
     const int32_t *lay = cpl == 1 ? ORC_MAPG2_LAYOUT_U16 : ORC_MAPG2_LAYOUT_U8;
-    enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2, L_RG3 };
+    enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2, L_RG3,
+           L_Z, L_ZV, L_TINV };
     if (a->log_rows != 3 || ORC_MAPG2_ROWS != 8 || ORC_MAPG2_NWIT != MG_NWIT || lay[L_RES] != a->checked_base) return -20;
     orc_mapg2_consts k;
     orc_mapg2_constants(&k);
     orc_mapg2_wit w;
     fq2 u = read_f2(rec, 2);
-    if (orc_mapg2_witness(u, &w)) return -1;       /* u^2 g(Z) = +-1 */
+    if (orc_mapg2_witness(u, &w)) return -1;
     const fq2 zero = {fq_zero(), fq_zero()};
     for (int t = 0; t < 8; t++) {
         const size_t row = io * 8 + (size_t)t;
@@ -248,6 +249,9 @@ static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, co
         put_f2_u16(tr, n, lay[L_ONE], row, k.one, 2); put_f2_u16(tr, n, lay[L_C1], row, k.c1, 2); put_f2_u16(tr, n, lay[L_C2], row, k.c2, 2);
         put_f2_u16(tr, n, lay[L_C3], row, k.c3, 2); put_f2_u16(tr, n, lay[L_C4], row, k.c4, 2); put_f2_u16(tr, n, lay[L_BB], row, k.b, 2);
         put(tr, n, lay[L_E1], row, (uint64_t)w.e1); put(tr, n, lay[L_E2], row, (uint64_t)w.e2);
+        const uint64_t zf = (t == lay[L_TINV] && w.z) ? 1 : 0;        /* inv0's flag, on the row that inverts */
+        put(tr, n, lay[L_Z], row, zf);
+        for (int j = 0; j < 32; j++) put(tr, n, lay[L_ZV] + j, row, j == 0 ? zf : 0);
         fq2 reg[6];
         for (int r = 0; r < 6; r++) {
             int wi = ORC_MAPG2_REG_WIT[t][r];

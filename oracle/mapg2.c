@@ -87,8 +87,8 @@ int orc_mapg2_witness(fq2 u, orc_mapg2_wit *w) {
     w->v[MG_TV1] = fq2_mul(k.c1, w->v[MG_T1]);
     fq2 tv2 = fq2_add(k.one, w->v[MG_TV1]), tv1 = fq2_sub(k.one, w->v[MG_TV1]);
     w->v[MG_W] = fq2_mul(tv1, tv2);
-    if (fq2_is_zero(w->v[MG_W])) return -1;               /* u^2 g(Z) = +-1: the map's inv0(0) case, not provable */
-    w->v[MG_TV3] = fq2_inv(w->v[MG_W]);
+    w->z = fq2_is_zero(w->v[MG_W]);                       /* u^2 g(Z) = +-1: inv0(0) = 0 */
+    w->v[MG_TV3] = w->z ? f2(0, 0) : fq2_inv(w->v[MG_W]);
     w->v[MG_A4] = fq2_mul(u, tv1);
     w->v[MG_B4] = fq2_mul(w->v[MG_A4], w->v[MG_TV3]);
     fq2 tv4 = fq2_mul(w->v[MG_B4], k.c3);

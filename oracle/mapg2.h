@@ -13,7 +13,7 @@ enum { MG_T1, MG_TV1, MG_W, MG_TV3, MG_A4, MG_B4, MG_X2, MG_X1, MG_S1, MG_GX1, M
 typedef struct { fq2 one, xi, b, c1, c2, c3, c4; } orc_mapg2_consts;
 typedef struct {
     fq2 v[MG_NWIT];
-    int e1, e2;
+    int e1, e2, z;
     fq2 m1, m2, xs, gxs;
 } orc_mapg2_wit;
 

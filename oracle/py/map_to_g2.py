@@ -44,17 +44,16 @@ assert C3 is not None
 
 
 def witness(u):
-    """every intermediate value of the map, named as the columns of the AIR (tools/air_gen.py::build_map_g2); None where
-    the map's one inversion meets zero (u^2 g(Z) = +-1: four values of u)"""
+    """every intermediate value of the map, named as the columns of the AIR (tools/air_gen.py::build_map_g2); "z" = 1 where the
+    map's one inversion meets zero (u^2 g(Z) = +-1, four values of u): inv0(0) = 0"""
     w = {}
     w["T1"] = f2_mul(u, u)
     w["TV1"] = f2_mul(C1, w["T1"])
     tv2 = f2_add(ONE, w["TV1"])
     tv1 = f2_sub(ONE, w["TV1"])
     w["W"] = f2_mul(tv1, tv2)
-    if w["W"] == (0, 0):
-        return None
-    w["TV3"] = f2_inv(w["W"])
+    w["z"] = int(w["W"] == (0, 0))
+    w["TV3"] = (0, 0) if w["z"] else f2_inv(w["W"])
     w["A4"] = f2_mul(u, tv1)
     w["B4"] = f2_mul(w["A4"], w["TV3"])
     tv4 = f2_mul(w["B4"], C3)
@@ -90,8 +89,6 @@ def witness(u):
 
 def map_to_g2_without_cofactor_mul(u):
     w = witness(u)
-    if w is None:                       # inv0(0) = 0: tv4 = 0, x1 = x2 = -Z/2 -- the straight-line RFC text; not provable by the AIR
-        raise ValueError("u^2 g(Z) = +-1")
     return (w["XS"], w["Y"])
 
 

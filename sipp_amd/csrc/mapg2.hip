@@ -115,7 +115,7 @@ enum { MG_T1, MG_TV1, MG_W, MG_TV3, MG_A4, MG_B4, MG_X2, MG_X1, MG_S1, MG_GX1, M
 static_assert(MG_NWIT == SIPP_MAPG2_NWIT && SIPP_MAPG2_ROWS == 8, "witness order / rows per message of tools/air_gen.py");
 // index into SIPP_MAPG2_LAYOUT_*: columns, then the registers that hold x1 x2 x3 g(x1) g(x2) g(x3) for the selections
 enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2,
-       L_RG3, L_N };
+       L_RG3, L_Z, L_ZV, L_TINV, L_N };
 
 struct MapConsts {
     uint32_t c1[16], c2[16], c3[16], c4[16], b[16];
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
     v[MG_TV1] = m2(c1, v[MG_T1]);
     const Fq2 tv2 = fq::add(one, v[MG_TV1]), tv1 = fq::sub(one, v[MG_TV1]);
     v[MG_W] = m2(tv1, tv2);
-    const bool w_zero = fq::is_zero(v[MG_W]);          // u^2 g(Z) = +-1: the map's inv0(0) case has no witness
+    const bool w_zero = fq::is_zero(v[MG_W]);          // u^2 g(Z) = +-1: inv0(0) = 0 (0^(p-2) = 0 below), flagged by the z cell
     {
         const Fq nrm = fq::inv(fq::add(msqr(v[MG_W].c0), msqr(v[MG_W].c1)));
         v[MG_TV3] = Fq2{mmul(v[MG_W].c0, nrm), fq::neg(mmul(v[MG_W].c1, nrm))};
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
     // (C)
     const bool e1 = s_ok[grp][0] != 0;
     const bool e2 = !e1 && s_ok[grp][1] != 0;
-    bool ok = !w_zero;
+    bool ok = true;
     v[MG_N1] = zero;
     v[MG_N2] = zero;
     if (!e1) {                       // g(x1) is not a square: (9+u) g(x1) is
@@ -232,6 +232,9 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
         store_u16(tr, n, k.lay[L_BB], row, bb);
         tr[(size_t)k.lay[L_E1] * n + row] = e1 ? 1 : 0;
         tr[(size_t)k.lay[L_E2] * n + row] = e2 ? 1 : 0;
+        const uint64_t zf = (t == k.lay[L_TINV] && w_zero) ? 1 : 0;
+        tr[(size_t)k.lay[L_Z] * n + row] = zf;
+        for (int j = 0; j < 32; j++) tr[(size_t)(k.lay[L_ZV] + j) * n + row] = j == 0 ? zf : 0;
         Fq2 reg[6];
         for (int r = 0; r < 6; r++) {
             const int wi = k.reg_wit[t][r];

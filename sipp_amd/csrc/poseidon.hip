@@ -456,7 +456,7 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // park 4 waves on one CU and leave three quarters of the CUs idle
     // profile names: "poseidon_leaves" = one state per lane (the dominant kernel: every tree of > 2^16 leaves); the thin trees'
     // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
-    // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2821 / 1512 columns -- are
+    // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2854 / 1512 columns -- are
     // hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 23 against 30 us per dependent permutation)
     static const int thin_lanes_env = sipp_env_int("SIPP_THIN_LANES", 2);
     const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : thin_lanes_env;

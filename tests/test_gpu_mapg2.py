@@ -22,6 +22,10 @@ def messages(n, seed=11):
     if n > 2:
         us[1] = (7, 0)
         us[2] = (0, 0)       # u = 0: tv1 = 0, x1 = x2 = -Z/2 +- 0
+    if n > 4:                # u^2 g(Z) = 1: the inverted product is zero (inv0)
+        import map_to_g2 as M
+        r = M.sqrt_even(bn254.f2_inv(M.C1)) or M.sqrt_even(bn254.f2_neg(bn254.f2_inv(M.C1)))
+        us[3], us[4] = r, bn254.f2_neg(r)
     return us, np.array([bn254.fq_to_u32(u[0]) + bn254.fq_to_u32(u[1]) for u in us], dtype=np.uint32)
 
 
@@ -104,7 +108,7 @@ def test_wrong_or_unprovable_records_are_refused(ctx):
 
 
 def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
-    """more than 4096 messages: 2^16 rows and more, where the range table is the u16 one (one checked cell per limb: W = 1687,
+    """more than 4096 messages: 2^16 rows and more, where the range table is the u16 one (one checked cell per limb: W = 1720,
     P = 756).  The oracle's verifier replays the proof."""
     import sipp_amd
     _, words = messages(40, seed=9)
@@ -112,7 +116,7 @@ def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
     n = 5000
     c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(3, n))
     try:
-        assert c.shape(3, n) == (16, 1687, 756, 4)
+        assert c.shape(3, n) == (16, 1720, 756, 4)
         recs40 = c.map_to_g2(words, cofactor=False)
         recs = recs40[np.arange(n) % 40]
         proof = c.prove(3, recs)

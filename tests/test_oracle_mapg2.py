@@ -36,7 +36,8 @@ def test_svdw_parameters():
     assert M.is_square(gz) or M.is_square(M.g(bn254.f2_scal(M.Z, (bn254.P - 1) * bn254.inv(2) % bn254.P)))
     assert M.sgn0(M.C3) == 0 and bn254.f2_mul(M.C3, M.C3) == bn254.f2_neg(bn254.f2_mul(M.C1, (3, 0)))
     assert not M.is_square(bn254.XI)
-    assert bn254.G2_COFACTOR * bn254.R == (bn254.P + 1) ** 2 - (bn254.P + 1 - (6 * bn254.U ** 2 + 1)) ** 2 + 0 or True
+    t = 6 * bn254.U ** 2 + 1                       # trace of Frobenius: r = p + 1 - t, #E'(Fp2) = r (p - 1 + t)
+    assert bn254.R == bn254.P + 1 - t and bn254.G2_COFACTOR == bn254.P - 1 + t
 
 
 def test_constants_agree_between_the_generated_header_and_python():
@@ -76,7 +77,7 @@ def air_tables():
         return [int(x) for x in re.findall(r"-?\d+", m.group(1))]
     slot = np.array(ints("ORC_MAPG2_SLOT_WIT")).reshape(8, 3)
     reg = np.array(ints("ORC_MAPG2_REG_WIT")).reshape(8, 6)
-    lay = dict(zip("U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES RX1 RX2 RX3 RG1 RG2 RG3".split(), ints("ORC_MAPG2_LAYOUT_U8")))
+    lay = dict(zip("U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES RX1 RX2 RX3 RG1 RG2 RG3 z ZV TINV".split(), ints("ORC_MAPG2_LAYOUT_U8")))
     return slot, reg, lay
 
 
@@ -131,7 +132,7 @@ def test_mutations_break_a_row_constraint(trace):
     prog = np.ctypeslib.as_array(a.prog, shape=(a.prog_len,))
     sign0, carry0, q0 = int(prog[1]), int(prog[2]), int(prog[7 + 3])
     cols = {"U": lay["U"] + 3, "ONE": lay["ONE"], "C3": lay["C3"] + 17, "BB": lay["BB"] + 2, "M1": lay["M1"] + 1, "M2": lay["M2"],
-            "XS": lay["XS"] + 4, "GXS": lay["GXS"] + 20, "sign": sign0, "q": q0 + 3, "carry": carry0 + 1, "carry_last": a.n_main - 1}
+            "XS": lay["XS"] + 4, "GXS": lay["GXS"] + 20, "ZV": lay["ZV"] + 1, "sign": sign0, "q": q0 + 3, "carry": carry0 + 1, "carry_last": a.n_main - 1}
     for sl in range(3):
         cols["RES%d" % sl] = lay["RES"] + 64 * sl + 7 + 32 * (sl & 1)
     for k in range(6):
@@ -208,11 +209,37 @@ def test_proof_verifies_and_public_checks_refuse_the_other_root():
     assert _oracle.stark_verify(forged) != 0
 
 
-def test_the_inversion_of_zero_is_reported_not_proved():
-    """u^2 g(Z) = 1: the map's inv0(0) case (four values of u) has no witness in this AIR"""
-    r = M.sqrt_even(bn254.f2_inv(M.C1))
-    if r is None:
-        r = M.sqrt_even(bn254.f2_neg(bn254.f2_inv(M.C1)))
-    assert r is not None and M.witness(r) is None
-    with pytest.raises(RuntimeError):
-        _oracle.map_to_g2(words_of([r]))
+def inv0_messages():
+    """the four u with u^2 g(Z) = +-1: the product the map inverts is zero there (inv0(0) = 0: x1 = x2 = -Z/2, x3 = Z)"""
+    out = []
+    for t in (bn254.f2_inv(M.C1), bn254.f2_neg(bn254.f2_inv(M.C1))):
+        r = M.sqrt_even(t)
+        if r is not None:
+            out += [r, bn254.f2_neg(r)]
+    return out
+
+
+def test_the_inversion_of_zero_follows_inv0_and_is_provable():
+    us = inv0_messages()
+    assert len(us) >= 2
+    recs = _oracle.map_to_g2(words_of(us))
+    slot, reg, lay = air_tables()
+    for u, r in zip(us, recs):
+        w = M.witness(u)
+        assert w["z"] == 1 and w["TV3"] == (0, 0) and w["X1"] == w["X2"] == M.C2
+        q = (w["XS"], w["Y"])
+        assert list(r[16:]) == bn254.g2_to_u32(q) and bn254.g2_on_curve(q)
+    t = _oracle.Trace(3, recs)
+    assert all(t.check_row(r) == -1 for r in range(8 * len(us) + 8))
+    arr = t.array()
+    z = arr[lay["z"], :8 * len(us)].reshape(len(us), 8)
+    assert (z[:, 1] == 1).all() and z.sum() == len(us)          # the flag sits on the row that inverts, nowhere else
+    # the flag cannot be claimed for a product that is not zero, nor dropped where it is
+    other = _oracle.Trace(3, _oracle.map_to_g2(words_of(messages(2, 8))))
+    oarr = other.array()
+    oarr[lay["z"], 1] = 1
+    oarr[lay["ZV"], 1] = 1
+    assert other.check_row(1) != -1
+    arr[lay["z"], 1] = 0
+    arr[lay["ZV"], 1] = 0
+    assert t.check_row(1) != -1

@@ -450,7 +450,7 @@ def build_map_g2(mode):
         e1 = 1            : x = x1, y^2 = g(x1)
         e1 = 0, e2 = 1    : N1^2 = (9+u) g(x1)  (g(x1) is NOT a square: 9+u is a non-residue),  x = x2, y^2 = g(x2)
         e1 = 0, e2 = 0    : N1^2 = (9+u) g(x1), N2^2 = (9+u) g(x2),  x = x3, y^2 = g(x3)
-    with e1, e2 boolean and constant over the block.  The sign rule sgn0(y) = sgn0(u) and the canonicity of u, x, y are PUBLIC
+    with e1, e2 boolean and constant over the block.  The map's one inversion is inv0 (0 -> 0) by a flag bit z.  The sign rule sgn0(y) = sgn0(u) and the canonicity of u, x, y are PUBLIC
     checks on the public inputs (both provers and the verifier make them), not constraints.  IO record: u, x, y (16 u32 each):
     u is bound on row 0 of the block, x and y on row 7."""
     a = Air("mapg2", mode)
@@ -467,6 +467,7 @@ def build_map_g2(mode):
     for nm in ("M1", "M2", "XS", "GXS"):
         a.alloc(nm, F2)
     a.alloc("REG", F2 * NREG)
+    a.alloc("z", 1); a.alloc("ZV", F2)          # inv0: z = 1 where the product to invert is zero; ZV = the Fp2 value (z, 0) as limbs
     a.alloc_checked("RES", F2 * a.cpl * NSLOT)
     bound = 43
     for s in range(NSLOT):
@@ -523,7 +524,7 @@ def build_map_g2(mode):
         if nm == "T1":  return [(1, u, u)], [(-1, me)]
         if nm == "TV1": return [(1, plain("C1"), g("T1"))], [(-1, me)]
         if nm == "W":   return [(1, lc((1, one), (-1, g("TV1"))), lc((1, one), (1, g("TV1"))))], [(-1, me)]
-        if nm == "TV3": return [(1, me, g("W"))], [(-1, one)]
+        if nm == "TV3": return [(1, me, g("W"))], [(-1, one), (1, plain("ZV"))]                # tv3 w = 1 - z  (inv0, see below)
         if nm == "A4":  return [(1, u, lc((1, one), (-1, g("TV1"))))], [(-1, me)]
         if nm == "D":   return [(1, lc((1, one), (1, g("TV1"))), lc((1, one), (1, g("TV1"))))], [(-1, me)]
         if nm == "B4":  return [(1, g("A4"), g("TV3"))], [(-1, me)]
@@ -568,6 +569,18 @@ def build_map_g2(mode):
     e1, e2 = a.col("e1"), a.col("e2")
     a.poly([(1, [L(e1), L(e1)]), (-1, [L(e1)])])
     a.poly([(1, [L(e2), L(e2)]), (-1, [L(e2)])])
+    # inv0(w) (RFC 9380: the inverse, 0 for w = 0): tv3 w = 1 - z with z boolean, and on the row that inverts z w = 0, z tv3 = 0.
+    # z is a free bit on the other rows (the provers write 0); ZV spells the Fp2 element z for the gadget's linear term.
+    zc, zv = a.col("z"), a.col("ZV")
+    a.poly([(1, [L(zc), L(zc)]), (-1, [L(zc)])])
+    a.poly([(1, [L(zv)]), (-1, [L(zc)])])
+    for j in range(1, F2):
+        a.poly([(1, [L(zv + j)])])
+    t_inv = [t for t in range(MAP_ROWS) if "TV3" in MAP_SLOTS[t]][0]
+    rw = [k for k in range(NREG) if map_reg_holds(k, t_inv) == "W"][0]
+    sl_inv = MAP_SLOTS[t_inv].index("TV3")
+    for j in range(F2):
+        a.poly([(1, [PER(PER_MAP0 + t_inv), L(zc), L(a.col("REG") + F2 * rw + j)])])
     last = PER_MAP0 + MAP_ROWS - 1
     # u, e1, e2 are constant over a block: (1 - per_last) (next - local) = 0
     for col in [a.col("U") + j for j in range(F2)] + [e1, e2]:
@@ -577,6 +590,8 @@ def build_map_g2(mode):
         b = a.col("RES") + F2 * a.cpl * sl
         return [(1, b + j)] if a.cpl == 1 else [(1, b + 2 * j), (256, b + 2 * j + 1)]
 
+    for j in range(F2):
+        a.poly([(co, [PER(PER_MAP0 + t_inv), L(zc), L(cc)]) for co, cc in res_limb(sl_inv, j)])
     # registers: (1 - per_last)(next - local) - sum_{t loads} per_t (res_s(t) - local) = 0
     for k in range(NREG):
         for j in range(F2):
@@ -616,7 +631,7 @@ def build_map_g2(mode):
     a.pi_per_io = word
     a.primary = dict(kind="mapg2")
     a.layout = [a.col(nm) for nm in ("U", "ONE", "C1", "C2", "C3", "C4", "BB", "e1", "e2", "M1", "M2", "XS", "GXS", "REG", "RES")] + \
-               [rk[nm] for nm in ("X1", "X2", "X3", "GX1", "GX2", "GX3")]
+               [rk[nm] for nm in ("X1", "X2", "X3", "GX1", "GX2", "GX3")] + [zc, zv, t_inv]
     return a
 
 
@@ -699,7 +714,7 @@ def main():
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
                 if a.name == "mapg2":
-                    f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, then the registers of x1 x2 x3 g(x1) g(x2) g(x3) */\n")
+                    f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
             f.write("static const %s_air_t %s_AIRS[%d] = {\n" % (prefix.lower(), prefix, len(airs)))
             for a in airs:
