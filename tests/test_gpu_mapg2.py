@@ -126,3 +126,18 @@ def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
     assert _oracle.stark_verify(proof) == 0
     proof[16 + 5] ^= 1
     assert _oracle.stark_verify(proof) != 0
+
+
+def test_two_thousand_random_messages_map_like_the_c_reading(ctx):
+    """values only (no proof): every branch and both sign cases many times over; the C reading takes ~2 ms per message"""
+    rng = np.random.default_rng(20261004)
+    words = np.zeros((2000, 16), dtype=np.uint32)
+    words[:, :8] = rng.integers(0, 2**32, size=(2000, 8), dtype=np.uint64)
+    words[:, 8:] = rng.integers(0, 2**32, size=(2000, 8), dtype=np.uint64)
+    words[:, 7] &= 0x1FFFFFFF          # < 2^253 < p
+    words[:, 15] &= 0x1FFFFFFF
+    words[::7, 8:] = 0                 # u in Fp
+    words[::11, :8] = 0                # u = c u: sgn0 from the second coordinate
+    got = ctx.map_to_g2(words, cofactor=False)
+    want = _oracle.map_to_g2(words)
+    assert (got == want).all(), np.argwhere((got != want).any(axis=1))[:8].tolist()
