@@ -11,6 +11,8 @@
 //   g1_exp_circuit(builder, &inputs)  -> Vec<G1Target>  :133         sipp::Prover::g1_exp_circuit(inputs)  -> outputs + proof
 //   g2_exp_circuit / fq12_exp_circuit                   :134-135     sipp::Prover::g2_exp_circuit / fq12_exp_circuit
 //   StarkProofWithPublicInputs<F, C, D> (starky)                     sipp::StarkProofWithPublicInputs (same field names)
+//   batch_map_to_g2_circuit(builder, &messages)  (src/bin/bls_aggregation.rs:65)   sipp::Prover::batch_map_to_g2_circuit(messages)
+//   map_to_g2_without_cofactor_mul(u).mul_by_cofactor()     (:100-104)            sipp::Prover::map_to_g2(messages)
 //   anyhow::Error at the .unwrap() of :253                           sipp::Error (carries the sipp_status)
 //
 // In the reference the three calls add a recursive verifier gadget and register a witness generator; at proving time the
@@ -70,6 +72,9 @@ using Fq12ExpIO = ExpIO<Fq12ExpInput, Fq12>;
 static_assert(sizeof(G1ExpIO) == 4 * SIPP_G1_IO_WORDS, "G1 IO record layout");
 static_assert(sizeof(G2ExpIO) == 4 * SIPP_G2_IO_WORDS, "G2 IO record layout");
 static_assert(sizeof(Fq12ExpIO) == 4 * SIPP_FQ12_IO_WORDS, "Fq12 IO record layout");
+// MapToG2 record: the message u in Fp2, then its point on the twist
+using MapG2IO = ExpIO<Fq2, G2Affine>;
+static_assert(sizeof(MapG2IO) == 4 * SIPP_MAP_G2_IO_WORDS, "MapToG2 IO record layout");
 
 // ---- errors: the reference's call sites unwrap an anyhow::Result; here a failing status throws ----
 class Error : public std::runtime_error {
@@ -296,6 +301,52 @@ class Prover {
     }
     ExpCircuitResult<Fq12> fq12_exp_circuit(const std::vector<Fq12ExpInput>& inputs) {
         return run<Fq12ExpInput, Fq12>(SIPP_FQ12_EXP, inputs);
+    }
+
+    // batch_map_to_g2_circuit(builder, &messages) of the BLS example (src/bin/bls_aggregation.rs:65), proving-time body: the points
+    // map_to_g2_without_cofactor_mul(u) (outputs) and the MapToG2 proof over the records (u, x, y).  Runs on the G2 ctx (its arena
+    // is the larger one whenever max_g2_io >= messages / 64).  The cofactor multiplication that follows in the reference is a pair
+    // of g2_exp_circuit obligations per message: map_to_g2() below returns them.
+    ExpCircuitResult<G2Affine> batch_map_to_g2_circuit(const std::vector<Fq2>& messages) {
+        if (messages.empty()) throw Error(SIPP_E_BADARG, "batch_map_to_g2_circuit: no messages");
+        sipp_ctx* c = ctx_[SIPP_G2_EXP];
+        std::vector<MapG2IO> io(messages.size());
+        for (size_t i = 0; i < io.size(); i++) {
+            io[i].in = messages[i];
+            std::memset(&io[i].out, 0, sizeof(G2Affine));
+        }
+        int rc = sipp_exp_outputs(c, SIPP_MAP_G2, reinterpret_cast<uint32_t*>(io.data()), io.size());
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_exp_outputs(MAP_G2): ") + sipp_last_error(c));
+        ExpCircuitResult<G2Affine> r;
+        const size_t cap = sipp_proof_size(c, SIPP_MAP_G2, io.size());
+        r.flat.assign(cap, 0);
+        size_t len = 0;
+        rc = sipp_map_to_g2_prove(c, words(io), io.size(), r.flat.data(), cap, &len);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_map_to_g2_prove: ") + sipp_last_error(c));
+        r.flat.resize(len);
+        finish(io, &r);
+        return r;
+    }
+    // messages.iter().map(|u| map_to_g2_without_cofactor_mul(*u).mul_by_cofactor()) (src/bin/bls_aggregation.rs:100-104): the points
+    // of G2, and the 2 n g2_exp_circuit inputs whose outputs clear the cofactor (G + [2p - r] Q, then - G)
+    struct MappedMessages {
+        std::vector<G2Affine> points;            // `ms`
+        std::vector<G2ExpInput> cofactor_inputs; // obligations for g2_exp_circuit
+    };
+    MappedMessages map_to_g2(const std::vector<Fq2>& messages) {
+        if (messages.empty()) throw Error(SIPP_E_BADARG, "map_to_g2: no messages");
+        sipp_ctx* c = ctx_[SIPP_G2_EXP];
+        const size_t n = messages.size();
+        std::vector<MapG2IO> io(n);
+        std::vector<G2ExpIO> g2(2 * n);
+        MappedMessages m;
+        m.points.resize(n);
+        const int rc = sipp_map_to_g2(c, reinterpret_cast<const uint32_t*>(messages.data()), n, reinterpret_cast<uint32_t*>(io.data()),
+                                      reinterpret_cast<uint32_t*>(g2.data()), reinterpret_cast<uint32_t*>(m.points.data()));
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_map_to_g2: ") + sipp_last_error(c));
+        m.cofactor_inputs.resize(2 * n);
+        for (size_t i = 0; i < 2 * n; i++) m.cofactor_inputs[i] = g2[i].in;
+        return m;
     }
 
     // the three calls of verifier_circuit.rs:133-135 together: outputs first, then the three proofs concurrently

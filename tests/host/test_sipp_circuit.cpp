@@ -7,6 +7,9 @@
 //   test_sipp_circuit fuzz <proof.bin> [n]        CPU only: from_flat on n damaged copies of the buffer (Error or round trip, never UB)
 //   test_sipp_circuit prove <ios.bin> <out_prefix>   GPU: <ios.bin> = 3 x (u64 count, records) [+ (count, A), (count, B)];
 //                                                    writes <out_prefix>{0,1,2}.bin
+//   test_sipp_circuit mapg2 <msgs.bin> <out_prefix>  GPU: the BLS example's front end (src/bin/bls_aggregation.rs:65, :100-104):
+//                                                    <msgs.bin> = (u64 count, count x 16 u32); writes <out_prefix>_proof.bin,
+//                                                    <out_prefix>_points.bin (the cofactor-cleared points)
 //
 // The verifier is the CPU oracle's (test infrastructure), linked only into this test binary.
 #include <cstring>
@@ -224,10 +227,46 @@ static int prove(const char* ios_path, const char* out_prefix) {
     return 0;
 }
 
+// messages -> batch_map_to_g2_circuit (proof verified by the oracle, public inputs = (u, x, y) in message order, padded by copies of
+// the last record) -> map_to_g2 (cleared points) -> the cofactor obligations through g2_exp_circuit: outputs = the cleared points
+static int mapg2(const char* msgs_path, const char* out_prefix) {
+    const std::vector<uint64_t> raw = read_u64(msgs_path);
+    CHECK(!raw.empty());
+    const size_t n = (size_t)raw[0];
+    CHECK(raw.size() >= 1 + n * 8);
+    std::vector<sipp::Fq2> msgs(n);
+    memcpy(msgs.data(), raw.data() + 1, n * sizeof(sipp::Fq2));
+    sipp::Prover prover(0, 2, 2 * n, 2);
+    const auto r = prover.batch_map_to_g2_circuit(msgs);
+    CHECK(r.outputs.size() == n);
+    orc_config cfg;
+    orc_default_config(&cfg);
+    CHECK(orc_stark_verify(r.flat.data(), r.flat.size(), &cfg) == 0);
+    CHECK(r.proof.public_inputs.size() % SIPP_MAP_G2_IO_WORDS == 0 && r.proof.public_inputs.size() / SIPP_MAP_G2_IO_WORDS >= n);
+    for (size_t i = 0; i < n; i++) {
+        sipp::MapG2IO rec;
+        rec.in = msgs[i];
+        rec.out = r.outputs[i];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec);
+        for (int k = 0; k < SIPP_MAP_G2_IO_WORDS; k++) CHECK(r.proof.public_inputs[i * SIPP_MAP_G2_IO_WORDS + k] == w[k]);
+    }
+    const auto m = prover.map_to_g2(msgs);
+    CHECK(m.points.size() == n && m.cofactor_inputs.size() == 2 * n);
+    for (size_t i = 0; i < n; i++) CHECK(memcmp(&m.cofactor_inputs[i].x, &r.outputs[i], sizeof(sipp::G2Affine)) == 0);
+    const auto c = prover.g2_exp_circuit(m.cofactor_inputs);
+    CHECK(orc_stark_verify(c.flat.data(), c.flat.size(), &cfg) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(memcmp(&c.outputs[n + i], &m.points[i], sizeof(sipp::G2Affine)) == 0);
+    std::ofstream(std::string(out_prefix) + "_proof.bin", std::ios::binary).write(reinterpret_cast<const char*>(r.flat.data()), (std::streamsize)(r.flat.size() * 8));
+    std::ofstream(std::string(out_prefix) + "_points.bin", std::ios::binary).write(reinterpret_cast<const char*>(m.points.data()), (std::streamsize)(n * sizeof(sipp::G2Affine)));
+    printf("mapg2 ok: %zu messages, MapToG2 proof %zu words, cofactor proof %zu words\n", n, r.flat.size(), c.flat.size());
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "layout") return layout(argc >= 3 ? argv[2] : nullptr);
         if (argc == 4 && std::string(argv[1]) == "prove") return prove(argv[2], argv[3]);
+        if (argc == 4 && std::string(argv[1]) == "mapg2") return mapg2(argv[2], argv[3]);
         if (argc >= 3 && std::string(argv[1]) == "fuzz") return fuzz(argv[2], argc >= 4 ? atoi(argv[3]) : 20000);
     } catch (const sipp::Error& e) {
         fprintf(stderr, "sipp::Error %d: %s\n", e.status(), e.what());

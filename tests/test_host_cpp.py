@@ -70,3 +70,33 @@ def test_sipp_circuit_cpp(tmp_path):
             assert len(got) == len(want) and (got == want).all(), k
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_bls_front_end_cpp(tmp_path):
+    """the BLS example's messages -> G2 step through the C++ host layer (src/bin/bls_aggregation.rs:65, :100-104):
+    batch_map_to_g2_circuit (proof accepted by the oracle's verifier, equal to the Python harness's), map_to_g2 (cleared points equal
+    the Python reading's), the cofactor obligations through g2_exp_circuit"""
+    import sys
+    import sipp_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import bn254
+    import map_to_g2 as M
+    exe = build_host_test()
+    us = [(5, 7), (0, 3), (bn254.P - 2, 11)]
+    words = np.array([bn254.fq_to_u32(u[0]) + bn254.fq_to_u32(u[1]) for u in us], dtype=np.uint32)
+    with open(tmp_path / "msgs.bin", "wb") as f:
+        f.write(np.uint64(len(us)).tobytes())
+        f.write(words.tobytes())
+    out = subprocess.run([exe, "mapg2", str(tmp_path / "msgs.bin"), str(tmp_path / "m")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mapg2 ok" in out.stdout, out.stdout + out.stderr
+    pts = np.fromfile(tmp_path / "m_points.bin", dtype=np.uint32).reshape(len(us), 32)
+    for u, p in zip(us, pts):
+        assert list(p) == bn254.g2_to_u32(M.map_to_g2(u))
+    got = np.fromfile(tmp_path / "m_proof.bin", dtype=np.uint64)
+    ctx = sipp_amd.Ctx(workspace_bytes=2 << 30)
+    try:
+        want = ctx.prove(3, ctx.map_to_g2(words, cofactor=False))
+    finally:
+        ctx.close()
+    assert len(got) == len(want) and (got == want).all()
