@@ -366,6 +366,8 @@ def main():
         # its cofactor clearing, and the MapToG2 proof (eight trace rows per message).  The 2 (n - 1) cofactor obligations are ordinary
         # G2ExpStark records (the main line's path), not timed again here.
         try:
+            if os.environ.get("SIPP_BENCH_MAP_G2", "1") in ("0", ""):      # scripts/profile_round.sh: counters of the instance alone
+                raise RuntimeError("skipped (SIPP_BENCH_MAP_G2=0)")
             mctx = ctxs[1]
             rng = np.random.default_rng(0x6d6170)
             msgs = np.zeros((args.n - 1, 16), dtype=np.uint32)

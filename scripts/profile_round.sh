@@ -7,6 +7,7 @@ OUT=$R/gpurun_out/prof_$1
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export SIPP_BENCH_IO_SHARD_N=0   # the profiled command is the n = 128 line alone (no io_sharded leg)
+export SIPP_BENCH_MAP_G2=0       # ... and without the messages -> G2 leg (profiled on its own at the end of this script)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_w.log"
@@ -15,4 +16,6 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_v"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tl" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/tl.log"
 # native chain
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/native" -o run -- python3 "$R/scripts/perf_native.py" 128 > "$OUT/native.txt" 2> "$OUT/native.log"
+# the messages -> G2 step of the BLS example
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mapg2" -o run -- python3 "$R/scripts/perf_mapg2.py" 127 > "$OUT/mapg2.txt" 2> "$OUT/mapg2.log"
 ls -R "$OUT" | head -40

@@ -297,7 +297,7 @@ extern "C" {
 // What the reference computes natively per message (src/bin/bls_aggregation.rs:100-104): the map, then the cofactor -- as
 // records the provers take (include/sipp_hip.h).  Three passes of the outputs-only trace kernels: the map, G + [h] Q, - G.
 int sipp_map_to_g2(sipp_ctx* ctx, const uint32_t* msgs, size_t n, uint32_t* map_ios, uint32_t* g2_ios, uint32_t* cleared) {
-    if (!ctx || !msgs || !map_ios || n == 0) return SIPP_E_BADARG;
+    if (!ctx || !msgs || !map_ios || n == 0 || n > ((size_t)1 << 17)) return SIPP_E_BADARG;   // 2^17 records: the provers' limit
     for (size_t i = 0; i < n; i++) {
         uint32_t* r = map_ios + i * SIPP_MAP_G2_IO_WORDS;
         memcpy(r, msgs + i * 16, 64);
@@ -308,7 +308,11 @@ int sipp_map_to_g2(sipp_ctx* ctx, const uint32_t* msgs, size_t n, uint32_t* map_
     std::vector<uint32_t> own;
     uint32_t* g = g2_ios;
     if (!g) {
-        own.resize(2 * n * SIPP_G2_IO_WORDS);
+        try {
+            own.resize(2 * n * SIPP_G2_IO_WORDS);      // n <= 2^17 (the call above refused anything larger)
+        } catch (const std::exception&) {
+            return sipp_fail(ctx, SIPP_E_NOMEM, "map_to_g2: host scratch for the cofactor obligations");
+        }
         g = own.data();
     }
     // (x, offset, exp_val, output): 32 + 32 + 8 + 32 words

@@ -103,6 +103,14 @@ def test_wrong_or_unprovable_records_are_refused(ctx):
     with pytest.raises(sipp_amd.SippError) as e:
         ctx.prove(3, bad)
     assert e.value.code == -8
+    # bad arguments of the native entry point: status, no crash
+    L = sipp_amd.lib()
+    out = np.zeros((4, 48), dtype=np.uint32)
+    assert L.sipp_map_to_g2(ctx.h, None, 4, out.ctypes.data, None, None) == -1            # SIPP_E_BADARG
+    assert L.sipp_map_to_g2(ctx.h, words.ctypes.data, 0, out.ctypes.data, None, None) == -1
+    assert L.sipp_map_to_g2(ctx.h, words.ctypes.data, 4, None, None, None) == -1
+    big = np.zeros(((1 << 17) + 1, 48), dtype=np.uint32)                                   # more records than a STARK of this kind takes
+    assert L.sipp_map_to_g2(ctx.h, np.zeros(((1 << 17) + 1, 16), dtype=np.uint32).ctypes.data, (1 << 17) + 1, big.ctypes.data, None, None) == -1
     # the ctx survives
     assert _oracle.stark_verify(ctx.prove(3, recs)) == 0
 
