@@ -1069,13 +1069,12 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                     uint64_t* d_trace, int* d_err) {
     const size_t n = (size_t)1 << log_n;
     const int cpl = a->cells_per_limb, nm = a->n_main, nc = a->n_checked;
-    ArenaMark mark = arena_mark(ctx);
+    ArenaScope scope(ctx);   // the row scratch and the lookup tables go back on EVERY exit path
     int col_bit = 0, col_e = 0, exp_off = 0;
     if (a->kind == 3) {
         // MapToG2: eight rows per message, no exponent / accumulator cells (mapg2.hip); the claimed point is compared there
         if (ctx->outputs_only) {
             SIPP_TRY(sipp_mapg2_outputs(ctx, const_cast<uint32_t*>(d_ios), num_io, d_err));
-            arena_release(ctx, mark);
             return SIPP_OK;
         }
         SIPP_TRY(sipp_mapg2_fill(ctx, a, d_ios, num_io, log_n, d_trace, d_err));
@@ -1109,7 +1108,6 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                 hipLaunchKernelGGL(curve_outputs_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
                                    const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
                 SIPP_CHECK_HIP(ctx, hipGetLastError());
-                arena_release(ctx, mark);
                 return SIPP_OK;
             }
             ProfScope ps(ctx, "trace_curve_rows");
@@ -1131,7 +1129,6 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                 hipLaunchKernelGGL(curve_outputs_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
                                    const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
                 SIPP_CHECK_HIP(ctx, hipGetLastError());
-                arena_release(ctx, mark);
                 return SIPP_OK;
             }
             ProfScope ps(ctx, "trace_curve_rows");
@@ -1145,7 +1142,6 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         hipLaunchKernelGGL(write_outputs_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios),
                            num_io, (uint32_t)a->pi_per_io, a->kind, d_trace, n, 1);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
-        arena_release(ctx, mark);
         return SIPP_OK;
     }
     if (a->kind != 3) {
@@ -1244,6 +1240,5 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
-    arena_release(ctx, mark);
     return SIPP_OK;
 }
