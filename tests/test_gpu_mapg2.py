@@ -149,3 +149,14 @@ def test_two_thousand_random_messages_map_like_the_c_reading(ctx):
     got = ctx.map_to_g2(words, cofactor=False)
     want = _oracle.map_to_g2(words)
     assert (got == want).all(), np.argwhere((got != want).any(axis=1))[:8].tolist()
+
+
+def test_golden_vectors(ctx):
+    """tests/golden/mapg2_vectors.json: records, cleared points and the proof digest from the GPU"""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mapg2_vectors.json")))
+    want = np.array(g["records"], dtype=np.uint32)
+    recs, _, pts = ctx.map_to_g2(want[:, :16])
+    assert (recs == want).all() and (pts == np.array(g["cleared"], dtype=np.uint32)).all()
+    assert hashlib.sha256(ctx.prove(3, recs).tobytes()).hexdigest() == g["proof"]["sha256"]

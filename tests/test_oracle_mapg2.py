@@ -243,3 +243,22 @@ def test_the_inversion_of_zero_follows_inv0_and_is_provable():
     arr[lay["z"], 1] = 0
     arr[lay["ZV"], 1] = 0
     assert t.check_row(1) != -1
+
+
+def test_golden_vectors_pin_both_readings_and_the_oracle_proof():
+    """tests/golden/mapg2_vectors.json (SELF-golden, tools/gen_golden.py mapg2): twelve messages incl. the edge cases; the C reading
+    reproduces the records, the Python reading the cleared points, and the oracle's proof of the records has the committed digest
+    (AIR tables, schedule, lookup fill rule, Fiat-Shamir order and FRI pinned against silent drift)"""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "mapg2_vectors.json")))
+    recs = np.array(g["records"], dtype=np.uint32)
+    assert (_oracle.map_to_g2(recs[:, :16]) == recs).all()
+    for r, c, b in zip(g["records"], g["cleared"], g["branch_e1_e2_z"]):
+        u = (bn254.u32_to_fq(r[:8]), bn254.u32_to_fq(r[8:16]))
+        w = M.witness(u)
+        assert [w["e1"], w["e2"], w["z"]] == b
+        assert bn254.g2_to_u32(bn254.g2_mul((w["XS"], w["Y"]), bn254.G2_COFACTOR)) == c
+    pf = _oracle.stark_prove(3, recs)
+    assert (int(len(pf)), int(pf[2]), int(pf[4]), int(pf[5])) == (g["proof"]["words"], g["proof"]["log_n"], g["proof"]["W"], g["proof"]["P"])
+    assert hashlib.sha256(pf.tobytes()).hexdigest() == g["proof"]["sha256"]

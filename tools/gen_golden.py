@@ -6,6 +6,7 @@ reference src/prover_native.rs / src/verifier_native.rs / src/transcript_native.
 binary (no cargo in this image).
 
     python tools/gen_golden.py 4 8 128
+    python tools/gen_golden.py mapg2        # tests/golden/mapg2_vectors.json
 """
 import os
 import sys
@@ -56,7 +57,39 @@ def proof_digests_n128():
         json.dump(out, open(os.path.join(ROOT, "tests", "golden", "proof_digests_n128.json"), "w"), indent=1)
 
 
+def mapg2_fixture():
+    """SELF-GOLDEN vectors of the messages -> G2 step: 12 messages (seeded, plus u = 0, u in Fp, u = c u and
+    the inv0 messages u^2 g(Z) = +-1) with their images under the Python reading of the map (oracle/py/map_to_g2.py), the
+    cofactor-cleared points, and the sha256 of the CPU oracle's MapToG2 proof of the 12 records."""
+    import hashlib
+    import json
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import bn254
+    import map_to_g2 as M
+    from tests import _oracle
+    rnd = random.Random(0x6d617067)
+    us = [(rnd.randrange(bn254.P), rnd.randrange(bn254.P)) for _ in range(6)] + [(0, 0), (12345, 0), (0, 67890)]
+    r = M.sqrt_even(bn254.f2_inv(M.C1)) or M.sqrt_even(bn254.f2_neg(bn254.f2_inv(M.C1)))
+    us += [r, bn254.f2_neg(r), (bn254.P - 1, bn254.P - 1)]
+    recs, cleared, branch = [], [], []
+    for u in us:
+        w = M.witness(u)
+        q = (w["XS"], w["Y"])
+        recs.append(bn254.fq_to_u32(u[0]) + bn254.fq_to_u32(u[1]) + bn254.g2_to_u32(q))
+        cleared.append(bn254.g2_to_u32(bn254.g2_mul(q, bn254.G2_COFACTOR)))
+        branch.append([w["e1"], w["e2"], w["z"]])
+    pf = _oracle.stark_prove(3, np.array(recs, dtype=np.uint32))
+    assert _oracle.stark_verify(pf) == 0
+    out = {"records": recs, "cleared": cleared, "branch_e1_e2_z": branch,
+           "proof": {"words": int(len(pf)), "log_n": int(pf[2]), "W": int(pf[4]), "P": int(pf[5]), "sha256": hashlib.sha256(pf.tobytes()).hexdigest()}}
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "mapg2_vectors.json"), "w"), indent=0)
+    print("mapg2 fixture:", len(us), "messages, branches", sorted(set(map(tuple, branch))), "proof", out["proof"]["sha256"][:16])
+
+
 def main():
+    if sys.argv[1:] == ["mapg2"]:
+        return mapg2_fixture()
     if sys.argv[1:] == ["digests"]:
         return proof_digests()
     if sys.argv[1:] == ["digests128"]:
