@@ -63,7 +63,7 @@ def test_round_shaped_call_and_infinity(ctx):
     assert (one_pair == np.array(bn.f12_to_u32(bn.pairing(A[0], B[0])), dtype=np.uint32)).all()
 
 
-@pytest.mark.parametrize("n", [4, 8, 128])
+@pytest.mark.parametrize("n", [4, 8, 128, 256])
 def test_native_chain_reproduces_the_fixtures(n):
     """sipp_prove_native + sipp_verify_native (reference src/prover_native.rs:26-80, src/verifier_native.rs:14-85) on the GPU:
     from A, B alone they reproduce the committed fixtures -- SIPPStatement limbs and every IO record of the three obligation

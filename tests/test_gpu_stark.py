@@ -102,6 +102,26 @@ def test_error_behaviour(ctx, ios4):
     assert _oracle.stark_verify(ctx.prove(0, ios4[0])) == 0     # still works afterwards
 
 
+def test_n256_instance_of_the_reference_test_verifies():
+    """the size the reference's own `test_sipp_circuit` runs today (src/verifier_circuit.rs:199-200: log_n = 8): 255 G1 / 255 G2 /
+    16 Fq12 records, N = 2^17 / 2^17 / 2^13, the three proofs of ONE instance on three concurrent ctxs; every proof through the
+    oracle's verifier, public inputs = the records"""
+    import sipp_amd
+    d = np.load("tests/golden/sipp_n256_ios.npz")
+    ios = [d[k] for k in ("g1", "g2", "fq12")]
+    assert [a.shape for a in ios] == [(255, 56), (255, 104), (16, 296)]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios])
+    try:
+        proofs = inst.prove(ios)
+    finally:
+        inst.close()
+    for kind, (pf, rec) in enumerate(zip(proofs, ios)):
+        assert int(pf[1]) == kind and int(pf[2]) == (17, 17, 13)[kind]
+        assert _oracle.stark_verify(pf) == 0, kind
+        nio = int(pf[3])
+        assert (pf[-nio * rec.shape[1]:].reshape(nio, rec.shape[1])[: rec.shape[0]] == rec).all()
+
+
 def test_large_n1024_proofs_verify():
     """deep traces (BASELINE config 3): n = 1024 -> 1023 G1 / 1023 G2 / 20 Fq12 IO records, N = 2^19 / 2^19 / 2^14 rows,
     2^20-leaf trees, 2-pass NTTs of size 2^19 / 2^20.  Checked through the oracle's verifier and the public inputs."""
