@@ -14,12 +14,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* API kinds: 0 g1, 1 g2, 2 fq12, 3 mapg2, 4 / 5 = the hardened g1 / g2 AIRs (same records, same rows; air->kind stays 0 / 1) */
 const orc_air_t *orc_air_get(int kind, unsigned log_n) {
-    int mode_u16 = log_n >= 16;
+    int mode_u16 = log_n >= 16, hard = kind >= 4;
+    if (kind < 0 || kind > 5) return NULL;
+    int base = hard ? kind - 4 : kind;
     for (size_t i = 0; i < sizeof(ORC_AIRS) / sizeof(ORC_AIRS[0]); i++)
-        if (ORC_AIRS[i].kind == kind && (ORC_AIRS[i].table_bits == 16) == mode_u16) return &ORC_AIRS[i];
+        if (ORC_AIRS[i].kind == base && ORC_AIRS[i].hardened == hard && (ORC_AIRS[i].table_bits == 16) == mode_u16) return &ORC_AIRS[i];
     return NULL;
 }
+int orc_air_api_kind(const orc_air_t *a) { return a->kind + 4 * a->hardened; }
 
 int orc_air_width(const orc_air_t *a) { return a->n_main + 2 * a->n_checked; }
 
@@ -132,6 +136,7 @@ void orc_test_forge(int flags) { g_forge = flags; }
 
 /* x and offset of every G1 / G2 record on E(Fp) / E'(Fp2) (the verifier's side of the refusal in fill_curve_io) */
 int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io) {
+    if (kind >= 4) kind -= 4;   /* hardened G1 / G2: the same records */
     if (kind == 3) { /* (u, x, y): the point on E'(Fp2) and the map's sign rule sgn0(y) = sgn0(u) (public checks, not constraints) */
         fq_init();
         for (size_t io = 0; io < num_io; io++) {
@@ -179,8 +184,13 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
             num = f2_mul(three, f2_mul(P.x, P.x, ext), ext); den = f2_mul(two, P.y, ext);
             xa = P.x; ya = P.y; xb = P.x;
         }
-        if (f2_inv(den, ext, &deninv)) return -1; /* R = +-P or 2-torsion: not provable */
-        lam = f2_mul(num, deninv, ext);
+        if (f2_inv(den, ext, &deninv)) {
+            /* R = +-P or 2-torsion: not provable.  TEST HOOK bit 2: what a cheating prover does where R = P on an add row -- the
+             * chord rule 0 lam = 0 holds for every lam, so it picks one (5) and walks on from a point of its choosing */
+            if (!((g_forge & 4) && is_add && fq2_is_zero(num))) return -1;
+            lam = mk2(fq_from_u64(5));
+        } else
+            lam = f2_mul(num, deninv, ext);
         fq2 x3 = fq2_sub(fq2_sub(f2_mul(lam, lam, ext), xa), xb);
         fq2 y3 = fq2_sub(f2_mul(lam, fq2_sub(xa, x3), ext), ya);
         put_f2_chk(tr, n, L.lam, row, lam, ext, cpl);
@@ -270,6 +280,39 @@ static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, co
     }
     fq_to_u32(w.xs.c0, out_words); fq_to_u32(w.xs.c1, out_words + 8);
     fq_to_u32(w.v[MG_Y].c0, out_words + 16); fq_to_u32(w.v[MG_Y].c1, out_words + 24);
+    return 0;
+}
+
+/* hardened curve AIRs (kinds 4 / 5): T3 = p - 1 - x3 with its borrow bits, and on add rows with bit = 1 the witness that R.x and P.x
+ * differ in a limb: nz_j = 1 / (Px_j - Rx_j) at the first such limb (a Goldilocks inverse of a 17-bit difference), 0 elsewhere */
+static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t row) {
+    const int ext = a->kind == 0 ? 1 : 2, nc = 16 * ext, cpl = a->cells_per_limb;
+    const int32_t *lay = a->kind == 0 ? (cpl == 1 ? ORC_HARD_LAYOUT_G1H_U16 : ORC_HARD_LAYOUT_G1H_U8)
+                                      : (cpl == 1 ? ORC_HARD_LAYOUT_G2H_U16 : ORC_HARD_LAYOUT_G2H_U8);
+    layout_t L = layout_of(a);
+    for (int c = 0; c < ext; c++) {
+        int64_t borrow = 0;
+        for (int i = 0; i < 16; i++) {
+            int64_t x = cpl == 1 ? (int64_t)tr[(size_t)(L.X3 + 16 * c + i) * n + row]
+                                 : (int64_t)(tr[(size_t)(L.X3 + 2 * (16 * c + i)) * n + row] + 256 * tr[(size_t)(L.X3 + 2 * (16 * c + i) + 1) * n + row]);
+            int64_t pm1 = (int64_t)ORC_BN_P_LIMBS[i] - (i == 0 ? 1 : 0);      /* p is odd: p - 1 only changes limb 0 */
+            int64_t d = pm1 - x - borrow;
+            borrow = d < 0;
+            uint64_t t = (uint64_t)(d + (borrow << 16));
+            if (cpl == 1) put(tr, n, lay[2] + 16 * c + i, row, t);
+            else { put(tr, n, lay[2] + 2 * (16 * c + i), row, t & 0xff); put(tr, n, lay[2] + 2 * (16 * c + i) + 1, row, t >> 8); }
+            if (i < 15) put(tr, n, lay[1] + 15 * c + i, row, (uint64_t)borrow);
+        }
+        if (borrow) return -30;                                              /* x3 >= p: cannot happen for the chain's canonical values */
+    }
+    for (int j = 0; j < nc; j++) put(tr, n, lay[0] + j, row, 0);
+    if ((row & 1) == 0 && tr[(size_t)L.bit * n + row]) {
+        int j;
+        for (j = 0; j < nc; j++)
+            if (tr[(size_t)(L.Px + j) * n + row] != tr[(size_t)(L.Rx + j) * n + row]) break;
+        if (j == nc) return (g_forge & 4) ? 0 : -31;                         /* R.x = P.x where the addition is used: no witness */
+        put(tr, n, lay[0] + j, row, gl_inv(gl_sub(tr[(size_t)(L.Px + j) * n + row], tr[(size_t)(L.Rx + j) * n + row])));
+    }
     return 0;
 }
 
@@ -411,16 +454,17 @@ static void permuted_cols(const uint64_t *col, size_t n, unsigned tbits, uint64_
     free(hist);
 }
 
-orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *err) {
+orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int *err) {
     fq_init();
     *err = 0;
-    if (num_io == 0) { *err = -1; return NULL; }
+    if (num_io == 0 || api_kind < 0 || api_kind > 5) { *err = -1; return NULL; }
+    const int kind = api_kind >= 4 ? api_kind - 4 : api_kind;   /* the hardened variants fill the same primary cells */
     const unsigned log_rows = kind == 3 ? 3 : 9;   /* rows per record: 512 (exponentiations), 8 (MapToG2); = air->log_rows */
     size_t nio = 2; /* at least two IO blocks, at least 1024 rows */
     while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
     unsigned log_n = log_rows;
     while (((size_t)1 << (log_n - log_rows)) < nio) log_n++;
-    const orc_air_t *a = orc_air_get(kind, log_n);
+    const orc_air_t *a = orc_air_get(api_kind, log_n);
     if (!a || (unsigned)a->log_rows != log_rows) { *err = -1; return NULL; }
     size_t n = (size_t)1 << log_n;
     if (n < ((size_t)1 << a->table_bits)) { *err = -7; return NULL; }
@@ -451,7 +495,8 @@ orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *er
     for (size_t r = 0; r < n; r++) t->trace[r] = r < T ? r : T - 1;
 #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < n; r++) {
-        int rc = fill_gadgets_row(a, t->trace, n, r);
+        int rc = a->hardened ? fill_harden_row(a, t->trace, n, r) : 0;
+        if (!rc) rc = fill_gadgets_row(a, t->trace, n, r);
         if (rc) {
 #pragma omp critical
             rc_all = rc;

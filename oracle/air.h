@@ -17,7 +17,8 @@ typedef struct {
     uint32_t *pis;   /* [num_io][pi_per_io] */
 } orc_trace;
 
-const orc_air_t *orc_air_get(int kind, unsigned log_n);
+const orc_air_t *orc_air_get(int kind, unsigned log_n);   /* API kind 0 .. 5 */
+int orc_air_api_kind(const orc_air_t *a);
 int orc_air_width(const orc_air_t *a);
 size_t orc_air_num_constraints(const orc_air_t *a);
 orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *err);

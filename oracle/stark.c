@@ -51,6 +51,7 @@ static int fq_words_canonical(const uint32_t *w) {
 /* every Fq element of every record < p; the exponent (8 words) may be any 256-bit value.
  * Record layouts (reference src/verifier_circuit.rs:92-124): (x, offset, exp_val, output). */
 int orc_pis_canonical(int kind, const uint32_t *pis, size_t num_io) {
+    if (kind >= 4) kind -= 4;   /* hardened G1 / G2: the same records */
     if (kind == 3) { /* MapToG2 records (u, x, y): six Fq elements, no exponent */
         for (size_t k = 0; k < 6 * num_io; k++)
             if (!fq_words_canonical(pis + 8 * k)) return 0;
@@ -171,7 +172,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
  * whatever the cells hold is committed and proved as is; the verifier must then refuse) */
 int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **proof_out, size_t *proof_len) {
     int err = 0;
-    const int kind = t->air->kind;
+    const int kind = orc_air_api_kind(t->air);
     const orc_air_t *a = t->air;
     const unsigned log_n = t->log_n, log_m = log_n + cfg->rate_bits;
     const size_t n = (size_t)1 << log_n;
@@ -361,7 +362,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
     const unsigned log_rows = kind == 3 ? 3 : 9;
-    if (kind < 0 || kind > 3 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
+    if (kind < 0 || kind > 5 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const orc_air_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||

@@ -140,7 +140,7 @@ class OrcAir(C.Structure):
                 ("n_main", C.c_int), ("checked_base", C.c_int), ("n_checked", C.c_int), ("n_ops", C.c_int),
                 ("n_constraints", C.c_int), ("n_aux", C.c_int), ("pi_per_io", C.c_int), ("n_gadgets", C.c_int),
                 ("carry_limbs", C.c_int), ("prog", C.POINTER(C.c_int64)), ("prog_len", C.c_int),
-                ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int)]
+                ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int), ("hardened", C.c_int)]
 
 
 class OrcTrace(C.Structure):

@@ -1,0 +1,118 @@
+"""The hardened G1 / G2 exponentiation AIRs (API kinds 4 / 5) on the CPU oracle.
+
+The plain chord rule  lam (Px - Rx) = Py - Ry  says nothing where the accumulator meets the running power (R = P: 0 lam = 0 for EVERY
+lam), so for a crafted record (offset a small multiple of x) a cheating prover can walk on from a point of its choosing.  The test
+below BUILDS that forgery through the oracle's test hook and shows both halves: the plain AIR's verifier accepts the false statement,
+the hardened AIR has no witness for it.  What the variant adds: x3 canonical (T3 = p - 1 - x3 with a borrow chain) and, on add rows,
+sum_j (Px_j - Rx_j) nz_j = bit."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from oracle.py import bn254 as bn
+from oracle.py import sipp_native as sn
+
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+
+
+@pytest.fixture(scope="module")
+def ios4():
+    d = np.load("tests/golden/sipp_n4_ios.npz")
+    return d["g1"], d["g2"]
+
+
+def hard_layout(name):
+    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
+    m = re.search(r"ORC_HARD_LAYOUT_%s\[3\] = \{([^}]*)\}" % name, txt)
+    return [int(x) for x in m.group(1).split(",")]
+
+
+@pytest.mark.parametrize("kind", [4, 5])
+def test_rows_hold_and_the_plain_columns_are_unchanged(ios4, kind):
+    ios = ios4[kind - 4]
+    t, plain = _oracle.Trace(kind, ios), _oracle.Trace(kind - 4, ios)
+    assert t.air.hardened == 1 and plain.air.hardened == 0 and t.air.kind == plain.air.kind == kind - 4
+    n = 1 << t.log_n
+    assert all(t.check_row(r) == -1 for r in range(0, n, 7))
+    a, b = t.array(), plain.array()
+    nz, cb, t3 = hard_layout("G%dH_U8" % (kind - 3))
+    # the plain AIR's unchecked cells, then (shifted by the new unchecked columns) its checked cells, are the same values
+    ub = plain.air.checked_base
+    assert (a[:ub] == b[:ub]).all()
+    shift = t.air.checked_base - ub
+    assert (a[ub + shift: ub + shift + plain.air.n_checked] == b[ub: ub + plain.air.n_checked]).all()
+    nc = 16 * (kind - 3)
+    # the inequality witness sits exactly on the add rows whose bit is set
+    bit = a[1 + 4 * nc]
+    used = (a[nz: nz + nc] != 0).any(axis=0)
+    assert (used == ((np.arange(n) % 2 == 0) & (bit == 1))).all()
+
+
+@pytest.mark.parametrize("kind", [4, 5])
+def test_mutations_of_the_new_cells_break_a_row(ios4, kind):
+    t = _oracle.Trace(kind, ios4[kind - 4])
+    arr = t.array()
+    nz, cb, t3 = hard_layout("G%dH_U8" % (kind - 3))
+    nc = 16 * (kind - 3)
+    bit = arr[1 + 4 * nc]
+    add_used = int(np.argwhere((np.arange(arr.shape[1]) % 2 == 0) & (bit == 1))[3][0])
+    add_unused = int(np.argwhere((np.arange(arr.shape[1]) % 2 == 0) & (bit == 0))[3][0])
+    j = int(np.argwhere(arr[nz: nz + nc, add_used] != 0)[0][0])
+    for col, row in ((nz + j, add_used), (nz + (j + 1) % nc, add_used), (nz, add_unused), (cb + 3, 5), (cb + 14, 6), (t3 + 9, 5), (t3, 512),
+                     (t3 + 2 * nc - 1, 7)):
+        old = int(arr[col, row])
+        arr[col, row] = old ^ 1
+        assert t.check_row(row) != -1, (col, row)
+        arr[col, row] = old
+        assert t.check_row(row) == -1
+    # a non-canonical x3 (x3 + p: the same residue, other limbs) cannot be written: its T3 would need a final borrow
+    x3 = t.air.checked_base + 2 * nc                      # lam | X3 | Y3, two cells per limb in the u8 variant
+    row = 9
+    limbs = [int(arr[x3 + 2 * i, row]) + 256 * int(arr[x3 + 2 * i + 1, row]) for i in range(16)]
+    v = sum(l << (16 * i) for i, l in enumerate(limbs)) + bn.P
+    if v < 1 << 256:
+        for i in range(16):
+            l = (v >> (16 * i)) & 0xFFFF
+            arr[x3 + 2 * i, row], arr[x3 + 2 * i + 1, row] = l & 0xFF, l >> 8
+        assert t.check_row(row) != -1
+
+
+@pytest.mark.parametrize("kind", [4, 5])
+def test_proof_verifies_and_is_bound_to_its_kind(ios4, kind):
+    ios = ios4[kind - 4]
+    pf = _oracle.stark_prove(kind, ios)
+    assert int(pf[1]) == kind and _oracle.stark_verify(pf) == 0
+    other = pf.copy()
+    other[1] = kind - 4                                   # presented as a proof of the plain AIR: shapes do not match
+    assert _oracle.stark_verify(other) != 0
+
+
+def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_impossible_in_the_hardened_one():
+    L = _oracle.load()
+    L.orc_test_forge.argtypes = [C.c_int]
+    x = bn.g1_mul(bn.G1, 77)
+    # offset = x, odd exponent: the first addition is R + P with R = P.  The true output is 4 x; the forger claims whatever its walk ends in.
+    rec = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(x) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 4))] * 2, dtype=np.uint32)
+    with pytest.raises(RuntimeError):
+        _oracle.Trace(0, rec)                             # the honest generators refuse the record
+    try:
+        L.orc_test_forge(2 | 4)                           # outputs taken from the chain; a free slope where the chord rule is 0 = 0
+        forged = _oracle.Trace(0, rec)
+        assert all(forged.check_row(r) == -1 for r in range(0, 1024))
+        pf = _oracle.stark_prove_trace(forged)
+        assert _oracle.stark_verify(pf) == 0              # THE HOLE: a verified proof ...
+        claimed = [int(v) for v in pf[-2 * 56:][40:56]]
+        assert claimed != bn.g1_to_u32(bn.g1_mul(x, 4))   # ... of a false statement (out != offset + [3] x)
+        # the hardened AIR: the forger finds no inequality witness; writing zeros breaks the add row
+        hard = _oracle.Trace(4, rec)
+        assert hard.check_row(0) != -1
+        pfh = _oracle.stark_prove_trace(hard)
+        assert _oracle.stark_verify(pfh) != 0
+    finally:
+        L.orc_test_forge(0)
+    with pytest.raises(RuntimeError):
+        _oracle.Trace(4, rec)                             # and its honest generator refuses the record like the plain one

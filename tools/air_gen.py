@@ -68,6 +68,7 @@ class Air:
         self.pi_per_io = 0
         self.max_e = 0
         self.log_rows = 9                           # log2 of the rows per IO record
+        self.hardened = 0
 
     # ---- column allocation: all unchecked first, then all checked ----
     def alloc(self, name, n):
@@ -275,14 +276,20 @@ def bind_pi(a, layout, tower=False):
 
 
 # ------------------------------------------------------------------------------------------------
-def build_curve(name, mode, ext):
+def build_curve(name, mode, ext, hardened=False):
     """G1 (ext = 1, coordinates in Fq) or G2 (ext = 2, coordinates in Fq2 = Fq[u]/(u^2+1)).
     Row: one affine group operation  (x3, y3) = A (+) B  with slope lam:
        add rows  (even): A = R (accumulator), B = P (running power);  lam (xB - xA) = yB - yA
        double rows (odd): A = B = P;                                   2 lam yA = 3 xA^2
        lam^2 = xA + xB + x3 ;  lam (xA - x3) = yA + y3
-    """
-    a = Air(name, mode)
+    hardened = True (kinds 4 / 5, names g1h / g2h): the chord rule above says nothing when xB = xA (0 lam = 0 holds for EVERY lam when
+    the accumulator meets the running power, R = P): the variant adds, per row,
+       * x3 CANONICAL: T3 = p - 1 - x3 as range-checked limbs with a boolean borrow chain (so the limbs of R.x and P.x, which are
+         copies of earlier x3's or public inputs, are THE limbs of their values), and
+       * on add rows  sum_j (Px_j - Rx_j) nz_j = bit  with free cells nz_j: where the addition is USED (bit = 1) the two x's differ in a
+         limb, hence mod p -- the slope is then determined, and a proof exists exactly for the records the plain chain proves."""
+    a = Air(name + ("h" if hardened else ""), mode)
+    a.hardened = 1 if hardened else 0
     a.gadgets = []
     a.group = 2                        # limb identity checked in base 2^32: 15 carries per gadget instead of 31
     nc = NL * ext                      # limbs per coordinate
@@ -297,6 +304,10 @@ def build_curve(name, mode, ext):
     bound = 42 if ext == 1 else 43
     for g in gad:
         a.declare_gadget_cols(g, bound)
+    if hardened:                       # after everything else: the columns of the plain AIR keep their positions
+        a.alloc("nz", nc)
+        a.alloc("cb", (NL - 1) * ext)
+        a.alloc_checked("T3", nc * a.cpl)
     a.finalize_columns()
 
     def comp_u(nm, c, **kw):   # component c (0/1) of an unchecked Fq2/Fq value
@@ -347,6 +358,28 @@ def build_curve(name, mode, ext):
     # IO record order (x, offset, exp_val, output): reference src/verifier_circuit.rs:92-105
     bind_pi(a, [("Px", w, "first"), ("Py", w, "first"), ("Rx", w, "first"), ("Ry", w, "first"), ("e", 8, "first"),
                 ("Rx", w, "last"), ("Ry", w, "last")])
+    if hardened:
+        bit = a.col("bit")
+        for c in range(ext):
+            for i in range(NL):
+                # (p - 1)_i - x3_i - b_{i-1} - t_i + 2^16 b_i = 0,  b_{-1} = b_15 = 0: t = p - 1 - x3 >= 0
+                pm1 = ((BN_P - 1) >> (16 * i)) & 0xFFFF
+                m = [(pm1, [])]
+                m += [(-co, [L(cc)]) for co, cc in a.limb_expr("X3", NL * c + i, True)]
+                m += [(-co, [L(cc)]) for co, cc in a.limb_expr("T3", NL * c + i, True)]
+                if i > 0:
+                    m += [(-1, [L(a.col("cb") + (NL - 1) * c + i - 1)])]
+                if i < NL - 1:
+                    m += [(65536, [L(a.col("cb") + (NL - 1) * c + i)])]
+                a.poly(m)
+            for i in range(NL - 1):
+                b = a.col("cb") + (NL - 1) * c + i
+                a.poly([(1, [L(b), L(b)]), (-1, [L(b)])])
+        m = [(-1, [PER(PER_ADD), L(bit)])]
+        for j in range(nc):
+            m += [(1, [PER(PER_ADD), L(a.col("Px") + j), L(a.col("nz") + j)]), (-1, [PER(PER_ADD), L(a.col("Rx") + j), L(a.col("nz") + j)])]
+        a.poly(m)
+        a.layout = [a.col("nz"), a.col("cb"), a.col("T3")]
     a.primary = dict(kind="curve", ext=ext)
     return a
 
@@ -662,10 +695,10 @@ def emit(a, f, prefix):
 def header_entry(a, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     g0 = a.gadgets[0]
-    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d},\n" % (
-        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
+    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d, %d},\n" % (
+        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3, "g1h": 0, "g2h": 1}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
         a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag,
-        a.log_rows))
+        a.log_rows, a.hardened))
 
 
 STRUCT = """typedef struct {
@@ -685,7 +718,8 @@ STRUCT = """typedef struct {
     const int64_t *prog;
     int prog_len;
     const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
-    int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 0 for mapg2 */
+    int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 3 for mapg2 */
+    int hardened;        /* 1: the curve AIR with canonical x3 and the x-inequality witness (API kinds 4 / 5 = kind + 4) */
 } %s_air_t;
 """
 
@@ -698,7 +732,8 @@ def column_map(a):
 def main():
     airs = []
     for mode in ("u16", "u8"):
-        airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode), build_map_g2(mode)]
+        airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode), build_map_g2(mode),
+                 build_curve("g1", mode, 1, hardened=True), build_curve("g2", mode, 2, hardened=True)]
     for path, prefix, guard in ((os.path.join(ROOT, "oracle", "air_tables.h"), "ORC", "ORACLE_AIR_TABLES_H"),
                                 (os.path.join(ROOT, "sipp_amd", "csrc", "air_tables.h"), "SIPP", "SIPP_AIR_TABLES_H")):
         with open(path, "w") as f:
@@ -713,6 +748,9 @@ def main():
             for a in airs:
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
+                if a.hardened:
+                    f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3) */\n" % a.name)
+                    f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[3] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
