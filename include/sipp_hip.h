@@ -69,7 +69,12 @@ void sipp_default_config(sipp_stark_config *cfg);
 
 /* Which STARK (reference src/verifier_circuit.rs:133 / :134 / :135) */
 typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
-               SIPP_MAP_G2 = 3 /* src/bin/bls_aggregation.rs:65, see sipp_map_to_g2_prove */ } sipp_kind;
+               SIPP_MAP_G2 = 3 /* src/bin/bls_aggregation.rs:65, see sipp_map_to_g2_prove */,
+               /* G1 / G2 exponentiation with the HARDENED AIR (same records, same rows, about 11 % more columns): x3 canonical and,
+                * where an addition is used, an inequality witness for the two x-coordinates -- the chord rule of the plain AIR is
+                * satisfied by any slope where the accumulator meets the running power.  Through sipp_prove /
+                * sipp_prove_async and the generic size / shape / trace functions. */
+               SIPP_G1_EXP_HARDENED = 4, SIPP_G2_EXP_HARDENED = 5 } sipp_kind;
 
 /* u32 words per IO record, (x, offset, exp_val, output) order:
  * G1 7*8 = 56, G2 13*8 = 104, Fq12 37*8 = 296. */
@@ -104,6 +109,9 @@ int sipp_g2_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_
                       size_t *proof_len);
 int sipp_fq12_exp_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
                         size_t *proof_len);
+/* The same for any sipp_kind (the only synchronous entry point of the hardened kinds). */
+int sipp_prove(sipp_ctx *ctx, int kind, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+               size_t *proof_len);
 /* Asynchronous form ("who calls it"): plonky2 runs the three witness generators behind
  * reference src/verifier_circuit.rs:133-135 serially on one thread, so a patched caller starts each proof as soon as
  * its IO values exist and collects the three afterwards.  sipp_prove_async hands the job to the ctx's own worker

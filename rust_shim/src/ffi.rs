@@ -26,6 +26,8 @@ pub const SIPP_G1_EXP: c_int = 0;
 pub const SIPP_G2_EXP: c_int = 1;
 pub const SIPP_FQ12_EXP: c_int = 2;
 pub const SIPP_MAP_G2: c_int = 3;
+pub const SIPP_G1_EXP_HARDENED: c_int = 4;
+pub const SIPP_G2_EXP_HARDENED: c_int = 5;
 pub const SIPP_SALT_SIZE: usize = 4;
 pub const SIPP_FRI_MAX_ROUNDS: usize = 32;
 
@@ -102,6 +104,8 @@ extern "C" {
     pub fn sipp_map_to_g2_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
     /// messages -> MapToG2 records, the G2ExpStark records of the cofactor clearing (2n, may be null), the cleared points (may be null)
     pub fn sipp_map_to_g2(ctx: *mut SippCtxOpaque, msgs: *const u32, n: usize, map_ios: *mut u32, g2_ios: *mut u32, cleared: *mut u32) -> c_int;
+    /// any kind, synchronously (kinds 4 / 5: G1 / G2 exponentiation with the hardened AIR)
+    pub fn sipp_prove(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
     pub fn sipp_prove_async(ctx: *mut SippCtxOpaque, kind: c_int, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize) -> c_int;
     pub fn sipp_wait(ctx: *mut SippCtxOpaque, proof_len: *mut usize) -> c_int;
     /// arrays of three, indexed by kind

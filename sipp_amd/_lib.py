@@ -70,6 +70,7 @@ SIGNATURES = {
     "sipp_g2_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_map_to_g2_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_prove": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_map_to_g2": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
@@ -326,13 +327,16 @@ class Ctx:
         return t
 
     def prove(self, kind, ios):
-        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12 / 3 MapToG2) for host IO records -> flat proof (uint64 ndarray)"""
+        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12 / 3 MapToG2 / 4, 5 hardened G1, G2) for host IO records -> flat proof"""
         ios = np.ascontiguousarray(ios, dtype=np.uint32)
         cap = self.L.sipp_proof_size(self.h, kind, ios.shape[0])
         if cap == 0:
             raise SippError(-1, "sipp_proof_size")
         out = np.zeros(cap, dtype=np.uint64)
         n = C.c_size_t()
+        if kind >= 4:       # the hardened G1 / G2 kinds: the generic entry point
+            self._ck(self.L.sipp_prove(self.h, kind, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
+            return out[: n.value]
         fn = (self.L.sipp_g1_exp_prove, self.L.sipp_g2_exp_prove, self.L.sipp_fq12_exp_prove, self.L.sipp_map_to_g2_prove)[kind]
         self._ck(fn(self.h, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
         return out[: n.value]

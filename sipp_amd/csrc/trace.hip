@@ -654,6 +654,55 @@ __global__ void write_outputs_kernel(uint32_t* __restrict__ ios, uint32_t num_io
     }
 }
 
+struct SippBnP {
+    uint32_t l[16];   // 16-bit limbs of the BN254 base-field prime
+};
+
+// ---- hardened curve AIRs (API kinds 4 / 5): per row T3 = p - 1 - x3 with its borrow bits, and on add rows whose bit is set the
+// witness that R.x and P.x differ in a limb: nz_j = 1 / (Px_j - Rx_j) in the Goldilocks field at the first such limb.  Reads cells
+// written by curve_rows_kernel and exp_rows_kernel; one lane per row, integer work only.
+__global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__ tr, size_t n, int ext, int cpl, int col_rx, int col_px,
+                                                         int col_bit, int col_x3, int col_nz, int col_cb, int col_t3, SippBnP pl,
+                                                         int* __restrict__ err) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int nc = 16 * ext;
+    bool bad = false;
+    for (int c = 0; c < ext; c++) {
+        int64_t borrow = 0;
+        for (int i = 0; i < 16; i++) {
+            const int64_t x = cpl == 1 ? (int64_t)tr[(size_t)(col_x3 + 16 * c + i) * n + row]
+                                       : (int64_t)(tr[(size_t)(col_x3 + 2 * (16 * c + i)) * n + row] + 256 * tr[(size_t)(col_x3 + 2 * (16 * c + i) + 1) * n + row]);
+            const int64_t d = (int64_t)pl.l[i] - (i == 0 ? 1 : 0) - x - borrow;
+            borrow = d < 0 ? 1 : 0;
+            const uint64_t t = (uint64_t)(d + (borrow << 16));
+            if (cpl == 1) {
+                tr[(size_t)(col_t3 + 16 * c + i) * n + row] = t;
+            } else {
+                tr[(size_t)(col_t3 + 2 * (16 * c + i)) * n + row] = t & 0xffu;
+                tr[(size_t)(col_t3 + 2 * (16 * c + i) + 1) * n + row] = t >> 8;
+            }
+            if (i < 15) tr[(size_t)(col_cb + 15 * c + i) * n + row] = (uint64_t)borrow;
+        }
+        bad |= borrow != 0;
+    }
+    int first = -1;
+    uint64_t dpx = 0, drx = 0;
+    const bool used = (row & 1) == 0 && tr[(size_t)col_bit * n + row] != 0;
+    for (int j = 0; j < nc; j++) {
+        const uint64_t px = tr[(size_t)(col_px + j) * n + row], rx = tr[(size_t)(col_rx + j) * n + row];
+        if (first < 0 && px != rx) {
+            first = j;
+            dpx = px;
+            drx = rx;
+        }
+    }
+    const uint64_t w = (used && first >= 0) ? gl::inv(gl::sub(dpx, drx)) : 0;
+    for (int j = 0; j < nc; j++) tr[(size_t)(col_nz + j) * n + row] = (used && j == first) ? w : 0;
+    bad |= used && first < 0;    // R.x = P.x where the addition is used: no witness (the plain chain refused the record already)
+    if (bad) atomicExch(err, SIPP_E_WITNESS);
+}
+
 // ---- exponent cells: closed form per row ----
 __global__ void exp_rows_kernel(const uint32_t* __restrict__ ios, uint32_t ppi, uint32_t exp_off, uint64_t* __restrict__ tr,
                                 size_t n, int col_bit, int col_e) {
@@ -1008,19 +1057,22 @@ __global__ void lookup_fill_kernel(const uint32_t* __restrict__ start, const uin
 }  // namespace
 
 // ---- host drivers -------------------------------------------------------------------------------------------
+// API kinds: 0 G1, 1 G2, 2 Fq12, 3 MapToG2, 4 / 5 = the hardened G1 / G2 AIRs (the same records and rows; air->kind stays 0 / 1)
 const sipp_air_t* sipp_air_get(int kind, uint32_t log_n) {
     const bool u16 = log_n >= 16;
+    if (kind < 0 || kind > 5) return nullptr;
+    const int hard = kind >= 4 ? 1 : 0, base = hard ? kind - 4 : kind;
     for (size_t i = 0; i < sizeof(SIPP_AIRS) / sizeof(SIPP_AIRS[0]); i++)
-        if (SIPP_AIRS[i].kind == kind && (SIPP_AIRS[i].table_bits == 16) == u16) return &SIPP_AIRS[i];
+        if (SIPP_AIRS[i].kind == base && SIPP_AIRS[i].hardened == hard && (SIPP_AIRS[i].table_bits == 16) == u16) return &SIPP_AIRS[i];
     return nullptr;
 }
 
 static int64_t* prog_on_device(sipp_ctx* ctx, const sipp_air_t* a) {
-    uint64_t* t = sipp_table_get(ctx, 100, (uint64_t)a->kind, (uint64_t)a->table_bits);
+    uint64_t* t = sipp_table_get(ctx, 100, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits);
     if (t) return (int64_t*)t;
     std::vector<uint64_t> v(a->prog_len);
     memcpy(v.data(), a->prog, (size_t)a->prog_len * 8);
-    if (sipp_table_put(ctx, 100, (uint64_t)a->kind, (uint64_t)a->table_bits, v, &t) != SIPP_OK) return nullptr;
+    if (sipp_table_put(ctx, 100, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits, v, &t) != SIPP_OK) return nullptr;
     return (int64_t*)t;
 }
 const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a) { return prog_on_device(ctx, a); }
@@ -1160,12 +1212,24 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                            (uint32_t)a->table_bits);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
+    if (a->hardened) {
+        if (a->kind > 1) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "hardened AIR: curves only");
+        const int ext = a->kind + 1, ncl = 16 * ext;
+        const int32_t* lay = a->kind == 0 ? (cpl == 1 ? SIPP_HARD_LAYOUT_G1H_U16 : SIPP_HARD_LAYOUT_G1H_U8)
+                                          : (cpl == 1 ? SIPP_HARD_LAYOUT_G2H_U16 : SIPP_HARD_LAYOUT_G2H_U8);
+        SippBnP pl;
+        for (int i = 0; i < 16; i++) pl.l[i] = SIPP_BN_P_LIMBS[i];
+        ProfScope ps(ctx, "trace_harden");
+        hipLaunchKernelGGL(harden_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n, ext, cpl, 1,
+                           1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], pl, d_err);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
     {
         GadgetArgs g;
         g.prog = prog_on_device(ctx, a);
         if (!g.prog) return SIPP_E_HIP;
         {
-            uint64_t* t = sipp_table_get(ctx, 101, (uint64_t)a->kind, (uint64_t)a->table_bits);
+            uint64_t* t = sipp_table_get(ctx, 101, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits);
             if (!t) {
                 // gadgets come first in the program: record where each one starts
                 std::vector<uint32_t> off;
@@ -1190,7 +1254,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                 if ((int)off.size() != a->n_gadgets) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "AIR program: gadget count mismatch");
                 std::vector<uint64_t> packed((off.size() + 1) / 2 + 1, 0);
                 memcpy(packed.data(), off.data(), off.size() * 4);
-                SIPP_TRY(sipp_table_put(ctx, 101, (uint64_t)a->kind, (uint64_t)a->table_bits, packed, &t));
+                SIPP_TRY(sipp_table_put(ctx, 101, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits, packed, &t));
             }
             g.gadget_off = reinterpret_cast<const uint32_t*>(t);
         }
