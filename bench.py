@@ -387,6 +387,35 @@ def main():
                                 "entry_points": "sipp_map_to_g2, sipp_map_to_g2_prove"}
         except Exception as e:                  # noqa: BLE001
             out["map_to_g2"] = {"error": repr(e)}
+        # secondary, outside the timed region: the same instance with the HARDENED G1 / G2 AIRs (kinds 4 / 5, DESIGN.md section 1:
+        # canonical x3 + x-inequality witness, +11 % columns) -- the price of closing the exceptional-addition case, stated next to
+        # the headline that keeps the plain AIR.  Three ctxs of their own, the three proofs started together (sipp_prove_async).
+        try:
+            if os.environ.get("SIPP_BENCH_HARDENED", "1") in ("0", ""):
+                raise RuntimeError("skipped (SIPP_BENCH_HARDENED=0)")
+            hk = (4, 5, 2)
+            hctx = [sipp_amd.Ctx(device=local_rank, workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(k, ios[i].shape[0])) for i, k in enumerate(hk)]
+            try:
+                for c, lvl in zip(hctx, (-1, 0, 1)):
+                    c._ck(c.L.sipp_ctx_set_stream_priority(c.h, lvl), "set_stream_priority")
+                def hstep():
+                    for c, k, a in zip(hctx, hk, ios):
+                        c.prove_async(k, a)
+                    return [c.wait() for c in hctx]
+                hstep()
+                t = time.perf_counter()
+                for _ in range(5):
+                    hp = hstep()
+                t_h = (time.perf_counter() - t) / 5
+                out["hardened_instance"] = {"kinds": list(hk), "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
+                                            "columns": [list(hctx[i].shape(hk[i], ios[i].shape[0])) for i in range(3)],
+                                            "proof_words": [int(len(x)) for x in hp],
+                                            "note": "no start gate (three independent sipp_prove_async): compare with ms_per_step"}
+            finally:
+                for c in hctx:
+                    c.close()
+        except Exception as e:                  # noqa: BLE001
+            out["hardened_instance"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ios, shapes)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
