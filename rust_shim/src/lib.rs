@@ -11,6 +11,8 @@ pub enum Kind {
     G2Exp = 1,   // 104 u32 per IO: Fq2 coordinates as (c0, c1)
     Fq12Exp = 2, // 296 u32 per IO: 12 MyFq12 coefficients for x, offset; exp_val; out
     MapG2 = 3,   // 48 u32 per IO:  u, x, y in Fq2 (batch_map_to_g2_circuit, src/bin/bls_aggregation.rs:65)
+    G1ExpHardened = 4, // the records of G1Exp / G2Exp proved with the hardened AIR (canonical x3 + x-inequality witness: no free slope
+    G2ExpHardened = 5, // where the accumulator meets the running power)
 }
 
 impl Kind {
@@ -20,6 +22,8 @@ impl Kind {
             Kind::G2Exp => 104,
             Kind::Fq12Exp => 296,
             Kind::MapG2 => 48,
+            Kind::G1ExpHardened => 56,
+            Kind::G2ExpHardened => 104,
         }
     }
 }
@@ -61,6 +65,7 @@ impl SippCtx {
                 Kind::G2Exp => ffi::sipp_g2_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::Fq12Exp => ffi::sipp_fq12_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::MapG2 => ffi::sipp_map_to_g2_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+                Kind::G1ExpHardened | Kind::G2ExpHardened => ffi::sipp_prove(self.raw, kind as i32, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
             }
         };
         if rc != 0 {
