@@ -278,7 +278,9 @@ class Prover {
         const size_t mx[3] = {max_g1_io, max_g2_io, max_fq12_io};
         for (int k = 0; k < 3; k++) {
             max_io_[k] = mx[k];
-            const int rc = sipp_ctx_create(&ctx_[k], device, nullptr, sipp_workspace_bytes(k, mx[k]));
+            // (the G1 / G2 arenas also hold the hardened AIRs of sipp_hip.h kinds 4 / 5: about 11 % more columns)
+            const size_t ws = k < 2 ? sipp_workspace_bytes(k + SIPP_G1_EXP_HARDENED, mx[k]) : sipp_workspace_bytes(k, mx[k]);
+            const int rc = sipp_ctx_create(&ctx_[k], device, nullptr, ws);
             if (rc != SIPP_OK) {
                 for (int j = 0; j < k; j++) sipp_ctx_destroy(ctx_[j]);
                 throw Error(rc, "sipp_ctx_create failed (see stderr)");
@@ -293,11 +295,13 @@ class Prover {
     Prover(const Prover&) = delete;
     Prover& operator=(const Prover&) = delete;
 
-    ExpCircuitResult<G1Affine> g1_exp_circuit(const std::vector<G1ExpInput>& inputs) {
-        return run<G1ExpInput, G1Affine>(SIPP_G1_EXP, inputs);
+    // hardened = true: the same obligations proved with the hardened curve AIR (sipp_hip.h kinds 4 / 5): for
+    // statements whose offsets an adversary may choose
+    ExpCircuitResult<G1Affine> g1_exp_circuit(const std::vector<G1ExpInput>& inputs, bool hardened = false) {
+        return run<G1ExpInput, G1Affine>(SIPP_G1_EXP, inputs, hardened);
     }
-    ExpCircuitResult<G2Affine> g2_exp_circuit(const std::vector<G2ExpInput>& inputs) {
-        return run<G2ExpInput, G2Affine>(SIPP_G2_EXP, inputs);
+    ExpCircuitResult<G2Affine> g2_exp_circuit(const std::vector<G2ExpInput>& inputs, bool hardened = false) {
+        return run<G2ExpInput, G2Affine>(SIPP_G2_EXP, inputs, hardened);
     }
     ExpCircuitResult<Fq12> fq12_exp_circuit(const std::vector<Fq12ExpInput>& inputs) {
         return run<Fq12ExpInput, Fq12>(SIPP_FQ12_EXP, inputs);
@@ -473,14 +477,17 @@ class Prover {
         r->proof = StarkProofWithPublicInputs::from_flat(r->flat.data(), r->flat.size());
     }
     template <class In, class Out>
-    ExpCircuitResult<Out> run(int kind, const std::vector<In>& inputs) {
+    ExpCircuitResult<Out> run(int kind, const std::vector<In>& inputs, bool hardened = false) {
         std::vector<ExpIO<In, Out>> io = outputs<In, Out>(kind, inputs);
         ExpCircuitResult<Out> r;
-        const size_t cap = sipp_proof_size(ctx_[kind], kind, io.size());
+        const int api_kind = hardened && kind < 2 ? kind + SIPP_G1_EXP_HARDENED : kind;
+        const size_t cap = sipp_proof_size(ctx_[kind], api_kind, io.size());
         r.flat.assign(cap, 0);
         size_t len = 0;
         int rc;
-        if (kind == SIPP_G1_EXP)
+        if (api_kind != kind)
+            rc = sipp_prove(ctx_[kind], api_kind, words(io), io.size(), r.flat.data(), cap, &len);
+        else if (kind == SIPP_G1_EXP)
             rc = sipp_g1_exp_prove(ctx_[kind], words(io), io.size(), r.flat.data(), cap, &len);
         else if (kind == SIPP_G2_EXP)
             rc = sipp_g2_exp_prove(ctx_[kind], words(io), io.size(), r.flat.data(), cap, &len);

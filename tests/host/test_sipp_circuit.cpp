@@ -255,6 +255,12 @@ static int mapg2(const char* msgs_path, const char* out_prefix) {
     for (size_t i = 0; i < n; i++) CHECK(memcmp(&m.cofactor_inputs[i].x, &r.outputs[i], sizeof(sipp::G2Affine)) == 0);
     const auto c = prover.g2_exp_circuit(m.cofactor_inputs);
     CHECK(orc_stark_verify(c.flat.data(), c.flat.size(), &cfg) == 0);
+    {   // the same obligations through the hardened AIR: another proof (kind 5 in its header), the same outputs
+        const auto ch = prover.g2_exp_circuit(m.cofactor_inputs, true);
+        CHECK(ch.flat.size() > c.flat.size() && ch.flat[1] == SIPP_G2_EXP_HARDENED);
+        CHECK(orc_stark_verify(ch.flat.data(), ch.flat.size(), &cfg) == 0);
+        for (size_t i = 0; i < 2 * n; i++) CHECK(memcmp(&ch.outputs[i], &c.outputs[i], sizeof(sipp::G2Affine)) == 0);
+    }
     for (size_t i = 0; i < n; i++) CHECK(memcmp(&c.outputs[n + i], &m.points[i], sizeof(sipp::G2Affine)) == 0);
     std::ofstream(std::string(out_prefix) + "_proof.bin", std::ios::binary).write(reinterpret_cast<const char*>(r.flat.data()), (std::streamsize)(r.flat.size() * 8));
     std::ofstream(std::string(out_prefix) + "_points.bin", std::ios::binary).write(reinterpret_cast<const char*>(m.points.data()), (std::streamsize)(n * sizeof(sipp::G2Affine)));
