@@ -68,7 +68,7 @@ for seed in range(first, first + count):
     if rng.integers(0, 4) == 0:
         k = int(rng.integers(0, n2))
         g2[k] = g2[k][:32 + 16] + words(fq()) + g2[k][32 + 24:]
-    for kind, recs in ((0, g1), (1, g2), (2, f12)):
+    for kind, recs in ((0, g1), (1, g2), (2, f12), (4, g1), (5, g2)):      # 4 / 5: the hardened AIRs on the same records
         try:
             ios = ctx.exp_outputs(kind, np.array(recs, dtype=np.uint32))
         except sipp_amd.SippError as e:      # an exceptional addition (negligible for random inputs): report, do not stop
