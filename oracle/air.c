@@ -171,6 +171,7 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
     size_t row0 = io * 512;
     fill_exponent(tr, n, &L, row0, exp, bits);
     fq2 three = mk2(fq_from_u64(3)), two = mk2(fq_from_u64(2));
+    int pending = 0;
     for (int r = 0; r < 512; r++) {
         size_t row = row0 + r;
         int is_add = (r & 1) == 0;
@@ -184,11 +185,16 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
             num = f2_mul(three, f2_mul(P.x, P.x, ext), ext); den = f2_mul(two, P.y, ext);
             xa = P.x; ya = P.y; xb = P.x;
         }
+        int same = 0;
         if (f2_inv(den, ext, &deninv)) {
-            /* R = +-P or 2-torsion: not provable.  TEST HOOK bit 2: what a cheating prover does where R = P on an add row -- the
+            /* R = +-P or 2-torsion: not provable by the plain AIR.  The hardened AIR proves R = P (the sum is the double the next row
+             * computes; slope cells 0, result unused).  TEST HOOK bit 2: what a cheating prover does there with the plain AIR -- the
              * chord rule 0 lam = 0 holds for every lam, so it picks one (5) and walks on from a point of its choosing */
-            if (!((g_forge & 4) && is_add && fq2_is_zero(num))) return -1;
-            lam = mk2(fq_from_u64(5));
+            if (is_add && fq2_is_zero(num) && (a->hardened || (g_forge & 4))) {
+                same = a->hardened && !(g_forge & 4);
+                lam = same ? mk2(fq_zero()) : mk2(fq_from_u64(5));
+            } else
+                return -1;
         } else
             lam = f2_mul(num, deninv, ext);
         fq2 x3 = fq2_sub(fq2_sub(f2_mul(lam, lam, ext), xa), xb);
@@ -196,8 +202,16 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
         put_f2_chk(tr, n, L.lam, row, lam, ext, cpl);
         put_f2_chk(tr, n, L.X3, row, x3, ext, cpl);
         put_f2_chk(tr, n, L.Y3, row, y3, ext, cpl);
-        if (is_add) { if (bits[r >> 1]) { R.x = x3; R.y = y3; } }
-        else if (r != 511) { P.x = x3; P.y = y3; }
+        if (is_add) {
+            if (same) pending = bits[r >> 1];             /* hardened, R = P: the accumulator takes the NEXT row's double */
+            else if (bits[r >> 1]) { R.x = x3; R.y = y3; }
+        } else {
+            if (pending) {
+                if (r == 511) return -1;                 /* no row left to hand the double over */
+                R.x = x3; R.y = y3; pending = 0;
+            }
+            if (r != 511) { P.x = x3; P.y = y3; }
+        }
     }
     /* output words */
     fq_to_u32(R.x.c0, out_words);
@@ -306,11 +320,27 @@ static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t ro
         if (borrow) return -30;                                              /* x3 >= p: cannot happen for the chain's canonical values */
     }
     for (int j = 0; j < nc; j++) put(tr, n, lay[0] + j, row, 0);
-    if ((row & 1) == 0 && tr[(size_t)L.bit * n + row]) {
+    /* eq: accumulator = running power (add rows); u = bit (1 - eq); eqc on a double row = bit eq of the add row before it */
+    int eq = 0, eqc = 0;
+    if ((row & 1) == 0) {
+        eq = 1;
+        for (int j = 0; j < nc && eq; j++)
+            eq = tr[(size_t)(L.Px + j) * n + row] == tr[(size_t)(L.Rx + j) * n + row] && tr[(size_t)(L.Py + j) * n + row] == tr[(size_t)(L.Ry + j) * n + row];
+        if (g_forge & 4) eq = 0;                                             /* the forger claims the chord */
+    } else {
+        eqc = tr[(size_t)L.bit * n + row - 1] != 0;
+        for (int j = 0; j < nc && eqc; j++)
+            eqc = tr[(size_t)(L.Px + j) * n + row - 1] == tr[(size_t)(L.Rx + j) * n + row - 1] &&
+                  tr[(size_t)(L.Py + j) * n + row - 1] == tr[(size_t)(L.Ry + j) * n + row - 1];
+        if (g_forge & 4) eqc = 0;
+    }
+    const int bit = tr[(size_t)L.bit * n + row] != 0, u = bit && !eq;
+    put(tr, n, lay[3], row, (uint64_t)eq); put(tr, n, lay[4], row, (uint64_t)u); put(tr, n, lay[5], row, (uint64_t)eqc);
+    if ((row & 1) == 0 && u) {
         int j;
         for (j = 0; j < nc; j++)
             if (tr[(size_t)(L.Px + j) * n + row] != tr[(size_t)(L.Rx + j) * n + row]) break;
-        if (j == nc) return (g_forge & 4) ? 0 : -31;                         /* R.x = P.x where the addition is used: no witness */
+        if (j == nc) return (g_forge & 4) ? 0 : -31;                         /* R.x = P.x, R.y != P.y where the addition is used: R = -P */
         put(tr, n, lay[0] + j, row, gl_inv(gl_sub(tr[(size_t)(L.Px + j) * n + row], tr[(size_t)(L.Rx + j) * n + row])));
     }
     return 0;

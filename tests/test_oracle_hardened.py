@@ -3,8 +3,9 @@
 The plain chord rule  lam (Px - Rx) = Py - Ry  says nothing where the accumulator meets the running power (R = P: 0 lam = 0 for EVERY
 lam), so for a crafted record (offset a small multiple of x) a cheating prover can walk on from a point of its choosing.  The test
 below BUILDS that forgery through the oracle's test hook and shows both halves: the plain AIR's verifier accepts the false statement,
-the hardened AIR has no witness for it.  What the variant adds: x3 canonical (T3 = p - 1 - x3 with a borrow chain) and, on add rows,
-sum_j (Px_j - Rx_j) nz_j = bit."""
+the hardened AIR has no witness for it -- and PROVES the true statement instead (R = P is a case of the variant: a flag eq, the sum
+taken from the next row's double).  What the variant adds: x3 canonical (T3 = p - 1 - x3 with a borrow chain), eq / u / eqc, and on add
+rows sum_j (Px_j - Rx_j) nz_j = u = bit (1 - eq)."""
 import ctypes as C
 import re
 import os
@@ -27,8 +28,8 @@ def ios4():
 
 def hard_layout(name):
     txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
-    m = re.search(r"ORC_HARD_LAYOUT_%s\[3\] = \{([^}]*)\}" % name, txt)
-    return [int(x) for x in m.group(1).split(",")]
+    m = re.search(r"ORC_HARD_LAYOUT_%s\[6\] = \{([^}]*)\}" % name, txt)
+    return [int(x) for x in m.group(1).split(",")]        # nz, cb, T3, eq, u, eqc
 
 
 @pytest.mark.parametrize("kind", [4, 5])
@@ -39,7 +40,7 @@ def test_rows_hold_and_the_plain_columns_are_unchanged(ios4, kind):
     n = 1 << t.log_n
     assert all(t.check_row(r) == -1 for r in range(0, n, 7))
     a, b = t.array(), plain.array()
-    nz, cb, t3 = hard_layout("G%dH_U8" % (kind - 3))
+    nz, cb, t3, eq, u, eqc = hard_layout("G%dH_U8" % (kind - 3))
     # the plain AIR's unchecked cells, then (shifted by the new unchecked columns) its checked cells, are the same values
     ub = plain.air.checked_base
     assert (a[:ub] == b[:ub]).all()
@@ -56,14 +57,15 @@ def test_rows_hold_and_the_plain_columns_are_unchanged(ios4, kind):
 def test_mutations_of_the_new_cells_break_a_row(ios4, kind):
     t = _oracle.Trace(kind, ios4[kind - 4])
     arr = t.array()
-    nz, cb, t3 = hard_layout("G%dH_U8" % (kind - 3))
+    nz, cb, t3, eq, u, eqc = hard_layout("G%dH_U8" % (kind - 3))
     nc = 16 * (kind - 3)
     bit = arr[1 + 4 * nc]
     add_used = int(np.argwhere((np.arange(arr.shape[1]) % 2 == 0) & (bit == 1))[3][0])
     add_unused = int(np.argwhere((np.arange(arr.shape[1]) % 2 == 0) & (bit == 0))[3][0])
     j = int(np.argwhere(arr[nz: nz + nc, add_used] != 0)[0][0])
     for col, row in ((nz + j, add_used), (nz + (j + 1) % nc, add_used), (nz, add_unused), (cb + 3, 5), (cb + 14, 6), (t3 + 9, 5), (t3, 512),
-                     (t3 + 2 * nc - 1, 7)):
+                     (t3 + 2 * nc - 1, 7), (eq, add_used), (eq, add_unused), (u, add_used), (u, add_unused), (u, 7), (eqc, add_used + 1),
+                     (eqc, 511)):
         old = int(arr[col, row])
         arr[col, row] = old ^ 1
         assert t.check_row(row) != -1, (col, row)
@@ -91,7 +93,7 @@ def test_proof_verifies_and_is_bound_to_its_kind(ios4, kind):
     assert _oracle.stark_verify(other) != 0
 
 
-def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_impossible_in_the_hardened_one():
+def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_the_hardened_one_proves_the_truth_instead():
     L = _oracle.load()
     L.orc_test_forge.argtypes = [C.c_int]
     x = bn.g1_mul(bn.G1, 77)
@@ -107,12 +109,54 @@ def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_impossibl
         assert _oracle.stark_verify(pf) == 0              # THE HOLE: a verified proof ...
         claimed = [int(v) for v in pf[-2 * 56:][40:56]]
         assert claimed != bn.g1_to_u32(bn.g1_mul(x, 4))   # ... of a false statement (out != offset + [3] x)
-        # the hardened AIR: the forger finds no inequality witness; writing zeros breaks the add row
+        # the hardened AIR: the forger (who claims the chord: eq = 0) finds no inequality witness; writing zeros breaks the add row
         hard = _oracle.Trace(4, rec)
         assert hard.check_row(0) != -1
         pfh = _oracle.stark_prove_trace(hard)
         assert _oracle.stark_verify(pfh) != 0
     finally:
         L.orc_test_forge(0)
+    # ... while its honest generator PROVES the record: R = P is a case of the hardened AIR (eq = 1: the sum is the next row's double)
+    good = _oracle.Trace(4, rec)
+    assert all(good.check_row(r) == -1 for r in range(1024))
+    nz, cb, t3, eq, u, eqc = hard_layout("G1H_U8")
+    arr = good.array()
+    # offset = x, e = 3: R = P = x, then R = P = 2 x (bit 1 set again), then R = P = 4 x with bit 2 clear: the flag three times, the
+    # double handed over twice
+    assert [int(arr[eq, r]) for r in range(8)] == [1, 0, 1, 0, 1, 0, 0, 0] and [int(arr[eqc, r]) for r in range(8)] == [0, 1, 0, 1, 0, 0, 0, 0]
+    assert not arr[u, :8].any()
+    pf = _oracle.stark_prove(4, rec)
+    assert _oracle.stark_verify(pf) == 0
+    assert [int(v) for v in pf[-2 * 56:][40:56]] == bn.g1_to_u32(bn.g1_mul(x, 4))                         # out = offset + [3] x = 4 x
+    # the flag cannot be dropped (the chord has no witness) nor claimed where R != P
+    arr[eq, 0], arr[u, 0] = 0, 1
+    assert good.check_row(0) != -1
+    arr[eq, 0], arr[u, 0] = 1, 0
+    arr[eq, 6] = 1                                        # row 6: R = 4 x, P = 8 x
+    assert good.check_row(6) != -1
+    arr[eq, 6] = 0
+    # what stays unprovable in both variants: the accumulator meets MINUS the running power (the sum is the point at infinity)
+    neg = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(bn.g1_neg(x)) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 2))], dtype=np.uint32)
+    for kind in (0, 4):
+        with pytest.raises(RuntimeError):
+            _oracle.Trace(kind, neg)
+
+
+def test_more_records_that_meet_the_running_power_are_proved_by_the_hardened_air_only():
+    """offset = [2^i - (e mod 2^i)] x with bit i of e set: the accumulator equals the running power on add row i"""
+    x = bn.g1_mul(bn.G1, 1234567)
+    recs = []
+    for e, i in ((0b1101, 2), (0b10001, 4), ((1 << 40) | 5, 40)):
+        k = (1 << i) - (e % (1 << i))
+        assert (e >> i) & 1
+        recs.append(bn.g1_to_u32(x) + bn.g1_to_u32(bn.g1_mul(x, k)) + sn.exp_to_u32(e) + bn.g1_to_u32(bn.g1_mul(x, (k + e) % bn.R)))
+    recs = np.array(recs, dtype=np.uint32)
     with pytest.raises(RuntimeError):
-        _oracle.Trace(4, rec)                             # and its honest generator refuses the record like the plain one
+        _oracle.Trace(0, recs)
+    t = _oracle.Trace(4, recs)
+    nz, cb, t3, eq, u, eqc = hard_layout("G1H_U8")
+    arr = t.array()
+    for io, (e, i) in enumerate(((0b1101, 2), (0b10001, 4), ((1 << 40) | 5, 40))):
+        assert int(arr[eq, 512 * io + 2 * i]) == 1 and int(arr[eqc, 512 * io + 2 * i + 1]) == 1
+    assert all(t.check_row(r) == -1 for r in range(0, 1 << t.log_n, 1))
+    assert _oracle.stark_verify(_oracle.stark_prove(4, recs)) == 0

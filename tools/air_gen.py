@@ -218,11 +218,13 @@ def exponent_logic(a):
         a.poly([(1, [X(e + i)]), (-1, [L(e + i)]), (-1, [PER(PER_LIMB_END), X(e + i)]), (1, [PER(PER_LIMB_END), L(e + i)])])
 
 
-def state_transition(a, state, result, upd_on_add, nl):
+def state_transition(a, state, result, upd_on_add, nl, use=None, late=None):
     """state/result: column names of nl 16-bit limbs (state unchecked, result checked).
     upd_on_add: True  -> accumulator: add rows: s' = bit ? res : s ; double rows (not last): s' = s
-                False -> running power: add rows: s' = s ; double rows (not last): s' = res"""
-    bit = a.col("bit")
+                False -> running power: add rows: s' = s ; double rows (not last): s' = res
+    hardened accumulator: `use` = the column that takes the place of bit on add rows (u = bit (1 - eq)); `late` = the column eqc
+    with which a double row hands ITS result to the accumulator: s' = eqc ? res : s  (the sum R + P for R = P is the double 2 P)"""
+    bit = a.col("bit") if use is None else use
     for i in range(nl):
         s = a.col(state) + i
         res = a.limb_expr(result, i, True)
@@ -232,8 +234,14 @@ def state_transition(a, state, result, upd_on_add, nl):
             m += [(-c, [PER(PER_ADD), L(bit), L(cc)]) for c, cc in res]
             a.poly(m)
             # (1 - per_add - per_last) * (s' - s) = 0     (double rows except the block's last row)
-            a.poly([(1, [X(s)]), (-1, [L(s)]), (-1, [PER(PER_ADD), X(s)]), (1, [PER(PER_ADD), L(s)]),
-                    (-1, [PER(PER_LAST), X(s)]), (1, [PER(PER_LAST), L(s)])])
+            m = [(1, [X(s)]), (-1, [L(s)]), (-1, [PER(PER_ADD), X(s)]), (1, [PER(PER_ADD), L(s)]),
+                 (-1, [PER(PER_LAST), X(s)]), (1, [PER(PER_LAST), L(s)])]
+            if late is not None:
+                # ... - (1 - per_add - per_last) * eqc * (res - s)
+                m += [(1, [L(late), L(s)]), (-1, [PER(PER_ADD), L(late), L(s)]), (-1, [PER(PER_LAST), L(late), L(s)])]
+                for c, cc in res:
+                    m += [(-c, [L(late), L(cc)]), (c, [PER(PER_ADD), L(late), L(cc)]), (c, [PER(PER_LAST), L(late), L(cc)])]
+            a.poly(m)
         else:
             a.poly([(1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_ADD), L(s)])])
             m = [(1, [X(s)]), (-1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_LAST), X(s)])]
@@ -307,6 +315,7 @@ def build_curve(name, mode, ext, hardened=False):
     if hardened:                       # after everything else: the columns of the plain AIR keep their positions
         a.alloc("nz", nc)
         a.alloc("cb", (NL - 1) * ext)
+        a.alloc("eq", 1); a.alloc("u", 1); a.alloc("eqc", 1)
         a.alloc_checked("T3", nc * a.cpl)
     a.finalize_columns()
 
@@ -350,8 +359,12 @@ def build_curve(name, mode, ext, hardened=False):
         a.gadget("y3%d" % c, t[c], lins, bound)
     a.emit_gadgets()
     exponent_logic(a)
-    state_transition(a, "Rx", "X3", True, nc)
-    state_transition(a, "Ry", "Y3", True, nc)
+    if hardened:
+        state_transition(a, "Rx", "X3", True, nc, use=a.col("u"), late=a.col("eqc"))
+        state_transition(a, "Ry", "Y3", True, nc, use=a.col("u"), late=a.col("eqc"))
+    else:
+        state_transition(a, "Rx", "X3", True, nc)
+        state_transition(a, "Ry", "Y3", True, nc)
     state_transition(a, "Px", "X3", False, nc)
     state_transition(a, "Py", "Y3", False, nc)
     w = 8 * ext
@@ -375,11 +388,24 @@ def build_curve(name, mode, ext, hardened=False):
             for i in range(NL - 1):
                 b = a.col("cb") + (NL - 1) * c + i
                 a.poly([(1, [L(b), L(b)]), (-1, [L(b)])])
-        m = [(-1, [PER(PER_ADD), L(bit)])]
+        # eq = 1: the accumulator IS the running power (all limbs of x and y equal; both canonical for honest provers, and a prover that
+        # cannot set eq has to find the inequality witness below); u = bit (1 - eq): the chord result is taken
+        eq, u, eqc = a.col("eq"), a.col("u"), a.col("eqc")
+        a.poly([(1, [L(eq), L(eq)]), (-1, [L(eq)])])
+        for j in range(nc):
+            a.poly([(1, [L(eq), L(a.col("Px") + j)]), (-1, [L(eq), L(a.col("Rx") + j)])])
+            a.poly([(1, [L(eq), L(a.col("Py") + j)]), (-1, [L(eq), L(a.col("Ry") + j)])])
+        a.poly([(1, [L(u)]), (-1, [L(bit)]), (1, [L(bit), L(eq)])])
+        # where the chord result is taken the x's differ in a limb: sum_j (Px_j - Rx_j) nz_j = u on add rows
+        m = [(-1, [PER(PER_ADD), L(u)])]
         for j in range(nc):
             m += [(1, [PER(PER_ADD), L(a.col("Px") + j), L(a.col("nz") + j)]), (-1, [PER(PER_ADD), L(a.col("Rx") + j), L(a.col("nz") + j)])]
         a.poly(m)
-        a.layout = [a.col("nz"), a.col("cb"), a.col("T3")]
+        # R = P with the bit set: the sum is the double the NEXT row computes: eqc (on that row) = bit eq (of this one); never on a
+        # block's last row (no row left to hand the result over)
+        a.poly([(1, [PER(PER_ADD), X(eqc)]), (-1, [PER(PER_ADD), L(bit), L(eq)])])
+        a.poly([(1, [PER(PER_LAST), L(eqc)])])
+        a.layout = [a.col("nz"), a.col("cb"), a.col("T3"), eq, u, eqc]
     a.primary = dict(kind="curve", ext=ext)
     return a
 
@@ -749,8 +775,8 @@ def main():
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
                 if a.hardened:
-                    f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3) */\n" % a.name)
-                    f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[3] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
+                    f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3), eq, u, eqc */\n" % a.name)
+                    f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[6] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
