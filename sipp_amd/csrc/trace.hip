@@ -408,14 +408,30 @@ struct CurveCols {
 };
 
 // one lane per row: affine coordinates, slope and result of the row's group operation
+// the same point in Jacobian coordinates (neither at infinity): X1 Z2^2 = X2 Z1^2 and Y1 Z2^3 = Y2 Z1^3
+template <int EXT>
+__device__ __forceinline__ bool jac_same(const Jac<EXT>& p, const Jac<EXT>& q) {
+    using F = Fld<EXT>;
+    const auto z1 = F::sqr(p.z), z2 = F::sqr(q.z);
+    if (!F::is_zero(F::sub(F::mul(p.x, z2), F::mul(q.x, z1)))) return false;
+    return F::is_zero(F::sub(F::mul(p.y, F::mul(z2, q.z)), F::mul(q.y, F::mul(z1, p.z))));
+}
+
+// hard != 0: the hardened AIR (API kinds 4 / 5): where the accumulator IS the running power on an add row (R = P) the row gets slope 0
+// instead of SIPP_E_WITNESS (its result is not used: flag eq), and the double row after it still shows the OLD accumulator -- the
+// sum, which is that row's own double, is handed over at the row's end (eqc); see tools/air_gen.py::build_curve
 template <int EXT>
 __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __restrict__ rows, uint64_t* __restrict__ tr,
-                                                        size_t n, CurveCols c, int* __restrict__ err) {
+                                                        size_t n, CurveCols c, int hard, int* __restrict__ err) {
     using F = Fld<EXT>;
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     RowPts<EXT> rp = rows[row];
     const bool is_add = (row & 1) == 0;
+    if (hard && !is_add) {
+        const RowPts<EXT> prev = rows[row - 1];
+        if (!jac_is_inf<EXT>(prev.R) && !jac_is_inf<EXT>(prev.P) && jac_same<EXT>(prev.R, prev.P)) rp.R = prev.R;
+    }
     // affine: x = X / Z^2, y = Y / Z^3 ; one inversion for both points
     auto zz = F::mul(rp.R.z, rp.P.z);
     if (F::is_zero(zz)) {
@@ -442,11 +458,12 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
         ya = py;
         xb = px;
     }
-    if (F::is_zero(den)) {
+    const bool same = hard && is_add && F::is_zero(den) && F::is_zero(num);   // R = P: a case of the hardened AIR
+    if (F::is_zero(den) && !same) {
         atomicExch(err, SIPP_E_WITNESS);
         return;
     }
-    auto lam = F::mul(num, F::inv(den));
+    auto lam = same ? F::sub(num, num) : F::mul(num, F::inv(den));
     auto x3 = F::sub(F::sub(F::mul(lam, lam), xa), xb);
     auto y3 = F::sub(F::mul(lam, F::sub(xa, x3)), ya);
     store_f_u16<EXT>(tr, n, c.Rx, row, rx);
@@ -662,8 +679,8 @@ struct SippBnP {
 // witness that R.x and P.x differ in a limb: nz_j = 1 / (Px_j - Rx_j) in the Goldilocks field at the first such limb.  Reads cells
 // written by curve_rows_kernel and exp_rows_kernel; one lane per row, integer work only.
 __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__ tr, size_t n, int ext, int cpl, int col_rx, int col_px,
-                                                         int col_bit, int col_x3, int col_nz, int col_cb, int col_t3, SippBnP pl,
-                                                         int* __restrict__ err) {
+                                                         int col_bit, int col_x3, int col_nz, int col_cb, int col_t3, int col_eq, int col_u,
+                                                         int col_eqc, SippBnP pl, int* __restrict__ err) {
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     const int nc = 16 * ext;
@@ -686,9 +703,21 @@ __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__
         }
         bad |= borrow != 0;
     }
+    // eq on an add row: every limb of R (x and y: the Ry cells follow the Rx cells, the Py cells the Px cells) equals P's; on a double
+    // row eqc = bit eq of the add row before it; u = bit (1 - eq)
+    const bool is_add = (row & 1) == 0;
+    const size_t cmp_row = is_add ? row : row - 1;
+    bool all_eq = true;
+    for (int j = 0; j < 2 * nc; j++)
+        all_eq &= tr[(size_t)(col_px + j) * n + cmp_row] == tr[(size_t)(col_rx + j) * n + cmp_row];
+    const bool bit = tr[(size_t)col_bit * n + row] != 0;
+    const bool eq = is_add && all_eq, eqc = !is_add && all_eq && tr[(size_t)col_bit * n + row - 1] != 0;
+    tr[(size_t)col_eq * n + row] = eq ? 1 : 0;
+    tr[(size_t)col_u * n + row] = (bit && !eq) ? 1 : 0;
+    tr[(size_t)col_eqc * n + row] = eqc ? 1 : 0;
     int first = -1;
     uint64_t dpx = 0, drx = 0;
-    const bool used = (row & 1) == 0 && tr[(size_t)col_bit * n + row] != 0;
+    const bool used = is_add && bit && !eq;
     for (int j = 0; j < nc; j++) {
         const uint64_t px = tr[(size_t)(col_px + j) * n + row], rx = tr[(size_t)(col_rx + j) * n + row];
         if (first < 0 && px != rx) {
@@ -699,7 +728,7 @@ __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__
     }
     const uint64_t w = (used && first >= 0) ? gl::inv(gl::sub(dpx, drx)) : 0;
     for (int j = 0; j < nc; j++) tr[(size_t)(col_nz + j) * n + row] = (used && j == first) ? w : 0;
-    bad |= used && first < 0;    // R.x = P.x where the addition is used: no witness (the plain chain refused the record already)
+    bad |= used && first < 0;    // R.x = P.x, R.y != P.y where the addition is used (R = -P): no witness (curve_rows refused it already)
     if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
 
@@ -1164,7 +1193,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<1>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
-                               d_trace, n, c, d_err);
+                               d_trace, n, c, a->hardened, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         } else {
             RowPts<2>* rows = arena_alloc_t<RowPts<2>>(ctx, n);
@@ -1185,7 +1214,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<2>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
-                               d_trace, n, c, d_err);
+                               d_trace, n, c, a->hardened, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         }
     }
@@ -1221,7 +1250,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         for (int i = 0; i < 16; i++) pl.l[i] = SIPP_BN_P_LIMBS[i];
         ProfScope ps(ctx, "trace_harden");
         hipLaunchKernelGGL(harden_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n, ext, cpl, 1,
-                           1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], pl, d_err);
+                           1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], pl, d_err);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
     {

@@ -1,6 +1,6 @@
 """The hardened G1 / G2 exponentiation AIRs (API kinds 4 / 5) on the GPU against the oracle: trace cell for cell, proof word for word
-(u8 variant, n = 4), the u16 variant at the n = 128 size through the oracle's verifier, and the crafted record of
-tests/test_oracle_hardened.py refused."""
+(u8 variant, n = 4), the u16 variant at the n = 128 size through the oracle's verifier, and the crafted records of
+tests/test_oracle_hardened.py: refused by the plain kinds, proved by the hardened ones."""
 import numpy as np
 import pytest
 
@@ -49,7 +49,7 @@ def test_u16_variant_at_the_n128_size_verifies(kind):
     ios = d[("g1", "g2")[kind - 4]]
     c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(kind, ios.shape[0]))
     try:
-        assert c.shape(kind, ios.shape[0]) == ((16, 723, 410, 4), (16, 1436, 820, 4))[kind - 4]
+        assert c.shape(kind, ios.shape[0]) == ((16, 726, 410, 4), (16, 1439, 820, 4))[kind - 4]
         pf = c.prove(kind, ios)
     finally:
         c.close()
@@ -58,13 +58,36 @@ def test_u16_variant_at_the_n128_size_verifies(kind):
     assert (pf[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])[: ios.shape[0]] == ios).all()
 
 
-def test_the_crafted_record_is_refused(ctx):
+def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
+    """offset = [2^i - (e mod 2^i)] x with bit i of e set (the accumulator equals the running power on add row i), G1 and G2: the plain
+    kinds return SIPP_E_WITNESS, the hardened kinds prove them -- trace and proof equal to the oracle's; R = -P is refused by both"""
     import sipp_amd
+    from sipp_amd._lib import to_host
     from oracle.py import bn254 as bn
     from oracle.py import sipp_native as sn
-    x = bn.g1_mul(bn.G1, 77)
-    rec = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(x) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 4))] * 2, dtype=np.uint32)
+    cases = ((3, 0), (0b1101, 2), ((1 << 40) | 5, 40))
+    x1, x2 = bn.g1_mul(bn.G1, 1234567), bn.g2_mul(bn.G2, 7654321)
+    g1, g2 = [], []
+    for e, i in cases:
+        k = (1 << i) - (e % (1 << i))
+        g1.append(bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_mul(x1, k)) + sn.exp_to_u32(e) + bn.g1_to_u32(bn.g1_mul(x1, (k + e) % bn.R)))
+        g2.append(bn.g2_to_u32(x2) + bn.g2_to_u32(bn.g2_mul(x2, k)) + sn.exp_to_u32(e) + bn.g2_to_u32(bn.g2_mul(x2, (k + e) % bn.R)))
+    for base, recs in ((0, np.array(g1, dtype=np.uint32)), (1, np.array(g2, dtype=np.uint32))):
+        with pytest.raises(sipp_amd.SippError) as e:
+            ctx.prove(base, recs)
+        assert e.value.code == -8
+        # the outputs alone come from the complete scan: right for these records in either kind
+        assert (ctx.exp_outputs(base + 4, recs) == recs).all()
+        ref = _oracle.Trace(base + 4, recs)
+        got = to_host(ctx.trace_build(base + 4, recs))
+        want = ref.array()
+        if not (got == want).all():
+            bad = np.argwhere(got != want)
+            raise AssertionError("kind %d: %d cells differ; first (col,row): %s" % (base + 4, len(bad), bad[:8].tolist()))
+        pf = ctx.prove(base + 4, recs)
+        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _oracle.stark_verify(pf) == 0
+    neg = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x1, 2))] * 2, dtype=np.uint32)
     for kind in (0, 4):
         with pytest.raises(sipp_amd.SippError) as e:
-            ctx.prove(kind, rec)
+            ctx.prove(kind, neg)
         assert e.value.code == -8

@@ -294,8 +294,11 @@ def build_curve(name, mode, ext, hardened=False):
     the accumulator meets the running power, R = P): the variant adds, per row,
        * x3 CANONICAL: T3 = p - 1 - x3 as range-checked limbs with a boolean borrow chain (so the limbs of R.x and P.x, which are
          copies of earlier x3's or public inputs, are THE limbs of their values), and
-       * on add rows  sum_j (Px_j - Rx_j) nz_j = bit  with free cells nz_j: where the addition is USED (bit = 1) the two x's differ in a
-         limb, hence mod p -- the slope is then determined, and a proof exists exactly for the records the plain chain proves."""
+       * a flag eq on add rows ("R IS P": every limb of x and y equal), u = bit (1 - eq) in the place of the bit in the accumulator's
+         transition, and  sum_j (Px_j - Rx_j) nz_j = u  with free cells nz_j: where the chord result is USED the two x's differ in a limb,
+         hence mod p, and the slope is determined;
+       * eqc on the double row after an add row with bit eq = 1: that row's own result (2 P = R + P) goes to the accumulator.
+    Unprovable in both variants: R = -P on an add row (the partial sum is the point at infinity)."""
     a = Air(name + ("h" if hardened else ""), mode)
     a.hardened = 1 if hardened else 0
     a.gadgets = []
