@@ -389,31 +389,23 @@ def main():
             out["map_to_g2"] = {"error": repr(e)}
         # secondary, outside the timed region: the same instance with the HARDENED G1 / G2 AIRs (kinds 4 / 5, DESIGN.md section 1:
         # canonical x3 + x-inequality witness, +11 % columns) -- the price of closing the exceptional-addition case, stated next to
-        # the headline that keeps the plain AIR.  Three ctxs of their own, the three proofs started together (sipp_prove_async).
+        # the headline that keeps the plain AIR.  Three ctxs of their own with sipp_ctx_set_hardened, through sipp_instance_prove.
         try:
             if os.environ.get("SIPP_BENCH_HARDENED", "1") in ("0", ""):
                 raise RuntimeError("skipped (SIPP_BENCH_HARDENED=0)")
-            hk = (4, 5, 2)
-            hctx = [sipp_amd.Ctx(device=local_rank, workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(k, ios[i].shape[0])) for i, k in enumerate(hk)]
+            hinst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios, hardened=True)
             try:
-                for c, lvl in zip(hctx, (-1, 0, 1)):
-                    c._ck(c.L.sipp_ctx_set_stream_priority(c.h, lvl), "set_stream_priority")
-                def hstep():
-                    for c, k, a in zip(hctx, hk, ios):
-                        c.prove_async(k, a)
-                    return [c.wait() for c in hctx]
-                hstep()
+                hinst.prove(ios)
                 t = time.perf_counter()
-                for _ in range(5):
-                    hp = hstep()
-                t_h = (time.perf_counter() - t) / 5
-                out["hardened_instance"] = {"kinds": list(hk), "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
-                                            "columns": [list(hctx[i].shape(hk[i], ios[i].shape[0])) for i in range(3)],
+                for _ in range(10):
+                    hp = hinst.prove(ios)
+                t_h = (time.perf_counter() - t) / 10
+                out["hardened_instance"] = {"kinds": [int(x[1]) for x in hp], "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
+                                            "columns": [list(hinst.ctxs[i].shape(i, ios[i].shape[0])) for i in range(3)],
                                             "proof_words": [int(len(x)) for x in hp],
-                                            "note": "no start gate (three independent sipp_prove_async): compare with ms_per_step"}
+                                            "entry_point": "sipp_instance_prove on ctxs with sipp_ctx_set_hardened"}
             finally:
-                for c in hctx:
-                    c.close()
+                hinst.close()
         except Exception as e:                  # noqa: BLE001
             out["hardened_instance"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:

@@ -94,6 +94,11 @@ void sipp_ctx_destroy(sipp_ctx *ctx);
  * an instance on three ctxs, G1 low / G2 normal / Fq12 high measured best.  Only while no proof is
  * in flight on the ctx.  (SIPP_STREAM_PRIORITY=high|low in the environment sets the initial priority at sipp_ctx_create.) */
 int sipp_ctx_set_stream_priority(sipp_ctx *ctx, int level);
+/* on != 0: on this ctx the kinds SIPP_G1_EXP / SIPP_G2_EXP mean the HARDENED AIRs (SIPP_G1_EXP_HARDENED / SIPP_G2_EXP_HARDENED below) in
+ * every call that takes the ctx -- sipp_g1_exp_prove, sipp_prove_async, sipp_instance_prove, sipp_instances_prove, sipp_proof_size,
+ * sipp_stark_shape, sipp_trace_build; the proof's header carries kind 4 / 5.  Size the arena with sipp_workspace_bytes(kind + 4, ..)
+ * (that function takes no ctx).  Only while no proof is in flight on the ctx. */
+int sipp_ctx_set_hardened(sipp_ctx *ctx, int on);
 const char *sipp_last_error(const sipp_ctx *ctx);
 int sipp_sync(sipp_ctx *ctx);
 /* the hipStream_t every launch of this ctx goes to (as void*) */

@@ -93,6 +93,8 @@ extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
     pub fn sipp_ctx_create(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, workspace_bytes: usize) -> c_int;
     pub fn sipp_ctx_destroy(ctx: *mut SippCtxOpaque);
+    /// kinds 0 / 1 on this ctx mean the hardened G1 / G2 AIRs (kinds 4 / 5)
+    pub fn sipp_ctx_set_hardened(ctx: *mut SippCtxOpaque, on: c_int) -> c_int;
     pub fn sipp_ctx_set_stream_priority(ctx: *mut SippCtxOpaque, level: c_int) -> c_int;
     pub fn sipp_last_error(ctx: *const SippCtxOpaque) -> *const c_char;
     pub fn sipp_sync(ctx: *mut SippCtxOpaque) -> c_int;

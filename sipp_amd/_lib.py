@@ -71,6 +71,7 @@ SIGNATURES = {
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_map_to_g2_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_prove": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_ctx_set_hardened": (C.c_int, [vp, C.c_int]),
     "sipp_map_to_g2": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
     "sipp_prove_async": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
     "sipp_wait": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
@@ -449,13 +450,17 @@ class Instance:
     (level L-B).  `priorities`: stream priority per kind ("high" / "low" / "" = normal); G1 low / G2 normal / Fq12 high
     measured best with the start gate of sipp_instance_prove (69.3 vs 71.2 ms per n = 128 instance for low / high / high)."""
 
-    def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "", "high")):
+    def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "", "high"), hardened=False):
+        """hardened: G1 / G2 with the hardened AIRs (kinds 4 / 5 in the proofs' headers; sipp_ctx_set_hardened)"""
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
         self.ctxs = []
         level = {"low": -1, "": 0, "normal": 0, "high": 1}
         for k in range(3):
-            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(k, max(1, self.num_io[k])))
+            wk = k + 4 if (hardened and k < 2) else k
+            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(wk, max(1, self.num_io[k])))
+            if hardened:
+                c._ck(self.L.sipp_ctx_set_hardened(c.h, 1), "set_hardened")
             c._ck(self.L.sipp_ctx_set_stream_priority(c.h, level[priorities[k]]), "set_stream_priority")
             self.ctxs.append(c)
         self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) if self.num_io[k] else 0 for k in range(3)]

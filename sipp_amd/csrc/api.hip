@@ -97,6 +97,17 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     delete ctx;
 }
 
+int sipp_ctx_set_hardened(sipp_ctx* ctx, int on) {
+    if (!ctx) return SIPP_E_BADARG;
+    std::unique_lock<std::mutex> lk(ctx->async.mu);
+    if (ctx->async.has_job) {
+        lk.unlock();
+        return sipp_fail(ctx, SIPP_E_BADARG, "set_hardened: a proof is in flight on this ctx");
+    }
+    ctx->hardened = on != 0;
+    return SIPP_OK;
+}
+
 int sipp_ctx_set_stream_priority(sipp_ctx* ctx, int level) {
     if (!ctx) return SIPP_E_BADARG;
     {

@@ -92,6 +92,8 @@ struct sipp_ctx {
 
     // sipp_exp_outputs: sipp_trace_fill stops after the accumulator chains and writes the outputs into the records
     bool outputs_only = false;
+    // sipp_ctx_set_hardened: kinds 0 / 1 on this ctx mean the hardened G1 / G2 AIRs (kinds 4 / 5)
+    bool hardened = false;
 
     // sipp_prove_async / sipp_wait: one worker thread per ctx, started on first use, one job at a time
     struct Async {

@@ -19,6 +19,10 @@
 static const int IO_WORDS[6] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS, SIPP_MAP_G2_IO_WORDS, SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS};
 // the hardened G1 / G2 kinds take the records of the plain ones
 static inline int base_kind(int kind) { return kind >= SIPP_G1_EXP_HARDENED ? kind - SIPP_G1_EXP_HARDENED : kind; }
+// sipp_ctx_set_hardened: on such a ctx the plain G1 / G2 kinds stand for the hardened ones (every entry point that takes a ctx)
+static inline int ctx_kind(const sipp_ctx* ctx, int kind) {
+    return (ctx && ctx->hardened && (kind == SIPP_G1_EXP || kind == SIPP_G2_EXP)) ? kind + SIPP_G1_EXP_HARDENED : kind;
+}
 #define SIPP_MAGIC 0x5349505053544b31ULL /* "SIPPSTK1" */
 
 struct Shape {
@@ -259,6 +263,7 @@ struct Oracle3 {
 static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io_in, uint64_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     if (!ctx || !ios || !proof_out || !proof_len) return SIPP_E_BADARG;
+    kind = ctx_kind(ctx, kind);
     struct GateGuard {  // whatever happens below, a proof waiting on this one is let go
         sipp_ctx* c;
         ~GateGuard() {
@@ -541,7 +546,7 @@ extern "C" {
 
 int sipp_stark_shape(const sipp_ctx* ctx, int kind, size_t num_io, uint32_t* log_rows, uint32_t* main_cols,
                      uint32_t* perm_cols, uint32_t* quotient_cols) {
-    (void)ctx;
+    kind = ctx_kind(ctx, kind);
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
     if (log_rows) *log_rows = s.log_n;
@@ -581,6 +586,7 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
 }
 
 size_t sipp_proof_size(const sipp_ctx* ctx, int kind, size_t num_io) {
+    kind = ctx_kind(ctx, kind);
     Shape s;
     if (!ctx || shape_of(kind, num_io, &s) != SIPP_OK) return 0;
     return proof_words(ctx->cfg, s);
@@ -588,6 +594,7 @@ size_t sipp_proof_size(const sipp_ctx* ctx, int kind, size_t num_io) {
 
 int sipp_trace_build(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* d_trace) {
     if (!ctx || !ios || !d_trace) return SIPP_E_BADARG;
+    kind = ctx_kind(ctx, kind);
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));

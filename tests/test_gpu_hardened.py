@@ -91,3 +91,26 @@ def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
         with pytest.raises(sipp_amd.SippError) as e:
             ctx.prove(kind, neg)
         assert e.value.code == -8
+
+
+def test_hardened_ctx_flag_through_the_instance_entry_point(ctx, ios4):
+    """sipp_ctx_set_hardened: kinds 0 / 1 on such a ctx mean 4 / 5 in every entry point -- sipp_instance_prove gives the proofs
+    sipp_prove(4 / 5) gives, Fq12 is untouched, and the flag can be taken back"""
+    import sipp_amd
+    d = np.load("tests/golden/sipp_n4_ios.npz")
+    ios = [d[k] for k in ("g1", "g2", "fq12")]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios], hardened=True)
+    try:
+        proofs = [p.copy() for p in inst.prove(ios)]
+        assert [int(p[1]) for p in proofs] == [4, 5, 2]
+        assert inst.ctxs[0].shape(0, ios[0].shape[0]) == ctx.shape(4, ios[0].shape[0])
+        c0 = inst.ctxs[0]
+        c0._ck(c0.L.sipp_ctx_set_hardened(c0.h, 0), "set_hardened")
+        plain = c0.prove(0, ios[0])
+        assert int(plain[1]) == 0 and (plain == ctx.prove(0, ios[0])).all()
+    finally:
+        inst.close()
+    for k in (0, 1):
+        assert (proofs[k] == ctx.prove(k + 4, ios[k])).all()
+    assert (proofs[2] == ctx.prove(2, ios[2])).all()
+    assert all(_oracle.stark_verify(p) == 0 for p in proofs)
