@@ -497,10 +497,10 @@ class InstanceQueue:
     """sipp_instances_prove: `in_flight` slots of three ctxs on one device; prove(list of [g1, g2, fq12]) proves every instance of
     the list, `in_flight` at a time, and returns their proofs (copies)."""
 
-    def __init__(self, num_io, in_flight=3, device=0, priorities=("low", "", "high")):
+    def __init__(self, num_io, in_flight=3, device=0, priorities=("low", "", "high"), hardened=False):
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
-        self.slots = [Instance(self.num_io, devices=(device,) * 3, priorities=priorities) for _ in range(in_flight)]
+        self.slots = [Instance(self.num_io, devices=(device,) * 3, priorities=priorities, hardened=hardened) for _ in range(in_flight)]
 
     def prove(self, instances):
         count, F = len(instances), len(self.slots)

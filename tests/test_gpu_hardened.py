@@ -114,3 +114,19 @@ def test_hardened_ctx_flag_through_the_instance_entry_point(ctx, ios4):
         assert (proofs[k] == ctx.prove(k + 4, ios[k])).all()
     assert (proofs[2] == ctx.prove(2, ios[2])).all()
     assert all(_oracle.stark_verify(p) == 0 for p in proofs)
+
+
+def test_hardened_queue(ctx):
+    """sipp_instances_prove over slots whose ctxs carry the hardened flag: every instance's G1 / G2 proofs are the kind 4 / 5 proofs"""
+    import sipp_amd
+    d = np.load("tests/golden/sipp_n4_ios.npz")
+    ios = [d[k] for k in ("g1", "g2", "fq12")]
+    q = sipp_amd.InstanceQueue([a.shape[0] for a in ios], in_flight=2, hardened=True)
+    try:
+        res = q.prove([ios, ios, ios])
+    finally:
+        q.close()
+    want = [ctx.prove(4, ios[0]), ctx.prove(5, ios[1]), ctx.prove(2, ios[2])]
+    for inst in res:
+        for k in range(3):
+            assert (inst[k] == want[k]).all()
