@@ -160,3 +160,22 @@ def test_golden_vectors(ctx):
     recs, _, pts = ctx.map_to_g2(want[:, :16])
     assert (recs == want).all() and (pts == np.array(g["cleared"], dtype=np.uint32)).all()
     assert hashlib.sha256(ctx.prove(3, recs).tobytes()).hexdigest() == g["proof"]["sha256"]
+
+
+def test_gpu_proof_is_accepted_by_the_python_reading_of_the_verifier():
+    """the chain GPU prover -> oracle/py/stark_verify.py, with no C oracle in between (a 3-query configuration: pure-Python hashing)"""
+    import sipp_amd
+    from oracle.py import stark_verify as sv
+    cfg = sipp_amd.default_config()
+    cfg.num_queries, cfg.pow_bits = 3, 6
+    _, words = messages(6, seed=21)
+    c = sipp_amd.Ctx(cfg=cfg, workspace_bytes=2 << 30)
+    try:
+        recs = c.map_to_g2(words, cofactor=False)
+        pf = c.prove(3, recs)
+    finally:
+        c.close()
+    assert sv.verify(pf, dict(num_queries=3, pow_bits=6)) is None
+    bad = pf.copy()
+    bad[16 + 3 * 64 + 2 * 9] = (int(bad[16 + 3 * 64 + 2 * 9]) + 1) % _oracle.P          # an opening at zeta
+    assert sv.verify(bad, dict(num_queries=3, pow_bits=6)) == "quotient identity 0"
