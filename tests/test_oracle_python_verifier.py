@@ -44,7 +44,7 @@ def test_air_tables_parse_like_the_c_structs():
             (a["n_main"], a["checked_base"], a["n_checked"], a["n_aux"], a["pi_per_io"], len(a["prog"]), a["log_rows"], a["hardened"])
 
 
-@pytest.mark.parametrize("kind", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("kind", [0, 3, 5])      # G1 plain, MapToG2, G2 hardened (Fq12 below; G2 plain / G1 hardened share their code paths)
 def test_python_verifier_accepts_c_proofs(ios4, kind):
     cfg, pycfg = small_cfg()
     ios = mapg2_records() if kind == 3 else ios4[kind % 4]
