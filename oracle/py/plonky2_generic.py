@@ -92,9 +92,12 @@ MDS_DIAG = [8] + [0] * 11
 WIDTH, RATE, HALF_FULL, PARTIAL = 12, 8, 4, 22
 
 
+# row r of the matrix is the circulant shifted by r, plus the diagonal:  M[r][c] = CIRC[(c - r) mod 12] + [c = r] DIAG[r]
+MDS_ROWS = [tuple(MDS_CIRC[(c - r) % WIDTH] + (MDS_DIAG[r] if c == r else 0) for c in range(WIDTH)) for r in range(WIDTH)]
+
+
 def _mds(state):
-    # row r of the matrix is the circulant shifted by r, plus the diagonal
-    return [(sum(state[(i + r) % WIDTH] * MDS_CIRC[i] for i in range(WIDTH)) + state[r] * MDS_DIAG[r]) % P for r in range(WIDTH)]
+    return [sum(map(int.__mul__, row, state)) % P for row in MDS_ROWS]
 
 
 def poseidon(state):
