@@ -107,6 +107,11 @@ def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_the_harde
         assert all(forged.check_row(r) == -1 for r in range(0, 1024))
         pf = _oracle.stark_prove_trace(forged)
         assert _oracle.stark_verify(pf) == 0              # THE HOLE: a verified proof ...
+        # ... for the second reading of the verifier too (a 3-query configuration: pure Python): the hole is the AIR's, not a verifier's
+        from oracle.py import stark_verify as sv
+        cfg3 = _oracle.default_config()
+        cfg3.num_queries, cfg3.pow_bits = 3, 6
+        assert sv.verify(_oracle.stark_prove_trace(forged, cfg3), dict(num_queries=3, pow_bits=6)) is None
         claimed = [int(v) for v in pf[-2 * 56:][40:56]]
         assert claimed != bn.g1_to_u32(bn.g1_mul(x, 4))   # ... of a false statement (out != offset + [3] x)
         # the hardened AIR: the forger (who claims the chord: eq = 0) finds no inequality witness; writing zeros breaks the add row
@@ -114,6 +119,7 @@ def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_the_harde
         assert hard.check_row(0) != -1
         pfh = _oracle.stark_prove_trace(hard)
         assert _oracle.stark_verify(pfh) != 0
+        assert sv.verify(_oracle.stark_prove_trace(hard, cfg3), dict(num_queries=3, pow_bits=6)) is not None
     finally:
         L.orc_test_forge(0)
     # ... while its honest generator PROVES the record: R = P is a case of the hardened AIR (eq = 1: the sum is the next row's double)
