@@ -171,10 +171,13 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
     size_t row0 = io * 512;
     fill_exponent(tr, n, &L, row0, exp, bits);
     fq2 three = mk2(fq_from_u64(3)), two = mk2(fq_from_u64(2));
-    int pending = 0;
+    int pending = 0, inf = 0;          /* hardened: inf = the accumulator is the identity (R keeps its last finite value) */
+    const int32_t *hl = !a->hardened ? NULL : a->kind == 0 ? (cpl == 1 ? ORC_HARD_LAYOUT_G1H_U16 : ORC_HARD_LAYOUT_G1H_U8)
+                                                          : (cpl == 1 ? ORC_HARD_LAYOUT_G2H_U16 : ORC_HARD_LAYOUT_G2H_U8);
     for (int r = 0; r < 512; r++) {
         size_t row = row0 + r;
         int is_add = (r & 1) == 0;
+        if (hl) put(tr, n, hl[7], row, (uint64_t)inf);
         put_f2_u16(tr, n, L.Rx, row, R.x, ext); put_f2_u16(tr, n, L.Ry, row, R.y, ext);
         put_f2_u16(tr, n, L.Px, row, P.x, ext); put_f2_u16(tr, n, L.Py, row, P.y, ext);
         fq2 lam, num, den, deninv, xa, ya, xb;
@@ -185,14 +188,18 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
             num = f2_mul(three, f2_mul(P.x, P.x, ext), ext); den = f2_mul(two, P.y, ext);
             xa = P.x; ya = P.y; xb = P.x;
         }
-        int same = 0;
+        int same = 0, opposite = 0;
         if (f2_inv(den, ext, &deninv)) {
-            /* R = +-P or 2-torsion: not provable by the plain AIR.  The hardened AIR proves R = P (the sum is the double the next row
-             * computes; slope cells 0, result unused).  TEST HOOK bit 2: what a cheating prover does there with the plain AIR -- the
-             * chord rule 0 lam = 0 holds for every lam, so it picks one (5) and walks on from a point of its choosing */
+            /* R = +-P or 2-torsion: not provable by the plain AIR.  The hardened AIR proves both: R = P (the sum is the double the next
+             * row computes) and R = -P (the sum is the identity: the bit inf); slope cells 0, result unused.  TEST HOOK bit 2: what a
+             * cheating prover does with the plain AIR where R = P -- the chord rule 0 lam = 0 holds for every lam, so it picks one (5)
+             * and walks on from a point of its choosing */
             if (is_add && fq2_is_zero(num) && (a->hardened || (g_forge & 4))) {
                 same = a->hardened && !(g_forge & 4);
                 lam = same ? mk2(fq_zero()) : mk2(fq_from_u64(5));
+            } else if (is_add && a->hardened && !(g_forge & 4)) {
+                opposite = 1;
+                lam = mk2(fq_zero());
             } else
                 return -1;
         } else
@@ -203,7 +210,10 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
         put_f2_chk(tr, n, L.X3, row, x3, ext, cpl);
         put_f2_chk(tr, n, L.Y3, row, y3, ext, cpl);
         if (is_add) {
-            if (same) pending = bits[r >> 1];             /* hardened, R = P: the accumulator takes the NEXT row's double */
+            if (inf) {                                    /* the identity plus P: a copy of P (R's cells were stale) */
+                if (bits[r >> 1]) { R = P; inf = 0; }
+            } else if (same) pending = bits[r >> 1];      /* hardened, R = P: the accumulator takes the NEXT row's double */
+            else if (opposite) inf = bits[r >> 1];        /* hardened, R = -P: the sum is the identity */
             else if (bits[r >> 1]) { R.x = x3; R.y = y3; }
         } else {
             if (pending) {
@@ -213,6 +223,7 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
             if (r != 511) { P.x = x3; P.y = y3; }
         }
     }
+    if (inf) return -1;                                   /* the output would be the identity: no affine record for it */
     /* output words */
     fq_to_u32(R.x.c0, out_words);
     if (ext == 2) { fq_to_u32(R.x.c1, out_words + 8); fq_to_u32(R.y.c0, out_words + 16); fq_to_u32(R.y.c1, out_words + 24); }
@@ -320,27 +331,46 @@ static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t ro
         if (borrow) return -30;                                              /* x3 >= p: cannot happen for the chain's canonical values */
     }
     for (int j = 0; j < nc; j++) put(tr, n, lay[0] + j, row, 0);
-    /* eq: accumulator = running power (add rows); u = bit (1 - eq); eqc on a double row = bit eq of the add row before it */
-    int eq = 0, eqc = 0;
-    if ((row & 1) == 0) {
-        eq = 1;
-        for (int j = 0; j < nc && eq; j++)
-            eq = tr[(size_t)(L.Px + j) * n + row] == tr[(size_t)(L.Rx + j) * n + row] && tr[(size_t)(L.Py + j) * n + row] == tr[(size_t)(L.Ry + j) * n + row];
-        if (g_forge & 4) eq = 0;                                             /* the forger claims the chord */
-    } else {
-        eqc = tr[(size_t)L.bit * n + row - 1] != 0;
-        for (int j = 0; j < nc && eqc; j++)
-            eqc = tr[(size_t)(L.Px + j) * n + row - 1] == tr[(size_t)(L.Rx + j) * n + row - 1] &&
-                  tr[(size_t)(L.Py + j) * n + row - 1] == tr[(size_t)(L.Ry + j) * n + row - 1];
-        if (g_forge & 4) eqc = 0;
+    /* flags (see tools/air_gen.py::build_curve): eq / ng on add rows: R = P / R = -P as limb vectors; inf was written by the chain;
+     * t1 = bit (1 - inf), u = t1 (1 - eq - ng), v = bit inf, w = t1 ng; eqc on a double row = t1 eq of the add row before it */
+    const int is_add = (row & 1) == 0;
+    const size_t cr = is_add ? row : row - 1;
+    int eq = 1, xeq = 1;
+    for (int j = 0; j < nc; j++) {
+        xeq = xeq && tr[(size_t)(L.Px + j) * n + cr] == tr[(size_t)(L.Rx + j) * n + cr];
+        eq = eq && tr[(size_t)(L.Py + j) * n + cr] == tr[(size_t)(L.Ry + j) * n + cr];
     }
-    const int bit = tr[(size_t)L.bit * n + row] != 0, u = bit && !eq;
-    put(tr, n, lay[3], row, (uint64_t)eq); put(tr, n, lay[4], row, (uint64_t)u); put(tr, n, lay[5], row, (uint64_t)eqc);
-    if ((row & 1) == 0 && u) {
+    eq = eq && xeq;
+    /* R = -P: the x limbs equal and Ry + Py = p limb by limb (carries cn) */
+    int ng = is_add && xeq && !eq;
+    uint64_t cnv[30];
+    memset(cnv, 0, sizeof cnv);
+    for (int c = 0; c < ext && ng; c++) {
+        int64_t carry = 0;
+        for (int i = 0; i < 16; i++) {
+            int64_t sum = (int64_t)tr[(size_t)(L.Ry + 16 * c + i) * n + row] + (int64_t)tr[(size_t)(L.Py + 16 * c + i) * n + row] + carry;
+            int64_t d = sum - (int64_t)ORC_BN_P_LIMBS[i];
+            if (d != 0 && d != 65536) { ng = 0; break; }
+            carry = d == 65536;
+            if (i < 15) cnv[15 * c + i] = (uint64_t)carry;
+        }
+        if (carry) ng = 0;
+    }
+    if (g_forge & 4) { eq = 0; ng = 0; }                                  /* the forger claims the chord */
+    const int bit = tr[(size_t)L.bit * n + row] != 0, infc = tr[(size_t)lay[7] * n + row] != 0;
+    const int eq_here = is_add && eq, t1 = bit && !infc, u = t1 && !eq_here && !ng, v = bit && infc, w = t1 && ng;
+    int eqc = 0;
+    if (!is_add) eqc = eq && !(g_forge & 4) && tr[(size_t)L.bit * n + row - 1] != 0 && tr[(size_t)lay[7] * n + row - 1] == 0;
+    put(tr, n, lay[3], row, (uint64_t)eq_here); put(tr, n, lay[4], row, (uint64_t)u); put(tr, n, lay[5], row, (uint64_t)eqc);
+    put(tr, n, lay[6], row, (uint64_t)ng); put(tr, n, lay[8], row, (uint64_t)t1); put(tr, n, lay[9], row, (uint64_t)v);
+    put(tr, n, lay[10], row, (uint64_t)w);
+    for (int j = 0; j < 16; j++) put(tr, n, lay[11] + j, row, j == 0 ? (uint64_t)ng : 0);
+    for (int j = 0; j < 15 * ext; j++) put(tr, n, lay[12] + j, row, ng ? cnv[j] : 0);
+    if (is_add && u) {
         int j;
         for (j = 0; j < nc; j++)
             if (tr[(size_t)(L.Px + j) * n + row] != tr[(size_t)(L.Rx + j) * n + row]) break;
-        if (j == nc) return (g_forge & 4) ? 0 : -31;                         /* R.x = P.x, R.y != P.y where the addition is used: R = -P */
+        if (j == nc) return (g_forge & 4) ? 0 : -31;                         /* the x's equal where the chord is used: no witness */
         put(tr, n, lay[0] + j, row, gl_inv(gl_sub(tr[(size_t)(L.Px + j) * n + row], tr[(size_t)(L.Rx + j) * n + row])));
     }
     return 0;

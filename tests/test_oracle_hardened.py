@@ -28,8 +28,14 @@ def ios4():
 
 def hard_layout(name):
     txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
-    m = re.search(r"ORC_HARD_LAYOUT_%s\[6\] = \{([^}]*)\}" % name, txt)
-    return [int(x) for x in m.group(1).split(",")]        # nz, cb, T3, eq, u, eqc
+    m = re.search(r"ORC_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
+    return [int(x) for x in m.group(1).split(",")][:6]    # nz, cb, T3, eq, u, eqc (then ng, inf, t1, v, w, NGV, cn)
+
+
+def hard_layout_all(name):
+    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
+    m = re.search(r"ORC_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
+    return dict(zip("nz cb T3 eq u eqc ng inf t1 v w NGV cn".split(), [int(x) for x in m.group(1).split(",")]))
 
 
 @pytest.mark.parametrize("kind", [4, 5])
@@ -141,11 +147,41 @@ def test_exceptional_addition_forgery_is_accepted_by_the_plain_air_and_the_harde
     arr[eq, 6] = 1                                        # row 6: R = 4 x, P = 8 x
     assert good.check_row(6) != -1
     arr[eq, 6] = 0
-    # what stays unprovable in both variants: the accumulator meets MINUS the running power (the sum is the point at infinity)
-    neg = np.array([bn.g1_to_u32(x) + bn.g1_to_u32(bn.g1_neg(x)) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x, 2))], dtype=np.uint32)
+
+
+def test_the_accumulator_passing_through_the_identity_is_proved_by_the_hardened_air_only():
+    """offset = -x with an odd exponent: the first used addition is R + P with R = -P, the sum is the identity (flag ng, state bit inf,
+    R keeps its cells), and the next used addition copies P: out = -x + [3] x = 2 x.  G1 and G2; the plain kinds refuse."""
+    x1, x2 = bn.g1_mul(bn.G1, 77), bn.g2_mul(bn.G2, 99)
+    g1 = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(e) + bn.g1_to_u32(bn.g1_mul(x1, e - 1))
+                   for e in (3, 0b1001, (1 << 200) | 1)], dtype=np.uint32)
+    g2 = np.array([bn.g2_to_u32(x2) + bn.g2_to_u32(bn.g2_neg(x2)) + sn.exp_to_u32(e) + bn.g2_to_u32(bn.g2_mul(x2, e - 1))
+                   for e in (3, 0b101)], dtype=np.uint32)
+    for base, recs, name in ((0, g1, "G1H_U8"), (1, g2, "G2H_U8")):
+        with pytest.raises(RuntimeError):
+            _oracle.Trace(base, recs)
+        t = _oracle.Trace(base + 4, recs)
+        lay = hard_layout_all(name)
+        arr = t.array()
+        assert all(t.check_row(r) == -1 for r in range(1 << t.log_n))
+        # row 0: ng and w; inf from row 1 until the next set bit's add row, where v copies P
+        assert (int(arr[lay["ng"], 0]), int(arr[lay["w"], 0]), int(arr[lay["u"], 0]), int(arr[lay["inf"], 0]), int(arr[lay["inf"], 1])) == (1, 1, 0, 0, 1)
+        first_set = 2 if base == 0 else 2          # e = 3: bit 1 -> add row 2
+        assert int(arr[lay["v"], first_set]) == 1 and int(arr[lay["inf"], first_set]) == 1 and int(arr[lay["inf"], first_set + 1]) == 0
+        pf = _oracle.stark_prove(base + 4, recs)
+        assert _oracle.stark_verify(pf) == 0
+        # the flags cannot be dropped or invented
+        for col, row in ((lay["ng"], 0), (lay["inf"], 1), (lay["v"], first_set), (lay["w"], 0), (lay["t1"], 0), (lay["NGV"], 0), (lay["NGV"] + 3, 0),
+                         (lay["ng"], 6), (lay["inf"], 9), (lay["cn"] + 2, 0)):
+            old = int(arr[col, row])
+            arr[col, row] = old ^ 1
+            assert t.check_row(row) != -1 or t.check_row(row - 1) != -1, (col, row)
+            arr[col, row] = old
+    # what no affine record can say: the OUTPUT is the identity (offset = -x, e = 1)
+    none = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(1) + bn.g1_to_u32(x1)] * 2, dtype=np.uint32)
     for kind in (0, 4):
         with pytest.raises(RuntimeError):
-            _oracle.Trace(kind, neg)
+            _oracle.Trace(kind, none)
 
 
 def test_more_records_that_meet_the_running_power_are_proved_by_the_hardened_air_only():

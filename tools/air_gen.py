@@ -218,7 +218,7 @@ def exponent_logic(a):
         a.poly([(1, [X(e + i)]), (-1, [L(e + i)]), (-1, [PER(PER_LIMB_END), X(e + i)]), (1, [PER(PER_LIMB_END), L(e + i)])])
 
 
-def state_transition(a, state, result, upd_on_add, nl, use=None, late=None):
+def state_transition(a, state, result, upd_on_add, nl, use=None, late=None, copy=None):
     """state/result: column names of nl 16-bit limbs (state unchecked, result checked).
     upd_on_add: True  -> accumulator: add rows: s' = bit ? res : s ; double rows (not last): s' = s
                 False -> running power: add rows: s' = s ; double rows (not last): s' = res
@@ -232,6 +232,9 @@ def state_transition(a, state, result, upd_on_add, nl, use=None, late=None):
             # per_add * (s' - s - bit*(res - s)) = 0
             m = [(1, [PER(PER_ADD), X(s)]), (-1, [PER(PER_ADD), L(s)]), (1, [PER(PER_ADD), L(bit), L(s)])]
             m += [(-c, [PER(PER_ADD), L(bit), L(cc)]) for c, cc in res]
+            if copy is not None:      # ... - v (other - s): the accumulator restarts from the other state (hardened: R was the identity)
+                vcol, other = copy
+                m += [(1, [PER(PER_ADD), L(vcol), L(s)]), (-1, [PER(PER_ADD), L(vcol), L(a.col(other) + i)])]
             a.poly(m)
             # (1 - per_add - per_last) * (s' - s) = 0     (double rows except the block's last row)
             m = [(1, [X(s)]), (-1, [L(s)]), (-1, [PER(PER_ADD), X(s)]), (1, [PER(PER_ADD), L(s)]),
@@ -319,6 +322,8 @@ def build_curve(name, mode, ext, hardened=False):
         a.alloc("nz", nc)
         a.alloc("cb", (NL - 1) * ext)
         a.alloc("eq", 1); a.alloc("u", 1); a.alloc("eqc", 1)
+        a.alloc("ng", 1); a.alloc("inf", 1); a.alloc("t1", 1); a.alloc("v", 1); a.alloc("w", 1)
+        a.alloc("NGV", NL); a.alloc("cn", (NL - 1) * ext)
         a.alloc_checked("T3", nc * a.cpl)
     a.finalize_columns()
 
@@ -347,6 +352,10 @@ def build_curve(name, mode, ext, hardened=False):
     for c in range(ext):
         prods = t1[c] + [(-3 * co, A, B) for (co, A, B) in t2[c]]
         lins = [(-1, comp_u("Py", c, flag=PER_ADD)), (1, comp_u("Ry", c, flag=PER_ADD))]
+        if hardened:
+            # ... + ng (Py - Ry) on add rows: where R = -P (flag ng) the chord rule would read 0 = 2 Py; NGV spells ng as a limb vector
+            ngv = ([(1, a.col("NGV"), 1, PER_ADD, 0)], NL)
+            prods = prods + [(1, ngv, Air.vsum(comp_u("Py", c), comp_u("Ry", c, coef=-1)))]
         a.gadget("slope%d" % c, prods, lins, bound)
     # x3:  lam^2 - xA - xB - x3 = 0 ;  xA + xB = per_add*(Rx + Px) + (1-per_add)*2Px
     t = fq2_mul_terms(lam, lam)
@@ -363,8 +372,8 @@ def build_curve(name, mode, ext, hardened=False):
     a.emit_gadgets()
     exponent_logic(a)
     if hardened:
-        state_transition(a, "Rx", "X3", True, nc, use=a.col("u"), late=a.col("eqc"))
-        state_transition(a, "Ry", "Y3", True, nc, use=a.col("u"), late=a.col("eqc"))
+        state_transition(a, "Rx", "X3", True, nc, use=a.col("u"), late=a.col("eqc"), copy=(a.col("v"), "Px"))
+        state_transition(a, "Ry", "Y3", True, nc, use=a.col("u"), late=a.col("eqc"), copy=(a.col("v"), "Py"))
     else:
         state_transition(a, "Rx", "X3", True, nc)
         state_transition(a, "Ry", "Y3", True, nc)
@@ -398,7 +407,40 @@ def build_curve(name, mode, ext, hardened=False):
         for j in range(nc):
             a.poly([(1, [L(eq), L(a.col("Px") + j)]), (-1, [L(eq), L(a.col("Rx") + j)])])
             a.poly([(1, [L(eq), L(a.col("Py") + j)]), (-1, [L(eq), L(a.col("Ry") + j)])])
-        a.poly([(1, [L(u)]), (-1, [L(bit)]), (1, [L(bit), L(eq)])])
+        # ng = 1: the accumulator is MINUS the running power (x limbs equal, Ry + Py = p limb by limb with boolean carries cn): the sum is
+        # the identity, which the state carries as the bit inf (R keeps its last finite value).  t1 = bit (1 - inf): a used addition
+        # with a finite accumulator; u = t1 (1 - eq - ng): the chord; w = t1 ng: the accumulator becomes the identity; v = bit inf: a
+        # used addition to the identity = a copy of P
+        ng, inf, t1, v, w, ngv, cn = (a.col(x) for x in ("ng", "inf", "t1", "v", "w", "NGV", "cn"))
+        for b in (ng, inf):
+            a.poly([(1, [L(b), L(b)]), (-1, [L(b)])])
+        a.poly([(1, [L(eq), L(ng)])])
+        a.poly([(1, [L(ngv)]), (-1, [L(ng)])])
+        for j in range(1, NL):
+            a.poly([(1, [L(ngv + j)])])
+        for j in range(nc):
+            a.poly([(1, [L(ng), L(a.col("Px") + j)]), (-1, [L(ng), L(a.col("Rx") + j)])])
+        for c in range(ext):
+            for i in range(NL):
+                m = [(1, [L(ng), L(a.col("Ry") + NL * c + i)]), (1, [L(ng), L(a.col("Py") + NL * c + i)]), (-P_LIMBS[i], [L(ng)])]
+                if i > 0:
+                    m += [(1, [L(ng), L(cn + (NL - 1) * c + i - 1)])]
+                if i < NL - 1:
+                    m += [(-65536, [L(ng), L(cn + (NL - 1) * c + i)])]
+                a.poly(m)
+            for i in range(NL - 1):
+                b = cn + (NL - 1) * c + i
+                a.poly([(1, [L(b), L(b)]), (-1, [L(b)])])
+        a.poly([(1, [L(t1)]), (-1, [L(bit)]), (1, [L(bit), L(inf)])])
+        a.poly([(1, [L(v)]), (-1, [L(bit), L(inf)])])
+        a.poly([(1, [L(w)]), (-1, [L(t1), L(ng)])])
+        a.poly([(1, [L(u)]), (-1, [L(t1)]), (1, [L(t1), L(eq)]), (1, [L(t1), L(ng)])])
+        # the identity bit: add rows: inf' = inf - v + w; double rows: inf' = inf; finite at both ends of a block
+        a.poly([(1, [PER(PER_ADD), X(inf)]), (-1, [PER(PER_ADD), L(inf)]), (1, [PER(PER_ADD), L(v)]), (-1, [PER(PER_ADD), L(w)])])
+        a.poly([(1, [X(inf)]), (-1, [L(inf)]), (-1, [PER(PER_ADD), X(inf)]), (1, [PER(PER_ADD), L(inf)]),
+                (-1, [PER(PER_LAST), X(inf)]), (1, [PER(PER_LAST), L(inf)])])
+        a.poly([(1, [PER(PER_FIRST), L(inf)])])
+        a.poly([(1, [PER(PER_LAST), L(inf)])])
         # where the chord result is taken the x's differ in a limb: sum_j (Px_j - Rx_j) nz_j = u on add rows
         m = [(-1, [PER(PER_ADD), L(u)])]
         for j in range(nc):
@@ -406,9 +448,9 @@ def build_curve(name, mode, ext, hardened=False):
         a.poly(m)
         # R = P with the bit set: the sum is the double the NEXT row computes: eqc (on that row) = bit eq (of this one); never on a
         # block's last row (no row left to hand the result over)
-        a.poly([(1, [PER(PER_ADD), X(eqc)]), (-1, [PER(PER_ADD), L(bit), L(eq)])])
+        a.poly([(1, [PER(PER_ADD), X(eqc)]), (-1, [PER(PER_ADD), L(t1), L(eq)])])
         a.poly([(1, [PER(PER_LAST), L(eqc)])])
-        a.layout = [a.col("nz"), a.col("cb"), a.col("T3"), eq, u, eqc]
+        a.layout = [a.col("nz"), a.col("cb"), a.col("T3"), eq, u, eqc, ng, inf, t1, v, w, ngv, cn]
     a.primary = dict(kind="curve", ext=ext)
     return a
 
@@ -778,8 +820,8 @@ def main():
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
                 if a.hardened:
-                    f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3), eq, u, eqc */\n" % a.name)
-                    f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[6] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
+                    f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3), eq, u, eqc, ng, inf, t1, v, w, NGV, cn */\n" % a.name)
+                    f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[13] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
