@@ -417,20 +417,30 @@ __device__ __forceinline__ bool jac_same(const Jac<EXT>& p, const Jac<EXT>& q) {
     return F::is_zero(F::sub(F::mul(p.y, F::mul(z2, q.z)), F::mul(q.y, F::mul(z1, p.z))));
 }
 
-// hard != 0: the hardened AIR (API kinds 4 / 5): where the accumulator IS the running power on an add row (R = P) the row gets slope 0
-// instead of SIPP_E_WITNESS (its result is not used: flag eq), and the double row after it still shows the OLD accumulator -- the
-// sum, which is that row's own double, is handed over at the row's end (eqc); see tools/air_gen.py::build_curve
+// hard != 0: the hardened AIR (API kinds 4 / 5; tools/air_gen.py::build_curve).  Where the accumulator IS the running power on an add
+// row (R = P) or its negative (R = -P) the row gets slope 0 instead of SIPP_E_WITNESS (its result is not used: flags eq / ng).  After
+// R = P the double row still shows the OLD accumulator -- the sum, which is that row's own double, is handed over at the row's end (eqc).
+// After R = -P the accumulator is the identity: the state bit inf (column col_inf, written here from the scan's true accumulator) is
+// set and the R cells keep the last finite value until a used addition copies P.
 template <int EXT>
 __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __restrict__ rows, uint64_t* __restrict__ tr,
-                                                        size_t n, CurveCols c, int hard, int* __restrict__ err) {
+                                                        size_t n, CurveCols c, int hard, int col_inf, int* __restrict__ err) {
     using F = Fld<EXT>;
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     RowPts<EXT> rp = rows[row];
     const bool is_add = (row & 1) == 0;
-    if (hard && !is_add) {
-        const RowPts<EXT> prev = rows[row - 1];
-        if (!jac_is_inf<EXT>(prev.R) && !jac_is_inf<EXT>(prev.P) && jac_same<EXT>(prev.R, prev.P)) rp.R = prev.R;
+    const bool inf_here = jac_is_inf<EXT>(rp.R);
+    if (hard) {
+        tr[(size_t)col_inf * n + row] = inf_here ? 1 : 0;
+        if (!is_add) {
+            const RowPts<EXT> prev = rows[row - 1];
+            if (!jac_is_inf<EXT>(prev.R) && !jac_is_inf<EXT>(prev.P) && jac_same<EXT>(prev.R, prev.P)) rp.R = prev.R;
+        }
+        // the identity has no cells: the last finite accumulator of the block stands in (the block's first row is finite)
+        size_t r2 = row;
+        const size_t row0 = row & ~(size_t)511;
+        while (jac_is_inf<EXT>(rp.R) && r2 > row0) rp.R = rows[--r2].R;
     }
     // affine: x = X / Z^2, y = Y / Z^3 ; one inversion for both points
     auto zz = F::mul(rp.R.z, rp.P.z);
@@ -458,7 +468,7 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
         ya = py;
         xb = px;
     }
-    const bool same = hard && is_add && F::is_zero(den) && F::is_zero(num);   // R = P: a case of the hardened AIR
+    const bool same = hard && is_add && !inf_here && F::is_zero(den);   // R = +-P with a finite accumulator: cases of the hardened AIR
     if (F::is_zero(den) && !same) {
         atomicExch(err, SIPP_E_WITNESS);
         return;
@@ -680,7 +690,8 @@ struct SippBnP {
 // written by curve_rows_kernel and exp_rows_kernel; one lane per row, integer work only.
 __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__ tr, size_t n, int ext, int cpl, int col_rx, int col_px,
                                                          int col_bit, int col_x3, int col_nz, int col_cb, int col_t3, int col_eq, int col_u,
-                                                         int col_eqc, SippBnP pl, int* __restrict__ err) {
+                                                         int col_eqc, int col_ng, int col_inf, int col_t1, int col_v, int col_w, int col_ngv,
+                                                         int col_cn, SippBnP pl, int* __restrict__ err) {
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     const int nc = 16 * ext;
@@ -703,21 +714,44 @@ __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__
         }
         bad |= borrow != 0;
     }
-    // eq on an add row: every limb of R (x and y: the Ry cells follow the Rx cells, the Py cells the Px cells) equals P's; on a double
-    // row eqc = bit eq of the add row before it; u = bit (1 - eq)
+    // flags (tools/air_gen.py::build_curve): eq / ng on add rows: R = P / R = -P as limb vectors (the Ry cells follow the Rx cells, the Py
+    // cells the Px cells; ng: the x limbs equal and Ry + Py = p limb by limb with the carries cn); inf was written by curve_rows_kernel;
+    // t1 = bit (1 - inf), u = t1 (1 - eq - ng), v = bit inf, w = t1 ng; eqc on a double row = t1 eq of the add row before it
     const bool is_add = (row & 1) == 0;
-    const size_t cmp_row = is_add ? row : row - 1;
-    bool all_eq = true;
-    for (int j = 0; j < 2 * nc; j++)
-        all_eq &= tr[(size_t)(col_px + j) * n + cmp_row] == tr[(size_t)(col_rx + j) * n + cmp_row];
-    const bool bit = tr[(size_t)col_bit * n + row] != 0;
-    const bool eq = is_add && all_eq, eqc = !is_add && all_eq && tr[(size_t)col_bit * n + row - 1] != 0;
+    const size_t cr = is_add ? row : row - 1;
+    bool xeq = true, yeq = true;
+    for (int j = 0; j < nc; j++) {
+        xeq &= tr[(size_t)(col_px + j) * n + cr] == tr[(size_t)(col_rx + j) * n + cr];
+        yeq &= tr[(size_t)(col_px + nc + j) * n + cr] == tr[(size_t)(col_rx + nc + j) * n + cr];
+    }
+    const bool eqv = xeq && yeq;
+    bool ng = is_add && xeq && !yeq;
+    uint32_t carries = 0;    // bit 15 c + i
+    for (int c = 0; c < ext; c++) {
+        int64_t carry = 0;
+        for (int i = 0; i < 16; i++) {
+            const int64_t sum = (int64_t)tr[(size_t)(col_rx + nc + 16 * c + i) * n + row] + (int64_t)tr[(size_t)(col_px + nc + 16 * c + i) * n + row] + carry;
+            const int64_t d = sum - (int64_t)pl.l[i];
+            if (d != 0 && d != 65536) ng = false;
+            carry = d == 65536 ? 1 : 0;
+            if (i < 15 && carry) carries |= 1u << (15 * c + i);
+        }
+        if (carry) ng = false;
+    }
+    const bool bit = tr[(size_t)col_bit * n + row] != 0, infc = tr[(size_t)col_inf * n + row] != 0;
+    const bool eq = is_add && eqv, t1 = bit && !infc, used = t1 && !eq && !ng;
+    const bool eqc = !is_add && eqv && tr[(size_t)col_bit * n + row - 1] != 0 && tr[(size_t)col_inf * n + row - 1] == 0;
     tr[(size_t)col_eq * n + row] = eq ? 1 : 0;
-    tr[(size_t)col_u * n + row] = (bit && !eq) ? 1 : 0;
+    tr[(size_t)col_u * n + row] = used ? 1 : 0;
     tr[(size_t)col_eqc * n + row] = eqc ? 1 : 0;
+    tr[(size_t)col_ng * n + row] = ng ? 1 : 0;
+    tr[(size_t)col_t1 * n + row] = t1 ? 1 : 0;
+    tr[(size_t)col_v * n + row] = (bit && infc) ? 1 : 0;
+    tr[(size_t)col_w * n + row] = (t1 && ng) ? 1 : 0;
+    for (int j = 0; j < 16; j++) tr[(size_t)(col_ngv + j) * n + row] = (j == 0 && ng) ? 1 : 0;
+    for (int j = 0; j < 15 * ext; j++) tr[(size_t)(col_cn + j) * n + row] = (ng && (carries >> j & 1)) ? 1 : 0;
     int first = -1;
     uint64_t dpx = 0, drx = 0;
-    const bool used = is_add && bit && !eq;
     for (int j = 0; j < nc; j++) {
         const uint64_t px = tr[(size_t)(col_px + j) * n + row], rx = tr[(size_t)(col_rx + j) * n + row];
         if (first < 0 && px != rx) {
@@ -726,9 +760,10 @@ __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__
             drx = rx;
         }
     }
-    const uint64_t w = (used && first >= 0) ? gl::inv(gl::sub(dpx, drx)) : 0;
-    for (int j = 0; j < nc; j++) tr[(size_t)(col_nz + j) * n + row] = (used && j == first) ? w : 0;
-    bad |= used && first < 0;    // R.x = P.x, R.y != P.y where the addition is used (R = -P): no witness (curve_rows refused it already)
+    const bool chord = is_add && used;
+    const uint64_t w = (chord && first >= 0) ? gl::inv(gl::sub(dpx, drx)) : 0;
+    for (int j = 0; j < nc; j++) tr[(size_t)(col_nz + j) * n + row] = (chord && j == first) ? w : 0;
+    bad |= chord && first < 0;    // the x's equal where the chord is used: no witness (curve_rows refused the row already)
     if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
 
@@ -1169,6 +1204,10 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     } else {
         const int ext = a->kind == 0 ? 1 : 2, ncl = 16 * ext;
+        const int32_t* hard_lay = !a->hardened ? nullptr
+                                  : a->kind == 0 ? (cpl == 1 ? SIPP_HARD_LAYOUT_G1H_U16 : SIPP_HARD_LAYOUT_G1H_U8)
+                                                 : (cpl == 1 ? SIPP_HARD_LAYOUT_G2H_U16 : SIPP_HARD_LAYOUT_G2H_U8);
+        const int hard_inf_col = hard_lay ? hard_lay[7] : 0;
         CurveCols c{1, 1 + ncl, 1 + 2 * ncl, 1 + 3 * ncl, a->checked_base, a->checked_base + ncl * cpl,
                     a->checked_base + 2 * ncl * cpl, cpl};
         col_bit = 1 + 4 * ncl;
@@ -1193,7 +1232,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<1>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
-                               d_trace, n, c, a->hardened, d_err);
+                               d_trace, n, c, a->hardened, hard_inf_col, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         } else {
             RowPts<2>* rows = arena_alloc_t<RowPts<2>>(ctx, n);
@@ -1214,7 +1253,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
             }
             ProfScope ps(ctx, "trace_curve_rows");
             hipLaunchKernelGGL(curve_rows_kernel<2>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
-                               d_trace, n, c, a->hardened, d_err);
+                               d_trace, n, c, a->hardened, hard_inf_col, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         }
     }
@@ -1250,7 +1289,8 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         for (int i = 0; i < 16; i++) pl.l[i] = SIPP_BN_P_LIMBS[i];
         ProfScope ps(ctx, "trace_harden");
         hipLaunchKernelGGL(harden_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n, ext, cpl, 1,
-                           1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], pl, d_err);
+                           1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], lay[7], lay[8], lay[9], lay[10], lay[11], lay[12],
+                           pl, d_err);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
     {

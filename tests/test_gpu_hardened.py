@@ -49,7 +49,7 @@ def test_u16_variant_at_the_n128_size_verifies(kind):
     ios = d[("g1", "g2")[kind - 4]]
     c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(kind, ios.shape[0]))
     try:
-        assert c.shape(kind, ios.shape[0]) == ((16, 726, 410, 4), (16, 1439, 820, 4))[kind - 4]
+        assert c.shape(kind, ios.shape[0]) == ((16, 762, 410, 4), (16, 1490, 820, 4))[kind - 4]
         pf = c.prove(kind, ios)
     finally:
         c.close()
@@ -60,7 +60,8 @@ def test_u16_variant_at_the_n128_size_verifies(kind):
 
 def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
     """offset = [2^i - (e mod 2^i)] x with bit i of e set (the accumulator equals the running power on add row i), G1 and G2: the plain
-    kinds return SIPP_E_WITNESS, the hardened kinds prove them -- trace and proof equal to the oracle's; R = -P is refused by both"""
+    kinds return SIPP_E_WITNESS, the hardened kinds prove them -- trace and proof equal to the oracle's; likewise where the accumulator
+    meets MINUS the running power (the sum is the identity); only an OUTPUT at the identity is refused by both"""
     import sipp_amd
     from sipp_amd._lib import to_host
     from oracle.py import bn254 as bn
@@ -86,10 +87,31 @@ def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
             raise AssertionError("kind %d: %d cells differ; first (col,row): %s" % (base + 4, len(bad), bad[:8].tolist()))
         pf = ctx.prove(base + 4, recs)
         assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _oracle.stark_verify(pf) == 0
-    neg = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(3) + bn.g1_to_u32(bn.g1_mul(x1, 2))] * 2, dtype=np.uint32)
+    # R = -P on a used addition: the accumulator passes through the identity (offset = -x, odd exponent; and a later meeting:
+    # offset = -[2^i + (e mod 2^i)] x with bit i set)
+    g1n, g2n = [], []
+    for e, i in ((3, 0), (0b1001, 0), (0b10110, 2), ((1 << 200) | 1, 0)):
+        k = (1 << i) + (e % (1 << i))
+        g1n.append(bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(bn.g1_mul(x1, k))) + sn.exp_to_u32(e) + bn.g1_to_u32(bn.g1_mul(x1, (e - k) % bn.R)))
+        g2n.append(bn.g2_to_u32(x2) + bn.g2_to_u32(bn.g2_neg(bn.g2_mul(x2, k))) + sn.exp_to_u32(e) + bn.g2_to_u32(bn.g2_mul(x2, (e - k) % bn.R)))
+    for base, recs in ((0, np.array(g1n, dtype=np.uint32)), (1, np.array(g2n[:3], dtype=np.uint32))):
+        with pytest.raises(sipp_amd.SippError) as e:
+            ctx.prove(base, recs)
+        assert e.value.code == -8
+        assert (ctx.exp_outputs(base + 4, recs) == recs).all()
+        got = to_host(ctx.trace_build(base + 4, recs))
+        ref = _oracle.Trace(base + 4, recs)          # (kept alive: array() is a view of its buffer)
+        want = ref.array()
+        if not (got == want).all():
+            bad = np.argwhere(got != want)
+            raise AssertionError("kind %d: %d cells differ; first (col,row): %s" % (base + 4, len(bad), bad[:8].tolist()))
+        pf = ctx.prove(base + 4, recs)
+        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _oracle.stark_verify(pf) == 0
+    # the OUTPUT at the identity: no record can say it; refused by both variants
+    none = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(1) + bn.g1_to_u32(x1)] * 2, dtype=np.uint32)
     for kind in (0, 4):
         with pytest.raises(sipp_amd.SippError) as e:
-            ctx.prove(kind, neg)
+            ctx.prove(kind, none)
         assert e.value.code == -8
 
 
