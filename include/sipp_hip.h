@@ -70,11 +70,11 @@ void sipp_default_config(sipp_stark_config *cfg);
 /* Which STARK (reference src/verifier_circuit.rs:133 / :134 / :135) */
 typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
                SIPP_MAP_G2 = 3 /* src/bin/bls_aggregation.rs:65, see sipp_map_to_g2_prove */,
-               /* G1 / G2 exponentiation with the HARDENED AIR (same records, same rows, about 11 % more columns): x3 canonical; where
+               /* G1 / G2 exponentiation with the HARDENED AIR (same records, same rows, about 14 % more columns): x3 canonical; where
                 * an addition is used, an inequality witness for the two x-coordinates -- the chord rule of the plain AIR is satisfied by
-                * ANY slope where the accumulator meets the running power -- and that case (R = P) proved through
-                * the next row's double instead of being refused.  Only R = -P (a partial sum at infinity) returns SIPP_E_WITNESS.
-                * Through sipp_prove / sipp_prove_async and the generic size / shape / trace functions. */
+                * ANY slope where the accumulator meets the running power; that case (R = P) is proved through the
+                * next row's double and R = -P through an identity state bit instead of being refused: every record whose OUTPUT is a
+                * finite point has a proof.  Through sipp_prove / sipp_prove_async and the generic size / shape / trace functions. */
                SIPP_G1_EXP_HARDENED = 4, SIPP_G2_EXP_HARDENED = 5 } sipp_kind;
 
 /* u32 words per IO record, (x, offset, exp_val, output) order:

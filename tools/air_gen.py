@@ -300,8 +300,11 @@ def build_curve(name, mode, ext, hardened=False):
        * a flag eq on add rows ("R IS P": every limb of x and y equal), u = bit (1 - eq) in the place of the bit in the accumulator's
          transition, and  sum_j (Px_j - Rx_j) nz_j = u  with free cells nz_j: where the chord result is USED the two x's differ in a limb,
          hence mod p, and the slope is determined;
-       * eqc on the double row after an add row with bit eq = 1: that row's own result (2 P = R + P) goes to the accumulator.
-    Unprovable in both variants: R = -P on an add row (the partial sum is the point at infinity)."""
+       * eqc on the double row after an add row with t1 eq = 1: that row's own result (2 P = R + P) goes to the accumulator;
+       * a flag ng ("R is -P": x limbs equal, Ry + Py = p with carries cn) and a state bit inf ("the accumulator is the identity"; R's cells
+         keep the last finite value): t1 = bit (1 - inf), w = t1 ng sets inf, v = bit inf copies P and clears it; the chord rule gets the
+         product ng (Py - Ry) (NGV = the flag as a limb vector) so that it holds where R = -P; inf = 0 on a block's first and last row.
+    Unprovable in both variants: an OUTPUT at the identity."""
     a = Air(name + ("h" if hardened else ""), mode)
     a.hardened = 1 if hardened else 0
     a.gadgets = []
