@@ -90,9 +90,12 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
  * Pass 0 to size the arena for n = 128 (about 24 GiB). */
 int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t workspace_bytes);
 void sipp_ctx_destroy(sipp_ctx *ctx);
-/* Priority of the ctx's HIP stream: level < 0 lowest, 0 normal, > 0 highest the device offers.  With the three proofs of
- * an instance on three ctxs, G1 low / G2 normal / Fq12 high measured best.  Only while no proof is
- * in flight on the ctx.  (SIPP_STREAM_PRIORITY=high|low in the environment sets the initial priority at sipp_ctx_create.) */
+/* The ctx's HIP stream: level > 0 = a stream of the highest priority the device offers; level <= 0 = a stream with a hardware
+ * queue of its own at normal priority (created with an all-ones CU mask: the runtime multiplexes ordinary streams onto a pool of
+ * four queues, such a stream is kept out of the pool -- measured 1.5 ms per n = 128 instance; level < 0 used
+ * to mean the lowest priority and still does under SIPP_DEDICATED_QUEUES=0).  With the three proofs of an instance on three ctxs:
+ * G1 and G2 <= 0, Fq12 high.  Only while no proof is in flight on the ctx.  (SIPP_STREAM_PRIORITY=high|low in the environment sets
+ * the level at sipp_ctx_create.) */
 int sipp_ctx_set_stream_priority(sipp_ctx *ctx, int level);
 /* on != 0: on this ctx the kinds SIPP_G1_EXP / SIPP_G2_EXP mean the HARDENED AIRs (SIPP_G1_EXP_HARDENED / SIPP_G2_EXP_HARDENED below) in
  * every call that takes the ctx -- sipp_g1_exp_prove, sipp_prove_async, sipp_instance_prove, sipp_instances_prove, sipp_proof_size,

@@ -22,6 +22,32 @@ void sipp_default_config(sipp_stark_config* cfg) {
     cfg->pow_rule = SIPP_POW_DUPLEX;
 }
 
+// The stream of a ctx.  level > 0: a high-priority stream.  Otherwise a stream with a HARDWARE QUEUE OF ITS OWN: the runtime
+// multiplexes ordinary streams onto a small pool of queues per priority (GPU_MAX_HW_QUEUES, 4), a stream created with a CU mask gets
+// a queue to itself -- the mask here is all ones, every CU stays usable.  Measured on the n = 128 instance:
+// G1 (formerly on the low-priority pool) on its own queue is worth 1.5 ms of 60 single and 0.9 of 51.8 ms queued; the blocking flag,
+// the priority value and the number of pool queues are not what moves it.  Such a stream has normal priority (the call takes none),
+// so "low" and "normal" are the same thing now.  SIPP_DEDICATED_QUEUES=0 restores pool streams with priorities.
+static hipError_t create_ctx_stream(int device, int level, hipStream_t* out) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least, hi = greatest priority (numerically lower)
+    static const int dedicated = sipp_env_int("SIPP_DEDICATED_QUEUES", 1);
+    if (level <= 0 && dedicated) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 && prop.multiProcessorCount <= 1024) {
+            uint32_t mask[32];
+            const uint32_t words = ((uint32_t)prop.multiProcessorCount + 31) / 32;
+            for (uint32_t i = 0; i < words; i++) {
+                const uint32_t left = (uint32_t)prop.multiProcessorCount - 32 * i;
+                mask[i] = left >= 32 ? 0xffffffffu : (1u << left) - 1;
+            }
+            if (hipExtStreamCreateWithCUMask(out, words, mask) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();   // no queue left for it: a pool stream below
+        }
+    }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, level > 0 ? hi : level < 0 ? lo : 0);
+}
+
 int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, size_t workspace_bytes) {
     if (!out) return SIPP_E_BADARG;
     *out = nullptr;
@@ -52,12 +78,9 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
     {
         // SIPP_STREAM_PRIORITY (read at ctx creation): "high" / "low" / unset.  With one ctx per STARK the thin,
         // latency-bound proof should be scheduled ahead of the fat ones.
-        int lo = 0, hi = 0, prio = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least, hi = greatest priority (numerically lower)
         const char* e = getenv("SIPP_STREAM_PRIORITY");
-        if (e && !strcmp(e, "high")) prio = hi;
-        if (e && !strcmp(e, "low")) prio = lo;
-        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess) return bail(SIPP_E_HIP);
+        const int level = e && !strcmp(e, "high") ? 1 : e && !strcmp(e, "low") ? -1 : 0;
+        if (create_ctx_stream(device, level, &ctx->stream) != hipSuccess) return bail(SIPP_E_HIP);
     }
     if (workspace_bytes == 0) workspace_bytes = (size_t)24 << 30;
     ctx->arena_size = workspace_bytes;
@@ -118,11 +141,8 @@ int sipp_ctx_set_stream_priority(sipp_ctx* ctx, int level) {
         }
     }
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    int lo = 0, hi = 0;
-    SIPP_CHECK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least, hi = greatest (numerically lower)
-    const int prio = level > 0 ? hi : level < 0 ? lo : 0;  // 0 is the default (normal) priority of a HIP stream
     hipStream_t ns = nullptr;
-    SIPP_CHECK_HIP(ctx, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, prio));
+    if (create_ctx_stream(ctx->device, level, &ns) != hipSuccess) return sipp_fail(ctx, SIPP_E_HIP, "set_stream_priority: no stream");
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->prof) {  // pending event pairs belong to the old stream: fold them into the totals first
