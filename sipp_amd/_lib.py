@@ -447,7 +447,8 @@ class Ctx:
 class Instance:
     """The three sub-proofs of one SIPP instance (reference src/verifier_circuit.rs:133-135) on three ctxs = three HIP
     streams, started together through sipp_instance_prove.  `devices` may name one GPU (default) or three
-    (level L-B).  `priorities`: stream priority per kind ("high" / "low" / "" = normal); G1 low / G2 normal / Fq12 high
+    (level L-B).  `priorities`: stream level per kind ("high" = a high-priority stream; "low" / "" = a stream with a hardware queue of its own at
+    normal priority, see sipp_ctx_set_stream_priority in include/sipp_hip.h); G1 low / G2 normal / Fq12 high
     measured best with the start gate of sipp_instance_prove (69.3 vs 71.2 ms per n = 128 instance for low / high / high)."""
 
     def __init__(self, num_io, devices=(0, 0, 0), priorities=("low", "", "high"), hardened=False):
