@@ -271,9 +271,11 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
             c->gate_release = nullptr;
         }
     } gate_guard{ctx};
-    // where a gated proof waits: before its first launch (0, the default) or after its own trace fill, in front of its first
-    // fat kernel (SIPP_GATE_POINT=1: measured 63.1 against 61.9-62.6 ms per n = 128 instance -- G1's early chains disturb G2's)
-    static const int gate_point = [] { const char* e = getenv("SIPP_GATE_POINT"); return e ? atoi(e) : 0; }();   // three host threads get here at once
+    // where a gated proof waits: before its first launch (SIPP_GATE_POINT=0, the default until round 3's last day); after its own trace
+    // fill, in front of its first fat kernel (1: measured 59.7 against 58.7 ms per n = 128 instance -- the wide fill kernels disturb
+    // G2's); or inside its trace fill, after the thin doubling / scan chain and before the first wide kernel (2, the default:
+    // trace.hip gate_after_chain -- 0.3 ms better than 0 over five alternating pairs; a kind without such a chain waits as under 1)
+    static const int gate_point = [] { const char* e = getenv("SIPP_GATE_POINT"); return e ? atoi(e) : 2; }();   // three host threads get here at once
     if (ctx->gate_wait && gate_point == 0) {
         ctx->gate_wait->wait();
         ctx->gate_wait = nullptr;

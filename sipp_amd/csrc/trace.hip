@@ -1181,6 +1181,16 @@ int sipp_fold_chain_finish(sipp_ctx* ctx, int kind, uint32_t* d_ios, uint32_t nu
 
 // d_ios: [num_io][pi_per_io] u32 on the device (padded); d_trace: [W][n] zero-initialised by the caller is NOT
 // required: every main column is written here.  d_err: device int, 0 on entry.
+// SIPP_GATE_POINT=2 (the default): a gated proof of an instance (stark.hip: G1 behind G2's trace fill) has its thin doubling / scan
+// chain -- 16 waves, 1.5 ms of pure latency -- in flight while it waits; everything wider starts after the gate
+static void gate_after_chain(sipp_ctx* ctx) {
+    static const int gate_point = sipp_env_int("SIPP_GATE_POINT", 2);
+    if (ctx->gate_wait && gate_point == 2) {
+        ctx->gate_wait->wait();
+        ctx->gate_wait = nullptr;
+    }
+}
+
 int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
                     uint64_t* d_trace, int* d_err) {
     const size_t n = (size_t)1 << log_n;
@@ -1224,6 +1234,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
+            gate_after_chain(ctx);
             if (ctx->outputs_only) {
                 hipLaunchKernelGGL(curve_outputs_kernel<1>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
                                    const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
@@ -1245,6 +1256,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
                                    (uint32_t)a->pi_per_io, rows);
             }
             SIPP_CHECK_HIP(ctx, hipGetLastError());
+            gate_after_chain(ctx);
             if (ctx->outputs_only) {
                 hipLaunchKernelGGL(curve_outputs_kernel<2>, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, rows,
                                    const_cast<uint32_t*>(d_ios), num_io, (uint32_t)a->pi_per_io, d_err);
