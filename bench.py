@@ -393,7 +393,8 @@ def main():
         try:
             if os.environ.get("SIPP_BENCH_HARDENED", "1") in ("0", ""):
                 raise RuntimeError("skipped (SIPP_BENCH_HARDENED=0)")
-            hinst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios, hardened=True)
+            hinst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3,
+                                      priorities=prios if "SIPP_BENCH_PRIOS" in os.environ else None, hardened=True)
             try:
                 hinst.prove(ios)
                 t = time.perf_counter()
