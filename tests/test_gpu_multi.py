@@ -187,3 +187,27 @@ def test_io_sharded_sub_proofs_cover_the_instance_and_verify(world):
     finally:
         ctx.close()
     assert seen == [a.shape[0] for a in ios]
+
+
+def test_pool_streams_and_dedicated_queues_give_the_same_proofs():
+    """the ctx streams (sipp_amd/csrc/api.hip create_ctx_stream): a hardware queue of their own by default, the runtime's pool with
+    priorities under SIPP_DEDICATED_QUEUES=0 -- the knob is read once per process, so the other setting runs in a child process;
+    scheduling must not show in a proof"""
+    import hashlib
+    import sipp_amd
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n4_ios.npz"))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios])
+    try:
+        here = [hashlib.sha256(p.tobytes()).hexdigest() for p in inst.prove(ios)]
+    finally:
+        inst.close()
+    code = ("import hashlib, numpy as np, sipp_amd\n"
+            "d = np.load('tests/golden/sipp_n4_ios.npz'); ios = [d['g1'], d['g2'], d['fq12']]\n"
+            "inst = sipp_amd.Instance([a.shape[0] for a in ios])\n"
+            "print(' '.join(hashlib.sha256(p.tobytes()).hexdigest() for p in inst.prove(ios)))\n"
+            "inst.close()\n")
+    env = dict(os.environ, SIPP_DEDICATED_QUEUES="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-3:] == here
