@@ -1118,6 +1118,48 @@ __global__ void lookup_fill_kernel(const uint32_t* __restrict__ start, const uin
     }
 }
 
+// The same two columns by EXPANSION instead of a search per position (the default; SIPP_LOOKUP_FILL_SEARCH=1 keeps the kernel above):
+// one lane per (column, value v) writes v to the positions start[v] .. start[v] + hist[v] - 1 -- the first of them carries v in the table
+// column too, the others a filler as above.  No dependent loads (the search takes 16 per position), writes in increasing position order.
+// Bins of more than 8 entries (constant cells, carries; every bin of a u8 table) are written by the whole wave, one bin after the other.
+__global__ void __launch_bounds__(256) lookup_expand_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ start,
+                                                           const uint32_t* __restrict__ dist, const uint32_t* __restrict__ zlist,
+                                                           const uint32_t* __restrict__ nzero, size_t n, uint32_t tbits,
+                                                           uint64_t* __restrict__ pin, uint64_t* __restrict__ ptab) {
+    const uint32_t T = 1u << tbits;
+    const size_t c = blockIdx.y;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = v < T;
+    const size_t tb = (c << tbits);
+    const uint32_t cnt = live ? hist[tb + v] : 0, s = live ? start[tb + v] : 0, d = live ? dist[tb + v] : 0;
+    const uint32_t nz = nzero[c];
+    const uint32_t* zl = zlist + tb;
+    uint64_t* pi = pin + c * n;
+    uint64_t* pt = ptab + c * n;
+    const uint32_t LIGHT = 8;
+    if (cnt && cnt <= LIGHT) {
+        pi[s] = v;
+        pt[s] = v;
+        for (uint32_t j = 1; j < cnt; j++) {
+            const uint32_t i = s + j, k = i - d;
+            pi[i] = v;
+            pt[i] = k < nz ? zl[k] : T - 1;
+        }
+    }
+    uint64_t heavy = __ballot(cnt > LIGHT);
+    const uint32_t lane = threadIdx.x & 63;
+    while (heavy) {
+        const int src = __ffsll((unsigned long long)heavy) - 1;
+        heavy &= heavy - 1;
+        const uint32_t hv = __shfl(v, src), hs = __shfl(s, src), hc = __shfl(cnt, src), hd = __shfl(d, src);
+        for (uint32_t j = lane; j < hc; j += 64) {
+            const uint32_t i = hs + j, k = i - hd;
+            pi[i] = hv;
+            pt[i] = j == 0 ? hv : (k < nz ? zl[k] : T - 1);
+        }
+    }
+}
+
 }  // namespace
 
 // ---- host drivers -------------------------------------------------------------------------------------------
@@ -1380,8 +1422,13 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         }
         {
             ProfScope ps(ctx, "lookup_fill");
-            hipLaunchKernelGGL(lookup_fill_kernel, dim3(4096), dim3(256), 0, ctx->stream, start, dist, zlist, nzero, n,
-                               (uint32_t)nc, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
+            static const int fill_search = sipp_env_int("SIPP_LOOKUP_FILL_SEARCH", 0);
+            if (fill_search)
+                hipLaunchKernelGGL(lookup_fill_kernel, dim3(4096), dim3(256), 0, ctx->stream, start, dist, zlist, nzero, n,
+                                   (uint32_t)nc, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
+            else
+                hipLaunchKernelGGL(lookup_expand_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)nc), dim3(256), 0, ctx->stream, hist,
+                                   start, dist, zlist, nzero, n, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
