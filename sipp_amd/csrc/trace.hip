@@ -1152,7 +1152,23 @@ __global__ void __launch_bounds__(256) lookup_expand_kernel(const uint32_t* __re
         const int src = __ffsll((unsigned long long)heavy) - 1;
         heavy &= heavy - 1;
         const uint32_t hv = __shfl(v, src), hs = __shfl(s, src), hc = __shfl(cnt, src), hd = __shfl(d, src);
-        for (uint32_t j = lane; j < hc; j += 64) {
+        // eight positions per lane and trip: the fillers' loads are in flight together (a constant column is ONE bin of n entries)
+        uint32_t j = lane;
+        for (; j + 7 * 64 < hc; j += 8 * 64) {
+            uint32_t f[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t k = hs + j + 64 * q - hd;
+                f[q] = k < nz ? zl[k] : T - 1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = hs + j + 64 * q;
+                pi[i] = hv;
+                pt[i] = (j + 64 * q) == 0 ? hv : f[q];
+            }
+        }
+        for (; j < hc; j += 64) {
             const uint32_t i = hs + j, k = i - hd;
             pi[i] = hv;
             pt[i] = j == 0 ? hv : (k < nz ? zl[k] : T - 1);
