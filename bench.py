@@ -96,6 +96,27 @@ def ntt_roofline(shapes, kernel_ms_serial):
                     "see DESIGN.md section 4"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <argv>` as a CHILD process (never exec: this process may not be
+    replaced) and pass its output and exit code through.  Called before anything in this process touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:          # rank 0's JSON line (and anything else the ranks print) as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +129,11 @@ def main():
                          "rank, 1 (skipped) when launched with more: 8 ranks x 5 slots x 3 worker threads would put 120 host "
                          "threads on one node for a secondary figure")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked bare (`python bench.py --gpus N`): start the N ranks ourselves, exactly as the driver's launcher would.  Nothing
+        # in this process has touched the GPU (torch is not even imported yet), the ranks are fresh children, rank 0's one JSON
+        # line is relayed and the launcher's exit code is ours.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.inflight is None:
         args.inflight = 5 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 1
 
@@ -117,10 +143,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        # one process per GPU: the launcher provides the ranks (no GPU call has happened yet, nothing is re-executed here)
-        raise SystemExit("bench.py --gpus %d needs %d ranks but WORLD_SIZE is %d: launch it as `python -m torch.distributed.run "
-                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`"
-                         % (args.gpus, args.gpus, world, args.gpus, args.gpus))
+        # a launcher that supplies the wrong WORLD_SIZE: a one-rank number must not be reported as the N-GPU leg
+        raise SystemExit("bench.py --gpus %d needs %d ranks but the launcher set WORLD_SIZE=%d: launch it as `python -m "
+                         "torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py "
+                         "--gpus %d ...`, or bare (`python bench.py --gpus %d` starts its own ranks)"
+                         % (args.gpus, args.gpus, world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SIPP HIP path has no CPU fallback")
     # SIPP_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- only to rehearse the N > 1 code path on a one-GPU box
@@ -130,7 +157,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     from sipp_amd import dist_util
-    red_device = dist_util.init_process_group(world, local_rank, rehearsal)   # "cuda" over RCCL, "cpu" over gloo / alone
+    # SIPP_BENCH_SINGLE_RANK_GROUP=1: a process group of ONE rank, so that a one-GPU box runs the RCCL branch of the timing contract
+    red_device = dist_util.init_process_group(world, local_rank, rehearsal,   # "cuda" over RCCL, "cpu" over gloo / alone
+                                              single_rank_group=bool(int(os.environ.get("SIPP_BENCH_SINGLE_RANK_GROUP", "0"))))
 
     import sipp_amd
     ios = load_ios(args.n)
@@ -283,6 +312,8 @@ def main():
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            # what carried the barrier and the max-over-ranks reduction of the timed region
+            "timing_reduction": ("%s:%s" % (dist.get_backend(), red_device)) if dist.is_initialized() else "single process",
             "config": {"workload": "n=%d SIPP instance per GPU: G1ExpStark %d IO (N=2^%d, W+P+Q=%d), G2ExpStark %d IO "
                                    "(N=2^%d, %d), Fq12ExpStark %d IO (N=2^%d, %d); IO records on host -> 3 flat proofs "
                                    "on host, the 3 sub-proofs on 3 concurrent HIP streams" % (args.n, ios[0].shape[0], shapes[0][0], sum(shapes[0][1:]),
@@ -444,7 +475,7 @@ def main():
     if rank == 0:
         out["io_sharded"] = io_sharded
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

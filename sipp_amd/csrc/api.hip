@@ -31,7 +31,7 @@ void sipp_default_config(sipp_stark_config* cfg) {
 static hipError_t create_ctx_stream(int device, int level, hipStream_t* out) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least, hi = greatest priority (numerically lower)
-    static const int dedicated = sipp_env_int("SIPP_DEDICATED_QUEUES", 1);
+    static const int dedicated = [] { const char* e = getenv("SIPP_DEDICATED_QUEUES"); return e ? atoi(e) : 1; }();
     if (level <= 0 && dedicated) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 && prop.multiProcessorCount <= 1024) {
@@ -75,13 +75,8 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
         return rc;
     };
     if (hipSetDevice(device) != hipSuccess) return bail(SIPP_E_HIP);
-    {
-        // SIPP_STREAM_PRIORITY (read at ctx creation): "high" / "low" / unset.  With one ctx per STARK the thin,
-        // latency-bound proof should be scheduled ahead of the fat ones.
-        const char* e = getenv("SIPP_STREAM_PRIORITY");
-        const int level = e && !strcmp(e, "high") ? 1 : e && !strcmp(e, "low") ? -1 : 0;
-        if (create_ctx_stream(device, level, &ctx->stream) != hipSuccess) return bail(SIPP_E_HIP);
-    }
+    // level 0; sipp_ctx_set_stream_priority replaces the stream (one ctx per STARK: the thin, latency-bound proof goes ahead)
+    if (create_ctx_stream(device, 0, &ctx->stream) != hipSuccess) return bail(SIPP_E_HIP);
     if (workspace_bytes == 0) workspace_bytes = (size_t)24 << 30;
     ctx->arena_size = workspace_bytes;
     if (hipMalloc((void**)&ctx->arena, workspace_bytes) != hipSuccess) return bail(SIPP_E_NOMEM);

@@ -163,13 +163,6 @@ static inline T* arena_alloc_t(sipp_ctx* ctx, size_t count) {
 }
 
 // ---- profiling-aware launch bracket ------------------------------------------
-// measurement knob from the environment, read once (a function-local `static const int v = sipp_env_int(...)` is
-// initialised thread-safely: the three host threads of an instance reach these at the same time)
-inline int sipp_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // (Round 2 had a SIPP_SYNC_SPIN knob that replaced hipStreamSynchronize by a hipStreamQuery poll through a macro of the same name:
 // it measured inside the box-to-box spread -- 61.5-61.7 against 61.8-62.0 ms -- burned a core per ctx and shadowed a HIP API name;
 // removed.)

@@ -378,15 +378,12 @@ SIPP_AVX512 void piece(uint64_t s[12], int impl) {
 
 typedef void (*permute_fn)(uint64_t*);
 permute_fn pick() {
-    // SIPP_HOST_POSEIDON = "scalar" | "lookahead" | "avx512" (state update of the partial rounds on the vector pipes too) |
-    // "mixed" (AVX-512 full rounds + scalar look-ahead partial rounds, the default where AVX-512 exists) overrides the choice.
-    // One dependent permutation on an EPYC 9575F (scripts/ubench/host_poseidon_bench.cpp): 1.17 / 1.08 / 0.77 / 0.76 us.
-    const char* e = getenv("SIPP_HOST_POSEIDON");
+    // scalar | scalar with look-ahead | AVX-512 (state update of the partial rounds on the vector pipes too) | mixed (AVX-512 full
+    // rounds + scalar look-ahead partial rounds): one dependent permutation on an EPYC 9575F 1.17 / 1.08 / 0.77 / 0.76 us
+    // (scripts/ubench/host_poseidon_bench.cpp).  Mixed where AVX-512 exists, else the look-ahead form; every form is reachable
+    // through sipp_host_poseidon_permute(.., impl) and checked against the oracle there (tests/test_abi.py).
     __builtin_cpu_init();  // this runs from a static initialiser of the shared library
     const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl");
-    if (e && e[0] == 's') return permute_scalar;
-    if (e && e[0] == 'l') return permute_scalar_lookahead;
-    if (e && e[0] == 'a') return have512 ? permute_avx512 : permute_scalar_lookahead;
     return have512 ? permute_avx512_mixed : permute_scalar_lookahead;
 }
 const permute_fn CHOSEN = pick();

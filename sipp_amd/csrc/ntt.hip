@@ -49,7 +49,6 @@ struct PassArgs {
     const uint64_t* pw_hi;
     uint64_t pw_step;
     uint64_t cscale;  // 0 = none; multiplied in after the butterflies
-    uint32_t r16;     // radix-2^4 register rounds (see tile_stages)
 };
 
 __device__ __forceinline__ uint32_t lds_idx(uint32_t e) { return e + (e >> LOG_SEG); }
@@ -78,26 +77,21 @@ __device__ __forceinline__ void tile_loop(uint32_t E, Load load, Use use) {
 #define SIPP_NTT_MLP 8
 #endif
 
-// LDS placement of tile element e: one u64 of padding per 16 (lds_idx), optionally one more per 2^BLK elements so that a
-// scatter over blocks (the bit-reversed gather of lde_gather_kernel) is conflict-free as well
+// LDS placement of tile element e: one u64 of padding per 16 (lds_idx)
 struct IdxPlain {
     __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
-};
-struct IdxBlocked {
-    uint32_t blk;   // log2 block size
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
 };
 
 // all butterfly stages of one bit group on an LDS tile of E elements: k stages over rows (element stride T = 2^lt)
 template <class Idx>
 __device__ __forceinline__ void tile_stages(uint64_t* tile, const uint64_t* wr_s, uint32_t E, uint32_t k, uint32_t lt, bool dit,
-                                            Idx lidx, bool r16) {
+                                            Idx lidx) {
     const uint32_t R = 1u << k, T = 1u << lt;
     uint32_t s = 0;
     // radix-2^4 in registers: a lane loads the 16 elements of a hexadecuple, applies FOUR stages and writes them back -- a quarter
     // of the LDS round trips, index arithmetic and barriers of radix 2^2, 15 twiddle loads instead of 24 (same 32 products)
     const uint32_t sixteenth = E >> 4;
-    for (; r16 && s + 3 < k; s += 4) {
+    for (; s + 3 < k; s += 4) {
         const uint32_t log_q = dit ? s : (k - 4 - s);
         const uint32_t q = 1u << log_q;
         for (uint32_t idx = threadIdx.x; idx < sixteenth; idx += blockDim.x) {
@@ -295,7 +289,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassArgs a) {
     if (a.tw_mode == 1 || a.pw_mode == 1) diag(a.tw_mode == 1, a.pw_mode == 1, 0);
 
     // ---- butterflies: k stages over the r dimension (element stride T), four (two, one) stages per LDS round trip ----
-    tile_stages(tile, wr_s, E, k, lt, a.dit != 0, IdxPlain{}, a.r16 != 0);
+    tile_stages(tile, wr_s, E, k, lt, a.dit != 0, IdxPlain{});
 
     if (a.tw_mode == 2 || a.pw_mode == 2) {
         diag(a.tw_mode == 2, a.pw_mode == 2, a.cscale);
@@ -341,7 +335,6 @@ struct ColArgs {
     const uint64_t* tw_inv;   // [n]: w_n^-(t bitrev_k1(r)) / n   at position p = r 2^k2 + t
     const uint64_t* tw_fwd;   // [n]: w_n^(t bitrev_k1(r))
     const uint64_t* pw;       // [2^rate_bits][n]: (7 w_m^h)^p, half h = natural LDE index mod 2^rate_bits
-    uint32_t r16;
 };
 
 __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
@@ -370,12 +363,12 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
             n, [&](uint32_t i) -> uint64_t { return in[i]; },
             [&](uint32_t i, uint64_t v) { tile[lds_idx(gl::bitrev(i, a.log_n))] = v; });
         __syncthreads();
-        tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{}, a.r16 != 0);
+        tile_stages(tile, w2i, n, k2, 0, true, IdxPlain{});
         tile_loop<SIPP_NTT_MLP, uint64_t>(
             n, [&](uint32_t p) -> uint64_t { return a.tw_inv[p]; },
             [&](uint32_t p, uint64_t w) { tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], w); });
         __syncthreads();
-        tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{}, a.r16 != 0);
+        tile_stages(tile, w1i, n, k1, k2, true, IdxPlain{});
         uint64_t* co = a.coeffs + (size_t)col * n;
         tile_loop<SIPP_NTT_MLP, uint64_t>(
             n, [&](uint32_t p) -> uint64_t { return tile[lds_idx(p)]; }, [&](uint32_t p, uint64_t v) { co[p] = v; });
@@ -396,120 +389,17 @@ __global__ void __launch_bounds__(1024) lde_column_kernel(ColArgs a) {
                 [&](uint32_t p, Two v) { tile[lds_idx(p)] = gl::mul(v.a, v.b); });
         }
         __syncthreads();
-        tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{}, a.r16 != 0);
+        tile_stages(tile, w1f, n, k1, k2, false, IdxPlain{});
         tile_loop<SIPP_NTT_MLP, uint64_t>(
             n, [&](uint32_t p) -> uint64_t { return a.tw_fwd[p]; },
             [&](uint32_t p, uint64_t w) { tile[lds_idx(p)] = gl::mul(tile[lds_idx(p)], w); });
         __syncthreads();
-        tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{}, a.r16 != 0);
+        tile_stages(tile, w2f, n, k2, 0, false, IdxPlain{});
         // natural LDE index i = i' 2^rate_bits + h sits at leaf position bitrev(h) n + bitrev(i'): the DIF's own order
         uint64_t* out = a.lde + (size_t)col * a.lde_stride + (size_t)gl::bitrev(h, a.rate_bits) * n;
         tile_loop<SIPP_NTT_MLP, uint64_t>(
             n, [&](uint32_t p) -> uint64_t { return tile[lds_idx(p)]; }, [&](uint32_t p, uint64_t v) { out[p] = v; });
     }
-}
-
-// ---- 2^15 <= N <= 2^17: three sweeps instead of five ------------------------------------------------------------------
-//   lde_gather_kernel  inverse DIT over the LOW k2 position bits, reading the natural-order values directly: a tile is 16
-//                      blocks of 2^k2 positions that differ in their top four position bits, i.e. in the low four bits of
-//                      the natural index, so every global read is a full 128-byte line (no bit-reversal copy).
-//   lde_mid_kernel     tile = 2^k1 rows x 16 positions: twiddle (x 1/N), inverse DIT over the HIGH k1 bits -> natural
-//                      coefficients (stored); x 7^p; rows [2^k1, 2^(k1+1)) = 0; forward DIF over the top k1 + 1 bits of the
-//                      2N-point coset transform; twiddle; stored into the LDE buffer.  (The last iNTT pass and the first LDE
-//                      pass work on the same strided set of coefficients.)
-//   ntt_pass_kernel    the remaining low k2 bits of the 2N-point DIF, contiguous blocks (unchanged).
-struct GatherArgs {
-    const uint64_t* in;    // [ncols][n] values, natural order
-    uint64_t* out;         // [ncols][n] positions after the low-bit DIT
-    uint32_t log_n, k2;
-    const uint64_t* wr;    // w_R2^-x
-    uint32_t r16;
-};
-
-__global__ void __launch_bounds__(256) lde_gather_kernel(GatherArgs a) {
-    extern __shared__ uint64_t smem[];
-    const uint32_t k2 = a.k2, R2 = 1u << k2, E = 16u << k2;
-    const IdxBlocked lidx{k2};
-    uint64_t* tile = smem;
-    uint64_t* wr_s = smem + (E + (E >> LOG_SEG) + 16);
-    const uint32_t mid_bits = a.log_n - 4 - k2;
-    const uint32_t tiles_per_col = 1u << mid_bits;
-    const uint32_t col = blockIdx.x >> mid_bits, mid = blockIdx.x & (tiles_per_col - 1);
-    const uint64_t* in = a.in + ((size_t)col << a.log_n);
-    uint64_t* out = a.out + ((size_t)col << a.log_n);
-    for (uint32_t i = threadIdx.x; i < (R2 >> 1); i += blockDim.x) wr_s[i] = a.wr[i];
-    // natural index = bitrev(position): [bitrev(r) | bitrev(mid) | bitrev4(g)]
-    const uint32_t nat_mid = gl::bitrev(mid, mid_bits) << 4;
-    tile_loop<SIPP_NTT_MLP, uint64_t>(
-        E,
-        [&](uint32_t e) -> uint64_t {
-            const uint32_t gq = e & 15, r = e >> 4;
-            return in[(gl::bitrev(r, k2) << (a.log_n - k2)) | nat_mid | gq];
-        },
-        [&](uint32_t e, uint64_t v) {
-            const uint32_t gq = e & 15, r = e >> 4;
-            tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = v;
-        });
-    __syncthreads();
-    tile_stages(tile, wr_s, E, k2, 0, true, lidx, a.r16 != 0);
-    tile_loop<SIPP_NTT_MLP, uint64_t>(
-        E, [&](uint32_t e) -> uint64_t { return tile[lidx(e)]; },
-        [&](uint32_t e, uint64_t v) {
-            const uint32_t g = e >> k2, r = e & (R2 - 1);
-            out[((size_t)g << (a.log_n - 4)) | ((size_t)mid << k2) | r] = v;
-        });
-}
-
-struct MidArgs {
-    uint64_t* coeffs;        // [ncols][n]: in = positions after lde_gather_kernel, out = natural coefficients (in place)
-    uint64_t* lde;           // [ncols][2n]: positions of the 2n-point DIF after its top k1 + 1 bits
-    uint32_t log_n, k1;
-    const uint64_t* wr_inv;  // w_R1^-x, x < R1 / 2
-    const uint64_t* wr_fwd;  // w_(2 R1)^x, x < R1
-    const uint64_t* tw_inv;  // [n]   w_n^-(t bitrev_k1(r)) / n         at position r 2^k2 + t
-    const uint64_t* pw;      // [n]   7^p
-    const uint64_t* tw_fwd;  // [2n]  w_2n^(t bitrev_(k1+1)(r'))         at position r' 2^k2 + t
-    uint32_t r16;
-};
-
-__global__ void __launch_bounds__(512) lde_mid_kernel(MidArgs a) {
-    extern __shared__ uint64_t smem[];
-    const uint32_t k1 = a.k1, R1 = 1u << k1, k2 = a.log_n - k1;
-    const uint32_t E1 = R1 << 4, E2 = E1 << 1;          // T = 16
-    uint64_t* tile = smem;
-    uint64_t* wi = smem + (E2 + (E2 >> LOG_SEG));
-    uint64_t* wf = wi + (R1 >> 1);
-    const uint32_t tiles_per_col = 1u << (k2 - 4);
-    const uint32_t col = blockIdx.x / tiles_per_col;
-    const uint32_t i0 = (blockIdx.x - col * tiles_per_col) << 4;
-    uint64_t* co = a.coeffs + ((size_t)col << a.log_n);
-    uint64_t* lde = a.lde + ((size_t)col << (a.log_n + 1));
-    for (uint32_t i = threadIdx.x; i < (R1 >> 1); i += blockDim.x) wi[i] = a.wr_inv[i];
-    for (uint32_t i = threadIdx.x; i < R1; i += blockDim.x) wf[i] = a.wr_fwd[i];
-    // element e = r 16 + t  <->  position p = r 2^k2 + i0 + t
-    auto pos = [&](uint32_t e) -> size_t { return ((size_t)(e >> 4) << k2) + i0 + (e & 15); };
-    tile_loop<SIPP_NTT_MLP, Two>(
-        E1,
-        [&](uint32_t e) -> Two {
-            const size_t p = pos(e);
-            return Two{co[p], a.tw_inv[p]};
-        },
-        [&](uint32_t e, Two v) { tile[lds_idx(e)] = gl::mul(v.a, v.b); });
-    __syncthreads();
-    tile_stages(tile, wi, E1, k1, 4, true, IdxPlain{}, a.r16 != 0);
-    tile_loop<SIPP_NTT_MLP, uint64_t>(
-        E1, [&](uint32_t e) -> uint64_t { return a.pw[pos(e)]; },
-        [&](uint32_t e, uint64_t w) {
-            const uint64_t c = tile[lds_idx(e)];
-            co[pos(e)] = c;
-            tile[lds_idx(e)] = gl::mul(c, w);                 // coset shift 7^p
-            tile[lds_idx(e + E1)] = 0;                        // zero padding of the LDE: rows R1 .. 2 R1 - 1
-        });
-    __syncthreads();
-    tile_stages(tile, wf, E2, k1 + 1, 4, false, IdxPlain{}, a.r16 != 0);
-    tile_loop<SIPP_NTT_MLP, uint64_t>(
-        E2, [&](uint32_t e) -> uint64_t { return a.tw_fwd[pos(e)]; },
-        [&](uint32_t e, uint64_t w) { lde[pos(e)] = gl::mul(tile[lds_idx(e)], w); });
 }
 
 __global__ void bitrev_cols_kernel(const uint64_t* in, size_t in_stride, uint64_t* out, size_t out_stride,
@@ -549,30 +439,17 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(const uint64_t* __res
 
 // ---- host side: tables + pass planning -----------------------------------------------------
 
-// SIPP_NTT_RADIX16: bit 0 pass kernel, bit 1 whole-column, bit 2 gather, bit 3 fused middle.  Default all on: the radix-2^4
-// rounds need ~100 VGPRs instead of 38 and are NOT faster alone (lde_mid 1.74 vs 1.50 ms, lde_column 1.33 vs 1.09 ms for 67 M
-// elements; the pass kernel 5-10 % faster), but they execute fewer instructions, and the instance is bound by instruction issue:
-// 66.5-67.1 ms per n = 128 instance against 67.8-67.9 ms (25-step runs, same box, alternating).
-int ntt_r16_mask() {
-    static const int v = sipp_env_int("SIPP_NTT_RADIX16", 15);
-    return v;
-}
-
-// Tile size per transform size, measured (round 2): a 2^13-element tile would turn the THREE passes of log_n = 21, 22 (N = 2^21
-// traces, n = 4096) into two, but every pass on it is slower than the saved sweep is worth -- with 256 threads (32 elements per
-// lane) twice as slow (n = 4096: 1697 vs 1464 ms per instance), with 512 threads (two 72-KB blocks per CU) 315 + 143 ms of
-// transform time against 285 + 128 ms.  The light strided passes (4-5 stages) already run at 2.5-3 TB/s; 2^12 stays.
-int ntt_ltile() {
-    static const int v = [] {
-        const int t = sipp_env_int("SIPP_NTT_LTILE", 12);
-        return t < 8 ? 8 : t > 13 ? 13 : t;
-    }();
-    return v;
-}
+// Radix-2^4 register rounds in every transform kernel: ~100 VGPRs instead of 38 and NOT faster alone (lde_column 1.33 vs 1.09 ms for
+// 67 M elements; the pass kernel 5-10 % faster), but fewer instructions, and the instance is bound by instruction issue: 66.5-67.1 ms
+// per n = 128 instance against 67.8-67.9 ms (round 2, 25-step runs, same box, alternating).
+// Tile = 2^12 elements for every size, measured (round 2): a 2^13-element tile would turn the THREE passes of log_n = 21, 22 into
+// two, but every pass on it is slower than the saved sweep is worth (256 threads: n = 4096 1697 vs 1464 ms per instance; 512 threads:
+// 315 + 143 ms of transform time against 285 + 128 ms).
+constexpr uint32_t NTT_LTILE = 12;
 
 // ks[0] = highest index bits ... ks.back() = lowest (contiguous) bits
 std::vector<uint32_t> plan(uint32_t log_n) {
-    const uint32_t LT = (uint32_t)ntt_ltile();
+    const uint32_t LT = NTT_LTILE;
     std::vector<uint32_t> ks;
     if (log_n <= LT) {
         ks.push_back(log_n);
@@ -630,7 +507,6 @@ int pow_tables(sipp_ctx* ctx, int kind_lo, int kind_hi, uint64_t key_a, uint64_t
 }
 
 int run_pass(sipp_ctx* ctx, const char* name, PassArgs& a, size_t ncols) {
-    a.r16 = ntt_r16_mask() & 1;
     const uint32_t log_e = a.k + a.lt + a.lg;
     const size_t E = (size_t)1 << log_e;
     size_t shmem = (E + (E >> LOG_SEG) + ((size_t)1 << (a.k ? a.k - 1 : 0))) * sizeof(uint64_t);
@@ -657,7 +533,7 @@ int ntt_run(sipp_ctx* ctx, bool dit, const uint64_t* d_in, size_t in_stride, uin
     // lo[i] = sum of ks after i
     std::vector<uint32_t> lo(P, 0);
     for (size_t i = P; i-- > 0;) lo[i] = (i + 1 < P) ? lo[i + 1] + ks[i + 1] : 0;
-    const uint32_t LT = (uint32_t)ntt_ltile();
+    const uint32_t LT = NTT_LTILE;
 
     uint64_t *pw_lo = nullptr, *pw_hi = nullptr;
     uint32_t pw_L = 0;
@@ -770,11 +646,6 @@ uint64_t* col_pw_table(sipp_ctx* ctx, uint32_t log_n, uint32_t rate_bits) {
     return t;
 }
 
-bool fused_lde_enabled() {
-    static const bool v = getenv("SIPP_NTT_UNFUSED") == nullptr;
-    return v;
-}
-
 int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* d_coeffs, uint64_t* d_lde, size_t lde_stride,
                size_t ncols, uint32_t log_n, uint32_t rate_bits, bool from_coeffs) {
     ColArgs a{};
@@ -786,101 +657,38 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
     a.tw_inv = col_tw_table(ctx, log_n, a.k1, true);
     a.tw_fwd = col_tw_table(ctx, log_n, a.k1, false);
     a.pw = col_pw_table(ctx, log_n, rate_bits);
-    a.r16 = (ntt_r16_mask() >> 1) & 1;
     if (!a.wr1_inv || !a.wr2_inv || !a.wr1_fwd || !a.wr2_fwd || !a.tw_inv || !a.tw_fwd || !a.pw) return SIPP_E_HIP;
     const size_t n = (size_t)1 << log_n;
     const size_t shmem = (n + (n >> LOG_SEG) + ((size_t)1 << a.k1) + ((size_t)1 << a.k2)) * sizeof(uint64_t);
     if (shmem > 160 * 1024) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "lde_column: column does not fit LDS");
     if (shmem > 64 * 1024)
         SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    // threads per block (SIPP_LDE_COL_THREADS overrides): big blocks hide LDS latency when the kernel runs alone, small ones
-    // are placed sooner beside the other proofs' resident hash waves
-    static const int thr_env = sipp_env_int("SIPP_LDE_COL_THREADS", 0);
-    // measured at n = 128 (3 proofs concurrent): 256 threads 71.2 ms, 512 72.2, 1024 75.1, 128 72.1 per instance
-    const unsigned threads = thr_env ? (unsigned)thr_env : n >= 16384 ? 512 : 256;
+    // threads per block: big blocks hide LDS latency when the kernel runs alone, small ones are placed sooner beside the other
+    // proofs' resident hash waves; measured at n = 128 (3 proofs concurrent): 256 threads 71.2 ms, 512 72.2, 1024 75.1, 128 72.1
+    const unsigned threads = n >= 16384 ? 512 : 256;
     ProfScope ps(ctx, "lde_column");
     hipLaunchKernelGGL(lde_column_kernel, dim3((unsigned)ncols), dim3(threads), shmem, ctx->stream, a);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
 
-// 2^15 <= n <= 2^17, blowup 2: gather + low-bit DIT | fused middle | low-bit DIF of the 2n-point transform.
-// (Tried for 2^18 .. 2^21 as well -- 8 / 4 blocks per gather tile, one extra strided pass, 8- or 9-bit fused top: no gain, 7.1-7.8 ms
-// against 7.1-7.3 ms for 134 M elements.  The three per-element tables (16 + 8 + 8 B per input element) no longer fit the 4 MB L2
-// of an XCD there, and the 16384-element tile of a 9-bit top runs one block per CU; the pass-by-pass path keeps those sizes.)
-int lde_three_sweeps(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n) {
-    const uint32_t k1 = 8, k2 = log_n - k1;
-    const size_t n = (size_t)1 << log_n;
-    {
-        GatherArgs g{};
-        g.in = d_values; g.out = d_coeffs; g.log_n = log_n; g.k2 = k2;
-        g.wr = wr_table(ctx, k2, true);
-        g.r16 = (ntt_r16_mask() >> 2) & 1;
-        if (!g.wr) return SIPP_E_HIP;
-        const size_t E = (size_t)16 << k2;
-        const size_t shmem = (E + (E >> LOG_SEG) + 16 + ((size_t)1 << (k2 - 1))) * sizeof(uint64_t);
-        const size_t tiles = (n / E) * ncols;
-        if (tiles > 0x7fffffffull) return SIPP_E_UNSUPPORTED;
-        if (shmem > 64 * 1024)
-            SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        ProfScope ps(ctx, "lde_gather");
-        hipLaunchKernelGGL(lde_gather_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, g);
-        SIPP_CHECK_HIP(ctx, hipGetLastError());
-    }
-    {
-        MidArgs m{};
-        m.coeffs = d_coeffs; m.lde = d_lde; m.log_n = log_n; m.k1 = k1;
-        m.wr_inv = wr_table(ctx, k1, true);
-        m.wr_fwd = wr_table(ctx, k1 + 1, false);
-        m.tw_inv = col_tw_table(ctx, log_n, k1, true);
-        m.pw = col_pw_table(ctx, log_n, 1);               // first coset half = 7^p
-        m.tw_fwd = col_tw_table(ctx, log_n + 1, k1 + 1, false);
-        m.r16 = (ntt_r16_mask() >> 3) & 1;
-        if (!m.wr_inv || !m.wr_fwd || !m.tw_inv || !m.pw || !m.tw_fwd) return SIPP_E_HIP;
-        const size_t E2 = (size_t)32 << k1;
-        const size_t shmem = (E2 + (E2 >> LOG_SEG) + ((size_t)1 << (k1 - 1)) + ((size_t)1 << k1)) * sizeof(uint64_t);
-        const size_t tiles = (n >> (k1 + 4)) * ncols;
-        if (tiles > 0x7fffffffull) return SIPP_E_UNSUPPORTED;
-        SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)lde_mid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        ProfScope ps(ctx, "lde_mid");
-        static const int mid_thr = sipp_env_int("SIPP_LDE_MID_THREADS", 256);
-        hipLaunchKernelGGL(lde_mid_kernel, dim3((unsigned)tiles), dim3((unsigned)mid_thr), shmem, ctx->stream, m);
-        SIPP_CHECK_HIP(ctx, hipGetLastError());
-    }
-    {
-        // low k2 bits of the 2n-point DIF: contiguous blocks of 2^k2 positions, in place
-        PassArgs a{};
-        a.in = d_lde; a.out = d_lde; a.in_stride = a.out_stride = 2 * n;
-        a.log_n = log_n + 1; a.k = k2; a.log_m = k2; a.dit = 0; a.n_in = 2 * n;
-        const uint32_t LT = (uint32_t)ntt_ltile();
-        a.lt = 0;
-        a.lg = LT > k2 ? LT - k2 : 0;
-        a.wr = wr_table(ctx, k2, false);
-        if (!a.wr) return SIPP_E_HIP;
-        SIPP_TRY(run_pass(ctx, "ntt_dif_pass", a, ncols));
-    }
-    return SIPP_OK;
-}
-
 }  // namespace
 
-// values [ncols][n] natural -> coefficients [ncols][n] natural + LDE [ncols][n << rate_bits] in leaf order; d_coeffs may
-// alias d_values only on the unfused path (the fused kernels read a column completely before they write it: aliasing is fine there too)
+// values [ncols][n] natural -> coefficients [ncols][n] natural + LDE [ncols][n << rate_bits] in leaf order.  Whole column in LDS for
+// 2^10 .. 2^14 rows, the tree-of-rings sweeps of ntt_tree.hip from 2^15; anything else (shorter columns, d_coeffs aliasing d_values
+// on a long column) is SIPP_E_UNSUPPORTED and the caller runs the pass-by-pass path (bit-reversal copy, DIT, DIF).
 int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                          uint32_t rate_bits) {
-    if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
+    if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
-    // long columns: the tree-of-rings sweeps of ntt_tree.hip (SIPP_TREE_MIN_LOG, default 18; never below the whole-column range)
-    if (fused_lde_enabled() && log_n >= 15 && sipp_tree_ntt_enabled(log_n) && d_values != d_coeffs)
+    if (sipp_tree_ntt_enabled(log_n) && d_values != d_coeffs)
         return sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
-    if (fused_lde_enabled() && log_n >= 15 && log_n <= 17 && rate_bits == 1 && d_values != d_coeffs)
-        return lde_three_sweeps(ctx, d_values, d_coeffs, d_lde, ncols, log_n);
-    return SIPP_E_UNSUPPORTED;   // caller falls back to the pass-by-pass path
+    return SIPP_E_UNSUPPORTED;
 }
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {
-    if (fused_lde_enabled() && log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
+    if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_coeffs, (size_t)1 << log_n, nullptr, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, true);
-    if (fused_lde_enabled() && log_n >= 15 && sipp_tree_ntt_enabled(log_n)) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+    if (sipp_tree_ntt_enabled(log_n)) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
     return SIPP_E_UNSUPPORTED;
 }
 

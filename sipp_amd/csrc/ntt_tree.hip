@@ -415,10 +415,9 @@ uint64_t* tree_coset_table(sipp_ctx* ctx, uint32_t LM) {
     return t;
 }
 
-int tree_colfast() {
-    static const int v = sipp_env_int("SIPP_TREE_COLFAST", 1);
-    return v;
-}
+// grid order: column-fastest, so that the blocks in flight share the same few KB of node constants (tile-fastest measured equal:
+// 6.77 against 6.77 ms)
+constexpr int tree_colfast() { return 1; }
 
 // bits of the strided sweeps above the first `low` position bits, highest first, at most 8 each
 std::vector<uint32_t> split_bits(uint32_t rem) {
@@ -484,50 +483,10 @@ int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_
     return launch_pass<true, false>(ctx, "ntt_tree_fwd", a, halves);
 }
 
-// values [ncols][n] natural -> coefficients [ncols][n] natural (d_values != d_coeffs)
-int tree_inverse(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, size_t ncols, uint32_t L) {
-    const uint64_t* tw = tree_flat_table(ctx, L, true);
-    if (!tw) return SIPP_E_HIP;
-    const uint32_t k2 = 8;
-    {
-        GatherArgs g{};
-        g.in = d_values; g.out = d_coeffs; g.L = L; g.k2 = k2; g.tw = tw; g.ncols = (uint32_t)ncols;
-        g.colfast = (uint32_t)tree_colfast();
-        const size_t E = (size_t)16 << k2;
-        const size_t shmem = (E + (E >> LOG_SEG) + 16) * sizeof(uint64_t);
-        const size_t tiles = ((size_t)1 << (L - 4 - k2)) * ncols;
-        if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
-        ProfScope ps(ctx, "ntt_tree_gather");
-        hipLaunchKernelGGL(tree_gather_kernel, dim3((unsigned)tiles), dim3(256), shmem, ctx->stream, g);
-        SIPP_CHECK_HIP(ctx, hipGetLastError());
-    }
-    std::vector<uint32_t> ks = split_bits(L - k2);   // highest first: run them from the back
-    uint32_t lo = k2;
-    for (size_t i = ks.size(); i-- > 0;) {
-        const uint32_t k = ks[i];
-        TreeArgs a{};
-        a.in = d_coeffs; a.out = d_coeffs; a.in_stride = a.out_stride = (size_t)1 << L;
-        a.L = L; a.k = k; a.lo = lo;
-        a.lt = LTILE - k < lo ? LTILE - k : lo;
-        a.lg = 0; a.q0 = 0; a.tw = tw; a.ncols = (uint32_t)ncols;
-        a.scale = i == 0 ? gl::inv((uint64_t)1 << L) : 0;
-        SIPP_TRY((launch_pass<false, true>(ctx, "ntt_tree_inv", a, 1)));
-        lo += k;
-    }
-    return SIPP_OK;
-}
-
 }  // namespace
 
-static bool fused_tree_ok() {
-    static const bool v = getenv("SIPP_NTT_UNFUSED") == nullptr;
-    return v;
-}
-
-bool sipp_tree_ntt_enabled(uint32_t log_n) {
-    static const int lo = sipp_env_int("SIPP_TREE_MIN_LOG", 15);
-    return log_n >= (uint32_t)lo && log_n >= 12 && log_n <= 25;
-}
+// the tree sweeps take every column of 2^15 .. 2^25 rows (shorter ones fit LDS whole: ntt.hip lde_column)
+bool sipp_tree_ntt_enabled(uint32_t log_n) { return log_n >= 15 && log_n <= 25; }
 
 // values -> coefficients + LDE with the fused middle sweep: gather (8 bits) | strided inverse sweeps | middle (inverse top ki bits +
 // forward top kf bits of every half) | the forward tree's remaining sweeps.  Needs L >= 13 (a strided top sweep exists).
@@ -604,10 +563,8 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
 int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
                               uint32_t log_n, uint32_t rate_bits) {
     if (d_values == d_coeffs || ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
-    static const int fused = sipp_env_int("SIPP_TREE_FUSED_MID", 1);
-    if (fused && log_n >= 13) return tree_from_values_fused(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
-    SIPP_TRY(tree_inverse(ctx, d_values, d_coeffs, ncols, log_n));
-    return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+    if (log_n < 13) return SIPP_E_UNSUPPORTED;     // no strided top sweep to fuse into (never asked for: sipp_tree_ntt_enabled)
+    return tree_from_values_fused(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
 }
 
 int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
@@ -621,7 +578,7 @@ int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t*
 // that reads the coefficients from L2 and writes every point once, instead of a zero-padded 2^log_m transform in three (shorter
 // polynomials would make one tiny block per subtree: they stay with the pass-by-pass path)
 int sipp_tree_coset_eval(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_out, size_t ncols, uint32_t log_n, uint32_t log_m) {
-    if (!fused_tree_ok() || ncols == 0 || ncols > 0xffffffu || log_n < 10 || log_m < log_n || log_m - log_n > 15 || log_m > 25)
+    if (ncols == 0 || ncols > 0xffffffu || log_n < 10 || log_m < log_n || log_m - log_n > 15 || log_m > 25)
         return SIPP_E_UNSUPPORTED;
     return tree_forward(ctx, d_coeffs, d_out, ncols, log_n, log_m - log_n);
 }

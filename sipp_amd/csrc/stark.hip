@@ -271,15 +271,9 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
             c->gate_release = nullptr;
         }
     } gate_guard{ctx};
-    // where a gated proof waits: before its first launch (SIPP_GATE_POINT=0, the default until round 3's last day); after its own trace
-    // fill, in front of its first fat kernel (1: measured 59.7 against 58.7 ms per n = 128 instance -- the wide fill kernels disturb
-    // G2's); or inside its trace fill, after the thin doubling / scan chain and before the first wide kernel (2, the default:
-    // trace.hip gate_after_chain -- 0.3 ms better than 0 over five alternating pairs; a kind without such a chain waits as under 1)
-    static const int gate_point = [] { const char* e = getenv("SIPP_GATE_POINT"); return e ? atoi(e) : 2; }();   // three host threads get here at once
-    if (ctx->gate_wait && gate_point == 0) {
-        ctx->gate_wait->wait();
-        ctx->gate_wait = nullptr;
-    }
+    // where a gated proof waits: inside its trace fill, after the thin doubling / scan chain and before the first wide kernel
+    // (trace.hip gate_after_chain; a kind without such a chain waits after its trace fill).  Measured alternatives: before the first
+    // launch +0.3 ms per n = 128 instance over five alternating pairs; after the whole trace fill 59.7 against 58.7 ms.
     SIPP_CHECK_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread may be new (one host thread per ctx)
     const sipp_stark_config& cfg = ctx->cfg;
     Shape s;
@@ -907,13 +901,10 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     // The other two proofs start once the longest (G2) has its trace filled: its latency-bound chains and lookup kernels
     // are otherwise crowded out by the others' long-running hash workgroups and G2 ends last by ~10 ms (n = 128: 73.3 ->
     // 70.2 ms per instance; n = 1024: neutral; releasing after G2's trace COMMIT instead: 75-81 ms; Fq12 first: 71-72 ms).
-    // SIPP_INSTANCE_GATE overrides which kinds wait (bit k = sipp_kind k; 0 = none).
     const int first = SIPP_G2_EXP;
     // round 2 (fused LDE kernels): only G1 waits -- 69.0-69.6 ms per n = 128 instance against 70.0-70.6 with Fq12 gated too
-    static const int gate_mask = [] {
-        const char* e = getenv("SIPP_INSTANCE_GATE");
-        return (e ? atoi(e) : (1 << SIPP_G1_EXP)) & ~(1 << SIPP_G2_EXP);
-    }();   // several queue slots (sipp_instances_prove) get here at once
+    // (re-swept in round 3 on the new kernels: no gate 60.6-61.4, Fq12 gated too 69.2-69.5 against 58.2-58.9 ms)
+    constexpr int gate_mask = 1 << SIPP_G1_EXP;
     const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     sipp_gate gate;
     int started[3] = {0, 0, 0}, rc = SIPP_OK;

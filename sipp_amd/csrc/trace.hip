@@ -1239,11 +1239,10 @@ int sipp_fold_chain_finish(sipp_ctx* ctx, int kind, uint32_t* d_ios, uint32_t nu
 
 // d_ios: [num_io][pi_per_io] u32 on the device (padded); d_trace: [W][n] zero-initialised by the caller is NOT
 // required: every main column is written here.  d_err: device int, 0 on entry.
-// SIPP_GATE_POINT=2 (the default): a gated proof of an instance (stark.hip: G1 behind G2's trace fill) has its thin doubling / scan
+// a gated proof of an instance (stark.hip: G1 behind G2's trace fill) has its thin doubling / scan
 // chain -- 16 waves, 1.5 ms of pure latency -- in flight while it waits; everything wider starts after the gate
 static void gate_after_chain(sipp_ctx* ctx) {
-    static const int gate_point = sipp_env_int("SIPP_GATE_POINT", 2);
-    if (ctx->gate_wait && gate_point == 2) {
+    if (ctx->gate_wait) {
         ctx->gate_wait->wait();
         ctx->gate_wait = nullptr;
     }
@@ -1438,13 +1437,8 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         }
         {
             ProfScope ps(ctx, "lookup_fill");
-            static const int fill_search = sipp_env_int("SIPP_LOOKUP_FILL_SEARCH", 0);
-            if (fill_search)
-                hipLaunchKernelGGL(lookup_fill_kernel, dim3(4096), dim3(256), 0, ctx->stream, start, dist, zlist, nzero, n,
-                                   (uint32_t)nc, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
-            else
-                hipLaunchKernelGGL(lookup_expand_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)nc), dim3(256), 0, ctx->stream, hist,
-                                   start, dist, zlist, nzero, n, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
+            hipLaunchKernelGGL(lookup_expand_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)nc), dim3(256), 0, ctx->stream, hist,
+                               start, dist, zlist, nzero, n, tb, d_trace + (size_t)nm * n, d_trace + (size_t)(nm + nc) * n);
         }
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }

@@ -3,6 +3,13 @@ no data-path collective); torch.distributed is used only for the barrier and the
 import os
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -39,13 +46,19 @@ def whole_job_rate(units_per_rank, world, max_step_seconds):
     return world * units_per_rank / max_step_seconds
 
 
-def init_process_group(world, local_rank, rehearsal=False):
+def init_process_group(world, local_rank, rehearsal=False, single_rank_group=False):
     """one process per GPU over RCCL (backend "nccl" on ROCm); rehearsal = every rank on one GPU over gloo, the only
-    difference being the backend and the device of the timing tensor.  No-op for a single rank."""
-    if world <= 1:
+    difference being the backend and the device of the timing tensor.  No-op for a single rank -- unless `single_rank_group`
+    asks for a group of one (a one-GPU box can then run the RCCL branch itself: barrier and the reductions on device tensors)."""
+    if world <= 1 and not single_rank_group:
         return "cpu"
     import torch
     import torch.distributed as dist
+    if world <= 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if rehearsal:
         dist.init_process_group("gloo")
         return "cpu"

@@ -125,3 +125,47 @@ def test_eight_rank_gloo_shards_of_the_large_configs(tmp_path):
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert all((tmp_path / ("rank%d.ok" % r)).exists() for r in range(8)), out.stdout + out.stderr
+
+
+def test_bare_bench_builds_the_launcher_command_line(monkeypatch):
+    """`python bench.py --gpus N` with no launcher starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same flags>` as a child, relays its stdout and returns its exit code"""
+    import io
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, cwd=None, stdout=None, text=None):
+            seen.update(cmd=cmd, env=env, cwd=cwd)
+            self.stdout = io.StringIO('{"n_gpus": 8}\n')
+
+        def wait(self):
+            return 3
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setenv("RANK", "5")
+    rc = bench.launch_ranks(8, ["--gpus", "8", "--steps", "4", "--warmup", "1"])
+    assert rc == 3
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "RANK" not in seen["env"]
+
+
+def test_bare_bench_without_a_gpu_passes_the_ranks_failure_on():
+    """no GPU in this container: the two ranks the bare invocation starts refuse to run (no CPU fallback), the parent relays that
+    as a non-zero exit code and prints no JSON line -- and it is the CHILDREN that were asked, i.e. the launch happened"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU box: tests/test_gpu_multi.py::test_bare_bench_starts_its_own_ranks runs the real thing")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "needs a GPU" in out.stderr and out.stderr.count("needs a GPU") >= 2
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -77,13 +77,14 @@ def test_bench_four_ranks_rehearsal_shards_the_n1024_instance():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("n,log_n,records", [(1024, 16, {0: [127, 127, 2], 3: [128, 128, 3], 7: [128, 128, 3]}),
+@pytest.mark.parametrize("n,log_n,records", [(1024, 16, {0: [127, 127, 2], 1: [128, 128, 3], 2: [128, 128, 2], 3: [128, 128, 3], 4: [128, 128, 2],
+                                                         5: [128, 128, 3], 6: [128, 128, 2], 7: [128, 128, 3]}),
                                              (4096, 18, {0: [511, 511, 3], 3: [512, 512, 3], 7: [512, 512, 3]})])
 def test_world8_shards_of_the_large_configs(n, log_n, records):
     """BASELINE configs[3] / configs[4]: the shards an 8-rank run proves -- n = 1024: 127 / 128 G1 and G2 records (N = 2^16)
     and 2 / 3 Fq12 records (the two-IO-block minimum and a padded block); n = 4096: 511 / 512 records, N = 2^18, the first
-    size outside the fused LDE kernels' range, with ragged 511-record lists padded by one copy.  Ranks 0, 3 and 7 through
-    sipp_instance_prove exactly as bench.py's io_sharded leg does: the oracle's verifier accepts every proof, the public
+    size outside the fused LDE kernels' range, with ragged 511-record lists padded by one copy.  ALL EIGHT ranks of n = 1024
+    (cheap: N = 2^16) and ranks 0, 3 and 7 of n = 4096 through sipp_instance_prove exactly as bench.py's io_sharded leg does: the oracle's verifier accepts every proof, the public
     inputs are the rank's slice (padding = copies of its last record), and a single ctx gives the same words."""
     import sipp_amd
     from tests import _oracle
@@ -118,14 +119,71 @@ def test_world8_shards_of_the_large_configs(n, log_n, records):
                 assert len(alone) == len(pf) and (alone == pf).all(), (rank, k)
 
 
-def test_bench_refuses_a_gpu_count_it_was_not_launched_with():
-    """`python bench.py --gpus 2` without a launcher must not report a one-GPU number as the 2-GPU leg"""
+def test_bench_refuses_a_launcher_with_the_wrong_world_size():
+    """a launcher that hands `bench.py --gpus 2` a WORLD_SIZE of 1 must not get a one-GPU number reported as the 2-GPU leg"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    env["WORLD_SIZE"] = "1"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                         capture_output=True, text=True, timeout=300, cwd=ROOT,
-                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0
     assert "torch.distributed.run" in (out.stdout + out.stderr)
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.timeout(1200)
+def test_bare_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (how the driver invokes `--gpus 1`): the process starts the two ranks itself
+    before it touches the GPU, relays rank 0's one line and its exit code.  Rehearsal mode = both ranks on GPU 0 over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SIPP_BENCH_REHEARSAL="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_HARDENED="0", SIPP_BENCH_MAP_G2="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert abs(r["value"] - 2 * 128 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    assert r["io_sharded"]["n=128"]["ranks"] == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_timing_contract_over_rccl_with_one_rank():
+    """the `nccl` (= RCCL) branch of dist_util.init_process_group has never had more than this box's one GPU: run it with a
+    process group of ONE rank -- bench.py's barrier, max-over-ranks and (min, max)-over-ranks reductions on DEVICE tensors
+    through RCCL, around the real timed region and the io_sharded leg"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(SIPP_BENCH_SINGLE_RANK_GROUP="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_HARDENED="0", SIPP_BENCH_MAP_G2="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--inflight", "1"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["timing_reduction"] == "nccl:cuda"
+    assert abs(r["value"] - 128 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+    lo, hi = r["io_sharded"]["n=128"]["rank_ms_per_instance_min_max"]
+    assert 0 < lo <= hi
+
+
+def test_dist_util_reductions_on_device_tensors_over_rccl():
+    """dist_util's helpers themselves over a one-rank RCCL group, in a child process (a process group is process state)"""
+    code = ("import os, torch\n"
+            "from sipp_amd import dist_util as du\n"
+            "torch.cuda.set_device(0)\n"
+            "dev = du.init_process_group(1, 0, single_rank_group=True)\n"
+            "import torch.distributed as dist\n"
+            "assert dev == 'cuda' and dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+            "du.barrier(torch.cuda.synchronize)\n"
+            "assert du.max_over_ranks(1.25, device=dev) == 1.25\n"
+            "assert du.min_max_over_ranks(2.5, device=dev) == (2.5, 2.5)\n"
+            "t, last = du.timed_steps(lambda: 7, 3, 1, sync=torch.cuda.synchronize, device=dev)\n"
+            "assert last == 7 and t > 0\n"
+            "dist.destroy_process_group()\n"
+            "print('rccl one-rank ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "rccl one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_instance_over_all_visible_devices_matches_single_device():
