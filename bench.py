@@ -12,6 +12,10 @@ Multi-GPU (--gpus N, launched by torch.distributed.run): the path shards by inde
 (level L-A): every rank proves its own instance, no data-path collective, weak
 scaling; value = N * 128 / max-over-ranks step time.
 
+AIR variant: since round 4 the timed region proves G1 / G2 with the HARDENED AIRs (API kinds 4 / 5, sipp_ctx_set_hardened) -- the plain
+kinds' chord rule is forgeable for crafted statements; the plain kinds (this repository's reading of the
+recalled upstream AIR) are timed beside it as `recalled_upstream_air`.  SIPP_BENCH_PLAIN_AIR=1 swaps the two.
+
 A secondary object `io_sharded` times ONE larger instance cut into `world` ranges of obligations (level L-D, strong scaling,
 no collective either).
 
@@ -31,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (spec)
 NTT_KERNELS = ("lde_column", "lde_gather", "lde_mid", "ntt_dif_pass", "ntt_dit_pass", "bitrev_cols", "ntt_tree_gather", "ntt_tree_inv",
                "ntt_tree_mid", "ntt_tree_fwd")
-PMC_FILE = "r03_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
+PMC_FILE = "r04_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
 
 
 def load_ios(n):
@@ -39,7 +43,7 @@ def load_ios(n):
     return [d["g1"], d["g2"], d["fq12"]]
 
 
-def cpu_baseline(ios, shapes, budget_s=150.0):
+def cpu_baseline(ios, shapes, kinds, budget_s=150.0):
     """The CPU restatement (oracle/stark.c, OpenMP -- a `port`, not the reference's Rust binary, which cannot be built here)
     timed on the SAME workload as the GPU line: the three full-size n = 128 sub-proofs, one after the other, measured not
     scaled.  Threads = the box's CPU share (16 for one GPU; the oracle does not get faster beyond it: G1 with 32 IO records
@@ -58,23 +62,23 @@ def cpu_baseline(ios, shapes, budget_s=150.0):
             secs.append(secs[0] * cells[k] / cells[0])
             continue
         t = time.time()
-        pf = _oracle.stark_prove(k, ios[k])
+        pf = _oracle.stark_prove(kinds[k], ios[k])
         secs.append(time.time() - t)
-        assert int(pf[2]) == shapes[k][0] and int(pf[4]) == shapes[k][1]      # the same AIR variant / shape as the GPU line
+        assert int(pf[1]) == kinds[k] and int(pf[2]) == shapes[k][0] and int(pf[4]) == shapes[k][1]      # the same AIR variant / shape as the GPU line
     total = sum(secs)
     n = ios[0].shape[0] + 1
     return {"value": n / total, "unit": "pairings/s", "cores": threads, "kind": "port",
             "seconds": [round(x, 2) for x in secs], "measured": measured,
-            "sample": "oracle/stark.c (OpenMP, %d threads) on the full workload of this line: the G1 / G2 / Fq12 sub-proofs of the "
-                      "n = %d instance took %s s%s" % (threads, n, " + ".join("%.1f" % x for x in secs),
+            "sample": "oracle/stark.c (OpenMP, %d threads) on the full workload of this line: the G1 / G2 / Fq12 sub-proofs (kinds %s) of the "
+                      "n = %d instance took %s s%s" % (threads, "/".join(str(k) for k in kinds), n, " + ".join("%.1f" % x for x in secs),
                                                      "" if measured else " (only the first measured, the others scaled by committed cells)")}
 
 
 def air_revision():
     """the AIR is this repository's own specification (tools/air_gen.py): identify the revision the numbers belong to"""
     import hashlib
-    h = hashlib.sha256(open(os.path.join(ROOT, "sipp_amd", "csrc", "air_tables.h"), "rb").read()).hexdigest()[:12]
-    return "air_tables.h sha256 %s (permuted lookups with independent (beta, gamma), statement-bound Fiat-Shamir)" % h
+    h = hashlib.sha256(open(os.path.join(ROOT, "data", "air_tables.h"), "rb").read()).hexdigest()[:12]
+    return "data/air_tables.h sha256 %s (permuted lookups with independent (beta, gamma), statement-bound Fiat-Shamir)" % h
 
 
 def ntt_roofline(shapes, kernel_ms_serial):
@@ -166,10 +170,15 @@ def main():
     # one ctx (= one HIP stream + workspace arena) and one host thread per STARK: the three sub-proofs are
     # independent, so their thin kernels and Fiat-Shamir round trips overlap.
     # The threads are the library's own (sipp_instance_prove = 3 x sipp_prove_async + sipp_wait).
-    prios = os.environ.get("SIPP_BENCH_PRIOS", "low,,high").split(",")   # G1, G2, Fq12
-    ws = [sipp_amd.lib().sipp_workspace_bytes(k, ios[k].shape[0]) for k in range(3)]
-    inst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios)
-    ctxs = inst.ctxs
+    # stream levels of G1, G2, Fq12; None = sipp_amd.Instance's default for the AIR variant
+    prios = os.environ["SIPP_BENCH_PRIOS"].split(",") if "SIPP_BENCH_PRIOS" in os.environ else None
+    hardened = not int(os.environ.get("SIPP_BENCH_PLAIN_AIR", "0"))
+    kinds = [4, 5, 2] if hardened else [0, 1, 2]
+    ws = [sipp_amd.lib().sipp_workspace_bytes(kinds[k], ios[k].shape[0]) for k in range(3)]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, priorities=prios, hardened=hardened)
+    ctxs = inst.distinct_ctxs()
+    if inst.single_ctx:
+        ctxs = ctxs * 3
     ctx = ctxs[0]
     shapes = [ctx.shape(k, ios[k].shape[0]) for k in range(3)]
     serial = bool(int(os.environ.get("SIPP_BENCH_SERIAL", "0")))
@@ -188,14 +197,13 @@ def main():
 
     def device_sync():
         torch.cuda.synchronize()
-        for c in ctxs:
-            c.sync()
+        inst.sync()
 
     def barrier():
         dist_util.barrier(device_sync)
 
     def start_profiling():
-        for c in ctxs:
+        for c in inst.distinct_ctxs():
             c.profile(True)
             c.profile_reset()
         proof_ms[:] = [0.0, 0.0, 0.0]
@@ -204,7 +212,7 @@ def main():
     elapsed, proofs = dist_util.timed_steps(step, args.steps, args.warmup, sync=device_sync, device=red_device,
                                             before_timing=start_profiling)
     prof = {}
-    for c in ctxs:
+    for c in inst.distinct_ctxs():
         for k, v in c.profile_report().items():
             e = prof.setdefault(k, {"calls": 0, "ms": 0.0})
             e["calls"] += v["calls"]
@@ -220,7 +228,8 @@ def main():
     pipelined = None
     if args.inflight > 1 and not serial and sum(ws) * (args.inflight + 1) < (240 << 30):
         # sipp_instances_prove: `inflight` slots of three ctxs take the instances of a queue from a shared counter
-        queue = sipp_amd.InstanceQueue([a.shape[0] for a in ios], in_flight=args.inflight, device=local_rank, priorities=prios)
+        queue = sipp_amd.InstanceQueue([a.shape[0] for a in ios], in_flight=args.inflight, device=local_rank, priorities=prios,
+                                       hardened=hardened)
         queue.prove([ios] * args.inflight)
         barrier()
         tp = time.perf_counter()
@@ -236,13 +245,13 @@ def main():
     # other proofs' kernels competing for the SIMDs
     kernel_ms_serial = None
     if rank == 0 and not serial:
-        for c in ctxs:
+        for c in inst.distinct_ctxs():
             c.profile(True)
             c.profile_reset()
         for k in range(3):
             ctxs[k].prove(k, ios[k])
         kernel_ms_serial = {}
-        for c in ctxs:
+        for c in inst.distinct_ctxs():
             for k, v in c.profile_report().items():
                 kernel_ms_serial[k] = kernel_ms_serial.get(k, 0.0) + v["ms"]
             c.profile(False)
@@ -269,6 +278,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", PMC_FILE)
         if args.n == 128 and os.path.exists(tpath):
             pmc = json.load(open(tpath))
+            if pmc.get("kinds", [0, 1, 2]) != kinds:      # counters of the other AIR variant do not belong to this line
+                pmc = {}
         issue_peak = 256 * 4 * 2.4e9 / 2 / 1e9    # G wave-instructions/s: 1024 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz
 
         def leaf_entry(kind, prof_name):
@@ -308,7 +319,8 @@ def main():
                              "frac": ach / issue_peak, "mix_ceiling": issue_peak / 1.5, "frac_of_mix_ceiling": ach / (issue_peak / 1.5),
                              "source": "profiles/%s (static: rocprofv3 --pmc SQ_INSTS_VALU of this command)" % PMC_FILE}
         out = {
-            "metric": "SIPP proof-gen wall-clock + pairings-aggregated/sec, n=%d (the 3 STARK sub-proofs; outer plonky2 proof not included)" % args.n,
+            "metric": "SIPP proof-gen wall-clock + pairings-aggregated/sec, n=%d (the 3 STARK sub-proofs, %s; outer plonky2 proof not included)"
+                      % (args.n, "hardened G1/G2 AIRs" if hardened else "plain G1/G2 AIRs: forgeable for crafted statements, see hardened_instance"),
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
@@ -321,6 +333,10 @@ def main():
                                                ios[2].shape[0], shapes[2][0], sum(shapes[2][1:])),
                        "stark_config": "rate_bits=1 cap_height=4 pow_bits=16 arity=16 queries=84 challenges=2 pow_rule=duplex",
                        "air_revision": air_revision(),
+                       "air_variant": ("hardened G1 / G2 exponentiation AIRs (API kinds 4 / 5: canonical x3, x-inequality witness, R = +-P proved; "
+                                       "+14 % columns) + Fq12ExpStark (kind 2)") if hardened else
+                                      "plain G1 / G2 exponentiation AIRs (kinds 0 / 1: incomplete chord rows as recalled from upstream) + Fq12ExpStark",
+                       "kinds": kinds,
                        "columns": {"G1ExpStark": {"log_n": shapes[0][0], "W": shapes[0][1], "P": shapes[0][2], "Q": shapes[0][3]},
                                    "G2ExpStark": {"log_n": shapes[1][0], "W": shapes[1][1], "P": shapes[1][2], "Q": shapes[1][3]},
                                    "Fq12ExpStark": {"log_n": shapes[2][0], "W": shapes[2][1], "P": shapes[2][2], "Q": shapes[2][3]}},
@@ -418,30 +434,34 @@ def main():
                                 "entry_points": "sipp_map_to_g2, sipp_map_to_g2_prove"}
         except Exception as e:                  # noqa: BLE001
             out["map_to_g2"] = {"error": repr(e)}
-        # secondary, outside the timed region: the same instance with the HARDENED G1 / G2 AIRs (kinds 4 / 5, DESIGN.md section 1:
-        # canonical x3 + x-inequality witness, +11 % columns) -- the price of closing the exceptional-addition case, stated next to
-        # the headline that keeps the plain AIR.  Three ctxs of their own with sipp_ctx_set_hardened, through sipp_instance_prove.
+        # secondary, outside the timed region: the same instance with the OTHER AIR variant of G1 / G2 -- by default the plain kinds 0 / 1
+        # (this repository's reading of the recalled upstream AIR, starky-bn254's incomplete chord rows: forgeable for crafted
+        # statements; 14 % fewer columns), next to the headline that proves the hardened kinds 4 / 5.  Three
+        # ctxs of their own, through sipp_instance_prove, sipp_amd.Instance's default stream levels for that variant.
+        other_key = "recalled_upstream_air" if hardened else "hardened_instance"
         try:
-            if os.environ.get("SIPP_BENCH_HARDENED", "1") in ("0", ""):
-                raise RuntimeError("skipped (SIPP_BENCH_HARDENED=0)")
-            hinst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3,
-                                      priorities=prios if "SIPP_BENCH_PRIOS" in os.environ else None, hardened=True)
+            if os.environ.get("SIPP_BENCH_OTHER_AIR", "1") in ("0", ""):
+                raise RuntimeError("skipped (SIPP_BENCH_OTHER_AIR=0)")
+            oinst = sipp_amd.Instance([a.shape[0] for a in ios], devices=(local_rank,) * 3, hardened=not hardened)
             try:
-                hinst.prove(ios)
+                oinst.prove(ios)
                 t = time.perf_counter()
                 for _ in range(10):
-                    hp = hinst.prove(ios)
+                    hp = oinst.prove(ios)
                 t_h = (time.perf_counter() - t) / 10
-                out["hardened_instance"] = {"kinds": [int(x[1]) for x in hp], "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
-                                            "columns": [list(hinst.ctxs[i].shape(i, ios[i].shape[0])) for i in range(3)],
-                                            "proof_words": [int(len(x)) for x in hp],
-                                            "entry_point": "sipp_instance_prove on ctxs with sipp_ctx_set_hardened"}
+                out[other_key] = {"kinds": [int(x[1]) for x in hp], "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
+                                  "columns": [list(oinst.ctxs[i].shape(i, ios[i].shape[0])) for i in range(3)],
+                                  "proof_words": [int(len(x)) for x in hp],
+                                  "entry_point": "sipp_instance_prove" + ("" if hardened else " on ctxs with sipp_ctx_set_hardened"),
+                                  "note": ("plain G1 / G2 AIRs: where the accumulator meets the running power on an add row the chord rule leaves "
+                                           "the slope free (tests/test_oracle_hardened.py builds the forgery); not the default since round 4")
+                                          if hardened else "hardened G1 / G2 AIRs (kinds 4 / 5)"}
             finally:
-                hinst.close()
+                oinst.close()
         except Exception as e:                  # noqa: BLE001
-            out["hardened_instance"] = {"error": repr(e)}
+            out[other_key] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ios, shapes)
+            out["cpu_baseline"] = cpu_baseline(ios, shapes, kinds)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
@@ -458,8 +478,9 @@ def main():
         io_sharded = {}
         for n_s in [int(x) for x in shard_sizes.split(",")]:
             mine = sipp_amd.shard_ios(load_ios(n_s), world, rank)
-            si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios)
+            si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios, hardened=hardened)
             k_s = 2
+            si_single = si.single_ctx
             own = []
             dts, _ = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
                                            device=red_device, local_out=own)
@@ -470,7 +491,10 @@ def main():
                                         "scaling": "strong" if world > 1 else "baseline (whole instance on one GPU)",
                                         "ranks": world, "steps": k_s,
                                         "rank_ms_per_instance_min_max": [1e3 * lo / k_s, 1e3 * hi / k_s],
-                                        "host_threads_per_rank": 4,
+                                        "host_threads_per_rank": 1 if si_single else 4,
+                                        # True: one ctx / one arena, the three proofs back to back (the three arenas together would
+                                        # exceed 60 % of the card's memory: n = 4096 on one rank)
+                                        "single_ctx": si_single, "kinds": kinds,
                                         "records_of_rank0": [int(a.shape[0]) for a in mine]}
     if rank == 0:
         out["io_sharded"] = io_sharded

@@ -74,7 +74,8 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
                 * an addition is used, an inequality witness for the two x-coordinates -- the chord rule of the plain AIR is satisfied by
                 * ANY slope where the accumulator meets the running power; that case (R = P) is proved through the
                 * next row's double and R = -P through an identity state bit instead of being refused: every record whose OUTPUT is a
-                * finite point has a proof.  Through sipp_prove / sipp_prove_async and the generic size / shape / trace functions. */
+                * finite point has a proof, except one that meets R = P on the LAST add row of its 512 rows (bit 255 of a 256-bit exponent:
+                * no row is left to hand the double over) -- SIPP_E_WITNESS, like an output at the identity.  Through sipp_prove / sipp_prove_async and the generic size / shape / trace functions. */
                SIPP_G1_EXP_HARDENED = 4, SIPP_G2_EXP_HARDENED = 5 } sipp_kind;
 
 /* u32 words per IO record, (x, offset, exp_val, output) order:
@@ -86,16 +87,20 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
 #define SIPP_MAP_G2_IO_WORDS 48
 
 /* ---- context ---------------------------------------------------------------- */
-/* `workspace_bytes` of HBM are reserved once; nothing is hipMalloc'ed afterwards.
+/* `workspace_bytes` of HBM are reserved once; afterwards the only allocations are the constant tables of a transform SIZE at its
+ * first use on the ctx (twiddles / node constants: at most 8 B per LDE row, built on the host once and kept until destroy).
  * Pass 0 to size the arena for n = 128 (about 24 GiB). */
 int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t workspace_bytes);
 void sipp_ctx_destroy(sipp_ctx *ctx);
 /* The ctx's HIP stream: level > 0 = a stream of the highest priority the device offers; level <= 0 = a stream with a hardware
  * queue of its own at normal priority (created with an all-ones CU mask: the runtime multiplexes ordinary streams onto a pool of
  * four queues, such a stream is kept out of the pool -- measured 1.5 ms per n = 128 instance; level < 0 used
- * to mean the lowest priority and still does under SIPP_DEDICATED_QUEUES=0).  With the three proofs of an instance on three ctxs:
- * G1 and G2 <= 0, Fq12 high.  Only while no proof is in flight on the ctx.  (SIPP_STREAM_PRIORITY=high|low in the environment sets
- * the level at sipp_ctx_create.) */
+ * to mean the lowest priority and still does under SIPP_DEDICATED_QUEUES=0).  Such a stream is BLOCKING with respect to the legacy
+ * default (NULL) stream -- hipExtStreamCreateWithCUMask takes no flags -- whereas the high-priority stream is hipStreamNonBlocking:
+ * an embedder that launches on the NULL stream serialises with the level <= 0 ctxs (not with a level > 0 one); launch on streams
+ * of your own (or per-thread default streams), or run with SIPP_DEDICATED_QUEUES=0 (every ctx stream non-blocking, the runtime's
+ * queue pool, about 1 ms per n = 128 instance).  With the three proofs of an instance on three ctxs:
+ * G1 and G2 <= 0, Fq12 high.  Only while no proof is in flight on the ctx.  sipp_ctx_create makes a level-0 stream. */
 int sipp_ctx_set_stream_priority(sipp_ctx *ctx, int level);
 /* on != 0: on this ctx the kinds SIPP_G1_EXP / SIPP_G2_EXP mean the HARDENED AIRs (SIPP_G1_EXP_HARDENED / SIPP_G2_EXP_HARDENED below) in
  * every call that takes the ctx -- sipp_g1_exp_prove, sipp_prove_async, sipp_instance_prove, sipp_instances_prove, sipp_proof_size,
@@ -133,7 +138,11 @@ int sipp_wait(sipp_ctx *ctx, size_t *proof_len);
 /* One SIPP instance = the three sub-proofs, concurrently on three DISTINCT ctxs (one HIP stream each; they may sit
  * on one GPU or on up to three GPUs, SURVEY.md section 8e level L-B).  Arrays are indexed by sipp_kind.  Returns the
  * first failing status; every proof that was started is waited for in any case.  num_io[k] == 0 skips kind k
- * (proof_len[k] = 0). */
+ * (proof_len[k] = 0).
+ * ctxs[0] == ctxs[1] == ctxs[2]: ONE ctx, the three proofs back to back on its stream and arena (workspace = the largest of the
+ * three sipp_workspace_bytes) -- for the large configurations, where one proof's kernels fill the chip and three concurrent
+ * arenas would not fit: n = 4096 needs 159 GB this way instead of 246 GB (181 / 279 GB with the hardened AIRs) and runs within 2 %
+ * of the three-stream time.  Two equal handles and a third are SIPP_E_BADARG. */
 int sipp_instance_prove(sipp_ctx *const ctxs[3], const uint32_t *const ios[3], const size_t num_io[3],
                         uint64_t *const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]);
 /* A queue of `count` independent instances on one GPU (or several): `in_flight` slots of three distinct ctxs each
@@ -162,6 +171,9 @@ size_t sipp_proof_size(const sipp_ctx *ctx, int kind, size_t num_io);
 size_t sipp_workspace_bytes(int kind, size_t num_io);
 /* the same for a non-default configuration (the LDEs grow with the blowup 2^rate_bits); cfg == NULL = default */
 size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config *cfg);
+/* memory of GPU `device` in bytes (hipMemGetInfo): what is free now and what the card has -- to decide between three concurrent
+ * arenas and one (sipp_instance_prove).  Either pointer may be NULL. */
+int sipp_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
 /* trace shape the prover will use: rows (log2), main columns, permutation-Z columns, quotient chunks */
 int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log_rows, uint32_t *main_cols,
                      uint32_t *perm_cols, uint32_t *quotient_cols);

@@ -15,17 +15,17 @@
 #include <string.h>
 
 /* API kinds: 0 g1, 1 g2, 2 fq12, 3 mapg2, 4 / 5 = the hardened g1 / g2 AIRs (same records, same rows; air->kind stays 0 / 1) */
-const orc_air_t *orc_air_get(int kind, unsigned log_n) {
+const air_spec_t *orc_air_get(int kind, unsigned log_n) {
     int mode_u16 = log_n >= 16, hard = kind >= 4;
     if (kind < 0 || kind > 5) return NULL;
     int base = hard ? kind - 4 : kind;
-    for (size_t i = 0; i < sizeof(ORC_AIRS) / sizeof(ORC_AIRS[0]); i++)
-        if (ORC_AIRS[i].kind == base && ORC_AIRS[i].hardened == hard && (ORC_AIRS[i].table_bits == 16) == mode_u16) return &ORC_AIRS[i];
+    for (size_t i = 0; i < sizeof(AIR_AIRS) / sizeof(AIR_AIRS[0]); i++)
+        if (AIR_AIRS[i].kind == base && AIR_AIRS[i].hardened == hard && (AIR_AIRS[i].table_bits == 16) == mode_u16) return &AIR_AIRS[i];
     return NULL;
 }
-int orc_air_api_kind(const orc_air_t *a) { return a->kind + 4 * a->hardened; }
+int orc_air_api_kind(const air_spec_t *a) { return a->kind + 4 * a->hardened; }
 
-int orc_air_width(const orc_air_t *a) { return a->n_main + 2 * a->n_checked; }
+int orc_air_width(const air_spec_t *a) { return a->n_main + 2 * a->n_checked; }
 
 /* ---- column name lookup is positional: the generator allocates in a fixed order ---- */
 typedef struct {
@@ -35,7 +35,7 @@ typedef struct {
     int gad0;          /* first gadget's unchecked sign column / checked q column are found from the program */
 } layout_t;
 
-static layout_t layout_of(const orc_air_t *a) {
+static layout_t layout_of(const air_spec_t *a) {
     layout_t L;
     memset(&L, 0, sizeof L);
     int cpl = a->cells_per_limb;
@@ -158,7 +158,7 @@ int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io) {
     return 1;
 }
 
-static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+static int fill_curve_io(const air_spec_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     layout_t L = layout_of(a);
     int ext = L.ext, cpl = a->cells_per_limb, w = 8 * ext;
     pt2 P = {read_f2(rec, ext), read_f2(rec + w, ext)};
@@ -172,8 +172,8 @@ static int fill_curve_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, 
     fill_exponent(tr, n, &L, row0, exp, bits);
     fq2 three = mk2(fq_from_u64(3)), two = mk2(fq_from_u64(2));
     int pending = 0, inf = 0;          /* hardened: inf = the accumulator is the identity (R keeps its last finite value) */
-    const int32_t *hl = !a->hardened ? NULL : a->kind == 0 ? (cpl == 1 ? ORC_HARD_LAYOUT_G1H_U16 : ORC_HARD_LAYOUT_G1H_U8)
-                                                          : (cpl == 1 ? ORC_HARD_LAYOUT_G2H_U16 : ORC_HARD_LAYOUT_G2H_U8);
+    const int32_t *hl = !a->hardened ? NULL : a->kind == 0 ? (cpl == 1 ? AIR_HARD_LAYOUT_G1H_U16 : AIR_HARD_LAYOUT_G1H_U8)
+                                                          : (cpl == 1 ? AIR_HARD_LAYOUT_G2H_U16 : AIR_HARD_LAYOUT_G2H_U8);
     for (int r = 0; r < 512; r++) {
         size_t row = row0 + r;
         int is_add = (r & 1) == 0;
@@ -237,7 +237,7 @@ static fq fq12_tower(const fq12 *x, int t) {
     return fq_add(x->c[i], fq_mul(fq_from_u64(9), x->c[i + 6]));
 }
 
-static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+static int fill_fq12_io(const air_spec_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     layout_t L = layout_of(a);
     int cpl = a->cells_per_limb;
     fq12 pw, acc;
@@ -263,15 +263,15 @@ static int fill_fq12_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, c
 }
 
 /* MapToG2 (kind 3): eight rows per record (u, x, y); columns and schedule from the tables tools/air_gen.py::build_map_g2 emits:
- * row t of the block holds the witnesses ORC_MAPG2_SLOT_WIT[t][0..2] in its three result slots and ORC_MAPG2_REG_WIT[t][0..5]
+ * row t of the block holds the witnesses AIR_MAPG2_SLOT_WIT[t][0..2] in its three result slots and AIR_MAPG2_REG_WIT[t][0..5]
  * in its six registers (zero where the table says -1); u, e1, e2 and the constants on every row; M1, M2, XS, GXS as the
  * (ungated) selection constraints define them from the registers of THAT row. */
-static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
+static int fill_map_io(const air_spec_t *a, uint64_t *tr, size_t n, size_t io, const uint32_t *rec, uint32_t *out_words) {
     const int cpl = a->cells_per_limb;
-    const int32_t *lay = cpl == 1 ? ORC_MAPG2_LAYOUT_U16 : ORC_MAPG2_LAYOUT_U8;
+    const int32_t *lay = cpl == 1 ? AIR_MAPG2_LAYOUT_U16 : AIR_MAPG2_LAYOUT_U8;
     enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2, L_RG3,
            L_Z, L_ZV, L_TINV };
-    if (a->log_rows != 3 || ORC_MAPG2_ROWS != 8 || ORC_MAPG2_NWIT != MG_NWIT || lay[L_RES] != a->checked_base) return -20;
+    if (a->log_rows != 3 || AIR_MAPG2_ROWS != 8 || AIR_MAPG2_NWIT != MG_NWIT || lay[L_RES] != a->checked_base) return -20;
     orc_mapg2_consts k;
     orc_mapg2_constants(&k);
     orc_mapg2_wit w;
@@ -289,12 +289,12 @@ static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, co
         for (int j = 0; j < 32; j++) put(tr, n, lay[L_ZV] + j, row, j == 0 ? zf : 0);
         fq2 reg[6];
         for (int r = 0; r < 6; r++) {
-            int wi = ORC_MAPG2_REG_WIT[t][r];
+            int wi = AIR_MAPG2_REG_WIT[t][r];
             reg[r] = wi < 0 ? zero : w.v[wi];
             put_f2_u16(tr, n, lay[L_REG] + 32 * r, row, reg[r], 2);
         }
         for (int sl = 0; sl < 3; sl++) {
-            int wi = ORC_MAPG2_SLOT_WIT[t][sl];
+            int wi = AIR_MAPG2_SLOT_WIT[t][sl];
             put_f2_chk(tr, n, lay[L_RES] + 32 * cpl * sl, row, wi < 0 ? zero : w.v[wi], 2, cpl);
         }
         const fq2 gx1 = reg[lay[L_RG1]], gx2 = reg[lay[L_RG2]], gx3 = reg[lay[L_RG3]];
@@ -310,17 +310,17 @@ static int fill_map_io(const orc_air_t *a, uint64_t *tr, size_t n, size_t io, co
 
 /* hardened curve AIRs (kinds 4 / 5): T3 = p - 1 - x3 with its borrow bits, and on add rows with bit = 1 the witness that R.x and P.x
  * differ in a limb: nz_j = 1 / (Px_j - Rx_j) at the first such limb (a Goldilocks inverse of a 17-bit difference), 0 elsewhere */
-static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t row) {
+static int fill_harden_row(const air_spec_t *a, uint64_t *tr, size_t n, size_t row) {
     const int ext = a->kind == 0 ? 1 : 2, nc = 16 * ext, cpl = a->cells_per_limb;
-    const int32_t *lay = a->kind == 0 ? (cpl == 1 ? ORC_HARD_LAYOUT_G1H_U16 : ORC_HARD_LAYOUT_G1H_U8)
-                                      : (cpl == 1 ? ORC_HARD_LAYOUT_G2H_U16 : ORC_HARD_LAYOUT_G2H_U8);
+    const int32_t *lay = a->kind == 0 ? (cpl == 1 ? AIR_HARD_LAYOUT_G1H_U16 : AIR_HARD_LAYOUT_G1H_U8)
+                                      : (cpl == 1 ? AIR_HARD_LAYOUT_G2H_U16 : AIR_HARD_LAYOUT_G2H_U8);
     layout_t L = layout_of(a);
     for (int c = 0; c < ext; c++) {
         int64_t borrow = 0;
         for (int i = 0; i < 16; i++) {
             int64_t x = cpl == 1 ? (int64_t)tr[(size_t)(L.X3 + 16 * c + i) * n + row]
                                  : (int64_t)(tr[(size_t)(L.X3 + 2 * (16 * c + i)) * n + row] + 256 * tr[(size_t)(L.X3 + 2 * (16 * c + i) + 1) * n + row]);
-            int64_t pm1 = (int64_t)ORC_BN_P_LIMBS[i] - (i == 0 ? 1 : 0);      /* p is odd: p - 1 only changes limb 0 */
+            int64_t pm1 = (int64_t)AIR_BN_P_LIMBS[i] - (i == 0 ? 1 : 0);      /* p is odd: p - 1 only changes limb 0 */
             int64_t d = pm1 - x - borrow;
             borrow = d < 0;
             uint64_t t = (uint64_t)(d + (borrow << 16));
@@ -349,7 +349,7 @@ static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t ro
         int64_t carry = 0;
         for (int i = 0; i < 16; i++) {
             int64_t sum = (int64_t)tr[(size_t)(L.Ry + 16 * c + i) * n + row] + (int64_t)tr[(size_t)(L.Py + 16 * c + i) * n + row] + carry;
-            int64_t d = sum - (int64_t)ORC_BN_P_LIMBS[i];
+            int64_t d = sum - (int64_t)AIR_BN_P_LIMBS[i];
             if (d != 0 && d != 65536) { ng = 0; break; }
             carry = d == 65536;
             if (i < 15) cnv[15 * c + i] = (uint64_t)carry;
@@ -377,7 +377,7 @@ static int fill_harden_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t ro
 }
 
 /* ---- generic gadget witnesses (integers) ---- */
-static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, const int per[ORC_N_PERIODIC],
+static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, const int per[AIR_N_PERIODIC],
                    int64_t *out, int *n_out) {
     int nl = (int)w[0], nt = (int)w[1];
     for (int i = 0; i < nl; i++) out[i] = 0;
@@ -393,14 +393,14 @@ static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, c
     return 2 + 5 * (size_t)nt;
 }
 
-static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t row) {
-    int per[ORC_N_PERIODIC];
-    for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = (int)(row % (size_t)ORC_PERIODIC[k][0]) == ORC_PERIODIC[k][1];
+static int fill_gadgets_row(const air_spec_t *a, uint64_t *tr, size_t n, size_t row) {
+    int per[AIR_N_PERIODIC];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = (int)(row % (size_t)AIR_PERIODIC[k][0]) == AIR_PERIODIC[k][1];
     const int64_t *w = a->prog, *end = a->prog + a->prog_len;
     int cpl = a->cells_per_limb;
     /* p^-1 mod 2^16 */
     uint32_t pinv = 1;
-    for (int i = 0; i < 5; i++) pinv = (pinv * (2 - ORC_BN_P_LIMBS[0] * pinv)) & 0xffff;
+    for (int i = 0; i < 5; i++) pinv = (pinv * (2 - AIR_BN_P_LIMBS[0] * pinv)) & 0xffff;
     while (w < end) {
         if (w[0] != 1) break; /* gadgets come first */
         int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
@@ -450,7 +450,7 @@ static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t r
             q[i] = ((uint32_t)limbs[i] * pinv) & 0xffff;
             int64_t carry = 0;
             for (int j = 0; i + j < 40; j++) {
-                int64_t t = limbs[i + j] - (j < 16 ? (int64_t)q[i] * ORC_BN_P_LIMBS[j] : 0) + carry;
+                int64_t t = limbs[i + j] - (j < 16 ? (int64_t)q[i] * AIR_BN_P_LIMBS[j] : 0) + carry;
                 limbs[i + j] = t & 0xffff;
                 carry = t >> 16;
                 if (j >= 16 && carry == 0) break;
@@ -471,7 +471,7 @@ static int fill_gadgets_row(const orc_air_t *a, uint64_t *tr, size_t n, size_t r
             for (int t = grp - 1; t >= 0; t--) {
                 int k = grp * m + t;
                 int64_t qp = 0;
-                for (int i = 0; i < 17; i++) { int j = k - i; if (j >= 0 && j < 16) qp += (int64_t)q[i] * ORC_BN_P_LIMBS[j]; }
+                for (int i = 0; i < 17; i++) { int j = k - i; if (j >= 0 && j < 16) qp += (int64_t)q[i] * AIR_BN_P_LIMBS[j]; }
                 dm = dm * 65536 + ((k < 31 ? e[k] : 0) - sgn * qp);
             }
             dm -= cprev; /* = -2^(16 g) c_m */
@@ -524,7 +524,7 @@ orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int
     while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
     unsigned log_n = log_rows;
     while (((size_t)1 << (log_n - log_rows)) < nio) log_n++;
-    const orc_air_t *a = orc_air_get(api_kind, log_n);
+    const air_spec_t *a = orc_air_get(api_kind, log_n);
     if (!a || (unsigned)a->log_rows != log_rows) { *err = -1; return NULL; }
     size_t n = (size_t)1 << log_n;
     if (n < ((size_t)1 << a->table_bits)) { *err = -7; return NULL; }
@@ -578,14 +578,14 @@ void orc_trace_free(orc_trace *t) {
 /* ---- periodic selectors and public-input polynomials ---- */
 /* S_{m,r0}(x) = (K/N) ((x g^-r0)^N - 1) / ((x g^-r0)^K - 1),  K = N/m  (1 on rows r = r0 mod m) */
 uint64_t orc_periodic_base(unsigned log_n, int which, uint64_t x) {
-    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)ORC_PERIODIC[which][0], r0 = (uint64_t)ORC_PERIODIC[which][1];
+    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)AIR_PERIODIC[which][0], r0 = (uint64_t)AIR_PERIODIC[which][1];
     uint64_t K = N / m, g = gl_root_of_unity(log_n);
     uint64_t y = gl_mul(x, gl_inv(gl_pow(g, r0)));
     uint64_t num = gl_sub(gl_pow(y, N), 1), den = gl_sub(gl_pow(y, K), 1);
     return gl_mul(gl_mul(num, gl_inv(den)), gl_mul(K % GL_P, gl_inv(N % GL_P)));
 }
 gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x) {
-    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)ORC_PERIODIC[which][0], r0 = (uint64_t)ORC_PERIODIC[which][1];
+    uint64_t N = (uint64_t)1 << log_n, m = (uint64_t)AIR_PERIODIC[which][0], r0 = (uint64_t)AIR_PERIODIC[which][1];
     uint64_t K = N / m, g = gl_root_of_unity(log_n);
     gl2 y = gl2_scale(x, gl_inv(gl_pow(g, r0)));
     gl2 num = gl2_sub(gl2_pow(y, N), gl2_from(1)), den = gl2_sub(gl2_pow(y, K), gl2_from(1));
@@ -593,7 +593,7 @@ gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x) {
 }
 
 /* value of aux column `ai` for IO `io`: the lo/hi half or the whole of a public u32 word */
-uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int ai) {
+uint64_t orc_aux_value(const air_spec_t *a, const uint32_t *pis, size_t io, int ai) {
     int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], sub = a->aux[4 * ai + 3];
     const uint32_t *rec = pis + io * a->pi_per_io;
     if (part == 3) { /* tower-basis limb of the MyFq12 value at words [word, word + 96) */
@@ -610,7 +610,7 @@ uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int a
 
 /* coefficients (length num_io) of the aux polynomial A with A(g^(rows_per_io io + shift)) = value(io):
  * interpolate over the order-num_io subgroup, then substitute x -> x g^-shift. */
-void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs) {
+void orc_aux_coeffs(const air_spec_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs) {
     unsigned log_io = log_n - (unsigned)a->log_rows;
     for (size_t io = 0; io < num_io; io++) coeffs[io] = orc_aux_value(a, pis, io, ai);
     orc_ifft(coeffs, log_io);
@@ -647,13 +647,13 @@ void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsi
 #define SUFFIX(n) n##_ext
 #include "air_eval.inc"
 
-void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
-                   const uint64_t per[ORC_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
+void orc_eval_base(const air_spec_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
+                   const uint64_t per[AIR_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
                    uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
                    const uint64_t beta[2], const uint64_t gamma[2], uint64_t out[2]) {
     evalctx_base c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
-    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = per[k];
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
     c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
     c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
@@ -661,12 +661,12 @@ void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *
     out[0] = c.acc[0]; out[1] = c.acc[1];
 }
 
-void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
-                  const gl2 per[ORC_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
+void orc_eval_ext(const air_spec_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
+                  const gl2 per[AIR_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
                   gl2 z_last, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2], gl2 out[2]) {
     evalctx_ext c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
-    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = per[k];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = per[k];
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
     c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
     c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
@@ -674,12 +674,12 @@ void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const
     out[0] = c.acc[0]; out[1] = c.acc[1];
 }
 
-size_t orc_air_num_constraints(const orc_air_t *a) { return (size_t)a->n_constraints + 3 + 6 * (size_t)a->n_checked; }
+size_t orc_air_num_constraints(const air_spec_t *a) { return (size_t)a->n_constraints + 3 + 6 * (size_t)a->n_checked; }
 
 /* Debug aid used by the tests: evaluate every constraint on trace row `row` (selectors in {0,1}); returns
  * the index of the first non-zero constraint or -1.  Z columns are not checked here (pass zeros -> skipped). */
 long orc_trace_check_row(const orc_trace *t, size_t row) {
-    const orc_air_t *a = t->air;
+    const air_spec_t *a = t->air;
     size_t n = (size_t)1 << t->log_n;
     int W = t->width;
     uint64_t *local = (uint64_t *)malloc(sizeof(uint64_t) * W), *next = (uint64_t *)malloc(sizeof(uint64_t) * W);
@@ -688,7 +688,7 @@ long orc_trace_check_row(const orc_trace *t, size_t row) {
     evalctx_base c;
     memset(&c, 0, sizeof c);
     c.local = local; c.next = next; c.aux = aux;
-    for (int k = 0; k < ORC_N_PERIODIC; k++) c.per[k] = (row % (size_t)ORC_PERIODIC[k][0]) == (size_t)ORC_PERIODIC[k][1];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = (row % (size_t)AIR_PERIODIC[k][0]) == (size_t)AIR_PERIODIC[k][1];
     size_t io = row >> a->log_rows;
     for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = orc_aux_value(a, t->pis, io, ai);
     /* alpha = 0 turns acc into "the last emitted constraint": walk constraint by constraint instead */

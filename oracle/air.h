@@ -9,7 +9,7 @@
 #include "air_tables.h"
 
 typedef struct {
-    const orc_air_t *air;
+    const air_spec_t *air;
     unsigned log_n;
     size_t num_io;   /* padded to a power of two */
     int width;       /* n_main + 2 n_checked */
@@ -17,10 +17,10 @@ typedef struct {
     uint32_t *pis;   /* [num_io][pi_per_io] */
 } orc_trace;
 
-const orc_air_t *orc_air_get(int kind, unsigned log_n);   /* API kind 0 .. 5 */
-int orc_air_api_kind(const orc_air_t *a);
-int orc_air_width(const orc_air_t *a);
-size_t orc_air_num_constraints(const orc_air_t *a);
+const air_spec_t *orc_air_get(int kind, unsigned log_n);   /* API kind 0 .. 5 */
+int orc_air_api_kind(const air_spec_t *a);
+int orc_air_width(const air_spec_t *a);
+size_t orc_air_num_constraints(const air_spec_t *a);
 orc_trace *orc_trace_build(int kind, const uint32_t *ios, size_t num_io, int *err);
 int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io);
 void orc_test_forge(int flags);   /* test hook, see air.c */
@@ -29,14 +29,14 @@ long orc_trace_check_row(const orc_trace *t, size_t row);
 
 uint64_t orc_periodic_base(unsigned log_n, int which, uint64_t x);
 gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x);
-uint64_t orc_aux_value(const orc_air_t *a, const uint32_t *pis, size_t io, int ai);
-void orc_aux_coeffs(const orc_air_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs);
+uint64_t orc_aux_value(const air_spec_t *a, const uint32_t *pis, size_t io, int ai);
+void orc_aux_coeffs(const air_spec_t *a, const uint32_t *pis, size_t num_io, unsigned log_n, int ai, uint64_t *coeffs);
 
-void orc_eval_base(const orc_air_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
-                   const uint64_t per[ORC_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
+void orc_eval_base(const air_spec_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
+                   const uint64_t per[AIR_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
                    uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
                    const uint64_t beta[2], const uint64_t gamma[2], uint64_t out[2]);
-void orc_eval_ext(const orc_air_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
-                  const gl2 per[ORC_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
+void orc_eval_ext(const air_spec_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
+                  const gl2 per[AIR_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
                   gl2 z_last, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2], gl2 out[2]);
 #endif

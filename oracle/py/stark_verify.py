@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY; PARITY UNPINNED.  Written from the specification, not from the C code: the flat proof layout of
 INTEGRATION.md section 2, the Fiat-Shamir order stated there, the AIR encoding documented at the top of tools/air_gen.py
-(the AIR tables are PARSED out of oracle/air_tables.h: the specification as data), and the generic layer of
+(the AIR tables are PARSED out of data/air_tables.h: the specification as data), and the generic layer of
 oracle/py/plonky2_generic.py (Poseidon, Merkle, challenger, FRI query check: the Python reading of plonky2).  Everything is
 evaluated over the quadratic extension at zeta with Python integers.
 
@@ -37,16 +37,16 @@ def air_tables():
     global _TABLES
     if _TABLES is not None:
         return _TABLES
-    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
+    txt = open(os.path.join(ROOT, "data", "air_tables.h")).read()
 
     def ints(body):
         return [int(x) for x in re.findall(r"-?\d+", body.replace("LL", ""))]
-    per = ints(re.search(r"ORC_PERIODIC\[\d+\]\[2\] = \{(.*?)\};", txt, re.S).group(1))
+    per = ints(re.search(r"AIR_PERIODIC\[\d+\]\[2\] = \{(.*?)\};", txt, re.S).group(1))
     periodic = [(per[2 * i], per[2 * i + 1]) for i in range(len(per) // 2)]
-    p_limbs = ints(re.search(r"ORC_BN_P_LIMBS\[16\] = \{(.*?)\};", txt, re.S).group(1))
-    arrays = {m.group(1): ints(m.group(2)) for m in re.finditer(r"static const int(?:64|32)_t (ORC_\w+_(?:PROG|AUX))\[\] = \{(.*?)\};", txt, re.S)}
+    p_limbs = ints(re.search(r"AIR_BN_P_LIMBS\[16\] = \{(.*?)\};", txt, re.S).group(1))
+    arrays = {m.group(1): ints(m.group(2)) for m in re.finditer(r"static const int(?:64|32)_t (AIR_\w+_(?:PROG|AUX))\[\] = \{(.*?)\};", txt, re.S)}
     airs = []
-    body = re.search(r"ORC_AIRS\[\d+\] = \{(.*?)\n\};", txt, re.S).group(1)
+    body = re.search(r"AIR_AIRS\[\d+\] = \{(.*?)\n\};", txt, re.S).group(1)
     for m in re.finditer(r'\{"(\w+)", ([^}]*)\}', body):
         f = [x.strip() for x in m.group(2).split(",")]
         names = ["kind", "table_bits", "cpl", "n_main", "checked_base", "n_checked", "n_ops", "n_constraints", "n_aux", "pi_per_io",

@@ -173,7 +173,7 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
 int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **proof_out, size_t *proof_len) {
     int err = 0;
     const int kind = orc_air_api_kind(t->air);
-    const orc_air_t *a = t->air;
+    const air_spec_t *a = t->air;
     const unsigned log_n = t->log_n, log_m = log_n + cfg->rate_bits;
     const size_t n = (size_t)1 << log_n;
     const int W = t->width, nc = a->n_checked, P = 2 * nc, Q = 4, nm = a->n_main;
@@ -259,8 +259,8 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
             for (size_t i = 0; i < mq; i++) {
                 uint64_t x = gl_mul(GL_GEN, gl_pow(wm, i));
                 size_t j = bitrev32((uint32_t)i, log_mq), jn = bitrev32((uint32_t)((i + 2) & (mq - 1)), log_mq);
-                uint64_t per[ORC_N_PERIODIC], lf, ll, zlast, out[2];
-                for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = orc_periodic_base(log_n, k, x);
+                uint64_t per[AIR_N_PERIODIC], lf, ll, zlast, out[2];
+                for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = orc_periodic_base(log_n, k, x);
                 selectors_base(log_n, x, &lf, &ll, &zlast);
                 for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = aux_lde[(size_t)ai * mq + i];
                 orc_eval_base(a, tl + j * W, tl + jn * W, aux, per, zl + j * P, zl + jn * P, lf, ll, zlast, alpha, beta, gamma, out);
@@ -363,7 +363,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
     const unsigned log_rows = kind == 3 ? 3 : 9;
     if (kind < 0 || kind > 5 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
-    const orc_air_t *a = orc_air_get(kind, log_n);
+    const air_spec_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||
         h[14] != cfg->arity_bits || h[15] != 0)
@@ -411,8 +411,8 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     for (int c = 0; c < P; c++) orc_chal_observe_ext(&ch, op[2 * W + P + c]);
     /* constraint check at zeta */
     {
-        gl2 per[ORC_N_PERIODIC], lf, ll, zlast, out[2];
-        for (int k = 0; k < ORC_N_PERIODIC; k++) per[k] = orc_periodic_ext(log_n, k, zeta);
+        gl2 per[AIR_N_PERIODIC], lf, ll, zlast, out[2];
+        for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = orc_periodic_ext(log_n, k, zeta);
         selectors_ext(log_n, zeta, &lf, &ll, &zlast);
         auxz = (gl2 *)malloc(sizeof(gl2) * (a->n_aux ? a->n_aux : 1));
         uint64_t *co = (uint64_t *)malloc(num_io * sizeof(uint64_t));

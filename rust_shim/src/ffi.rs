@@ -123,6 +123,7 @@ extern "C" {
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes_cfg(kind: c_int, num_io: usize, cfg: *const SippStarkConfig) -> usize;
+    pub fn sipp_device_memory(device: c_int, free_bytes: *mut usize, total_bytes: *mut usize) -> c_int;
     pub fn sipp_stark_shape(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize, log_rows: *mut u32, main_cols: *mut u32,
                             perm_cols: *mut u32, quotient_cols: *mut u32) -> c_int;
     pub fn sipp_inner_product(ctx: *mut SippCtxOpaque, g1: *const u32, g2: *const u32, n: usize, out: *mut u32) -> c_int;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # queue depth sweep of bench.py's `pipelined` figure (GPU box): ab_inflight.sh 5 6 8 ...   (alternating passes)
-export SIPP_BENCH_IO_SHARD_N= SIPP_BENCH_MAP_G2=0 SIPP_BENCH_HARDENED=0
+export SIPP_BENCH_IO_SHARD_N= SIPP_BENCH_MAP_G2=0 SIPP_BENCH_OTHER_AIR=0
 for pass in $(seq ${PASSES:-2}); do
   for k in "$@"; do
     echo -n "[inflight $k] "

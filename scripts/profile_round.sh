@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export SIPP_BENCH_IO_SHARD_N=0   # the profiled command is the n = 128 line alone (no io_sharded leg)
 export SIPP_BENCH_MAP_G2=0       # ... and without the messages -> G2 leg (profiled on its own at the end of this script)
-export SIPP_BENCH_HARDENED=0     # ... and without the hardened-AIR leg
+export SIPP_BENCH_OTHER_AIR=0     # ... and without the other AIR variant's leg
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_w.log"

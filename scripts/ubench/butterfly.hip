@@ -9,7 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "gl.hpp"
-#include "gl_mul_variants.cuh"
+#include "gl_mul_variants.hpp"
 
 template <int V>
 __device__ __forceinline__ void bfly(uint64_t& u, uint64_t& v, uint64_t s) {

@@ -1,4 +1,4 @@
-// scripts/ubench/gl_mul_variants.cuh -- Goldilocks products tried against the compiler's sequence (gl::mul_nc), kept as measured
+// scripts/ubench/gl_mul_variants.hpp -- Goldilocks products tried against the compiler's sequence (gl::mul_nc), kept as measured
 // experiments (scripts/ubench/mulmod4.hip, butterfly.hip).  NOT product code: none of them paid inside a kernel --
 //   VOP2 carry chain (mul_nc)                  1.26-1.28 T products/s against the compiler's 1.41-1.42 T
 //   one hand-scheduled block, fixed temporaries (mul_nc3)   1.65-1.67 T alone (+17 %), nothing inside the transform kernels of
@@ -8,7 +8,8 @@
 #ifndef GLL_T
 #define GLL_T 100
 #endif
-#include "gl_lazy.cuh"
+#define GLL_REGS_INC "gl_lazy_regs.inc"   /* scripts/ubench: every register window */
+#include "gl_lazy.hpp"
 
 namespace gll {
 

@@ -1,7 +1,7 @@
 // The full-round MDS layer of Poseidon-Goldilocks (12 x 12 circulant + diagonal, entries <= 49) on the MATRIX pipe (VERDICT r2 #3a):
 // does moving the small-constant linear layer of the one-state-per-lane hash to v_mfma_i32_32x32x32_i8 pay?
 //
-//   VALU form (what poseidon.cuh::mds_full does): per output two chains of 12 v_mad_u64_u32 over the 32-bit halves + one 96-bit
+//   VALU form (what poseidon.hpp::mds_full does): per output two chains of 12 v_mad_u64_u32 over the 32-bit halves + one 96-bit
 //   reduction: 12 x (24 + ~10) instructions per state.
 //   MFMA form: the 12 state words are cut into 8 byte planes (48 v_perm_b32 = six 4x4 byte transposes, 24 v_xor to make the bytes
 //   signed: i8 operands are signed, the +128 per byte is repaid through the accumulator's start value); per byte plane ONE

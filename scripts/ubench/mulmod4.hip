@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "gl.hpp"
-#include "gl_mul_variants.cuh"
+#include "gl_mul_variants.hpp"
 
 template <int V>
 __global__ void __launch_bounds__(256) k(const uint64_t* in, uint64_t* out, int iters) {

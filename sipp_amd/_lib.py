@@ -90,6 +90,7 @@ SIGNATURES = {
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
+    "sipp_device_memory": (C.c_int, [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "sipp_workspace_bytes_cfg": (C.c_size_t, [C.c_int, C.c_size_t, C.POINTER(StarkConfig)]),
     "sipp_fri_const_arity": (None, [C.POINTER(FriParams), C.c_uint32, C.c_uint32, C.c_uint32]),
     "sipp_commit_batch_ex": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]),
@@ -145,6 +146,15 @@ def default_config():
     cfg = StarkConfig()
     lib().sipp_default_config(C.byref(cfg))
     return cfg
+
+
+def device_memory_bytes(device=0):
+    """total memory of GPU `device` (sipp_device_memory)"""
+    total = C.c_size_t()
+    rc = lib().sipp_device_memory(int(device), None, C.byref(total))
+    if rc != 0:
+        raise SippError(rc, "device_memory")
+    return total.value
 
 
 def to_device(arr):
@@ -451,8 +461,14 @@ class Instance:
     normal priority, see sipp_ctx_set_stream_priority in include/sipp_hip.h); G1 low / G2 normal / Fq12 high
     measured best with the start gate of sipp_instance_prove (69.3 vs 71.2 ms per n = 128 instance for low / high / high)."""
 
-    def __init__(self, num_io, devices=(0, 0, 0), priorities=None, hardened=False):
+    # three concurrent arenas above this share of the card's memory -> one ctx, the proofs back to back (sipp_instance_prove with
+    # three equal handles): of the BASELINE configs only n = 4096 on ONE GPU (246 GB plain, 279 GB hardened of 288 GB)
+    SINGLE_CTX_SHARE = 0.6
+
+    def __init__(self, num_io, devices=(0, 0, 0), priorities=None, hardened=False, single_ctx=None):
         """hardened: G1 / G2 with the hardened AIRs (kinds 4 / 5 in the proofs' headers; sipp_ctx_set_hardened).
+        single_ctx: True = one ctx / one arena, the three proofs back to back; False = three ctxs on three streams; None = three
+        unless their arenas together exceed SINGLE_CTX_SHARE of the device's memory (and the devices are one device).
         priorities=None: ("low", "", "high"), and ("low", "high", "high") for a hardened instance -- there G2 ahead of G1 measured
         64.0 - 64.2 against 66.9 - 68.1 ms per n = 128 instance (the plain instance loses 1.5 ms with it: 59.4 - 60.5 against 57.9 - 58.7)"""
         if priorities is None:
@@ -461,13 +477,26 @@ class Instance:
         self.num_io = tuple(int(x) for x in num_io)
         self.ctxs = []
         level = {"low": -1, "": 0, "normal": 0, "high": 1}
-        for k in range(3):
-            wk = k + 4 if (hardened and k < 2) else k
-            c = Ctx(device=devices[k], workspace_bytes=self.L.sipp_workspace_bytes(wk, max(1, self.num_io[k])))
-            if hardened:
-                c._ck(self.L.sipp_ctx_set_hardened(c.h, 1), "set_hardened")
-            c._ck(self.L.sipp_ctx_set_stream_priority(c.h, level[priorities[k]]), "set_stream_priority")
-            self.ctxs.append(c)
+        ws = [self.L.sipp_workspace_bytes(k + 4 if (hardened and k < 2) else k, max(1, self.num_io[k])) for k in range(3)]
+        if single_ctx is None:
+            single_ctx = len(set(devices)) == 1 and sum(ws) > self.SINGLE_CTX_SHARE * device_memory_bytes(devices[0])
+        self.single_ctx = bool(single_ctx)
+        try:
+            if self.single_ctx:
+                c = Ctx(device=devices[0], workspace_bytes=max(ws))
+                self.ctxs = [c, c, c]
+                if hardened:
+                    c._ck(self.L.sipp_ctx_set_hardened(c.h, 1), "set_hardened")
+            else:
+                for k in range(3):
+                    c = Ctx(device=devices[k], workspace_bytes=ws[k])
+                    self.ctxs.append(c)
+                    if hardened:
+                        c._ck(self.L.sipp_ctx_set_hardened(c.h, 1), "set_hardened")
+                    c._ck(self.L.sipp_ctx_set_stream_priority(c.h, level[priorities[k]]), "set_stream_priority")
+        except Exception:
+            self.close()          # the ctxs (and their arenas) created so far
+            raise
         self.caps = [self.L.sipp_proof_size(self.ctxs[k].h, k, self.num_io[k]) if self.num_io[k] else 0 for k in range(3)]
         self.out = [np.zeros(max(c, 1), dtype=np.uint64) for c in self.caps]
 
@@ -488,12 +517,15 @@ class Instance:
             raise SippError(rc, "instance_prove: " + msgs)
         return [self.out[k][: pl[k]] for k in range(3)]
 
+    def distinct_ctxs(self):
+        return self.ctxs[:1] if getattr(self, "single_ctx", False) else list(self.ctxs)
+
     def sync(self):
-        for c in self.ctxs:
+        for c in self.distinct_ctxs():
             c.sync()
 
     def close(self):
-        for c in self.ctxs:
+        for c in self.distinct_ctxs():
             c.close()
         self.ctxs = []
 
@@ -502,10 +534,17 @@ class InstanceQueue:
     """sipp_instances_prove: `in_flight` slots of three ctxs on one device; prove(list of [g1, g2, fq12]) proves every instance of
     the list, `in_flight` at a time, and returns their proofs (copies)."""
 
-    def __init__(self, num_io, in_flight=3, device=0, priorities=("low", "", "high"), hardened=False):
+    def __init__(self, num_io, in_flight=3, device=0, priorities=None, hardened=False):
+        """priorities=None: Instance's own default for the AIR variant (a hardened queue wants G2 ahead of G1)"""
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
-        self.slots = [Instance(self.num_io, devices=(device,) * 3, priorities=priorities, hardened=hardened) for _ in range(in_flight)]
+        self.slots = []
+        try:
+            for _ in range(in_flight):
+                self.slots.append(Instance(self.num_io, devices=(device,) * 3, priorities=priorities, hardened=hardened))
+        except Exception:
+            self.close()
+            raise
 
     def prove(self, instances):
         count, F = len(instances), len(self.slots)

@@ -11,8 +11,9 @@ def _stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".cuh", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h"))]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "sipp_hip.h"))
+    srcs.append(os.path.join(os.path.dirname(HERE), "data", "air_tables.h"))
     return any(os.path.getmtime(s) > t for s in srcs)
 
 

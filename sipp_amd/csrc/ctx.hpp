@@ -237,13 +237,13 @@ int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n);
 
 // ---- AIR layer (trace.hip / quotient.hip / stark.hip) -----------------------------------------
 #include "air_tables.h"
-const sipp_air_t* sipp_air_get(int kind, uint32_t log_n);
-const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a);
-int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
+const air_spec_t* sipp_air_get(int kind, uint32_t log_n);
+const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const air_spec_t* a);
+int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
                     uint64_t* d_trace, int* d_err);
 size_t sipp_curve_rows_bytes(int kind, uint32_t log_n);
 // mapg2.hip: the map Fp2 -> E'(Fp2) (MapToG2 AIR, kind 3): primary witness rows / (x, y) written into the records
-int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
+int sipp_mapg2_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
                     int* d_err);
 int sipp_mapg2_outputs(sipp_ctx* ctx, uint32_t* d_ios, uint32_t num_io, int* d_err);
 // outputs of n1 G1 and n2 G2 obligations, the two accumulator chains on two streams (native.hip's fold of a SIPP round)

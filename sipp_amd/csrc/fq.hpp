@@ -1,4 +1,4 @@
-// sipp_amd/csrc/fq.cuh -- BN254 base field Fq on gfx950: 8 x u32 limbs, Montgomery form (R = 2^261).
+// sipp_amd/csrc/fq.hpp -- BN254 base field Fq on gfx950: 8 x u32 limbs, Montgomery form (R = 2^261).
 //
 // Used only by the trace-fill kernels (the native double-and-add / square-and-multiply chains whose
 // intermediate values become trace cells).  Replaces ark-bn254's Fq (reference Cargo.toml:9) on the device.

@@ -1,4 +1,4 @@
-// sipp_amd/csrc/gl_lazy.cuh -- lazy Goldilocks add / sub / canonicalisation as carry chains through VCC (gfx950, device only).
+// sipp_amd/csrc/gl_lazy.hpp -- lazy Goldilocks add / sub / canonicalisation as carry chains through VCC (gfx950, device only).
 //
 // Butterflies do not need canonical values in between: with w canonical (< p) and u ANY u64 congruent to the true value,
 // u + w  and  u - w  need ONE conditional correction by 2^64 mod p = 2^32 - 1 and stay in [0, 2^64) -- five instructions each,
@@ -72,7 +72,29 @@ __device__ __forceinline__ uint64_t sub_nc(uint64_t u, uint64_t w) {
 // Measured: 1.41 -> 1.65 T products/s alone (scripts/ubench/mulmod4.hip); the one-state-per-lane leaf hash 1.65 -> 1.85 G permutations/s
 // at 2^17 leaves and 2.01 -> 2.21 G at 2^21 (its S-boxes are 472 of these per permutation); nothing in the transform kernels.
 }  // namespace gll
-#include "gl_lazy_regs.inc"
+// GLL_R<i> = "v<GLL_T + i>", GLL_P<i> = "v[<GLL_T + i>:<GLL_T + i + 1>]" (i even).  The product library uses ONE window (v140 .. v149,
+// poseidon.hip); the microbenchmarks' other windows come from their own table (scripts/ubench/gl_lazy_regs.inc via GLL_REGS_INC).
+#if GLL_T == 140 && !defined(GLL_REGS_INC)
+#define GLL_R0 "v140"
+#define GLL_R1 "v141"
+#define GLL_R2 "v142"
+#define GLL_R3 "v143"
+#define GLL_R4 "v144"
+#define GLL_R5 "v145"
+#define GLL_R6 "v146"
+#define GLL_R7 "v147"
+#define GLL_R8 "v148"
+#define GLL_R9 "v149"
+#define GLL_P0 "v[140:141]"
+#define GLL_P2 "v[142:143]"
+#define GLL_P4 "v[144:145]"
+#define GLL_P6 "v[146:147]"
+#define GLL_P8 "v[148:149]"
+#elif defined(GLL_REGS_INC)
+#include GLL_REGS_INC
+#else
+#error "gl_lazy.hpp: GLL_T must be 140 (or name a register table with GLL_REGS_INC)"
+#endif
 namespace gll {
 
 __device__ __forceinline__ uint64_t mul_nc(uint64_t a, uint64_t b) {

@@ -1,5 +1,5 @@
 // sipp_amd/csrc/host_poseidon.hpp -- host-side Poseidon-Goldilocks permutation (host_poseidon.cpp) of the Fiat-Shamir
-// challenger: plain C++ / AVX-512, no HIP.  Same function as the device permutation of poseidon.cuh.
+// challenger: plain C++ / AVX-512, no HIP.  Same function as the device permutation of poseidon.hpp.
 #pragma once
 #include <stdint.h>
 

@@ -12,7 +12,7 @@
 // found.  Latency-bound scalar-style code on few waves; the field product is kept out of line so that everything shares one copy.
 #include "air_tables.h"
 #include "ctx.hpp"
-#include "fq.cuh"
+#include "fq.hpp"
 #include "mapg2_constants.h"
 
 namespace {
@@ -112,8 +112,8 @@ __device__ __forceinline__ void store_chk(uint64_t* tr, size_t n, int col, size_
 
 enum { MG_T1, MG_TV1, MG_W, MG_TV3, MG_A4, MG_B4, MG_X2, MG_X1, MG_S1, MG_GX1, MG_S2, MG_GX2, MG_D, MG_E, MG_F, MG_X3, MG_S3,
        MG_GX3, MG_N1, MG_N2, MG_Y, MG_NWIT };
-static_assert(MG_NWIT == SIPP_MAPG2_NWIT && SIPP_MAPG2_ROWS == 8, "witness order / rows per message of tools/air_gen.py");
-// index into SIPP_MAPG2_LAYOUT_*: columns, then the registers that hold x1 x2 x3 g(x1) g(x2) g(x3) for the selections
+static_assert(MG_NWIT == AIR_MAPG2_NWIT && AIR_MAPG2_ROWS == 8, "witness order / rows per message of tools/air_gen.py");
+// index into AIR_MAPG2_LAYOUT_*: columns, then the registers that hold x1 x2 x3 g(x1) g(x2) g(x3) for the selections
 enum { L_U, L_ONE, L_C1, L_C2, L_C3, L_C4, L_BB, L_E1, L_E2, L_M1, L_M2, L_XS, L_GXS, L_REG, L_RES, L_RX1, L_RX2, L_RX3, L_RG1, L_RG2,
        L_RG3, L_Z, L_ZV, L_TINV, L_N };
 
@@ -254,23 +254,23 @@ __global__ void __launch_bounds__(64) mapg2_rows_kernel(uint32_t* __restrict__ i
     }
 }
 
-MapConsts map_consts(const sipp_air_t* a) {
+MapConsts map_consts(const air_spec_t* a) {
     MapConsts k;
     memcpy(k.c1, SIPP_MAPG2_C1, 64);
     memcpy(k.c2, SIPP_MAPG2_C2, 64);
     memcpy(k.c3, SIPP_MAPG2_C3, 64);
     memcpy(k.c4, SIPP_MAPG2_C4, 64);
     memcpy(k.b, SIPP_MAPG2_B, 64);
-    memcpy(k.slot_wit, SIPP_MAPG2_SLOT_WIT, sizeof k.slot_wit);
-    memcpy(k.reg_wit, SIPP_MAPG2_REG_WIT, sizeof k.reg_wit);
-    memcpy(k.lay, (a && a->cells_per_limb == 1) ? SIPP_MAPG2_LAYOUT_U16 : SIPP_MAPG2_LAYOUT_U8, sizeof k.lay);
+    memcpy(k.slot_wit, AIR_MAPG2_SLOT_WIT, sizeof k.slot_wit);
+    memcpy(k.reg_wit, AIR_MAPG2_REG_WIT, sizeof k.reg_wit);
+    memcpy(k.lay, (a && a->cells_per_limb == 1) ? AIR_MAPG2_LAYOUT_U16 : AIR_MAPG2_LAYOUT_U8, sizeof k.lay);
     return k;
 }
 
 }  // namespace
 
 // primary witness of the MapToG2 AIR: d_ios [num_io][48] (padded: 8 num_io == n rows), every primary cell of rows 8 io .. 8 io + 7
-int sipp_mapg2_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
+int sipp_mapg2_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
                     int* d_err) {
     const size_t n = (size_t)1 << log_n;
     const MapConsts k = map_consts(a);

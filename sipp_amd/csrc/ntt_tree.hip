@@ -24,7 +24,7 @@
 // table of n/2 entries, and a coset tree a heap-ordered table (index (Q << l) + i under the subtree root Q).  Tables are shared by
 // every column; the grid is ordered column-fastest so that the blocks in flight work on the same few KB of them.
 #include "ctx.hpp"
-#include "gl_lazy.cuh"
+#include "gl_lazy.hpp"
 
 namespace {
 
@@ -32,7 +32,7 @@ namespace {
 #define SIPP_TREE_LAZY 1
 #endif
 // forward butterfly (u, v) -> (u + s v, u - s v): u may be ANY u64 congruent to its value, the product is made canonical, the
-// sum and the difference take one conditional correction each and stay in [0, 2^64) (gl_lazy.cuh); what leaves the last sweep is
+// sum and the difference take one conditional correction each and stay in [0, 2^64) (gl_lazy.hpp); what leaves the last sweep is
 // canonicalised at the store
 __device__ __forceinline__ void bfly_fwd(uint64_t& u, uint64_t& v, uint64_t s) {
 #if SIPP_TREE_LAZY
@@ -450,6 +450,10 @@ int launch_pass(sipp_ctx* ctx, const char* name, TreeArgs& a, unsigned halves) {
 }
 
 constexpr uint32_t LTILE = 12;
+// the coset heap table has 2^(log_n + rate_bits) words and is built on the host at the first use of a size (like every transform
+// table: the one hipMalloc outside sipp_ctx_create, sipp_table_put): capped at 2^26 words = 512 MiB; beyond it the callers fall
+// back to the pass-by-pass path, whose tables are O(sqrt) of the size.  The largest BASELINE config needs 2^22.
+constexpr uint32_t TREE_MAX_LOG_M = 26;
 
 // coefficients [ncols][n] natural -> the 2^rate_bits halves of the leaf-order LDE
 int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t L, uint32_t rate_bits) {
@@ -562,14 +566,14 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
 
 int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
                               uint32_t log_n, uint32_t rate_bits) {
-    if (d_values == d_coeffs || ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
+    if (d_values == d_coeffs || ncols == 0 || ncols > 0xffffffu || log_n + rate_bits > TREE_MAX_LOG_M) return SIPP_E_UNSUPPORTED;
     if (log_n < 13) return SIPP_E_UNSUPPORTED;     // no strided top sweep to fuse into (never asked for: sipp_tree_ntt_enabled)
     return tree_from_values_fused(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
 }
 
 int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                               uint32_t rate_bits) {
-    if (ncols == 0 || ncols > 0xffffffu) return SIPP_E_UNSUPPORTED;
+    if (ncols == 0 || ncols > 0xffffffu || log_n + rate_bits > TREE_MAX_LOG_M) return SIPP_E_UNSUPPORTED;
     return tree_forward(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
 }
 
@@ -578,7 +582,7 @@ int sipp_tree_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t*
 // that reads the coefficients from L2 and writes every point once, instead of a zero-padded 2^log_m transform in three (shorter
 // polynomials would make one tiny block per subtree: they stay with the pass-by-pass path)
 int sipp_tree_coset_eval(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_out, size_t ncols, uint32_t log_n, uint32_t log_m) {
-    if (ncols == 0 || ncols > 0xffffffu || log_n < 10 || log_m < log_n || log_m - log_n > 15 || log_m > 25)
+    if (ncols == 0 || ncols > 0xffffffu || log_n < 10 || log_m < log_n || log_m - log_n > 15 || log_m > 25)   // <= TREE_MAX_LOG_M
         return SIPP_E_UNSUPPORTED;
     return tree_forward(ctx, d_coeffs, d_out, ncols, log_n, log_m - log_n);
 }

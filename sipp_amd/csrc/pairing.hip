@@ -5,7 +5,7 @@
 //
 // Mapping: one WAVE per (A_i, B_i) runs the Miller loop (homogeneous projective twist arithmetic, no inversion; the 36 / 18 Fq2
 // products of every Fq12 product and the products of one dependency level of a point step spread over the lanes), values in Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six
-// Fq2 coefficients in Montgomery form (fq.cuh), resident in LDS.  One workgroup then multiplies
+// Fq2 coefficients in Montgomery form (fq.hpp), resident in LDS.  One workgroup then multiplies
 // the n Miller values (strided partial products + a tree) and one wave applies the final exponentiation: easy part
 // (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers by u); the result is
 // exactly f^((p^12 - 1)/r).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fq.cuh"
+#include "fq.hpp"
 #include "pairing_constants.h"
 
 namespace {

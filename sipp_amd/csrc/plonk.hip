@@ -158,9 +158,11 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
 
 int check(sipp_ctx* ctx, const sipp_plonk_params* p, uint32_t log_n, uint32_t* log_d, uint32_t* m) {
     if (!p || p->num_routed_wires == 0 || p->num_challenges == 0 || log_n < 1 || log_n > 24) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: bad parameters");
+    if (p->max_degree < 2 || p->max_degree > 64)      // before the loop below: 1u << 32 is undefined
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: the chunk size (quotient degree factor) must be a power of two in 2 .. 64");
     uint32_t ld = 0;
     while ((1u << ld) < p->max_degree) ld++;
-    if (p->max_degree < 2 || (1u << ld) != p->max_degree || ld > 6)
+    if ((1u << ld) != p->max_degree)
         return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "plonk: the chunk size (quotient degree factor) must be a power of two in 2 .. 64");
     const uint32_t chunks = (p->num_routed_wires + p->max_degree - 1) / p->max_degree;
     if (chunks > MAX_CHUNKS || p->num_challenges > MAX_CH)
@@ -332,7 +334,11 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
 }
 
 size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params* p, const sipp_fri_params* fp) {
-    if (!p || !fp || p->max_degree == 0) return 0;
+    // the bounds of check(): sizes below are u32 products
+    if (!p || !fp || p->max_degree < 2 || p->max_degree > 64 || (p->max_degree & (p->max_degree - 1)) || p->num_routed_wires == 0 ||
+        p->num_challenges == 0 || p->num_challenges > MAX_CH || (p->num_routed_wires + p->max_degree - 1) / p->max_degree > MAX_CHUNKS ||
+        log_n < 1 || log_n > 24)
+        return 0;
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = C * ((R + D - 1) / D);
     const size_t cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
     sipp_oracle oracles[4] = {{nullptr, nullptr, nullptr, R, 0}, {nullptr, nullptr, nullptr, R, 0}, {nullptr, nullptr, nullptr, nz, 0},

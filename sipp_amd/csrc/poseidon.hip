@@ -7,14 +7,14 @@
 // consecutive u64 of one column per load (512 B, fully coalesced) and no transpose ever exists.
 // Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
 #include "ctx.hpp"
-// ten VGPRs for the 64-bit temporaries of the hand-scheduled Goldilocks product (gl_lazy.cuh): v140 .. v149 keep the one-state-per-lane
+// ten VGPRs for the 64-bit temporaries of the hand-scheduled Goldilocks product (gl_lazy.hpp): v140 .. v149 keep the one-state-per-lane
 // leaf kernel at 150 VGPRs (152 without; its budget is 168 = three waves per SIMD)
 #ifndef GLL_T
 #define GLL_T 140
 #endif
-#include "poseidon.cuh"
-#include "poseidon_quad.cuh"
-#include "poseidon_pair.cuh"
+#include "poseidon.hpp"
+#include "poseidon_quad.hpp"
+#include "poseidon_pair.hpp"
 #include "prover.hpp"
 
 namespace {
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIPP_L
 poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                              uint32_t ncols, uint64_t n_leaves,
                                                              uint64_t* __restrict__ digests) {
-    // no early exit: the matrix-pipe form of the linear layers needs every lane of the wave (poseidon.cuh::permute<true>); a lane
+    // no early exit: the matrix-pipe form of the linear layers needs every lane of the wave (poseidon.hpp::permute<true>); a lane
     // past the end hashes the last leaf again and skips the store
     const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t j = j0 < n_leaves ? j0 : n_leaves - 1;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) poseidon_leaves_copy_kernel(const uint64_
     for (uint32_t q = 0; q < 4; q++) d[q] = q < ncols ? lde[j + (size_t)q * col_stride] : 0;
 }
 
-// ---- four lanes per state (poseidon_quad.cuh): thin launches ----
+// ---- four lanes per state (poseidon_quad.hpp): thin launches ----
 __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
                                                                   uint64_t* __restrict__ digests) {
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_
     }
 }
 
-// ---- two lanes per state (poseidon_pair.cuh): the middle ground for thin launches ----
+// ---- two lanes per state (poseidon_pair.hpp): the middle ground for thin launches ----
 __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
                                                                   uint64_t* __restrict__ digests) {
@@ -127,54 +127,6 @@ __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_
         d[2] = s[2];
         d[3] = s[3];
     }
-}
-
-__global__ void __launch_bounds__(256) merkle_level_quad_kernel(const uint64_t* __restrict__ child,
-                                                               uint64_t* __restrict__ parent, uint64_t n_parents) {
-    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
-    poseidon_quad::load_tables(tab);
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t i = tid >> 2;
-    const uint32_t q = (uint32_t)tid & 3;
-    // every lane of the wave runs the permutation (DPP needs whole quads); out-of-range quads work on zeros
-    const bool live = i < n_parents;
-    uint64_t s[3] = {0, 0, 0};
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t e = 3 * q + j;
-            if (e < 8) s[j] = child[8 * i + e];
-        }
-    }
-    poseidon_quad::permute(s, q, tab);
-    if (!live) return;
-    uint64_t* d = parent + 4 * i;
-    if (q == 0) {
-        d[0] = s[0];
-        d[1] = s[1];
-        d[2] = s[2];
-    } else if (q == 1) {
-        d[3] = s[0];
-    }
-}
-
-// parent[i] = two_to_one(child[2i], child[2i+1])
-__global__ void __launch_bounds__(256) merkle_level_kernel(const uint64_t* __restrict__ child,
-                                                          uint64_t* __restrict__ parent, uint64_t n_parents) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_parents) return;
-    uint64_t s[12];
-    const uint64_t* c = child + 8 * i;
-#pragma unroll
-    for (int q = 0; q < 8; q++) s[q] = c[q];
-#pragma unroll
-    for (int q = 8; q < 12; q++) s[q] = 0;
-    poseidon::permute(s);
-    uint64_t* d = parent + 4 * i;
-    d[0] = s[0];
-    d[1] = s[1];
-    d[2] = s[2];
-    d[3] = s[3];
 }
 
 // ---- one launch per SUBTREE instead of one per level ------------------------------------------------------------------
@@ -279,7 +231,7 @@ __global__ void __launch_bounds__(256) fri_leaves_kernel(const uint64_t* __restr
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
-// the same with four lanes per leaf (poseidon_quad.cuh): FRI trees are small (2^13, 2^9, 2^5 leaves at n = 128) and sit
+// the same with four lanes per leaf (poseidon_quad.hpp): FRI trees are small (2^13, 2^9, 2^5 leaves at n = 128) and sit
 // on the latency-bound tail of a proof, where a lone wave per SIMD takes 50 us per permutation and a quad 18 us
 __global__ void __launch_bounds__(256) fri_leaves_quad_kernel(const uint64_t* __restrict__ vals, uint64_t len,
                                                              uint64_t* __restrict__ digests) {
@@ -366,13 +318,10 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
     if ((resp >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
 }
 
-uint64_t quad_threshold() {
-    static const uint64_t v = [] {
-        const char* e = getenv("SIPP_QUAD_MAX_LEAVES");
-        return e ? (uint64_t)atol(e) : (uint64_t)65536;
-    }();
-    return v;
-}
+// thin launches (the Fq12 trees, the upper Merkle levels, FRI layers): up to this many states several lanes work on one state.
+// Measured both ways (round 3): one state per lane for the Fq12 trees costs 74-75 against 58-59 ms per instance single and 60-61
+// against 51 ms queued -- the 1374 sequential permutations per leaf become the critical path.
+constexpr uint64_t quad_threshold() { return 65536; }
 
 }  // namespace
 
@@ -458,15 +407,14 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
     // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2854 / 1512 columns -- are
     // hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 23 against 30 us per dependent permutation)
-    static const int thin_lanes_env = sipp_env_int("SIPP_THIN_LANES", 2);
-    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : thin_lanes_env;
+    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : 2;
     const bool thin = ncols > 4 && n <= quad_threshold() && n >= (thin_lanes_p == 2 ? 32 : 16);
     ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : !thin ? "poseidon_leaves" : thin_lanes_p == 2 ? "poseidon_leaves_pair" : "poseidon_leaves_quad");
-    // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.cuh, the default since round 2) costs
+    // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.hpp, the default since round 2) costs
     // 33.1 k lane-instructions per permutation against 39.5 k for four and is SLOWER alone (2^13 x 4096 columns: 19.1 ms against
     // 12.0 ms: 37 us per sequential permutation instead of 23 us) but FASTER where it matters, beside the other two proofs: the
     // instance is bound by total instruction issue (68.5 ms against 70.5-70.8 ms single, 61.1 against 63.6-63.9 ms with three
-    // instances in flight).  SIPP_THIN_LANES=4 restores the four-lane kernel.
+    // instances in flight).
     const int thin_lanes = thin_lanes_p;
     if (ncols <= 4) {
         hipLaunchKernelGGL(poseidon_leaves_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_lde, col_stride,
@@ -495,15 +443,9 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     return SIPP_OK;
 }
 
-// SIPP_MERKLE_PER_LEVEL=1: the one-launch-per-level form (kept for A/B measurements)
-static bool merkle_per_level() {
-    static const bool v = getenv("SIPP_MERKLE_PER_LEVEL") != nullptr;
-    return v;
-}
-
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height) {
     if (cap_height > log_leaves) cap_height = log_leaves;
-    if (!merkle_per_level()) {
+    {   // one launch per SUBTREE (146 -> 28 launches per n = 128 instance; the per-level form's kernel time was 4.5 against 5.2 ms)
         uint32_t level = 0;
         const uint32_t top = log_leaves - cap_height;     // levels to produce
         while (level < top) {
@@ -524,24 +466,6 @@ int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, u
         }
         return SIPP_OK;
     }
-    uint64_t off = 0;
-    for (uint32_t l = 0; l < log_leaves - cap_height; l++) {
-        uint64_t n_child = (uint64_t)1 << (log_leaves - l);
-        uint64_t n_par = n_child >> 1;
-        ProfScope ps(ctx, "merkle_level");
-        if (n_par <= quad_threshold()) {
-            unsigned grid = (unsigned)((4 * n_par + 255) / 256);
-            hipLaunchKernelGGL(merkle_level_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
-                               d_tree + 4 * (off + n_child), n_par);
-        } else {
-            unsigned grid = (unsigned)((n_par + 255) / 256);
-            hipLaunchKernelGGL(merkle_level_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_tree + 4 * off,
-                               d_tree + 4 * (off + n_child), n_par);
-        }
-        SIPP_CHECK_HIP(ctx, hipGetLastError());
-        off += n_child;
-    }
-    return SIPP_OK;
 }
 
 int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n) {

@@ -1,4 +1,4 @@
-// sipp_amd/csrc/poseidon.cuh -- Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds),
+// sipp_amd/csrc/poseidon.hpp -- Poseidon-Goldilocks permutation (width 12, x^7, 4 + 22 + 4 rounds),
 // one state per lane, for gfx950.
 //
 // Replaces plonky2's PoseidonPermutation / PoseidonHash (hash/poseidon.rs @ 541e127; selected by the
@@ -23,7 +23,7 @@
 //  * the round loops are NOT unrolled (code stays inside the instruction cache); the per-lane loops are.
 #pragma once
 #include "gl.hpp"
-#include "gl_lazy.cuh"
+#include "gl_lazy.hpp"
 #include "poseidon_constants.h"
 
 namespace poseidon {
@@ -38,7 +38,7 @@ __constant__ uint32_t c_blk3[2 * SIPP_POSEIDON_BLK_WORDS];
 __constant__ uint32_t c_comb3[396];
 __constant__ uint64_t c_comb_c[12];
 
-// S-box products: the hand-scheduled block of gl_lazy.cuh when the translation unit reserves its temporaries (GLL_T), the compiler's
+// S-box products: the hand-scheduled block of gl_lazy.hpp when the translation unit reserves its temporaries (GLL_T), the compiler's
 // sequence otherwise (-DSIPP_POSEIDON_C_MUL keeps the latter for A/B runs)
 #if defined(GLL_T) && !defined(SIPP_POSEIDON_C_MUL)
 #define SIPP_PMUL gll::mul_nc

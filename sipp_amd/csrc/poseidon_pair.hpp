@@ -1,7 +1,7 @@
-// sipp_amd/csrc/poseidon_pair.cuh -- Poseidon-Goldilocks with TWO lanes per state (32 states per wave).
+// sipp_amd/csrc/poseidon_pair.hpp -- Poseidon-Goldilocks with TWO lanes per state (32 states per wave).
 //
 // Between one state per lane (21.3 k lane-instructions per permutation, but a 2^14-leaf tree is only 256 waves and a sponge
-// over ~1000 permutations per leaf then takes 50 us per permutation) and four lanes per state (poseidon_quad.cuh: 4x the waves,
+// over ~1000 permutations per leaf then takes 50 us per permutation) and four lanes per state (poseidon_quad.hpp: 4x the waves,
 // 39.6 k lane-instructions per permutation): lane h of a pair holds elements 6h .. 6h + 5, the partner's six arrive through a DPP
 // quad_perm swap.  Rotating by the pair offset gives elements (6h + d) mod 12, d = 0 .. 11, in BOTH lanes, so the circulant MDS
 // uses the lane-uniform coefficient C[(d - j) mod 12] (only the DIAG[0] term is lane dependent).  In the partial rounds the
@@ -9,7 +9,7 @@
 // summed across the pair.  Per-element constants come from the LDS copy of the tables (poseidon_quad::load_tables).
 // Bit-exact with the other two layouts (tests/test_gpu_generic.py).
 #pragma once
-#include "poseidon_quad.cuh"
+#include "poseidon_quad.hpp"
 
 namespace poseidon_pair {
 
@@ -66,8 +66,8 @@ __device__ __forceinline__ void mds_full(uint64_t s[6], uint32_t diag0 /* 8 in t
     }
 }
 
-// LDS copy of the lazy-block tables of the one-lane kernel (poseidon.cuh::partial_rounds_blocked), plus the limbs of 25 = M[0][0]
-// then the limbs of the merged affine layer of round 3 (poseidon.cuh::full_round3_combined): C3[11][12][3] and its constants
+// LDS copy of the lazy-block tables of the one-lane kernel (poseidon.hpp::partial_rounds_blocked), plus the limbs of 25 = M[0][0]
+// then the limbs of the merged affine layer of round 3 (poseidon.hpp::full_round3_combined): C3[11][12][3] and its constants
 constexpr int B_C25 = 2 * SIPP_POSEIDON_BLK_WORDS, B_COMB3 = B_C25 + 3, B_COMBC = B_COMB3 + 396, B_WORDS = B_COMBC + 24;
 __device__ __forceinline__ void load_block_tables(uint32_t* blk) {
     for (int i = threadIdx.x; i < B_WORDS; i += blockDim.x) {

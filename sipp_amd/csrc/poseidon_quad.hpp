@@ -1,4 +1,4 @@
-// sipp_amd/csrc/poseidon_quad.cuh -- Poseidon-Goldilocks with FOUR lanes per state (16 states per wave).
+// sipp_amd/csrc/poseidon_quad.hpp -- Poseidon-Goldilocks with FOUR lanes per state (16 states per wave).
 //
 // Why: a sponge over W columns is sequential per leaf, so a launch has only (#leaves / 64) waves when every
 // lane owns a whole state.  The Fq12 STARK (2^14 leaves x ~1,700 permutations) and the upper Merkle levels
@@ -12,7 +12,7 @@
 // Per-element constants (round constants, sparse-layer vectors) differ per lane and come from an LDS copy
 // of the tables.  Bit-exact with the one-state-per-lane permutation (tests/test_gpu_generic.py).
 #pragma once
-#include "poseidon.cuh"
+#include "poseidon.hpp"
 
 namespace poseidon_quad {
 

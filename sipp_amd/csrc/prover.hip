@@ -145,8 +145,8 @@ struct QuotArgs {
     const uint64_t* seg_pow;                   // [n_seg][2]: alpha_c^(#program constraints after the segment)
     int n_seg;
     uint64_t* part;                            // [n_seg][2][m] partial Horner sums
-    const uint64_t* per_tab[SIPP_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
-    uint32_t per_mask[SIPP_N_PERIODIC];
+    const uint64_t* per_tab[AIR_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
+    uint32_t per_mask[AIR_N_PERIODIC];
     uint64_t zh_inv[2];   // 1 / (x^N - 1) for even / odd natural index
     uint64_t zh[2];       // x^N - 1
     uint64_t ninv;        // 1 / N
@@ -166,12 +166,12 @@ struct QuotArgs {
 struct QCtx {
     const QuotArgs* a;
     size_t j, jn, m;
-    uint64_t per[SIPP_N_PERIODIC];
+    uint64_t per[AIR_N_PERIODIC];
     uint64_t acc0, acc1;
     // selects instead of a dynamically indexed private array (which would live in scratch memory); k is wave-uniform.  Indices
     // 0 .. 3: the exponentiation AIRs' selectors, 4 .. 11: MapToG2's eight row types
     __device__ __forceinline__ uint64_t periodic(int k) const {
-        static_assert(SIPP_N_PERIODIC == 12, "periodic(): update the select chain");
+        static_assert(AIR_N_PERIODIC == 12, "periodic(): update the select chain");
         if (k < 4) return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
         if (k < 8) return k == 4 ? per[4] : k == 5 ? per[5] : k == 6 ? per[6] : per[7];
         return k == 8 ? per[8] : k == 9 ? per[9] : k == 10 ? per[10] : per[11];
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
-    for (int k = 0; k < SIPP_N_PERIODIC; k++) c.per[k] = a.per_tab[k][i & a.per_mask[k]];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = a.per_tab[k][i & a.per_mask[k]];
     const int64_t* w = a.prog + a.seg_off[g];
     const uint32_t n_poly = a.seg_cnt[g];
     if (n_poly) {
@@ -906,7 +906,7 @@ int sipp_k_gather_tasks(sipp_ctx* ctx, const QueryGatherTask* d_tasks, uint32_t 
     return SIPP_OK;
 }
 
-int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
+int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
                      const uint64_t gamma[2], uint64_t* d_zv) {
     const size_t n = (size_t)1 << log_n;
     const int P = 2 * a->n_checked;
@@ -939,7 +939,7 @@ int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace
     return SIPP_OK;
 }
 
-int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
+int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
                     size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
                     const uint64_t gamma[2], uint64_t* d_out) {
     const uint32_t log_m = log_n + 1;
@@ -955,8 +955,8 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.beta[0] = beta[0]; q.beta[1] = beta[1];
     const uint64_t g = gl::root_of_unity(log_n), wm = gl::root_of_unity(log_m);
     // periodic tables over natural LDE index i mod 2 m_k
-    for (int k = 0; k < SIPP_N_PERIODIC; k++) {
-        const uint64_t mk = (uint64_t)SIPP_PERIODIC[k][0], r0 = (uint64_t)SIPP_PERIODIC[k][1];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) {
+        const uint64_t mk = (uint64_t)AIR_PERIODIC[k][0], r0 = (uint64_t)AIR_PERIODIC[k][1];
         uint64_t* t = sipp_table_get(ctx, 200 + k, log_n, 0);
         if (!t) {
             const uint64_t K = n / mk;
@@ -981,7 +981,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const ui
     q.ninv = gl::inv(n % gl::P);
     q.g_inv = gl::inv(g);
     q.w_m = wm;
-    for (int i = 0; i < 16; i++) q.p_limbs[i] = SIPP_BN_P_LIMBS[i];
+    for (int i = 0; i < 16; i++) q.p_limbs[i] = AIR_BN_P_LIMBS[i];
     q.out = d_out;
     for (int ch = 0; ch < 2; ch++) {
         // (alpha = 0 has probability 2^-64 per challenge; the factorised fold divides by alpha, so refuse it loudly)

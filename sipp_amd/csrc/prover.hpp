@@ -7,11 +7,11 @@
 #include "host_poseidon.hpp"
 #include "poseidon_constants.h"
 
-int sipp_k_z_columns(sipp_ctx* ctx, const sipp_air_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
+int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
                      const uint64_t gamma[2], uint64_t* d_zv);
 // quotient on the coset 7 <w_2N> (the first 2N leaves of the LDEs, whose columns are lde_stride apart); d_aux [n_aux][2N],
 // d_out [2][2N] in leaf order
-int sipp_k_quotient(sipp_ctx* ctx, const sipp_air_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
+int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
                     size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
                     const uint64_t gamma[2], uint64_t* d_out);
 int sipp_k_pow_table(sipp_ctx* ctx, gl::E2 base, size_t n, uint64_t* d_tab);

@@ -26,7 +26,7 @@ static inline int ctx_kind(const sipp_ctx* ctx, int kind) {
 #define SIPP_MAGIC 0x5349505053544b31ULL /* "SIPPSTK1" */
 
 struct Shape {
-    const sipp_air_t* air;
+    const air_spec_t* air;
     uint32_t log_n;
     uint32_t num_io;  // padded
     int W, P, Q;
@@ -278,7 +278,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     const sipp_stark_config& cfg = ctx->cfg;
     Shape s;
     SIPP_TRY(shape_of(kind, num_io_in, &s));
-    const sipp_air_t* a = s.air;
+    const air_spec_t* a = s.air;
     const FriParamsDev fp = fri_params_of(cfg, s.log_n);
     const uint32_t log_n = s.log_n, log_m = log_n + cfg.rate_bits, R = (uint32_t)fp.arity_bits.size();
     // the layer kernels (transforms, leaf hashing) work on at least 16 values: a limit of this implementation, not of FRI --
@@ -359,7 +359,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         ctx->gate_release->release();
         ctx->gate_release = nullptr;
     }
-    if (ctx->gate_wait) {  // gate_point == 1
+    if (ctx->gate_wait) {  // a gated kind without a chain in its trace fill (trace.hip gate_after_chain took the others)
         ctx->gate_wait->wait();
         ctx->gate_wait = nullptr;
     }
@@ -562,6 +562,19 @@ int sipp_io_shard(size_t num_io, uint32_t world, uint32_t rank, size_t* first, s
 }
 
 size_t sipp_workspace_bytes(int kind, size_t num_io) { return sipp_workspace_bytes_cfg(kind, num_io, nullptr); }
+
+int sipp_device_memory(int device, size_t* free_bytes, size_t* total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SIPP_E_HIP;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) return SIPP_E_HIP;
+    (void)hipSetDevice(prev);
+    if (free_bytes) *free_bytes = fr;
+    if (total_bytes) *total_bytes = tot;
+    return SIPP_OK;
+}
 
 size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config* cfg) {
     Shape s;
@@ -897,6 +910,20 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     if (!ctxs || !ios || !num_io || !proof_out || !proof_cap || !proof_len) return SIPP_E_BADARG;
     for (int k = 0; k < 3; k++)
         if (!ctxs[k]) return SIPP_E_BADARG;
+    if (ctxs[0] == ctxs[1] && ctxs[1] == ctxs[2]) {
+        // ONE ctx for the instance: the three proofs back to back on its stream and its arena (sized for the largest of them).  What the
+        // large configurations want: at n = 4096 the fat kernels of one proof fill the chip on their own, three streams buy 2 % (1234
+        // against 1259 ms) and need the three arenas live at once (246 GB; with the hardened AIRs 279 GB of the card's 288); back to
+        // back the instance needs 159 GB (181 GB).  Largest first, like the concurrent order.
+        const int serial[3] = {SIPP_G2_EXP, SIPP_G1_EXP, SIPP_FQ12_EXP};
+        for (int k = 0; k < 3; k++) proof_len[k] = 0;
+        for (int i = 0; i < 3; i++) {
+            const int k = serial[i];
+            if (num_io[k] == 0) continue;
+            SIPP_TRY(sipp_prove(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k], &proof_len[k]));
+        }
+        return SIPP_OK;
+    }
     if (ctxs[0] == ctxs[1] || ctxs[0] == ctxs[2] || ctxs[1] == ctxs[2]) return SIPP_E_BADARG;
     // The other two proofs start once the longest (G2) has its trace filled: its latency-bound chains and lookup kernels
     // are otherwise crowded out by the others' long-running hash workgroups and G2 ends last by ~10 ms (n = 128: 73.3 ->

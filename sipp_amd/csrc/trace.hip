@@ -17,7 +17,7 @@
 
 #include "air_tables.h"
 #include "ctx.hpp"
-#include "fq.cuh"
+#include "fq.hpp"
 
 namespace {
 
@@ -468,7 +468,9 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
         ya = py;
         xb = px;
     }
-    const bool same = hard && is_add && !inf_here && F::is_zero(den);   // R = +-P with a finite accumulator: cases of the hardened AIR
+    // R = +-P on an add row: cases of the hardened AIR (flags eq / ng; slope cells 0, result unused).  Under inf the R cells are the
+    // stale last finite accumulator and the row's result is unused as well (t1 = 0): the same slope-0 row, as oracle/air.c fills it
+    const bool same = hard && is_add && F::is_zero(den);
     if (F::is_zero(den) && !same) {
         atomicExch(err, SIPP_E_WITNESS);
         return;
@@ -764,6 +766,9 @@ __global__ void __launch_bounds__(256) harden_rows_kernel(uint64_t* __restrict__
     const uint64_t w = (chord && first >= 0) ? gl::inv(gl::sub(dpx, drx)) : 0;
     for (int j = 0; j < nc; j++) tr[(size_t)(col_nz + j) * n + row] = (chord && j == first) ? w : 0;
     bad |= chord && first < 0;    // the x's equal where the chord is used: no witness (curve_rows refused the row already)
+    // R = P on a block's LAST add row (bit 255 set): no row is left to hand the double over -- the constraint PER_LAST eqc = 0 cannot
+    // hold, the record has no proof (oracle/air.c fill_curve_io refuses it at the same place)
+    bad |= eqc && (row & 511) == 511;
     if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
 
@@ -830,8 +835,8 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
                                                         int* __restrict__ err) {
     size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
-    int per[SIPP_N_PERIODIC];
-    for (int k = 0; k < SIPP_N_PERIODIC; k++) per[k] = (int)(row % (size_t)SIPP_PERIODIC[k][0]) == SIPP_PERIODIC[k][1];
+    int per[AIR_N_PERIODIC];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = (int)(row % (size_t)AIR_PERIODIC[k][0]) == AIR_PERIODIC[k][1];
     const int64_t* w = g.prog + g.gadget_off[blockIdx.y];
     bool bad = false;
     const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
@@ -1088,39 +1093,9 @@ __global__ void __launch_bounds__(256) lookup_scan_kernel(const uint32_t* __rest
     }
 }
 
-// one lane per (column, sorted position i)
-__global__ void lookup_fill_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ dist,
-                                   const uint32_t* __restrict__ zlist, const uint32_t* __restrict__ nzero, size_t n,
-                                   uint32_t ncols, uint32_t tbits, uint64_t* __restrict__ pin, uint64_t* __restrict__ ptab) {
-    const uint32_t T = 1u << tbits;
-    size_t total = n * ncols;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        size_t c = idx / n;
-        uint32_t i = (uint32_t)(idx - c * n);
-        const uint32_t* st = start + (c << tbits);
-        // largest v with start[v] <= i  (values with empty buckets share a start with their successor: take the
-        // last such v whose bucket is non-empty, i.e. the largest v with start[v] <= i)
-        uint32_t lo = 0, hi = T - 1;
-        while (lo < hi) {
-            uint32_t mid = (lo + hi + 1) >> 1;
-            if (st[mid] <= i) lo = mid; else hi = mid - 1;
-        }
-        uint32_t v = lo;
-        pin[idx] = v;
-        uint32_t out;
-        if (st[v] == i) {
-            out = v;
-        } else {
-            uint32_t k = i - dist[(c << tbits) + v];
-            out = k < nzero[c] ? zlist[(c << tbits) + k] : T - 1;
-        }
-        ptab[idx] = out;
-    }
-}
-
-// The same two columns by EXPANSION instead of a search per position (the default; SIPP_LOOKUP_FILL_SEARCH=1 keeps the kernel above):
-// one lane per (column, value v) writes v to the positions start[v] .. start[v] + hist[v] - 1 -- the first of them carries v in the table
-// column too, the others a filler as above.  No dependent loads (the search takes 16 per position), writes in increasing position order.
+// The permuted input / table columns by EXPANSION (round 3; a binary search per position took 16 dependent loads, 0.57 ms of G2's
+// exposed head): one lane per (column, value v) writes v to the positions start[v] .. start[v] + hist[v] - 1 -- the first of them carries v in the table
+// column too, the others a filler (the next unused table value from zlist, T - 1 when those run out).  No dependent loads (the search takes 16 per position), writes in increasing position order.
 // Bins of more than 8 entries (constant cells, carries; every bin of a u8 table) are written by the whole wave, one bin after the other.
 __global__ void __launch_bounds__(256) lookup_expand_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ start,
                                                            const uint32_t* __restrict__ dist, const uint32_t* __restrict__ zlist,
@@ -1180,16 +1155,16 @@ __global__ void __launch_bounds__(256) lookup_expand_kernel(const uint32_t* __re
 
 // ---- host drivers -------------------------------------------------------------------------------------------
 // API kinds: 0 G1, 1 G2, 2 Fq12, 3 MapToG2, 4 / 5 = the hardened G1 / G2 AIRs (the same records and rows; air->kind stays 0 / 1)
-const sipp_air_t* sipp_air_get(int kind, uint32_t log_n) {
+const air_spec_t* sipp_air_get(int kind, uint32_t log_n) {
     const bool u16 = log_n >= 16;
     if (kind < 0 || kind > 5) return nullptr;
     const int hard = kind >= 4 ? 1 : 0, base = hard ? kind - 4 : kind;
-    for (size_t i = 0; i < sizeof(SIPP_AIRS) / sizeof(SIPP_AIRS[0]); i++)
-        if (SIPP_AIRS[i].kind == base && SIPP_AIRS[i].hardened == hard && (SIPP_AIRS[i].table_bits == 16) == u16) return &SIPP_AIRS[i];
+    for (size_t i = 0; i < sizeof(AIR_AIRS) / sizeof(AIR_AIRS[0]); i++)
+        if (AIR_AIRS[i].kind == base && AIR_AIRS[i].hardened == hard && (AIR_AIRS[i].table_bits == 16) == u16) return &AIR_AIRS[i];
     return nullptr;
 }
 
-static int64_t* prog_on_device(sipp_ctx* ctx, const sipp_air_t* a) {
+static int64_t* prog_on_device(sipp_ctx* ctx, const air_spec_t* a) {
     uint64_t* t = sipp_table_get(ctx, 100, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits);
     if (t) return (int64_t*)t;
     std::vector<uint64_t> v(a->prog_len);
@@ -1197,7 +1172,7 @@ static int64_t* prog_on_device(sipp_ctx* ctx, const sipp_air_t* a) {
     if (sipp_table_put(ctx, 100, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits, v, &t) != SIPP_OK) return nullptr;
     return (int64_t*)t;
 }
-const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const sipp_air_t* a) { return prog_on_device(ctx, a); }
+const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const air_spec_t* a) { return prog_on_device(ctx, a); }
 
 // bytes of the Jacobian row scratch sipp_trace_fill takes from the arena FIRST for a curve AIR (kind 0 / 1) of 2^log_n rows
 size_t sipp_curve_rows_bytes(int kind, uint32_t log_n) {
@@ -1248,7 +1223,7 @@ static void gate_after_chain(sipp_ctx* ctx) {
     }
 }
 
-int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
+int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n,
                     uint64_t* d_trace, int* d_err) {
     const size_t n = (size_t)1 << log_n;
     const int cpl = a->cells_per_limb, nm = a->n_main, nc = a->n_checked;
@@ -1272,8 +1247,8 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     } else {
         const int ext = a->kind == 0 ? 1 : 2, ncl = 16 * ext;
         const int32_t* hard_lay = !a->hardened ? nullptr
-                                  : a->kind == 0 ? (cpl == 1 ? SIPP_HARD_LAYOUT_G1H_U16 : SIPP_HARD_LAYOUT_G1H_U8)
-                                                 : (cpl == 1 ? SIPP_HARD_LAYOUT_G2H_U16 : SIPP_HARD_LAYOUT_G2H_U8);
+                                  : a->kind == 0 ? (cpl == 1 ? AIR_HARD_LAYOUT_G1H_U16 : AIR_HARD_LAYOUT_G1H_U8)
+                                                 : (cpl == 1 ? AIR_HARD_LAYOUT_G2H_U16 : AIR_HARD_LAYOUT_G2H_U8);
         const int hard_inf_col = hard_lay ? hard_lay[7] : 0;
         CurveCols c{1, 1 + ncl, 1 + 2 * ncl, 1 + 3 * ncl, a->checked_base, a->checked_base + ncl * cpl,
                     a->checked_base + 2 * ncl * cpl, cpl};
@@ -1352,10 +1327,10 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
     if (a->hardened) {
         if (a->kind > 1) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "hardened AIR: curves only");
         const int ext = a->kind + 1, ncl = 16 * ext;
-        const int32_t* lay = a->kind == 0 ? (cpl == 1 ? SIPP_HARD_LAYOUT_G1H_U16 : SIPP_HARD_LAYOUT_G1H_U8)
-                                          : (cpl == 1 ? SIPP_HARD_LAYOUT_G2H_U16 : SIPP_HARD_LAYOUT_G2H_U8);
+        const int32_t* lay = a->kind == 0 ? (cpl == 1 ? AIR_HARD_LAYOUT_G1H_U16 : AIR_HARD_LAYOUT_G1H_U8)
+                                          : (cpl == 1 ? AIR_HARD_LAYOUT_G2H_U16 : AIR_HARD_LAYOUT_G2H_U8);
         SippBnP pl;
-        for (int i = 0; i < 16; i++) pl.l[i] = SIPP_BN_P_LIMBS[i];
+        for (int i = 0; i < 16; i++) pl.l[i] = AIR_BN_P_LIMBS[i];
         ProfScope ps(ctx, "trace_harden");
         hipLaunchKernelGGL(harden_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n, ext, cpl, 1,
                            1 + 2 * ncl, col_bit, a->checked_base + ncl * cpl, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], lay[7], lay[8], lay[9], lay[10], lay[11], lay[12],
@@ -1398,9 +1373,9 @@ int sipp_trace_fill(sipp_ctx* ctx, const sipp_air_t* a, const uint32_t* d_ios, u
         }
         g.prog_len = a->prog_len;
         g.cpl = cpl;
-        for (int i = 0; i < 16; i++) g.p_limbs[i] = SIPP_BN_P_LIMBS[i];
+        for (int i = 0; i < 16; i++) g.p_limbs[i] = AIR_BN_P_LIMBS[i];
         uint32_t pinv = 1;
-        for (int i = 0; i < 5; i++) pinv = (pinv * (2 - SIPP_BN_P_LIMBS[0] * pinv)) & 0xffff;
+        for (int i = 0; i < 5; i++) pinv = (pinv * (2 - AIR_BN_P_LIMBS[0] * pinv)) & 0xffff;
         g.pinv16 = pinv;
         ProfScope ps(ctx, "trace_gadgets");
         hipLaunchKernelGGL(gadget_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)a->n_gadgets), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);

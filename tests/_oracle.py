@@ -20,7 +20,8 @@ def build(force=False):
         subprocess.check_call(["make", "-C", ODIR, "-s", "asan"])
         return os.path.join(ODIR, "liboracle_asan.so")
     so = os.path.join(ODIR, "liboracle.so")
-    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h", ".inc"))]
+    srcs.append(os.path.join(os.path.dirname(ODIR), "data", "air_tables.h"))    # the AIR specification, shared with the product
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ODIR, "-s"])
     return so

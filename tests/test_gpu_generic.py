@@ -56,7 +56,7 @@ def test_ntt_matches_oracle(ctx, oracle, log_n):
 @pytest.mark.parametrize("log_n,ncols", [(4, 1), (6, 11), (9, 3), (10, 4), (11, 3), (12, 9), (13, 17), (14, 5), (15, 3), (16, 5),
                                          (17, 2), (18, 2), (19, 2), (20, 1), (21, 1), (22, 1)])
 def test_commit_matches_oracle(ctx, log_n, ncols):
-    """PolynomialBatch::from_values on the device -- whole-column fused kernel (2^10..2^14), gather / fused-top / low-pass sweeps (2^15..2^21), pass-by-pass path elsewhere --
+    """PolynomialBatch::from_values on the device -- whole-column fused kernel (2^10..2^14), the tree-of-rings sweeps (2^15 and above), pass-by-pass path below 2^10 --
     and the per-subtree Merkle kernels: coefficients, every LDE cell, EVERY tree level and the cap equal the oracle's"""
     rng = np.random.default_rng(100 + log_n)
     vals = _oracle.rand_field(rng, (ncols, 1 << log_n))
@@ -90,6 +90,24 @@ def test_long_column_batches_at_other_blowups_match_the_oracle(ctx, log_n, rate_
         assert (host(coeffs) == ref.coeffs).all()
     assert (host(lde).T == ref.leaves).all()
     assert (cap == ref.cap).all()
+
+
+@pytest.mark.parametrize("log_n", [12, 16, 18])
+def test_in_place_lde_takes_the_pass_by_pass_path(ctx, log_n):
+    """values and coefficients in ONE buffer (sipp_lde_batch with d_coeffs == d_values): the fused kernels of a long column decline
+    that (they read natural-order values while they write coefficients), so the call runs the pass-by-pass path -- copy, tiled
+    bit-reversal, multi-pass DIT, multi-pass coset DIF -- at sizes the default commitments no longer send there.  Same
+    coefficients and LDE cells as the oracle (and as the fused path: test_commit_matches_oracle)."""
+    import torch
+    rng = np.random.default_rng(900 + log_n)
+    ncols = 3
+    vals = _oracle.rand_field(rng, (ncols, 1 << log_n))
+    ref = _oracle.Batch(vals, log_n)
+    buf = dev(vals)
+    lde = torch.empty((ncols, 2 << log_n), dtype=torch.int64, device=buf.device)
+    ctx._ck(ctx.L.sipp_lde_batch(ctx.h, buf.data_ptr(), buf.data_ptr(), lde.data_ptr(), ncols, log_n), "lde_batch in place")
+    assert (host(buf) == ref.coeffs).all()
+    assert (host(lde).T == ref.leaves).all()
 
 
 def test_leaves_and_cap_separately(ctx):

@@ -135,7 +135,7 @@ def test_bare_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher (how the driver invokes `--gpus 1`): the process starts the two ranks itself
     before it touches the GPU, relays rank 0's one line and its exit code.  Rehearsal mode = both ranks on GPU 0 over gloo."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(SIPP_BENCH_REHEARSAL="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_HARDENED="0", SIPP_BENCH_MAP_G2="0")
+    env.update(SIPP_BENCH_REHEARSAL="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_OTHER_AIR="0", SIPP_BENCH_MAP_G2="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
@@ -153,7 +153,7 @@ def test_bench_timing_contract_over_rccl_with_one_rank():
     process group of ONE rank -- bench.py's barrier, max-over-ranks and (min, max)-over-ranks reductions on DEVICE tensors
     through RCCL, around the real timed region and the io_sharded leg"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(SIPP_BENCH_SINGLE_RANK_GROUP="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_HARDENED="0", SIPP_BENCH_MAP_G2="0",
+    env.update(SIPP_BENCH_SINGLE_RANK_GROUP="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_OTHER_AIR="0", SIPP_BENCH_MAP_G2="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline", "--inflight", "1"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
@@ -245,6 +245,54 @@ def test_io_sharded_sub_proofs_cover_the_instance_and_verify(world):
     finally:
         ctx.close()
     assert seen == [a.shape[0] for a in ios]
+
+
+@pytest.mark.parametrize("hardened", [False, True])
+def test_one_ctx_instance_proves_back_to_back_the_same_words(hardened):
+    """sipp_instance_prove with three EQUAL handles: one ctx, one arena sized for the largest proof, the three proofs one after the
+    other (what sipp_amd.Instance picks by itself when three arenas would not fit the card: n = 4096 on one GPU) -- the same words
+    as three ctxs on three streams; two equal handles and a third are refused"""
+    import ctypes as C
+    import sipp_amd
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    three = sipp_amd.Instance([a.shape[0] for a in ios], hardened=hardened, single_ctx=False)
+    one = sipp_amd.Instance([a.shape[0] for a in ios], hardened=hardened, single_ctx=True)
+    try:
+        assert not three.single_ctx and len(three.distinct_ctxs()) == 3
+        assert one.single_ctx and len(one.distinct_ctxs()) == 1 and one.ctxs[0] is one.ctxs[2]
+        want = [p.copy() for p in three.prove(ios)]
+        for _ in range(2):
+            got = one.prove(ios)
+            for k in range(3):
+                assert int(got[k][1]) == (k + 4 if hardened and k < 2 else k)
+                assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), k
+        # the automatic choice: three arenas of this size are nowhere near 60 % of the card
+        auto = sipp_amd.Instance([a.shape[0] for a in ios], hardened=hardened)
+        assert not auto.single_ctx
+        auto.close()
+        L, vp = sipp_amd.lib(), C.c_void_p
+        h = (vp * 3)(three.ctxs[0].h, three.ctxs[0].h, three.ctxs[2].h)
+        pi = (vp * 3)(*[a.ctypes.data for a in ios])
+        ni = (C.c_size_t * 3)(*[a.shape[0] for a in ios])
+        po = (vp * 3)(*[o.ctypes.data for o in three.out])
+        pc = (C.c_size_t * 3)(*three.caps)
+        pl = (C.c_size_t * 3)()
+        assert L.sipp_instance_prove(h, pi, ni, po, pc, pl) == -1          # SIPP_E_BADARG
+    finally:
+        three.close()
+        one.close()
+
+
+def test_device_memory_reports_the_card():
+    import ctypes as C
+    import sipp_amd
+    L = sipp_amd.lib()
+    fr, tot = C.c_size_t(), C.c_size_t()
+    assert L.sipp_device_memory(0, C.byref(fr), C.byref(tot)) == 0
+    assert 0 < fr.value <= tot.value and tot.value > (64 << 30)
+    assert sipp_amd._lib.device_memory_bytes(0) == tot.value
+    assert L.sipp_device_memory(99, None, None) != 0
 
 
 def test_pool_streams_and_dedicated_queues_give_the_same_proofs():

@@ -27,14 +27,14 @@ def ios4():
 
 
 def hard_layout(name):
-    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
-    m = re.search(r"ORC_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
+    txt = open(os.path.join(ROOT, "data", "air_tables.h")).read()
+    m = re.search(r"AIR_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
     return [int(x) for x in m.group(1).split(",")][:6]    # nz, cb, T3, eq, u, eqc (then ng, inf, t1, v, w, NGV, cn)
 
 
 def hard_layout_all(name):
-    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
-    m = re.search(r"ORC_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
+    txt = open(os.path.join(ROOT, "data", "air_tables.h")).read()
+    m = re.search(r"AIR_HARD_LAYOUT_%s\[13\] = \{([^}]*)\}" % name, txt)
     return dict(zip("nz cb T3 eq u eqc ng inf t1 v w NGV cn".split(), [int(x) for x in m.group(1).split(",")]))
 
 

@@ -70,14 +70,14 @@ def test_c_and_python_readings_of_the_map_agree():
 
 
 def air_tables():
-    """the MapToG2 schedule and column layout as tools/air_gen.py emitted them (oracle/air_tables.h)"""
-    txt = open(os.path.join(ROOT, "oracle", "air_tables.h")).read()
+    """the MapToG2 schedule and column layout as tools/air_gen.py emitted them (data/air_tables.h)"""
+    txt = open(os.path.join(ROOT, "data", "air_tables.h")).read()
     def ints(name):
         m = re.search(r"%s(?:\[\d+\])+ = \{(.*?)\};" % name, txt, re.S)
         return [int(x) for x in re.findall(r"-?\d+", m.group(1))]
-    slot = np.array(ints("ORC_MAPG2_SLOT_WIT")).reshape(8, 3)
-    reg = np.array(ints("ORC_MAPG2_REG_WIT")).reshape(8, 6)
-    lay = dict(zip("U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES RX1 RX2 RX3 RG1 RG2 RG3 z ZV TINV".split(), ints("ORC_MAPG2_LAYOUT_U8")))
+    slot = np.array(ints("AIR_MAPG2_SLOT_WIT")).reshape(8, 3)
+    reg = np.array(ints("AIR_MAPG2_REG_WIT")).reshape(8, 6)
+    lay = dict(zip("U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES RX1 RX2 RX3 RG1 RG2 RG3 z ZV TINV".split(), ints("AIR_MAPG2_LAYOUT_U8")))
     return slot, reg, lay
 
 

@@ -10,8 +10,8 @@ semantics out = offset + [exp] x  /  out = offset * x^exp from src/verifier_circ
 
 An AIR is emitted as DATA (a flat int64 "program" + a header) consumed by two independent interpreters:
 oracle/air.c (CPU restatement: witness fill, constraint evaluation for prover and verifier) and
-sipp_amd/csrc/air.cuh (HIP: witness fill and quotient kernels).  Both copies of the tables are written
-by this script: oracle/air_tables.h and sipp_amd/csrc/air_tables.h.
+sipp_amd/csrc/air.hpp (HIP: witness fill and quotient kernels).  Both copies of the tables are written
+by this script: data/air_tables.h (one file for both).
 
 Column model
   main columns  = [TABLE] + unchecked cells + checked cells (range-checked against the TABLE column)
@@ -794,7 +794,7 @@ STRUCT = """typedef struct {
     const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
     int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 3 for mapg2 */
     int hardened;        /* 1: the curve AIR with canonical x3 and the x-inequality witness (API kinds 4 / 5 = kind + 4) */
-} %s_air_t;
+} air_spec_t;
 """
 
 
@@ -808,12 +808,12 @@ def main():
     for mode in ("u16", "u8"):
         airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode), build_map_g2(mode),
                  build_curve("g1", mode, 1, hardened=True), build_curve("g2", mode, 2, hardened=True)]
-    for path, prefix, guard in ((os.path.join(ROOT, "oracle", "air_tables.h"), "ORC", "ORACLE_AIR_TABLES_H"),
-                                (os.path.join(ROOT, "sipp_amd", "csrc", "air_tables.h"), "SIPP", "SIPP_AIR_TABLES_H")):
+    # ONE file, included by the product (sipp_amd/csrc, -I data) and by the checker (oracle/, -I data) alike
+    for path, prefix, guard in ((os.path.join(ROOT, "data", "air_tables.h"), "AIR", "SIPP_AIR_TABLES_H"),):
         with open(path, "w") as f:
             f.write("/* GENERATED by tools/air_gen.py -- the AIR specification as data; do not edit. */\n")
             f.write("#ifndef %s\n#define %s\n#include <stdint.h>\n" % (guard, guard))
-            f.write(STRUCT % prefix.lower())
+            f.write(STRUCT)
             f.write("#define %s_N_PERIODIC %d\n" % (prefix, len(PERIODICS)))
             f.write("static const int32_t %s_PERIODIC[%d][2] = {%s};\n" % (
                 prefix, len(PERIODICS), ", ".join("{%d, %d}" % p for p in PERIODICS)))
@@ -828,7 +828,7 @@ def main():
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
-            f.write("static const %s_air_t %s_AIRS[%d] = {\n" % (prefix.lower(), prefix, len(airs)))
+            f.write("static const air_spec_t %s_AIRS[%d] = {\n" % (prefix, len(airs)))
             for a in airs:
                 f.write(header_entry(a, prefix))
             f.write("};\n#endif\n")

@@ -189,7 +189,7 @@ def blocked_tables(vs, ws):
         state[i+1] before round r = S_i + sum_{r0 <= t < r} x_t * vs[t][i]
         d_r = M00 * x_r + sum_i ws[r][i] * S_i + sum_{r0 <= t < r} x_t * CC[r][t],   CC[r][t] = sum_i ws[r][i] * vs[t][i]
     so no lane is reduced mod p inside the block: every term is a multiply-accumulate with a CONSTANT, and the
-    kernel cuts constants into 22-bit limbs so that 64-bit accumulators never overflow (poseidon.cuh Acc6).
+    kernel cuts constants into 22-bit limbs so that 64-bit accumulators never overflow (poseidon.hpp Acc6).
     Returns CC as a dict (r, t) -> value."""
     cc = {}
     for r in range(N_PARTIAL):
@@ -250,7 +250,7 @@ def combined_layer(first, Mi):
 
 
 def blocked_perm_combined(state, rc, tables, cc):
-    """blocked_perm with the combined layer (python model of poseidon.cuh::permute)"""
+    """blocked_perm with the combined layer (python model of poseidon.hpp::permute)"""
     first, scalars, Mi, vs, ws = tables
     M = mds_matrix()
     C, c = combined_layer(first, Mi)
@@ -278,7 +278,7 @@ def limbs3(c):
 
 
 def blocked_words(vs, ws, cc):
-    """u32 table read by poseidon.cuh partial_rounds_blocked: per block [ per local round k: ws[r][0..10] then
+    """u32 table read by poseidon.hpp partial_rounds_blocked: per block [ per local round k: ws[r][0..10] then
     CC[r][r0..r0+k-1] ] then vs transposed [i][k]; every constant as 3 limbs."""
     out = []
     for r0 in range(0, N_PARTIAL, BLK):
