@@ -302,6 +302,16 @@ int sipp_plonk_zs_partial_products(sipp_ctx *ctx, const uint64_t *d_wires, const
 int sipp_plonk_quotient_chunks(sipp_ctx *ctx, const uint64_t *d_wires_lde, const uint64_t *d_sigmas_lde, const uint64_t *d_zs_lde,
                                uint32_t log_n, uint32_t rate_bits, const sipp_plonk_params *p, const uint64_t *betas,
                                const uint64_t *gammas, const uint64_t *alphas, uint64_t *d_chunks);
+/* The same with the circuit's GATE-CONSTRAINT terms (round 4): plonk/vanishing_poly.rs builds vanishing_terms = vanishing_z_1_terms ++
+ * vanishing_partial_products_terms ++ constraint_terms and runs ONE reduce_with_powers over all of them per challenge.  The gates of the
+ * reference's circuit live in un-vendored crates, so their terms are the caller's: d_gate_terms [num_gate_terms][N << rate_bits], one
+ * column per constraint, at the rows of the committed LDEs in leaf order (only the first N max_degree rows -- the quotient coset 7 <w_(N D)>
+ * -- are read; any u64 congruent to the value).  A patched plonky2 whose gates stay on the CPU (or in its own kernels) evaluates them on
+ * the wires LDE it committed through sipp_commit_batch_ex and hands the columns over.  num_gate_terms == 0 / NULL: the call above. */
+int sipp_plonk_quotient_chunks_ex(sipp_ctx *ctx, const uint64_t *d_wires_lde, const uint64_t *d_sigmas_lde, const uint64_t *d_zs_lde,
+                                  uint32_t log_n, uint32_t rate_bits, const sipp_plonk_params *p, const uint64_t *betas,
+                                  const uint64_t *gammas, const uint64_t *alphas, const uint64_t *d_gate_terms, uint32_t num_gate_terms,
+                                  uint64_t *d_chunks);
 /* The whole argument as one call: commitments of sigmas, wires, zs_partial_products and quotient chunks, the transcript
  * (circuit_digest[4], public_inputs_hash[4], wires cap -> betas, gammas; zs cap -> alphas; quotient cap -> zeta) and one opening proof
  * (zeta: the four oracles; g zeta: the Z columns).  Flat proof (u64 words):
@@ -312,6 +322,23 @@ size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params *p, co
 int sipp_plonk_perm_prove(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *d_sigmas, uint32_t log_n, const sipp_plonk_params *p,
                           const sipp_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4],
                           uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
+
+/* prove() of plonk/prover.rs except gate evaluation and witness generation: as sipp_plonk_perm_prove, plus
+ *   - the gate-constraint terms in the quotient (d_gate_terms as for sipp_plonk_quotient_chunks_ex; may be NULL / 0),
+ *   - the PUBLIC INPUTS: public_inputs_hash = hash_n_to_hash_no_pad(public_inputs) is computed here and observed after circuit_digest;
+ *     the inputs themselves travel behind the opening proof,
+ *   - oracles the caller committed already with sipp_commit_batch_ex at this blowup and cap height (both optional): sigmas_oracle (the
+ *     constants_sigmas commitment is made once per circuit), and wires_oracle + wires_cap (the caller needed the wires LDE for its gates:
+ *     the same buffers are opened here, nothing is transformed twice).  d_wires / d_sigmas VALUES are always needed (Z and the partial
+ *     products are computed from values).
+ * Flat proof "SIPPPLK2": header[8] = magic, log_n, num_routed_wires, max_degree, num_challenges, total_len, num_gate_terms,
+ * n_public_inputs | wires cap | zs_partial_products cap | quotient cap | opening proof | public_inputs.
+ * proof_cap >= sipp_plonk_perm_proof_size(..) + n_public_inputs. */
+int sipp_plonk_prove_ex(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *d_sigmas, const sipp_oracle *wires_oracle,
+                        const uint64_t *wires_cap, const sipp_oracle *sigmas_oracle, uint32_t log_n, const sipp_plonk_params *p,
+                        const sipp_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t *public_inputs,
+                        uint32_t n_public_inputs, const uint64_t *d_gate_terms, uint32_t num_gate_terms, uint64_t *proof_out,
+                        size_t proof_cap, size_t *proof_len);
 
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.

@@ -7,7 +7,12 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define PLONK_MAGIC 0x314b4c5050504953ULL /* "SIPPPLK1" */
+#define PLONK_MAGIC 0x314b4c5050504953ULL  /* "SIPPPLK1" */
+#define PLONK_MAGIC2 0x324b4c5050504953ULL /* "SIPPPLK2": with gate-constraint terms and public inputs */
+
+static int plonk_prove_impl(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p, const orc_fri_params *fp,
+                            const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const uint64_t *public_inputs,
+                            uint32_t n_public_inputs, const orc_plonk_gates *g, uint64_t **proof, size_t *len);
 
 uint64_t orc_plonk_k_i(uint32_t j) { return gl_pow(7, j); }   /* get_unique_coset_shifts: g^j, g = MULTIPLICATIVE_GROUP_GENERATOR */
 
@@ -88,12 +93,33 @@ static void vanishing_terms_base(uint64_t x, uint64_t l0, const uint64_t *wv, co
 int orc_plonk_quotient_chunks(const uint64_t *wires_c, const uint64_t *sigmas_c, const uint64_t *zs_c, unsigned log_n,
                               const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
                               uint64_t *out) {
+    return orc_plonk_quotient_chunks_ex(wires_c, sigmas_c, zs_c, log_n, p, betas, gammas, alphas, NULL, 0, out);
+}
+
+/* the product gates of the synthetic test circuit on the quotient coset 7 <w_{N D}>, natural order: term k = w_{3k} w_{3k+1} - w_{3k+2} */
+void orc_plonk_gate_terms_coset(const uint64_t *wires_c, unsigned log_n, unsigned log_d, const orc_plonk_gates *g, uint64_t *out) {
+    const size_t n = (size_t)1 << log_n, nd = n << log_d;
+    uint64_t *wl = (uint64_t *)malloc((size_t)3 * g->num_mul * nd * 8);
+#pragma omp parallel for schedule(dynamic)
+    for (uint32_t j = 0; j < 3 * g->num_mul; j++) orc_coset_lde(wires_c + (size_t)j * n, log_n, log_d, 7, wl + (size_t)j * nd);
+    for (uint32_t k = 0; k < g->num_mul; k++)
+        for (size_t i = 0; i < nd; i++)
+            out[(size_t)k * nd + i] = gl_sub(gl_mul(wl[(size_t)(3 * k) * nd + i], wl[(size_t)(3 * k + 1) * nd + i]), wl[(size_t)(3 * k + 2) * nd + i]);
+    free(wl);
+}
+
+/* eval_vanishing_poly_base_batch with the circuit's gate-constraint terms supplied by the caller: vanishing_terms =
+ * vanishing_z_1_terms ++ vanishing_partial_products_terms ++ constraint_terms (plonk/vanishing_poly.rs), ONE reduce_with_powers over all
+ * of them per challenge.  gate_terms: [n_gate_terms][N D], natural order of the coset (NULL / 0: the permutation argument alone). */
+int orc_plonk_quotient_chunks_ex(const uint64_t *wires_c, const uint64_t *sigmas_c, const uint64_t *zs_c, unsigned log_n,
+                                 const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                                 const uint64_t *gate_terms, uint32_t n_gate_terms, uint64_t *out) {
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, np = orc_plonk_num_prods(p), m = np + 1;
     unsigned log_d = 0;
     while ((1u << log_d) < D) log_d++;
     if ((1u << log_d) != D || D < 2) return -2;
     const size_t n = (size_t)1 << log_n, nd = n << log_d;
-    const uint32_t nz = C * (1 + np), n_terms = C + C * m;
+    const uint32_t nz = C * (1 + np), n_perm = C + C * m, n_terms = n_perm + n_gate_terms;
     /* coset LDEs on 7 <w_{N D}>, natural order */
     uint64_t *wl = (uint64_t *)malloc((size_t)R * nd * 8), *sl = (uint64_t *)malloc((size_t)R * nd * 8), *zl = (uint64_t *)malloc((size_t)nz * nd * 8);
 #pragma omp parallel for schedule(dynamic)
@@ -123,6 +149,7 @@ int orc_plonk_quotient_chunks(const uint64_t *wires_c, const uint64_t *sigmas_c,
             for (uint32_t j = 0; j < nz; j++) zs[j] = zl[(size_t)j * nd + i];
             for (uint32_t c = 0; c < C; c++) zn[c] = zl[(size_t)c * nd + ((i + D) & (nd - 1))];   /* Z(g x): D steps on the coset */
             vanishing_terms_base(x, l0, wv, sg, zs, zn, zs + C, p, k_is, betas, gammas, terms);
+            for (uint32_t k = 0; k < n_gate_terms; k++) terms[n_perm + k] = gate_terms[(size_t)k * nd + i];
             const uint64_t zhi = gl_inv(zh);
             for (uint32_t c = 0; c < C; c++) {
                 uint64_t acc = 0;                               /* reduce_with_powers: sum_k alpha^k term_k */
@@ -150,9 +177,15 @@ int orc_plonk_quotient_chunks(const uint64_t *wires_c, const uint64_t *sigmas_c,
 
 void orc_plonk_eval_vanishing(gl2 x, const gl2 *wv, const gl2 *sg, const gl2 *zs, const gl2 *zs_next, const gl2 *pps, unsigned log_n,
                               const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas, gl2 *out) {
+    orc_plonk_eval_vanishing_ex(x, wv, sg, zs, zs_next, pps, log_n, p, betas, gammas, alphas, NULL, 0, out);
+}
+
+void orc_plonk_eval_vanishing_ex(gl2 x, const gl2 *wv, const gl2 *sg, const gl2 *zs, const gl2 *zs_next, const gl2 *pps, unsigned log_n,
+                                 const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                                 const gl2 *gate_terms, uint32_t n_gate_terms, gl2 *out) {
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, np = orc_plonk_num_prods(p), m = np + 1;
     const uint64_t n = (uint64_t)1 << log_n;
-    const uint32_t n_terms = C + C * m;
+    const uint32_t n_terms = C + C * m + n_gate_terms;
     gl2 *terms = (gl2 *)malloc(n_terms * sizeof(gl2));
     const gl2 zh = gl2_sub(gl2_pow(x, n), gl2_from(1));
     const gl2 l0 = gl2_mul(zh, gl2_inv(gl2_scale(gl2_sub(x, gl2_from(1)), n)));
@@ -169,6 +202,7 @@ void orc_plonk_eval_vanishing(gl2 x, const gl2 *wv, const gl2 *sg, const gl2 *zs
             const gl2 prev = q == 0 ? zs[c] : pps[c * np + q - 1], next = q == np ? zs_next[c] : pps[c * np + q];
             terms[t++] = gl2_sub(gl2_mul(prev, num), gl2_mul(next, den));
         }
+    for (uint32_t k = 0; k < n_gate_terms; k++) terms[t++] = gate_terms[k];
     for (uint32_t c = 0; c < C; c++) {
         gl2 acc = gl2_from(0);
         for (size_t k = n_terms; k-- > 0;) acc = gl2_add(gl2_scale(acc, alphas[c]), terms[k]);
@@ -184,6 +218,25 @@ static void draw(orc_challenger *ch, uint32_t C, uint64_t *v) {
 
 int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p, const orc_fri_params *fp,
                          const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], uint64_t **proof, size_t *len) {
+    return plonk_prove_impl(wires, sigmas, log_n, p, fp, circuit_digest, public_inputs_hash, NULL, 0, NULL, proof, len);
+}
+
+/* prove() with the gates' constraint terms in the quotient and the public inputs in the transcript (plonk/prover.rs: public_inputs_hash =
+ * hash_n_to_hash_no_pad(public_inputs); the challenger observes circuit_digest, that hash, the wires cap).  Flat proof "SIPPPLK2":
+ *   header[8]: magic, log_n, num_routed_wires, max_degree, num_challenges, total_len, n_gate_terms, n_public_inputs
+ *   wires cap | zs_partial_products cap | quotient cap | opening proof | public_inputs */
+int orc_plonk_prove_ex(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p, const orc_fri_params *fp,
+                       const uint64_t circuit_digest[4], const uint64_t *public_inputs, uint32_t n_public_inputs, const orc_plonk_gates *g,
+                       uint64_t **proof, size_t *len) {
+    uint64_t pih[4];
+    if (!g || 3 * g->num_mul > p->num_routed_wires || p->max_degree < 2) return -1;
+    orc_hash_no_pad(public_inputs, n_public_inputs, pih);
+    return plonk_prove_impl(wires, sigmas, log_n, p, fp, circuit_digest, pih, public_inputs, n_public_inputs, g, proof, len);
+}
+
+static int plonk_prove_impl(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p, const orc_fri_params *fp,
+                            const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const uint64_t *public_inputs,
+                            uint32_t n_public_inputs, const orc_plonk_gates *g, uint64_t **proof, size_t *len) {
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = orc_plonk_zs_cols(p);
     if (C == 0 || C > 8 || R == 0 || D < 2) return -1;
     const size_t n = (size_t)1 << log_n, cap_n = (size_t)1 << fp->cap_height;
@@ -204,7 +257,17 @@ int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned
     orc_chal_observe_cap(&ch, orc_batch_cap(bz), cap_n);
     draw(&ch, C, alphas);
     uint64_t *qc = (uint64_t *)malloc((size_t)C * D * n * 8);
-    int rc = orc_plonk_quotient_chunks(orc_batch_coeffs(bw), orc_batch_coeffs(bs), orc_batch_coeffs(bz), log_n, p, betas, gammas, alphas, qc);
+    uint64_t *gt = NULL;
+    const uint32_t n_gt = g ? g->num_mul : 0;
+    if (n_gt) {
+        unsigned log_d = 0;
+        while ((1u << log_d) < D) log_d++;
+        gt = (uint64_t *)malloc((size_t)n_gt * (n << log_d) * 8);
+        orc_plonk_gate_terms_coset(orc_batch_coeffs(bw), log_n, log_d, g, gt);
+    }
+    int rc = orc_plonk_quotient_chunks_ex(orc_batch_coeffs(bw), orc_batch_coeffs(bs), orc_batch_coeffs(bz), log_n, p, betas, gammas, alphas, gt,
+                                          n_gt, qc);
+    free(gt);
     orc_batch *bq = rc == 0 ? orc_batch_from_coeffs(qc, (size_t)C * D, log_n, fp->rate_bits, fp->cap_height) : NULL;
     free(qc);
     if (rc) { orc_batch_free(bs); orc_batch_free(bw); orc_batch_free(bz); return rc; }
@@ -217,14 +280,15 @@ int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned
     size_t op_len = 0;
     rc = orc_fri_prove_openings(oracles, 4, batches, 2, log_n, fp, &ch, &op, &op_len);
     if (rc == 0) {
-        const size_t total = 8 + 3 * cap_n * 4 + op_len;
+        const size_t total = 8 + 3 * cap_n * 4 + op_len + (g ? n_public_inputs : 0);
         uint64_t *out = (uint64_t *)malloc(total * 8);
-        const uint64_t h[8] = {PLONK_MAGIC, log_n, R, D, C, total, 0, 0};
+        const uint64_t h[8] = {g ? PLONK_MAGIC2 : PLONK_MAGIC, log_n, R, D, C, total, n_gt, g ? n_public_inputs : 0};
         memcpy(out, h, sizeof h);
         memcpy(out + 8, orc_batch_cap(bw), cap_n * 32);
         memcpy(out + 8 + cap_n * 4, orc_batch_cap(bz), cap_n * 32);
         memcpy(out + 8 + 2 * cap_n * 4, orc_batch_cap(bq), cap_n * 32);
         memcpy(out + 8 + 3 * cap_n * 4, op, op_len * 8);
+        if (g && n_public_inputs) memcpy(out + 8 + 3 * cap_n * 4 + op_len, public_inputs, (size_t)n_public_inputs * 8);
         *proof = out;
         *len = total;
     }
@@ -233,15 +297,38 @@ int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned
     return rc;
 }
 
+static int plonk_verify_impl(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
+                             const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const orc_plonk_gates *g);
+
 int orc_plonk_perm_verify(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
                           const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4]) {
+    return plonk_verify_impl(proof, len, sigmas_cap, p, fp, circuit_digest, public_inputs_hash, NULL);
+}
+
+/* plonk/verifier.rs with the gates: the public inputs come with the proof, their hash enters the transcript, and the gate-constraint terms
+ * at zeta are evaluated from the opened wires (the synthetic circuit's product gates) */
+int orc_plonk_verify_ex(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
+                        const uint64_t circuit_digest[4], const orc_plonk_gates *g) {
+    if (!g || len < 8 || proof[0] != PLONK_MAGIC2 || proof[6] != g->num_mul || proof[7] > len) return -201;
+    uint64_t pih[4];
+    const size_t n_pi = (size_t)proof[7];
+    orc_hash_no_pad(proof + len - n_pi, n_pi, pih);
+    return plonk_verify_impl(proof, len, sigmas_cap, p, fp, circuit_digest, pih, g);
+}
+
+static int plonk_verify_impl(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
+                             const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const orc_plonk_gates *g) {
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, np = orc_plonk_num_prods(p), nz = orc_plonk_zs_cols(p);
     const size_t cap_n = (size_t)1 << fp->cap_height;
-    if (len < 8 + 3 * cap_n * 4 || proof[0] != PLONK_MAGIC || proof[2] != R || proof[3] != D || proof[4] != C || proof[5] != len) return -201;
+    if (len < 8 + 3 * cap_n * 4 || proof[0] != (g ? PLONK_MAGIC2 : PLONK_MAGIC) || proof[2] != R || proof[3] != D || proof[4] != C || proof[5] != len)
+        return -201;
+    if (g && 3 * g->num_mul > R) return -201;
+    const size_t n_pi = g ? (size_t)proof[7] : 0;
+    if (n_pi > len - (8 + 3 * cap_n * 4)) return -201;
     const unsigned log_n = (unsigned)proof[1];
     if (log_n < 1 || log_n > 26 || C == 0 || C > 8) return -202;
     const uint64_t *wcap = proof + 8, *zcap = wcap + cap_n * 4, *qcap = zcap + cap_n * 4, *op = qcap + cap_n * 4;
-    const size_t op_len = len - (size_t)(op - proof);
+    const size_t op_len = len - (size_t)(op - proof) - n_pi;
     orc_challenger ch;
     orc_chal_init(&ch);
     orc_chal_observe_many(&ch, circuit_digest, 4);
@@ -267,7 +354,11 @@ int orc_plonk_perm_verify(const uint64_t *proof, size_t len, const uint64_t *sig
     (void)np;
     /* plonk/verifier.rs: vanishing(zeta) == Z_H(zeta) * sum_d zeta^(N d) q_{c,d}(zeta) for every challenge */
     gl2 van[8];
-    orc_plonk_eval_vanishing(zeta, wv, sg, zs, zs_next, pps, log_n, p, betas, gammas, alphas, van);
+    const uint32_t n_gt = g ? g->num_mul : 0;
+    gl2 *gt = (gl2 *)malloc((n_gt + 1) * sizeof(gl2));
+    for (uint32_t k = 0; k < n_gt; k++) gt[k] = gl2_sub(gl2_mul(wv[3 * k], wv[3 * k + 1]), wv[3 * k + 2]);
+    orc_plonk_eval_vanishing_ex(zeta, wv, sg, zs, zs_next, pps, log_n, p, betas, gammas, alphas, gt, n_gt, van);
+    free(gt);
     const gl2 zeta_n = gl2_pow(zeta, (uint64_t)1 << log_n), zh = gl2_sub(zeta_n, gl2_from(1));
     int rc = 0;
     for (uint32_t c = 0; c < C && rc == 0; c++) {

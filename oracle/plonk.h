@@ -40,6 +40,28 @@ int orc_plonk_quotient_chunks(const uint64_t *wires_c, const uint64_t *sigmas_c,
                               const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
                               uint64_t *out);
 
+/* ---- the same with the circuit's GATE-CONSTRAINT terms (round 4): vanishing_terms = z_1 terms ++ partial-product terms ++ constraint
+ * terms, one reduce_with_powers over all of them (plonk/vanishing_poly.rs).  The reference's circuit is not vendored, so the terms are
+ * the caller's; the test circuit below stands in for a gate set: num_mul product gates, term k = w_{3k} w_{3k+1} - w_{3k+2} on every row. */
+typedef struct {
+    uint32_t num_mul;
+} orc_plonk_gates;
+/* that circuit's terms on the quotient coset 7 <w_{N D}>, natural order: out [num_mul][N D] */
+void orc_plonk_gate_terms_coset(const uint64_t *wires_c, unsigned log_n, unsigned log_d, const orc_plonk_gates *g, uint64_t *out);
+int orc_plonk_quotient_chunks_ex(const uint64_t *wires_c, const uint64_t *sigmas_c, const uint64_t *zs_c, unsigned log_n,
+                                 const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas, const uint64_t *alphas,
+                                 const uint64_t *gate_terms, uint32_t n_gate_terms, uint64_t *out);
+void orc_plonk_eval_vanishing_ex(gl2 x, const gl2 *wires, const gl2 *sigmas, const gl2 *zs, const gl2 *zs_next, const gl2 *pps,
+                                 unsigned log_n, const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas,
+                                 const uint64_t *alphas, const gl2 *gate_terms, uint32_t n_gate_terms, gl2 *out);
+/* the flow with gates and public inputs: flat proof "SIPPPLK2" = header[8] (.., n_gate_terms, n_public_inputs) | the three caps | opening
+ * proof | public_inputs; transcript: circuit_digest, hash_no_pad(public_inputs), wires cap -> ... as above */
+int orc_plonk_prove_ex(const uint64_t *wires, const uint64_t *sigmas, unsigned log_n, const orc_plonk_params *p, const orc_fri_params *fp,
+                       const uint64_t circuit_digest[4], const uint64_t *public_inputs, uint32_t n_public_inputs, const orc_plonk_gates *g,
+                       uint64_t **proof, size_t *len);
+int orc_plonk_verify_ex(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
+                        const uint64_t circuit_digest[4], const orc_plonk_gates *g);
+
 /* the verifier's side: vanishing terms at an extension point from opened values, reduced with the powers of every alpha */
 void orc_plonk_eval_vanishing(gl2 x, const gl2 *wires, const gl2 *sigmas, const gl2 *zs, const gl2 *zs_next, const gl2 *pps,
                               unsigned log_n, const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas,

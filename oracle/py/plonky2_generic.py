@@ -491,9 +491,11 @@ def check_partial_products(numerators, denominators, partials, z_x, z_gx, max_de
     return out
 
 
-def eval_vanishing_poly_permutation(n_log, x, wires, sigmas, zs, zs_next, partial_products, betas, gammas, alphas, max_degree):
-    """the permutation terms of eval_vanishing_poly at the extension point x from opened values, reduced with the powers of every alpha:
-    vanishing_z_1_terms ++ vanishing_partial_products_terms (no gates: the circuit is not vendored)"""
+def eval_vanishing_poly_permutation(n_log, x, wires, sigmas, zs, zs_next, partial_products, betas, gammas, alphas, max_degree,
+                                    constraint_terms=()):
+    """eval_vanishing_poly at the extension point x from opened values, reduced with the powers of every alpha:
+    vanishing_z_1_terms ++ vanishing_partial_products_terms ++ constraint_terms (the gates' terms at x are the caller's: the circuit is not
+    vendored; () = the permutation argument alone)"""
     num_routed, num_ch = len(wires), len(betas)
     num_prods = len(partial_products) // num_ch
     k_is = get_unique_coset_shifts(num_routed)
@@ -505,7 +507,7 @@ def eval_vanishing_poly_permutation(n_log, x, wires, sigmas, zs, zs_next, partia
         denominators = [wires[j] + sigmas[j] * ext(betas[i]) + ext(gammas[i]) for j in range(num_routed)]
         pp_terms += check_partial_products(numerators, denominators, partial_products[i * num_prods:(i + 1) * num_prods], zs[i], zs_next[i],
                                            max_degree)
-    terms = z1_terms + pp_terms
+    terms = z1_terms + pp_terms + list(constraint_terms)
     out = []
     for a in alphas:                                             # reduce_with_powers
         acc = ext(0)

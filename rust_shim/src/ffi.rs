@@ -147,10 +147,19 @@ extern "C" {
     pub fn sipp_plonk_quotient_chunks(ctx: *mut SippCtxOpaque, d_wires_lde: *const u64, d_sigmas_lde: *const u64, d_zs_lde: *const u64, log_n: u32,
                                       rate_bits: u32, p: *const SippPlonkParams, betas: *const u64, gammas: *const u64, alphas: *const u64,
                                       d_chunks: *mut u64) -> c_int;
+    pub fn sipp_plonk_quotient_chunks_ex(ctx: *mut SippCtxOpaque, d_wires_lde: *const u64, d_sigmas_lde: *const u64, d_zs_lde: *const u64, log_n: u32,
+                                         rate_bits: u32, p: *const SippPlonkParams, betas: *const u64, gammas: *const u64, alphas: *const u64,
+                                         d_gate_terms: *const u64, num_gate_terms: u32, d_chunks: *mut u64) -> c_int;
     pub fn sipp_plonk_perm_proof_size(log_n: u32, p: *const SippPlonkParams, fp: *const SippFriParams) -> usize;
     pub fn sipp_plonk_perm_prove(ctx: *mut SippCtxOpaque, d_wires: *const u64, d_sigmas: *const u64, log_n: u32, p: *const SippPlonkParams,
                                  fp: *const SippFriParams, circuit_digest: *const u64, public_inputs_hash: *const u64, proof_out: *mut u64,
                                  proof_cap: usize, proof_len: *mut usize) -> c_int;
+    /// prove() except gate evaluation and witness generation: caller-supplied gate-constraint terms, public inputs, pre-committed oracles
+    pub fn sipp_plonk_prove_ex(ctx: *mut SippCtxOpaque, d_wires: *const u64, d_sigmas: *const u64, wires_oracle: *const SippOracle,
+                               wires_cap: *const u64, sigmas_oracle: *const SippOracle, log_n: u32, p: *const SippPlonkParams,
+                               fp: *const SippFriParams, circuit_digest: *const u64, public_inputs: *const u64, n_public_inputs: u32,
+                               d_gate_terms: *const u64, num_gate_terms: u32, proof_out: *mut u64, proof_cap: usize,
+                               proof_len: *mut usize) -> c_int;
     pub fn sipp_ntt_batch(ctx: *mut SippCtxOpaque, d_cols: *mut u64, col_stride: usize, ncols: usize, log_n: u32, inverse: c_int) -> c_int;
     pub fn sipp_lde_batch(ctx: *mut SippCtxOpaque, d_values: *const u64, d_coeffs: *mut u64, d_lde: *mut u64, ncols: usize, log_n: u32) -> c_int;
     pub fn sipp_poseidon_leaves(ctx: *mut SippCtxOpaque, d_lde: *const u64, ncols: usize, log_leaves: u32, d_digests: *mut u64) -> c_int;

@@ -100,6 +100,9 @@ SIGNATURES = {
     "sipp_plonk_num_partial_products": (C.c_uint32, [C.POINTER(PlonkParams)]),
     "sipp_plonk_zs_partial_products": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), u64p, u64p, vp]),
     "sipp_plonk_quotient_chunks": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(PlonkParams), u64p, u64p, u64p, vp]),
+    "sipp_plonk_quotient_chunks_ex": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(PlonkParams), u64p, u64p, u64p, vp, C.c_uint32, vp]),
+    "sipp_plonk_prove_ex": (C.c_int, [vp, vp, vp, C.POINTER(Oracle), u64p, C.POINTER(Oracle), C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams),
+                                      u64p, u64p, C.c_uint32, vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_plonk_perm_proof_size": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams)]),
     "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
@@ -312,6 +315,37 @@ class Ctx:
                                                    C.byref(p), self._u64(betas), self._u64(gammas), self._u64(alphas), out.data_ptr()),
                  "plonk_quotient_chunks")
         return out
+
+    def plonk_quotient_chunks_ex(self, wires_lde, sigmas_lde, zs_lde, log_n, rate_bits, p, betas, gammas, alphas, gate_terms):
+        """gate_terms: [K, N << rate_bits] device int64 (leaf order) or None"""
+        import torch
+        out = torch.empty((p.num_challenges * p.max_degree, 1 << log_n), dtype=torch.int64, device=wires_lde.device)
+        k = 0 if gate_terms is None else gate_terms.shape[0]
+        self._ck(self.L.sipp_plonk_quotient_chunks_ex(self.h, wires_lde.data_ptr(), sigmas_lde.data_ptr(), zs_lde.data_ptr(), log_n, rate_bits,
+                                                      C.byref(p), self._u64(betas), self._u64(gammas), self._u64(alphas),
+                                                      None if gate_terms is None else gate_terms.data_ptr(), k, out.data_ptr()),
+                 "plonk_quotient_chunks_ex")
+        return out
+
+    def plonk_prove_ex(self, wires, sigmas, log_n, p, fp, digest, public_inputs, gate_terms=None, wires_oracle=None, wires_cap=None,
+                       sigmas_oracle=None):
+        """sipp_plonk_prove_ex: the flow with gate terms, public inputs (host ints) and optional pre-committed oracles (Oracle structs)"""
+        pis = [int(x) for x in public_inputs]
+        cap = self.L.sipp_plonk_perm_proof_size(log_n, C.byref(p), C.byref(fp))
+        if cap == 0:
+            raise SippError(-1, "sipp_plonk_perm_proof_size")
+        cap += len(pis)
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        k = 0 if gate_terms is None else gate_terms.shape[0]
+        wc_arr = None if wires_cap is None else np.ascontiguousarray(wires_cap, dtype=np.uint64).reshape(-1)     # alive until the call returns
+        wcap = None if wc_arr is None else wc_arr.ctypes.data_as(u64p)
+        self._ck(self.L.sipp_plonk_prove_ex(self.h, wires.data_ptr(), sigmas.data_ptr(), None if wires_oracle is None else C.byref(wires_oracle), wcap,
+                                            None if sigmas_oracle is None else C.byref(sigmas_oracle), log_n, C.byref(p), C.byref(fp),
+                                            self._u64(digest), self._u64(pis) if pis else None, len(pis),
+                                            None if gate_terms is None else gate_terms.data_ptr(), k, out.ctypes.data, cap, C.byref(n)),
+                 "plonk_prove_ex")
+        return out[: n.value]
 
     def plonk_perm_prove(self, wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
         cap = self.L.sipp_plonk_perm_proof_size(log_n, C.byref(p), C.byref(fp))

@@ -112,6 +112,8 @@ struct QuotArgs {
     uint64_t zh[64];
     uint64_t n_field;         // n as a field element
     uint64_t* qv;             // [C][n D]  leaf order of the quotient coset
+    const uint64_t* gt;       // [n_gt][stride] caller-supplied gate-constraint terms, leaf order (nullptr: none)
+    uint32_t n_gt;
 };
 
 __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
@@ -153,6 +155,9 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
             prev = next;
         }
     }
+    // constraint_terms: the circuit's gate constraints at this point, evaluated by the caller (vanishing_poly.rs appends them to the
+    // permutation terms; one reduce_with_powers runs over all of them)
+    for (uint32_t k = 0; k < a.n_gt; k++) push(gl::canon(a.gt[(size_t)k * a.stride + pos]));
     for (uint32_t c = 0; c < C; c++) a.qv[(size_t)c * nd + pos] = gl::mul(acc[c], zhi);
 }
 
@@ -226,6 +231,14 @@ int sipp_plonk_zs_partial_products(sipp_ctx* ctx, const uint64_t* d_wires, const
 int sipp_plonk_quotient_chunks(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
                                uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas,
                                const uint64_t* alphas, uint64_t* d_chunks) {
+    return sipp_plonk_quotient_chunks_ex(ctx, d_wires_lde, d_sigmas_lde, d_zs_lde, log_n, rate_bits, p, betas, gammas, alphas, nullptr, 0, d_chunks);
+}
+
+int sipp_plonk_quotient_chunks_ex(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
+                                  uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas,
+                                  const uint64_t* alphas, const uint64_t* d_gate_terms, uint32_t num_gate_terms, uint64_t* d_chunks) {
+    if ((num_gate_terms != 0) != (d_gate_terms != nullptr) || num_gate_terms > (1u << 20)) return ctx ? sipp_fail(ctx, SIPP_E_BADARG, "plonk: gate terms and their count disagree") : SIPP_E_BADARG;
+
     if (!ctx || !d_wires_lde || !d_sigmas_lde || !d_zs_lde || !betas || !gammas || !alphas || !d_chunks) return SIPP_E_BADARG;
     uint32_t log_d, m;
     SIPP_TRY(check(ctx, p, log_n, &log_d, &m));
@@ -252,6 +265,8 @@ int sipp_plonk_quotient_chunks(sipp_ctx* ctx, const uint64_t* d_wires_lde, const
     a.bk = upload_bk(ctx, p, betas);
     if (!a.bk) return SIPP_E_NOMEM;
     a.qv = d_chunks;           // [C][n D]: values in leaf order, transformed in place
+    a.gt = d_gate_terms;
+    a.n_gt = num_gate_terms;
     {
         ProfScope ps(ctx, "plonk_quotient");
         hipLaunchKernelGGL(plonk_quotient_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, ctx->stream, a);
@@ -264,10 +279,55 @@ int sipp_plonk_quotient_chunks(sipp_ctx* ctx, const uint64_t* d_wires_lde, const
 
 // the flow of oracle/plonk.c::orc_plonk_perm_prove on the device: four PolynomialBatch commitments, the transcript on the host, one
 // opening proof at zeta / g zeta.  Flat proof: header[8] | wires cap | zs_partial_products cap | quotient cap | opening proof.
+namespace {
+// Optional parts of the flow: gate-constraint terms in the quotient, public inputs in the transcript and behind the proof ("SIPPPLK2"),
+// and oracles the caller committed already (sigmas once per circuit; wires before it evaluated its gates on their LDE)
+struct PlonkExtra {
+    const uint64_t* d_gate_terms = nullptr;
+    uint32_t n_gate_terms = 0;
+    const uint64_t* public_inputs = nullptr;
+    uint32_t n_public_inputs = 0;
+    bool v2 = false;
+    const sipp_oracle* sigmas_oracle = nullptr;
+    const sipp_oracle* wires_oracle = nullptr;
+    const uint64_t* wires_cap = nullptr;
+};
+int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
+                     const sipp_fri_params* fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const PlonkExtra& ex,
+                     uint64_t* proof_out, size_t proof_cap, size_t* proof_len);
+}  // namespace
+
 int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
                           const sipp_fri_params* fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4],
                           uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
     if (!ctx || !d_wires || !d_sigmas || !fp || !circuit_digest || !public_inputs_hash || !proof_out || !proof_len) return SIPP_E_BADARG;
+    return plonk_prove_impl(ctx, d_wires, d_sigmas, log_n, p, fp, circuit_digest, public_inputs_hash, PlonkExtra{}, proof_out, proof_cap, proof_len);
+}
+
+int sipp_plonk_prove_ex(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, const sipp_oracle* wires_oracle, const uint64_t* wires_cap,
+                        const sipp_oracle* sigmas_oracle, uint32_t log_n, const sipp_plonk_params* p, const sipp_fri_params* fp,
+                        const uint64_t circuit_digest[4], const uint64_t* public_inputs, uint32_t n_public_inputs, const uint64_t* d_gate_terms,
+                        uint32_t num_gate_terms, uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !d_wires || !d_sigmas || !fp || !p || !circuit_digest || !proof_out || !proof_len || (n_public_inputs && !public_inputs) ||
+        (num_gate_terms != 0) != (d_gate_terms != nullptr) || (wires_oracle != nullptr) != (wires_cap != nullptr) || n_public_inputs > (1u << 24))
+        return SIPP_E_BADARG;
+    if ((wires_oracle && (wires_oracle->n_polys != p->num_routed_wires || wires_oracle->n_salt || !wires_oracle->d_coeffs || !wires_oracle->d_lde ||
+                          !wires_oracle->d_tree)) ||
+        (sigmas_oracle && (sigmas_oracle->n_polys != p->num_routed_wires || sigmas_oracle->n_salt || !sigmas_oracle->d_coeffs ||
+                           !sigmas_oracle->d_lde || !sigmas_oracle->d_tree)))
+        return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a pre-committed oracle must hold num_routed_wires unsalted polynomials");
+    uint64_t pih[4];
+    host::Challenger::hash_no_pad(public_inputs, n_public_inputs, pih);      // plonk/prover.rs: hash_n_to_hash_no_pad(public_inputs)
+    PlonkExtra ex;
+    ex.d_gate_terms = d_gate_terms; ex.n_gate_terms = num_gate_terms; ex.public_inputs = public_inputs; ex.n_public_inputs = n_public_inputs;
+    ex.v2 = true; ex.sigmas_oracle = sigmas_oracle; ex.wires_oracle = wires_oracle; ex.wires_cap = wires_cap;
+    return plonk_prove_impl(ctx, d_wires, d_sigmas, log_n, p, fp, circuit_digest, pih, ex, proof_out, proof_cap, proof_len);
+}
+
+namespace {
+int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
+                     const sipp_fri_params* fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const PlonkExtra& ex,
+                     uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
     uint32_t log_d, m;
     SIPP_TRY(check(ctx, p, log_n, &log_d, &m));
     if (fp->rate_bits < log_d || fp->rate_bits > 3 || fp->cap_height > 8 || fp->hiding)
@@ -278,7 +338,14 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
     const size_t n = (size_t)1 << log_n, M = n << fp->rate_bits, cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
     const uint32_t ncols[4] = {R, R, nz, C * D};
     uint64_t *co[4], *lde[4], *tree[4];
+    const sipp_oracle* pre[4] = {ex.sigmas_oracle, ex.wires_oracle, nullptr, nullptr};
     for (int o = 0; o < 4; o++) {
+        if (pre[o]) {      // committed by the caller: read only
+            co[o] = const_cast<uint64_t*>(pre[o]->d_coeffs);
+            lde[o] = const_cast<uint64_t*>(pre[o]->d_lde);
+            tree[o] = const_cast<uint64_t*>(pre[o]->d_tree);
+            continue;
+        }
         co[o] = arena_alloc_t<uint64_t>(ctx, (size_t)ncols[o] * n);
         lde[o] = arena_alloc_t<uint64_t>(ctx, (size_t)ncols[o] * M);
         tree[o] = arena_alloc_t<uint64_t>(ctx, 2 * M * 4);
@@ -286,8 +353,11 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
     }
     std::vector<uint64_t> caps(4 * cap_n * 4);
     auto cap_of = [&](int o) { return caps.data() + (size_t)o * cap_n * 4; };
-    SIPP_TRY(sipp_commit_batch_ex(ctx, d_sigmas, 0, co[0], lde[0], tree[0], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(0)));
-    SIPP_TRY(sipp_commit_batch_ex(ctx, d_wires, 0, co[1], lde[1], tree[1], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(1)));
+    if (!pre[0]) SIPP_TRY(sipp_commit_batch_ex(ctx, d_sigmas, 0, co[0], lde[0], tree[0], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(0)));
+    if (!pre[1])
+        SIPP_TRY(sipp_commit_batch_ex(ctx, d_wires, 0, co[1], lde[1], tree[1], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(1)));
+    else
+        memcpy(cap_of(1), ex.wires_cap, cap_n * 32);
     host::Challenger ch;
     ch.observe_many(circuit_digest, 4);
     ch.observe_many(public_inputs_hash, 4);
@@ -303,7 +373,8 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
     }
     ch.observe_many(cap_of(2), cap_n * 4);
     for (uint32_t c = 0; c < C; c++) alphas[c] = ch.get();
-    SIPP_TRY(sipp_plonk_quotient_chunks(ctx, lde[1], lde[0], lde[2], log_n, fp->rate_bits, p, betas, gammas, alphas, co[3]));
+    SIPP_TRY(sipp_plonk_quotient_chunks_ex(ctx, lde[1], lde[0], lde[2], log_n, fp->rate_bits, p, betas, gammas, alphas, ex.d_gate_terms,
+                                           ex.n_gate_terms, co[3]));
     SIPP_TRY(sipp_commit_batch_ex(ctx, co[3], 1, co[3], lde[3], tree[3], (size_t)C * D, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(3)));
     ch.observe_many(cap_of(3), cap_n * 4);
     const gl::E2 zeta = ch.get_ext();
@@ -313,9 +384,9 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
     const gl::E2 gz = gl::scale(zeta, gl::root_of_unity(log_n));
     sipp_fri_batch batches[2] = {{{zeta.c0, zeta.c1}, 4, r0}, {{gz.c0, gz.c1}, 1, r1}};
     const size_t op_cap = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
-    const size_t head = 8 + 3 * cap_n * 4;
+    const size_t head = 8 + 3 * cap_n * 4, tail = ex.v2 ? ex.n_public_inputs : 0;
     if (op_cap == 0) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: FRI parameters do not fit the degree");
-    if (proof_cap < head + op_cap) return sipp_fail(ctx, SIPP_E_BUFSZ, "plonk: proof buffer too small (see sipp_plonk_perm_proof_size)");
+    if (proof_cap < head + op_cap + tail) return sipp_fail(ctx, SIPP_E_BUFSZ, "plonk: proof buffer too small (see sipp_plonk_perm_proof_size)");
     sipp_challenger cs{};
     memcpy(cs.state, ch.state, sizeof cs.state);
     memcpy(cs.in_buf, ch.in_buf, sizeof cs.in_buf);
@@ -323,15 +394,18 @@ int sipp_plonk_perm_prove(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t
     cs.n_in = ch.n_in;
     cs.n_out = ch.n_out;
     size_t op_len = 0;
-    SIPP_TRY(sipp_fri_prove_openings(ctx, oracles, 4, batches, 2, log_n, fp, &cs, proof_out + head, proof_cap - head, &op_len));
-    const uint64_t h[8] = {0x314b4c5050504953ULL /* "SIPPPLK1" */, log_n, R, D, C, head + op_len, 0, 0};
+    SIPP_TRY(sipp_fri_prove_openings(ctx, oracles, 4, batches, 2, log_n, fp, &cs, proof_out + head, proof_cap - head - tail, &op_len));
+    const uint64_t h[8] = {ex.v2 ? 0x324b4c5050504953ULL /* "SIPPPLK2" */ : 0x314b4c5050504953ULL /* "SIPPPLK1" */, log_n, R, D, C,
+                           head + op_len + tail, ex.v2 ? ex.n_gate_terms : 0, tail};
     memcpy(proof_out, h, sizeof h);
+    if (tail) memcpy(proof_out + head + op_len, ex.public_inputs, tail * 8);
     memcpy(proof_out + 8, cap_of(1), cap_n * 32);
     memcpy(proof_out + 8 + cap_n * 4, cap_of(2), cap_n * 32);
     memcpy(proof_out + 8 + 2 * cap_n * 4, cap_of(3), cap_n * 32);
-    *proof_len = head + op_len;
+    *proof_len = head + op_len + tail;
     return SIPP_OK;
 }
+}  // namespace
 
 size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params* p, const sipp_fri_params* fp) {
     // the bounds of check(): sizes below are u32 products

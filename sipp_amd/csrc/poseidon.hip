@@ -36,6 +36,9 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
     const uint64_t* p = lde + j;
+#ifndef SIPP_POSEIDON_VALU_MDS
+    __shared__ uint64_t stash[11 * 256];      // poseidon.hpp::partial_rounds_blocked: eleven state words per lane wait here
+#endif
     // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
 #pragma unroll 1
     for (uint32_t c = 0; c < ncols; c += 8) {
@@ -46,7 +49,7 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #ifdef SIPP_POSEIDON_VALU_MDS
         poseidon::permute<false>(s);
 #else
-        poseidon::permute<true>(s);
+        poseidon::permute<true>(s, stash + threadIdx.x, blockDim.x);
 #endif
     }
     if (j0 >= n_leaves) return;
@@ -394,6 +397,8 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_blk3), SIPP_POSEIDON_BLK3, sizeof(SIPP_POSEIDON_BLK3)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb3), SIPP_POSEIDON_COMB3, sizeof(SIPP_POSEIDON_COMB3)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb_c), SIPP_POSEIDON_COMB_C, sizeof(SIPP_POSEIDON_COMB_C)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_dense_a), SIPP_POSEIDON_DENSE_A, sizeof(SIPP_POSEIDON_DENSE_A)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_dense_start), SIPP_POSEIDON_DENSE_START, sizeof(SIPP_POSEIDON_DENSE_START)));
     return SIPP_OK;
 }
 

@@ -37,6 +37,10 @@ __constant__ uint64_t c_fast_what[22 * 11];
 __constant__ uint32_t c_blk3[2 * SIPP_POSEIDON_BLK_WORDS];
 __constant__ uint32_t c_comb3[396];
 __constant__ uint64_t c_comb_c[12];
+// dense constant products on the matrix pipe (dense_mfma below): per-lane A fragments in global memory (16 B per lane and digit,
+// read with one coalesced load), chain start constants wave-uniform
+__device__ uint32_t d_dense_a[SIPP_POSEIDON_DENSE_MATS * 8 * 64 * 4];
+__constant__ uint64_t c_dense_start[SIPP_POSEIDON_DENSE_MATS * 12 * 2];
 
 // S-box products: the hand-scheduled block of gl_lazy.hpp when the translation unit reserves its temporaries (GLL_T), the compiler's
 // sequence otherwise (-DSIPP_POSEIDON_C_MUL keeps the latter for A/B runs)
@@ -189,6 +193,92 @@ __device__ __forceinline__ void mds_full_mfma(uint64_t s[12], const uint64_t* __
         s[r] = SIPP_PRED96(h, l);
     }
 }
+
+// ---- DENSE products with full 64-bit constants on the matrix pipe (round 4) ----------------------------------------------------------
+// out[r] = sum_e M[r][e] x_e (+ addend_r) + const_r for one of the five constant matrices the lazy partial rounds are built from (the
+// merged affine layer of full round 3; W and V of each block of eleven rounds; tables and the algebra: tools/gen_poseidon_header.py
+// dense_tables / dense_model).  x_e: ANY u64, as 8 byte planes (the transposes of mds_full_mfma); the constants: 8 signed base-256 digits;
+// 64 products of (plane a) x (digit b), chained in the accumulator by t = a + b (<= 8 x 12 x 2^14 < 2^21 each), and the fifteen sums D_t
+// folded into two signed 64-bit chains L, H with 2^64 = 2^32 - 1, 2^96 = -1 (mod p): 19 multiply-adds per output instead of 66 (72) and
+// ONE 96-bit reduction (4 instructions) instead of an Acc6 reduction (~50).  The A fragments have the block-diagonal layout of
+// mds_a_fragment, so every lane finds its own outputs in accumulator registers 0 .. 11.
+template <bool ADDEND>
+__device__ __forceinline__ void dense_mfma(const uint32_t lo[12], const uint32_t hi[12], uint32_t mat, uint64_t out[12], const uint64_t* __restrict__ addend,
+                                           uint32_t addend_stride, uint32_t z) {
+    uint32_t plane[8][3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        uint32_t o[4];
+        mds_transpose4(lo + 4 * g, o);
+#pragma unroll
+        for (int b = 0; b < 4; b++) plane[b][g] = o[b] ^ 0x80808080u;
+        mds_transpose4(hi + 4 * g, o);
+#pragma unroll
+        for (int b = 0; b < 4; b++) plane[4 + b][g] = o[b] ^ 0x80808080u;
+    }
+    // this lane's A fragments of the eight digits: 12 of the 16 bytes are columns of the matrix (k = 16 h + e, e < 12), the rest is zero
+    // and never loaded -- 24 VGPRs instead of 32
+    typedef int v3i __attribute__((ext_vector_type(3)));
+    v3i afr[8];
+    {
+        // wave-uniform base + one 32-bit lane offset (no per-lane 64-bit pointers hoisted out of the caller's loops)
+        const uint32_t* __restrict__ A = d_dense_a + mat * (8 * 64 * 4);
+        const uint32_t lane4 = (threadIdx.x & 63) * 4;
+#pragma unroll
+        for (int b = 0; b < 8; b++) afr[b] = *reinterpret_cast<const v3i*>(A + (lane4 + b * 256));
+    }
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    const int32_t n1 = (int32_t)(0xffffffffu + z), n8 = -p8, n16 = -p16, n24 = -p24, p1 = (int32_t)(1u + z);
+    const uint64_t* __restrict__ K = c_dense_start + mat * 24 + z;
+    int64_t L[12], H[12];
+#pragma unroll
+    for (int t = 0; t < 15; t++) {
+        __builtin_amdgcn_sched_barrier(0);      // one accumulator chain at a time: keeps a single D (16 VGPRs) live
+        mfma_v16i d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int a = (t > 7 ? t - 7 : 0); a <= (t < 7 ? t : 7); a++) {
+            const mfma_v4i bfrag = {(int)plane[a][0], (int)plane[a][1], (int)plane[a][2], 0};
+            const mfma_v4i afrag = {afr[t - a][0], afr[t - a][1], afr[t - a][2], 0};
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, bfrag, d, 0, 0, 0);
+        }
+        const int32_t pw = (t & 3) == 0 ? p1 : (t & 3) == 1 ? p8 : (t & 3) == 2 ? p16 : p24;
+        const int32_t nw = (t & 3) == 0 ? n1 : (t & 3) == 1 ? n8 : (t & 3) == 2 ? n16 : n24;
+#pragma unroll
+        for (int r = 0; r < 11; r++) {
+            if (t == 0) {
+                uint64_t l0 = K[2 * r], h0 = K[2 * r + 1];          // chain starts (positive: + 2^50), plus the per-lane addend's halves
+                if (ADDEND) {                                       // per-lane addend (LDS stash, see partial_rounds_blocked)
+                    const uint64_t av = addend[r * addend_stride];
+                    l0 += (uint32_t)av;
+                    h0 += av >> 32;
+                }
+                L[r] = (int64_t)d[r] + (int64_t)l0;
+                H[r] = (int64_t)h0;
+            } else if (t < 4) {
+                L[r] = (int64_t)d[r] * (int64_t)pw + L[r];
+                asm volatile("" : "+v"(L[r]));
+                continue;
+            } else if (t < 8) {
+                H[r] = (int64_t)d[r] * (int64_t)pw + H[r];
+            } else if (t < 12) {
+                H[r] = (int64_t)d[r] * (int64_t)pw + H[r];
+                L[r] = (int64_t)d[r] * (int64_t)nw + L[r];
+            } else {
+                L[r] = (int64_t)d[r] * (int64_t)nw + L[r];
+            }
+            // the chains are folded HERE, one D at a time: without the opaque use the compiler reassociates the sums and keeps all
+            // fifteen accumulators (240 VGPRs) until the end
+            asm volatile("" : "+v"(L[r]), "+v"(H[r]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 11; r++) {
+        const uint64_t a = (uint64_t)L[r], hh = (uint64_t)H[r];   // both in (0, 2^52)
+        const uint64_t l = a + (hh << 32);
+        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
+        out[r] = SIPP_PRED96(h, l);
+    }
+}
 #endif
 
 using gl::Acc160;
@@ -210,6 +300,7 @@ using gl::Acc6;
 // full round 3 without its own MDS: its linear layer, the FIRST constants of the sparse form and the dense 11 x 11
 // pre-multiplication are ONE affine map s -> C s + c (tools/gen_poseidon_header.py combined_layer).  Row 0 of C is row 0 of
 // the MDS (small constants); rows 1..11 are 12 lazy MACs each, with c as the accumulators' start value.
+template <bool MFMA>
 __device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z) {
     uint32_t lo[12], hi[12];
 #pragma unroll
@@ -230,6 +321,13 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z)
         const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
         s[0] = gl::add_nc(SIPP_PRED96(h, l), c_comb_c[z]);
     }
+    if (MFMA) {
+        uint64_t o[12];
+        dense_mfma<false>(lo, hi, 0, o, nullptr, 0, z);        // rows 1 .. 11 of C, their constants in the chain starts
+#pragma unroll
+        for (int i = 1; i < 12; i++) s[i] = o[i - 1];
+        return;
+    }
 #pragma unroll
     for (int i = 1; i < 12; i++) {
         Acc6 acc;
@@ -240,18 +338,31 @@ __device__ __forceinline__ void full_round3_combined(uint64_t s[12], uint32_t z)
     }
 }
 
-__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t z) {
+// stash (MFMA form only): LDS, 11 words per lane at stash[i * stash_stride] -- the block-start state S is an INPUT of the first dense
+// product and the ADDEND of the second, eleven rounds later; in between it waits in LDS instead of 22 VGPRs (the compiler spilled
+// half of it to scratch: ~35 scratch accesses per permutation with three waves per SIMD to hide them)
+template <bool MFMA>
+__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t z, uint64_t* __restrict__ stash = nullptr, uint32_t stash_stride = 0) {
     constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
+    static_assert(!MFMA || B == 11, "the matrix-pipe form is laid out for blocks of eleven rounds");
 #pragma unroll 1
     for (int b = 0; b < 22 / B; b++) {
         const uint32_t* __restrict__ T = c_blk3 + z + SIPP_POSEIDON_BLK_WORDS * b;
-        uint32_t sl[11], sh[11], xl[B], xh[B];
+        uint32_t sl[12], sh[12], xl[12], xh[12];
 #pragma unroll
         for (int j = 0; j < 11; j++) {
             sl[j] = (uint32_t)s[j + 1];
             sh[j] = (uint32_t)(s[j + 1] >> 32);
         }
+        sl[11] = sh[11] = xl[11] = xh[11] = 0;
         uint64_t s0 = s[0];
+        // the block-start state's share of every round's lane-0 value, sum_i W[k][i] S_i, is ONE dense product: on the matrix pipe
+        uint64_t pre[12];
+        if (MFMA) {
+#pragma unroll
+            for (int j = 0; j < 11; j++) stash[j * stash_stride] = s[j + 1];
+            dense_mfma<false>(sl, sh, 1 + 2 * (uint32_t)b, pre, nullptr, 0, z);
+        }
 #pragma unroll
         for (int k = 0; k < B; k++) {
             const uint64_t x = gl::add_nc(sbox(s0), c_fast_scalar[B * b + k + z]);
@@ -260,15 +371,29 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t 
             const uint32_t* __restrict__ Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
             Acc6 acc;
             acc.zero();
-            acc.a[0] = (uint64_t)xl[k] * 25u;  // M[0][0] = CIRC[0] + DIAG[0]
-            acc.a[3] = (uint64_t)xh[k] * 25u;
+            if (MFMA) {
+                // 25 x_k + pre_k: x_k < 2^64, so the halves times 25 stay below 2^37; pre_k's halves ride along
+                acc.a[0] = (uint64_t)xl[k] * 25u + (uint32_t)pre[k];
+                acc.a[3] = (uint64_t)xh[k] * 25u + (uint32_t)(pre[k] >> 32);
+            } else {
+                acc.a[0] = (uint64_t)xl[k] * 25u;  // M[0][0] = CIRC[0] + DIAG[0]
+                acc.a[3] = (uint64_t)xh[k] * 25u;
 #pragma unroll
-            for (int i = 0; i < 11; i++) acc.mac(sl[i], sh[i], Wt + 3 * i);
+                for (int i = 0; i < 11; i++) acc.mac(sl[i], sh[i], Wt + 3 * i);
+            }
 #pragma unroll
             for (int j = 0; j < k; j++) acc.mac(xl[j], xh[j], Wt + 33 + 3 * j);
             s0 = acc.reduce();
         }
         s[0] = s0;
+        if (MFMA) {
+            // S_i + sum_k V[i][k] x_k: the second dense product of the block, the block-start state as the per-lane addend
+            uint64_t o[12];
+            dense_mfma<true>(xl, xh, 2 + 2 * (uint32_t)b, o, stash, stash_stride, z);
+#pragma unroll
+            for (int i = 0; i < 11; i++) s[i + 1] = o[i];
+            continue;
+        }
         const uint32_t* __restrict__ V = T + 33 * B + 3 * (B * (B - 1) / 2);
 #pragma unroll
         for (int i = 0; i < 11; i++) {
@@ -285,7 +410,7 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t 
 // of the wave and MFMA ignores EXEC, so it may only be used where every lane of the wave is active and runs this function: the
 // leaf-hash kernel, whose launches are whole waves (-DSIPP_POSEIDON_VALU_MDS switches it off for A/B runs).
 template <bool MFMA = false>
-__device__ __forceinline__ void permute(uint64_t s[12]) {
+__device__ __forceinline__ void permute(uint64_t s[12], uint64_t* __restrict__ stash = nullptr, uint32_t stash_stride = 0) {
     // an opaque zero added to every table index: the tables are wave-uniform and loop-invariant, and without this the
     // compiler hoists ~650 scalar loads out of the caller's column loop, runs out of SGPRs and parks the constants in
     // VGPR lanes (v_writelane once, then a v_readlane + wait states per constant per permutation)
@@ -296,8 +421,13 @@ __device__ __forceinline__ void permute(uint64_t s[12]) {
     const mfma_v4i afrag = MFMA ? mds_a_fragment() : mfma_v4i{0, 0, 0, 0};
 #pragma unroll 1
     for (int r = 0; r < 3; r++) full_round<MFMA>(s, r, z, afrag);
-    full_round3_combined(s, z);
-    partial_rounds_blocked(s, z);
+#ifdef SIPP_POSEIDON_VALU_DENSE           // A/B switch: the dense constant products as lazy multiply-adds on the VALU (round 3's form)
+    full_round3_combined<false>(s, z);
+    partial_rounds_blocked<false>(s, z);
+#else
+    full_round3_combined<MFMA>(s, z);
+    partial_rounds_blocked<MFMA>(s, z, stash, stash_stride);
+#endif
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[12 * 26 + i + z]);
 #pragma unroll 1

@@ -442,6 +442,101 @@ def plonk_random_instance(seed, log_n, num_routed, n_cycles=None):
     return vals.reshape(num_routed, n).copy(), sig, perm
 
 
+class OrcPlonkGates(C.Structure):
+    _fields_ = [("num_mul", C.c_uint32)]
+
+
+def _plonk_gate_sigs(L):
+    if not getattr(L, "_plonk_gate_sigs", False):
+        pp, gp = C.POINTER(OrcPlonkParams), C.POINTER(OrcPlonkGates)
+        L.orc_plonk_gate_terms_coset.argtypes = [u64p, C.c_uint, C.c_uint, gp, u64p]
+        L.orc_plonk_gate_terms_coset.restype = None
+        L.orc_plonk_quotient_chunks_ex.argtypes = [u64p, u64p, u64p, C.c_uint, pp, u64p, u64p, u64p, u64p, C.c_uint32, u64p]
+        L.orc_plonk_quotient_chunks_ex.restype = C.c_int
+        L.orc_plonk_prove_ex.argtypes = [u64p, u64p, C.c_uint, pp, C.POINTER(OrcFriParams), u64p, u64p, C.c_uint32, gp,
+                                         C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_size_t)]
+        L.orc_plonk_prove_ex.restype = C.c_int
+        L.orc_plonk_verify_ex.argtypes = [u64p, C.c_size_t, u64p, pp, C.POINTER(OrcFriParams), u64p, gp]
+        L.orc_plonk_verify_ex.restype = C.c_int
+        L._plonk_gate_sigs = True
+    return L
+
+
+def plonk_gate_instance(seed, log_n, num_routed, num_mul):
+    """the synthetic circuit of oracle/plonk.h: num_mul product gates w_{3k} w_{3k+1} = w_{3k+2} on EVERY row, and a random wire
+    permutation over all the other columns (cycles with constant values); the output columns 3k + 2 are unrouted in effect (sigma =
+    identity there).  Returns wires, sigma values, the permutation."""
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    assert 3 * num_mul <= num_routed
+    outs = set(3 * k + 2 for k in range(num_mul))
+    free_pos = np.array([j * n + i for j in range(num_routed) if j not in outs for i in range(n)], dtype=np.uint32)
+    total = num_routed * n
+    perm = np.arange(total, dtype=np.uint32)
+    vals = np.zeros(total, dtype=np.uint64)
+    order = rng.permutation(free_pos)
+    cuts = np.sort(rng.choice(np.arange(1, len(order)), size=max(1, len(order) // 3) - 1, replace=False))
+    start = 0
+    for end in list(cuts) + [len(order)]:
+        cyc = order[start:end]
+        perm[cyc] = np.roll(cyc, -1)
+        vals[cyc] = rand_field(rng, (1,))[0]
+        start = end
+    w = vals.reshape(num_routed, n).copy()
+    for k in range(num_mul):
+        a, b = w[3 * k].astype(object), w[3 * k + 1].astype(object)
+        w[3 * k + 2] = np.array([int(x) * int(y) % P for x, y in zip(a, b)], dtype=np.uint64)
+    sig = np.zeros((num_routed, n), dtype=np.uint64)
+    _plonk_lib().orc_plonk_sigmas_from_perm(perm, num_routed, log_n, sig.reshape(-1))
+    return w, sig, perm
+
+
+def plonk_gate_terms_coset(wires_c, log_n, log_d, num_mul):
+    """term k = w_{3k} w_{3k+1} - w_{3k+2} on the coset 7 <w_{N D}>, natural order: [num_mul][N D]"""
+    L = _plonk_gate_sigs(_plonk_lib())
+    out = np.zeros((num_mul, (1 << log_n) << log_d), dtype=np.uint64)
+    g = OrcPlonkGates(num_mul)
+    L.orc_plonk_gate_terms_coset(np.ascontiguousarray(wires_c).reshape(-1), log_n, log_d, C.byref(g), out.reshape(-1))
+    return out
+
+
+def plonk_quotient_chunks_ex(wires_c, sigmas_c, zs_c, log_n, p, betas, gammas, alphas, gate_terms):
+    L = _plonk_gate_sigs(_plonk_lib())
+    out = np.zeros((p.num_challenges * p.max_degree, 1 << log_n), dtype=np.uint64)
+    gt = np.ascontiguousarray(gate_terms, dtype=np.uint64)
+    rc = L.orc_plonk_quotient_chunks_ex(np.ascontiguousarray(wires_c).reshape(-1), np.ascontiguousarray(sigmas_c).reshape(-1),
+                                        np.ascontiguousarray(zs_c).reshape(-1), log_n, C.byref(p), np.asarray(betas, dtype=np.uint64),
+                                        np.asarray(gammas, dtype=np.uint64), np.asarray(alphas, dtype=np.uint64), gt.reshape(-1), gt.shape[0],
+                                        out.reshape(-1))
+    if rc:
+        raise RuntimeError("orc_plonk_quotient_chunks_ex: %d" % rc)
+    return out
+
+
+def plonk_prove_ex(wires, sigmas, log_n, p, fp, digest, public_inputs, num_mul):
+    L = _plonk_gate_sigs(_plonk_lib())
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    pis = np.asarray(list(public_inputs) or [0], dtype=np.uint64)
+    g = OrcPlonkGates(num_mul)
+    rc = L.orc_plonk_prove_ex(np.ascontiguousarray(wires).reshape(-1), np.ascontiguousarray(sigmas).reshape(-1), log_n, C.byref(p), C.byref(fp),
+                              np.asarray(digest, dtype=np.uint64), pis, len(list(public_inputs)), C.byref(g), C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError("orc_plonk_prove_ex: %d" % rc)
+    pf = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_free(out)
+    return pf
+
+
+def plonk_verify_ex(proof, sigmas_cap, p, fp, digest, num_mul):
+    L = _plonk_gate_sigs(_plonk_lib())
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    g = OrcPlonkGates(num_mul)
+    return L.orc_plonk_verify_ex(proof, len(proof), np.ascontiguousarray(sigmas_cap, dtype=np.uint64).reshape(-1), C.byref(p), C.byref(fp),
+                                 np.asarray(digest, dtype=np.uint64), C.byref(g))
+
+
 def plonk_zs(wires, sigmas, log_n, p, betas, gammas):
     out = np.zeros((plonk_zs_cols(p), 1 << log_n), dtype=np.uint64)
     _plonk_lib().orc_plonk_zs_partial_products(np.ascontiguousarray(wires).reshape(-1), np.ascontiguousarray(sigmas).reshape(-1), log_n, C.byref(p),

@@ -2,12 +2,16 @@
 sipp_plonk_perm_prove) against oracle/plonk.c: Z and partial-product columns, quotient coefficient chunks and the complete flat
 proof identical word for word; the oracle's verifier accepts the device's proof.  SURVEY.md section 8f rank 2, the protocol-generic part
 of `data.prove` (reference src/verifier_circuit.rs:253) that needs no circuit."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
 from tests import _oracle
 from tests.test_gpu_fri_generic import to_params
 from tests.test_oracle_plonk import fri
+
+P = _oracle.P
 
 pytestmark = pytest.mark.gpu
 
@@ -119,3 +123,77 @@ def test_workspace_too_small_fails_cleanly_and_the_ctx_survives():
         assert (got == _oracle.plonk_perm_prove(wires, sig, log_n, op, fp)).all()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("log_n,R,D,C,rate_bits,K,n_pi,precommitted", [(10, 80, 8, 2, 3, 20, 6, True), (11, 13, 4, 3, 2, 4, 0, False),
+                                                                        (10, 9, 2, 1, 1, 3, 17, True)])
+def test_gate_terms_and_public_inputs_match_the_oracle(ctx, log_n, R, D, C, rate_bits, K, n_pi, precommitted):
+    """round 4 (SURVEY 8f rank 2 continued): everything of prove() except gate evaluation.  The caller's gate-constraint terms (here the
+    synthetic circuit of oracle/plonk.h: K product gates, evaluated on the coset by the oracle's helper and handed to the device in LEAF
+    order) are folded behind the permutation terms with the same powers of alpha; the public inputs are hashed into the transcript and
+    travel with the proof; the wires / sigmas oracles may be committed by the caller beforehand.  Quotient chunks and the whole "SIPPPLK2"
+    proof word for word, the oracle's verifier (which evaluates the gates at zeta itself) accepts the device's proof."""
+    import sipp_amd
+    op = _oracle.plonk_params(R, D, C)
+    gp = sipp_amd.PlonkParams(R, D, C)
+    wires, sig, _ = _oracle.plonk_gate_instance(1300 + log_n + R, log_n, R, K)
+    rng = np.random.default_rng(5)
+    betas, gammas, alphas = (_oracle.rand_field(rng, (C,)) for _ in range(3))
+    d_w, d_s = dev(wires), dev(sig)
+    cap_h = 2
+    log_d = D.bit_length() - 1
+    n, m = 1 << log_n, (1 << log_n) << rate_bits
+    w_or, w_cap, (wc, wl, wt) = ctx.commit_ex(d_w, log_n, rate_bits, cap_h)
+    s_or, _, (sc, sl, st) = ctx.commit_ex(d_s, log_n, rate_bits, cap_h)
+    got_zs = ctx.plonk_zs(d_w, d_s, log_n, gp, betas, gammas)
+    _, _, (zc, zl, _) = ctx.commit_ex(got_zs, log_n, rate_bits, cap_h)
+    # the gates' terms: natural order on the coset 7 <w_{N D}> from the oracle -> leaf order of the blowup-2^rate_bits LDE (the quotient
+    # coset is its first N D leaves: leaf j = natural row bitrev(j) of the coset)
+    gt_nat = _oracle.plonk_gate_terms_coset(host(wc), log_n, log_d, K)
+    nd, lq = n << log_d, log_n + log_d
+    rev = np.array([int(format(j, "0%db" % lq)[::-1], 2) for j in range(nd)])
+    gt_leaf = np.zeros((K, m), dtype=np.uint64)
+    gt_leaf[:, :nd] = gt_nat[:, rev]
+    if rate_bits > log_d:
+        gt_leaf[:, nd:] = 0xDEADBEEF                    # rows outside the quotient coset are never read
+    d_gt = dev(gt_leaf)
+    ref_q = _oracle.plonk_quotient_chunks_ex(host(wc), host(sc), host(zc), log_n, op, betas, gammas, alphas, gt_nat)
+    got_q = host(ctx.plonk_quotient_chunks_ex(wl, sl, zl, log_n, rate_bits, gp, betas, gammas, alphas, d_gt))
+    bad = np.argwhere(got_q != ref_q)
+    assert bad.size == 0, "first mismatching (chunk, coefficient): %s" % bad[:4].tolist()
+    assert (got_q != host(ctx.plonk_quotient_chunks(wl, sl, zl, log_n, rate_bits, gp, betas, gammas, alphas))).any()
+    # the whole flow
+    fp = fri(log_n, rate_bits=rate_bits, cap_height=cap_h, nq=5, arity=3, fpb=3)
+    pis = [(11 * k + 3) % P for k in range(n_pi)]
+    digest = (21, 22, 23, 24)
+    ref = _oracle.plonk_prove_ex(wires, sig, log_n, op, fp, digest, pis, K)
+    kw = dict(wires_oracle=w_or, wires_cap=w_cap, sigmas_oracle=s_or) if precommitted else {}
+    got = ctx.plonk_prove_ex(d_w, d_s, log_n, gp, to_params(fp), digest, pis, gate_terms=d_gt, **kw)
+    assert len(got) == len(ref) and int(got[0]) == 0x324b4c5050504953 and int(got[6]) == K and int(got[7]) == n_pi
+    diff = np.nonzero(got != ref)[0]
+    assert diff.size == 0, "first mismatch at word %d of %d" % (diff[0], len(ref))
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=rate_bits, cap_height=cap_h).cap
+    assert _oracle.plonk_verify_ex(got, sig_cap, op, fp, digest, K) == 0
+    # a broken gate (one output cell) with honestly recomputed terms: the device proves, the verifier refuses at the quotient identity
+    broken = wires.copy()
+    broken[2, 5] = (int(broken[2, 5]) + 1) % P
+    d_b = dev(broken)
+    _, _, (bc, _, _) = ctx.commit_ex(d_b, log_n, rate_bits, cap_h)
+    bt = np.zeros((K, m), dtype=np.uint64)
+    bt[:, :nd] = _oracle.plonk_gate_terms_coset(host(bc), log_n, log_d, K)[:, rev]
+    bad_pf = ctx.plonk_prove_ex(d_b, d_s, log_n, gp, to_params(fp), digest, pis, gate_terms=dev(bt))
+    assert _oracle.plonk_verify_ex(bad_pf, sig_cap, op, fp, digest, K) == -210
+
+
+def test_gate_term_argument_errors(ctx):
+    import sipp_amd
+    import torch
+    gp = sipp_amd.PlonkParams(9, 2, 1)
+    z = torch.zeros((9, 2048), dtype=torch.int64, device="cuda")
+    zz = torch.zeros((2, 2048), dtype=torch.int64, device="cuda")
+    L = ctx.L
+    one = (C.c_uint64 * 1)(1)
+    out = torch.zeros((2, 1024), dtype=torch.int64, device="cuda")
+    # a count without a pointer, a pointer without a count
+    assert L.sipp_plonk_quotient_chunks_ex(ctx.h, z.data_ptr(), z.data_ptr(), zz.data_ptr(), 10, 1, C.byref(gp), one, one, one, None, 3, out.data_ptr()) == -1
+    assert L.sipp_plonk_quotient_chunks_ex(ctx.h, z.data_ptr(), z.data_ptr(), zz.data_ptr(), 10, 1, C.byref(gp), one, one, one, z.data_ptr(), 0, out.data_ptr()) == -1

@@ -116,3 +116,108 @@ def test_python_reading_replays_a_c_oracle_proof():
         for d in reversed(range(D)):
             acc = acc * zeta_n + q_o[c * D + d]
         assert van[c] == (zeta_n - g2.ext(1)) * acc, c
+
+
+# ---- round 4: the circuit's gate-constraint terms in the quotient, the public inputs in the transcript (everything of prove() but the
+# gates themselves and witness generation) ----
+@pytest.mark.parametrize("log_n,R,D,C,K,n_pi", [(6, 16, 8, 2, 3, 5), (5, 13, 4, 3, 4, 0), (6, 9, 2, 1, 2, 9)])
+def test_gate_terms_and_public_inputs_prove_and_verify(log_n, R, D, C, K, n_pi):
+    """the synthetic circuit (K product gates on every row + a random wire permutation): the quotient with the gates' terms folded behind
+    the permutation terms is a polynomial of the right degree (the verifier's identity at zeta holds with ITS evaluation of the gates on
+    the opened wires); a wire that breaks ONE gate on ONE row is refused; so is a changed public input (it moves every challenge)"""
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, perm = _oracle.plonk_gate_instance(70 + log_n + R, log_n, R, K)
+    fp = fri(log_n, rate_bits=max(3, D.bit_length() - 1))
+    pis = [(7 * k + 1) % P for k in range(n_pi)]
+    digest = (5, 6, 7, 8)
+    pf = _oracle.plonk_prove_ex(wires, sig, log_n, p, fp, digest, pis, K)
+    assert int(pf[0]) == 0x324b4c5050504953 and int(pf[6]) == K and int(pf[7]) == n_pi and int(pf[5]) == len(pf)
+    assert [int(v) for v in pf[len(pf) - n_pi:]] == pis
+    sig_cap = _oracle.Batch(sig, log_n, rate_bits=fp.rate_bits, cap_height=fp.cap_height).cap
+    assert _oracle.plonk_verify_ex(pf, sig_cap, p, fp, digest, K) == 0
+    # the permutation-only verifier / another gate count do not take this proof
+    assert _oracle.plonk_perm_verify(pf, sig_cap, p, fp, digest=digest) != 0
+    assert _oracle.plonk_verify_ex(pf, sig_cap, p, fp, digest, K - 1) != 0
+    if n_pi:
+        bad = pf.copy()
+        bad[-1] = (int(bad[-1]) + 1) % P
+        assert _oracle.plonk_verify_ex(bad, sig_cap, p, fp, digest, K) != 0
+    # one product gate broken on one row (the output column is unrouted: the permutation argument alone would not notice)
+    broken = wires.copy()
+    broken[2, 3] = (int(broken[2, 3]) + 1) % P
+    assert _oracle.plonk_perm_verify(_oracle.plonk_perm_prove(broken, sig, log_n, p, fp), sig_cap, p, fp) == 0
+    assert _oracle.plonk_verify_ex(_oracle.plonk_prove_ex(broken, sig, log_n, p, fp, digest, pis, K), sig_cap, p, fp, digest, K) == -210
+
+
+def test_gate_terms_vanish_on_the_subgroup_and_enter_behind_the_permutation_terms():
+    """the terms the oracle folds: zero on the trace domain (every D-th point of the coset after un-shifting is not on it, so check by
+    interpolation: term polynomial = product of wire polynomials mod nothing, degree < 2N), and their position in reduce_with_powers --
+    with alpha = 0 only the FIRST term (Z(1) = 1) survives, with the gate terms scaled by alpha^(C + C m + k)"""
+    log_n, R, D, C, K = 5, 7, 2, 1, 2
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, _ = _oracle.plonk_gate_instance(3, log_n, R, K)
+    n = 1 << log_n
+    rng = np.random.default_rng(9)
+    betas, gammas, alphas = (_oracle.rand_field(rng, (C,)) for _ in range(3))
+    wb = _oracle.Batch(wires, log_n, rate_bits=1, cap_height=0)
+    sb = _oracle.Batch(sig, log_n, rate_bits=1, cap_height=0)
+    zs = _oracle.plonk_zs(wires, sig, log_n, p, betas, gammas)
+    zb = _oracle.Batch(zs, log_n, rate_bits=1, cap_height=0)
+    gt = _oracle.plonk_gate_terms_coset(wb.coeffs, log_n, 1, K)
+    q0 = _oracle.plonk_quotient_chunks(wb.coeffs, sb.coeffs, zb.coeffs, log_n, p, betas, gammas, alphas)
+    q1 = _oracle.plonk_quotient_chunks_ex(wb.coeffs, sb.coeffs, zb.coeffs, log_n, p, betas, gammas, alphas, gt)
+    # honest wires: both are polynomial quotients, and they differ by alpha^(n_perm + k) * (gate term k / Z_H), itself a polynomial
+    npd = _oracle.plonk_num_prods(p)
+    n_perm = C + C * (npd + 1)
+    a = int(alphas[0])
+    w2 = pow(7, (P - 1) >> (log_n + 1), P)
+    x = 7 * pow(w2, 5, P) % P                                   # a point of the coset: evaluate both sides there
+    ev = lambda chunks: sum(int(c) * pow(x, j, P) for j, c in enumerate(np.concatenate(list(chunks)))) % P
+    zh = (pow(x, n, P) - 1) % P
+    want = (ev(q0[:D]) + sum(pow(a, n_perm + k, P) * int(gt[k, 5]) for k in range(K)) * pow(zh, P - 2, P)) % P
+    assert ev(q1[:D]) == want
+
+
+def test_python_reading_replays_a_proof_with_gates_and_public_inputs():
+    """the second reading (oracle/py/plonky2_generic.py) on a "SIPPPLK2" proof: hash_n_to_hash_no_pad of the public inputs, the transcript,
+    and the verifier's identity at zeta with the gate terms it computes itself from the opened wires"""
+    from oracle.py import plonky2_generic as g2
+    log_n, R, D, C, K = 4, 7, 2, 2, 2
+    p = _oracle.plonk_params(R, D, C)
+    wires, sig, _ = _oracle.plonk_gate_instance(21, log_n, R, K)
+    fp = fri(log_n, rate_bits=2, cap_height=1, nq=3, arity=1, fpb=2)
+    pis = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3]
+    pf = [int(v) for v in _oracle.plonk_prove_ex(wires, sig, log_n, p, fp, (9, 8, 7, 6), pis, K)]
+    cap_words = 4 << fp.cap_height
+    wcap, zcap, qcap = pf[8:8 + cap_words], pf[8 + cap_words:8 + 2 * cap_words], pf[8 + 2 * cap_words:8 + 3 * cap_words]
+    assert pf[len(pf) - len(pis):] == pis
+    ch = g2.Challenger()
+    ch.observe_many([9, 8, 7, 6])
+    ch.observe_many(g2.hash_no_pad(pis))
+    ch.observe_cap([wcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    betas, gammas = ch.get_n(C), ch.get_n(C)
+    ch.observe_cap([zcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    alphas = ch.get_n(C)
+    ch.observe_cap([qcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    zeta = ch.get_ext()
+    npd = _oracle.plonk_num_prods(p)
+    op = pf[8 + 3 * cap_words + 8:]
+    take = iter(range(0, 10 ** 9, 2))
+    ext_at = lambda: (lambda k: g2.Ext(op[k], op[k + 1]))(next(take))
+    sg_o = [ext_at() for _ in range(R)]
+    w_o = [ext_at() for _ in range(R)]
+    zs_o = [ext_at() for _ in range(C)]
+    pp_o = [ext_at() for _ in range(C * npd)]
+    q_o = [ext_at() for _ in range(C * D)]
+    zn_o = [ext_at() for _ in range(C)]
+    gates = [w_o[3 * k] * w_o[3 * k + 1] - w_o[3 * k + 2] for k in range(K)]
+    van = g2.eval_vanishing_poly_permutation(log_n, zeta, w_o, sg_o, zs_o, zn_o, pp_o, betas, gammas, alphas, D, gates)
+    zeta_n = zeta ** (1 << log_n)
+    for c in range(C):
+        acc = g2.ext(0)
+        for d in reversed(range(D)):
+            acc = acc * zeta_n + q_o[c * D + d]
+        assert van[c] == (zeta_n - g2.ext(1)) * acc, c
+    # without the gate terms the identity must NOT hold (they really are in the quotient)
+    van0 = g2.eval_vanishing_poly_permutation(log_n, zeta, w_o, sg_o, zs_o, zn_o, pp_o, betas, gammas, alphas, D)
+    assert van0[0] != van[0]

@@ -271,6 +271,108 @@ def blocked_perm_combined(state, rc, tables, cc):
     return s
 
 
+# ---- dense constant products on the matrix pipe (round 4; poseidon.hpp::dense_mfma) -----------------------------------------
+# The five dense products with full 64-bit constants that the lazy form of the partial rounds leaves -- the merged affine layer of full
+# round 3 (rows 1..11 of C, 12 inputs), and per block of 11 rounds W (d_r's share of the block-start state: W[k][i] = ws[r0+k][i]) and
+# V (the block-end update: V[i][k] = vs[r0+k][i]) -- as int8 products of BYTE PLANES: the state words are cut into 8 unsigned bytes
+# u_a, made signed by ^ 0x80 (s_a = u_a - 128); every constant into 8 SIGNED base-256 digits d_b of c or c - p; then
+#   sum_e c_e x_e = sum_t 2^(8t) D_t + 128 * 0x0101010101010101 * sum_e c'_e,    D_t = sum_(a+b=t) sum_e d_(e,b) s_(e,a)   (int32)
+# and with 2^64 = 2^32 - 1, 2^96 = -1 (mod p) the fifteen D_t fold into two signed 64-bit chains
+#   L = sum_(t<4) D_t 2^(8t) - sum_(8<=t<12) D_t 2^(8(t-8)) - sum_(t>=12) D_t 2^(8(t-12)),  H = sum_(4<=t<8) D_t 2^(8(t-4)) + sum_(8<=t<12) D_t 2^(8(t-8))
+# value = L + 2^32 H + K.  The chains START at K's halves plus 2^50 (so that both stay positive; K absorbs -2^50 (1 + 2^32)).
+DENSE_OFF = 1 << 50
+
+
+def signed_digits(c):
+    """8 digits in [-128, 127] with sum d_b 256^b = c or c - p"""
+    for cand in (c, c - P):
+        v, ds = cand, []
+        for _ in range(8):
+            d = v & 0xFF
+            if d >= 128:
+                d -= 256
+            ds.append(d)
+            v = (v - d) >> 8
+        if v == 0:
+            assert sum(d << (8 * b) for b, d in enumerate(ds)) == cand
+            return ds, cand
+    raise AssertionError("no signed-digit form for %x" % c)
+
+
+def dense_matrices(first, Mi, vs, ws):
+    """[(rows x 12 matrix, additive constants per row)] in kernel order: 0 = combined layer rows 1..11; 1 + 2 b = W of block b; 2 + 2 b = V"""
+    Cm, cv = combined_layer(first, Mi)
+    mats = [([Cm[i][:] for i in range(1, 12)], [cv[i] for i in range(1, 12)])]
+    for r0 in range(0, N_PARTIAL, BLK):
+        Wm = [[ws[r0 + k][i] for i in range(W - 1)] + [0] for k in range(BLK)]
+        Vm = [[vs[r0 + k][i] for k in range(BLK)] + [0] for i in range(W - 1)]
+        mats.append((Wm, [0] * BLK))
+        mats.append((Vm, [0] * (W - 1)))
+    return mats
+
+
+def dense_tables(mats):
+    """A fragments [mat][limb b][lane 0..63][4 u32] (this lane's 16 bytes of the block-diagonal A of v_mfma_i32_32x32x32_i8: row = lane & 31,
+    k = 16 (lane >> 5) + e -- the layout of poseidon.hpp::mds_a_fragment) and chain starts [mat][row 0..11][L, H] (u64)"""
+    frag, starts = [], []
+    for Mx, add in mats:
+        dig = [[signed_digits(c) for c in row] for row in Mx]
+        for b in range(8):
+            for lane in range(64):
+                row, h = lane & 31, lane >> 5
+                mine = row < 24 and ((row >> 2) & 1) == h
+                reg = (row & 3) + 4 * (row >> 3)
+                w = [0, 0, 0, 0]
+                if mine and reg < len(Mx):
+                    for e in range(12):
+                        w[e >> 2] |= (dig[reg][e][0][b] & 0xFF) << (8 * (e & 3))
+                frag += w
+        for r in range(12):
+            if r < len(Mx):
+                bias = 128 * 0x0101010101010101 * sum(dig[r][e][1] for e in range(12))
+                K = (bias + add[r] - DENSE_OFF * (1 + (1 << 32))) % P
+            else:
+                K = (-DENSE_OFF * (1 + (1 << 32))) % P
+            starts += [(K & 0xFFFFFFFF) + DENSE_OFF, (K >> 32) + DENSE_OFF]
+    return frag, starts
+
+
+def dense_model(mat_index, frag, starts, x, addend=None):
+    """python model of poseidon.hpp::dense_mfma for one lane (lane 0: rows 0..11 sit in A rows (r & 3) + 8 (r >> 2)): x = 12 arbitrary u64"""
+    planes = [[((x[e] >> (8 * a)) & 0xFF) - 128 for e in range(12)] for a in range(8)]
+
+    def a_byte(b, reg, e):           # A[row][k = e] of limb b as the lane that owns row `row` of half 0 holds it
+        row = (reg & 3) + 8 * (reg >> 2)
+        w = frag[((mat_index * 8 + b) * 64 + row) * 4 + (e >> 2)]
+        v = (w >> (8 * (e & 3))) & 0xFF
+        return v - 256 if v >= 128 else v
+
+    out = []
+    for r in range(12):
+        D = [sum(a_byte(t - a, r, e) * planes[a][e] for a in range(max(0, t - 7), min(7, t) + 1) for e in range(12)) for t in range(15)]
+        assert all(-(1 << 31) <= d < (1 << 31) for d in D)
+        L, H = starts[(mat_index * 12 + r) * 2], starts[(mat_index * 12 + r) * 2 + 1]
+        if addend is not None:
+            L += addend[r] & 0xFFFFFFFF
+            H += addend[r] >> 32
+        for t in range(15):
+            if t < 4:
+                L += D[t] << (8 * t)
+            elif t < 8:
+                H += D[t] << (8 * (t - 4))
+            elif t < 12:
+                H += D[t] << (8 * (t - 8))
+                L -= D[t] << (8 * (t - 8))
+            else:
+                L -= D[t] << (8 * (t - 12))
+        assert 0 < L < (1 << 52) and 0 < H < (1 << 52)       # the kernel's chains are positive 64-bit values
+        lo = (L + (H << 32)) & 0xFFFFFFFFFFFFFFFF
+        hi = (H >> 32) + (1 if lo < L else 0)
+        assert hi < (1 << 32)
+        out.append((lo + (hi << 64)) % P)                     # reduce96 of (hi, lo)
+    return out
+
+
 def limbs3(c):
     """22 + 22 + 20 bits"""
     assert 0 <= c < P
@@ -302,6 +404,13 @@ def fmt32(vals, per=8):
     return "\n".join(out)
 
 
+def fmt32x(vals, per=8):
+    out = []
+    for i in range(0, len(vals), per):
+        out.append("    " + ", ".join("0x%08xu" % v for v in vals[i:i + per]) + ",")
+    return "\n".join(out)
+
+
 def fmt(vals, per=4):
     out = []
     for i in range(0, len(vals), per):
@@ -323,6 +432,17 @@ def main():
         assert a == b, ("fast partial rounds mismatch", t)
         assert a == blocked_perm(st, rc, tables, cc), ("blocked partial rounds mismatch", t)
         assert a == blocked_perm_combined(st, rc, tables, cc), ("combined layer mismatch", t)
+    # the matrix-pipe form of the five dense products against plain matrix-vector products, on arbitrary (non-canonical) u64 inputs
+    mats = dense_matrices(first, Mi, vs, ws)
+    dfrag, dstarts = dense_tables(mats)
+    for mi, (Mx, add) in enumerate(mats):
+        for t in range(6):
+            x = [rnd.randrange(1 << 64) for _ in range(12)] if t > 1 else [(1 << 64) - 1] * 12 if t else [0] * 12
+            extra = [rnd.randrange(1 << 64) for _ in range(12)] if (mi and mi % 2 == 0) else None
+            got = dense_model(mi, dfrag, dstarts, x, extra)
+            for r in range(len(Mx)):
+                want = (sum(Mx[r][e] * x[e] for e in range(12)) + add[r] + (extra[r] if extra else 0)) % P
+                assert got[r] == want, ("dense product on the matrix pipe", mi, r, t)
     kat0 = naive_perm([0] * 12, rc)
     assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
 
@@ -359,6 +479,12 @@ def main():
         comb3 = [w for i in range(1, 12) for j in range(12) for w in limbs3(Cm[i][j])]
         f.write("static const uint32_t SIPP_POSEIDON_COMB3[396] = {\n" + fmt32(comb3) + "\n};\n")
         f.write("static const uint64_t SIPP_POSEIDON_COMB_C[12] = {\n" + fmt(cv) + "\n};\n")
+        f.write("// dense constant products on the matrix pipe (poseidon.hpp::dense_mfma; dense_tables() in tools/gen_poseidon_header.py):\n"
+                "// matrices 0 = rows 1..11 of the combined layer, 1 + 2 b = W of block b, 2 + 2 b = V of block b; A fragments\n"
+                "// [matrix][digit b][lane][4] of signed base-256 digits, chain starts [matrix][row][L, H]\n")
+        f.write("#define SIPP_POSEIDON_DENSE_MATS %d\n" % len(mats))
+        f.write("static const uint32_t SIPP_POSEIDON_DENSE_A[%d] = {\n" % len(dfrag) + fmt32x(dfrag) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_DENSE_START[%d] = {\n" % len(dstarts) + fmt(dstarts) + "\n};\n")
     assert all(Mi[0][j] == (1 if j == 0 else 0) for j in range(12)) and all(Mi[i][0] == 0 for i in range(1, 12))
     print("ok: headers written; fast-partial tables verified against naive permutation")
 
