@@ -380,7 +380,7 @@ def main():
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms] if serial else None,
             "pipelined": pipelined,
         }
-        # secondary, outside the timed region: the native SIPP chain in front of the circuit
+        # secondary, outside the timed region: the native SIPP chain in front of the circuit (HISTORY.md section 7)
         # on this GPU -- sipp_prove_native = 3n - 2 pairings + the folds, sipp_verify_native = the obligation lists the timed
         # region consumes.  Never allowed to break the main line.
         try:
@@ -409,7 +409,7 @@ def main():
         except Exception as e:                  # noqa: BLE001
             out["native_chain"] = {"error": repr(e)}
         # secondary, outside the timed region: the messages -> G2 step in front of SIPP's BLS example (reference
-        # src/bin/bls_aggregation.rs:65, :100-104) for the n - 1 messages of this instance: the native map with
+        # src/bin/bls_aggregation.rs:65, :100-104; HISTORY.md section 7b) for the n - 1 messages of this instance: the native map with
         # its cofactor clearing, and the MapToG2 proof (eight trace rows per message).  The 2 (n - 1) cofactor obligations are ordinary
         # G2ExpStark records (the main line's path), not timed again here.
         try:

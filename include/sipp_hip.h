@@ -94,7 +94,7 @@ int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, si
 void sipp_ctx_destroy(sipp_ctx *ctx);
 /* The ctx's HIP stream: level > 0 = a stream of the highest priority the device offers; level <= 0 = a stream with a hardware
  * queue of its own at normal priority (created with an all-ones CU mask: the runtime multiplexes ordinary streams onto a pool of
- * four queues, such a stream is kept out of the pool -- measured 1.5 ms per n = 128 instance; level < 0 used
+ * four queues, such a stream is kept out of the pool -- measured 1.5 ms per n = 128 instance, HISTORY.md section 6c; level < 0 used
  * to mean the lowest priority and still does under SIPP_DEDICATED_QUEUES=0).  Such a stream is BLOCKING with respect to the legacy
  * default (NULL) stream -- hipExtStreamCreateWithCUMask takes no flags -- whereas the high-priority stream is hipStreamNonBlocking:
  * an embedder that launches on the NULL stream serialises with the level <= 0 ctxs (not with a level > 0 one); launch on streams
@@ -140,9 +140,9 @@ int sipp_wait(sipp_ctx *ctx, size_t *proof_len);
  * first failing status; every proof that was started is waited for in any case.  num_io[k] == 0 skips kind k
  * (proof_len[k] = 0).
  * ctxs[0] == ctxs[1] == ctxs[2]: ONE ctx, the three proofs back to back on its stream and arena (workspace = the largest of the
- * three sipp_workspace_bytes) -- for the large configurations, where one proof's kernels fill the chip and three concurrent
- * arenas would not fit: n = 4096 needs 159 GB this way instead of 246 GB (181 / 279 GB with the hardened AIRs) and runs within 2 %
- * of the three-stream time.  Two equal handles and a third are SIPP_E_BADARG. */
+ * three sipp_workspace_bytes) -- for configurations whose three arenas do not fit the card together: n = 4096 needs 159 GB this
+ * way instead of 246 GB (179 / 276 GB with the hardened AIRs, which only fit this way) at 5.5 % more time per instance (1234 against
+ * 1169 ms; 13 - 15 % at n = 1024, where the proofs' thin phases overlap more).  Two equal handles and a third are SIPP_E_BADARG. */
 int sipp_instance_prove(sipp_ctx *const ctxs[3], const uint32_t *const ios[3], const size_t num_io[3],
                         uint64_t *const proof_out[3], const size_t proof_cap[3], size_t proof_len[3]);
 /* A queue of `count` independent instances on one GPU (or several): `in_flight` slots of three distinct ctxs each

@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_v"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/tl" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/tl.log"
 # native chain
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/native" -o run -- python3 "$R/scripts/perf_native.py" 128 > "$OUT/native.txt" 2> "$OUT/native.log"
-# the messages -> G2 step of the BLS example
+# the messages -> G2 step of the BLS example (HISTORY.md section 7b)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mapg2" -o run -- python3 "$R/scripts/perf_mapg2.py" 127 > "$OUT/mapg2.txt" 2> "$OUT/mapg2.log"
 # the hardened G1 / G2 AIRs beside the plain ones
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hardened" -o run -- python3 "$R/scripts/perf_hardened.py" > "$OUT/hardened.txt" 2> "$OUT/hardened.log"

@@ -496,8 +496,10 @@ class Instance:
     measured best with the start gate of sipp_instance_prove (69.3 vs 71.2 ms per n = 128 instance for low / high / high)."""
 
     # three concurrent arenas above this share of the card's memory -> one ctx, the proofs back to back (sipp_instance_prove with
-    # three equal handles): of the BASELINE configs only n = 4096 on ONE GPU (246 GB plain, 279 GB hardened of 288 GB)
-    SINGLE_CTX_SHARE = 0.6
+    # three equal handles): of the BASELINE configs only the HARDENED n = 4096 instance on ONE GPU (276 GB of 288 GB; the plain one's
+    # 246 GB fit).  Measured (scripts/large_n_modes.py, round 4): back to back costs 5.5 % at n = 4096 (1234 against 1169 ms, plain) and
+    # 13 - 15 % at n = 1024 (357 against 311 ms) -- so three streams wherever they fit.
+    SINGLE_CTX_SHARE = 0.9
 
     def __init__(self, num_io, devices=(0, 0, 0), priorities=None, hardened=False, single_ctx=None):
         """hardened: G1 / G2 with the hardened AIRs (kinds 4 / 5 in the proofs' headers; sipp_ctx_set_hardened).

@@ -24,7 +24,7 @@ void sipp_default_config(sipp_stark_config* cfg) {
 
 // The stream of a ctx.  level > 0: a high-priority stream.  Otherwise a stream with a HARDWARE QUEUE OF ITS OWN: the runtime
 // multiplexes ordinary streams onto a small pool of queues per priority (GPU_MAX_HW_QUEUES, 4), a stream created with a CU mask gets
-// a queue to itself -- the mask here is all ones, every CU stays usable.  Measured on the n = 128 instance:
+// a queue to itself -- the mask here is all ones, every CU stays usable.  Measured on the n = 128 instance (HISTORY.md section 6c):
 // G1 (formerly on the low-priority pool) on its own queue is worth 1.5 ms of 60 single and 0.9 of 51.8 ms queued; the blocking flag,
 // the priority value and the number of pool queues are not what moves it.  Such a stream has normal priority (the call takes none),
 // so "low" and "normal" are the same thing now.  SIPP_DEDICATED_QUEUES=0 restores pool streams with priorities.

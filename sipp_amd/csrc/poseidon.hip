@@ -412,7 +412,10 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
     // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2854 / 1512 columns -- are
     // hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 23 against 30 us per dependent permutation)
-    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : 2;
+#ifndef SIPP_THIN_LANES            // compile-time A/B switch (scripts/ab_obj.sh): lanes per state of the thin trees' leaf kernel
+#define SIPP_THIN_LANES 2
+#endif
+    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : SIPP_THIN_LANES;
     const bool thin = ncols > 4 && n <= quad_threshold() && n >= (thin_lanes_p == 2 ? 32 : 16);
     ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : !thin ? "poseidon_leaves" : thin_lanes_p == 2 ? "poseidon_leaves_pair" : "poseidon_leaves_quad");
     // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.hpp, the default since round 2) costs

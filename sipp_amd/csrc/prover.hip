@@ -143,6 +143,7 @@ struct QuotArgs {
     const uint32_t* seg_off;                   // word offset of the segment in prog
     const uint32_t* seg_cnt;                   // 0 = gadget, else number of POLY ops in the run
     const uint64_t* seg_pow;                   // [n_seg][2]: alpha_c^(#program constraints after the segment)
+    const uint32_t* apoly3;                    // [2][64][3]: limbs (gl::limbs3) of alpha_c^e, e < 64: the fold inside a run of POLY ops
     int n_seg;
     uint64_t* part;                            // [n_seg][2][m] partial Horner sums
     const uint64_t* per_tab[AIR_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
@@ -164,23 +165,27 @@ struct QuotArgs {
 };
 
 struct QCtx {
-    const QuotArgs* a;
+    // copies of the few kernel arguments the helpers need: a POINTER to the by-value argument struct would force the whole struct
+    // (about 1 KB) into every lane's scratch memory
+    const uint64_t* lde;
+    size_t lde_stride;
+    uint64_t alpha0, alpha1;
     size_t j, jn, m;
-    uint64_t per[AIR_N_PERIODIC];
+    uint64_t p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;     // scalars, not an array: the object must stay in registers
     uint64_t acc0, acc1;
     // selects instead of a dynamically indexed private array (which would live in scratch memory); k is wave-uniform.  Indices
     // 0 .. 3: the exponentiation AIRs' selectors, 4 .. 11: MapToG2's eight row types
     __device__ __forceinline__ uint64_t periodic(int k) const {
         static_assert(AIR_N_PERIODIC == 12, "periodic(): update the select chain");
-        if (k < 4) return k == 0 ? per[0] : k == 1 ? per[1] : k == 2 ? per[2] : per[3];
-        if (k < 8) return k == 4 ? per[4] : k == 5 ? per[5] : k == 6 ? per[6] : per[7];
-        return k == 8 ? per[8] : k == 9 ? per[9] : k == 10 ? per[10] : per[11];
+        if (k < 4) return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+        if (k < 8) return k == 4 ? p4 : k == 5 ? p5 : k == 6 ? p6 : p7;
+        return k == 8 ? p8 : k == 9 ? p9 : k == 10 ? p10 : p11;
     }
-    __device__ __forceinline__ uint64_t local(int c) const { return a->lde[(size_t)c * a->lde_stride + j]; }
-    __device__ __forceinline__ uint64_t next(int c) const { return a->lde[(size_t)c * a->lde_stride + jn]; }
+    __device__ __forceinline__ uint64_t local(int c) const { return lde[(size_t)c * lde_stride + j]; }
+    __device__ __forceinline__ uint64_t next(int c) const { return lde[(size_t)c * lde_stride + jn]; }
     __device__ __forceinline__ void emit(uint64_t v) {
-        acc0 = gl::mad(acc0, a->alpha[0], v);
-        acc1 = gl::mad(acc1, a->alpha[1], v);
+        acc0 = gl::mad(acc0, alpha0, v);
+        acc1 = gl::mad(acc1, alpha1, v);
     }
 };
 
@@ -210,39 +215,81 @@ __device__ __forceinline__ int qvec(const int64_t* w, const QCtx& c, uint64_t (&
 
 // one lane per (LDE point, gadget): the gadget's 32/grp + 1 constraints folded with alpha from zero, then scaled by
 // alpha^(number of gadget constraints that follow), so that the sum over gadgets equals the sequential Horner value.
-__global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a) {
+// Two instantiations, two launches: POLY = the runs of polynomial constraints (few registers, many waves), !POLY = the gadgets (their
+// limb arrays need ~150 VGPRs).  As ONE kernel the allocator gave both the gadget path's registers and more (250 VGPRs, 1.1 KB of
+// scratch per lane, two waves per SIMD): 9.9 instead of 3.9 ms per n = 128 instance when the lazy fold below was added to it.
+template <bool POLY>
+__global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0) {
     const size_t m = (size_t)1 << a.log_m;
     const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const int g = blockIdx.y;
+    const int g = seg0 + (int)blockIdx.y;
     const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);  // natural LDE index
     QCtx c;
-    c.a = &a;
+    c.lde = a.lde;
+    c.lde_stride = a.lde_stride;
+    c.alpha0 = a.alpha[0];
+    c.alpha1 = a.alpha[1];
     c.m = m;
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
-    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = a.per_tab[k][i & a.per_mask[k]];
+#define SIPP_PER(k) c.p##k = a.per_tab[k][i & a.per_mask[k]]
+    SIPP_PER(0); SIPP_PER(1); SIPP_PER(2); SIPP_PER(3); SIPP_PER(4); SIPP_PER(5);
+    SIPP_PER(6); SIPP_PER(7); SIPP_PER(8); SIPP_PER(9); SIPP_PER(10); SIPP_PER(11);
+#undef SIPP_PER
     const int64_t* w = a.prog + a.seg_off[g];
     const uint32_t n_poly = a.seg_cnt[g];
-    if (n_poly) {
+    if (POLY) {
+        // A run of up to 64 polynomial constraints: acc_c = sum_k alpha_c^(n_poly - 1 - k) v_k is a linear combination with WAVE-UNIFORM
+        // weights, taken lazily (six multiply-adds per constraint and challenge, one reduction per run) instead of two Horner
+        // products per constraint.  Monomials: the coefficient is +-1 in all but a few per cent of them -- the product starts at the
+        // first factor and is added or subtracted (a scalar branch); only other coefficients cost a product.
+        gl::Acc6 f0, f1;
+        f0.zero();
+        f1.zero();
+        // plain locals (not the QCtx object: behind a by-reference capture it ended up in scratch memory)
+        const uint64_t* __restrict__ lde = a.lde;
+        const uint64_t* __restrict__ aux = a.aux;
+        const size_t stride = a.lde_stride, jl = c.j, jn = c.jn;
+        const uint64_t p0 = c.p0, p1 = c.p1, p2 = c.p2, p3 = c.p3, p4 = c.p4, p5 = c.p5, p6 = c.p6, p7 = c.p7, p8 = c.p8, p9 = c.p9,
+                       p10 = c.p10, p11 = c.p11;
+        auto periodic = [&](int k) -> uint64_t {
+            static_assert(AIR_N_PERIODIC == 12, "periodic(): update the select chain");
+            if (k < 4) return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+            if (k < 8) return k == 4 ? p4 : k == 5 ? p5 : k == 6 ? p6 : p7;
+            return k == 8 ? p8 : k == 9 ? p9 : k == 10 ? p10 : p11;
+        };
+        auto operand = [&](int kind, int idx) -> uint64_t {
+            return kind == 0 ? lde[(size_t)idx * stride + jl] : kind == 1 ? lde[(size_t)idx * stride + jn] : kind == 2 ? aux[(size_t)idx * m + jl]
+                                                                                                                  : periodic(idx);
+        };
         for (uint32_t op = 0; op < n_poly; op++) {
             const int nmono = (int)w[1];
             w += 2;
             uint64_t sum = 0;
             for (int mo = 0; mo < nmono; mo++) {
-                uint64_t t = gl::from_i64(*w++);
+                const int64_t coef = *w++;
                 const int nf = (int)*w++;
-                for (int f = 0; f < nf; f++) {
-                    const int kind = (int)w[0], idx = (int)w[1];
-                    w += 2;
-                    uint64_t v = kind == 0 ? c.local(idx) : kind == 1 ? c.next(idx)
-                                 : kind == 2 ? a.aux[(size_t)idx * m + j] : c.periodic(idx);
-                    t = gl::mul(t, v);
+                if (nf == 0) {
+                    sum = gl::add(sum, gl::from_i64(coef));
+                    continue;
                 }
-                sum = gl::add(sum, t);
+                uint64_t t = operand((int)w[0], (int)w[1]);
+                w += 2;
+                for (int f = 1; f < nf; f++) {
+                    t = gl::mul(t, operand((int)w[0], (int)w[1]));
+                    w += 2;
+                }
+                if (coef == 1) sum = gl::add(sum, t);          // operands are canonical (committed LDE cells, selector values), products too
+                else if (coef == -1) sum = gl::sub(sum, t);
+                else sum = gl::mad(gl::from_i64(coef), t, sum);
             }
-            c.emit(sum);
+            const uint32_t* __restrict__ pw = a.apoly3 + 3 * (n_poly - 1 - op);
+            f0.mac((uint32_t)sum, (uint32_t)(sum >> 32), pw);
+            f1.mac((uint32_t)sum, (uint32_t)(sum >> 32), pw + 192);
         }
+        c.acc0 = f0.reduce();
+        c.acc1 = f1.reduce();
     } else {
         const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
         const int64_t coffset = w[5];
@@ -410,7 +457,10 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);
     QCtx c;
-    c.a = &a;
+    c.lde = a.lde;
+    c.lde_stride = a.lde_stride;
+    c.alpha0 = a.alpha[0];
+    c.alpha1 = a.alpha[1];
     c.m = m;
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
@@ -998,6 +1048,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         }
     }
     // segment table: offsets, kinds, alpha powers (tiny; rebuilt per proof because alpha changes)
+    int n_gadget_segs = 0;
     ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
     {
         std::vector<uint32_t> off, cnt;
@@ -1037,7 +1088,11 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         }
         const int ns = (int)off.size();
         q.n_seg = ns;
-        std::vector<uint64_t> host((size_t)ns * 2 + ns + 2, 0);
+        n_gadget_segs = 0;
+        while (n_gadget_segs < ns && cnt[n_gadget_segs] == 0) n_gadget_segs++;
+        for (int g = n_gadget_segs; g < ns; g++)
+            if (cnt[g] == 0) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "quotient: gadgets must precede the polynomial constraints");
+        std::vector<uint64_t> host((size_t)ns * 2 + ns + 2 + 192, 0);      // + [2][64][3] u32: limbs of alpha_c^e, e < 64
         int after = 0;
         for (int g = ns - 1; g >= 0; g--) {
             host[2 * g] = gl::pow(alpha[0], (uint64_t)after);
@@ -1047,6 +1102,19 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         uint32_t* h32 = reinterpret_cast<uint32_t*>(&host[2 * ns]);
         memcpy(h32, off.data(), (size_t)ns * 4);
         memcpy(h32 + ns, cnt.data(), (size_t)ns * 4);
+        const size_t ap_at = (size_t)ns * 2 + (((size_t)2 * ns + 1) >> 1);     // behind the two u32 tables (ns + ns words)
+        {
+            uint32_t* ap = reinterpret_cast<uint32_t*>(&host[ap_at]);
+            for (int ch = 0; ch < 2; ch++) {
+                uint64_t x = 1;
+                for (int e = 0; e < 64; e++) {
+                    ap[(ch * 64 + e) * 3 + 0] = (uint32_t)x & 0x3FFFFFu;
+                    ap[(ch * 64 + e) * 3 + 1] = (uint32_t)(x >> 22) & 0x3FFFFFu;
+                    ap[(ch * 64 + e) * 3 + 2] = (uint32_t)(x >> 44);
+                    x = gl::mul(x, alpha[ch]);
+                }
+            }
+        }
         uint64_t* d_tab = arena_alloc_t<uint64_t>(ctx, host.size());
         q.part = arena_alloc_t<uint64_t>(ctx, (size_t)ns * 2 * m);
         if (!d_tab || !q.part) return SIPP_E_NOMEM;
@@ -1055,6 +1123,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         q.seg_pow = d_tab;
         q.seg_off = reinterpret_cast<const uint32_t*>(d_tab + 2 * ns);
         q.seg_cnt = q.seg_off + ns;
+        q.apoly3 = reinterpret_cast<const uint32_t*>(d_tab + ap_at);
     }
     {
         // alpha powers of the K constraints that follow the program (range table 3, lookups 2 nc, permutation 4 nc)
@@ -1070,7 +1139,12 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
     }
     {
         ProfScope ps(ctx, "quotient_prog");
-        hipLaunchKernelGGL(quotient_prog_kernel, dim3((unsigned)(m / 64), (unsigned)q.n_seg), dim3(64), 0, ctx->stream, q);
+        // the program's segments: gadgets first, then the runs of polynomial constraints (the order the table above was built in)
+        if (n_gadget_segs)
+            hipLaunchKernelGGL(quotient_prog_kernel<false>, dim3((unsigned)(m / 64), (unsigned)n_gadget_segs), dim3(64), 0, ctx->stream, q, 0);
+        if (q.n_seg > n_gadget_segs)
+            hipLaunchKernelGGL(quotient_prog_kernel<true>, dim3((unsigned)(m / 64), (unsigned)(q.n_seg - n_gadget_segs)), dim3(64), 0, ctx->stream,
+                               q, n_gadget_segs);
     }
     {
         ProfScope ps(ctx, "quotient_rest");

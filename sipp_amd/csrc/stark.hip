@@ -911,10 +911,10 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     for (int k = 0; k < 3; k++)
         if (!ctxs[k]) return SIPP_E_BADARG;
     if (ctxs[0] == ctxs[1] && ctxs[1] == ctxs[2]) {
-        // ONE ctx for the instance: the three proofs back to back on its stream and its arena (sized for the largest of them).  What the
-        // large configurations want: at n = 4096 the fat kernels of one proof fill the chip on their own, three streams buy 2 % (1234
-        // against 1259 ms) and need the three arenas live at once (246 GB; with the hardened AIRs 279 GB of the card's 288); back to
-        // back the instance needs 159 GB (181 GB).  Largest first, like the concurrent order.
+        // ONE ctx for the instance: the three proofs back to back on its stream and its arena (sized for the largest of them) -- for
+        // instances whose three arenas do not fit the card together (n = 4096 with the hardened AIRs: 276 GB of 288; back to back
+        // 179 GB).  Three streams are worth 5.5 % at n = 4096 and 13 - 15 % at n = 1024 (scripts/large_n_modes.py), so this is the
+        // fallback, not the default.  Largest first, like the concurrent order.
         const int serial[3] = {SIPP_G2_EXP, SIPP_G1_EXP, SIPP_FQ12_EXP};
         for (int k = 0; k < 3; k++) proof_len[k] = 0;
         for (int i = 0; i < 3; i++) {

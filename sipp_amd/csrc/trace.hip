@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
 // Fq[w]/(w^12 - 18 w^6 + 82) (one small-constant product each); (D) 24 lanes combine them; (E) state update + snapshot.
 // Beside the path: waves 4..5 convert and store the trace cells of the PREVIOUS bit's two rows from the snapshot while
 // waves 0..3 are in (A).  Round 1's kernel (288 lanes, 24-lane fold with 36 additions and two products in sequence,
-// conversion on the path) took 2.97 ms for the 14 records of n = 128, this one the time in DESIGN.md section 6b.
+// conversion on the path) took 2.97 ms for the 14 records of n = 128, this one the time in HISTORY.md section 6b.
 struct Fq12Cols {
     int acc, pw, C, cpl;
 };

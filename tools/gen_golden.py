@@ -58,7 +58,7 @@ def proof_digests_n128():
 
 
 def mapg2_fixture():
-    """SELF-GOLDEN vectors of the messages -> G2 step: 12 messages (seeded, plus u = 0, u in Fp, u = c u and
+    """SELF-GOLDEN vectors of the messages -> G2 step (HISTORY.md section 7b): 12 messages (seeded, plus u = 0, u in Fp, u = c u and
     the inv0 messages u^2 g(Z) = +-1) with their images under the Python reading of the map (oracle/py/map_to_g2.py), the
     cofactor-cleared points, and the sha256 of the CPU oracle's MapToG2 proof of the 12 records."""
     import hashlib
