@@ -38,7 +38,10 @@ def leaf(k, what):
             "valu_insts_per_launch": v[k]["SQ_INSTS_VALU"] / max(1, nv.get(k, 0))}
 
 
+line = json.loads(open("%s/bench_line.json" % src).read().strip().splitlines()[-1])
 out = {
+    # the AIR variant of the profiled instance (bench.py uses these counters only for a line of the same kinds)
+    "kinds": line["config"]["kinds"],
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE, --pmc SQ_INSTS_VALU) --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
     "calibration": "scripts/ubench/fetch_calib.hip: 1 GiB read with the leaf kernel's 8-B-per-lane column pattern reports FETCH_SIZE = 524,293.5 KB (exactly 1/2, as MI355X_MICROARCH.md section HBM says for wide coalesced reads); 1 GiB written reports WRITE_SIZE = 1,048,576 KB (exact)",
     "fetch_correction": 2.0,
@@ -47,13 +50,13 @@ out = {
     "leaf_pair": leaf("poseidon_leaves_pair_kernel", "two lanes per state: the thin Fq12 trees"),
     "valu_insts_per_instance": tot / steps_profiled,
 }
-NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel",
-       "tree_gather_kernel", "tree_pass_kernel")
+NTT = ("ntt_pass_kernel", "lde_column_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel", "tree_gather_kernel", "tree_mid_kernel",
+       "tree_pass_kernel")
 out["ntt"] = {"kernels": {k: {"launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"]}
                           for k in NTT if nf.get(k, 0)},
               "traffic_bytes_per_instance": sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / steps_profiled,
               "note": "all NTT / LDE kernels of one n = 128 instance (4 instances profiled: 1 warm-up + 2 timed steps + the serial step); FETCH_SIZE x2"}
-out["merkle"] = {k: nf.get(k, 0) // steps_profiled for k in ("merkle_subtree_kernel", "merkle_level_kernel", "merkle_level_quad_kernel") if nf.get(k, 0)}
+out["merkle"] = {k: nf.get(k, 0) // steps_profiled for k in ("merkle_subtree_kernel",) if nf.get(k, 0)}
 json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --inflight 1",
            "instances_profiled": steps_profiled, "valu_insts_per_instance": tot / steps_profiled,
            "per_kernel": {k: {"SQ_INSTS_VALU_per_instance": x["SQ_INSTS_VALU"] / steps_profiled, "share": x["SQ_INSTS_VALU"] / tot,
