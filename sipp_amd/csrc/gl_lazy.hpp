@@ -139,6 +139,12 @@ __device__ __forceinline__ uint64_t reduce96_nc(uint32_t hi32, uint64_t lo) {
     return r;
 }
 
+// N independent products as one block of interleaved chains (tools/gen_gl_muln.py): for kernels where a lone wave per SIMD has nothing
+// else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v199, s80 .. s91.
+#if GLL_T == 140
+#include "gl_lazy_muln.inc"
+#endif
+
 // (The same tail as a stand-alone 128 -> 64 reduction for the lazy accumulators of the partial rounds -- nine instructions against the
 // compiler's ~15, 55 uses per permutation -- measured no gain: 9.13-9.23 against 8.89-9.01 ms for 2^17 leaves x 1024 columns; not kept.)
 #endif  // GLL_T

@@ -101,27 +101,39 @@ __global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_
     }
 }
 
-// ---- two lanes per state (poseidon_pair.hpp): the middle ground for thin launches ----
+// ---- two lanes per state (poseidon_pair.hpp): the thin trees; lanes l and l + 32 of a wave share leaf 32 wave + (l & 31) ----
+__device__ uint32_t d_pair_a[poseidon_pair::PA_WORDS];
+__device__ uint32_t d_pair_mds_a[256];
+__device__ uint32_t d_pair_cc[poseidon_pair::CC_WORDS];
+__device__ uint64_t d_pair_start[poseidon_pair::PS_WORDS];
+
 __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
                                                                   uint64_t* __restrict__ digests) {
     __shared__ uint64_t tab[poseidon_quad::T_WORDS];
-    __shared__ uint32_t blk[poseidon_pair::B_WORDS];
-    poseidon_quad::load_tables(tab);
-    poseidon_pair::load_block_tables(blk);
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t leaf = tid >> 1;
-    const uint32_t h = (uint32_t)tid & 1;
-    if (leaf >= n_leaves) return;  // n_leaves is a multiple of 32: whole pairs / waves leave together
+    __shared__ __attribute__((aligned(16))) uint32_t pa[poseidon_pair::PA_WORDS];
+    __shared__ uint32_t cc[poseidon_pair::CC_WORDS];
+    __shared__ uint64_t ps[poseidon_pair::PS_WORDS];
+    for (int i = threadIdx.x; i < poseidon_pair::PA_WORDS; i += blockDim.x) pa[i] = d_pair_a[i];
+    for (int i = threadIdx.x; i < poseidon_pair::CC_WORDS; i += blockDim.x) cc[i] = d_pair_cc[i];
+    for (int i = threadIdx.x; i < poseidon_pair::PS_WORDS; i += blockDim.x) ps[i] = d_pair_start[i];
+    poseidon_quad::load_tables(tab);            // ends with the barrier
+    const poseidon_pair::Tables T{tab, pa, cc, ps};
+    const uint32_t lane = threadIdx.x & 63, h = lane >> 5;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t leaf = wave * 32 + (lane & 31);
+    if (leaf >= n_leaves) return;  // n_leaves is a multiple of 32: whole waves leave together (the matrix pipe needs every lane)
+    const poseidon::mfma_v4i afrag = *reinterpret_cast<const poseidon::mfma_v4i*>(d_pair_mds_a + 4 * lane);
     uint64_t s[6] = {0, 0, 0, 0, 0, 0};
     const uint64_t* p = lde + leaf;
+#pragma unroll 1
     for (uint32_t c = 0; c < ncols; c += 8) {
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const uint32_t e = 6 * h + j;
             if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
         }
-        poseidon_pair::permute(s, h, tab, blk);
+        poseidon_pair::permute(s, lane, T, afrag);
     }
     if (h == 0) {
         uint64_t* d = digests + 4 * leaf;
@@ -399,6 +411,10 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb_c), SIPP_POSEIDON_COMB_C, sizeof(SIPP_POSEIDON_COMB_C)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_dense_a), SIPP_POSEIDON_DENSE_A, sizeof(SIPP_POSEIDON_DENSE_A)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_dense_start), SIPP_POSEIDON_DENSE_START, sizeof(SIPP_POSEIDON_DENSE_START)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_a), SIPP_POSEIDON_PAIR_A, sizeof(SIPP_POSEIDON_PAIR_A)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_mds_a), SIPP_POSEIDON_PAIR_MDS_A, sizeof(SIPP_POSEIDON_PAIR_MDS_A)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_cc), SIPP_POSEIDON_PAIR_CC3, sizeof(SIPP_POSEIDON_PAIR_CC3)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_start), SIPP_POSEIDON_PAIR_START, sizeof(SIPP_POSEIDON_PAIR_START)));
     return SIPP_OK;
 }
 

@@ -1,210 +1,300 @@
-// sipp_amd/csrc/poseidon_pair.hpp -- Poseidon-Goldilocks with TWO lanes per state (32 states per wave).
+// sipp_amd/csrc/poseidon_pair.hpp -- Poseidon-Goldilocks with TWO lanes per state (32 states per wave), linear layers on the matrix pipe.
 //
-// Between one state per lane (21.3 k lane-instructions per permutation, but a 2^14-leaf tree is only 256 waves and a sponge
-// over ~1000 permutations per leaf then takes 50 us per permutation) and four lanes per state (poseidon_quad.hpp: 4x the waves,
-// 39.6 k lane-instructions per permutation): lane h of a pair holds elements 6h .. 6h + 5, the partner's six arrive through a DPP
-// quad_perm swap.  Rotating by the pair offset gives elements (6h + d) mod 12, d = 0 .. 11, in BOTH lanes, so the circulant MDS
-// uses the lane-uniform coefficient C[(d - j) mod 12] (only the DIAG[0] term is lane dependent).  In the partial rounds the
-// S-box of element 0 is evaluated by both lanes (one result is redundant), the sparse row dot product is split 6 + 6 and
-// summed across the pair.  Per-element constants come from the LDS copy of the tables (poseidon_quad::load_tables).
-// Bit-exact with the other two layouts (tests/test_gpu_generic.py).
+// Between one state per lane (a 2^14-leaf tree is only 256 waves, and a sponge over ~1000 permutations per leaf then takes 50 us per
+// permutation) and four lanes per state (poseidon_quad.hpp: 4x the waves, 39.6 k lane-instructions per permutation).  A lone wave per
+// SIMD issues one instruction per four cycles at best, so what such a thin launch pays for is the instruction count PER LANE.
+//
+// Layout (round 4): lanes l and l + 32 share state n = l & 31; lane (n, h) holds the six elements 6 h + j.  That is the operand layout
+// of v_mfma_i32_32x32x32_i8 -- B[k][n] comes from lane (n, k >> 4), D[i][n] goes to lane (n, (i >> 2) & 1) -- so ONE instruction sees the
+// whole state of 32 leaves in its K dimension, the halves' sums meet inside the matrix pipe, and every lane finds the six outputs it
+// owns in its own accumulator registers: no lane exchange for any linear layer.  The unused rows / columns of the 32 x 32 x 32 shape
+// carry a second product each (tools/gen_poseidon_header.py pair_tables): a full-round MDS layer is 4 instructions, a dense product
+// with full 64-bit constants (byte planes x signed base-256 digits, poseidon.hpp::dense_mfma) 20 instead of 64.
+//   * full rounds: S-boxes as blocks of three interleaved hand-scheduled products (gl_lazy.hpp mul3_nc), MDS on the matrix pipe with the
+//     next round's constants in the chain starts;
+//   * round 3's linear layer, the first constants of the sparse form and the dense pre-multiplication: ONE dense product (12 rows);
+//   * the 22 partial rounds lazily in two blocks of 11 (poseidon.hpp::partial_rounds_blocked): W S and S + V x as dense products, the
+//     triangular rest (x_j, j < k, times CC[k][j]) split over the pair by parity and summed through v_permlane32_swap; both lanes hold
+//     element 0 and evaluate x^7 together (x^2 on both, x^3 on the even and x^4 on the odd lane, exchanged, x^3 x^4 on both).
+// MFMA ignores EXEC: the kernel must run whole waves (n_leaves is a multiple of 32).  Bit-exact with the other layouts
+// (tests/test_gpu_generic.py).  Round 3's form (lanes 2 i / 2 i + 1, DPP, everything on the VALU): 12.9 k instructions per lane and
+// permutation; this one: see DESIGN.md section 4.
 #pragma once
 #include "poseidon_quad.hpp"
 
 namespace poseidon_pair {
 
 using namespace poseidon_quad;   // table layout T_*
+using poseidon::mfma_v16i;
+using poseidon::mfma_v4i;
 
-// value held by the other lane of the pair
-__device__ __forceinline__ uint32_t pair_swap32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
-}
-__device__ __forceinline__ uint64_t pair_swap(uint64_t v) {
-    return ((uint64_t)pair_swap32((uint32_t)(v >> 32)) << 32) | pair_swap32((uint32_t)v);
-}
-// value held by the even lane of the pair
-__device__ __forceinline__ uint64_t pair_bcast0(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)v, 0xA0 /* quad_perm [0, 0, 2, 2] */, 0xf, 0xf, true);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(v >> 32), 0xA0, 0xf, 0xf, true);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-struct Gathered {
-    uint32_t lo[12], hi[12];  // index d: element (6 h + d) mod 12
+// LDS tables of the kernel (beside poseidon_quad's `tab`)
+constexpr int PA_WORDS = 5 * SIPP_POSEIDON_PAIR_FRAGS * 64 * 4, CC_WORDS = 792, PS_WORDS = 120;
+struct Tables {
+    const uint64_t* tab;      // poseidon_quad::load_tables
+    const uint32_t* pa;       // dense A fragments [matrix][b / 2][lane][4]
+    const uint32_t* cc;       // CC limbs [block][k][j 0..11][3]
+    const uint64_t* ps;       // dense chain starts [matrix][element][L, H]
 };
-__device__ __forceinline__ void gather(const uint64_t s[6], Gathered& g) {
+
+// v (this lane's) -> the even lane's and the odd lane's value, in both lanes of the pair
+__device__ __forceinline__ void both32(uint32_t v, uint32_t& even, uint32_t& odd) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    even = r[0];
+    odd = r[1];
+}
+__device__ __forceinline__ void both(uint64_t v, uint64_t& even, uint64_t& odd) {
+    uint32_t el, ol, eh, oh;
+    both32((uint32_t)v, el, ol);
+    both32((uint32_t)(v >> 32), eh, oh);
+    even = ((uint64_t)eh << 32) | el;
+    odd = ((uint64_t)oh << 32) | ol;
+}
+
+// S-box layer of a full round on the lane's six elements (they carry the round's constants already): 24 products as eight blocks of
+// three interleaved hand-scheduled chains (19 instructions per product against the compiler's 23; measured 18.8 -> 18.1 ms for 2^14
+// leaves x 4942 columns in round 3's layout; the one-chain block in the partial rounds: 22.0 ms, its latency is exposed there)
+__device__ __forceinline__ void sbox6(uint64_t s[6]) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const uint32_t l = (uint32_t)s[j], h = (uint32_t)(s[j] >> 32);
-        g.lo[j] = l;
-        g.hi[j] = h;
-        g.lo[6 + j] = pair_swap32(l);
-        g.hi[6 + j] = pair_swap32(h);
+    for (int g = 0; g < 2; g++) {
+        uint64_t x[3], x2[3], x3[3], x4[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) x[j] = s[3 * g + j];
+        gll::mul3_nc(x2, x, x);
+        gll::mul3_nc(x3, x2, x);
+        gll::mul3_nc(x4, x2, x2);
+        gll::mul3_nc(x, x3, x4);
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[3 * g + j] = x[j];
     }
 }
 
-// out[6 h + j] = sum_d C[(d - j) mod 12] * in[(6 h + d) mod 12]  (+ 8 in[0] for element 0)
-__device__ __forceinline__ void mds_full(uint64_t s[6], uint32_t diag0 /* 8 in the even lane, else 0 */) {
-    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    Gathered g;
-    gather(s, g);
+// the eight byte planes of the lane's six words as B words: P[a][0] = bytes a of words 0 .. 3, P[a][1] = bytes a of words 4, 5 (+ two
+// bytes that meet zero columns of A), made signed by ^ 0x80.  Three 4 x 4 byte transposes.
+__device__ __forceinline__ void planes6(const uint32_t lo[6], const uint32_t hi[6], uint32_t P[8][2]) {
+    uint32_t o[4];
+    poseidon::mds_transpose4(lo, o);
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        uint64_t al = 0, ah = 0;
+    for (int b = 0; b < 4; b++) P[b][0] = o[b] ^ 0x80808080u;
+    poseidon::mds_transpose4(hi, o);
 #pragma unroll
-        for (int d = 0; d < 12; d++) {
-            al += (uint64_t)g.lo[d] * CIRC[(d - j + 12) % 12];
-            ah += (uint64_t)g.hi[d] * CIRC[(d - j + 12) % 12];
-        }
-        if (j == 0) {
-            al += (uint64_t)g.lo[0] * diag0;
-            ah += (uint64_t)g.hi[0] * diag0;
-        }
-        const uint64_t l = al + (ah << 32);
-        const uint32_t h = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-        s[j] = gl::reduce96_nc(h, l);
+    for (int b = 0; b < 4; b++) P[4 + b][0] = o[b] ^ 0x80808080u;
+    const uint32_t in[4] = {lo[4], lo[5], hi[4], hi[5]};
+    poseidon::mds_transpose4(in, o);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t x = o[b] ^ 0x80808080u;
+        P[b][1] = x;
+        P[4 + b][1] = x >> 16;
     }
 }
-
-// LDS copy of the lazy-block tables of the one-lane kernel (poseidon.hpp::partial_rounds_blocked), plus the limbs of 25 = M[0][0]
-// then the limbs of the merged affine layer of round 3 (poseidon.hpp::full_round3_combined): C3[11][12][3] and its constants
-constexpr int B_C25 = 2 * SIPP_POSEIDON_BLK_WORDS, B_COMB3 = B_C25 + 3, B_COMBC = B_COMB3 + 396, B_WORDS = B_COMBC + 24;
-__device__ __forceinline__ void load_block_tables(uint32_t* blk) {
-    for (int i = threadIdx.x; i < B_WORDS; i += blockDim.x) {
-        uint32_t v;
-        if (i < B_C25) v = poseidon::c_blk3[i];
-        else if (i < B_COMB3) v = i == B_C25 ? 25u : 0u;
-        else if (i < B_COMBC) v = poseidon::c_comb3[i - B_COMB3];
-        else v = (uint32_t)(poseidon::c_comb_c[(i - B_COMBC) >> 1] >> (32 * ((i - B_COMBC) & 1)));
-        blk[i] = v;
-    }
-    __syncthreads();
+__device__ __forceinline__ mfma_v4i plane_pair(const uint32_t P[8][2], int a) {
+    return mfma_v4i{(int)P[a][0], (int)P[a][1], (int)P[a + 1][0], (int)P[a + 1][1]};
 }
+#define SIPP_PAIR_ZERO16 mfma_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 
-// Full round 3 without its own MDS: its linear layer, the first constants of the sparse form and the dense 11 x 11
-// pre-multiplication are ONE affine map s -> C s + c (tools/gen_poseidon_header.py combined_layer): row 0 is the MDS row with
-// its small constants, rows 1..11 are twelve lazy multiply-accumulates each, started from c.
-__device__ __forceinline__ void full_round3_combined(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
-    constexpr uint32_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const uint32_t e0 = 6 * h;
-#pragma unroll
-    for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * 3 + e0 + j]));
-    Gathered g;
-    gather(s, g);
-    const uint32_t* C3 = blk + B_COMB3;
-    const uint32_t* CC = blk + B_COMBC;
+// out = MDS s (+ add): register j of the product with planes (a, a + 1) is M x plane a, register 6 + j is M x plane a + 1 (A = diag(M, M))
+// bias0: 128 rowsum(M) 0x01010101 of this lane's FIRST element (row 0 of the MDS carries the extra diagonal 8)
+template <bool ADD>
+__device__ __forceinline__ void mds_pair(uint64_t s[6], const uint64_t* __restrict__ add, uint64_t bias0, mfma_v4i afrag, uint32_t z) {
+    uint32_t lo[6], hi[6], P[8][2];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        const uint32_t e = e0 + j;
-        // rows 1..11 (for the even lane's j = 0 the row index is clamped and the result replaced below)
-        const uint32_t row = e ? e - 1 : 0;
-        gl::Acc6 acc;
-        acc.set(CC[2 * e], CC[2 * e + 1]);
+        lo[j] = (uint32_t)s[j];
+        hi[j] = (uint32_t)(s[j] >> 32);
+    }
+    planes6(lo, hi, P);
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    int64_t al[6], ah[6];
 #pragma unroll
-        for (int d = 0; d < 12; d++) {
-            const uint32_t ie = d < 6 ? e0 + d : e0 + d - 12 + (h ? 0 : 12);   // (6 h + d) mod 12
-            acc.mac(g.lo[d], g.hi[d], C3 + 3 * (row * 12 + ie));
-        }
-        uint64_t r = acc.reduce();
-        if (j == 0) {
-            // element 0: row 0 of the MDS (+ DIAG[0] = 8) on the even lane, with gathered index d = element d there
-            uint64_t al = (uint64_t)g.lo[0] * 8u, ah = (uint64_t)g.hi[0] * 8u;
+    for (int q = 0; q < 4; q++) {
+        const mfma_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, plane_pair(P, 2 * q), SIPP_PAIR_ZERO16, 0, 0, 0);
 #pragma unroll
-            for (int d = 0; d < 12; d++) {
-                al += (uint64_t)g.lo[d] * CIRC[d];
-                ah += (uint64_t)g.hi[d] * CIRC[d];
+        for (int j = 0; j < 6; j++) {
+            int64_t& acc = q < 2 ? al[j] : ah[j];
+            if ((q & 1) == 0) {
+                const uint64_t bias = j == 0 ? bias0 : (uint64_t)(128u * 256u) * 0x01010101ull;
+                const uint64_t c = ADD ? (q < 2 ? (uint64_t)(uint32_t)add[j] : (add[j] >> 32)) : 0;
+                acc = (int64_t)d[j] + (int64_t)(bias + c);
+                acc = (int64_t)d[6 + j] * (int64_t)p8 + acc;
+            } else {
+                acc = (int64_t)d[j] * (int64_t)p16 + acc;
+                acc = (int64_t)d[6 + j] * (int64_t)p24 + acc;
             }
-            const uint64_t l = al + (ah << 32);
-            const uint32_t hh = (uint32_t)(ah >> 32) + (l < al ? 1u : 0u);
-            const uint64_t c0 = ((uint64_t)CC[1] << 32) | CC[0];
-            const uint64_t m0 = gl::add_nc(gl::reduce96_nc(hh, l), c0);
-            r = h ? r : m0;
         }
-        s[j] = r;
-        asm volatile("" ::: "memory");   // keep the next row's table loads behind this one (register pressure)
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const uint64_t a = (uint64_t)al[j], hh = (uint64_t)ah[j];
+        const uint64_t l = a + (hh << 32);
+        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
+        s[j] = gll::reduce96_nc(h, l);
     }
 }
 
-// The 22 partial rounds, lazily in two blocks of 11 like the one-lane kernel: inside a block only element 0 is reduced mod p,
-// everything else is (u32 half of a start-of-block value or of an x_k) x (22-bit limb of a constant) accumulated into 64-bit sums
-// (gl::Acc6).  Split over the pair: a lane multiplies its OWN six start values and the x_j of its parity, the two partial sums
-// meet through one DPP swap; both lanes then hold element 0 and evaluate x^7 together -- x^2 on both, x^3 on the even and x^4
-// on the odd lane, swapped, x^3 x^4 on both: three products deep instead of four.  Constants are per lane (they depend on
-// which six elements the lane owns), hence from LDS.
-__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
+// out[j] = sum_e M[6 h + j][e] x_e + const (+ addend_j): one of the five dense constant products (tools/gen_poseidon_header.py
+// pair_matrices).  Digit sums D_t, t = a + b, as in poseidon.hpp::dense_mfma; here the chain of planes (a, a + 1), a = 0, 2, 4, 6, against
+// fragment b = t - a leaves D_t in registers j and D_(t+1) in registers 6 + j: 20 instructions, 8 chains.
+template <bool ADDEND>
+__device__ __forceinline__ void dense_pair(const uint32_t lo[6], const uint32_t hi[6], uint32_t mat, uint64_t out[6], const Tables& T, uint32_t lane,
+                                           uint32_t e0, const uint32_t* addlo, const uint32_t* addhi, uint32_t z) {
+    uint32_t P[8][2];
+    planes6(lo, hi, P);
+    mfma_v4i afr[SIPP_POSEIDON_PAIR_FRAGS];
+    {
+        const uint32_t* __restrict__ A = T.pa + mat * (SIPP_POSEIDON_PAIR_FRAGS * 256) + lane * 4;
+#pragma unroll
+        for (int f = 0; f < SIPP_POSEIDON_PAIR_FRAGS; f++) afr[f] = *reinterpret_cast<const mfma_v4i*>(A + f * 256);
+    }
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    const int32_t n1 = (int32_t)(0xffffffffu + z), n8 = -p8, n16 = -p16, n24 = -p24, p1 = (int32_t)(1u + z);
+    const uint64_t* __restrict__ K = T.ps + (mat * 12 + e0) * 2;
+    int64_t L[6], H[6];
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0 += 2) {
+        __builtin_amdgcn_sched_barrier(0);      // one accumulator chain at a time
+        mfma_v16i d = SIPP_PAIR_ZERO16;
+#pragma unroll
+        for (int a = 0; a < 8; a += 2) {
+            const int b = t0 - a;
+            if (b < 0 || b > 8) continue;
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[b / 2], plane_pair(P, a), d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int t = t0 + u;
+            if (t > 14) continue;
+            const int32_t pw = (t & 3) == 0 ? p1 : (t & 3) == 1 ? p8 : (t & 3) == 2 ? p16 : p24;
+            const int32_t nw = (t & 3) == 0 ? n1 : (t & 3) == 1 ? n8 : (t & 3) == 2 ? n16 : n24;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int32_t dv = d[6 * u + j];
+                if (t == 0) {
+                    uint64_t l0 = K[2 * j], h0 = K[2 * j + 1];      // chain starts (positive: + 2^50)
+                    if (ADDEND) {
+                        l0 += addlo[j];
+                        h0 += addhi[j];
+                    }
+                    L[j] = (int64_t)dv + (int64_t)l0;
+                    H[j] = (int64_t)h0;
+                } else if (t < 4) {
+                    L[j] = (int64_t)dv * (int64_t)pw + L[j];
+                } else if (t < 8) {
+                    H[j] = (int64_t)dv * (int64_t)pw + H[j];
+                } else if (t < 12) {
+                    H[j] = (int64_t)dv * (int64_t)pw + H[j];
+                    L[j] = (int64_t)dv * (int64_t)nw + L[j];
+                } else {
+                    L[j] = (int64_t)dv * (int64_t)nw + L[j];
+                }
+                // fold here, one D at a time (the compiler would otherwise reassociate and keep every accumulator alive)
+                asm volatile("" : "+v"(L[j]), "+v"(H[j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const uint64_t a = (uint64_t)L[j], hh = (uint64_t)H[j];   // both in (0, 2^52)
+        const uint64_t l = a + (hh << 32);
+        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
+        out[j] = gll::reduce96_nc(h, l);
+    }
+}
+
+// The 22 partial rounds, lazily in two blocks of 11 (the algebra: poseidon.hpp::partial_rounds_blocked).  s0: element 0, held by both
+// lanes.  A lane keeps the x_k of its parity (k = 2 m + h): they are its inputs of the V product and its share of the triangular sums.
+__device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint32_t h, const uint32_t lane, const Tables& T, uint32_t z) {
     constexpr int B = SIPP_POSEIDON_BLK_ROUNDS;
-    const uint32_t* C25 = blk + 2 * SIPP_POSEIDON_BLK_WORDS;
+    static_assert(B == 11, "the matrix-pipe form is laid out for blocks of eleven rounds");
+    const uint32_t e0 = 6 * h;
+    const uint32_t c25 = h ? 0u : 25u;           // M[0][0] x_k enters the even lane's sum
 #pragma unroll 1
     for (int b = 0; b < 22 / B; b++) {
-        const uint32_t* T = blk + SIPP_POSEIDON_BLK_WORDS * b;
-        uint32_t sl[6], sh[6], xl[B], xh[B];
+        uint32_t sl[6], sh[6], xl[6], xh[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             sl[j] = (uint32_t)s[j];
             sh[j] = (uint32_t)(s[j] >> 32);
+            xl[j] = xh[j] = 0;
         }
-        uint64_t s0 = pair_bcast0(s[0]);
+        uint64_t s0, unused;
+        both(s[0], s0, unused);
+        // pre_k = sum_i W[k][i] S_i, k = 6 h + j (the column of element 0 is zero: the even lane's s[0] does not enter)
+        uint64_t pre[6];
+        dense_pair<false>(sl, sh, 1 + 2 * (uint32_t)b, pre, T, lane, e0, nullptr, nullptr, z);
+        const uint32_t* __restrict__ CC = T.cc + (b * B) * 36 + 3 * h;
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const uint64_t x2 = SIPP_PMUL_THIN(s0, s0);
-            const uint64_t y = SIPP_PMUL_THIN(x2, h ? x2 : s0);
-            const uint64_t x = gl::add_nc(SIPP_PMUL_THIN(y, pair_swap(y)), tab[T_SCALAR + B * b + k]);
-            xl[k] = (uint32_t)x;
-            xh[k] = (uint32_t)(x >> 32);
-            const uint32_t* Wt = T + 33 * k + 3 * (k * (k - 1) / 2);
+            const uint64_t x2 = gl::mul_nc(s0, s0);
+            const uint64_t y = gl::mul_nc(x2, h ? x2 : s0);
+            uint64_t y3, y4;
+            both(y, y3, y4);
+            const uint64_t x = gl::add_nc(gl::mul_nc(y3, y4), T.tab[T_SCALAR + B * b + k]);
+            const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
             gl::Acc6 acc;
             acc.zero();
+            // 25 x_k on the even lane, pre_k on the lane that owns it
+            const bool mine = (k < 6) == (h == 0);
+            const uint64_t pk = pre[k % 6];
+            acc.a[0] = (uint64_t)xlo * c25 + (mine ? (uint32_t)pk : 0u);
+            acc.a[3] = (uint64_t)xhi * c25 + (mine ? (uint32_t)(pk >> 32) : 0u);
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                // element e = 6 h + j carries weight e - 1; the even lane's j = 0 IS element 0: it contributes 25 x_k
-                const bool is0 = j == 0 && h == 0;
-                const uint32_t* w = is0 ? C25 : Wt + 3 * (6 * h + j - 1);
-                acc.mac(is0 ? xl[k] : sl[j], is0 ? xh[k] : sh[j], w);
-            }
-#pragma unroll
-            for (int m = 0; 2 * m < k; m++) {
-                // x_j, j < k: j = 2 m on the even lane, 2 m + 1 (if it exists) on the odd one
-                const bool odd_ok = 2 * m + 1 < k;
-                const uint32_t lo = h ? (odd_ok ? xl[odd_ok ? 2 * m + 1 : 0] : 0u) : xl[2 * m];
-                const uint32_t hi = h ? (odd_ok ? xh[odd_ok ? 2 * m + 1 : 0] : 0u) : xh[2 * m];
-                acc.mac(lo, hi, Wt + 33 + 3 * (2 * m + (odd_ok ? h : 0)));
+            for (int m = 0; 2 * m < k; m++) acc.mac(xl[m], xh[m], CC + (k * 12 + 2 * m) * 3);     // x_(2 m + h); CC[k][j >= k] = 0
+            // keep x_k: slot k >> 1 of the lane of parity k & 1 (an even k may overwrite the odd lane's slot: x_(k+1) follows)
+            if ((k & 1) == 0) {
+                xl[k >> 1] = xlo;
+                xh[k >> 1] = xhi;
+            } else {
+                xl[k >> 1] = h ? xlo : xl[k >> 1];
+                xh[k >> 1] = h ? xhi : xh[k >> 1];
             }
             const uint64_t part = gl::canon(acc.reduce());
-            s0 = gl::add(part, pair_swap(part));
+            uint64_t pe, po;
+            both(part, pe, po);
+            s0 = gl::add(pe, po);
         }
-        const uint32_t* V = T + 33 * B + 3 * (B * (B - 1) / 2);
+        // S_e + sum_k V[e][k] x_k (+ the constants of full round 26 behind the last block), the block-start state as the addend
+        uint64_t o[6];
+        dense_pair<true>(xl, xh, 2 + 2 * (uint32_t)b, o, T, lane, e0, sl, sh, z);
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const bool is0 = j == 0 && h == 0;
-            gl::Acc6 acc;
-            acc.set(sl[j], sh[j]);
-            const uint32_t* v = V + 3 * ((is0 ? 0 : 6 * h + j - 1) * B);
-#pragma unroll
-            for (int k = 0; k < B; k++) acc.mac(xl[k], xh[k], v + 3 * k);
-            const uint64_t r = acc.reduce();
-            s[j] = is0 ? s0 : r;
-        }
+        for (int j = 0; j < 6; j++) s[j] = o[j];
+        s[0] = h ? o[0] : s0;
     }
 }
 
-// s: this lane's six elements (6 h + j); h = lane & 1; tab = LDS tables
-__device__ __forceinline__ void permute(uint64_t s[6], const uint32_t h, const uint64_t* tab, const uint32_t* blk) {
-    const uint32_t diag0 = h == 0 ? 8u : 0u;
-    const uint32_t e0 = 6 * h;
+// s: this lane's six elements (6 h + j); lane = lane of the wave; h = lane >> 5; afrag = this lane's words of SIPP_POSEIDON_PAIR_MDS_A
+__device__ __forceinline__ void permute(uint64_t s[6], const uint32_t lane, const Tables& T, mfma_v4i afrag) {
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    const uint32_t h = lane >> 5, e0 = 6 * h;
+    const uint64_t bias0 = (uint64_t)(128u * (256u + (h ? 0u : 8u))) * 0x01010101ull;
+    const uint64_t* __restrict__ rc = T.tab + T_RC + e0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) s[j] = gl::add_nc(s[j], rc[j]);
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
-        mds_full(s, diag0);
+        sbox6(s);
+        mds_pair<true>(s, rc + 12 * (r + 1), bias0, afrag, z);
     }
-    full_round3_combined(s, h, tab, blk);
-    partial_rounds_blocked(s, h, tab, blk);
+    {   // full round 3: its MDS, the first constants of the sparse form and the dense pre-multiplication are ONE affine map
+        sbox6(s);
+        uint32_t lo[6], hi[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            lo[j] = (uint32_t)s[j];
+            hi[j] = (uint32_t)(s[j] >> 32);
+        }
+        dense_pair<false>(lo, hi, 0, s, T, lane, e0, nullptr, nullptr, z);
+    }
+    partial_rounds_blocked(s, h, lane, T, z);
+    s[0] = h ? s[0] : gl::add_nc(s[0], rc[12 * 26]);      // element 0 left the blocks without round 26's constant
 #pragma unroll 1
-    for (int r = 26; r < 30; r++) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) s[j] = poseidon::sbox_thin(gl::add_nc(s[j], tab[T_RC + 12 * r + e0 + j]));
-        mds_full(s, diag0);
+    for (int r = 26; r < 29; r++) {
+        sbox6(s);
+        mds_pair<true>(s, rc + 12 * (r + 1), bias0, afrag, z);
     }
+    sbox6(s);
+    mds_pair<false>(s, nullptr, bias0, afrag, z);
 #pragma unroll
     for (int j = 0; j < 6; j++) s[j] = gl::canon(s[j]);
 }

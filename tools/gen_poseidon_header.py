@@ -373,6 +373,179 @@ def dense_model(mat_index, frag, starts, x, addend=None):
     return out
 
 
+# ---- the same products for the TWO-LANES-PER-STATE kernel (poseidon_pair.hpp): lanes l and l + 32 share a state -------------------
+# v_mfma_i32_32x32x32_i8 reads A[i][k] from lane (i = l & 31, k = 16 (l >> 5) + byte), B[k][n] from lane (n = l & 31, k = 16 (l >> 5) +
+# byte) and leaves D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][n = l & 31] in register r of lane l.  With lane (n, h) holding the six elements
+# 6 h + j of state n, ONE instruction sees the whole state of 32 leaves in its K dimension, and the unused rows / columns carry a second
+# product: K slot ps (bytes 8 ps + j of the lane's sixteen) = a second byte plane, M slot ds (registers 6 ds + j) = a second digit.
+#   MDS layers (small constants): A = diag(M, M): register j = M x (plane a), register 6 + j = M x (plane a + 1): 4 instructions per layer.
+#   dense products: B = [plane a | plane a + 1] (a even), A_b = rows ds: [digit b + ds | digit b + ds - 1]: register 6 ds + j collects
+#   the digit sum t + ds, t = a + b: 20 instructions per product (chains t = 0, 2, .. 14 over a = 0, 2, 4, 6) instead of 64.
+PAIR_FRAGS = 5          # b = 0, 2, 4, 6, 8
+
+
+def pair_row(rho):
+    """A row rho -> (output half h, register) of the lane that finds it"""
+    return (rho >> 2) & 1, (rho & 3) + 4 * (rho >> 3)
+
+
+def pair_fragment(entry):
+    """[lane 0..63][4 u32]: entry(e_out, ds, e_in, ps) -> signed byte"""
+    frag = []
+    for lane in range(64):
+        rho, hh = lane & 31, lane >> 5
+        h_out, reg = pair_row(rho)
+        w = [0, 0, 0, 0]
+        if reg < 12:
+            j, ds = reg % 6, reg // 6
+            for ps in range(2):
+                for jj in range(6):
+                    v = entry(6 * h_out + j, ds, 6 * hh + jj, ps)
+                    assert -128 <= v <= 127
+                    byte = 8 * ps + jj
+                    w[byte >> 2] |= (v & 0xFF) << (8 * (byte & 3))
+        frag += w
+    return frag
+
+
+def mfma_model(afrag, bfrag, acc):
+    """D = A B + C of v_mfma_i32_32x32x32_i8 on per-lane operands: afrag / bfrag [64][4 u32], acc [64][16] -> [64][16]"""
+    def sb(words, byte):
+        v = (words[byte >> 2] >> (8 * (byte & 3))) & 0xFF
+        return v - 256 if v >= 128 else v
+    A = [[sb(afrag[i + 32 * (k >> 4)], k & 15) for k in range(32)] for i in range(32)]
+    B = [[sb(bfrag[n + 32 * (k >> 4)], k & 15) for n in range(32)] for k in range(32)]
+    out = []
+    for lane in range(64):
+        n, h = lane & 31, lane >> 5
+        regs = []
+        for r in range(16):
+            i = (r & 3) + 8 * (r >> 2) + 4 * h
+            v = acc[lane][r] + sum(A[i][k] * B[k][n] for k in range(32))
+            assert -(1 << 31) <= v < (1 << 31)
+            regs.append(v)
+        out.append(regs)
+    return out
+
+
+def pair_matrices(first, Mi, vs, ws, rc):
+    """12 x 12 matrices over (output slot, input slot) and additive constants, kernel order: 0 = the whole combined layer of round 3;
+    1 + 2 b = W of block b (output slot k = local round, input slot = element); 2 + 2 b = V (output slot = element, input slot 6 hh + jj =
+    local round 2 jj + hh: a lane keeps the x_k of its parity); the constants of full round 26 ride on the last V"""
+    Cm, cv = combined_layer(first, Mi)
+    mats = [([row[:] for row in Cm], cv[:])]
+    for r0 in range(0, N_PARTIAL, BLK):
+        Wm = [[0] + [ws[r0 + k][i] for i in range(W - 1)] for k in range(BLK)] + [[0] * 12]
+        Vm = [[0] * 12]
+        for i in range(W - 1):
+            row = [0] * 12
+            for k in range(BLK):
+                row[6 * (k & 1) + (k >> 1)] = vs[r0 + k][i]
+            Vm.append(row)
+        last = r0 + BLK == N_PARTIAL
+        mats.append((Wm, [0] * 12))
+        mats.append((Vm, [0] + [rc[12 * (N_FULL_HALF + N_PARTIAL) + e] if last else 0 for e in range(1, 12)]))
+    return mats
+
+
+def pair_planes(x6):
+    """the eight byte planes of a lane's six words as B words [a][2]: bytes 0..5 of the pair = the elements' bytes (^ 0x80)"""
+    out = []
+    for a in range(8):
+        by = [(((x >> (8 * a)) & 0xFF) ^ 0x80) for x in x6] + [0, 0]
+        out.append([by[0] | by[1] << 8 | by[2] << 16 | by[3] << 24, by[4] | by[5] << 8])
+    return out
+
+
+def pair_tables(mats):
+    """A fragments [mat][f = b / 2][lane][4] and chain starts [mat][element][L, H]"""
+    frag, starts = [], []
+    for Mx, add in mats:
+        dig = [[signed_digits(c) for c in row] for row in Mx]
+
+        for f in range(PAIR_FRAGS):
+            def entry(eo, ds, ei, ps, b=2 * f):
+                beta = b + ds - ps
+                return dig[eo][ei][0][beta] if 0 <= beta <= 7 else 0
+            frag += pair_fragment(entry)
+        for e in range(12):
+            bias = 128 * 0x0101010101010101 * sum(dig[e][i][1] for i in range(12))
+            K = (bias + add[e] - DENSE_OFF * (1 + (1 << 32))) % P
+            starts += [(K & 0xFFFFFFFF) + DENSE_OFF, (K >> 32) + DENSE_OFF]
+    return frag, starts
+
+
+def pair_mds_fragment():
+    M = mds_matrix()
+    return pair_fragment(lambda eo, ds, ei, ps: M[eo][ei] if ds == ps else 0)
+
+
+def pair_fold(D, L, H, t):
+    """digit sum D_t into the chains (the arithmetic of poseidon.hpp::dense_mfma)"""
+    if t < 4:
+        L += D << (8 * t)
+    elif t < 8:
+        H += D << (8 * (t - 4))
+    elif t < 12:
+        H += D << (8 * (t - 8))
+        L -= D << (8 * (t - 8))
+    else:
+        L -= D << (8 * (t - 12))
+    return L, H
+
+
+def pair_dense_model(mi, frag, starts, x12, addend=None):
+    """python model of poseidon_pair.hpp::dense_pair for one state (every column n of the wave holds the same state)"""
+    planes = [pair_planes(x12[6 * h:6 * h + 6]) for h in range(2)]
+    L = [starts[(mi * 12 + e) * 2] + ((addend[e] & 0xFFFFFFFF) if addend else 0) for e in range(12)]
+    H = [starts[(mi * 12 + e) * 2 + 1] + ((addend[e] >> 32) if addend else 0) for e in range(12)]
+    for t in range(0, 16, 2):
+        acc = [[0] * 16 for _ in range(64)]
+        for a in range(0, 8, 2):
+            b = t - a
+            if b < 0 or b > 8:
+                continue
+            f = b // 2
+            afr = [frag[((mi * PAIR_FRAGS + f) * 64 + lane) * 4:((mi * PAIR_FRAGS + f) * 64 + lane) * 4 + 4] for lane in range(64)]
+            bfr = [planes[lane >> 5][a] + planes[lane >> 5][a + 1] for lane in range(64)]
+            acc = mfma_model(afr, bfr, acc)
+        for h in range(2):
+            for j in range(6):
+                e = 6 * h + j
+                L[e], H[e] = pair_fold(acc[32 * h][j], L[e], H[e], t)
+                if t + 1 < 15:
+                    L[e], H[e] = pair_fold(acc[32 * h][6 + j], L[e], H[e], t + 1)
+                else:
+                    assert acc[32 * h][6 + j] == 0
+    out = []
+    for e in range(12):
+        assert 0 < L[e] < (1 << 52) and 0 < H[e] < (1 << 52)
+        lo = (L[e] + (H[e] << 32)) & 0xFFFFFFFFFFFFFFFF
+        hi = (H[e] >> 32) + (1 if lo < L[e] else 0)
+        out.append((lo + (hi << 64)) % P)
+    return out
+
+
+def pair_mds_model(frag, x12, add12):
+    """python model of poseidon_pair.hpp::mds_pair: out = M x + add (mod p)"""
+    planes = [pair_planes(x12[6 * h:6 * h + 6]) for h in range(2)]
+    D = []
+    for a in range(0, 8, 2):
+        afr = [frag[lane * 4:lane * 4 + 4] for lane in range(64)]
+        bfr = [planes[lane >> 5][a] + planes[lane >> 5][a + 1] for lane in range(64)]
+        D.append(mfma_model(afr, bfr, [[0] * 16 for _ in range(64)]))
+    M = mds_matrix()
+    out = []
+    for e in range(12):
+        h, j = e // 6, e % 6
+        bias = 128 * sum(M[e]) * 0x01010101
+        al = bias + (add12[e] & 0xFFFFFFFF) + sum((D[a][32 * h][j] << (16 * a)) + (D[a][32 * h][6 + j] << (16 * a + 8)) for a in range(2))
+        ah = bias + (add12[e] >> 32) + sum((D[2 + a][32 * h][j] << (16 * a)) + (D[2 + a][32 * h][6 + j] << (16 * a + 8)) for a in range(2))
+        assert 0 <= al < (1 << 44) and 0 <= ah < (1 << 44)
+        out.append((al + (ah << 32)) % P)
+    return out
+
+
 def limbs3(c):
     """22 + 22 + 20 bits"""
     assert 0 <= c < P
@@ -443,6 +616,22 @@ def main():
             for r in range(len(Mx)):
                 want = (sum(Mx[r][e] * x[e] for e in range(12)) + add[r] + (extra[r] if extra else 0)) % P
                 assert got[r] == want, ("dense product on the matrix pipe", mi, r, t)
+    # the two-lanes-per-state forms of the same products (poseidon_pair.hpp) against plain matrix-vector products
+    pmats = pair_matrices(first, Mi, vs, ws, rc)
+    pfrag, pstarts = pair_tables(pmats)
+    pmds = pair_mds_fragment()
+    Mm = mds_matrix()
+    for t in range(4):
+        x = [rnd.randrange(1 << 64) for _ in range(12)] if t > 1 else [(1 << 64) - 1] * 12 if t else [0] * 12
+        addc = [rnd.randrange(P) for _ in range(12)]
+        got = pair_mds_model(pmds, x, addc)
+        assert got == [(sum(Mm[r][e] * x[e] for e in range(12)) + addc[r]) % P for r in range(12)], ("pair MDS on the matrix pipe", t)
+        for mi, (Mx, add) in enumerate(pmats):
+            extra = [rnd.randrange(1 << 64) for _ in range(12)] if (mi and mi % 2 == 0) else None
+            got = pair_dense_model(mi, pfrag, pstarts, x, extra)
+            for r in range(12):
+                want = (sum(Mx[r][e] * x[e] for e in range(12)) + add[r] + (extra[r] if extra else 0)) % P
+                assert got[r] == want, ("pair dense product on the matrix pipe", mi, r, t)
     kat0 = naive_perm([0] * 12, rc)
     assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
 
@@ -485,6 +674,21 @@ def main():
         f.write("#define SIPP_POSEIDON_DENSE_MATS %d\n" % len(mats))
         f.write("static const uint32_t SIPP_POSEIDON_DENSE_A[%d] = {\n" % len(dfrag) + fmt32x(dfrag) + "\n};\n")
         f.write("static const uint64_t SIPP_POSEIDON_DENSE_START[%d] = {\n" % len(dstarts) + fmt(dstarts) + "\n};\n")
+        f.write("// the same for the two-lanes-per-state kernel (poseidon_pair.hpp; pair_tables() / pair_mds_fragment() in the generator):\n"
+                "// A fragments [matrix][b / 2][lane][4] carrying two digits and two byte planes each, chain starts [matrix][element][L, H],\n"
+                "// and the block-diagonal fragment diag(MDS, MDS) of the full-round layers\n")
+        f.write("#define SIPP_POSEIDON_PAIR_FRAGS %d\n" % PAIR_FRAGS)
+        f.write("static const uint32_t SIPP_POSEIDON_PAIR_A[%d] = {\n" % len(pfrag) + fmt32x(pfrag) + "\n};\n")
+        f.write("static const uint64_t SIPP_POSEIDON_PAIR_START[%d] = {\n" % len(pstarts) + fmt(pstarts) + "\n};\n")
+        f.write("static const uint32_t SIPP_POSEIDON_PAIR_MDS_A[%d] = {\n" % len(pmds) + fmt32x(pmds) + "\n};\n")
+        f.write("// CC[r][t] of the lazy blocks (blocked_tables) as limb triples, [block][local round k][local round j 0..11] with zeros for\n"
+                "// j >= k: the lanes of a pair read the entries of their parity without a bound check\n")
+        cc3 = []
+        for r0 in range(0, N_PARTIAL, BLK):
+            for k in range(BLK):
+                for j in range(12):
+                    cc3 += limbs3(cc[(r0 + k, r0 + j)]) if j < k else [0, 0, 0]
+        f.write("static const uint32_t SIPP_POSEIDON_PAIR_CC3[%d] = {\n" % len(cc3) + fmt32(cc3) + "\n};\n")
     assert all(Mi[0][j] == (1 if j == 0 else 0) for j in range(12)) and all(Mi[i][0] == 0 for i in range(1, 12))
     print("ok: headers written; fast-partial tables verified against naive permutation")
 
