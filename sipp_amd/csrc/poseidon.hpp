@@ -147,6 +147,18 @@ __device__ __forceinline__ void mds_transpose4(const uint32_t in[4], uint32_t ou
     out[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
 }
 
+// d + start as ONE multiply-add (one = an opaque wave-uniform 1; the compiler's sign extension + 64-bit addition are three instructions).
+// Not inline asm: D registers are read here, and the wait states between a matrix-pipe write and a VALU read come from the compiler's
+// hazard recogniser, which does not look into asm blocks
+__device__ __forceinline__ int64_t chain_start(int32_t d, uint64_t start, int32_t one) { return (int64_t)d * (int64_t)one + (int64_t)start; }
+// a + 2^32 hh (both below 2^63) -> any u64 congruent to it: the carry of the middle words goes into the 96-bit reduction's high word (two
+// carry instructions instead of a 64-bit addition, a 64-bit compare and a select)
+__device__ __forceinline__ uint64_t fold_chains(uint64_t a, uint64_t hh) {
+    uint32_t c = 0;
+    const uint32_t mid = __builtin_addc((uint32_t)(a >> 32), (uint32_t)hh, 0u, &c);
+    return SIPP_PRED96((uint32_t)(hh >> 32) + c, ((uint64_t)mid << 32) | (uint32_t)a);
+}
+
 template <bool ADD>
 __device__ __forceinline__ void mds_full_mfma(uint64_t s[12], const uint64_t* __restrict__ add, mfma_v4i afrag, uint32_t z) {
     uint32_t lo[12], hi[12], plane[8][3];
@@ -166,7 +178,7 @@ __device__ __forceinline__ void mds_full_mfma(uint64_t s[12], const uint64_t* __
         for (int b = 0; b < 4; b++) plane[4 + b][g] = o[b] ^ 0x80808080u;
     }
     // 2^8, 2^16, 2^24 as wave-uniform values the compiler cannot fold into literals (VOP3 has no literal operand on gfx9: SGPRs)
-    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z), p1 = (int32_t)(1u + z);
     int64_t al[12], ah[12];
 #pragma unroll
     for (int b = 0; b < 8; b++) {
@@ -179,19 +191,14 @@ __device__ __forceinline__ void mds_full_mfma(uint64_t s[12], const uint64_t* __
                 // chain start: the bias of the four planes of this chain, and the next round's constant
                 const uint64_t bias = (uint64_t)(128u * (256u + (r == 0 ? 8u : 0u))) * 0x01010101ull;
                 const uint64_t c = ADD ? (b < 4 ? (uint64_t)(uint32_t)add[r] : (add[r] >> 32)) : 0;
-                acc = (int64_t)d[r] + (int64_t)(bias + c);
+                acc = chain_start(d[r], bias + c, p1);
             } else {
                 acc = (int64_t)d[r] * (int64_t)((b & 3) == 1 ? p8 : (b & 3) == 2 ? p16 : p24) + acc;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 12; r++) {
-        const uint64_t a = (uint64_t)al[r], hh = (uint64_t)ah[r];
-        const uint64_t l = a + (hh << 32);
-        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
-        s[r] = SIPP_PRED96(h, l);
-    }
+    for (int r = 0; r < 12; r++) s[r] = fold_chains((uint64_t)al[r], (uint64_t)ah[r]);
 }
 
 // ---- DENSE products with full 64-bit constants on the matrix pipe (round 4) ----------------------------------------------------------
@@ -252,7 +259,7 @@ __device__ __forceinline__ void dense_mfma(const uint32_t lo[12], const uint32_t
                     l0 += (uint32_t)av;
                     h0 += av >> 32;
                 }
-                L[r] = (int64_t)d[r] + (int64_t)l0;
+                L[r] = chain_start(d[r], l0, p1);
                 H[r] = (int64_t)h0;
             } else if (t < 4) {
                 L[r] = (int64_t)d[r] * (int64_t)pw + L[r];
@@ -272,12 +279,7 @@ __device__ __forceinline__ void dense_mfma(const uint32_t lo[12], const uint32_t
         }
     }
 #pragma unroll
-    for (int r = 0; r < 11; r++) {
-        const uint64_t a = (uint64_t)L[r], hh = (uint64_t)H[r];   // both in (0, 2^52)
-        const uint64_t l = a + (hh << 32);
-        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
-        out[r] = SIPP_PRED96(h, l);
-    }
+    for (int r = 0; r < 11; r++) out[r] = fold_chains((uint64_t)L[r], (uint64_t)H[r]);   // both chains in (0, 2^52)
 }
 #endif
 

@@ -93,6 +93,9 @@ __device__ __forceinline__ mfma_v4i plane_pair(const uint32_t P[8][2], int a) {
 }
 #define SIPP_PAIR_ZERO16 mfma_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 
+using poseidon::chain_start;   // d + start as one multiply-add
+using poseidon::fold_chains;   // (L, H) chains -> u64
+
 // out = MDS s (+ add): register j of the product with planes (a, a + 1) is M x plane a, register 6 + j is M x plane a + 1 (A = diag(M, M))
 // bias0: 128 rowsum(M) 0x01010101 of this lane's FIRST element (row 0 of the MDS carries the extra diagonal 8)
 template <bool ADD>
@@ -104,32 +107,34 @@ __device__ __forceinline__ void mds_pair(uint64_t s[6], const uint64_t* __restri
         hi[j] = (uint32_t)(s[j] >> 32);
     }
     planes6(lo, hi, P);
-    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z);
+    const int32_t p8 = (int32_t)(256u + z), p16 = (int32_t)(65536u + z), p24 = (int32_t)(16777216u + z), p1 = (int32_t)(1u + z);
     int64_t al[6], ah[6];
+    // the wave issues in order and the matrix pipe takes one product per 32 cycles: the folds of product q sit between the issue of
+    // products q + 1 and q + 2 (a lone wave per SIMD has nobody else to fill the wait)
+    mfma_v16i d[4];
+    d[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, plane_pair(P, 0), SIPP_PAIR_ZERO16, 0, 0, 0);
+    d[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, plane_pair(P, 2), SIPP_PAIR_ZERO16, 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const mfma_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, plane_pair(P, 2 * q), SIPP_PAIR_ZERO16, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < 4) d[q + 2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag, plane_pair(P, 2 * q + 4), SIPP_PAIR_ZERO16, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             int64_t& acc = q < 2 ? al[j] : ah[j];
             if ((q & 1) == 0) {
                 const uint64_t bias = j == 0 ? bias0 : (uint64_t)(128u * 256u) * 0x01010101ull;
                 const uint64_t c = ADD ? (q < 2 ? (uint64_t)(uint32_t)add[j] : (add[j] >> 32)) : 0;
-                acc = (int64_t)d[j] + (int64_t)(bias + c);
-                acc = (int64_t)d[6 + j] * (int64_t)p8 + acc;
+                acc = chain_start(d[q][j], bias + c, p1);
+                acc = (int64_t)d[q][6 + j] * (int64_t)p8 + acc;
             } else {
-                acc = (int64_t)d[j] * (int64_t)p16 + acc;
-                acc = (int64_t)d[6 + j] * (int64_t)p24 + acc;
+                acc = (int64_t)d[q][j] * (int64_t)p16 + acc;
+                acc = (int64_t)d[q][6 + j] * (int64_t)p24 + acc;
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const uint64_t a = (uint64_t)al[j], hh = (uint64_t)ah[j];
-        const uint64_t l = a + (hh << 32);
-        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
-        s[j] = gll::reduce96_nc(h, l);
-    }
+    for (int j = 0; j < 6; j++) s[j] = fold_chains((uint64_t)al[j], (uint64_t)ah[j]);
 }
 
 // out[j] = sum_e M[6 h + j][e] x_e + const (+ addend_j): one of the five dense constant products (tools/gen_poseidon_header.py
@@ -150,55 +155,67 @@ __device__ __forceinline__ void dense_pair(const uint32_t lo[6], const uint32_t 
     const int32_t n1 = (int32_t)(0xffffffffu + z), n8 = -p8, n16 = -p16, n24 = -p24, p1 = (int32_t)(1u + z);
     const uint64_t* __restrict__ K = T.ps + (mat * 12 + e0) * 2;
     int64_t L[6], H[6];
-#pragma unroll
-    for (int t0 = 0; t0 < 16; t0 += 2) {
-        __builtin_amdgcn_sched_barrier(0);      // one accumulator chain at a time
-        mfma_v16i d = SIPP_PAIR_ZERO16;
+    // chain t0 (digit sums t0 and t0 + 1) = the products of planes (a, a + 1), a = 0, 2, 4, 6, with fragment b = t0 - a in 0 .. 8.  The wave
+    // issues in order and the matrix pipe takes a product per 32 cycles: chain t0 + 2 is issued BETWEEN the folds of chain t0, one product
+    // per group of folds (a lone wave per SIMD has nobody else to fill the wait)
+    auto product = [&](mfma_v16i& d, int t0, int i, bool first) {     // the i-th product of chain t0
+        int n = 0;
 #pragma unroll
         for (int a = 0; a < 8; a += 2) {
             const int b = t0 - a;
             if (b < 0 || b > 8) continue;
-            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[b / 2], plane_pair(P, a), d, 0, 0, 0);
+            if (n == i) d = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[b / 2], plane_pair(P, a), first ? SIPP_PAIR_ZERO16 : d, 0, 0, 0);
+            n++;
         }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int t = t0 + u;
-            if (t > 14) continue;
-            const int32_t pw = (t & 3) == 0 ? p1 : (t & 3) == 1 ? p8 : (t & 3) == 2 ? p16 : p24;
-            const int32_t nw = (t & 3) == 0 ? n1 : (t & 3) == 1 ? n8 : (t & 3) == 2 ? n16 : n24;
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const int32_t dv = d[6 * u + j];
-                if (t == 0) {
-                    uint64_t l0 = K[2 * j], h0 = K[2 * j + 1];      // chain starts (positive: + 2^50)
-                    if (ADDEND) {
-                        l0 += addlo[j];
-                        h0 += addhi[j];
-                    }
-                    L[j] = (int64_t)dv + (int64_t)l0;
-                    H[j] = (int64_t)h0;
-                } else if (t < 4) {
-                    L[j] = (int64_t)dv * (int64_t)pw + L[j];
-                } else if (t < 8) {
-                    H[j] = (int64_t)dv * (int64_t)pw + H[j];
-                } else if (t < 12) {
-                    H[j] = (int64_t)dv * (int64_t)pw + H[j];
-                    L[j] = (int64_t)dv * (int64_t)nw + L[j];
-                } else {
-                    L[j] = (int64_t)dv * (int64_t)nw + L[j];
-                }
-                // fold here, one D at a time (the compiler would otherwise reassociate and keep every accumulator alive)
-                asm volatile("" : "+v"(L[j]), "+v"(H[j]));
+    };
+    auto products_of = [](int t0) { return t0 > 14 ? 0 : t0 <= 6 ? t0 / 2 + 1 : t0 == 8 ? 4 : (16 - t0) / 2; };
+    auto fold = [&](const mfma_v16i& d, int t, int j) {
+        const int32_t pw = (t & 3) == 0 ? p1 : (t & 3) == 1 ? p8 : (t & 3) == 2 ? p16 : p24;
+        const int32_t nw = (t & 3) == 0 ? n1 : (t & 3) == 1 ? n8 : (t & 3) == 2 ? n16 : n24;
+        const int32_t dv = d[6 * (t & 1) + j];
+        if (t == 0) {
+            uint64_t l0 = K[2 * j], h0 = K[2 * j + 1];      // chain starts (positive: + 2^50)
+            if (ADDEND) {
+                l0 += addlo[j];
+                h0 += addhi[j];
             }
+            L[j] = chain_start(dv, l0, p1);
+            H[j] = (int64_t)h0;
+        } else if (t < 4) {
+            L[j] = (int64_t)dv * (int64_t)pw + L[j];
+        } else if (t < 8) {
+            H[j] = (int64_t)dv * (int64_t)pw + H[j];
+        } else if (t < 12) {
+            H[j] = (int64_t)dv * (int64_t)pw + H[j];
+            L[j] = (int64_t)dv * (int64_t)nw + L[j];
+        } else {
+            L[j] = (int64_t)dv * (int64_t)nw + L[j];
+        }
+        // fold here, one D at a time (the compiler would otherwise reassociate and keep every accumulator alive)
+        asm volatile("" : "+v"(L[j]), "+v"(H[j]));
+    };
+    mfma_v16i dd[2];
+    product(dd[0], 0, 0, true);
+#pragma unroll
+    for (int t0 = 0; t0 < 16; t0 += 2) {
+        mfma_v16i& cur = dd[(t0 >> 1) & 1];
+        mfma_v16i& nxt = dd[((t0 >> 1) + 1) & 1];
+        const int n = products_of(t0 + 2);
+        const int items = t0 == 14 ? 6 : 12;                 // (t, j) folds of this chain: t0 first, then t0 + 1
+        int done = 0;
+#pragma unroll
+        for (int i = 0; i < (n ? n : 1); i++) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (n) product(nxt, t0 + 2, i, i == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int upto = items * (i + 1) / (n ? n : 1);
+#pragma unroll
+            for (int it = done; it < upto; it++) fold(cur, t0 + it / 6, it % 6);
+            done = upto;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const uint64_t a = (uint64_t)L[j], hh = (uint64_t)H[j];   // both in (0, 2^52)
-        const uint64_t l = a + (hh << 32);
-        const uint32_t h = (uint32_t)(hh >> 32) + (l < a ? 1u : 0u);
-        out[j] = gll::reduce96_nc(h, l);
-    }
+    for (int j = 0; j < 6; j++) out[j] = fold_chains((uint64_t)L[j], (uint64_t)H[j]);   // both chains in (0, 2^52)
 }
 
 // The 22 partial rounds, lazily in two blocks of 11 (the algebra: poseidon.hpp::partial_rounds_blocked).  s0: element 0, held by both
