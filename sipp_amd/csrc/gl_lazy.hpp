@@ -139,6 +139,26 @@ __device__ __forceinline__ uint64_t reduce96_nc(uint32_t hi32, uint64_t lo) {
     return r;
 }
 
+// (hi, lo) -> any u64 congruent to lo + 2^64 hi: the tail of the product block on its own (nine instructions against ~15 with wait states
+// in the compiler's code for gl::reduce128_nc).  For the thin hash kernel, where a lone wave per SIMD pays for every instruction it issues;
+// in the one-state-per-lane kernel (three waves per SIMD) it measured no gain (round 3) and is not used there.
+__device__ __forceinline__ uint64_t reduce128_nc(uint64_t hi, uint64_t lo) {
+    uint64_t r;
+    asm("v_mad_u64_u32 " GLL_P2 ", vcc, %1, -1, %3\n\t"
+        "v_subb_co_u32_e32 " GLL_R8 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"
+        "v_mov_b32_e32 " GLL_R9 ", 0\n\t"
+        "v_lshl_add_u64 " GLL_P2 ", " GLL_P2 ", 0, " GLL_P8 "\n\t"
+        "v_sub_co_u32_e32 " GLL_R2 ", vcc, " GLL_R2 ", %2\n\t"
+        "v_subbrev_co_u32_e32 " GLL_R3 ", vcc, 0, " GLL_R3 ", vcc\n\t"
+        "v_subb_co_u32_e32 " GLL_R5 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"
+        "v_lshrrev_b32_e32 " GLL_R4 ", 31, " GLL_R5 "\n\t"
+        "v_lshl_add_u64 %0, " GLL_P2 ", 0, " GLL_P4
+        : "=v"(r)
+        : "v"((uint32_t)hi), "v"((uint32_t)(hi >> 32)), "v"(lo)
+        : "vcc", GLL_R0, GLL_R2, GLL_R3, GLL_R4, GLL_R5, GLL_R8, GLL_R9);
+    return r;
+}
+
 // N independent products as one block of interleaved chains (tools/gen_gl_muln.py): for kernels where a lone wave per SIMD has nothing
 // else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v199, s80 .. s91.
 #if GLL_T == 140

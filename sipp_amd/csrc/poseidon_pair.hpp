@@ -218,6 +218,30 @@ __device__ __forceinline__ void dense_pair(const uint32_t lo[6], const uint32_t 
     for (int j = 0; j < 6; j++) out[j] = fold_chains((uint64_t)L[j], (uint64_t)H[j]);   // both chains in (0, 2^52)
 }
 
+// the partial rounds' chain is one dependent product after the other: the compiler's four multiply-adds (they overlap) with the
+// hand-scheduled reduction behind them
+__device__ __forceinline__ uint64_t mul_chain(uint64_t a, uint64_t b) {
+    uint64_t hi, lo;
+    gl::mul_wide(a, b, hi, lo);
+    return gll::reduce128_nc(hi, lo);
+}
+// gl::Acc6::reduce with that reduction
+__device__ __forceinline__ uint64_t acc6_reduce(const gl::Acc6& acc) {
+    uint32_t l[4], h[4], v[5];
+    gl::Acc6::fold3(l, acc.a[0], acc.a[1], acc.a[2]);
+    gl::Acc6::fold3(h, acc.a[3], acc.a[4], acc.a[5]);
+    uint32_t c = 0;
+    v[0] = l[0];
+    v[1] = __builtin_addc(l[1], h[0], c, &c);
+    v[2] = __builtin_addc(l[2], h[1], c, &c);
+    v[3] = __builtin_addc(l[3], h[2], c, &c);
+    v[4] = h[3] + c;
+    const uint64_t r = gll::reduce128_nc(((uint64_t)v[3] << 32) | v[2], ((uint64_t)v[1] << 32) | v[0]);
+    const uint64_t t = (uint64_t)v[4] << 32;  // 2^128 = -2^32 (mod p)
+    const uint64_t d = r - t;
+    return r < t ? d - gl::EPS : d;
+}
+
 // The 22 partial rounds, lazily in two blocks of 11 (the algebra: poseidon.hpp::partial_rounds_blocked).  s0: element 0, held by both
 // lanes.  A lane keeps the x_k of its parity (k = 2 m + h): they are its inputs of the V product and its share of the triangular sums.
 __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint32_t h, const uint32_t lane, const Tables& T, uint32_t z) {
@@ -242,11 +266,11 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint
         const uint32_t* __restrict__ CC = T.cc + (b * B) * 36 + 3 * h;
 #pragma unroll
         for (int k = 0; k < B; k++) {
-            const uint64_t x2 = gl::mul_nc(s0, s0);
-            const uint64_t y = gl::mul_nc(x2, h ? x2 : s0);
+            const uint64_t x2 = mul_chain(s0, s0);
+            const uint64_t y = mul_chain(x2, h ? x2 : s0);
             uint64_t y3, y4;
             both(y, y3, y4);
-            const uint64_t x = gl::add_nc(gl::mul_nc(y3, y4), T.tab[T_SCALAR + B * b + k]);
+            const uint64_t x = gl::add_nc(mul_chain(y3, y4), T.tab[T_SCALAR + B * b + k]);
             const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
             gl::Acc6 acc;
             acc.zero();
@@ -265,10 +289,10 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint
                 xl[k >> 1] = h ? xlo : xl[k >> 1];
                 xh[k >> 1] = h ? xhi : xh[k >> 1];
             }
-            const uint64_t part = gl::canon(acc.reduce());
+            const uint64_t part = gll::canon(acc6_reduce(acc));
             uint64_t pe, po;
             both(part, pe, po);
-            s0 = gl::add(pe, po);
+            s0 = gll::add_nc(pe, po);
         }
         // S_e + sum_k V[e][k] x_k (+ the constants of full round 26 behind the last block), the block-start state as the addend
         uint64_t o[6];
