@@ -505,10 +505,11 @@ class Instance:
         """hardened: G1 / G2 with the hardened AIRs (kinds 4 / 5 in the proofs' headers; sipp_ctx_set_hardened).
         single_ctx: True = one ctx / one arena, the three proofs back to back; False = three ctxs on three streams; None = three
         unless their arenas together exceed SINGLE_CTX_SHARE of the device's memory (and the devices are one device).
-        priorities=None: ("low", "", "high"), and ("low", "high", "high") for a hardened instance -- there G2 ahead of G1 measured
-        64.0 - 64.2 against 66.9 - 68.1 ms per n = 128 instance (the plain instance loses 1.5 ms with it: 59.4 - 60.5 against 57.9 - 58.7)"""
+        priorities=None: ("low", "", "high") for both AIR variants.  (Until the thin trees' hasher moved to the matrix pipe in round 4 a
+        hardened instance wanted G2 on a high-priority stream too: 64.0 - 64.2 against 66.9 - 68.1 ms.  With the shorter Fq12 chain the
+        settings are level -- scripts/sweep_prios.sh, two passes: single 56.4 - 57.5 for both, five queued 49.7 - 49.9 against 50.9 ms.)"""
         if priorities is None:
-            priorities = ("low", "high", "high") if hardened else ("low", "", "high")
+            priorities = ("low", "", "high")
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
         self.ctxs = []
@@ -571,7 +572,7 @@ class InstanceQueue:
     the list, `in_flight` at a time, and returns their proofs (copies)."""
 
     def __init__(self, num_io, in_flight=3, device=0, priorities=None, hardened=False):
-        """priorities=None: Instance's own default for the AIR variant (a hardened queue wants G2 ahead of G1)"""
+        """priorities=None: Instance's own default"""
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
         self.slots = []
