@@ -124,6 +124,23 @@ def test_leaves_and_cap_separately(ctx):
     assert (ctx.merkle_cap(tree, log_n + 1) == ref.cap).all()
 
 
+@pytest.mark.parametrize("log_leaves,ncols", [(5, 5), (5, 8), (6, 9), (7, 16), (9, 63), (12, 24), (14, 41), (16, 12)])
+def test_thin_tree_leaf_hasher_matches_the_oracle(ctx, log_leaves, ncols):
+    """the two-lanes-per-state leaf kernel (poseidon_pair.hpp: linear layers on the matrix pipe, lanes l / l + 32 share a leaf) on the
+    launches it serves -- 32 .. 2^16 leaves, more than four columns, whole and ragged last chunks -- against hash_n_to_hash_no_pad of the
+    oracle, leaf by leaf; the cells include 0, p - 1 and the values around 2^32 and 2^63"""
+    rng = np.random.default_rng(1000 * log_leaves + ncols)
+    n = 1 << log_leaves
+    cells = _oracle.rand_field(rng, (ncols, n))
+    edge = np.array([0, 1, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, (1 << 63) - 1, 1 << 63, 0xFFFFFFFF00000000], dtype=np.uint64)
+    cells[:, : len(edge)] = edge[None, :]
+    cells[0, :] = P - 1
+    dig = host(ctx.poseidon_leaves(dev(cells), log_leaves))
+    step = max(1, n // 257)
+    for j in list(range(0, 16)) + list(range(16, n, step)) + [n - 1]:
+        assert (dig[j] == _oracle.hash_no_pad(cells[:, j])).all(), (log_leaves, ncols, j)
+
+
 def test_hash_or_noop_narrow_leaves(ctx):
     rng = np.random.default_rng(6)
     for ncols in (1, 3, 4, 5, 8, 9):
