@@ -27,7 +27,7 @@ n = 1 << log_n
 for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
     print("  %-18s calls/iter %4d  %.3f ms/iter" % (k, v["calls"] // K, v["ms"] / K))
 perms = (2 * n) * ((ncols + 7) // 8)
-leaf = [k for k in ("poseidon_leaves", "poseidon_leaves_pair", "poseidon_leaves_quad") if k in rep][0]
+leaf = [k for k in ("poseidon_leaves", "poseidon_leaves_pair") if k in rep][0]
 print("leaf perms/s (%s): %.3f G" % (leaf, perms / (rep[leaf]["ms"] / K * 1e-3) / 1e9))
 ntt_bytes = 8 * n * ncols
 print("lde bytes (1 read + 2 write): %.1f MB" % (3 * ntt_bytes / 1e6))

@@ -6,6 +6,7 @@
 // Layout: the LDE is column-major [col][leaf] in LEAF order, so the 64 lanes of a wave read 64
 // consecutive u64 of one column per load (512 B, fully coalesced) and no transpose ever exists.
 // Digests are [node][4] u64 (32 B per lane, contiguous across the wave).
+#include <type_traits>
 #include "ctx.hpp"
 // ten VGPRs for the 64-bit temporaries of the hand-scheduled Goldilocks product (gl_lazy.hpp): v140 .. v149 keep the one-state-per-lane
 // leaf kernel at 150 VGPRs (152 without; its budget is 168 = three waves per SIMD)
@@ -13,7 +14,6 @@
 #define GLL_T 140
 #endif
 #include "poseidon.hpp"
-#include "poseidon_quad.hpp"
 #include "poseidon_pair.hpp"
 #include "prover.hpp"
 
@@ -71,59 +71,17 @@ __global__ void __launch_bounds__(256) poseidon_leaves_copy_kernel(const uint64_
     for (uint32_t q = 0; q < 4; q++) d[q] = q < ncols ? lde[j + (size_t)q * col_stride] : 0;
 }
 
-// ---- four lanes per state (poseidon_quad.hpp): thin launches ----
-__global__ void __launch_bounds__(256) poseidon_leaves_quad_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
-                                                                  uint32_t ncols, uint64_t n_leaves,
-                                                                  uint64_t* __restrict__ digests) {
-    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
-    poseidon_quad::load_tables(tab);
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t leaf = tid >> 2;
-    const uint32_t q = (uint32_t)tid & 3;
-    if (leaf >= n_leaves) return;  // n_leaves is a multiple of 16: whole quads / waves leave together
-    uint64_t s[3] = {0, 0, 0};
-    const uint64_t* p = lde + leaf;
-    for (uint32_t c = 0; c < ncols; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t e = 3 * q + j;
-            if (e < 8 && c + e < ncols) s[j] = p[(size_t)(c + e) * col_stride];
-        }
-        poseidon_quad::permute(s, q, tab);
-    }
-    uint64_t* d = digests + 4 * leaf;
-    if (q == 0) {
-        d[0] = s[0];
-        d[1] = s[1];
-        d[2] = s[2];
-    } else if (q == 1) {
-        d[3] = s[0];
-    }
-}
-
 // ---- two lanes per state (poseidon_pair.hpp): the thin trees; lanes l and l + 32 of a wave share leaf 32 wave + (l & 31) ----
-__device__ uint32_t d_pair_a[poseidon_pair::PA_WORDS];
-__device__ uint32_t d_pair_mds_a[256];
-__device__ uint32_t d_pair_cc[poseidon_pair::CC_WORDS];
-__device__ uint64_t d_pair_start[poseidon_pair::PS_WORDS];
-
 __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
                                                                   uint32_t ncols, uint64_t n_leaves,
                                                                   uint64_t* __restrict__ digests) {
-    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
-    __shared__ __attribute__((aligned(16))) uint32_t pa[poseidon_pair::PA_WORDS];
-    __shared__ uint32_t cc[poseidon_pair::CC_WORDS];
-    __shared__ uint64_t ps[poseidon_pair::PS_WORDS];
-    for (int i = threadIdx.x; i < poseidon_pair::PA_WORDS; i += blockDim.x) pa[i] = d_pair_a[i];
-    for (int i = threadIdx.x; i < poseidon_pair::CC_WORDS; i += blockDim.x) cc[i] = d_pair_cc[i];
-    for (int i = threadIdx.x; i < poseidon_pair::PS_WORDS; i += blockDim.x) ps[i] = d_pair_start[i];
-    poseidon_quad::load_tables(tab);            // ends with the barrier
-    const poseidon_pair::Tables T{tab, pa, cc, ps};
+    __shared__ poseidon_pair::Tables T;
+    poseidon_pair::load_tables(T);
     const uint32_t lane = threadIdx.x & 63, h = lane >> 5;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t leaf = wave * 32 + (lane & 31);
     if (leaf >= n_leaves) return;  // n_leaves is a multiple of 32: whole waves leave together (the matrix pipe needs every lane)
-    const poseidon::mfma_v4i afrag = *reinterpret_cast<const poseidon::mfma_v4i*>(d_pair_mds_a + 4 * lane);
+    const poseidon::mfma_v4i afrag = poseidon_pair::mds_fragment(lane);
     uint64_t s[6] = {0, 0, 0, 0, 0, 0};
     const uint64_t* p = lde + leaf;
 #pragma unroll 1
@@ -150,11 +108,17 @@ __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_
 // block after a barrier (__syncthreads orders the block's global writes).  A 2^17-leaf tree takes 2 launches instead of 13,
 // a 2^22-leaf tree 2 instead of 18; the wide levels run with all lanes busy, only the tip of a subtree (< 64 / < 16 parents)
 // leaves lanes idle.  tree: levels back to back, level l at digest offset sum_{i<l} (n_leaves >> i).
-template <bool QUAD>
+struct NoTables {};
+template <bool THIN>
 __global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uint32_t log_leaves,
                                                             uint32_t level0, uint32_t lw, uint32_t nlev) {
-    __shared__ uint64_t tab[QUAD ? poseidon_quad::T_WORDS : 1];
-    if (QUAD) poseidon_quad::load_tables(tab);
+    // THIN (levels of at most 2^16 parents): two lanes per node (poseidon_pair.hpp), 128 parents per trip of the block
+    __shared__ typename std::conditional<THIN, poseidon_pair::Tables, NoTables>::type T;
+    poseidon::mfma_v4i afrag = {0, 0, 0, 0};
+    if constexpr (THIN) {
+        poseidon_pair::load_tables(T);
+        afrag = poseidon_pair::mds_fragment(threadIdx.x & 63);
+    }
     uint64_t off = 0;
     for (uint32_t l = 0; l < level0; l++) off += (uint64_t)1 << (log_leaves - l);
     uint64_t n_level = (uint64_t)1 << (log_leaves - level0);       // nodes of the current level in the whole tree
@@ -164,31 +128,28 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uin
         const uint64_t* child = tree + 4 * (off + first);
         uint64_t* parent = tree + 4 * (off + n_level + (first >> 1));
         cnt >>= 1;
-        if (QUAD) {
-            const uint32_t q = threadIdx.x & 3;
-            for (uint32_t base = 0; base < cnt; base += 64) {
-                // whole waves run the permutation together (DPP needs complete quads); a wave past the end skips it
-                if (base + ((threadIdx.x & ~63u) >> 2) >= cnt) continue;
-                const uint32_t i = base + (threadIdx.x >> 2);
+        if constexpr (THIN) {
+            const uint32_t lane = threadIdx.x & 63, h = lane >> 5, w0 = (threadIdx.x >> 6) * 32;
+            for (uint32_t base = 0; base < cnt; base += 128) {
+                // whole waves run the permutation together (the matrix pipe reads every lane's registers); a wave past the end skips it
+                if (base + w0 >= cnt) continue;
+                const uint32_t i = base + w0 + (lane & 31);
                 const bool live = i < cnt;
-                uint64_t st[3] = {0, 0, 0};
+                uint64_t st[6] = {0, 0, 0, 0, 0, 0};
                 if (live) {
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        const uint32_t e = 3 * q + j;
+                    for (int j = 0; j < 6; j++) {
+                        const uint32_t e = 6 * h + j;
                         if (e < 8) st[j] = child[8 * (uint64_t)i + e];
                     }
                 }
-                poseidon_quad::permute(st, q, tab);
-                if (live) {
+                poseidon_pair::permute(st, lane, T, afrag);
+                if (live && h == 0) {
                     uint64_t* d = parent + 4 * (uint64_t)i;
-                    if (q == 0) {
-                        d[0] = st[0];
-                        d[1] = st[1];
-                        d[2] = st[2];
-                    } else if (q == 1) {
-                        d[3] = st[0];
-                    }
+                    d[0] = st[0];
+                    d[1] = st[1];
+                    d[2] = st[2];
+                    d[3] = st[3];
                 }
             }
         } else {
@@ -246,38 +207,38 @@ __global__ void __launch_bounds__(256) fri_leaves_kernel(const uint64_t* __restr
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
 }
 
-// the same with four lanes per leaf (poseidon_quad.hpp): FRI trees are small (2^13, 2^9, 2^5 leaves at n = 128) and sit
-// on the latency-bound tail of a proof, where a lone wave per SIMD takes 50 us per permutation and a quad 18 us
-__global__ void __launch_bounds__(256) fri_leaves_quad_kernel(const uint64_t* __restrict__ vals, uint64_t len,
+// the same with two lanes per leaf (poseidon_pair.hpp): FRI trees are small (2^13, 2^9, 2^5 leaves at n = 128) and sit on the
+// latency-bound tail of a proof, where a lone wave per SIMD takes 50 us per one-lane permutation and 23 us per two-lane one
+__global__ void __launch_bounds__(256) fri_leaves_pair_kernel(const uint64_t* __restrict__ vals, uint64_t len,
                                                              uint64_t* __restrict__ digests) {
-    __shared__ uint64_t tab[poseidon_quad::T_WORDS];
-    poseidon_quad::load_tables(tab);
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t k = tid >> 2;
-    const uint32_t q = (uint32_t)tid & 3;
-    const bool live = k < (len >> 4);   // every lane runs the permutation (DPP needs whole quads)
+    __shared__ poseidon_pair::Tables T;
+    poseidon_pair::load_tables(T);
+    const uint32_t lane = threadIdx.x & 63, h = lane >> 5;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nl = len >> 4;
+    if (wave * 32 >= nl) return;        // whole waves; inside the last one every lane runs the permutation (the matrix pipe reads them all)
+    const uint64_t k = wave * 32 + (lane & 31);
+    const bool live = k < nl;
     const uint64_t kk = live ? k : 0;
+    const poseidon::mfma_v4i afrag = poseidon_pair::mds_fragment(lane);
     const uint64_t* c0 = vals + 16 * kk;
     const uint64_t* c1 = vals + len + 16 * kk;
-    uint64_t s[3] = {0, 0, 0};
+    uint64_t s[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t e = 3 * q + j;
+        for (int j = 0; j < 6; j++) {
+            const uint32_t e = 6 * h + j;
             if (e < 8) s[j] = (e & 1) ? c1[4 * chunk + (e >> 1)] : c0[4 * chunk + (e >> 1)];
         }
-        poseidon_quad::permute(s, q, tab);
+        poseidon_pair::permute(s, lane, T, afrag);
     }
-    if (!live) return;
+    if (!live || h) return;
     uint64_t* d = digests + 4 * k;
-    if (q == 0) {
-        d[0] = s[0];
-        d[1] = s[1];
-        d[2] = s[2];
-    } else if (q == 1) {
-        d[3] = s[0];
-    }
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+    d[3] = s[3];
 }
 
 // any arity: leaf k = 2^ab extension values = 2^(ab + 1) words; <= 4 words are the digest themselves (hash_or_noop)
@@ -333,10 +294,10 @@ __global__ void __launch_bounds__(256) pow_kernel(PowArgs a) {
     if ((resp >> (64 - a.pow_bits)) == 0) atomicMin(a.result, (unsigned long long)w);
 }
 
-// thin launches (the Fq12 trees, the upper Merkle levels, FRI layers): up to this many states several lanes work on one state.
+// thin launches (the Fq12 trees, the upper Merkle levels, FRI layers): up to this many states two lanes work on one state.
 // Measured both ways (round 3): one state per lane for the Fq12 trees costs 74-75 against 58-59 ms per instance single and 60-61
 // against 51 ms queued -- the 1374 sequential permutations per leaf become the critical path.
-constexpr uint64_t quad_threshold() { return 65536; }
+constexpr uint64_t thin_threshold() { return 65536; }
 
 }  // namespace
 
@@ -347,8 +308,8 @@ int sipp_k_fri_leaves(sipp_ctx* ctx, const uint64_t* d_vals, size_t len, uint32_
         if (arity_bits < 1 || arity_bits > 4) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "fri_leaves: arity must be 2, 4, 8 or 16");
         hipLaunchKernelGGL(fri_leaves_any_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
                            arity_bits, d_digests);
-    } else if (nl <= quad_threshold())
-        hipLaunchKernelGGL(fri_leaves_quad_kernel, dim3((unsigned)((4 * nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals,
+    } else if (nl <= thin_threshold())
+        hipLaunchKernelGGL(fri_leaves_pair_kernel, dim3((unsigned)((2 * nl + 255) / 256)), dim3(256), 0, ctx->stream, d_vals,
                            (uint64_t)len, d_digests);
     else
         hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, d_vals, (uint64_t)len,
@@ -411,10 +372,10 @@ int sipp_poseidon_init_constants(sipp_ctx* ctx) {
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_comb_c), SIPP_POSEIDON_COMB_C, sizeof(SIPP_POSEIDON_COMB_C)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::d_dense_a), SIPP_POSEIDON_DENSE_A, sizeof(SIPP_POSEIDON_DENSE_A)));
     SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon::c_dense_start), SIPP_POSEIDON_DENSE_START, sizeof(SIPP_POSEIDON_DENSE_START)));
-    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_a), SIPP_POSEIDON_PAIR_A, sizeof(SIPP_POSEIDON_PAIR_A)));
-    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_mds_a), SIPP_POSEIDON_PAIR_MDS_A, sizeof(SIPP_POSEIDON_PAIR_MDS_A)));
-    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_cc), SIPP_POSEIDON_PAIR_CC3, sizeof(SIPP_POSEIDON_PAIR_CC3)));
-    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(d_pair_start), SIPP_POSEIDON_PAIR_START, sizeof(SIPP_POSEIDON_PAIR_START)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon_pair::d_pair_a), SIPP_POSEIDON_PAIR_A, sizeof(SIPP_POSEIDON_PAIR_A)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon_pair::d_pair_mds_a), SIPP_POSEIDON_PAIR_MDS_A, sizeof(SIPP_POSEIDON_PAIR_MDS_A)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon_pair::d_pair_cc), SIPP_POSEIDON_PAIR_CC3, sizeof(SIPP_POSEIDON_PAIR_CC3)));
+    SIPP_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(poseidon_pair::d_pair_start), SIPP_POSEIDON_PAIR_START, sizeof(SIPP_POSEIDON_PAIR_START)));
     return SIPP_OK;
 }
 
@@ -422,39 +383,24 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
                            uint64_t* d_digests) {
     if (ncols == 0 || ncols > 0xffffffffull) return sipp_fail(ctx, SIPP_E_BADARG, "poseidon_leaves: bad ncols");
     uint64_t n = (uint64_t)1 << log_leaves;
-    // one wave per block while the launch has fewer waves than SIMDs on the chip: a 256-lane block would
-    // park 4 waves on one CU and leave three quarters of the CUs idle
     // profile names: "poseidon_leaves" = one state per lane (the dominant kernel: every tree of > 2^16 leaves); the thin trees'
-    // two- / four-lane kernels and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own
-    // (trees of at most 2^12 leaves with hundreds of columns and more -- MapToG2 for n = 128: 2048 leaves x 2854 / 1512 columns -- are
-    // hashed alone on a near-empty GPU: there the four-lane kernel's shorter chain wins, 23 against 30 us per dependent permutation)
-#ifndef SIPP_THIN_LANES            // compile-time A/B switch (scripts/ab_obj.sh): lanes per state of the thin trees' leaf kernel
-#define SIPP_THIN_LANES 2
-#endif
-    const int thin_lanes_p = (n <= 4096 && ncols >= 512) ? 4 : SIPP_THIN_LANES;
-    const bool thin = ncols > 4 && n <= quad_threshold() && n >= (thin_lanes_p == 2 ? 32 : 16);
-    ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : !thin ? "poseidon_leaves" : thin_lanes_p == 2 ? "poseidon_leaves_pair" : "poseidon_leaves_quad");
-    // thin launches (<= 2^16 leaves: the Fq12 trees): lanes per state.  Two (poseidon_pair.hpp, the default since round 2) costs
-    // 33.1 k lane-instructions per permutation against 39.5 k for four and is SLOWER alone (2^13 x 4096 columns: 19.1 ms against
-    // 12.0 ms: 37 us per sequential permutation instead of 23 us) but FASTER where it matters, beside the other two proofs: the
-    // instance is bound by total instruction issue (68.5 ms against 70.5-70.8 ms single, 61.1 against 63.6-63.9 ms with three
-    // instances in flight).
-    const int thin_lanes = thin_lanes_p;
+    // two-lane kernel and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own.
+    // Thin launches (32 .. 2^16 leaves: the Fq12 trees, MapToG2's): two lanes per state (poseidon_pair.hpp) -- 9.4 k instructions per
+    // lane and permutation, 23 us per dependent permutation alone, 13.3 ms for 2^14 leaves x 4942 columns.  History: four lanes over DPP
+    // quads (round 1: 8.1 k per lane, also 23 us, twice the lanes) and two lanes over DPP pairs on the VALU alone (rounds 2 - 3: 12.9 k,
+    // 30 us) -- the instance is bound by total instruction issue, the lone Fq12 proof by the count per lane.
+    const bool thin = ncols > 4 && n <= thin_threshold() && n >= 32;
+    ProfScope ps(ctx, ncols <= 4 ? "poseidon_leaves_noop" : thin ? "poseidon_leaves_pair" : "poseidon_leaves");
     if (ncols <= 4) {
         hipLaunchKernelGGL(poseidon_leaves_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_lde, col_stride,
                            (uint32_t)ncols, n, d_digests);
-    } else if (thin_lanes == 2 && ncols > 4 && n >= 32 && n <= quad_threshold()) {
+    } else if (thin) {
         unsigned grid = (unsigned)((2 * n + 255) / 256);
         hipLaunchKernelGGL(poseidon_leaves_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
                            (uint32_t)ncols, n, d_digests);
-    } else if (ncols > 4 && n >= 16 && n <= quad_threshold()) {
-        // thin launch: four lanes per state -> 4x the waves
-        unsigned grid = (unsigned)((4 * n + 255) / 256);
-        hipLaunchKernelGGL(poseidon_leaves_quad_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_lde, col_stride,
-                           (uint32_t)ncols, n, d_digests);
     } else {
         // 256-lane blocks (one wave per SIMD of a CU) measured best: 64-lane blocks spread unevenly (1.10 vs 1.61 G perm/s
-        // at 2^17 leaves), 512 is slightly slower
+        // at 2^17 leaves), 512 is slightly slower; trees of fewer than 32 leaves: one wave
         const unsigned bs = n <= 65536 ? 64 : 256;
         // (cutting this launch into k launches over leaf ranges, so that its waves retire in batches and the other proofs' thin kernels
         // get placed in between, was measured in round 3: 58.8 -> 63.8 / 82.0 / 124.5 ms per instance for k = 2 / 4 / 8 -- a chunk has
@@ -481,7 +427,7 @@ int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, u
             const unsigned blocks = 1u << (log_nodes - lw);
             const uint64_t widest_parents = (uint64_t)1 << (log_nodes - 1);
             ProfScope ps(ctx, "merkle_subtree");
-            if (widest_parents <= quad_threshold())
+            if (widest_parents <= thin_threshold())
                 hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, d_tree, log_leaves, level, lw, nlev);
             else
                 hipLaunchKernelGGL(merkle_subtree_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, d_tree, log_leaves, level, lw, nlev);

@@ -51,19 +51,6 @@ __constant__ uint64_t c_dense_start[SIPP_POSEIDON_DENSE_MATS * 12 * 2];
 #define SIPP_PMUL gl::mul_nc
 #define SIPP_PRED96 gl::reduce96_nc
 #endif
-// the two- and four-lanes-per-state kernels (two waves per SIMD, latency-bound): the compiler's products interleave across the
-// state elements, the fixed-register blocks cannot -- measured slower there (pair kernel 35.5 against 32 ms per n = 128 instance)
-#ifdef SIPP_POSEIDON_THIN_ASM_MUL
-#define SIPP_PMUL_THIN SIPP_PMUL
-#else
-#define SIPP_PMUL_THIN gl::mul_nc
-#endif
-__device__ __forceinline__ uint64_t sbox_thin(uint64_t x) {
-    uint64_t x2 = SIPP_PMUL_THIN(x, x);
-    uint64_t x3 = SIPP_PMUL_THIN(x2, x);
-    uint64_t x4 = SIPP_PMUL_THIN(x2, x2);
-    return SIPP_PMUL_THIN(x3, x4);
-}
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
     uint64_t x2 = SIPP_PMUL(x, x);

@@ -1,8 +1,10 @@
 // sipp_amd/csrc/poseidon_pair.hpp -- Poseidon-Goldilocks with TWO lanes per state (32 states per wave), linear layers on the matrix pipe.
 //
-// Between one state per lane (a 2^14-leaf tree is only 256 waves, and a sponge over ~1000 permutations per leaf then takes 50 us per
-// permutation) and four lanes per state (poseidon_quad.hpp: 4x the waves, 39.6 k lane-instructions per permutation).  A lone wave per
-// SIMD issues one instruction per four cycles at best, so what such a thin launch pays for is the instruction count PER LANE.
+// For every THIN launch (the Fq12 trees, Merkle levels of at most 2^16 parents, FRI layer leaves): with one state per lane a 2^14-leaf tree
+// is only 256 waves and a sponge over ~1000 permutations per leaf takes 50 us per permutation.  A lone wave per SIMD issues one
+// instruction per four cycles at best, so what a thin launch pays for is the instruction count PER LANE.  (Rounds 1 - 3 also had four
+// lanes per state over DPP quads: 8.1 k instructions per lane, 23 us per dependent permutation -- what this layout reaches with half the
+// lanes, 9.4 k and 22.8 us; removed in round 4.)
 //
 // Layout (round 4): lanes l and l + 32 share state n = l & 31; lane (n, h) holds the six elements 6 h + j.  That is the operand layout
 // of v_mfma_i32_32x32x32_i8 -- B[k][n] comes from lane (n, k >> 4), D[i][n] goes to lane (n, (i >> 2) & 1) -- so ONE instruction sees the
@@ -20,22 +22,39 @@
 // (tests/test_gpu_generic.py).  Round 3's form (lanes 2 i / 2 i + 1, DPP, everything on the VALU): 12.9 k instructions per lane and
 // permutation; this one: see DESIGN.md section 4.
 #pragma once
-#include "poseidon_quad.hpp"
+#include "poseidon.hpp"
 
 namespace poseidon_pair {
 
-using namespace poseidon_quad;   // table layout T_*
 using poseidon::mfma_v16i;
 using poseidon::mfma_v4i;
 
-// LDS tables of the kernel (beside poseidon_quad's `tab`)
+// constant tables of the layout (generated: tools/gen_poseidon_header.py pair_tables; uploaded by sipp_poseidon_init_constants)
 constexpr int PA_WORDS = 5 * SIPP_POSEIDON_PAIR_FRAGS * 64 * 4, CC_WORDS = 792, PS_WORDS = 120;
+__device__ __attribute__((aligned(16))) uint32_t d_pair_a[PA_WORDS];       // dense A fragments [matrix][b / 2][lane][4]
+__device__ __attribute__((aligned(16))) uint32_t d_pair_mds_a[256];        // diag(MDS, MDS) [lane][4]
+__device__ uint32_t d_pair_cc[CC_WORDS];                                   // CC limbs [block][k][j 0..11][3]
+__device__ uint64_t d_pair_start[PS_WORDS];                                // dense chain starts [matrix][element][L, H]
+
+// their copy in LDS (per-lane indexed: not for scalar loads), 39 KB per block
 struct Tables {
-    const uint64_t* tab;      // poseidon_quad::load_tables
-    const uint32_t* pa;       // dense A fragments [matrix][b / 2][lane][4]
-    const uint32_t* cc;       // CC limbs [block][k][j 0..11][3]
-    const uint64_t* ps;       // dense chain starts [matrix][element][L, H]
+    uint64_t rc[360];         // round constants [round][element]
+    uint64_t scalar[22];      // lane-0 constants of the sparse partial rounds
+    uint64_t ps[PS_WORDS];
+    __attribute__((aligned(16))) uint32_t pa[PA_WORDS];
+    uint32_t cc[CC_WORDS];
 };
+// every thread of the block; ends with a barrier
+__device__ __forceinline__ void load_tables(Tables& T) {
+    for (int i = threadIdx.x; i < 360; i += blockDim.x) T.rc[i] = poseidon::c_rc[i];
+    for (int i = threadIdx.x; i < 22; i += blockDim.x) T.scalar[i] = poseidon::c_fast_scalar[i];
+    for (int i = threadIdx.x; i < PS_WORDS; i += blockDim.x) T.ps[i] = d_pair_start[i];
+    for (int i = threadIdx.x; i < PA_WORDS; i += blockDim.x) T.pa[i] = d_pair_a[i];
+    for (int i = threadIdx.x; i < CC_WORDS; i += blockDim.x) T.cc[i] = d_pair_cc[i];
+    __syncthreads();
+}
+// this lane's words of diag(MDS, MDS)
+__device__ __forceinline__ mfma_v4i mds_fragment(uint32_t lane) { return *reinterpret_cast<const mfma_v4i*>(d_pair_mds_a + 4 * lane); }
 
 // v (this lane's) -> the even lane's and the odd lane's value, in both lanes of the pair
 __device__ __forceinline__ void both32(uint32_t v, uint32_t& even, uint32_t& odd) {
@@ -270,7 +289,7 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[6], const uint
             const uint64_t y = mul_chain(x2, h ? x2 : s0);
             uint64_t y3, y4;
             both(y, y3, y4);
-            const uint64_t x = gl::add_nc(mul_chain(y3, y4), T.tab[T_SCALAR + B * b + k]);
+            const uint64_t x = gl::add_nc(mul_chain(y3, y4), T.scalar[B * b + k]);
             const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
             gl::Acc6 acc;
             acc.zero();
@@ -309,7 +328,7 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t lane, cons
     asm volatile("" : "+s"(z));
     const uint32_t h = lane >> 5, e0 = 6 * h;
     const uint64_t bias0 = (uint64_t)(128u * (256u + (h ? 0u : 8u))) * 0x01010101ull;
-    const uint64_t* __restrict__ rc = T.tab + T_RC + e0;
+    const uint64_t* __restrict__ rc = T.rc + e0;
 #pragma unroll
     for (int j = 0; j < 6; j++) s[j] = gl::add_nc(s[j], rc[j]);
 #pragma unroll 1
