@@ -28,34 +28,19 @@
 
 namespace {
 
-#ifndef SIPP_TREE_LAZY
-#define SIPP_TREE_LAZY 1
-#endif
 // forward butterfly (u, v) -> (u + s v, u - s v): u may be ANY u64 congruent to its value, the product is made canonical, the
 // sum and the difference take one conditional correction each and stay in [0, 2^64) (gl_lazy.hpp); what leaves the last sweep is
 // canonicalised at the store
 __device__ __forceinline__ void bfly_fwd(uint64_t& u, uint64_t& v, uint64_t s) {
-#if SIPP_TREE_LAZY
     const uint64_t w = gll::canon(gl::mul_nc(v, s)), a = u;
     u = gll::add_nc(a, w);
     v = gll::sub_nc(a, w);
-#else
-    const uint64_t w = gl::mul(v, s), a = u;
-    u = gl::add(a, w);
-    v = gl::sub(a, w);
-#endif
 }
 // inverse butterfly (a, b) -> (a + b, (a - b) / s) on canonical values
 __device__ __forceinline__ void bfly_inv(uint64_t& a, uint64_t& b, uint64_t sinv) {
-#if SIPP_TREE_LAZY
     const uint64_t u = a, v = b;
     a = gl::add(u, v);
     b = gll::canon(gl::mul_nc(gll::sub_nc(u, v), sinv));
-#else
-    const uint64_t u = a, v = b;
-    a = gl::add(u, v);
-    b = gl::mul(gl::sub(u, v), sinv);
-#endif
 }
 
 constexpr int LOG_SEG = 4;

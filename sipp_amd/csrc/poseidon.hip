@@ -36,9 +36,7 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
     const uint64_t* p = lde + j;
-#ifndef SIPP_POSEIDON_VALU_MDS
     __shared__ uint64_t stash[11 * 256];      // poseidon.hpp::partial_rounds_blocked: eleven state words per lane wait here
-#endif
     // one call site for the permutation (it is ~50 KB of code): the ragged last chunk only masks its loads
 #pragma unroll 1
     for (uint32_t c = 0; c < ncols; c += 8) {
@@ -46,11 +44,7 @@ poseidon_leaves_kernel(const uint64_t* __restrict__ lde, size_t col_stride,
 #pragma unroll
         for (int i = 0; i < 8; i++)
             if ((uint32_t)i < m) s[i] = p[(size_t)(c + i) * col_stride];
-#ifdef SIPP_POSEIDON_VALU_MDS
-        poseidon::permute<false>(s);
-#else
         poseidon::permute<true>(s, stash + threadIdx.x, blockDim.x);
-#endif
     }
     if (j0 >= n_leaves) return;
     uint64_t* d = digests + 4 * j;

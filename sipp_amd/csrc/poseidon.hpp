@@ -42,15 +42,12 @@ __constant__ uint64_t c_comb_c[12];
 __device__ uint32_t d_dense_a[SIPP_POSEIDON_DENSE_MATS * 8 * 64 * 4];
 __constant__ uint64_t c_dense_start[SIPP_POSEIDON_DENSE_MATS * 12 * 2];
 
-// S-box products: the hand-scheduled block of gl_lazy.hpp when the translation unit reserves its temporaries (GLL_T), the compiler's
-// sequence otherwise (-DSIPP_POSEIDON_C_MUL keeps the latter for A/B runs)
-#if defined(GLL_T) && !defined(SIPP_POSEIDON_C_MUL)
+// S-box products and 96-bit reductions: the hand-scheduled blocks of gl_lazy.hpp (the translation unit reserves their temporaries: GLL_T)
+#ifndef GLL_T
+#error "poseidon.hpp: define GLL_T (first of the ten VGPRs of gl_lazy.hpp's product block) before including it"
+#endif
 #define SIPP_PMUL gll::mul_nc
 #define SIPP_PRED96 gll::reduce96_nc
-#else
-#define SIPP_PMUL gl::mul_nc
-#define SIPP_PRED96 gl::reduce96_nc
-#endif
 __device__ __forceinline__ uint64_t sbox(uint64_t x) {
     // lazy reduction: every intermediate is any u64 congruent to the true value (canonicalised once at the end)
     uint64_t x2 = SIPP_PMUL(x, x);
@@ -397,7 +394,8 @@ __device__ __forceinline__ void partial_rounds_blocked(uint64_t s[12], uint32_t 
 
 // MFMA = the full-round linear layers on the matrix pipe (mds_full_mfma).  The matrix A of that product is spread over ALL 64 lanes
 // of the wave and MFMA ignores EXEC, so it may only be used where every lane of the wave is active and runs this function: the
-// leaf-hash kernel, whose launches are whole waves (-DSIPP_POSEIDON_VALU_MDS switches it off for A/B runs).
+// leaf-hash kernel, whose launches are whole waves; every other user (Merkle levels above 2^16 parents, the proof-of-work grind, single
+// permutations) runs the VALU form permute<false>.
 template <bool MFMA = false>
 __device__ __forceinline__ void permute(uint64_t s[12], uint64_t* __restrict__ stash = nullptr, uint32_t stash_stride = 0) {
     // an opaque zero added to every table index: the tables are wave-uniform and loop-invariant, and without this the
@@ -410,13 +408,8 @@ __device__ __forceinline__ void permute(uint64_t s[12], uint64_t* __restrict__ s
     const mfma_v4i afrag = MFMA ? mds_a_fragment() : mfma_v4i{0, 0, 0, 0};
 #pragma unroll 1
     for (int r = 0; r < 3; r++) full_round<MFMA>(s, r, z, afrag);
-#ifdef SIPP_POSEIDON_VALU_DENSE           // A/B switch: the dense constant products as lazy multiply-adds on the VALU (round 3's form)
-    full_round3_combined<false>(s, z);
-    partial_rounds_blocked<false>(s, z);
-#else
     full_round3_combined<MFMA>(s, z);
     partial_rounds_blocked<MFMA>(s, z, stash, stash_stride);
-#endif
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl::add_nc(s[i], c_rc[12 * 26 + i + z]);
 #pragma unroll 1

@@ -40,6 +40,9 @@ __device__ uint64_t d_pair_start[PS_WORDS];                                // de
 struct Tables {
     uint64_t rc[360];         // round constants [round][element]
     uint64_t scalar[22];      // lane-0 constants of the sparse partial rounds
+    // chain starts of the seven MDS layers [layer][element][low chain, high chain]: the halves of the NEXT round's constant (rounds 1, 2, 3,
+    // 27, 28, 29; none behind round 29) plus 128 rowsum(MDS) 0x01010101, the repayment of the byte planes' sign flip
+    uint64_t ms[7 * 12 * 2];
     uint64_t ps[PS_WORDS];
     __attribute__((aligned(16))) uint32_t pa[PA_WORDS];
     uint32_t cc[CC_WORDS];
@@ -48,6 +51,11 @@ struct Tables {
 __device__ __forceinline__ void load_tables(Tables& T) {
     for (int i = threadIdx.x; i < 360; i += blockDim.x) T.rc[i] = poseidon::c_rc[i];
     for (int i = threadIdx.x; i < 22; i += blockDim.x) T.scalar[i] = poseidon::c_fast_scalar[i];
+    for (int i = threadIdx.x; i < 7 * 12 * 2; i += blockDim.x) {
+        const int layer = i / 24, e = (i >> 1) % 12, half = i & 1;
+        const uint64_t c = layer < 6 ? poseidon::c_rc[12 * (layer < 3 ? layer + 1 : layer + 24) + e] : 0;     // rounds 1..3, 27..29
+        T.ms[i] = (uint64_t)(128u * (256u + (e ? 0u : 8u))) * 0x01010101ull + (half ? c >> 32 : (uint64_t)(uint32_t)c);
+    }
     for (int i = threadIdx.x; i < PS_WORDS; i += blockDim.x) T.ps[i] = d_pair_start[i];
     for (int i = threadIdx.x; i < PA_WORDS; i += blockDim.x) T.pa[i] = d_pair_a[i];
     for (int i = threadIdx.x; i < CC_WORDS; i += blockDim.x) T.cc[i] = d_pair_cc[i];
@@ -115,10 +123,9 @@ __device__ __forceinline__ mfma_v4i plane_pair(const uint32_t P[8][2], int a) {
 using poseidon::chain_start;   // d + start as one multiply-add
 using poseidon::fold_chains;   // (L, H) chains -> u64
 
-// out = MDS s (+ add): register j of the product with planes (a, a + 1) is M x plane a, register 6 + j is M x plane a + 1 (A = diag(M, M))
-// bias0: 128 rowsum(M) 0x01010101 of this lane's FIRST element (row 0 of the MDS carries the extra diagonal 8)
-template <bool ADD>
-__device__ __forceinline__ void mds_pair(uint64_t s[6], const uint64_t* __restrict__ add, uint64_t bias0, mfma_v4i afrag, uint32_t z) {
+// out = MDS s + the next round's constants: register j of the product with planes (a, a + 1) is M x plane a, register 6 + j is
+// M x plane a + 1 (A = diag(M, M)).  K: this lane's six pairs of chain starts (Tables::ms)
+__device__ __forceinline__ void mds_pair(uint64_t s[6], const uint64_t* __restrict__ K, mfma_v4i afrag, uint32_t z) {
     uint32_t lo[6], hi[6], P[8][2];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -142,9 +149,7 @@ __device__ __forceinline__ void mds_pair(uint64_t s[6], const uint64_t* __restri
         for (int j = 0; j < 6; j++) {
             int64_t& acc = q < 2 ? al[j] : ah[j];
             if ((q & 1) == 0) {
-                const uint64_t bias = j == 0 ? bias0 : (uint64_t)(128u * 256u) * 0x01010101ull;
-                const uint64_t c = ADD ? (q < 2 ? (uint64_t)(uint32_t)add[j] : (add[j] >> 32)) : 0;
-                acc = chain_start(d[q][j], bias + c, p1);
+                acc = chain_start(d[q][j], K[2 * j + (q >> 1)], p1);
                 acc = (int64_t)d[q][6 + j] * (int64_t)p8 + acc;
             } else {
                 acc = (int64_t)d[q][j] * (int64_t)p16 + acc;
@@ -327,14 +332,14 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t lane, cons
     uint32_t z = 0;
     asm volatile("" : "+s"(z));
     const uint32_t h = lane >> 5, e0 = 6 * h;
-    const uint64_t bias0 = (uint64_t)(128u * (256u + (h ? 0u : 8u))) * 0x01010101ull;
     const uint64_t* __restrict__ rc = T.rc + e0;
+    const uint64_t* __restrict__ ms = T.ms + 2 * e0;
 #pragma unroll
     for (int j = 0; j < 6; j++) s[j] = gl::add_nc(s[j], rc[j]);
 #pragma unroll 1
     for (int r = 0; r < 3; r++) {
         sbox6(s);
-        mds_pair<true>(s, rc + 12 * (r + 1), bias0, afrag, z);
+        mds_pair(s, ms + 24 * r, afrag, z);
     }
     {   // full round 3: its MDS, the first constants of the sparse form and the dense pre-multiplication are ONE affine map
         sbox6(s);
@@ -349,12 +354,10 @@ __device__ __forceinline__ void permute(uint64_t s[6], const uint32_t lane, cons
     partial_rounds_blocked(s, h, lane, T, z);
     s[0] = h ? s[0] : gl::add_nc(s[0], rc[12 * 26]);      // element 0 left the blocks without round 26's constant
 #pragma unroll 1
-    for (int r = 26; r < 29; r++) {
+    for (int r = 26; r < 30; r++) {
         sbox6(s);
-        mds_pair<true>(s, rc + 12 * (r + 1), bias0, afrag, z);
+        mds_pair(s, ms + 24 * (r - 23), afrag, z);      // layers 3 .. 6
     }
-    sbox6(s);
-    mds_pair<false>(s, nullptr, bias0, afrag, z);
 #pragma unroll
     for (int j = 0; j < 6; j++) s[j] = gl::canon(s[j]);
 }
