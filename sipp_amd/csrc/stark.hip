@@ -931,6 +931,8 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
     const int first = SIPP_G2_EXP;
     // round 2 (fused LDE kernels): only G1 waits -- 69.0-69.6 ms per n = 128 instance against 70.0-70.6 with Fq12 gated too
     // (re-swept in round 3 on the new kernels: no gate 60.6-61.4, Fq12 gated too 69.2-69.5 against 58.2-58.9 ms)
+    // (round 4, after the thin trees' hasher moved to the matrix pipe, scripts/ab_prebuilt.sh, three alternating passes: no gate
+    // 57.9-58.9 against 56.4-56.6 ms single, the queue of five 49.3-49.6 either way)
     constexpr int gate_mask = 1 << SIPP_G1_EXP;
     const int order[3] = {SIPP_G2_EXP, SIPP_FQ12_EXP, SIPP_G1_EXP};  // the largest proof first
     sipp_gate gate;
