@@ -75,6 +75,10 @@ __global__ void __launch_bounds__(256) poseidon_leaves_pair_kernel(const uint64_
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t leaf = wave * 32 + (lane & 31);
     if (leaf >= n_leaves) return;  // n_leaves is a multiple of 32: whole waves leave together (the matrix pipe needs every lane)
+    // the thin trees' waves ahead of the fat kernels' waves they share a SIMD with (issue arbitration: priority, then age): the Fq12 proof
+    // is the last of an instance to end.  scripts/ab_prebuilt.sh, three alternating passes: 55.1 - 55.6 against 56.0 - 56.4 ms single
+    // (s_setprio 3: 55.6 - 56.4), five queued 49.0 either way.  (Round 3 saw no effect: its two-lane kernel was 40 % longer.)
+    __builtin_amdgcn_s_setprio(1);
     const poseidon::mfma_v4i afrag = poseidon_pair::mds_fragment(lane);
     uint64_t s[6] = {0, 0, 0, 0, 0, 0};
     const uint64_t* p = lde + leaf;

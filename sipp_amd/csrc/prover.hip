@@ -162,6 +162,10 @@ struct QuotArgs {
     // products of a gadget (group 2): limbs of gamma_c^i, i < 8, gamma_c = 1 / alpha_c; gamma_c; alpha_c^16 (see quotient_prog_kernel)
     uint32_t ginv3[2][8][3];
     uint64_t gamma_inv[2], alpha16[2];
+    // quotient_rest over a THIN domain (the Fq12 STARK: 2^14 points are 64 blocks, each walking ~1500 checked columns): the columns are cut
+    // into `chunks` ranges (blockIdx.y), every range leaves its three sums per challenge in rest_part [chunk][6][m], quotient_finish adds up
+    int chunks;
+    uint64_t* rest_part;
 };
 
 struct QCtx {
@@ -452,6 +456,39 @@ struct RestAcc {
     __device__ __forceinline__ uint64_t value(int c) const { return gl::add(folded[c], gl::canon(a[c].reduce())); }
 };
 
+// the point's multipliers: lagrange_first, z_last, lagrange_last, 1 / Z_H
+struct RestPoint {
+    uint64_t lf, zl, ll, zh_inv;
+};
+__device__ __forceinline__ RestPoint rest_point(const QuotArgs& a, uint32_t i) {
+    const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_m, i));
+    const uint64_t zh = a.zh[i & 1];
+    RestPoint r;
+    r.zl = gl::sub(x, a.g_inv);
+    r.lf = gl::mul(gl::mul(zh, a.ninv), gl::inv(gl::sub(x, 1)));
+    r.ll = gl::mul(gl::mul(gl::mul(zh, a.ninv), a.g_inv), gl::inv(r.zl));
+    r.zh_inv = a.zh_inv[i & 1];
+    return r;
+}
+// program partials + the three weighted sums -> the quotient's value at the point
+__device__ __forceinline__ void rest_store(const QuotArgs& a, size_t m, size_t j, const RestPoint& pt, const uint64_t F[2], const uint64_t T[2],
+                                           const uint64_t R[2]) {
+    uint64_t acc[2] = {0, 0};
+    for (int g = 0; g < a.n_seg; g++) {
+        acc[0] = gl::add(acc[0], a.part[((size_t)g * 2 + 0) * m + j]);
+        acc[1] = gl::add(acc[1], a.part[((size_t)g * 2 + 1) * m + j]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint64_t v = gl::mul(acc[q], a.alphaK[q]);
+        v = gl::add(v, R[q]);
+        v = gl::mad(pt.lf, F[q], v);
+        v = gl::mad(pt.zl, T[q], v);
+        a.out[(size_t)q * m + j] = gl::mul(v, pt.zh_inv);
+    }
+}
+
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const size_t m = (size_t)1 << a.log_m;
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -465,23 +502,17 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
-    for (int g = 0; g < a.n_seg; g++) {
-        c.acc0 = gl::add(c.acc0, a.part[((size_t)g * 2 + 0) * m + j]);
-        c.acc1 = gl::add(c.acc1, a.part[((size_t)g * 2 + 1) * m + j]);
-    }
-    const uint64_t x = gl::mul(gl::GEN, gl::pow(a.w_m, i));
-    const uint64_t zh = a.zh[i & 1];
-    const uint64_t zl = gl::sub(x, a.g_inv);
-    const uint64_t lf = gl::mul(gl::mul(zh, a.ninv), gl::inv(gl::sub(x, 1)));
-    const uint64_t ll = gl::mul(gl::mul(gl::mul(zh, a.ninv), a.g_inv), gl::inv(zl));
     const uint32_t* __restrict__ ap = a.apow3;
     RestAcc F, T, R;  // x lagrange_first, x z_last, plain
     F.init();
     T.init();
     R.init();
-    // range table
-    const uint64_t tl = c.local(0), tn = c.next(0);
-    {
+    // range table (the first chunk's)
+    const uint64_t tl = c.local(0);
+    RestPoint pt{};
+    if (!SPLIT || blockIdx.y == 0) {
+        pt = rest_point(a, i);
+        const uint64_t tn = c.next(0), ll = pt.ll;
         const uint64_t d = gl::sub(tn, tl);
         F.mac(tl, ap, ap + 9);
         T.mac(gl::mul(d, gl::sub(d, 1)), ap + 3, ap + 12);
@@ -495,7 +526,10 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const uint64_t b0 = a.beta[0], b1 = a.beta[1];
     const uint64_t tg0 = gl::add(tl, b0), tg1 = gl::add(tl, b1);
     constexpr int U = 2;
-    for (int k0 = 0; k0 < nc; k0 += U) {
+    // this block's range of checked columns: all of them, or the blockIdx.y-th of a.chunks ranges (multiples of U)
+    const int per = SPLIT ? ((nc + a.chunks - 1) / a.chunks + U - 1) / U * U : nc;
+    const int kbeg = SPLIT ? (int)blockIdx.y * per : 0, kend = SPLIT ? min(nc, kbeg + per) : nc;
+    for (int k0 = kbeg; k0 < kend; k0 += U) {
         uint64_t pin[U], ptab[U], npin[U], nptab[U], col[U], z0[U], zn0[U], z1[U], zn1[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -513,7 +547,7 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int k = k0 + u;
-            if (k < nc) {
+            if (k < kend) {
                 const uint32_t* __restrict__ w0 = ap + 18 + 36 * k;  // [c][slot][3]
                 const uint32_t* __restrict__ w1 = w0 + 18;
                 F.mac(gl::sub(pin[u], ptab[u]), w0, w1);
@@ -531,15 +565,26 @@ __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
         T.maybe_fold(U);
         R.maybe_fold(2 * U);
     }
-    uint64_t acc[2] = {c.acc0, c.acc1};
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        uint64_t v = gl::mul(acc[q], a.alphaK[q]);
-        v = gl::add(v, R.value(q));
-        v = gl::mad(lf, F.value(q), v);
-        v = gl::mad(zl, T.value(q), v);
-        a.out[(size_t)q * m + j] = gl::mul(v, a.zh_inv[i & 1]);
+    const uint64_t f[2] = {F.value(0), F.value(1)}, t[2] = {T.value(0), T.value(1)}, r[2] = {R.value(0), R.value(1)};
+    if (SPLIT) {
+        uint64_t* __restrict__ o = a.rest_part + (size_t)blockIdx.y * 6 * m + j;
+        o[0] = f[0]; o[m] = f[1]; o[2 * m] = t[0]; o[3 * m] = t[1]; o[4 * m] = r[0]; o[5 * m] = r[1];
+        return;
     }
+    rest_store(a, m, j, pt, f, t, r);
+}
+
+// the thin form's second step: the chunks' sums added up (canonical field elements: the order does not matter)
+__global__ void __launch_bounds__(256) quotient_finish_kernel(QuotArgs a) {
+    const size_t m = (size_t)1 << a.log_m;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);
+    uint64_t v[6] = {0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < a.chunks; ch++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) v[q] = gl::add(v[q], a.rest_part[((size_t)ch * 6 + q) * m + j]);
+    const uint64_t f[2] = {v[0], v[1]}, t[2] = {v[2], v[3]}, r[2] = {v[4], v[5]};
+    rest_store(a, m, j, rest_point(a, i), f, t, r);
 }
 
 // =====================================================================================================
@@ -1148,7 +1193,17 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
     }
     {
         ProfScope ps(ctx, "quotient_rest");
-        hipLaunchKernelGGL(quotient_rest_kernel, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
+        // a thin domain (<= 2^15 points = 128 blocks) with many checked columns: the columns in up to 16 ranges of at least 32, two kernels
+        q.chunks = log_m <= 15 ? std::min(16, a->n_checked / 32) : 1;
+        if (q.chunks > 1) {
+            q.rest_part = arena_alloc_t<uint64_t>(ctx, (size_t)q.chunks * 6 * m);
+            if (!q.rest_part) return SIPP_E_NOMEM;
+            hipLaunchKernelGGL(quotient_rest_kernel<true>, dim3((unsigned)(m / 256), (unsigned)q.chunks), dim3(256), 0, ctx->stream, q);
+            hipLaunchKernelGGL(quotient_finish_kernel, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
+        } else {
+            q.chunks = 1;
+            hipLaunchKernelGGL(quotient_rest_kernel<false>, dim3((unsigned)(m / 256)), dim3(256), 0, ctx->stream, q);
+        }
     }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;

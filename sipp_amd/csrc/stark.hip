@@ -587,6 +587,7 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
                    + 3 * 8 * m                                          // three Merkle trees
                    + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
+                   + (m <= ((size_t)1 << 15) ? 96 * m : 0)                     // thin quotient domains: 16 column ranges x 6 sums (prover.hip)
                    + 80 * n;                                            // power tables, FRI layers, combine partials
     size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
                    + n * 400                                            // Jacobian row scratch of the curve chains
