@@ -160,7 +160,7 @@ __device__ __forceinline__ uint64_t reduce128_nc(uint64_t hi, uint64_t lo) {
 }
 
 // N independent products as one block of interleaved chains (tools/gen_gl_muln.py): for kernels where a lone wave per SIMD has nothing
-// else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v199, s80 .. s91.
+// else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v169, s80 .. s85.
 #if GLL_T == 140
 #include "gl_lazy_muln.inc"
 #endif
