@@ -966,15 +966,18 @@ __global__ void hist_kernel(const uint64_t* __restrict__ cols, size_t n, uint32_
     }
 }
 
-// u16 table: the 65,536 bins do not fit LDS as u32, so one block counts ONE HALF of the value range (32,768 bins,
-// 128 KiB) of one (column, chunk of rows); wave-uniform values (constant cells such as high carry limbs) take a
-// single LDS atomic per wave instead of 64 serialised ones.
+// u16 table: the 65,536 bins do not fit LDS as u32, so one block counts ONE QUARTER of the value range (16,384 bins, 64 KiB) of one
+// (column, chunk of rows); wave-uniform values (constant cells such as high carry limbs) take a single LDS atomic per wave instead of
+// 64 serialised ones.  (Halves -- 128 KiB per block -- until round 4: such a block finds no CU while another proof's leaf-hash launch is
+// resident, 22.5 KB of LDS per block and two or three blocks per CU: G1's histogram waited 12.7 ms for 0.3 ms of work behind G2's leaf
+// hashing, 382 ms at n = 4096.  A quarter fits beside them; the column is read four times instead of twice: 0.5 MB each.)
+constexpr uint32_t HIST16_BINS = 16384, HIST16_PARTS = 65536 / HIST16_BINS, HIST16_SHIFT = 14;
 __global__ void __launch_bounds__(1024) hist_u16_kernel(const uint64_t* __restrict__ cols, size_t n, uint32_t* __restrict__ hist) {
     extern __shared__ uint32_t hs[];
-    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) hs[i] = 0;
+    for (uint32_t i = threadIdx.x; i < HIST16_BINS; i += 1024) hs[i] = 0;
     __syncthreads();
     const size_t c = blockIdx.z;
-    const uint32_t half = blockIdx.y;
+    const uint32_t part = blockIdx.y;
     const uint64_t* col = cols + c * n;
     const size_t chunk = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
     for (size_t i0 = lo; i0 < hi; i0 += 1024) {
@@ -983,14 +986,14 @@ __global__ void __launch_bounds__(1024) hist_u16_kernel(const uint64_t* __restri
         const uint32_t v = live ? (uint32_t)col[i] & 0xffffu : 0xffffffffu;
         const uint32_t v0 = __builtin_amdgcn_readfirstlane(v);
         if (__all(v == v0)) {
-            if (v0 != 0xffffffffu && (v0 >> 15) == half && (threadIdx.x & 63) == 0) atomicAdd(&hs[v0 & 32767], 64u);
-        } else if (live && (v >> 15) == half) {
-            atomicAdd(&hs[v & 32767], 1u);
+            if (v0 != 0xffffffffu && (v0 >> HIST16_SHIFT) == part && (threadIdx.x & 63) == 0) atomicAdd(&hs[v0 & (HIST16_BINS - 1)], 64u);
+        } else if (live && (v >> HIST16_SHIFT) == part) {
+            atomicAdd(&hs[v & (HIST16_BINS - 1)], 1u);
         }
     }
     __syncthreads();
-    uint32_t* out = hist + (c << 16) + ((size_t)half << 15);
-    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+    uint32_t* out = hist + (c << 16) + ((size_t)part << HIST16_SHIFT);
+    for (uint32_t i = threadIdx.x; i < HIST16_BINS; i += 1024) {
         const uint32_t x = hs[i];
         if (x) {
             if (gridDim.x == 1) out[i] = x;     // this block owns the bins (hist is zero-initialised)
@@ -1400,8 +1403,8 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
                 hipLaunchKernelGGL(hist_u8_kernel, dim3(chunks, (unsigned)nc), dim3(256), 0, ctx->stream, cols, n, hist);
             } else if (tb == 16) {
                 const unsigned chunks = (unsigned)std::max<size_t>(1, std::min<size_t>(8, n >> 17));
-                SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)hist_u16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-                hipLaunchKernelGGL(hist_u16_kernel, dim3(chunks, 2, (unsigned)nc), dim3(1024), 131072, ctx->stream, cols, n, hist);
+                hipLaunchKernelGGL(hist_u16_kernel, dim3(chunks, HIST16_PARTS, (unsigned)nc), dim3(1024), HIST16_BINS * sizeof(uint32_t), ctx->stream,
+                                   cols, n, hist);
             } else {
                 hipLaunchKernelGGL(hist_kernel, dim3(4096), dim3(256), 0, ctx->stream, cols, n, (uint32_t)nc, tb, hist);
             }
