@@ -59,16 +59,18 @@ __device__ __forceinline__ uint64_t sub_nc(uint64_t u, uint64_t w) {
 
 #ifdef GLL_T
 // ---- the product as ONE hand-scheduled block ------------------------------------------------------------------------------
-// The compiler's code for the sequences above carries ~31 instructions per product (it rebuilds every zero-extended 64-bit addend
-// of v_mad_u64_u32 with moves, splits 64-bit additions, and selects through SGPR pairs); the block below has 18.  Inline asm
-// cannot name the halves of a 64-bit operand, so the 64-bit temporaries are FIXED physical registers listed as clobbers
-// (GLL_T = first of ten consecutive VGPRs, even, defined by the translation unit BEFORE this header: poseidon.hip reserves v140 .. v149): v[T:T+1] .. v[T+6:T+7] are the four partial products, v[T+8:T+9] is the
-// zero-extended addend (its high half is zeroed in every block: the compiler may use the registers between two blocks).
-//   t0 = a0 b0;  t1 = a0 b1 + hi(t0);  t2 = a1 b0 + lo(t1);  hi = a1 b1 + hi(t1) + hi(t2);  lo = (lo(t0), lo(t2))
-//   T  = lo(hi) (2^32 - 1) + lo        carry c      (one multiply-add: 2^64 = 2^32 - 1 mod p)
-//   T += c (2^32 - 1)                  cannot wrap: T < (2^32 - 1)^2 after a carry
-//   T -= hi(hi)                        borrow b     (2^96 = -1 mod p; no borrow after a carry: T >= 2^32 - 1 >= hi(hi) then)
-//   T += b p                           = T - (2^32 - 1) mod 2^64, cannot wrap
+// The compiler's code for the sequences above carries 23 - 31 instructions per product (it rebuilds every zero-extended 64-bit addend
+// of v_mad_u64_u32 with moves, splits 64-bit additions, and selects through SGPR pairs); the block below has 16 (19 until round 4's last
+// day).  Inline asm cannot name the halves of a 64-bit operand, so the 64-bit temporaries are FIXED physical registers listed as
+// clobbers (GLL_T = first of ten consecutive VGPRs, even, defined by the translation unit BEFORE this header: poseidon.hip reserves
+// v140 .. v149): v[T:T+1] .. v[T+6:T+7] are the partial products, v[T+8:T+9] a zero-extended addend; one SGPR pair (s94:95) carries cA.
+//   t0 = a0 b0;  m = a0 b1 + a1 b0 mod 2^64 with carry cA (the second cross product takes the first as its 64-bit addend: no
+//   zero-extended temporaries);  lo = t0 + 2^32 lo(m) with the carry into X = hi(m) + carry and its carry X':  hi = a1 b1 + (X, X')
+//   -- the product is lo + 2^64 hi + 2^96 cA, hi < 2^64 - 2^32 cA.  Then, with 2^64 = 2^32 - 1 and 2^96 = -1 (mod p):
+//   T  = lo(hi) (2^32 - 1) + lo        carry c      (one multiply-add)
+//   T += c (2^32 - 1)                  cannot wrap: T <= 2^64 - 2^33 after a carry
+//   T -= hi(hi) + cA                   borrow b     (cA rides as the borrow-in of the subtraction; hi(hi) + cA < 2^32)
+//   T += b p                           = T - (2^32 - 1) mod 2^64, cannot wrap the other way
 // Measured: 1.41 -> 1.65 T products/s alone (scripts/ubench/mulmod4.hip); the one-state-per-lane leaf hash 1.65 -> 1.85 G permutations/s
 // at 2^17 leaves and 2.01 -> 2.21 G at 2^21 (its S-boxes are 472 of these per permutation); nothing in the transform kernels.
 }  // namespace gll
@@ -90,6 +92,9 @@ __device__ __forceinline__ uint64_t sub_nc(uint64_t u, uint64_t w) {
 #define GLL_P4 "v[144:145]"
 #define GLL_P6 "v[146:147]"
 #define GLL_P8 "v[148:149]"
+#define GLL_SA "s[94:95]"
+#define GLL_SA0 "s94"
+#define GLL_SA1 "s95"
 #elif defined(GLL_REGS_INC)
 #include GLL_REGS_INC
 #else
@@ -99,28 +104,25 @@ namespace gll {
 
 __device__ __forceinline__ uint64_t mul_nc(uint64_t a, uint64_t b) {
     uint64_t r;
-    asm("v_mov_b32_e32 " GLL_R9 ", 0\n\t"
-        "v_mad_u64_u32 " GLL_P0 ", vcc, %1, %3, 0\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R1 "\n\t"
-        "v_mad_u64_u32 " GLL_P2 ", vcc, %1, %4, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R2 "\n\t"
-        "v_mad_u64_u32 " GLL_P4 ", vcc, %2, %3, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R3 "\n\t"
-        "v_mad_u64_u32 " GLL_P6 ", vcc, %2, %4, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R8 ", " GLL_R5 "\n\t"
-        "v_lshl_add_u64 " GLL_P6 ", " GLL_P6 ", 0, " GLL_P8 "\n\t"
-        "v_mov_b32_e32 " GLL_R1 ", " GLL_R4 "\n\t"
-        "v_mad_u64_u32 " GLL_P2 ", vcc, " GLL_R6 ", -1, " GLL_P0 "\n\t"
+    asm("v_mad_u64_u32 " GLL_P0 ", vcc, %1, %3, 0\n\t"                           /* t0 = a0 b0 */
+        "v_mad_u64_u32 " GLL_P2 ", vcc, %1, %4, 0\n\t"                           /* a0 b1 */
+        "v_mad_u64_u32 " GLL_P4 ", " GLL_SA ", %2, %3, " GLL_P2 "\n\t"            /* m = a0 b1 + a1 b0 mod 2^64, carry cA (worth 2^96 = -1) */
+        "v_add_co_u32_e32 " GLL_R1 ", vcc, " GLL_R1 ", " GLL_R4 "\n\t"            /* lo = (lo(t0), hi(t0) + lo(m)) */
+        "v_addc_co_u32_e32 " GLL_R6 ", vcc, 0, " GLL_R5 ", vcc\n\t"               /* hi(m) + carry */
+        "v_addc_co_u32_e64 " GLL_R7 ", vcc, 0, 0, vcc\n\t"                        /* ... and its carry: the pair is the addend of the last product */
+        "v_mad_u64_u32 " GLL_P6 ", vcc, %2, %4, " GLL_P6 "\n\t"                   /* hi = a1 b1 + that */
+        "v_mad_u64_u32 " GLL_P2 ", vcc, " GLL_R6 ", -1, " GLL_P0 "\n\t"            /* T = lo(hi) (2^32 - 1) + lo, carry c */
         "v_subb_co_u32_e32 " GLL_R8 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"     /* -c (carry-in reads of VCC need no wait states) */
-        "v_lshl_add_u64 " GLL_P2 ", " GLL_P2 ", 0, " GLL_P8 "\n\t"
-        "v_sub_co_u32_e32 " GLL_R2 ", vcc, " GLL_R2 ", " GLL_R7 "\n\t"
+        "v_mov_b32_e32 " GLL_R9 ", 0\n\t"
+        "v_lshl_add_u64 " GLL_P2 ", " GLL_P2 ", 0, " GLL_P8 "\n\t"                /* T += c (2^32 - 1) */
+        "v_subb_co_u32_e64 " GLL_R2 ", vcc, " GLL_R2 ", " GLL_R7 ", " GLL_SA "\n\t" /* T -= hi(hi) + cA, borrow b */
         "v_subbrev_co_u32_e32 " GLL_R3 ", vcc, 0, " GLL_R3 ", vcc\n\t"
         "v_subb_co_u32_e32 " GLL_R5 ", vcc, " GLL_R0 ", " GLL_R0 ", vcc\n\t"     /* -b */
         "v_lshrrev_b32_e32 " GLL_R4 ", 31, " GLL_R5 "\n\t"
-        "v_lshl_add_u64 %0, " GLL_P2 ", 0, " GLL_P4
+        "v_lshl_add_u64 %0, " GLL_P2 ", 0, " GLL_P4                                /* T += b p */
         : "=v"(r)
         : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32))
-        : "vcc", GLL_R0, GLL_R1, GLL_R2, GLL_R3, GLL_R4, GLL_R5, GLL_R6, GLL_R7, GLL_R8, GLL_R9);
+        : "vcc", GLL_SA0, GLL_SA1, GLL_R0, GLL_R1, GLL_R2, GLL_R3, GLL_R4, GLL_R5, GLL_R6, GLL_R7, GLL_R8, GLL_R9);
     return r;
 }
 
@@ -160,7 +162,7 @@ __device__ __forceinline__ uint64_t reduce128_nc(uint64_t hi, uint64_t lo) {
 }
 
 // N independent products as one block of interleaved chains (tools/gen_gl_muln.py): for kernels where a lone wave per SIMD has nothing
-// else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v169, s80 .. s85.
+// else to issue between two dependent instructions of a chain (the two-lanes-per-state hash kernel).  Windows v140 .. v169, s80 .. s91.
 #if GLL_T == 140
 #include "gl_lazy_muln.inc"
 #endif
