@@ -383,7 +383,7 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
     uint64_t n = (uint64_t)1 << log_leaves;
     // profile names: "poseidon_leaves" = one state per lane (the dominant kernel: every tree of > 2^16 leaves); the thin trees'
     // two-lane kernel and the unhashed <= 4-column leaves (hash_or_noop: a copy) have names of their own.
-    // Thin launches (32 .. 2^16 leaves: the Fq12 trees, MapToG2's): two lanes per state (poseidon_pair.hpp) -- 9.4 k instructions per
+    // Thin launches (32 .. 2^16 leaves: the Fq12 trees, MapToG2's): two lanes per state (poseidon_pair.hpp) -- 8.7 k instructions per
     // lane and permutation, 23 us per dependent permutation alone, 13.3 ms for 2^14 leaves x 4942 columns.  History: four lanes over DPP
     // quads (round 1: 8.1 k per lane, also 23 us, twice the lanes) and two lanes over DPP pairs on the VALU alone (rounds 2 - 3: 12.9 k,
     // 30 us) -- the instance is bound by total instruction issue, the lone Fq12 proof by the count per lane.

@@ -4,7 +4,7 @@
 // is only 256 waves and a sponge over ~1000 permutations per leaf takes 50 us per permutation.  A lone wave per SIMD issues one
 // instruction per four cycles at best, so what a thin launch pays for is the instruction count PER LANE.  (Rounds 1 - 3 also had four
 // lanes per state over DPP quads: 8.1 k instructions per lane, 23 us per dependent permutation -- what this layout reaches with half the
-// lanes, 9.4 k and 22.8 us; removed in round 4.)
+// lanes, 8.7 k and 22 us; removed in round 4.)
 //
 // Layout (round 4): lanes l and l + 32 share state n = l & 31; lane (n, h) holds the six elements 6 h + j.  That is the operand layout
 // of v_mfma_i32_32x32x32_i8 -- B[k][n] comes from lane (n, k >> 4), D[i][n] goes to lane (n, (i >> 2) & 1) -- so ONE instruction sees the
@@ -79,7 +79,7 @@ __device__ __forceinline__ void both(uint64_t v, uint64_t& even, uint64_t& odd) 
 }
 
 // S-box layer of a full round on the lane's six elements (they carry the round's constants already): 24 products as eight blocks of
-// three interleaved hand-scheduled chains (19 instructions per product against the compiler's 23; measured 18.8 -> 18.1 ms for 2^14
+// three interleaved hand-scheduled chains (16 instructions per product against the compiler's 23; with 19 it measured 18.8 -> 18.1 ms for 2^14
 // leaves x 4942 columns in round 3's layout; the one-chain block in the partial rounds: 22.0 ms, its latency is exposed there)
 __device__ __forceinline__ void sbox6(uint64_t s[6]) {
 #pragma unroll
