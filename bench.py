@@ -74,6 +74,24 @@ def cpu_baseline(ios, shapes, kinds, budget_s=150.0):
                                                      "" if measured else " (only the first measured, the others scaled by committed cells)")}
 
 
+def verify_proofs(proofs):
+    """the CPU checker (oracle/stark.c's verifier, test infrastructure) over proofs this run produced, OUTSIDE every timed region:
+    a bench line for proofs nobody checked is a claim, not a result.  Returns True when every non-empty proof is accepted."""
+    from tests import _oracle
+    ok = True
+    for pf in proofs:
+        if len(pf):
+            ok = ok and _oracle.stark_verify(np.ascontiguousarray(pf)) == 0
+    return bool(ok)
+
+
+def all_ranks_true(flag, device):
+    """a per-rank boolean folded over the ranks (min): the line says `verified` only if every rank's proofs were accepted"""
+    from sipp_amd import dist_util
+    lo, _ = dist_util.min_max_over_ranks(1.0 if flag else 0.0, device=device)
+    return bool(lo > 0.5)
+
+
 def air_revision():
     """the AIR is this repository's own specification (tools/air_gen.py): identify the revision the numbers belong to"""
     import hashlib
@@ -211,6 +229,9 @@ def main():
     # W untimed warm-up steps, then exactly K steps between barrier + synchronize, max over ranks
     elapsed, proofs = dist_util.timed_steps(step, args.steps, args.warmup, sync=device_sync, device=red_device,
                                             before_timing=start_profiling)
+    proofs = [p.copy() for p in proofs]           # the instance's output buffers are reused by the later legs
+    # every rank pushes the proofs of its LAST timed step through the oracle's verifier (outside the timed region)
+    verified_main = all_ranks_true(verify_proofs(proofs), red_device)
     prof = {}
     for c in inst.distinct_ctxs():
         for k, v in c.profile_report().items():
@@ -233,11 +254,14 @@ def main():
         queue.prove([ios] * args.inflight)
         barrier()
         tp = time.perf_counter()
-        queue.prove([ios] * (args.inflight * args.steps))
+        qproofs = queue.prove([ios] * (args.inflight * args.steps))
         barrier()
         dtp = dist_util_max(time.perf_counter() - tp)
+        # the last instance of the queue through the verifier; every instance must equal the single-instance proofs word for word
+        q_ok = verify_proofs(qproofs[-1]) and all(len(a) == len(b) and (a == b).all() for inst_p in qproofs for a, b in zip(inst_p, proofs))
         pipelined = {"instances_in_flight": args.inflight, "ms_per_instance": 1e3 * dtp / (args.steps * args.inflight),
                      "value": args.n * world * args.inflight * args.steps / dtp, "unit": "pairings/s",
+                     "verified": all_ranks_true(q_ok, red_device),
                      "entry_point": "sipp_instances_prove (queue of %d instances)" % (args.inflight * args.steps)}
         queue.close()
 
@@ -324,6 +348,8 @@ def main():
             "value": value, "unit": "pairings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            # the three proofs of the last timed step, on every rank, through oracle/stark.c's verifier after the timed region
+            "verified": verified_main,
             # what carried the barrier and the max-over-ranks reduction of the timed region
             "timing_reduction": ("%s:%s" % (dist.get_backend(), red_device)) if dist.is_initialized() else "single process",
             "config": {"workload": "n=%d SIPP instance per GPU: G1ExpStark %d IO (N=2^%d, W+P+Q=%d), G2ExpStark %d IO "
@@ -405,6 +431,7 @@ def main():
                             "sample": "oracle/py/bn254.py pairing (pure Python big integers) on 3 pairs"}
             out["native_chain"] = {"cpu_baseline": cpu_pair, "prove_native_ms": 1e3 * t_np, "verify_native_ms": 1e3 * t_nv, "pairings": 3 * args.n - 2,
                                    "pairings_per_s": (3 * args.n - 2) / t_np, "accepted": bool(okn),
+                                   "verified": bool(okn) and bool(all((a == b).all() for a, b in zip(nios, ios))),
                                    "obligations_equal_bench_input": bool(all((a == b).all() for a, b in zip(nios, ios)))}
         except Exception as e:                  # noqa: BLE001
             out["native_chain"] = {"error": repr(e)}
@@ -429,6 +456,7 @@ def main():
             mproof = mctx.prove(3, mrec)
             t_mp = time.perf_counter() - t
             out["map_to_g2"] = {"messages": args.n - 1, "map_and_cofactor_ms": 1e3 * t_map, "proof_ms": 1e3 * t_mp,
+                                "verified": verify_proofs([mproof]),
                                 "proof_words": int(len(mproof)), "shape": list(mctx.shape(3, args.n - 1)),
                                 "cofactor_obligations": int(mg2.shape[0]),
                                 "entry_points": "sipp_map_to_g2, sipp_map_to_g2_prove"}
@@ -450,6 +478,7 @@ def main():
                     hp = oinst.prove(ios)
                 t_h = (time.perf_counter() - t) / 10
                 out[other_key] = {"kinds": [int(x[1]) for x in hp], "ms_per_instance": 1e3 * t_h, "value": args.n / t_h, "unit": "pairings/s",
+                                  "verified": verify_proofs(hp),
                                   "columns": [list(oinst.ctxs[i].shape(i, ios[i].shape[0])) for i in range(3)],
                                   "proof_words": [int(len(x)) for x in hp],
                                   "entry_point": "sipp_instance_prove" + ("" if hardened else " on ctxs with sipp_ctx_set_hardened"),
@@ -482,14 +511,16 @@ def main():
             k_s = 2
             si_single = si.single_ctx
             own = []
-            dts, _ = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
-                                           device=red_device, local_out=own)
+            dts, sproofs = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
+                                                 device=red_device, local_out=own)
+            sproofs = [p.copy() for p in sproofs]
             si.close()
+            s_ok = all_ranks_true(verify_proofs(sproofs), red_device)     # every rank's shard proofs of the last step, after the timing
             lo, hi = dist_util.min_max_over_ranks(own[0], device=red_device)
             io_sharded["n=%d" % n_s] = {"ms_per_instance": 1e3 * dts / k_s, "value": n_s * k_s / dts, "unit": "pairings/s",
                                         # one rank proves the whole instance on one GPU: the figure the sharded runs are divided into
                                         "scaling": "strong" if world > 1 else "baseline (whole instance on one GPU)",
-                                        "ranks": world, "steps": k_s,
+                                        "ranks": world, "steps": k_s, "verified": s_ok,
                                         "rank_ms_per_instance_min_max": [1e3 * lo / k_s, 1e3 * hi / k_s],
                                         "host_threads_per_rank": 1 if si_single else 4,
                                         # True: one ctx / one arena, the three proofs back to back (the three arenas together would

@@ -2,6 +2,9 @@
 // (VOP2, carry in VCC) and three-operand (VOP3, carry / mask in an SGPR pair) encodings, 64-bit adds, compares, selects, and the
 // multiply-add.  Eight independent destination registers per block, blocks repeated back to back, 8 waves per SIMD, every CU busy.
 // Reports the time per wave-instruction per SIMD RELATIVE to v_add_u32 (the clock under load is not 2.4 GHz, so ratios, not cycles).
+// Round 5: every block also stamps s_memtime (shader clock) and s_memrealtime (100 MHz) around its loop into a buffer of its own
+// (MI355X_MICROARCH.md, DVFS give-back item 6): the median quotient is the clock the chip HOLDS under that instruction stream, so the
+// table gives cycles per wave-instruction as well as nanoseconds -- the calibration DESIGN.md section 9 / bench.py's `valu` object use.
 // build: hipcc -O3 --offload-arch=gfx950 scripts/ubench/enc_rates.hip -o scripts/ubench/bin/enc_rates
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,7 +16,8 @@
 #define ADD_U32(i) "v_add_u32_e32 v" S(8) "+" #i ", v16, v8\n"
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
+__global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint64_t* stamps) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t x[8], y[8];
     uint64_t z[8];
     for (int i = 0; i < 8; i++) {
@@ -62,6 +66,12 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters) {
     uint32_t s = 0;
     for (int i = 0; i < 8; i++) s += x[i] + (uint32_t)z[i] + (uint32_t)(z[i] >> 32);
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {           // a buffer no other code reads
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
 }
 
 static double base_ms = 0;
@@ -70,22 +80,36 @@ void run(const char* name) {
     uint32_t* d;
     const int blocks = 256 * 8, threads = 256, iters = 2048;
     (void)hipMalloc(&d, blocks * threads * 4);
+    uint64_t* st;
+    (void)hipMalloc(&st, blocks * 16);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
         (void)hipEventRecord(e0);
-        k<OP><<<blocks, threads>>>(d, iters);
+        k<OP><<<blocks, threads>>>(d, iters, st);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
     }
     if (OP == 0) base_ms = ms;
     const double winst = (double)blocks * (threads / 64) * iters * 32;
-    printf("%-28s %8.3f ms  %6.2f x v_add_u32   (%.2f ns per wave-instruction per SIMD)\n", name, ms, ms / base_ms,
-           ms * 1e6 / (winst / 1024));
+    static uint64_t h[256 * 8 * 2];
+    (void)hipMemcpy(h, st, blocks * 16, hipMemcpyDeviceToHost);
+    double q[256 * 8];
+    for (int b = 0; b < blocks; b++) q[b] = h[2 * b + 1] ? (double)h[2 * b] / (double)h[2 * b + 1] * 0.1 : 0.0;   // GHz
+    for (int i = 1; i < blocks; i++) {       // insertion sort: the median block
+        double v = q[i];
+        int j = i - 1;
+        for (; j >= 0 && q[j] > v; j--) q[j + 1] = q[j];
+        q[j + 1] = v;
+    }
+    const double ghz = q[blocks / 2], ns = ms * 1e6 / (winst / 1024);
+    printf("%-28s %8.3f ms  %6.2f x v_add_u32   %.2f ns per wave-instruction per SIMD   in-kernel clock %.3f GHz   %.2f cycles\n", name, ms,
+           ms / base_ms, ns, ghz, ns * ghz);
     (void)hipFree(d);
+    (void)hipFree(st);
 }
 
 int main() {

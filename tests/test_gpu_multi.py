@@ -76,25 +76,33 @@ def test_bench_four_ranks_rehearsal_shards_the_n1024_instance():
     assert 0 < lo <= hi <= sh["ms_per_instance"] * 1.001
 
 
+_SHARDS_1024 = {0: [127, 127, 2], 1: [128, 128, 3], 2: [128, 128, 2], 3: [128, 128, 3], 4: [128, 128, 2], 5: [128, 128, 3], 6: [128, 128, 2],
+                7: [128, 128, 3]}
+_SHARDS_4096 = {r: [511 if r == 0 else 512, 511 if r == 0 else 512, 3] for r in range(8)}
+
+
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("n,log_n,records", [(1024, 16, {0: [127, 127, 2], 1: [128, 128, 3], 2: [128, 128, 2], 3: [128, 128, 3], 4: [128, 128, 2],
-                                                         5: [128, 128, 3], 6: [128, 128, 2], 7: [128, 128, 3]}),
-                                             (4096, 18, {0: [511, 511, 3], 3: [512, 512, 3], 7: [512, 512, 3]})])
-def test_world8_shards_of_the_large_configs(n, log_n, records):
+@pytest.mark.parametrize("n,log_n,records,hardened", [
+    (1024, 16, _SHARDS_1024, False), (1024, 16, _SHARDS_1024, True),
+    (4096, 18, {r: _SHARDS_4096[r] for r in (0, 3, 7)}, False), (4096, 18, _SHARDS_4096, True)])
+def test_world8_shards_of_the_large_configs(n, log_n, records, hardened):
     """BASELINE configs[3] / configs[4]: the shards an 8-rank run proves -- n = 1024: 127 / 128 G1 and G2 records (N = 2^16)
     and 2 / 3 Fq12 records (the two-IO-block minimum and a padded block); n = 4096: 511 / 512 records, N = 2^18, the first
-    size outside the fused LDE kernels' range, with ragged 511-record lists padded by one copy.  ALL EIGHT ranks of n = 1024
-    (cheap: N = 2^16) and ranks 0, 3 and 7 of n = 4096 through sipp_instance_prove exactly as bench.py's io_sharded leg does: the oracle's verifier accepts every proof, the public
-    inputs are the rank's slice (padding = copies of its last record), and a single ctx gives the same words."""
+    size outside the fused LDE kernels' range, with ragged 511-record lists padded by one copy.  Through sipp_instance_prove exactly
+    as bench.py's io_sharded leg does, for BOTH AIR variants: ALL EIGHT ranks of n = 1024 (plain and hardened) and of n = 4096 with
+    the hardened kinds 4 / 5 (the variant the leg times); ranks 0, 3 and 7 of n = 4096 with the plain kinds.  The oracle's verifier
+    accepts every proof, the public inputs are the rank's slice (padding = copies of its last record), and a single ctx gives the
+    same words."""
     import sipp_amd
     from tests import _oracle
     d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % n))
     ios = [d["g1"], d["g2"], d["fq12"]]
     L = sipp_amd.lib()
+    seen = [0, 0, 0]
     for rank, want_counts in records.items():
         mine = sipp_amd.shard_ios(ios, 8, rank)
         assert [int(a.shape[0]) for a in mine] == want_counts, rank
-        inst = sipp_amd.Instance([a.shape[0] for a in mine])
+        inst = sipp_amd.Instance([a.shape[0] for a in mine], hardened=hardened)
         try:
             proofs = [p.copy() for p in inst.prove(mine)]
         finally:
@@ -102,7 +110,10 @@ def test_world8_shards_of_the_large_configs(n, log_n, records):
         for k in range(3):
             first, count = sipp_amd.io_shard(ios[k].shape[0], 8, rank)
             assert (mine[k] == ios[k][first: first + count]).all()
+            seen[k] += count
             pf = proofs[k]
+            kind = k + 4 if hardened and k < 2 else k
+            assert int(pf[1]) == kind
             nio = int(pf[3])
             assert nio >= max(2, count) and nio & (nio - 1) == 0
             if k < 2:
@@ -111,12 +122,16 @@ def test_world8_shards_of_the_large_configs(n, log_n, records):
             pis = pf[-nio * mine[k].shape[1]:].reshape(nio, mine[k].shape[1])
             assert (pis[:count] == mine[k]).all() and (pis[count:] == mine[k][-1]).all(), (rank, k)
             if rank == 3:
-                c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(k, count))
+                c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(kind, count))
                 try:
+                    if hardened:
+                        c._ck(L.sipp_ctx_set_hardened(c.h, 1), "set_hardened")
                     alone = c.prove(k, mine[k])
                 finally:
                     c.close()
                 assert len(alone) == len(pf) and (alone == pf).all(), (rank, k)
+    if len(records) == 8:
+        assert seen == [a.shape[0] for a in ios]          # the eight ranges tile the three lists
 
 
 def test_bench_refuses_a_launcher_with_the_wrong_world_size():

@@ -122,10 +122,44 @@ def test_n256_instance_of_the_reference_test_verifies():
         assert (pf[-nio * rec.shape[1]:].reshape(nio, rec.shape[1])[: rec.shape[0]] == rec).all()
 
 
-def test_large_n1024_proofs_verify():
-    """deep traces (BASELINE config 3): n = 1024 -> 1023 G1 / 1023 G2 / 20 Fq12 IO records, N = 2^19 / 2^19 / 2^14 rows,
-    2^20-leaf trees, 2-pass NTTs of size 2^19 / 2^20.  Checked through the oracle's verifier and the public inputs."""
+def _instance_proofs_verify(n, hardened, log_n):
+    """the three sub-proofs of the n-pairing fixture through sipp_amd.Instance exactly as bench.py's `io_sharded` leg builds it
+    (hardened=True: API kinds 4 / 5, the headline variant; three ctxs, or ONE arena with the proofs back to back where three do
+    not fit the card -- hardened n = 4096), every proof through the oracle's verifier, public inputs = the records"""
     import sipp_amd
+    d = np.load("tests/golden/sipp_n%d_ios.npz" % n)
+    ios = [d[k] for k in ("g1", "g2", "fq12")]
+    inst = sipp_amd.Instance([a.shape[0] for a in ios], hardened=hardened)
+    single = inst.single_ctx
+    try:
+        proofs = [p.copy() for p in inst.prove(ios)]
+    finally:
+        inst.close()
+    for k, (pf, rec) in enumerate(zip(proofs, ios)):
+        assert int(pf[1]) == (k + 4 if hardened and k < 2 else k), k
+        nio = int(pf[3])
+        assert nio >= rec.shape[0] and (nio & (nio - 1)) == 0
+        if k < 2:
+            assert int(pf[2]) == log_n and nio == n
+        assert _oracle.stark_verify(pf) == 0, (k, hardened)
+        pis = pf[-nio * rec.shape[1]:].reshape(nio, rec.shape[1])
+        assert (pis[: rec.shape[0]] == rec).all() and (pis[rec.shape[0]:] == rec[-1]).all()
+        bad = pf.copy()
+        bad[16 + 64 + 5] ^= 1                              # one bit of the Z cap
+        assert _oracle.stark_verify(bad) != 0
+    return single
+
+
+@pytest.mark.parametrize("hardened", [False, True])
+def test_large_n1024_proofs_verify(hardened):
+    """deep traces (BASELINE config 3): n = 1024 -> 1023 G1 / 1023 G2 / 20 Fq12 IO records, N = 2^19 / 2^19 / 2^14 rows,
+    2^20-leaf trees, tree-of-rings transforms of 2^19 / 2^20 points, the u16 lookup table.  Plain kinds: one ctx per kind; hardened
+    kinds 4 / 5 (the variant bench.py's `value` and `io_sharded` legs prove): through sipp_amd.Instance.  Checked through the
+    oracle's verifier and the public inputs."""
+    import sipp_amd
+    if hardened:
+        assert _instance_proofs_verify(1024, True, 19) is False       # three arenas fit the card
+        return
     d = np.load("tests/golden/sipp_n1024_ios.npz")
     L = sipp_amd.lib()
     for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
@@ -183,10 +217,15 @@ def test_edge_exponents_and_degenerate_inputs(ctx):
     assert e.value.code == -8
 
 
-def test_max_size_n4096_proofs_verify():
+@pytest.mark.parametrize("hardened", [False, True])
+def test_max_size_n4096_proofs_verify(hardened):
     """largest BASELINE config: n = 4096 -> 4095 G1 / 4095 G2 / 24 Fq12 IO records, N = 2^21 rows, LDE 2^22 rows
-    (three-pass NTT), 82 GB / 160 GB arenas.  The oracle's verifier must accept every proof."""
+    (five-sweep tree transforms), 82 GB / 160 GB arenas.  The oracle's verifier must accept every proof.  hardened: kinds 4 / 5
+    through the single-arena Instance (179 GB, the three proofs back to back) exactly as bench.py's io_sharded["n=4096"] builds it."""
     import sipp_amd
+    if hardened:
+        assert _instance_proofs_verify(4096, True, 21) is True        # three arenas (276 GB) do not fit: one ctx
+        return
     d = np.load("tests/golden/sipp_n4096_ios.npz")
     L = sipp_amd.lib()
     for kind, key in ((0, "g1"), (1, "g2"), (2, "fq12")):
