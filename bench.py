@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (spec)
 NTT_KERNELS = ("lde_column", "lde_gather", "lde_mid", "ntt_dif_pass", "ntt_dit_pass", "bitrev_cols", "ntt_tree_gather", "ntt_tree_inv",
                "ntt_tree_mid", "ntt_tree_fwd")
-PMC_FILE = "r04_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
+PMC_FILE = "r05_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
 
 
 def load_ios(n):
@@ -298,13 +298,20 @@ def main():
                 e["perms"] += m * ((cols + 7) // 8)
                 e["batches"] += 1
         leaf_perms = leaf["one"]["perms"] + leaf["pair"]["perms"]
-        pmc = {}
+        pmc, pmc_state = {}, "no counters for this size (the PMC passes profile the n = 128 line)"
         tpath = os.path.join(ROOT, "profiles", PMC_FILE)
         if args.n == 128 and os.path.exists(tpath):
+            from sipp_amd import build as sipp_build
             pmc = json.load(open(tpath))
+            pmc_state = "current"
             if pmc.get("kinds", [0, 1, 2]) != kinds:      # counters of the other AIR variant do not belong to this line
-                pmc = {}
-        issue_peak = 256 * 4 * 2.4e9 / 2 / 1e9    # G wave-instructions/s: 1024 SIMD-32, one wave64 instruction per 2 cycles at 2.4 GHz
+                pmc, pmc_state = {}, "counters of the other AIR variant: not used"
+            elif pmc.get("source_sha256") != sipp_build.source_hash():
+                # the kernels changed after the PMC passes were taken (scripts/profile_round.sh): stale counters are refused, not reported
+                pmc, pmc_state = {}, ("STALE: profiles/%s was collected on other kernel sources (sha256 %s...); re-run "
+                                      "scripts/profile_round.sh" % (PMC_FILE, str(pmc.get("source_sha256"))[:12]))
+        # nominal issue peak: 1024 SIMDs, one wave64 instruction per 2 cycles (a PAIR of plain 32-bit forms per quad-cycle) at 2.4 GHz
+        issue_peak = 256 * 4 * 2.4e9 / 2 / 1e9    # G wave-instructions/s
 
         def leaf_entry(kind, prof_name):
             lk_ = prof.get(prof_name, {"calls": 0, "ms": 0.0})
@@ -315,14 +322,34 @@ def main():
             bpl = leaf[kind]["bytes"] * args.steps / n_l
             ach = bpl / (avg * 1e-3) / 1e9
             st = pmc.get("leaf_" + kind, {})
+            al = pmc.get("leaf_" + kind + "_alone") or {}
             vi = st.get("valu_insts_per_launch")
+            valu_obj = None
+            if vi:
+                ach_v = vi / (avg * 1e-3) / 1e9
+                valu_obj = {"unit": "G wave-instructions/s", "achieved": ach_v, "peak_nominal": issue_peak, "frac_nominal": ach_v / issue_peak,
+                            "insts_per_launch": vi}
+                if al.get("eff_clock_ghz") and al.get("cycles_per_inst"):
+                    # calibrated ceiling of THIS kernel's instruction mix at the clock the chip holds under it (both from the PMC pass
+                    # of this command, profiles/PMC_FILE; method and the counters' meaning: profiles/README.md, r05_enc_rates.txt):
+                    #   a VALU instruction occupies its SIMD for 4 cycles unless it issues as one of a pair (plain 32-bit VOP1 / VOP2
+                    #   forms only); cycles_per_inst = 4 (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / SQ_INSTS_VALU
+                    clk, cpi = al["eff_clock_ghz"], al["cycles_per_inst"]
+                    cal = 1024.0 * clk / cpi
+                    valu_obj.update({"eff_clock_ghz": clk, "cycles_per_inst": cpi,
+                                     "mix_cost": cpi / 2.0,      # issue slots of the nominal peak (2 cycles) per instruction
+                                     "peak_calibrated": cal, "frac_of_calibrated": ach_v / cal,
+                                     # the kernel ALONE on the chip, as the counter pass saw it (static): launch time and the share of
+                                     # its SIMD cycles the VALUs were busy (4 x SQ_ACTIVE_INST_VALU / (1024 x GRBM_GUI_ACTIVE / 8))
+                                     "alone": {"avg_launch_ms": al["avg_launch_ms"], "achieved": vi / (al["avg_launch_ms"] * 1e-3) / 1e9,
+                                               "frac_of_calibrated": vi / (al["avg_launch_ms"] * 1e-3) / 1e9 / cal,
+                                               "valu_busy_frac": al.get("valu_busy_frac")}})
             return {"kernel": prof_name, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bpl,
                     "launches": n_l, "avg_launch_ms": avg, "traffic": st.get("traffic_bytes_per_launch"),
                     "perms_per_s": leaf[kind]["perms"] * args.steps / (lk_["ms"] * 1e-3),
                     # the kernel's real bound: wave-level VALU instructions per launch (PMC SQ_INSTS_VALU of this same command,
                     # static) over the live launch time, against the issue peak (MI355X_MICROARCH.md, wave scheduling)
-                    "valu": ({"unit": "G wave-instructions/s", "achieved": vi / (avg * 1e-3) / 1e9, "peak": issue_peak,
-                              "frac": vi / (avg * 1e-3) / 1e9 / issue_peak, "insts_per_launch": vi} if vi else None)}, lk_
+                    "valu": valu_obj}, lk_
 
         one, lk = leaf_entry("one", "poseidon_leaves")
         pair, lkp = leaf_entry("pair", "poseidon_leaves_pair")
@@ -339,9 +366,16 @@ def main():
         if pmc.get("valu_insts_per_instance"):
             vi = pmc["valu_insts_per_instance"]
             ach = vi / (ms_per_step * 1e-3) / 1e9
-            valu_instance = {"unit": "G wave-instructions/s", "insts_per_instance": vi, "achieved": ach, "peak": issue_peak,
-                             "frac": ach / issue_peak, "mix_ceiling": issue_peak / 1.5, "frac_of_mix_ceiling": ach / (issue_peak / 1.5),
+            al = pmc.get("leaf_one_alone") or {}
+            valu_instance = {"unit": "G wave-instructions/s", "insts_per_instance": vi, "achieved": ach, "peak_nominal": issue_peak,
+                             "frac_nominal": ach / issue_peak,
                              "source": "profiles/%s (static: rocprofv3 --pmc SQ_INSTS_VALU of this command)" % PMC_FILE}
+            if al.get("eff_clock_ghz"):
+                # the instance's mix priced like its dominant kernel's (cycles per instruction and clock of poseidon_leaves alone; the
+                # transform kernels pair 15 - 18 % of their instructions, the hash kernels 0 - 4 %: profiles/PMC_FILE)
+                cal = 1024.0 * al["eff_clock_ghz"] / al.get("cycles_per_inst", 4.0)
+                valu_instance.update({"peak_calibrated": cal, "frac_of_calibrated": ach / cal, "eff_clock_ghz": al["eff_clock_ghz"],
+                                      "cycles_per_inst": al.get("cycles_per_inst", 4.0)})
         out = {
             "metric": "SIPP proof-gen wall-clock + pairings-aggregated/sec, n=%d (the 3 STARK sub-proofs, %s; outer plonky2 proof not included)"
                       % (args.n, "hardened G1/G2 AIRs" if hardened else "plain G1/G2 AIRs: forgeable for crafted statements, see hardened_instance"),
@@ -372,6 +406,7 @@ def main():
                          "traffic_source": ("profiles/%s (static: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                             "command, FETCH_SIZE x2 gfx950 correction; not re-measured in this run)" % PMC_FILE)
                                            if traffic is not None else None,
+                         "pmc_counters": pmc_state,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": launches, "avg_launch_ms": avg_ms, "valu": valu, "valu_instance": valu_instance,
                          "two_lane_kernel": pair if pair is not one else None,
@@ -406,6 +441,10 @@ def main():
             "proof_ms_per_step": [round(x / args.steps, 2) for x in proof_ms] if serial else None,
             "pipelined": pipelined,
         }
+        if pipelined and valu_instance and valu_instance.get("peak_calibrated"):
+            # five instances queued: the same instruction count over the queued time per instance
+            pipelined["valu_frac_of_calibrated"] = (valu_instance["insts_per_instance"] / (pipelined["ms_per_instance"] * 1e-3) / 1e9
+                                                    / valu_instance["peak_calibrated"] / world)
         # secondary, outside the timed region: the native SIPP chain in front of the circuit (HISTORY.md section 7)
         # on this GPU -- sipp_prove_native = 3n - 2 pairings + the folds, sipp_verify_native = the obligation lists the timed
         # region consumes.  Never allowed to break the main line.

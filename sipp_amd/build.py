@@ -17,6 +17,21 @@ def _stale():
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def source_hash():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.hpp, *.h, *.inc, *.cpp + data/air_tables.h), in
+    name order: recorded next to the PMC counters under profiles/ (scripts/profile_round.sh) so that bench.py can tell counters of
+    another code state from current ones"""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")))
+    for f in names:
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(b"air_tables.h\0")
+    h.update(open(os.path.join(os.path.dirname(HERE), "data", "air_tables.h"), "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the C-ABI shared library."""
     if force:
@@ -29,4 +44,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "hash":
+        print(source_hash())
+    else:
+        print(build(verbose=True))
