@@ -49,14 +49,11 @@ __device__ __forceinline__ uint32_t lds_idx(uint32_t e) { return e + (e >> LOG_S
 struct IdxPlain {
     __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return lds_idx(e); }
 };
-struct IdxBlocked {
-    uint32_t blk;
-    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return e + (e >> LOG_SEG) + (e >> blk); }
-};
 
 #ifndef SIPP_NTT_MLP
 #define SIPP_NTT_MLP 8
 #endif
+
 template <int U, class Load, class Use>
 __device__ __forceinline__ void tile_loop(uint32_t E, Load load, Use use) {
     const uint32_t step = blockDim.x;
@@ -229,7 +226,196 @@ __global__ void __launch_bounds__(256) tree_pass_kernel(TreeArgs a) {
         [&](uint32_t e, uint64_t v) { out[pos_of(e)] = sc ? gl::mul(v, sc) : FWD ? gl::canon(v) : v; });
 }
 
+// ---- round 5: the sweeps over full 2^12-element tiles with the tile loaded by LDS-DMA ------------------------------------------------
+// global_load_lds_dwordx4 has no VGPR destination: the whole 32-KB tile of a block is in flight at once (the register-staged tile_loop
+// keeps 8 x 8 bytes per lane in flight) and the load phase costs no VALU work.  The DMA writes LDS lane-linear (base + 16 lane), so the
+// tile cannot be padded: it is XOR-swizzled on element bits 1 .. 4 (pairs of elements stay together, 16-byte aligned) through the
+// per-lane SOURCE address -- exactly 32 KB, five blocks per CU -- and wherever a lane owns consecutive elements (the contiguous sweep's
+// last round, every store phase) an LDS access moves 16 bytes.  Measured (profiles/r05_ab_tree_dma.txt): contiguous sweep 3.84 -> 3.15 ms
+// at 2^18 x 1024, 0.95 -> 0.74 ms at 2^16 x 1024.  A persistent DOUBLE-buffered form (tile k + 1 streaming in during tile k's rounds;
+// 64 KB per block, two blocks per CU) was slower than the round-4 kernel at every size: same file.
+__device__ __forceinline__ uint32_t swz(uint32_t e) { return e ^ (((e >> 5) & 7u) << 1) ^ (((e >> 8) & 1u) << 4); }
+struct IdxSwz {
+    __device__ __forceinline__ uint32_t operator()(uint32_t e) const { return swz(e); }
+};
+struct DmaArgs {
+    const uint64_t* in;
+    uint64_t* out;
+    size_t in_stride, out_stride, in_half, out_half;
+    uint32_t L, q0, ncols, halves;
+    const uint64_t* tw;
+    uint32_t work;               // tiles x columns x halves
+};
+
+__device__ __forceinline__ void dma_decode(const DmaArgs& a, uint32_t w, uint32_t& tix, uint32_t& col, uint32_t& h) {
+    const uint32_t per_half = a.ncols << (a.L - 12);
+    h = w / per_half;
+    const uint32_t r = w - h * per_half;
+    tix = r / a.ncols;             // column-fastest: the blocks in flight share node constants
+    col = r - tix * a.ncols;
+}
+
+__device__ __forceinline__ void dma_issue(const DmaArgs& a, uint32_t w, uint64_t* buf) {
+    uint32_t tix, col, h;
+    dma_decode(a, w, tix, col, h);
+    const uint64_t* src = a.in + (size_t)col * a.in_stride + (size_t)h * a.in_half + ((size_t)tix << 12);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t P = ((c * 4 + wave) << 6) + lane;                           // pair slot in LDS (lane-linear inside the piece)
+        const uint32_t pe = P ^ ((P >> 4) & 7u) ^ (((P >> 7) & 1u) << 3);          // the pair of elements that lives there
+        // inline asm, not __builtin_amdgcn_global_load_lds: the compiler cannot tell the two buffers of one LDS array apart and would
+        // wait vmcnt(0) before the first ds_read after a DMA it knows of -- the transfer would never overlap the butterflies.  M0 = the
+        // piece's LDS byte address (wave-uniform), saved and restored around the instruction (cdna_hip_programming.md, LDS-DMA recipe)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(buf + (((c * 4 + wave) << 6) << 1)));
+        const uint64_t* g = src + 2 * pe;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    }
+}
+
+// the tile's top four levels (row strides 2^8 .. 2^11): fifteen node constants, the same for every lane -- scalar loads, so that no
+// vector-memory wait (which would drain the DMA in flight: vmcnt counts in order) sits in this round
+__device__ __forceinline__ void tree_round_top(uint64_t* tile, const uint64_t* tw_, uint32_t z0) {
+    // the table is read-only for the whole launch: constant address space, so that uniform addresses become s_load (lgkmcnt, not vmcnt)
+    const __attribute__((address_space(4))) uint64_t* tw = (const __attribute__((address_space(4))) uint64_t*)tw_;
+    const uint32_t j = threadIdx.x;
+    uint64_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = tile[swz(j + 256 * i)];
+#pragma unroll
+    for (int sg = 3; sg >= 0; sg--) {
+        const uint32_t lev = 3 - sg;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i & (1 << sg)) continue;
+            const uint64_t w = tw[(z0 << lev) + (uint32_t)(i >> (sg + 1))];
+            bfly_fwd(x[i], x[i + (1 << sg)], w);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) tile[swz(j + 256 * i)] = x[i];
+    __syncthreads();
+}
+
+// the last four levels: a lane owns sixteen consecutive elements = eight 16-byte pairs
+template <class Tw>
+__device__ __forceinline__ void tree_round_last(uint64_t* tile, uint32_t k, Tw tw) {
+    const uint32_t b = threadIdx.x;
+    const uint32_t e0 = b << 4;
+    uint64_t x[16];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + swz(e0 + 2 * m));
+        x[2 * m] = v.x;
+        x[2 * m + 1] = v.y;
+    }
+#pragma unroll
+    for (int sg = 3; sg >= 0; sg--) {
+        const uint32_t lev = k - 1 - sg;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i & (1 << sg)) continue;
+            const uint64_t w = tw(0, lev, (b << (3 - sg)) + (uint32_t)(i >> (sg + 1)));
+            bfly_fwd(x[i], x[i + (1 << sg)], w);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        ulonglong2 v;
+        v.x = x[2 * m];
+        v.y = x[2 * m + 1];
+        *reinterpret_cast<ulonglong2*>(tile + swz(e0 + 2 * m)) = v;
+    }
+    __syncthreads();
+}
+
+// the contiguous forward sweep (the tile's twelve leaf-most levels), one tile per block
+__global__ void __launch_bounds__(256) tree_fwd_dma_kernel(DmaArgs a) {
+    extern __shared__ uint64_t smem[];
+    constexpr uint32_t E = 4096, K = 12;
+    const uint32_t w = blockIdx.x;
+    uint64_t* tile = smem;
+    dma_issue(a, w, tile);
+    uint32_t tix, col, h;
+    dma_decode(a, w, tix, col, h);
+    const uint32_t z0 = ((a.q0 + h) << (a.L - K)) + tix;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tree_round_top(tile, a.tw, __builtin_amdgcn_readfirstlane(z0));
+    tree_round<true, 4>(tile, E, K, 0, 4, IdxSwz{}, TwGlobal{a.tw, z0, 1});
+    tree_round_last(tile, K, TwGlobal{a.tw, z0, 1});
+    uint64_t* out = a.out + (size_t)col * a.out_stride + (size_t)h * a.out_half + ((size_t)tix << 12);
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t pe = c * 256 + threadIdx.x;
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + swz(2 * pe));
+        v.x = gl::canon(v.x);
+        v.y = gl::canon(v.y);
+        *reinterpret_cast<ulonglong2*>(out + 2 * pe) = v;
+    }
+}
+
+// strided sweeps (lo > 0: tile = 2^k rows x 2^lt columns, lt >= 1 so that a 16-byte pair is contiguous in HBM), either direction:
+// DMA load through the per-lane source address, node constants staged in LDS behind the tile, 16-byte stores
+template <bool FWD>
+__global__ void __launch_bounds__(256) tree_pass_dma_kernel(TreeArgs a) {
+    extern __shared__ uint64_t smem[];
+    const uint32_t k = a.k, lt = a.lt, lo = a.lo;
+    constexpr uint32_t E = 4096;
+    const uint32_t T = 1u << lt;
+    uint64_t* tile = smem;
+    uint64_t* tws = smem + E;
+    uint32_t col, tix;
+    tix = blockIdx.x / a.ncols;
+    col = blockIdx.x - tix * a.ncols;
+    const uint64_t* in = a.in + (size_t)col * a.in_stride + (size_t)blockIdx.y * a.in_half;
+    uint64_t* out = a.out + (size_t)col * a.out_stride + (size_t)blockIdx.y * a.out_half;
+    const uint32_t Q = a.q0 ? a.q0 + blockIdx.y : 0;
+    const uint32_t hi = tix >> (lo - lt);
+    const uint32_t base = (hi << (lo + k)) + ((tix & ((1u << (lo - lt)) - 1)) << lt);
+    auto pos_of = [&](uint32_t e) -> uint32_t { return base + ((e >> lt) << lo) + (e & (T - 1)); };
+    const uint32_t z0 = (Q << (a.L - lo - k)) + hi;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t P = ((c * 4 + wave) << 6) + lane;
+        const uint32_t pe = P ^ ((P >> 4) & 7u) ^ (((P >> 7) & 1u) << 3);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(tile + (((c * 4 + wave) << 6) << 1)));
+        const uint64_t* g = in + pos_of(2 * pe);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    }
+    {
+        const uint32_t R = 1u << k;
+        for (uint32_t J = threadIdx.x; J < R; J += blockDim.x) {
+            if (!J) continue;
+            const uint32_t lev = 31 - __clz(J);
+            tws[J] = a.tw[(z0 << lev) + (J - (1u << lev))];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tree_stages<FWD>(tile, E, k, lt, IdxSwz{}, TwLds{tws, k});
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t pe = c * 256 + threadIdx.x;
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + swz(2 * pe));
+        if (FWD) {
+            v.x = gl::canon(v.x);
+            v.y = gl::canon(v.y);
+        }
+        *reinterpret_cast<ulonglong2*>(out + pos_of(2 * pe)) = v;
+    }
+}
+
 // Fused MIDDLE sweep: the inverse's top ki levels and, on the same tile, the top kf levels of every half's forward tree.
+// (Round 5: tile by LDS-DMA, swizzled, 16-byte accesses where a lane owns a pair: 3.28 -> 2.96 ms at 2^18 x 1024; forcing four waves
+// per SIMD costs 13 spilled registers and returns less: 3.08 ms.)
 // Tile = 2^max(ki, kf) rows (the top position bits) x 2^lt columns of a column of coefficients-to-be.  Reads N, writes N (coefficients,
 // scaled by 1/N) + 2^rate_bits N (first forward sweep of every half) -- instead of an inverse sweep (16 N) plus a forward sweep that
 // reads the coefficients once per half (16 N + 16 N at blowup 2).  The scaled coefficients wait in registers (16 per lane) while the
@@ -247,9 +433,10 @@ struct MidArgs {
 __global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
     extern __shared__ uint64_t smem[];
     const uint32_t k = a.kf > a.ki ? a.kf : a.ki, lt = a.lt, lo = a.L - k;
-    const uint32_t E = 1u << (k + lt), T = 1u << lt, R = 1u << k;
-    uint64_t* tile = smem;
-    uint64_t* twi = smem + (E + (E >> LOG_SEG));
+    constexpr uint32_t E = 4096;                           // k + lt = 12; lt >= 4 (k <= 8): a 16-byte pair is contiguous in HBM
+    const uint32_t T = 1u << lt, R = 1u << k;
+    uint64_t* tile = smem;                                 // swizzled like the DMA tiles (swz), no padding
+    uint64_t* twi = smem + E;
     uint64_t* twf = twi + R;
     const uint32_t tiles_per_col = 1u << (lo - lt);
     uint32_t col, tix;
@@ -265,35 +452,50 @@ __global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
     uint64_t* lde = a.lde + ((size_t)col << (a.L + a.rate_bits));
     const uint32_t base = tix << lt;                       // the top pass: no bits above the tile's rows
     auto pos_of = [&](uint32_t e) -> uint32_t { return base + ((e >> lt) << lo) + (e & (T - 1)); };
-    tile_loop<SIPP_NTT_MLP>(
-        E, [&](uint32_t e) -> uint64_t { return co[pos_of(e)]; }, [&](uint32_t e, uint64_t v) { tile[lds_idx(e)] = v; });
+    {
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {                 // the tile by LDS-DMA (see tree_pass_dma_kernel)
+            const uint32_t P = ((c * 4 + wave) << 6) + lane;
+            const uint32_t pe = P ^ ((P >> 4) & 7u) ^ (((P >> 7) & 1u) << 3);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(size_t)(__attribute__((address_space(3))) void*)(tile + (((c * 4 + wave) << 6) << 1)));
+            const uint64_t* g = co + pos_of(2 * pe);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    }
     for (uint32_t J = threadIdx.x; J < R; J += blockDim.x) {
         if (!J) continue;
         const uint32_t lev = 31 - __clz(J);
         twi[J] = a.tw_inv[J - (1u << lev)];                // root node 0 of the flat table
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    tree_stages<false>(tile, E, k, lt, IdxPlain{}, TwLds{twi, k}, k - a.ki);
-    // coefficients: scaled, stored, kept (E / 256 = 16 per lane)
-    constexpr int PER = 16;
-    uint64_t c[PER];
+    tree_stages<false>(tile, E, k, lt, IdxSwz{}, TwLds{twi, k}, k - a.ki);
+    // coefficients: scaled, stored, kept (eight 16-byte pairs per lane)
+    constexpr int PER = 8;
+    ulonglong2 c[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const uint32_t e = threadIdx.x + u * 256;
-        c[u] = e < E ? gl::mul(tile[lds_idx(e)], a.scale) : 0;
+        const uint32_t e = 2 * (threadIdx.x + u * 256);
+        c[u] = *reinterpret_cast<const ulonglong2*>(tile + swz(e));
+        c[u].x = gl::mul(c[u].x, a.scale);
+        c[u].y = gl::mul(c[u].y, a.scale);
     }
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const uint32_t e = threadIdx.x + u * 256;
-        if (e < E) co[pos_of(e)] = c[u];
+        const uint32_t e = 2 * (threadIdx.x + u * 256);
+        *reinterpret_cast<ulonglong2*>(co + pos_of(e)) = c[u];
     }
     const uint32_t halves = 1u << a.rate_bits;
     for (uint32_t h = 0; h < halves; h++) {
-        __syncthreads();                                   // the previous half's stores (and twf readers) are done with LDS
+        __syncthreads();                                   // the previous half's readers (and twf readers) are done with LDS
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const uint32_t e = threadIdx.x + u * 256;
-            if (e < E) tile[lds_idx(e)] = c[u];
+            const uint32_t e = 2 * (threadIdx.x + u * 256);
+            *reinterpret_cast<ulonglong2*>(tile + swz(e)) = c[u];
         }
         const uint32_t Q = halves + h;
         for (uint32_t J = threadIdx.x; J < R; J += blockDim.x) {
@@ -302,15 +504,23 @@ __global__ void __launch_bounds__(256) tree_mid_kernel(MidArgs a) {
             twf[J] = a.tw_fwd[(Q << lev) + (J - (1u << lev))];
         }
         __syncthreads();
-        tree_stages<true>(tile, E, k, lt, IdxPlain{}, TwLds{twf, k}, k - a.kf);
+        tree_stages<true>(tile, E, k, lt, IdxSwz{}, TwLds{twf, k}, k - a.kf);
         uint64_t* out = lde + (size_t)h * n;
-        tile_loop<SIPP_NTT_MLP>(
-            E, [&](uint32_t e) -> uint64_t { return tile[lds_idx(e)]; }, [&](uint32_t e, uint64_t v) { out[pos_of(e)] = gl::canon(v); });
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const uint32_t e = 2 * (threadIdx.x + u * 256);
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + swz(e));
+            v.x = gl::canon(v.x);
+            v.y = gl::canon(v.y);
+            *reinterpret_cast<ulonglong2*>(out + pos_of(e)) = v;
+        }
     }
 }
 
 // inverse, first sweep: natural-order values -> the k2 leaf-most levels.  Tile = 16 groups of 2^k2 positions that differ in their
 // top four position bits, i.e. in the low four bits of the natural index: every global read is a full 128-byte line.
+// (Round 5: node constants of both rounds requested ahead of the tile as 16-byte loads, swizzled 32-KB tile, 16-byte LDS / store
+// accesses: 1.62 -> 1.20 ms at 2^18 x 1024, 0.40 -> 0.30 ms at 2^16 x 1024.)
 struct GatherArgs {
     const uint64_t* in;     // [ncols][n] values, natural order
     uint64_t* out;          // [ncols][n] positions (leaf order) after the k2 lowest levels
@@ -319,11 +529,13 @@ struct GatherArgs {
     uint32_t ncols, colfast;
 };
 
-__global__ void __launch_bounds__(256) tree_gather_kernel(GatherArgs a) {
-    extern __shared__ uint64_t smem[];
-    const uint32_t k2 = a.k2, R2 = 1u << k2, E = 16u << k2;
-    const IdxBlocked lidx{k2};
-    uint64_t* tile = smem;
+// tile layout: element e = (g << 8) | r at gswz(e) -- the swizzle of the DMA tiles plus the group's upper three bits on element bits
+// 1 .. 3, so that the load phase (a wave writes sixteen groups at once) spreads over the banks as well; exactly 32 KB
+__device__ __forceinline__ uint32_t gswz(uint32_t e) { return swz(e) ^ (((e >> 9) & 7u) << 1); }
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tree_gather_kernel(GatherArgs a) {
+    extern __shared__ uint64_t tile[];
+    constexpr uint32_t k2 = 8, E = 16u << k2;
     const uint32_t mid_bits = a.L - 4 - k2;
     uint32_t col, mid;
     if (a.colfast) {
@@ -336,6 +548,34 @@ __global__ void __launch_bounds__(256) tree_gather_kernel(GatherArgs a) {
     const uint64_t* in = a.in + ((size_t)col << a.L);
     uint64_t* out = a.out + ((size_t)col << a.L);
     const uint32_t nat_mid = gl::bitrev(mid, mid_bits) << 4;
+    // lane (g, b): group g = top four position bits, its blocks hang under node zg of level L - k2
+    const uint32_t b = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const uint32_t zg = (g << mid_bits) + mid;
+    // node constants of BOTH rounds are requested before the tile: round 1's (levels 7 .. 4 below zg: 8 + 4 + 2 + 1 consecutive
+    // entries per lane) come back ahead of the tile, round 2's (levels 3 .. 0: fifteen per group) wait in registers -- no round starts
+    // with a table access in its critical path (the round-4 kernel: fifteen 8-byte loads at the head of each round)
+    uint64_t w7[8], w6[4], w5[2], w4, wt[15];
+    {
+        const ulonglong2* p7 = reinterpret_cast<const ulonglong2*>(a.tw + ((size_t)zg << 7) + 8 * b);
+        const ulonglong2* p6 = reinterpret_cast<const ulonglong2*>(a.tw + ((size_t)zg << 6) + 4 * b);
+        const ulonglong2* p5 = reinterpret_cast<const ulonglong2*>(a.tw + ((size_t)zg << 5) + 2 * b);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const ulonglong2 v = p7[m];
+            w7[2 * m] = v.x;
+            w7[2 * m + 1] = v.y;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const ulonglong2 v = p6[m];
+            w6[2 * m] = v.x;
+            w6[2 * m + 1] = v.y;
+        }
+        const ulonglong2 v5 = p5[0];
+        w5[0] = v5.x;
+        w5[1] = v5.y;
+        w4 = a.tw[((size_t)zg << 4) + b];
+    }
     tile_loop<SIPP_NTT_MLP>(
         E,
         [&](uint32_t e) -> uint64_t {
@@ -344,17 +584,66 @@ __global__ void __launch_bounds__(256) tree_gather_kernel(GatherArgs a) {
         },
         [&](uint32_t e, uint64_t v) {
             const uint32_t gq = e & 15, r = e >> 4;
-            tile[lidx((gl::bitrev(gq, 4) << k2) | r)] = v;
+            tile[gswz((gl::bitrev(gq, 4) << k2) | r)] = v;
         });
+#pragma unroll
+    for (int lev = 0; lev < 4; lev++)
+#pragma unroll
+        for (int q = 0; q < (1 << lev); q++) wt[(1 << lev) - 1 + q] = a.tw[((size_t)zg << lev) + q];
     __syncthreads();
-    // group g = top four position bits: its blocks hang under node (g << mid_bits) + mid of level L - k2
-    tree_stages<false>(tile, E, k2, 0, lidx, TwGlobal{a.tw, mid, 1u << mid_bits});
-    tile_loop<SIPP_NTT_MLP>(
-        E, [&](uint32_t e) -> uint64_t { return tile[lidx(e)]; },
-        [&](uint32_t e, uint64_t v) {
-            const uint32_t g = e >> k2, r = e & (R2 - 1);
-            out[((size_t)g << (a.L - 4)) | ((size_t)mid << k2) | r] = v;
-        });
+    uint64_t x[16];
+    // round 1: position strides 1 .. 8 -- the lane's sixteen consecutive positions, 16 bytes per LDS access
+    {
+        const uint32_t e0 = (g << k2) | (b << 4);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + gswz(e0 + 2 * m));
+            x[2 * m] = v.x;
+            x[2 * m + 1] = v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) bfly_inv(x[i], x[i + 1], w7[i >> 1]);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (!(i & 2)) bfly_inv(x[i], x[i + 2], w6[i >> 2]);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (!(i & 4)) bfly_inv(x[i], x[i + 4], w5[i >> 3]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) bfly_inv(x[i], x[i + 8], w4);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            ulonglong2 v;
+            v.x = x[2 * m];
+            v.y = x[2 * m + 1];
+            *reinterpret_cast<ulonglong2*>(tile + gswz(e0 + 2 * m)) = v;
+        }
+    }
+    __syncthreads();
+    // round 2: position strides 16 .. 128; the constants depend on the group alone
+    {
+        const uint32_t e0 = (g << k2) | b;
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = tile[gswz(e0 + 16 * i)];
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+            const int lev = 3 - sg;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (i & (1 << sg)) continue;
+                bfly_inv(x[i], x[i + (1 << sg)], wt[(1 << lev) - 1 + (i >> (sg + 1))]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) tile[gswz(e0 + 16 * i)] = x[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++) {
+        const uint32_t e = 2 * (c * 256 + threadIdx.x);
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + gswz(e));
+        *reinterpret_cast<ulonglong2*>(out + (((size_t)(e >> k2)) << (a.L - 4) | ((size_t)mid << k2) | (e & 255u))) = v;
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -417,6 +706,19 @@ std::vector<uint32_t> split_bits(uint32_t rem) {
     return ks;
 }
 
+int launch_fwd_dma(sipp_ctx* ctx, const TreeArgs& t, unsigned halves) {
+    DmaArgs a{};
+    a.in = t.in; a.out = t.out; a.in_stride = t.in_stride; a.out_stride = t.out_stride; a.in_half = t.in_half; a.out_half = t.out_half;
+    a.L = t.L; a.q0 = t.q0; a.ncols = t.ncols; a.halves = halves; a.tw = t.tw;
+    const size_t work = ((size_t)t.ncols << (t.L - 12)) * halves;
+    if (work > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
+    a.work = (uint32_t)work;
+    ProfScope ps(ctx, "ntt_tree_fwd");
+    hipLaunchKernelGGL(tree_fwd_dma_kernel, dim3((unsigned)work), dim3(256), 4096 * sizeof(uint64_t), ctx->stream, a);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
+
 template <bool FWD, bool TWLDS>
 int launch_pass(sipp_ctx* ctx, const char* name, TreeArgs& a, unsigned halves) {
     const uint32_t log_e = a.k + a.lt + a.lg;
@@ -428,6 +730,14 @@ int launch_pass(sipp_ctx* ctx, const char* name, TreeArgs& a, unsigned halves) {
     if (shmem > 64 * 1024)
         SIPP_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     a.colfast = (uint32_t)tree_colfast();
+    // full tiles of the strided sweeps: the DMA kernel (a pair of elements must be contiguous in HBM: lt >= 1)
+    if (TWLDS && a.lo > 0 && log_e == 12 && a.lg == 0 && a.lt >= 1 && a.scale == 0) {
+        const size_t sh = (4096 + ((size_t)1 << a.k)) * sizeof(uint64_t);
+        ProfScope psd(ctx, name);
+        hipLaunchKernelGGL(tree_pass_dma_kernel<FWD>, dim3((unsigned)tiles, halves), dim3(256), sh, ctx->stream, a);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        return SIPP_OK;
+    }
     ProfScope ps(ctx, name);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, halves), dim3(256), shmem, ctx->stream, a);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
@@ -469,6 +779,7 @@ int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_
     a.in_half = first ? 0 : n;
     a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
     a.L = L; a.k = kc; a.lo = 0; a.lt = 0; a.lg = 0; a.q0 = halves; a.tw = tw; a.scale = 0; a.ncols = (uint32_t)ncols;
+    if (kc == LTILE) return launch_fwd_dma(ctx, a, halves);      // shorter columns (sipp_tree_coset_eval): the register-staged kernel
     return launch_pass<true, false>(ctx, "ntt_tree_fwd", a, halves);
 }
 
@@ -498,7 +809,7 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
         g.in = d_values; g.out = d_coeffs; g.L = L; g.k2 = k2; g.tw = twi; g.ncols = (uint32_t)ncols;
         g.colfast = (uint32_t)tree_colfast();
         const size_t E = (size_t)16 << k2;
-        const size_t shmem = (E + (E >> LOG_SEG) + 16) * sizeof(uint64_t);
+        const size_t shmem = E * sizeof(uint64_t);               // swizzled, no padding: five blocks per CU
         const size_t tiles = ((size_t)1 << (L - 4 - k2)) * ncols;
         if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
         ProfScope ps(ctx, "ntt_tree_gather");
@@ -524,7 +835,7 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
         m.tw_inv = twi; m.tw_fwd = twf; m.scale = gl::inv((uint64_t)1 << L); m.ncols = (uint32_t)ncols;
         m.colfast = (uint32_t)tree_colfast();
         const size_t E = (size_t)1 << LTILE;
-        const size_t shmem = (E + (E >> LOG_SEG) + ((size_t)2 << km)) * sizeof(uint64_t);
+        const size_t shmem = (E + ((size_t)2 << km)) * sizeof(uint64_t);       // swizzled tile + the two constant heaps
         const size_t tiles = ((size_t)1 << (L - LTILE)) * ncols;
         if (tiles > 0x7fffffffull) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "tree ntt: too many tiles for one launch");
         ProfScope ps(ctx, "ntt_tree_mid");
@@ -546,7 +857,7 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
     a.in = d_lde; a.in_stride = n << rate_bits; a.in_half = n;
     a.out = d_lde; a.out_stride = n << rate_bits; a.out_half = n;
     a.L = L; a.k = LTILE; a.lo = 0; a.lt = 0; a.lg = 0; a.q0 = halves; a.tw = twf; a.scale = 0; a.ncols = (uint32_t)ncols;
-    return launch_pass<true, false>(ctx, "ntt_tree_fwd", a, halves);
+    return launch_fwd_dma(ctx, a, halves);
 }
 
 int sipp_tree_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols,
