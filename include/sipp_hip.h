@@ -61,9 +61,24 @@ typedef struct {
     uint32_t pow_rule;        /* SIPP_POW_DUPLEX (0): observe the witness, response = next challenge (plonky2 fri/prover.rs
                                  of 2023); SIPP_POW_HASH (1): response = hash_no_pad(challenger.get_hash() || witness)[0]
                                  (the earlier rule).  Kept as data until upstream's pinned revision can be read. */
+    uint32_t fs_rule;         /* where Fiat-Shamir starts.  SIPP_FS_STATEMENT (0, default): this repository's format -- the challenger
+                                 observes the statement (kind, shape, config, Merkle root of the public inputs) before the trace cap;
+                                 SIPP_FS_UPSTREAM (1): starky's order as recalled: the challenger starts at the
+                                 trace cap, the public inputs are NOT in the transcript (upstream's exposure: a verifier must bind them
+                                 by other means, as the recursive circuit does by connecting them to its own targets) */
+    uint32_t lookup_rule;     /* challenges of a lookup's two permutation factors.  SIPP_LOOKUP_INDEPENDENT (0, default):
+                                 Z' (pin + gamma)(ptab + beta) = Z (col + gamma)(tab + beta) -- column and table cannot trade entries;
+                                 SIPP_LOOKUP_SHARED (1): both factors use gamma, (beta, gamma) are drawn as before and beta is unused
+                                 -- starky's permutation pairs of ONE column each as recalled (reduce_with_powers over a single
+                                 column leaves beta^0), which proves only the union multiset.  Header word 15 of a flat proof
+                                 records fs_rule | lookup_rule << 1. */
 } sipp_stark_config;
 #define SIPP_POW_DUPLEX 0
 #define SIPP_POW_HASH 1
+#define SIPP_FS_STATEMENT 0
+#define SIPP_FS_UPSTREAM 1
+#define SIPP_LOOKUP_INDEPENDENT 0
+#define SIPP_LOOKUP_SHARED 1
 
 void sipp_default_config(sipp_stark_config *cfg);
 

@@ -26,7 +26,8 @@ Ext = g.Ext
 ROOT = g.ROOT
 MAGIC = 0x5349505053544b31
 
-DEFAULT = dict(rate_bits=1, cap_height=4, pow_bits=16, arity_bits=4, final_poly_bits=5, num_queries=84, num_challenges=2, pow_rule=0)
+DEFAULT = dict(rate_bits=1, cap_height=4, pow_bits=16, arity_bits=4, final_poly_bits=5, num_queries=84, num_challenges=2, pow_rule=0, fs_rule=0,
+               lookup_rule=0)
 
 _TABLES = None
 
@@ -265,7 +266,7 @@ def verify(proof, cfg=None):
     a = air_of(kind, log_n)
     if a is None or W != a["n_main"] + 2 * a["n_checked"] or Pz != 2 * a["n_checked"] or Q != 4 or cap_h != cfg["cap_height"] or \
             nq != cfg["num_queries"] or ppi != a["pi_per_io"] or total != len(pf) or rate_bits != cfg["rate_bits"] or \
-            arity_bits != cfg["arity_bits"] or zero != 0:
+            arity_bits != cfg["arity_bits"] or zero != (cfg["fs_rule"] | (cfg["lookup_rule"] << 1)):
         return "header / configuration"
     n = 1 << log_n
     arities = g.reduction_arity_bits(cfg["arity_bits"], cfg["final_poly_bits"], log_n, rate_bits, cap_h)
@@ -285,9 +286,10 @@ def verify(proof, cfg=None):
         pos[0] += k
         return v
     ch = g.Challenger()
-    ch.observe_many([kind, log_n, num_io, W, Pz, Q, rate_bits, cap_h, cfg["pow_bits"], arity_bits, cfg["final_poly_bits"], nq,
-                     cfg["num_challenges"], cfg["pow_rule"], ppi, 0])
-    ch.observe_many(pi_root(pis, num_io, ppi))
+    if not cfg["fs_rule"]:        # this repository's format; fs_rule = 1: starky's recalled order, nothing before the trace cap
+        ch.observe_many([kind, log_n, num_io, W, Pz, Q, rate_bits, cap_h, cfg["pow_bits"], arity_bits, cfg["final_poly_bits"], nq,
+                         cfg["num_challenges"], cfg["pow_rule"], ppi, cfg["lookup_rule"]])
+        ch.observe_many(pi_root(pis, num_io, ppi))
     ncap = 1 << cap_h
     caps3 = []
     trace_cap = [take(4) for _ in range(ncap)]
@@ -296,6 +298,8 @@ def verify(proof, cfg=None):
     for i in range(2):
         betas[i] = ch.get()
         gammas[i] = ch.get()
+        if cfg["lookup_rule"]:    # both factors of a lookup under gamma
+            betas[i] = gammas[i]
     z_cap = [take(4) for _ in range(ncap)]
     ch.observe_cap(z_cap)
     alphas = [ch.get(), ch.get()]

@@ -7,17 +7,17 @@
  * and A.11.  Reached from the reference only through src/verifier_circuit.rs:133-135.
  * Deterministic: the proof-of-work witness is the SMALLEST valid nonce.
  *
- * Fiat-Shamir binds the STATEMENT first (this repository's proof format, not upstream's starky of mid-2023, which
- * started from the trace cap): before the trace cap the challenger observes
+ * Fiat-Shamir binds the STATEMENT first (this repository's proof format, cfg->fs_rule = 0; upstream's starky of mid-2023
+ * started from the trace cap: cfg->fs_rule = 1 reproduces that order): before the trace cap the challenger observes
  *   kind, log_n, num_io, W, P, Q, rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries,
- *   num_challenges, pow_rule, pi_per_io, 0                                      (16 elements)
+ *   num_challenges, pow_rule, pi_per_io, lookup_rule                             (16 elements)
  *   pi_root[4] = Merkle root (two_to_one) over d_io = hash_no_pad(the pi_per_io u32 words of IO record io)
  * Public inputs must be canonical: every Fq element of a record < p (checked by prover and verifier), so the
  * result cells, which the AIR only range-checks to < 2^256, cannot smuggle a non-canonical output into the statement.
  *
  * Flat proof layout (u64 words; shared with the HIP prover):
  *   header[16]: magic, kind, log_n, num_io, W, P, Q, cap_height, n_fri_rounds, final_poly_len, num_queries,
- *               pi_per_io, total_len, 0, 0, 0
+ *               pi_per_io, total_len, rate_bits, arity_bits, fs_rule | lookup_rule << 1
  *   trace_cap | z_cap | quotient_cap                       (each 2^cap_height x 4)
  *   openings: local[W] next[W] z[P] z_next[P] quotient[Q]  (ext: 2 words each)
  *   fri commit caps [n_rounds][2^cap_height x 4] | final_poly[len] ext | pow_witness
@@ -36,6 +36,7 @@
 void orc_default_config(orc_config *c) {
     c->rate_bits = 1; c->cap_height = 4; c->pow_bits = 16; c->arity_bits = 4; c->final_poly_bits = 5;
     c->num_queries = 84; c->num_challenges = 2; c->pow_rule = ORC_POW_DUPLEX;
+    c->fs_rule = 0; c->lookup_rule = 0;
 }
 
 /* ---------------- statement binding ---------------- */
@@ -93,9 +94,10 @@ void orc_pi_root(const uint32_t *pis, size_t num_io, int ppi, uint64_t root[4]) 
 
 static void observe_statement(orc_challenger *ch, int kind, unsigned log_n, size_t num_io, int W, int P, int Q,
                               const orc_config *cfg, int ppi, const uint32_t *pis) {
+    if (cfg->fs_rule) return;   /* starky's recalled order: nothing before the trace cap (the public inputs stay outside the transcript) */
     uint64_t st[16] = {(uint64_t)kind, log_n, num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg->rate_bits, cfg->cap_height,
                        cfg->pow_bits, cfg->arity_bits, cfg->final_poly_bits, cfg->num_queries, cfg->num_challenges,
-                       cfg->pow_rule, (uint64_t)ppi, 0};
+                       cfg->pow_rule, (uint64_t)ppi, cfg->lookup_rule};
     uint64_t root[4];
     orc_chal_observe_many(ch, st, 16);
     orc_pi_root(pis, num_io, ppi, root);
@@ -180,7 +182,8 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     const uint64_t g = gl_root_of_unity(log_n);
     wbuf pf = {0, 0, 0};
     uint64_t hdr[16] = {MAGIC, (uint64_t)kind, log_n, t->num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg->cap_height,
-                        fri_rounds(cfg, log_n), 0, cfg->num_queries, (uint64_t)a->pi_per_io, 0, cfg->rate_bits, cfg->arity_bits, 0};
+                        fri_rounds(cfg, log_n), 0, cfg->num_queries, (uint64_t)a->pi_per_io, 0, cfg->rate_bits, cfg->arity_bits,
+                        (uint64_t)(cfg->fs_rule | (cfg->lookup_rule << 1))};
     wb_push(&pf, hdr, 16);
     const size_t cap_n = (size_t)1 << (cfg->cap_height < log_m ? cfg->cap_height : log_m);
 
@@ -193,7 +196,10 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     wb_push(&pf, orc_batch_cap(bt), cap_n * 4);
     /* 2. permutation challenges and Z polys */
     uint64_t beta[2], gamma[2];
-    for (int i = 0; i < 2; i++) { beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch); }
+    for (int i = 0; i < 2; i++) {
+        beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch);
+        if (cfg->lookup_rule) beta[i] = gamma[i];   /* shared challenge: Z' (pin + g)(ptab + g) = Z (col + g)(tab + g) */
+    }
     uint64_t *zv = (uint64_t *)malloc((size_t)P * n * sizeof(uint64_t));
 #pragma omp parallel
     {
@@ -366,7 +372,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     const air_spec_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||
-        h[14] != cfg->arity_bits || h[15] != 0)
+        h[14] != cfg->arity_bits || h[15] != (uint64_t)(cfg->fs_rule | (cfg->lookup_rule << 1)) || cfg->fs_rule > 1 || cfg->lookup_rule > 1)
         return -102;
     const size_t n = (size_t)1 << log_n;
     const unsigned rounds = fri_rounds(cfg, log_n);
@@ -393,7 +399,10 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     const uint64_t *trace_cap = rb_take(&rb, cap_n * 4);
     orc_chal_observe_cap(&ch, trace_cap, cap_n);
     uint64_t beta[2], gamma[2], alpha[2];
-    for (int i = 0; i < 2; i++) { beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch); }
+    for (int i = 0; i < 2; i++) {
+        beta[i] = orc_chal_get(&ch); gamma[i] = orc_chal_get(&ch);
+        if (cfg->lookup_rule) beta[i] = gamma[i];
+    }
     const uint64_t *z_cap = rb_take(&rb, cap_n * 4);
     orc_chal_observe_cap(&ch, z_cap, cap_n);
     alpha[0] = orc_chal_get(&ch); alpha[1] = orc_chal_get(&ch);

@@ -9,6 +9,10 @@
 typedef struct {
     uint32_t rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries, num_challenges;
     uint32_t pow_rule; /* ORC_POW_DUPLEX (default) or ORC_POW_HASH: which recollection of upstream's grind rule (stark.c) */
+    uint32_t fs_rule;     /* 0 (default): the statement is observed before the trace cap (this repository's format); 1: starky's
+                             recalled order -- the challenger starts at the trace cap */
+    uint32_t lookup_rule; /* 0 (default): independent (beta, gamma) for a lookup's two permutation factors; 1: both factors under
+                             gamma (starky's single-column permutation pairs as recalled; beta drawn and unused) */
 } orc_config;
 #define ORC_POW_DUPLEX 0
 #define ORC_POW_HASH 1

@@ -20,6 +20,10 @@ pub struct SippStarkConfig {
     pub num_challenges: u32,
     /// 0 = duplex grind (plonky2 fri/prover.rs of 2023), 1 = hash grind (the earlier rule)
     pub pow_rule: u32,
+    /// 0 = the statement is observed before the trace cap (this library's format), 1 = starky's recalled order (starts at the trace cap)
+    pub fs_rule: u32,
+    /// 0 = independent (beta, gamma) per lookup factor, 1 = both factors under gamma (single-column permutation pairs as recalled)
+    pub lookup_rule: u32,
 }
 
 pub const SIPP_G1_EXP: c_int = 0;

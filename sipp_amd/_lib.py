@@ -25,7 +25,7 @@ class SippError(RuntimeError):
 
 class StarkConfig(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "arity_bits", "final_poly_bits",
-                                          "num_queries", "num_challenges", "pow_rule")]
+                                          "num_queries", "num_challenges", "pow_rule", "fs_rule", "lookup_rule")]
 
 
 class FriParams(C.Structure):

@@ -20,6 +20,8 @@ void sipp_default_config(sipp_stark_config* cfg) {
     cfg->num_queries = 84;
     cfg->num_challenges = 2;
     cfg->pow_rule = SIPP_POW_DUPLEX;
+    cfg->fs_rule = SIPP_FS_STATEMENT;
+    cfg->lookup_rule = SIPP_LOOKUP_INDEPENDENT;
 }
 
 // The stream of a ctx.  level > 0: a high-priority stream.  Otherwise a stream with a HARDWARE QUEUE OF ITS OWN: the runtime
@@ -62,7 +64,7 @@ int sipp_ctx_create(sipp_ctx** out, int device, const sipp_stark_config* cfg, si
     // blowup 2 / 4 / 8, reduction arity 2 / 4 / 8 / 16 (constant), two challenges (the AIRs' quotient kernels fold exactly two)
     if (ctx->cfg.rate_bits < 1 || ctx->cfg.rate_bits > 3 || ctx->cfg.num_challenges != 2 || ctx->cfg.arity_bits < 1 ||
         ctx->cfg.arity_bits > 4 || ctx->cfg.cap_height > 8 || ctx->cfg.pow_bits > 32 || ctx->cfg.pow_rule > SIPP_POW_HASH ||
-        ctx->cfg.num_queries == 0 || ctx->cfg.num_queries > 1024 || ctx->cfg.final_poly_bits > 12) {
+        ctx->cfg.fs_rule > SIPP_FS_UPSTREAM || ctx->cfg.lookup_rule > SIPP_LOOKUP_SHARED || ctx->cfg.num_queries == 0 || ctx->cfg.num_queries > 1024 || ctx->cfg.final_poly_bits > 12) {
         delete ctx;
         return SIPP_E_UNSUPPORTED;
     }

@@ -324,7 +324,8 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     };
     {
         uint64_t hdr[16] = {SIPP_MAGIC, (uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.cap_height,
-                            R, (uint64_t)final_len, nq, (uint64_t)a->pi_per_io, total_words, cfg.rate_bits, cfg.arity_bits, 0};
+                            R, (uint64_t)final_len, nq, (uint64_t)a->pi_per_io, total_words, cfg.rate_bits, cfg.arity_bits,
+                            (uint64_t)(cfg.fs_rule | (cfg.lookup_rule << 1))};
         push(hdr, 16);
     }
 
@@ -368,11 +369,12 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     // ---- 1. trace commitment ----
     SIPP_TRY(commit_values_launch(ctx, d_trace, (size_t)W, log_n, T.coeffs, T.lde, T.tree));
     // Fiat-Shamir starts from the statement (hashed on the host while the commitment kernels run)
+    // (cfg.fs_rule = SIPP_FS_UPSTREAM: starky's recalled order instead -- the challenger starts at the trace cap)
     host::Challenger ch;
-    {
+    if (cfg.fs_rule == SIPP_FS_STATEMENT) {
         const uint64_t st[16] = {(uint64_t)kind, log_n, s.num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.rate_bits,
                                  cfg.cap_height, cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries,
-                                 cfg.num_challenges, cfg.pow_rule, (uint64_t)a->pi_per_io, 0};
+                                 cfg.num_challenges, cfg.pow_rule, (uint64_t)a->pi_per_io, (uint64_t)cfg.lookup_rule};
         uint64_t root[4];
         ch.observe_many(st, 16);
         pi_root(pis.data(), s.num_io, a->pi_per_io, root);
@@ -388,6 +390,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     for (int i = 0; i < 2; i++) {
         beta[i] = ch.get();
         gamma[i] = ch.get();
+        if (cfg.lookup_rule == SIPP_LOOKUP_SHARED) beta[i] = gamma[i];     // both factors of a lookup under ONE challenge (sipp_hip.h)
     }
     {
         ArenaMark mz = arena_mark(ctx);

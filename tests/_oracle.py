@@ -204,7 +204,7 @@ def map_to_g2(u_words):
 # ---------------- STARK prover / verifier (oracle/stark.c) ----------------
 class OrcConfig(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "pow_bits", "arity_bits", "final_poly_bits",
-                                          "num_queries", "num_challenges", "pow_rule")]
+                                          "num_queries", "num_challenges", "pow_rule", "fs_rule", "lookup_rule")]
 
 
 def default_config():

@@ -434,6 +434,44 @@ def test_other_blowups_arities_and_pow_rules_match_the_oracle(ios4, rate_bits, a
             ctx.close()
 
 
+@pytest.mark.parametrize("fs_rule,lookup_rule", [(1, 0), (0, 1), (1, 1)])
+def test_protocol_rules_match_the_oracle_word_for_word(ios4, fs_rule, lookup_rule):
+    """sipp_stark_config.fs_rule / lookup_rule (include/sipp_hip.h): starky's recalled transcript order (challenger
+    starts at the trace cap) and single-column permutation pairs under one challenge, as DATA next to pow_rule.  Full-size
+    configuration (84 queries, 16 grinding bits), every plain kind and a hardened one: the GPU proof is the oracle's word for word
+    and both verifiers accept it under the same rules.  Rule 0 / 0 stays the default (the committed digests do not move)."""
+    import ctypes as C
+    import sipp_amd
+    from oracle.py import stark_verify as sv
+    cfg = sipp_amd.default_config()
+    ocfg = _oracle.default_config()
+    for c in (cfg, ocfg):
+        c.fs_rule, c.lookup_rule = fs_rule, lookup_rule
+    L = sipp_amd.lib()
+    for kind in (0, 1, 2, 4):
+        ios = ios4[kind & 3]
+        ctx = sipp_amd.Ctx(cfg=cfg, workspace_bytes=L.sipp_workspace_bytes_cfg(kind, ios.shape[0], C.byref(cfg)))
+        try:
+            if kind >= 4:
+                ctx._ck(L.sipp_ctx_set_hardened(ctx.h, 1), "set_hardened")
+            got = ctx.prove(kind & 3, ios)
+        finally:
+            ctx.close()
+        ref = _oracle.stark_prove(kind, ios, ocfg)
+        assert int(got[1]) == kind and int(got[15]) == (fs_rule | lookup_rule << 1)
+        assert len(got) == len(ref)
+        diff = np.nonzero(got != ref)[0]
+        assert diff.size == 0, "kind %d: first mismatch at word %d (%s)" % (kind, diff[0], locate(ref, int(diff[0])))
+        assert _oracle.stark_verify(got, ocfg) == 0
+        assert _oracle.stark_verify(got) == -102            # not a proof under the default rules
+        if kind == 0:
+            assert sv.verify(got, dict(fs_rule=fs_rule, lookup_rule=lookup_rule)) is None
+    bad = sipp_amd.default_config()
+    bad.fs_rule = 2
+    h = C.c_void_p()
+    assert L.sipp_ctx_create(C.byref(h), 0, C.byref(bad), 1 << 20) == -7       # SIPP_E_UNSUPPORTED
+
+
 def test_g2_cofactor_clearing_runs_through_the_g2_exp_stark(ctx):
     """SURVEY 8f rank 4 (reference src/bin/bls_aggregation.rs:65,103-106), the arithmetic half: messages mapped to E'(Fp2) are
     multiplied by the cofactor 2p - r.  That is a G2 obligation out = offset + [exp] x with exp = cofactor (254 bits) on points
