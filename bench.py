@@ -92,6 +92,14 @@ def all_ranks_true(flag, device):
     return bool(lo > 0.5)
 
 
+def price_vs_world1(lists, world, hardened):
+    from sipp_amd import proof_cost
+    one = proof_cost.instance_price(lists, 1, hardened)
+    w = proof_cost.instance_price(lists, world, hardened)
+    return {"proofs": w["proofs"], "proof_words": w["proof_words"], "query_openings": w["query_openings"], "verifier_hashes": w["verifier_hashes"],
+            "proof_words_vs_world1": w["proof_words"] / one["proof_words"], "verifier_hashes_vs_world1": w["verifier_hashes"] / one["verifier_hashes"]}
+
+
 def air_revision():
     """the AIR is this repository's own specification (tools/air_gen.py): identify the revision the numbers belong to"""
     import hashlib
@@ -563,9 +571,12 @@ def main():
                                         "rank_ms_per_instance_min_max": [1e3 * lo / k_s, 1e3 * hi / k_s],
                                         "host_threads_per_rank": 1 if si_single else 4,
                                         # True: one ctx / one arena, the three proofs back to back (the three arenas together would
-                                        # exceed 60 % of the card's memory: n = 4096 on one rank)
+                                        # exceed 90 % of the card's memory, or what is free of it: n = 4096 on one rank)
                                         "single_ctx": si_single, "kinds": kinds,
-                                        "records_of_rank0": [int(a.shape[0]) for a in mine]}
+                                        "records_of_rank0": [int(a.shape[0]) for a in mine],
+                                        # what this sharding costs the verifier side (sipp_amd/proof_cost.py, counted from the proofs'
+                                        # shapes): 3 * world proofs instead of 3 for the recursive verifier behind verifier_circuit.rs:133-147
+                                        "verifier_price": price_vs_world1([a.shape[0] for a in load_ios(n_s)], world, hardened)}
     if rank == 0:
         out["io_sharded"] = io_sharded
         print(json.dumps(out))

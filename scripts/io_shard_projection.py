@@ -45,4 +45,7 @@ for rank in range(world):
 worst = max(s["ms"] for s in shards)
 print(json.dumps({"n": n, "world": world, "whole_instance_on_one_gpu_ms": round(whole, 2), "shards_one_at_a_time": shards,
                   "slowest_shard_ms": worst, "projected_speedup": round(whole / worst, 2),
+                  # the other side of the ledger (sipp_amd/proof_cost.py): what the 3 * world proofs cost a verifier, against world = 1
+                  "verifier_price": {k: v for k, v in __import__("sipp_amd").proof_cost.instance_price([a.shape[0] for a in ios], world, False).items()},
+                  "verifier_price_world1": {k: v for k, v in __import__("sipp_amd").proof_cost.instance_price([a.shape[0] for a in ios], 1, False).items()},
                   "note": "projection: every shard timed alone on ONE MI355X; no data moves between ranks in level L-D"}))

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export SIPP_BENCH_IO_SHARD_N=0
 export SIPP_BENCH_MAP_G2=0       # the profiled command is the instance alone: no messages -> G2 leg,
-export SIPP_BENCH_OTHER_AIR=0    # no leg for the other AIR variant (SIPP_BENCH_HARDENED=0 in the environment profiles the plain kinds)
+export SIPP_BENCH_OTHER_AIR=0    # no leg for the other AIR variant (SIPP_BENCH_PLAIN_AIR=1 in the environment profiles the plain kinds)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --n $N --steps $STEPS --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log" || exit 1
 echo "stats done $N"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --n $N --steps 1 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log" || exit 1

@@ -160,6 +160,15 @@ def device_memory_bytes(device=0):
     return total.value
 
 
+def device_free_bytes(device=0):
+    """free memory of GPU `device` right now (sipp_device_memory)"""
+    free = C.c_size_t()
+    rc = lib().sipp_device_memory(int(device), C.byref(free), None)
+    if rc != 0:
+        raise SippError(rc, "device_memory")
+    return free.value
+
+
 def to_device(arr):
     """host uint64 ndarray -> device tensor (int64 bit pattern)"""
     import torch
@@ -516,7 +525,9 @@ class Instance:
         level = {"low": -1, "": 0, "normal": 0, "high": 1}
         ws = [self.L.sipp_workspace_bytes(k + 4 if (hardened and k < 2) else k, max(1, self.num_io[k])) for k in range(3)]
         if single_ctx is None:
-            single_ctx = len(set(devices)) == 1 and sum(ws) > self.SINGLE_CTX_SHARE * device_memory_bytes(devices[0])
+            # three arenas only where they fit what is FREE on the card now (other instances, a queue's earlier slots, torch's pool)
+            single_ctx = len(set(devices)) == 1 and sum(ws) > min(self.SINGLE_CTX_SHARE * device_memory_bytes(devices[0]),
+                                                                  device_free_bytes(devices[0]))
         self.single_ctx = bool(single_ctx)
         try:
             if self.single_ctx:
@@ -576,9 +587,17 @@ class InstanceQueue:
         self.L = lib()
         self.num_io = tuple(int(x) for x in num_io)
         self.slots = []
+        # every slot needs three DISTINCT ctxs (sipp_instances_prove refuses duplicate handles): no one-ctx fallback here -- say so
+        # before the first hipMalloc instead of failing in the middle of the slots
+        need = in_flight * sum(self.L.sipp_workspace_bytes(k + 4 if (hardened and k < 2) else k, max(1, self.num_io[k])) for k in range(3))
+        free = device_free_bytes(device)
+        if need > free:
+            raise SippError(-3, "InstanceQueue: %d slots x three arenas need %.1f GB, %.1f GB are free on device %d; lower in_flight "
+                                "(or prove such instances one at a time through Instance, which falls back to one arena)"
+                            % (in_flight, need / 2**30, free / 2**30, device))
         try:
             for _ in range(in_flight):
-                self.slots.append(Instance(self.num_io, devices=(device,) * 3, priorities=priorities, hardened=hardened))
+                self.slots.append(Instance(self.num_io, devices=(device,) * 3, priorities=priorities, hardened=hardened, single_ctx=False))
         except Exception:
             self.close()
             raise

@@ -1034,6 +1034,11 @@ int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace
     return SIPP_OK;
 }
 
+// PRECONDITION: every cell of d_lde / d_zlde / d_aux is CANONICAL (< p).  The lazy POLY path adds and subtracts +-1-coefficient
+// monomials with gl::add / gl::sub directly on raw operands (no product in between to canonicalise them): gl::sub(a, b) with b >= p
+// would be off by 2^32 - 1.  Every producer keeps this: the tree sweeps (ntt_tree.hip) and lde_column canonicalise at their last store
+// (gl::canon in the forward sweeps' store phase), the aux LDEs come from the same transforms.  A lazy store there would corrupt the
+// quotient and show only as a proof mismatch.
 int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const uint64_t* d_lde, const uint64_t* d_zlde,
                     size_t lde_stride, const uint64_t* d_aux, const uint64_t alpha[2], const uint64_t beta[2],
                     const uint64_t gamma[2], uint64_t* d_out) {
@@ -1194,7 +1199,7 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
     {
         ProfScope ps(ctx, "quotient_rest");
         // a thin domain (<= 2^15 points = 128 blocks) with many checked columns: the columns in up to 16 ranges of at least 32, two kernels
-        q.chunks = log_m <= 15 ? std::min(16, a->n_checked / 32) : 1;
+        q.chunks = (int)sipp_quotient_rest_chunks(log_n, a->n_checked);
         if (q.chunks > 1) {
             q.rest_part = arena_alloc_t<uint64_t>(ctx, (size_t)q.chunks * 6 * m);
             if (!q.rest_part) return SIPP_E_NOMEM;

@@ -7,6 +7,13 @@
 #include "host_poseidon.hpp"
 #include "poseidon_constants.h"
 
+// quotient_rest over a thin quotient domain (2N <= 2^15 points) walks its checked columns in up to sixteen ranges of at least 32 and
+// needs chunks x 6 sums per point of scratch; ONE rule for the kernel launch (prover.hip) and the arena size (stark.hip)
+inline uint32_t sipp_quotient_rest_chunks(uint32_t log_n, int n_checked) {
+    if (log_n + 1 > 15) return 1;
+    const int c = n_checked / 32 < 16 ? n_checked / 32 : 16;
+    return c > 1 ? (uint32_t)c : 1;
+}
 int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace, uint32_t log_n, const uint64_t beta[2],
                      const uint64_t gamma[2], uint64_t* d_zv);
 // quotient on the coset 7 <w_2N> (the first 2N leaves of the LDEs, whose columns are lde_stride apart); d_aux [n_aux][2N],

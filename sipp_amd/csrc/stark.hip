@@ -590,7 +590,8 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
                    + 3 * 8 * m                                          // three Merkle trees
                    + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
-                   + (m <= ((size_t)1 << 15) ? 96 * m : 0)                     // thin quotient domains: 16 column ranges x 6 sums (prover.hip)
+                   + (sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) > 1                 // thin QUOTIENT domains (2N points, whatever
+                          ? (size_t)sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) * 6 * 2 * n : 0)   // the blowup): ranges x 6 sums
                    + 80 * n;                                            // power tables, FRI layers, combine partials
     size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
                    + n * 400                                            // Jacobian row scratch of the curve chains
@@ -921,12 +922,17 @@ int sipp_instance_prove(sipp_ctx* const ctxs[3], const uint32_t* const ios[3], c
         // fallback, not the default.  Largest first, like the concurrent order.
         const int serial[3] = {SIPP_G2_EXP, SIPP_G1_EXP, SIPP_FQ12_EXP};
         for (int k = 0; k < 3; k++) proof_len[k] = 0;
+        int first_rc = SIPP_OK;      // like the three-ctx path: every proof is attempted, the first failing status is returned
         for (int i = 0; i < 3; i++) {
             const int k = serial[i];
             if (num_io[k] == 0) continue;
-            SIPP_TRY(sipp_prove(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k], &proof_len[k]));
+            const int rc = sipp_prove(ctxs[k], k, ios[k], num_io[k], proof_out[k], proof_cap[k], &proof_len[k]);
+            if (rc != SIPP_OK) {
+                proof_len[k] = 0;
+                if (first_rc == SIPP_OK) first_rc = rc;
+            }
         }
-        return SIPP_OK;
+        return first_rc;
     }
     if (ctxs[0] == ctxs[1] || ctxs[0] == ctxs[2] || ctxs[1] == ctxs[2]) return SIPP_E_BADARG;
     // The other two proofs start once the longest (G2) has its trace filled: its latency-bound chains and lookup kernels

@@ -12,24 +12,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def _regenerates_identically(script, outputs):
-    before = {p: open(os.path.join(ROOT, p)).read() for p in outputs}
-    try:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", script)], stdout=subprocess.DEVNULL)
-        for p in outputs:
-            assert open(os.path.join(ROOT, p)).read() == before[p], "%s is not what tools/%s emits" % (p, script)
-    finally:
-        for p, text in before.items():
-            open(os.path.join(ROOT, p), "w").write(text)
+def _regenerates_identically(script, outputs, tmp_path):
+    """the generator writes below tmp_path (--out-root); the tracked sources are only READ (their mtimes must not move: sipp_amd/build.py
+    would relink the library under a running test process)"""
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", script), "--out-root", str(tmp_path)], stdout=subprocess.DEVNULL)
+    for p in outputs:
+        assert open(os.path.join(str(tmp_path), p), "rb").read() == open(os.path.join(ROOT, p), "rb").read(), \
+            "%s is not what tools/%s emits" % (p, script)
 
 
-def test_poseidon_headers_are_current():
+def test_poseidon_headers_are_current(tmp_path):
     # (the generator also re-derives the fast partial-round tables and checks every form against the naive permutation before it writes)
-    _regenerates_identically("gen_poseidon_header.py", ["sipp_amd/csrc/poseidon_constants.h", "oracle/poseidon_constants.h"])
+    _regenerates_identically("gen_poseidon_header.py", ["sipp_amd/csrc/poseidon_constants.h", "oracle/poseidon_constants.h"], tmp_path)
 
 
-def test_interleaved_product_block_is_current():
-    _regenerates_identically("gen_gl_muln.py", ["sipp_amd/csrc/gl_lazy_muln.inc"])
+def test_interleaved_product_block_is_current(tmp_path):
+    _regenerates_identically("gen_gl_muln.py", ["sipp_amd/csrc/gl_lazy_muln.inc"], tmp_path)
 
 
 def test_matrix_pipe_models_reproduce_matrix_products():

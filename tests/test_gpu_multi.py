@@ -282,7 +282,7 @@ def test_one_ctx_instance_proves_back_to_back_the_same_words(hardened):
             for k in range(3):
                 assert int(got[k][1]) == (k + 4 if hardened and k < 2 else k)
                 assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), k
-        # the automatic choice: three arenas of this size are nowhere near 60 % of the card
+        # the automatic choice: three arenas of this size are nowhere near 90 % of the card (Instance.SINGLE_CTX_SHARE)
         auto = sipp_amd.Instance([a.shape[0] for a in ios], hardened=hardened)
         assert not auto.single_ctx
         auto.close()

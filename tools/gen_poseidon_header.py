@@ -636,14 +636,18 @@ def main():
     assert kat0[0] == 0x3c18a9786cb0b359 and kat0[11] == 0x1792b1c4342109d7
 
     hdr = "/* GENERATED by tools/gen_poseidon_header.py from data/poseidon_goldilocks_rc.txt -- do not edit. */\n"
-    with open(os.path.join(ROOT, "oracle", "poseidon_constants.h"), "w") as f:
+    # --out-root DIR: write below DIR instead of the repository (tests/test_generated_tables.py compares bytes; tracked files stay untouched)
+    out_root = sys.argv[sys.argv.index("--out-root") + 1] if "--out-root" in sys.argv else ROOT
+    os.makedirs(os.path.join(out_root, "oracle"), exist_ok=True)
+    os.makedirs(os.path.join(out_root, "sipp_amd", "csrc"), exist_ok=True)
+    with open(os.path.join(out_root, "oracle", "poseidon_constants.h"), "w") as f:
         f.write(hdr)
         f.write("#ifndef ORACLE_POSEIDON_CONSTANTS_H\n#define ORACLE_POSEIDON_CONSTANTS_H\n#include <stdint.h>\n")
         f.write("static const uint64_t POSEIDON_RC[360] = {\n" + fmt(rc) + "\n};\n")
         f.write("static const uint64_t POSEIDON_CIRC[12] = {%s};\n" % ", ".join(map(str, CIRC)))
         f.write("static const uint64_t POSEIDON_DIAG[12] = {%s};\n" % ", ".join(map(str, DIAG)))
         f.write("#endif\n")
-    with open(os.path.join(ROOT, "sipp_amd", "csrc", "poseidon_constants.h"), "w") as f:
+    with open(os.path.join(out_root, "sipp_amd", "csrc", "poseidon_constants.h"), "w") as f:
         f.write(hdr)
         f.write("#pragma once\n#include <stdint.h>\n")
         f.write("// index = 12*round + lane, rounds 0..29 (4 full, 22 partial, 4 full)\n")
