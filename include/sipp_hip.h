@@ -355,6 +355,43 @@ int sipp_plonk_prove_ex(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *
                         uint32_t n_public_inputs, const uint64_t *d_gate_terms, uint32_t num_gate_terms, uint64_t *proof_out,
                         size_t proof_cap, size_t *proof_len);
 
+/* ---- round 5: GATES AS DATA -- evaluate_gate_constraints on the device ---------------------------------------------------------------
+ * plonk/vanishing_poly.rs evaluate_gate_constraints / gates/gate.rs eval_filtered / gates/selectors.rs for a gate set the CALLER describes
+ * (the reference's circuit, src/verifier_circuit.rs:213-226, is built by un-vendored crates): a gate = its selector (which selector
+ * column, which value = the gate's index, the range of gate indices of its selector group) and a PROGRAM -- one polynomial per
+ * constraint over the row's wires, the constant columns and the public-inputs hash, as a sum of monomials.  Constraint term j of the
+ * circuit = sum over gates of filter_g * constraint_{g,j};  filter_g(s) = prod_{i in group, i != g} (i - s) * (UNUSED - s when the
+ * circuit has more than one selector column), UNUSED = 2^32 - 1.  The terms follow the permutation terms in ONE reduce_with_powers.
+ * Program words (int64, host memory): per constraint  n_mono, then per monomial  coef, n_factors, (kind, index) x n_factors;
+ * kind 0 = wire, 1 = constant column (index into the num_constants columns, selectors included), 2 = public_inputs_hash word. */
+typedef struct {
+    uint32_t selector_index, row, group_lo, group_hi;
+    uint32_t prog_offset, num_constraints;
+} sipp_plonk_gate;
+typedef struct {
+    uint32_t num_wires;       /* all wire columns of the wires oracle (>= num_routed_wires; 135 / 136 in plonky2's standard configs) */
+    uint32_t num_constants;   /* columns of the constants_sigmas oracle in front of the sigmas: num_selectors selector columns, then gate constants */
+    uint32_t num_selectors;
+    uint32_t num_gates;
+    const sipp_plonk_gate *gates;
+    const int64_t *programs;
+    uint32_t program_words;
+} sipp_plonk_circuit;
+/* prove() of plonk/prover.rs except witness generation: d_wires [num_wires][N] (the first num_routed_wires are routed) and
+ * d_constants_sigmas [num_constants + num_routed_wires][N] are VALUES in natural row order; the gate constraints are evaluated on the
+ * quotient coset by the interpreter inside the quotient kernel (no column per constraint is materialised).  Optional pre-committed
+ * oracles as for sipp_plonk_prove_ex (constants_sigmas once per circuit).  Flat proof "SIPPPLK3": header[16] = magic, log_n,
+ * num_routed_wires, max_degree, num_challenges, total_len, num_wires, num_constants, num_selectors, num_gates, num_gate_constraints,
+ * n_public_inputs, 0, 0, 0, 0 | wires cap | zs_partial_products cap | quotient cap | opening proof (zeta: every column of the four
+ * oracles constants_sigmas, wires, zs_partial_products, quotient chunks; g zeta: the Z columns) | public_inputs.
+ * SIPP_E_BADARG for a malformed circuit (an operand out of range, a program that runs past program_words). */
+size_t sipp_plonk_gates_proof_size(uint32_t log_n, const sipp_plonk_params *p, const sipp_fri_params *fp, const sipp_plonk_circuit *c,
+                                   uint32_t n_public_inputs);
+int sipp_plonk_prove_gates(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_t *d_constants_sigmas, const sipp_oracle *wires_oracle,
+                           const uint64_t *wires_cap, const sipp_oracle *constants_sigmas_oracle, uint32_t log_n, const sipp_plonk_params *p,
+                           const sipp_fri_params *fp, const sipp_plonk_circuit *c, const uint64_t circuit_digest[4],
+                           const uint64_t *public_inputs, uint32_t n_public_inputs, uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

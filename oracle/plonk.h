@@ -62,6 +62,44 @@ int orc_plonk_prove_ex(const uint64_t *wires, const uint64_t *sigmas, unsigned l
 int orc_plonk_verify_ex(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p, const orc_fri_params *fp,
                         const uint64_t circuit_digest[4], const orc_plonk_gates *g);
 
+/* ---- round 5: GATES AS DATA (plonk_gates.c) ------------------------------------------------------------------------------------------
+ * plonky2's evaluate_gate_constraints (plonk/vanishing_poly.rs) with the gate set given as DATA: a gate = its selector (which selector
+ * column, which value = the gate's index, the range of gate indices its group covers: gates/selectors.rs) and a PROGRAM -- one polynomial
+ * per constraint over the row's wires, constant columns and the public-inputs hash, as a sum of monomials.  Constraint term j of the
+ * circuit = sum over gates of filter_g * constraint_{g,j} (gate.rs eval_filtered adds into a shared vector), filter_g(s) = prod_{i in group,
+ * i != g} (i - s) * (UNUSED - s if the circuit has more than one selector column), UNUSED = 2^32 - 1.
+ * Oracles: constants_sigmas = [selectors | gate constants | sigmas of the routed wires] (num_constants columns in front of the sigmas),
+ * wires = ALL num_wires columns (the first num_routed_wires are routed), zs_partial_products, quotient chunks.
+ * Program words (int64): per constraint  n_mono, then per monomial  coef, n_factors, (kind, index) x n_factors;  kind 0 = wire,
+ * 1 = constant column (index into the num_constants columns: selectors included), 2 = public_inputs_hash word. */
+typedef struct {
+    uint32_t selector_index, row, group_lo, group_hi;
+    uint32_t prog_offset, num_constraints;
+} orc_plonk_gate;
+typedef struct {
+    uint32_t num_wires, num_constants, num_selectors, num_gates;
+    const orc_plonk_gate *gates;
+    const int64_t *programs;
+    uint32_t program_words;
+} orc_plonk_circuit;
+#define ORC_UNUSED_SELECTOR 0xffffffffULL
+uint32_t orc_plonk_num_gate_constraints(const orc_plonk_circuit *c);
+/* 0 if the programs are well formed (operands in range, lengths consistent) */
+int orc_plonk_circuit_check(const orc_plonk_circuit *c, const orc_plonk_params *p);
+/* the circuit's constraint terms at ONE row / point over the base field: wires[num_wires], consts[num_constants], pih[4] -> out[num_gate_constraints] */
+void orc_plonk_gate_constraints_base(const orc_plonk_circuit *c, const uint64_t *wires, const uint64_t *consts, const uint64_t pih[4], uint64_t *out);
+void orc_plonk_gate_constraints_ext(const orc_plonk_circuit *c, const gl2 *wires, const gl2 *consts, const uint64_t pih[4], gl2 *out);
+/* flat proof "SIPPPLK3": header[16] = magic, log_n, num_routed_wires, max_degree, num_challenges, total_len, num_wires, num_constants,
+ * num_selectors, num_gates, num_gate_constraints, n_public_inputs, 0, 0, 0, 0 | wires cap | zs_partial_products cap | quotient cap |
+ * opening proof (zeta: constants_sigmas, wires, zs_partial_products, quotient chunks -- all columns; g zeta: the Z columns) | public_inputs.
+ * wires [num_wires][N], constants_sigmas [num_constants + num_routed_wires][N]: VALUES, natural row order. */
+int orc_plonk_prove_gates(const uint64_t *wires, const uint64_t *constants_sigmas, unsigned log_n, const orc_plonk_params *p,
+                          const orc_fri_params *fp, const orc_plonk_circuit *c, const uint64_t circuit_digest[4], const uint64_t *public_inputs,
+                          uint32_t n_public_inputs, uint64_t **proof, size_t *len);
+/* cs_cap: the verifier's copy of the constants_sigmas commitment */
+int orc_plonk_verify_gates(const uint64_t *proof, size_t len, const uint64_t *cs_cap, const orc_plonk_params *p, const orc_fri_params *fp,
+                           const orc_plonk_circuit *c, const uint64_t circuit_digest[4]);
+
 /* the verifier's side: vanishing terms at an extension point from opened values, reduced with the powers of every alpha */
 void orc_plonk_eval_vanishing(gl2 x, const gl2 *wires, const gl2 *sigmas, const gl2 *zs, const gl2 *zs_next, const gl2 *pps,
                               unsigned log_n, const orc_plonk_params *p, const uint64_t *betas, const uint64_t *gammas,

@@ -515,3 +515,47 @@ def eval_vanishing_poly_permutation(n_log, x, wires, sigmas, zs, zs_next, partia
             acc = acc * ext(a) + t
         out.append(acc)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------- gates as data
+# Second reading of gates/selectors.rs (compute_filter, UNUSED_SELECTOR), gates/gate.rs (eval_filtered: a gate's constraints times its
+# filter, ADDED into the circuit's shared constraint vector) and plonk/vanishing_poly.rs (evaluate_gate_constraints), for a gate set
+# given as data (include/sipp_hip.h "gates as data"; oracle/plonk.h): gates = [(selector_index, row, group_lo, group_hi, prog_offset,
+# num_constraints)], programs = flat integers -- per constraint n_mono, per monomial coef, n_factors, (kind, index) pairs; kind 0 = wire,
+# 1 = constant column, 2 = public_inputs_hash word.
+UNUSED_SELECTOR = (1 << 32) - 1
+
+
+def compute_filter(row, group_range, s, many_selector):
+    f = ext(1)
+    for i in group_range:
+        if i != row:
+            f = f * (ext(i) - s)
+    if many_selector:
+        f = f * (ext(UNUSED_SELECTOR) - s)
+    return f
+
+
+def evaluate_gate_constraints(gates, programs, num_selectors, local_wires, local_constants, public_inputs_hash):
+    """all arguments at ONE point (extension elements): -> the circuit's constraint vector (length = max over gates)"""
+    num_gate_constraints = max(g[5] for g in gates)
+    constraints = [ext(0)] * num_gate_constraints
+    prog = [int(x) for x in programs]
+    for (sel, row, lo, hi, off, ncons) in gates:
+        filt = compute_filter(row, range(lo, hi), local_constants[sel], num_selectors > 1)
+        w = off
+        for j in range(ncons):
+            n_mono = prog[w]
+            w += 1
+            acc = ext(0)
+            for _ in range(n_mono):
+                term = ext(prog[w] % P)
+                nf = prog[w + 1]
+                w += 2
+                for _f in range(nf):
+                    kind, idx = prog[w], prog[w + 1]
+                    w += 2
+                    term = term * (local_wires[idx] if kind == 0 else local_constants[idx] if kind == 1 else ext(public_inputs_hash[idx]))
+                acc = acc + term
+            constraints[j] = constraints[j] + filt * acc
+    return constraints

@@ -49,6 +49,26 @@ class PlonkParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("num_routed_wires", "max_degree", "num_challenges")]
 
 
+class PlonkGate(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("selector_index", "row", "group_lo", "group_hi", "prog_offset", "num_constraints")]
+
+
+class PlonkCircuit(C.Structure):
+    """sipp_plonk_circuit: the gate set as data (include/sipp_hip.h, "gates as data")"""
+    _fields_ = [("num_wires", C.c_uint32), ("num_constants", C.c_uint32), ("num_selectors", C.c_uint32), ("num_gates", C.c_uint32),
+                ("gates", C.POINTER(PlonkGate)), ("programs", C.POINTER(C.c_int64)), ("program_words", C.c_uint32)]
+
+    @classmethod
+    def from_dict(cls, circ):
+        """circ: dict(num_wires, num_constants, num_selectors, gates=[(selector_index, row, lo, hi, prog_offset, n_constraints)], programs)"""
+        gates = (PlonkGate * len(circ["gates"]))(*[PlonkGate(*[int(x) for x in g]) for g in circ["gates"]])
+        prog = np.ascontiguousarray(circ["programs"], dtype=np.int64)
+        c = cls(circ["num_wires"], circ["num_constants"], circ["num_selectors"], len(circ["gates"]), gates,
+                prog.ctypes.data_as(C.POINTER(C.c_int64)), len(prog))
+        c._keep = (gates, prog)           # the struct points into these
+        return c
+
+
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
                 ("n_out", C.c_uint64)]
@@ -104,6 +124,9 @@ SIGNATURES = {
     "sipp_plonk_prove_ex": (C.c_int, [vp, vp, vp, C.POINTER(Oracle), u64p, C.POINTER(Oracle), C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams),
                                       u64p, u64p, C.c_uint32, vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_plonk_perm_proof_size": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams)]),
+    "sipp_plonk_gates_proof_size": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), C.POINTER(PlonkCircuit), C.c_uint32]),
+    "sipp_plonk_prove_gates": (C.c_int, [vp, vp, vp, C.POINTER(Oracle), u64p, C.POINTER(Oracle), C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams),
+                                         C.POINTER(PlonkCircuit), u64p, u64p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
@@ -354,6 +377,25 @@ class Ctx:
                                             self._u64(digest), self._u64(pis) if pis else None, len(pis),
                                             None if gate_terms is None else gate_terms.data_ptr(), k, out.ctypes.data, cap, C.byref(n)),
                  "plonk_prove_ex")
+        return out[: n.value]
+
+    def plonk_prove_gates(self, wires, constants_sigmas, log_n, p, fp, circuit, digest, public_inputs, wires_oracle=None, wires_cap=None,
+                          cs_oracle=None):
+        """sipp_plonk_prove_gates: wires [num_wires][N], constants_sigmas [num_constants + num_routed][N] device tensors (values);
+        circuit = PlonkCircuit; the gate constraints are interpreted inside the quotient kernel.  Returns the flat "SIPPPLK3" proof."""
+        pis = [int(x) for x in public_inputs]
+        cap = self.L.sipp_plonk_gates_proof_size(log_n, C.byref(p), C.byref(fp), C.byref(circuit), len(pis))
+        if cap == 0:
+            raise SippError(-1, "sipp_plonk_gates_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        wc_arr = None if wires_cap is None else np.ascontiguousarray(wires_cap, dtype=np.uint64).reshape(-1)
+        wcap = None if wc_arr is None else wc_arr.ctypes.data_as(u64p)
+        self._ck(self.L.sipp_plonk_prove_gates(self.h, wires.data_ptr(), constants_sigmas.data_ptr(),
+                                               None if wires_oracle is None else C.byref(wires_oracle), wcap,
+                                               None if cs_oracle is None else C.byref(cs_oracle), log_n, C.byref(p), C.byref(fp), C.byref(circuit),
+                                               self._u64(digest), self._u64(pis) if pis else None, len(pis), out.ctypes.data, cap, C.byref(n)),
+                 "plonk_prove_gates")
         return out[: n.value]
 
     def plonk_perm_prove(self, wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):

@@ -114,6 +114,13 @@ struct QuotArgs {
     uint64_t* qv;             // [C][n D]  leaf order of the quotient coset
     const uint64_t* gt;       // [n_gt][stride] caller-supplied gate-constraint terms, leaf order (nullptr: none)
     uint32_t n_gt;
+    // gates as data (sipp_plonk_prove_gates): the circuit's gate set interpreted at every point of the quotient coset
+    const uint64_t* cl;       // [num_constants][stride] constant columns (selectors first), leaf order; nullptr: no gate set
+    const sipp_plonk_gate* gates;
+    const int64_t* prog;
+    const uint64_t* gapow;    // [C][n_gc]: alpha_c^(number of terms in front of gate constraint j)
+    uint32_t n_gates, many_sel, n_gc;
+    uint64_t pih[4];
 };
 
 __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
@@ -158,6 +165,52 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
     // constraint_terms: the circuit's gate constraints at this point, evaluated by the caller (vanishing_poly.rs appends them to the
     // permutation terms; one reduce_with_powers runs over all of them)
     for (uint32_t k = 0; k < a.n_gt; k++) push(gl::canon(a.gt[(size_t)k * a.stride + pos]));
+    if (a.cl) {
+        // evaluate_gate_constraints with the gate set as data: term_j = sum_g filter_g c_{g,j}, so per challenge
+        //   sum_j alpha^(n0 + j) term_j = sum_g filter_g (sum_j alpha^(n0 + j) c_{g,j});  the walk over gates, constraints, monomials and
+        // factors is wave-uniform (every lane runs the same program on its own point), operands are committed LDE cells (canonical)
+        auto operand = [&](int64_t kind, int64_t idx) -> uint64_t {
+            return kind == 0 ? a.wl[(size_t)idx * a.stride + pos] : kind == 1 ? a.cl[(size_t)idx * a.stride + pos] : a.pih[idx];
+        };
+        for (uint32_t g = 0; g < a.n_gates; g++) {
+            const sipp_plonk_gate ga = a.gates[g];
+            if (!ga.num_constraints) continue;
+            const uint64_t sv = a.cl[(size_t)ga.selector_index * a.stride + pos];
+            uint64_t f = 1;                                              // compute_filter (gates/selectors.rs)
+            for (uint32_t i = ga.group_lo; i < ga.group_hi; i++)
+                if (i != ga.row) f = gl::mul(f, gl::sub((uint64_t)i, sv));
+            if (a.many_sel) f = gl::mul(f, gl::sub(0xffffffffull, sv));
+            uint64_t part[MAX_CH];
+#pragma unroll
+            for (uint32_t c = 0; c < MAX_CH; c++) part[c] = 0;
+            const int64_t* w = a.prog + ga.prog_offset;
+            for (uint32_t j = 0; j < ga.num_constraints; j++) {
+                const int nm = (int)*w++;
+                uint64_t sum = 0;
+                for (int mo = 0; mo < nm; mo++) {
+                    const int64_t coef = w[0];
+                    const int nf = (int)w[1];
+                    w += 2;
+                    if (nf == 0) {
+                        sum = gl::add(sum, gl::from_i64(coef));
+                        continue;
+                    }
+                    uint64_t t = operand(w[0], w[1]);
+                    w += 2;
+                    for (int q = 1; q < nf; q++, w += 2) t = gl::mul(t, operand(w[0], w[1]));
+                    if (coef == 1) sum = gl::add(sum, t);
+                    else if (coef == -1) sum = gl::sub(sum, t);
+                    else sum = gl::mad(gl::from_i64(coef), t, sum);
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < MAX_CH; c++)
+                    if (c < C) part[c] = gl::mad(a.gapow[(size_t)c * a.n_gc + j], sum, part[c]);
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < MAX_CH; c++)
+                if (c < C) acc[c] = gl::mad(f, part[c], acc[c]);
+        }
+    }
     for (uint32_t c = 0; c < C; c++) a.qv[(size_t)c * nd + pos] = gl::mul(acc[c], zhi);
 }
 
@@ -234,9 +287,68 @@ int sipp_plonk_quotient_chunks(sipp_ctx* ctx, const uint64_t* d_wires_lde, const
     return sipp_plonk_quotient_chunks_ex(ctx, d_wires_lde, d_sigmas_lde, d_zs_lde, log_n, rate_bits, p, betas, gammas, alphas, nullptr, 0, d_chunks);
 }
 
+namespace {
+// the gate set on the device: the constant columns' LDE, the circuit (host description, validated by the caller) and the hash of the public inputs
+struct GateSet {
+    const uint64_t* d_consts_lde;
+    const sipp_plonk_circuit* c;
+    const uint64_t* pih;
+};
+int quotient_chunks_impl(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
+                         uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas,
+                         const uint64_t* d_gate_terms, uint32_t num_gate_terms, const GateSet* gs, uint64_t* d_chunks);
+}  // namespace
+
 int sipp_plonk_quotient_chunks_ex(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
                                   uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas,
                                   const uint64_t* alphas, const uint64_t* d_gate_terms, uint32_t num_gate_terms, uint64_t* d_chunks) {
+    return quotient_chunks_impl(ctx, d_wires_lde, d_sigmas_lde, d_zs_lde, log_n, rate_bits, p, betas, gammas, alphas, d_gate_terms, num_gate_terms,
+                                nullptr, d_chunks);
+}
+
+namespace {
+uint32_t num_gate_constraints(const sipp_plonk_circuit* c) {
+    uint32_t m = 0;
+    for (uint32_t g = 0; g < c->num_gates; g++) m = std::max(m, c->gates[g].num_constraints);
+    return m;
+}
+
+// every operand in range, every program inside program_words: an index out of range would be a read outside the LDE buffers
+int circuit_check(sipp_ctx* ctx, const sipp_plonk_circuit* c, const sipp_plonk_params* p) {
+    if (!c || !p || c->num_wires < p->num_routed_wires || c->num_wires > 4096 || c->num_selectors == 0 || c->num_selectors > c->num_constants ||
+        c->num_constants > 1024 || c->num_gates == 0 || c->num_gates > 4096 || !c->gates || (!c->programs && c->program_words))
+        return sipp_fail(ctx, SIPP_E_BADARG, "plonk: malformed circuit description");
+    for (uint32_t g = 0; g < c->num_gates; g++) {
+        const sipp_plonk_gate& ga = c->gates[g];
+        if (ga.selector_index >= c->num_selectors || ga.group_lo > ga.row || ga.row >= ga.group_hi || ga.group_hi > c->num_gates ||
+            ga.group_hi - ga.group_lo > 64 || ga.num_constraints > 4096)
+            return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate's selector group is malformed");
+        size_t w = ga.prog_offset;
+        for (uint32_t j = 0; j < ga.num_constraints; j++) {
+            if (w >= c->program_words) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate program runs past program_words");
+            const int64_t nm = c->programs[w++];
+            if (nm < 0 || nm > 4096) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate program is malformed");
+            for (int64_t m = 0; m < nm; m++) {
+                if (w + 2 > c->program_words) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate program runs past program_words");
+                const int64_t nf = c->programs[w + 1];
+                w += 2;
+                if (nf < 0 || nf > 64 || w + 2 * (size_t)nf > c->program_words)
+                    return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate program runs past program_words");
+                for (int64_t f = 0; f < nf; f++, w += 2) {
+                    const int64_t kind = c->programs[w], idx = c->programs[w + 1];
+                    if (kind < 0 || kind > 2 || idx < 0 || (kind == 0 && idx >= c->num_wires) || (kind == 1 && idx >= c->num_constants) ||
+                        (kind == 2 && idx >= 4))
+                        return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a gate program names an operand out of range");
+                }
+            }
+        }
+    }
+    return SIPP_OK;
+}
+
+int quotient_chunks_impl(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint64_t* d_sigmas_lde, const uint64_t* d_zs_lde, uint32_t log_n,
+                         uint32_t rate_bits, const sipp_plonk_params* p, const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas,
+                         const uint64_t* d_gate_terms, uint32_t num_gate_terms, const GateSet* gs, uint64_t* d_chunks) {
     if ((num_gate_terms != 0) != (d_gate_terms != nullptr) || num_gate_terms > (1u << 20)) return ctx ? sipp_fail(ctx, SIPP_E_BADARG, "plonk: gate terms and their count disagree") : SIPP_E_BADARG;
 
     if (!ctx || !d_wires_lde || !d_sigmas_lde || !d_zs_lde || !betas || !gammas || !alphas || !d_chunks) return SIPP_E_BADARG;
@@ -267,6 +379,31 @@ int sipp_plonk_quotient_chunks_ex(sipp_ctx* ctx, const uint64_t* d_wires_lde, co
     a.qv = d_chunks;           // [C][n D]: values in leaf order, transformed in place
     a.gt = d_gate_terms;
     a.n_gt = num_gate_terms;
+    if (gs) {
+        const sipp_plonk_circuit* c = gs->c;
+        a.cl = gs->d_consts_lde;
+        a.n_gates = c->num_gates; a.many_sel = c->num_selectors > 1; a.n_gc = num_gate_constraints(c);
+        for (int q = 0; q < 4; q++) a.pih[q] = gl::canon(gs->pih[q]);
+        // alpha_c^(terms in front of gate constraint j): the permutation terms C + C m, then the caller's own terms
+        std::vector<uint64_t> gp((size_t)C * std::max(1u, a.n_gc));
+        for (uint32_t cc = 0; cc < C; cc++) {
+            uint64_t x = gl::pow(a.alpha[cc], (uint64_t)C + (uint64_t)C * m + num_gate_terms);
+            for (uint32_t j = 0; j < a.n_gc; j++) {
+                gp[(size_t)cc * a.n_gc + j] = x;
+                x = gl::mul(x, a.alpha[cc]);
+            }
+        }
+        uint64_t* d_gp = arena_alloc_t<uint64_t>(ctx, gp.size());
+        sipp_plonk_gate* d_gates = arena_alloc_t<sipp_plonk_gate>(ctx, c->num_gates);
+        int64_t* d_prog = arena_alloc_t<int64_t>(ctx, std::max(1u, c->program_words));
+        if (!d_gp || !d_gates || !d_prog) return SIPP_E_NOMEM;
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_gp, gp.data(), gp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_gates, c->gates, (size_t)c->num_gates * sizeof(sipp_plonk_gate), hipMemcpyHostToDevice, ctx->stream));
+        if (c->program_words)
+            SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_prog, c->programs, (size_t)c->program_words * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `gp` and the caller's arrays are host memory
+        a.gapow = d_gp; a.gates = d_gates; a.prog = d_prog;
+    }
     {
         ProfScope ps(ctx, "plonk_quotient");
         hipLaunchKernelGGL(plonk_quotient_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, ctx->stream, a);
@@ -276,6 +413,7 @@ int sipp_plonk_quotient_chunks_ex(sipp_ctx* ctx, const uint64_t* d_wires_lde, co
     SIPP_TRY(sipp_ntt_dit(ctx, d_chunks, nd, log_n + log_d, C, true, NttDiag{gl::inv(gl::GEN), 0}));
     return sipp_sync(ctx);
 }
+}  // namespace
 
 // the flow of oracle/plonk.c::orc_plonk_perm_prove on the device: four PolynomialBatch commitments, the transcript on the host, one
 // opening proof at zeta / g zeta.  Flat proof: header[8] | wires cap | zs_partial_products cap | quotient cap | opening proof.
@@ -291,6 +429,9 @@ struct PlonkExtra {
     const sipp_oracle* sigmas_oracle = nullptr;
     const sipp_oracle* wires_oracle = nullptr;
     const uint64_t* wires_cap = nullptr;
+    // gates as data ("SIPPPLK3"): d_wires holds circ->num_wires columns, d_sigmas is the WHOLE constants_sigmas batch (num_constants
+    // columns in front of the sigmas)
+    const sipp_plonk_circuit* circ = nullptr;
 };
 int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_sigmas, uint32_t log_n, const sipp_plonk_params* p,
                      const sipp_fri_params* fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4], const PlonkExtra& ex,
@@ -336,7 +477,9 @@ int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_s
     ArenaScope scope(ctx);
     const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = C * m;
     const size_t n = (size_t)1 << log_n, M = n << fp->rate_bits, cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
-    const uint32_t ncols[4] = {R, R, nz, C * D};
+    const uint32_t K = ex.circ ? ex.circ->num_constants : 0, Wn = ex.circ ? ex.circ->num_wires : R;
+    const uint32_t ncols[4] = {K + R, Wn, nz, C * D};
+    const uint64_t* d_sigma_vals = d_sigmas + (size_t)K * n;      // the sigmas behind the constant columns
     uint64_t *co[4], *lde[4], *tree[4];
     const sipp_oracle* pre[4] = {ex.sigmas_oracle, ex.wires_oracle, nullptr, nullptr};
     for (int o = 0; o < 4; o++) {
@@ -353,9 +496,10 @@ int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_s
     }
     std::vector<uint64_t> caps(4 * cap_n * 4);
     auto cap_of = [&](int o) { return caps.data() + (size_t)o * cap_n * 4; };
-    if (!pre[0]) SIPP_TRY(sipp_commit_batch_ex(ctx, d_sigmas, 0, co[0], lde[0], tree[0], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(0)));
+    if (!pre[0])
+        SIPP_TRY(sipp_commit_batch_ex(ctx, d_sigmas, 0, co[0], lde[0], tree[0], ncols[0], log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(0)));
     if (!pre[1])
-        SIPP_TRY(sipp_commit_batch_ex(ctx, d_wires, 0, co[1], lde[1], tree[1], R, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(1)));
+        SIPP_TRY(sipp_commit_batch_ex(ctx, d_wires, 0, co[1], lde[1], tree[1], ncols[1], log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(1)));
     else
         memcpy(cap_of(1), ex.wires_cap, cap_n * 32);
     host::Challenger ch;
@@ -368,23 +512,27 @@ int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_s
     {
         uint64_t* zs = arena_alloc_t<uint64_t>(ctx, (size_t)nz * n);
         if (!zs) return SIPP_E_NOMEM;
-        SIPP_TRY(sipp_plonk_zs_partial_products(ctx, d_wires, d_sigmas, log_n, p, betas, gammas, zs));
+        SIPP_TRY(sipp_plonk_zs_partial_products(ctx, d_wires, d_sigma_vals, log_n, p, betas, gammas, zs));
         SIPP_TRY(sipp_commit_batch_ex(ctx, zs, 0, co[2], lde[2], tree[2], nz, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(2)));
     }
     ch.observe_many(cap_of(2), cap_n * 4);
     for (uint32_t c = 0; c < C; c++) alphas[c] = ch.get();
-    SIPP_TRY(sipp_plonk_quotient_chunks_ex(ctx, lde[1], lde[0], lde[2], log_n, fp->rate_bits, p, betas, gammas, alphas, ex.d_gate_terms,
-                                           ex.n_gate_terms, co[3]));
+    {
+        const GateSet gs{lde[0], ex.circ, public_inputs_hash};
+        SIPP_TRY(quotient_chunks_impl(ctx, lde[1], lde[0] + (size_t)K * M, lde[2], log_n, fp->rate_bits, p, betas, gammas, alphas, ex.d_gate_terms,
+                                      ex.n_gate_terms, ex.circ ? &gs : nullptr, co[3]));
+    }
     SIPP_TRY(sipp_commit_batch_ex(ctx, co[3], 1, co[3], lde[3], tree[3], (size_t)C * D, log_n, fp->rate_bits, fp->cap_height, nullptr, 0, cap_of(3)));
     ch.observe_many(cap_of(3), cap_n * 4);
     const gl::E2 zeta = ch.get_ext();
     sipp_oracle oracles[4];
     for (int o = 0; o < 4; o++) oracles[o] = sipp_oracle{co[o], lde[o], tree[o], ncols[o], 0};
-    const sipp_poly_range r0[4] = {{0, 0, R}, {1, 0, R}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
+    const sipp_poly_range r0[4] = {{0, 0, ncols[0]}, {1, 0, ncols[1]}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
     const gl::E2 gz = gl::scale(zeta, gl::root_of_unity(log_n));
     sipp_fri_batch batches[2] = {{{zeta.c0, zeta.c1}, 4, r0}, {{gz.c0, gz.c1}, 1, r1}};
     const size_t op_cap = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
-    const size_t head = 8 + 3 * cap_n * 4, tail = ex.v2 ? ex.n_public_inputs : 0;
+    const size_t hw = ex.circ ? 16 : 8;                          // header words
+    const size_t head = hw + 3 * cap_n * 4, tail = ex.v2 ? ex.n_public_inputs : 0;
     if (op_cap == 0) return sipp_fail(ctx, SIPP_E_BADARG, "plonk: FRI parameters do not fit the degree");
     if (proof_cap < head + op_cap + tail) return sipp_fail(ctx, SIPP_E_BUFSZ, "plonk: proof buffer too small (see sipp_plonk_perm_proof_size)");
     sipp_challenger cs{};
@@ -395,13 +543,19 @@ int plonk_prove_impl(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_s
     cs.n_out = ch.n_out;
     size_t op_len = 0;
     SIPP_TRY(sipp_fri_prove_openings(ctx, oracles, 4, batches, 2, log_n, fp, &cs, proof_out + head, proof_cap - head - tail, &op_len));
-    const uint64_t h[8] = {ex.v2 ? 0x324b4c5050504953ULL /* "SIPPPLK2" */ : 0x314b4c5050504953ULL /* "SIPPPLK1" */, log_n, R, D, C,
-                           head + op_len + tail, ex.v2 ? ex.n_gate_terms : 0, tail};
-    memcpy(proof_out, h, sizeof h);
+    if (ex.circ) {
+        const uint64_t h[16] = {0x334b4c5050504953ULL /* "SIPPPLK3" */, log_n, R, D, C, head + op_len + tail, Wn, K, ex.circ->num_selectors,
+                                ex.circ->num_gates, num_gate_constraints(ex.circ), tail, 0, 0, 0, 0};
+        memcpy(proof_out, h, sizeof h);
+    } else {
+        const uint64_t h[8] = {ex.v2 ? 0x324b4c5050504953ULL /* "SIPPPLK2" */ : 0x314b4c5050504953ULL /* "SIPPPLK1" */, log_n, R, D, C,
+                               head + op_len + tail, ex.v2 ? ex.n_gate_terms : 0, tail};
+        memcpy(proof_out, h, sizeof h);
+    }
     if (tail) memcpy(proof_out + head + op_len, ex.public_inputs, tail * 8);
-    memcpy(proof_out + 8, cap_of(1), cap_n * 32);
-    memcpy(proof_out + 8 + cap_n * 4, cap_of(2), cap_n * 32);
-    memcpy(proof_out + 8 + 2 * cap_n * 4, cap_of(3), cap_n * 32);
+    memcpy(proof_out + hw, cap_of(1), cap_n * 32);
+    memcpy(proof_out + hw + cap_n * 4, cap_of(2), cap_n * 32);
+    memcpy(proof_out + hw + 2 * cap_n * 4, cap_of(3), cap_n * 32);
     *proof_len = head + op_len + tail;
     return SIPP_OK;
 }
@@ -421,4 +575,42 @@ size_t sipp_plonk_perm_proof_size(uint32_t log_n, const sipp_plonk_params* p, co
     sipp_fri_batch batches[2] = {{{0, 0}, 4, r0}, {{0, 0}, 1, r1}};
     const size_t op = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
     return op ? 8 + 3 * cap_n * 4 + op : 0;
+}
+
+size_t sipp_plonk_gates_proof_size(uint32_t log_n, const sipp_plonk_params* p, const sipp_fri_params* fp, const sipp_plonk_circuit* c,
+                                   uint32_t n_public_inputs) {
+    if (!p || !fp || !c || p->max_degree < 2 || p->max_degree > 64 || (p->max_degree & (p->max_degree - 1)) || p->num_routed_wires == 0 ||
+        p->num_challenges == 0 || p->num_challenges > MAX_CH || (p->num_routed_wires + p->max_degree - 1) / p->max_degree > MAX_CHUNKS ||
+        log_n < 1 || log_n > 24 || c->num_wires < p->num_routed_wires || c->num_wires > 4096 || c->num_constants > 1024)
+        return 0;
+    const uint32_t R = p->num_routed_wires, D = p->max_degree, C = p->num_challenges, nz = C * ((R + D - 1) / D);
+    const size_t cap_n = (size_t)1 << std::min(fp->cap_height, log_n + fp->rate_bits);
+    sipp_oracle oracles[4] = {{nullptr, nullptr, nullptr, c->num_constants + R, 0}, {nullptr, nullptr, nullptr, c->num_wires, 0},
+                              {nullptr, nullptr, nullptr, nz, 0}, {nullptr, nullptr, nullptr, C * D, 0}};
+    const sipp_poly_range r0[4] = {{0, 0, c->num_constants + R}, {1, 0, c->num_wires}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
+    sipp_fri_batch batches[2] = {{{0, 0}, 4, r0}, {{0, 0}, 1, r1}};
+    const size_t op = sipp_fri_proof_size(oracles, 4, batches, 2, log_n, fp);
+    return op ? 16 + 3 * cap_n * 4 + op + n_public_inputs : 0;
+}
+
+int sipp_plonk_prove_gates(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_constants_sigmas, const sipp_oracle* wires_oracle,
+                           const uint64_t* wires_cap, const sipp_oracle* constants_sigmas_oracle, uint32_t log_n, const sipp_plonk_params* p,
+                           const sipp_fri_params* fp, const sipp_plonk_circuit* c, const uint64_t circuit_digest[4], const uint64_t* public_inputs,
+                           uint32_t n_public_inputs, uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    if (!ctx || !d_wires || !d_constants_sigmas || !fp || !p || !c || !circuit_digest || !proof_out || !proof_len ||
+        (n_public_inputs && !public_inputs) || (wires_oracle != nullptr) != (wires_cap != nullptr) || n_public_inputs > (1u << 24))
+        return SIPP_E_BADARG;
+    SIPP_TRY(circuit_check(ctx, c, p));
+    if ((wires_oracle && (wires_oracle->n_polys != c->num_wires || wires_oracle->n_salt || !wires_oracle->d_coeffs || !wires_oracle->d_lde ||
+                          !wires_oracle->d_tree)) ||
+        (constants_sigmas_oracle &&
+         (constants_sigmas_oracle->n_polys != c->num_constants + p->num_routed_wires || constants_sigmas_oracle->n_salt ||
+          !constants_sigmas_oracle->d_coeffs || !constants_sigmas_oracle->d_lde || !constants_sigmas_oracle->d_tree)))
+        return sipp_fail(ctx, SIPP_E_BADARG, "plonk: a pre-committed oracle must hold every column of its batch, unsalted");
+    uint64_t pih[4];
+    host::Challenger::hash_no_pad(public_inputs, n_public_inputs, pih);
+    PlonkExtra ex;
+    ex.public_inputs = public_inputs; ex.n_public_inputs = n_public_inputs; ex.v2 = true;
+    ex.sigmas_oracle = constants_sigmas_oracle; ex.wires_oracle = wires_oracle; ex.wires_cap = wires_cap; ex.circ = c;
+    return plonk_prove_impl(ctx, d_wires, d_constants_sigmas, log_n, p, fp, circuit_digest, pih, ex, proof_out, proof_cap, proof_len);
 }

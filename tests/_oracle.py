@@ -537,6 +537,78 @@ def plonk_verify_ex(proof, sigmas_cap, p, fp, digest, num_mul):
                                  np.asarray(digest, dtype=np.uint64), C.byref(g))
 
 
+# ---- gates as data (oracle/plonk_gates.c) ----
+class OrcPlonkGate(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("selector_index", "row", "group_lo", "group_hi", "prog_offset", "num_constraints")]
+
+
+class OrcPlonkCircuit(C.Structure):
+    _fields_ = [("num_wires", C.c_uint32), ("num_constants", C.c_uint32), ("num_selectors", C.c_uint32), ("num_gates", C.c_uint32),
+                ("gates", C.POINTER(OrcPlonkGate)), ("programs", C.POINTER(C.c_int64)), ("program_words", C.c_uint32)]
+
+
+def plonk_circuit(circ, cls=(OrcPlonkGate, OrcPlonkCircuit)):
+    """tools/plonk_synth.circuit() -> the C struct (keeps the arrays it points into alive as attributes)"""
+    G, CC = cls
+    gates = (G * len(circ["gates"]))(*[G(*[int(x) for x in g]) for g in circ["gates"]])
+    prog = np.ascontiguousarray(circ["programs"], dtype=np.int64)
+    c = CC(circ["num_wires"], circ["num_constants"], circ["num_selectors"], len(circ["gates"]), gates,
+           prog.ctypes.data_as(C.POINTER(C.c_int64)), len(prog))
+    c._keep = (gates, prog)
+    return c
+
+
+def _plonk_gates_lib():
+    L = _plonk_lib()
+    if not getattr(L, "_plonk_gates_sigs", False):
+        pp, cp, fpp = C.POINTER(OrcPlonkParams), C.POINTER(OrcPlonkCircuit), C.POINTER(OrcFriParams)
+        L.orc_plonk_prove_gates.argtypes = [u64p, u64p, C.c_uint, pp, fpp, cp, u64p, u64p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint64)),
+                                            C.POINTER(C.c_size_t)]
+        L.orc_plonk_prove_gates.restype = C.c_int
+        L.orc_plonk_verify_gates.argtypes = [u64p, C.c_size_t, u64p, pp, fpp, cp, u64p]
+        L.orc_plonk_verify_gates.restype = C.c_int
+        L.orc_plonk_gate_constraints_base.argtypes = [cp, u64p, u64p, u64p, u64p]
+        L.orc_plonk_gate_constraints_base.restype = None
+        L.orc_plonk_circuit_check.argtypes = [cp, pp]
+        L.orc_plonk_circuit_check.restype = C.c_int
+        L._plonk_gates_sigs = True
+    return L
+
+
+def plonk_prove_gates(wires, constants_sigmas, log_n, p, fp, circ, digest, public_inputs):
+    L = _plonk_gates_lib()
+    cc = plonk_circuit(circ)
+    out = C.POINTER(C.c_uint64)()
+    n = C.c_size_t()
+    pis = np.asarray(list(public_inputs) or [0], dtype=np.uint64)
+    rc = L.orc_plonk_prove_gates(np.ascontiguousarray(wires, dtype=np.uint64).reshape(-1), np.ascontiguousarray(constants_sigmas, dtype=np.uint64).reshape(-1),
+                                 log_n, C.byref(p), C.byref(fp), C.byref(cc), np.asarray(digest, dtype=np.uint64), pis, len(list(public_inputs)),
+                                 C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError("orc_plonk_prove_gates: %d" % rc)
+    pf = np.ctypeslib.as_array(out, shape=(n.value,)).copy()
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_free(out)
+    return pf
+
+
+def plonk_verify_gates(proof, cs_cap, p, fp, circ, digest):
+    L = _plonk_gates_lib()
+    cc = plonk_circuit(circ)
+    proof = np.ascontiguousarray(proof, dtype=np.uint64)
+    return L.orc_plonk_verify_gates(proof, len(proof), np.ascontiguousarray(cs_cap, dtype=np.uint64).reshape(-1), C.byref(p), C.byref(fp), C.byref(cc),
+                                    np.asarray(digest, dtype=np.uint64))
+
+
+def plonk_gate_constraints_base(circ, wires_row, consts_row, pih):
+    L = _plonk_gates_lib()
+    cc = plonk_circuit(circ)
+    out = np.zeros(max(1, circ["num_gate_constraints"]), dtype=np.uint64)
+    L.orc_plonk_gate_constraints_base(C.byref(cc), np.ascontiguousarray(wires_row, dtype=np.uint64), np.ascontiguousarray(consts_row, dtype=np.uint64),
+                                      np.asarray(pih, dtype=np.uint64), out)
+    return out
+
+
 def plonk_zs(wires, sigmas, log_n, p, betas, gammas):
     out = np.zeros((plonk_zs_cols(p), 1 << log_n), dtype=np.uint64)
     _plonk_lib().orc_plonk_zs_partial_products(np.ascontiguousarray(wires).reshape(-1), np.ascontiguousarray(sigmas).reshape(-1), log_n, C.byref(p),

@@ -197,3 +197,52 @@ def test_gate_term_argument_errors(ctx):
     # a count without a pointer, a pointer without a count
     assert L.sipp_plonk_quotient_chunks_ex(ctx.h, z.data_ptr(), z.data_ptr(), zz.data_ptr(), 10, 1, C.byref(gp), one, one, one, None, 3, out.data_ptr()) == -1
     assert L.sipp_plonk_quotient_chunks_ex(ctx.h, z.data_ptr(), z.data_ptr(), zz.data_ptr(), 10, 1, C.byref(gp), one, one, one, z.data_ptr(), 0, out.data_ptr()) == -1
+
+
+# ---------------------------------------------------------------------------------------------------- gates as data (round 5)
+@pytest.mark.parametrize("log_n,num_wires,num_routed,rate_bits,cap_h", [(10, 40, 24, 3, 2), (11, 136, 80, 3, 4), (10, 36, 16, 3, 0)])
+def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_routed, rate_bits, cap_h):
+    """sipp_plonk_prove_gates ("SIPPPLK3"): the outer flow with the circuit's gates evaluated ON THE DEVICE from the gate set's programs
+    (arithmetic, base-sum, public-input and x^7 gates in two selector groups: tools/plonk_synth.py; the middle case has the column counts of
+    CircuitConfig::standard_ecc_config, reference src/verifier_circuit.rs:213) -- constants_sigmas / wires / Z / quotient commitments,
+    transcript, openings and FRI: the flat proof is the oracle's word for word and its verifier accepts it; with the constants_sigmas
+    and wires oracles committed beforehand the same words come out; a malformed program is refused before any kernel runs."""
+    import sipp_amd
+    from tests.test_oracle_plonk import _synth
+    ps, circ, wires, cs, gate, pis, pih = _synth(log_n, num_wires, num_routed, seed=40 + log_n)
+    op, gp = _oracle.plonk_params(num_routed, 8, 2), sipp_amd.PlonkParams(num_routed, 8, 2)
+    ofp = fri(log_n, rate_bits=rate_bits, cap_height=cap_h, nq=5, arity=4, fpb=3)
+    gfp = to_params(ofp)
+    digest = (11, 12, 13, 14)
+    ref = _oracle.plonk_prove_gates(wires, cs, log_n, op, ofp, circ, digest, pis)
+    gc = sipp_amd.PlonkCircuit.from_dict(circ)
+    d_w, d_cs = dev(wires), dev(cs)
+    got = ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, gfp, gc, digest, pis)
+    assert len(got) == len(ref)
+    diff = np.nonzero(got != ref)[0]
+    assert diff.size == 0, "first mismatch at word %d of %d" % (diff[0], len(ref))
+    cs_cap = _oracle.Batch(cs, log_n, rate_bits=rate_bits, cap_height=cap_h).cap
+    assert _oracle.plonk_verify_gates(got, cs_cap, op, ofp, circ, digest) == 0
+    # the caller's own commitments (constants_sigmas once per circuit; wires before the call): the same proof
+    K = circ["num_constants"]
+    cs_or, _cs_cap, keep1 = ctx.commit_ex(d_cs, log_n, rate_bits, cap_h)
+    w_or, w_cap, keep2 = ctx.commit_ex(d_w, log_n, rate_bits, cap_h)
+    assert cs_or.n_polys == K + num_routed and w_or.n_polys == num_wires and (_cs_cap == cs_cap).all()
+    got2 = ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, gfp, gc, digest, pis, wires_oracle=w_or, wires_cap=w_cap, cs_oracle=cs_or)
+    assert (got2 == ref).all()
+    del keep1, keep2
+    # a broken witness is proved as it is and refused by the verifier (the quotient identity fails at zeta)
+    w2 = wires.copy()
+    w2[3, int(np.flatnonzero(gate == 1)[2])] ^= 1
+    bad = ctx.plonk_prove_gates(dev(w2), d_cs, log_n, gp, gfp, gc, digest, pis)
+    assert _oracle.plonk_verify_gates(bad, cs_cap, op, ofp, circ, digest) == -210
+    # malformed circuits: an operand out of range, a program that runs past its words
+    for mut in ("operand", "length"):
+        c2 = dict(circ, programs=circ["programs"].copy())
+        if mut == "operand":
+            c2["programs"][4] = num_wires            # first monomial of arithmetic op 0: (kind, index) pairs start at word 3
+        else:
+            c2["programs"] = c2["programs"][:-3]
+        with pytest.raises(sipp_amd.SippError) as e:
+            ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, gfp, sipp_amd.PlonkCircuit.from_dict(c2), digest, pis)
+        assert e.value.code == -1

@@ -221,3 +221,112 @@ def test_python_reading_replays_a_proof_with_gates_and_public_inputs():
     # without the gate terms the identity must NOT hold (they really are in the quotient)
     van0 = g2.eval_vanishing_poly_permutation(log_n, zeta, w_o, sg_o, zs_o, zn_o, pp_o, betas, gammas, alphas, D)
     assert van0[0] != van[0]
+
+
+# ---------------------------------------------------------------------------------------------------- gates as data (round 5)
+def _synth(log_n, num_wires=40, num_routed=24, seed=5, pis=(3, 1, 4, 1, 5)):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import plonk_synth as ps
+    circ = ps.circuit(num_wires, num_routed)
+    pih = [int(x) for x in _oracle.hash_no_pad(np.array(pis, dtype=np.uint64))]
+    wires, cs, gate = ps.witness(circ, log_n, seed, pih)
+    return ps, circ, wires, cs, gate, list(pis), pih
+
+
+def test_synthetic_gate_circuit_witness_satisfies_its_programs():
+    """tools/plonk_synth.py: every row satisfies the gate its selector names, under three readings of the programs (plain Python over the
+    integers, oracle/plonk_gates.c over the base field, oracle/py/plonky2_generic.py over the extension); on a row of ANOTHER gate the
+    filter is zero there and nowhere else; a tampered cell shows in exactly the constraints that read it"""
+    from oracle.py import plonky2_generic as g2
+    ps, circ, wires, cs, gate, pis, pih = _synth(7)
+    n = 1 << 7
+    assert ps.check_rows(circ, wires, cs, pih, range(n))
+    assert set(int(g) for g in gate) == {0, 1, 2, 3, 4}
+    for r in (0, 1, 2, 3, 4, 6, 77):
+        out = _oracle.plonk_gate_constraints_base(circ, wires[:, r], cs[:circ["num_constants"], r], pih)
+        assert not out.any(), (r, int(gate[r]))
+        e = g2.evaluate_gate_constraints(circ["gates"], circ["programs"], circ["num_selectors"], [g2.ext(int(v)) for v in wires[:, r]],
+                                         [g2.ext(int(v)) for v in cs[:circ["num_constants"], r]], pih)
+        assert all(v == g2.ext(0) for v in e)
+    r = int(np.flatnonzero(gate == 1)[0])
+    bad = wires[:, r].copy()
+    bad[3] ^= 1                                           # the output of arithmetic op 0
+    out = _oracle.plonk_gate_constraints_base(circ, bad, cs[:circ["num_constants"], r], pih)
+    assert out[0] != 0 and not out[1:].any()
+    e = g2.evaluate_gate_constraints(circ["gates"], circ["programs"], circ["num_selectors"], [g2.ext(int(v)) for v in bad],
+                                     [g2.ext(int(v)) for v in cs[:circ["num_constants"], r]], pih)
+    assert int(e[0][0]) == int(out[0]) and int(e[0][1]) == 0
+
+
+def test_gates_as_data_prove_verify_and_reject():
+    """orc_plonk_prove_gates / orc_plonk_verify_gates ("SIPPPLK3"): the whole outer flow with the gate set as data -- constants_sigmas
+    (selectors, gate constants, sigmas), all wires, Z / partial products, quotient chunks with the gate terms, openings, FRI.  Accepted;
+    refused after tampering with a wire cell of the witness (the quotient no longer fits), with an opened value, with a public input,
+    and for another circuit's programs."""
+    ps, circ, wires, cs, gate, pis, pih = _synth(7)
+    log_n = 7
+    p = _oracle.plonk_params(circ["num_routed"], 8, 2)
+    fp = fri(log_n, rate_bits=3, cap_height=2, nq=4, arity=2, fpb=3)
+    digest = (9, 8, 7, 6)
+    pf = _oracle.plonk_prove_gates(wires, cs, log_n, p, fp, circ, digest, pis)
+    assert int(pf[6]) == circ["num_wires"] and int(pf[7]) == 4 and int(pf[10]) == circ["num_gate_constraints"] and int(pf[11]) == len(pis)
+    cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=2).cap
+    assert _oracle.plonk_verify_gates(pf, cs_cap, p, fp, circ, digest) == 0
+    bad = pf.copy()
+    bad[16 + 3 * 16 + 8 + 2 * (4 + circ["num_routed"]) + 6] ^= 1      # an opened wire value
+    assert _oracle.plonk_verify_gates(bad, cs_cap, p, fp, circ, digest) != 0
+    bad = pf.copy()
+    bad[-1] ^= 1                                                       # a public input: another hash, another transcript
+    assert _oracle.plonk_verify_gates(bad, cs_cap, p, fp, circ, digest) != 0
+    other = dict(circ, programs=circ["programs"].copy())
+    other["programs"][1] = 2                                           # arithmetic op 0 with coefficient 2
+    assert _oracle.plonk_verify_gates(pf, cs_cap, p, fp, other, digest) == -210
+    w2 = wires.copy()
+    r = int(np.flatnonzero(gate == 4)[3])
+    w2[12 + 5, r] ^= 1                                                 # an S-box output: the constraint polynomial is no multiple of Z_H,
+    pf2 = _oracle.plonk_prove_gates(w2, cs, log_n, p, fp, circ, digest, pis)     # the interpolated "quotient" does not reproduce it at zeta
+    assert _oracle.plonk_verify_gates(pf2, cs_cap, p, fp, circ, digest) == -210
+
+
+def test_python_reading_replays_a_proof_with_gates_as_data():
+    """the second reading on a "SIPPPLK3" proof: transcript, the gate constraints at zeta from the OPENED constants and wires
+    (oracle/py/plonky2_generic.py evaluate_gate_constraints), the verifier's identity"""
+    from oracle.py import plonky2_generic as g2
+    ps, circ, wires, cs, gate, pis, pih = _synth(6, num_wires=36, num_routed=16)
+    log_n, R, D, C, K, W = 6, 16, 8, 2, 4, 36
+    p = _oracle.plonk_params(R, D, C)
+    fp = fri(log_n, rate_bits=3, cap_height=1, nq=3, arity=1, fpb=2)
+    pf = [int(v) for v in _oracle.plonk_prove_gates(wires, cs, log_n, p, fp, circ, (1, 2, 3, 4), pis)]
+    cap_words = 4 << fp.cap_height
+    wcap, zcap, qcap = (pf[16 + k * cap_words:16 + (k + 1) * cap_words] for k in range(3))
+    assert pf[len(pf) - len(pis):] == pis and g2.hash_no_pad(pis) == pih
+    ch = g2.Challenger()
+    ch.observe_many([1, 2, 3, 4])
+    ch.observe_many(pih)
+    ch.observe_cap([wcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    betas, gammas = ch.get_n(C), ch.get_n(C)
+    ch.observe_cap([zcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    alphas = ch.get_n(C)
+    ch.observe_cap([qcap[4 * k:4 * k + 4] for k in range(1 << fp.cap_height)])
+    zeta = ch.get_ext()
+    npd = _oracle.plonk_num_prods(p)
+    op = pf[16 + 3 * cap_words + 8:]
+    take = iter(range(0, 10 ** 9, 2))
+    ext_at = lambda: (lambda k: g2.Ext(op[k], op[k + 1]))(next(take))
+    c_o = [ext_at() for _ in range(K)]
+    sg_o = [ext_at() for _ in range(R)]
+    w_o = [ext_at() for _ in range(W)]
+    zs_o = [ext_at() for _ in range(C)]
+    pp_o = [ext_at() for _ in range(C * npd)]
+    q_o = [ext_at() for _ in range(C * D)]
+    zn_o = [ext_at() for _ in range(C)]
+    terms = g2.evaluate_gate_constraints(circ["gates"], circ["programs"], circ["num_selectors"], w_o, c_o, pih)
+    van = g2.eval_vanishing_poly_permutation(log_n, zeta, w_o[:R], sg_o, zs_o, zn_o, pp_o, betas, gammas, alphas, D, terms)
+    zeta_n = zeta ** (1 << log_n)
+    for c in range(C):
+        acc = g2.ext(0)
+        for d in reversed(range(D)):
+            acc = acc * zeta_n + q_o[c * D + d]
+        assert van[c] == (zeta_n - g2.ext(1)) * acc, c
