@@ -100,6 +100,93 @@ def price_vs_world1(lists, world, hardened):
             "proof_words_vs_world1": w["proof_words"] / one["proof_words"], "verifier_hashes_vs_world1": w["verifier_hashes"] / one["verifier_hashes"]}
 
 
+def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
+    """Secondary leg, outside the timed region of `value`: plonky2's outer prove() at the SHAPE of the
+    reference's circuit configuration -- CircuitConfig::standard_ecc_config (reference src/verifier_circuit.rs:213: 136 wires, 80 routed,
+    2 challenges, quotient degree factor 8, FRI rate_bits 3 / cap 4 / 28 queries / 16 grinding bits / arity 16) -- on a SYNTHETIC circuit
+    of 2^log_n rows (tools/plonk_synth.py: arithmetic, base-sum, public-input and x^7 gates in two selector groups; the reference's own
+    gate set and witness live in un-vendored crates) through sipp_plonk_prove_gates: wires commitment, Z / partial products, the gate
+    constraints interpreted inside the quotient kernel, quotient commitment, openings, FRI.  constants_sigmas is committed once, outside
+    the timing, as plonky2 does at circuit-build time.  Witness generation (numpy) is not timed: the path starts at the wire values."""
+    import ctypes as C
+    import torch
+    import sipp_amd
+    from sipp_amd._lib import to_device
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import plonk_synth as ps
+    n = 1 << log_n
+    W, R, D, CH, rate_bits, cap_h, nq, pow_bits = 136, 80, 8, 2, 3, 4, 28, 16
+    circ = ps.circuit(W, R)
+    K = circ["num_constants"]
+    L = sipp_amd.lib()
+    cols_timed = W + CH * ((R + D - 1) // D) + CH * D                  # wires, zs_partial_products, quotient chunks
+    ws = int(8 * n * (9 * (K + R + cols_timed) + 64) + (4 << 30))
+    ctx = sipp_amd.Ctx(device=device, workspace_bytes=ws)
+    try:
+        pis = [3, 1, 4, 1, 5, 9, 2, 6]
+        st = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
+        st[0, :len(pis)] = torch.tensor(pis, dtype=torch.int64)
+        pih = [int(x) & 0xFFFFFFFFFFFFFFFF for x in ctx.poseidon_permute(st)[0, :4].tolist()]    # hash_n_to_hash_no_pad of <= 8 inputs
+        t0 = time.perf_counter()
+        wires, cs, _gate = ps.witness(circ, log_n, 2026, pih)
+        t_wit = time.perf_counter() - t0
+        d_w, d_cs = to_device(wires), to_device(cs)
+        gp = sipp_amd.PlonkParams(R, D, CH)
+        fp = sipp_amd.FriParams()
+        fp.rate_bits, fp.cap_height, fp.pow_bits, fp.num_queries, fp.pow_rule, fp.hiding = rate_bits, cap_h, pow_bits, nq, 0, 0
+        L.sipp_fri_const_arity(C.byref(fp), 4, 5, log_n)
+        gc = sipp_amd.PlonkCircuit.from_dict(circ)
+        digest = (0x53495050, 0x6f757465, 0x72706c6f, 0x6e6b3035)
+        cs_or, cs_cap, keep = ctx.commit_ex(d_cs, log_n, rate_bits, cap_h)          # once per circuit
+        prove = lambda: ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, fp, gc, digest, pis, cs_oracle=cs_or)
+        prove()
+        ctx.profile(True)
+        ctx.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pf = prove()
+        ctx.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        rep = {k: v["ms"] / steps for k, v in ctx.profile_report().items()}
+        ctx.profile(False)
+        del keep
+        ntt_names = [k for k in rep if k.startswith(("ntt_", "lde_", "bitrev"))]
+        leaf_names = [k for k in rep if k.startswith("poseidon_leaves")]
+        ntt_ms, leaf_ms = sum(rep[k] for k in ntt_names), sum(rep[k] for k in leaf_names)
+        # algorithmic bytes of the transforms: values -> coefficients -> blowup-8 LDE per column of wires and zs (8 N read, 8 N + 64 N
+        # written), coefficients -> LDE for the quotient chunks (8 N + 64 N), the quotient's own coset iNTT (2 x 8 N x 16 B)
+        zs_cols, q_cols = CH * ((R + D - 1) // D), CH * D
+        ntt_bytes = 80.0 * n * (W + zs_cols) + 72.0 * n * q_cols + 16.0 * 8 * n * CH
+        m = 8 * n
+        perms = m * sum((c + 7) // 8 for c in (W, zs_cols, q_cols))
+        leaf_bytes = 8.0 * m * (W + zs_cols + q_cols) + 3 * 32.0 * m
+        verified = None
+        if verify:
+            from tests import _oracle
+            ofp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_h, pow_bits=pow_bits, num_queries=nq, pow_rule=0, hiding=0, arity_bits=4,
+                                     final_poly_bits=5, degree_bits=log_n)
+            verified = _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
+        return {"what": "plonky2 prove() below witness generation on a synthetic circuit with gates as data (sipp_plonk_prove_gates)",
+                "shape": {"degree_bits": log_n, "num_wires": W, "num_routed_wires": R, "num_constants": K, "num_challenges": CH, "quotient_degree_factor": D,
+                          "rate_bits": rate_bits, "cap_height": cap_h, "num_queries": nq, "pow_bits": pow_bits, "arity": 16,
+                          "gates": ps.GATE_NAMES, "num_gate_constraints": circ["num_gate_constraints"], "program_words": int(len(circ["programs"]))},
+                "config_ref": "CircuitConfig::standard_ecc_config (reference src/verifier_circuit.rs:213); degree of the reference's circuit unknown "
+                              "(built by un-vendored crates): 2^%d rows here" % log_n,
+                "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified, "witness_generation_s_not_timed": t_wit,
+                "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
+                "roofline": {"transforms": {"bound": "hbm", "kernels": sorted(ntt_names), "algorithmic_bytes": ntt_bytes, "ms": ntt_ms,
+                                            "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ntt_ms else None},
+                             "leaf_hashing": {"bound": "valu", "kernels": sorted(leaf_names), "permutations": perms, "ms": leaf_ms,
+                                              "perms_per_s": perms / (leaf_ms * 1e-3) if leaf_ms else None,
+                                              "algorithmic_bytes": leaf_bytes, "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9 if leaf_ms else None,
+                                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if leaf_ms else None},
+                             "quotient_with_gates_ms": rep.get("plonk_quotient")}}
+    finally:
+        ctx.close()
+
+
 def air_revision():
     """the AIR is this repository's own specification (tools/air_gen.py): identify the revision the numbers belong to"""
     import hashlib
@@ -579,6 +666,14 @@ def main():
                                         "verifier_price": price_vs_world1([a.shape[0] for a in load_ios(n_s)], world, hardened)}
     if rank == 0:
         out["io_sharded"] = io_sharded
+        # secondary, one rank only: the outer plonky2 prover at the reference's circuit configuration (SIPP_BENCH_OUTER_PLONK=0 skips,
+        # SIPP_BENCH_OUTER_PLONK=<log2 rows> sizes it; default 2^18)
+        op_bits = os.environ.get("SIPP_BENCH_OUTER_PLONK", "18")
+        if world == 1 and op_bits not in ("", "0") and not serial:
+            try:
+                out["outer_plonk"] = outer_plonk_leg(local_rank, int(op_bits))
+            except Exception as e:                  # noqa: BLE001 -- never allowed to break the main line
+                out["outer_plonk"] = {"error": repr(e)}
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -147,4 +147,9 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU -- python3 b
                           for k, x in sorted(v.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]) if x["SQ_INSTS_VALU"] > 0}},
           open(dst + "_valu_by_kernel.json", "w"), indent=1)
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
+try:      # the outer-prover leg (scripts/perf_plonk.py under rocprofv3 --kernel-trace --stats)
+    shutil.copy("%s/plonk/run_kernel_stats.csv" % src, dst + "_plonk_kernel_stats.csv")
+    shutil.copy("%s/plonk.txt" % src, dst + "_plonk.txt")
+except Exception as ex:            # noqa: BLE001
+    print("no outer-prover profile:", ex)
 print(json.dumps(out, indent=1)[:3000])

@@ -168,7 +168,7 @@ def test_bench_timing_contract_over_rccl_with_one_rank():
     process group of ONE rank -- bench.py's barrier, max-over-ranks and (min, max)-over-ranks reductions on DEVICE tensors
     through RCCL, around the real timed region and the io_sharded leg"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(SIPP_BENCH_SINGLE_RANK_GROUP="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_OTHER_AIR="0", SIPP_BENCH_MAP_G2="0",
+    env.update(SIPP_BENCH_SINGLE_RANK_GROUP="1", SIPP_BENCH_IO_SHARD_N="128", SIPP_BENCH_OTHER_AIR="0", SIPP_BENCH_MAP_G2="0", SIPP_BENCH_OUTER_PLONK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline", "--inflight", "1"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)

@@ -151,18 +151,19 @@ def witness(circ, log_n, seed, pih):
     for q in range(3):
         flat[order[:, q]] = vals
     wires[:R] = flat.reshape(R, n)
-    # outputs
+    # outputs (on the rows of their gate only)
+    ia, isb, ibs = np.flatnonzero(ar), np.flatnonzero(sb), np.flatnonzero(bs)
+    ca0, ca1, cs0 = c0[ia], c1[ia], c0[isb]
     for k in range(n_ops):
-        out = gl_add(gl_mul(c0, gl_mul(wires[4 * k], wires[4 * k + 1])), gl_mul(c1, wires[4 * k + 2]))
-        wires[4 * k + 3] = np.where(ar, out, wires[4 * k + 3])
+        wires[4 * k + 3, ia] = gl_add(gl_mul(ca0, gl_mul(wires[4 * k, ia], wires[4 * k + 1, ia])), gl_mul(ca1, wires[4 * k + 2, ia]))
     for i in range(N_SBOX):
-        wires[N_SBOX + i] = np.where(sb, gl_pow7(gl_add(wires[i], c0)), wires[N_SBOX + i])
-    bits = rng.integers(0, 2, size=(N_LIMBS, n), dtype=np.uint64)
-    total = np.zeros(n, dtype=np.uint64)
+        wires[N_SBOX + i, isb] = gl_pow7(gl_add(wires[i, isb], cs0))
+    bits = rng.integers(0, 2, size=(N_LIMBS, len(ibs)), dtype=np.uint64)
+    total = np.zeros(len(ibs), dtype=np.uint64)
     for i in range(N_LIMBS):
-        wires[1 + i] = np.where(bs, bits[i], wires[1 + i])
+        wires[1 + i, ibs] = bits[i]
         total = total + (bits[i] << np.uint64(i))
-    wires[0] = np.where(bs, total % PP, wires[0])
+    wires[0, ibs] = total % PP
     for i in range(4):
         wires[i, 0] = np.uint64(int(pih[i]))
     # constants: selectors, gate constants; sigmas: k_col' w^row' of the cell a position maps to
@@ -170,7 +171,10 @@ def witness(circ, log_n, seed, pih):
     sel1 = np.where(gate == 4, gate, UNUSED).astype(np.uint64)
     pw = powers(root_of_unity(log_n), n)
     ks = np.array([pow(7, j, P) for j in range(R)], dtype=np.uint64)
-    sig = gl_mul(ks[perm >> log_n], pw[perm & (n - 1)]).reshape(R, n)
+    sig = np.empty((R, n), dtype=np.uint64)
+    pm = perm.reshape(R, n)
+    for j in range(R):                                   # column by column: the temporaries of gl_mul stay in cache
+        sig[j] = gl_mul(ks[pm[j] >> log_n], pw[pm[j] & (n - 1)])
     cs = np.concatenate([np.stack([sel0, sel1, c0, c1]), sig]).astype(np.uint64)
     return np.ascontiguousarray(wires), np.ascontiguousarray(cs), gate
 
