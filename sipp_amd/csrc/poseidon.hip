@@ -112,6 +112,9 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uin
                                                             uint32_t level0, uint32_t lw, uint32_t nlev) {
     // THIN (levels of at most 2^16 parents): two lanes per node (poseidon_pair.hpp), 128 parents per trip of the block
     __shared__ typename std::conditional<THIN, poseidon_pair::Tables, NoTables>::type T;
+    // FAT: the leaf kernel's permutation (linear layers on the matrix pipe; eleven state words per lane wait in LDS).  Its launches
+    // (sipp_k_merkle_levels) give every lane a parent on every level -- 1024, 512, 256 per block -- as the matrix-pipe form requires
+    __shared__ uint64_t stash[THIN ? 1 : 11 * 256];
     poseidon::mfma_v4i afrag = {0, 0, 0, 0};
     if constexpr (THIN) {
         poseidon_pair::load_tables(T);
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uin
                 for (int k = 0; k < 8; k++) st[k] = c[k];
 #pragma unroll
                 for (int k = 8; k < 12; k++) st[k] = 0;
-                poseidon::permute(st);
+                poseidon::permute<true>(st, stash + threadIdx.x, 256);
                 uint64_t* d = parent + 4 * (uint64_t)i;
                 d[0] = st[0];
                 d[1] = st[1];
@@ -422,8 +425,16 @@ int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, u
             // wide levels); the last launch is a single block over <= 2^10 nodes that climbs to the cap
             uint32_t lw = log_nodes <= 10 ? log_nodes : log_nodes >= 18 ? 10 : 8;
             uint32_t nlev = lw < top - level ? lw : top - level;
-            const unsigned blocks = 1u << (log_nodes - lw);
             const uint64_t widest_parents = (uint64_t)1 << (log_nodes - 1);
+            if (widest_parents > thin_threshold()) {
+                // FAT levels (one state per lane): a block climbs only while every lane has a parent -- 2^11 nodes -> 1024, 512, 256
+                // parents, three levels per launch.  Climbing ten levels in one block (round 1 - 4) left its lanes idle on seven of
+                // them: eleven permutation times for 1023 permutations, 36 % of the lanes' time (7.8 -> 3.0 ms for the three
+                // 2^21-leaf trees of bench.py's outer_plonk leg); the thin levels below keep the subtree form (few nodes, launch-bound)
+                lw = 11;
+                nlev = 3 < top - level ? 3 : top - level;
+            }
+            const unsigned blocks = 1u << (log_nodes - lw);
             ProfScope ps(ctx, "merkle_subtree");
             if (widest_parents <= thin_threshold())
                 hipLaunchKernelGGL(merkle_subtree_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, d_tree, log_leaves, level, lw, nlev);
