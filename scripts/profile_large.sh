@@ -10,6 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export SIPP_BENCH_IO_SHARD_N=0
 export SIPP_BENCH_MAP_G2=0       # the profiled command is the instance alone: no messages -> G2 leg,
+export SIPP_BENCH_OUTER_PLONK=0  # no outer-prover leg,
 export SIPP_BENCH_OTHER_AIR=0    # no leg for the other AIR variant (SIPP_BENCH_PLAIN_AIR=1 in the environment profiles the plain kinds)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --n $N --steps $STEPS --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log" || exit 1
 echo "stats done $N"

@@ -29,7 +29,7 @@ f, nf = counters("pmc_f")
 w, nw = counters("pmc_w")
 instances = 3      # the PMC passes run bench.py --steps 1 --warmup 1 plus the serial step bench.py appends
 NTT = ("ntt_pass_kernel", "lde_column_kernel", "lde_gather_kernel", "lde_mid_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel",
-       "tree_gather_kernel", "tree_mid_kernel", "tree_pass_kernel")
+       "tree_gather_kernel", "tree_mid_kernel", "tree_pass_kernel", "tree_pass_dma_kernel", "tree_fwd_dma_kernel")
 alg = line["roofline_ntt"]["algorithmic_bytes_per_step"]
 traffic = sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / instances
 out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 bench.py --n %s --steps 1 --warmup 1 --no-cpu-baseline --inflight 1"

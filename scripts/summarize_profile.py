@@ -128,13 +128,14 @@ out = {
     # every kernel alone on the chip (counter collection serialises the dispatches)
     "leaf_one_alone": alone(vd, "poseidon_leaves_kernel"),
     "leaf_pair_alone": alone(vd, "poseidon_leaves_pair_kernel"),
-    "transforms_alone": {k: alone(vd, k) for k in ("tree_pass_kernel", "tree_mid_kernel", "tree_gather_kernel", "lde_column_kernel") if alone(vd, k)},
+    "transforms_alone": {k: alone(vd, k) for k in ("tree_fwd_dma_kernel", "tree_pass_dma_kernel", "tree_pass_kernel", "tree_mid_kernel", "tree_gather_kernel", "lde_column_kernel")
+                         if alone(vd, k)},
     "valu_calibration": {"what": "the same counters over scripts/ubench/enc_rates (profiles/<round>_enc_rates.txt): quad-cycles (4 cycles) the VALU "
                                  "is busy per instruction of each FORM; a form that pairs (SQ_ACTIVE_INST_VALU2) costs half a quad-cycle",
                          "forms": calib},
 }
 NTT = ("ntt_pass_kernel", "lde_column_kernel", "bitrev_tiled_kernel", "bitrev_cols_kernel", "tree_gather_kernel", "tree_mid_kernel",
-       "tree_pass_kernel")
+       "tree_pass_kernel", "tree_pass_dma_kernel", "tree_fwd_dma_kernel")
 out["ntt"] = {"kernels": {k: {"launches": nf.get(k, 0), "FETCH_SIZE_kb_sum": f[k]["FETCH_SIZE"], "WRITE_SIZE_kb_sum": w[k]["WRITE_SIZE"]}
                           for k in NTT if nf.get(k, 0)},
               "traffic_bytes_per_instance": sum(2.0 * f[k]["FETCH_SIZE"] + w[k]["WRITE_SIZE"] for k in NTT) * 1024.0 / steps_profiled,
