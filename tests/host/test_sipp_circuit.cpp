@@ -19,8 +19,8 @@
 
 #include "sipp_host.hpp"
 
-struct orc_config {
-    uint32_t rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries, num_challenges;
+struct orc_config {      // oracle/stark.h, field for field (the checker's configuration: orc_default_config fills all ten)
+    uint32_t rate_bits, cap_height, pow_bits, arity_bits, final_poly_bits, num_queries, num_challenges, pow_rule, fs_rule, lookup_rule;
 };
 extern "C" void orc_default_config(orc_config* c);
 extern "C" int orc_stark_verify(const uint64_t* proof, size_t len, const orc_config* cfg);

@@ -22,6 +22,21 @@ def build_host_test():
     return EXE
 
 
+def test_host_test_mirrors_the_oracle_config_struct():
+    """tests/host/test_sipp_circuit.cpp declares the checker's orc_config itself (it links liboracle.so without its headers): the
+    declaration must list the fields of oracle/stark.h in order -- a shorter mirror lets orc_default_config write past the object"""
+    import re
+
+    def fields(text, start):
+        body = text[text.index(start):]
+        body = body[body.index("{") + 1:body.index("}")]
+        body = re.sub(r"/\*.*?\*/|//[^\n]*", "", body, flags=re.S)
+        return [n.strip() for part in body.split(";") for n in part.replace("uint32_t", "").split(",") if n.strip()]
+    want = fields(open(os.path.join(ROOT, "oracle", "stark.h")).read(), "typedef struct {")
+    got = fields(open(os.path.join(HOST, "test_sipp_circuit.cpp")).read(), "struct orc_config {")
+    assert want == got and len(want) == 10, (want, got)
+
+
 def test_header_is_plain_c():
     """include/sipp_hip.h is the FFI surface: it must compile as C (what cgo / bindgen / ctypes consume)."""
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
