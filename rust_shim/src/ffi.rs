@@ -92,6 +92,31 @@ pub struct SippPlonkParams {
     pub num_challenges: u32,
 }
 
+/// one gate type of a circuit given as data (sipp_hip.h, "gates as data"): its selector and where its constraint programs start
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkGate {
+    pub selector_index: u32,
+    pub row: u32,
+    pub group_lo: u32,
+    pub group_hi: u32,
+    pub prog_offset: u32,
+    pub num_constraints: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkCircuit {
+    pub num_wires: u32,
+    pub num_constants: u32,
+    pub num_selectors: u32,
+    pub num_gates: u32,
+    pub gates: *const SippPlonkGate,
+    /// per constraint: n_mono, then per monomial coef, n_factors, (kind, index) pairs; kind 0 = wire, 1 = constant column, 2 = public_inputs_hash word
+    pub programs: *const i64,
+    pub program_words: u32,
+}
+
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
@@ -164,6 +189,13 @@ extern "C" {
                                fp: *const SippFriParams, circuit_digest: *const u64, public_inputs: *const u64, n_public_inputs: u32,
                                d_gate_terms: *const u64, num_gate_terms: u32, proof_out: *mut u64, proof_cap: usize,
                                proof_len: *mut usize) -> c_int;
+    /// prove() except witness generation: the gate constraints are interpreted on the device from the circuit description
+    pub fn sipp_plonk_gates_proof_size(log_n: u32, p: *const SippPlonkParams, fp: *const SippFriParams, c: *const SippPlonkCircuit,
+                                       n_public_inputs: u32) -> usize;
+    pub fn sipp_plonk_prove_gates(ctx: *mut SippCtxOpaque, d_wires: *const u64, d_constants_sigmas: *const u64, wires_oracle: *const SippOracle,
+                                  wires_cap: *const u64, constants_sigmas_oracle: *const SippOracle, log_n: u32, p: *const SippPlonkParams,
+                                  fp: *const SippFriParams, c: *const SippPlonkCircuit, circuit_digest: *const u64, public_inputs: *const u64,
+                                  n_public_inputs: u32, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
     pub fn sipp_ntt_batch(ctx: *mut SippCtxOpaque, d_cols: *mut u64, col_stride: usize, ncols: usize, log_n: u32, inverse: c_int) -> c_int;
     pub fn sipp_lde_batch(ctx: *mut SippCtxOpaque, d_values: *const u64, d_coeffs: *mut u64, d_lde: *mut u64, ncols: usize, log_n: u32) -> c_int;
     pub fn sipp_poseidon_leaves(ctx: *mut SippCtxOpaque, d_lde: *const u64, ncols: usize, log_leaves: u32, d_digests: *mut u64) -> c_int;
