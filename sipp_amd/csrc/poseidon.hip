@@ -119,6 +119,11 @@ __global__ void __launch_bounds__(256) merkle_subtree_kernel(uint64_t* tree, uin
     if constexpr (THIN) {
         poseidon_pair::load_tables(T);
         afrag = poseidon_pair::mds_fragment(threadIdx.x & 63);
+        // the thin levels are a chain of dependent permutations (one per level) run by a few waves: ahead of the fat kernels' waves they
+        // share a SIMD with (issue arbitration: priority, then age), like the thin leaf kernel's.  scripts/ab_prebuilt.sh, two boxes, five
+        // alternating passes: lone instance -1.1 ms (55.6 -> 54.3; 56.4 -> 55.2), queue -0.1 ... -0.4; levels 2 / 3 the same.  The same
+        // level on every non-hash kernel costs 1 - 3 ms, on the thin chain kernels alone (curve chains, FRI tail) adds nothing.
+        __builtin_amdgcn_s_setprio(1);
     }
     uint64_t off = 0;
     for (uint32_t l = 0; l < level0; l++) off += (uint64_t)1 << (log_leaves - l);

@@ -332,3 +332,47 @@ def test_pool_streams_and_dedicated_queues_give_the_same_proofs():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-3:] == here
+
+
+def test_instance_queue_refuses_slots_that_do_not_fit_and_never_picks_one_ctx():
+    """sipp_instances_prove needs three DISTINCT ctxs per slot, so InstanceQueue never takes Instance's one-ctx fallback, and
+    a queue whose arenas exceed the card's free memory is refused before the first allocation with SIPP_E_NOMEM and a message that says
+    what to change"""
+    import sipp_amd
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
+    ios = [d["g1"], d["g2"], d["fq12"]]
+    q = sipp_amd.InstanceQueue([a.shape[0] for a in ios], in_flight=2)
+    try:
+        assert all(not s.single_ctx and len(s.distinct_ctxs()) == 3 for s in q.slots)
+        proofs = q.prove([ios, ios, ios])
+        assert len(proofs) == 3 and all(len(p[k]) > 0 for p in proofs for k in range(3))
+    finally:
+        q.close()
+    with pytest.raises(sipp_amd.SippError) as e:
+        sipp_amd.InstanceQueue([4095, 4095, 24], in_flight=4, hardened=True)        # 4 x 276 GB
+    assert e.value.code == -3 and "in_flight" in str(e.value)
+
+
+def test_one_ctx_instance_attempts_every_proof_and_returns_the_first_failure():
+    """the one-ctx branch of sipp_instance_prove behaves like the three-ctx path: a kind that fails (an unprovable G2 record) does not
+    stop the others; the first failing status comes back and the failed kind reports length 0"""
+    import ctypes as C
+    import sipp_amd
+    from tests import _oracle
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
+    ios = [d["g1"].copy(), d["g2"].copy(), d["fq12"].copy()]
+    ios[1][0, -1] ^= 1                                       # claimed output off by one
+    one = sipp_amd.Instance([a.shape[0] for a in ios], single_ctx=True)
+    try:
+        L, vp = sipp_amd.lib(), C.c_void_p
+        h = (vp * 3)(*[c.h for c in one.ctxs])
+        pi = (vp * 3)(*[a.ctypes.data for a in ios])
+        ni = (C.c_size_t * 3)(*[a.shape[0] for a in ios])
+        po = (vp * 3)(*[o.ctypes.data for o in one.out])
+        pc = (C.c_size_t * 3)(*one.caps)
+        pl = (C.c_size_t * 3)()
+        assert L.sipp_instance_prove(h, pi, ni, po, pc, pl) == -8          # SIPP_E_WITNESS
+        assert pl[1] == 0 and pl[0] > 0 and pl[2] > 0
+        assert _oracle.stark_verify(one.out[0][: pl[0]]) == 0 and _oracle.stark_verify(one.out[2][: pl[2]]) == 0
+    finally:
+        one.close()
