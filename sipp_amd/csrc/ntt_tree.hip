@@ -797,11 +797,16 @@ static int tree_from_values_fused(sipp_ctx* ctx, const uint64_t* d_values, uint6
     const uint64_t* twf = tree_coset_table(ctx, L + rate_bits);
     if (!twi || !twf) return SIPP_E_HIP;
     const uint32_t k2 = 8;
-    const std::vector<uint32_t> fks = split_bits(L - LTILE);          // forward strided sweeps, top first
+    std::vector<uint32_t> fks = split_bits(L - LTILE);                // forward strided sweeps, top first
+    // nine levels above the contiguous sweep (2^21 rows: n = 4096) ALL inside the middle sweep -- tile 2^9 rows x 8 columns, 64-byte row
+    // segments -- instead of five there and a strided sweep of four (memory-bound: 2 N read + 2 N written for four levels): all tree
+    // sweeps of 2^21 x 128 10.03 -> 9.13 ms (round 5).  Ten levels (32-byte segments) are NOT worth it: the middle sweep of 2^18 x 1024
+    // with ten inverse levels took 7.4 instead of 3.0 + 0.84 ms.
+    if (L - LTILE == 9) fks = {9};
     const uint32_t kf = fks[0];
-    // inverse levels inside the middle sweep: all that is left above the gather when they fit a tile's rows (L <= 16: three sweeps in
+    // inverse levels inside the middle sweep: all that is left above the gather when they fit a tile's rows (L <= 17: three sweeps in
     // all), else as many as the forward's top sweep has
-    const uint32_t ki = L - k2 <= 8 ? L - k2 : kf;
+    const uint32_t ki = L - k2 <= 9 ? L - k2 : kf;                    // (nine: 2^17 rows in three sweeps, 3.90 -> 3.79 ms for 1024 columns)
     const uint32_t km = kf > ki ? kf : ki;
     const unsigned halves = 1u << rate_bits;
     {
