@@ -246,3 +246,14 @@ def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_rout
         with pytest.raises(sipp_amd.SippError) as e:
             ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, gfp, sipp_amd.PlonkCircuit.from_dict(c2), digest, pis)
         assert e.value.code == -1
+
+
+def test_bench_outer_plonk_leg_runs_and_verifies():
+    """bench.py's `outer_plonk` leg (plonky2 prove() at the standard_ecc_config column counts, gates as data) at a small size: the leg
+    proves, the oracle's verifier accepts the proof, and the object carries its own roofline entries"""
+    import bench
+    r = bench.outer_plonk_leg(0, log_n=12, steps=1)
+    assert r["verified"] is True and r["ms_per_proof"] > 0 and r["proof_words"] > 0
+    assert r["shape"]["num_wires"] == 136 and r["shape"]["num_routed_wires"] == 80 and r["shape"]["rate_bits"] == 3
+    assert r["roofline"]["transforms"]["algorithmic_bytes"] > 0 and r["roofline"]["leaf_hashing"]["permutations"] == (8 << 12) * (17 + 3 + 2)
+    assert "plonk_quotient" in r["kernel_ms_per_proof"]
