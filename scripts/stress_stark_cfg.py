@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One-off stress run of the three STARK provers under RANDOM sipp_stark_config values (GPU box): blowup 2 / 4 / 8, cap height,
-proof-of-work bits and rule, reduction arity 2 .. 16, final polynomial size, query count -- on a random number of records of the
-n = 8 fixture, every proof word for word against the CPU oracle and through its verifier; a configuration one side refuses must
-be refused by the other.  usage: stress_stark_cfg.py [first_seed=900] [count=30]"""
+proof-of-work bits and rule, Fiat-Shamir start and lookup-challenge rule (round 5: fs_rule, lookup_rule), reduction arity 2 .. 16, final
+polynomial size, query count -- plain and hardened curve kinds, on a random number of records of the n = 8 fixture, every proof word
+for word against the CPU oracle and through its verifier; a configuration one side refuses must be refused by the other.  usage: stress_stark_cfg.py [first_seed=900] [count=30]"""
 import ctypes as C
 import os
 import sys
@@ -27,13 +27,14 @@ for seed in range(first, first + count):
     cfg, ocfg = sipp_amd.default_config(), _oracle.default_config()
     vals = dict(rate_bits=int(rng.integers(1, 4)), cap_height=int(rng.integers(0, 7)), pow_bits=int(rng.integers(0, 15)),
                 arity_bits=int(rng.integers(1, 5)), final_poly_bits=int(rng.integers(0, 8)), num_queries=int(rng.integers(1, 40)),
-                pow_rule=int(rng.integers(0, 2)))
+                pow_rule=int(rng.integers(0, 2)), fs_rule=int(rng.integers(0, 2)), lookup_rule=int(rng.integers(0, 2)))
     for c in (cfg, ocfg):
         for k, v in vals.items():
             setattr(c, k, v)
-    kind = int(rng.integers(0, 3))
-    num = int(rng.integers(1, lists[kind].shape[0] + 1))
-    ios = np.ascontiguousarray(lists[kind][:num])
+    kind = int(rng.integers(0, 5))
+    kind = kind if kind < 3 else kind + 1                      # 0 G1, 1 G2, 2 Fq12, 4 / 5 the hardened G1 / G2 AIRs
+    num = int(rng.integers(1, lists[kind & 3].shape[0] + 1))
+    ios = np.ascontiguousarray(lists[kind & 3][:num])
     tag = "seed %d kind %d records %d %s" % (seed, kind, num, vals)
     try:
         ref = _oracle.stark_prove(kind, ios, ocfg)
