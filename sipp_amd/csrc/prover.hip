@@ -621,8 +621,10 @@ __global__ void pow_table4_kernel(Pow4Args a) {
 // The power tables are read once per block and k, i.e. once per OCOLS coefficients; the products are summed lazily in
 // 160 bits (gl::Acc160) and reduced once per lane.
 // (more columns per block would re-use the tables but leave too few waves in flight: measured)
+// (tn = the distance between the two components of a power table: the tables hold [c0[n] | c1[n]]; a block that sums a SEGMENT of
+// the rows -- openings_seg_kernel -- passes pointers to the segment's first row and the whole table's n)
 __device__ __forceinline__ void openings_column(const uint64_t* __restrict__ col, size_t n, const uint64_t* __restrict__ t0,
-                                                const uint64_t* __restrict__ t1, uint64_t* __restrict__ out4) {
+                                                const uint64_t* __restrict__ t1, size_t tn, uint64_t* __restrict__ out4) {
     __shared__ uint64_t s[4][256];
     gl::Acc160 acc[4];
     // OB coefficient indices per trip: all their loads are issued before the first product (the rolled loop waited for five
@@ -635,9 +637,9 @@ __device__ __forceinline__ void openings_column(const uint64_t* __restrict__ col
         for (int b = 0; b < OB; b++) {
             const size_t kb = k + (size_t)b * 256;
             p0[b] = t0[kb];
-            p1[b] = t0[n + kb];
+            p1[b] = t0[tn + kb];
             q0[b] = t1 ? t1[kb] : 0;
-            q1[b] = t1 ? t1[n + kb] : 0;
+            q1[b] = t1 ? t1[tn + kb] : 0;
             v[b] = col[kb];
         }
 #pragma unroll
@@ -653,10 +655,10 @@ __device__ __forceinline__ void openings_column(const uint64_t* __restrict__ col
     for (; k < n; k += 256) {
         const uint64_t v = col[k];
         acc[0].mac(v, t0[k]);
-        acc[1].mac(v, t0[n + k]);
+        acc[1].mac(v, t0[tn + k]);
         if (t1) {
             acc[2].mac(v, t1[k]);
-            acc[3].mac(v, t1[n + k]);
+            acc[3].mac(v, t1[tn + k]);
         }
     }
 #pragma unroll
@@ -673,7 +675,27 @@ __device__ __forceinline__ void openings_column(const uint64_t* __restrict__ col
 __global__ void __launch_bounds__(256) openings_kernel(const uint64_t* __restrict__ coeffs, size_t n, uint32_t ncols,
                                                       const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
                                                       uint64_t* __restrict__ out) {
-    openings_column(coeffs + (size_t)blockIdx.x * n, n, t0, t1, out + (size_t)blockIdx.x * 4);
+    openings_column(coeffs + (size_t)blockIdx.x * n, n, t0, t1, n, out + (size_t)blockIdx.x * 4);
+}
+// Launches of FEW columns (the outer prover's oracles: 84 + 136 + 20 + 16 polynomials of 2^18 .. 2^20 coefficients, one launch per
+// range of a batch) leave most of the 256 CUs idle with one block per column: 2.9 ms of a 37.7-ms proof at 2^18 rows.  Block (column,
+// segment) sums gridDim.y-th of the rows into partial[column][segment][4]; openings_fold_kernel adds the segments (field sums: the
+// result does not depend on the split).
+__global__ void __launch_bounds__(256) openings_seg_kernel(const uint64_t* __restrict__ coeffs, size_t n, size_t seg_len,
+                                                          const uint64_t* __restrict__ t0, const uint64_t* __restrict__ t1,
+                                                          uint64_t* __restrict__ partial) {
+    const size_t lo = (size_t)blockIdx.y * seg_len, len = min(seg_len, n - lo);
+    openings_column(coeffs + (size_t)blockIdx.x * n + lo, len, t0 + lo, t1 ? t1 + lo : nullptr, n,
+                    partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4);
+}
+__global__ void __launch_bounds__(256) openings_fold_kernel(const uint64_t* __restrict__ partial, uint32_t ncols, uint32_t segs,
+                                                           uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;     // (column, component)
+    if (i >= 4 * ncols) return;
+    const uint64_t* p = partial + (size_t)(i >> 2) * segs * 4 + (i & 3);
+    uint64_t acc = 0;
+    for (uint32_t sg = 0; sg < segs; sg++) acc = gl::add(acc, p[4 * sg]);
+    out[i] = acc;
 }
 
 // the three oracles of a STARK (trace, Z, quotient chunks) in ONE launch: block b opens column b of their concatenation; the
@@ -697,7 +719,7 @@ __global__ void __launch_bounds__(256) openings3_kernel(Open3Args a) {
         col = a.coeffs[2] + (size_t)(b - a.ncols[0] - a.ncols[1]) * a.n;
         t1 = nullptr;
     }
-    openings_column(col, a.n, a.t0, t1, a.out + (size_t)b * 4);
+    openings_column(col, a.n, a.t0, t1, a.n, a.out + (size_t)b * 4);
 }
 
 // partial[slice][{0,1}][{c0,c1}][k]: acc over the columns of this slice of alpha^c * coef_c[k];
@@ -1238,8 +1260,21 @@ int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_
                     const uint64_t* d_t1, uint64_t* d_out) {
     if (!ncols) return SIPP_OK;
     ProfScope ps(ctx, "openings");
-    hipLaunchKernelGGL(openings_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, d_coeffs, n, (uint32_t)ncols, d_t0, d_t1,
-                       d_out);
+    // about 2048 blocks whatever the column count; a segment is at least 1024 rows
+    const size_t want = (2048 + ncols - 1) / ncols, segs = std::min<size_t>(std::min<size_t>(64, want), n / 1024);
+    if (segs <= 1) {
+        hipLaunchKernelGGL(openings_kernel, dim3((unsigned)ncols), dim3(256), 0, ctx->stream, d_coeffs, n, (uint32_t)ncols, d_t0, d_t1,
+                           d_out);
+    } else {
+        ArenaScope scope(ctx);   // (the stream is ordered: later users of the block wait)
+        uint64_t* partial = arena_alloc_t<uint64_t>(ctx, ncols * segs * 4);
+        if (!partial) return SIPP_E_NOMEM;
+        const size_t seg_len = (n + segs - 1) / segs;
+        hipLaunchKernelGGL(openings_seg_kernel, dim3((unsigned)ncols, (unsigned)segs), dim3(256), 0, ctx->stream, d_coeffs, n, seg_len,
+                           d_t0, d_t1, partial);
+        hipLaunchKernelGGL(openings_fold_kernel, dim3((unsigned)((4 * ncols + 255) / 256)), dim3(256), 0, ctx->stream, partial,
+                           (uint32_t)ncols, (uint32_t)segs, d_out);
+    }
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }
