@@ -677,8 +677,19 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
 // values [ncols][n] natural -> coefficients [ncols][n] natural + LDE [ncols][n << rate_bits] in leaf order.  Whole column in LDS for
 // 2^10 .. 2^14 rows, the tree-of-rings sweeps of ntt_tree.hip from 2^15; anything else (shorter columns, d_coeffs aliasing d_values
 // on a long column) is SIPP_E_UNSUPPORTED and the caller runs the pass-by-pass path (bit-reversal copy, DIT, DIF).
+// Columns of 2^13 / 2^14 rows (the Fq12 STARK at n = 128 .. 256: 2524 + 1512 columns of 2^14) take the tree sweeps of ntt_tree.hip, not
+// lde_column_kernel (round 5): that kernel holds the whole column in LDS -- ONE 1024-lane block per CU, a block-wide barrier per stage,
+// separate twiddle passes over the tile -- and ran at half the tree sweeps' butterfly rate: 2.31 ms of transforms per n = 128 instance
+// against 1.52 ms in three tree sweeps (gather | middle | contiguous), although those move 9 N words over HBM instead of 4 N.
+// 2^10 .. 2^12 rows stay here (the fused tree needs a strided top sweep: 2^13).  SIPP_LDE_COLUMN_MAX=14 restores the old routing.
+static uint32_t lde_column_max() {
+    static const uint32_t v = [] { const char* e = getenv("SIPP_LDE_COLUMN_MAX"); return e ? (uint32_t)atoi(e) : 12u; }();
+    return v;
+}
 int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                          uint32_t rate_bits) {
+    if (log_n > lde_column_max() && log_n >= 13 && log_n <= 14 && d_values != d_coeffs)
+        return sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
     if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
     if (sipp_tree_ntt_enabled(log_n) && d_values != d_coeffs)
@@ -686,6 +697,7 @@ int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_co
     return SIPP_E_UNSUPPORTED;
 }
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {
+    if (log_n > lde_column_max() && log_n >= 13 && log_n <= 14) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
     if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_coeffs, (size_t)1 << log_n, nullptr, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, true);
     if (sipp_tree_ntt_enabled(log_n)) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);

@@ -785,7 +785,7 @@ int tree_forward(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_
 
 }  // namespace
 
-// the tree sweeps take every column of 2^15 .. 2^25 rows (shorter ones fit LDS whole: ntt.hip lde_column)
+// the tree sweeps take every column of 2^15 .. 2^25 rows here; ntt.hip routes 2^13 / 2^14 to them as well (shorter ones fit LDS whole: lde_column)
 bool sipp_tree_ntt_enabled(uint32_t log_n) { return log_n >= 15 && log_n <= 25; }
 
 // values -> coefficients + LDE with the fused middle sweep: gather (8 bits) | strided inverse sweeps | middle (inverse top ki bits +
