@@ -18,7 +18,7 @@ lists = [d["g1"], d["g2"], d["fq12"]]
 cases = [(int(a), int(b)) for a, b in (c.split(":") for c in (sys.argv[1] if len(sys.argv) > 1 else "0:40,2:20,1:40,0:130").split(","))]
 bad = 0
 for kind, num in cases:
-    ios = np.ascontiguousarray(lists[kind][:num])
+    ios = np.ascontiguousarray(lists[kind & 3][:num])     # kinds 4 / 5: the hardened G1 / G2 AIRs over the same records
     ctx = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(kind, num))
     try:
         t = time.time()

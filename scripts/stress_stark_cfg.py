@@ -2,7 +2,7 @@
 """One-off stress run of the three STARK provers under RANDOM sipp_stark_config values (GPU box): blowup 2 / 4 / 8, cap height,
 proof-of-work bits and rule, Fiat-Shamir start and lookup-challenge rule (round 5: fs_rule, lookup_rule), reduction arity 2 .. 16, final
 polynomial size, query count -- plain and hardened curve kinds, on a random number of records of the n = 8 fixture, every proof word
-for word against the CPU oracle and through its verifier; a configuration one side refuses must be refused by the other.  usage: stress_stark_cfg.py [first_seed=900] [count=30]"""
+for word against the CPU oracle and through its verifier; a configuration one side refuses must be refused by the other.  usage: stress_stark_cfg.py [first_seed=900] [count=30] [max_records: 9 .. max records of the n = 1024 fixture instead (2^13 .. rows)]"""
 import ctypes as C
 import os
 import sys
@@ -17,8 +17,9 @@ from tests import _oracle  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 900
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
-lists = [d["g1"], d["g2"], d["fq12"]]
+maxrec = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n1024_ios.npz" if maxrec else "sipp_n8_ios.npz"))
+lists = [d["g1"][:maxrec], d["g2"][:maxrec], d["fq12"][:maxrec]] if maxrec else [d["g1"], d["g2"], d["fq12"]]
 L = sipp_amd.lib()
 bad = 0
 t0 = time.time()
@@ -33,7 +34,7 @@ for seed in range(first, first + count):
             setattr(c, k, v)
     kind = int(rng.integers(0, 5))
     kind = kind if kind < 3 else kind + 1                      # 0 G1, 1 G2, 2 Fq12, 4 / 5 the hardened G1 / G2 AIRs
-    num = int(rng.integers(1, lists[kind & 3].shape[0] + 1))
+    num = int(rng.integers(9 if maxrec else 1, lists[kind & 3].shape[0] + 1))
     ios = np.ascontiguousarray(lists[kind & 3][:num])
     tag = "seed %d kind %d records %d %s" % (seed, kind, num, vals)
     try:
