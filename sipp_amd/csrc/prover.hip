@@ -722,6 +722,93 @@ __global__ void __launch_bounds__(256) openings3_kernel(Open3Args a) {
     openings_column(col, a.n, a.t0, t1, a.n, a.out + (size_t)b * 4);
 }
 
+// The same three oracles with the power tables shared by a GROUP of columns (round 5).  With one block per column every block streams
+// its column AND the four power tables (two points x two components): five words from memory per coefficient, four of them tables --
+// at 2^21 rows the tables (64 MB) fit no cache and openings3_kernel ran at 0.4 of the bandwidth its columns alone need (29.8 ms per
+// n = 4096 instance against 11.7 ms for 58 GB at 5 TB/s).  Block (group of OG columns of ONE oracle, segment of the rows): a lane loads
+// the four table words of a row once and multiplies them into OG x 4 accumulators; partial[column][segment][4] is folded by
+// openings_fold_kernel.  The quotient chunks (oracle 2) are opened at the first point only.
+// (groups of 2 / 3 / 6 / 8 columns and 1 / 4 rows in flight per lane measured: 4 x 2 is the fastest at n = 128, 1024 and 4096 --
+//  0.75 / 4.4 / 18.3 ms of openings per instance against 1.08 / 7.5 / 29.8 with one block per column; 8 columns: 1.3 / 5.4 / 19.7)
+constexpr int OG = 4;
+struct OpenGArgs {
+    const uint64_t* coeffs[3];
+    uint32_t ncols[3];
+    size_t n, seg_len;
+    const uint64_t *t0, *t1;
+    uint64_t* partial;     // [total columns][segments][4]
+};
+__global__ void __launch_bounds__(256) openings_group_kernel(OpenGArgs a) {
+    __shared__ uint64_t s[4][256];
+    // which oracle, which columns
+    uint32_t g = blockIdx.x, orc = 0, col_base = 0;
+    while (orc < 2 && g >= (a.ncols[orc] + OG - 1) / OG) {
+        g -= (a.ncols[orc] + OG - 1) / OG;
+        col_base += a.ncols[orc];
+        orc++;
+    }
+    const uint32_t c0 = g * OG, cnt = min((uint32_t)OG, a.ncols[orc] - c0);
+    const bool two = orc < 2;
+    const size_t n = a.n, lo = (size_t)blockIdx.y * a.seg_len, hi = min(n, lo + a.seg_len);
+    const uint64_t* col = a.coeffs[orc] + (size_t)c0 * n;
+    gl::Acc160 acc[OG][4];
+    constexpr int OB = 2;
+    size_t k = lo + threadIdx.x;
+    for (; k + (OB - 1) * 256 < hi; k += OB * 256) {
+        uint64_t p0[OB], p1[OB], q0[OB], q1[OB], v[OB][OG];
+#pragma unroll
+        for (int b = 0; b < OB; b++) {
+            const size_t kb = k + (size_t)b * 256;
+            p0[b] = a.t0[kb];
+            p1[b] = a.t0[n + kb];
+            q0[b] = two ? a.t1[kb] : 0;
+            q1[b] = two ? a.t1[n + kb] : 0;
+#pragma unroll
+            for (int c = 0; c < OG; c++) v[b][c] = (uint32_t)c < cnt ? col[(size_t)c * n + kb] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < OB; b++)
+#pragma unroll
+            for (int c = 0; c < OG; c++) {
+                if ((uint32_t)c >= cnt) break;
+                acc[c][0].mac(v[b][c], p0[b]);
+                acc[c][1].mac(v[b][c], p1[b]);
+                if (two) {
+                    acc[c][2].mac(v[b][c], q0[b]);
+                    acc[c][3].mac(v[b][c], q1[b]);
+                }
+            }
+    }
+    for (; k < hi; k += 256) {
+        const uint64_t p0 = a.t0[k], p1 = a.t0[n + k], q0 = two ? a.t1[k] : 0, q1 = two ? a.t1[n + k] : 0;
+#pragma unroll
+        for (int c = 0; c < OG; c++) {
+            if ((uint32_t)c >= cnt) break;
+            const uint64_t v = col[(size_t)c * n + k];
+            acc[c][0].mac(v, p0);
+            acc[c][1].mac(v, p1);
+            if (two) {
+                acc[c][2].mac(v, q0);
+                acc[c][3].mac(v, q1);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < OG; c++) {
+        if ((uint32_t)c >= cnt) break;
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::canon(acc[c][q].reduce());
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                for (int q = 0; q < 4; q++) s[q][threadIdx.x] = gl::add(s[q][threadIdx.x], s[q][threadIdx.x + off]);
+            __syncthreads();
+        }
+        if (threadIdx.x < 4) a.partial[((size_t)(col_base + c0 + c) * gridDim.y + blockIdx.y) * 4 + threadIdx.x] = s[threadIdx.x][0];
+        __syncthreads();
+    }
+}
+
 // partial[slice][{0,1}][{c0,c1}][k]: acc over the columns of this slice of alpha^c * coef_c[k];
 // batch 1 (trace | Z) is the same sum restricted to c < n1.
 struct CombArgs {
@@ -1290,7 +1377,28 @@ int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uin
         a.ncols[i] = ncols[i];
     }
     a.n = n; a.t0 = d_t0; a.t1 = d_t1; a.out = d_out;
-    hipLaunchKernelGGL(openings3_kernel, dim3(total), dim3(256), 0, ctx->stream, a);
+    static const int grouped = [] { const char* e = getenv("SIPP_OPENINGS_GROUPED"); return e ? atoi(e) : 1; }();
+    if (!grouped || n < 1024) {
+        hipLaunchKernelGGL(openings3_kernel, dim3(total), dim3(256), 0, ctx->stream, a);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+        return SIPP_OK;
+    }
+    OpenGArgs g;
+    unsigned groups = 0;
+    for (int i = 0; i < 3; i++) {
+        g.coeffs[i] = d_coeffs[i];
+        g.ncols[i] = ncols[i];
+        groups += (ncols[i] + OG - 1) / OG;
+    }
+    // about 4096 blocks; a segment is at least 1024 rows and there are at most SIPP_OPENINGS_MAX_SEGS of them (the arena contract)
+    const size_t segs = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(SIPP_OPENINGS_MAX_SEGS, (4096 + groups - 1) / groups), n / 1024));
+    ArenaScope scope(ctx);   // (the stream is ordered: later users of the block wait)
+    g.partial = arena_alloc_t<uint64_t>(ctx, (size_t)total * segs * 4);
+    if (!g.partial) return SIPP_E_NOMEM;
+    g.n = n; g.seg_len = (n + segs - 1) / segs; g.t0 = d_t0; g.t1 = d_t1;
+    hipLaunchKernelGGL(openings_group_kernel, dim3(groups, (unsigned)segs), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(openings_fold_kernel, dim3((4 * total + 255) / 256), dim3(256), 0, ctx->stream, g.partial, (uint32_t)total,
+                       (uint32_t)segs, d_out);
     SIPP_CHECK_HIP(ctx, hipGetLastError());
     return SIPP_OK;
 }

@@ -592,6 +592,7 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
                    + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
                    + (sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) > 1                 // thin QUOTIENT domains (2N points, whatever
                           ? (size_t)sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) * 6 * 2 * n : 0)   // the blowup): ranges x 6 sums
+                   + (W + P + Q) * SIPP_OPENINGS_MAX_SEGS * 4               // partial sums of the grouped openings
                    + 80 * n;                                            // power tables, FRI layers, combine partials
     size_t bytes = 8 * words + nc * ((size_t)16 << s.air->table_bits)   // lookup histogram / scan scratch
                    + n * 400                                            // Jacobian row scratch of the curve chains
