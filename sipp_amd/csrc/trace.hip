@@ -417,17 +417,60 @@ __device__ __forceinline__ bool jac_same(const Jac<EXT>& p, const Jac<EXT>& q) {
     return F::is_zero(F::sub(F::mul(p.y, F::mul(z2, q.z)), F::mul(q.y, F::mul(z1, p.z))));
 }
 
+// Inverses of one NONZERO base-field value per lane for a whole block (Montgomery's trick through LDS, round 5): prefix and suffix
+// products by two Hillis-Steele scans, ONE inversion per block (lane 0, Euclid: ~37 k instructions) and two products per lane --
+// 2 log2(B) + 3 products per lane instead of a 380-product exponentiation in EVERY lane.  curve_rows_kernel spent 9 of 10
+// instructions in its two Fermat inversions per row (27 ms of an n = 4096 instance).  s, s2: B values of LDS each.
+template <int B>
+__device__ __forceinline__ Fq block_inverse(const Fq& v, Fq* s, Fq* s2) {
+    const int t = threadIdx.x;
+    const Fq one = fq::one_m();
+    Fq pre = v, suf = v;
+    s[t] = v;
+    s2[t] = v;
+    __syncthreads();
+#pragma unroll 1
+    for (int off = 1; off < B; off <<= 1) {
+        const Fq lo = t >= off ? s[t - off] : one, hi = t + off < B ? s2[t + off] : one;
+        __syncthreads();
+        pre = fq::mul(pre, lo);
+        suf = fq::mul(suf, hi);
+        s[t] = pre;
+        s2[t] = suf;
+        __syncthreads();
+    }
+    // s[t] = v_0 .. v_t, s2[t] = v_t .. v_{B-1}
+    if (t == 0) s2[0] = fq::inv_gcd(s[B - 1]);
+    __syncthreads();
+    Fq r = s2[0];
+    r = fq::mul(r, t ? s[t - 1] : one);
+    r = fq::mul(r, t + 1 < B ? s2[t + 1] : one);
+    return r;
+}
+template <int B>
+__device__ __forceinline__ Fq block_inverse_of(const Fq& w, Fq* s, Fq* s2) { return block_inverse<B>(w, s, s2); }
+template <int B>
+__device__ __forceinline__ Fq2 block_inverse_of(const Fq2& w, Fq* s, Fq* s2) {
+    const Fq ni = block_inverse<B>(fq::add(fq::sqr(w.c0), fq::sqr(w.c1)), s, s2);   // 1 / (w0 + w1 u) = (w0 - w1 u) / (w0^2 + w1^2)
+    return Fq2{fq::mul(w.c0, ni), fq::neg(fq::mul(w.c1, ni))};
+}
+
 // hard != 0: the hardened AIR (API kinds 4 / 5; tools/air_gen.py::build_curve).  Where the accumulator IS the running power on an add
 // row (R = P) or its negative (R = -P) the row gets slope 0 instead of SIPP_E_WITNESS (its result is not used: flags eq / ng).  After
 // R = P the double row still shows the OLD accumulator -- the sum, which is that row's own double, is handed over at the row's end (eqc).
 // After R = -P the accumulator is the identity: the state bit inf (column col_inf, written here from the scan's true accumulator) is
 // set and the R cells keep the last finite value until a used addition copies P.
+// The row needs 1 / (ZR ZP) for the affine coordinates and 1 / den for the slope; both come out of ONE inverse per row, of
+// w = (ZR ZP) b with b = ZR ZP D (add rows: den = D / (ZR ZP)^2, D = XP ZR^2 - XR ZP^2, slope = (YP ZR^3 - YR ZP^3) / b) or
+// b = 2 YP ZP (double rows: slope = 3 XP^2 / b) -- and that inverse is shared by the block (block_inverse).
+constexpr int ROWS_BLOCK = 256;
 template <int EXT>
-__global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __restrict__ rows, uint64_t* __restrict__ tr,
-                                                        size_t n, CurveCols c, int hard, int col_inf, int* __restrict__ err) {
+__global__ void __launch_bounds__(ROWS_BLOCK) curve_rows_kernel(const RowPts<EXT>* __restrict__ rows, uint64_t* __restrict__ tr,
+                                                               size_t n, CurveCols c, int hard, int col_inf, int* __restrict__ err) {
     using F = Fld<EXT>;
-    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n) return;
+    using T = typename F::T;
+    __shared__ Fq s_pre[ROWS_BLOCK], s_suf[ROWS_BLOCK];
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // n is a multiple of the block: every lane has a row
     RowPts<EXT> rp = rows[row];
     const bool is_add = (row & 1) == 0;
     const bool inf_here = jac_is_inf<EXT>(rp.R);
@@ -442,42 +485,40 @@ __global__ void __launch_bounds__(128) curve_rows_kernel(const RowPts<EXT>* __re
         const size_t row0 = row & ~(size_t)511;
         while (jac_is_inf<EXT>(rp.R) && r2 > row0) rp.R = rows[--r2].R;
     }
-    // affine: x = X / Z^2, y = Y / Z^3 ; one inversion for both points
-    auto zz = F::mul(rp.R.z, rp.P.z);
-    if (F::is_zero(zz)) {
-        atomicExch(err, SIPP_E_WITNESS);
-        return;
-    }
-    auto izz = F::inv(zz);
-    auto izr = F::mul(izz, rp.P.z), izp = F::mul(izz, rp.R.z);
-    auto izr2 = F::mul(izr, izr), izp2 = F::mul(izp, izp);
-    auto rx = F::mul(rp.R.x, izr2), ry = F::mul(rp.R.y, F::mul(izr2, izr));
-    auto px = F::mul(rp.P.x, izp2), py = F::mul(rp.P.y, F::mul(izp2, izp));
-    typename F::T num, den, xa, ya, xb;
+    const T one = one_of((T*)nullptr);
+    const T zz = F::mul(rp.R.z, rp.P.z);
+    bool bad = F::is_zero(zz);
+    T num, b;
     if (is_add) {
-        num = F::sub(py, ry);
-        den = F::sub(px, rx);
-        xa = rx;
-        ya = ry;
-        xb = px;
+        const T rz2 = F::sqr(rp.R.z), pz2 = F::sqr(rp.P.z);
+        num = F::sub(F::mul(rp.P.y, F::mul(rz2, rp.R.z)), F::mul(rp.R.y, F::mul(pz2, rp.P.z)));
+        b = F::mul(zz, F::sub(F::mul(rp.P.x, rz2), F::mul(rp.R.x, pz2)));
     } else {
-        auto pxx = F::mul(px, px);
+        const T pxx = F::sqr(rp.P.x);
         num = F::add(F::add(pxx, pxx), pxx);
-        den = F::add(py, py);
-        xa = px;
-        ya = py;
-        xb = px;
+        const T yz = F::mul(rp.P.y, rp.P.z);
+        b = F::add(yz, yz);
     }
     // R = +-P on an add row: cases of the hardened AIR (flags eq / ng; slope cells 0, result unused).  Under inf the R cells are the
     // stale last finite accumulator and the row's result is unused as well (t1 = 0): the same slope-0 row, as oracle/air.c fills it
-    const bool same = hard && is_add && F::is_zero(den);
-    if (F::is_zero(den) && !same) {
+    const bool same = hard && is_add && !bad && F::is_zero(b);
+    bad = bad || (F::is_zero(b) && !same);
+    const T asel = bad ? one : zz, bsel = (bad || same) ? one : b;
+    const T iw = block_inverse_of<ROWS_BLOCK>(F::mul(asel, bsel), s_pre, s_suf);
+    if (bad) {   // (after the block's barriers)
         atomicExch(err, SIPP_E_WITNESS);
         return;
     }
-    auto lam = same ? F::sub(num, num) : F::mul(num, F::inv(den));
-    auto x3 = F::sub(F::sub(F::mul(lam, lam), xa), xb);
-    auto y3 = F::sub(F::mul(lam, F::sub(xa, x3)), ya);
+    // affine: x = X / Z^2, y = Y / Z^3
+    const T izz = F::mul(bsel, iw), ib = F::mul(asel, iw);
+    const T izr = F::mul(izz, rp.P.z), izp = F::mul(izz, rp.R.z);
+    const T izr2 = F::mul(izr, izr), izp2 = F::mul(izp, izp);
+    const T rx = F::mul(rp.R.x, izr2), ry = F::mul(rp.R.y, F::mul(izr2, izr));
+    const T px = F::mul(rp.P.x, izp2), py = F::mul(rp.P.y, F::mul(izp2, izp));
+    const T xa = is_add ? rx : px, ya = is_add ? ry : py, xb = px;
+    const T lam = same ? F::sub(num, num) : F::mul(num, ib);
+    const T x3 = F::sub(F::sub(F::mul(lam, lam), xa), xb);
+    const T y3 = F::sub(F::mul(lam, F::sub(xa, x3)), ya);
     store_f_u16<EXT>(tr, n, c.Rx, row, rx);
     store_f_u16<EXT>(tr, n, c.Ry, row, ry);
     store_f_u16<EXT>(tr, n, c.Px, row, px);
@@ -1277,7 +1318,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
                 return SIPP_OK;
             }
             ProfScope ps(ctx, "trace_curve_rows");
-            hipLaunchKernelGGL(curve_rows_kernel<1>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
+            hipLaunchKernelGGL(curve_rows_kernel<1>, dim3((unsigned)(n / ROWS_BLOCK)), dim3(ROWS_BLOCK), 0, ctx->stream, rows,
                                d_trace, n, c, a->hardened, hard_inf_col, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         } else {
@@ -1299,7 +1340,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
                 return SIPP_OK;
             }
             ProfScope ps(ctx, "trace_curve_rows");
-            hipLaunchKernelGGL(curve_rows_kernel<2>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, rows,
+            hipLaunchKernelGGL(curve_rows_kernel<2>, dim3((unsigned)(n / ROWS_BLOCK)), dim3(ROWS_BLOCK), 0, ctx->stream, rows,
                                d_trace, n, c, a->hardened, hard_inf_col, d_err);
             SIPP_CHECK_HIP(ctx, hipGetLastError());
         }
