@@ -15,13 +15,19 @@ using gl::E2;
 // =====================================================================================================
 // permutation Z:  Z[r] = prod_{r' < r} (c + g)(t + b) / ((pin + g)(ptab + b))   (g = gamma_i, b = beta_i: independent
 // challenges for the column factor and the table factor, so the two multisets are permuted separately)
-// phase A: 256 lanes x ZR rows per block: batch-inverted ratios, block-local inclusive products
-// phase B: one block per Z column: exclusive scan of the block totals
-// phase C: Z = total_before_block * local_inclusive[r - 1]
+// Round 5: NO inversion per lane.  With num_r = (c + g)(t + b), den_r = (pin + g)(ptab + b) and T = prod over ALL rows of den,
+//     Z[r] = (prod_{r' < r} num_r') (prod_{r' >= r} den_r') / T,
+// an exclusive PREFIX product of the numerators times an inclusive SUFFIX product of the denominators: two scans and ONE field
+// inversion per column (phase B) instead of a batch inversion in every lane (72 products per 16 rows) and its three products per row --
+// 8 products per row and challenge instead of 14 (the kernel is bound by its products: 27 ms of an n = 4096 instance).
+// phase A: 256 lanes x ZR rows per block: lane-local and block-local prefix / suffix products, their product per row, two block totals
+// phase B: one block per Z column: exclusive prefix scan of the numerator totals, exclusive suffix scan of the denominator totals, 1 / T
+// phase C: Z = (prefix before the block)(suffix after the block) / T  x  what phase A left
 // =====================================================================================================
+// inclusive multiplicative scan across 256 lanes (Hillis-Steele in LDS); REV: from the last lane down (suffix products)
+template <bool REV>
 __device__ __forceinline__ uint64_t block_scan_mul_256(uint64_t v, uint64_t* s) {
-    // inclusive multiplicative scan across 256 lanes (Hillis-Steele in LDS)
-    const int t = threadIdx.x;
+    const int t = REV ? 255 - (int)threadIdx.x : (int)threadIdx.x;
     s[t] = v;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -31,91 +37,144 @@ __device__ __forceinline__ uint64_t block_scan_mul_256(uint64_t v, uint64_t* s) 
         s[t] = v;
         __syncthreads();
     }
-    return v;
+    return v;     // s[t'] holds the inclusive product of scan positions 0 .. t'
 }
 
-// ZR rows per lane: the lane's batch inversion (72 products) is shared by ZR rows -- 16 when the trace is long enough
+// four inclusive scans in one pass of barriers: v[0], v[1] prefix products (lane 0 upwards), v[2], v[3] suffix products (lane 255
+// downwards); afterwards s[q][lane] holds lane's inclusive value of scan q
+__device__ __forceinline__ void block_scan4_mul_256(uint64_t (&v)[4], uint64_t (*s)[256]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; q++) s[q][t] = v[q];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint64_t o[4];
+        o[0] = t >= off ? s[0][t - off] : 1;
+        o[1] = t >= off ? s[1][t - off] : 1;
+        o[2] = t + off < 256 ? s[2][t + off] : 1;
+        o[3] = t + off < 256 ? s[3][t + off] : 1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v[q] = gl::mul(v[q], o[q]);
+            s[q][t] = v[q];
+        }
+        __syncthreads();
+    }
+}
+
+// one block = one checked column x 256 ZR rows, BOTH challenges from one load of the four cells of a row (the kernel is bound by its
+// memory traffic: 8 + 2 words per checked cell with one block per (challenge, column), 4 + 2 here)
 template <int ZR>
 __global__ void __launch_bounds__(256) z_phase_a(const uint64_t* __restrict__ trace, size_t n, int nm, int nc, int cbase,
                                                 uint64_t gamma0, uint64_t gamma1, uint64_t beta0, uint64_t beta1,
                                                 uint64_t* __restrict__ zv, uint64_t* __restrict__ totals) {
-    __shared__ uint64_t s[256];
-    const int zi = blockIdx.y, i = zi / nc, j = zi % nc;
-    const uint64_t g = i ? gamma1 : gamma0, b = i ? beta1 : beta0;
+    __shared__ uint64_t s[4][256];
+    const int j = blockIdx.y;
     const size_t r0 = (size_t)blockIdx.x * (256 * ZR) + (size_t)threadIdx.x * ZR;
     // a lane owns ZR consecutive rows = ZR * 8 contiguous bytes of each column: 16-byte vector accesses
     const ulonglong2* col = reinterpret_cast<const ulonglong2*>(trace + (size_t)(cbase + j) * n + r0);
     const ulonglong2* tab = reinterpret_cast<const ulonglong2*>(trace + r0);
     const ulonglong2* pin = reinterpret_cast<const ulonglong2*>(trace + (size_t)(nm + j) * n + r0);
     const ulonglong2* ptab = reinterpret_cast<const ulonglong2*>(trace + (size_t)(nm + nc + j) * n + r0);
-    uint64_t num[ZR], den[ZR], pre[ZR];
+    uint64_t num[2][ZR], den[2][ZR];
 #pragma unroll
     for (int k = 0; k < ZR; k += 2) {
         const ulonglong2 c2 = col[k >> 1], t2 = tab[k >> 1], p2 = pin[k >> 1], q2 = ptab[k >> 1];
-        num[k] = gl::mul(gl::add(c2.x, g), gl::add(t2.x, b));
-        den[k] = gl::mul(gl::add(p2.x, g), gl::add(q2.x, b));
-        num[k + 1] = gl::mul(gl::add(c2.y, g), gl::add(t2.y, b));
-        den[k + 1] = gl::mul(gl::add(p2.y, g), gl::add(q2.y, b));
-    }
-    uint64_t acc = 1;
 #pragma unroll
-    for (int k = 0; k < ZR; k++) {
-        pre[k] = acc;
-        acc = gl::mul(acc, den[k]);
+        for (int i = 0; i < 2; i++) {
+            const uint64_t g = i ? gamma1 : gamma0, b = i ? beta1 : beta0;
+            num[i][k] = gl::mul(gl::add(c2.x, g), gl::add(t2.x, b));
+            den[i][k] = gl::mul(gl::add(p2.x, g), gl::add(q2.x, b));
+            num[i][k + 1] = gl::mul(gl::add(c2.y, g), gl::add(t2.y, b));
+            den[i][k + 1] = gl::mul(gl::add(p2.y, g), gl::add(q2.y, b));
+        }
     }
-    uint64_t inv = gl::inv(acc);
-    // num[k] becomes the ratio, then the lane-local inclusive product
+    // num[i][k] <- product of the lane's numerators BEFORE row k;  den[i][k] <- product of its denominators FROM row k on
+    uint64_t v[4];
 #pragma unroll
-    for (int k = ZR - 1; k >= 0; k--) {
-        const uint64_t di = gl::mul(inv, pre[k]);
-        inv = gl::mul(inv, den[k]);
-        num[k] = gl::mul(num[k], di);
+    for (int i = 0; i < 2; i++) {
+        uint64_t ntot = 1;
+#pragma unroll
+        for (int k = 0; k < ZR; k++) {
+            const uint64_t x = num[i][k];
+            num[i][k] = ntot;
+            ntot = gl::mul(ntot, x);
+        }
+#pragma unroll
+        for (int k = ZR - 2; k >= 0; k--) den[i][k] = gl::mul(den[i][k], den[i][k + 1]);
+        v[i] = ntot;
+        v[2 + i] = den[i][0];
     }
+    // block-local: numerators of the lanes before this one, denominators of the lanes after it
+    block_scan4_mul_256(v, s);
 #pragma unroll
-    for (int k = 1; k < ZR; k++) num[k] = gl::mul(num[k], num[k - 1]);
-    const uint64_t incl = block_scan_mul_256(num[ZR - 1], s);
-    const uint64_t before = threadIdx.x ? s[threadIdx.x - 1] : 1;
-    ulonglong2* out = reinterpret_cast<ulonglong2*>(zv + (size_t)zi * n + r0);
+    for (int i = 0; i < 2; i++) {
+        const int zi = i * nc + j;
+        const uint64_t nbefore = threadIdx.x ? s[i][threadIdx.x - 1] : 1, dafter = threadIdx.x < 255 ? s[2 + i][threadIdx.x + 1] : 1;
+        const uint64_t ls = gl::mul(nbefore, dafter);
+        ulonglong2* out = reinterpret_cast<ulonglong2*>(zv + (size_t)zi * n + r0);
 #pragma unroll
-    for (int k = 0; k < ZR; k += 2) {
-        ulonglong2 o;
-        o.x = gl::mul(before, num[k]);
-        o.y = gl::mul(before, num[k + 1]);
-        out[k >> 1] = o;
+        for (int k = 0; k < ZR; k += 2) {
+            ulonglong2 o;
+            o.x = gl::mul(ls, gl::mul(num[i][k], den[i][k]));
+            o.y = gl::mul(ls, gl::mul(num[i][k + 1], den[i][k + 1]));
+            out[k >> 1] = o;
+        }
+        // totals[zi][0][blk] = the block's numerators, totals[zi][1][blk] = its denominators
+        if (threadIdx.x == 255) totals[((size_t)zi * 2) * gridDim.x + blockIdx.x] = v[i];
+        if (threadIdx.x == 0) totals[((size_t)zi * 2 + 1) * gridDim.x + blockIdx.x] = v[2 + i];
     }
-    if (threadIdx.x == 255) totals[(size_t)zi * gridDim.x + blockIdx.x] = incl;
 }
 
 __global__ void __launch_bounds__(256) z_phase_b(uint64_t* __restrict__ totals, int nblk) {
-    // exclusive multiplicative scan of nblk totals of one Z column (nblk <= 2^15), chunked by 256
+    // per Z column (nblk <= 2^15 blocks, chunked by 256): tn[blk] <- (numerators of the blocks before blk) (denominators of the blocks
+    // after it) / T, T = all denominators
     __shared__ uint64_t s[256];
-    uint64_t* t = totals + (size_t)blockIdx.x * nblk;
+    uint64_t* tn = totals + (size_t)blockIdx.x * 2 * nblk;
+    uint64_t* td = tn + nblk;
+    // exclusive prefix products of tn, in place
     uint64_t carry = 1;
     for (int base = 0; base < nblk; base += 256) {
-        int idx = base + threadIdx.x;
-        uint64_t v = idx < nblk ? t[idx] : 1;
-        uint64_t incl = block_scan_mul_256(v, s);
-        uint64_t excl = gl::mul(carry, threadIdx.x ? s[threadIdx.x - 1] : 1);
-        uint64_t last = s[255];
+        const int idx = base + threadIdx.x;
+        const uint64_t v = idx < nblk ? tn[idx] : 1;
+        (void)block_scan_mul_256<false>(v, s);
+        const uint64_t excl = gl::mul(carry, threadIdx.x ? s[threadIdx.x - 1] : 1);
+        const uint64_t last = s[255];
         __syncthreads();
-        if (idx < nblk) t[idx] = excl;
+        if (idx < nblk) tn[idx] = excl;
         carry = gl::mul(carry, last);
-        (void)incl;
         __syncthreads();
     }
+    // exclusive suffix products of td, from the last chunk down; `carry` ends as T
+    carry = 1;
+    for (int base = ((nblk - 1) / 256) * 256; base >= 0; base -= 256) {
+        const int idx = base + threadIdx.x;
+        const uint64_t v = idx < nblk ? td[idx] : 1;
+        (void)block_scan_mul_256<true>(v, s);                    // s[255 - lane] = product of lanes lane .. 255
+        const uint64_t excl = gl::mul(carry, threadIdx.x < 255 ? s[255 - threadIdx.x - 1] : 1);
+        const uint64_t all = s[255];
+        __syncthreads();
+        if (idx < nblk) td[idx] = excl;
+        carry = gl::mul(carry, all);
+        __syncthreads();
+    }
+    const uint64_t tinv = gl::inv(carry);
+    for (int idx = threadIdx.x; idx < nblk; idx += 256) tn[idx] = gl::mul(gl::mul(tn[idx], td[idx]), tinv);
 }
 
 template <int ZR>
 __global__ void __launch_bounds__(256) z_phase_c(uint64_t* __restrict__ zv, size_t n, const uint64_t* __restrict__ totals) {
-    // in: block-local inclusive products L[r]; out: Z[r] = T_blk * L[r-1] (exclusive)
     constexpr int ZBLOCK = 256 * ZR;
-    __shared__ uint64_t s[ZBLOCK];
     const int zi = blockIdx.y;
-    uint64_t* z = zv + (size_t)zi * n + (size_t)blockIdx.x * ZBLOCK;
-    const uint64_t tb = totals[(size_t)zi * gridDim.x + blockIdx.x];
-    for (int k = threadIdx.x; k < ZBLOCK; k += 256) s[k] = z[k];
-    __syncthreads();
-    for (int k = threadIdx.x; k < ZBLOCK; k += 256) z[k] = k ? gl::mul(tb, s[k - 1]) : tb;
+    ulonglong2* z = reinterpret_cast<ulonglong2*>(zv + (size_t)zi * n + (size_t)blockIdx.x * ZBLOCK);
+    const uint64_t tb = totals[((size_t)zi * 2) * gridDim.x + blockIdx.x];
+    for (int k = threadIdx.x; k < ZBLOCK / 2; k += 256) {
+        ulonglong2 v = z[k];
+        v.x = gl::mul(tb, v.x);
+        v.y = gl::mul(tb, v.y);
+        z[k] = v;
+    }
 }
 
 // =====================================================================================================
@@ -1114,28 +1173,28 @@ int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace
                      const uint64_t gamma[2], uint64_t* d_zv) {
     const size_t n = (size_t)1 << log_n;
     const int P = 2 * a->n_checked;
-    // rows per lane: 16 on long traces (the lane's inversion is amortised over 16 rows), 4 otherwise
-    const int zr = (n >= 16384) ? 16 : 4;
+    // rows per lane: 8 on long traces (two challenges x (numerators, denominators) x 8 rows live in registers), 4 otherwise
+    const int zr = (n >= 16384) ? 8 : 4;
     const size_t zblock = (size_t)256 * zr;
     const unsigned nblk = (unsigned)(n / zblock);
     if (n % zblock) return sipp_fail(ctx, SIPP_E_BADARG, "z_columns: n must be a multiple of 1024");
     ArenaScope scope(ctx);   // the scratch goes back on EVERY exit path (the stream is ordered: later users of the block wait)
-    uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)P * nblk);
+    uint64_t* totals = arena_alloc_t<uint64_t>(ctx, (size_t)2 * P * nblk);     // numerator and denominator totals of every block
     if (!totals) return SIPP_E_NOMEM;
     {
         ProfScope ps(ctx, "z_phase_a");
-        if (zr == 16)
-            hipLaunchKernelGGL(z_phase_a<16>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
+        if (zr == 8)
+            hipLaunchKernelGGL(z_phase_a<8>, dim3(nblk, P / 2), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
                                a->checked_base, gamma[0], gamma[1], beta[0], beta[1], d_zv, totals);
         else
-            hipLaunchKernelGGL(z_phase_a<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
+            hipLaunchKernelGGL(z_phase_a<4>, dim3(nblk, P / 2), dim3(256), 0, ctx->stream, d_trace, n, a->n_main, a->n_checked,
                                a->checked_base, gamma[0], gamma[1], beta[0], beta[1], d_zv, totals);
     }
     {
         ProfScope ps(ctx, "z_phase_bc");
         hipLaunchKernelGGL(z_phase_b, dim3(P), dim3(256), 0, ctx->stream, totals, (int)nblk);
-        if (zr == 16)
-            hipLaunchKernelGGL(z_phase_c<16>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
+        if (zr == 8)
+            hipLaunchKernelGGL(z_phase_c<8>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
         else
             hipLaunchKernelGGL(z_phase_c<4>, dim3(nblk, P), dim3(256), 0, ctx->stream, d_zv, n, totals);
     }
