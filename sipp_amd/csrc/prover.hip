@@ -550,7 +550,14 @@ __device__ __forceinline__ void rest_store(const QuotArgs& a, size_t m, size_t j
 template <bool SPLIT>
 __global__ void __launch_bounds__(256) quotient_rest_kernel(QuotArgs a) {
     const size_t m = (size_t)1 << a.log_m;
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // Which 256 points a block takes (round 5).  The next row of the point with natural index i is i + 2, at leaf position bitrev(i + 2):
+    // far from bitrev(i), so a block of 256 CONSECUTIVE leaf positions read every `next` cell from lines no lane of it reads as `local` --
+    // nine words per checked column and point, four of them a second fetch of data another block fetches as its own (the kernel runs at
+    // the memory's pace: 186 GB for an n = 4096 instance).  A block takes eight runs of 32 leaf positions instead, the runs being the
+    // eight values of bits 1 .. 3 of i: seven of the eight `next` runs are then `local` runs of the same block, fetched once.
+    constexpr uint32_t RB = 3, RW = 256u >> RB;
+    const uint32_t tid = threadIdx.x, run = tid / RW, blk = blockIdx.x, half = blk / (uint32_t)(m >> 9);
+    const size_t j = (size_t)half * (m >> 1) + (size_t)run * (m >> (RB + 1)) + (size_t)(blk % (uint32_t)(m >> 9)) * RW + tid % RW;
     const uint32_t i = gl::bitrev((uint32_t)j, a.log_m);
     QCtx c;
     c.lde = a.lde;
