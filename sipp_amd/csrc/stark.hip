@@ -380,6 +380,41 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
         pi_root(pis.data(), s.num_io, a->pi_per_io, root);
         ch.observe_many(root, 4);
     }
+    // public-input polynomials (they depend on the statement alone): interpolated over the order-nio subgroup and shifted HERE, while
+    // the host would only wait for the trace commitment's cap (0.4 - 0.65 ms of host time that used to sit between the alphas and
+    // the quotient launches of every proof: `profiles/r05_timeline.txt`, the gap in front of ntt_pass_kernel); their LDE to the
+    // quotient coset is launched where the quotient needs it
+    const int n_aux = a->n_aux;
+    const uint32_t log_io = log_n - (uint32_t)a->log_rows;
+    const size_t nio = s.num_io;
+    std::vector<uint64_t> auxc((size_t)n_aux * nio), col(nio);
+    {
+        const uint64_t g = gl::root_of_unity(log_n);
+        for (int ai = 0; ai < n_aux; ai++) {
+            const int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], shift = a->aux[4 * ai + 2], sub = a->aux[4 * ai + 3];
+            for (size_t io = 0; io < nio; io++) {
+                const uint32_t* rec = &pis[io * a->pi_per_io];
+                if (part == 3) {
+                    uint16_t limbs[16];
+                    fq12_tower_limbs(rec + word, sub / 16, limbs);
+                    col[io] = limbs[sub % 16];
+                } else {
+                    uint32_t w = rec[word];
+                    col[io] = part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
+                }
+            }
+            host_ifft(col, log_io);
+            if (shift) {
+                const uint64_t sft = gl::inv(gl::pow(g, (uint64_t)shift));
+                uint64_t f = 1;
+                for (size_t j = 0; j < nio; j++) {
+                    col[j] = gl::mul(col[j], f);
+                    f = gl::mul(f, sft);
+                }
+            }
+            memcpy(&auxc[(size_t)ai * nio], col.data(), nio * 8);
+        }
+    }
     SIPP_TRY(read_cap(ctx, T.tree, log_m, cap_host));
     ch.observe_many(cap_host, cap_words);
     push(cap_host, cap_words);
@@ -412,36 +447,7 @@ static int prove_impl(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_i
     // ---- 4. quotient ----
     {
         ArenaMark mark_q = arena_mark(ctx);
-        const int n_aux = a->n_aux;
-        const uint32_t log_io = log_n - (uint32_t)a->log_rows;
-        const size_t nio = s.num_io;
-        // public-input polynomials: interpolate over the order-nio subgroup, shift, LDE to the coset
-        std::vector<uint64_t> auxc((size_t)n_aux * nio), col(nio);
-        const uint64_t g = gl::root_of_unity(log_n);
-        for (int ai = 0; ai < n_aux; ai++) {
-            const int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], shift = a->aux[4 * ai + 2], sub = a->aux[4 * ai + 3];
-            for (size_t io = 0; io < nio; io++) {
-                const uint32_t* rec = &pis[io * a->pi_per_io];
-                if (part == 3) {
-                    uint16_t limbs[16];
-                    fq12_tower_limbs(rec + word, sub / 16, limbs);
-                    col[io] = limbs[sub % 16];
-                } else {
-                    uint32_t w = rec[word];
-                    col[io] = part == 0 ? (w & 0xffff) : part == 1 ? (w >> 16) : w;
-                }
-            }
-            host_ifft(col, log_io);
-            if (shift) {
-                const uint64_t sft = gl::inv(gl::pow(g, (uint64_t)shift));
-                uint64_t f = 1;
-                for (size_t j = 0; j < nio; j++) {
-                    col[j] = gl::mul(col[j], f);
-                    f = gl::mul(f, sft);
-                }
-            }
-            memcpy(&auxc[(size_t)ai * nio], col.data(), nio * 8);
-        }
+        // (the public-input polynomials' coefficients were interpolated on the host while the trace commitment ran: auxc)
         uint64_t* d_auxc = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * nio + 1);
         uint64_t* d_aux = arena_alloc_t<uint64_t>(ctx, (size_t)n_aux * mq + 1);
         if (!d_auxc || !d_aux) return SIPP_E_NOMEM;
