@@ -10,14 +10,16 @@
  */
 #include "air.h"
 #include "mapg2.h"
+#include "pairing.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-/* API kinds: 0 g1, 1 g2, 2 fq12, 3 mapg2, 4 / 5 = the hardened g1 / g2 AIRs (same records, same rows; air->kind stays 0 / 1) */
+/* API kinds: 0 g1, 1 g2, 2 fq12, 3 mapg2, 4 / 5 = the hardened g1 / g2 AIRs (same records, same rows; air->kind stays 0 / 1),
+ * 6 = the final pairing (pairing.c) */
 const air_spec_t *orc_air_get(int kind, unsigned log_n) {
-    int mode_u16 = log_n >= 16, hard = kind >= 4;
-    if (kind < 0 || kind > 5) return NULL;
+    int mode_u16 = log_n >= 16, hard = kind == 4 || kind == 5;
+    if (kind < 0 || kind > 6) return NULL;
     int base = hard ? kind - 4 : kind;
     for (size_t i = 0; i < sizeof(AIR_AIRS) / sizeof(AIR_AIRS[0]); i++)
         if (AIR_AIRS[i].kind == base && AIR_AIRS[i].hardened == hard && (AIR_AIRS[i].table_bits == 16) == mode_u16) return &AIR_AIRS[i];
@@ -136,7 +138,13 @@ void orc_test_forge(int flags) { g_forge = flags; }
 
 /* x and offset of every G1 / G2 record on E(Fp) / E'(Fp2) (the verifier's side of the refusal in fill_curve_io) */
 int orc_records_on_curve(int kind, const uint32_t *pis, size_t num_io) {
-    if (kind >= 4) kind -= 4;   /* hardened G1 / G2: the same records */
+    kind = orc_record_kind(kind);   /* hardened G1 / G2: the same records */
+    if (kind == 6) { /* (P, Q, Z): P on E(Fp), Q on E'(Fp2) AND of order r -- the chord rows of the pairing AIR are sound for such Q only */
+        int ok = 1;
+#pragma omp parallel for schedule(dynamic) reduction(&& : ok)
+        for (size_t io = 0; io < num_io; io++) ok = ok && orc_pairing_record_ok(pis + io * 144);
+        return ok;
+    }
     if (kind == 3) { /* (u, x, y): the point on E'(Fp2) and the map's sign rule sgn0(y) = sgn0(u) (public checks, not constraints) */
         fq_init();
         for (size_t io = 0; io < num_io; io++) {
@@ -377,7 +385,7 @@ static int fill_harden_row(const air_spec_t *a, uint64_t *tr, size_t n, size_t r
 }
 
 /* ---- generic gadget witnesses (integers) ---- */
-static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, const int per[AIR_N_PERIODIC],
+static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, const int *per,
                    int64_t *out, int *n_out) {
     int nl = (int)w[0], nt = (int)w[1];
     for (int i = 0; i < nl; i++) out[i] = 0;
@@ -394,8 +402,10 @@ static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, c
 }
 
 static int fill_gadgets_row(const air_spec_t *a, uint64_t *tr, size_t n, size_t row) {
-    int per[AIR_N_PERIODIC];
+    int per[AIR_N_PERIODIC + 64];     /* closed-form selectors, then the AIR's selector columns (value-periodic, small integers) */
     for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = (int)(row % (size_t)AIR_PERIODIC[k][0]) == AIR_PERIODIC[k][1];
+    if (a->n_vflag > 64) return -21;
+    for (int k = 0; k < a->n_vflag; k++) per[AIR_N_PERIODIC + k] = (int)air_vper_value(a, k, (int)(row & (((size_t)1 << a->log_rows) - 1)));
     const int64_t *w = a->prog, *end = a->prog + a->prog_len;
     int cpl = a->cells_per_limb;
     /* p^-1 mod 2^16 */
@@ -517,8 +527,8 @@ static void permuted_cols(const uint64_t *col, size_t n, unsigned tbits, uint64_
 orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int *err) {
     fq_init();
     *err = 0;
-    if (num_io == 0 || api_kind < 0 || api_kind > 5) { *err = -1; return NULL; }
-    const int kind = api_kind >= 4 ? api_kind - 4 : api_kind;   /* the hardened variants fill the same primary cells */
+    if (num_io == 0 || api_kind < 0 || api_kind > 6) { *err = -1; return NULL; }
+    const int kind = orc_record_kind(api_kind);   /* the hardened variants fill the same primary cells */
     const unsigned log_rows = kind == 3 ? 3 : 9;   /* rows per record: 512 (exponentiations), 8 (MapToG2); = air->log_rows */
     size_t nio = 2; /* at least two IO blocks, at least 1024 rows */
     while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
@@ -533,7 +543,7 @@ orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int
     t->air = a; t->log_n = log_n; t->num_io = nio; t->width = W;
     t->trace = (uint64_t *)calloc((size_t)W * n, sizeof(uint64_t));
     t->pis = (uint32_t *)calloc(nio * a->pi_per_io, sizeof(uint32_t));
-    int ppi = a->pi_per_io, out_words = kind == 0 ? 16 : kind == 2 ? 96 : 32;
+    int ppi = a->pi_per_io, out_words = kind == 0 ? 16 : (kind == 2 || kind == 6) ? 96 : 32;
     int rc_all = 0;
 #pragma omp parallel for schedule(dynamic)
     for (size_t io = 0; io < nio; io++) {
@@ -542,7 +552,8 @@ orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int
         memcpy(pi, rec, ppi * sizeof(uint32_t));
         uint32_t outw[96];
         int rc = kind == 2 ? fill_fq12_io(a, t->trace, n, io, rec, outw) : kind == 3 ? fill_map_io(a, t->trace, n, io, rec, outw)
-                                                                          : fill_curve_io(a, t->trace, n, io, rec, outw);
+                 : kind == 6 ? ((g_forge & 1) || orc_pairing_record_ok(rec) ? orc_pairing_run(a, t->trace, n, io * 512, rec, outw) : -1)
+                             : fill_curve_io(a, t->trace, n, io, rec, outw);
         if (rc == 0 && (g_forge & 2)) memcpy(pi + ppi - out_words, outw, out_words * sizeof(uint32_t));
         else if (rc == 0 && memcmp(outw, rec + ppi - out_words, out_words * sizeof(uint32_t)) != 0) rc = -8; /* claimed output wrong */
         if (rc) {
@@ -590,6 +601,22 @@ gl2 orc_periodic_ext(unsigned log_n, int which, gl2 x) {
     gl2 y = gl2_scale(x, gl_inv(gl_pow(g, r0)));
     gl2 num = gl2_sub(gl2_pow(y, N), gl2_from(1)), den = gl2_sub(gl2_pow(y, K), gl2_from(1));
     return gl2_scale(gl2_mul(num, gl2_inv(den)), gl_mul(K % GL_P, gl_inv(N % GL_P)));
+}
+
+/* value-periodic columns: column k takes the value air_vper_value(a, k, r mod R) on trace row r (R = 2^log_rows rows per record), so
+ * it is the polynomial P_k(x^(N/R)) with P_k (degree < R) interpolating the R values over the order-R subgroup */
+int orc_air_n_vper(const air_spec_t *a) { return a->n_vflag + a->n_vconst; }
+int orc_air_n_per(const air_spec_t *a) { return AIR_N_PERIODIC + orc_air_n_vper(a); }
+void orc_vper_coeffs(const air_spec_t *a, int k, uint64_t *coeffs) {
+    const size_t R = (size_t)1 << a->log_rows;
+    for (size_t r = 0; r < R; r++) coeffs[r] = gl_from_i64(air_vper_value(a, k, (int)r));
+    orc_ifft(coeffs, (unsigned)a->log_rows);
+}
+gl2 orc_vper_ext(const air_spec_t *a, unsigned log_n, const uint64_t *coeffs, gl2 x) {
+    const size_t R = (size_t)1 << a->log_rows;
+    gl2 y = gl2_pow(x, (uint64_t)1 << (log_n - (unsigned)a->log_rows)), acc = gl2_from(0);
+    for (size_t i = R; i-- > 0;) acc = gl2_add(gl2_mul(acc, y), gl2_from(coeffs[i]));
+    return acc;
 }
 
 /* value of aux column `ai` for IO `io`: the lo/hi half or the whole of a public u32 word */
@@ -648,12 +675,12 @@ void orc_aux_coeffs(const air_spec_t *a, const uint32_t *pis, size_t num_io, uns
 #include "air_eval.inc"
 
 void orc_eval_base(const air_spec_t *air, const uint64_t *local, const uint64_t *next, const uint64_t *aux,
-                   const uint64_t per[AIR_N_PERIODIC], const uint64_t *z_local, const uint64_t *z_next,
+                   const uint64_t *per, const uint64_t *z_local, const uint64_t *z_next,
                    uint64_t lag_first, uint64_t lag_last, uint64_t z_last, const uint64_t alpha[2],
                    const uint64_t beta[2], const uint64_t gamma[2], uint64_t out[2]) {
     evalctx_base c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
-    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = per[k];
+    c.per = per;
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
     c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
     c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
@@ -662,11 +689,11 @@ void orc_eval_base(const air_spec_t *air, const uint64_t *local, const uint64_t 
 }
 
 void orc_eval_ext(const air_spec_t *air, const gl2 *local, const gl2 *next, const gl2 *aux,
-                  const gl2 per[AIR_N_PERIODIC], const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
+                  const gl2 *per, const gl2 *z_local, const gl2 *z_next, gl2 lag_first, gl2 lag_last,
                   gl2 z_last, const uint64_t alpha[2], const uint64_t beta[2], const uint64_t gamma[2], gl2 out[2]) {
     evalctx_ext c;
     c.local = local; c.next = next; c.aux = aux; c.z_local = z_local; c.z_next = z_next;
-    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = per[k];
+    c.per = per;
     c.lag_first = lag_first; c.lag_last = lag_last; c.z_last = z_last;
     c.alpha[0] = alpha[0]; c.alpha[1] = alpha[1]; c.beta[0] = beta[0]; c.beta[1] = beta[1];
     c.gamma[0] = gamma[0]; c.gamma[1] = gamma[1];
@@ -688,7 +715,11 @@ long orc_trace_check_row(const orc_trace *t, size_t row) {
     evalctx_base c;
     memset(&c, 0, sizeof c);
     c.local = local; c.next = next; c.aux = aux;
-    for (int k = 0; k < AIR_N_PERIODIC; k++) c.per[k] = (row % (size_t)AIR_PERIODIC[k][0]) == (size_t)AIR_PERIODIC[k][1];
+    uint64_t *perv = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)orc_air_n_per(a));
+    for (int k = 0; k < AIR_N_PERIODIC; k++) perv[k] = (row % (size_t)AIR_PERIODIC[k][0]) == (size_t)AIR_PERIODIC[k][1];
+    for (int k = 0; k < orc_air_n_vper(a); k++)
+        perv[AIR_N_PERIODIC + k] = gl_from_i64(air_vper_value(a, k, (int)(row & (((size_t)1 << a->log_rows) - 1))));
+    c.per = perv;
     size_t io = row >> a->log_rows;
     for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = orc_aux_value(a, t->pis, io, ai);
     /* alpha = 0 turns acc into "the last emitted constraint": walk constraint by constraint instead */
@@ -702,6 +733,6 @@ long orc_trace_check_row(const orc_trace *t, size_t row) {
         eval_program_base(a, &c);
         if (c.acc[0] != 0 || c.acc[1] != 0) bad = (long)c.n_emitted;
     }
-    free(local); free(next); free(aux);
+    free(local); free(next); free(aux); free(perv);
     return bad;
 }

@@ -56,14 +56,45 @@ def air_tables():
         a["name"], a["prog"], a["aux"] = m.group(1), arrays[f[12]], arrays[f[14]]
         assert len(a["prog"]) == int(f[13])
         a["log_rows"], a["hardened"] = int(f[15]), int(f[16])
+        a["n_vflag"], a["n_vconst"] = int(f[17]), int(f[19])
         airs.append(a)
-    _TABLES = (periodic, p_limbs, airs)
+    # the pairing AIR's value-periodic columns (period 512): selector rows, constant vectors and the row -> vector index
+    def table(name):
+        m = re.search(r"%s\[(\d+)\](?:\[(\d+)\])? = \{(.*?)\};" % name, txt, re.S)
+        v = ints(m.group(3))
+        if m.group(2) is None:
+            return v
+        w = int(m.group(2))
+        return [v[i * w:(i + 1) * w] for i in range(int(m.group(1)))]
+    vper = dict(vflag=table("AIR_PAIRING_VFLAG"), gconst=table("AIR_PAIRING_GCONST"), gidx=table("AIR_PAIRING_GIDX"))
+    _TABLES = (periodic, p_limbs, airs, vper)
     return _TABLES
 
 
+def vper_values(a, k):
+    """the 2^log_rows values of value-periodic column k of AIR a (air_vper_value of data/air_tables.h)"""
+    vper = air_tables()[3]
+    if k < a["n_vflag"]:
+        return vper["vflag"][k]
+    return [vper["gconst"][gi][k - a["n_vflag"]] for gi in vper["gidx"]]
+
+
+def vper_at(a, log_n, zeta):
+    """value-periodic column k is P_k(x^(N / R)), P_k interpolating its R = 2^log_rows values over the order-R subgroup"""
+    y = zeta ** (1 << (log_n - a["log_rows"]))
+    out = []
+    cache = {}
+    for k in range(a["n_vflag"] + a["n_vconst"]):
+        vals = tuple(v % P for v in vper_values(a, k))
+        if vals not in cache:
+            cache[vals] = g.eval_poly([Ext(c) for c in g.ifft(list(vals))], y)
+        out.append(cache[vals])
+    return out
+
+
 def air_of(kind, log_n):
-    periodic, p_limbs, airs = air_tables()
-    base, hard = (kind - 4, 1) if kind >= 4 else (kind, 0)
+    periodic, p_limbs, airs, _ = air_tables()
+    base, hard = (kind - 4, 1) if kind in (4, 5) else (kind, 0)
     for a in airs:
         if a["kind"] == base and a["hardened"] == hard and (a["table_bits"] == 16) == (log_n >= 16):
             return a
@@ -78,9 +109,19 @@ def _fq(words):
 def records_ok(kind, pis, num_io, ppi):
     """None, or why the public inputs are refused: every field element canonical, the points of a record on their curve, and for
     MapToG2 the sign rule sgn0(y) = sgn0(u)"""
-    base = kind - 4 if kind >= 4 else kind
+    base = kind - 4 if kind in (4, 5) else kind
     for io in range(num_io):
         rec = pis[io * ppi:(io + 1) * ppi]
+        if base == 6:      # (P, Q, Z): canonical, P on E, Q on E' and of order r (the pairing AIR's chord rows are sound for such Q only)
+            vals = [_fq(rec[8 * k: 8 * k + 8]) for k in range(18)]
+            if any(v >= bn.P for v in vals):
+                return "non-canonical record"
+            q = ((vals[2], vals[3]), (vals[4], vals[5]))
+            if not bn.g1_on_curve((vals[0], vals[1])) or not bn.g2_on_curve(q):
+                return "record off the curve"
+            if bn.g2_mul(q, bn.R - 1) != bn.g2_neg(q):
+                return "Q outside the r-torsion"
+            continue
         if base == 3:
             vals = [_fq(rec[8 * k: 8 * k + 8]) for k in range(6)]
             if any(v >= bn.P for v in vals):
@@ -153,7 +194,7 @@ def aux_at(a, pis, num_io, log_n, zeta):
 def eval_constraints(a, log_n, local, nxt, aux, per, z_local, z_next, lag_first, lag_last, z_last, alphas, betas, gammas):
     """all constraints folded with alpha (acc = acc alpha + c) for each of the two challenges, in the specification's order:
     the program (gadgets, polynomial constraints), the range table, the permuted lookups, the permutation products"""
-    _, p_limbs, _ = air_tables()
+    p_limbs = air_tables()[1]
     acc = [Ext(0), Ext(0)]
 
     def emit(v):
@@ -261,7 +302,7 @@ def verify(proof, cfg=None):
         return "non-canonical word"
     kind, log_n, num_io, W, Pz, Q, cap_h, n_rounds, final_len, nq, ppi, total, rate_bits, arity_bits, zero = pf[1:16]
     log_rows = 3 if kind == 3 else 9
-    if not (0 <= kind <= 5) or not (10 <= log_n <= 26) or num_io != 1 << (log_n - log_rows):
+    if not (0 <= kind <= 6) or not (10 <= log_n <= 26) or num_io != 1 << (log_n - log_rows):
         return "header"
     a = air_of(kind, log_n)
     if a is None or W != a["n_main"] + 2 * a["n_checked"] or Pz != 2 * a["n_checked"] or Q != 4 or cap_h != cfg["cap_height"] or \
@@ -315,8 +356,8 @@ def verify(proof, cfg=None):
     for v in local + z_local + quot + nxt + z_next:      # the zeta batch, then the g zeta batch
         ch.observe_ext(v)
     # ---- the constraints at zeta
-    periodic, _, _ = air_tables()
-    per = [periodic_at(log_n, m, r0, zeta) for m, r0 in periodic]
+    periodic = air_tables()[0]
+    per = [periodic_at(log_n, m, r0, zeta) for m, r0 in periodic] + vper_at(a, log_n, zeta)
     gN = g.primitive_root_of_unity(log_n)
     gi = g.inv(gN)
     zn = zeta ** n

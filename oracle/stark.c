@@ -52,9 +52,9 @@ static int fq_words_canonical(const uint32_t *w) {
 /* every Fq element of every record < p; the exponent (8 words) may be any 256-bit value.
  * Record layouts (reference src/verifier_circuit.rs:92-124): (x, offset, exp_val, output). */
 int orc_pis_canonical(int kind, const uint32_t *pis, size_t num_io) {
-    if (kind >= 4) kind -= 4;   /* hardened G1 / G2: the same records */
-    if (kind == 3) { /* MapToG2 records (u, x, y): six Fq elements, no exponent */
-        for (size_t k = 0; k < 6 * num_io; k++)
+    kind = orc_record_kind(kind);   /* hardened G1 / G2: the same records */
+    if (kind == 3 || kind == 6) { /* MapToG2 records (u, x, y): six Fq elements; pairing records (P, Q, Z): eighteen; no exponent */
+        for (size_t k = 0; k < (size_t)(kind == 3 ? 6 : 18) * num_io; k++)
             if (!fq_words_canonical(pis + 8 * k)) return 0;
         return 1;
     }
@@ -252,6 +252,20 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
             free(co);
         }
     }
+    /* value-periodic columns on the quotient coset: P_k at (7 w_2N^i)^(N/R) = 7^(N/R) w_2R^i -- 2R distinct values, a coset LDE of P_k */
+    const int n_vper = orc_air_n_vper(a), n_per = orc_air_n_per(a);
+    const size_t R2 = (size_t)2 << a->log_rows;
+    uint64_t *vper_tab = (uint64_t *)malloc((size_t)(n_vper ? n_vper : 1) * R2 * sizeof(uint64_t));
+    {
+        const uint64_t shift = gl_pow(GL_GEN, (uint64_t)1 << (log_n - (unsigned)a->log_rows));
+#pragma omp parallel for schedule(dynamic)
+        for (int k = 0; k < n_vper; k++) {
+            uint64_t *co = (uint64_t *)malloc((R2 / 2) * sizeof(uint64_t));
+            orc_vper_coeffs(a, k, co);
+            orc_coset_lde(co, (unsigned)a->log_rows, 1, shift, vper_tab + (size_t)k * R2);
+            free(co);
+        }
+    }
     uint64_t *qv = (uint64_t *)malloc(2 * mq * sizeof(uint64_t)); /* [2][mq] natural order */
     {
         uint64_t wm = gl_root_of_unity(log_mq);
@@ -261,22 +275,24 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
 #pragma omp parallel
         {
             uint64_t *aux = (uint64_t *)malloc(sizeof(uint64_t) * (a->n_aux ? a->n_aux : 1));
+            uint64_t *per = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n_per);
 #pragma omp for schedule(static)
             for (size_t i = 0; i < mq; i++) {
                 uint64_t x = gl_mul(GL_GEN, gl_pow(wm, i));
                 size_t j = bitrev32((uint32_t)i, log_mq), jn = bitrev32((uint32_t)((i + 2) & (mq - 1)), log_mq);
-                uint64_t per[AIR_N_PERIODIC], lf, ll, zlast, out[2];
+                uint64_t lf, ll, zlast, out[2];
                 for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = orc_periodic_base(log_n, k, x);
+                for (int k = 0; k < n_vper; k++) per[AIR_N_PERIODIC + k] = vper_tab[(size_t)k * R2 + (i & (R2 - 1))];
                 selectors_base(log_n, x, &lf, &ll, &zlast);
                 for (int ai = 0; ai < a->n_aux; ai++) aux[ai] = aux_lde[(size_t)ai * mq + i];
                 orc_eval_base(a, tl + j * W, tl + jn * W, aux, per, zl + j * P, zl + jn * P, lf, ll, zlast, alpha, beta, gamma, out);
                 qv[i] = gl_mul(out[0], zh_inv[i & 1]);
                 qv[mq + i] = gl_mul(out[1], zh_inv[i & 1]);
             }
-            free(aux);
+            free(aux); free(per);
         }
     }
-    free(aux_lde);
+    free(aux_lde); free(vper_tab);
     /* coset iFFT -> 2 polys of 2N coefficients -> 4 chunks of N */
     uint64_t *qc = (uint64_t *)malloc((size_t)Q * n * sizeof(uint64_t));
     {
@@ -368,7 +384,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
     const unsigned log_rows = kind == 3 ? 3 : 9;
-    if (kind < 0 || kind > 5 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
+    if (kind < 0 || kind > 6 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const air_spec_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||
@@ -420,8 +436,17 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     for (int c = 0; c < P; c++) orc_chal_observe_ext(&ch, op[2 * W + P + c]);
     /* constraint check at zeta */
     {
-        gl2 per[AIR_N_PERIODIC], lf, ll, zlast, out[2];
+        gl2 lf, ll, zlast, out[2];
+        gl2 *per = (gl2 *)malloc(sizeof(gl2) * (size_t)orc_air_n_per(a));
         for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = orc_periodic_ext(log_n, k, zeta);
+        {   /* the AIR's value-periodic columns (selectors and constants of the pairing schedule): interpolated from the tables */
+            uint64_t *vc = (uint64_t *)malloc(sizeof(uint64_t) << a->log_rows);
+            for (int k = 0; k < orc_air_n_vper(a); k++) {
+                orc_vper_coeffs(a, k, vc);
+                per[AIR_N_PERIODIC + k] = orc_vper_ext(a, log_n, vc, zeta);
+            }
+            free(vc);
+        }
         selectors_ext(log_n, zeta, &lf, &ll, &zlast);
         auxz = (gl2 *)malloc(sizeof(gl2) * (a->n_aux ? a->n_aux : 1));
         uint64_t *co = (uint64_t *)malloc(num_io * sizeof(uint64_t));
@@ -431,6 +456,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
         }
         free(co);
         orc_eval_ext(a, op, op + W, auxz, per, op + 2 * W, op + 2 * W + P, lf, ll, zlast, alpha, beta, gamma, out);
+        free(per);
         gl2 zh = gl2_sub(gl2_pow(zeta, n), gl2_from(1));
         if (gl2_eq(zh, gl2_from(0))) { rc = -107; goto out; }
         gl2 zn = gl2_pow(zeta, n);

@@ -7,8 +7,9 @@
 // products of every Fq12 product and the products of one dependency level of a point step spread over the lanes), values in Fq12 = Fq2[w]/(w^6 - xi), xi = 9 + u, as six
 // Fq2 coefficients in Montgomery form (fq.hpp), resident in LDS.  One workgroup then multiplies
 // the n Miller values (strided partial products + a tree) and one wave applies the final exponentiation: easy part
-// (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers by u); the result is
-// exactly f^((p^12 - 1)/r).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
+// (p^6 - 1)(p^2 + 1), hard part by the chain of ark-ec 0.4's Bn::final_exponentiation (Fuentes-Castaneda et al.; three powers by
+// u), as recalled: what `Bn254::pairing` returns at reference src/prover_native.rs:20 is f^(lambda (p^12 - 1)/r) with
+// lambda = 2u(6u^2 + 3u + 1), NOT the plain reduced pairing (round 6).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
 // (c_i = a_i - 9 b_i, c_{i+6} = b_i for the Fq2 coefficient a_i + b_i u of w^i), 8 x u32 limbs each.
 // The field routines are deliberately NOT inlined (one copy each, operands through pointers) to keep the code small.
 #include <vector>
@@ -131,8 +132,8 @@ __device__ __noinline__ void t6_inv(T6& r, const T6& a) {
     }
 }
 
-// ---- final exponentiation f^((p^12 - 1)/r) by ONE WAVE (oracle/py/bn254.py::final_exp computes the same value by plain
-// square-and-multiply): easy part (p^6 - 1)(p^2 + 1), hard part (p^4 - p^2 + 1)/r by the Devegili-Scott-Dahab chain (three powers
+// ---- final exponentiation f^(lambda (p^12 - 1)/r), lambda = 2u(6u^2 + 3u + 1), by ONE WAVE (oracle/py/bn254.py::final_exp
+// computes the same value by plain square-and-multiply): easy part (p^6 - 1)(p^2 + 1), hard part by arkworks' chain (three powers
 // by u).  Every Fq12 value lives in LDS, the 36 Fq2 products of an Fq12 product are
 // taken by 36 lanes (then 11 lanes sum the anti-diagonals and 6 fold w^6 = xi), conjugations and Frobenius maps by 6 lanes;
 // only the single inversion of the easy part runs on one lane.  ~290 Fq12 products: 33 ms on one lane, ~1 ms this way.
@@ -308,7 +309,7 @@ struct FinalExpLds {
     CoopScratch64 sc;
     CycloScratch cs;
 };
-// L.f in: the Miller product; L.f out: f^((p^12 - 1)/r).  Called by all 64 lanes of a one-wave workgroup.
+// L.f in: the Miller product; L.f out: f^(lambda (p^12 - 1)/r).  Called by all 64 lanes of a one-wave workgroup.
 __device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
     CoopScratch64& sc = L.sc;
     coop_conj(L.t, L.f);
@@ -321,38 +322,30 @@ __device__ __forceinline__ void final_exp_coop(FinalExpLds& L) {
     coop_mul64(L.g, L.t, L.u, sc);  // f^(p^6 - 1)
     coop_frob(L.t, L.g, 2);
     coop_mul64(L.g, L.t, L.g, sc);  // ^(p^2 + 1)
+    // hard part: arkworks' chain (ark-ec 0.4 models/bn: Fuentes-Castaneda et al., "Faster hashing to G2"), y_k as named there
     coop_pow_u(L.fx, L.g, sc, L.cs);
-    coop_pow_u(L.fx2, L.fx, sc, L.cs);
-    coop_pow_u(L.fx3, L.fx2, sc, L.cs);
-    coop_frob(L.y0, L.g, 1);
-    coop_frob(L.t, L.g, 2);
-    coop_mul64(L.y0, L.y0, L.t, sc);
-    coop_frob(L.t, L.g, 3);
-    coop_mul64(L.y0, L.y0, L.t, sc);
-    coop_conj(L.y1, L.g);
-    coop_frob(L.y2, L.fx2, 2);
-    coop_frob(L.t, L.fx, 1);
-    coop_conj(L.y3, L.t);
-    coop_frob(L.t, L.fx2, 1);
-    coop_mul64(L.t, L.fx, L.t, sc);
-    coop_conj(L.y4, L.t);
-    coop_conj(L.y5, L.fx2);
-    coop_frob(L.t, L.fx3, 1);
-    coop_mul64(L.t, L.fx3, L.t, sc);
-    coop_conj(L.y6, L.t);
-    coop_mul64(L.t0, L.y6, L.y6, sc);
-    coop_mul64(L.t0, L.t0, L.y4, sc);
-    coop_mul64(L.t0, L.t0, L.y5, sc);
-    coop_mul64(L.t1, L.y3, L.y5, sc);
-    coop_mul64(L.t1, L.t1, L.t0, sc);
-    coop_mul64(L.t0, L.t0, L.y2, sc);
-    coop_mul64(L.t1, L.t1, L.t1, sc);
-    coop_mul64(L.t1, L.t1, L.t0, sc);
-    coop_mul64(L.t1, L.t1, L.t1, sc);
-    coop_mul64(L.t0, L.t1, L.y1, sc);
-    coop_mul64(L.t1, L.t1, L.y0, sc);
-    coop_mul64(L.t0, L.t0, L.t0, sc);
-    coop_mul64(L.f, L.t0, L.t1, sc);
+    coop_conj(L.y0, L.fx);                 // y0 = r^-u
+    coop_cyclo_sqr64(L.y1, L.y0, L.cs);    // y1 = y0^2
+    coop_cyclo_sqr64(L.y2, L.y1, L.cs);    // y2 = y1^2
+    coop_mul64(L.y3, L.y2, L.y1, sc);      // y3 = y2 y1
+    coop_pow_u(L.fx2, L.y3, sc, L.cs);
+    coop_conj(L.y4, L.fx2);                // y4 = y3^-u
+    coop_cyclo_sqr64(L.y5, L.y4, L.cs);    // y5 = y4^2
+    coop_pow_u(L.y6, L.y5, sc, L.cs);      // conj(y6) = y5^u
+    coop_conj(L.t, L.y3);                  // conj(y3)
+    coop_mul64(L.t0, L.y6, L.y4, sc);      // y7 = conj(y6) y4
+    coop_mul64(L.t0, L.t0, L.t, sc);       // y8 = y7 conj(y3)
+    coop_mul64(L.t1, L.t0, L.y1, sc);      // y9 = y8 y1
+    coop_mul64(L.fx3, L.t0, L.y4, sc);     // y10 = y8 y4
+    coop_mul64(L.fx3, L.fx3, L.g, sc);     // y11 = y10 r
+    coop_frob(L.t, L.t1, 1);               // y12 = y9^p
+    coop_mul64(L.fx3, L.t, L.fx3, sc);     // y13 = y12 y11
+    coop_frob(L.t, L.t0, 2);               // y8^(p^2)
+    coop_mul64(L.fx3, L.t, L.fx3, sc);     // y14
+    coop_conj(L.t, L.g);
+    coop_mul64(L.t1, L.t, L.t1, sc);       // y15 = conj(r) y9
+    coop_frob(L.t, L.t1, 3);
+    coop_mul64(L.f, L.t, L.fx3, sc);       // y16 = y15^(p^3) y14
 }
 
 // ---- Miller loop: one WAVE per pair.  f lives in LDS and its products are spread over the lanes like in the final

@@ -141,7 +141,9 @@ class OrcAir(C.Structure):
                 ("n_main", C.c_int), ("checked_base", C.c_int), ("n_checked", C.c_int), ("n_ops", C.c_int),
                 ("n_constraints", C.c_int), ("n_aux", C.c_int), ("pi_per_io", C.c_int), ("n_gadgets", C.c_int),
                 ("carry_limbs", C.c_int), ("prog", C.POINTER(C.c_int64)), ("prog_len", C.c_int),
-                ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int), ("hardened", C.c_int)]
+                ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int), ("hardened", C.c_int),
+                ("n_vflag", C.c_int), ("vflag", C.POINTER(C.c_int8)), ("n_vconst", C.c_int), ("vconst", C.POINTER(C.c_int64)),
+                ("vconst_idx", C.POINTER(C.c_int8))]
 
 
 class OrcTrace(C.Structure):
@@ -199,6 +201,24 @@ def map_to_g2(u_words):
         out[i, :16] = u[i]
         out[i, 16:] = xy
     return out
+
+
+# ---------------- the final pairing of the BLS example (oracle/pairing.c) ----------------
+def pairing(pq_words):
+    """P | Q (48 u32) -> the 96 words of e(P, Q) (arkworks' value) by the C reading of the pairing AIR's schedule"""
+    L = load()
+    L.orc_pairing.argtypes = [u32p, u32p]
+    out = np.zeros(96, dtype=np.uint32)
+    rc = L.orc_pairing(np.ascontiguousarray(pq_words, dtype=np.uint32), out)
+    if rc != 0:
+        raise RuntimeError("orc_pairing failed: %d" % rc)
+    return out
+
+
+def pairing_record_ok(rec):
+    L = load()
+    L.orc_pairing_record_ok.argtypes = [u32p]
+    return bool(L.orc_pairing_record_ok(np.ascontiguousarray(rec, dtype=np.uint32)))
 
 
 # ---------------- STARK prover / verifier (oracle/stark.c) ----------------

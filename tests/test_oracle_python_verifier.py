@@ -31,11 +31,12 @@ def mapg2_records():
 
 
 def test_air_tables_parse_like_the_c_structs():
-    periodic, p_limbs, airs = sv.air_tables()
+    periodic, p_limbs, airs, vper = sv.air_tables()
     assert len(periodic) == 12 and sum(l << (16 * i) for i, l in enumerate(p_limbs)) == sv.bn.P
     for a in airs:
         t = None
         kind = a["kind"] + 4 * a["hardened"]
+        assert (a["n_vflag"], a["n_vconst"]) == ((len(vper["vflag"]), 192) if kind == 6 else (0, 0))
         c = _oracle.load()
         c.orc_air_get.restype = __import__("ctypes").POINTER(_oracle.OrcAir)
         c.orc_air_get.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_uint]

@@ -35,6 +35,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pairing_sched as PS  # noqa: E402  (the row schedule of the final-pairing AIR)
 
 BN_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 NL = 16          # 16-bit limbs per Fq element
@@ -69,6 +71,10 @@ class Air:
         self.max_e = 0
         self.log_rows = 9                           # log2 of the rows per IO record
         self.hardened = 0
+        # VALUE-periodic columns (round 6, the pairing AIR): index N_PERIODIC + k in VEC flags and K_PER factors.  vflags: name -> 512
+        # small integers (-1 / 0 / 1: usable as VEC flags); vconst: n columns whose row values come from a table of constant vectors
+        self.vflag_names, self.vflags = [], []
+        self.n_vconst = 0
 
     # ---- column allocation: all unchecked first, then all checked ----
     def alloc(self, name, n):
@@ -754,6 +760,276 @@ def emit_map_schedule(f, prefix):
 
 
 # ------------------------------------------------------------------------------------------------
+N_PERIODIC = len(PERIODICS)
+
+
+def build_pairing(mode):
+    """Z = e(P, Q): ONE optimal ate pairing per 512-row block, the statement behind `pairing_circuit(final_A, final_B)` ==
+    final_Z of the reference's BLS example (src/bin/bls_aggregation.rs:76-77), with arkworks' value (final exponent
+    lambda (p^12 - 1)/r: oracle/py/bn254.py).  The row schedule is tools/pairing_sched.py (458 active rows: Miller loop in affine
+    coordinates, easy part, ark-ec's hard-part chain); a row holds
+      * the Fq12 unit: operands A, B (unchecked cells, multiplexed from the NREG registers by the schedule's selector columns; B
+        may be the line of the same row or, on the inversion row, the result C itself), constants G (the row's Frobenius /
+        conjugation constants, cells tied to periodic columns), result C (checked): twelve gadgets
+            sum_{i+j=k} A_i B_j + xi sum_{i+j=k+6} A_i B_j + [conj^c(A_k) G_k] - sC C_k - sBC G_k = 0        (tower basis, build_fq12)
+        so that MUL / LINE rows state C = A B, the INV row A C = 1 (G = 1 there), FROB rows C_k = conj^c(A_k) G_k (B = 0 there);
+      * the G2 unit: T (the running twist point), QS (the chord's other point: Q, pi(Q) or -pi^2(Q) by the selectors), five Fq2
+        results S0..S4 = (lam, x3, y3, -lam x_P, lam x_T - y_T) on step rows, the Frobenius images of Q on row 0: ten gadgets.
+    Selector columns are VALUE-periodic (period 512, arbitrary values -- N_PERIODIC + k in flags and K_PER factors): both sides
+    interpolate them from the schedule.  Soundness of the chord rows (x_T != x_QS) rests on Q having order r: the VERIFIER checks
+    P on E, Q on E' and [r] Q = O as public conditions (oracle/stark.c), like the curve checks of the other kinds.
+    IO record: P (16 u32), Q (32: x.c0, x.c1, y.c0, y.c1), Z (96: MyFq12 coefficients) = 144 words."""
+    a = Air("pairing", mode)
+    a.gadgets = []
+    a.group = 2
+    NR = PS.NREG
+    F2, F12 = 2 * NL, 12 * NL
+    sched = PS.SCHEDULE
+    rows = PS.ROWS
+    assert rows == ROWS_PER_IO
+
+    # ---- value-periodic selector columns ----
+    def vflag(name, fn):
+        a.vflag_names.append(name)
+        a.vflags.append([int(fn(r)) for r in sched])
+        return N_PERIODIC + len(a.vflags) - 1
+
+    is_f = lambda *ops: (lambda r: r["fop"] in ops)
+    is_g = lambda *ops: (lambda r: r["gop"] in ops)
+    sA = [vflag("sA%d" % k, lambda r, k=k: r["fop"] != PS.F_IDLE and r["ra"] == k) for k in range(NR)]
+    sB = [vflag("sB%d" % k, lambda r, k=k: r["fop"] == PS.F_MUL and r["rb"] == k) for k in range(NR)]
+    sBL = vflag("sBL", is_f(PS.F_LINE))
+    sBC = vflag("sBC", is_f(PS.F_INV))
+    sC = vflag("sC", is_f(PS.F_MUL, PS.F_LINE, PS.F_FROB))
+    sFR = vflag("sFR", is_f(PS.F_FROB))
+    sFS = vflag("sFS", lambda r: 0 if r["fop"] != PS.F_FROB else (-1 if PS.G_CONJ_COEF[r["gc"]] else 1))
+    ld = [vflag("ld%d" % k, lambda r, k=k: r["fop"] != PS.F_IDLE and r["rd"] == k) for k in range(NR)]
+    ldG = vflag("ldG", lambda r: r["fop"] == PS.F_IDLE and r["rd"] >= 0)
+    rd0 = [r["rd"] for r in sched if r["fop"] == PS.F_IDLE and r["rd"] >= 0]
+    assert rd0 == [sched[0]["rd"]] and sched[0]["gop"] == PS.G_FQ       # the one load from the constants: row 0
+    gTG = vflag("gTG", is_g(PS.G_TG))
+    gCHm = [vflag("gCH%d" % m, is_g(PS.G_CH0 + m)) for m in range(3)]
+    gCH = vflag("gCH", is_g(PS.G_CH0, PS.G_CH1, PS.G_CH2))
+    gST = vflag("gST", is_g(PS.G_TG, PS.G_CH0, PS.G_CH1, PS.G_CH2))
+    gFQ = vflag("gFQ", is_g(PS.G_FQ))
+    gLT = vflag("gLT", is_g(PS.G_TG, PS.G_CH0, PS.G_CH1))
+    a.n_vconst = F12
+    PG = N_PERIODIC + len(a.vflags)             # PG + j: the value of constant cell G_j on the row
+
+    # ---- columns ----
+    for nm in ("PX", "PY"):
+        a.alloc(nm, NL)
+    for nm in ("QX", "QY", "Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "QSX", "QSY", "FXC", "FYC"):
+        a.alloc(nm, F2)
+    for nm in ("A", "B", "G"):
+        a.alloc(nm, F12)
+    a.alloc("REG", NR * F12)
+    a.alloc_checked("C", F12 * a.cpl)
+    for sl in range(5):
+        a.alloc_checked("S%d" % sl, F2 * a.cpl)
+    for k in range(12):
+        a.declare_gadget_cols("c%d" % k, 44)
+    for sl in range(5):
+        for c in range(2):
+            a.declare_gadget_cols("s%d_%d" % (sl, c), 43)
+    a.finalize_columns()
+
+    # ---- the Fq12 unit ----
+    def coef_u(nm, t, **kw):
+        tm, n = a.vec_u16(nm, **kw)
+        return [(co, b + NL * t, st, f, ng) for (co, b, st, f, ng) in tm], n
+
+    def coef_c(nm, t, **kw):
+        tm, n = a.vec_chk(nm, **kw)
+        return [(co, b + NL * a.cpl * t, st, f, ng) for (co, b, st, f, ng) in tm], n
+
+    A = lambda i, c: coef_u("A", 2 * i + c)
+    B = lambda j, c: coef_u("B", 2 * j + c)
+    for k in range(6):
+        for comp in range(2):
+            prods = []
+            for i in range(6):
+                for j in range(6):
+                    if i + j == k:
+                        if comp == 0:
+                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1))]
+                        else:
+                            prods += [(1, A(i, 0), B(j, 1)), (1, A(i, 1), B(j, 0))]
+                    elif i + j == k + 6:
+                        if comp == 0:
+                            prods += [(9, A(i, 0), B(j, 0)), (-9, A(i, 1), B(j, 1)), (-1, A(i, 0), B(j, 1)), (-1, A(i, 1), B(j, 0))]
+                        else:
+                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1)), (9, A(i, 0), B(j, 1)), (9, A(i, 1), B(j, 0))]
+            # FROB rows: (a0 + s a1 u)(g0 + g1 u), s = sFS = +-1
+            if comp == 0:
+                prods += [(1, A(k, 0), coef_u("G", 2 * k, flag=sFR)), (-1, A(k, 1), coef_u("G", 2 * k + 1, flag=sFS))]
+            else:
+                prods += [(1, A(k, 0), coef_u("G", 2 * k + 1, flag=sFR)), (1, A(k, 1), coef_u("G", 2 * k, flag=sFS))]
+            t = 2 * k + comp
+            a.gadget("c%d" % t, prods, [(-1, coef_c("C", t, flag=sC)), (-1, coef_u("G", t, flag=sBC))], 44)
+
+    # ---- the G2 unit ----
+    def u2(nm):                      # unchecked Fq2 value: (component, coef, flag) -> vector
+        return lambda c, coef=1, flag=-1: ([(coef, a.col(nm) + NL * c, 1, flag, 0)], NL)
+
+    def fq_as_f2(nm):                # an Fq value x as the Fq2 element (x, 0): component 1 has no terms
+        return lambda c, coef=1, flag=-1: ([(coef, a.col(nm), 1, flag, 0)] if c == 0 else [], NL)
+
+    def c2(nm):                      # checked Fq2 value
+        def f(c, coef=1, flag=-1):
+            b = a.col(nm) + NL * a.cpl * c
+            if a.cpl == 1:
+                return [(coef, b, 1, flag, 0)], NL
+            return [(coef, b, 2, flag, 0), (coef * 256, b + 1, 2, flag, 0)], NL
+        return f
+
+    def lc(*terms):
+        return lambda c, coef=1, flag=-1: Air.vsum(*[fn(c, coef * k, flag) for k, fn in terms])
+
+    def f2prod(coef, fa, fb, flag, conj=False):
+        """{component: [(coef, vecA, vecB)]} of coef * fa * fb (fa conjugated first if conj); the flag sits on fa"""
+        s = -1 if conj else 1
+        out = {0: [(coef, fa(0, 1, flag), fb(0)), (-coef * s, fa(1, 1, flag), fb(1))],
+               1: [(coef, fa(0, 1, flag), fb(1)), (coef * s, fa(1, 1, flag), fb(0))]}
+        return {c: [(co, va, vb) for co, va, vb in v if va[0] and vb[0]] for c, v in out.items()}
+
+    LAM, X3, Y3, L1N, L3 = (c2("S%d" % sl) for sl in range(5))
+    TX, TY, QSX, QSY, QX, QY, FXC, FYC = (u2(nm) for nm in ("TX", "TY", "QSX", "QSY", "QX", "QY", "FXC", "FYC"))
+    PXf = fq_as_f2("PX")
+    slots = [
+        # S0 = lam:  TG: 2 lam y_T - 3 x_T^2;  CH: lam (x_QS - x_T) - (y_QS - y_T);  FQ: conj(x_Q) FX - S0
+        ([f2prod(2, LAM, TY, gTG), f2prod(-3, TX, TX, gTG), f2prod(1, LAM, lc((1, QSX), (-1, TX)), gCH), f2prod(1, QX, FXC, gFQ, conj=True)],
+         [(-1, QSY, gCH), (1, TY, gCH), (-1, LAM, gFQ)]),
+        # S1 = x3:   lam^2 - x_T - x_B - x3 (x_B = x_T on tangent rows, x_QS on chord rows);  FQ: conj(y_Q) FY - S1
+        ([f2prod(1, LAM, LAM, gST), f2prod(1, QY, FYC, gFQ, conj=True)],
+         [(-1, TX, gST), (-1, TX, gTG), (-1, QSX, gCH), (-1, X3, gST), (-1, X3, gFQ)]),
+        # S2 = y3:   lam (x_T - x3) - y_T - y3;  FQ: conj(S0) FX - S2  (x of pi^2(Q))
+        ([f2prod(1, LAM, lc((1, TX), (-1, X3)), gST), f2prod(1, LAM, FXC, gFQ, conj=True)],
+         [(-1, TY, gST), (-1, Y3, gST), (-1, Y3, gFQ)]),
+        # S3 = -lam x_P:  lam x_P + S3;  FQ: conj(S1) FY + S3  (y of -pi^2(Q))
+        ([f2prod(1, LAM, PXf, gST), f2prod(1, X3, FYC, gFQ, conj=True)],
+         [(1, L1N, gST), (1, L1N, gFQ)]),
+        # S4 = lam x_T - y_T
+        ([f2prod(1, LAM, TX, gST)], [(-1, TY, gST), (-1, L3, gST)]),
+    ]
+    for sl, (prods, lins) in enumerate(slots):
+        for c in range(2):
+            pp = [p for d in prods for p in d[c]]
+            ll = [(coef, fn(c, 1, fl)) for coef, fn, fl in lins]
+            a.gadget("s%d_%d" % (sl, c), pp, ll, 43)
+    a.emit_gadgets()
+
+    # ---- polynomial constraints ----
+    col = a.col
+    last = PER_LAST
+
+    def climb(name, j):              # 16-bit limb j of a checked vector as [(coef, col)]
+        b = col(name)
+        return [(1, b + j)] if a.cpl == 1 else [(1, b + 2 * j), (256, b + 2 * j + 1)]
+
+    def keep_or_load(c, loads):
+        """(1 - per_last)(next - local) - sum_f per[f] (value - local) = 0 for loads = [(flag, [(coef, col)])]; the flags are 0 on
+        a block's last row (nothing is loaded there), where the next block starts free"""
+        m = [(1, [X(c)]), (-1, [L(c)]), (-1, [PER(last), X(c)]), (1, [PER(last), L(c)])]
+        for fl, val in loads:
+            m += [(1, [PER(fl), L(c)])] + [(-co, [PER(fl), L(cc)]) for co, cc in val]
+        a.poly(m)
+
+    # operands
+    for j in range(F12):
+        a.poly([(1, [L(col("A") + j)])] + [(-1, [PER(sA[k]), L(col("REG") + F12 * k + j)]) for k in range(NR)])
+        t, l = divmod(j, NL)
+        m = [(1, [L(col("B") + j)])] + [(-1, [PER(sB[k]), L(col("REG") + F12 * k + j)]) for k in range(NR)]
+        m += [(-co, [PER(sBC), L(cc)]) for co, cc in climb("C", j)]
+        # the line y_P - lam x_P w + (lam x_T - y_T) w^3: tower components 0 (y_P), 2 / 3 (S3), 6 / 7 (S4)
+        if t == 0:
+            m += [(-1, [PER(sBL), L(col("PY") + l)])]
+        elif t in (2, 3):
+            m += [(-co, [PER(sBL), L(cc)]) for co, cc in climb("S3", NL * (t - 2) + l)]
+        elif t in (6, 7):
+            m += [(-co, [PER(sBL), L(cc)]) for co, cc in climb("S4", NL * (t - 6) + l)]
+        a.poly(m)
+        a.poly([(1, [L(col("G") + j)]), (-1, [PER(PG + j)])])
+    # registers
+    for k in range(NR):
+        for j in range(F12):
+            loads = [(ld[k], climb("C", j))]
+            if k == rd0[0]:
+                loads.append((ldG, [(1, col("G") + j)]))
+            keep_or_load(col("REG") + F12 * k + j, loads)
+    # P and Q are constant over a block; T, pi(Q), -pi^2(Q) are registers of the G2 unit
+    for nm, n in (("PX", NL), ("PY", NL), ("QX", F2), ("QY", F2)):
+        for j in range(n):
+            keep_or_load(col(nm) + j, [])
+    for j in range(F2):
+        keep_or_load(col("Q1X") + j, [(gFQ, climb("S0", j))])
+        keep_or_load(col("Q1Y") + j, [(gFQ, climb("S1", j))])
+        keep_or_load(col("Q2X") + j, [(gFQ, climb("S2", j))])
+        keep_or_load(col("Q2Y") + j, [(gFQ, climb("S3", j))])
+        keep_or_load(col("TX") + j, [(gLT, climb("S1", j)), (gFQ, [(1, col("QX") + j)])])
+        keep_or_load(col("TY") + j, [(gLT, climb("S2", j)), (gFQ, [(1, col("QY") + j)])])
+        for d, srcs in (("QSX", ("QX", "Q1X", "Q2X")), ("QSY", ("QY", "Q1Y", "Q2Y"))):
+            a.poly([(1, [L(col(d) + j)])] + [(-1, [PER(gCHm[m_]), L(col(srcs[m_]) + j)]) for m_ in range(3)])
+    # the twist's Frobenius constants
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
+    import bn254
+    for nm, v in (("FXC", bn254.FROB_X), ("FYC", bn254.FROB_Y)):
+        for c in range(2):
+            for i in range(NL):
+                a.poly([(1, [L(col(nm) + NL * c + i)]), (-((v[c] >> (16 * i)) & 0xFFFF), [])])
+    # public inputs: P, Q on the block's first row, Z (tower limbs of the MyFq12 words) in the result register on its last row
+    word = 0
+    for nm, nwords in (("PX", 8), ("PY", 8), ("QX", 16), ("QY", 16)):
+        for j in range(nwords):
+            for part in (0, 1):
+                ai = len(a.aux)
+                a.aux.append((word + j, part, 0, 0))
+                a.poly([(1, [PER(PER_FIRST), L(col(nm) + 2 * j + part)]), (-1, [PER(PER_FIRST), AUX(ai)])])
+        word += nwords
+    res = col("REG") + F12 * PS.RESULT_REG
+    for sub in range(F12):
+        ai = len(a.aux)
+        a.aux.append((word, 3, ROWS_PER_IO - 1, sub))
+        a.poly([(1, [PER(PER_LAST), L(res + sub)]), (-1, [PER(PER_LAST), AUX(ai)])])
+    word += 96
+    a.pi_per_io = word
+    a.primary = dict(kind="pairing")
+    a.layout = [col(nm) for nm in ("PX", "PY", "QX", "QY", "Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "QSX", "QSY", "FXC", "FYC", "A", "B", "G",
+                                   "REG", "C", "S0")]
+    return a
+
+
+def emit_pairing_schedule(f, prefix, a):
+    """the schedule and the constant vectors for the two trace generators; the selector columns for everybody"""
+    S = PS.SCHEDULE
+    f.write("/* final-pairing AIR (tools/pairing_sched.py): per row {fq12 op (0 idle 1 mul 2 line 3 inv 4 frob), register of A, register of B,\n"
+            "   constant vector, register loaded at the end of the row, g2 op (0 idle 1 tangent 2 / 3 / 4 chord with Q / pi(Q) / -pi^2(Q) 5 frobenius of Q)} */\n")
+    f.write("#define %s_PAIRING_ROWS %d\n#define %s_PAIRING_NREG %d\n#define %s_PAIRING_RESULT_REG %d\n#define %s_PAIRING_ACTIVE_ROWS %d\n" % (
+        prefix, PS.ROWS, prefix, PS.NREG, prefix, PS.RESULT_REG, prefix, PS.N_ACTIVE))
+    f.write("static const int8_t %s_PAIRING_SCHED[%d][6] = {\n" % (prefix, PS.ROWS))
+    for i in range(0, PS.ROWS, 8):
+        f.write("    " + ", ".join("{%d, %d, %d, %d, %d, %d}" % (r["fop"], r["ra"], r["rb"], r["gc"], r["rd"], r["gop"]) for r in S[i:i + 8]) + ",\n")
+    f.write("};\n")
+    # constant vectors as 16-bit limbs in cell order (tower component t = 2 i + c, 16 limbs each); the last one is zero
+    vecs = [[(g[i][c] >> (16 * l)) & 0xFFFF for i in range(6) for c in range(2) for l in range(NL)] for g in PS.G_CONSTS] + [[0] * (12 * NL)]
+    f.write("/* constant vectors: 1, conjugation, Frobenius p / p^2 / p^3, zero; whether the operand's coefficients are conjugated first */\n")
+    f.write("#define %s_PAIRING_NGCONST %d\n" % (prefix, len(vecs)))
+    f.write("static const int64_t %s_PAIRING_GCONST[%d][%d] = {\n" % (prefix, len(vecs), 12 * NL))
+    for v in vecs:
+        f.write("    {" + ", ".join(map(str, v)) + "},\n")
+    f.write("};\n")
+    f.write("static const int8_t %s_PAIRING_GCONJ[%d] = {%s};\n" % (prefix, len(vecs), ", ".join(map(str, PS.G_CONJ_COEF + [0]))))
+    f.write("static const int8_t %s_PAIRING_GIDX[%d] = {%s};\n" % (prefix, PS.ROWS, ", ".join(
+        str(r["gc"] if r["gc"] >= 0 else len(vecs) - 1) for r in S)))
+    f.write("/* selector columns (period %d): %s */\n" % (PS.ROWS, " ".join(a.vflag_names)))
+    f.write("#define %s_PAIRING_NVFLAG %d\n" % (prefix, len(a.vflags)))
+    f.write("static const int8_t %s_PAIRING_VFLAG[%d][%d] = {\n" % (prefix, len(a.vflags), PS.ROWS))
+    for v in a.vflags:
+        f.write("    {" + ", ".join(map(str, v)) + "},\n")
+    f.write("};\n")
+
+
+# ------------------------------------------------------------------------------------------------
 def emit(a, f, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     f.write("static const int64_t %s_PROG[] = {\n" % tag)
@@ -769,15 +1045,17 @@ def emit(a, f, prefix):
 def header_entry(a, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     g0 = a.gadgets[0]
-    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d, %d},\n" % (
-        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3, "g1h": 0, "g2h": 1}[a.name], a.tbits, a.cpl, a.n_main, a.checked_base,
-        a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag,
-        a.log_rows, a.hardened))
+    vp = "%d, %s_PAIRING_VFLAG[0], %d, %s_PAIRING_GCONST[0], %s_PAIRING_GIDX" % (len(a.vflags), prefix, a.n_vconst, prefix, prefix) \
+        if a.vflags else "0, 0, 0, 0, 0"
+    return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d, %d, %s},\n" % (
+        a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3, "g1h": 0, "g2h": 1, "pairing": 6}[a.name], a.tbits, a.cpl, a.n_main,
+        a.checked_base, a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag,
+        a.log_rows, a.hardened, vp))
 
 
 STRUCT = """typedef struct {
     const char *name;
-    int kind;            /* 0 g1, 1 g2, 2 fq12, 3 mapg2 */
+    int kind;            /* 0 g1, 1 g2, 2 fq12, 3 mapg2, 6 pairing */
     int table_bits;      /* 16 or 8 */
     int cells_per_limb;  /* checked cells per 16-bit limb: 1 (u16 table) or 2 (u8 table) */
     int n_main;          /* TABLE + unchecked + checked cells */
@@ -794,7 +1072,19 @@ STRUCT = """typedef struct {
     const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
     int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 3 for mapg2 */
     int hardened;        /* 1: the curve AIR with canonical x3 and the x-inequality witness (API kinds 4 / 5 = kind + 4) */
+    /* VALUE-periodic columns (period 2^log_rows, arbitrary values; index AIR_N_PERIODIC + k in VEC flags and periodic factors):
+     * k < n_vflag: selector vflag[k][row] in {-1, 0, 1};  n_vflag <= k < n_vflag + n_vconst: vconst[vconst_idx[row]][k - n_vflag] */
+    int n_vflag;
+    const int8_t *vflag;
+    int n_vconst;
+    const int64_t *vconst;
+    const int8_t *vconst_idx;
 } air_spec_t;
+/* value of value-periodic column k (0-based) on row `row` of a block */
+static inline int64_t air_vper_value(const air_spec_t *a, int k, int row) {
+    if (k < a->n_vflag) return a->vflag[((size_t)k << a->log_rows) + (size_t)row];
+    return a->vconst[(size_t)a->vconst_idx[row] * (size_t)a->n_vconst + (size_t)(k - a->n_vflag)];
+}
 """
 
 
@@ -807,7 +1097,7 @@ def main():
     airs = []
     for mode in ("u16", "u8"):
         airs += [build_curve("g1", mode, 1), build_curve("g2", mode, 2), build_fq12(mode), build_map_g2(mode),
-                 build_curve("g1", mode, 1, hardened=True), build_curve("g2", mode, 2, hardened=True)]
+                 build_curve("g1", mode, 1, hardened=True), build_curve("g2", mode, 2, hardened=True), build_pairing(mode)]
     # ONE file, included by the product (sipp_amd/csrc, -I data) and by the checker (oracle/, -I data) alike
     for path, prefix, guard in ((os.path.join(ROOT, "data", "air_tables.h"), "AIR", "SIPP_AIR_TABLES_H"),):
         with open(path, "w") as f:
@@ -819,12 +1109,16 @@ def main():
                 prefix, len(PERIODICS), ", ".join("{%d, %d}" % p for p in PERIODICS)))
             f.write("static const uint32_t %s_BN_P_LIMBS[16] = {%s};\n" % (prefix, ", ".join(map(str, P_LIMBS))))
             emit_map_schedule(f, prefix)
+            emit_pairing_schedule(f, prefix, [x for x in airs if x.name == "pairing"][0])
             for a in airs:
                 f.write("/* %s: %s */\n" % (a.name + "_" + a.mode, column_map(a)))
                 emit(a, f, prefix)
                 if a.hardened:
                     f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3), eq, u, eqc, ng, inf, t1, v, w, NGV, cn */\n" % a.name)
                     f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[13] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
+                if a.name == "pairing":
+                    f.write("/* columns of PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC A B G REG C S0 */\n")
+                    f.write("static const int32_t %s_PAIRING_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
                     f.write("static const int32_t %s_MAPG2_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))

@@ -1,6 +1,8 @@
 """Executable prototype of sipp_amd/csrc/pairing.hip: the same representation (Fq12 = Fq2[w]/(w^6 - xi)), the same affine Miller
-loop and the same final exponentiation (easy part, Devegili-Scott-Dahab hard part), in big-int Python, checked against
-oracle/py/bn254.py (plain (p^12 - 1)/r power).  Run it to re-verify the formulas: python tools/pairing_prototype.py"""
+loop and the same final exponentiation (easy part, then the hard part by the chain of ark-ec 0.4's Bn::final_exponentiation as
+recalled: Fuentes-Castaneda et al.), in big-int Python, checked against oracle/py/bn254.py (plain power by
+lambda (p^12 - 1)/r, lambda = 2u(6u^2 + 3u + 1)); the Devegili-Scott-Dahab chain the GPU ran until round 5 is kept as
+`final_exp_reduced` (the plain reduced pairing).  Run it to re-verify the formulas: python tools/pairing_prototype.py"""
 import sys, random
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.py import bn254 as bn
@@ -97,7 +99,21 @@ def miller(Pt, Q):
 
 def exp_x(a):
     return t_pow(a, U)
+def exp_neg_x(a):
+    return t_conj(exp_x(a))
 def final_exp(f):
+    """ark-ec 0.4 models/bn/mod.rs final_exponentiation, y_k named as there (recalled)"""
+    r = t_mul(t_conj(f), t_inv(f))            # f^(p^6 - 1)
+    r = t_mul(t_frob(r, 2), r)                # ^(p^2 + 1)
+    y0 = exp_neg_x(r); y1 = t_sqr(y0); y2 = t_sqr(y1); y3 = t_mul(y2, y1)
+    y4 = exp_neg_x(y3); y5 = t_sqr(y4); y6 = exp_neg_x(y5)
+    y3 = t_conj(y3); y6 = t_conj(y6)
+    y7 = t_mul(y6, y4); y8 = t_mul(y7, y3); y9 = t_mul(y8, y1); y10 = t_mul(y8, y4); y11 = t_mul(y10, r)
+    y12 = t_frob(y9, 1); y13 = t_mul(y12, y11)
+    y8 = t_frob(y8, 2); y14 = t_mul(y8, y13)
+    y15 = t_frob(t_mul(t_conj(r), y9), 3)
+    return t_mul(y15, y14)
+def final_exp_reduced(f):
     # easy part: f^((p^6 - 1)(p^2 + 1))
     g = t_mul(t_conj(f), t_inv(f))
     g = t_mul(t_frob(g, 2), g)
@@ -135,6 +151,8 @@ if __name__ == "__main__":
     assert t_to_c(m) == bn.miller_loop(Pt, Q), "miller"
     e = final_exp(m)
     assert t_to_c(e) == bn.pairing(Pt, Q), "final exp"
+    assert t_to_c(final_exp_reduced(m)) == bn.pairing_reduced(Pt, Q), "reduced final exp"
+    assert t_to_c(t_pow(final_exp_reduced(m), bn.ARK_MULTIPLIER)) == bn.pairing(Pt, Q), "ark value = reduced ^ lambda"
     print("prototype ok")
 
 
