@@ -91,7 +91,8 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
                 * next row's double and R = -P through an identity state bit instead of being refused: every record whose OUTPUT is a
                 * finite point has a proof, except one that meets R = P on the LAST add row of its 512 rows (bit 255 of a 256-bit exponent:
                 * no row is left to hand the double over) -- SIPP_E_WITNESS, like an output at the identity.  Through sipp_prove / sipp_prove_async and the generic size / shape / trace functions. */
-               SIPP_G1_EXP_HARDENED = 4, SIPP_G2_EXP_HARDENED = 5 } sipp_kind;
+               SIPP_G1_EXP_HARDENED = 4, SIPP_G2_EXP_HARDENED = 5,
+               SIPP_PAIRING = 6 /* src/bin/bls_aggregation.rs:76-77, see sipp_pairing_prove */ } sipp_kind;
 
 /* u32 words per IO record, (x, offset, exp_val, output) order:
  * G1 7*8 = 56, G2 13*8 = 104, Fq12 37*8 = 296. */
@@ -100,6 +101,8 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
 #define SIPP_FQ12_IO_WORDS 296
 /* MapToG2 records (u, x, y): the message in Fp2 and its point on the twist, 6*8 = 48 */
 #define SIPP_MAP_G2_IO_WORDS 48
+/* final-pairing records (P, Q, Z): a G1 point (16), a G2 point (32: x.c0, x.c1, y.c0, y.c1), e(P, Q) as 12 MyFq12 coefficients (96) */
+#define SIPP_PAIRING_IO_WORDS 144
 
 /* ---- context ---------------------------------------------------------------- */
 /* `workspace_bytes` of HBM are reserved once; afterwards the only allocations are the constant tables of a transform SIZE at its
@@ -205,6 +208,18 @@ int sipp_stark_shape(const sipp_ctx *ctx, int kind, size_t num_io, uint32_t *log
  * with kind = SIPP_MAP_G2. */
 int sipp_map_to_g2_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
                          size_t *proof_len);
+/* The STARK behind the in-circuit FINAL PAIRING of the reference's BLS example (src/bin/bls_aggregation.rs:76-77:
+ * `let z = pairing_circuit(builder, final_A, final_B); Fq12Target::connect(builder, &z, &final_Z)`), the way this path does
+ * everything else: as a STARK obligation instead of outer-circuit gates.  ios: num_io records (P, Q, Z) of SIPP_PAIRING_IO_WORDS u32;
+ * Z = e(P, Q) with the value `ark_bn254::Bn254::pairing` returns (src/prover_native.rs:20; the reduced optimal ate pairing raised
+ * to 2u(6u^2 + 3u + 1): ark-ec's final exponentiation as recalled) is compared with the device-computed one (SIPP_E_WITNESS if it
+ * differs, if P / Q are off their curves, if a word is >= p, or if a step of the affine Miller loop degenerates -- Q outside the
+ * r-torsion).  512 trace rows per pairing (64 tangent + 38 chord steps, the easy part, ark-ec's hard-part chain),
+ * at least 1024 rows.  A VERIFIER of such a proof must check [r] Q = O besides the curve equations (oracle/stark.c does): the chord
+ * rows are sound for points of order r only.  Generic entry points (sipp_prove, sipp_prove_async, sipp_proof_size,
+ * sipp_workspace_bytes, sipp_stark_shape, sipp_trace_build, sipp_exp_outputs: Z computed and written) with kind = SIPP_PAIRING. */
+int sipp_pairing_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
+                       size_t *proof_len);
 /* What the reference computes natively per message (src/bin/bls_aggregation.rs:100-104), on the device:
  *   map_ios [n][48]      (u, x, y) records for sipp_map_to_g2_prove;
  *   g2_ios  [2n][104]    (may be NULL) the G2ExpStark obligations of the cofactor clearing, h = 2p - r:

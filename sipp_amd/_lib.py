@@ -90,6 +90,7 @@ SIGNATURES = {
     "sipp_g2_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_fq12_exp_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_map_to_g2_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_pairing_prove": (C.c_int, [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_prove": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_ctx_set_hardened": (C.c_int, [vp, C.c_int]),
     "sipp_map_to_g2": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp]),
@@ -423,13 +424,16 @@ class Ctx:
         return t
 
     def prove(self, kind, ios):
-        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12 / 3 MapToG2 / 4, 5 hardened G1, G2) for host IO records -> flat proof"""
+        """one STARK sub-proof (kind 0 G1 / 1 G2 / 2 Fq12 / 3 MapToG2 / 4, 5 hardened G1, G2 / 6 final pairing) for host IO records -> flat proof"""
         ios = np.ascontiguousarray(ios, dtype=np.uint32)
         cap = self.L.sipp_proof_size(self.h, kind, ios.shape[0])
         if cap == 0:
             raise SippError(-1, "sipp_proof_size")
         out = np.zeros(cap, dtype=np.uint64)
         n = C.c_size_t()
+        if kind == 6:
+            self._ck(self.L.sipp_pairing_prove(self.h, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "pairing_prove")
+            return out[: n.value]
         if kind >= 4:       # the hardened G1 / G2 kinds: the generic entry point
             self._ck(self.L.sipp_prove(self.h, kind, ios.ctypes.data, ios.shape[0], out.ctypes.data, cap, C.byref(n)), "prove")
             return out[: n.value]

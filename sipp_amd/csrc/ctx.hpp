@@ -246,6 +246,11 @@ size_t sipp_curve_rows_bytes(int kind, uint32_t log_n);
 int sipp_mapg2_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
                     int* d_err);
 int sipp_mapg2_outputs(sipp_ctx* ctx, uint32_t* d_ios, uint32_t num_io, int* d_err);
+// pairing.hip: the final pairing (pairing AIR, kind 6): primary witness rows, or (ctx->outputs_only) Z written into the records
+int sipp_pairing_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
+                      int* d_err);
+// the AIR's selector columns (value-periodic, small integers) on the device: [n_vflag][2^log_rows] int8; nullptr for an AIR without
+const int8_t* sipp_air_vflag_device(sipp_ctx* ctx, const air_spec_t* a);
 // outputs of n1 G1 and n2 G2 obligations, the two accumulator chains on two streams (native.hip's fold of a SIPP round)
 int sipp_fold_outputs(sipp_ctx* ctx, uint32_t* g1_ios, size_t n1, uint32_t* g2_ios, size_t n2);
 // the same in two phases: begin starts the 255 doublings of every record's point x on two side streams (the exponent and

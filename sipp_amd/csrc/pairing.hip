@@ -14,6 +14,7 @@
 // The field routines are deliberately NOT inlined (one copy each, operands through pointers) to keep the code small.
 #include <vector>
 
+#include "air_tables.h"
 #include "ctx.hpp"
 #include "fq.hpp"
 #include "pairing_constants.h"
@@ -719,7 +720,277 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ va
     }
 }
 
+
+// =====================================================================================================================================
+// Primary witness of the final-pairing AIR (API kind 6; tools/air_gen.py::build_pairing, schedule tools/pairing_sched.py): ONE WAVE
+// per record walks the 512 rows of its block -- the statement behind `pairing_circuit(final_A, final_B)` == final_Z of the
+// reference's BLS example (src/bin/bls_aggregation.rs:76-77).  Per row: the G2 unit (an AFFINE tangent / chord step with its line
+// coefficients -- the cells hold the affine slope, so every step takes one Fq2 inversion -- on lane 0), the Fq12 unit (36 lanes per
+// product as in the final exponentiation above; the one inversion on lane 0; Frobenius / conjugation rows on 6 lanes), then all 64
+// lanes write the row's 156 field elements as 16-bit (8-bit) limb cells, and the registers take over what the schedule says.
+// oracle/pairing.c is the CPU reading the tests compare with cell for cell.
+// =====================================================================================================================================
+enum { PL_PX, PL_PY, PL_QX, PL_QY, PL_Q1X, PL_Q1Y, PL_Q2X, PL_Q2Y, PL_TX, PL_TY, PL_QSX, PL_QSY, PL_FXC, PL_FYC, PL_A, PL_B, PL_G, PL_REG, PL_C,
+       PL_S0, PL_N };
+enum { PV_QX, PV_QY, PV_Q1X, PV_Q1Y, PV_Q2X, PV_Q2Y, PV_TX, PV_TY, PV_QSX, PV_QSY, PV_FXC, PV_FYC, PV_N };
+struct PairCols {
+    int32_t lay[PL_N];
+    int32_t cpl, nreg, result_reg;
+};
+// the row's values in the order the cell writer walks them: 156 field elements (Montgomery form)
+struct PairVals {
+    T6 reg[6];
+    T6 A, B, G, C;
+    Fq px, py;
+    Fq2 pts[PV_N];
+    Fq2 S[5];
+};
+static_assert(sizeof(PairVals) == 156 * sizeof(Fq), "PairVals is walked as an array of Fq");
+// device copy of the schedule tables (data/air_tables.h): [512][6] int8 | gidx [512] int8 | gconj [8] int8 | gconst [6][192] u16
+constexpr int PT_SCHED = 0, PT_GIDX = 3072, PT_GCONJ = 3584, PT_GCONST = 3592, PT_BYTES = 3592 + 6 * 192 * 2;
+
+__device__ __forceinline__ Fq load_words_mont(const uint32_t* w) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = w[i];
+    return fq::to_mont(r);
+}
+__device__ __forceinline__ bool f2_eq(const Fq2& a, const Fq2& b) { return fq::is_zero(fq::sub(a, b)); }
+
+__global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__ ios, uint32_t num_io, const uint8_t* __restrict__ tab,
+                                                         PairCols k, uint64_t* __restrict__ tr, size_t n, int mode, int* __restrict__ err) {
+    __shared__ PairVals V;
+    __shared__ CoopScratch64 sc;
+    __shared__ int s_bad;
+    const uint32_t l = threadIdx.x;
+    const uint32_t io = blockIdx.x;
+    if (io >= num_io) return;
+    uint32_t* rec = ios + (size_t)io * 144;
+    const Fq2 zero2 = f2_zero();
+    // ---- the record: P, Q (checked: on their curves; the verifier also wants [r] Q = O), constants, empty registers ----
+    if (l == 0) {
+        s_bad = 0;
+        V.px = load_words_mont(rec);
+        V.py = load_words_mont(rec + 8);
+        V.pts[PV_QX] = Fq2{load_words_mont(rec + 16), load_words_mont(rec + 24)};
+        V.pts[PV_QY] = Fq2{load_words_mont(rec + 32), load_words_mont(rec + 40)};
+        for (int i = PV_Q1X; i < PV_FXC; i++) V.pts[i] = zero2;
+        V.pts[PV_FXC] = pairing_k::GAMMA[0][2];
+        V.pts[PV_FYC] = pairing_k::GAMMA[0][3];
+        // y^2 = x^3 + 3 ;  (9 + u)(y^2 - x^3) = 3
+        const Fq three = fq::small_m(3);
+        Fq t;
+        fq_mul(t, V.px, V.px);
+        fq_mul(t, t, V.px);
+        Fq y2;
+        fq_mul(y2, V.py, V.py);
+        if (!fq::is_zero(fq::sub(fq::sub(y2, t), three))) s_bad = 1;
+        Fq2 x3, yy, d;
+        f2_sqr(x3, V.pts[PV_QX]);
+        f2_mul(x3, x3, V.pts[PV_QX]);
+        f2_sqr(yy, V.pts[PV_QY]);
+        f2_mul_xi(d, fq::sub(yy, x3));
+        if (!fq::is_zero(fq::sub(d.c0, three)) || !fq::is_zero(d.c1)) s_bad = 1;
+    }
+    if (l < 36) V.reg[l / 6].c[l % 6] = zero2;
+    __syncthreads();
+    if (s_bad) {
+        if (l == 0) atomicExch(err, SIPP_E_WITNESS);
+        return;
+    }
+    const int8_t* sched = reinterpret_cast<const int8_t*>(tab + PT_SCHED);
+    const int8_t* gidx = reinterpret_cast<const int8_t*>(tab + PT_GIDX);
+    const int8_t* gconj = reinterpret_cast<const int8_t*>(tab + PT_GCONJ);
+    const uint16_t* gconst = reinterpret_cast<const uint16_t*>(tab + PT_GCONST);
+    Fq* flat = reinterpret_cast<Fq*>(&V);
+    for (int t = 0; t < 512; t++) {
+        const int fop = sched[6 * t], ra = sched[6 * t + 1], rb = sched[6 * t + 2], rd = sched[6 * t + 4], gop = sched[6 * t + 5];
+        const int gi = gidx[t];
+        // ---- (1) the G2 unit (lane 0) and the row's constants (lanes 32 .. 43) ----
+        if (l == 0) {
+            Fq2 S0 = zero2, S1 = zero2, S2 = zero2, S3 = zero2, S4 = zero2, qsx = zero2, qsy = zero2;
+            const Fq2 tx = V.pts[PV_TX], ty = V.pts[PV_TY];
+            if (gop == 5) {
+                f2_mul(S0, f2_conj(V.pts[PV_QX]), V.pts[PV_FXC]);
+                f2_mul(S1, f2_conj(V.pts[PV_QY]), V.pts[PV_FYC]);
+                f2_mul(S2, f2_conj(S0), V.pts[PV_FXC]);
+                f2_mul(S3, f2_conj(S1), V.pts[PV_FYC]);
+                S3 = f2_neg(S3);
+            } else if (gop != 0) {
+                Fq2 num, den, xb;
+                if (gop == 1) {
+                    den = f2_dbl(ty);
+                    f2_sqr(num, tx);
+                    num = fq::add(f2_dbl(num), num);
+                    xb = tx;
+                } else {
+                    qsx = V.pts[gop == 2 ? PV_QX : gop == 3 ? PV_Q1X : PV_Q2X];
+                    qsy = V.pts[gop == 2 ? PV_QY : gop == 3 ? PV_Q1Y : PV_Q2Y];
+                    den = fq::sub(qsx, tx);
+                    num = fq::sub(qsy, ty);
+                    xb = qsx;
+                }
+                if (fq::is_zero(den)) {
+                    s_bad = 1;                     // a degenerate step: Q is not a point of order r (or T met +-Q): no affine slope
+                } else {
+                    Fq2 di, t2;
+                    f2_inv(di, den);
+                    f2_mul(S0, num, di);
+                    f2_sqr(S1, S0);
+                    S1 = fq::sub(fq::sub(S1, tx), xb);
+                    f2_mul(t2, S0, fq::sub(tx, S1));
+                    S2 = fq::sub(t2, ty);
+                    f2_scale(S3, S0, V.px);
+                    S3 = f2_neg(S3);
+                    f2_mul(t2, S0, tx);
+                    S4 = fq::sub(t2, ty);
+                }
+            }
+            V.S[0] = S0; V.S[1] = S1; V.S[2] = S2; V.S[3] = S3; V.S[4] = S4;
+            V.pts[PV_QSX] = qsx;
+            V.pts[PV_QSY] = qsy;
+        }
+        if (l >= 32 && l < 44) {
+            const uint32_t e = l - 32;          // Fq element e of the row's constant vector (16-bit limbs in the table)
+            const uint16_t* src = gconst + (size_t)gi * 192 + 16 * e;
+            Fq v;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v.l[i] = (uint32_t)src[2 * i] | ((uint32_t)src[2 * i + 1] << 16);
+            Fq* g = reinterpret_cast<Fq*>(&V.G);
+            g[e] = fq::to_mont(v);
+        }
+        __syncthreads();
+        // ---- (2) operands ----
+        if (l < 6) {
+            V.A.c[l] = ra >= 0 ? V.reg[ra].c[l] : zero2;
+            Fq2 b = zero2;
+            if (fop == 1) b = V.reg[rb].c[l];
+            else if (fop == 2) b = l == 0 ? Fq2{V.py, fq::zero()} : l == 1 ? V.S[3] : l == 3 ? V.S[4] : zero2;
+            V.B.c[l] = b;
+        }
+        __syncthreads();
+        // ---- (3) the Fq12 unit ----
+        if (fop == 1 || fop == 2) {
+            coop_mul64(V.C, V.A, V.B, sc);
+        } else if (fop == 3) {
+            if (l == 0) {
+                T6 a = V.A, b;
+                bool zero = true;
+                for (int i = 0; i < 6; i++) zero = zero && fq::is_zero(a.c[i]);
+                if (zero) {
+                    s_bad = 1;
+                    for (int i = 0; i < 6; i++) b.c[i] = zero2;
+                } else {
+                    t6_inv(b, a);
+                }
+                V.C = b;
+                V.B = b;
+            }
+            __syncthreads();
+        } else {
+            if (l < 6) {
+                Fq2 c = zero2;
+                if (fop == 4) f2_mul(c, gconj[gi] ? f2_conj(V.A.c[l]) : V.A.c[l], V.G.c[l]);
+                V.C.c[l] = c;
+            }
+            __syncthreads();
+        }
+        // ---- (4) the row's cells ----
+        if (mode == 0) {
+            const size_t row = (size_t)io * 512 + (size_t)t;
+            for (uint32_t e = l; e < 156; e += 64) {
+                int col, chk = 0;
+                if (e < 72) col = k.lay[PL_REG] + 16 * (int)e;
+                else if (e < 84) col = k.lay[PL_A] + 16 * (int)(e - 72);
+                else if (e < 96) col = k.lay[PL_B] + 16 * (int)(e - 84);
+                else if (e < 108) col = k.lay[PL_G] + 16 * (int)(e - 96);
+                else if (e < 120) { col = k.lay[PL_C] + 16 * k.cpl * (int)(e - 108); chk = 1; }
+                else if (e < 122) col = k.lay[PL_PX + (int)(e - 120)];
+                else if (e < 146) col = k.lay[PL_QX + (int)((e - 122) >> 1)] + 16 * (int)((e - 122) & 1);
+                else { col = k.lay[PL_S0] + 16 * k.cpl * (int)(e - 146); chk = 1; }
+                const Fq v = fq::from_mont(flat[e]);
+                if (chk && k.cpl == 2) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t limb = (v.l[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                        tr[(size_t)(col + 2 * i) * n + row] = limb & 0xffu;
+                        tr[(size_t)(col + 2 * i + 1) * n + row] = limb >> 8;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) tr[(size_t)(col + i) * n + row] = (v.l[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- (5) end of the row: registers ----
+        if (l < 6 && rd >= 0) V.reg[rd].c[l] = fop == 0 ? V.G.c[l] : V.C.c[l];
+        if (l == 0) {
+            if (gop == 5) {
+                V.pts[PV_TX] = V.pts[PV_QX]; V.pts[PV_TY] = V.pts[PV_QY];
+                V.pts[PV_Q1X] = V.S[0]; V.pts[PV_Q1Y] = V.S[1]; V.pts[PV_Q2X] = V.S[2]; V.pts[PV_Q2Y] = V.S[3];
+            } else if (gop >= 1 && gop <= 3) {
+                V.pts[PV_TX] = V.S[1]; V.pts[PV_TY] = V.S[2];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the result: MyFq12 coefficients c_i = a_i - 9 b_i, c_{i+6} = b_i; compared with the record (mode 0) or written into it ----
+    if (l < 6) {
+        const T6& res = V.reg[k.result_reg];
+        const Fq nine = fq::small_m(9);
+        Fq nb;
+        fq_mul(nb, nine, res.c[l].c1);
+        const Fq lo = fq::from_mont(fq::sub(res.c[l].c0, nb)), hi = fq::from_mont(res.c[l].c1);
+        uint32_t* z = rec + 48;
+        bool bad = s_bad != 0;
+        for (int i = 0; i < 8; i++) {
+            if (mode == 1) {
+                z[8 * l + i] = lo.l[i];
+                z[8 * (l + 6) + i] = hi.l[i];
+            } else {
+                bad |= z[8 * l + i] != lo.l[i] || z[8 * (l + 6) + i] != hi.l[i];
+            }
+        }
+        if (bad) atomicExch(err, SIPP_E_WITNESS);
+    }
+}
+
 }  // namespace
+
+// primary witness of the final-pairing AIR: d_ios [num_io][144] (padded: 512 num_io == n rows).  outputs_only ctx: the records'
+// Z words are written instead (sipp_exp_outputs with kind = SIPP_PAIRING)
+int sipp_pairing_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
+                      int* d_err) {
+    const size_t n = (size_t)1 << log_n;
+    const bool outputs = ctx->outputs_only;
+    PairCols k;
+    const int32_t* lay = (a && a->cells_per_limb == 2) ? AIR_PAIRING_LAYOUT_U8 : AIR_PAIRING_LAYOUT_U16;
+    memcpy(k.lay, lay, sizeof k.lay);
+    k.cpl = a ? a->cells_per_limb : 1;
+    k.nreg = AIR_PAIRING_NREG;
+    k.result_reg = AIR_PAIRING_RESULT_REG;
+    static_assert(AIR_PAIRING_ROWS == 512 && AIR_PAIRING_NREG == 6 && AIR_PAIRING_NGCONST == 6, "pairing_rows_kernel: table shapes");
+    if (!outputs && (!a || a->kind != 6 || a->log_rows != 9 || a->checked_base != k.lay[PL_C] || a->pi_per_io != 144 || (size_t)num_io * 512 != n))
+        return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: table / shape mismatch");
+    uint64_t* t = sipp_table_get(ctx, 102, 0, 0);
+    if (!t) {
+        std::vector<uint64_t> packed((PT_BYTES + 7) / 8, 0);
+        uint8_t* b = reinterpret_cast<uint8_t*>(packed.data());
+        memcpy(b + PT_SCHED, AIR_PAIRING_SCHED, 3072);
+        memcpy(b + PT_GIDX, AIR_PAIRING_GIDX, 512);
+        memcpy(b + PT_GCONJ, AIR_PAIRING_GCONJ, AIR_PAIRING_NGCONST);
+        uint16_t* gc = reinterpret_cast<uint16_t*>(b + PT_GCONST);
+        for (int g = 0; g < AIR_PAIRING_NGCONST; g++)
+            for (int i = 0; i < 192; i++) gc[g * 192 + i] = (uint16_t)AIR_PAIRING_GCONST[g][i];
+        SIPP_TRY(sipp_table_put(ctx, 102, 0, 0, packed, &t));
+    }
+    ProfScope ps(ctx, "trace_pairing");
+    hipLaunchKernelGGL(pairing_rows_kernel, dim3(num_io), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io,
+                       reinterpret_cast<const uint8_t*>(t), k, d_trace, n, outputs ? 1 : 0, d_err);
+    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    return SIPP_OK;
+}
 
 // `count` products over consecutive groups of pairs: group k = pairs [off[k], off[k + 1])
 int sipp_inner_products_groups(sipp_ctx* ctx, const uint32_t* g1, const uint32_t* g2, const uint32_t* off, size_t count, uint32_t* out) {

@@ -5,6 +5,8 @@
 // StarkOpeningSet::new and plonky2's PolynomialBatch::prove_openings / fri_committed_trees
 // (@ InternetMaximalism/plonky2 541e127; reached from reference src/verifier_circuit.rs:133-135 only).
 // All arithmetic is Goldilocks u64 / quadratic extension; nothing here is GEMM shaped.
+#include <map>
+
 #include "ctx.hpp"
 #include "prover.hpp"
 
@@ -207,6 +209,10 @@ struct QuotArgs {
     uint64_t* part;                            // [n_seg][2][m] partial Horner sums
     const uint64_t* per_tab[AIR_N_PERIODIC];  // table k has 2 * m_k entries, indexed by natural i mod 2 m_k
     uint32_t per_mask[AIR_N_PERIODIC];
+    // the AIR's value-periodic columns (periodic index AIR_N_PERIODIC + k; the pairing AIR's selectors and constants) on the
+    // quotient coset: [n_vper][2 R], R = rows per record, indexed by natural i mod 2 R
+    const uint64_t* vper_tab;
+    uint32_t vper_mask;
     uint64_t zh_inv[2];   // 1 / (x^N - 1) for even / odd natural index
     uint64_t zh[2];       // x^N - 1
     uint64_t ninv;        // 1 / N
@@ -236,10 +242,14 @@ struct QCtx {
     size_t j, jn, m;
     uint64_t p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11;     // scalars, not an array: the object must stay in registers
     uint64_t acc0, acc1;
+    const uint64_t* vper;       // the lane's entry of value-periodic column 0; column k sits k * vper_stride words further
+    uint32_t vper_stride;
     // selects instead of a dynamically indexed private array (which would live in scratch memory); k is wave-uniform.  Indices
-    // 0 .. 3: the exponentiation AIRs' selectors, 4 .. 11: MapToG2's eight row types
+    // 0 .. 3: the exponentiation AIRs' selectors, 4 .. 11: MapToG2's eight row types; from AIR_N_PERIODIC on: the AIR's value-periodic
+    // columns, read from their table
     __device__ __forceinline__ uint64_t periodic(int k) const {
         static_assert(AIR_N_PERIODIC == 12, "periodic(): update the select chain");
+        if (k >= AIR_N_PERIODIC) return vper[(size_t)(k - AIR_N_PERIODIC) * vper_stride];
         if (k < 4) return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
         if (k < 8) return k == 4 ? p4 : k == 5 ? p5 : k == 6 ? p6 : p7;
         return k == 8 ? p8 : k == 9 ? p9 : k == 10 ? p10 : p11;
@@ -296,6 +306,8 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
     c.j = j;
     c.jn = gl::bitrev((uint32_t)((i + 2) & (m - 1)), a.log_m);
     c.acc0 = c.acc1 = 0;
+    c.vper = a.vper_tab + (i & a.vper_mask);
+    c.vper_stride = a.vper_mask + 1;
 #define SIPP_PER(k) c.p##k = a.per_tab[k][i & a.per_mask[k]]
     SIPP_PER(0); SIPP_PER(1); SIPP_PER(2); SIPP_PER(3); SIPP_PER(4); SIPP_PER(5);
     SIPP_PER(6); SIPP_PER(7); SIPP_PER(8); SIPP_PER(9); SIPP_PER(10); SIPP_PER(11);
@@ -316,8 +328,11 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
         const size_t stride = a.lde_stride, jl = c.j, jn = c.jn;
         const uint64_t p0 = c.p0, p1 = c.p1, p2 = c.p2, p3 = c.p3, p4 = c.p4, p5 = c.p5, p6 = c.p6, p7 = c.p7, p8 = c.p8, p9 = c.p9,
                        p10 = c.p10, p11 = c.p11;
+        const uint64_t* __restrict__ vper = c.vper;
+        const uint32_t vper_stride = c.vper_stride;
         auto periodic = [&](int k) -> uint64_t {
             static_assert(AIR_N_PERIODIC == 12, "periodic(): update the select chain");
+            if (k >= AIR_N_PERIODIC) return vper[(size_t)(k - AIR_N_PERIODIC) * vper_stride];
             if (k < 4) return k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
             if (k < 8) return k == 4 ? p4 : k == 5 ? p5 : k == 6 ? p6 : p7;
             return k == 8 ? p8 : k == 9 ? p9 : k == 10 ? p10 : p11;
@@ -1209,6 +1224,36 @@ int sipp_k_z_columns(sipp_ctx* ctx, const air_spec_t* a, const uint64_t* d_trace
     return SIPP_OK;
 }
 
+// natural-order NTT on the host (sizes up to 2 R = 1024: the value-periodic columns below): out[i] = sum_j a[j] w^(i j), w a primitive
+// 2^log_n-th root (inverse: w^-1 and the factor 1 / n)
+static void host_ntt(uint64_t* a, uint32_t log_n, bool inverse) {
+    const size_t n = (size_t)1 << log_n;
+    for (size_t i = 0; i < n; i++) {
+        const size_t j = gl::bitrev((uint32_t)i, log_n);
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    uint64_t root = gl::root_of_unity(log_n);
+    if (inverse) root = gl::inv(root);
+    for (uint32_t s = 1; s <= log_n; s++) {
+        const size_t mlen = (size_t)1 << s, h = mlen >> 1;
+        uint64_t wm = root;
+        for (uint32_t k = s; k < log_n; k++) wm = gl::sqr(wm);
+        for (size_t k = 0; k < n; k += mlen) {
+            uint64_t w = 1;
+            for (size_t j = 0; j < h; j++) {
+                const uint64_t t = gl::mul(w, a[k + j + h]), u = a[k + j];
+                a[k + j] = gl::add(u, t);
+                a[k + j + h] = gl::sub(u, t);
+                w = gl::mul(w, wm);
+            }
+        }
+    }
+    if (inverse) {
+        const uint64_t ninv = gl::inv((uint64_t)n);
+        for (size_t i = 0; i < n; i++) a[i] = gl::mul(a[i], ninv);
+    }
+}
+
 // PRECONDITION: every cell of d_lde / d_zlde / d_aux is CANONICAL (< p).  The lazy POLY path adds and subtracts +-1-coefficient
 // monomials with gl::add / gl::sub directly on raw operands (no product in between to canonicalise them): gl::sub(a, b) with b >= p
 // would be off by 2^32 - 1.  Every producer keeps this: the tree sweeps (ntt_tree.hip) and lde_column canonicalise at their last store
@@ -1247,6 +1292,44 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         }
         q.per_tab[k] = t;
         q.per_mask[k] = (uint32_t)(2 * mk - 1);
+    }
+    // value-periodic columns: column k is P_k(x^(N/R)) with P_k interpolating its R values over the order-R subgroup; on the
+    // quotient coset x_i = 7 w_2N^i it takes the 2 R values P_k(7^(N/R) w_2R^i): a coset LDE of P_k, built once per trace length
+    q.vper_tab = nullptr;
+    q.vper_mask = 0;
+    if (a->n_vflag + a->n_vconst > 0) {
+        const uint32_t lr = (uint32_t)a->log_rows;
+        const size_t R = (size_t)1 << lr, R2 = 2 * R;
+        const int nv = a->n_vflag + a->n_vconst;
+        uint64_t* t = sipp_table_get(ctx, 104, log_n, (uint64_t)a->kind);
+        if (!t) {
+            std::vector<uint64_t> tab((size_t)nv * R2), col(R2);
+            const uint64_t shift = gl::pow(gl::GEN, (uint64_t)1 << (log_n - lr));
+            std::map<std::vector<int64_t>, int> seen;      // many columns repeat (the constants are mostly zero)
+            std::vector<int64_t> vals(R);
+            for (int k = 0; k < nv; k++) {
+                for (size_t r = 0; r < R; r++) vals[r] = air_vper_value(a, k, (int)r);
+                auto it = seen.find(vals);
+                if (it != seen.end()) {
+                    memcpy(&tab[(size_t)k * R2], &tab[(size_t)it->second * R2], R2 * 8);
+                    continue;
+                }
+                seen.emplace(vals, k);
+                for (size_t r = 0; r < R; r++) col[r] = gl::from_i64(vals[r]);
+                host_ntt(col.data(), lr, true);
+                uint64_t f = 1;
+                for (size_t j = 0; j < R; j++) {
+                    col[j] = gl::mul(col[j], f);
+                    f = gl::mul(f, shift);
+                }
+                for (size_t j = R; j < R2; j++) col[j] = 0;
+                host_ntt(col.data(), lr + 1, false);
+                memcpy(&tab[(size_t)k * R2], col.data(), R2 * 8);
+            }
+            SIPP_TRY(sipp_table_put(ctx, 104, log_n, (uint64_t)a->kind, tab, &t));
+        }
+        q.vper_tab = t;
+        q.vper_mask = (uint32_t)(R2 - 1);
     }
     const uint64_t sN = gl::pow(gl::GEN, n);
     q.zh[0] = gl::sub(sN, 1);

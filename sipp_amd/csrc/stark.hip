@@ -16,9 +16,12 @@
 
 #include "prover.hpp"
 
-static const int IO_WORDS[6] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS, SIPP_MAP_G2_IO_WORDS, SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS};
+static const int IO_WORDS[7] = {SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS, SIPP_FQ12_IO_WORDS, SIPP_MAP_G2_IO_WORDS, SIPP_G1_IO_WORDS, SIPP_G2_IO_WORDS,
+                                SIPP_PAIRING_IO_WORDS};
 // the hardened G1 / G2 kinds take the records of the plain ones
-static inline int base_kind(int kind) { return kind >= SIPP_G1_EXP_HARDENED ? kind - SIPP_G1_EXP_HARDENED : kind; }
+static inline int base_kind(int kind) {
+    return (kind == SIPP_G1_EXP_HARDENED || kind == SIPP_G2_EXP_HARDENED) ? kind - SIPP_G1_EXP_HARDENED : kind;
+}
 // sipp_ctx_set_hardened: on such a ctx the plain G1 / G2 kinds stand for the hardened ones (every entry point that takes a ctx)
 static inline int ctx_kind(const sipp_ctx* ctx, int kind) {
     return (ctx && ctx->hardened && (kind == SIPP_G1_EXP || kind == SIPP_G2_EXP)) ? kind + SIPP_G1_EXP_HARDENED : kind;
@@ -33,7 +36,7 @@ struct Shape {
 };
 
 static int shape_of(int kind, size_t num_io, Shape* s) {
-    if (kind < 0 || kind > SIPP_G2_EXP_HARDENED || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
+    if (kind < 0 || kind > SIPP_PAIRING || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
     const uint32_t log_rows = kind == SIPP_MAP_G2 ? 3 : 9;   // rows per record: 512 (exponentiations), 8 (MapToG2)
     uint32_t nio = 2;  // at least two IO blocks, at least 1024 rows
     while (nio < num_io || ((size_t)nio << log_rows) < 1024) nio <<= 1;
@@ -228,8 +231,8 @@ static bool fq_words_canonical(const uint32_t* w) {
 // every Fq element of every record < p (the exponent may be any 256-bit value): (x, offset, exp_val, output)
 static bool pis_canonical(int kind, const uint32_t* pis, size_t num_io) {
     kind = base_kind(kind);
-    if (kind == SIPP_MAP_G2) {   // (u, x, y): six Fq elements, no exponent
-        for (size_t k = 0; k < 6 * num_io; k++)
+    if (kind == SIPP_MAP_G2 || kind == SIPP_PAIRING) {   // (u, x, y): six Fq elements; (P, Q, Z): eighteen; no exponent
+        for (size_t k = 0; k < (size_t)(kind == SIPP_MAP_G2 ? 6 : 18) * num_io; k++)
             if (!fq_words_canonical(pis + 8 * k)) return false;
         return true;
     }
@@ -644,7 +647,7 @@ int sipp_exp_outputs(sipp_ctx* ctx, int kind, uint32_t* ios, size_t num_io) {
     kind = base_kind(kind);   // the outputs of the hardened kinds are the plain chains'
     Shape s;
     SIPP_TRY(shape_of(kind, num_io, &s));
-    const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : kind == SIPP_FQ12_EXP ? 96 : 32;
+    const size_t ppi = IO_WORDS[kind], out_words = kind == SIPP_G1_EXP ? 16 : (kind == SIPP_FQ12_EXP || kind == SIPP_PAIRING) ? 96 : 32;
     ArenaScope scope(ctx);
     uint32_t* d_ios = nullptr;
     int rc = upload_ios(ctx, kind, ios, num_io, s, &d_ios, nullptr);
@@ -845,7 +848,7 @@ int sipp_fq12_exp_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint6
 }
 // any kind, synchronously (the hardened G1 / G2 kinds have no entry point of their own)
 int sipp_prove(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
-    if (kind < SIPP_G1_EXP || kind > SIPP_G2_EXP_HARDENED) return ctx ? sipp_fail(ctx, SIPP_E_BADARG, "sipp_prove: unknown kind") : SIPP_E_BADARG;
+    if (kind < SIPP_G1_EXP || kind > SIPP_PAIRING) return ctx ? sipp_fail(ctx, SIPP_E_BADARG, "sipp_prove: unknown kind") : SIPP_E_BADARG;
     return prove_impl(ctx, kind, ios, num_io, proof_out, proof_cap, proof_len);
 }
 
@@ -853,6 +856,9 @@ int sipp_prove(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint
 int sipp_map_to_g2_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap,
                          size_t* proof_len) {
     return prove_impl(ctx, SIPP_MAP_G2, ios, num_io, proof_out, proof_cap, proof_len);
+}
+int sipp_pairing_prove(sipp_ctx* ctx, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap, size_t* proof_len) {
+    return prove_impl(ctx, SIPP_PAIRING, ios, num_io, proof_out, proof_cap, proof_len);
 }
 
 // ---- asynchronous form -------------------------------------------------------------------------------------
@@ -879,7 +885,7 @@ static void async_worker(sipp_ctx* ctx) {
 
 int sipp_prove_async(sipp_ctx* ctx, int kind, const uint32_t* ios, size_t num_io, uint64_t* proof_out, size_t proof_cap) {
     if (!ctx || !ios || !proof_out) return SIPP_E_BADARG;
-    if (kind < SIPP_G1_EXP || kind > SIPP_G2_EXP_HARDENED) return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: unknown kind");
+    if (kind < SIPP_G1_EXP || kind > SIPP_PAIRING) return sipp_fail(ctx, SIPP_E_BADARG, "prove_async: unknown kind");
     sipp_ctx::Async& a = ctx->async;
     std::unique_lock<std::mutex> lk(a.mu);
     if (a.has_job) {

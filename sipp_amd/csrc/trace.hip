@@ -842,13 +842,16 @@ struct GadgetArgs {
     int cpl;
     uint32_t p_limbs[16];
     uint32_t pinv16;
+    // the AIR's selector columns (flags AIR_N_PERIODIC + k of a VEC): [n_vflag][2^log_rows] int8, values -1 / 0 / 1 (the pairing AIR)
+    const int8_t* vflag;
+    uint32_t rows_mask, log_rows;
 };
 
 // limb vector with a STATIC number of limbs (16 for operands, 17 for the quotient: fixed by tools/air_gen.py): the limbs
 // stay in registers.  Every limb of the specification is a small combination of 16-bit cells, far below 2^31; `ovf`
 // is set if that ever fails, and the row is then reported as SIPP_E_WITNESS instead of being computed wrongly.
 template <int NLV>
-__device__ __forceinline__ int ivec_dev(const int64_t* w, const uint64_t* tr, size_t n, size_t row, const int* per,
+__device__ __forceinline__ int ivec_dev(const int64_t* w, const uint64_t* tr, size_t n, size_t row, const int* per, const GadgetArgs& g,
                                         int32_t (&out)[NLV], bool& ovf) {
     const int nt = (int)w[1];
     int64_t acc[NLV];
@@ -858,7 +861,12 @@ __device__ __forceinline__ int ivec_dev(const int64_t* w, const uint64_t* tr, si
         const int64_t* tm = w + 2 + 5 * t;
         int32_t f = (int32_t)tm[0];
         const int base = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
-        if (flag >= 0) f *= neg ? 1 - per[flag] : per[flag];
+        if (flag >= 0) {
+            const int pv = flag < AIR_N_PERIODIC ? per[flag]
+                                                 : (int)g.vflag[((size_t)(flag - AIR_N_PERIODIC) << g.log_rows) + (row & g.rows_mask)];
+            f *= neg ? 1 - pv : pv;
+        }
+        if (f == 0) continue;
 #pragma unroll
         for (int i = 0; i < NLV; i++) acc[i] += (int64_t)f * (int32_t)(uint32_t)tr[(size_t)(base + i * stride) * n + row];
     }
@@ -893,8 +901,8 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
     for (int p = 0; p < np; p++) {
         const int64_t coef = *w++;
         int32_t va[16], vb[16];
-        w += ivec_dev<16>(w, tr, n, row, per, va, bad);
-        w += ivec_dev<16>(w, tr, n, row, per, vb, bad);
+        w += ivec_dev<16>(w, tr, n, row, per, g, va, bad);
+        w += ivec_dev<16>(w, tr, n, row, per, g, vb, bad);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int64_t a64 = coef * va[i];
@@ -908,7 +916,7 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
     for (int p = 0; p < nl; p++) {
         const int64_t coef = *w++;
         int32_t va[16];
-        w += ivec_dev<16>(w, tr, n, row, per, va, bad);
+        w += ivec_dev<16>(w, tr, n, row, per, g, va, bad);
 #pragma unroll
         for (int i = 0; i < 16; i++) e[i] += coef * va[i];
     }
@@ -1198,11 +1206,12 @@ __global__ void __launch_bounds__(256) lookup_expand_kernel(const uint32_t* __re
 }  // namespace
 
 // ---- host drivers -------------------------------------------------------------------------------------------
-// API kinds: 0 G1, 1 G2, 2 Fq12, 3 MapToG2, 4 / 5 = the hardened G1 / G2 AIRs (the same records and rows; air->kind stays 0 / 1)
+// API kinds: 0 G1, 1 G2, 2 Fq12, 3 MapToG2, 4 / 5 = the hardened G1 / G2 AIRs (the same records and rows; air->kind stays 0 / 1),
+// 6 = the final pairing
 const air_spec_t* sipp_air_get(int kind, uint32_t log_n) {
     const bool u16 = log_n >= 16;
-    if (kind < 0 || kind > 5) return nullptr;
-    const int hard = kind >= 4 ? 1 : 0, base = hard ? kind - 4 : kind;
+    if (kind < 0 || kind > 6) return nullptr;
+    const int hard = (kind == 4 || kind == 5) ? 1 : 0, base = hard ? kind - 4 : kind;
     for (size_t i = 0; i < sizeof(AIR_AIRS) / sizeof(AIR_AIRS[0]); i++)
         if (AIR_AIRS[i].kind == base && AIR_AIRS[i].hardened == hard && (AIR_AIRS[i].table_bits == 16) == u16) return &AIR_AIRS[i];
     return nullptr;
@@ -1217,6 +1226,17 @@ static int64_t* prog_on_device(sipp_ctx* ctx, const air_spec_t* a) {
     return (int64_t*)t;
 }
 const int64_t* sipp_air_prog_device(sipp_ctx* ctx, const air_spec_t* a) { return prog_on_device(ctx, a); }
+const int8_t* sipp_air_vflag_device(sipp_ctx* ctx, const air_spec_t* a) {
+    if (a->n_vflag == 0) return nullptr;
+    uint64_t* t = sipp_table_get(ctx, 103, (uint64_t)a->kind, 0);
+    if (!t) {
+        const size_t bytes = (size_t)a->n_vflag << a->log_rows;
+        std::vector<uint64_t> v((bytes + 7) / 8, 0);
+        memcpy(v.data(), a->vflag, bytes);
+        if (sipp_table_put(ctx, 103, (uint64_t)a->kind, 0, v, &t) != SIPP_OK) return nullptr;
+    }
+    return reinterpret_cast<const int8_t*>(t);
+}
 
 // bytes of the Jacobian row scratch sipp_trace_fill takes from the arena FIRST for a curve AIR (kind 0 / 1) of 2^log_n rows
 size_t sipp_curve_rows_bytes(int kind, uint32_t log_n) {
@@ -1273,6 +1293,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
     const int cpl = a->cells_per_limb, nm = a->n_main, nc = a->n_checked;
     ArenaScope scope(ctx);   // the row scratch and the lookup tables go back on EVERY exit path
     int col_bit = 0, col_e = 0, exp_off = 0;
+    const bool exp_air = a->kind != 3 && a->kind != 6;   // the exponentiation AIRs: exponent cells, an accumulator compared with the record
     if (a->kind == 3) {
         // MapToG2: eight rows per message, no exponent / accumulator cells (mapg2.hip); the claimed point is compared there
         if (ctx->outputs_only) {
@@ -1280,6 +1301,10 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
             return SIPP_OK;
         }
         SIPP_TRY(sipp_mapg2_fill(ctx, a, d_ios, num_io, log_n, d_trace, d_err));
+    } else if (a->kind == 6) {
+        // the final pairing: one wave per record walks the schedule (pairing.hip); the claimed value is compared there
+        SIPP_TRY(sipp_pairing_fill(ctx, a, d_ios, num_io, log_n, d_trace, d_err));
+        if (ctx->outputs_only) return SIPP_OK;
     } else if (a->kind == 2) {
         Fq12Cols c{1, 1 + 192, a->checked_base, cpl};
         col_bit = 1 + 384;
@@ -1352,7 +1377,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
         SIPP_CHECK_HIP(ctx, hipGetLastError());
         return SIPP_OK;
     }
-    if (a->kind != 3) {
+    if (exp_air) {
         // accumulator state columns: R (curves, column 1) or acc (Fq12, column 1)
         ProfScope ps(ctx, "trace_check_outputs");
         hipLaunchKernelGGL(check_outputs_kernel, dim3((num_io + 63) / 64), dim3(64), 0, ctx->stream, d_ios, num_io,
@@ -1361,7 +1386,7 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
     }
     {
         ProfScope ps(ctx, "trace_exp_table");
-        if (a->kind != 3)
+        if (exp_air)
             hipLaunchKernelGGL(exp_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_ios,
                                (uint32_t)a->pi_per_io, (uint32_t)exp_off, d_trace, n, col_bit, col_e);
         hipLaunchKernelGGL(table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_trace, n,
@@ -1421,6 +1446,10 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
         uint32_t pinv = 1;
         for (int i = 0; i < 5; i++) pinv = (pinv * (2 - AIR_BN_P_LIMBS[0] * pinv)) & 0xffff;
         g.pinv16 = pinv;
+        g.vflag = sipp_air_vflag_device(ctx, a);
+        if (a->n_vflag && !g.vflag) return SIPP_E_HIP;
+        g.log_rows = (uint32_t)a->log_rows;
+        g.rows_mask = (1u << a->log_rows) - 1;
         ProfScope ps(ctx, "trace_gadgets");
         hipLaunchKernelGGL(gadget_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)a->n_gadgets), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
