@@ -77,12 +77,36 @@ def cpu_baseline(ios, shapes, kinds, budget_s=150.0):
 def verify_proofs(proofs):
     """the CPU checker (oracle/stark.c's verifier, test infrastructure) over proofs this run produced, OUTSIDE every timed region:
     a bench line for proofs nobody checked is a claim, not a result.  Returns True when every non-empty proof is accepted."""
-    from tests import _oracle
-    ok = True
-    for pf in proofs:
-        if len(pf):
-            ok = ok and _oracle.stark_verify(np.ascontiguousarray(pf)) == 0
-    return bool(ok)
+    try:
+        from tests import _oracle
+        ok = True
+        for pf in proofs:
+            if len(pf):
+                ok = ok and _oracle.stark_verify(np.ascontiguousarray(pf)) == 0
+        return bool(ok)
+    except Exception as e:      # a checker that cannot run (build failure, missing compiler) is `verified: false`, never a rank that
+        VERIFY_ERRORS.append("%s: %s" % (type(e).__name__, e))   # leaves the collective the other ranks are waiting in
+        return False
+
+
+VERIFY_ERRORS = []
+
+
+def prepare_checker(rank, barrier):
+    """the oracle library is built ONCE, by rank 0, BEFORE the timed region (liboracle.so is git-ignored: on a fresh tree all N
+    ranks would otherwise run the same `make` at once, right after the timing); the others load it after the barrier.  A failure
+    is recorded, not raised: every rank must reach the reductions that follow."""
+    def build():
+        try:
+            from tests import _oracle
+            _oracle.load()
+        except Exception as e:
+            VERIFY_ERRORS.append("%s: %s" % (type(e).__name__, e))
+    if rank == 0:
+        build()
+    barrier()
+    if rank != 0:
+        build()
 
 
 def all_ranks_true(flag, device):
@@ -321,6 +345,7 @@ def main():
             c.profile_reset()
         proof_ms[:] = [0.0, 0.0, 0.0]
 
+    prepare_checker(rank, barrier)
     # W untimed warm-up steps, then exactly K steps between barrier + synchronize, max over ranks
     elapsed, proofs = dist_util.timed_steps(step, args.steps, args.warmup, sync=device_sync, device=red_device,
                                             before_timing=start_profiling)
@@ -479,6 +504,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             # the three proofs of the last timed step, on every rank, through oracle/stark.c's verifier after the timed region
             "verified": verified_main,
+            **({"verify_errors": VERIFY_ERRORS[:3]} if VERIFY_ERRORS else {}),
             # what carried the barrier and the max-over-ranks reduction of the timed region
             "timing_reduction": ("%s:%s" % (dist.get_backend(), red_device)) if dist.is_initialized() else "single process",
             "config": {"workload": "n=%d SIPP instance per GPU: G1ExpStark %d IO (N=2^%d, W+P+Q=%d), G2ExpStark %d IO "

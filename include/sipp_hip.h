@@ -109,6 +109,23 @@ typedef enum { SIPP_G1_EXP = 0, SIPP_G2_EXP = 1, SIPP_FQ12_EXP = 2,
  * first use on the ctx (twiddles / node constants: at most 8 B per LDE row, built on the host once and kept until destroy).
  * Pass 0 to size the arena for n = 128 (about 24 GiB). */
 int sipp_ctx_create(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t workspace_bytes);
+/* The version of THIS header (bumped whenever a struct of the ABI changes size or meaning: 2 = sipp_stark_config with ten fields,
+ * round 5; 3 = round 6, SIPP_PAIRING).  A binding that cannot be rebuilt with the library (the Rust shim) creates its contexts through
+ * sipp_ctx_create_checked, which refuses (SIPP_E_BADARG, *out = NULL, nothing read from cfg) a caller whose header version or
+ * sizeof(sipp_stark_config) differs from the library's -- a struct two fields short would otherwise be read past its end and stray
+ * bits taken for fs_rule / lookup_rule. */
+#define SIPP_ABI_VERSION 3u
+uint32_t sipp_abi_version(void);
+int sipp_ctx_create_checked(sipp_ctx **out, int device, const sipp_stark_config *cfg, size_t cfg_size, uint32_t abi_version,
+                            size_t workspace_bytes);
+/* Which of two equivalent kernels serves a step (results are identical; the non-default routes are the fallbacks the tests keep
+ * alive -- until round 5 they hid behind environment variables).  routes = OR of:
+ *   SIPP_ROUTE_OPENINGS_UNGROUPED  openings at zeta / g zeta by one block per column instead of the grouped kernel (traces >= 1024 rows)
+ *   SIPP_ROUTE_LDE_COLUMN_WIDE     columns of 2^13 / 2^14 rows through the whole-column-in-LDS transform instead of the tree sweeps
+ * Only while no proof is in flight on the ctx. */
+#define SIPP_ROUTE_OPENINGS_UNGROUPED 1u
+#define SIPP_ROUTE_LDE_COLUMN_WIDE 2u
+int sipp_ctx_set_kernel_routes(sipp_ctx *ctx, uint32_t routes);
 void sipp_ctx_destroy(sipp_ctx *ctx);
 /* The ctx's HIP stream: level > 0 = a stream of the highest priority the device offers; level <= 0 = a stream with a hardware
  * queue of its own at normal priority (created with an all-ones CU mask: the runtime multiplexes ordinary streams onto a pool of
@@ -211,8 +228,8 @@ int sipp_map_to_g2_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint
 /* The STARK behind the in-circuit FINAL PAIRING of the reference's BLS example (src/bin/bls_aggregation.rs:76-77:
  * `let z = pairing_circuit(builder, final_A, final_B); Fq12Target::connect(builder, &z, &final_Z)`), the way this path does
  * everything else: as a STARK obligation instead of outer-circuit gates.  ios: num_io records (P, Q, Z) of SIPP_PAIRING_IO_WORDS u32;
- * Z = e(P, Q) with the value `ark_bn254::Bn254::pairing` returns (src/prover_native.rs:20; the reduced optimal ate pairing raised
- * to 2u(6u^2 + 3u + 1): ark-ec's final exponentiation as recalled) is compared with the device-computed one (SIPP_E_WITNESS if it
+ * Z = e(P, Q) with the value `plonky2_bn254_pairing::pairing::pairing` returns (src/prover_native.rs:8,20; as recalled it restates
+ * arkworks' Bn254::pairing: the reduced optimal ate pairing raised to 2u(6u^2 + 3u + 1), ark-ec's final exponentiation) is compared with the device-computed one (SIPP_E_WITNESS if it
  * differs, if P / Q are off their curves, if a word is >= p, or if a step of the affine Miller loop degenerates -- Q outside the
  * r-torsion).  512 trace rows per pairing (64 tangent + 38 chord steps, the easy part, ark-ec's hard-part chain),
  * at least 1024 rows.  A VERIFIER of such a proof must check [r] Q = O besides the curve equations (oracle/stark.c does): the chord
@@ -413,7 +430,10 @@ int sipp_plonk_prove_gates(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_
 int sipp_ntt_batch(sipp_ctx *ctx, uint64_t *d_cols, size_t col_stride, size_t ncols, uint32_t log_n, int inverse);
 /* PolynomialBatch::from_values, column-major and transpose-free:
  *   d_values [ncols][N] natural order  ->  d_coeffs [ncols][N] (natural, may alias d_values)
- *   d_lde [ncols][N << rate_bits] in LEAF order (position j = natural LDE row bitrev(j)). */
+ *   d_lde [ncols][N << rate_bits] in LEAF order (position j = natural LDE row bitrev(j)).
+ * ALIGNMENT (this call, sipp_commit_batch, sipp_commit_batch_ex and the oracles handed to the plonk entry points): for columns of
+ * 2^13 rows and more every device pointer must be 16-byte aligned (the transforms move 16 bytes per lane); an 8-byte-aligned
+ * view is SIPP_E_BADARG.  hipMalloc / torch allocations are; slices at odd u64 offsets are not. */
 int sipp_lde_batch(sipp_ctx *ctx, const uint64_t *d_values, uint64_t *d_coeffs, uint64_t *d_lde, size_t ncols,
                    uint32_t log_n);
 /* hash_or_noop of every leaf: d_lde [ncols][n_leaves] leaf order -> d_digests [n_leaves][4] */

@@ -75,6 +75,13 @@ static_assert(sizeof(Fq12ExpIO) == 4 * SIPP_FQ12_IO_WORDS, "Fq12 IO record layou
 // MapToG2 record: the message u in Fp2, then its point on the twist
 using MapG2IO = ExpIO<Fq2, G2Affine>;
 static_assert(sizeof(MapG2IO) == 4 * SIPP_MAP_G2_IO_WORDS, "MapToG2 IO record layout");
+// final-pairing record: (P, Q), then e(P, Q)
+struct PairingInput {
+    G1Affine p;
+    G2Affine q;
+};
+using PairingIO = ExpIO<PairingInput, Fq12>;
+static_assert(sizeof(PairingIO) == 4 * SIPP_PAIRING_IO_WORDS, "pairing IO record layout");
 
 // ---- errors: the reference's call sites unwrap an anyhow::Result; here a failing status throws ----
 class Error : public std::runtime_error {
@@ -279,7 +286,8 @@ class Prover {
         for (int k = 0; k < 3; k++) {
             max_io_[k] = mx[k];
             // (the G1 / G2 arenas also hold the hardened AIRs of sipp_hip.h kinds 4 / 5: about 14 % more columns, 11 % more time)
-            const size_t ws = k < 2 ? sipp_workspace_bytes(k + SIPP_G1_EXP_HARDENED, mx[k]) : sipp_workspace_bytes(k, mx[k]);
+            size_t ws = k < 2 ? sipp_workspace_bytes(k + SIPP_G1_EXP_HARDENED, mx[k]) : sipp_workspace_bytes(k, mx[k]);
+            if (k == SIPP_G2_EXP) ws = std::max(ws, sipp_workspace_bytes(SIPP_PAIRING, 1));   // pairing_circuit runs there
             const int rc = sipp_ctx_create(&ctx_[k], device, nullptr, ws);
             if (rc != SIPP_OK) {
                 for (int j = 0; j < k; j++) sipp_ctx_destroy(ctx_[j]);
@@ -330,6 +338,32 @@ class Prover {
         r.flat.resize(len);
         finish(io, &r);
         return r;
+    }
+    // pairing_circuit(builder, final_A, final_B) of the BLS example (src/bin/bls_aggregation.rs:76), proving-time body: the value
+    // e(final_A, final_B) (output; the caller connects it to final_Z, :77) and the final-pairing proof over the record (P, Q, Z).
+    // Several pairs give one proof over several records.  Runs on the G2 ctx.
+    ExpCircuitResult<Fq12> pairing_circuit(const std::vector<PairingInput>& pairs) {
+        if (pairs.empty()) throw Error(SIPP_E_BADARG, "pairing_circuit: no pairs");
+        sipp_ctx* c = ctx_[SIPP_G2_EXP];
+        std::vector<PairingIO> io(pairs.size());
+        for (size_t i = 0; i < io.size(); i++) {
+            io[i].in = pairs[i];
+            std::memset(&io[i].out, 0, sizeof(Fq12));
+        }
+        int rc = sipp_exp_outputs(c, SIPP_PAIRING, reinterpret_cast<uint32_t*>(io.data()), io.size());
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_exp_outputs(PAIRING): ") + sipp_last_error(c));
+        ExpCircuitResult<Fq12> r;
+        const size_t cap = sipp_proof_size(c, SIPP_PAIRING, io.size());
+        r.flat.assign(cap, 0);
+        size_t len = 0;
+        rc = sipp_pairing_prove(c, words(io), io.size(), r.flat.data(), cap, &len);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_pairing_prove: ") + sipp_last_error(c));
+        r.flat.resize(len);
+        finish(io, &r);
+        return r;
+    }
+    ExpCircuitResult<Fq12> pairing_circuit(const G1Affine& final_A, const G2Affine& final_B) {
+        return pairing_circuit(std::vector<PairingInput>{PairingInput{final_A, final_B}});
     }
     // messages.iter().map(|u| map_to_g2_without_cofactor_mul(*u).mul_by_cofactor()) (src/bin/bls_aggregation.rs:100-104): the points
     // of G2, and the 2 n g2_exp_circuit inputs whose outputs clear the cofactor (G + [2p - r] Q, then - G)

@@ -4,7 +4,7 @@
  *
  * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED.  The reference asks for this value at src/bin/bls_aggregation.rs:76-77
  * (`pairing_circuit(final_A, final_B)` connected to `final_Z`) and natively at src/prover_native.rs:20 / src/verifier_native.rs:80
- * (`Bn254::pairing`, `plonky2_bn254_pairing::pairing::pairing`); neither ark-ec 0.4 nor plonky2-bn254-pairing @ fe5c3a8 is
+ * (`plonky2_bn254_pairing::pairing::pairing`, recalled to restate arkworks' `Bn254::pairing`); neither ark-ec 0.4 nor plonky2-bn254-pairing @ fe5c3a8 is
  * vendored.  Restated: the optimal ate Miller loop in affine coordinates (the algorithm of oracle/py/bn254.py::miller_loop) and
  * ark-ec's final exponentiation as recalled -- easy part, then the chain y0 .. y16 of Bn::final_exponentiation (Fuentes-Castaneda
  * et al.), whose value is f^(lambda (p^12 - 1)/r), lambda = 2u(6u^2 + 3u + 1).  The second reading is

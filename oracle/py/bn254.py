@@ -233,7 +233,8 @@ def miller_loop(Pt, Q):
 
 
 REDUCED_EXP = (P**12 - 1) // R
-# What `ark_bn254::Bn254::pairing` (reference src/prover_native.rs:20, src/verifier_native.rs:80) returns is NOT the plain reduced
+# What `plonky2_bn254_pairing::pairing::pairing` (reference src/prover_native.rs:8,20, src/verifier_native.rs:8,80; recalled to
+# restate arkworks' `Bn254::pairing`, against which its own tests compare) returns is NOT the plain reduced
 # pairing f^((p^12 - 1)/r): ark-ec 0.4's Bn::final_exponentiation takes the hard part by the chain of Fuentes-Castaneda et al.
 # ("Faster hashing to G2"), whose result is, in its own words, elt^(2z(6z^2 + 3z + 1)(q^4 - q^2 + 1)/r), z = U (RECALLED -- ark-ec is
 # not vendored; tools/pairing_prototype.py runs the recalled chain step by step and finds exactly this power).  The multiplier is

@@ -32,6 +32,9 @@ pub const SIPP_FQ12_EXP: c_int = 2;
 pub const SIPP_MAP_G2: c_int = 3;
 pub const SIPP_G1_EXP_HARDENED: c_int = 4;
 pub const SIPP_G2_EXP_HARDENED: c_int = 5;
+pub const SIPP_PAIRING: c_int = 6;
+/// the version of include/sipp_hip.h these bindings were written against (sipp_ctx_create_checked refuses a library of another version)
+pub const SIPP_ABI_VERSION: u32 = 3;
 pub const SIPP_SALT_SIZE: usize = 4;
 pub const SIPP_FRI_MAX_ROUNDS: usize = 32;
 
@@ -121,6 +124,9 @@ pub struct SippPlonkCircuit {
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
     pub fn sipp_ctx_create(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, workspace_bytes: usize) -> c_int;
+    pub fn sipp_abi_version() -> u32;
+    pub fn sipp_ctx_create_checked(out: *mut *mut SippCtxOpaque, device: c_int, cfg: *const SippStarkConfig, cfg_size: usize, abi_version: u32, workspace_bytes: usize) -> c_int;
+    pub fn sipp_ctx_set_kernel_routes(ctx: *mut SippCtxOpaque, routes: u32) -> c_int;
     pub fn sipp_ctx_destroy(ctx: *mut SippCtxOpaque);
     /// kinds 0 / 1 on this ctx mean the hardened G1 / G2 AIRs (kinds 4 / 5)
     pub fn sipp_ctx_set_hardened(ctx: *mut SippCtxOpaque, on: c_int) -> c_int;
@@ -133,6 +139,7 @@ extern "C" {
     pub fn sipp_fq12_exp_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
     /// kind 3: the STARK behind batch_map_to_g2_circuit (reference src/bin/bls_aggregation.rs:65); records (u, x, y) of 48 u32
     pub fn sipp_map_to_g2_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_pairing_prove(ctx: *mut SippCtxOpaque, ios: *const u32, num_io: usize, proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
     /// messages -> MapToG2 records, the G2ExpStark records of the cofactor clearing (2n, may be null), the cleared points (may be null)
     pub fn sipp_map_to_g2(ctx: *mut SippCtxOpaque, msgs: *const u32, n: usize, map_ios: *mut u32, g2_ios: *mut u32, cleared: *mut u32) -> c_int;
     /// any kind, synchronously (kinds 4 / 5: G1 / G2 exponentiation with the hardened AIR)

@@ -13,6 +13,7 @@ pub enum Kind {
     MapG2 = 3,   // 48 u32 per IO:  u, x, y in Fq2 (batch_map_to_g2_circuit, src/bin/bls_aggregation.rs:65)
     G1ExpHardened = 4, // the records of G1Exp / G2Exp proved with the hardened AIR (canonical x3 + x-inequality witness: no free slope
     G2ExpHardened = 5, // where the accumulator meets the running power)
+    Pairing = 6, // 144 u32 per IO: P (G1), Q (G2), e(P, Q) as 12 MyFq12 coefficients (pairing_circuit, src/bin/bls_aggregation.rs:76)
 }
 
 impl Kind {
@@ -24,6 +25,7 @@ impl Kind {
             Kind::MapG2 => 48,
             Kind::G1ExpHardened => 56,
             Kind::G2ExpHardened => 104,
+            Kind::Pairing => 144,
         }
     }
 }
@@ -40,9 +42,12 @@ impl SippCtx {
     pub fn new(device: i32, kind: Kind, max_num_io: usize) -> Result<Self> {
         let mut raw = std::ptr::null_mut();
         let ws = unsafe { ffi::sipp_workspace_bytes(kind as i32, max_num_io) };
-        let rc = unsafe { ffi::sipp_ctx_create(&mut raw, device, std::ptr::null(), ws) };
+        // the checked form: a library built from another header version (another sipp_stark_config) is refused, not misread
+        let rc = unsafe {
+            ffi::sipp_ctx_create_checked(&mut raw, device, std::ptr::null(), std::mem::size_of::<ffi::SippStarkConfig>(), ffi::SIPP_ABI_VERSION, ws)
+        };
         if rc != 0 {
-            return Err(anyhow!("sipp_ctx_create failed: status {rc}"));
+            return Err(anyhow!("sipp_ctx_create_checked failed: status {rc} (library ABI version {})", unsafe { ffi::sipp_abi_version() }));
         }
         Ok(Self { raw })
     }
@@ -65,6 +70,7 @@ impl SippCtx {
                 Kind::G2Exp => ffi::sipp_g2_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::Fq12Exp => ffi::sipp_fq12_exp_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::MapG2 => ffi::sipp_map_to_g2_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
+                Kind::Pairing => ffi::sipp_pairing_prove(self.raw, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
                 Kind::G1ExpHardened | Kind::G2ExpHardened => ffi::sipp_prove(self.raw, kind as i32, ios.as_ptr(), num_io, buf.as_mut_ptr(), cap, &mut len),
             }
         };

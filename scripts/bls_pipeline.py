@@ -3,7 +3,8 @@
     messages -> ms (map + cofactor)                          sipp_map_to_g2
     a = pks + [-G1], b = ms + [agg]: inner_product == 1      sipp_inner_product           (the aggregate verifies)
     sipp_prove_native / sipp_verify_native                   native chain -> obligation lists
-    five STARK proofs, concurrently on five ctxs:            MapToG2, the cofactor G2ExpStark (254 obligations), G1 / G2 / Fq12 of SIPP
+    six STARK proofs, concurrently on six ctxs:              MapToG2, the cofactor G2ExpStark (254 obligations), G1 / G2 / Fq12 of SIPP,
+                                                             the final pairing pairing_circuit(final_A, final_B) == final_Z (:76-77)
 
 Keys and signatures are made on the host with Python big integers (the signers' side, not timed).  usage: bls_pipeline.py [n=128] [reps=3]
 (by hand, on a GPU box; the proofs are checked by the oracle's verifier when SIPP_BLS_VERIFY=1)."""
@@ -22,10 +23,10 @@ pks = [bn.g1_mul(bn.G1, sk) for sk in sks]
 msgs = [(rnd.randrange(bn.P), rnd.randrange(bn.P)) for _ in range(n - 1)]
 words = np.array([bn.fq_to_u32(u[0]) + bn.fq_to_u32(u[1]) for u in msgs], dtype=np.uint32)
 nio = (n - 1, n - 1, 2 * (n.bit_length() - 1))
-kinds = (3, 1, 0, 1, 2)            # MapToG2, cofactor (G2), then the SIPP instance's G1 / G2 / Fq12
-sizes = (n - 1, 2 * (n - 1)) + nio
+kinds = (3, 1, 0, 1, 2, 6)         # MapToG2, cofactor (G2), the SIPP instance's G1 / G2 / Fq12, the final pairing
+sizes = (n - 1, 2 * (n - 1)) + nio + (1,)
 ctxs = [sipp_amd.Ctx(workspace_bytes=max(1 << 30, L.sipp_workspace_bytes(k, m))) for k, m in zip(kinds, sizes)]
-for c, lvl in zip(ctxs, (1, 0, -1, 0, 1)):
+for c, lvl in zip(ctxs, (1, 0, -1, 0, 1, 1)):
     c._ck(L.sipp_ctx_set_stream_priority(c.h, lvl), "prio")
 main = ctxs[3]                      # the SIPP G2 ctx also runs the native steps
 t0 = time.perf_counter()
@@ -47,8 +48,9 @@ def run():
     ctxs[0].prove_async(3, recs); ctxs[1].prove_async(1, cof)
     proof = main.prove_native(A, B)
     okv, st, ios = main.verify_native(A, B, proof);                  t.append(time.perf_counter())
-    for c, k, a in zip(ctxs[2:], kinds[2:], ios):
+    for c, k, a in zip(ctxs[2:5], kinds[2:5], ios):
         c.prove_async(k, a)
+    ctxs[5].prove_async(6, np.ascontiguousarray(st[-144:].reshape(1, 144)))      # (final_A, final_B, final_Z) of the statement
     pfs = [c.wait() for c in ctxs];                                  t.append(time.perf_counter())
     return ok and okv, pfs, [1e3 * (b - a) for a, b in zip(t, t[1:])], 1e3 * (t[-1] - t[0])
 

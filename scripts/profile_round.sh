@@ -19,10 +19,19 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -o
 # so these are the figures of every kernel ALONE on the chip.
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_v" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_v.log"
 # the same counters over the instruction-form micro-benchmark: what the counters MEAN (a stream of v_add_u32 pairs: half a quad-cycle
-# per instruction; carry / 64-bit / multiply forms: one quad-cycle each) -- the calibration bench.py's `valu` object rests on
-"$R/scripts/ubench/bin/enc_rates" > "$OUT/enc_rates.txt" 2> "$OUT/enc_rates.log"
-"$R/scripts/ubench/bin/canon_rates" > "$OUT/canon_rates.txt" 2>> "$OUT/enc_rates.log"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_enc" -o run -- "$R/scripts/ubench/bin/enc_rates" > "$OUT/pmc_enc.txt" 2> "$OUT/pmc_enc.log"
+# per instruction; carry / 64-bit / multiply forms: one quad-cycle each) -- the calibration bench.py's `valu` object rests on.
+# The binaries are git-ignored: built HERE, and every calibration step must succeed -- an empty enc_rates.txt next to a fresh
+# source_sha256.txt would stamp counters as current whose calibration is missing (scripts/summarize_profile.py refuses that too).
+mkdir -p "$R/scripts/ubench/bin"
+for b in enc_rates canon_rates; do
+    if [ ! -x "$R/scripts/ubench/bin/$b" ] || [ "$R/scripts/ubench/$b.hip" -nt "$R/scripts/ubench/bin/$b" ]; then
+        /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I "$R/sipp_amd/csrc" -o "$R/scripts/ubench/bin/$b" "$R/scripts/ubench/$b.hip" || { echo "profile_round: cannot build scripts/ubench/$b" >&2; exit 1; }
+    fi
+done
+"$R/scripts/ubench/bin/enc_rates" > "$OUT/enc_rates.txt" 2> "$OUT/enc_rates.log" || { echo "profile_round: enc_rates failed" >&2; exit 1; }
+"$R/scripts/ubench/bin/canon_rates" > "$OUT/canon_rates.txt" 2>> "$OUT/enc_rates.log" || { echo "profile_round: canon_rates failed" >&2; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_enc" -o run -- "$R/scripts/ubench/bin/enc_rates" > "$OUT/pmc_enc.txt" 2> "$OUT/pmc_enc.log" || { echo "profile_round: the counter pass over enc_rates failed" >&2; exit 1; }
+[ -s "$OUT/enc_rates.txt" ] || { echo "profile_round: empty calibration output" >&2; exit 1; }
 # which code the counters belong to (bench.py compares it with the tree it runs from)
 python3 "$R/sipp_amd/build.py" hash > "$OUT/source_sha256.txt"
 # concurrency timeline of the same command (kernel trace only)

@@ -110,8 +110,12 @@ try:
     shutil.copy("%s/enc_rates.txt" % src, dst + "_enc_rates.txt")
     with open(dst + "_enc_rates.txt", "a") as fh:
         fh.write("\n# scripts/ubench/bin/canon_rates\n" + open("%s/canon_rates.txt" % src).read())
+    if not calib or not forms:
+        raise RuntimeError("empty calibration (enc_rates.txt / pmc_enc without usable rows)")
 except Exception as ex:            # noqa: BLE001
+    # no calibrated fields without a calibration: bench.py's `peak_calibrated` figures rest on these rows
     print("no enc_rates calibration:", ex)
+    calib = None
 out = {
     # the AIR variant of the profiled instance (bench.py uses these counters only for a line of the same kinds)
     "kinds": line["config"]["kinds"],

@@ -82,6 +82,9 @@ SIGNATURES = {
     "sipp_default_config": (None, [C.POINTER(StarkConfig)]),
     "sipp_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(StarkConfig), C.c_size_t]),
     "sipp_ctx_destroy": (None, [vp]),
+    "sipp_abi_version": (C.c_uint32, []),
+    "sipp_ctx_create_checked": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(StarkConfig), C.c_size_t, C.c_uint32, C.c_size_t]),
+    "sipp_ctx_set_kernel_routes": (C.c_int, [vp, C.c_uint32]),
     "sipp_ctx_set_stream_priority": (C.c_int, [vp, C.c_int]),
     "sipp_last_error": (C.c_char_p, [vp]),
     "sipp_sync": (C.c_int, [vp]),

@@ -117,6 +117,27 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     delete ctx;
 }
 
+uint32_t sipp_abi_version(void) { return SIPP_ABI_VERSION; }
+
+int sipp_ctx_create_checked(sipp_ctx** out, int device, const sipp_stark_config* cfg, size_t cfg_size, uint32_t abi_version,
+                            size_t workspace_bytes) {
+    if (out) *out = nullptr;
+    // a caller built against another header (a shorter sipp_stark_config would be read past its end) is refused before anything is read
+    if (abi_version != SIPP_ABI_VERSION || (cfg && cfg_size != sizeof(sipp_stark_config))) return SIPP_E_BADARG;
+    return sipp_ctx_create(out, device, cfg, workspace_bytes);
+}
+
+int sipp_ctx_set_kernel_routes(sipp_ctx* ctx, uint32_t routes) {
+    if (!ctx || (routes & ~(uint32_t)(SIPP_ROUTE_OPENINGS_UNGROUPED | SIPP_ROUTE_LDE_COLUMN_WIDE))) return SIPP_E_BADARG;
+    std::unique_lock<std::mutex> lk(ctx->async.mu);
+    if (ctx->async.has_job) {
+        lk.unlock();
+        return sipp_fail(ctx, SIPP_E_BADARG, "set_kernel_routes: a proof is in flight on this ctx");
+    }
+    ctx->kernel_routes = routes;
+    return SIPP_OK;
+}
+
 int sipp_ctx_set_hardened(sipp_ctx* ctx, int on) {
     if (!ctx) return SIPP_E_BADARG;
     std::unique_lock<std::mutex> lk(ctx->async.mu);

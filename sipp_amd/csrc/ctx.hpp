@@ -94,6 +94,7 @@ struct sipp_ctx {
     bool outputs_only = false;
     // sipp_ctx_set_hardened: kinds 0 / 1 on this ctx mean the hardened G1 / G2 AIRs (kinds 4 / 5)
     bool hardened = false;
+    uint32_t kernel_routes = 0;     // sipp_ctx_set_kernel_routes: SIPP_ROUTE_* bits (fallback kernels kept under test)
 
     // sipp_prove_async / sipp_wait: one worker thread per ctx, started on first use, one job at a time
     struct Async {

@@ -681,26 +681,38 @@ int lde_column(sipp_ctx* ctx, const uint64_t* d_in, size_t in_stride, uint64_t* 
 // lde_column_kernel (round 5): that kernel holds the whole column in LDS -- ONE 1024-lane block per CU, a block-wide barrier per stage,
 // separate twiddle passes over the tile -- and ran at half the tree sweeps' butterfly rate: 2.31 ms of transforms per n = 128 instance
 // against 1.52 ms in three tree sweeps (gather | middle | contiguous), although those move 9 N words over HBM instead of 4 N.
-// 2^10 .. 2^12 rows stay here (the fused tree needs a strided top sweep: 2^13).  SIPP_LDE_COLUMN_MAX=14 restores the old routing.
-static uint32_t lde_column_max() {
-    static const uint32_t v = [] { const char* e = getenv("SIPP_LDE_COLUMN_MAX"); return e ? (uint32_t)atoi(e) : 12u; }();
-    return v;
+// 2^10 .. 2^12 rows stay here (the fused tree needs a strided top sweep: 2^13).  sipp_ctx_set_kernel_routes(ctx,
+// SIPP_ROUTE_LDE_COLUMN_WIDE) restores the old routing (lde_column_kernel up to 2^14 rows): the fallback stays tested
+// (tests/test_gpu_generic.py).
+static uint32_t lde_column_max(const sipp_ctx* ctx) { return (ctx->kernel_routes & SIPP_ROUTE_LDE_COLUMN_WIDE) ? 14u : 12u; }
+// the tree sweeps move 16 bytes per lane (LDS-DMA tiles, ulonglong2 stores): every base pointer must be 16-byte aligned (column
+// strides are multiples of 2^13 words there).  An 8-byte-aligned view (a tensor slice at an odd u64 offset) is refused, not
+// left to the hardware's unaligned-access mode.
+static bool tree_aligned(const void* a, const void* b, const void* c) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15u) == 0;
+}
+static int tree_misaligned(sipp_ctx* ctx) {
+    return sipp_fail(ctx, SIPP_E_BADARG, "transform: device buffers of columns of 2^13 rows and more must be 16-byte aligned");
 }
 int sipp_lde_from_values(sipp_ctx* ctx, const uint64_t* d_values, uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n,
                          uint32_t rate_bits) {
-    if (log_n > lde_column_max() && log_n >= 13 && log_n <= 14 && d_values != d_coeffs)
-        return sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
+    if (log_n > lde_column_max(ctx) && log_n >= 13 && log_n <= 14 && d_values != d_coeffs)
+        return tree_aligned(d_values, d_coeffs, d_lde) ? sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits)
+                                                      : tree_misaligned(ctx);
     if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_values, (size_t)1 << log_n, d_coeffs, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, false);
     if (sipp_tree_ntt_enabled(log_n) && d_values != d_coeffs)
-        return sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits);
+        return tree_aligned(d_values, d_coeffs, d_lde) ? sipp_tree_lde_from_values(ctx, d_values, d_coeffs, d_lde, ncols, log_n, rate_bits)
+                                                      : tree_misaligned(ctx);
     return SIPP_E_UNSUPPORTED;
 }
 int sipp_lde_from_coeffs(sipp_ctx* ctx, const uint64_t* d_coeffs, uint64_t* d_lde, size_t ncols, uint32_t log_n, uint32_t rate_bits) {
-    if (log_n > lde_column_max() && log_n >= 13 && log_n <= 14) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+    if (log_n > lde_column_max(ctx) && log_n >= 13 && log_n <= 14)
+        return tree_aligned(d_coeffs, d_lde, nullptr) ? sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits) : tree_misaligned(ctx);
     if (log_n >= 10 && log_n <= 14 && ncols <= 0x7fffffffu)
         return lde_column(ctx, d_coeffs, (size_t)1 << log_n, nullptr, d_lde, (size_t)1 << (log_n + rate_bits), ncols, log_n, rate_bits, true);
-    if (sipp_tree_ntt_enabled(log_n)) return sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits);
+    if (sipp_tree_ntt_enabled(log_n))
+        return tree_aligned(d_coeffs, d_lde, nullptr) ? sipp_tree_lde_from_coeffs(ctx, d_coeffs, d_lde, ncols, log_n, rate_bits) : tree_misaligned(ctx);
     return SIPP_E_UNSUPPORTED;
 }
 

@@ -8,7 +8,8 @@
 // Fq2 coefficients in Montgomery form (fq.hpp), resident in LDS.  One workgroup then multiplies
 // the n Miller values (strided partial products + a tree) and one wave applies the final exponentiation: easy part
 // (p^6 - 1)(p^2 + 1), hard part by the chain of ark-ec 0.4's Bn::final_exponentiation (Fuentes-Castaneda et al.; three powers by
-// u), as recalled: what `Bn254::pairing` returns at reference src/prover_native.rs:20 is f^(lambda (p^12 - 1)/r) with
+// u), as recalled: what `plonky2_bn254_pairing::pairing::pairing` (reference src/prover_native.rs:8,20; a restatement of arkworks'
+// Bn254::pairing) returns is f^(lambda (p^12 - 1)/r) with
 // lambda = 2u(6u^2 + 3u + 1), NOT the plain reduced pairing (round 6).  Output: the 12 coefficients of the reference's MyFq12 form Fq[w]/(w^12 - 18 w^6 + 82)
 // (c_i = a_i - 9 b_i, c_{i+6} = b_i for the Fq2 coefficient a_i + b_i u of w^i), 8 x u32 limbs each.
 // The field routines are deliberately NOT inlined (one copy each, operands through pointers) to keep the code small.

@@ -1526,7 +1526,7 @@ int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uin
         a.ncols[i] = ncols[i];
     }
     a.n = n; a.t0 = d_t0; a.t1 = d_t1; a.out = d_out;
-    static const int grouped = [] { const char* e = getenv("SIPP_OPENINGS_GROUPED"); return e ? atoi(e) : 1; }();
+    const bool grouped = !(ctx->kernel_routes & SIPP_ROUTE_OPENINGS_UNGROUPED);   // the fallback route stays tested (test_gpu_stark.py)
     if (!grouped || n < 1024) {
         hipLaunchKernelGGL(openings3_kernel, dim3(total), dim3(256), 0, ctx->stream, a);
         SIPP_CHECK_HIP(ctx, hipGetLastError());

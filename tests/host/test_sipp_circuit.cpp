@@ -180,6 +180,19 @@ static int prove(const char* ios_path, const char* out_prefix) {
             CHECK(e.status() == SIPP_E_WITNESS);
         }
         printf("native chain ok: %zu pairs, %zu proof messages\n", A.size(), sipp_proof.size());
+        // the BLS example's last step (src/bin/bls_aggregation.rs:76-77): z = pairing_circuit(final_A, final_B), connected to final_Z
+        const auto pr = prover.pairing_circuit(v.statement.final_A, v.statement.final_B);
+        CHECK(pr.outputs.size() == 1 && std::memcmp(&pr.outputs[0], &v.statement.final_Z, sizeof(sipp::Fq12)) == 0);
+        orc_config pcfg;
+        orc_default_config(&pcfg);
+        CHECK(orc_stark_verify(pr.flat.data(), pr.flat.size(), &pcfg) == 0);
+        CHECK(pr.proof.kind == (uint32_t)SIPP_PAIRING && pr.proof.to_flat() == pr.flat);
+        // the public inputs are the record (final_A, final_B, final_Z), padded by a copy
+        const uint32_t* fa = reinterpret_cast<const uint32_t*>(&v.statement.final_A);
+        for (size_t i = 0; i < 16; i++) CHECK(pr.proof.public_inputs[i] == fa[i]);
+        const uint32_t* fz = reinterpret_cast<const uint32_t*>(&v.statement.final_Z);
+        for (size_t i = 0; i < 96; i++) CHECK(pr.proof.public_inputs[48 + i] == fz[i]);
+        printf("final pairing ok: proof of %zu words verified\n", pr.flat.size());
     }
 
     // the three calls of verifier_circuit.rs:133-135

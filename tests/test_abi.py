@@ -27,6 +27,24 @@ def test_binding_covers_header():
     assert sorted(_lib.SIGNATURES) == declared_symbols()
 
 
+def test_abi_version_and_checked_create():
+    """a caller built against another header is refused before its (shorter) sipp_stark_config is read; the Rust shim's
+    constant follows the header's"""
+    import ctypes as C
+    L = sipp_amd.lib()
+    hdr = open(os.path.join(ROOT, "include", "sipp_hip.h")).read()
+    ver = int(re.search(r"#define SIPP_ABI_VERSION (\d+)u", hdr).group(1))
+    assert L.sipp_abi_version() == ver
+    ffi = open(os.path.join(ROOT, "rust_shim", "src", "ffi.rs")).read()
+    assert int(re.search(r"pub const SIPP_ABI_VERSION: u32 = (\d+);", ffi).group(1)) == ver
+    assert "sipp_ctx_create_checked" in open(os.path.join(ROOT, "rust_shim", "src", "lib.rs")).read()
+    cfg = sipp_amd.default_config()
+    h = C.c_void_p(1)
+    assert L.sipp_ctx_create_checked(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg), ver + 1, 1 << 20) == -1 and not h.value   # SIPP_E_BADARG
+    h = C.c_void_p(1)
+    assert L.sipp_ctx_create_checked(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg) - 8, ver, 1 << 20) == -1 and not h.value  # the round-4 struct
+
+
 def test_default_config_is_standard_fast_config():
     cfg = sipp_amd.default_config()
     assert (cfg.rate_bits, cfg.cap_height, cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries,

@@ -9,8 +9,9 @@ what `verify_bls_aggregation` (:40-85) delegates to STARKs):
                     ->  pairing(final_A, final_B) == final_Z           sipp_inner_product        (:120)
                     ->  batch_map_to_g2_circuit                        sipp_map_to_g2_prove + the cofactor G2ExpStark proof  (:65)
                     ->  sipp_verifier_circuit's three STARKs           sipp_instance_prove       (:73)
+                    ->  pairing_circuit(final_A, final_B) == final_Z   sipp_pairing_prove        (:76-77)
 
-Every proof goes through the oracle's verifier; the in-circuit final pairing (:76) and the outer plonky2 proof are not built."""
+Every proof goes through the oracle's verifier; the outer plonky2 proof is not built."""
 import os
 import sys
 
@@ -35,7 +36,7 @@ def test_bls_aggregation_n8():
     msgs = [(rnd.randrange(bn.P), rnd.randrange(bn.P)) for _ in range(n - 1)]
     words = np.array([bn.fq_to_u32(u[0]) + bn.fq_to_u32(u[1]) for u in msgs], dtype=np.uint32)
     L = sipp_amd.lib()
-    ctx = sipp_amd.Ctx(workspace_bytes=max(1 << 30, L.sipp_workspace_bytes(1, 2 * (n - 1)), L.sipp_workspace_bytes(3, n - 1)))
+    ctx = sipp_amd.Ctx(workspace_bytes=max(1 << 30, L.sipp_workspace_bytes(1, 2 * (n - 1)), L.sipp_workspace_bytes(3, n - 1), L.sipp_workspace_bytes(6, 1)))
     try:
         map_recs, cof_recs, ms_words = ctx.map_to_g2(words)
         ms = [((bn.u32_to_fq(list(w[0:8])), bn.u32_to_fq(list(w[8:16]))), (bn.u32_to_fq(list(w[16:24])), bn.u32_to_fq(list(w[24:32]))))
@@ -65,9 +66,17 @@ def test_bls_aggregation_n8():
         # the STARKs: messages -> points, the cofactor clearing, and the three of the SIPP verifier
         pf_map = ctx.prove(3, map_recs)
         pf_cof = ctx.prove(1, cof_recs)
+        # the in-circuit final pairing (:76-77) as a STARK obligation: the record (final_A, final_B, final_Z)
+        final_rec = np.concatenate([fa, fb, fz]).reshape(1, 144)
+        pf_pair = ctx.prove(6, final_rec)
+        with pytest.raises(sipp_amd.SippError):          # another final_Z has no proof
+            bad = final_rec.copy()
+            bad[0, 60] ^= 4
+            ctx.prove(6, bad)
     finally:
         ctx.close()
     assert _oracle.stark_verify(pf_map) == 0 and _oracle.stark_verify(pf_cof) == 0
+    assert _oracle.stark_verify(pf_pair) == 0 and (pf_pair[-288:-144] == final_rec[0]).all()
     nio = int(pf_map[3])
     assert (pf_map[-nio * 48:].reshape(nio, 48)[: n - 1] == map_recs).all()
     # the cleared points the SIPP statement's B consists of are the outputs the cofactor proof binds

@@ -78,6 +78,49 @@ def test_full_size_n128_proofs_equal_the_oracle_digests(ctx):
         assert hashlib.sha256(pf.tobytes()).hexdigest() == gold[key]["sha256"], key
 
 
+def test_fallback_kernel_routes_give_the_same_proofs(ios4):
+    """the two non-default kernel routes (sipp_ctx_set_kernel_routes; until round 5 environment switches) stay word for
+    word equal to the oracle: openings by one block per column (traces >= 1024 rows), and columns of 2^13 rows through the
+    whole-column-in-LDS transform (the Fq12 STARK of n = 128: the committed digest)"""
+    import hashlib
+    import json
+    import sipp_amd
+    L = sipp_amd.lib()
+    c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(2, 16))
+    try:
+        assert L.sipp_ctx_set_kernel_routes(c.h, 4) == -1                 # unknown bit
+        assert L.sipp_ctx_set_kernel_routes(c.h, 3) == 0
+        for kind in (0, 2):
+            pf = c.prove(kind, ios4[kind])
+            ref = _oracle.stark_prove(kind, ios4[kind])
+            assert len(pf) == len(ref) and (pf == ref).all(), kind
+        gold = json.load(open("tests/golden/proof_digests_n128.json"))["fq12"]
+        pf = c.prove(2, np.load("tests/golden/sipp_n128_ios.npz")["fq12"])
+        assert int(pf[2]) == 13 and hashlib.sha256(pf.tobytes()).hexdigest() == gold["sha256"]
+    finally:
+        c.close()
+
+
+def test_misaligned_device_buffers_are_refused_by_the_tree_transforms():
+    """the tree sweeps move 16 bytes per lane; an 8-byte-aligned view of a device buffer (a tensor slice at an odd u64
+    offset) is SIPP_E_BADARG through the public building block sipp_lde_batch, not left to the unaligned-access mode"""
+    import torch
+    import sipp_amd
+    L = sipp_amd.lib()
+    c = sipp_amd.Ctx(workspace_bytes=1 << 30)
+    try:
+        n, ncols = 1 << 15, 4
+        buf = torch.zeros(ncols * n + 2, dtype=torch.int64, device="cuda")
+        co = torch.zeros(ncols * n + 2, dtype=torch.int64, device="cuda")
+        lde = torch.zeros(2 * ncols * n + 2, dtype=torch.int64, device="cuda")
+        assert L.sipp_lde_batch(c.h, buf.data_ptr(), co.data_ptr(), lde.data_ptr(), ncols, 15) == 0
+        assert L.sipp_lde_batch(c.h, buf.data_ptr() + 8, co.data_ptr(), lde.data_ptr(), ncols, 15) == -1
+        assert L.sipp_lde_batch(c.h, buf.data_ptr(), co.data_ptr(), lde.data_ptr() + 8, ncols, 15) == -1
+        assert L.sipp_lde_batch(c.h, buf.data_ptr(), co.data_ptr(), lde.data_ptr(), ncols, 15) == 0       # the ctx survives
+    finally:
+        c.close()
+
+
 def test_error_behaviour(ctx, ios4):
     """the C ABI's error contract (include/sipp_hip.h): wrong claimed output -> SIPP_E_WITNESS (the CPU restatement
     refuses the same record), short buffer -> SIPP_E_BUFSZ, bad arguments -> SIPP_E_BADARG; the ctx stays usable."""

@@ -77,6 +77,7 @@ def test_sipp_circuit_cpp(tmp_path):
                          timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "native chain ok" in out.stdout
+    assert "final pairing ok" in out.stdout          # pairing_circuit(final_A, final_B) == final_Z (src/bin/bls_aggregation.rs:76-77)
     ctx = sipp_amd.Ctx(workspace_bytes=8 << 30)
     try:
         for k in range(3):

@@ -50,14 +50,20 @@ def proof_digests_n128():
     path = os.path.join(ROOT, "tests", "golden", "proof_digests_n128.json")
     if os.path.exists(path):
         out = json.load(open(path))        # digests128 <key> ...: only the named proofs are recomputed
-    todo = sys.argv[2:] or ["g1", "g2", "fq12", "g1_hardened", "g2_hardened"]
-    # the hardened G1 / G2 AIRs (API kinds 4 / 5, the variant bench.py's headline proves since round 4) over the same IO records
-    for kind, key, src in ((0, "g1", "g1"), (1, "g2", "g2"), (2, "fq12", "fq12"), (4, "g1_hardened", "g1"), (5, "g2_hardened", "g2")):
+    todo = sys.argv[2:] or ["g1", "g2", "fq12", "g1_hardened", "g2_hardened", "g1_upstream_rules", "g2_upstream_rules", "fq12_upstream_rules"]
+    # the hardened G1 / G2 AIRs (API kinds 4 / 5, the variant bench.py's headline proves since round 4) over the same IO records;
+    # *_upstream_rules: the plain kinds under fs_rule = lookup_rule = pow_rule = 1, the configuration closest to upstream's starky as
+    # recalled -- what tests/test_reference_capture.py compares a cargo capture with
+    up = _oracle.default_config()
+    up.fs_rule, up.lookup_rule, up.pow_rule = 1, 1, 1
+    for kind, key, src, cfg in ((0, "g1", "g1", None), (1, "g2", "g2", None), (2, "fq12", "fq12", None), (4, "g1_hardened", "g1", None),
+                                (5, "g2_hardened", "g2", None), (0, "g1_upstream_rules", "g1", up), (1, "g2_upstream_rules", "g2", up),
+                                (2, "fq12_upstream_rules", "fq12", up)):
         if key not in todo:
             continue
         t = time.time()
-        pf = _oracle.stark_prove(kind, d[src])
-        assert _oracle.stark_verify(pf) == 0
+        pf = _oracle.stark_prove(kind, d[src], cfg)
+        assert _oracle.stark_verify(pf, cfg) == 0
         out[key] = {"kind": kind, "words": int(len(pf)), "log_n": int(pf[2]), "W": int(pf[4]), "P": int(pf[5]),
                     "sha256": hashlib.sha256(pf.tobytes()).hexdigest(), "oracle_seconds": round(time.time() - t, 1)}
         print(key, out[key], flush=True)
