@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters (spec)
 NTT_KERNELS = ("lde_column", "lde_gather", "lde_mid", "ntt_dif_pass", "ntt_dit_pass", "bitrev_cols", "ntt_tree_gather", "ntt_tree_inv",
                "ntt_tree_mid", "ntt_tree_fwd")
-PMC_FILE = "r05_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
+PMC_FILE = "r06_pmc.json"   # rocprofv3 PMC passes of this same command (scripts/profile_round.sh), committed under profiles/
 
 
 def load_ios(n):
@@ -128,10 +128,12 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
     """Secondary leg, outside the timed region of `value`: plonky2's outer prove() at the SHAPE of the
     reference's circuit configuration -- CircuitConfig::standard_ecc_config (reference src/verifier_circuit.rs:213: 136 wires, 80 routed,
     2 challenges, quotient degree factor 8, FRI rate_bits 3 / cap 4 / 28 queries / 16 grinding bits / arity 16) -- on a SYNTHETIC circuit
-    of 2^log_n rows (tools/plonk_synth.py: arithmetic, base-sum, public-input and x^7 gates in two selector groups; the reference's own
-    gate set and witness live in un-vendored crates) through sipp_plonk_prove_gates: wires commitment, Z / partial products, the gate
-    constraints interpreted inside the quotient kernel, quotient commitment, openings, FRI.  constants_sigmas is committed once, outside
-    the timing, as plonky2 does at circuit-build time.  Witness generation (numpy) is not timed: the path starts at the wire values."""
+    of 2^log_n rows (tools/plonk_synth.py, round 6: RECURSION-SHAPED -- Poseidon (the whole permutation, 118 constraints of degree 7),
+    U32 multiply-add with 2-bit limb range checks, random access, reducing, arithmetic, base-sum, constant and public-input gates in
+    three selector groups; the reference's own gate set and witness live in un-vendored crates) through sipp_plonk_prove_gates: wires
+    commitment, Z / partial products, the gate constraints interpreted inside the quotient kernel, quotient commitment, openings, FRI.
+    constants_sigmas is committed once, outside the timing, as plonky2 does at circuit-build time.  Witness generation stays on the host
+    (numpy, this leg's own generator): its time is part of the object's headline (`witness_generation_s`, `end_to_end_s_per_proof`)."""
     import ctypes as C
     import torch
     import sipp_amd
@@ -194,10 +196,14 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         return {"what": "plonky2 prove() below witness generation on a synthetic circuit with gates as data (sipp_plonk_prove_gates)",
                 "shape": {"degree_bits": log_n, "num_wires": W, "num_routed_wires": R, "num_constants": K, "num_challenges": CH, "quotient_degree_factor": D,
                           "rate_bits": rate_bits, "cap_height": cap_h, "num_queries": nq, "pow_bits": pow_bits, "arity": 16,
-                          "gates": ps.GATE_NAMES, "num_gate_constraints": circ["num_gate_constraints"], "program_words": int(len(circ["programs"]))},
+                          "gates": circ["gate_names"], "num_gate_constraints": circ["num_gate_constraints"], "program_words": int(len(circ["programs"])),
+                          "constraints_per_gate": [int(g[5]) for g in circ["gates"]]},
                 "config_ref": "CircuitConfig::standard_ecc_config (reference src/verifier_circuit.rs:213); degree of the reference's circuit unknown "
                               "(built by un-vendored crates): 2^%d rows here" % log_n,
-                "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified, "witness_generation_s_not_timed": t_wit,
+                "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified,
+                # HEADLINE, next to ms_per_proof: the host side of the same proof.  The GPU path starts at the wire values; producing them
+                # (this leg's numpy generator, one core) costs far more than proving them -- what a deployment would have to move next
+                "witness_generation_s": t_wit, "end_to_end_s_per_proof": t_wit + ms * 1e-3,
                 "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
                 "roofline": {"transforms": {"bound": "hbm", "kernels": sorted(ntt_names), "algorithmic_bytes": ntt_bytes, "ms": ntt_ms,
                                             "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -206,9 +212,40 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                                               "perms_per_s": perms / (leaf_ms * 1e-3) if leaf_ms else None,
                                               "algorithmic_bytes": leaf_bytes, "achieved": leaf_bytes / (leaf_ms * 1e-3) / 1e9 if leaf_ms else None,
                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": leaf_bytes / (leaf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if leaf_ms else None},
-                             "quotient_with_gates_ms": rep.get("plonk_quotient")}}
+                             "quotient_with_gates_ms": rep.get("plonk_quotient"),
+                             "plonk_quotient": plonk_quotient_roofline(circ, n, W, K, R, CH, D, zs_cols, rep.get("plonk_quotient"))}}
     finally:
         ctx.close()
+
+
+def plonk_quotient_roofline(circ, n, W, K, R, CH, D, zs_cols, ms):
+    """the outer prover's quotient kernel (permutation terms + every gate's program at every point of the blowup-8 coset, one lane per
+    point) against both bounds: HBM (each LDE cell of constants_sigmas, wires, Z / partial products read once, the quotient values
+    written) and VALU (field products the programs ask for: per monomial its factors and a non-unit coefficient, per constraint the
+    filter and the alpha fold of every challenge; ~26 wave instructions per product at one instruction per 4 cycles)"""
+    if not ms:
+        return None
+    prog = [int(x) for x in circ["programs"]]
+    products = 0
+    for (_si, _row, lo, hi, off, nc) in circ["gates"]:
+        w = off
+        products += (hi - lo)                                # the gate's filter
+        for _ in range(nc):
+            nm = prog[w]
+            w += 1
+            for _m in range(nm):
+                coef, nf = prog[w], prog[w + 1]
+                w += 2 + 2 * nf
+                products += max(0, nf - 1) + (1 if abs(coef) != 1 and nf else 0)
+            products += 1 + CH                               # filter x constraint, one alpha fold per challenge
+    m = 8 * n
+    bytes_alg = 8.0 * m * (K + R + W + zs_cols) + 8.0 * m * CH
+    peak_products = 1024 * 64 * 2.2e9 / (4 * 26)             # lanes x clock / (cycles per instruction x instructions per product)
+    ach = products * m / (ms * 1e-3)
+    return {"bound": "valu", "ms": ms, "gate_products_per_point": products, "points": m, "achieved_products_per_s": ach,
+            "peak_products_per_s_est": peak_products, "frac_valu_est": ach / peak_products,
+            "hbm": {"algorithmic_bytes": bytes_alg, "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
 def air_revision():
@@ -218,7 +255,7 @@ def air_revision():
     return "data/air_tables.h sha256 %s (permuted lookups with independent (beta, gamma), statement-bound Fiat-Shamir)" % h
 
 
-def ntt_roofline(shapes, kernel_ms_serial):
+def ntt_roofline(shapes, kernel_ms_serial, pmc=None):
     """second roofline object, for the NTT / LDE kernels (the HBM-class kernels north_star names), from the SERIAL kernel
     times of this run.  Algorithmic bytes: SURVEY section 8(d) -- per committed column 8 N read + 8 N coefficients +
     16 N LDE written (iNTT 2 + LDE 3 minus the intermediate the fused kernels never write = 32 N B per column of W and P; the
@@ -231,10 +268,29 @@ def ntt_roofline(shapes, kernel_ms_serial):
     if ms <= 0:
         return None
     ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernels": list(names), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_step": alg, "serial_ms_per_step": ms,
-            "note": "VALU-bound in practice: ~20 Goldilocks products (26 instructions each) + 39 modular add/sub per 32 bytes; "
-                    "see DESIGN.md section 4"}
+    out = {"bound": "hbm", "kernels": list(names), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "algorithmic_bytes_per_step": alg, "serial_ms_per_step": ms,
+           "note": "VALU-bound in practice: ~20 Goldilocks products (26 instructions each) + 39 modular add/sub per 32 bytes; "
+                   "see DESIGN.md section 4"}
+    # every sweep's own bound, from the counter passes of this same command (profiles/PMC_FILE: each kernel ALONE
+    # on the chip): HBM bytes it really moves per launch (2 x FETCH_SIZE + WRITE_SIZE) over its launch time = achieved TB/s against the
+    # 8 TB/s peak, and the share of its SIMD cycles the VALUs were busy -- a sweep near 0.8 busy at 3 - 4 TB/s gains nothing from moving
+    # fewer bytes; only the strided inverse sweep of the long columns is memory-bound (profiles/r06_ab_transforms.txt)
+    if pmc and pmc.get("ntt") and pmc.get("transforms_alone"):
+        per = []
+        for k, al in pmc["transforms_alone"].items():
+            tr = pmc["ntt"]["kernels"].get(k)
+            if not tr or not tr.get("launches") or not al.get("avg_launch_ms"):
+                continue
+            b = (2.0 * tr["FETCH_SIZE_kb_sum"] + tr["WRITE_SIZE_kb_sum"]) * 1024.0 / tr["launches"]
+            per.append({"kernel": k, "ms_per_launch_alone": al["avg_launch_ms"], "traffic_bytes_per_launch": b,
+                        "achieved_tbps": b / (al["avg_launch_ms"] * 1e-3) / 1e12, "frac_of_hbm_peak": b / (al["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "valu_busy_frac": al.get("valu_busy_frac"), "cycles_per_inst": al.get("cycles_per_inst")})
+        out["per_kernel"] = sorted(per, key=lambda e: -e["ms_per_launch_alone"])
+        if pmc["ntt"].get("traffic_bytes_per_instance"):
+            out["traffic_bytes_per_step"] = pmc["ntt"]["traffic_bytes_per_instance"]
+            out["traffic_over_algorithmic"] = pmc["ntt"]["traffic_bytes_per_instance"] / alg
+    return out
 
 
 def launch_ranks(n, argv):
@@ -541,7 +597,7 @@ def main():
             # the same kernels with the three proofs run one after the other (one extra step outside the timed region)
             "kernel_ms_serial": ({k: round(v, 3) for k, v in sorted(kernel_ms_serial.items(), key=lambda kv: -kv[1])}
                                  if kernel_ms_serial else None),
-            "roofline_ntt": ntt_roofline(shapes, kernel_ms_serial),
+            "roofline_ntt": ntt_roofline(shapes, kernel_ms_serial, pmc),
             # committed LDE cells (2N (W + P + Q) per STARK) per second of wall clock: an AIR-independent rate
             "lde_cells_per_s": sum(2.0 * (1 << s[0]) * (s[1] + s[2] + s[3]) for s in shapes) / (ms_per_step * 1e-3),
             # compulsory HBM traffic of a whole STARK, 8 N (12 W + 12 P + 7 Q) bytes, over the step time
@@ -622,6 +678,32 @@ def main():
                                 "entry_points": "sipp_map_to_g2, sipp_map_to_g2_prove"}
         except Exception as e:                  # noqa: BLE001
             out["map_to_g2"] = {"error": repr(e)}
+        # secondary, outside the timed region: the in-circuit FINAL PAIRING of the BLS example (src/bin/bls_aggregation.rs:76-77) as a STARK
+        # obligation: the record (final_A, final_B, final_Z) of THIS instance's statement, one pairing in 512 trace rows (kind 6)
+        try:
+            if os.environ.get("SIPP_BENCH_PAIRING", "1") in ("0", ""):
+                raise RuntimeError("skipped (SIPP_BENCH_PAIRING=0)")
+            st = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % args.n))["statement"]
+            prec = np.ascontiguousarray(st[-144:].reshape(1, 144))
+            pctx = sipp_amd.Ctx(device=local_rank, workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(6, 1))
+            try:
+                pctx.prove(6, prec)
+                pctx.profile(True)
+                pctx.profile_reset()
+                t = time.perf_counter()
+                for _ in range(5):
+                    pproof = pctx.prove(6, prec)
+                t_pp = (time.perf_counter() - t) / 5
+                prep = pctx.profile_report()
+                pctx.profile(False)
+                out["final_pairing"] = {"records": 1, "proof_ms": 1e3 * t_pp, "verified": verify_proofs([pproof]), "proof_words": int(len(pproof)),
+                                        "shape": list(pctx.shape(6, 1)),
+                                        "kernel_ms_per_proof": {k: round(v["ms"] / 5, 3) for k, v in sorted(prep.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                                        "entry_point": "sipp_pairing_prove (pairing_circuit(final_A, final_B) == final_Z as a STARK obligation)"}
+            finally:
+                pctx.close()
+        except Exception as e:                  # noqa: BLE001
+            out["final_pairing"] = {"error": repr(e)}
         # secondary, outside the timed region: the same instance with the OTHER AIR variant of G1 / G2 -- by default the plain kinds 0 / 1
         # (this repository's reading of the recalled upstream AIR, starky-bn254's incomplete chord rows: forgeable for crafted
         # statements; 14 % fewer columns), next to the headline that proves the hardened kinds 4 / 5.  Three

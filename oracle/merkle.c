@@ -26,15 +26,20 @@ int orc_get_max_threads(void) {
 #endif
 }
 
-orc_merkle *orc_merkle_new(const uint64_t *leaves, unsigned log_leaves, size_t leaf_len, unsigned cap_height) {
+/* `own` != 0: the tree takes `leaves` (malloc'ed by the caller) over instead of copying it -- the batches of the large configurations
+ * (n = 1024: 12.5 GB of leaves per oracle) would otherwise hold two copies at their peak */
+static orc_merkle *merkle_build(uint64_t *leaves, int own, unsigned log_leaves, size_t leaf_len, unsigned cap_height) {
     orc_merkle *t = (orc_merkle *)calloc(1, sizeof *t);
     size_t n = (size_t)1 << log_leaves;
     if (cap_height > log_leaves) cap_height = log_leaves;
     t->log_leaves = log_leaves;
     t->cap_height = cap_height;
     t->leaf_len = leaf_len;
-    t->leaves = (uint64_t *)malloc(n * leaf_len * sizeof(uint64_t));
-    memcpy(t->leaves, leaves, n * leaf_len * sizeof(uint64_t));
+    if (own) t->leaves = leaves;
+    else {
+        t->leaves = (uint64_t *)malloc(n * leaf_len * sizeof(uint64_t));
+        memcpy(t->leaves, leaves, n * leaf_len * sizeof(uint64_t));
+    }
     unsigned n_levels = log_leaves - cap_height + 1;
     t->level_off = (size_t *)malloc((n_levels + 1) * sizeof(size_t));
     size_t total = 0;
@@ -52,6 +57,9 @@ orc_merkle *orc_merkle_new(const uint64_t *leaves, unsigned log_leaves, size_t l
     }
     t->cap = t->digests + 4 * t->level_off[n_levels - 1];
     return t;
+}
+orc_merkle *orc_merkle_new(const uint64_t *leaves, unsigned log_leaves, size_t leaf_len, unsigned cap_height) {
+    return merkle_build((uint64_t *)leaves, 0, log_leaves, leaf_len, cap_height);
 }
 
 void orc_merkle_free(orc_merkle *t) {
@@ -102,8 +110,7 @@ orc_batch *orc_batch_from_coeffs(const uint64_t *coeffs, size_t ncols, unsigned 
         }
         free(col);
     }
-    b->tree = orc_merkle_new(leaves, log_m, ncols, cap_height);
-    free(leaves);
+    b->tree = merkle_build(leaves, 1, log_m, ncols, cap_height);
     return b;
 }
 

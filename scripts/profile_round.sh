@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 export SIPP_BENCH_IO_SHARD_N=0   # the profiled command is the n = 128 line alone (no io_sharded leg)
 export SIPP_BENCH_MAP_G2=0       # ... and without the messages -> G2 leg (profiled on its own at the end of this script)
 export SIPP_BENCH_OTHER_AIR=0     # ... and without the other AIR variant's leg
+export SIPP_BENCH_PAIRING=0       # ... and without the final-pairing leg (profiled on its own at the end of this script)
 export SIPP_BENCH_OUTER_PLONK=0   # ... and without the outer-prover leg (profiled on its own at the end of this script)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 > "$OUT/bench_line.json" 2> "$OUT/stats.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_f" -o run -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --inflight 1 > /dev/null 2> "$OUT/pmc_f.log"
@@ -44,4 +45,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mapg2" -o run -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hardened" -o run -- python3 "$R/scripts/perf_hardened.py" > "$OUT/hardened.txt" 2> "$OUT/hardened.log"
 # the outer plonky2 prover at the reference's circuit configuration, gates as data (bench.py `outer_plonk`)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/plonk" -o run -- python3 "$R/scripts/perf_plonk.py" 18 5 > "$OUT/plonk.txt" 2> "$OUT/plonk.log"
+# the final-pairing STARK of the BLS example (kind 6, round 6): one record
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pairing" -o run -- python3 "$R/scripts/perf_pairing_stark.py" 1 5 > "$OUT/pairing.txt" 2> "$OUT/pairing.log"
 ls -R "$OUT" | head -40

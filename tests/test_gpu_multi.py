@@ -119,6 +119,14 @@ def test_world8_shards_of_the_large_configs(n, log_n, records, hardened):
             if k < 2:
                 assert int(pf[2]) == log_n and nio == (1 << (log_n - 9))
             assert _oracle.stark_verify(pf) == 0, (rank, k)
+            if n == 4096 and hardened and rank == 3:
+                # BASELINE configs[4]: rank 3's world-8 shard word for word -- the sha256 of the oracle's proof of the same slice
+                # (tools/gen_golden.py digests_large), not only a verifier pass
+                import hashlib
+                import json
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_digests_large.json")))
+                g = gold["n4096_world8_rank3." + ("g1_hardened", "g2_hardened", "fq12")[k]]
+                assert g["records"] == count and len(pf) == g["words"] and hashlib.sha256(pf.tobytes()).hexdigest() == g["sha256"], (rank, k)
             pis = pf[-nio * mine[k].shape[1]:].reshape(nio, mine[k].shape[1])
             assert (pis[:count] == mine[k]).all() and (pis[count:] == mine[k][-1]).all(), (rank, k)
             if rank == 3:

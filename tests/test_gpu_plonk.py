@@ -204,7 +204,8 @@ def test_gate_term_argument_errors(ctx):
 def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_routed, rate_bits, cap_h):
     """sipp_plonk_prove_gates ("SIPPPLK3"): the outer flow with the circuit's gates evaluated ON THE DEVICE from the gate set's programs
     (arithmetic, base-sum, public-input and x^7 gates in two selector groups: tools/plonk_synth.py; the middle case has the column counts of
-    CircuitConfig::standard_ecc_config, reference src/verifier_circuit.rs:213) -- constants_sigmas / wires / Z / quotient commitments,
+    CircuitConfig::standard_ecc_config, reference src/verifier_circuit.rs:213, and with them the RECURSION-SHAPED gate set of round 6:
+    Poseidon, U32 multiply-add, random access, reducing, ... -- 118 gate constraints in three selector groups) -- constants_sigmas / wires / Z / quotient commitments,
     transcript, openings and FRI: the flat proof is the oracle's word for word and its verifier accepts it; with the constants_sigmas
     and wires oracles committed beforehand the same words come out; a malformed program is refused before any kernel runs."""
     import sipp_amd
@@ -257,3 +258,9 @@ def test_bench_outer_plonk_leg_runs_and_verifies():
     assert r["shape"]["num_wires"] == 136 and r["shape"]["num_routed_wires"] == 80 and r["shape"]["rate_bits"] == 3
     assert r["roofline"]["transforms"]["algorithmic_bytes"] > 0 and r["roofline"]["leaf_hashing"]["permutations"] == (8 << 12) * (17 + 3 + 2)
     assert "plonk_quotient" in r["kernel_ms_per_proof"]
+    # round 6: a recursion-shaped gate mix (>= 100 gate constraints, the Poseidon gate among them), the host column in the headline,
+    # the quotient kernel against both bounds
+    assert r["shape"]["num_gate_constraints"] >= 100 and "Poseidon" in r["shape"]["gates"] and "U32MulAdd" in r["shape"]["gates"]
+    assert r["witness_generation_s"] > 0 and abs(r["end_to_end_s_per_proof"] - r["witness_generation_s"] - r["ms_per_proof"] * 1e-3) < 1e-9
+    q = r["roofline"]["plonk_quotient"]
+    assert q["bound"] == "valu" and q["gate_products_per_point"] > 5000 and 0 < q["frac_valu_est"] < 1.5 and 0 < q["hbm"]["frac"] < 1

@@ -70,6 +70,36 @@ def proof_digests_n128():
         json.dump(out, open(os.path.join(ROOT, "tests", "golden", "proof_digests_n128.json"), "w"), indent=1)
 
 
+def proof_digests_large():
+    """word-for-word parity at the LARGE configs without running the CPU prover inside the tests -- sha256 of the
+    oracle's proofs for BASELINE configs[2] (n = 1024 on one GPU: hardened G1 / G2, Fq12) and for rank 3's world-8 shard of
+    configs[4] (n = 4096: records [3 n / 8, 4 n / 8) of every list, sipp_io_shard).  Hours of CPU and ~40 GB of memory for the
+    n = 1024 G2 proof: run one key at a time (`digests_large n1024.g2_hardened`)."""
+    import hashlib
+    import json
+    from tests import _oracle
+    path = os.path.join(ROOT, "tests", "golden", "proof_digests_large.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    jobs = {}
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n1024_ios.npz"))
+    for kind, key, src in ((2, "fq12", "fq12"), (4, "g1_hardened", "g1"), (5, "g2_hardened", "g2")):
+        jobs["n1024." + key] = (kind, d[src])
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n4096_ios.npz"))
+    for kind, key, src in ((2, "fq12", "fq12"), (4, "g1_hardened", "g1"), (5, "g2_hardened", "g2")):
+        a = d[src]
+        first, last = a.shape[0] * 3 // 8, a.shape[0] * 4 // 8        # sipp_io_shard(num_io, 8, 3)
+        jobs["n4096_world8_rank3." + key] = (kind, a[first:last])
+    for name in sys.argv[2:] or sorted(jobs):
+        kind, recs = jobs[name]
+        t = time.time()
+        pf = _oracle.stark_prove(kind, np.ascontiguousarray(recs))
+        assert _oracle.stark_verify(pf) == 0
+        out[name] = {"kind": kind, "records": int(recs.shape[0]), "words": int(len(pf)), "log_n": int(pf[2]), "W": int(pf[4]), "P": int(pf[5]),
+                     "sha256": hashlib.sha256(pf.tobytes()).hexdigest(), "oracle_seconds": round(time.time() - t, 1)}
+        print(name, out[name], flush=True)
+        json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+
+
 def mapg2_fixture():
     """SELF-GOLDEN vectors of the messages -> G2 step (HISTORY.md section 7b): 12 messages (seeded, plus u = 0, u in Fp, u = c u and
     the inv0 messages u^2 g(Z) = +-1) with their images under the Python reading of the map (oracle/py/map_to_g2.py), the
@@ -107,6 +137,8 @@ def main():
         return proof_digests()
     if sys.argv[1:2] == ["digests128"]:
         return proof_digests_n128()
+    if sys.argv[1:2] == ["digests_large"]:
+        return proof_digests_large()
     for n in [int(x) for x in sys.argv[1:]]:
         t = time.time()
         A, B = sn.synthetic_inputs(n, SEEDS.get(n, n))
