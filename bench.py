@@ -116,6 +116,16 @@ def all_ranks_true(flag, device):
     return bool(lo > 0.5)
 
 
+def projected_shards(n, hardened, world=8):
+    path = os.path.join(ROOT, "profiles", "r06_io_shard_projection_%s_n%d_%d.json" % ("hardened" if hardened else "plain", n, world))
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {"projection": True, "world": d["world"], "whole_instance_on_one_gpu_ms": d["whole_instance_on_one_gpu_ms"],
+            "slowest_shard_ms": d["slowest_shard_ms"], "projected_speedup": d["projected_speedup"],
+            "arena_bytes_per_rank_max": max(s["arena_bytes"] for s in d["shards_one_at_a_time"]), "source": os.path.basename(path)}
+
+
 def price_vs_world1(lists, world, hardened):
     from sipp_amd import proof_cost
     one = proof_cost.instance_price(lists, 1, hardened)
@@ -752,6 +762,7 @@ def main():
             si = sipp_amd.Instance([a.shape[0] for a in mine], devices=(local_rank,) * 3, priorities=prios, hardened=hardened)
             k_s = 2
             si_single = si.single_ctx
+            arena_bytes = sum(int(c.workspace_bytes) for c in si.distinct_ctxs())
             own = []
             dts, sproofs = dist_util.timed_steps(lambda: si.prove(mine), k_s, 1, sync=lambda: (torch.cuda.synchronize(), si.sync()),
                                                  device=red_device, local_out=own)
@@ -768,6 +779,12 @@ def main():
                                         # True: one ctx / one arena, the three proofs back to back (the three arenas together would
                                         # exceed 90 % of the card's memory, or what is free of it: n = 4096 on one rank)
                                         "single_ctx": si_single, "kinds": kinds,
+                                        # HBM this rank reserved for its shard (the sum of its ctxs' arenas)
+                                        "arena_bytes_per_rank": arena_bytes,
+                                        # what a `world`-GPU run of this instance is PROJECTED to take, from one GPU proving every rank's shard alone
+                                        # (scripts/io_shard_projection.py, committed): no multi-GPU run has been possible on this pool -- every
+                                        # speed-up figure of DESIGN.md section 5 is such a projection
+                                        "projected_world8": projected_shards(n_s, hardened),
                                         "records_of_rank0": [int(a.shape[0]) for a in mine],
                                         # what this sharding costs the verifier side (sipp_amd/proof_cost.py, counted from the proofs'
                                         # shapes): 3 * world proofs instead of 3 for the recursive verifier behind verifier_circuit.rs:133-147

@@ -222,6 +222,7 @@ class Ctx:
         if rc != 0:
             raise SippError(rc, "sipp_ctx_create")
         self.h = h
+        self.workspace_bytes = int(workspace_bytes) if workspace_bytes else 24 << 30      # the arena this ctx reserved (0 = the library's default)
         self.cfg = cfg if cfg is not None else default_config()
 
     def close(self):

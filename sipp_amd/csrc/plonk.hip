@@ -184,6 +184,9 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
 #pragma unroll
             for (uint32_t c = 0; c < MAX_CH; c++) part[c] = 0;
             const int64_t* w = a.prog + ga.prog_offset;
+            int64_t pw_kind = -1, pw_idx = -1;                            // the last pure power evaluated: operand, exponent, value
+            int pw_exp = 0;
+            uint64_t pw_val = 0;
             for (uint32_t j = 0; j < ga.num_constraints; j++) {
                 const int nm = (int)*w++;
                 uint64_t sum = 0;
@@ -195,9 +198,32 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
                         sum = gl::add(sum, gl::from_i64(coef));
                         continue;
                     }
-                    uint64_t t = operand(w[0], w[1]);
-                    w += 2;
-                    for (int q = 1; q < nf; q++, w += 2) t = gl::mul(t, operand(w[0], w[1]));
+                    // a monomial that is a pure POWER of one operand (the S-box terms of a Poseidon gate: w^7, and the binomial
+                    // expansion of (in + rc)^7: w, w^2, .. w^7 one after the other): one load, the power by squaring -- or ONE product
+                    // when the previous monomial was the next lower power of the same operand.  Wave-uniform decisions (program words).
+                    const int64_t k0 = w[0], i0 = w[1];
+                    bool pure = nf > 1;
+                    for (int q = 1; q < nf && pure; q++) pure = w[2 * q] == k0 && w[2 * q + 1] == i0;
+                    uint64_t t;
+                    if (pure) {
+                        const uint64_t x = operand(k0, i0);
+                        if (k0 == pw_kind && i0 == pw_idx && nf == pw_exp + 1) {
+                            t = gl::mul(pw_val, x);
+                        } else {
+                            t = x;
+                            for (int bit = 30 - __builtin_clz((unsigned)nf); bit >= 0; bit--) {
+                                t = gl::mul(t, t);
+                                if ((nf >> bit) & 1) t = gl::mul(t, x);
+                            }
+                        }
+                        pw_kind = k0; pw_idx = i0; pw_exp = nf; pw_val = t;
+                        w += 2 * nf;
+                    } else {
+                        t = operand(k0, i0);
+                        w += 2;
+                        for (int q = 1; q < nf; q++, w += 2) t = gl::mul(t, operand(w[0], w[1]));
+                        if (nf == 1) { pw_kind = k0; pw_idx = i0; pw_exp = 1; pw_val = t; }
+                    }
                     if (coef == 1) sum = gl::add(sum, t);
                     else if (coef == -1) sum = gl::sub(sum, t);
                     else sum = gl::mad(gl::from_i64(coef), t, sum);
