@@ -726,7 +726,8 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ va
 // Primary witness of the final-pairing AIR (API kind 6; tools/air_gen.py::build_pairing, schedule tools/pairing_sched.py): ONE WAVE
 // per record walks the 512 rows of its block -- the statement behind `pairing_circuit(final_A, final_B)` == final_Z of the
 // reference's BLS example (src/bin/bls_aggregation.rs:76-77).  Per row: the G2 unit (an AFFINE tangent / chord step with its line
-// coefficients -- the cells hold the affine slope, so every step takes one Fq2 inversion -- on lane 0), the Fq12 unit (36 lanes per
+// coefficients on lane 0; the 102 slopes come from a projective pass over the point chain and ONE batched inversion in front of the
+// rows), the Fq12 unit (36 lanes per
 // product as in the final exponentiation above; the one inversion on lane 0; Frobenius / conjugation rows on 6 lanes), then all 64
 // lanes write the row's 156 field elements as 16-bit (8-bit) limb cells, and the registers take over what the schedule says.
 // oracle/pairing.c is the CPU reading the tests compare with cell for cell.
@@ -748,6 +749,7 @@ struct PairVals {
 };
 static_assert(sizeof(PairVals) == 156 * sizeof(Fq), "PairVals is walked as an array of Fq");
 // device copy of the schedule tables (data/air_tables.h): [512][6] int8 | gidx [512] int8 | gconj [8] int8 | gconst [6][192] u16
+constexpr int PAIR_STEPS = 102;      // 64 tangent + 36 + 2 chord steps of the schedule
 constexpr int PT_SCHED = 0, PT_GIDX = 3072, PT_GCONJ = 3584, PT_GCONST = 3592, PT_BYTES = 3592 + 6 * 192 * 2;
 
 __device__ __forceinline__ Fq load_words_mont(const uint32_t* w) {
@@ -763,6 +765,7 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     __shared__ PairVals V;
     __shared__ CoopScratch64 sc;
     __shared__ int s_bad;
+    __shared__ Fq2 s_num[PAIR_STEPS], s_den[PAIR_STEPS], s_pre[PAIR_STEPS];     // the steps' slopes (see below): 19.6 KB
     const uint32_t l = threadIdx.x;
     const uint32_t io = blockIdx.x;
     if (io >= num_io) return;
@@ -804,6 +807,88 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     const int8_t* gconj = reinterpret_cast<const int8_t*>(tab + PT_GCONJ);
     const uint16_t* gconst = reinterpret_cast<const uint16_t*>(tab + PT_GCONST);
     Fq* flat = reinterpret_cast<Fq*>(&V);
+    // ---- the 102 affine slopes AHEAD of the rows, with ONE inversion: the point chain in homogeneous coordinates (no inversion per
+    // step; slope of step s = N_s / D_s with N = 3 X^2, D = 2 Y Z for a tangent, N = y_Q Z - Y, D = x_Q Z - X for a chord), then
+    // Montgomery's trick over the D_s.  An inversion per step (binary gcd on one lane, ~90 us) made 10 of the kernel's 18.5 ms.
+    if (l == 0) {
+        const Fq2 qx = V.pts[PV_QX], qy = V.pts[PV_QY];
+        Fq2 q1x, q1y, q2x, q2y;
+        f2_mul(q1x, f2_conj(qx), V.pts[PV_FXC]);
+        f2_mul(q1y, f2_conj(qy), V.pts[PV_FYC]);
+        f2_mul(q2x, f2_conj(q1x), V.pts[PV_FXC]);
+        f2_mul(q2y, f2_conj(q1y), V.pts[PV_FYC]);
+        q2y = f2_neg(q2y);
+        Fq2 X = qx, Y = qy, Z = f2_one();
+        int ns = 0;
+        for (int t = 1; t < 512 && ns < PAIR_STEPS; t++) {
+            const int gop = sched[6 * t + 5];
+            if (gop < 1 || gop > 4) continue;
+            Fq2 N, D, a, b;
+            if (gop == 1) {
+                f2_sqr(a, X);
+                N = fq::add(f2_dbl(a), a);
+                f2_mul(b, Y, Z);
+                D = f2_dbl(b);
+                Fq2 D2, D3, XD2, W, Z3;
+                f2_sqr(D2, D);
+                f2_mul(D3, D2, D);
+                f2_mul(XD2, X, D2);
+                f2_sqr(a, N);
+                f2_mul(a, a, Z);
+                W = fq::sub(a, f2_dbl(XD2));
+                f2_mul(a, N, fq::sub(XD2, W));
+                f2_mul(b, Y, D3);
+                f2_mul(Z3, D3, Z);
+                f2_mul(X, D, W);
+                Y = fq::sub(a, b);
+                Z = Z3;
+            } else {
+                const Fq2 xq = gop == 2 ? qx : gop == 3 ? q1x : q2x, yq = gop == 2 ? qy : gop == 3 ? q1y : q2y;
+                f2_mul(a, yq, Z);
+                N = fq::sub(a, Y);
+                f2_mul(a, xq, Z);
+                D = fq::sub(a, X);
+                Fq2 D2, D3, E, xqE, W, Z3;
+                f2_sqr(D2, D);
+                f2_mul(D3, D2, D);
+                f2_mul(E, D2, Z);
+                f2_mul(xqE, xq, E);
+                f2_sqr(a, N);
+                f2_mul(a, a, Z);
+                f2_mul(b, X, D2);
+                W = fq::sub(fq::sub(a, b), xqE);
+                f2_mul(Z3, D3, Z);
+                f2_mul(a, N, fq::sub(xqE, W));
+                f2_mul(b, yq, Z3);
+                f2_mul(X, D, W);
+                Y = fq::sub(a, b);
+                Z = Z3;
+            }
+            if (fq::is_zero(D)) {          // a degenerate step (Q outside the r-torsion): no slope; keep the batch invertible
+                s_bad = 1;
+                D = f2_one();
+            }
+            s_num[ns] = N;
+            s_den[ns] = D;
+            ns++;
+        }
+        // prefix products, one inversion, slopes in place of the numerators
+        Fq2 acc = f2_one();
+        for (int i = 0; i < ns; i++) {
+            s_pre[i] = acc;
+            f2_mul(acc, acc, s_den[i]);
+        }
+        Fq2 inv;
+        f2_inv(inv, acc);
+        for (int i = ns - 1; i >= 0; i--) {
+            Fq2 di;
+            f2_mul(di, inv, s_pre[i]);                 // 1 / D_i
+            f2_mul(inv, inv, s_den[i]);
+            f2_mul(s_num[i], s_num[i], di);            // the slope of step i
+        }
+    }
+    __syncthreads();
+    int step = 0;
     for (int t = 0; t < 512; t++) {
         const int fop = sched[6 * t], ra = sched[6 * t + 1], rb = sched[6 * t + 2], rd = sched[6 * t + 4], gop = sched[6 * t + 5];
         const int gi = gidx[t];
@@ -831,12 +916,12 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
                     num = fq::sub(qsy, ty);
                     xb = qsx;
                 }
-                if (fq::is_zero(den)) {
+                if (fq::is_zero(den) || step >= PAIR_STEPS) {
                     s_bad = 1;                     // a degenerate step: Q is not a point of order r (or T met +-Q): no affine slope
                 } else {
-                    Fq2 di, t2;
-                    f2_inv(di, den);
-                    f2_mul(S0, num, di);
+                    Fq2 t2;
+                    S0 = s_num[step];              // = num / den, from the chain above (one batched inversion)
+                    (void)num;
                     f2_sqr(S1, S0);
                     S1 = fq::sub(fq::sub(S1, tx), xb);
                     f2_mul(t2, S0, fq::sub(tx, S1));
@@ -851,6 +936,7 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
             V.pts[PV_QSX] = qsx;
             V.pts[PV_QSY] = qsy;
         }
+        if (gop >= 1 && gop <= 4) step++;
         if (l >= 32 && l < 44) {
             const uint32_t e = l - 32;          // Fq element e of the row's constant vector (16-bit limbs in the table)
             const uint16_t* src = gconst + (size_t)gi * 192 + 16 * e;
@@ -976,6 +1062,10 @@ int sipp_pairing_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios,
         return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: table / shape mismatch");
     uint64_t* t = sipp_table_get(ctx, 102, 0, 0);
     if (!t) {
+        int steps = 0;
+        for (int r = 0; r < AIR_PAIRING_ROWS; r++) steps += AIR_PAIRING_SCHED[r][5] >= 1 && AIR_PAIRING_SCHED[r][5] <= 4;
+        if (steps != PAIR_STEPS || AIR_PAIRING_SCHED[0][5] != 5)
+            return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: the schedule's point steps do not match the kernel's slope table");
         std::vector<uint64_t> packed((PT_BYTES + 7) / 8, 0);
         uint8_t* b = reinterpret_cast<uint8_t*>(packed.data());
         memcpy(b + PT_SCHED, AIR_PAIRING_SCHED, 3072);

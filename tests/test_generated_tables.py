@@ -87,3 +87,20 @@ def test_pair_fragment_layout_follows_the_instruction():
             assert by[b] == want, (lane, b)
         seen[(h_out, reg, hh)] = True
     assert used == 48 and len(seen) == 48      # 2 output halves x 12 registers x 2 input halves
+
+
+def test_committed_digest_files_cover_the_baseline_configs():
+    """the sha256 digests the GPU parity tests compare with exist for every configuration they claim: n = 4 and n = 128 (plain, hardened,
+    upstream rules), BASELINE configs[2] (n = 1024) and rank 3's world-8 shard of configs[4] (n = 4096), each with the oracle's shape"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, "tests", "golden", "proof_digests_n128.json")))
+    assert set(g) >= {"g1", "g2", "fq12", "g1_hardened", "g2_hardened", "g1_upstream_rules", "g2_upstream_rules", "fq12_upstream_rules"}
+    big = json.load(open(os.path.join(root, "tests", "golden", "proof_digests_large.json")))
+    for cfg, log_n, recs in (("n1024", 19, 1023), ("n4096_world8_rank3", 18, 512)):
+        for key, kind in (("g1_hardened", 4), ("g2_hardened", 5), ("fq12", 2)):
+            e = big["%s.%s" % (cfg, key)]
+            assert e["kind"] == kind and len(e["sha256"]) == 64
+            if kind != 2:
+                assert e["log_n"] == log_n and e["records"] == recs

@@ -122,8 +122,8 @@ def test_large_products_by_bilinearity(ctx, n):
     """more pairs than one workgroup has lanes (strided partial products + tree): prod_i e([a_i] G1, [b_i] G2) must equal
     e([sum a_i b_i] G1, G2) -- a size-independent property, both sides computed on the device"""
     rng = np.random.default_rng(n)
-    a = [int.from_bytes(rng.bytes(16), "little") + 1 for _ in range(n)]
-    b = [int.from_bytes(rng.bytes(16), "little") + 1 for _ in range(n)]
+    a = [int.from_bytes(rng.bytes(6), "little") + 1 for _ in range(n)]       # 48-bit scalars: the host side (big-int point multiples) is the
+    b = [int.from_bytes(rng.bytes(6), "little") + 1 for _ in range(n)]       # test's time, the property does not depend on their size
     g1, g2 = limbs([bn.g1_mul(bn.G1, x) for x in a], [bn.g2_mul(bn.G2, y) for y in b])
     lhs = ctx.inner_products(g1, g2)[0]
     s = sum(x * y for x, y in zip(a, b)) % bn.R
