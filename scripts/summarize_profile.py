@@ -157,4 +157,21 @@ try:      # the outer-prover leg (scripts/perf_plonk.py under rocprofv3 --kernel
     shutil.copy("%s/plonk.txt" % src, dst + "_plonk.txt")
 except Exception as ex:            # noqa: BLE001
     print("no outer-prover profile:", ex)
+# the side legs of scripts/profile_round.sh: the native chain, messages -> G2, plain against hardened, the final-pairing STARK (round 6)
+for sub, name in (("native", "native_chain_n128"), ("mapg2", "mapg2"), ("hardened", "hardened"), ("pairing", "pairing")):
+    try:
+        shutil.copy("%s/%s/run_kernel_stats.csv" % (src, sub), "%s_%s_kernel_stats.csv" % (dst, name))
+        shutil.copy("%s/%s.txt" % (src, sub), "%s_%s.txt" % (dst, name))
+    except Exception as ex:        # noqa: BLE001
+        print("no %s profile:" % sub, ex)
+try:      # stream concurrency of the last traced step (scripts/timeline.py over the kernel trace of the timeline pass)
+    import subprocess, os
+    tl = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "timeline.py"), "%s/tl/run_kernel_trace.csv" % src],
+                        capture_output=True, text=True, timeout=600)
+    if tl.returncode == 0 and tl.stdout.strip():
+        open(dst + "_timeline.txt", "w").write(tl.stdout)
+    else:
+        print("no timeline:", tl.stderr[-300:])
+except Exception as ex:            # noqa: BLE001
+    print("no timeline:", ex)
 print(json.dumps(out, indent=1)[:3000])
