@@ -27,7 +27,7 @@ def points(seed):
 @pytest.fixture(scope="module")
 def ctx():
     import sipp_amd
-    c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(6, 4))
+    c = sipp_amd.Ctx(workspace_bytes=sipp_amd.lib().sipp_workspace_bytes(6, 16))
     yield c
     c.close()
 
@@ -44,6 +44,29 @@ def test_outputs_are_the_oracles_pairings(ctx, recs3):
     got = ctx.exp_outputs(6, blank)
     assert (got == recs3).all()
     assert (_oracle.pairing(recs3[1, :48]) == recs3[1, 48:]).all()
+
+
+def test_edge_points_and_bilinearity(ctx):
+    """the value kernel on the points the BLS example meets (-G1, small multiples, -G2 = [r - 1] G2) and on random ones, against the C
+    reading; bilinearity e([2] P, [3] Q) = e(P, Q)^6 computed on the device on both sides"""
+    rnd = random.Random(77)
+    ps = [bn.G1, bn.g1_neg(bn.G1), bn.g1_mul(bn.G1, 2), bn.g1_mul(bn.G1, 3), bn.g1_mul(bn.G1, bn.R - 2)] + [bn.g1_mul(bn.G1, rnd.randrange(1, bn.R)) for _ in range(5)]
+    qs = [bn.G2, bn.g2_mul(bn.G2, 2), bn.g2_neg(bn.G2), bn.g2_mul(bn.G2, 5), bn.g2_mul(bn.G2, bn.R - 3)] + [bn.g2_mul(bn.G2, rnd.randrange(1, bn.R)) for _ in range(5)]
+    recs = np.zeros((len(ps), 144), dtype=np.uint32)
+    for i, (a, b) in enumerate(zip(ps, qs)):
+        recs[i, :48] = bn.g1_to_u32(a) + bn.g2_to_u32(b)
+    got = ctx.exp_outputs(6, recs)
+    for i in range(len(ps)):
+        assert (got[i, 48:] == _oracle.pairing(recs[i, :48])).all(), i
+    e = lambda i: [bn.u32_to_fq(list(got[i, 48 + 8 * k: 56 + 8 * k])) for k in range(12)]
+    assert e(1) == bn.f12_inv(e(0))                          # e(-G1, G2) = e(G1, G2)^-1
+    two_three = np.zeros((1, 144), dtype=np.uint32)
+    two_three[0, :48] = bn.g1_to_u32(bn.g1_mul(ps[5], 2)) + bn.g2_to_u32(bn.g2_mul(qs[5], 3))
+    lhs = ctx.exp_outputs(6, two_three)[0, 48:]
+    assert [bn.u32_to_fq(list(lhs[8 * k: 8 * k + 8])) for k in range(12)] == bn.f12_pow(e(5), 6)
+    # and all ten records in ONE proof (sixteen blocks, six of them padding)
+    proof = ctx.prove(6, got)
+    assert int(proof[2]) == 13 and int(proof[3]) == 16 and _oracle.stark_verify(proof) == 0
 
 
 def test_trace_matches_oracle_cell_for_cell(ctx, recs3):
