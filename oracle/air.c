@@ -402,9 +402,9 @@ static size_t ivec(const int64_t *w, const uint64_t *tr, size_t n, size_t row, c
 }
 
 static int fill_gadgets_row(const air_spec_t *a, uint64_t *tr, size_t n, size_t row) {
-    int per[AIR_N_PERIODIC + 64];     /* closed-form selectors, then the AIR's selector columns (value-periodic, small integers) */
+    int per[AIR_N_PERIODIC + 160];    /* closed-form selectors, then the AIR's selector columns (value-periodic, small integers) */
     for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = (int)(row % (size_t)AIR_PERIODIC[k][0]) == AIR_PERIODIC[k][1];
-    if (a->n_vflag > 64) return -21;
+    if (a->n_vflag > 160) return -21;
     for (int k = 0; k < a->n_vflag; k++) per[AIR_N_PERIODIC + k] = (int)air_vper_value(a, k, (int)(row & (((size_t)1 << a->log_rows) - 1)));
     const int64_t *w = a->prog, *end = a->prog + a->prog_len;
     int cpl = a->cells_per_limb;
@@ -529,7 +529,7 @@ orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int
     *err = 0;
     if (num_io == 0 || api_kind < 0 || api_kind > 6) { *err = -1; return NULL; }
     const int kind = orc_record_kind(api_kind);   /* the hardened variants fill the same primary cells */
-    const unsigned log_rows = kind == 3 ? 3 : 9;   /* rows per record: 512 (exponentiations), 8 (MapToG2); = air->log_rows */
+    const unsigned log_rows = orc_kind_log_rows(kind);   /* rows per record: 512 (exponentiations), 8 (MapToG2), 8192 (pairing); = air->log_rows */
     size_t nio = 2; /* at least two IO blocks, at least 1024 rows */
     while (nio < num_io || (nio << log_rows) < 1024) nio <<= 1;
     unsigned log_n = log_rows;
@@ -552,7 +552,7 @@ orc_trace *orc_trace_build(int api_kind, const uint32_t *ios, size_t num_io, int
         memcpy(pi, rec, ppi * sizeof(uint32_t));
         uint32_t outw[96];
         int rc = kind == 2 ? fill_fq12_io(a, t->trace, n, io, rec, outw) : kind == 3 ? fill_map_io(a, t->trace, n, io, rec, outw)
-                 : kind == 6 ? ((g_forge & 1) || orc_pairing_record_ok(rec) ? orc_pairing_run(a, t->trace, n, io * 512, rec, outw) : -1)
+                 : kind == 6 ? ((g_forge & 1) || orc_pairing_record_ok(rec) ? orc_pairing_run(a, t->trace, n, io << 13, rec, outw) : -1)
                              : fill_curve_io(a, t->trace, n, io, rec, outw);
         if (rc == 0 && (g_forge & 2)) memcpy(pi + ppi - out_words, outw, out_words * sizeof(uint32_t));
         else if (rc == 0 && memcmp(outw, rec + ppi - out_words, out_words * sizeof(uint32_t)) != 0) rc = -8; /* claimed output wrong */

@@ -20,6 +20,8 @@ typedef struct {
 const air_spec_t *orc_air_get(int kind, unsigned log_n);   /* API kind 0 .. 6 */
 /* kinds 4 / 5 (hardened G1 / G2) take the records of kinds 0 / 1 */
 static inline int orc_record_kind(int kind) { return (kind == 4 || kind == 5) ? kind - 4 : kind; }
+/* log2 of the trace rows per record: 512 (the exponentiations), 8 (MapToG2), 8192 (the final pairing: one identity per row) */
+static inline unsigned orc_kind_log_rows(int kind) { return kind == 3 ? 3 : kind == 6 ? 13 : 9; }
 int orc_air_api_kind(const air_spec_t *a);
 int orc_air_width(const air_spec_t *a);
 size_t orc_air_num_constraints(const air_spec_t *a);

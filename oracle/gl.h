@@ -31,17 +31,17 @@ typedef unsigned __int128 u128;
 #define GL_TWO_ADIC_ROOT 1753635133440165772ULL /* order 2^32 */
 #define GL_EXT_W 7ULL
 
-static inline uint64_t gl_canon(uint64_t a) { return a >= GL_P ? a - GL_P : a; }
+/* (branch-free: the operands are as good as random, a mispredicted branch costs more than the arithmetic) */
+static inline uint64_t gl_canon(uint64_t a) { return a - (GL_P & (0 - (uint64_t)(a >= GL_P))); }
 
 static inline uint64_t gl_add(uint64_t a, uint64_t b) {
     /* a, b canonical */
     uint64_t s = a + b;
-    if (s < a || s >= GL_P) s -= GL_P;
-    return s;
+    return s - (GL_P & (0 - (uint64_t)((s < a) | (s >= GL_P))));
 }
 
 static inline uint64_t gl_sub(uint64_t a, uint64_t b) {
-    return a >= b ? a - b : a + (GL_P - b);
+    return a - b + (GL_P & (0 - (uint64_t)(a < b)));
 }
 
 static inline uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
@@ -53,10 +53,10 @@ static inline uint64_t gl_reduce128(u128 x) {
     uint64_t hi_hi = hi >> 32;
     uint64_t hi_lo = hi & GL_EPS;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS; /* borrow: + p  == - (2^32 - 1) mod 2^64 */
+    t0 -= GL_EPS & (0 - (uint64_t)(lo < hi_hi)); /* borrow: + p  == - (2^32 - 1) mod 2^64 */
     uint64_t t1 = hi_lo * GL_EPS;
     uint64_t r = t0 + t1;
-    if (r < t0) r += GL_EPS; /* carry: 2^64 == 2^32 - 1 */
+    r += GL_EPS & (0 - (uint64_t)(r < t0)); /* carry: 2^64 == 2^32 - 1 */
     return gl_canon(r);
 }
 

@@ -30,8 +30,6 @@ static fq2 f2_mul_xi(fq2 a) { /* (a0 + a1 u)(9 + u) */
     return r;
 }
 
-static t6 t6_zero(void) { t6 r; for (int i = 0; i < 6; i++) r.c[i] = f2z(); return r; }
-
 static t6 t6_mul(const t6 *a, const t6 *b) {
     fq2 d[11];
     for (int k = 0; k < 11; k++) d[k] = f2z();
@@ -125,7 +123,7 @@ int orc_pairing_record_ok(const uint32_t *rec) {
 }
 
 /* ---- cell writers (the column-major trace of oracle/air.c) ---- */
-static void put_fq(uint64_t *tr, size_t n, int col, size_t row, fq v, int cpl) {
+static void put_fq(uint64_t *tr, size_t n, int col, size_t row, fq v, int cpl) {   /* cpl 0 / 1: one cell per limb; 2: two (lo, hi byte) */
     uint16_t l[16];
     fq_to_limbs16(v, l);
     for (int i = 0; i < 16; i++) {
@@ -133,102 +131,126 @@ static void put_fq(uint64_t *tr, size_t n, int col, size_t row, fq v, int cpl) {
         else { tr[(size_t)(col + 2 * i) * n + row] = l[i] & 0xff; tr[(size_t)(col + 2 * i + 1) * n + row] = l[i] >> 8; }
     }
 }
-static void put_f2(uint64_t *tr, size_t n, int col, size_t row, fq2 v, int cpl) { /* cpl 0: unchecked */
-    put_fq(tr, n, col, row, v.c0, cpl);
-    put_fq(tr, n, col + 16 * (cpl ? cpl : 1), row, v.c1, cpl);
-}
-static void put_t6(uint64_t *tr, size_t n, int col, size_t row, const t6 *v, int cpl) {
-    for (int i = 0; i < 6; i++) put_f2(tr, n, col + 32 * (cpl ? cpl : 1) * i, row, v->c[i], cpl);
-}
 
-enum { L_PX, L_PY, L_QX, L_QY, L_Q1X, L_Q1Y, L_Q2X, L_Q2Y, L_TX, L_TY, L_QSX, L_QSY, L_FXC, L_FYC, L_A, L_B, L_G, L_REG, L_C, L_S0, L_N };
+enum { L_PX, L_PY, L_QX, L_QY, L_Q1X, L_Q1Y, L_Q2X, L_Q2Y, L_TX, L_TY, L_QSX, L_QSY, L_FXC, L_FYC, L_SR, L_GC, L_A, L_B, L_CACC, L_REG, L_RES, L_N };
+/* row types and descriptor fields of tools/pairing_rows.py */
+enum { T_IDLE, T_FMUL, T_FFROB, T_FINVW, T_FINVC, T_FCOPY, T_FCOMMIT, T_GW, T_GSL, T_GX3, T_GY3, T_GL1, T_GL3, T_GFQ };
+enum { F_TYP, F_T, F_RA, F_RB, F_BSEL, F_GC, F_LD, F_SK, F_CHM, F_END };
 
-/* runs the schedule on one record (P: 16 words, Q: 32 words).  tr != NULL: every primary cell of rows [row0, row0 + 512) of the
- * column-major trace (n rows per column) is written.  out_words receives the 96 words of the result.  Returns 0, -1 for a
- * degenerate step / a value without inverse, -20 for tables this code does not understand. */
+static t6 t6_from12(const fq v[12]) { t6 r; for (int i = 0; i < 6; i++) { r.c[i].c0 = v[2 * i]; r.c[i].c1 = v[2 * i + 1]; } return r; }
+static void t6_to12(const t6 *a, fq v[12]) { for (int i = 0; i < 6; i++) { v[2 * i] = a->c[i].c0; v[2 * i + 1] = a->c[i].c1; } }
+
+/* runs the ROW PROGRAM (AIR_PAIRING_ROWPROG: one modular identity per row, 2^13 rows) on one record (P: 16 words, Q: 32 words).
+ * tr != NULL: every primary cell of rows [row0, row0 + 2^13) of the column-major trace (n rows per column) is written.  out_words
+ * receives the 96 words of the result.  Returns 0, -1 for a degenerate step / a value without inverse / a failing check row, -20 for
+ * tables this code does not understand. */
 int orc_pairing_run(const air_spec_t *a, uint64_t *tr, size_t n, size_t row0, const uint32_t *rec, uint32_t *out_words) {
     fq_init();
-    if (AIR_PAIRING_ROWS != 512 || AIR_PAIRING_NREG > 8) return -20;
+    if (AIR_PAIRING_LOG_ROWS != 13 || AIR_PAIRING_NREG > 8 || AIR_PAIRING_NFIELDS < 10) return -20;
     const int cpl = a ? a->cells_per_limb : 1;
     const int32_t *lay = (a && cpl == 2) ? AIR_PAIRING_LAYOUT_U8 : AIR_PAIRING_LAYOUT_U16;
-    if (tr && (!a || a->kind != 6 || a->log_rows != 9 || lay[L_C] != a->checked_base)) return -20;
-    const fq px = fq_from_u32(rec), py = fq_from_u32(rec + 8);
+    if (tr && (!a || a->kind != 6 || a->log_rows != 13 || lay[L_RES] != a->checked_base)) return -20;
+    const fq px = fq_from_u32(rec), py = fq_from_u32(rec + 8), zero = fq_zero();
     const fq2 qx = read2(rec + 16), qy = read2(rec + 32);
-    /* the twist's Frobenius constants xi^((p-1)/3), xi^((p-1)/2) = the w^2 and w^3 entries of the p-power constant vector */
-    const t6 g1c = gconst(2);
+    const t6 g1c = gconst(2);       /* the twist's Frobenius constants = the w^2 and w^3 entries of the p-power constant vector */
     const fq2 frob_x = g1c.c[2], frob_y = g1c.c[3];
-    t6 regs[8];
-    for (int k = 0; k < 8; k++) regs[k] = t6_zero();
-    fq2 tx = f2z(), ty = f2z(), q1x = f2z(), q1y = f2z(), q2x = f2z(), q2y = f2z();
-    const fq2 pxe = {px, fq_zero()}, pye = {py, fq_zero()};
-    for (int t = 0; t < 512; t++) {
-        const int8_t *r = AIR_PAIRING_SCHED[t];
-        const int fop = r[0], ra = r[1], rb = r[2], rd = r[4], gop = r[5];
-        fq2 S[5] = {f2z(), f2z(), f2z(), f2z(), f2z()}, qsx = f2z(), qsy = f2z();
-        if (gop == 5) {
-            S[0] = fq2_mul(f2_conj(qx), frob_x);
-            S[1] = fq2_mul(f2_conj(qy), frob_y);
-            S[2] = fq2_mul(f2_conj(S[0]), frob_x);
-            S[3] = f2_neg(fq2_mul(f2_conj(S[1]), frob_y));
-        } else if (gop != 0) {
-            fq2 num, den, xb;
-            if (gop == 1) {
-                den = fq2_add(ty, ty);
-                num = f2_small(3, fq2_mul(tx, tx));
-                xb = tx;
-            } else {
-                qsx = gop == 2 ? qx : gop == 3 ? q1x : q2x;
-                qsy = gop == 2 ? qy : gop == 3 ? q1y : q2y;
-                den = fq2_sub(qsx, tx);
-                num = fq2_sub(qsy, ty);
-                xb = qsx;
+    fq regs[8][12], cacc[12], S[5][2], inv12[12], prod12[12];
+    for (int k = 0; k < 8; k++) for (int t = 0; t < 12; t++) regs[k][t] = zero;
+    for (int t = 0; t < 12; t++) { cacc[t] = zero; inv12[t] = zero; prod12[t] = zero; }
+    for (int s = 0; s < 5; s++) S[s][0] = S[s][1] = zero;
+    fq2 tx = f2z(), ty = f2z(), q1x = f2z(), q1y = f2z(), q2x = f2z(), q2y = f2z(), lamw = f2z();
+    const fq2 pxe = {px, zero};
+    for (int r = 0; r < AIR_PAIRING_ROWS; r++) {
+        const int8_t *d = AIR_PAIRING_ROWPROG[r];
+        const int typ = d[F_TYP], t = d[F_T], ra = d[F_RA], rb = d[F_RB], bsel = d[F_BSEL], gc = d[F_GC], ld = d[F_LD], sk = d[F_SK], chm = d[F_CHM],
+                  end = d[F_END];
+        fq A[12], B[12], res = zero;
+        for (int i = 0; i < 12; i++) { A[i] = ra >= 0 ? regs[ra][i] : zero; B[i] = zero; }
+        if (rb >= 0) for (int i = 0; i < 12; i++) B[i] = regs[rb][i];
+        else if (bsel == 1) { B[0] = py; B[2] = S[3][0]; B[3] = S[3][1]; B[6] = S[4][0]; B[7] = S[4][1]; }
+        else if (bsel == 2) for (int i = 0; i < 12; i++) B[i] = cacc[i];
+        fq2 qsx = f2z(), qsy = f2z();
+        if (sk == 2) { qsx = chm == 0 ? qx : chm == 1 ? q1x : q2x; qsy = chm == 0 ? qy : chm == 1 ? q1y : q2y; }
+        const fq u = limbs_to_fq(AIR_PAIRING_GC[gc]), v = limbs_to_fq(AIR_PAIRING_GC[gc] + 16);
+        const fq2 lam = {S[0][0], S[0][1]}, x3 = {S[1][0], S[1][1]};
+        if (typ == T_FMUL || typ == T_FINVC) {
+            if (t == 0) { t6 a6 = t6_from12(A), b6 = t6_from12(B), c6 = t6_mul(&a6, &b6); t6_to12(&c6, prod12); }
+            if (typ == T_FMUL) res = prod12[t];
+            else if (!fq_eq(prod12[t], u)) return -1;                 /* A * CACC = 1, component t */
+        } else if (typ == T_FFROB) {
+            res = fq_add(fq_mul(A[2 * (t / 2)], u), fq_mul(A[2 * (t / 2) + 1], v));
+        } else if (typ == T_FINVW) {
+            if (t == 0) { t6 a6 = t6_from12(A), i6; if (t6_inv(&a6, &i6)) return -1; t6_to12(&i6, inv12); }
+            res = inv12[t];
+        } else if (typ == T_FCOPY) {
+            res = B[t];
+        } else if (typ == T_GW) {
+            if (t == 0) {
+                fq2 num, den;
+                if (sk == 1) { den = fq2_add(ty, ty); num = f2_small(3, fq2_mul(tx, tx)); }
+                else { den = fq2_sub(qsx, tx); num = fq2_sub(qsy, ty); }
+                if (fq2_is_zero(den)) return -1;
+                lamw = fq2_mul(num, fq2_inv(den));
             }
-            if (fq2_is_zero(den)) return -1;
-            fq2 lam = fq2_mul(num, fq2_inv(den));
-            S[0] = lam;
-            S[1] = fq2_sub(fq2_sub(fq2_mul(lam, lam), tx), xb);
-            S[2] = fq2_sub(fq2_mul(lam, fq2_sub(tx, S[1])), ty);
-            S[3] = f2_neg(fq2_mul(lam, pxe));
-            S[4] = fq2_sub(fq2_mul(lam, tx), ty);
-        }
-        const int gi = AIR_PAIRING_GIDX[t];
-        const t6 G = gconst(gi);
-        t6 A = ra >= 0 ? regs[ra] : t6_zero(), B = t6_zero(), C = t6_zero();
-        if (fop == 1) {
-            B = regs[rb];
-            C = t6_mul(&A, &B);
-        } else if (fop == 2) {
-            B.c[0] = pye; B.c[1] = S[3]; B.c[3] = S[4];
-            C = t6_mul(&A, &B);
-        } else if (fop == 3) {
-            if (t6_inv(&A, &C)) return -1;
-            B = C;
-        } else if (fop == 4) {
-            for (int i = 0; i < 6; i++) C.c[i] = fq2_mul(AIR_PAIRING_GCONJ[gi] ? f2_conj(A.c[i]) : A.c[i], G.c[i]);
+            res = t ? lamw.c1 : lamw.c0;
+        } else if (typ == T_GSL) {
+            fq2 lhs = sk == 1 ? fq2_sub(f2_small(2, fq2_mul(lam, ty)), f2_small(3, fq2_mul(tx, tx)))
+                              : fq2_sub(fq2_mul(lam, fq2_sub(qsx, tx)), fq2_sub(qsy, ty));
+            if (!fq_is_zero(t ? lhs.c1 : lhs.c0)) return -1;
+        } else if (typ == T_GX3) {
+            fq2 w = fq2_sub(fq2_sub(fq2_mul(lam, lam), tx), sk == 1 ? tx : qsx);
+            res = t ? w.c1 : w.c0;
+        } else if (typ == T_GY3) {
+            fq2 w = fq2_sub(fq2_mul(lam, fq2_sub(tx, x3)), ty);
+            res = t ? w.c1 : w.c0;
+        } else if (typ == T_GL1) {
+            fq2 w = f2_neg(fq2_mul(lam, pxe));
+            res = t ? w.c1 : w.c0;
+        } else if (typ == T_GL3) {
+            fq2 w = fq2_sub(fq2_mul(lam, tx), ty);
+            res = t ? w.c1 : w.c0;
+        } else if (typ == T_GFQ) {
+            const int slot = t >> 1;
+            const fq2 s0 = {S[0][0], S[0][1]}, s1 = {S[1][0], S[1][1]};
+            fq2 w = slot == 0 ? fq2_mul(f2_conj(qx), frob_x) : slot == 1 ? fq2_mul(f2_conj(qy), frob_y)
+                    : slot == 2 ? fq2_mul(f2_conj(s0), frob_x) : f2_neg(fq2_mul(f2_conj(s1), frob_y));
+            res = (t & 1) ? w.c1 : w.c0;
         }
         if (tr) {
-            const size_t row = row0 + (size_t)t;
+            const size_t row = row0 + (size_t)r;
             put_fq(tr, n, lay[L_PX], row, px, 0); put_fq(tr, n, lay[L_PY], row, py, 0);
-            put_f2(tr, n, lay[L_QX], row, qx, 0); put_f2(tr, n, lay[L_QY], row, qy, 0);
-            put_f2(tr, n, lay[L_Q1X], row, q1x, 0); put_f2(tr, n, lay[L_Q1Y], row, q1y, 0);
-            put_f2(tr, n, lay[L_Q2X], row, q2x, 0); put_f2(tr, n, lay[L_Q2Y], row, q2y, 0);
-            put_f2(tr, n, lay[L_TX], row, tx, 0); put_f2(tr, n, lay[L_TY], row, ty, 0);
-            put_f2(tr, n, lay[L_QSX], row, qsx, 0); put_f2(tr, n, lay[L_QSY], row, qsy, 0);
-            put_f2(tr, n, lay[L_FXC], row, frob_x, 0); put_f2(tr, n, lay[L_FYC], row, frob_y, 0);
-            put_t6(tr, n, lay[L_A], row, &A, 0); put_t6(tr, n, lay[L_B], row, &B, 0); put_t6(tr, n, lay[L_G], row, &G, 0);
-            for (int k = 0; k < AIR_PAIRING_NREG; k++) put_t6(tr, n, lay[L_REG] + 192 * k, row, &regs[k], 0);
-            put_t6(tr, n, lay[L_C], row, &C, cpl);
-            for (int sl = 0; sl < 5; sl++) put_f2(tr, n, lay[L_S0] + 32 * cpl * sl, row, S[sl], cpl);
+            const fq2 pts[12] = {qx, qy, q1x, q1y, q2x, q2y, tx, ty, qsx, qsy, frob_x, frob_y};
+            for (int i = 0; i < 12; i++) { put_fq(tr, n, lay[L_QX + i], row, pts[i].c0, 0); put_fq(tr, n, lay[L_QX + i] + 16, row, pts[i].c1, 0); }
+            for (int s = 0; s < 5; s++) { put_fq(tr, n, lay[L_SR] + 32 * s, row, S[s][0], 0); put_fq(tr, n, lay[L_SR] + 32 * s + 16, row, S[s][1], 0); }
+            put_fq(tr, n, lay[L_GC], row, u, 0); put_fq(tr, n, lay[L_GC] + 16, row, v, 0);
+            for (int i = 0; i < 12; i++) {
+                put_fq(tr, n, lay[L_A] + 16 * i, row, A[i], 0); put_fq(tr, n, lay[L_B] + 16 * i, row, B[i], 0);
+                put_fq(tr, n, lay[L_CACC] + 16 * i, row, cacc[i], 0);
+                for (int k = 0; k < AIR_PAIRING_NREG; k++) put_fq(tr, n, lay[L_REG] + 192 * k + 16 * i, row, regs[k][i], 0);
+            }
+            put_fq(tr, n, lay[L_RES], row, res, cpl);
         }
-        if (rd >= 0) regs[rd] = fop == 0 ? G : C;
-        if (gop == 5) { tx = qx; ty = qy; q1x = S[0]; q1y = S[1]; q2x = S[2]; q2y = S[3]; }
-        else if (gop == 1 || gop == 2 || gop == 3) { tx = S[1]; ty = S[2]; }
+        /* end of the row: loads */
+        if (typ == T_FMUL || typ == T_FFROB || typ == T_FINVW || typ == T_FCOPY) cacc[t] = res;
+        else if (typ == T_GW) S[0][t] = res;
+        else if (typ == T_GX3) S[1][t] = res;
+        else if (typ == T_GY3) S[2][t] = res;
+        else if (typ == T_GL1) S[3][t] = res;
+        else if (typ == T_GL3) S[4][t] = res;
+        else if (typ == T_GFQ) S[t >> 1][t & 1] = res;
+        if (typ == T_FCOMMIT && ld >= 0) for (int i = 0; i < 12; i++) regs[ld][i] = cacc[i];
+        if (end == 1) { tx.c0 = S[1][0]; tx.c1 = S[1][1]; ty.c0 = S[2][0]; ty.c1 = S[2][1]; }
+        else if (end == 2) {
+            tx = qx; ty = qy;
+            q1x.c0 = S[0][0]; q1x.c1 = S[0][1]; q1y.c0 = S[1][0]; q1y.c1 = S[1][1];
+            q2x.c0 = S[2][0]; q2x.c1 = S[2][1]; q2y.c0 = S[3][0]; q2y.c1 = S[3][1];
+        }
     }
-    const t6 *res = &regs[AIR_PAIRING_RESULT_REG];
+    const fq *res12 = regs[AIR_PAIRING_RESULT_REG];
     fq nine = fq_from_u64(9);
     for (int i = 0; i < 6; i++) {           /* MyFq12 coefficients: c_i = a_i - 9 b_i, c_{i+6} = b_i */
-        fq_to_u32(fq_sub(res->c[i].c0, fq_mul(nine, res->c[i].c1)), out_words + 8 * i);
-        fq_to_u32(res->c[i].c1, out_words + 8 * (i + 6));
+        fq_to_u32(fq_sub(res12[2 * i], fq_mul(nine, res12[2 * i + 1])), out_words + 8 * i);
+        fq_to_u32(res12[2 * i + 1], out_words + 8 * (i + 6));
     }
     return 0;
 }

@@ -9,15 +9,30 @@
 #include "poseidon_constants.h"
 #include <string.h>
 
+/* the MDS entries are below 2^6: the two 32-bit halves of every state word are accumulated in plain 64-bit words (twelve
+ * products of 32 x 6 bits each) and joined by ONE reduction per output -- the same value as sum_i s[(i + r) % 12] CIRC[i] + s[r] DIAG[r].
+ * The loops run over the OUTPUT index innermost (contiguous, 32 x 32 -> 64 bit products) so that the compiler can use the vector
+ * multiplier; two clones, picked by the loader for the machine the library runs on. */
+__attribute__((target_clones("avx2", "default"), optimize("O3", "tree-vectorize")))
 static void mds_layer(uint64_t s[12]) {
-    uint64_t out[12];
-    for (int r = 0; r < 12; r++) {
-        u128 acc = 0; /* 12 * 2^64 * 2^6 fits easily */
-        for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * POSEIDON_CIRC[i];
-        acc += (u128)s[r] * POSEIDON_DIAG[r];
-        out[r] = gl_reduce128(acc);
+    uint32_t lo[24], hi[24];
+    uint64_t al[12], ah[12];
+    for (int i = 0; i < 12; i++) {
+        lo[i] = lo[i + 12] = (uint32_t)s[i];
+        hi[i] = hi[i + 12] = (uint32_t)(s[i] >> 32);
     }
-    memcpy(s, out, sizeof out);
+    for (int r = 0; r < 12; r++) {
+        al[r] = (uint64_t)lo[r] * (uint32_t)POSEIDON_DIAG[r];
+        ah[r] = (uint64_t)hi[r] * (uint32_t)POSEIDON_DIAG[r];
+    }
+    for (int i = 0; i < 12; i++) {
+        const uint32_t c = (uint32_t)POSEIDON_CIRC[i];
+        for (int r = 0; r < 12; r++) {
+            al[r] += (uint64_t)lo[i + r] * c;
+            ah[r] += (uint64_t)hi[i + r] * c;
+        }
+    }
+    for (int r = 0; r < 12; r++) s[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
 }
 
 static inline uint64_t sbox(uint64_t x) {

@@ -56,9 +56,10 @@ def air_tables():
         a["name"], a["prog"], a["aux"] = m.group(1), arrays[f[12]], arrays[f[14]]
         assert len(a["prog"]) == int(f[13])
         a["log_rows"], a["hardened"] = int(f[15]), int(f[16])
-        a["n_vflag"], a["n_vconst"] = int(f[17]), int(f[19])
+        a["n_vflag"], a["n_fields"], a["n_vconst"], a["vconst_field"] = int(f[17]), int(f[19]), int(f[22]), int(f[24])
         airs.append(a)
-    # the pairing AIR's value-periodic columns (period 512): selector rows, constant vectors and the row -> vector index
+    # the pairing AIR's value-periodic columns (period 2^13), DERIVED from its row program: flag k on a row = sum of weight over the terms
+    # (field, value, weight) of the flag whose field of the row's descriptor equals value; constants = a table row named by a field
     def table(name):
         m = re.search(r"%s\[(\d+)\](?:\[(\d+)\])? = \{(.*?)\};" % name, txt, re.S)
         v = ints(m.group(3))
@@ -66,7 +67,8 @@ def air_tables():
             return v
         w = int(m.group(2))
         return [v[i * w:(i + 1) * w] for i in range(int(m.group(1)))]
-    vper = dict(vflag=table("AIR_PAIRING_VFLAG"), gconst=table("AIR_PAIRING_GCONST"), gidx=table("AIR_PAIRING_GIDX"))
+    vper = dict(rowprog=table("AIR_PAIRING_ROWPROG"), flagdef=table("AIR_PAIRING_FLAGDEF"), flagoff=table("AIR_PAIRING_FLAGOFF"),
+                gc=table("AIR_PAIRING_GC"))
     _TABLES = (periodic, p_limbs, airs, vper)
     return _TABLES
 
@@ -74,9 +76,11 @@ def air_tables():
 def vper_values(a, k):
     """the 2^log_rows values of value-periodic column k of AIR a (air_vper_value of data/air_tables.h)"""
     vper = air_tables()[3]
+    rows = vper["rowprog"]
     if k < a["n_vflag"]:
-        return vper["vflag"][k]
-    return [vper["gconst"][gi][k - a["n_vflag"]] for gi in vper["gidx"]]
+        terms = vper["flagdef"][vper["flagoff"][k]:vper["flagoff"][k + 1]]
+        return [sum(w for f, v, w in terms if d[f] == v) for d in rows]
+    return [vper["gc"][d[a["vconst_field"]]][k - a["n_vflag"]] for d in rows]
 
 
 def vper_at(a, log_n, zeta):
@@ -301,7 +305,7 @@ def verify(proof, cfg=None):
     if any(v >= P for v in pf[16:]) or any(v >> 32 for v in pf[1:16]):
         return "non-canonical word"
     kind, log_n, num_io, W, Pz, Q, cap_h, n_rounds, final_len, nq, ppi, total, rate_bits, arity_bits, zero = pf[1:16]
-    log_rows = 3 if kind == 3 else 9
+    log_rows = 3 if kind == 3 else 13 if kind == 6 else 9
     if not (0 <= kind <= 6) or not (10 <= log_n <= 26) or num_io != 1 << (log_n - log_rows):
         return "header"
     a = air_of(kind, log_n)

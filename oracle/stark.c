@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define MAGIC 0x5349505053544b31ULL /* "SIPPSTK1" */
 
@@ -172,8 +173,14 @@ int orc_stark_prove(int kind, const uint32_t *ios, size_t num_io, const orc_conf
 
 /* the prover proper, from a filled trace (tests tamper with the trace between orc_trace_build and this call:
  * whatever the cells hold is committed and proved as is; the verifier must then refuse) */
+/* ORC_TIMING=1 in the environment: the prover's stages on stderr (seconds since the start of the proof) */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+#define STAGE(name) do { if (timing) fprintf(stderr, "[oracle prove] %-18s %.2f s\n", name, now_s() - t0); } while (0)
+
 int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **proof_out, size_t *proof_len) {
     int err = 0;
+    const int timing = getenv("ORC_TIMING") != NULL;
+    const double t0 = now_s();
     const int kind = orc_air_api_kind(t->air);
     const air_spec_t *a = t->air;
     const unsigned log_n = t->log_n, log_m = log_n + cfg->rate_bits;
@@ -194,6 +201,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     orc_batch *bt = orc_batch_from_values(t->trace, (size_t)W, log_n, cfg->rate_bits, cfg->cap_height);
     orc_chal_observe_cap(&ch, orc_batch_cap(bt), cap_n);
     wb_push(&pf, orc_batch_cap(bt), cap_n * 4);
+    STAGE("trace commitment");
     /* 2. permutation challenges and Z polys */
     uint64_t beta[2], gamma[2];
     for (int i = 0; i < 2; i++) {
@@ -230,6 +238,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
     free(zv);
     orc_chal_observe_cap(&ch, orc_batch_cap(bz), cap_n);
     wb_push(&pf, orc_batch_cap(bz), cap_n * 4);
+    STAGE("lookup products");
     /* 3. alphas */
     uint64_t alpha[2];
     alpha[0] = orc_chal_get(&ch); alpha[1] = orc_chal_get(&ch);
@@ -266,6 +275,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
             free(co);
         }
     }
+    STAGE("aux / periodic");
     uint64_t *qv = (uint64_t *)malloc(2 * mq * sizeof(uint64_t)); /* [2][mq] natural order */
     {
         uint64_t wm = gl_root_of_unity(log_mq);
@@ -293,6 +303,7 @@ int orc_stark_prove_trace(const orc_trace *t, const orc_config *cfg, uint64_t **
         }
     }
     free(aux_lde); free(vper_tab);
+    STAGE("quotient values");
     /* coset iFFT -> 2 polys of 2N coefficients -> 4 chunks of N */
     uint64_t *qc = (uint64_t *)malloc((size_t)Q * n * sizeof(uint64_t));
     {
@@ -383,7 +394,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     unsigned log_n = (unsigned)h[2];
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
-    const unsigned log_rows = kind == 3 ? 3 : 9;
+    const unsigned log_rows = orc_kind_log_rows(kind);
     if (kind < 0 || kind > 6 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const air_spec_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||

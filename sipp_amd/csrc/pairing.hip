@@ -19,6 +19,7 @@
 #include "ctx.hpp"
 #include "fq.hpp"
 #include "pairing_constants.h"
+#include "pairing_rowsrc.h"
 
 namespace {
 
@@ -723,23 +724,20 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ va
 
 
 // =====================================================================================================================================
-// Primary witness of the final-pairing AIR (API kind 6; tools/air_gen.py::build_pairing, schedule tools/pairing_sched.py): ONE WAVE
-// per record walks the 512 rows of its block -- the statement behind `pairing_circuit(final_A, final_B)` == final_Z of the
-// reference's BLS example (src/bin/bls_aggregation.rs:76-77).  Per row: the G2 unit (an AFFINE tangent / chord step with its line
-// coefficients on lane 0; the 102 slopes come from a projective pass over the point chain and ONE batched inversion in front of the
-// rows), the Fq12 unit (36 lanes per
-// product as in the final exponentiation above; the one inversion on lane 0; Frobenius / conjugation rows on 6 lanes), then all 64
-// lanes write the row's 156 field elements as 16-bit (8-bit) limb cells, and the registers take over what the schedule says.
+// Primary witness of the final-pairing AIR (API kind 6; tools/air_gen.py::build_pairing, NARROW layout: one modular identity per row,
+// 2^13 rows per pairing, row program tools/pairing_rows.py) -- the statement behind `pairing_circuit(final_A, final_B)` == final_Z of
+// the reference's BLS example (src/bin/bls_aggregation.rs:76-77).  Two kernels:
+//   pairing_values_kernel   ONE WAVE per record walks the OPERATION schedule (tools/pairing_sched.py: 458 operations): the G2 unit (an
+//                           AFFINE tangent / chord step with its line coefficients on lane 0; the 102 slopes come from a projective pass
+//                           over the point chain and ONE batched inversion in front), the Fq12 unit (36 lanes per product as in the
+//                           final exponentiation above; the one inversion on lane 0; Frobenius / conjugation on 6 lanes).  Every value a
+//                           row of the trace produces is LOGGED into the record's pool at the index of that row (pairing_rowsrc.h).
+//   pairing_expand_kernel   one thread per (row, field element): looks the element's pool index up in the host-built source table (the
+//                           row program replayed symbolically: pairing_rowsrc.h) and writes its 16 limb cells (32 for the checked
+//                           result) -- consecutive lanes are consecutive rows of one column.
 // oracle/pairing.c is the CPU reading the tests compare with cell for cell.
 // =====================================================================================================================================
-enum { PL_PX, PL_PY, PL_QX, PL_QY, PL_Q1X, PL_Q1Y, PL_Q2X, PL_Q2Y, PL_TX, PL_TY, PL_QSX, PL_QSY, PL_FXC, PL_FYC, PL_A, PL_B, PL_G, PL_REG, PL_C,
-       PL_S0, PL_N };
-enum { PV_QX, PV_QY, PV_Q1X, PV_Q1Y, PV_Q2X, PV_Q2Y, PV_TX, PV_TY, PV_QSX, PV_QSY, PV_FXC, PV_FYC, PV_N };
-struct PairCols {
-    int32_t lay[PL_N];
-    int32_t cpl, nreg, result_reg;
-};
-// the row's values in the order the cell writer walks them: 156 field elements (Montgomery form)
+enum { PV_QX, PV_QY, PV_Q1X, PV_Q1Y, PV_Q2X, PV_Q2Y, PV_TX, PV_TY, PV_FXC, PV_FYC, PV_N };
 struct PairVals {
     T6 reg[6];
     T6 A, B, G, C;
@@ -747,10 +745,12 @@ struct PairVals {
     Fq2 pts[PV_N];
     Fq2 S[5];
 };
-static_assert(sizeof(PairVals) == 156 * sizeof(Fq), "PairVals is walked as an array of Fq");
-// device copy of the schedule tables (data/air_tables.h): [512][6] int8 | gidx [512] int8 | gconj [8] int8 | gconst [6][192] u16
 constexpr int PAIR_STEPS = 102;      // 64 tangent + 36 + 2 chord steps of the schedule
-constexpr int PT_SCHED = 0, PT_GIDX = 3072, PT_GCONJ = 3584, PT_GCONST = 3592, PT_BYTES = 3592 + 6 * 192 * 2;
+// device copy of the schedule tables (data/air_tables.h): [512][6] int8 | gconj [8] int8 | gconst [6][192] u16 | oprow [512] i16 |
+// steprow [104] i16 | row constants [NGC][32] u16
+constexpr int PT_SCHED = 0, PT_GCONJ = 3072, PT_GCONST = 3080, PT_OPROW = PT_GCONST + 6 * 192 * 2, PT_STEPROW = PT_OPROW + 1024,
+              PT_GC = PT_STEPROW + 208, PT_BYTES = PT_GC + AIR_PAIRING_NGC * 64;
+static_assert(PT_GCONST % 2 == 0 && PT_OPROW % 2 == 0 && PT_GC % 2 == 0, "16-bit tables are aligned");
 
 __device__ __forceinline__ Fq load_words_mont(const uint32_t* w) {
     Fq r;
@@ -759,9 +759,16 @@ __device__ __forceinline__ Fq load_words_mont(const uint32_t* w) {
     return fq::to_mont(r);
 }
 __device__ __forceinline__ bool f2_eq(const Fq2& a, const Fq2& b) { return fq::is_zero(fq::sub(a, b)); }
+__device__ __forceinline__ void pool_put(uint32_t* __restrict__ pool, int idx, const Fq& mont) {
+    const Fq v = fq::from_mont(mont);
+    uint4* o = reinterpret_cast<uint4*>(pool + (size_t)idx * 8);
+    o[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    o[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
 
-__global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__ ios, uint32_t num_io, const uint8_t* __restrict__ tab,
-                                                         PairCols k, uint64_t* __restrict__ tr, size_t n, int mode, int* __restrict__ err) {
+// pools: [num_io][PP_N][8] u32, zeroed by the caller (rows without a result read zero); mode 1: values only, Z written into the record
+__global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict__ ios, uint32_t num_io, const uint8_t* __restrict__ tab,
+                                                           uint32_t* __restrict__ pools, int mode, int* __restrict__ err) {
     __shared__ PairVals V;
     __shared__ CoopScratch64 sc;
     __shared__ int s_bad;
@@ -770,6 +777,7 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     const uint32_t io = blockIdx.x;
     if (io >= num_io) return;
     uint32_t* rec = ios + (size_t)io * 144;
+    uint32_t* pool = pools + (size_t)io * PP_N * 8;
     const Fq2 zero2 = f2_zero();
     // ---- the record: P, Q (checked: on their curves; the verifier also wants [r] Q = O), constants, empty registers ----
     if (l == 0) {
@@ -803,11 +811,24 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
         return;
     }
     const int8_t* sched = reinterpret_cast<const int8_t*>(tab + PT_SCHED);
-    const int8_t* gidx = reinterpret_cast<const int8_t*>(tab + PT_GIDX);
     const int8_t* gconj = reinterpret_cast<const int8_t*>(tab + PT_GCONJ);
     const uint16_t* gconst = reinterpret_cast<const uint16_t*>(tab + PT_GCONST);
-    Fq* flat = reinterpret_cast<Fq*>(&V);
-    // ---- the 102 affine slopes AHEAD of the rows, with ONE inversion: the point chain in homogeneous coordinates (no inversion per
+    const int16_t* oprow = reinterpret_cast<const int16_t*>(tab + PT_OPROW);
+    const int16_t* steprow = reinterpret_cast<const int16_t*>(tab + PT_STEPROW);
+    // ---- the pool's fixed part: P, Q (the record's words as they are), the twist's Frobenius constants, the row constants ----
+    if (mode == 0) {
+        if (l < 6) {
+            const uint32_t* w = rec + 8 * l;
+            for (int i = 0; i < 8; i++) pool[(size_t)(PP_PX + l) * 8 + i] = w[i];
+        } else if (l < 10) {
+            const Fq2& c = V.pts[l < 8 ? PV_FXC : PV_FYC];
+            pool_put(pool, PP_FROBC + (l - 6), (l & 1) ? c.c1 : c.c0);
+        }
+        const uint16_t* gcs = reinterpret_cast<const uint16_t*>(tab + PT_GC);
+        for (int e = l; e < 2 * AIR_PAIRING_NGC; e += 64)
+            for (int i = 0; i < 8; i++) pool[(size_t)(PP_GC + e) * 8 + i] = (uint32_t)gcs[16 * e + 2 * i] | ((uint32_t)gcs[16 * e + 2 * i + 1] << 16);
+    }
+    // ---- the 102 affine slopes AHEAD of the walk, with ONE inversion: the point chain in homogeneous coordinates (no inversion per
     // step; slope of step s = N_s / D_s with N = 3 X^2, D = 2 Y Z for a tangent, N = y_Q Z - Y, D = x_Q Z - X for a chord), then
     // Montgomery's trick over the D_s.  An inversion per step (binary gcd on one lane, ~90 us) made 10 of the kernel's 18.5 ms.
     if (l == 0) {
@@ -820,7 +841,7 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
         q2y = f2_neg(q2y);
         Fq2 X = qx, Y = qy, Z = f2_one();
         int ns = 0;
-        for (int t = 1; t < 512 && ns < PAIR_STEPS; t++) {
+        for (int t = 1; t < AIR_PAIRING_OPS && ns < PAIR_STEPS; t++) {
             const int gop = sched[6 * t + 5];
             if (gop < 1 || gop > 4) continue;
             Fq2 N, D, a, b;
@@ -889,12 +910,13 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     }
     __syncthreads();
     int step = 0;
-    for (int t = 0; t < 512; t++) {
-        const int fop = sched[6 * t], ra = sched[6 * t + 1], rb = sched[6 * t + 2], rd = sched[6 * t + 4], gop = sched[6 * t + 5];
-        const int gi = gidx[t];
-        // ---- (1) the G2 unit (lane 0) and the row's constants (lanes 32 .. 43) ----
+    for (int t = 0; t < AIR_PAIRING_OPS; t++) {
+        const int fop = sched[6 * t], ra = sched[6 * t + 1], rb = sched[6 * t + 2], gc = sched[6 * t + 3], rd = sched[6 * t + 4], gop = sched[6 * t + 5];
+        const int gi = gc < 0 ? 0 : gc;
+        if (fop == 0 && gop == 0 && rd < 0) continue;      // an idle operation (uniform over the wave)
+        // ---- (1) the G2 unit (lane 0) and the operation's constants (lanes 32 .. 43) ----
         if (l == 0) {
-            Fq2 S0 = zero2, S1 = zero2, S2 = zero2, S3 = zero2, S4 = zero2, qsx = zero2, qsy = zero2;
+            Fq2 S0 = zero2, S1 = zero2, S2 = zero2, S3 = zero2, S4 = zero2;
             const Fq2 tx = V.pts[PV_TX], ty = V.pts[PV_TY];
             if (gop == 5) {
                 f2_mul(S0, f2_conj(V.pts[PV_QX]), V.pts[PV_FXC]);
@@ -903,25 +925,19 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
                 f2_mul(S3, f2_conj(S1), V.pts[PV_FYC]);
                 S3 = f2_neg(S3);
             } else if (gop != 0) {
-                Fq2 num, den, xb;
+                Fq2 den, xb;
                 if (gop == 1) {
                     den = f2_dbl(ty);
-                    f2_sqr(num, tx);
-                    num = fq::add(f2_dbl(num), num);
                     xb = tx;
                 } else {
-                    qsx = V.pts[gop == 2 ? PV_QX : gop == 3 ? PV_Q1X : PV_Q2X];
-                    qsy = V.pts[gop == 2 ? PV_QY : gop == 3 ? PV_Q1Y : PV_Q2Y];
-                    den = fq::sub(qsx, tx);
-                    num = fq::sub(qsy, ty);
-                    xb = qsx;
+                    xb = V.pts[gop == 2 ? PV_QX : gop == 3 ? PV_Q1X : PV_Q2X];
+                    den = fq::sub(xb, tx);
                 }
                 if (fq::is_zero(den) || step >= PAIR_STEPS) {
                     s_bad = 1;                     // a degenerate step: Q is not a point of order r (or T met +-Q): no affine slope
                 } else {
                     Fq2 t2;
                     S0 = s_num[step];              // = num / den, from the chain above (one batched inversion)
-                    (void)num;
                     f2_sqr(S1, S0);
                     S1 = fq::sub(fq::sub(S1, tx), xb);
                     f2_mul(t2, S0, fq::sub(tx, S1));
@@ -933,12 +949,9 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
                 }
             }
             V.S[0] = S0; V.S[1] = S1; V.S[2] = S2; V.S[3] = S3; V.S[4] = S4;
-            V.pts[PV_QSX] = qsx;
-            V.pts[PV_QSY] = qsy;
         }
-        if (gop >= 1 && gop <= 4) step++;
-        if (l >= 32 && l < 44) {
-            const uint32_t e = l - 32;          // Fq element e of the row's constant vector (16-bit limbs in the table)
+        if (l >= 32 && l < 44 && (fop == 4 || fop == 0)) {
+            const uint32_t e = l - 32;          // Fq element e of the operation's constant vector (16-bit limbs in the table)
             const uint16_t* src = gconst + (size_t)gi * 192 + 16 * e;
             Fq v;
 #pragma unroll
@@ -947,6 +960,16 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
             g[e] = fq::to_mont(v);
         }
         __syncthreads();
+        // ---- the step's five values into the pool: slope, x3, y3, -lam x_P, lam x_T - y_T at the rows that produce them ----
+        if (mode == 0 && gop != 0 && l < 10) {
+            const Fq* sv = reinterpret_cast<const Fq*>(V.S);
+            if (gop == 5) {
+                if (l < 8) pool_put(pool, PP_ROW + (int)l, sv[l]);
+            } else if (step < PAIR_STEPS) {
+                pool_put(pool, PP_ROW + steprow[step] + (int)(l < 2 ? l : l + 2), sv[l]);
+            }
+        }
+        if (gop >= 1 && gop <= 4) step++;
         // ---- (2) operands ----
         if (l < 6) {
             V.A.c[l] = ra >= 0 ? V.reg[ra].c[l] : zero2;
@@ -971,7 +994,6 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
                     t6_inv(b, a);
                 }
                 V.C = b;
-                V.B = b;
             }
             __syncthreads();
         } else {
@@ -982,35 +1004,8 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
             }
             __syncthreads();
         }
-        // ---- (4) the row's cells ----
-        if (mode == 0) {
-            const size_t row = (size_t)io * 512 + (size_t)t;
-            for (uint32_t e = l; e < 156; e += 64) {
-                int col, chk = 0;
-                if (e < 72) col = k.lay[PL_REG] + 16 * (int)e;
-                else if (e < 84) col = k.lay[PL_A] + 16 * (int)(e - 72);
-                else if (e < 96) col = k.lay[PL_B] + 16 * (int)(e - 84);
-                else if (e < 108) col = k.lay[PL_G] + 16 * (int)(e - 96);
-                else if (e < 120) { col = k.lay[PL_C] + 16 * k.cpl * (int)(e - 108); chk = 1; }
-                else if (e < 122) col = k.lay[PL_PX + (int)(e - 120)];
-                else if (e < 146) col = k.lay[PL_QX + (int)((e - 122) >> 1)] + 16 * (int)((e - 122) & 1);
-                else { col = k.lay[PL_S0] + 16 * k.cpl * (int)(e - 146); chk = 1; }
-                const Fq v = fq::from_mont(flat[e]);
-                if (chk && k.cpl == 2) {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const uint32_t limb = (v.l[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-                        tr[(size_t)(col + 2 * i) * n + row] = limb & 0xffu;
-                        tr[(size_t)(col + 2 * i + 1) * n + row] = limb >> 8;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) tr[(size_t)(col + i) * n + row] = (v.l[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- (5) end of the row: registers ----
+        // ---- (4) the operation's twelve results into the pool; registers ----
+        if (mode == 0 && l < 12 && oprow[t] >= 0) pool_put(pool, PP_ROW + oprow[t] + (int)l, reinterpret_cast<const Fq*>(&V.C)[l]);
         if (l < 6 && rd >= 0) V.reg[rd].c[l] = fop == 0 ? V.G.c[l] : V.C.c[l];
         if (l == 0) {
             if (gop == 5) {
@@ -1024,7 +1019,7 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     }
     // ---- the result: MyFq12 coefficients c_i = a_i - 9 b_i, c_{i+6} = b_i; compared with the record (mode 0) or written into it ----
     if (l < 6) {
-        const T6& res = V.reg[k.result_reg];
+        const T6& res = V.reg[AIR_PAIRING_RESULT_REG];
         const Fq nine = fq::small_m(9);
         Fq nb;
         fq_mul(nb, nine, res.c[l].c1);
@@ -1043,43 +1038,97 @@ __global__ void __launch_bounds__(64) pairing_rows_kernel(uint32_t* __restrict__
     }
 }
 
+struct PairElemCols {
+    int32_t col[PE_N];
+    int32_t cpl;
+};
+
+// grid (n / 256, PE_N): thread = one row of one field element; src [PE_N][8192] u16; pools [num_io][PP_N][8]
+__global__ void __launch_bounds__(256) pairing_expand_kernel(const uint16_t* __restrict__ src, const uint32_t* __restrict__ pools, PairElemCols k,
+                                                            uint64_t* __restrict__ tr, size_t n) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t e = blockIdx.y;
+    if (row >= n) return;
+    const uint32_t r = (uint32_t)row & (AIR_PAIRING_ROWS - 1), io = (uint32_t)(row >> AIR_PAIRING_LOG_ROWS);
+    const uint32_t id = src[(size_t)e * AIR_PAIRING_ROWS + r];
+    const uint4* p = reinterpret_cast<const uint4*>(pools + ((size_t)io * PP_N + id) * 8);
+    const uint4 lo = p[0], hi = p[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const int col = k.col[e];
+    if (e == PE_RES && k.cpl == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t limb = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            tr[(size_t)(col + 2 * i) * n + row] = limb & 0xffu;
+            tr[(size_t)(col + 2 * i + 1) * n + row] = limb >> 8;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) tr[(size_t)(col + i) * n + row] = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+    }
+}
+
 }  // namespace
 
-// primary witness of the final-pairing AIR: d_ios [num_io][144] (padded: 512 num_io == n rows).  outputs_only ctx: the records'
+// primary witness of the final-pairing AIR: d_ios [num_io][144] (padded: 8192 num_io == n rows).  outputs_only ctx: the records'
 // Z words are written instead (sipp_exp_outputs with kind = SIPP_PAIRING)
 int sipp_pairing_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, uint32_t num_io, uint32_t log_n, uint64_t* d_trace,
                       int* d_err) {
     const size_t n = (size_t)1 << log_n;
     const bool outputs = ctx->outputs_only;
-    PairCols k;
     const int32_t* lay = (a && a->cells_per_limb == 2) ? AIR_PAIRING_LAYOUT_U8 : AIR_PAIRING_LAYOUT_U16;
-    memcpy(k.lay, lay, sizeof k.lay);
-    k.cpl = a ? a->cells_per_limb : 1;
-    k.nreg = AIR_PAIRING_NREG;
-    k.result_reg = AIR_PAIRING_RESULT_REG;
-    static_assert(AIR_PAIRING_ROWS == 512 && AIR_PAIRING_NREG == 6 && AIR_PAIRING_NGCONST == 6, "pairing_rows_kernel: table shapes");
-    if (!outputs && (!a || a->kind != 6 || a->log_rows != 9 || a->checked_base != k.lay[PL_C] || a->pi_per_io != 144 || (size_t)num_io * 512 != n))
+    static_assert(AIR_PAIRING_ROWS == 8192 && AIR_PAIRING_OPS == 512 && AIR_PAIRING_NREG == 6 && AIR_PAIRING_NGCONST == 6 && PP_N < 65536,
+                  "pairing kernels: table shapes");
+    if (!outputs && (!a || a->kind != 6 || a->log_rows != AIR_PAIRING_LOG_ROWS || a->checked_base != lay[20] || a->pi_per_io != 144 ||
+                     (size_t)num_io * AIR_PAIRING_ROWS != n))
         return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: table / shape mismatch");
     uint64_t* t = sipp_table_get(ctx, 102, 0, 0);
     if (!t) {
-        int steps = 0;
-        for (int r = 0; r < AIR_PAIRING_ROWS; r++) steps += AIR_PAIRING_SCHED[r][5] >= 1 && AIR_PAIRING_SCHED[r][5] <= 4;
-        if (steps != PAIR_STEPS || AIR_PAIRING_SCHED[0][5] != 5)
-            return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: the schedule's point steps do not match the kernel's slope table");
         std::vector<uint64_t> packed((PT_BYTES + 7) / 8, 0);
         uint8_t* b = reinterpret_cast<uint8_t*>(packed.data());
         memcpy(b + PT_SCHED, AIR_PAIRING_SCHED, 3072);
-        memcpy(b + PT_GIDX, AIR_PAIRING_GIDX, 512);
         memcpy(b + PT_GCONJ, AIR_PAIRING_GCONJ, AIR_PAIRING_NGCONST);
         uint16_t* gc = reinterpret_cast<uint16_t*>(b + PT_GCONST);
         for (int g = 0; g < AIR_PAIRING_NGCONST; g++)
             for (int i = 0; i < 192; i++) gc[g * 192 + i] = (uint16_t)AIR_PAIRING_GCONST[g][i];
+        int16_t steprow[104] = {0};
+        if (pairing_log_rows(reinterpret_cast<int16_t*>(b + PT_OPROW), steprow, PAIR_STEPS) != PAIR_STEPS)
+            return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: the row program does not pair up with the operation schedule");
+        memcpy(b + PT_STEPROW, steprow, sizeof steprow);
+        uint16_t* rc = reinterpret_cast<uint16_t*>(b + PT_GC);
+        for (int g = 0; g < AIR_PAIRING_NGC; g++)
+            for (int i = 0; i < 32; i++) rc[g * 32 + i] = (uint16_t)AIR_PAIRING_GC[g][i];
         SIPP_TRY(sipp_table_put(ctx, 102, 0, 0, packed, &t));
     }
-    ProfScope ps(ctx, "trace_pairing");
-    hipLaunchKernelGGL(pairing_rows_kernel, dim3(num_io), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io,
-                       reinterpret_cast<const uint8_t*>(t), k, d_trace, n, outputs ? 1 : 0, d_err);
-    SIPP_CHECK_HIP(ctx, hipGetLastError());
+    uint32_t* d_pools = nullptr;
+    uint64_t* src = nullptr;
+    if (!outputs) {
+        src = sipp_table_get(ctx, 106, 0, 0);
+        if (!src) {
+            std::vector<uint64_t> packed(((size_t)PE_N * AIR_PAIRING_ROWS * 2 + 7) / 8, 0);
+            if (pairing_row_sources(reinterpret_cast<uint16_t*>(packed.data())) != 0)
+                return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "pairing AIR: the row program reads what the source replay does not know");
+            SIPP_TRY(sipp_table_put(ctx, 106, 0, 0, packed, &src));
+        }
+        d_pools = arena_alloc_t<uint32_t>(ctx, (size_t)num_io * PP_N * 8);
+        if (!d_pools) return sipp_fail(ctx, SIPP_E_NOMEM, "pairing AIR: value pools");
+        SIPP_CHECK_HIP(ctx, hipMemsetAsync(d_pools, 0, (size_t)num_io * PP_N * 32, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, "trace_pairing");
+        hipLaunchKernelGGL(pairing_values_kernel, dim3(num_io), dim3(64), 0, ctx->stream, const_cast<uint32_t*>(d_ios), num_io,
+                           reinterpret_cast<const uint8_t*>(t), d_pools, outputs ? 1 : 0, d_err);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
+    if (!outputs) {
+        ProfScope ps(ctx, "trace_pairing_cells");
+        PairElemCols k;
+        for (int e = 0; e < PE_N; e++) k.col[e] = pairing_elem_col(lay, e);
+        k.cpl = a->cells_per_limb;
+        hipLaunchKernelGGL(pairing_expand_kernel, dim3((unsigned)((n + 255) / 256), PE_N), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const uint16_t*>(src), d_pools, k, d_trace, n);
+        SIPP_CHECK_HIP(ctx, hipGetLastError());
+    }
     return SIPP_OK;
 }
 

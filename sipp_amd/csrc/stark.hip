@@ -37,7 +37,8 @@ struct Shape {
 
 static int shape_of(int kind, size_t num_io, Shape* s) {
     if (kind < 0 || kind > SIPP_PAIRING || num_io == 0 || num_io > ((size_t)1 << 17)) return SIPP_E_BADARG;
-    const uint32_t log_rows = kind == SIPP_MAP_G2 ? 3 : 9;   // rows per record: 512 (exponentiations), 8 (MapToG2)
+    // rows per record: 512 (exponentiations), 8 (MapToG2), 8192 (the final pairing)
+    const uint32_t log_rows = kind == SIPP_MAP_G2 ? 3 : kind == SIPP_PAIRING ? AIR_PAIRING_LOG_ROWS : 9;
     uint32_t nio = 2;  // at least two IO blocks, at least 1024 rows
     while (nio < num_io || ((size_t)nio << log_rows) < 1024) nio <<= 1;
     uint32_t log_n = log_rows;

@@ -902,6 +902,13 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
         const int64_t coef = *w++;
         int32_t va[16], vb[16];
         w += ivec_dev<16>(w, tr, n, row, per, g, va, bad);
+        bool live = false;
+#pragma unroll
+        for (int i = 0; i < 16; i++) live |= va[i] != 0;
+        if (!live) {                 // a product another row type switches on (the pairing AIR: one of ~300 per row): nothing to add
+            w += 2 + 5 * (int)w[1];
+            continue;
+        }
         w += ivec_dev<16>(w, tr, n, row, per, g, vb, bad);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -1232,7 +1239,9 @@ const int8_t* sipp_air_vflag_device(sipp_ctx* ctx, const air_spec_t* a) {
     if (!t) {
         const size_t bytes = (size_t)a->n_vflag << a->log_rows;
         std::vector<uint64_t> v((bytes + 7) / 8, 0);
-        memcpy(v.data(), a->vflag, bytes);
+        int8_t* f = reinterpret_cast<int8_t*>(v.data());       // flag k on row r: the weights of its terms the row descriptor meets
+        for (int k = 0; k < a->n_vflag; k++)
+            for (int r = 0; r < (1 << a->log_rows); r++) f[((size_t)k << a->log_rows) + (size_t)r] = (int8_t)air_vper_value(a, k, r);
         if (sipp_table_put(ctx, 103, (uint64_t)a->kind, 0, v, &t) != SIPP_OK) return nullptr;
     }
     return reinterpret_cast<const int8_t*>(t);

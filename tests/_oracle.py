@@ -142,8 +142,8 @@ class OrcAir(C.Structure):
                 ("n_constraints", C.c_int), ("n_aux", C.c_int), ("pi_per_io", C.c_int), ("n_gadgets", C.c_int),
                 ("carry_limbs", C.c_int), ("prog", C.POINTER(C.c_int64)), ("prog_len", C.c_int),
                 ("aux", C.POINTER(C.c_int32)), ("log_rows", C.c_int), ("hardened", C.c_int),
-                ("n_vflag", C.c_int), ("vflag", C.POINTER(C.c_int8)), ("n_vconst", C.c_int), ("vconst", C.POINTER(C.c_int64)),
-                ("vconst_idx", C.POINTER(C.c_int8))]
+                ("n_vflag", C.c_int), ("rowprog", C.POINTER(C.c_int8)), ("n_fields", C.c_int), ("flagdef", C.POINTER(C.c_int16)),
+                ("flagoff", C.POINTER(C.c_int16)), ("n_vconst", C.c_int), ("vconst", C.POINTER(C.c_int64)), ("vconst_field", C.c_int)]
 
 
 class OrcTrace(C.Structure):

@@ -64,16 +64,16 @@ def test_edge_points_and_bilinearity(ctx):
     two_three[0, :48] = bn.g1_to_u32(bn.g1_mul(ps[5], 2)) + bn.g2_to_u32(bn.g2_mul(qs[5], 3))
     lhs = ctx.exp_outputs(6, two_three)[0, 48:]
     assert [bn.u32_to_fq(list(lhs[8 * k: 8 * k + 8])) for k in range(12)] == bn.f12_pow(e(5), 6)
-    # and all ten records in ONE proof (sixteen blocks, six of them padding)
+    # and all ten records in ONE proof (sixteen blocks of 2^13 rows, six of them padding)
     proof = ctx.prove(6, got)
-    assert int(proof[2]) == 13 and int(proof[3]) == 16 and _oracle.stark_verify(proof) == 0
+    assert int(proof[2]) == 17 and int(proof[3]) == 16 and _oracle.stark_verify(proof) == 0
 
 
 def test_trace_matches_oracle_cell_for_cell(ctx, recs3):
     from sipp_amd._lib import to_host
     for recs in (recs3[1:2], recs3):
         ref = _oracle.Trace(6, recs)
-        assert ref.air.table_bits == 8 and ref.air.log_rows == 9 and ref.log_n == (10 if len(recs) == 1 else 11)
+        assert ref.air.table_bits == 8 and ref.air.log_rows == 13 and ref.log_n == (14 if len(recs) == 1 else 15)
         assert ctx.shape(6, len(recs))[:2] == (ref.log_n, ref.width)
         got = to_host(ctx.trace_build(6, recs))
         want = ref.array()

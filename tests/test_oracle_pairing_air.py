@@ -1,7 +1,7 @@
 """The final-pairing AIR (API kind 6; reference src/bin/bls_aggregation.rs:76-77: `pairing_circuit(final_A, final_B)` connected to
-`final_Z`) on the CPU: three readings of the value (the plain power of oracle/py/bn254.py, the schedule run in big-int Python by
-tools/pairing_sched.py, the schedule run by oracle/pairing.c), the trace against the AIR program row by row, proofs through both
-verifiers, and what is refused."""
+`final_Z`) on the CPU: four readings of the value (the plain power of oracle/py/bn254.py, the operation schedule and its row program run
+in big-int Python by tools/pairing_sched.py / tools/pairing_rows.py, the row program run by oracle/pairing.c), the trace against the
+AIR program row by row, proofs through both verifiers, the mutation suite, and what is refused."""
 import os
 import random
 import sys
@@ -15,6 +15,7 @@ from oracle.py import stark_verify as sv
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
 import pairing_sched as PS  # noqa: E402
+import pairing_rows as PR  # noqa: E402
 
 
 def record(Pt, Q, Z=None):
@@ -57,11 +58,35 @@ def test_schedule_shape():
             loaded.add(r["rd"])
 
 
+def test_row_program_shape():
+    """one identity per row: every operation of the schedule is 12 component rows (24 for the inversion: witness, then check) plus a commit
+    row, every point step 12 rows (slope witness, slope check, x3, y3, the two line coefficients), the Frobenius of Q 8"""
+    from collections import Counter
+    c = Counter(d[PR.F_TYP] for d in PR.ROWPROG)
+    ops = Counter(r["fop"] for r in PS.SCHEDULE)
+    assert PR.ROWS == 8192 and PR.N_ACTIVE == 7185 <= PR.ROWS
+    assert c[PR.T_FMUL] == 12 * (ops[PS.F_MUL] + ops[PS.F_LINE] - 1) and c[PR.T_FCOPY] == 12 and c[PR.T_FFROB] == 12 * ops[PS.F_FROB]
+    assert c[PR.T_FINVW] == c[PR.T_FINVC] == 12 and c[PR.T_FCOMMIT] == PS.N_ACTIVE - 1
+    assert c[PR.T_GW] == c[PR.T_GSL] == c[PR.T_GX3] == c[PR.T_GY3] == c[PR.T_GL1] == c[PR.T_GL3] == 2 * 102 and c[PR.T_GFQ] == 8
+    # a register is committed before it is read; the accumulator's twelve components are all produced before a commit
+    loaded, filled = set(), set()
+    for d in PR.ROWPROG:
+        for k in (d[PR.F_RA], d[PR.F_RB]):
+            assert k < 0 or k in loaded
+        if d[PR.F_TYP] in (PR.T_FMUL, PR.T_FFROB, PR.T_FINVW, PR.T_FCOPY):
+            filled.add(d[PR.F_T])
+        if d[PR.F_TYP] == PR.T_FCOMMIT:
+            assert filled == set(range(12))
+            loaded.add(d[PR.F_LD])
+            filled = set()
+
+
 @pytest.mark.parametrize("seed", [1, 2])
-def test_three_readings_of_the_value(seed):
+def test_four_readings_of_the_value(seed):
     Pt, Q = points(seed)
     want = bn.pairing(Pt, Q)
     assert PS.simulate(Pt, Q) == want
+    assert PR.simulate_rows(Pt, Q) == want
     assert (_oracle.pairing(record(Pt, Q)[:48]) == np.array(bn.f12_to_u32(want), dtype=np.uint32)).all()
 
 
@@ -69,49 +94,56 @@ def test_generator_pairing():
     assert (_oracle.pairing(record(bn.G1, bn.G2)[:48]) == np.array(bn.f12_to_u32(bn.pairing(bn.G1, bn.G2)), dtype=np.uint32)).all()
 
 
-def test_trace_cells_follow_the_python_schedule_and_satisfy_the_program():
-    """every primary cell of the C trace equals what tools/pairing_sched.py::simulate computes for that row; every row satisfies every
+def _layout():
+    import re
+    names = "PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC SR GC A B CACC REG RES".split()
+    vals = [int(x) for x in re.search(r"AIR_PAIRING_LAYOUT_U8\[\d+\] = \{(.*?)\}", open("data/air_tables.h").read()).group(1).split(",")]
+    return dict(zip(names, vals))
+
+
+def test_trace_cells_follow_the_python_row_program_and_satisfy_the_air():
+    """every primary cell of the C trace equals what tools/pairing_rows.py::simulate_rows holds on that row; every row satisfies every
     constraint of the AIR program (orc_trace_check_row)"""
     Pt, Q = points(5)
     tr = _oracle.Trace(6, record(Pt, Q).reshape(1, 144))
-    assert tr.log_n == 10 and tr.num_io == 2
+    assert tr.log_n == 14 and tr.num_io == 2 and tr.width == 2716
     t = tr.array()
     assert all(tr.check_row(r) == -1 for r in range(1 << tr.log_n))
     rows = []
-    PS.simulate(Pt, Q, rows)
-    lay = dict(zip("PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC A B G REG C S0".split(),
-                   [int(x) for x in __import__("re").search(r"AIR_PAIRING_LAYOUT_U8\[\d+\] = \{(.*?)\}", open("data/air_tables.h").read()).group(1).split(",")]))
+    PR.simulate_rows(Pt, Q, rows)
+    lay = _layout()
 
-    def fq_cells(col, row, checked):
+    def fq_at(col, row, checked=False):
         if not checked:
             return sum(int(t[col + i, row]) << (16 * i) for i in range(16))
         return sum((int(t[col + 2 * i, row]) + 256 * int(t[col + 2 * i + 1, row])) << (16 * i) for i in range(16))
 
-    def f2_cells(col, row, checked=False):
-        w = 32 if checked else 16
-        return (fq_cells(col, row, checked), fq_cells(col + w, row, checked))
-
-    for r in (0, 1, 2, 3, 100, 167, 168, 169, 170, 300, PS.N_ACTIVE - 1, PS.N_ACTIVE, 511):
+    first = lambda typ: next(i for i, d in enumerate(PR.ROWPROG) if d[PR.F_TYP] == typ)
+    probe = {0, 7, 8, 9, 19, 20, 25, 31, 32, 33, first(PR.T_FINVW), first(PR.T_FINVW) + 11, first(PR.T_FINVC) + 5, first(PR.T_FFROB) + 3,
+             first(PR.T_FCOMMIT), first(PR.T_FCOMMIT) + 1, 4000, PR.N_ACTIVE - 1, PR.N_ACTIVE, 8191}
+    for r in sorted(probe):
         v = rows[r]
-        assert f2_cells(lay["TX"], r) == v["T"][0] and f2_cells(lay["TY"], r) == v["T"][1]
-        assert f2_cells(lay["QSX"], r) == v["QS"][0]
-        for i in range(6):
-            assert f2_cells(lay["A"] + 32 * i, r) == v["A"][i] and f2_cells(lay["B"] + 32 * i, r) == v["B"][i]
-            assert f2_cells(lay["G"] + 32 * i, r) == v["G"][i]
-            assert f2_cells(lay["C"] + 64 * i, r, True) == v["C"][i]
-            for k in range(PS.NREG):
-                assert f2_cells(lay["REG"] + 192 * k + 32 * i, r) == v["regs"][k][i]
-        for sl in range(5):
-            assert f2_cells(lay["S0"] + 64 * sl, r, True) == v["S"][sl]
+        assert fq_at(lay["RES"], r, True) == v["res"], r
+        assert [fq_at(lay["GC"] + 16 * i, r) for i in range(2)] == list(v["gc"])
+        for i in range(12):
+            assert fq_at(lay["A"] + 16 * i, r) == v["A"][i] and fq_at(lay["B"] + 16 * i, r) == v["B"][i] and fq_at(lay["CACC"] + 16 * i, r) == v["cacc"][i]
+            for k in range(PR.NREG):
+                assert fq_at(lay["REG"] + 192 * k + 16 * i, r) == v["regs"][k][i]
+        for q in range(10):
+            assert fq_at(lay["SR"] + 16 * q, r) == v["S"][q // 2][q % 2]
+        assert [fq_at(lay[nm] + 16 * c, r) for nm in ("TX", "TY") for c in range(2)] == v["T"]
+        assert [fq_at(lay[nm] + 16 * c, r) for nm in ("QSX", "QSY") for c in range(2)] == v["QS"]
+        assert [fq_at(lay[nm] + 16 * c, r) for nm in ("Q1X", "Q1Y") for c in range(2)] == v["Q1"]
+        assert [fq_at(lay[nm] + 16 * c, r) for nm in ("Q2X", "Q2Y") for c in range(2)] == v["Q2N"]
     # the second block is the padding copy of the record
-    assert (t[:, 512:1024][lay["A"]:lay["A"] + 192] == t[:, :512][lay["A"]:lay["A"] + 192]).all()
+    assert (t[1:, 8192:] == t[1:, :8192])[: lay["RES"] - 1].all()
 
 
 def test_proofs_verify_with_both_readers_and_tampering_is_refused():
     cfg, pycfg = small_cfg()
     recs = np.stack([record(bn.G1, bn.G2), record(*points(7))])          # (three records, a padded block: tests/test_gpu_pairing_stark.py)
     pf = _oracle.stark_prove(6, recs, cfg)
-    assert int(pf[1]) == 6 and int(pf[2]) == 10 and int(pf[3]) == 2
+    assert int(pf[1]) == 6 and int(pf[2]) == 14 and int(pf[3]) == 2 and int(pf[4]) == 2716 and int(pf[5]) == 252
     assert _oracle.stark_verify(pf, cfg) == 0
     assert sv.verify(pf, pycfg) is None
     # a public-input word of Z, of Q: both verifiers refuse
@@ -119,11 +151,6 @@ def test_proofs_verify_with_both_readers_and_tampering_is_refused():
         bad = pf.copy()
         bad[off] ^= 1
         assert _oracle.stark_verify(bad, cfg) != 0 and sv.verify(bad, pycfg) is not None
-
-
-def test_default_configuration_proof_verifies():
-    pf = _oracle.stark_prove(6, record(*points(9)).reshape(1, 144))
-    assert _oracle.stark_verify(pf) == 0
 
 
 def test_wrong_result_is_not_provable():
@@ -162,66 +189,44 @@ def test_points_off_the_curve_or_outside_the_r_torsion_are_refused():
 
 
 # ---------------------------------------------------------------------------------------------------- AIR mutation suite
-def _layout():
-    import re
-    names = "PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC A B G REG C S0".split()
-    vals = [int(x) for x in re.search(r"AIR_PAIRING_LAYOUT_U8\[\d+\] = \{(.*?)\}", open("data/air_tables.h").read()).group(1).split(",")]
-    return dict(zip(names, vals))
+# RES is the gadget's unknown; on rows whose identity does not contain it (flag `fres` = 0: a commit, a slope CHECK -- the slope sits in SR
+# already --, the inversion's check, idle rows) it is range-checked and read by nothing.  A block's first row loads SR slot 0 from RES
+# (the first component of pi(Q).x), so what that cell held before is never read.
+FREE_CELLS = {("RES", rn) for rn in ("commit", "tangent_slope", "chord_slope", "inverse_check", "last_active", "idle", "block_last")} | {
+    ("SR_slope", "next_block_first")}
 
 
 def test_every_column_class_mutation_breaks_a_row_constraint_or_is_a_documented_free_cell():
-    """one cell of every column class is changed on every ROW TYPE of the schedule (the Frobenius row 0, a squaring row, a tangent and a
-    chord line row, the last chord, the inversion row, a Frobenius-map row, a plain product of the hard part, the last active row, an idle
-    row, the block's last row and the next block's first): a constraint of that row or of the row before must fail -- except for the cells
-    the AIR leaves FREE on purpose, listed below with the reason (they are never read: results of an idle unit, registers before their
-    first load).  The list is exhaustive: anything else undetected fails the test."""
+    """one cell of every column class is changed on every ROW TYPE of the row program (a Frobenius-of-Q row, the first product's component
+    rows, a commit, a slope witness / check, x3, y3, both line coefficients of a tangent and of a chord step, the copy of the first line,
+    the inversion's witness and check rows, a Frobenius-map row, the last active row, an idle row, the block's last row and the next
+    block's first): a constraint of that row or of the row before must fail -- except for the cells the AIR leaves FREE on purpose, listed
+    below with the reason.  The list is exhaustive: anything else undetected fails the test."""
     lay = _layout()
     Pt, Q = points(31)
     tr = _oracle.Trace(6, record(Pt, Q).reshape(1, 144))
     arr = tr.array()
     a = tr.air
-    S = PS.SCHEDULE
-    first = lambda pred: next(i for i, r in enumerate(S) if pred(r))
+    first = lambda typ, sk=None, nth=0: [i for i, d in enumerate(PR.ROWPROG) if d[PR.F_TYP] == typ and (sk is None or d[PR.F_SK] == sk)][nth]
     rows = {
-        "frob_of_q": 0,
-        "square": first(lambda r: r["fop"] == PS.F_MUL and r["gop"] == PS.G_IDLE),
-        "tangent_line": first(lambda r: r["gop"] == PS.G_TG),
-        "chord_line": first(lambda r: r["gop"] == PS.G_CH0),
-        "last_chord": first(lambda r: r["gop"] == PS.G_CH2),
-        "inverse": first(lambda r: r["fop"] == PS.F_INV),
-        "frobenius_map": first(lambda r: r["fop"] == PS.F_FROB and PS.G_CONJ_COEF[r["gc"]]),
-        "hard_part_product": PS.N_ACTIVE - 3,
-        "last_active": PS.N_ACTIVE - 1,
-        "idle": PS.N_ACTIVE + 5,
-        "block_last": 511,
-        "next_block_first": 512,
+        "frob_of_q": 2, "frob_of_q_last": 7,
+        "product": first(PR.T_FMUL, None, 5), "copy_line": first(PR.T_FCOPY, None, 3), "commit": first(PR.T_FCOMMIT),
+        "slope_witness": first(PR.T_GW, PR.SK_TANGENT), "tangent_slope": first(PR.T_GSL, PR.SK_TANGENT, 1), "chord_slope": first(PR.T_GSL, PR.SK_CHORD),
+        "x3_tangent": first(PR.T_GX3, PR.SK_TANGENT), "x3_chord": first(PR.T_GX3, PR.SK_CHORD, 1), "y3": first(PR.T_GY3, None, 1),
+        "line1": first(PR.T_GL1), "line3": first(PR.T_GL3, None, 1), "step_end": first(PR.T_GL3, None, 1),
+        "inverse_witness": first(PR.T_FINVW, None, 4), "inverse_check": first(PR.T_FINVC, None, 7), "frobenius_map": first(PR.T_FFROB, None, 9),
+        "last_active": PR.N_ACTIVE - 1, "idle": PR.N_ACTIVE + 5, "block_last": PR.ROWS - 1, "next_block_first": PR.ROWS,
     }
     prog = np.ctypeslib.as_array(a.prog, shape=(a.prog_len,))
-    cols = {"PX": lay["PX"] + 3, "PY": lay["PY"] + 1, "QX": lay["QX"] + 17, "QY": lay["QY"] + 2, "Q1X": lay["Q1X"] + 4, "Q1Y": lay["Q1Y"] + 20,
-            "Q2X": lay["Q2X"] + 1, "Q2Y": lay["Q2Y"] + 9, "TX": lay["TX"] + 5, "TY": lay["TY"] + 18, "QSX": lay["QSX"] + 2, "QSY": lay["QSY"] + 19,
-            "FXC": lay["FXC"] + 7, "FYC": lay["FYC"] + 16, "A": lay["A"] + 16 * 3 + 2, "B": lay["B"] + 16 * 6 + 1, "G": lay["G"] + 16 * 2,
-            "REG_result": lay["REG"] + 192 * PS.RESULT_REG + 16 * 5 + 3, "REG_other": lay["REG"] + 192 * 3 + 7,
-            "C": lay["C"] + 32 * 4 + 6, "S0": lay["S0"] + 5, "S1": lay["S0"] + 64 + 3, "S2": lay["S0"] + 128 + 40, "S3": lay["S0"] + 192 + 8,
-            "S4": lay["S0"] + 256 + 33, "sign_fq12": int(prog[1]), "q_fq12": int(prog[7 + 3]) + 2, "carry_fq12": int(prog[2]) + 1,
-            "carry_last_gadget": a.n_main - 1}
     q0 = int(prog[7 + 3])
-    step_rows = {"tangent_line", "chord_line", "last_chord"}
-    f_rows = {"square", "tangent_line", "chord_line", "last_chord", "frobenius_map", "hard_part_product", "last_active"}   # sC = 1: C is the result
-    free = set()
-    for rn in rows:
-        # G2 unit idle: its five results are unconstrained (range-checked only) and nothing loads them
-        if rn not in step_rows and rn not in ("frob_of_q", "next_block_first"):
-            free |= {(c, rn) for c in ("S0", "S1", "S2", "S3", "S4")}
-        # Fq12 unit idle or the inversion row's right-hand side: C is not "the result" (sC = 0) -- on the inversion row it IS constrained (A C = 1)
-        if rn not in f_rows and rn != "inverse":
-            free.add(("C", rn))
-    free |= {("S4", "frob_of_q"), ("S4", "next_block_first")}                # row 0 computes four values (pi(Q), -pi^2(Q)); the fifth slot is idle
-    # a block's FIRST row starts free: registers, T, pi(Q), -pi^2(Q) are loaded by the schedule before anything reads them
-    for c in ("Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "REG_result", "REG_other"):
-        free |= {(c, "frob_of_q"), (c, "next_block_first")}
-    # the last chord (with -pi^2(Q)) gives the last LINE; its point is not loaded into T, so x3 / y3 feed nothing -- but they are still
-    # tied to the slope by their gadgets, hence detected: nothing to list.  REG_other = register 3 may hold a dead value:
-    undetected = []
+    cols = {"PX": lay["PX"] + 3, "PY": lay["PY"] + 1, "QX": lay["QX"] + 17, "QY": lay["QY"] + 2, "Q1X": lay["Q1X"] + 4, "Q1Y": lay["Q1Y"] + 20,
+            "Q2X": lay["Q2X"] + 1, "Q2Y": lay["Q2Y"] + 9, "Q2Y_c1": lay["Q2Y"] + 19, "TX": lay["TX"] + 5, "TY": lay["TY"] + 18, "QSX": lay["QSX"] + 2,
+            "QSY": lay["QSY"] + 19, "FXC": lay["FXC"] + 7, "FYC": lay["FYC"] + 16, "GC": lay["GC"] + 16, "A": lay["A"] + 16 * 3 + 2, "B": lay["B"] + 16 * 6 + 1,
+            "CACC": lay["CACC"] + 16 * 5 + 3, "REG_result": lay["REG"] + 192 * PR.RESULT_REG + 16 * 5 + 3, "REG_other": lay["REG"] + 192 * 3 + 7,
+            "SR_slope": lay["SR"] + 5, "SR_x3": lay["SR"] + 32 + 3, "SR_y3": lay["SR"] + 64 + 17, "SR_l1": lay["SR"] + 96 + 8, "SR_l3": lay["SR"] + 128 + 20,
+            "RES": lay["RES"] + 3, "sign": int(prog[1]), "q": q0 + 2, "carry": int(prog[2]) + 1, "carry_last": a.n_main - 1}
+    free = set(FREE_CELLS)
+    undetected, listed_but_detected = [], []
     for cname, col in cols.items():
         assert 0 < col < a.n_main, (cname, col)
         for rn, r in rows.items():
@@ -230,8 +235,11 @@ def test_every_column_class_mutation_breaks_a_row_constraint_or_is_a_documented_
             arr[col, r] = old ^ 1
             seen = tr.check_row(r) != -1 or (r > 0 and tr.check_row(r - 1) != -1)
             arr[col, r] = old
-            if not seen and cname == "sign_fq12" and not arr[q0:q0 + 34, r].any():
+            if not seen and cname == "sign" and not arr[q0:q0 + 34, r].any():
                 continue                                   # the gadget's quotient is zero on this row: + 0 = - 0, the sign bit carries nothing
             if not seen and (cname, rn) not in free:
                 undetected.append((cname, rn))
-    assert not undetected, undetected
+            if seen and (cname, rn) in free:
+                listed_but_detected.append((cname, rn))
+    assert not undetected, sorted(undetected)
+    assert not listed_but_detected, listed_but_detected

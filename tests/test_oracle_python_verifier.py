@@ -36,7 +36,7 @@ def test_air_tables_parse_like_the_c_structs():
     for a in airs:
         t = None
         kind = a["kind"] + 4 * a["hardened"]
-        assert (a["n_vflag"], a["n_vconst"]) == ((len(vper["vflag"]), 192) if kind == 6 else (0, 0))
+        assert (a["n_vflag"], a["n_vconst"]) == ((len(vper["flagoff"]) - 1, 32) if kind == 6 else (0, 0))
         c = _oracle.load()
         c.orc_air_get.restype = __import__("ctypes").POINTER(_oracle.OrcAir)
         c.orc_air_get.argtypes = [__import__("ctypes").c_int, __import__("ctypes").c_uint]

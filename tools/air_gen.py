@@ -764,213 +764,227 @@ N_PERIODIC = len(PERIODICS)
 
 
 def build_pairing(mode):
-    """Z = e(P, Q): ONE optimal ate pairing per 512-row block, the statement behind `pairing_circuit(final_A, final_B)` ==
-    final_Z of the reference's BLS example (src/bin/bls_aggregation.rs:76-77), with arkworks' value (final exponent
-    lambda (p^12 - 1)/r: oracle/py/bn254.py).  The row schedule is tools/pairing_sched.py (458 active rows: Miller loop in affine
-    coordinates, easy part, ark-ec's hard-part chain); a row holds
-      * the Fq12 unit: operands A, B (unchecked cells, multiplexed from the NREG registers by the schedule's selector columns; B
-        may be the line of the same row or, on the inversion row, the result C itself), constants G (the row's Frobenius /
-        conjugation constants, cells tied to periodic columns), result C (checked): twelve gadgets
-            sum_{i+j=k} A_i B_j + xi sum_{i+j=k+6} A_i B_j + [conj^c(A_k) G_k] - sC C_k - sBC G_k = 0        (tower basis, build_fq12)
-        so that MUL / LINE rows state C = A B, the INV row A C = 1 (G = 1 there), FROB rows C_k = conj^c(A_k) G_k (B = 0 there);
-      * the G2 unit: T (the running twist point), QS (the chord's other point: Q, pi(Q) or -pi^2(Q) by the selectors), five Fq2
-        results S0..S4 = (lam, x3, y3, -lam x_P, lam x_T - y_T) on step rows, the Frobenius images of Q on row 0: ten gadgets.
-    Selector columns are VALUE-periodic (period 512, arbitrary values -- N_PERIODIC + k in flags and K_PER factors): both sides
-    interpolate them from the schedule.  Soundness of the chord rows (x_T != x_QS) rests on Q having order r: the VERIFIER checks
-    P on E, Q on E' and [r] Q = O as public conditions (oracle/stark.c), like the curve checks of the other kinds.
+    """Z = e(P, Q), the statement behind `pairing_circuit(final_A, final_B)` == final_Z of the reference's BLS example
+    (src/bin/bls_aggregation.rs:76-77), arkworks' value (final exponent lambda (p^12 - 1)/r: oracle/py/bn254.py).  NARROW layout (round
+    6b): ONE modular identity per row, 2^13 rows per pairing -- the operation schedule of tools/pairing_sched.py expanded by
+    tools/pairing_rows.py (one row per Fq component of an Fq12 product / Frobenius map / point step; 7185 active rows).  Cells:
+      REG      six Fq12 registers (12 x 16 limbs each);      A, B   the current operation's operands, multiplexed from REG by the row's
+                                                                    selectors (B may be the line of the current step, or CACC)
+      CACC     the components of the current Fq12 result as they are produced (committed to a register by an FCOMMIT row)
+      SR       the five Fq2 results of the current point step (slope, x3, y3, -lam x_P, lam x_T - y_T), T the running twist point, QS the
+               chord's other point (Q, pi(Q), -pi^2(Q) by selectors), Q1 / Q2N = pi(Q) / -pi^2(Q), P and Q constant over the block
+      GC       the row's two constants (u, v): a Frobenius coefficient with its signs folded in, or 1 for the inversion check
+      RES      the row's result (checked: 16 limbs), q / carries / sign of THE gadget
+    The gadget's identity on a row of type (tools/pairing_rows.py):
+      FMUL t   sum_{i+j=k} A_i B_j + xi sum_{i+j=k+6} A_i B_j  [component t]  - RES = 0        FINVC t: the same  - u = 0  (B = CACC)
+      FFROB t  A_(k,0) u + A_(k,1) v - RES = 0       FCOPY t  B_t - RES = 0       FINVW / GW / FCOMMIT / IDLE: nothing (RES free, range-checked)
+      GSL c    component c of  2 lam y_T - 3 x_T^2  (tangent)  /  lam (x_QS - x_T) - (y_QS - y_T)  (chord)
+      GX3 / GY3 / GL1 / GL3 / GFQ: component c of the value's defining identity, RES the unknown
+    Row types, operand selectors and loads are VALUE-PERIODIC columns (period 2^13) DERIVED from the row program: flag k on a row =
+    sum of weight [row field == value] over the flag's terms (AIR_PAIRING_FLAGDEF) -- both provers and both verifiers evaluate the same
+    table.  The VERIFIER checks P on E, Q on E' and [r] Q = O as public conditions (the chord rows are sound for Q of order r).
     IO record: P (16 u32), Q (32: x.c0, x.c1, y.c0, y.c1), Z (96: MyFq12 coefficients) = 144 words."""
+    import pairing_rows as PR
     a = Air("pairing", mode)
     a.gadgets = []
     a.group = 2
-    NR = PS.NREG
+    a.log_rows = PR.LOG_ROWS
+    NR = PR.NREG
     F2, F12 = 2 * NL, 12 * NL
-    sched = PS.SCHEDULE
-    rows = PS.ROWS
-    assert rows == ROWS_PER_IO
+    # ---- derived fields of the row descriptors: one equality per flag term ----
+    T = PR
+    rows = []
+    for r, d in enumerate(PR.ROWPROG):
+        typ, t = d[PR.F_TYP], d[PR.F_T]
+        ft = t if typ in (T.T_FMUL, T.T_FINVC) else -1
+        fk = t // 2 if typ == T.T_FFROB else -1
+        ct = t if typ == T.T_FCOPY else -1
+        lc = t if typ in (T.T_FMUL, T.T_FFROB, T.T_FINVW, T.T_FCOPY) else -1
+        sk = d[PR.F_SK]
+        gt = -1
+        if typ == T.T_GSL:
+            gt = (0 if sk == T.SK_TANGENT else 2) + t
+        elif typ == T.T_GX3:
+            gt = (4 if sk == T.SK_TANGENT else 6) + t
+        elif typ == T.T_GY3:
+            gt = 8 + t
+        elif typ == T.T_GL1:
+            gt = 10 + t
+        elif typ == T.T_GL3:
+            gt = 12 + t
+        elif typ == T.T_GFQ:
+            gt = 14 + t
+        ls = {T.T_GW: t, T.T_GX3: 2 + t, T.T_GY3: 4 + t, T.T_GL1: 6 + t, T.T_GL3: 8 + t, T.T_GFQ: t}.get(typ, -1)
+        rows.append(list(d) + [ft, fk, ct, lc, gt, ls, 1 if r == 0 else 0, 1 if r == PR.ROWS - 1 else 0])
+    (X_FT, X_FK, X_CT, X_LC, X_GT, X_LS, X_FIRST, X_LAST) = range(PR.N_FIELDS, PR.N_FIELDS + 8)
+    a.rowprog, a.n_fields = rows, PR.N_FIELDS + 8
+    a.flagdefs = []
 
-    # ---- value-periodic selector columns ----
-    def vflag(name, fn):
+    def vflag(name, terms):
+        """terms: [(field, value, weight)]"""
         a.vflag_names.append(name)
-        a.vflags.append([int(fn(r)) for r in sched])
-        return N_PERIODIC + len(a.vflags) - 1
+        a.flagdefs.append(list(terms))
+        return N_PERIODIC + len(a.flagdefs) - 1
 
-    is_f = lambda *ops: (lambda r: r["fop"] in ops)
-    is_g = lambda *ops: (lambda r: r["gop"] in ops)
-    sA = [vflag("sA%d" % k, lambda r, k=k: r["fop"] != PS.F_IDLE and r["ra"] == k) for k in range(NR)]
-    sB = [vflag("sB%d" % k, lambda r, k=k: r["fop"] == PS.F_MUL and r["rb"] == k) for k in range(NR)]
-    sBL = vflag("sBL", is_f(PS.F_LINE))
-    sBC = vflag("sBC", is_f(PS.F_INV))
-    sC = vflag("sC", is_f(PS.F_MUL, PS.F_LINE, PS.F_FROB))
-    sFR = vflag("sFR", is_f(PS.F_FROB))
-    sFS = vflag("sFS", lambda r: 0 if r["fop"] != PS.F_FROB else (-1 if PS.G_CONJ_COEF[r["gc"]] else 1))
-    ld = [vflag("ld%d" % k, lambda r, k=k: r["fop"] != PS.F_IDLE and r["rd"] == k) for k in range(NR)]
-    ldG = vflag("ldG", lambda r: r["fop"] == PS.F_IDLE and r["rd"] >= 0)
-    rd0 = [r["rd"] for r in sched if r["fop"] == PS.F_IDLE and r["rd"] >= 0]
-    assert rd0 == [sched[0]["rd"]] and sched[0]["gop"] == PS.G_FQ       # the one load from the constants: row 0
-    gTG = vflag("gTG", is_g(PS.G_TG))
-    gCHm = [vflag("gCH%d" % m, is_g(PS.G_CH0 + m)) for m in range(3)]
-    gCH = vflag("gCH", is_g(PS.G_CH0, PS.G_CH1, PS.G_CH2))
-    gST = vflag("gST", is_g(PS.G_TG, PS.G_CH0, PS.G_CH1, PS.G_CH2))
-    gFQ = vflag("gFQ", is_g(PS.G_FQ))
-    gLT = vflag("gLT", is_g(PS.G_TG, PS.G_CH0, PS.G_CH1))
-    a.n_vconst = F12
-    PG = N_PERIODIC + len(a.vflags)             # PG + j: the value of constant cell G_j on the row
+    eq = lambda f, v, w=1: [(f, v, w)]
+    sA = [vflag("sA%d" % k, eq(PR.F_RA, k)) for k in range(NR)]
+    sB = [vflag("sB%d" % k, eq(PR.F_RB, k)) for k in range(NR)]
+    sBL = vflag("sBL", eq(PR.F_BSEL, PR.B_LINE))
+    sBC = vflag("sBC", eq(PR.F_BSEL, PR.B_CACC))
+    fm = [vflag("fm%d" % t, eq(X_FT, t)) for t in range(12)]
+    ff = [vflag("ff%d" % k, eq(X_FK, k)) for k in range(6)]
+    fcp = [vflag("fcp%d" % t, eq(X_CT, t)) for t in range(12)]
+    GT = lambda *codes: [(X_GT, c, 1) for c in codes]
+    g_slT = [vflag("gslT%d" % c, GT(0 + c)) for c in range(2)]
+    g_slC = [vflag("gslC%d" % c, GT(2 + c)) for c in range(2)]
+    g_x3 = [vflag("gx3_%d" % c, GT(4 + c, 6 + c)) for c in range(2)]
+    g_x3T = [vflag("gx3T%d" % c, GT(4 + c)) for c in range(2)]
+    g_x3C = [vflag("gx3C%d" % c, GT(6 + c)) for c in range(2)]
+    g_y3 = [vflag("gy3_%d" % c, GT(8 + c)) for c in range(2)]
+    g_l1 = [vflag("gl1_%d" % c, GT(10 + c)) for c in range(2)]
+    g_l3 = [vflag("gl3_%d" % c, GT(12 + c)) for c in range(2)]
+    g_fq = [vflag("gfq%d" % t, GT(14 + t)) for t in range(8)]
+    # RES enters the identity with -1 (it is the value the other terms define) or +1 (GL1: lam x_P + RES; GFQ slot 3: conj(S1) FY + RES)
+    fres = vflag("fres", [(PR.F_TYP, T.T_FMUL, -1), (PR.F_TYP, T.T_FFROB, -1), (PR.F_TYP, T.T_FCOPY, -1), (PR.F_TYP, T.T_GX3, -1),
+                          (PR.F_TYP, T.T_GY3, -1), (PR.F_TYP, T.T_GL3, -1), (PR.F_TYP, T.T_GL1, 1)] +
+                 [(X_GT, 14 + t, -1) for t in range(6)] + [(X_GT, 20, 1), (X_GT, 21, 1)])
+    fgc = vflag("fgc", eq(PR.F_TYP, T.T_FINVC))
+    lc = [vflag("lc%d" % t, eq(X_LC, t)) for t in range(12)]
+    ld = [vflag("ld%d" % k, eq(PR.F_LD, k)) for k in range(NR)]
+    lS = [vflag("lS%d" % q, eq(X_LS, q)) for q in range(10)]
+    gCHm = [vflag("gCH%d" % m, eq(PR.F_CHM, m)) for m in range(3)]
+    ldT = vflag("ldT", eq(PR.F_END, PR.END_STEP))
+    ldFQ = vflag("ldFQ", eq(PR.F_END, PR.END_FQ))
+    vfirst = vflag("first", eq(X_FIRST, 1))
+    vlast = vflag("last", eq(X_LAST, 1))
+    a.n_vconst = F2
+    PG = N_PERIODIC + len(a.flagdefs)
+    a.gc_pairs = PR.GC_PAIRS
 
     # ---- columns ----
     for nm in ("PX", "PY"):
         a.alloc(nm, NL)
     for nm in ("QX", "QY", "Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "QSX", "QSY", "FXC", "FYC"):
         a.alloc(nm, F2)
-    for nm in ("A", "B", "G"):
+    a.alloc("SR", 5 * F2)
+    a.alloc("GC", F2)
+    for nm in ("A", "B", "CACC"):
         a.alloc(nm, F12)
     a.alloc("REG", NR * F12)
-    a.alloc_checked("C", F12 * a.cpl)
-    for sl in range(5):
-        a.alloc_checked("S%d" % sl, F2 * a.cpl)
-    for k in range(12):
-        a.declare_gadget_cols("c%d" % k, 44)
-    for sl in range(5):
-        for c in range(2):
-            a.declare_gadget_cols("s%d_%d" % (sl, c), 43)
+    a.alloc_checked("RES", NL * a.cpl)
+    a.declare_gadget_cols("g", 44)
     a.finalize_columns()
+    col = a.col
 
-    # ---- the Fq12 unit ----
-    def coef_u(nm, t, **kw):
-        tm, n = a.vec_u16(nm, **kw)
-        return [(co, b + NL * t, st, f, ng) for (co, b, st, f, ng) in tm], n
+    # ---- the gadget ----
+    def U(nm, off, flag=-1, coef=1):                    # 16 unchecked limbs at column nm + off
+        return [(coef, col(nm) + off, 1, flag, 0)], NL
 
-    def coef_c(nm, t, **kw):
-        tm, n = a.vec_chk(nm, **kw)
-        return [(co, b + NL * a.cpl * t, st, f, ng) for (co, b, st, f, ng) in tm], n
-
-    A = lambda i, c: coef_u("A", 2 * i + c)
-    B = lambda j, c: coef_u("B", 2 * j + c)
+    Av = lambda i, c, flag=-1: U("A", NL * (2 * i + c), flag)
+    Bv = lambda j, c: U("B", NL * (2 * j + c))
+    prods, lins = [], []
     for k in range(6):
         for comp in range(2):
-            prods = []
+            fl = fm[2 * k + comp]
             for i in range(6):
                 for j in range(6):
                     if i + j == k:
                         if comp == 0:
-                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1))]
+                            prods += [(1, Av(i, 0, fl), Bv(j, 0)), (-1, Av(i, 1, fl), Bv(j, 1))]
                         else:
-                            prods += [(1, A(i, 0), B(j, 1)), (1, A(i, 1), B(j, 0))]
+                            prods += [(1, Av(i, 0, fl), Bv(j, 1)), (1, Av(i, 1, fl), Bv(j, 0))]
                     elif i + j == k + 6:
                         if comp == 0:
-                            prods += [(9, A(i, 0), B(j, 0)), (-9, A(i, 1), B(j, 1)), (-1, A(i, 0), B(j, 1)), (-1, A(i, 1), B(j, 0))]
+                            prods += [(9, Av(i, 0, fl), Bv(j, 0)), (-9, Av(i, 1, fl), Bv(j, 1)), (-1, Av(i, 0, fl), Bv(j, 1)), (-1, Av(i, 1, fl), Bv(j, 0))]
                         else:
-                            prods += [(1, A(i, 0), B(j, 0)), (-1, A(i, 1), B(j, 1)), (9, A(i, 0), B(j, 1)), (9, A(i, 1), B(j, 0))]
-            # FROB rows: (a0 + s a1 u)(g0 + g1 u), s = sFS = +-1
-            if comp == 0:
-                prods += [(1, A(k, 0), coef_u("G", 2 * k, flag=sFR)), (-1, A(k, 1), coef_u("G", 2 * k + 1, flag=sFS))]
-            else:
-                prods += [(1, A(k, 0), coef_u("G", 2 * k + 1, flag=sFR)), (1, A(k, 1), coef_u("G", 2 * k, flag=sFS))]
-            t = 2 * k + comp
-            a.gadget("c%d" % t, prods, [(-1, coef_c("C", t, flag=sC)), (-1, coef_u("G", t, flag=sBC))], 44)
-
-    # ---- the G2 unit ----
-    def u2(nm):                      # unchecked Fq2 value: (component, coef, flag) -> vector
-        return lambda c, coef=1, flag=-1: ([(coef, a.col(nm) + NL * c, 1, flag, 0)], NL)
-
-    def fq_as_f2(nm):                # an Fq value x as the Fq2 element (x, 0): component 1 has no terms
-        return lambda c, coef=1, flag=-1: ([(coef, a.col(nm), 1, flag, 0)] if c == 0 else [], NL)
-
-    def c2(nm):                      # checked Fq2 value
-        def f(c, coef=1, flag=-1):
-            b = a.col(nm) + NL * a.cpl * c
-            if a.cpl == 1:
-                return [(coef, b, 1, flag, 0)], NL
-            return [(coef, b, 2, flag, 0), (coef * 256, b + 1, 2, flag, 0)], NL
-        return f
-
-    def lc(*terms):
-        return lambda c, coef=1, flag=-1: Air.vsum(*[fn(c, coef * k, flag) for k, fn in terms])
-
-    def f2prod(coef, fa, fb, flag, conj=False):
-        """{component: [(coef, vecA, vecB)]} of coef * fa * fb (fa conjugated first if conj); the flag sits on fa"""
-        s = -1 if conj else 1
-        out = {0: [(coef, fa(0, 1, flag), fb(0)), (-coef * s, fa(1, 1, flag), fb(1))],
-               1: [(coef, fa(0, 1, flag), fb(1)), (coef * s, fa(1, 1, flag), fb(0))]}
-        return {c: [(co, va, vb) for co, va, vb in v if va[0] and vb[0]] for c, v in out.items()}
-
-    LAM, X3, Y3, L1N, L3 = (c2("S%d" % sl) for sl in range(5))
-    TX, TY, QSX, QSY, QX, QY, FXC, FYC = (u2(nm) for nm in ("TX", "TY", "QSX", "QSY", "QX", "QY", "FXC", "FYC"))
-    PXf = fq_as_f2("PX")
-    slots = [
-        # S0 = lam:  TG: 2 lam y_T - 3 x_T^2;  CH: lam (x_QS - x_T) - (y_QS - y_T);  FQ: conj(x_Q) FX - S0
-        ([f2prod(2, LAM, TY, gTG), f2prod(-3, TX, TX, gTG), f2prod(1, LAM, lc((1, QSX), (-1, TX)), gCH), f2prod(1, QX, FXC, gFQ, conj=True)],
-         [(-1, QSY, gCH), (1, TY, gCH), (-1, LAM, gFQ)]),
-        # S1 = x3:   lam^2 - x_T - x_B - x3 (x_B = x_T on tangent rows, x_QS on chord rows);  FQ: conj(y_Q) FY - S1
-        ([f2prod(1, LAM, LAM, gST), f2prod(1, QY, FYC, gFQ, conj=True)],
-         [(-1, TX, gST), (-1, TX, gTG), (-1, QSX, gCH), (-1, X3, gST), (-1, X3, gFQ)]),
-        # S2 = y3:   lam (x_T - x3) - y_T - y3;  FQ: conj(S0) FX - S2  (x of pi^2(Q))
-        ([f2prod(1, LAM, lc((1, TX), (-1, X3)), gST), f2prod(1, LAM, FXC, gFQ, conj=True)],
-         [(-1, TY, gST), (-1, Y3, gST), (-1, Y3, gFQ)]),
-        # S3 = -lam x_P:  lam x_P + S3;  FQ: conj(S1) FY + S3  (y of -pi^2(Q))
-        ([f2prod(1, LAM, PXf, gST), f2prod(1, X3, FYC, gFQ, conj=True)],
-         [(1, L1N, gST), (1, L1N, gFQ)]),
-        # S4 = lam x_T - y_T
-        ([f2prod(1, LAM, TX, gST)], [(-1, TY, gST), (-1, L3, gST)]),
-    ]
-    for sl, (prods, lins) in enumerate(slots):
-        for c in range(2):
-            pp = [p for d in prods for p in d[c]]
-            ll = [(coef, fn(c, 1, fl)) for coef, fn, fl in lins]
-            a.gadget("s%d_%d" % (sl, c), pp, ll, 43)
+                            prods += [(1, Av(i, 0, fl), Bv(j, 0)), (-1, Av(i, 1, fl), Bv(j, 1)), (9, Av(i, 0, fl), Bv(j, 1)), (9, Av(i, 1, fl), Bv(j, 0))]
+    for k in range(6):                                  # FFROB: A_(k,0) u + A_(k,1) v
+        prods += [(1, Av(k, 0, ff[k]), U("GC", 0)), (1, Av(k, 1, ff[k]), U("GC", NL))]
+    for t in range(12):                                 # FCOPY: B_t
+        lins.append((1, U("B", NL * t, fcp[t])))
+    lins.append((-1, U("GC", 0, fgc)))                  # FINVC: ... - u
+    res = a.vec_chk("RES", NL, flag=fres)               # the signed flag carries the -1 / +1
+    lins.append((1, res))
+    S = lambda s, c, flag=-1, coef=1: U("SR", F2 * s + NL * c, flag, coef)
+    Pt = lambda nm, c, flag=-1, coef=1: U(nm, NL * c, flag, coef)
+    dif = lambda va, vb: Air.vsum(va, ([(-co, b, st, f, ng) for (co, b, st, f, ng) in vb[0]], NL))
+    # slope checks
+    prods += [(2, S(0, 0, g_slT[0]), Pt("TY", 0)), (-2, S(0, 1, g_slT[0]), Pt("TY", 1)), (-3, Pt("TX", 0, g_slT[0]), Pt("TX", 0)), (3, Pt("TX", 1, g_slT[0]), Pt("TX", 1))]
+    prods += [(2, S(0, 0, g_slT[1]), Pt("TY", 1)), (2, S(0, 1, g_slT[1]), Pt("TY", 0)), (-6, Pt("TX", 0, g_slT[1]), Pt("TX", 1))]
+    dX = lambda c: dif(Pt("QSX", c), Pt("TX", c))
+    prods += [(1, S(0, 0, g_slC[0]), dX(0)), (-1, S(0, 1, g_slC[0]), dX(1))]
+    lins += [(-1, Pt("QSY", 0, g_slC[0])), (1, Pt("TY", 0, g_slC[0]))]
+    prods += [(1, S(0, 0, g_slC[1]), dX(1)), (1, S(0, 1, g_slC[1]), dX(0))]
+    lins += [(-1, Pt("QSY", 1, g_slC[1])), (1, Pt("TY", 1, g_slC[1]))]
+    # x3 = lam^2 - x_T - x_B
+    prods += [(1, S(0, 0, g_x3[0]), S(0, 0)), (-1, S(0, 1, g_x3[0]), S(0, 1)), (2, S(0, 0, g_x3[1]), S(0, 1))]
+    for c in range(2):
+        lins += [(-1, Pt("TX", c, g_x3[c])), (-1, Pt("TX", c, g_x3T[c])), (-1, Pt("QSX", c, g_x3C[c]))]
+    # y3 = lam (x_T - x3) - y_T
+    dT = lambda c: dif(Pt("TX", c), S(1, c))
+    prods += [(1, S(0, 0, g_y3[0]), dT(0)), (-1, S(0, 1, g_y3[0]), dT(1)), (1, S(0, 0, g_y3[1]), dT(1)), (1, S(0, 1, g_y3[1]), dT(0))]
+    for c in range(2):
+        lins.append((-1, Pt("TY", c, g_y3[c])))
+    # L1N: lam x_P + RES = 0;  L3 = lam x_T - y_T
+    for c in range(2):
+        prods.append((1, S(0, c, g_l1[c]), U("PX", 0)))
+    prods += [(1, S(0, 0, g_l3[0]), Pt("TX", 0)), (-1, S(0, 1, g_l3[0]), Pt("TX", 1)), (1, S(0, 0, g_l3[1]), Pt("TX", 1)), (1, S(0, 1, g_l3[1]), Pt("TX", 0))]
+    for c in range(2):
+        lins.append((-1, Pt("TY", c, g_l3[c])))
+    # GFQ: conj(x) F: c = 0: x0 f0 + x1 f1;  c = 1: x0 f1 - x1 f0
+    for slot, (src, cst) in enumerate(((lambda c, fl: Pt("QX", c, fl), "FXC"), (lambda c, fl: Pt("QY", c, fl), "FYC"),
+                                       (lambda c, fl: S(0, c, fl), "FXC"), (lambda c, fl: S(1, c, fl), "FYC"))):
+        f0, f1 = g_fq[2 * slot], g_fq[2 * slot + 1]
+        prods += [(1, src(0, f0), Pt(cst, 0)), (1, src(1, f0), Pt(cst, 1)), (1, src(0, f1), Pt(cst, 1)), (-1, src(1, f1), Pt(cst, 0))]
+    a.gadget("g", prods, lins, 44)
     a.emit_gadgets()
 
     # ---- polynomial constraints ----
-    col = a.col
-    last = PER_LAST
-
-    def climb(name, j):              # 16-bit limb j of a checked vector as [(coef, col)]
-        b = col(name)
+    def climb(j):                    # 16-bit limb j of RES as [(coef, col)]
+        b = col("RES")
         return [(1, b + j)] if a.cpl == 1 else [(1, b + 2 * j), (256, b + 2 * j + 1)]
 
     def keep_or_load(c, loads):
-        """(1 - per_last)(next - local) - sum_f per[f] (value - local) = 0 for loads = [(flag, [(coef, col)])]; the flags are 0 on
-        a block's last row (nothing is loaded there), where the next block starts free"""
-        m = [(1, [X(c)]), (-1, [L(c)]), (-1, [PER(last), X(c)]), (1, [PER(last), L(c)])]
+        """(1 - last)(next - local) - sum_f per[f] (value - local) = 0; no load flag is set on a block's last row"""
+        m = [(1, [X(c)]), (-1, [L(c)]), (-1, [PER(vlast), X(c)]), (1, [PER(vlast), L(c)])]
         for fl, val in loads:
             m += [(1, [PER(fl), L(c)])] + [(-co, [PER(fl), L(cc)]) for co, cc in val]
         a.poly(m)
 
-    # operands
     for j in range(F12):
-        a.poly([(1, [L(col("A") + j)])] + [(-1, [PER(sA[k]), L(col("REG") + F12 * k + j)]) for k in range(NR)])
         t, l = divmod(j, NL)
+        a.poly([(1, [L(col("A") + j)])] + [(-1, [PER(sA[k]), L(col("REG") + F12 * k + j)]) for k in range(NR)])
         m = [(1, [L(col("B") + j)])] + [(-1, [PER(sB[k]), L(col("REG") + F12 * k + j)]) for k in range(NR)]
-        m += [(-co, [PER(sBC), L(cc)]) for co, cc in climb("C", j)]
-        # the line y_P - lam x_P w + (lam x_T - y_T) w^3: tower components 0 (y_P), 2 / 3 (S3), 6 / 7 (S4)
-        if t == 0:
+        m += [(-1, [PER(sBC), L(col("CACC") + j)])]
+        if t == 0:                   # the line y_P - lam x_P w + (lam x_T - y_T) w^3: tower components 0 (y_P), 2 / 3 (SR3), 6 / 7 (SR4)
             m += [(-1, [PER(sBL), L(col("PY") + l)])]
         elif t in (2, 3):
-            m += [(-co, [PER(sBL), L(cc)]) for co, cc in climb("S3", NL * (t - 2) + l)]
+            m += [(-1, [PER(sBL), L(col("SR") + F2 * 3 + NL * (t - 2) + l)])]
         elif t in (6, 7):
-            m += [(-co, [PER(sBL), L(cc)]) for co, cc in climb("S4", NL * (t - 6) + l)]
+            m += [(-1, [PER(sBL), L(col("SR") + F2 * 4 + NL * (t - 6) + l)])]
         a.poly(m)
-        a.poly([(1, [L(col("G") + j)]), (-1, [PER(PG + j)])])
-    # registers
+        keep_or_load(col("CACC") + j, [(lc[t], climb(l))])
+    for j in range(F2):
+        a.poly([(1, [L(col("GC") + j)]), (-1, [PER(PG + j)])])
     for k in range(NR):
         for j in range(F12):
-            loads = [(ld[k], climb("C", j))]
-            if k == rd0[0]:
-                loads.append((ldG, [(1, col("G") + j)]))
-            keep_or_load(col("REG") + F12 * k + j, loads)
-    # P and Q are constant over a block; T, pi(Q), -pi^2(Q) are registers of the G2 unit
+            keep_or_load(col("REG") + F12 * k + j, [(ld[k], [(1, col("CACC") + j)])])
+    for q in range(10):
+        for l in range(NL):
+            keep_or_load(col("SR") + NL * q + l, [(lS[q], climb(l))])
     for nm, n in (("PX", NL), ("PY", NL), ("QX", F2), ("QY", F2)):
         for j in range(n):
             keep_or_load(col(nm) + j, [])
     for j in range(F2):
-        keep_or_load(col("Q1X") + j, [(gFQ, climb("S0", j))])
-        keep_or_load(col("Q1Y") + j, [(gFQ, climb("S1", j))])
-        keep_or_load(col("Q2X") + j, [(gFQ, climb("S2", j))])
-        keep_or_load(col("Q2Y") + j, [(gFQ, climb("S3", j))])
-        keep_or_load(col("TX") + j, [(gLT, climb("S1", j)), (gFQ, [(1, col("QX") + j)])])
-        keep_or_load(col("TY") + j, [(gLT, climb("S2", j)), (gFQ, [(1, col("QY") + j)])])
-        for d, srcs in (("QSX", ("QX", "Q1X", "Q2X")), ("QSY", ("QY", "Q1Y", "Q2Y"))):
-            a.poly([(1, [L(col(d) + j)])] + [(-1, [PER(gCHm[m_]), L(col(srcs[m_]) + j)]) for m_ in range(3)])
-    # the twist's Frobenius constants
+        keep_or_load(col("Q1X") + j, [(ldFQ, [(1, col("SR") + F2 * 0 + j)])])
+        keep_or_load(col("Q1Y") + j, [(ldFQ, [(1, col("SR") + F2 * 1 + j)])])
+        keep_or_load(col("Q2X") + j, [(ldFQ, [(1, col("SR") + F2 * 2 + j)])])
+        # (the last GFQ row produces component 1 of -pi^2(Q).y itself: that half comes straight from RES, the SR cell takes it at the same time)
+        keep_or_load(col("Q2Y") + j, [(ldFQ, [(1, col("SR") + F2 * 3 + j)] if j < NL else climb(j - NL))])
+        keep_or_load(col("TX") + j, [(ldT, [(1, col("SR") + F2 * 1 + j)]), (ldFQ, [(1, col("QX") + j)])])
+        keep_or_load(col("TY") + j, [(ldT, [(1, col("SR") + F2 * 2 + j)]), (ldFQ, [(1, col("QY") + j)])])
+        for dst, srcs in (("QSX", ("QX", "Q1X", "Q2X")), ("QSY", ("QY", "Q1Y", "Q2Y"))):
+            a.poly([(1, [L(col(dst) + j)])] + [(-1, [PER(gCHm[m_]), L(col(srcs[m_]) + j)]) for m_ in range(3)])
     sys.path.insert(0, os.path.join(ROOT, "oracle", "py"))
     import bn254
     for nm, v in (("FXC", bn254.FROB_X), ("FYC", bn254.FROB_Y)):
@@ -984,49 +998,65 @@ def build_pairing(mode):
             for part in (0, 1):
                 ai = len(a.aux)
                 a.aux.append((word + j, part, 0, 0))
-                a.poly([(1, [PER(PER_FIRST), L(col(nm) + 2 * j + part)]), (-1, [PER(PER_FIRST), AUX(ai)])])
+                a.poly([(1, [PER(vfirst), L(col(nm) + 2 * j + part)]), (-1, [PER(vfirst), AUX(ai)])])
         word += nwords
-    res = col("REG") + F12 * PS.RESULT_REG
+    resreg = col("REG") + F12 * PR.RESULT_REG
     for sub in range(F12):
         ai = len(a.aux)
-        a.aux.append((word, 3, ROWS_PER_IO - 1, sub))
-        a.poly([(1, [PER(PER_LAST), L(res + sub)]), (-1, [PER(PER_LAST), AUX(ai)])])
+        a.aux.append((word, 3, PR.ROWS - 1, sub))
+        a.poly([(1, [PER(vlast), L(resreg + sub)]), (-1, [PER(vlast), AUX(ai)])])
     word += 96
     a.pi_per_io = word
     a.primary = dict(kind="pairing")
-    a.layout = [col(nm) for nm in ("PX", "PY", "QX", "QY", "Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "QSX", "QSY", "FXC", "FYC", "A", "B", "G",
-                                   "REG", "C", "S0")]
+    a.layout = [col(nm) for nm in ("PX", "PY", "QX", "QY", "Q1X", "Q1Y", "Q2X", "Q2Y", "TX", "TY", "QSX", "QSY", "FXC", "FYC", "SR", "GC", "A", "B",
+                                   "CACC", "REG", "RES")]
     return a
 
 
 def emit_pairing_schedule(f, prefix, a):
-    """the schedule and the constant vectors for the two trace generators; the selector columns for everybody"""
+    """the row program, the row constants and the flag definitions of the pairing AIR: for the trace generators AND the constraint side"""
+    import pairing_rows as PR
+    f.write("/* final-pairing AIR (tools/pairing_rows.py): one row descriptor per trace row of a block; fields: %s,\n"
+            "   then derived: fmul component, frobenius coefficient, copy component, CACC load, g2 identity code, SR load, first row, last row */\n"
+            % "typ t ra rb bsel gc ld sk chm end")
+    f.write("#define %s_PAIRING_LOG_ROWS %d\n#define %s_PAIRING_ROWS %d\n#define %s_PAIRING_NFIELDS %d\n#define %s_PAIRING_NREG %d\n"
+            "#define %s_PAIRING_RESULT_REG %d\n#define %s_PAIRING_ACTIVE_ROWS %d\n" % (
+                prefix, PR.LOG_ROWS, prefix, PR.ROWS, prefix, a.n_fields, prefix, PR.NREG, prefix, PR.RESULT_REG, prefix, PR.N_ACTIVE))
+    f.write("static const int8_t %s_PAIRING_ROWPROG[%d][%d] = {\n" % (prefix, PR.ROWS, a.n_fields))
+    for i in range(0, PR.ROWS, 4):
+        f.write("    " + ", ".join("{%s}" % ", ".join(map(str, r)) for r in a.rowprog[i:i + 4]) + ",\n")
+    f.write("};\n")
+    f.write("/* row constants (u, v) as 16-bit limbs: FFROB rows RES = A_(k,0) u + A_(k,1) v; FINVC component 0: u = 1 */\n")
+    f.write("#define %s_PAIRING_NGC %d\n" % (prefix, len(a.gc_pairs)))
+    f.write("static const int64_t %s_PAIRING_GC[%d][%d] = {\n" % (prefix, len(a.gc_pairs), 2 * NL))
+    for u, v in a.gc_pairs:
+        f.write("    {" + ", ".join(str((x >> (16 * l)) & 0xFFFF) for x in (u, v) for l in range(NL)) + "},\n")
+    f.write("};\n")
+    f.write("/* selector columns: %s\n   flag k on a row = sum over its terms FLAGDEF[FLAGOFF[k] .. FLAGOFF[k+1]) of weight [row field == value] */\n"
+            % " ".join(a.vflag_names))
+    flat, off = [], [0]
+    for terms in a.flagdefs:
+        flat += terms
+        off.append(len(flat))
+    f.write("#define %s_PAIRING_NVFLAG %d\n" % (prefix, len(a.flagdefs)))
+    f.write("static const int16_t %s_PAIRING_FLAGDEF[%d][3] = {%s};\n" % (prefix, len(flat), ", ".join("{%d, %d, %d}" % t for t in flat)))
+    f.write("static const int16_t %s_PAIRING_FLAGOFF[%d] = {%s};\n" % (prefix, len(off), ", ".join(map(str, off))))
+    # the operation schedule the row program was expanded from: the GPU's witness kernel walks operations, not rows (pairing.hip)
     S = PS.SCHEDULE
-    f.write("/* final-pairing AIR (tools/pairing_sched.py): per row {fq12 op (0 idle 1 mul 2 line 3 inv 4 frob), register of A, register of B,\n"
-            "   constant vector, register loaded at the end of the row, g2 op (0 idle 1 tangent 2 / 3 / 4 chord with Q / pi(Q) / -pi^2(Q) 5 frobenius of Q)} */\n")
-    f.write("#define %s_PAIRING_ROWS %d\n#define %s_PAIRING_NREG %d\n#define %s_PAIRING_RESULT_REG %d\n#define %s_PAIRING_ACTIVE_ROWS %d\n" % (
-        prefix, PS.ROWS, prefix, PS.NREG, prefix, PS.RESULT_REG, prefix, PS.N_ACTIVE))
+    f.write("/* the operation schedule (tools/pairing_sched.py): {fq12 op (0 idle 1 mul 2 line 3 inv 4 frob), register of A, register of B, constant vector,\n"
+            "   register loaded, g2 op (0 idle 1 tangent 2 / 3 / 4 chord with Q / pi(Q) / -pi^2(Q) 5 frobenius of Q)} and its constant vectors */\n")
+    f.write("#define %s_PAIRING_OPS %d\n" % (prefix, PS.ROWS))
     f.write("static const int8_t %s_PAIRING_SCHED[%d][6] = {\n" % (prefix, PS.ROWS))
     for i in range(0, PS.ROWS, 8):
         f.write("    " + ", ".join("{%d, %d, %d, %d, %d, %d}" % (r["fop"], r["ra"], r["rb"], r["gc"], r["rd"], r["gop"]) for r in S[i:i + 8]) + ",\n")
     f.write("};\n")
-    # constant vectors as 16-bit limbs in cell order (tower component t = 2 i + c, 16 limbs each); the last one is zero
     vecs = [[(g[i][c] >> (16 * l)) & 0xFFFF for i in range(6) for c in range(2) for l in range(NL)] for g in PS.G_CONSTS] + [[0] * (12 * NL)]
-    f.write("/* constant vectors: 1, conjugation, Frobenius p / p^2 / p^3, zero; whether the operand's coefficients are conjugated first */\n")
     f.write("#define %s_PAIRING_NGCONST %d\n" % (prefix, len(vecs)))
     f.write("static const int64_t %s_PAIRING_GCONST[%d][%d] = {\n" % (prefix, len(vecs), 12 * NL))
     for v in vecs:
         f.write("    {" + ", ".join(map(str, v)) + "},\n")
     f.write("};\n")
     f.write("static const int8_t %s_PAIRING_GCONJ[%d] = {%s};\n" % (prefix, len(vecs), ", ".join(map(str, PS.G_CONJ_COEF + [0]))))
-    f.write("static const int8_t %s_PAIRING_GIDX[%d] = {%s};\n" % (prefix, PS.ROWS, ", ".join(
-        str(r["gc"] if r["gc"] >= 0 else len(vecs) - 1) for r in S)))
-    f.write("/* selector columns (period %d): %s */\n" % (PS.ROWS, " ".join(a.vflag_names)))
-    f.write("#define %s_PAIRING_NVFLAG %d\n" % (prefix, len(a.vflags)))
-    f.write("static const int8_t %s_PAIRING_VFLAG[%d][%d] = {\n" % (prefix, len(a.vflags), PS.ROWS))
-    for v in a.vflags:
-        f.write("    {" + ", ".join(map(str, v)) + "},\n")
-    f.write("};\n")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1045,8 +1075,8 @@ def emit(a, f, prefix):
 def header_entry(a, prefix):
     tag = "%s_%s_%s" % (prefix, a.name, a.mode)
     g0 = a.gadgets[0]
-    vp = "%d, %s_PAIRING_VFLAG[0], %d, %s_PAIRING_GCONST[0], %s_PAIRING_GIDX" % (len(a.vflags), prefix, a.n_vconst, prefix, prefix) \
-        if a.vflags else "0, 0, 0, 0, 0"
+    vp = "%d, %s_PAIRING_ROWPROG[0], %d, %s_PAIRING_FLAGDEF[0], %s_PAIRING_FLAGOFF, %d, %s_PAIRING_GC[0], 5" % (
+        len(a.flagdefs), prefix, a.n_fields, prefix, prefix, a.n_vconst, prefix) if getattr(a, "flagdefs", None) else "0, 0, 0, 0, 0, 0, 0, 0"
     return ("    {\"%s\", %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %s_PROG, %d, %s_AUX, %d, %d, %s},\n" % (
         a.name + "_" + a.mode, {"g1": 0, "g2": 1, "fq12": 2, "mapg2": 3, "g1h": 0, "g2h": 1, "pairing": 6}[a.name], a.tbits, a.cpl, a.n_main,
         a.checked_base, a.n_checked, a.n_ops, a.n_constraints, len(a.aux), a.pi_per_io, len(a.gadgets), g0["ncl"], tag, len(a.prog), tag,
@@ -1072,18 +1102,28 @@ STRUCT = """typedef struct {
     const int32_t *aux;  /* (pi word, part, row shift, sub) per aux column -- see bind_pi in tools/air_gen.py */
     int log_rows;        /* log2 of the trace rows per IO record: 9 for the exponentiation AIRs, 3 for mapg2 */
     int hardened;        /* 1: the curve AIR with canonical x3 and the x-inequality witness (API kinds 4 / 5 = kind + 4) */
-    /* VALUE-periodic columns (period 2^log_rows, arbitrary values; index AIR_N_PERIODIC + k in VEC flags and periodic factors):
-     * k < n_vflag: selector vflag[k][row] in {-1, 0, 1};  n_vflag <= k < n_vflag + n_vconst: vconst[vconst_idx[row]][k - n_vflag] */
+    /* VALUE-periodic columns (period 2^log_rows, arbitrary values; index AIR_N_PERIODIC + k in VEC flags and periodic factors), DERIVED
+     * from a row program: k < n_vflag: selector = sum over the terms flagdef[flagoff[k] .. flagoff[k + 1]) = {field, value, weight} of
+     * weight [rowprog[row][field] == value];  n_vflag <= k < n_vflag + n_vconst: vconst[rowprog[row][vconst_field]][k - n_vflag] */
     int n_vflag;
-    const int8_t *vflag;
+    const int8_t *rowprog;      /* [2^log_rows][n_fields] */
+    int n_fields;
+    const int16_t *flagdef;     /* [][3] */
+    const int16_t *flagoff;     /* [n_vflag + 1] */
     int n_vconst;
-    const int64_t *vconst;
-    const int8_t *vconst_idx;
+    const int64_t *vconst;      /* [][n_vconst] */
+    int vconst_field;
 } air_spec_t;
 /* value of value-periodic column k (0-based) on row `row` of a block */
 static inline int64_t air_vper_value(const air_spec_t *a, int k, int row) {
-    if (k < a->n_vflag) return a->vflag[((size_t)k << a->log_rows) + (size_t)row];
-    return a->vconst[(size_t)a->vconst_idx[row] * (size_t)a->n_vconst + (size_t)(k - a->n_vflag)];
+    const int8_t *d = a->rowprog + (size_t)row * (size_t)a->n_fields;
+    if (k < a->n_vflag) {
+        int64_t v = 0;
+        for (int i = a->flagoff[k]; i < a->flagoff[k + 1]; i++)
+            if (d[a->flagdef[3 * i]] == a->flagdef[3 * i + 1]) v += a->flagdef[3 * i + 2];
+        return v;
+    }
+    return a->vconst[(size_t)d[a->vconst_field] * (size_t)a->n_vconst + (size_t)(k - a->n_vflag)];
 }
 """
 
@@ -1117,7 +1157,7 @@ def main():
                     f.write("/* hardened %s: columns of nz (x-inequality witness), cb (borrow bits), T3 (p - 1 - x3), eq, u, eqc, ng, inf, t1, v, w, NGV, cn */\n" % a.name)
                     f.write("static const int32_t %s_HARD_LAYOUT_%s_%s[13] = {%s};\n" % (prefix, a.name.upper(), a.mode.upper(), ", ".join(map(str, a.layout))))
                 if a.name == "pairing":
-                    f.write("/* columns of PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC A B G REG C S0 */\n")
+                    f.write("/* columns of PX PY QX QY Q1X Q1Y Q2X Q2Y TX TY QSX QSY FXC FYC SR GC A B CACC REG RES */\n")
                     f.write("static const int32_t %s_PAIRING_LAYOUT_%s[%d] = {%s};\n" % (prefix, a.mode.upper(), len(a.layout), ", ".join(map(str, a.layout))))
                 if a.name == "mapg2":
                     f.write("/* columns of U ONE C1 C2 C3 C4 BB e1 e2 M1 M2 XS GXS REG RES, the registers of x1 x2 x3 g(x1) g(x2) g(x3), columns of z ZV, the row type that inverts */\n")
