@@ -737,13 +737,12 @@ __global__ void __launch_bounds__(64) final_exp_kernel(const T6* __restrict__ va
 //                           result) -- consecutive lanes are consecutive rows of one column.
 // oracle/pairing.c is the CPU reading the tests compare with cell for cell.
 // =====================================================================================================================================
-enum { PV_QX, PV_QY, PV_Q1X, PV_Q1Y, PV_Q2X, PV_Q2Y, PV_TX, PV_TY, PV_FXC, PV_FYC, PV_N };
+enum { PV_QX, PV_QY, PV_FXC, PV_FYC, PV_N };
 struct PairVals {
     T6 reg[6];
     T6 A, B, G, C;
     Fq px, py;
     Fq2 pts[PV_N];
-    Fq2 S[5];
 };
 constexpr int PAIR_STEPS = 102;      // 64 tangent + 36 + 2 chord steps of the schedule
 // device copy of the schedule tables (data/air_tables.h): [512][6] int8 | gconj [8] int8 | gconst [6][192] u16 | oprow [512] i16 |
@@ -766,13 +765,51 @@ __device__ __forceinline__ void pool_put(uint32_t* __restrict__ pool, int idx, c
     o[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// ---- the point chain AHEAD of the walk (pairing_values_kernel): scratch of one level of independent Fq2 products ----
+constexpr int PAIR_NS = 104;         // PAIR_STEPS rounded up
+struct StepLevel {
+    Fq2 a[4], b[4], o[4];
+    Fq part[12];
+};
+// o[k] = a[k] * b[k], k < cnt <= 4: lanes 3 k .. 3 k + 2 take the three Karatsuba parts, two of them join.  Operands written by lane 0
+// before the call; every lane of the block calls (barriers inside)
+__device__ __forceinline__ void level_mul(StepLevel& W, uint32_t l, uint32_t cnt) {
+    __syncthreads();
+    const uint32_t k = l / 3, part = l % 3;
+    if (k < cnt) karatsuba_part(W.part[l], W.a[k], W.b[k], part);
+    __syncthreads();
+    if (k < cnt && part < 2) {
+        const Fq v = karatsuba_join(&W.part[3 * k], part);
+        (part ? W.o[k].c1 : W.o[k].c0) = v;
+    }
+    __syncthreads();
+}
+// inclusive products along an array of n <= 128 entries by 64 lanes (Hillis-Steele; seven levels of two products per lane):
+// forward: out[i] = in[0] ... in[i]; backward: out[i] = in[i] ... in[n - 1].  Returns the buffer that holds the result (b0 or b1; b0 = input)
+__device__ __forceinline__ Fq2* scan_products(Fq2* b0, Fq2* b1, uint32_t n, bool backward, uint32_t l) {
+    Fq2 *src = b0, *dst = b1;
+    for (uint32_t d = 1; d < n; d <<= 1) {
+        for (uint32_t i = l; i < n; i += 64) {
+            const bool has = backward ? i + d < n : i >= d;
+            if (has) f2_mul(dst[i], src[i], src[backward ? i + d : i - d]);
+            else dst[i] = src[i];
+        }
+        __syncthreads();
+        Fq2* t = src; src = dst; dst = t;
+    }
+    return src;
+}
+
 // pools: [num_io][PP_N][8] u32, zeroed by the caller (rows without a result read zero); mode 1: values only, Z written into the record
 __global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict__ ios, uint32_t num_io, const uint8_t* __restrict__ tab,
                                                            uint32_t* __restrict__ pools, int mode, int* __restrict__ err) {
     __shared__ PairVals V;
     __shared__ CoopScratch64 sc;
     __shared__ int s_bad;
-    __shared__ Fq2 s_num[PAIR_STEPS], s_den[PAIR_STEPS], s_pre[PAIR_STEPS];     // the steps' slopes (see below): 19.6 KB
+    // the 102 point steps' values, produced AHEAD of the walk (see below): slope, x3, y3, -lam x_P, lam x_T - y_T; 8 x 6.5 KB
+    __shared__ Fq2 a_lam[PAIR_NS], a_den[PAIR_NS], a_x[PAIR_NS], a_y[PAIR_NS], a_p0[PAIR_NS], a_p1[PAIR_NS], a_q0[PAIR_NS], a_q1[PAIR_NS];
+    __shared__ Fq2 s_frob[4], s_inv;
+    static_assert(sizeof(StepLevel) <= sizeof(CoopScratch64), "the level scratch lives in the product scratch");
     const uint32_t l = threadIdx.x;
     const uint32_t io = blockIdx.x;
     if (io >= num_io) return;
@@ -786,7 +823,6 @@ __global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict
         V.py = load_words_mont(rec + 8);
         V.pts[PV_QX] = Fq2{load_words_mont(rec + 16), load_words_mont(rec + 24)};
         V.pts[PV_QY] = Fq2{load_words_mont(rec + 32), load_words_mont(rec + 40)};
-        for (int i = PV_Q1X; i < PV_FXC; i++) V.pts[i] = zero2;
         V.pts[PV_FXC] = pairing_k::GAMMA[0][2];
         V.pts[PV_FYC] = pairing_k::GAMMA[0][3];
         // y^2 = x^3 + 3 ;  (9 + u)(y^2 - x^3) = 3
@@ -828,127 +864,164 @@ __global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict
         for (int e = l; e < 2 * AIR_PAIRING_NGC; e += 64)
             for (int i = 0; i < 8; i++) pool[(size_t)(PP_GC + e) * 8 + i] = (uint32_t)gcs[16 * e + 2 * i] | ((uint32_t)gcs[16 * e + 2 * i + 1] << 16);
     }
-    // ---- the 102 affine slopes AHEAD of the walk, with ONE inversion: the point chain in homogeneous coordinates (no inversion per
-    // step; slope of step s = N_s / D_s with N = 3 X^2, D = 2 Y Z for a tangent, N = y_Q Z - Y, D = x_Q Z - X for a chord), then
-    // Montgomery's trick over the D_s.  An inversion per step (binary gcd on one lane, ~90 us) made 10 of the kernel's 18.5 ms.
-    if (l == 0) {
+    // ---- the 102 point steps AHEAD of the walk.  (a) The point chain in homogeneous coordinates, no inversion: slope of step s =
+    // N_s / D_s with N = 3 X^2, D = 2 Y Z for a tangent, N = y_Q Z - Y, D = x_Q Z - X for a chord; the independent Fq2 products of a
+    // step run level by level on 3 lanes each (4 levels for a tangent, 5 for a chord).  (b) Z_0 = 1 and Z' = D^3 Z: every 1 / Z_s is
+    // the cube of 1 / (D_0 ... D_s), so ONE inversion (of D_0 ... D_101) and two product scans give every 1 / D_s and 1 / Z_s.  (c) One
+    // lane per step: slope, affine (x3, y3) = (X', Y') / Z', the line coefficients.  On one lane with an inversion per step this was
+    // 10 of the kernel's 18.5 ms, with the batched inversion alone (round 6a) 5.6 of 8.6 ms; now 0.9.
+    {
+        StepLevel& W = *reinterpret_cast<StepLevel*>(&sc);
+        Fq2 X, Y, Z, q1x, q1y, q2x, q2y;
         const Fq2 qx = V.pts[PV_QX], qy = V.pts[PV_QY];
-        Fq2 q1x, q1y, q2x, q2y;
-        f2_mul(q1x, f2_conj(qx), V.pts[PV_FXC]);
-        f2_mul(q1y, f2_conj(qy), V.pts[PV_FYC]);
-        f2_mul(q2x, f2_conj(q1x), V.pts[PV_FXC]);
-        f2_mul(q2y, f2_conj(q1y), V.pts[PV_FYC]);
-        q2y = f2_neg(q2y);
-        Fq2 X = qx, Y = qy, Z = f2_one();
+        if (l == 0) {
+            W.a[0] = f2_conj(qx); W.b[0] = V.pts[PV_FXC];
+            W.a[1] = f2_conj(qy); W.b[1] = V.pts[PV_FYC];
+        }
+        level_mul(W, l, 2);
+        if (l == 0) {
+            q1x = W.o[0]; q1y = W.o[1];
+            W.a[0] = f2_conj(q1x); W.a[1] = f2_conj(q1y);
+        }
+        level_mul(W, l, 2);
+        if (l == 0) {
+            q2x = W.o[0]; q2y = f2_neg(W.o[1]);
+            s_frob[0] = q1x; s_frob[1] = q1y; s_frob[2] = q2x; s_frob[3] = q2y;
+            X = qx; Y = qy; Z = f2_one();
+        }
         int ns = 0;
         for (int t = 1; t < AIR_PAIRING_OPS && ns < PAIR_STEPS; t++) {
             const int gop = sched[6 * t + 5];
             if (gop < 1 || gop > 4) continue;
-            Fq2 N, D, a, b;
+            Fq2 N, D, D2, D3, U, Wv;
             if (gop == 1) {
-                f2_sqr(a, X);
-                N = fq::add(f2_dbl(a), a);
-                f2_mul(b, Y, Z);
-                D = f2_dbl(b);
-                Fq2 D2, D3, XD2, W, Z3;
-                f2_sqr(D2, D);
-                f2_mul(D3, D2, D);
-                f2_mul(XD2, X, D2);
-                f2_sqr(a, N);
-                f2_mul(a, a, Z);
-                W = fq::sub(a, f2_dbl(XD2));
-                f2_mul(a, N, fq::sub(XD2, W));
-                f2_mul(b, Y, D3);
-                f2_mul(Z3, D3, Z);
-                f2_mul(X, D, W);
-                Y = fq::sub(a, b);
-                Z = Z3;
+                if (l == 0) { W.a[0] = X; W.b[0] = X; W.a[1] = Y; W.b[1] = Z; }
+                level_mul(W, l, 2);
+                if (l == 0) {
+                    N = fq::add(f2_dbl(W.o[0]), W.o[0]);
+                    D = f2_dbl(W.o[1]);
+                    if (fq::is_zero(D)) { s_bad = 1; D = f2_one(); }      // a degenerate step (Q outside the r-torsion): no slope
+                    W.a[0] = D; W.b[0] = D; W.a[1] = N; W.b[1] = N;
+                }
+                level_mul(W, l, 2);
+                if (l == 0) {
+                    D2 = W.o[0];
+                    W.a[0] = D2; W.b[0] = D; W.a[1] = X; W.b[1] = D2; W.a[2] = W.o[1]; W.b[2] = Z;
+                }
+                level_mul(W, l, 3);
+                if (l == 0) {
+                    D3 = W.o[0];
+                    Wv = fq::sub(W.o[2], f2_dbl(W.o[1]));
+                    U = fq::sub(W.o[1], Wv);
+                    W.a[0] = N; W.b[0] = U; W.a[1] = Y; W.b[1] = D3; W.a[2] = D3; W.b[2] = Z; W.a[3] = D; W.b[3] = Wv;
+                }
+                level_mul(W, l, 4);
+                if (l == 0) {
+                    Y = fq::sub(W.o[0], W.o[1]);
+                    Z = W.o[2];
+                    X = W.o[3];
+                }
             } else {
-                const Fq2 xq = gop == 2 ? qx : gop == 3 ? q1x : q2x, yq = gop == 2 ? qy : gop == 3 ? q1y : q2y;
-                f2_mul(a, yq, Z);
-                N = fq::sub(a, Y);
-                f2_mul(a, xq, Z);
-                D = fq::sub(a, X);
-                Fq2 D2, D3, E, xqE, W, Z3;
-                f2_sqr(D2, D);
-                f2_mul(D3, D2, D);
-                f2_mul(E, D2, Z);
-                f2_mul(xqE, xq, E);
-                f2_sqr(a, N);
-                f2_mul(a, a, Z);
-                f2_mul(b, X, D2);
-                W = fq::sub(fq::sub(a, b), xqE);
-                f2_mul(Z3, D3, Z);
-                f2_mul(a, N, fq::sub(xqE, W));
-                f2_mul(b, yq, Z3);
-                f2_mul(X, D, W);
-                Y = fq::sub(a, b);
-                Z = Z3;
+                Fq2 xq, yq;
+                if (l == 0) {
+                    xq = gop == 2 ? qx : gop == 3 ? q1x : q2x;
+                    yq = gop == 2 ? qy : gop == 3 ? q1y : q2y;
+                    W.a[0] = yq; W.b[0] = Z; W.a[1] = xq; W.b[1] = Z;
+                }
+                level_mul(W, l, 2);
+                if (l == 0) {
+                    N = fq::sub(W.o[0], Y);
+                    D = fq::sub(W.o[1], X);
+                    if (fq::is_zero(D)) { s_bad = 1; D = f2_one(); }
+                    W.a[0] = D; W.b[0] = D; W.a[1] = N; W.b[1] = N;
+                }
+                level_mul(W, l, 2);
+                if (l == 0) {
+                    D2 = W.o[0];
+                    W.a[0] = D2; W.b[0] = D; W.a[1] = D2; W.b[1] = Z; W.a[2] = W.o[1]; W.b[2] = Z; W.a[3] = X; W.b[3] = D2;
+                }
+                level_mul(W, l, 4);
+                if (l == 0) {
+                    D3 = W.o[0];
+                    U = W.o[2];                      // N^2 Z
+                    Wv = W.o[3];                     // X D^2
+                    W.a[0] = xq; W.b[0] = W.o[1]; W.a[1] = D3; W.b[1] = Z;
+                }
+                level_mul(W, l, 2);
+                if (l == 0) {
+                    const Fq2 xqE = W.o[0];
+                    Z = W.o[1];
+                    Wv = fq::sub(fq::sub(U, Wv), xqE);
+                    W.a[0] = N; W.b[0] = fq::sub(xqE, Wv); W.a[1] = yq; W.b[1] = Z; W.a[2] = D; W.b[2] = Wv;
+                }
+                level_mul(W, l, 3);
+                if (l == 0) {
+                    Y = fq::sub(W.o[0], W.o[1]);
+                    X = W.o[2];
+                }
             }
-            if (fq::is_zero(D)) {          // a degenerate step (Q outside the r-torsion): no slope; keep the batch invertible
-                s_bad = 1;
-                D = f2_one();
+            if (l == 0) {
+                a_lam[ns] = N; a_den[ns] = D; a_x[ns] = X; a_y[ns] = Y;
+                a_p0[ns] = D; a_q0[ns] = D;
             }
-            s_num[ns] = N;
-            s_den[ns] = D;
             ns++;
         }
-        // prefix products, one inversion, slopes in place of the numerators
-        Fq2 acc = f2_one();
-        for (int i = 0; i < ns; i++) {
-            s_pre[i] = acc;
-            f2_mul(acc, acc, s_den[i]);
+        __syncthreads();
+        // (b) prefix and suffix products of the denominators, one inversion
+        const Fq2* pre = scan_products(a_p0, a_p1, (uint32_t)ns, false, l);
+        const Fq2* suf = scan_products(a_q0, a_q1, (uint32_t)ns, true, l);
+        if (l == 0) f2_inv(s_inv, pre[ns - 1]);
+        __syncthreads();
+        // (c) one lane per step: 1 / (D_0 ... D_s) = inv suf[s + 1]; 1 / D_s = that times D_0 ... D_(s-1); 1 / Z'_s = its cube
+        Fq2 lam[2], x3[2], y3[2];
+        for (int r = 0; r < 2; r++) {
+            const int sidx = (int)l + 64 * r;
+            if (sidx < ns) {
+                Fq2 ip = s_inv, dinv, t2;
+                if (sidx + 1 < ns) f2_mul(ip, s_inv, suf[sidx + 1]);
+                dinv = ip;
+                if (sidx > 0) f2_mul(dinv, ip, pre[sidx - 1]);
+                f2_mul(lam[r], a_lam[sidx], dinv);
+                f2_sqr(t2, ip);
+                f2_mul(t2, t2, ip);
+                f2_mul(x3[r], a_x[sidx], t2);
+                f2_mul(y3[r], a_y[sidx], t2);
+            }
         }
-        Fq2 inv;
-        f2_inv(inv, acc);
-        for (int i = ns - 1; i >= 0; i--) {
-            Fq2 di;
-            f2_mul(di, inv, s_pre[i]);                 // 1 / D_i
-            f2_mul(inv, inv, s_den[i]);
-            f2_mul(s_num[i], s_num[i], di);            // the slope of step i
+        __syncthreads();
+        for (int r = 0; r < 2; r++) {
+            const int sidx = (int)l + 64 * r;
+            if (sidx < ns) { a_lam[sidx] = lam[r]; a_x[sidx] = x3[r]; a_y[sidx] = y3[r]; }
         }
+        __syncthreads();
+        for (int r = 0; r < 2; r++) {
+            const int sidx = (int)l + 64 * r;
+            if (sidx < ns) {
+                const Fq2 tx = sidx ? a_x[sidx - 1] : qx, ty = sidx ? a_y[sidx - 1] : qy;
+                Fq2 s3, t2;
+                f2_scale(s3, lam[r], V.px);
+                f2_mul(t2, lam[r], tx);
+                a_p0[sidx] = f2_neg(s3);                 // -lam x_P
+                a_p1[sidx] = fq::sub(t2, ty);            // lam x_T - y_T
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     int step = 0;
     for (int t = 0; t < AIR_PAIRING_OPS; t++) {
         const int fop = sched[6 * t], ra = sched[6 * t + 1], rb = sched[6 * t + 2], gc = sched[6 * t + 3], rd = sched[6 * t + 4], gop = sched[6 * t + 5];
         const int gi = gc < 0 ? 0 : gc;
         if (fop == 0 && gop == 0 && rd < 0) continue;      // an idle operation (uniform over the wave)
-        // ---- (1) the G2 unit (lane 0) and the operation's constants (lanes 32 .. 43) ----
-        if (l == 0) {
-            Fq2 S0 = zero2, S1 = zero2, S2 = zero2, S3 = zero2, S4 = zero2;
-            const Fq2 tx = V.pts[PV_TX], ty = V.pts[PV_TY];
+        const int st = step < PAIR_STEPS ? step : PAIR_STEPS - 1;
+        // ---- (1) the point step's five values (from the tables above) into the pool, at the rows that produce them: slope, x3, y3,
+        // -lam x_P, lam x_T - y_T; the Frobenius images of Q on the first operation; the operation's constants (lanes 32 .. 43) ----
+        if (mode == 0 && gop != 0 && l < 10) {
             if (gop == 5) {
-                f2_mul(S0, f2_conj(V.pts[PV_QX]), V.pts[PV_FXC]);
-                f2_mul(S1, f2_conj(V.pts[PV_QY]), V.pts[PV_FYC]);
-                f2_mul(S2, f2_conj(S0), V.pts[PV_FXC]);
-                f2_mul(S3, f2_conj(S1), V.pts[PV_FYC]);
-                S3 = f2_neg(S3);
-            } else if (gop != 0) {
-                Fq2 den, xb;
-                if (gop == 1) {
-                    den = f2_dbl(ty);
-                    xb = tx;
-                } else {
-                    xb = V.pts[gop == 2 ? PV_QX : gop == 3 ? PV_Q1X : PV_Q2X];
-                    den = fq::sub(xb, tx);
-                }
-                if (fq::is_zero(den) || step >= PAIR_STEPS) {
-                    s_bad = 1;                     // a degenerate step: Q is not a point of order r (or T met +-Q): no affine slope
-                } else {
-                    Fq2 t2;
-                    S0 = s_num[step];              // = num / den, from the chain above (one batched inversion)
-                    f2_sqr(S1, S0);
-                    S1 = fq::sub(fq::sub(S1, tx), xb);
-                    f2_mul(t2, S0, fq::sub(tx, S1));
-                    S2 = fq::sub(t2, ty);
-                    f2_scale(S3, S0, V.px);
-                    S3 = f2_neg(S3);
-                    f2_mul(t2, S0, tx);
-                    S4 = fq::sub(t2, ty);
-                }
+                if (l < 8) pool_put(pool, PP_ROW + (int)l, (l & 1) ? s_frob[l >> 1].c1 : s_frob[l >> 1].c0);
+            } else {
+                const Fq2& v = l < 2 ? a_lam[st] : l < 4 ? a_x[st] : l < 6 ? a_y[st] : l < 8 ? a_p0[st] : a_p1[st];
+                pool_put(pool, PP_ROW + steprow[st] + (int)(l < 2 ? l : l + 2), (l & 1) ? v.c1 : v.c0);
             }
-            V.S[0] = S0; V.S[1] = S1; V.S[2] = S2; V.S[3] = S3; V.S[4] = S4;
         }
         if (l >= 32 && l < 44 && (fop == 4 || fop == 0)) {
             const uint32_t e = l - 32;          // Fq element e of the operation's constant vector (16-bit limbs in the table)
@@ -959,25 +1032,15 @@ __global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict
             Fq* g = reinterpret_cast<Fq*>(&V.G);
             g[e] = fq::to_mont(v);
         }
-        __syncthreads();
-        // ---- the step's five values into the pool: slope, x3, y3, -lam x_P, lam x_T - y_T at the rows that produce them ----
-        if (mode == 0 && gop != 0 && l < 10) {
-            const Fq* sv = reinterpret_cast<const Fq*>(V.S);
-            if (gop == 5) {
-                if (l < 8) pool_put(pool, PP_ROW + (int)l, sv[l]);
-            } else if (step < PAIR_STEPS) {
-                pool_put(pool, PP_ROW + steprow[step] + (int)(l < 2 ? l : l + 2), sv[l]);
-            }
-        }
-        if (gop >= 1 && gop <= 4) step++;
         // ---- (2) operands ----
         if (l < 6) {
             V.A.c[l] = ra >= 0 ? V.reg[ra].c[l] : zero2;
             Fq2 b = zero2;
             if (fop == 1) b = V.reg[rb].c[l];
-            else if (fop == 2) b = l == 0 ? Fq2{V.py, fq::zero()} : l == 1 ? V.S[3] : l == 3 ? V.S[4] : zero2;
+            else if (fop == 2) b = l == 0 ? Fq2{V.py, fq::zero()} : l == 1 ? a_p0[st] : l == 3 ? a_p1[st] : zero2;
             V.B.c[l] = b;
         }
+        if (gop >= 1 && gop <= 4) step++;
         __syncthreads();
         // ---- (3) the Fq12 unit ----
         if (fop == 1 || fop == 2) {
@@ -1007,14 +1070,6 @@ __global__ void __launch_bounds__(64) pairing_values_kernel(uint32_t* __restrict
         // ---- (4) the operation's twelve results into the pool; registers ----
         if (mode == 0 && l < 12 && oprow[t] >= 0) pool_put(pool, PP_ROW + oprow[t] + (int)l, reinterpret_cast<const Fq*>(&V.C)[l]);
         if (l < 6 && rd >= 0) V.reg[rd].c[l] = fop == 0 ? V.G.c[l] : V.C.c[l];
-        if (l == 0) {
-            if (gop == 5) {
-                V.pts[PV_TX] = V.pts[PV_QX]; V.pts[PV_TY] = V.pts[PV_QY];
-                V.pts[PV_Q1X] = V.S[0]; V.pts[PV_Q1Y] = V.S[1]; V.pts[PV_Q2X] = V.S[2]; V.pts[PV_Q2Y] = V.S[3];
-            } else if (gop >= 1 && gop <= 3) {
-                V.pts[PV_TX] = V.S[1]; V.pts[PV_TY] = V.S[2];
-            }
-        }
         __syncthreads();
     }
     // ---- the result: MyFq12 coefficients c_i = a_i - 9 b_i, c_{i+6} = b_i; compared with the record (mode 0) or written into it ----
