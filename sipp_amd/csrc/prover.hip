@@ -387,7 +387,16 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
         // arithmetic: the value is the one the coefficient-wise Horner fold of oracle/air_eval.inc produces.
         uint64_t psum[2] = {0, 0};
         const int np = (int)*w++;
+        // a gadget with many products (the pairing AIR's: ~300) is cut into slices, one lane each: slice k takes the products p = k mod
+        // n_slices, slice 0 everything else of the gadget; the parts add up (the fold is linear in the products)
+        const uint32_t n_slices = (n_poly >> 31) ? (n_poly >> 8) & 0xffu : 1u, slice = (n_poly >> 31) ? n_poly & 0xffu : 0u;
         for (int p = 0; p < np; p++) {
+            if (n_slices > 1 && (uint32_t)p % n_slices != slice) {
+                w += 1;
+                w += 2 + 5 * (int)w[1];
+                w += 2 + 5 * (int)w[1];
+                continue;
+            }
             const uint64_t coef = gl::from_i64(*w++);
             uint64_t va[16], vb[16];
             w += qvec<16>(w, c, va);
@@ -411,7 +420,7 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
                 psum[ch] = gl::mad(coef, t, psum[ch]);
             }
         }
-        const int nl = (int)*w++;
+        const int nl = slice == 0 ? (int)*w++ : 0;
         for (int p = 0; p < nl; p++) {
             const uint64_t coef = gl::from_i64(*w++);
             uint64_t va[16];
@@ -419,6 +428,7 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
 #pragma unroll
             for (int ii = 0; ii < 16; ii++) e[ii] = gl::mad(coef, va[ii], e[ii]);
         }
+        if (slice == 0) {
         uint64_t q[17];
         (void)qvec<17>(qdesc, c, q);
         const uint64_t s = c.local(sign_col);
@@ -463,6 +473,7 @@ __global__ void __launch_bounds__(64) quotient_prog_kernel(QuotArgs a, int seg0)
             }
         }
         c.emit(gl::mul(s, gl::sub(s, 1)));
+        }
         // the product part of the fold (grp == 2: the generator's only setting, checked on the host)
         c.acc0 = gl::mad(a.alpha16[0], psum[0], c.acc0);
         c.acc1 = gl::mad(a.alpha16[1], psum[1], c.acc1);
@@ -1381,6 +1392,16 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
                 w += 1;
                 w += 2 + 5 * w[1];
             }
+            // many products: slices of about 40 (at most SIPP_QUOTIENT_MAX_SLICES), entries of the same offset with no constraints of their own
+            if (np > 64) {
+                const uint32_t nsl = (uint32_t)std::min<int64_t>(SIPP_QUOTIENT_MAX_SLICES, (np + 39) / 40);
+                cnt.back() = 0x80000000u | (nsl << 8);
+                for (uint32_t k = 1; k < nsl; k++) {
+                    off.push_back(off.back());
+                    cnt.push_back(0x80000000u | (nsl << 8) | k);
+                    ncons.push_back(0);
+                }
+            }
         }
         while (w < end) {  // runs of POLY ops
             off.push_back((uint32_t)(w - a->prog));
@@ -1397,9 +1418,10 @@ int sipp_k_quotient(sipp_ctx* ctx, const air_spec_t* a, uint32_t log_n, const ui
         const int ns = (int)off.size();
         q.n_seg = ns;
         n_gadget_segs = 0;
-        while (n_gadget_segs < ns && cnt[n_gadget_segs] == 0) n_gadget_segs++;
+        auto is_gadget = [](uint32_t c) { return c == 0 || (c >> 31) != 0; };
+        while (n_gadget_segs < ns && is_gadget(cnt[n_gadget_segs])) n_gadget_segs++;
         for (int g = n_gadget_segs; g < ns; g++)
-            if (cnt[g] == 0) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "quotient: gadgets must precede the polynomial constraints");
+            if (is_gadget(cnt[g])) return sipp_fail(ctx, SIPP_E_UNSUPPORTED, "quotient: gadgets must precede the polynomial constraints");
         std::vector<uint64_t> host((size_t)ns * 2 + ns + 2 + 192, 0);      // + [2][64][3] u32: limbs of alpha_c^e, e < 64
         int after = 0;
         for (int g = ns - 1; g >= 0; g--) {

@@ -27,6 +27,8 @@ int sipp_k_openings(sipp_ctx* ctx, const uint64_t* d_coeffs, size_t ncols, size_
                     const uint64_t* d_t1, uint64_t* d_out);
 // (scratch of the grouped form: at most SIPP_OPENINGS_MAX_SEGS x 4 words per column -- sipp_workspace_bytes_cfg counts them)
 constexpr size_t SIPP_OPENINGS_MAX_SEGS = 32;
+// a gadget of more than 64 products is evaluated by up to this many lanes per quotient point (prover.hip: slices of its product list)
+constexpr int SIPP_QUOTIENT_MAX_SLICES = 8;
 int sipp_k_openings3(sipp_ctx* ctx, const uint64_t* const d_coeffs[3], const uint32_t ncols[3], size_t n, const uint64_t* d_t0,
                      const uint64_t* d_t1, uint64_t* d_out);
 int sipp_k_fri_final(sipp_ctx* ctx, const uint64_t* const src[3], const int cnt[3], size_t n, const uint32_t* d_apow3,

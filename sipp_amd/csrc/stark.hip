@@ -599,7 +599,8 @@ size_t sipp_workspace_bytes_cfg(int kind, size_t num_io, const sipp_stark_config
     size_t words = n * (2 * W + 3 * P)                                  // trace values + coefficients, Z values (x2) + coefficients
                    + m * (W + P + Q + 2 + (size_t)s.air->n_aux)         // LDEs, quotient values, public-input LDEs
                    + 3 * 8 * m                                          // three Merkle trees
-                   + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2)  // quotient segment partials
+                   + 2 * m * (1 + (size_t)s.air->n_gadgets + (size_t)s.air->n_constraints / 64 + 2 +
+                              (kind == SIPP_PAIRING ? SIPP_QUOTIENT_MAX_SLICES : 0))  // quotient segment partials (+ the slices of a many-product gadget)
                    + (sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) > 1                 // thin QUOTIENT domains (2N points, whatever
                           ? (size_t)sipp_quotient_rest_chunks(s.log_n, s.air->n_checked) * 6 * 2 * n : 0)   // the blowup): ranges x 6 sums
                    + (W + P + Q) * SIPP_OPENINGS_MAX_SEGS * 4               // partial sums of the grouped openings

@@ -845,6 +845,11 @@ struct GadgetArgs {
     // the AIR's selector columns (flags AIR_N_PERIODIC + k of a VEC): [n_vflag][2^log_rows] int8, values -1 / 0 / 1 (the pairing AIR)
     const int8_t* vflag;
     uint32_t rows_mask, log_rows;
+    // a gadget of MANY products (the pairing AIR's ~300, a dozen of them live on a row): gadget_products_kernel sums them with one WAVE
+    // per row -- prod_off[p] = word offset of product p, prod_off[np] = of what follows the products -- into esum [n][32]
+    const uint32_t* prod_off;
+    int64_t* esum;
+    int np;
 };
 
 // limb vector with a STATIC number of limbs (16 for operands, 17 for the quotient: fixed by tools/air_gen.py): the limbs
@@ -897,7 +902,13 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
     int64_t e[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) e[i] = 0;
-    const int np = (int)*w++;
+    int np = (int)*w++;
+    if (g.esum) {                    // the products are summed already (gadget_products_kernel)
+#pragma unroll
+        for (int i = 0; i < 31; i++) e[i] = g.esum[row * 32 + (size_t)i];
+        w = g.prog + g.prod_off[np];
+        np = 0;
+    }
     for (int p = 0; p < np; p++) {
         const int64_t coef = *w++;
         int32_t va[16], vb[16];
@@ -1007,6 +1018,50 @@ __global__ void __launch_bounds__(64) gadget_rows_kernel(GadgetArgs g, uint64_t*
                 cprev = ck;
             }
         }
+    }
+    if (bad) atomicExch(err, SIPP_E_WITNESS);
+}
+
+// one WAVE per row: lane l takes the products l, l + 64, ... of the row's (single) gadget -- almost all of them are switched off by the
+// row's selectors and cost a flag lookup --, the 31 coefficient sums are added up across the wave
+__global__ void __launch_bounds__(64) gadget_products_kernel(GadgetArgs g, const uint64_t* __restrict__ tr, size_t n, int* __restrict__ err) {
+    const size_t row = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    int per[AIR_N_PERIODIC];
+    for (int k = 0; k < AIR_N_PERIODIC; k++) per[k] = (int)(row % (size_t)AIR_PERIODIC[k][0]) == AIR_PERIODIC[k][1];
+    bool bad = false;
+    int64_t e[31];
+#pragma unroll
+    for (int i = 0; i < 31; i++) e[i] = 0;
+    for (int p = (int)lane; p < g.np; p += 64) {
+        const int64_t* w = g.prog + g.prod_off[p];
+        const int64_t coef = *w++;
+        int32_t va[16], vb[16];
+        w += ivec_dev<16>(w, tr, n, row, per, g, va, bad);
+        bool live = false;
+#pragma unroll
+        for (int i = 0; i < 16; i++) live |= va[i] != 0;
+        if (!live) continue;
+        (void)ivec_dev<16>(w, tr, n, row, per, g, vb, bad);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int64_t a64 = coef * va[i];
+            const int32_t ai = (int32_t)a64;
+            bad |= a64 != (int64_t)ai;
+#pragma unroll
+            for (int j = 0; j < 16; j++) e[i + j] += (int64_t)ai * vb[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 31; i++) {
+        long long v = e[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        e[i] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 31; i++) g.esum[row * 32 + (size_t)i] = e[i];
     }
     if (bad) atomicExch(err, SIPP_E_WITNESS);
 }
@@ -1460,6 +1515,41 @@ int sipp_trace_fill(sipp_ctx* ctx, const air_spec_t* a, const uint32_t* d_ios, u
         g.log_rows = (uint32_t)a->log_rows;
         g.rows_mask = (1u << a->log_rows) - 1;
         ProfScope ps(ctx, "trace_gadgets");
+        g.prod_off = nullptr;
+        g.esum = nullptr;
+        g.np = 0;
+        if (a->n_gadgets == 1) {
+            // the one gadget's product offsets (table 107); more than 64 products: a wave per row sums them first
+            uint64_t* pt = sipp_table_get(ctx, 107, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits);
+            if (!pt) {
+                std::vector<uint32_t> po;
+                const int64_t* w = a->prog + 7;
+                w += 2 + 5 * w[1];
+                const int64_t np = *w++;
+                for (int64_t p = 0; p < np; p++) {
+                    po.push_back((uint32_t)(w - a->prog));
+                    w += 1;
+                    w += 2 + 5 * w[1];
+                    w += 2 + 5 * w[1];
+                }
+                po.push_back((uint32_t)(w - a->prog));
+                std::vector<uint64_t> packed(po.size() / 2 + 2, 0);
+                packed[0] = (uint64_t)np;
+                memcpy(packed.data() + 1, po.data(), po.size() * 4);
+                SIPP_TRY(sipp_table_put(ctx, 107, (uint64_t)(a->kind + 8 * a->hardened), (uint64_t)a->table_bits, packed, &pt));
+            }
+            // (the count sits in the device table; re-derive it on the host from the program: cheap)
+            const int64_t* w = a->prog + 7;
+            w += 2 + 5 * w[1];
+            const int np = (int)*w;
+            if (np > 64) {
+                g.esum = arena_alloc_t<int64_t>(ctx, n * 32);
+                if (!g.esum) return SIPP_E_NOMEM;
+                g.prod_off = reinterpret_cast<const uint32_t*>(pt + 1);
+                g.np = np;
+                hipLaunchKernelGGL(gadget_products_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);
+            }
+        }
         hipLaunchKernelGGL(gadget_rows_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)a->n_gadgets), dim3(64), 0, ctx->stream, g, d_trace, n, d_err);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
