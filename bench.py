@@ -689,7 +689,7 @@ def main():
         except Exception as e:                  # noqa: BLE001
             out["map_to_g2"] = {"error": repr(e)}
         # secondary, outside the timed region: the in-circuit FINAL PAIRING of the BLS example (src/bin/bls_aggregation.rs:76-77) as a STARK
-        # obligation: the record (final_A, final_B, final_Z) of THIS instance's statement, one pairing in 512 trace rows (kind 6)
+        # obligation: the record (final_A, final_B, final_Z) of THIS instance's statement, one pairing in 2^13 trace rows (kind 6)
         try:
             if os.environ.get("SIPP_BENCH_PAIRING", "1") in ("0", ""):
                 raise RuntimeError("skipped (SIPP_BENCH_PAIRING=0)")

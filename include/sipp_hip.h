@@ -231,8 +231,8 @@ int sipp_map_to_g2_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint
  * Z = e(P, Q) with the value `plonky2_bn254_pairing::pairing::pairing` returns (src/prover_native.rs:8,20; as recalled it restates
  * arkworks' Bn254::pairing: the reduced optimal ate pairing raised to 2u(6u^2 + 3u + 1), ark-ec's final exponentiation) is compared with the device-computed one (SIPP_E_WITNESS if it
  * differs, if P / Q are off their curves, if a word is >= p, or if a step of the affine Miller loop degenerates -- Q outside the
- * r-torsion).  512 trace rows per pairing (64 tangent + 38 chord steps, the easy part, ark-ec's hard-part chain),
- * at least 1024 rows.  A VERIFIER of such a proof must check [r] Q = O besides the curve equations (oracle/stark.c does): the chord
+ * r-torsion).  2^13 trace rows per pairing, one modular identity per row (64 tangent + 38 chord steps, the easy part, ark-ec's hard-part
+ * chain: 7185 active rows), at least two blocks.  A VERIFIER of such a proof must check [r] Q = O besides the curve equations (oracle/stark.c does): the chord
  * rows are sound for points of order r only.  Generic entry points (sipp_prove, sipp_prove_async, sipp_proof_size,
  * sipp_workspace_bytes, sipp_stark_shape, sipp_trace_build, sipp_exp_outputs: Z computed and written) with kind = SIPP_PAIRING. */
 int sipp_pairing_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,

@@ -757,7 +757,6 @@ __device__ __forceinline__ Fq load_words_mont(const uint32_t* w) {
     for (int i = 0; i < 8; i++) r.l[i] = w[i];
     return fq::to_mont(r);
 }
-__device__ __forceinline__ bool f2_eq(const Fq2& a, const Fq2& b) { return fq::is_zero(fq::sub(a, b)); }
 __device__ __forceinline__ void pool_put(uint32_t* __restrict__ pool, int idx, const Fq& mont) {
     const Fq v = fq::from_mont(mont);
     uint4* o = reinterpret_cast<uint4*>(pool + (size_t)idx * 8);
