@@ -45,7 +45,8 @@ typedef enum {
     SIPP_E_SUBGROUP = -5,    /* zeta landed in the trace subgroup (starky prover.rs ensure!) */
     SIPP_E_QUOTIENT = -6,    /* constraints not satisfied: quotient has too high degree */
     SIPP_E_UNSUPPORTED = -7, /* configuration not supported by this build */
-    SIPP_E_WITNESS = -8      /* IO record not provable (point at infinity / not on curve) */
+    SIPP_E_WITNESS = -8,     /* IO record not provable (point at infinity / not on curve) */
+    SIPP_E_VERIFY = -9       /* sipp_stark_verify: the proof is not accepted (the stage is reported through `reason`) */
 } sipp_status;
 
 /* starky StarkConfig::standard_fast_config(); supported ranges in brackets */
@@ -237,6 +238,23 @@ int sipp_map_to_g2_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint
  * sipp_workspace_bytes, sipp_stark_shape, sipp_trace_build, sipp_exp_outputs: Z computed and written) with kind = SIPP_PAIRING. */
 int sipp_pairing_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64_t *proof_out, size_t proof_cap,
                        size_t *proof_len);
+/* ---- verification ----------------------------------------------------------------------------------------------------------
+ * The check of a flat proof made by any of the provers above (every kind): what starky's native `verify_stark_proof` does inside the
+ * reference's proof generators right after `prove` (starky-bn254 @ 2d46f9e, un-vendored) and what `data.verify`
+ * (src/verifier_circuit.rs:254) rests on.  HOST code (about 40 k Poseidon permutations and one evaluation of the AIR at zeta: a few
+ * milliseconds to a few tens, one core; no GPU, no ctx): header and configuration, canonical words, the PUBLIC conditions of the
+ * statement (record elements below p; points on their curves; MapToG2: the sign rule; pairing: Q of order r), the Fiat-Shamir replay,
+ * the constraints at zeta against the quotient openings, FRI (proof of work, Merkle paths of the three oracles and of every layer, the
+ * fold of every query, the final polynomial).  cfg = NULL: the default configuration.
+ * Returns SIPP_OK, SIPP_E_BADARG / SIPP_E_UNSUPPORTED, or SIPP_E_VERIFY with the stage in *reason (may be NULL):
+ *   100 header  101 kind / size  102 shape or configuration differs  103 FRI rounds  104 / 105 public-input words  106 truncated
+ *   107 zeta in the trace domain  108 a record element >= p  109 a record's point off its curve / sign rule / order of Q
+ *   110 / 111 the constraints of challenge 0 / 1 do not meet the quotient  120 FRI section  121 proof of work
+ *   122 query truncated  123 / 124 / 125 Merkle path of the trace / Z / quotient oracle  130 layer truncated  131 fold mismatch
+ *   132 Merkle path of a layer  133 final polynomial  140 trailing words  141 a word that is not a canonical field element
+ * (the oracle's verifier, oracle/stark.c, reports the same stages: tests/test_product_verifier.py compares them proof by proof). */
+int sipp_stark_verify(const uint64_t *proof, size_t len, const sipp_stark_config *cfg, int *reason);
+
 /* What the reference computes natively per message (src/bin/bls_aggregation.rs:100-104), on the device:
  *   map_ios [n][48]      (u, x, y) records for sipp_map_to_g2_prove;
  *   g2_ios  [2n][104]    (may be NULL) the G2ExpStark obligations of the cofactor clearing, h = 2p - r:

@@ -13,7 +13,7 @@ P = 2**64 - 2**32 + 1
 
 STATUS = {
     0: "SIPP_OK", -1: "SIPP_E_BADARG", -2: "SIPP_E_HIP", -3: "SIPP_E_NOMEM", -4: "SIPP_E_BUFSZ",
-    -5: "SIPP_E_SUBGROUP", -6: "SIPP_E_QUOTIENT", -7: "SIPP_E_UNSUPPORTED", -8: "SIPP_E_WITNESS",
+    -5: "SIPP_E_SUBGROUP", -6: "SIPP_E_QUOTIENT", -7: "SIPP_E_UNSUPPORTED", -8: "SIPP_E_WITNESS", -9: "SIPP_E_VERIFY",
 }
 
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "sipp_native_proof_words": (C.c_size_t, [C.c_size_t]),
     "sipp_prove_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "sipp_verify_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]),
+    "sipp_stark_verify": (C.c_int, [u64p, C.c_size_t, C.POINTER(StarkConfig), C.POINTER(C.c_int)]),
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
@@ -170,6 +171,21 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+SIPP_E_VERIFY = -9
+
+
+def stark_verify(proof, cfg=None):
+    """sipp_stark_verify: the library's own check of a flat proof (host code; no ctx, no GPU).  Returns 0 for an accepted proof, else the
+    stage that refused it (include/sipp_hip.h lists them: 110 = the constraints do not meet the quotient, 123 = a Merkle path ...).
+    Raises SippError for a call the library cannot serve (SIPP_E_BADARG / SIPP_E_UNSUPPORTED)."""
+    pf = np.ascontiguousarray(proof, dtype=np.uint64)
+    reason = C.c_int(0)
+    rc = lib().sipp_stark_verify(pf.ctypes.data_as(u64p), len(pf), C.byref(cfg) if cfg is not None else None, C.byref(reason))
+    if rc not in (0, SIPP_E_VERIFY):
+        raise SippError(rc, "sipp_stark_verify")
+    return reason.value
 
 
 def default_config():

@@ -1,0 +1,840 @@
+// sipp_amd/csrc/verify.cpp -- the VERIFIER of this library's STARK proofs: sipp_stark_verify (include/sipp_hip.h).
+//
+// What it stands for in the reference: every `*_exp_circuit` proof generator of starky-bn254 calls starky's native
+// `verify_stark_proof` on the proof it has just made (recalled), and `data.verify(proof)` of
+// src/verifier_circuit.rs:254 rests on the same checks inside the recursive verifier.  Verification is HOST work by nature --
+// about 40 k Poseidon permutations and one evaluation of the constraints at zeta, milliseconds on one core -- so this file is plain
+// C++ (no HIP, no GPU needed): the proving side stays on the device, the check of a proof does not need one.
+//
+// Same protocol as the provers (stark.hip / fri.hip), read from the proof's own words:
+//   header (16 words) | trace cap | Z cap | quotient cap | openings at zeta and g zeta | FRI (layer caps, final polynomial, PoW witness,
+//   query rounds) | public inputs (the IO records, one u32 per word)
+// The AIR is data (data/air_tables.h, the program both provers interpret); this is its evaluation over the quadratic extension.
+// Nothing here comes from oracle/: the oracle's verifier (oracle/stark.c) is the independent reading the tests hold this one against,
+// verdict by verdict and, for damaged proofs, refusal stage by refusal stage (tests/test_product_verifier.py).
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/sipp_hip.h"
+#include "air_tables.h"
+#include "gl.hpp"
+#include "host_challenger.hpp"
+
+const air_spec_t* sipp_air_get(int kind, uint32_t log_n);   // trace.hip: the AIR of an API kind at a trace length
+
+namespace {
+
+using gl::E2;
+constexpr uint64_t MAGIC = 0x5349505053544b31ULL;   // "SIPPSTK1"
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// BN254 base field on the host (4 x 64-bit limbs, Montgomery form): the PUBLIC side of a statement -- are the records' points on
+// their curves, is the pairing's Q of order r, the sign rule of the map to G2, the tower limbs of an Fq12 value.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+struct Fq {
+    uint64_t l[4];
+};
+const uint64_t BN_P[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+// r - 1 (the group order minus one): [r - 1] Q = -Q  <=>  [r] Q = O for Q != O
+const uint64_t BN_RM1[4] = {0x43e1f593f0000000ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+
+struct FqCtx {
+    uint64_t ninv;   // -p^-1 mod 2^64
+    Fq r2, one;      // 2^512 mod p, 2^256 mod p
+};
+bool fq_geq_p(const Fq& a) {
+    for (int i = 3; i >= 0; i--) {
+        if (a.l[i] > BN_P[i]) return true;
+        if (a.l[i] < BN_P[i]) return false;
+    }
+    return true;
+}
+void fq_sub_p(Fq& a) {
+    uint64_t bw = 0;
+    for (int i = 0; i < 4; i++) {
+        const u128 d = (u128)a.l[i] - BN_P[i] - bw;
+        a.l[i] = (uint64_t)d;
+        bw = (uint64_t)(d >> 64) & 1;
+    }
+}
+Fq fq_add(const Fq& a, const Fq& b) {
+    Fq r;
+    uint64_t c = 0;
+    for (int i = 0; i < 4; i++) {
+        const u128 s = (u128)a.l[i] + b.l[i] + c;
+        r.l[i] = (uint64_t)s;
+        c = (uint64_t)(s >> 64);
+    }
+    if (c || fq_geq_p(r)) fq_sub_p(r);      // p < 2^254: the sum fits 255 bits, c is always 0
+    return r;
+}
+Fq fq_sub(const Fq& a, const Fq& b) {
+    Fq r;
+    uint64_t bw = 0;
+    for (int i = 0; i < 4; i++) {
+        const u128 d = (u128)a.l[i] - b.l[i] - bw;
+        r.l[i] = (uint64_t)d;
+        bw = (uint64_t)(d >> 64) & 1;
+    }
+    if (bw) {
+        uint64_t c = 0;
+        for (int i = 0; i < 4; i++) {
+            const u128 s = (u128)r.l[i] + BN_P[i] + c;
+            r.l[i] = (uint64_t)s;
+            c = (uint64_t)(s >> 64);
+        }
+    }
+    return r;
+}
+bool fq_is_zero(const Fq& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+bool fq_eq(const Fq& a, const Fq& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+// Montgomery product a b / 2^256 (coarsely integrated operand scanning)
+Fq fq_mul(const FqCtx& k, const Fq& a, const Fq& b) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * k.ninv;
+        c = (u128)m * BN_P[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * BN_P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fq r = {{t[0], t[1], t[2], t[3]}};
+    if (t[4] || fq_geq_p(r)) fq_sub_p(r);
+    return r;
+}
+FqCtx fq_ctx() {
+    FqCtx k;
+    uint64_t x = 1;                       // Newton: x = p^-1 mod 2^64
+    for (int i = 0; i < 6; i++) x *= 2 - BN_P[0] * x;
+    k.ninv = 0 - x;
+    Fq v = {{1, 0, 0, 0}};
+    for (int i = 0; i < 256; i++) v = fq_add(v, v);
+    k.one = v;
+    for (int i = 0; i < 256; i++) v = fq_add(v, v);
+    k.r2 = v;
+    return k;
+}
+// eight u32 words (little-endian, canonical: checked before) -> Montgomery form
+Fq fq_from_words(const FqCtx& k, const uint32_t* w) {
+    Fq a;
+    for (int i = 0; i < 4; i++) a.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    return fq_mul(k, a, k.r2);
+}
+Fq fq_from_mont(const FqCtx& k, const Fq& a) {
+    const Fq one = {{1, 0, 0, 0}};
+    return fq_mul(k, a, one);
+}
+Fq fq_small(const FqCtx& k, uint64_t v) {
+    const Fq a = {{v, 0, 0, 0}};
+    return fq_mul(k, a, k.r2);
+}
+Fq fq_inv(const FqCtx& k, const Fq& a) {   // a^(p - 2)
+    uint64_t e[4] = {BN_P[0] - 2, BN_P[1], BN_P[2], BN_P[3]};
+    Fq r = k.one, b = a;
+    for (int i = 0; i < 254; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) r = fq_mul(k, r, b);
+        b = fq_mul(k, b, b);
+    }
+    return r;
+}
+bool words_canonical(const uint32_t* w) {
+    for (int q = 3; q >= 0; q--) {
+        const uint64_t v = (uint64_t)w[2 * q] | ((uint64_t)w[2 * q + 1] << 32);
+        if (v < BN_P[q]) return true;
+        if (v > BN_P[q]) return false;
+    }
+    return false;
+}
+// Fq2 = Fq[u] / (u^2 + 1)
+struct Fq2 {
+    Fq c0, c1;
+};
+Fq2 f2_add(const Fq2& a, const Fq2& b) { return Fq2{fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; }
+Fq2 f2_sub(const Fq2& a, const Fq2& b) { return Fq2{fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; }
+Fq2 f2_mul(const FqCtx& k, const Fq2& a, const Fq2& b) {
+    return Fq2{fq_sub(fq_mul(k, a.c0, b.c0), fq_mul(k, a.c1, b.c1)), fq_add(fq_mul(k, a.c0, b.c1), fq_mul(k, a.c1, b.c0))};
+}
+bool f2_is_zero(const Fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+bool f2_eq(const Fq2& a, const Fq2& b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+Fq2 f2_inv(const FqCtx& k, const Fq2& a) {
+    const Fq n = fq_inv(k, fq_add(fq_mul(k, a.c0, a.c0), fq_mul(k, a.c1, a.c1)));
+    const Fq zero = {{0, 0, 0, 0}};
+    return Fq2{fq_mul(k, a.c0, n), fq_sub(zero, fq_mul(k, a.c1, n))};
+}
+Fq2 f2_from_words(const FqCtx& k, const uint32_t* w) { return Fq2{fq_from_words(k, w), fq_from_words(k, w + 8)}; }
+// y^2 = x^3 + 3 on E(Fq)
+bool on_g1(const FqCtx& k, const Fq& x, const Fq& y) {
+    return fq_eq(fq_sub(fq_mul(k, y, y), fq_mul(k, fq_mul(k, x, x), x)), fq_small(k, 3));
+}
+// (9 + u)(y^2 - x^3) = 3 on the twist E'(Fq2): y^2 = x^3 + 3 / (9 + u)
+bool on_twist(const FqCtx& k, const Fq2& x, const Fq2& y) {
+    const Fq2 d = f2_sub(f2_mul(k, y, y), f2_mul(k, f2_mul(k, x, x), x));
+    const Fq nine = fq_small(k, 9);
+    const Fq re = fq_sub(fq_mul(k, nine, d.c0), d.c1), im = fq_add(d.c0, fq_mul(k, nine, d.c1));
+    return fq_eq(re, fq_small(k, 3)) && fq_is_zero(im);
+}
+// [r - 1] Q == -Q by affine double-and-add from the top bit (a step without an affine slope means Q is not of order r)
+bool g2_order_r(const FqCtx& k, const Fq2& qx, const Fq2& qy) {
+    Fq2 tx = qx, ty = qy;
+    const Fq three = fq_small(k, 3);
+    for (int i = 252; i >= 0; i--) {
+        Fq2 den = f2_add(ty, ty);
+        if (f2_is_zero(den)) return false;
+        Fq2 t2 = f2_mul(k, tx, tx);
+        t2 = Fq2{fq_mul(k, t2.c0, three), fq_mul(k, t2.c1, three)};
+        Fq2 lam = f2_mul(k, t2, f2_inv(k, den));
+        Fq2 x3 = f2_sub(f2_sub(f2_mul(k, lam, lam), tx), tx);
+        ty = f2_sub(f2_mul(k, lam, f2_sub(tx, x3)), ty);
+        tx = x3;
+        if ((BN_RM1[i >> 6] >> (i & 63)) & 1) {
+            den = f2_sub(qx, tx);
+            if (f2_is_zero(den)) return false;
+            lam = f2_mul(k, f2_sub(qy, ty), f2_inv(k, den));
+            x3 = f2_sub(f2_sub(f2_mul(k, lam, lam), tx), qx);
+            ty = f2_sub(f2_mul(k, lam, f2_sub(tx, x3)), ty);
+            tx = x3;
+        }
+    }
+    const Fq2 zero = Fq2{Fq{{0, 0, 0, 0}}, Fq{{0, 0, 0, 0}}};
+    return f2_eq(tx, qx) && f2_eq(ty, f2_sub(zero, qy));
+}
+// sgn0 of RFC 9380 for Fq2 (the sign rule of the map to G2: src/bin/bls_aggregation.rs:102 through map_to_g2_without_cofactor_mul)
+int f2_sgn0(const FqCtx& k, const Fq2& a) {
+    const Fq c0 = fq_from_mont(k, a.c0), c1 = fq_from_mont(k, a.c1);
+    const int s0 = (int)(c0.l[0] & 1), z0 = fq_is_zero(c0), s1 = (int)(c1.l[0] & 1);
+    return s0 | (z0 & s1);
+}
+
+int base_kind(int kind) { return kind == SIPP_G1_EXP_HARDENED ? SIPP_G1_EXP : kind == SIPP_G2_EXP_HARDENED ? SIPP_G2_EXP : kind; }
+
+// every Fq element of every record below p (the exponent of an exponentiation record may be any 256-bit value)
+bool records_canonical(int kind, const uint32_t* pis, size_t num_io) {
+    kind = base_kind(kind);
+    if (kind == SIPP_MAP_G2 || kind == SIPP_PAIRING) {
+        const size_t fe = kind == SIPP_MAP_G2 ? 6 : 18;
+        for (size_t e = 0; e < fe * num_io; e++)
+            if (!words_canonical(pis + 8 * e)) return false;
+        return true;
+    }
+    const int fe = kind == SIPP_G1_EXP ? 2 : kind == SIPP_G2_EXP ? 4 : 12;
+    const int ppi = 8 * (3 * fe + 1);
+    for (size_t io = 0; io < num_io; io++)
+        for (int e = 0; e < 3 * fe + 1; e++)
+            if (e != 2 * fe && !words_canonical(pis + io * ppi + 8 * e)) return false;
+    return true;
+}
+// the statement is about group elements (src/verifier_circuit.rs:92-124): x and offset of a G1 / G2 record on their curve, the point of
+// a MapToG2 record on the twist with the map's sign, (P, Q) of a pairing record on E / E' with Q of order r
+bool records_on_curve(const FqCtx& k, int kind, const uint32_t* pis, size_t num_io) {
+    kind = base_kind(kind);
+    for (size_t io = 0; io < num_io; io++) {
+        if (kind == SIPP_PAIRING) {
+            const uint32_t* rec = pis + io * SIPP_PAIRING_IO_WORDS;
+            if (io > 0 && memcmp(rec, rec - SIPP_PAIRING_IO_WORDS, 48 * sizeof(uint32_t)) == 0) continue;   // a padding copy of the record before
+            const Fq2 qx = f2_from_words(k, rec + 16), qy = f2_from_words(k, rec + 32);
+            if (!on_g1(k, fq_from_words(k, rec), fq_from_words(k, rec + 8)) || !on_twist(k, qx, qy) || !g2_order_r(k, qx, qy)) return false;
+        } else if (kind == SIPP_MAP_G2) {
+            const uint32_t* rec = pis + io * SIPP_MAP_G2_IO_WORDS;
+            const Fq2 u = f2_from_words(k, rec), x = f2_from_words(k, rec + 16), y = f2_from_words(k, rec + 32);
+            if (!on_twist(k, x, y) || f2_sgn0(k, u) != f2_sgn0(k, y)) return false;
+        } else if (kind == SIPP_G1_EXP) {
+            const uint32_t* rec = pis + io * SIPP_G1_IO_WORDS;
+            if (!on_g1(k, fq_from_words(k, rec), fq_from_words(k, rec + 8)) || !on_g1(k, fq_from_words(k, rec + 16), fq_from_words(k, rec + 24)))
+                return false;
+        } else if (kind == SIPP_G2_EXP) {
+            const uint32_t* rec = pis + io * SIPP_G2_IO_WORDS;
+            if (!on_twist(k, f2_from_words(k, rec), f2_from_words(k, rec + 16)) ||
+                !on_twist(k, f2_from_words(k, rec + 32), f2_from_words(k, rec + 48)))
+                return false;
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Goldilocks helpers
+// ------------------------------------------------------------------------------------------------------------------------------
+E2 e2(uint64_t c0) { return E2{c0, 0}; }
+E2 e2_from_i64(int64_t v) { return E2{gl::from_i64(v), 0}; }
+// 1 / x for every entry (Montgomery's trick; no entry is zero)
+void batch_inverse(std::vector<E2>& v) {
+    std::vector<E2> pre(v.size());
+    E2 acc = e2(1);
+    for (size_t i = 0; i < v.size(); i++) {
+        pre[i] = acc;
+        acc = gl::mul(acc, v[i]);
+    }
+    E2 inv = gl::inv(acc);
+    for (size_t i = v.size(); i-- > 0;) {
+        const E2 x = v[i];
+        v[i] = gl::mul(inv, pre[i]);
+        inv = gl::mul(inv, x);
+    }
+}
+// weights of the interpolation over the subgroup H of order 2^log_h at the point y outside H:
+//   f(y) = sum_r f(h^r) c_r,  c_r = (y^|H| - 1) / |H| * h^r / (y - h^r)
+// false when y lies in H
+bool lagrange_weights(unsigned log_h, E2 y, std::vector<E2>& c) {
+    const size_t H = (size_t)1 << log_h;
+    const uint64_t h = gl::root_of_unity(log_h);
+    c.resize(H);
+    uint64_t hr = 1;
+    for (size_t r = 0; r < H; r++) {
+        c[r] = gl::sub(y, e2(hr));
+        if (c[r].c0 == 0 && c[r].c1 == 0) return false;
+        hr = gl::mul(hr, h);
+    }
+    batch_inverse(c);
+    const E2 zh = gl::scale(gl::sub(gl::pow(y, (uint64_t)H), e2(1)), gl::inv((uint64_t)H % gl::P));
+    hr = 1;
+    for (size_t r = 0; r < H; r++) {
+        c[r] = gl::mul(gl::scale(c[r], hr), zh);
+        hr = gl::mul(hr, h);
+    }
+    return true;
+}
+
+struct Reader {
+    const uint64_t* p;
+    size_t pos, len;
+    bool bad = false;
+    const uint64_t* take(size_t n) {
+        if (bad || n > len - pos) {
+            bad = true;
+            return p;       // (never dereferenced past a check of `bad`: callers test before use or read at most what a header has)
+        }
+        const uint64_t* r = p + pos;
+        pos += n;
+        return r;
+    }
+};
+
+struct FriShape {
+    uint32_t rate_bits, cap_height, pow_bits, num_queries, pow_rule;
+    std::vector<uint32_t> arity_bits;
+};
+// FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits)
+FriShape fri_shape(const sipp_stark_config& c, unsigned degree_bits) {
+    FriShape p;
+    p.rate_bits = c.rate_bits; p.cap_height = c.cap_height; p.pow_bits = c.pow_bits; p.num_queries = c.num_queries; p.pow_rule = c.pow_rule;
+    while (degree_bits > c.final_poly_bits && degree_bits + c.rate_bits - c.arity_bits >= c.cap_height && degree_bits >= c.arity_bits &&
+           p.arity_bits.size() < 32) {
+        p.arity_bits.push_back(c.arity_bits);
+        degree_bits -= c.arity_bits;
+    }
+    return p;
+}
+
+// hash_or_noop(leaf) climbed to the cap entry the index points at
+bool merkle_ok(const uint64_t* leaf, size_t leaf_len, size_t index, const uint64_t* siblings, size_t n_siblings, const uint64_t* cap) {
+    uint64_t cur[4] = {0, 0, 0, 0};
+    if (leaf_len <= 4) memcpy(cur, leaf, leaf_len * 8);
+    else host::Challenger::hash_no_pad(leaf, leaf_len, cur);
+    for (size_t l = 0; l < n_siblings; l++) {
+        uint64_t nxt[4];
+        if ((index >> l) & 1) host::Challenger::two_to_one(siblings + 4 * l, cur, nxt);
+        else host::Challenger::two_to_one(cur, siblings + 4 * l, nxt);
+        memcpy(cur, nxt, 32);
+    }
+    return memcmp(cur, cap + 4 * (index >> n_siblings), 32) == 0;
+}
+
+void observe_ext(host::Challenger& ch, E2 v) {
+    ch.observe(v.c0);
+    ch.observe(v.c1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// the AIR program at one point of the extension field (constraint order = alpha-power order: acc <- acc alpha + c, as starky's
+// ConstraintConsumer): gadgets (32 / group coefficient equations + the booleanity of the sign), polynomial constraints, then the range
+// table (3), the permuted lookups (2 per checked column), the permutation products (2 per Z column)
+// ------------------------------------------------------------------------------------------------------------------------------
+struct Eval {
+    const E2 *local, *next, *aux, *per, *z_local, *z_next;
+    E2 lag_first, lag_last, z_last;
+    uint64_t alpha[2], beta[2], gamma[2];
+    E2 acc[2];
+    void emit(E2 v) {
+        acc[0] = gl::add(gl::scale(acc[0], alpha[0]), v);
+        acc[1] = gl::add(gl::scale(acc[1], alpha[1]), v);
+    }
+    // a limb vector of the program: sum of terms coef [flag] cells(base + i stride); returns the words read
+    size_t vec(const int64_t* w, E2* out, int& n_out) const {
+        const int n = (int)w[0], nt = (int)w[1];
+        for (int i = 0; i < n; i++) out[i] = e2(0);
+        for (int t = 0; t < nt; t++) {
+            const int64_t* tm = w + 2 + 5 * t;
+            const int base = (int)tm[1], stride = (int)tm[2], flag = (int)tm[3], neg = (int)tm[4];
+            E2 f = e2_from_i64(tm[0]);
+            if (flag >= 0) {
+                E2 pv = per[flag];
+                if (neg) pv = gl::sub(e2(1), pv);
+                f = gl::mul(f, pv);
+            }
+            for (int i = 0; i < n; i++) out[i] = gl::add(out[i], gl::mul(f, local[base + i * stride]));
+        }
+        n_out = n;
+        return 2 + 5 * (size_t)nt;
+    }
+    void program(const air_spec_t* a) {
+        const int64_t* w = a->prog;
+        const int64_t* end = a->prog + a->prog_len;
+        E2 va[17], vb[17], q[17], e[33];
+        while (w < end) {
+            if (w[0] == 1) {
+                const int sign_col = (int)w[1], cbase = (int)w[2], ncl = (int)w[3], lb = (int)w[4];
+                const int64_t coffset = w[5];
+                const int grp = (int)w[6];
+                w += 7;
+                int nq, na, nb;
+                w += vec(w, q, nq);
+                for (int k = 0; k < 33; k++) e[k] = e2(0);
+                const int np = (int)*w++;
+                for (int p = 0; p < np; p++) {
+                    const E2 coef = e2_from_i64(*w++);
+                    w += vec(w, va, na);
+                    bool live = false;
+                    for (int i = 0; i < na; i++) live = live || va[i].c0 != 0 || va[i].c1 != 0;
+                    if (!live) {              // (exactly zero operand: the product adds nothing)
+                        w += 2 + 5 * (size_t)w[1];
+                        continue;
+                    }
+                    w += vec(w, vb, nb);
+                    for (int i = 0; i < na; i++) {
+                        const E2 ai = gl::mul(coef, va[i]);
+                        for (int j = 0; j < nb; j++) e[i + j] = gl::add(e[i + j], gl::mul(ai, vb[j]));
+                    }
+                }
+                const int nl = (int)*w++;
+                for (int p = 0; p < nl; p++) {
+                    const E2 coef = e2_from_i64(*w++);
+                    w += vec(w, va, na);
+                    for (int i = 0; i < na; i++) e[i] = gl::add(e[i], gl::mul(coef, va[i]));
+                }
+                const E2 s = local[sign_col];
+                const E2 sgn = gl::sub(e2(1), gl::add(s, s));
+                E2 cprev = e2(0);
+                const int nm = 32 / grp;
+                for (int m = 0; m < nm; m++) {
+                    E2 v = e2(0);
+                    for (int t = grp - 1; t >= 0; t--) {
+                        const int k = grp * m + t;
+                        E2 qp = e2(0);
+                        for (int i = 0; i < nq; i++) {
+                            const int j = k - i;
+                            if (j >= 0 && j < 16) qp = gl::add(qp, gl::scale(q[i], (uint64_t)AIR_BN_P_LIMBS[j]));
+                        }
+                        v = gl::add(gl::scale(v, 65536), gl::sub(e[k], gl::mul(sgn, qp)));
+                    }
+                    E2 ck = e2(0);
+                    if (m < nm - 1) {
+                        for (int l = 0; l < ncl; l++) ck = gl::add(ck, gl::scale(local[cbase + m * ncl + l], ((uint64_t)1 << (lb * l)) % gl::P));
+                        ck = gl::sub(ck, e2_from_i64(coffset));
+                    }
+                    v = gl::sub(v, cprev);
+                    v = gl::add(v, gl::scale(ck, ((uint64_t)1 << (16 * grp)) % gl::P));
+                    emit(v);
+                    cprev = ck;
+                }
+                emit(gl::mul(s, gl::sub(s, e2(1))));
+            } else {
+                const int nmono = (int)w[1];
+                w += 2;
+                E2 sum = e2(0);
+                for (int m = 0; m < nmono; m++) {
+                    E2 t = e2_from_i64(*w++);
+                    const int nf = (int)*w++;
+                    for (int f = 0; f < nf; f++) {
+                        const int kind = (int)w[0], idx = (int)w[1];
+                        w += 2;
+                        t = gl::mul(t, kind == 0 ? local[idx] : kind == 1 ? next[idx] : kind == 2 ? aux[idx] : per[idx]);
+                    }
+                    sum = gl::add(sum, t);
+                }
+                emit(sum);
+            }
+        }
+    }
+    void all(const air_spec_t* a) {
+        acc[0] = acc[1] = e2(0);
+        program(a);
+        const int nm = a->n_main, nc = a->n_checked;
+        const E2 one = e2(1);
+        // range table column 0: 0, 1, ..., T - 1, T - 1, ...
+        const E2 tl = local[0], tn = next[0], d = gl::sub(tn, tl);
+        emit(gl::mul(lag_first, tl));
+        emit(gl::mul(z_last, gl::mul(d, gl::sub(d, one))));
+        emit(gl::mul(lag_last, gl::sub(tl, e2_from_i64(((int64_t)1 << a->table_bits) - 1))));
+        for (int j = 0; j < nc; j++) {
+            const E2 pin = local[nm + j], ptab = local[nm + nc + j], npin = next[nm + j], nptab = next[nm + nc + j];
+            emit(gl::mul(lag_first, gl::sub(pin, ptab)));
+            emit(gl::mul(z_last, gl::mul(gl::sub(npin, pin), gl::sub(npin, nptab))));
+        }
+        // Z' (pin + gamma)(ptab + beta) = Z (col + gamma)(table + beta), one Z per checked column per challenge
+        for (int i = 0; i < 2; i++) {
+            const E2 g = e2(gamma[i]), b = e2(beta[i]);
+            for (int j = 0; j < nc; j++) {
+                const E2 z = z_local[i * nc + j], zn = z_next[i * nc + j];
+                const E2 lhs = gl::mul(gl::add(local[a->checked_base + j], g), gl::add(tl, b));
+                const E2 rhs = gl::mul(gl::add(local[nm + j], g), gl::add(local[nm + nc + j], b));
+                emit(gl::mul(lag_first, gl::sub(z, one)));
+                emit(gl::sub(gl::mul(zn, rhs), gl::mul(z, lhs)));
+            }
+        }
+    }
+};
+
+// the 16-bit tower-basis limb `sub` (component sub / 16, limb sub % 16) of the MyFq12 value at rec[word .. word + 96):
+// component 2 i = c_i + 9 c_(i+6), component 2 i + 1 = c_(i+6)
+uint64_t tower_limb(const FqCtx& k, const uint32_t* rec, int sub) {
+    const int t = sub / 16, i = t >> 1;
+    Fq v = fq_from_words(k, rec + 8 * (i + 6));
+    if ((t & 1) == 0) v = fq_add(fq_from_words(k, rec + 8 * i), fq_mul(k, fq_small(k, 9), v));
+    v = fq_from_mont(k, v);
+    const int l = sub % 16;
+    return (v.l[l >> 2] >> (16 * (l & 3))) & 0xffff;
+}
+uint64_t aux_value(const FqCtx& k, const air_spec_t* a, const uint32_t* pis, size_t io, int ai) {
+    const int word = a->aux[4 * ai], part = a->aux[4 * ai + 1], sub = a->aux[4 * ai + 3];
+    const uint32_t* rec = pis + io * (size_t)a->pi_per_io;
+    if (part == 3) return tower_limb(k, rec + word, sub);
+    const uint32_t w = rec[word];
+    return part == 0 ? (w & 0xffffu) : part == 1 ? (w >> 16) : w;
+}
+
+int log_rows_of(int kind) { return kind == SIPP_MAP_G2 ? 3 : kind == SIPP_PAIRING ? AIR_PAIRING_LOG_ROWS : 9; }
+
+int verify(const uint64_t* proof, size_t len, const sipp_stark_config& cfg) {
+    Reader rb{proof, 0, len};
+    if (len < 16) return 100;
+    const uint64_t* h = rb.take(16);
+    if (h[0] != MAGIC) return 100;
+    for (int i = 1; i < 16; i++)
+        if (h[i] >> 32) return 100;          // every header word is a small integer: no high bits to hide a second encoding in
+    // every body word is a field element in canonical form (x + p would hash and compute like x: a second encoding of the same proof)
+    for (size_t i = 16; i < len; i++)
+        if (proof[i] >= gl::P) return 141;
+    const int kind = (int)h[1];
+    const unsigned log_n = (unsigned)h[2];
+    const size_t num_io = (size_t)h[3];
+    const int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
+    if (kind < 0 || kind > SIPP_PAIRING || log_n < 10 || log_n > 26) return 101;
+    const unsigned log_rows = (unsigned)log_rows_of(kind);
+    if (num_io != ((size_t)1 << (log_n - log_rows))) return 101;
+    const air_spec_t* a = sipp_air_get(kind, log_n);
+    if (cfg.fs_rule > 1 || cfg.lookup_rule > 1 || cfg.rate_bits < 1 || cfg.rate_bits > 3 || cfg.cap_height > 8 || cfg.arity_bits < 1 ||
+        cfg.arity_bits > 4 || cfg.num_queries < 1 || cfg.num_queries > 1024 || cfg.pow_bits > 32 || cfg.pow_rule > 1)
+        return 102;
+    if (!a || (unsigned)a->log_rows != log_rows || W != a->n_main + 2 * a->n_checked || P != 2 * a->n_checked || Q != 4 ||
+        h[7] != cfg.cap_height || h[10] != cfg.num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg.rate_bits ||
+        h[14] != cfg.arity_bits || h[15] != (uint64_t)(cfg.fs_rule | (cfg.lookup_rule << 1)))
+        return 102;
+    const size_t n = (size_t)1 << log_n;
+    const FriShape fp = fri_shape(cfg, log_n);
+    if (h[8] != fp.arity_bits.size()) return 103;
+    const size_t cap_n = (size_t)1 << cfg.cap_height;
+    const size_t n_pi = num_io * (size_t)a->pi_per_io;
+    if (len < 16 + n_pi) return 104;
+    std::vector<uint32_t> pis(n_pi ? n_pi : 1);
+    for (size_t k = 0; k < n_pi; k++) {
+        const uint64_t v = proof[len - n_pi + k];
+        if (v >> 32) return 105;
+        pis[k] = (uint32_t)v;
+    }
+    if (!records_canonical(kind, pis.data(), num_io)) return 108;
+    const FqCtx fk = fq_ctx();
+    if (!records_on_curve(fk, kind, pis.data(), num_io)) return 109;
+
+    host::Challenger ch;
+    if (cfg.fs_rule == SIPP_FS_STATEMENT) {
+        // the statement ahead of the trace cap: kind, shape, configuration, Merkle root of the records
+        const uint64_t st[16] = {(uint64_t)kind, log_n, num_io, (uint64_t)W, (uint64_t)P, (uint64_t)Q, cfg.rate_bits, cfg.cap_height,
+                                 cfg.pow_bits, cfg.arity_bits, cfg.final_poly_bits, cfg.num_queries, cfg.num_challenges,
+                                 cfg.pow_rule, (uint64_t)a->pi_per_io, cfg.lookup_rule};
+        ch.observe_many(st, 16);
+        const size_t ppi = (size_t)a->pi_per_io;
+        std::vector<uint64_t> d(num_io * 4), tmp(ppi);
+        for (size_t io = 0; io < num_io; io++) {
+            for (size_t k = 0; k < ppi; k++) tmp[k] = pis[io * ppi + k];
+            host::Challenger::hash_no_pad(tmp.data(), ppi, &d[4 * io]);
+        }
+        for (size_t cnt = num_io; cnt > 1; cnt >>= 1)
+            for (size_t i = 0; i < cnt / 2; i++) {
+                uint64_t out[4];
+                host::Challenger::two_to_one(&d[8 * i], &d[8 * i + 4], out);
+                memcpy(&d[4 * i], out, 32);
+            }
+        ch.observe_many(d.data(), 4);
+    }
+    const uint64_t* trace_cap = rb.take(cap_n * 4);
+    if (rb.bad) return 106;
+    ch.observe_many(trace_cap, cap_n * 4);
+    uint64_t beta[2], gamma[2], alpha[2];
+    for (int i = 0; i < 2; i++) {
+        beta[i] = ch.get();
+        gamma[i] = ch.get();
+        if (cfg.lookup_rule) beta[i] = gamma[i];
+    }
+    const uint64_t* z_cap = rb.take(cap_n * 4);
+    if (rb.bad) return 106;
+    ch.observe_many(z_cap, cap_n * 4);
+    alpha[0] = ch.get();
+    alpha[1] = ch.get();
+    const uint64_t* q_cap = rb.take(cap_n * 4);
+    if (rb.bad) return 106;
+    ch.observe_many(q_cap, cap_n * 4);
+    const E2 zeta = ch.get_ext();
+    const size_t n_open = (size_t)(2 * W + 2 * P + Q);
+    const uint64_t* opw = rb.take(2 * n_open);
+    if (rb.bad) return 106;
+    std::vector<E2> op(n_open);
+    for (size_t k = 0; k < n_open; k++) op[k] = E2{opw[2 * k], opw[2 * k + 1]};
+    // opened values in the order the prover observed them: local | Z | quotient at zeta, then next | Z next at g zeta
+    for (int c = 0; c < W; c++) observe_ext(ch, op[c]);
+    for (int c = 0; c < P; c++) observe_ext(ch, op[2 * W + c]);
+    for (int c = 0; c < Q; c++) observe_ext(ch, op[2 * W + 2 * P + c]);
+    for (int c = 0; c < W; c++) observe_ext(ch, op[W + c]);
+    for (int c = 0; c < P; c++) observe_ext(ch, op[2 * W + P + c]);
+
+    // ---- the constraints at zeta ----
+    const uint64_t g = gl::root_of_unity(log_n), gi = gl::inv(g);
+    const E2 zn = gl::pow(zeta, (uint64_t)n);
+    const E2 zh = gl::sub(zn, e2(1));
+    if (zh.c0 == 0 && zh.c1 == 0) return 107;
+    {
+        Eval ev;
+        const int n_vper = a->n_vflag + a->n_vconst;
+        std::vector<E2> per((size_t)AIR_N_PERIODIC + (size_t)n_vper);
+        const uint64_t ninv = gl::inv((uint64_t)n % gl::P);
+        // closed-form selectors S_(m, r0)(x) = (K / N) ((x g^-r0)^N - 1) / ((x g^-r0)^K - 1), K = N / m: 1 on the rows r = r0 mod m
+        for (int k = 0; k < AIR_N_PERIODIC; k++) {
+            const uint64_t m = (uint64_t)AIR_PERIODIC[k][0], r0 = (uint64_t)AIR_PERIODIC[k][1], K = (uint64_t)n / m;
+            const E2 y = gl::scale(zeta, gl::inv(gl::pow(g, r0)));
+            const E2 num = gl::sub(gl::pow(y, (uint64_t)n), e2(1)), den = gl::sub(gl::pow(y, K), e2(1));
+            if (den.c0 == 0 && den.c1 == 0) return 107;
+            per[k] = gl::scale(gl::mul(num, gl::inv(den)), gl::mul(K % gl::P, ninv));
+        }
+        // the AIR's value-periodic columns (the pairing AIR's selectors and row constants): column k is P_k(x^(N / R)), P_k interpolating
+        // its R values over the subgroup of order R -- evaluated through the interpolation weights at y = zeta^(N / R), one set for all
+        if (n_vper > 0) {
+            const unsigned lr = (unsigned)a->log_rows;
+            const size_t R = (size_t)1 << lr;
+            std::vector<E2> cw;
+            if (!lagrange_weights(lr, gl::pow(zeta, (uint64_t)1 << (log_n - lr)), cw)) return 107;
+            for (int kk = 0; kk < n_vper; kk++) {
+                E2 acc = e2(0);
+                for (size_t r = 0; r < R; r++) {
+                    const int64_t v = air_vper_value(a, kk, (int)r);
+                    if (v == 0) continue;
+                    acc = v == 1 ? gl::add(acc, cw[r]) : v == -1 ? gl::sub(acc, cw[r]) : gl::add(acc, gl::scale(cw[r], gl::from_i64(v)));
+                }
+                per[(size_t)AIR_N_PERIODIC + (size_t)kk] = acc;
+            }
+        }
+        // public-input polynomials: A_ai(g^(rows io + shift)) = value(io), i.e. the interpolation over the subgroup of order num_io at
+        // zeta g^-shift; one set of weights per distinct shift
+        std::vector<E2> auxz((size_t)(a->n_aux ? a->n_aux : 1));
+        {
+            const unsigned log_io = log_n - log_rows;
+            std::vector<int> shifts;
+            for (int ai = 0; ai < a->n_aux; ai++) {
+                const int sh = a->aux[4 * ai + 2];
+                bool seen = false;
+                for (int s : shifts) seen = seen || s == sh;
+                if (!seen) shifts.push_back(sh);
+            }
+            std::vector<E2> cw;
+            for (int sh : shifts) {
+                // A(x) = I(x g^-shift), I (degree < num_io) interpolating the values over the subgroup of order num_io (g^rows generates it)
+                const E2 y = gl::scale(zeta, gl::inv(gl::pow(g, (uint64_t)sh)));
+                if (!lagrange_weights(log_io, y, cw)) return 107;
+                for (int ai = 0; ai < a->n_aux; ai++) {
+                    if (a->aux[4 * ai + 2] != sh) continue;
+                    E2 acc = e2(0);
+                    for (size_t io = 0; io < num_io; io++) acc = gl::add(acc, gl::scale(cw[io], aux_value(fk, a, pis.data(), io, ai)));
+                    auxz[(size_t)ai] = acc;
+                }
+            }
+        }
+        ev.local = op.data();
+        ev.next = op.data() + W;
+        ev.aux = auxz.data();
+        ev.per = per.data();
+        ev.z_local = op.data() + 2 * W;
+        ev.z_next = op.data() + 2 * W + P;
+        // L_first, L_last, x - g^-1 (zero on the last row)
+        const E2 zhn = gl::scale(zh, ninv);
+        const E2 d_first = gl::sub(zeta, e2(1)), d_last = gl::sub(zeta, e2(gi));
+        if ((d_first.c0 == 0 && d_first.c1 == 0) || (d_last.c0 == 0 && d_last.c1 == 0)) return 107;
+        ev.lag_first = gl::mul(zhn, gl::inv(d_first));
+        ev.lag_last = gl::mul(gl::scale(zhn, gi), gl::inv(d_last));
+        ev.z_last = d_last;
+        for (int i = 0; i < 2; i++) {
+            ev.alpha[i] = alpha[i];
+            ev.beta[i] = beta[i];
+            ev.gamma[i] = gamma[i];
+        }
+        ev.all(a);
+        for (int i = 0; i < 2; i++) {
+            const E2 qz = gl::add(op[2 * W + 2 * P + 2 * i], gl::mul(zn, op[2 * W + 2 * P + 2 * i + 1]));
+            if (!gl::eq(ev.acc[i], gl::mul(zh, qz))) return 110 + i;
+        }
+    }
+
+    // ---- FRI: the batch (local | Z | quotient) opened at zeta, (local | Z) at g zeta ----
+    const E2 fa = ch.get_ext();
+    const E2 gzeta = gl::scale(zeta, g);
+    if ((size_t)h[9] != (n >> (fp.arity_bits.size() * cfg.arity_bits))) return 120;
+    const unsigned log_m = log_n + cfg.rate_bits;
+    const size_t m = (size_t)1 << log_m;
+    std::vector<const uint64_t*> rcaps(fp.arity_bits.size());
+    std::vector<E2> betas(fp.arity_bits.size());
+    unsigned sum_ab = 0;
+    for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+        rcaps[r] = rb.take(cap_n * 4);
+        if (rb.bad) return 120;
+        ch.observe_many(rcaps[r], cap_n * 4);
+        betas[r] = ch.get_ext();
+        sum_ab += fp.arity_bits[r];
+    }
+    if (sum_ab > log_n) return 120;
+    const size_t flen = n >> sum_ab;
+    std::vector<E2> fpoly(flen ? flen : 1);
+    {
+        const uint64_t* e = rb.take(2 * flen);
+        if (rb.bad) return 120;
+        for (size_t i = 0; i < flen; i++) {
+            fpoly[i] = E2{e[2 * i], e[2 * i + 1]};
+            observe_ext(ch, fpoly[i]);
+        }
+    }
+    const uint64_t* pwp = rb.take(1);
+    if (rb.bad) return 120;
+    uint64_t resp;
+    if (cfg.pow_rule == SIPP_POW_HASH) {
+        uint64_t in[5], out[4];
+        for (int i = 0; i < 4; i++) in[i] = ch.get();
+        in[4] = *pwp;
+        host::Challenger::hash_no_pad(in, 5, out);
+        resp = out[0];
+    } else {
+        ch.observe(*pwp);
+        resp = ch.get();
+    }
+    if (cfg.pow_bits && (resp >> (64 - cfg.pow_bits)) != 0) return 121;
+    // reduced openings per batch: sum_j alpha^j opened_j; batch 0 = W + P + Q values, batch 1 = W + P
+    const int nb0 = W + P + Q, nb1 = W + P;
+    E2 red[2] = {e2(0), e2(0)};
+    for (int j = nb0; j-- > 0;) {
+        const E2 v = j < W ? op[j] : j < W + P ? op[2 * W + (j - W)] : op[2 * W + 2 * P + (j - W - P)];
+        red[0] = gl::add(gl::mul(red[0], fa), v);
+    }
+    for (int j = nb1; j-- > 0;) {
+        const E2 v = j < W ? op[W + j] : op[2 * W + P + (j - W)];
+        red[1] = gl::add(gl::mul(red[1], fa), v);
+    }
+    const E2 shf1 = gl::pow(fa, (uint64_t)nb1);
+    const uint64_t wm = gl::root_of_unity(log_m);
+    const int ncols3[3] = {W, P, Q};
+    const uint64_t* caps3[3] = {trace_cap, z_cap, q_cap};
+    const unsigned ns0 = log_m - cfg.cap_height;
+    for (uint32_t qi = 0; qi < cfg.num_queries; qi++) {
+        const size_t x = (size_t)(ch.get() % m);
+        const uint64_t* rows[3];
+        for (int o = 0; o < 3; o++) {
+            rows[o] = rb.take((size_t)ncols3[o]);
+            const uint64_t* sib = rb.take((size_t)ns0 * 4);
+            if (rb.bad) return 122;
+            if (!merkle_ok(rows[o], (size_t)ncols3[o], x, sib, ns0, caps3[o])) return 123 + o;
+        }
+        uint64_t sub_x = gl::mul(gl::GEN, gl::pow(wm, (uint64_t)gl::bitrev((uint32_t)x, log_m)));
+        // fri_combine_initial
+        E2 sum = e2(0);
+        for (int b = 0; b < 2; b++) {
+            E2 acc = e2(0), ap = e2(1);
+            for (int o = 0; o < (b == 0 ? 3 : 2); o++)
+                for (int c = 0; c < ncols3[o]; c++) {
+                    acc = gl::add(acc, gl::scale(ap, rows[o][c]));
+                    ap = gl::mul(ap, fa);
+                }
+            const E2 num = gl::sub(acc, red[b]), den = gl::sub(e2(sub_x), b == 0 ? zeta : gzeta);
+            if (den.c0 == 0 && den.c1 == 0) return 122;
+            sum = gl::add(b == 0 ? sum : gl::mul(sum, shf1), gl::mul(num, gl::inv(den)));
+        }
+        E2 old = gl::scale(sum, sub_x);        // the final polynomial was multiplied by X
+        size_t xi = x;
+        unsigned log_tree = log_m;
+        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+            const unsigned ab = fp.arity_bits[r];
+            const size_t arity = (size_t)1 << ab;
+            log_tree -= ab;
+            const unsigned ns = log_tree > cfg.cap_height ? log_tree - cfg.cap_height : 0;
+            const uint64_t* evw = rb.take(2 * arity);
+            const uint64_t* sib = rb.take((size_t)ns * 4);
+            if (rb.bad) return 130;
+            const size_t within = xi & (arity - 1);
+            E2 evs[16];
+            for (size_t k = 0; k < arity; k++) evs[k] = E2{evw[2 * k], evw[2 * k + 1]};
+            if (!gl::eq(evs[within], old)) return 131;
+            // compute_evaluation: interpolate {(coset_start w^i, evs[bitrev(i)])} and evaluate at beta_r
+            const uint64_t w = gl::root_of_unity(ab);
+            const uint64_t rev_within = gl::bitrev((uint32_t)within, ab);
+            const uint64_t coset_start = gl::mul(sub_x, gl::pow(w, (uint64_t)arity - rev_within));
+            uint64_t pts[16];
+            for (size_t i = 0; i < arity; i++) pts[i] = gl::mul(coset_start, gl::pow(w, (uint64_t)i));
+            E2 acc = e2(0);
+            for (size_t i = 0; i < arity; i++) {
+                E2 numr = evs[gl::bitrev((uint32_t)i, ab)];
+                uint64_t den = 1;
+                for (size_t k = 0; k < arity; k++) {
+                    if (k == i) continue;
+                    numr = gl::mul(numr, gl::sub(betas[r], e2(pts[k])));
+                    den = gl::mul(den, gl::sub(pts[i], pts[k]));
+                }
+                acc = gl::add(acc, gl::scale(numr, gl::inv(den)));
+            }
+            old = acc;
+            xi >>= ab;
+            if (!merkle_ok(evw, 2 * arity, xi, sib, ns, rcaps[r])) return 132;
+            sub_x = gl::pow(sub_x, (uint64_t)arity);
+        }
+        E2 fv = e2(0);
+        for (size_t i = flen; i-- > 0;) fv = gl::add(gl::scale(fv, sub_x), fpoly[i]);
+        if (!gl::eq(fv, old)) return 133;
+    }
+    if (rb.pos + n_pi != len) return 140;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sipp_stark_verify(const uint64_t* proof, size_t len, const sipp_stark_config* cfg, int* reason) {
+    if (reason) *reason = 0;
+    if (!proof) return SIPP_E_BADARG;
+    sipp_stark_config c;
+    if (cfg) c = *cfg;
+    else sipp_default_config(&c);
+    if (c.num_challenges != 2) return SIPP_E_UNSUPPORTED;
+    const int r = verify(proof, len, c);
+    if (reason) *reason = r;
+    return r == 0 ? SIPP_OK : SIPP_E_VERIFY;
+}
