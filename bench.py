@@ -74,15 +74,23 @@ def cpu_baseline(ios, shapes, kinds, budget_s=150.0):
                                                      "" if measured else " (only the first measured, the others scaled by committed cells)")}
 
 
-def verify_proofs(proofs):
-    """the CPU checker (oracle/stark.c's verifier, test infrastructure) over proofs this run produced, OUTSIDE every timed region:
-    a bench line for proofs nobody checked is a claim, not a result.  Returns True when every non-empty proof is accepted."""
+def verify_proofs(proofs, lib_ms=None):
+    """every proof this run produced goes, OUTSIDE every timed region, through BOTH verifiers: the library's own (sipp_stark_verify:
+    host code of the product, what a user of the library runs -- the generators' verify_stark_proof / data.verify of the reference) and
+    the CPU checker (oracle/stark.c's verifier, test infrastructure): a bench line for proofs nobody checked is a claim, not a result.
+    Returns True when every non-empty proof is accepted by both; lib_ms (a list) receives the library verifier's time per proof."""
     try:
+        import sipp_amd
         from tests import _oracle
         ok = True
         for pf in proofs:
             if len(pf):
-                ok = ok and _oracle.stark_verify(np.ascontiguousarray(pf)) == 0
+                pf = np.ascontiguousarray(pf)
+                t = time.perf_counter()
+                lib_ok = sipp_amd.stark_verify(pf) == 0
+                if lib_ms is not None:
+                    lib_ms.append(round(1e3 * (time.perf_counter() - t), 2))
+                ok = ok and lib_ok and _oracle.stark_verify(pf) == 0
         return bool(ok)
     except Exception as e:      # a checker that cannot run (build failure, missing compiler) is `verified: false`, never a rank that
         VERIFY_ERRORS.append("%s: %s" % (type(e).__name__, e))   # leaves the collective the other ranks are waiting in
@@ -417,7 +425,8 @@ def main():
                                             before_timing=start_profiling)
     proofs = [p.copy() for p in proofs]           # the instance's output buffers are reused by the later legs
     # every rank pushes the proofs of its LAST timed step through the oracle's verifier (outside the timed region)
-    verified_main = all_ranks_true(verify_proofs(proofs), red_device)
+    lib_verify_ms = []
+    verified_main = all_ranks_true(verify_proofs(proofs, lib_verify_ms), red_device)
     prof = {}
     for c in inst.distinct_ctxs():
         for k, v in c.profile_report().items():
@@ -570,6 +579,8 @@ def main():
             "dtype": "u64", "data": "synthetic",
             # the three proofs of the last timed step, on every rank, through oracle/stark.c's verifier after the timed region
             "verified": verified_main,
+            # ... and through the library's own verifier first (sipp_stark_verify: host C++, one core; ms per proof, G1 / G2 / Fq12)
+            "library_verifier": {"ms_per_proof": lib_verify_ms, "entry_point": "sipp_stark_verify (verify_stark_proof of the generators / data.verify)"},
             **({"verify_errors": VERIFY_ERRORS[:3]} if VERIFY_ERRORS else {}),
             # what carried the barrier and the max-over-ranks reduction of the timed region
             "timing_reduction": ("%s:%s" % (dist.get_backend(), red_device)) if dist.is_initialized() else "single process",

@@ -242,7 +242,7 @@ int sipp_pairing_prove(sipp_ctx *ctx, const uint32_t *ios, size_t num_io, uint64
  * The check of a flat proof made by any of the provers above (every kind): what starky's native `verify_stark_proof` does inside the
  * reference's proof generators right after `prove` (starky-bn254 @ 2d46f9e, un-vendored) and what `data.verify`
  * (src/verifier_circuit.rs:254) rests on.  HOST code (about 40 k Poseidon permutations and one evaluation of the AIR at zeta: a few
- * milliseconds to a few tens, one core; no GPU, no ctx): header and configuration, canonical words, the PUBLIC conditions of the
+ * milliseconds to a few tens on up to eight threads; no GPU, no ctx): header and configuration, canonical words, the PUBLIC conditions of the
  * statement (record elements below p; points on their curves; MapToG2: the sign rule; pairing: Q of order r), the Fiat-Shamir replay,
  * the constraints at zeta against the quotient openings, FRI (proof of work, Merkle paths of the three oracles and of every layer, the
  * fold of every query, the final polynomial).  cfg = NULL: the default configuration.

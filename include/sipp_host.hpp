@@ -93,6 +93,15 @@ class Error : public std::runtime_error {
     int status_;
 };
 
+// starky's `verify_stark_proof` as the generators call it after `prove`, and the check `data.verify(proof)` rests on (reference
+// src/verifier_circuit.rs:254): the library's own verifier (sipp_stark_verify: host code, no GPU).  Throws Error(SIPP_E_VERIFY)
+// naming the refusing stage (include/sipp_hip.h).
+inline void verify_stark_proof(const std::vector<uint64_t>& flat, const sipp_stark_config* cfg = nullptr) {
+    int reason = 0;
+    const int rc = ::sipp_stark_verify(flat.data(), flat.size(), cfg, &reason);
+    if (rc != SIPP_OK) throw Error(rc, "verify_stark_proof: refused at stage " + std::to_string(reason));
+}
+
 // ---- starky's proof structs (field names of starky::proof / plonky2::fri::proof) ----
 using F = uint64_t;  // canonical Goldilocks
 struct Ext {

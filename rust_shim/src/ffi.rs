@@ -156,6 +156,9 @@ extern "C" {
     /// range of an obligation list that GPU `rank` of `world` proves as a STARK of its own (level L-D)
     pub fn sipp_io_shard(num_io: usize, world: u32, rank: u32, first: *mut usize, count: *mut usize) -> c_int;
     pub fn sipp_exp_outputs(ctx: *mut SippCtxOpaque, kind: c_int, ios: *mut u32, num_io: usize) -> c_int;
+    /// the library's verifier of a flat proof (host code): starky's native verify_stark_proof in the generators / data.verify
+    /// (reference src/verifier_circuit.rs:254); cfg null = default; *reason receives the refusing stage (include/sipp_hip.h)
+    pub fn sipp_stark_verify(proof: *const u64, len: usize, cfg: *const SippStarkConfig, reason: *mut c_int) -> c_int;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes_cfg(kind: c_int, num_io: usize, cfg: *const SippStarkConfig) -> usize;

@@ -86,6 +86,14 @@ impl SippCtx {
 /// Level L-D: the slice of an obligation list that GPU `rank` of `world` proves as a STARK
 /// of its own.  On the circuit side `g1_exp_circuit` / `g2_exp_circuit` / `fq12_exp_circuit` (reference
 /// src/verifier_circuit.rs:133-135) are then called once per range, each generator proving its slice on its own GPU.
+/// `verify_stark_proof` of the generators (right after `prove`) and the checks behind `data.verify(proof)` (reference
+/// src/verifier_circuit.rs:254): the library's own host-side verifier over the flat proof; Err carries the refusing stage.
+pub fn verify_stark_proof(proof: &[u64]) -> Result<()> {
+    let mut reason: std::os::raw::c_int = 0;
+    let rc = unsafe { ffi::sipp_stark_verify(proof.as_ptr(), proof.len(), std::ptr::null(), &mut reason) };
+    if rc == 0 { Ok(()) } else { Err(anyhow::anyhow!("sipp_stark_verify: status {} at stage {}", rc, reason)) }
+}
+
 pub fn io_shard(num_io: usize, world: u32, rank: u32) -> Result<std::ops::Range<usize>> {
     let (mut first, mut count) = (0usize, 0usize);
     let rc = unsafe { ffi::sipp_io_shard(num_io, world, rank, &mut first, &mut count) };

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/sipp_hip.h"
@@ -757,8 +758,25 @@ int verify(const uint64_t* proof, size_t len, const sipp_stark_config& cfg) {
     const int ncols3[3] = {W, P, Q};
     const uint64_t* caps3[3] = {trace_cap, z_cap, q_cap};
     const unsigned ns0 = log_m - cfg.cap_height;
-    for (uint32_t qi = 0; qi < cfg.num_queries; qi++) {
-        const size_t x = (size_t)(ch.get() % m);
+    // the query rounds are independent once their indices are drawn and have one size: words of a round = the three oracle rows with
+    // their paths + every layer's coset with its path.  They are checked by a few threads; the verdict is the FIRST refusing round's,
+    // as if they had been read one after the other.
+    size_t qwords = 0;
+    for (int o = 0; o < 3; o++) qwords += (size_t)ncols3[o] + (size_t)ns0 * 4;
+    {
+        unsigned lt = log_m;
+        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+            lt -= fp.arity_bits[r];
+            qwords += ((size_t)2 << fp.arity_bits[r]) + (size_t)(lt > cfg.cap_height ? lt - cfg.cap_height : 0) * 4;
+        }
+    }
+    std::vector<size_t> xs(cfg.num_queries);
+    for (uint32_t qi = 0; qi < cfg.num_queries; qi++) xs[qi] = (size_t)(ch.get() % m);
+    const size_t q_base = rb.pos;
+    auto query = [&](uint32_t qi) -> int {
+        Reader rb{proof, q_base + (size_t)qi * qwords, len};
+        if (rb.pos > len) return 122;
+        const size_t x = xs[qi];
         const uint64_t* rows[3];
         for (int o = 0; o < 3; o++) {
             rows[o] = rb.take((size_t)ncols3[o]);
@@ -820,7 +838,24 @@ int verify(const uint64_t* proof, size_t len, const sipp_stark_config& cfg) {
         E2 fv = e2(0);
         for (size_t i = flen; i-- > 0;) fv = gl::add(gl::scale(fv, sub_x), fpoly[i]);
         if (!gl::eq(fv, old)) return 133;
+        return 0;
+    };
+    std::vector<int> verdict(cfg.num_queries, 0);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
+        if (nt > cfg.num_queries) nt = cfg.num_queries;
+        auto work = [&](unsigned t) {
+            for (uint32_t qi = t; qi < cfg.num_queries; qi += nt) verdict[qi] = query(qi);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread& th : pool) th.join();
     }
+    for (uint32_t qi = 0; qi < cfg.num_queries; qi++)
+        if (verdict[qi]) return verdict[qi];
+    rb.pos = q_base + (size_t)cfg.num_queries * qwords;
     if (rb.pos + n_pi != len) return 140;
     return 0;
 }

@@ -11,7 +11,8 @@
 //                                                    <msgs.bin> = (u64 count, count x 16 u32); writes <out_prefix>_proof.bin,
 //                                                    <out_prefix>_points.bin (the cofactor-cleared points)
 //
-// The verifier is the CPU oracle's (test infrastructure), linked only into this test binary.
+// Every proof goes through the library's own verifier (sipp::verify_stark_proof = data.verify's checks) AND through the CPU oracle's
+// (test infrastructure, linked only into this test binary).
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -185,7 +186,8 @@ static int prove(const char* ios_path, const char* out_prefix) {
         CHECK(pr.outputs.size() == 1 && std::memcmp(&pr.outputs[0], &v.statement.final_Z, sizeof(sipp::Fq12)) == 0);
         orc_config pcfg;
         orc_default_config(&pcfg);
-        CHECK(orc_stark_verify(pr.flat.data(), pr.flat.size(), &pcfg) == 0);
+        sipp::verify_stark_proof(pr.flat);                                        // the library's verifier ...
+        CHECK(orc_stark_verify(pr.flat.data(), pr.flat.size(), &pcfg) == 0);       // ... and the oracle's
         CHECK(pr.proof.kind == (uint32_t)SIPP_PAIRING && pr.proof.to_flat() == pr.flat);
         // the public inputs are the record (final_A, final_B, final_Z), padded by a copy
         const uint32_t* fa = reinterpret_cast<const uint32_t*>(&v.statement.final_A);
@@ -211,7 +213,15 @@ static int prove(const char* ios_path, const char* out_prefix) {
     const std::vector<uint64_t>* flats[3] = {&r1.flat, &r2.flat, &r12.flat};
     const sipp::StarkProofWithPublicInputs* proofs[3] = {&r1.proof, &r2.proof, &r12.proof};
     for (int k = 0; k < 3; k++) {
+        sipp::verify_stark_proof(*flats[k]);
         CHECK(orc_stark_verify(flats[k]->data(), flats[k]->size(), &ocfg) == 0);
+        {   // a damaged proof is refused by both, at the same stage
+            std::vector<uint64_t> bad = *flats[k];
+            bad[bad.size() / 2] ^= 1;
+            int stage = 0;
+            CHECK(sipp_stark_verify(bad.data(), bad.size(), nullptr, &stage) == SIPP_E_VERIFY);
+            CHECK(stage == -orc_stark_verify(bad.data(), bad.size(), &ocfg));
+        }
         CHECK(proofs[k]->to_flat() == *flats[k]);
         CHECK(proofs[k]->kind == (uint32_t)k);
         std::ofstream f(std::string(out_prefix) + char('0' + k) + ".bin", std::ios::binary);
@@ -254,6 +264,7 @@ static int mapg2(const char* msgs_path, const char* out_prefix) {
     CHECK(r.outputs.size() == n);
     orc_config cfg;
     orc_default_config(&cfg);
+    sipp::verify_stark_proof(r.flat);
     CHECK(orc_stark_verify(r.flat.data(), r.flat.size(), &cfg) == 0);
     CHECK(r.proof.public_inputs.size() % SIPP_MAP_G2_IO_WORDS == 0 && r.proof.public_inputs.size() / SIPP_MAP_G2_IO_WORDS >= n);
     for (size_t i = 0; i < n; i++) {
@@ -267,6 +278,7 @@ static int mapg2(const char* msgs_path, const char* out_prefix) {
     CHECK(m.points.size() == n && m.cofactor_inputs.size() == 2 * n);
     for (size_t i = 0; i < n; i++) CHECK(memcmp(&m.cofactor_inputs[i].x, &r.outputs[i], sizeof(sipp::G2Affine)) == 0);
     const auto c = prover.g2_exp_circuit(m.cofactor_inputs);
+    sipp::verify_stark_proof(c.flat);
     CHECK(orc_stark_verify(c.flat.data(), c.flat.size(), &cfg) == 0);
     {   // the same obligations through the hardened AIR: another proof (kind 5 in its header), the same outputs
         const auto ch = prover.g2_exp_circuit(m.cofactor_inputs, true);

@@ -18,7 +18,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle", "py"))
 
@@ -75,8 +75,8 @@ def test_bls_aggregation_n8():
             ctx.prove(6, bad)
     finally:
         ctx.close()
-    assert _oracle.stark_verify(pf_map) == 0 and _oracle.stark_verify(pf_cof) == 0
-    assert _oracle.stark_verify(pf_pair) == 0 and (pf_pair[-288:-144] == final_rec[0]).all()
+    assert _verify.both_accept(pf_map) and _verify.both_accept(pf_cof)
+    assert _verify.both_accept(pf_pair) and (pf_pair[-288:-144] == final_rec[0]).all()
     nio = int(pf_map[3])
     assert (pf_map[-nio * 48:].reshape(nio, 48)[: n - 1] == map_recs).all()
     # the cleared points the SIPP statement's B consists of are the outputs the cofactor proof binds
@@ -89,7 +89,7 @@ def test_bls_aggregation_n8():
     finally:
         inst.close()
     for kind in range(3):
-        assert _oracle.stark_verify(proofs[kind]) == 0
+        assert _verify.both_accept(proofs[kind])
         nio = int(proofs[kind][3])
         w = ios[kind].shape[1]
         assert (proofs[kind][-nio * w:].reshape(nio, w)[: ios[kind].shape[0]] == ios[kind]).all()

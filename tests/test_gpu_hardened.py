@@ -4,7 +4,7 @@ tests/test_oracle_hardened.py: refused by the plain kinds, proved by the hardene
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def test_trace_and_proof_match_the_oracle(ctx, ios4, kind):
     pf = ctx.prove(kind, ios)
     want = _oracle.stark_prove(kind, ios)
     assert int(pf[1]) == kind and pf.shape == want.shape and (pf == want).all()
-    assert _oracle.stark_verify(pf) == 0
+    assert _verify.both_accept(pf)
     # the plain kind on the same ctx afterwards: its own program, its own proof (tables are cached per AIR variant)
     assert (ctx.prove(kind - 4, ios) == _oracle.stark_prove(kind - 4, ios)).all()
 
@@ -53,7 +53,7 @@ def test_u16_variant_at_the_n128_size_verifies(kind):
         pf = c.prove(kind, ios)
     finally:
         c.close()
-    assert _oracle.stark_verify(pf) == 0
+    assert _verify.both_accept(pf)
     nio = int(pf[3])
     assert (pf[-nio * ios.shape[1]:].reshape(nio, ios.shape[1])[: ios.shape[0]] == ios).all()
 
@@ -86,7 +86,7 @@ def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
             bad = np.argwhere(got != want)
             raise AssertionError("kind %d: %d cells differ; first (col,row): %s" % (base + 4, len(bad), bad[:8].tolist()))
         pf = ctx.prove(base + 4, recs)
-        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _oracle.stark_verify(pf) == 0
+        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _verify.both_accept(pf)
     # R = -P on a used addition: the accumulator passes through the identity (offset = -x, odd exponent; and a later meeting:
     # offset = -[2^i + (e mod 2^i)] x with bit i set)
     g1n, g2n = [], []
@@ -106,7 +106,7 @@ def test_records_that_meet_the_running_power_plain_refuses_hardened_proves(ctx):
             bad = np.argwhere(got != want)
             raise AssertionError("kind %d: %d cells differ; first (col,row): %s" % (base + 4, len(bad), bad[:8].tolist()))
         pf = ctx.prove(base + 4, recs)
-        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _oracle.stark_verify(pf) == 0
+        assert (pf == _oracle.stark_prove(base + 4, recs)).all() and _verify.both_accept(pf)
     # the OUTPUT at the identity: no record can say it; refused by both variants
     none = np.array([bn.g1_to_u32(x1) + bn.g1_to_u32(bn.g1_neg(x1)) + sn.exp_to_u32(1) + bn.g1_to_u32(x1)] * 2, dtype=np.uint32)
     for kind in (0, 4):
@@ -135,7 +135,7 @@ def test_hardened_ctx_flag_through_the_instance_entry_point(ctx, ios4):
     for k in (0, 1):
         assert (proofs[k] == ctx.prove(k + 4, ios[k])).all()
     assert (proofs[2] == ctx.prove(2, ios[2])).all()
-    assert all(_oracle.stark_verify(p) == 0 for p in proofs)
+    assert all(_verify.both_accept(p) for p in proofs)
 
 
 def test_hardened_queue(ctx):

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle", "py"))
 
@@ -80,7 +80,7 @@ def test_proof_matches_oracle_word_for_word_and_verifies(ctx):
     _, words = messages(5, seed=3)
     recs = ctx.map_to_g2(words, cofactor=False)
     proof = ctx.prove(3, recs)
-    assert _oracle.stark_verify(proof) == 0
+    assert _verify.both_accept(proof)
     want = _oracle.stark_prove(3, recs)
     assert proof.shape == want.shape and (proof == want).all()
 
@@ -112,7 +112,7 @@ def test_wrong_or_unprovable_records_are_refused(ctx):
     big = np.zeros(((1 << 17) + 1, 48), dtype=np.uint32)                                   # more records than a STARK of this kind takes
     assert L.sipp_map_to_g2(ctx.h, np.zeros(((1 << 17) + 1, 16), dtype=np.uint32).ctypes.data, (1 << 17) + 1, big.ctypes.data, None, None) == -1
     # the ctx survives
-    assert _oracle.stark_verify(ctx.prove(3, recs)) == 0
+    assert _verify.both_accept(ctx.prove(3, recs))
 
 
 def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
@@ -131,9 +131,9 @@ def test_u16_variant_at_2_to_the_16_rows_is_accepted_by_the_oracle_verifier():
     finally:
         c.close()
     assert (int(proof[1]), int(proof[2]), int(proof[3])) == (3, 16, 8192)
-    assert _oracle.stark_verify(proof) == 0
+    assert _verify.both_accept(proof)
     proof[16 + 5] ^= 1
-    assert _oracle.stark_verify(proof) != 0
+    assert _verify.both_refuse(proof)
 
 
 def test_two_thousand_random_messages_map_like_the_c_reading(ctx):

@@ -94,7 +94,7 @@ def test_world8_shards_of_the_large_configs(n, log_n, records, hardened):
     accepts every proof, the public inputs are the rank's slice (padding = copies of its last record), and a single ctx gives the
     same words."""
     import sipp_amd
-    from tests import _oracle
+    from tests import _oracle, _verify
     d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n%d_ios.npz" % n))
     ios = [d["g1"], d["g2"], d["fq12"]]
     L = sipp_amd.lib()
@@ -118,7 +118,7 @@ def test_world8_shards_of_the_large_configs(n, log_n, records, hardened):
             assert nio >= max(2, count) and nio & (nio - 1) == 0
             if k < 2:
                 assert int(pf[2]) == log_n and nio == (1 << (log_n - 9))
-            assert _oracle.stark_verify(pf) == 0, (rank, k)
+            assert _verify.both_accept(pf), (rank, k)
             if n == 4096 and hardened and rank == 3:
                 # BASELINE configs[4]: rank 3's world-8 shard word for word -- the sha256 of the oracle's proof of the same slice
                 # (tools/gen_golden.py digests_large), not only a verifier pass
@@ -242,7 +242,7 @@ def test_io_sharded_sub_proofs_cover_the_instance_and_verify(world):
     Every shard's proofs are what a single ctx produces for the same slice, the CPU verifier accepts them, their public
     inputs are exactly the slice, and the slices tile the lists.  world = 8 leaves ranks without any Fq12 record."""
     import sipp_amd
-    from tests import _oracle
+    from tests import _oracle, _verify
     d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
     ios = [d["g1"], d["g2"], d["fq12"]]
     seen = [0, 0, 0]
@@ -264,7 +264,7 @@ def test_io_sharded_sub_proofs_cover_the_instance_and_verify(world):
                 seen[k] += count
                 alone = ctx.prove(k, mine[k])
                 assert len(alone) == len(proofs[k]) and (alone == proofs[k]).all(), (rank, k)
-                assert _oracle.stark_verify(proofs[k]) == 0, (rank, k)
+                assert _verify.both_accept(proofs[k]), (rank, k)
     finally:
         ctx.close()
     assert seen == [a.shape[0] for a in ios]
@@ -366,7 +366,7 @@ def test_one_ctx_instance_attempts_every_proof_and_returns_the_first_failure():
     stop the others; the first failing status comes back and the failed kind reports length 0"""
     import ctypes as C
     import sipp_amd
-    from tests import _oracle
+    from tests import _oracle, _verify
     d = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n8_ios.npz"))
     ios = [d["g1"].copy(), d["g2"].copy(), d["fq12"].copy()]
     ios[1][0, -1] ^= 1                                       # claimed output off by one
@@ -381,6 +381,6 @@ def test_one_ctx_instance_attempts_every_proof_and_returns_the_first_failure():
         pl = (C.c_size_t * 3)()
         assert L.sipp_instance_prove(h, pi, ni, po, pc, pl) == -8          # SIPP_E_WITNESS
         assert pl[1] == 0 and pl[0] > 0 and pl[2] > 0
-        assert _oracle.stark_verify(one.out[0][: pl[0]]) == 0 and _oracle.stark_verify(one.out[2][: pl[2]]) == 0
+        assert _verify.both_accept(one.out[0][: pl[0]]) and _verify.both_accept(one.out[2][: pl[2]])
     finally:
         one.close()

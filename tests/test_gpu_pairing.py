@@ -94,7 +94,7 @@ def test_whole_pipeline_from_points_to_three_proofs():
     A, B -> sipp_prove_native -> sipp_verify_native (statement + obligation lists) -> sipp_instance_prove -> three STARK
     proofs whose public inputs are exactly those obligations; each proof is checked by the oracle's verifier."""
     import sipp_amd
-    from tests import _oracle
+    from tests import _oracle, _verify
     n = 8
     d = np.load("tests/golden/sipp_n%d_ios.npz" % n)
     A, B = d["statement"][: 16 * n].reshape(n, 16), d["statement"][16 * n: 48 * n].reshape(n, 32)
@@ -109,7 +109,7 @@ def test_whole_pipeline_from_points_to_three_proofs():
         proofs = inst.prove(ios)
         for kind in range(3):
             pf = proofs[kind]
-            assert _oracle.stark_verify(pf) == 0
+            assert _verify.both_accept(pf)
             nio = int(pf[3])
             pis = pf[-nio * ios[kind].shape[1]:].reshape(nio, ios[kind].shape[1])
             assert (pis[: ios[kind].shape[0]] == ios[kind]).all()

@@ -6,7 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 from oracle.py import bn254 as bn
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +66,7 @@ def test_edge_points_and_bilinearity(ctx):
     assert [bn.u32_to_fq(list(lhs[8 * k: 8 * k + 8])) for k in range(12)] == bn.f12_pow(e(5), 6)
     # and all ten records in ONE proof (sixteen blocks of 2^13 rows, six of them padding)
     proof = ctx.prove(6, got)
-    assert int(proof[2]) == 17 and int(proof[3]) == 16 and _oracle.stark_verify(proof) == 0
+    assert int(proof[2]) == 17 and int(proof[3]) == 16 and _verify.both_accept(proof)
 
 
 def test_trace_matches_oracle_cell_for_cell(ctx, recs3):
@@ -91,7 +91,7 @@ def test_proof_matches_oracle_word_for_word_and_verifies(ctx, recs3, count):
     assert len(proof) == len(ref)
     if not (proof == ref).all():
         raise AssertionError("first differing word: %d of %d" % (int(np.argmax(proof != ref)), len(ref)))
-    assert _oracle.stark_verify(proof) == 0
+    assert _verify.both_accept(proof)
     assert int(proof[1]) == 6 and int(proof[3]) == (2 if count == 1 else 4)
 
 
@@ -128,4 +128,4 @@ def test_wrong_result_and_bad_points_are_refused_on_both_sides(ctx, recs3):
     with pytest.raises(sipp_amd.SippError):
         ctx.prove(6, big)
     # the ctx still proves afterwards
-    assert _oracle.stark_verify(ctx.prove(6, recs3[:1])) == 0
+    assert _verify.both_accept(ctx.prove(6, recs3[:1]))
