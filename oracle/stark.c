@@ -395,7 +395,7 @@ int orc_stark_verify(const uint64_t *proof, size_t len, const orc_config *cfg) {
     size_t num_io = (size_t)h[3];
     int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
     const unsigned log_rows = orc_kind_log_rows(kind);
-    if (kind < 0 || kind > 6 || log_n < 10 || log_n > 26 || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
+    if (kind < 0 || kind > 6 || log_n < 10 || log_n > 26 || log_n <= log_rows || num_io != ((size_t)1 << (log_n - log_rows))) return -101;
     const air_spec_t *a = orc_air_get(kind, log_n);
     if (!a || W != orc_air_width(a) || P != 2 * a->n_checked || Q != 4 || h[7] != cfg->cap_height ||
         h[10] != cfg->num_queries || (int)h[11] != a->pi_per_io || h[12] != len || h[13] != cfg->rate_bits ||

@@ -22,3 +22,14 @@ PY
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 tests/host/test_sipp_circuit_asan layout /tmp/sipp_asan_proof.bin
 # ... and from_flat on 20,000 damaged copies of that buffer: an Error or a round trip, never undefined behaviour
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 tests/host/test_sipp_circuit_asan fuzz /tmp/sipp_asan_proof.bin 20000
+# the library's verifier (sipp_amd/csrc/verify.cpp, compiled into the test binary with the sanitizers) on 20,000 damaged proofs per kind
+make -C tests/host -s verify_fuzz_asan
+env -u SIPP_ORACLE_ASAN python - <<'PY'
+import numpy as np
+from tests import _oracle
+g = np.load("tests/golden/sipp_n4_ios.npz")
+_oracle.stark_prove(4, g["g1"]).tofile("/tmp/sipp_asan_g1h.bin")
+_oracle.stark_prove(2, g["fq12"]).tofile("/tmp/sipp_asan_fq12.bin")
+PY
+ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 tests/host/verify_fuzz_asan /tmp/sipp_asan_g1h.bin 20000
+ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 tests/host/verify_fuzz_asan /tmp/sipp_asan_fq12.bin 20000 5

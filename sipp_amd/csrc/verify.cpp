@@ -540,7 +540,7 @@ int verify(const uint64_t* proof, size_t len, const sipp_stark_config& cfg) {
     const int W = (int)h[4], P = (int)h[5], Q = (int)h[6];
     if (kind < 0 || kind > SIPP_PAIRING || log_n < 10 || log_n > 26) return 101;
     const unsigned log_rows = (unsigned)log_rows_of(kind);
-    if (num_io != ((size_t)1 << (log_n - log_rows))) return 101;
+    if (log_n <= log_rows || num_io != ((size_t)1 << (log_n - log_rows))) return 101;       // at least two records' blocks
     const air_spec_t* a = sipp_air_get(kind, log_n);
     if (cfg.fs_rule > 1 || cfg.lookup_rule > 1 || cfg.rate_bits < 1 || cfg.rate_bits > 3 || cfg.cap_height > 8 || cfg.arity_bits < 1 ||
         cfg.arity_bits > 4 || cfg.num_queries < 1 || cfg.num_queries > 1024 || cfg.pow_bits > 32 || cfg.pow_rule > 1)

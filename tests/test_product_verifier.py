@@ -177,3 +177,17 @@ def test_bad_arguments():
     with pytest.raises(sipp_amd.SippError):
         sipp_amd.stark_verify(np.zeros(32, dtype=np.uint64), cfg)
     assert sipp_amd.stark_verify(np.zeros(8, dtype=np.uint64)) == 100
+
+
+def test_damaged_proofs_under_the_sanitizers(tmp_path, ios4):
+    """verify.cpp + the host permutation compiled INTO a test binary with AddressSanitizer / UBSan (tests/host/verify_fuzz.cpp): header
+    fields at extreme values, truncations with a consistent length word, random words, shifted blocks -- every damaged proof ends in a
+    refusal with a stage of the documented range, nothing is read out of bounds (scripts/run_asan.sh runs 20,000 per kind)"""
+    import subprocess
+    host = os.path.join(os.path.dirname(__file__), "host")
+    subprocess.check_call(["make", "-C", host, "-s", "verify_fuzz_asan"])
+    path = tmp_path / "proof.bin"
+    _oracle.stark_prove(1, ios4[1]).tofile(path)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([os.path.join(host, "verify_fuzz_asan"), str(path), "800", "3"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "verify fuzz ok" in out.stdout and " 0 accepted" in out.stdout, out.stdout + out.stderr
