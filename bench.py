@@ -210,7 +210,12 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
             from tests import _oracle
             ofp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_h, pow_bits=pow_bits, num_queries=nq, pow_rule=0, hiding=0, arity_bits=4,
                                      final_poly_bits=5, degree_bits=log_n)
-            verified = _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
+            # both verifiers: the library's own (sipp_plonk_verify_gates: data.verify's part for the outer proof) and the oracle's
+            from tests import _verify
+            t_v = time.perf_counter()
+            lib_ok = _verify.lib_plonk_verify(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
+            lib_verify_ms = round(1e3 * (time.perf_counter() - t_v), 2)
+            verified = lib_ok and _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
         return {"what": "plonky2 prove() below witness generation on a synthetic circuit with gates as data (sipp_plonk_prove_gates)",
                 "shape": {"degree_bits": log_n, "num_wires": W, "num_routed_wires": R, "num_constants": K, "num_challenges": CH, "quotient_degree_factor": D,
                           "rate_bits": rate_bits, "cap_height": cap_h, "num_queries": nq, "pow_bits": pow_bits, "arity": 16,
@@ -219,6 +224,7 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                 "config_ref": "CircuitConfig::standard_ecc_config (reference src/verifier_circuit.rs:213); degree of the reference's circuit unknown "
                               "(built by un-vendored crates): 2^%d rows here" % log_n,
                 "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified,
+                **({"library_verifier_ms": lib_verify_ms} if verify else {}),
                 # HEADLINE, next to ms_per_proof: the host side of the same proof.  The GPU path starts at the wire values; producing them
                 # (this leg's numpy generator, one core) costs far more than proving them -- what a deployment would have to move next
                 "witness_generation_s": t_wit, "end_to_end_s_per_proof": t_wit + ms * 1e-3,

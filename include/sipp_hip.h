@@ -442,6 +442,22 @@ int sipp_plonk_prove_gates(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_
                            const sipp_fri_params *fp, const sipp_plonk_circuit *c, const uint64_t circuit_digest[4],
                            const uint64_t *public_inputs, uint32_t n_public_inputs, uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
 
+/* ---- verification of the generic proofs (host code like sipp_stark_verify; stages in *reason, may be NULL) -------------------------
+ * sipp_fri_verify_openings: PolynomialBatch::verify_openings over a proof of sipp_fri_prove_openings -- caps[o] = the cap of oracle o
+ * (2^cap_height x 4 words), ncols / n_salt (may be NULL = 0) per oracle, the batches as proved; the caller's transcript goes in and
+ * comes out (the opened values are observed as they are read).  Stages: 100 header, 106 truncated openings, 120 .. 133 as in
+ * sipp_stark_verify, 140 trailing words, 141 a non-canonical word.
+ * sipp_plonk_verify_gates: plonk/verifier.rs for a proof of sipp_plonk_prove_gates ("SIPPPLK3") -- what `data.verify(proof)` (reference
+ * src/verifier_circuit.rs:254) does with the outer proof: the gate constraints at zeta from the OPENED constants and wires through the
+ * same gate programs, Z(1) = 1, the partial products, one reduce_with_powers per challenge against the quotient chunks, the opening
+ * proof.  constants_sigmas_cap and circuit_digest are the circuit's (verifier data).  Stages: 201 header / circuit / parameters,
+ * 202 size, 203 truncated, 210 the vanishing polynomial does not meet the quotient, then the FRI stages above. */
+int sipp_fri_verify_openings(const uint64_t *proof, size_t len, const uint64_t *const *caps, const uint32_t *ncols, const uint32_t *n_salt,
+                             size_t n_oracles, const sipp_fri_batch *batches, size_t n_batches, uint32_t log_n, const sipp_fri_params *p,
+                             sipp_challenger *ch, int *reason);
+int sipp_plonk_verify_gates(const uint64_t *proof, size_t len, const uint64_t *constants_sigmas_cap, const sipp_plonk_params *p,
+                            const sipp_fri_params *fp, const sipp_plonk_circuit *c, const uint64_t circuit_digest[4], int *reason);
+
 /* ---- building blocks (device buffers; used by the parity tests and bench.py) -- */
 /* plonky2 fft()/ifft(): natural order in, natural order out, in place.
  * d_cols is [ncols][col_stride] u64 with the first 2^log_n entries of each column used. */

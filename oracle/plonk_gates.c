@@ -222,6 +222,8 @@ int orc_plonk_verify_gates(const uint64_t *proof, size_t len, const uint64_t *cs
     if (n_pi > len - (16 + 3 * cap_n * 4)) return -201;
     const unsigned log_n = (unsigned)proof[1];
     if (log_n < 1 || log_n > 26 || C == 0 || C > 8) return -202;
+    for (size_t i = 16; i < len; i++)
+        if (proof[i] >= GL_P) return -141;   /* canonical field elements only: x + p would be a second encoding of x */
     uint64_t pih[4];
     orc_hash_no_pad(proof + len - n_pi, n_pi, pih);
     const uint64_t *wcap = proof + 16, *zcap = wcap + cap_n * 4, *qcap = zcap + cap_n * 4, *op = qcap + cap_n * 4;

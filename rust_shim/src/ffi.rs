@@ -159,6 +159,12 @@ extern "C" {
     /// the library's verifier of a flat proof (host code): starky's native verify_stark_proof in the generators / data.verify
     /// (reference src/verifier_circuit.rs:254); cfg null = default; *reason receives the refusing stage (include/sipp_hip.h)
     pub fn sipp_stark_verify(proof: *const u64, len: usize, cfg: *const SippStarkConfig, reason: *mut c_int) -> c_int;
+    /// the verifiers of the generic proofs (host code): PolynomialBatch::verify_openings, and plonk/verifier.rs for the outer proof
+    pub fn sipp_fri_verify_openings(proof: *const u64, len: usize, caps: *const *const u64, ncols: *const u32, n_salt: *const u32, n_oracles: usize,
+                                    batches: *const SippFriBatch, n_batches: usize, log_n: u32, p: *const SippFriParams, ch: *mut SippChallenger,
+                                    reason: *mut c_int) -> c_int;
+    pub fn sipp_plonk_verify_gates(proof: *const u64, len: usize, constants_sigmas_cap: *const u64, p: *const SippPlonkParams, fp: *const SippFriParams,
+                                   c: *const SippPlonkCircuit, circuit_digest: *const u64, reason: *mut c_int) -> c_int;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes(kind: c_int, num_io: usize) -> usize;
     pub fn sipp_workspace_bytes_cfg(kind: c_int, num_io: usize, cfg: *const SippStarkConfig) -> usize;

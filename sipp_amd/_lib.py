@@ -112,6 +112,10 @@ SIGNATURES = {
     "sipp_prove_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
     "sipp_verify_native": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]),
     "sipp_stark_verify": (C.c_int, [u64p, C.c_size_t, C.POINTER(StarkConfig), C.POINTER(C.c_int)]),
+    "sipp_fri_verify_openings": (C.c_int, [u64p, C.c_size_t, C.POINTER(u64p), u32p, u32p, C.c_size_t, C.POINTER(FriBatch), C.c_size_t, C.c_uint32,
+                                           C.POINTER(FriParams), C.POINTER(Challenger), C.POINTER(C.c_int)]),
+    "sipp_plonk_verify_gates": (C.c_int, [u64p, C.c_size_t, u64p, C.POINTER(PlonkParams), C.POINTER(FriParams), C.POINTER(PlonkCircuit), u64p,
+                                          C.POINTER(C.c_int)]),
     "sipp_proof_size": (C.c_size_t, [vp, C.c_int, C.c_size_t]),
     "sipp_stark_shape": (C.c_int, [vp, C.c_int, C.c_size_t, u32p, u32p, u32p, u32p]),
     "sipp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),

@@ -504,6 +504,179 @@ struct Eval {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// FRI verification (plonky2 fri/verifier.rs as recalled: verify_fri_proof with PrecomputedReducedOpenings, fri_combine_initial,
+// compute_evaluation per layer, the final polynomial) over any number of oracles and opening batches.  The reader stands behind the
+// opened values; `opened[b]` are batch b's values in opening order; alpha has been drawn.  Query rounds are independent once their
+// indices are drawn and have one size -- the oracle rows with their paths + every layer's coset with its path -- so a few threads check
+// them; the verdict is the FIRST refusing round's, as if they had been read one after the other.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct FriBatchV {
+    E2 point;
+    uint32_t n_ranges;
+    const sipp_poly_range* ranges;
+};
+size_t batch_len(const FriBatchV& b) {
+    size_t k = 0;
+    for (uint32_t r = 0; r < b.n_ranges; r++) k += b.ranges[r].col_end - b.ranges[r].col_begin;
+    return k;
+}
+int fri_verify(Reader& rb, const uint64_t* const* caps, const uint32_t* ncols, const uint32_t* n_salt, size_t n_oracles, const FriBatchV* batches,
+               const E2* const* opened, size_t n_batches, unsigned log_n, const FriShape& fp, E2 alpha, host::Challenger& ch) {
+    const uint64_t* proof = rb.p;
+    const size_t len = rb.len;
+    const unsigned log_m = log_n + fp.rate_bits;
+    const size_t m = (size_t)1 << log_m, n = (size_t)1 << log_n;
+    const size_t cap_n = (size_t)1 << fp.cap_height;
+    if (fp.cap_height > log_m) return 120;
+    std::vector<const uint64_t*> rcaps(fp.arity_bits.size());
+    std::vector<E2> betas(fp.arity_bits.size());
+    unsigned sum_ab = 0;
+    for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+        rcaps[r] = rb.take(cap_n * 4);
+        if (rb.bad) return 120;
+        ch.observe_many(rcaps[r], cap_n * 4);
+        betas[r] = ch.get_ext();
+        if (fp.arity_bits[r] < 1 || fp.arity_bits[r] > 4) return 120;
+        sum_ab += fp.arity_bits[r];
+    }
+    if (sum_ab > log_n) return 120;
+    const size_t flen = n >> sum_ab;
+    std::vector<E2> fpoly(flen ? flen : 1);
+    {
+        const uint64_t* e = rb.take(2 * flen);
+        if (rb.bad) return 120;
+        for (size_t i = 0; i < flen; i++) {
+            fpoly[i] = E2{e[2 * i], e[2 * i + 1]};
+            observe_ext(ch, fpoly[i]);
+        }
+    }
+    const uint64_t* pwp = rb.take(1);
+    if (rb.bad) return 120;
+    uint64_t resp;
+    if (fp.pow_rule == SIPP_POW_HASH) {
+        uint64_t in[5], out[4];
+        for (int i = 0; i < 4; i++) in[i] = ch.get();
+        in[4] = *pwp;
+        host::Challenger::hash_no_pad(in, 5, out);
+        resp = out[0];
+    } else {
+        ch.observe(*pwp);
+        resp = ch.get();
+    }
+    if (fp.pow_bits && (resp >> (64 - fp.pow_bits)) != 0) return 121;
+    // reduced openings per batch: sum_j alpha^j opened_j, and alpha^(values of the batch)
+    std::vector<E2> red(n_batches), shf(n_batches);
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t k = batch_len(batches[b]);
+        E2 acc = e2(0);
+        for (size_t j = k; j-- > 0;) acc = gl::add(gl::mul(acc, alpha), opened[b][j]);
+        red[b] = acc;
+        shf[b] = gl::pow(alpha, (uint64_t)k);
+    }
+    const uint64_t wm = gl::root_of_unity(log_m);
+    const unsigned ns0 = log_m - fp.cap_height;
+    size_t qwords = 0;
+    for (size_t o = 0; o < n_oracles; o++) qwords += (size_t)ncols[o] + (size_t)n_salt[o] + (size_t)ns0 * 4;
+    {
+        unsigned lt = log_m;
+        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+            lt -= fp.arity_bits[r];
+            qwords += ((size_t)2 << fp.arity_bits[r]) + (size_t)(lt > fp.cap_height ? lt - fp.cap_height : 0) * 4;
+        }
+    }
+    std::vector<size_t> xs(fp.num_queries);
+    for (uint32_t qi = 0; qi < fp.num_queries; qi++) xs[qi] = (size_t)(ch.get() % m);
+    const size_t q_base = rb.pos;
+    auto query = [&](uint32_t qi) -> int {
+        Reader rq{proof, q_base + (size_t)qi * qwords, len};
+        if (rq.pos > len) return 122;
+        const size_t x = xs[qi];
+        std::vector<const uint64_t*> rows(n_oracles);
+        for (size_t o = 0; o < n_oracles; o++) {
+            const size_t ll = (size_t)ncols[o] + (size_t)n_salt[o];
+            rows[o] = rq.take(ll);
+            const uint64_t* sib = rq.take((size_t)ns0 * 4);
+            if (rq.bad) return 122;
+            if (!merkle_ok(rows[o], ll, x, sib, ns0, caps[o])) return 123 + (int)(o < 3 ? o : 3);
+        }
+        uint64_t sub_x = gl::mul(gl::GEN, gl::pow(wm, (uint64_t)gl::bitrev((uint32_t)x, log_m)));
+        // fri_combine_initial (salt words are never combined)
+        E2 sum = e2(0);
+        for (size_t b = 0; b < n_batches; b++) {
+            E2 acc = e2(0), ap = e2(1);
+            for (uint32_t r = 0; r < batches[b].n_ranges; r++) {
+                const sipp_poly_range& rg = batches[b].ranges[r];
+                for (uint32_t c = rg.col_begin; c < rg.col_end; c++) {
+                    acc = gl::add(acc, gl::scale(ap, rows[rg.oracle][c]));
+                    ap = gl::mul(ap, alpha);
+                }
+            }
+            const E2 num = gl::sub(acc, red[b]), den = gl::sub(e2(sub_x), batches[b].point);
+            if (den.c0 == 0 && den.c1 == 0) return 122;
+            sum = gl::add(gl::mul(sum, shf[b]), gl::mul(num, gl::inv(den)));
+        }
+        E2 old = gl::scale(sum, sub_x);        // the final polynomial was multiplied by X
+        size_t xi = x;
+        unsigned log_tree = log_m;
+        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
+            const unsigned ab = fp.arity_bits[r];
+            const size_t arity = (size_t)1 << ab;
+            log_tree -= ab;
+            const unsigned ns = log_tree > fp.cap_height ? log_tree - fp.cap_height : 0;
+            const uint64_t* evw = rq.take(2 * arity);
+            const uint64_t* sib = rq.take((size_t)ns * 4);
+            if (rq.bad) return 130;
+            const size_t within = xi & (arity - 1);
+            E2 evs[16];
+            for (size_t k = 0; k < arity; k++) evs[k] = E2{evw[2 * k], evw[2 * k + 1]};
+            if (!gl::eq(evs[within], old)) return 131;
+            // compute_evaluation: interpolate {(coset_start w^i, evs[bitrev(i)])} and evaluate at beta_r
+            const uint64_t w = gl::root_of_unity(ab);
+            const uint64_t rev_within = gl::bitrev((uint32_t)within, ab);
+            const uint64_t coset_start = gl::mul(sub_x, gl::pow(w, (uint64_t)arity - rev_within));
+            uint64_t pts[16];
+            for (size_t i = 0; i < arity; i++) pts[i] = gl::mul(coset_start, gl::pow(w, (uint64_t)i));
+            E2 acc = e2(0);
+            for (size_t i = 0; i < arity; i++) {
+                E2 numr = evs[gl::bitrev((uint32_t)i, ab)];
+                uint64_t den = 1;
+                for (size_t k = 0; k < arity; k++) {
+                    if (k == i) continue;
+                    numr = gl::mul(numr, gl::sub(betas[r], e2(pts[k])));
+                    den = gl::mul(den, gl::sub(pts[i], pts[k]));
+                }
+                acc = gl::add(acc, gl::scale(numr, gl::inv(den)));
+            }
+            old = acc;
+            xi >>= ab;
+            if (!merkle_ok(evw, 2 * arity, xi, sib, ns, rcaps[r])) return 132;
+            sub_x = gl::pow(sub_x, (uint64_t)arity);
+        }
+        E2 fv = e2(0);
+        for (size_t i = flen; i-- > 0;) fv = gl::add(gl::scale(fv, sub_x), fpoly[i]);
+        if (!gl::eq(fv, old)) return 133;
+        return 0;
+    };
+    std::vector<int> verdict(fp.num_queries, 0);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
+        if (nt > fp.num_queries) nt = fp.num_queries;
+        auto work = [&](unsigned t) {
+            for (uint32_t qi = t; qi < fp.num_queries; qi += nt) verdict[qi] = query(qi);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
+        if (nt) work(0);
+        for (std::thread& th : pool) th.join();
+    }
+    for (uint32_t qi = 0; qi < fp.num_queries; qi++)
+        if (verdict[qi]) return verdict[qi];
+    rb.pos = q_base + (size_t)fp.num_queries * qwords;
+    return 0;
+}
+
 // the 16-bit tower-basis limb `sub` (component sub / 16, limb sub % 16) of the MyFq12 value at rec[word .. word + 96):
 // component 2 i = c_i + 9 c_(i+6), component 2 i + 1 = c_(i+6)
 uint64_t tower_limb(const FqCtx& k, const uint32_t* rec, int sub) {
@@ -703,164 +876,242 @@ int verify(const uint64_t* proof, size_t len, const sipp_stark_config& cfg) {
 
     // ---- FRI: the batch (local | Z | quotient) opened at zeta, (local | Z) at g zeta ----
     const E2 fa = ch.get_ext();
-    const E2 gzeta = gl::scale(zeta, g);
     if ((size_t)h[9] != (n >> (fp.arity_bits.size() * cfg.arity_bits))) return 120;
-    const unsigned log_m = log_n + cfg.rate_bits;
-    const size_t m = (size_t)1 << log_m;
-    std::vector<const uint64_t*> rcaps(fp.arity_bits.size());
-    std::vector<E2> betas(fp.arity_bits.size());
-    unsigned sum_ab = 0;
-    for (size_t r = 0; r < fp.arity_bits.size(); r++) {
-        rcaps[r] = rb.take(cap_n * 4);
-        if (rb.bad) return 120;
-        ch.observe_many(rcaps[r], cap_n * 4);
-        betas[r] = ch.get_ext();
-        sum_ab += fp.arity_bits[r];
-    }
-    if (sum_ab > log_n) return 120;
-    const size_t flen = n >> sum_ab;
-    std::vector<E2> fpoly(flen ? flen : 1);
-    {
-        const uint64_t* e = rb.take(2 * flen);
-        if (rb.bad) return 120;
-        for (size_t i = 0; i < flen; i++) {
-            fpoly[i] = E2{e[2 * i], e[2 * i + 1]};
-            observe_ext(ch, fpoly[i]);
-        }
-    }
-    const uint64_t* pwp = rb.take(1);
-    if (rb.bad) return 120;
-    uint64_t resp;
-    if (cfg.pow_rule == SIPP_POW_HASH) {
-        uint64_t in[5], out[4];
-        for (int i = 0; i < 4; i++) in[i] = ch.get();
-        in[4] = *pwp;
-        host::Challenger::hash_no_pad(in, 5, out);
-        resp = out[0];
-    } else {
-        ch.observe(*pwp);
-        resp = ch.get();
-    }
-    if (cfg.pow_bits && (resp >> (64 - cfg.pow_bits)) != 0) return 121;
-    // reduced openings per batch: sum_j alpha^j opened_j; batch 0 = W + P + Q values, batch 1 = W + P
-    const int nb0 = W + P + Q, nb1 = W + P;
-    E2 red[2] = {e2(0), e2(0)};
-    for (int j = nb0; j-- > 0;) {
-        const E2 v = j < W ? op[j] : j < W + P ? op[2 * W + (j - W)] : op[2 * W + 2 * P + (j - W - P)];
-        red[0] = gl::add(gl::mul(red[0], fa), v);
-    }
-    for (int j = nb1; j-- > 0;) {
-        const E2 v = j < W ? op[W + j] : op[2 * W + P + (j - W)];
-        red[1] = gl::add(gl::mul(red[1], fa), v);
-    }
-    const E2 shf1 = gl::pow(fa, (uint64_t)nb1);
-    const uint64_t wm = gl::root_of_unity(log_m);
-    const int ncols3[3] = {W, P, Q};
+    const sipp_poly_range r0[3] = {{0, 0, (uint32_t)W}, {1, 0, (uint32_t)P}, {2, 0, (uint32_t)Q}};
+    const FriBatchV batches[2] = {{zeta, 3, r0}, {gl::scale(zeta, g), 2, r0}};
+    std::vector<E2> o0((size_t)(W + P + Q)), o1((size_t)(W + P));
+    for (int c = 0; c < W; c++) { o0[c] = op[c]; o1[c] = op[W + c]; }
+    for (int c = 0; c < P; c++) { o0[W + c] = op[2 * W + c]; o1[W + c] = op[2 * W + P + c]; }
+    for (int c = 0; c < Q; c++) o0[W + P + c] = op[2 * W + 2 * P + c];
+    const E2* opened[2] = {o0.data(), o1.data()};
     const uint64_t* caps3[3] = {trace_cap, z_cap, q_cap};
-    const unsigned ns0 = log_m - cfg.cap_height;
-    // the query rounds are independent once their indices are drawn and have one size: words of a round = the three oracle rows with
-    // their paths + every layer's coset with its path.  They are checked by a few threads; the verdict is the FIRST refusing round's,
-    // as if they had been read one after the other.
-    size_t qwords = 0;
-    for (int o = 0; o < 3; o++) qwords += (size_t)ncols3[o] + (size_t)ns0 * 4;
-    {
-        unsigned lt = log_m;
-        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
-            lt -= fp.arity_bits[r];
-            qwords += ((size_t)2 << fp.arity_bits[r]) + (size_t)(lt > cfg.cap_height ? lt - cfg.cap_height : 0) * 4;
-        }
-    }
-    std::vector<size_t> xs(cfg.num_queries);
-    for (uint32_t qi = 0; qi < cfg.num_queries; qi++) xs[qi] = (size_t)(ch.get() % m);
-    const size_t q_base = rb.pos;
-    auto query = [&](uint32_t qi) -> int {
-        Reader rb{proof, q_base + (size_t)qi * qwords, len};
-        if (rb.pos > len) return 122;
-        const size_t x = xs[qi];
-        const uint64_t* rows[3];
-        for (int o = 0; o < 3; o++) {
-            rows[o] = rb.take((size_t)ncols3[o]);
-            const uint64_t* sib = rb.take((size_t)ns0 * 4);
-            if (rb.bad) return 122;
-            if (!merkle_ok(rows[o], (size_t)ncols3[o], x, sib, ns0, caps3[o])) return 123 + o;
-        }
-        uint64_t sub_x = gl::mul(gl::GEN, gl::pow(wm, (uint64_t)gl::bitrev((uint32_t)x, log_m)));
-        // fri_combine_initial
-        E2 sum = e2(0);
-        for (int b = 0; b < 2; b++) {
-            E2 acc = e2(0), ap = e2(1);
-            for (int o = 0; o < (b == 0 ? 3 : 2); o++)
-                for (int c = 0; c < ncols3[o]; c++) {
-                    acc = gl::add(acc, gl::scale(ap, rows[o][c]));
-                    ap = gl::mul(ap, fa);
-                }
-            const E2 num = gl::sub(acc, red[b]), den = gl::sub(e2(sub_x), b == 0 ? zeta : gzeta);
-            if (den.c0 == 0 && den.c1 == 0) return 122;
-            sum = gl::add(b == 0 ? sum : gl::mul(sum, shf1), gl::mul(num, gl::inv(den)));
-        }
-        E2 old = gl::scale(sum, sub_x);        // the final polynomial was multiplied by X
-        size_t xi = x;
-        unsigned log_tree = log_m;
-        for (size_t r = 0; r < fp.arity_bits.size(); r++) {
-            const unsigned ab = fp.arity_bits[r];
-            const size_t arity = (size_t)1 << ab;
-            log_tree -= ab;
-            const unsigned ns = log_tree > cfg.cap_height ? log_tree - cfg.cap_height : 0;
-            const uint64_t* evw = rb.take(2 * arity);
-            const uint64_t* sib = rb.take((size_t)ns * 4);
-            if (rb.bad) return 130;
-            const size_t within = xi & (arity - 1);
-            E2 evs[16];
-            for (size_t k = 0; k < arity; k++) evs[k] = E2{evw[2 * k], evw[2 * k + 1]};
-            if (!gl::eq(evs[within], old)) return 131;
-            // compute_evaluation: interpolate {(coset_start w^i, evs[bitrev(i)])} and evaluate at beta_r
-            const uint64_t w = gl::root_of_unity(ab);
-            const uint64_t rev_within = gl::bitrev((uint32_t)within, ab);
-            const uint64_t coset_start = gl::mul(sub_x, gl::pow(w, (uint64_t)arity - rev_within));
-            uint64_t pts[16];
-            for (size_t i = 0; i < arity; i++) pts[i] = gl::mul(coset_start, gl::pow(w, (uint64_t)i));
-            E2 acc = e2(0);
-            for (size_t i = 0; i < arity; i++) {
-                E2 numr = evs[gl::bitrev((uint32_t)i, ab)];
-                uint64_t den = 1;
-                for (size_t k = 0; k < arity; k++) {
-                    if (k == i) continue;
-                    numr = gl::mul(numr, gl::sub(betas[r], e2(pts[k])));
-                    den = gl::mul(den, gl::sub(pts[i], pts[k]));
-                }
-                acc = gl::add(acc, gl::scale(numr, gl::inv(den)));
-            }
-            old = acc;
-            xi >>= ab;
-            if (!merkle_ok(evw, 2 * arity, xi, sib, ns, rcaps[r])) return 132;
-            sub_x = gl::pow(sub_x, (uint64_t)arity);
-        }
-        E2 fv = e2(0);
-        for (size_t i = flen; i-- > 0;) fv = gl::add(gl::scale(fv, sub_x), fpoly[i]);
-        if (!gl::eq(fv, old)) return 133;
-        return 0;
-    };
-    std::vector<int> verdict(cfg.num_queries, 0);
-    {
-        unsigned nt = std::thread::hardware_concurrency();
-        nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
-        if (nt > cfg.num_queries) nt = cfg.num_queries;
-        auto work = [&](unsigned t) {
-            for (uint32_t qi = t; qi < cfg.num_queries; qi += nt) verdict[qi] = query(qi);
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
-        work(0);
-        for (std::thread& th : pool) th.join();
-    }
-    for (uint32_t qi = 0; qi < cfg.num_queries; qi++)
-        if (verdict[qi]) return verdict[qi];
-    rb.pos = q_base + (size_t)cfg.num_queries * qwords;
+    const uint32_t ncols3[3] = {(uint32_t)W, (uint32_t)P, (uint32_t)Q}, salt3[3] = {0, 0, 0};
+    const int rc = fri_verify(rb, caps3, ncols3, salt3, 3, batches, opened, 2, log_n, fp, fa, ch);
+    if (rc) return rc;
     if (rb.pos + n_pi != len) return 140;
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// PolynomialBatch opening proofs ("SIPPFRI1", sipp_fri_prove_openings) and the outer prover's proofs ("SIPPPLK3", sipp_plonk_prove_gates)
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr uint64_t FRI_MAGIC = 0x5349505046524931ULL;    // "SIPPFRI1"
+constexpr uint64_t PLONK_MAGIC3 = 0x334b4c5050504953ULL;  // "SIPPPLK3" (as bytes in memory)
+
+FriShape fri_shape_of(const sipp_fri_params& p) {
+    FriShape f;
+    f.rate_bits = p.rate_bits; f.cap_height = p.cap_height; f.pow_bits = p.pow_bits; f.num_queries = p.num_queries; f.pow_rule = p.pow_rule;
+    for (uint32_t r = 0; r < p.n_rounds && r < SIPP_FRI_MAX_ROUNDS; r++) f.arity_bits.push_back(p.arity_bits[r]);
+    return f;
+}
+bool fri_params_ok(const sipp_fri_params& p, unsigned log_n) {
+    return p.rate_bits >= 1 && p.rate_bits <= 8 && p.cap_height <= 16 && p.cap_height <= log_n + p.rate_bits && p.pow_bits <= 32 && p.num_queries >= 1 &&
+           p.num_queries <= 1024 && p.pow_rule <= 1 && p.n_rounds <= SIPP_FRI_MAX_ROUNDS && log_n >= 1 && log_n <= 26;
+}
+
+// the section written by PolynomialBatch::prove_openings: header[8], the opened values batch by batch (observed as they are read), then
+// what fri_verify reads.  `sec` / `sec_len`: the section alone (its header carries its own length)
+int fri_openings_verify(const uint64_t* sec, size_t sec_len, const uint64_t* const* caps, const uint32_t* ncols, const uint32_t* n_salt,
+                        size_t n_oracles, const FriBatchV* batches, size_t n_batches, unsigned log_n, const sipp_fri_params& p, host::Challenger& ch) {
+    if (sec_len < 8 || sec[0] != FRI_MAGIC || sec[1] != p.n_rounds || sec[3] != p.num_queries || sec[4] != n_oracles || sec[5] != n_batches ||
+        sec[6] != sec_len || sec[7] != log_n)
+        return 100;
+    for (size_t i = 8; i < sec_len; i++)
+        if (sec[i] >= gl::P) return 141;
+    for (size_t b = 0; b < n_batches; b++)
+        for (uint32_t r = 0; r < batches[b].n_ranges; r++) {
+            const sipp_poly_range& rg = batches[b].ranges[r];
+            if (rg.oracle >= n_oracles || rg.col_begin > rg.col_end || rg.col_end > ncols[rg.oracle]) return 100;
+        }
+    Reader rb{sec, 8, sec_len};
+    std::vector<std::vector<E2>> opened(n_batches);
+    std::vector<const E2*> optr(n_batches);
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t k = batch_len(batches[b]);
+        const uint64_t* e = rb.take(2 * k);
+        if (rb.bad) return 106;
+        opened[b].resize(k ? k : 1);
+        for (size_t j = 0; j < k; j++) {
+            opened[b][j] = E2{e[2 * j], e[2 * j + 1]};
+            observe_ext(ch, opened[b][j]);
+        }
+        optr[b] = opened[b].data();
+    }
+    const E2 alpha = ch.get_ext();
+    const int rc = fri_verify(rb, caps, ncols, n_salt, n_oracles, batches, optr.data(), n_batches, log_n, fri_shape_of(p), alpha, ch);
+    if (rc) return rc;
+    return rb.pos == sec_len ? 0 : 140;
+}
+
+// a gate set handed over as data: operands in range, programs inside program_words (what sipp_plonk_prove_gates refuses too)
+bool circuit_ok(const sipp_plonk_circuit& c, const sipp_plonk_params& p) {
+    if (c.num_wires < p.num_routed_wires || c.num_selectors == 0 || c.num_selectors > c.num_constants || c.num_gates == 0 || !c.gates ||
+        (!c.programs && c.program_words))
+        return false;
+    for (uint32_t g = 0; g < c.num_gates; g++) {
+        const sipp_plonk_gate& ga = c.gates[g];
+        if (ga.selector_index >= c.num_selectors || ga.group_lo > ga.row || ga.row >= ga.group_hi || ga.group_hi > c.num_gates) return false;
+        size_t w = ga.prog_offset;
+        for (uint32_t j = 0; j < ga.num_constraints; j++) {
+            if (w >= c.program_words) return false;
+            const int64_t nm = c.programs[w++];
+            if (nm < 0 || nm > 4096) return false;
+            for (int64_t mo = 0; mo < nm; mo++) {
+                if (w + 2 > c.program_words) return false;
+                const int64_t nf = c.programs[w + 1];
+                w += 2;
+                if (nf < 0 || nf > 64 || w + 2 * (size_t)nf > c.program_words) return false;
+                for (int64_t f = 0; f < nf; f++, w += 2) {
+                    const int64_t kind = c.programs[w], idx = c.programs[w + 1];
+                    if (kind < 0 || kind > 2 || idx < 0 || (kind == 0 && idx >= c.num_wires) || (kind == 1 && idx >= c.num_constants) ||
+                        (kind == 2 && idx >= 4))
+                        return false;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// plonk/verifier.rs with the gate constraints evaluated at zeta from the OPENED constants and wires (gates as data: per gate a selector
+// filter and one polynomial per constraint), the permutation argument's Z(1) = 1 and partial-product terms, one reduce_with_powers per
+// challenge against the quotient chunks, then the opening proof
+int plonk_verify(const uint64_t* proof, size_t len, const uint64_t* cs_cap, const sipp_plonk_params& p, const sipp_fri_params& fp,
+                 const sipp_plonk_circuit& c, const uint64_t digest[4]) {
+    if (p.num_routed_wires == 0 || p.max_degree < 2 || p.max_degree > 64 || (p.max_degree & (p.max_degree - 1)) || p.num_challenges == 0 ||
+        p.num_challenges > 8 || !circuit_ok(c, p))
+        return 201;
+    const uint32_t R = p.num_routed_wires, D = p.max_degree, C = p.num_challenges, np = (R + D - 1) / D - 1, nz = C * (1 + np), m = np + 1;
+    const uint32_t W = c.num_wires, K = c.num_constants;
+    uint32_t ngc = 0;
+    for (uint32_t g = 0; g < c.num_gates; g++) ngc = c.gates[g].num_constraints > ngc ? c.gates[g].num_constraints : ngc;
+    if (fp.cap_height > 16) return 201;
+    const size_t cap_n = (size_t)1 << fp.cap_height;
+    if (len < 16 + 3 * cap_n * 4 || proof[0] != PLONK_MAGIC3 || proof[2] != R || proof[3] != D || proof[4] != C || proof[5] != len || proof[6] != W ||
+        proof[7] != K || proof[8] != c.num_selectors || proof[9] != c.num_gates || proof[10] != ngc || (proof[12] | proof[13] | proof[14] | proof[15]))
+        return 201;
+    const size_t n_pi = (size_t)proof[11];
+    if (proof[11] > len - (16 + 3 * cap_n * 4)) return 201;
+    const unsigned log_n = (unsigned)proof[1];
+    if (proof[1] < 1 || proof[1] > 26 || !fri_params_ok(fp, log_n)) return 202;
+    // every body word is a field element in canonical form (x + p would hash and compute like x: a second encoding of the same proof)
+    for (size_t i = 16; i < len; i++)
+        if (proof[i] >= gl::P) return 141;
+    uint64_t pih[4];
+    host::Challenger::hash_no_pad(proof + len - n_pi, n_pi, pih);
+    const uint64_t *wcap = proof + 16, *zcap = wcap + cap_n * 4, *qcap = zcap + cap_n * 4, *op = qcap + cap_n * 4;
+    const size_t op_len = len - (size_t)(op - proof) - n_pi;
+    host::Challenger ch;
+    ch.observe_many(digest, 4);
+    ch.observe_many(pih, 4);
+    ch.observe_many(wcap, cap_n * 4);
+    uint64_t betas[8], gammas[8], alphas[8];
+    for (uint32_t i = 0; i < C; i++) betas[i] = ch.get();
+    for (uint32_t i = 0; i < C; i++) gammas[i] = ch.get();
+    ch.observe_many(zcap, cap_n * 4);
+    for (uint32_t i = 0; i < C; i++) alphas[i] = ch.get();
+    ch.observe_many(qcap, cap_n * 4);
+    const E2 zeta = ch.get_ext();
+    const size_t n0 = (size_t)K + R + W + nz + (size_t)C * D, n_open = n0 + C;
+    if (op_len < 8 + 2 * n_open) return 203;
+    std::vector<E2> v(n_open);
+    for (size_t k = 0; k < n_open; k++) v[k] = E2{op[8 + 2 * k], op[8 + 2 * k + 1]};
+    const E2 *cv = v.data(), *sg = cv + K, *wv = cv + K + R, *zs = wv + W, *pps = zs + C, *qs = zs + nz, *zs_next = cv + n0;
+    // gate constraint terms: term j = sum over gates of filter_g(selector) * constraint_(g, j)
+    std::vector<E2> terms;
+    const uint64_t n = (uint64_t)1 << log_n;
+    const E2 zeta_n = gl::pow(zeta, n), zh = gl::sub(zeta_n, e2(1));
+    {
+        const E2 d1 = gl::sub(zeta, e2(1));
+        if (d1.c0 == 0 && d1.c1 == 0) return 107;
+        const E2 l0 = gl::mul(zh, gl::inv(gl::scale(d1, n % gl::P)));
+        for (uint32_t cc = 0; cc < C; cc++) terms.push_back(gl::mul(l0, gl::sub(zs[cc], e2(1))));
+        for (uint32_t cc = 0; cc < C; cc++)
+            for (uint32_t q = 0; q < m; q++) {
+                E2 num = e2(1), den = e2(1);
+                for (uint32_t j = q * D; j < (q + 1) * D && j < R; j++) {
+                    const E2 sid = gl::scale(zeta, gl::mul(betas[cc], gl::pow(7, (uint64_t)j)));       // k_j = 7^j: get_unique_coset_shifts
+                    num = gl::mul(num, gl::add(gl::add(wv[j], sid), e2(gammas[cc])));
+                    den = gl::mul(den, gl::add(gl::add(wv[j], gl::scale(sg[j], betas[cc])), e2(gammas[cc])));
+                }
+                const E2 prev = q == 0 ? zs[cc] : pps[cc * np + q - 1], next = q == np ? zs_next[cc] : pps[cc * np + q];
+                terms.push_back(gl::sub(gl::mul(prev, num), gl::mul(next, den)));
+            }
+        std::vector<E2> gt(ngc ? ngc : 1, e2(0));
+        for (uint32_t g = 0; g < c.num_gates; g++) {
+            const sipp_plonk_gate& ga = c.gates[g];
+            E2 f = e2(1);
+            const E2 sel = cv[ga.selector_index];
+            for (uint32_t i = ga.group_lo; i < ga.group_hi; i++)
+                if (i != ga.row) f = gl::mul(f, gl::sub(e2(i), sel));
+            if (c.num_selectors > 1) f = gl::mul(f, gl::sub(e2(0xffffffffull), sel));
+            const int64_t* w = c.programs + ga.prog_offset;
+            for (uint32_t j = 0; j < ga.num_constraints; j++) {
+                const int64_t nm = *w++;
+                E2 sum = e2(0);
+                for (int64_t mo = 0; mo < nm; mo++) {
+                    E2 t = e2_from_i64(w[0]);
+                    const int64_t nf = w[1];
+                    w += 2;
+                    for (int64_t k = 0; k < nf; k++, w += 2) t = gl::mul(t, w[0] == 0 ? wv[w[1]] : w[0] == 1 ? cv[w[1]] : e2(pih[w[1]]));
+                    sum = gl::add(sum, t);
+                }
+                gt[j] = gl::add(gt[j], gl::mul(f, sum));
+            }
+        }
+        for (uint32_t j = 0; j < ngc; j++) terms.push_back(gt[j]);
+    }
+    for (uint32_t cc = 0; cc < C; cc++) {
+        E2 van = e2(0);
+        for (size_t k = terms.size(); k-- > 0;) van = gl::add(gl::scale(van, alphas[cc]), terms[k]);
+        E2 acc = e2(0);
+        for (uint32_t d = D; d-- > 0;) acc = gl::add(gl::mul(acc, zeta_n), qs[cc * D + d]);
+        if (!gl::eq(van, gl::mul(zh, acc))) return 210;
+    }
+    const uint64_t* caps[4] = {cs_cap, wcap, zcap, qcap};
+    const uint32_t ncols[4] = {K + R, W, nz, C * D}, salt[4] = {0, 0, 0, 0};
+    const sipp_poly_range r0[4] = {{0, 0, K + R}, {1, 0, W}, {2, 0, nz}, {3, 0, C * D}}, r1[1] = {{2, 0, C}};
+    const FriBatchV batches[2] = {{zeta, 4, r0}, {gl::scale(zeta, gl::root_of_unity(log_n)), 1, r1}};
+    return fri_openings_verify(op, op_len, caps, ncols, salt, 4, batches, 2, log_n, fp, ch);
+}
+
 }  // namespace
+
+extern "C" int sipp_fri_verify_openings(const uint64_t* proof, size_t len, const uint64_t* const* caps, const uint32_t* ncols, const uint32_t* n_salt,
+                                        size_t n_oracles, const sipp_fri_batch* batches, size_t n_batches, uint32_t log_n, const sipp_fri_params* p,
+                                        sipp_challenger* chal, int* reason) {
+    if (reason) *reason = 0;
+    if (!proof || !caps || !ncols || !batches || !p || !chal || n_oracles == 0 || n_oracles > 64 || n_batches == 0 || n_batches > 64) return SIPP_E_BADARG;
+    if (!fri_params_ok(*p, log_n)) return SIPP_E_UNSUPPORTED;
+    std::vector<FriBatchV> bv(n_batches);
+    for (size_t b = 0; b < n_batches; b++) bv[b] = FriBatchV{E2{batches[b].point[0], batches[b].point[1]}, batches[b].n_ranges, batches[b].ranges};
+    std::vector<uint32_t> zero(n_oracles, 0);
+    host::Challenger ch;
+    memcpy(ch.state, chal->state, sizeof ch.state);
+    memcpy(ch.in_buf, chal->in_buf, sizeof ch.in_buf);
+    memcpy(ch.out_buf, chal->out_buf, sizeof ch.out_buf);
+    if (chal->n_in > 8 || chal->n_out > 8) return SIPP_E_BADARG;
+    ch.n_in = (uint32_t)chal->n_in;
+    ch.n_out = (uint32_t)chal->n_out;
+    const int r = fri_openings_verify(proof, len, caps, ncols, n_salt ? n_salt : zero.data(), n_oracles, bv.data(), n_batches, log_n, *p, ch);
+    memcpy(chal->state, ch.state, sizeof ch.state);
+    memcpy(chal->in_buf, ch.in_buf, sizeof ch.in_buf);
+    memcpy(chal->out_buf, ch.out_buf, sizeof ch.out_buf);
+    chal->n_in = ch.n_in;
+    chal->n_out = ch.n_out;
+    if (reason) *reason = r;
+    return r == 0 ? SIPP_OK : SIPP_E_VERIFY;
+}
+
+extern "C" int sipp_plonk_verify_gates(const uint64_t* proof, size_t len, const uint64_t* constants_sigmas_cap, const sipp_plonk_params* p,
+                                       const sipp_fri_params* fp, const sipp_plonk_circuit* c, const uint64_t circuit_digest[4], int* reason) {
+    if (reason) *reason = 0;
+    if (!proof || !constants_sigmas_cap || !p || !fp || !c || !circuit_digest) return SIPP_E_BADARG;
+    const int r = plonk_verify(proof, len, constants_sigmas_cap, *p, *fp, *c, circuit_digest);
+    if (reason) *reason = r;
+    return r == 0 ? SIPP_OK : SIPP_E_VERIFY;
+}
 
 extern "C" int sipp_stark_verify(const uint64_t* proof, size_t len, const sipp_stark_config* cfg, int* reason) {
     if (reason) *reason = 0;

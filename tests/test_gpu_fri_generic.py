@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 from tests.test_oracle_fri_generic import random_instance
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +91,9 @@ def test_generic_opening_proof_identical_to_oracle(ctx, log_n, rate_bits, cap_he
     assert (gch.n_in, gch.n_out) == (och.n_in, och.n_out)
     assert _oracle.fri_verify_openings(got, [o.cap for o in oracles], [o.ncols for o in oracles], [o.n_salt for o in oracles], batches,
                                        log_n, fp, _oracle.challenger([7, 7, 7])) == 0
+    stage, _ = _verify.lib_fri_verify(got, [o.cap for o in oracles], [o.ncols for o in oracles], [o.n_salt for o in oracles], batches, log_n, fp,
+                                      _oracle.challenger([7, 7, 7]))
+    assert stage == 0                        # the library's own verifier (sipp_fri_verify_openings)
 
 
 def test_generic_api_argument_errors(ctx):

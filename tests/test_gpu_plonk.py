@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests import _oracle
+from tests import _oracle, _verify
 from tests.test_gpu_fri_generic import to_params
 from tests.test_oracle_plonk import fri
 
@@ -224,6 +224,7 @@ def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_rout
     assert diff.size == 0, "first mismatch at word %d of %d" % (diff[0], len(ref))
     cs_cap = _oracle.Batch(cs, log_n, rate_bits=rate_bits, cap_height=cap_h).cap
     assert _oracle.plonk_verify_gates(got, cs_cap, op, ofp, circ, digest) == 0
+    assert _verify.lib_plonk_verify(got, cs_cap, op, ofp, circ, digest) == 0          # the library's own verifier (sipp_plonk_verify_gates)
     # the caller's own commitments (constants_sigmas once per circuit; wires before the call): the same proof
     K = circ["num_constants"]
     cs_or, _cs_cap, keep1 = ctx.commit_ex(d_cs, log_n, rate_bits, cap_h)
@@ -236,7 +237,7 @@ def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_rout
     w2 = wires.copy()
     w2[3, int(np.flatnonzero(gate == 1)[2])] ^= 1
     bad = ctx.plonk_prove_gates(dev(w2), d_cs, log_n, gp, gfp, gc, digest, pis)
-    assert _oracle.plonk_verify_gates(bad, cs_cap, op, ofp, circ, digest) == -210
+    assert _oracle.plonk_verify_gates(bad, cs_cap, op, ofp, circ, digest) == -210 and _verify.lib_plonk_verify(bad, cs_cap, op, ofp, circ, digest) == 210
     # malformed circuits: an operand out of range, a program that runs past its words
     for mut in ("operand", "length"):
         c2 = dict(circ, programs=circ["programs"].copy())
