@@ -304,11 +304,23 @@ def poseidon_rows(inp):
     wires = {}
 
     def mds(v):
+        # the entries are below 2^6: the 32-bit halves of the state words are accumulated exactly in uint64 (twelve products of at most 38
+        # bits) and each output is reduced ONCE: lo + 2^32 hi with hi < 2^42, 2^64 = 2^32 - 1 (five times faster than twelve field products)
+        lo = [x & M32 for x in v]
+        hi = [x >> np.uint64(32) for x in v]
         out = []
         for r in range(12):
-            acc = np.zeros_like(v[0])
+            al = np.zeros_like(v[0])
+            ah = np.zeros_like(v[0])
             for c in range(12):
-                acc = gl_add(acc, gl_mul_small(v[c], MDS[r][c]))
+                k = np.uint64(MDS[r][c])
+                if k:
+                    al = al + lo[c] * k
+                    ah = ah + hi[c] * k
+            # value = al + 2^32 (ah_lo + 2^32 ah_hi) = al + 2^32 ah_lo + (2^32 - 1) ah_hi, every summand below 2^64
+            ah_lo, ah_hi = ah & M32, ah >> np.uint64(32)
+            acc = gl_add(al % PP, ((ah_lo << np.uint64(32)) % PP))
+            acc = gl_add(acc, (ah_hi << np.uint64(32)) - ah_hi)
             out.append(acc)
         return out
     for rnd in range(30):
