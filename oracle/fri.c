@@ -353,6 +353,11 @@ int orc_fri_verify_openings(const uint64_t *proof, size_t len, const uint64_t *c
     if (len < 8 || proof[0] != FRI_MAGIC || proof[1] != p->n_rounds || proof[3] != p->num_queries || proof[4] != n_oracles ||
         proof[5] != n_batches || proof[6] != len || proof[7] != log_n)
         return -100;
+    {   /* header word 2 = length of the final polynomial: fixed by the parameters (an unchecked word would be a second encoding of the proof) */
+        unsigned sum_ab = 0;
+        for (unsigned r = 0; r < p->n_rounds; r++) sum_ab += p->arity_bits[r];
+        if (sum_ab > log_n || proof[2] != (((uint64_t)1 << log_n) >> sum_ab)) return -100;
+    }
     for (size_t i = 8; i < len; i++)
         if (proof[i] >= GL_P) return -141; /* canonical field elements only: x + p would be a second encoding of x */
     size_t pos = 8;

@@ -33,3 +33,5 @@ _oracle.stark_prove(2, g["fq12"]).tofile("/tmp/sipp_asan_fq12.bin")
 PY
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 tests/host/verify_fuzz_asan /tmp/sipp_asan_g1h.bin 20000
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 tests/host/verify_fuzz_asan /tmp/sipp_asan_fq12.bin 20000 5
+# ... and the generic verifiers (opening proofs, outer proofs) on serialized cases: tests/test_product_verifier_generic.py writes and runs them
+env -u SIPP_ORACLE_ASAN python -m pytest tests/test_product_verifier_generic.py -q -k sanitizers

@@ -917,6 +917,11 @@ int fri_openings_verify(const uint64_t* sec, size_t sec_len, const uint64_t* con
     if (sec_len < 8 || sec[0] != FRI_MAGIC || sec[1] != p.n_rounds || sec[3] != p.num_queries || sec[4] != n_oracles || sec[5] != n_batches ||
         sec[6] != sec_len || sec[7] != log_n)
         return 100;
+    {   // header word 2 = length of the final polynomial: fixed by the parameters (an unchecked word would be a second encoding of the proof)
+        unsigned sum_ab = 0;
+        for (uint32_t r = 0; r < p.n_rounds && r < SIPP_FRI_MAX_ROUNDS; r++) sum_ab += p.arity_bits[r];
+        if (sum_ab > log_n || sec[2] != (((uint64_t)1 << log_n) >> sum_ab)) return 100;
+    }
     for (size_t i = 8; i < sec_len; i++)
         if (sec[i] >= gl::P) return 141;
     for (size_t b = 0; b < n_batches; b++)

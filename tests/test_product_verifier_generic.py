@@ -116,3 +116,54 @@ def test_opening_proofs_of_polynomial_batches(rate_bits, cap_height, arities, po
     # another transcript in front: the challenges differ, nothing fits
     g, _ = lib_fri_verify(pf, caps, ncols, n_salt, batches, log_n, fp, _oracle.challenger([7, 7, 8]))
     assert g == -_oracle.fri_verify_openings(pf, caps, ncols, n_salt, batches, log_n, fp, _oracle.challenger([7, 7, 8])) != 0
+
+
+def _fri_words(fp):
+    return [fp.rate_bits, fp.cap_height, fp.pow_bits, fp.num_queries, fp.pow_rule, fp.hiding, fp.n_rounds] + [int(fp.arity_bits[i]) for i in range(32)]
+
+
+def _run_fuzz_case(tmp_path, words, iters):
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(__file__), "host")
+    subprocess.check_call(["make", "-C", host, "-s", "verify_fuzz_asan"])
+    path = tmp_path / "case.bin"
+    np.array([int(x) % (1 << 64) for x in words], dtype=np.uint64).tofile(path)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([os.path.join(host, "verify_fuzz_asan"), "case", str(path), str(iters)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "verify fuzz ok" in out.stdout and " 0 accepted" in out.stdout, out.stdout + out.stderr
+
+
+def test_generic_verifiers_on_damaged_proofs_under_the_sanitizers(tmp_path):
+    """verify.cpp compiled with AddressSanitizer / UBSan (tests/host/verify_fuzz.cpp, `case` mode): an opening proof over a salted and a plain
+    oracle, and an outer proof with its circuit, damaged 1,500 times each (header words, truncations with a consistent length word, random words,
+    extensions): refusals only, nothing read out of bounds"""
+    log_n, rate_bits, cap_height = 10, 2, 2
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    a, b = _oracle.rand_field(rng, (5, n)), _oracle.rand_field(rng, (3, n))
+    oa = _oracle.SaltedBatch(a, log_n, rate_bits, cap_height, from_values=True, salt=_oracle.rand_field(rng, (4, n << rate_bits)))
+    ob = _oracle.Batch(b, log_n, rate_bits=rate_bits, cap_height=cap_height)
+    fp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_height, pow_bits=5, num_queries=7, pow_rule=0, hiding=1, arities=[3, 2, 1])
+    batches = [((123456789, 987654321), [(0, 0, 5), (1, 1, 3)]), ((55555, 0), [(1, 0, 2)])]
+    pf = _oracle.fri_prove_openings([oa, ob], batches, log_n, fp, _oracle.challenger([1, 2]))
+    ch = _oracle.challenger([1, 2])
+    words = [1, log_n, 2, len(batches)] + _fri_words(fp)
+    for o, nc, ns in ((oa, 5, 4), (ob, 3, 0)):
+        words += [nc, ns] + [int(x) for x in np.asarray(o.cap).reshape(-1)]
+    for pt, ranges in batches:
+        words += [pt[0], pt[1], len(ranges)] + [x for r in ranges for x in r]
+    words += [int(ch.state[i]) for i in range(12)] + [int(ch.in_buf[i]) for i in range(8)] + [int(ch.n_in)] + [int(ch.out_buf[i]) for i in range(8)] + [int(ch.n_out)]
+    words += [len(pf)] + [int(x) for x in pf]
+    _run_fuzz_case(tmp_path, words, 1500)
+    ps, circ, wires, cs, gate, pis, pih = _synth(7)
+    p = _oracle.plonk_params(circ["num_routed"], 8, 2)
+    fp = fri(7, rate_bits=3, cap_height=2, nq=4, arity=2, fpb=3)
+    digest = (9, 8, 7, 6)
+    pf = _oracle.plonk_prove_gates(wires, cs, 7, p, fp, circ, digest, pis)
+    cs_cap = _oracle.Batch(cs, 7, rate_bits=3, cap_height=2).cap
+    words = [2, p.num_routed_wires, p.max_degree, p.num_challenges] + _fri_words(fp)
+    words += [circ["num_wires"], circ["num_constants"], circ["num_selectors"], len(circ["gates"])] + [int(x) for g in circ["gates"] for x in g]
+    words += [len(circ["programs"])] + [int(x) for x in circ["programs"]]
+    words += list(digest) + [int(x) for x in np.asarray(cs_cap).reshape(-1)] + [len(pf)] + [int(x) for x in pf]
+    _run_fuzz_case(tmp_path, words, 1500)
