@@ -23,7 +23,8 @@ def source_hash():
     another code state from current ones"""
     import hashlib
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")))
+    # (verify.cpp is the host-only verifier: no kernel, no part of any profiled command's device or host time -- not in the hash)
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp", ".h", ".inc")) and f != "verify.cpp")
     for f in names:
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(CSRC, f), "rb").read())

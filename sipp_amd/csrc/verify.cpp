@@ -667,7 +667,13 @@ int fri_verify(Reader& rb, const uint64_t* const* caps, const uint32_t* ncols, c
             for (uint32_t qi = t; qi < fp.num_queries; qi += nt) verdict[qi] = query(qi);
         };
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, t);
+        unsigned started = 1;
+        try {
+            for (; started < nt; started++) pool.emplace_back(work, started);
+        } catch (...) {                    // no more threads to be had: the rounds nobody took are checked here
+            for (uint32_t qi = 0; qi < fp.num_queries; qi++)
+                if (qi % nt >= started) verdict[qi] = query(qi);
+        }
         if (nt) work(0);
         for (std::thread& th : pool) th.join();
     }
@@ -1099,7 +1105,12 @@ extern "C" int sipp_fri_verify_openings(const uint64_t* proof, size_t len, const
     if (chal->n_in > 8 || chal->n_out > 8) return SIPP_E_BADARG;
     ch.n_in = (uint32_t)chal->n_in;
     ch.n_out = (uint32_t)chal->n_out;
-    const int r = fri_openings_verify(proof, len, caps, ncols, n_salt ? n_salt : zero.data(), n_oracles, bv.data(), n_batches, log_n, *p, ch);
+    int r;
+    try {
+        r = fri_openings_verify(proof, len, caps, ncols, n_salt ? n_salt : zero.data(), n_oracles, bv.data(), n_batches, log_n, *p, ch);
+    } catch (...) {                        // (allocation failure: nothing crosses the C boundary)
+        return SIPP_E_NOMEM;
+    }
     memcpy(chal->state, ch.state, sizeof ch.state);
     memcpy(chal->in_buf, ch.in_buf, sizeof ch.in_buf);
     memcpy(chal->out_buf, ch.out_buf, sizeof ch.out_buf);
@@ -1113,7 +1124,12 @@ extern "C" int sipp_plonk_verify_gates(const uint64_t* proof, size_t len, const 
                                        const sipp_fri_params* fp, const sipp_plonk_circuit* c, const uint64_t circuit_digest[4], int* reason) {
     if (reason) *reason = 0;
     if (!proof || !constants_sigmas_cap || !p || !fp || !c || !circuit_digest) return SIPP_E_BADARG;
-    const int r = plonk_verify(proof, len, constants_sigmas_cap, *p, *fp, *c, circuit_digest);
+    int r;
+    try {
+        r = plonk_verify(proof, len, constants_sigmas_cap, *p, *fp, *c, circuit_digest);
+    } catch (...) {
+        return SIPP_E_NOMEM;
+    }
     if (reason) *reason = r;
     return r == 0 ? SIPP_OK : SIPP_E_VERIFY;
 }
@@ -1125,7 +1141,12 @@ extern "C" int sipp_stark_verify(const uint64_t* proof, size_t len, const sipp_s
     if (cfg) c = *cfg;
     else sipp_default_config(&c);
     if (c.num_challenges != 2) return SIPP_E_UNSUPPORTED;
-    const int r = verify(proof, len, c);
+    int r;
+    try {
+        r = verify(proof, len, c);
+    } catch (...) {
+        return SIPP_E_NOMEM;
+    }
     if (reason) *reason = r;
     return r == 0 ? SIPP_OK : SIPP_E_VERIFY;
 }
