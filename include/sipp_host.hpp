@@ -102,6 +102,15 @@ inline void verify_stark_proof(const std::vector<uint64_t>& flat, const sipp_sta
     if (rc != SIPP_OK) throw Error(rc, "verify_stark_proof: refused at stage " + std::to_string(reason));
 }
 
+// `data.verify(proof)` for the OUTER proof (reference src/verifier_circuit.rs:254; plonk/verifier.rs) of sipp_plonk_prove_gates: verifier data =
+// the constants_sigmas cap and the circuit digest; the gate set is the data the prover interpreted.  Throws Error(SIPP_E_VERIFY) naming the stage.
+inline void verify_plonk_proof(const std::vector<uint64_t>& flat, const std::vector<uint64_t>& constants_sigmas_cap, const sipp_plonk_params& params,
+                               const sipp_fri_params& fri, const sipp_plonk_circuit& circuit, const uint64_t circuit_digest[4]) {
+    int reason = 0;
+    const int rc = ::sipp_plonk_verify_gates(flat.data(), flat.size(), constants_sigmas_cap.data(), &params, &fri, &circuit, circuit_digest, &reason);
+    if (rc != SIPP_OK) throw Error(rc, "verify_plonk_proof: refused at stage " + std::to_string(reason));
+}
+
 // ---- starky's proof structs (field names of starky::proof / plonky2::fri::proof) ----
 using F = uint64_t;  // canonical Goldilocks
 struct Ext {

@@ -94,6 +94,15 @@ pub fn verify_stark_proof(proof: &[u64]) -> Result<()> {
     if rc == 0 { Ok(()) } else { Err(anyhow::anyhow!("sipp_stark_verify: status {} at stage {}", rc, reason)) }
 }
 
+/// `data.verify(proof)` for the outer proof (reference src/verifier_circuit.rs:254): plonk/verifier.rs over a proof of sipp_plonk_prove_gates,
+/// with the circuit's verifier data (constants_sigmas cap, digest) and the gate set the prover interpreted.
+pub fn verify_plonk_proof(proof: &[u64], constants_sigmas_cap: &[u64], params: &ffi::SippPlonkParams, fri: &ffi::SippFriParams,
+                          circuit: &ffi::SippPlonkCircuit, circuit_digest: &[u64; 4]) -> Result<()> {
+    let mut reason: std::os::raw::c_int = 0;
+    let rc = unsafe { ffi::sipp_plonk_verify_gates(proof.as_ptr(), proof.len(), constants_sigmas_cap.as_ptr(), params, fri, circuit, circuit_digest.as_ptr(), &mut reason) };
+    if rc == 0 { Ok(()) } else { Err(anyhow::anyhow!("sipp_plonk_verify_gates: status {} at stage {}", rc, reason)) }
+}
+
 pub fn io_shard(num_io: usize, world: u32, rank: u32) -> Result<std::ops::Range<usize>> {
     let (mut first, mut count) = (0usize, 0usize);
     let rc = unsafe { ffi::sipp_io_shard(num_io, world, rank, &mut first, &mut count) };
