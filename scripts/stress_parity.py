@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off stress run of the proof parity (GPU box): fresh random obligations per seed -- random points, random Fq12 elements,
 random exponents incl. edge patterns, random record counts 1..9 -- outputs from sipp_exp_outputs, then every proof word for
-word against the CPU oracle and through its verifier.  usage: stress_parity.py [first_seed=100] [count=30]"""
+word against the CPU oracle, through its verifier and through the library's own; every fourth seed also 1 .. 3 final-pairing records (kind 6).  usage: stress_parity.py [first_seed=100] [count=30]"""
 import os
 import sys
 import time
@@ -93,10 +93,21 @@ for seed in range(first, first + count):
             print("MISMATCH seed %d kind %d: oracle proves, GPU refuses (%s)" % (seed, kind, str(ge)[:100]))
             np.save(os.path.join(ROOT, "gpurun_out", "stress_fail_seed%d_kind%d.npy" % (seed, kind)), ios)
             continue
-        ok = len(got) == len(ref) and bool((got == ref).all()) and _oracle.stark_verify(got) == 0
+        ok = len(got) == len(ref) and bool((got == ref).all()) and _oracle.stark_verify(got) == 0 and sipp_amd.stark_verify(got) == 0
         if not ok:
             bad += 1
             print("MISMATCH seed %d kind %d (%d records)" % (seed, kind, len(recs)))
+    if seed % 4 == 0:                # the final-pairing AIR (kind 6): 1 .. 3 records of random / edge multiples of the generators
+        npair = int(rng.integers(1, 4))
+        prec = np.zeros((npair, 144), dtype=np.uint32)
+        for k in range(npair):
+            prec[k, :48] = bn.g1_to_u32(bn.g1_mul(bn.G1, scalar() % bn.R or 1)) + bn.g2_to_u32(bn.g2_mul(bn.G2, scalar() % bn.R or 5))
+        pios = ctx.exp_outputs(6, prec)
+        got = ctx.prove(6, pios)
+        ref = _oracle.stark_prove(6, pios)
+        if not (len(got) == len(ref) and bool((got == ref).all()) and _oracle.stark_verify(got) == 0 and sipp_amd.stark_verify(got) == 0):
+            bad += 1
+            print("MISMATCH seed %d kind 6 (%d records)" % (seed, npair))
     print("seed %d ok (%d/%d/%d records, %.0f s)" % (seed, n1, n2, n12, time.time() - t0), flush=True)
 print("done: %d seeds, %d mismatches" % (count, bad))
 sys.exit(1 if bad else 0)
