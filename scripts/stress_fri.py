@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import sipp_amd  # noqa: E402
 from sipp_amd._lib import to_device  # noqa: E402
-from tests import _oracle  # noqa: E402
+from tests import _oracle, _verify  # noqa: E402
 from tests.test_gpu_fri_generic import gpu_challenger, to_params  # noqa: E402
 
 P = _oracle.P
@@ -103,6 +103,10 @@ for seed in range(first, first + count):
         ok = ok and [gch.state[i] for i in range(12)] == [och.state[i] for i in range(12)]
         ok = ok and _oracle.fri_verify_openings(got, [o.cap for o in oracles], [o.ncols for o in oracles], [o.n_salt for o in oracles],
                                                 batches, log_n, fp, _oracle.challenger([seed, 1, 2])) == 0
+        # ... and the library's own verifier (sipp_fri_verify_openings), transcript included
+        lib_stage, lib_ch = _verify.lib_fri_verify(got, [o.cap for o in oracles], [o.ncols for o in oracles], [o.n_salt for o in oracles], batches, log_n, fp,
+                                                   _oracle.challenger([seed, 1, 2]))
+        ok = ok and lib_stage == 0 and lib_ch == bytes(och)
     except sipp_amd.SippError as e:
         if e.code == -7:        # SIPP_E_UNSUPPORTED: outside the documented range of the GPU layer (e.g. a layer of < 16 values)
             declined += 1

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import plonk_synth as ps  # noqa: E402
 import sipp_amd  # noqa: E402
 from sipp_amd._lib import to_device  # noqa: E402
-from tests import _oracle  # noqa: E402
+from tests import _oracle, _verify  # noqa: E402
 from tests.test_gpu_fri_generic import to_params  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
@@ -62,6 +62,7 @@ for seed in range(first, first + count):
         continue
     cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=cap_h).cap
     ok = len(got) == len(ref) and bool((got == ref).all()) and _oracle.plonk_verify_gates(got, cs_cap, op, ofp, circ, digest) == 0
+    ok = ok and _verify.lib_plonk_verify(got, cs_cap, op, ofp, circ, digest) == 0          # the library's own verifier
     bad += not ok
     print(("ok   " if ok else "MISMATCH ") + tag + " (%.0f s)" % (time.time() - t0), flush=True)
 ctx.close()
