@@ -320,6 +320,8 @@ class Prover {
     }
     Prover(const Prover&) = delete;
     Prover& operator=(const Prover&) = delete;
+    // every *_circuit call verifies its proof before returning it (default: on, as upstream's generators do)
+    void set_verify_after_prove(bool on) { verify_after_prove_ = on; }
 
     // hardened = true: the same obligations proved with the hardened curve AIR (sipp_hip.h kinds 4 / 5): for
     // statements whose offsets an adversary may choose
@@ -498,6 +500,7 @@ class Prover {
    private:
     sipp_ctx* ctx_[3] = {nullptr, nullptr, nullptr};
     size_t max_io_[3] = {0, 0, 0};
+    bool verify_after_prove_ = true;
 
     template <class IO>
     static const uint32_t* words(const std::vector<IO>& v) {
@@ -523,9 +526,12 @@ class Prover {
         return io;
     }
     template <class In, class Out>
-    static void finish(const std::vector<ExpIO<In, Out>>& io, ExpCircuitResult<Out>* r) {
+    void finish(const std::vector<ExpIO<In, Out>>& io, ExpCircuitResult<Out>* r) const {
         r->outputs.resize(io.size());
         for (size_t i = 0; i < io.size(); i++) r->outputs[i] = io[i].out;
+        // the generators of starky-bn254 run starky's verify_stark_proof on the proof they have just made: the library's
+        // own verifier, a few milliseconds on the host; set_verify_after_prove(false) leaves the check to the caller
+        if (verify_after_prove_) verify_stark_proof(r->flat);
         r->proof = StarkProofWithPublicInputs::from_flat(r->flat.data(), r->flat.size());
     }
     template <class In, class Out>
