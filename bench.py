@@ -150,8 +150,12 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
     U32 multiply-add with 2-bit limb range checks, random access, reducing, arithmetic, base-sum, constant and public-input gates in
     three selector groups; the reference's own gate set and witness live in un-vendored crates) through sipp_plonk_prove_gates: wires
     commitment, Z / partial products, the gate constraints interpreted inside the quotient kernel, quotient commitment, openings, FRI.
-    constants_sigmas is committed once, outside the timing, as plonky2 does at circuit-build time.  Witness generation stays on the host
-    (numpy, this leg's own generator): its time is part of the object's headline (`witness_generation_s`, `end_to_end_s_per_proof`)."""
+    constants_sigmas is committed once, outside the timing, as plonky2 does at circuit-build time.  A timed step is the WHOLE prove():
+    witness generation on the device (sipp_plonk_generate_witness: the gates' generators, one lane per row, in place on the wire table
+    -- until round 6's last step a numpy generator on one host core, 2.3 s beside a 72 ms proof) and then everything below it.  What
+    stays on the host is what plonky2 does outside prove(): building the circuit and assigning the input cells (`host_circuit_and_inputs_s`).
+    The C port of the generators (oracle/plonk_witness.c, OpenMP) runs once on the same inputs: its table must equal the device's
+    (`witness_matches_cpu_port`) and its time is the CPU column of this step."""
     import ctypes as C
     import torch
     import sipp_amd
@@ -172,9 +176,11 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         st[0, :len(pis)] = torch.tensor(pis, dtype=torch.int64)
         pih = [int(x) & 0xFFFFFFFFFFFFFFFF for x in ctx.poseidon_permute(st)[0, :4].tolist()]    # hash_n_to_hash_no_pad of <= 8 inputs
         t0 = time.perf_counter()
-        wires, cs, _gate = ps.witness(circ, log_n, 2026, pih)
-        t_wit = time.perf_counter() - t0
+        wires, cs, _gate = ps.witness(circ, log_n, 2026, pih, inputs_only=True)       # input cells, constants, sigmas: the caller's side
+        t_inputs = time.perf_counter() - t0
+        gens = ps.generators(circ)
         d_w, d_cs = to_device(wires), to_device(cs)
+        d_k = d_cs[:K]
         gp = sipp_amd.PlonkParams(R, D, CH)
         fp = sipp_amd.FriParams()
         fp.rate_bits, fp.cap_height, fp.pow_bits, fp.num_queries, fp.pow_rule, fp.hiding = rate_bits, cap_h, pow_bits, nq, 0, 0
@@ -182,7 +188,9 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         gc = sipp_amd.PlonkCircuit.from_dict(circ)
         digest = (0x53495050, 0x6f757465, 0x72706c6f, 0x6e6b3035)
         cs_or, cs_cap, keep = ctx.commit_ex(d_cs, log_n, rate_bits, cap_h)          # once per circuit
-        prove = lambda: ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, fp, gc, digest, pis, cs_oracle=cs_or)
+        def prove():
+            ctx.plonk_generate_witness(d_w, d_k, log_n, gens, pih)             # in place; the input cells are not written: repeatable
+            return ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, fp, gc, digest, pis, cs_oracle=cs_or)
         prove()
         ctx.profile(True)
         ctx.profile_reset()
@@ -195,6 +203,8 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         rep = {k: v["ms"] / steps for k, v in ctx.profile_report().items()}
         ctx.profile(False)
         del keep
+        wit_names = [k for k in rep if k.startswith("witness_")]
+        wit_ms = sum(rep[k] for k in wit_names)
         ntt_names = [k for k in rep if k.startswith(("ntt_", "lde_", "bitrev"))]
         leaf_names = [k for k in rep if k.startswith("poseidon_leaves")]
         ntt_ms, leaf_ms = sum(rep[k] for k in ntt_names), sum(rep[k] for k in leaf_names)
@@ -206,8 +216,15 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         perms = m * sum((c + 7) // 8 for c in (W, zs_cols, q_cols))
         leaf_bytes = 8.0 * m * (W + zs_cols + q_cols) + 3 * 32.0 * m
         verified = None
+        cpu_wit = {}
         if verify:
             from tests import _oracle
+            from sipp_amd._lib import to_host
+            t_c = time.perf_counter()
+            ref_w = _oracle.plonk_generate_witness(wires, cs[:K], log_n, gens, pih)
+            cpu_wit = {"cpu_witness_generation_s": time.perf_counter() - t_c, "cpu_witness_kind": "port (oracle/plonk_witness.c, OpenMP, incl. one copy of the table)",
+                       "cpu_cores": os.cpu_count(), "witness_matches_cpu_port": bool((to_host(d_w) == ref_w).all())}
+            del ref_w
             ofp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_h, pow_bits=pow_bits, num_queries=nq, pow_rule=0, hiding=0, arity_bits=4,
                                      final_poly_bits=5, degree_bits=log_n)
             # both verifiers: the library's own (sipp_plonk_verify_gates: data.verify's part for the outer proof) and the oracle's
@@ -215,8 +232,8 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
             t_v = time.perf_counter()
             lib_ok = _verify.lib_plonk_verify(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
             lib_verify_ms = round(1e3 * (time.perf_counter() - t_v), 2)
-            verified = lib_ok and _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
-        return {"what": "plonky2 prove() below witness generation on a synthetic circuit with gates as data (sipp_plonk_prove_gates)",
+            verified = lib_ok and _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0 and cpu_wit["witness_matches_cpu_port"]
+        return {"what": "plonky2 prove() INCLUDING witness generation (sipp_plonk_generate_witness, then sipp_plonk_prove_gates) on a synthetic circuit with gates and generators as data",
                 "shape": {"degree_bits": log_n, "num_wires": W, "num_routed_wires": R, "num_constants": K, "num_challenges": CH, "quotient_degree_factor": D,
                           "rate_bits": rate_bits, "cap_height": cap_h, "num_queries": nq, "pow_bits": pow_bits, "arity": 16,
                           "gates": circ["gate_names"], "num_gate_constraints": circ["num_gate_constraints"], "program_words": int(len(circ["programs"])),
@@ -225,9 +242,10 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                               "(built by un-vendored crates): 2^%d rows here" % log_n,
                 "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified,
                 **({"library_verifier_ms": lib_verify_ms} if verify else {}),
-                # HEADLINE, next to ms_per_proof: the host side of the same proof.  The GPU path starts at the wire values; producing them
-                # (this leg's numpy generator, one core) costs far more than proving them -- what a deployment would have to move next
-                "witness_generation_s": t_wit, "end_to_end_s_per_proof": t_wit + ms * 1e-3,
+                # HEADLINE, next to ms_per_proof (which contains it): witness generation now runs on the device (row-local generators; values
+                # that travel between rows through copy constraints are the caller's to order).  The host keeps what plonky2 does outside prove()
+                "witness_generation_s": wit_ms * 1e-3, "witness_generation_ms": wit_ms, "prove_below_witness_ms": ms - wit_ms,
+                "end_to_end_s_per_proof": ms * 1e-3, "host_circuit_and_inputs_s": t_inputs, **cpu_wit,
                 "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
                 "roofline": {"transforms": {"bound": "hbm", "kernels": sorted(ntt_names), "algorithmic_bytes": ntt_bytes, "ms": ntt_ms,
                                             "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

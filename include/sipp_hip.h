@@ -442,6 +442,41 @@ int sipp_plonk_prove_gates(sipp_ctx *ctx, const uint64_t *d_wires, const uint64_
                            const sipp_fri_params *fp, const sipp_plonk_circuit *c, const uint64_t circuit_digest[4],
                            const uint64_t *public_inputs, uint32_t n_public_inputs, uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
 
+/* ---- round 6: the gates' WITNESS GENERATORS on the device ---------------------------------------------------------------------------
+ * plonky2's prove() starts with generate_partial_witness (iop/generator.rs; reference src/verifier_circuit.rs:253 `data.prove(pw)`): every
+ * gate instance's SimpleGenerator fills the wires its constraints determine from the wires the caller (or a copy constraint) set.  Here the
+ * generators of the gate families a recursive verifier is made of run for ALL rows of their gate at once, one lane per row, in place on
+ * the wire table the prover reads next: a generator = (family, the selector column and value that mark its rows, layout parameters p[]).
+ *   SIPP_GEN_ARITHMETIC     p = n_ops, const col c0, const col c1       w[4k+3] = c0 w[4k] w[4k+1] + c1 w[4k+2]          (ArithmeticBaseGenerator)
+ *   SIPP_GEN_BASE_SPLIT     p = n_limbs, bits per limb                  w[1+i] = limb i of the integer w[0]                (BaseSplitGenerator)
+ *   SIPP_GEN_CONSTANT       p = n, first const col                      w[i] = const[p1 + i]                               (ConstantGate)
+ *   SIPP_GEN_PUBLIC_INPUT   --                                          w[i] = public_inputs_hash[i], i < 4                (PublicInputGate)
+ *   SIPP_GEN_U32_MUL_ADD    p = n_ops, stride, limbs per half           per op at b: (lo, hi) of w[b] w[b+1] + w[b+2] into b+3, b+4, then the
+ *                                                                       2-bit limbs of lo and of hi                        (U32ArithmeticGenerator)
+ *   SIPP_GEN_RANDOM_ACCESS  p = copies, stride, bits                    per copy at b: index, claimed, 2^bits items, bits: claimed = items[index],
+ *                                                                       bits of index                                      (RandomAccessGenerator)
+ *   SIPP_GEN_REDUCING       p = K, W                                    alpha (2), old acc (2), K coefficients, K accumulators (2 each) over
+ *                                                                       F[X]/(X^2 - W): acc_i = acc_(i-1) alpha + c_i      (ReducingGenerator)
+ *   SIPP_GEN_POSEIDON       p = in, out, sbox                           the permutation of w[in .. in+12): every S-box input of rounds 1 .. 29
+ *                                                                       (36 + 22 + 48 wires from sbox) and the 12 outputs  (PoseidonGenerator)
+ * The generators are ROW-LOCAL: values that reach a gate's inputs through copy constraints from another gate's outputs have to be there
+ * already (the caller orders its calls by level); d_constants = the circuit's constant columns [num_constants][N] (selectors first: the
+ * front of d_constants_sigmas).  SIPP_E_BADARG for a layout that leaves the wire table or an unknown family. */
+#define SIPP_GEN_ARITHMETIC 1
+#define SIPP_GEN_BASE_SPLIT 2
+#define SIPP_GEN_CONSTANT 3
+#define SIPP_GEN_PUBLIC_INPUT 4
+#define SIPP_GEN_U32_MUL_ADD 5
+#define SIPP_GEN_RANDOM_ACCESS 6
+#define SIPP_GEN_REDUCING 7
+#define SIPP_GEN_POSEIDON 8
+typedef struct {
+    uint32_t kind, selector_index, row;
+    uint32_t p[5];
+} sipp_plonk_generator;
+int sipp_plonk_generate_witness(sipp_ctx *ctx, uint64_t *d_wires, const uint64_t *d_constants, uint32_t log_n, uint32_t num_wires,
+                                uint32_t num_constants, const sipp_plonk_generator *gens, size_t n_gens, const uint64_t public_inputs_hash[4]);
+
 /* ---- verification of the generic proofs (host code like sipp_stark_verify; stages in *reason, may be NULL) -------------------------
  * sipp_fri_verify_openings: PolynomialBatch::verify_openings over a proof of sipp_fri_prove_openings -- caps[o] = the cap of oracle o
  * (2^cap_height x 4 words), ncols / n_salt (may be NULL = 0) per oracle, the batches as proved; the caller's transcript goes in and

@@ -116,4 +116,17 @@ int orc_plonk_perm_prove(const uint64_t *wires, const uint64_t *sigmas, unsigned
 /* sigmas_cap: the verifier's copy of the constants_sigmas commitment (part of the verifier data in plonky2) */
 int orc_plonk_perm_verify(const uint64_t *proof, size_t len, const uint64_t *sigmas_cap, const orc_plonk_params *p,
                           const orc_fri_params *fp, const uint64_t circuit_digest[4], const uint64_t public_inputs_hash[4]);
+/* ---- round 6: the gates' WITNESS GENERATORS (plonk_witness.c) -----------------------------------------------------------------------
+ * plonky2's generate_partial_witness (iop/generator.rs), first step of prove(): the SimpleGenerator of every gate instance fills the wires
+ * the gate's constraints determine.  Row-local, family by family, layouts as data (the product's sipp_plonk_generator, include/sipp_hip.h):
+ * kind 1 arithmetic (p: n_ops, c0 column, c1 column), 2 base split (n_limbs, bits), 3 constant (n, first column), 4 public input,
+ * 5 U32 multiply-add (n_ops, stride, 2-bit limbs per half), 6 random access (copies, stride, bits), 7 reducing (K, W), 8 Poseidon (in, out,
+ * first S-box wire).  wires [num_wires][N] in place, consts [num_constants][N]; rows of a generator = consts[selector_index][row] == row value.
+ * Returns 0, or -1 for a layout that leaves the tables / an unknown family. */
+typedef struct {
+    uint32_t kind, selector_index, row;
+    uint32_t p[5];
+} orc_plonk_generator;
+int orc_plonk_generate_witness(uint64_t *wires, const uint64_t *consts, unsigned log_n, uint32_t num_wires, uint32_t num_constants,
+                               const orc_plonk_generator *gens, size_t n_gens, const uint64_t pih[4]);
 #endif

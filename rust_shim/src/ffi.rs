@@ -120,6 +120,16 @@ pub struct SippPlonkCircuit {
     pub program_words: u32,
 }
 
+/// one gate family's witness generator with its layout (include/sipp_hip.h, "WITNESS GENERATORS"): kind = SIPP_GEN_*
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkGenerator {
+    pub kind: u32,
+    pub selector_index: u32,
+    pub row: u32,
+    pub p: [u32; 5],
+}
+
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
@@ -163,6 +173,8 @@ extern "C" {
     pub fn sipp_fri_verify_openings(proof: *const u64, len: usize, caps: *const *const u64, ncols: *const u32, n_salt: *const u32, n_oracles: usize,
                                     batches: *const SippFriBatch, n_batches: usize, log_n: u32, p: *const SippFriParams, ch: *mut SippChallenger,
                                     reason: *mut c_int) -> c_int;
+    pub fn sipp_plonk_generate_witness(ctx: *mut SippCtxOpaque, d_wires: *mut u64, d_constants: *const u64, log_n: u32, num_wires: u32,
+                                       num_constants: u32, gens: *const SippPlonkGenerator, n_gens: usize, public_inputs_hash: *const u64) -> c_int;
     pub fn sipp_plonk_verify_gates(proof: *const u64, len: usize, constants_sigmas_cap: *const u64, p: *const SippPlonkParams, fp: *const SippFriParams,
                                    c: *const SippPlonkCircuit, circuit_digest: *const u64, reason: *mut c_int) -> c_int;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;

@@ -69,6 +69,11 @@ class PlonkCircuit(C.Structure):
         return c
 
 
+class PlonkGenerator(C.Structure):
+    """sipp_plonk_generator: one gate family's witness generator with its layout (include/sipp_hip.h, "WITNESS GENERATORS")"""
+    _fields_ = [("kind", C.c_uint32), ("selector_index", C.c_uint32), ("row", C.c_uint32), ("p", C.c_uint32 * 5)]
+
+
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
                 ("n_out", C.c_uint64)]
@@ -136,6 +141,7 @@ SIGNATURES = {
     "sipp_plonk_gates_proof_size": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), C.POINTER(PlonkCircuit), C.c_uint32]),
     "sipp_plonk_prove_gates": (C.c_int, [vp, vp, vp, C.POINTER(Oracle), u64p, C.POINTER(Oracle), C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams),
                                          C.POINTER(PlonkCircuit), u64p, u64p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_plonk_generate_witness": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PlonkGenerator), C.c_size_t, u64p]),
     "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
@@ -422,6 +428,13 @@ class Ctx:
                                                self._u64(digest), self._u64(pis) if pis else None, len(pis), out.ctypes.data, cap, C.byref(n)),
                  "plonk_prove_gates")
         return out[: n.value]
+
+    def plonk_generate_witness(self, wires, constants, log_n, gens, pih=None):
+        """sipp_plonk_generate_witness: the gates' witness generators, in place on the device wire table [num_wires][N]; constants
+        [>= num_constants][N] device tensor (the front of constants_sigmas); gens = [(kind, selector_index, row, p0 .. p4)]"""
+        arr = (PlonkGenerator * len(gens))(*[PlonkGenerator(int(g[0]), int(g[1]), int(g[2]), (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
+        self._ck(self.L.sipp_plonk_generate_witness(self.h, wires.data_ptr(), constants.data_ptr(), log_n, wires.shape[0], constants.shape[0], arr,
+                                                    len(gens), None if pih is None else self._u64([int(x) for x in pih])), "plonk_generate_witness")
 
     def plonk_perm_prove(self, wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
         cap = self.L.sipp_plonk_perm_proof_size(log_n, C.byref(p), C.byref(fp))

@@ -620,6 +620,26 @@ def plonk_verify_gates(proof, cs_cap, p, fp, circ, digest):
                                     np.asarray(digest, dtype=np.uint64))
 
 
+# ---- the gates' witness generators (oracle/plonk_witness.c) ----
+class OrcPlonkGenerator(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("selector_index", C.c_uint32), ("row", C.c_uint32), ("p", C.c_uint32 * 5)]
+
+
+def plonk_generate_witness(wires, consts, log_n, gens, pih, threads=None):
+    """orc_plonk_generate_witness on a COPY of wires [num_wires][N]; consts [num_constants][N]; gens = tools/plonk_synth.generators(circ)"""
+    L = _plonk_lib()
+    L.orc_plonk_generate_witness.argtypes = [u64p, u64p, C.c_uint, C.c_uint32, C.c_uint32, C.POINTER(OrcPlonkGenerator), C.c_size_t, u64p]
+    L.orc_plonk_generate_witness.restype = C.c_int
+    w = np.ascontiguousarray(wires, dtype=np.uint64).copy()
+    k = np.ascontiguousarray(consts, dtype=np.uint64)
+    arr = (OrcPlonkGenerator * len(gens))(*[OrcPlonkGenerator(g[0], g[1], g[2], (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
+    rc = L.orc_plonk_generate_witness(w.reshape(-1), k.reshape(-1), log_n, w.shape[0], k.shape[0], arr, len(gens),
+                                      np.asarray([int(x) for x in pih], dtype=np.uint64))
+    if rc:
+        raise RuntimeError("orc_plonk_generate_witness: %d" % rc)
+    return w
+
+
 def plonk_gate_constraints_base(circ, wires_row, consts_row, pih):
     L = _plonk_gates_lib()
     cc = plonk_circuit(circ)

@@ -250,6 +250,48 @@ def test_gates_as_data_proof_identical_to_oracle(ctx, log_n, num_wires, num_rout
         assert e.value.code == -1
 
 
+@pytest.mark.parametrize("log_n", [10, 14])
+def test_witness_generators_match_the_oracle_and_feed_the_prover(ctx, log_n):
+    """sipp_plonk_generate_witness (round 6: plonky2's generate_partial_witness for the recursion-shaped gate set, one lane per row): from
+    the input cells alone -- the generated cells hold garbage -- the device rebuilds the wire table of oracle/plonk_witness.c (and of
+    the numpy generator) bit for bit, family by family and all at once; the proof of the generated table is the oracle's proof of the
+    numpy witness word for word; layouts that leave the table are SIPP_E_BADARG before any launch"""
+    import sipp_amd
+    from tests.test_oracle_plonk import _synth
+    ps, circ, wires, cs, gate, pis, pih = _synth(log_n, 136, 80, seed=60 + log_n)
+    K = circ["num_constants"]
+    gens = ps.generators(circ)
+    blank = ps.blank_generated(circ, wires, gate, value=0xDEADBEEF)
+    ref = _oracle.plonk_generate_witness(blank, cs[:K], log_n, gens, pih)
+    assert (ref == wires).all()
+    d_cs = dev(cs)
+    d_w = dev(blank)
+    ctx.plonk_generate_witness(d_w, d_cs[:K], log_n, gens, pih)
+    got = host(d_w)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, "first mismatch: wire %d row %d (gate %d)" % (bad[0][0], bad[0][1], gate[bad[0][1]])
+    # one family alone leaves every other row as it was
+    for fam in (ps.GEN_POSEIDON, ps.GEN_U32_MUL_ADD, ps.GEN_REDUCING):
+        d_w1 = dev(blank)
+        g1 = [g for g in gens if g[0] == fam]
+        ctx.plonk_generate_witness(d_w1, d_cs[:K], log_n, g1, pih)
+        assert (host(d_w1) == _oracle.plonk_generate_witness(blank, cs[:K], log_n, g1, pih)).all()
+    if log_n == 10:
+        op, gp = _oracle.plonk_params(80, 8, 2), sipp_amd.PlonkParams(80, 8, 2)
+        ofp = fri(log_n, rate_bits=3, cap_height=2, nq=5, arity=4, fpb=3)
+        digest = (21, 22, 23, 24)
+        want = _oracle.plonk_prove_gates(wires, cs, log_n, op, ofp, circ, digest, pis)
+        pf = ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, to_params(ofp), sipp_amd.PlonkCircuit.from_dict(circ), digest, pis)
+        assert len(pf) == len(want) and (pf == want).all()
+    for bad_gen in ((ps.GEN_POSEIDON, 2, 8, 0, 12, 40, 0, 0), (ps.GEN_ARITHMETIC, 0, 1, 35, 3, 4, 0, 0), (ps.GEN_CONSTANT, 0, 4, 2, 4, 0, 0, 0),
+                    (ps.GEN_REDUCING, 5, 7, 40, 7, 0, 0, 0), (9, 0, 1, 0, 0, 0, 0, 0)):
+        with pytest.raises(sipp_amd.SippError) as e:
+            ctx.plonk_generate_witness(d_w, d_cs[:K], log_n, [bad_gen], pih)
+        assert e.value.code == -1
+    with pytest.raises(sipp_amd.SippError):                                  # a PublicInput generator needs the hash
+        ctx.plonk_generate_witness(d_w, d_cs[:K], log_n, [g for g in gens if g[0] == ps.GEN_PUBLIC_INPUT], None)
+
+
 def test_bench_outer_plonk_leg_runs_and_verifies():
     """bench.py's `outer_plonk` leg (plonky2 prove() at the standard_ecc_config column counts, gates as data) at a small size: the leg
     proves, the oracle's verifier accepts the proof, and the object carries its own roofline entries"""
@@ -262,6 +304,9 @@ def test_bench_outer_plonk_leg_runs_and_verifies():
     # round 6: a recursion-shaped gate mix (>= 100 gate constraints, the Poseidon gate among them), the host column in the headline,
     # the quotient kernel against both bounds
     assert r["shape"]["num_gate_constraints"] >= 100 and "Poseidon" in r["shape"]["gates"] and "U32MulAdd" in r["shape"]["gates"]
-    assert r["witness_generation_s"] > 0 and abs(r["end_to_end_s_per_proof"] - r["witness_generation_s"] - r["ms_per_proof"] * 1e-3) < 1e-9
+    # the last step of round 6: witness generation on the device, inside the timed step, equal to the C port's table
+    assert 0 < r["witness_generation_s"] < 0.05 and abs(r["end_to_end_s_per_proof"] - r["ms_per_proof"] * 1e-3) < 1e-9
+    assert r["witness_matches_cpu_port"] is True and r["cpu_witness_generation_s"] > 0 and "witness_poseidon" in r["kernel_ms_per_proof"]
+    assert abs(r["prove_below_witness_ms"] + r["witness_generation_ms"] - r["ms_per_proof"]) < 1e-6
     q = r["roofline"]["plonk_quotient"]
     assert q["bound"] == "valu" and q["gate_products_per_point"] > 5000 and 0 < q["frac_valu_est"] < 1.5 and 0 < q["hbm"]["frac"] < 1

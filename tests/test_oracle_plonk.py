@@ -301,6 +301,34 @@ def test_recursion_shaped_circuit_witness_proof_and_rejection():
     assert _oracle.plonk_verify_gates(pf3, cs_cap, p, fp, circ, digest) == -210
 
 
+def test_witness_generators_fill_what_the_numpy_generator_fills():
+    """round 6: generate_partial_witness for the recursion-shaped gate set as row-local generators given as data (oracle/plonk_witness.c,
+    the checker of sipp_plonk_generate_witness).  From the INPUT cells alone (every generated cell blanked; tools/plonk_synth.py names
+    them) the C generators rebuild the numpy generator's wire table bit for bit; the inputs-only form of the numpy generator holds the
+    same inputs; the result satisfies every gate program; a layout that leaves the table is refused"""
+    ps, circ, wires, cs, gate, pis, pih = _synth(8, 136, 80, seed=21)
+    K = circ["num_constants"]
+    gens = ps.generators(circ)
+    assert sorted(g[2] for g in gens) == list(range(1, 9))                  # every gate but the no-op has a generator
+    blank = ps.blank_generated(circ, wires, gate, value=0x1234)
+    assert int((blank != wires).sum()) > 15000
+    got = _oracle.plonk_generate_witness(blank, cs[:K], 8, gens, pih)
+    assert (got == wires).all()
+    assert ps.check_rows(circ, got, cs, pih, range(1 << 8))
+    w_in, cs_in, gate_in = ps.witness(circ, 8, 21, pih, inputs_only=True)
+    assert (cs_in == cs).all() and (gate_in == gate).all()
+    assert (ps.blank_generated(circ, w_in, gate, value=0x1234) == blank).all()
+    assert (_oracle.plonk_generate_witness(w_in, cs[:K], 8, gens, pih) == wires).all()
+    # one family at a time touches only its rows' generated cells
+    only = _oracle.plonk_generate_witness(blank, cs[:K], 8, [g for g in gens if g[0] == ps.GEN_POSEIDON], pih)
+    rows8 = np.flatnonzero(gate == 8)
+    assert (only[:, rows8] == wires[:, rows8]).all() and (np.delete(only, rows8, axis=1) == np.delete(blank, rows8, axis=1)).all()
+    for bad in ((ps.GEN_POSEIDON, 2, 8, 0, 12, 40, 0, 0), (ps.GEN_ARITHMETIC, 0, 1, 35, 3, 4, 0, 0), (ps.GEN_CONSTANT, 0, 4, 2, 4, 0, 0, 0),
+                (ps.GEN_REDUCING, 5, 7, 40, 7, 0, 0, 0), (9, 0, 1, 0, 0, 0, 0, 0)):
+        with pytest.raises(RuntimeError):
+            _oracle.plonk_generate_witness(blank, cs[:K], 8, [bad], pih)
+
+
 def test_gates_as_data_prove_verify_and_reject():
     """orc_plonk_prove_gates / orc_plonk_verify_gates ("SIPPPLK3"): the whole outer flow with the gate set as data -- constants_sigmas
     (selectors, gate constants, sigmas), all wires, Z / partial products, quotient chunks with the gate terms, openings, FRI.  Accepted;

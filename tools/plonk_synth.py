@@ -334,7 +334,46 @@ def poseidon_rows(inp):
     return st, wires
 
 
-def witness_recursion_shaped(circ, log_n, seed, pih):
+# ---- the gates' witness generators as data (include/sipp_hip.h sipp_plonk_generator; oracle/plonk.h orc_plonk_generator) -----------------
+GEN_ARITHMETIC, GEN_BASE_SPLIT, GEN_CONSTANT, GEN_PUBLIC_INPUT, GEN_U32_MUL_ADD, GEN_RANDOM_ACCESS, GEN_REDUCING, GEN_POSEIDON = range(1, 9)
+
+
+def generators(circ):
+    """[(kind, selector_index, row, p0 .. p4)] for the recursion-shaped circuit: one generator per gate that has dependent wires"""
+    assert circ.get("rich"), "generators are described for the recursion-shaped gate set"
+    return [(GEN_ARITHMETIC, 0, 1, circ["n_arith_ops"], 3, 4, 0, 0),
+            (GEN_BASE_SPLIT, 0, 2, N_LIMBS, 1, 0, 0, 0),
+            (GEN_PUBLIC_INPUT, 0, 3, 0, 0, 0, 0, 0),
+            (GEN_CONSTANT, 0, 4, 2, 3, 0, 0, 0),
+            (GEN_U32_MUL_ADD, 1, 5, U32_OPS, U32_STRIDE, U32_LIMBS, 0, 0),
+            (GEN_RANDOM_ACCESS, 1, 6, RA_COPIES, RA_STRIDE, 2, 0, 0),
+            (GEN_REDUCING, 1, 7, RED_K, EXT_W, 0, 0, 0),
+            (GEN_POSEIDON, 2, 8, POS_IN, POS_OUT, POS_SBOX, 0, 0)]
+
+
+def generated_wires(circ):
+    """gate index -> the wires its generator WRITES (everything else on a row of that gate is an input or a free cell)"""
+    n_ops = circ["n_arith_ops"]
+    u32 = [U32_STRIDE * j + k for j in range(U32_OPS) for k in range(3, U32_STRIDE)]
+    ra = [RA_STRIDE * j + k for j in range(RA_COPIES) for k in (1, 6, 7)]
+    return {1: [4 * k + 3 for k in range(n_ops)], 2: list(range(1, 1 + N_LIMBS)), 3: [0, 1, 2, 3], 4: [0, 1], 5: u32, 6: ra,
+            7: list(range(4 + RED_K, 4 + 3 * RED_K)), 8: list(range(POS_OUT, POS_OUT + 12)) + list(range(POS_SBOX, POS_SBOX + 106))}
+
+
+def blank_generated(circ, wires, gate, value=0):
+    """a copy of the wire table with every generated cell overwritten (what the caller holds BEFORE witness generation)"""
+    out = wires.copy()
+    for g, ws in generated_wires(circ).items():
+        rows = np.flatnonzero(gate == g)
+        for w in ws:
+            out[w, rows] = np.uint64(value)
+    return out
+
+
+def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False):
+    """inputs_only: the INPUT cells and the circuit's constants / sigmas only -- what a caller holds before generate_partial_witness; the
+    field arithmetic of the generators (arithmetic, reducing, Poseidon rows) is skipped and their cells keep random words (same random
+    stream: every input cell equals the full witness')"""
     rng = np.random.default_rng(seed)
     n = 1 << log_n
     Wn, R, n_ops = circ["num_wires"], circ["num_routed"], circ["n_arith_ops"]
@@ -368,7 +407,7 @@ def witness_recursion_shaped(circ, log_n, seed, pih):
     wires[:R] = flat.reshape(R, n)
     # ---- outputs, gate by gate (on the rows of that gate only)
     ia = ix[1]
-    for k in range(n_ops):
+    for k in range(0 if inputs_only else n_ops):
         wires[4 * k + 3, ia] = gl_add(gl_mul(c0[ia], gl_mul(wires[4 * k, ia], wires[4 * k + 1, ia])), gl_mul(c1[ia], wires[4 * k + 2, ia]))
     ibs = ix[2]
     bits = rng.integers(0, 2, size=(N_LIMBS, len(ibs)), dtype=np.uint64)
@@ -402,17 +441,18 @@ def witness_recursion_shaped(circ, log_n, seed, pih):
     idr = ix[7]
     a0, a1 = wires[2, idr], wires[3, idr]
     al0, al1 = wires[0, idr], wires[1, idr]
-    for i in range(RED_K):
+    for i in range(0 if inputs_only else RED_K):
         n0 = gl_add(gl_add(gl_mul(a0, al0), gl_mul_small(gl_mul(a1, al1), EXT_W)), wires[4 + i, idr])
         n1 = gl_add(gl_mul(a0, al1), gl_mul(a1, al0))
         wires[4 + RED_K + 2 * i, idr], wires[5 + RED_K + 2 * i, idr] = n0, n1
         a0, a1 = n0, n1
     ip = ix[8]
-    out, sb = poseidon_rows(np.stack([wires[POS_IN + i, ip] for i in range(12)]))
-    for i in range(12):
-        wires[POS_OUT + i, ip] = out[i]
-    for w, v in sb.items():
-        wires[w, ip] = v
+    if not inputs_only:
+        out, sb = poseidon_rows(np.stack([wires[POS_IN + i, ip] for i in range(12)]))
+        for i in range(12):
+            wires[POS_OUT + i, ip] = out[i]
+        for w, v in sb.items():
+            wires[w, ip] = v
     # ---- constants: three selector columns, the gates' constants; sigmas
     sels = [np.where((gate >= lo) & (gate < hi), gate, UNUSED).astype(np.uint64) for lo, hi in ((0, 5), (5, 8), (8, 9))]
     pw = powers(root_of_unity(log_n), n)
@@ -425,11 +465,12 @@ def witness_recursion_shaped(circ, log_n, seed, pih):
     return np.ascontiguousarray(wires), np.ascontiguousarray(cs), gate
 
 
-def witness(circ, log_n, seed, pih):
+def witness(circ, log_n, seed, pih, inputs_only=False):
     """wires [num_wires][N], constants_sigmas [4 + num_routed][N] (VALUES, natural row order) satisfying every gate and a random wire
     permutation over the gates' free input cells (cycles of three cells, constant on a cycle); pih = hash_no_pad(public inputs)"""
     if circ.get("rich"):
-        return witness_recursion_shaped(circ, log_n, seed, pih)
+        return witness_recursion_shaped(circ, log_n, seed, pih, inputs_only)
+    assert not inputs_only
     rng = np.random.default_rng(seed)
     n = 1 << log_n
     Wn, R, n_ops = circ["num_wires"], circ["num_routed"], circ["n_arith_ops"]
