@@ -189,5 +189,5 @@ def test_damaged_proofs_under_the_sanitizers(tmp_path, ios4):
     path = tmp_path / "proof.bin"
     _oracle.stark_prove(1, ios4[1]).tofile(path)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    out = subprocess.run([os.path.join(host, "verify_fuzz_asan"), str(path), "800", "3"], capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run([os.path.join(host, "verify_fuzz_asan"), str(path), "400", "3"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "verify fuzz ok" in out.stdout and " 0 accepted" in out.stdout, out.stdout + out.stderr
