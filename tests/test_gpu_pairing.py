@@ -115,6 +115,33 @@ def test_whole_pipeline_from_points_to_three_proofs():
             assert (pis[: ios[kind].shape[0]] == ios[kind]).all()
     finally:
         inst.close()
+    # the tail of the reference's test (src/verifier_circuit.rs:253-268): `data.prove(pw)` -> `data.verify(proof)` -> the proof's public
+    # inputs read back as a SIPPStatement equal the native one.  The outer circuit here is the recursion-shaped STAND-IN (tools/plonk_synth.py:
+    # it does not verify the three STARK proofs -- the reference's circuit lives in un-vendored crates), but the flow is the reference's:
+    # public inputs = SIPPStatementTarget::to_vec() limbs (statements.rs:24-39), their hash bound by the PublicInput gate, witness
+    # generation and prove() on the device, both verifiers of the outer proof, statement round trip.
+    from tests.test_oracle_plonk import fri, _synth
+    from tests.test_gpu_fri_generic import to_params
+    from sipp_amd._lib import to_device
+    log_n, pis = 10, [int(x) for x in st]
+    assert len(pis) == 48 * n + 240
+    ps, circ, wires, cs, gate, _pis, pih = _synth(log_n, 136, 80, seed=3, pis=pis)
+    K = circ["num_constants"]
+    ctx = sipp_amd.Ctx(workspace_bytes=2 << 30)
+    try:
+        d_w, d_cs = to_device(ps.blank_generated(circ, wires, gate)), to_device(cs)
+        ctx.plonk_generate_witness(d_w, d_cs[:K], log_n, ps.generators(circ), pih)
+        ofp = fri(log_n, rate_bits=3, cap_height=4, nq=28, arity=4, fpb=5)
+        op, digest = _oracle.plonk_params(80, 8, 2), (0x53495050, 1, 2, 3)
+        outer = ctx.plonk_prove_gates(d_w, d_cs, log_n, sipp_amd.PlonkParams(80, 8, 2), to_params(ofp), sipp_amd.PlonkCircuit.from_dict(circ), digest, pis)
+    finally:
+        ctx.close()
+    cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=4).cap
+    assert _verify.lib_plonk_verify(outer, cs_cap, op, ofp, circ, digest) == 0 and _oracle.plonk_verify_gates(outer, cs_cap, op, ofp, circ, digest) == 0
+    assert (outer[-len(pis):].astype(np.uint32) == d["statement"]).all()              # SIPPStatement::from_vec(proof.public_inputs) == statement
+    forged = outer.copy()
+    forged[-1] ^= 1                                                                     # another final_Z limb: the hash in the transcript no longer matches
+    assert _verify.lib_plonk_verify(forged, cs_cap, op, ofp, circ, digest) != 0 and _oracle.plonk_verify_gates(forged, cs_cap, op, ofp, circ, digest) != 0
 
 
 @pytest.mark.parametrize("n", [300, 513])
