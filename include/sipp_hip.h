@@ -123,9 +123,12 @@ int sipp_ctx_create_checked(sipp_ctx **out, int device, const sipp_stark_config 
  * alive -- until round 5 they hid behind environment variables).  routes = OR of:
  *   SIPP_ROUTE_OPENINGS_UNGROUPED  openings at zeta / g zeta by one block per column instead of the grouped kernel (traces >= 1024 rows)
  *   SIPP_ROUTE_LDE_COLUMN_WIDE     columns of 2^13 / 2^14 rows through the whole-column-in-LDS transform instead of the tree sweeps
+ *   SIPP_ROUTE_WITNESS_NO_GRAPH    sipp_plonk_generate_witness_levels launches its two kernels per level one by one instead of replaying
+ *                                  the captured hipGraph
  * Only while no proof is in flight on the ctx. */
 #define SIPP_ROUTE_OPENINGS_UNGROUPED 1u
 #define SIPP_ROUTE_LDE_COLUMN_WIDE 2u
+#define SIPP_ROUTE_WITNESS_NO_GRAPH 4u
 int sipp_ctx_set_kernel_routes(sipp_ctx *ctx, uint32_t routes);
 void sipp_ctx_destroy(sipp_ctx *ctx);
 /* The ctx's HIP stream: level > 0 = a stream of the highest priority the device offers; level <= 0 = a stream with a hardware
@@ -476,6 +479,25 @@ typedef struct {
 } sipp_plonk_generator;
 int sipp_plonk_generate_witness(sipp_ctx *ctx, uint64_t *d_wires, const uint64_t *d_constants, uint32_t log_n, uint32_t num_wires,
                                 uint32_t num_constants, const sipp_plonk_generator *gens, size_t n_gens, const uint64_t public_inputs_hash[4]);
+/* The same for a circuit whose COPY CONSTRAINTS carry outputs of one row to inputs of another (hash chains, Merkle paths, accumulators):
+ * generate_partial_witness resolves that order with a work list at proving time; here the circuit builder fixes it once as a SCHEDULE --
+ * the rows sorted by level and, per level, the cells its outputs feed (cell = wire * N + row).  For l = 0 .. n_levels - 1: the generators
+ * on d_rows[level_offsets[l] .. level_offsets[l + 1]) (one lane per row; a row runs the generator whose selector value it holds), then
+ * d_wires[d_copy_dst[k]] = d_wires[d_copy_src[k]] for k in [copy_offsets[l], copy_offsets[l + 1]).  Two small launches per level: the
+ * sequence is captured once as a hipGraph per ctx and replayed while the arguments stay the same (SIPP_ROUTE_WITNESS_NO_GRAPH, or an
+ * enabled profile, launches them one by one).  d_rows / d_copy_* are device arrays, the offsets host arrays of n_levels + 1 entries.
+ * SIPP_E_BADARG also for a row or cell outside the table (checked on the device, reported after the last level). */
+typedef struct {
+    uint32_t n_levels;
+    const uint32_t *d_rows;
+    const uint32_t *level_offsets;
+    const uint64_t *d_copy_src;
+    const uint64_t *d_copy_dst;
+    const uint32_t *copy_offsets;
+} sipp_plonk_schedule;
+int sipp_plonk_generate_witness_levels(sipp_ctx *ctx, uint64_t *d_wires, const uint64_t *d_constants, uint32_t log_n, uint32_t num_wires,
+                                       uint32_t num_constants, const sipp_plonk_generator *gens, size_t n_gens,
+                                       const uint64_t public_inputs_hash[4], const sipp_plonk_schedule *sched);
 
 /* ---- verification of the generic proofs (host code like sipp_stark_verify; stages in *reason, may be NULL) -------------------------
  * sipp_fri_verify_openings: PolynomialBatch::verify_openings over a proof of sipp_fri_prove_openings -- caps[o] = the cap of oracle o

@@ -129,4 +129,12 @@ typedef struct {
 } orc_plonk_generator;
 int orc_plonk_generate_witness(uint64_t *wires, const uint64_t *consts, unsigned log_n, uint32_t num_wires, uint32_t num_constants,
                                const orc_plonk_generator *gens, size_t n_gens, const uint64_t pih[4]);
+/* the same LEVEL BY LEVEL for a circuit whose copy constraints carry outputs to inputs of other rows (generate_partial_witness' work list,
+ * fixed at circuit-build time): for l = 0 .. n_levels - 1 run the generators on rows[level_offsets[l] .. level_offsets[l + 1]), then copy
+ * cell copy_src[k] to cell copy_dst[k] (cell = wire * N + row) for k in [copy_offsets[l], copy_offsets[l + 1]).  -1 also for a row or cell
+ * outside the table. */
+int orc_plonk_generate_witness_levels(uint64_t *wires, const uint64_t *consts, unsigned log_n, uint32_t num_wires, uint32_t num_constants,
+                                      const orc_plonk_generator *gens, size_t n_gens, const uint64_t pih[4], uint32_t n_levels,
+                                      const uint32_t *rows, const uint32_t *level_offsets, const uint64_t *copy_src, const uint64_t *copy_dst,
+                                      const uint32_t *copy_offsets);
 #endif

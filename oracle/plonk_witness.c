@@ -128,3 +128,29 @@ int orc_plonk_generate_witness(uint64_t *wires, const uint64_t *consts, unsigned
     }
     return 0;
 }
+
+int orc_plonk_generate_witness_levels(uint64_t *wires, const uint64_t *consts, unsigned log_n, uint32_t num_wires, uint32_t num_constants,
+                                      const orc_plonk_generator *gens, size_t n_gens, const uint64_t pih[4], uint32_t n_levels,
+                                      const uint32_t *rows, const uint32_t *level_offsets, const uint64_t *copy_src, const uint64_t *copy_dst,
+                                      const uint32_t *copy_offsets) {
+    if (!wires || !consts || (!gens && n_gens) || log_n < 1 || log_n > 26 || !n_levels || !rows || !level_offsets || !copy_offsets) return -1;
+    const size_t n = (size_t)1 << log_n, cells = (size_t)num_wires * n;
+    for (size_t k = 0; k < n_gens; k++)
+        if (!layout_ok(&gens[k], num_wires, num_constants) || (gens[k].kind == 4 && !pih)) return -1;
+    for (uint32_t l = 0; l < n_levels; l++)
+        if (level_offsets[l] > level_offsets[l + 1] || copy_offsets[l] > copy_offsets[l + 1]) return -1;
+    if (level_offsets[n_levels] > n || (copy_offsets[n_levels] && (!copy_src || !copy_dst))) return -1;
+    for (uint32_t k = 0; k < level_offsets[n_levels]; k++)
+        if (rows[k] >= n) return -1;
+    for (uint32_t k = 0; k < copy_offsets[n_levels]; k++)
+        if (copy_src[k] >= cells || copy_dst[k] >= cells) return -1;
+    for (uint32_t l = 0; l < n_levels; l++) {
+        for (uint32_t k = level_offsets[l]; k < level_offsets[l + 1]; k++) {
+            const size_t i = rows[k];
+            for (size_t g = 0; g < n_gens; g++)
+                if (consts[(size_t)gens[g].selector_index * n + i] == gens[g].row) run_row(wires, consts, n, i, &gens[g], pih);
+        }
+        for (uint32_t k = copy_offsets[l]; k < copy_offsets[l + 1]; k++) wires[copy_dst[k]] = wires[copy_src[k]];
+    }
+    return 0;
+}

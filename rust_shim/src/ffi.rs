@@ -130,6 +130,19 @@ pub struct SippPlonkGenerator {
     pub p: [u32; 5],
 }
 
+/// the order copy constraints force on the generators, fixed at circuit-build time: rows sorted by level (device), per level the cells its
+/// outputs feed (device; cell = wire * N + row); the offsets are host arrays of n_levels + 1 entries
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkSchedule {
+    pub n_levels: u32,
+    pub d_rows: *const u32,
+    pub level_offsets: *const u32,
+    pub d_copy_src: *const u64,
+    pub d_copy_dst: *const u64,
+    pub copy_offsets: *const u32,
+}
+
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
@@ -175,6 +188,9 @@ extern "C" {
                                     reason: *mut c_int) -> c_int;
     pub fn sipp_plonk_generate_witness(ctx: *mut SippCtxOpaque, d_wires: *mut u64, d_constants: *const u64, log_n: u32, num_wires: u32,
                                        num_constants: u32, gens: *const SippPlonkGenerator, n_gens: usize, public_inputs_hash: *const u64) -> c_int;
+    pub fn sipp_plonk_generate_witness_levels(ctx: *mut SippCtxOpaque, d_wires: *mut u64, d_constants: *const u64, log_n: u32, num_wires: u32,
+                                              num_constants: u32, gens: *const SippPlonkGenerator, n_gens: usize, public_inputs_hash: *const u64,
+                                              sched: *const SippPlonkSchedule) -> c_int;
     pub fn sipp_plonk_verify_gates(proof: *const u64, len: usize, constants_sigmas_cap: *const u64, p: *const SippPlonkParams, fp: *const SippFriParams,
                                    c: *const SippPlonkCircuit, circuit_digest: *const u64, reason: *mut c_int) -> c_int;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;

@@ -74,6 +74,26 @@ class PlonkGenerator(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("selector_index", C.c_uint32), ("row", C.c_uint32), ("p", C.c_uint32 * 5)]
 
 
+class PlonkSchedule(C.Structure):
+    """sipp_plonk_schedule: rows sorted by level + the copies each level's outputs feed (include/sipp_hip.h)"""
+    _fields_ = [("n_levels", C.c_uint32), ("d_rows", C.c_void_p), ("level_offsets", C.POINTER(C.c_uint32)), ("d_copy_src", C.c_void_p),
+                ("d_copy_dst", C.c_void_p), ("copy_offsets", C.POINTER(C.c_uint32))]
+
+    @classmethod
+    def from_dict(cls, sched):
+        """sched: tools/plonk_synth.chain_schedule() -- uploads rows / copy cells, keeps the host offsets alive"""
+        import torch
+        rows = torch.from_numpy(np.ascontiguousarray(sched["rows"], dtype=np.uint32).view(np.int32)).cuda()
+        src = to_device(np.ascontiguousarray(sched["copy_src"] if len(sched["copy_src"]) else [0], dtype=np.uint64))
+        dst = to_device(np.ascontiguousarray(sched["copy_dst"] if len(sched["copy_dst"]) else [0], dtype=np.uint64))
+        lo = np.ascontiguousarray(sched["level_offsets"], dtype=np.uint32)
+        co = np.ascontiguousarray(sched["copy_offsets"], dtype=np.uint32)
+        s = cls(int(sched["n_levels"]), rows.data_ptr(), lo.ctypes.data_as(C.POINTER(C.c_uint32)), src.data_ptr(), dst.data_ptr(),
+                co.ctypes.data_as(C.POINTER(C.c_uint32)))
+        s._keep = (rows, src, dst, lo, co)
+        return s
+
+
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
                 ("n_out", C.c_uint64)]
@@ -142,6 +162,8 @@ SIGNATURES = {
     "sipp_plonk_prove_gates": (C.c_int, [vp, vp, vp, C.POINTER(Oracle), u64p, C.POINTER(Oracle), C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams),
                                          C.POINTER(PlonkCircuit), u64p, u64p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sipp_plonk_generate_witness": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PlonkGenerator), C.c_size_t, u64p]),
+    "sipp_plonk_generate_witness_levels": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PlonkGenerator), C.c_size_t, u64p,
+                                                     C.POINTER(PlonkSchedule)]),
     "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
@@ -435,6 +457,14 @@ class Ctx:
         arr = (PlonkGenerator * len(gens))(*[PlonkGenerator(int(g[0]), int(g[1]), int(g[2]), (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
         self._ck(self.L.sipp_plonk_generate_witness(self.h, wires.data_ptr(), constants.data_ptr(), log_n, wires.shape[0], constants.shape[0], arr,
                                                     len(gens), None if pih is None else self._u64([int(x) for x in pih])), "plonk_generate_witness")
+
+    def plonk_generate_witness_levels(self, wires, constants, log_n, gens, pih, sched):
+        """sipp_plonk_generate_witness_levels: the generators level by level with the copies between levels (sched = PlonkSchedule);
+        synchronises the ctx stream (the schedule's bounds are checked on the device)"""
+        arr = (PlonkGenerator * len(gens))(*[PlonkGenerator(int(g[0]), int(g[1]), int(g[2]), (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
+        self._ck(self.L.sipp_plonk_generate_witness_levels(self.h, wires.data_ptr(), constants.data_ptr(), log_n, wires.shape[0], constants.shape[0],
+                                                           arr, len(gens), None if pih is None else self._u64([int(x) for x in pih]), C.byref(sched)),
+                 "plonk_generate_witness_levels")
 
     def plonk_perm_prove(self, wires, sigmas, log_n, p, fp, digest=(1, 2, 3, 4), pih=(0, 0, 0, 0)):
         cap = self.L.sipp_plonk_perm_proof_size(log_n, C.byref(p), C.byref(fp))

@@ -105,6 +105,7 @@ void sipp_ctx_destroy(sipp_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    sipp_witness_graph_release(ctx);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -128,7 +129,7 @@ int sipp_ctx_create_checked(sipp_ctx** out, int device, const sipp_stark_config*
 }
 
 int sipp_ctx_set_kernel_routes(sipp_ctx* ctx, uint32_t routes) {
-    if (!ctx || (routes & ~(uint32_t)(SIPP_ROUTE_OPENINGS_UNGROUPED | SIPP_ROUTE_LDE_COLUMN_WIDE))) return SIPP_E_BADARG;
+    if (!ctx || (routes & ~(uint32_t)(SIPP_ROUTE_OPENINGS_UNGROUPED | SIPP_ROUTE_LDE_COLUMN_WIDE | SIPP_ROUTE_WITNESS_NO_GRAPH))) return SIPP_E_BADARG;
     std::unique_lock<std::mutex> lk(ctx->async.mu);
     if (ctx->async.has_job) {
         lk.unlock();

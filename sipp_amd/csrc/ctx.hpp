@@ -95,6 +95,13 @@ struct sipp_ctx {
     // sipp_ctx_set_hardened: kinds 0 / 1 on this ctx mean the hardened G1 / G2 AIRs (kinds 4 / 5)
     bool hardened = false;
     uint32_t kernel_routes = 0;     // sipp_ctx_set_kernel_routes: SIPP_ROUTE_* bits (fallback kernels kept under test)
+    // witness.hip: the launch sequence of sipp_plonk_generate_witness_levels captured as a hipGraph (two launches per level: launch-bound),
+    // replayed while the key (buffers, schedule, generators) stays the same; released by sipp_witness_graph_release
+    struct WitnessGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        std::vector<uint64_t> key;
+    } wgraph;
 
     // sipp_prove_async / sipp_wait: one worker thread per ctx, started on first use, one job at a time
     struct Async {
@@ -235,6 +242,7 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
                            uint64_t* d_digests);
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height);
 int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n);
+void sipp_witness_graph_release(sipp_ctx* ctx);   // witness.hip
 
 // ---- AIR layer (trace.hip / quotient.hip / stark.hip) -----------------------------------------
 #include "air_tables.h"

@@ -55,13 +55,11 @@ __device__ __forceinline__ void mds(uint64_t (&s)[12]) {
     for (int r = 0; r < 12; r++) s[r] = out[r];
 }
 
-__global__ void __launch_bounds__(256) plonk_witness_kernel(GenArgs a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = a.n;
-    if (i >= n) return;
-    const sipp_plonk_generator g = a.g;
-    if (a.consts[(size_t)g.selector_index * n + i] != g.row) return;
-    auto W = [&](uint32_t j) -> uint64_t& { return a.wires[(size_t)j * n + i]; };
-    auto K = [&](uint32_t j) -> uint64_t { return a.consts[(size_t)j * n + i]; };
+// one generator on one row
+__device__ __forceinline__ void run_generator(uint64_t* wires, const uint64_t* consts, uint32_t n, uint32_t i, const sipp_plonk_generator& g,
+                                              const uint64_t* pih) {
+    auto W = [&](uint32_t j) -> uint64_t& { return wires[(size_t)j * n + i]; };
+    auto K = [&](uint32_t j) -> uint64_t { return consts[(size_t)j * n + i]; };
     switch (g.kind) {
     case SIPP_GEN_ARITHMETIC: {
         const uint64_t c0 = K(g.p[1]), c1 = K(g.p[2]);
@@ -78,7 +76,7 @@ __global__ void __launch_bounds__(256) plonk_witness_kernel(GenArgs a) {
         for (uint32_t l = 0; l < g.p[0]; l++) W(l) = K(g.p[1] + l);
         break;
     case SIPP_GEN_PUBLIC_INPUT:
-        for (uint32_t l = 0; l < 4; l++) W(l) = a.pih[l];
+        for (uint32_t l = 0; l < 4; l++) W(l) = pih[l];
         break;
     case SIPP_GEN_U32_MUL_ADD:
         for (uint32_t op = 0; op < g.p[0]; op++) {
@@ -144,6 +142,52 @@ __global__ void __launch_bounds__(256) plonk_witness_kernel(GenArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) plonk_witness_kernel(GenArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = a.n;
+    if (i >= n) return;
+    if (a.consts[(size_t)a.g.selector_index * n + i] != a.g.row) return;
+    run_generator(a.wires, a.consts, n, i, a.g, a.pih);
+}
+
+// ---- level by level -------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_GENS = 16;
+struct LevelArgs {
+    uint64_t* wires;
+    const uint64_t* consts;
+    uint32_t n, n_gens;
+    const uint32_t* rows;     // the level's rows
+    uint32_t count;
+    int* err;
+    uint64_t pih[4];
+    sipp_plonk_generator g[MAX_GENS];
+};
+
+// one lane per row of the level; the row runs the generator whose selector value it holds (the lanes of a wave may hold different gates:
+// the families are short except Poseidon, whose rows a schedule keeps together)
+__global__ void __launch_bounds__(64) plonk_witness_level_kernel(LevelArgs a) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.count) return;
+    const uint32_t i = a.rows[k];
+    if (i >= a.n) {
+        *a.err = 1;
+        return;
+    }
+    for (uint32_t q = 0; q < a.n_gens; q++)
+        if (a.consts[(size_t)a.g[q].selector_index * a.n + i] == a.g[q].row) run_generator(a.wires, a.consts, a.n, i, a.g[q], a.pih);
+}
+
+__global__ void __launch_bounds__(256) plonk_witness_copy_kernel(uint64_t* wires, const uint64_t* src, const uint64_t* dst, uint32_t count,
+                                                                 uint64_t cells, int* err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t s = src[k], d = dst[k];
+    if (s >= cells || d >= cells) {
+        *err = 1;
+        return;
+    }
+    wires[d] = wires[s];
+}
+
 // the wires a generator reads or writes stay inside the table; constant columns inside the constants
 bool layout_ok(const sipp_plonk_generator& g, uint32_t num_wires, uint32_t num_constants) {
     if (g.selector_index >= num_constants) return false;
@@ -169,10 +213,9 @@ const char* gen_name(uint32_t kind) {
 
 }  // namespace
 
-extern "C" int sipp_plonk_generate_witness(sipp_ctx* ctx, uint64_t* d_wires, const uint64_t* d_constants, uint32_t log_n, uint32_t num_wires,
-                                           uint32_t num_constants, const sipp_plonk_generator* gens, size_t n_gens,
-                                           const uint64_t public_inputs_hash[4]) {
-    if (!ctx) return SIPP_E_BADARG;
+// argument checks shared by both entry points; uploads this translation unit's round constants when a Poseidon generator is there
+static int witness_prepare(sipp_ctx* ctx, const uint64_t* d_wires, const uint64_t* d_constants, uint32_t log_n, uint32_t num_wires,
+                           uint32_t num_constants, const sipp_plonk_generator* gens, size_t n_gens, const uint64_t* public_inputs_hash) {
     if (!d_wires || !d_constants || (!gens && n_gens) || log_n < 1 || log_n > 26 || !num_wires || !num_constants)
         return sipp_fail(ctx, SIPP_E_BADARG, "plonk witness: null table, no columns or log_n outside 1 .. 26");
     bool needs_pih = false, needs_rc = false;
@@ -194,6 +237,14 @@ extern "C" int sipp_plonk_generate_witness(sipp_ctx* ctx, uint64_t* d_wires, con
             done[dev] = true;
         }
     }
+    return SIPP_OK;
+}
+
+extern "C" int sipp_plonk_generate_witness(sipp_ctx* ctx, uint64_t* d_wires, const uint64_t* d_constants, uint32_t log_n, uint32_t num_wires,
+                                           uint32_t num_constants, const sipp_plonk_generator* gens, size_t n_gens,
+                                           const uint64_t public_inputs_hash[4]) {
+    if (!ctx) return SIPP_E_BADARG;
+    SIPP_TRY(witness_prepare(ctx, d_wires, d_constants, log_n, num_wires, num_constants, gens, n_gens, public_inputs_hash));
     const uint32_t n = 1u << log_n;
     for (size_t k = 0; k < n_gens; k++) {
         GenArgs a;
@@ -203,5 +254,91 @@ extern "C" int sipp_plonk_generate_witness(sipp_ctx* ctx, uint64_t* d_wires, con
         hipLaunchKernelGGL(plonk_witness_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
         SIPP_CHECK_HIP(ctx, hipGetLastError());
     }
+    return SIPP_OK;
+}
+
+void sipp_witness_graph_release(sipp_ctx* ctx) {
+    if (ctx->wgraph.exec) (void)hipGraphExecDestroy(ctx->wgraph.exec);
+    if (ctx->wgraph.graph) (void)hipGraphDestroy(ctx->wgraph.graph);
+    ctx->wgraph.exec = nullptr;
+    ctx->wgraph.graph = nullptr;
+    ctx->wgraph.key.clear();
+}
+
+extern "C" int sipp_plonk_generate_witness_levels(sipp_ctx* ctx, uint64_t* d_wires, const uint64_t* d_constants, uint32_t log_n,
+                                                  uint32_t num_wires, uint32_t num_constants, const sipp_plonk_generator* gens, size_t n_gens,
+                                                  const uint64_t public_inputs_hash[4], const sipp_plonk_schedule* sched) {
+    if (!ctx) return SIPP_E_BADARG;
+    SIPP_TRY(witness_prepare(ctx, d_wires, d_constants, log_n, num_wires, num_constants, gens, n_gens, public_inputs_hash));
+    if (!sched || !sched->n_levels || sched->n_levels > (1u << 20) || !sched->d_rows || !sched->level_offsets || !sched->copy_offsets || n_gens > MAX_GENS)
+        return sipp_fail(ctx, SIPP_E_BADARG, "plonk witness: no schedule, no level, or more than 16 generators");
+    const uint32_t n = 1u << log_n, L = sched->n_levels;
+    for (uint32_t l = 0; l < L; l++)
+        if (sched->level_offsets[l] > sched->level_offsets[l + 1] || sched->copy_offsets[l] > sched->copy_offsets[l + 1])
+            return sipp_fail(ctx, SIPP_E_BADARG, "plonk witness: schedule offsets must not decrease");
+    if (sched->level_offsets[L] > n || (sched->copy_offsets[L] && (!sched->d_copy_src || !sched->d_copy_dst)))
+        return sipp_fail(ctx, SIPP_E_BADARG, "plonk witness: more scheduled rows than the table has, or copies without their cell lists");
+    // the error flag lives in a persistent one-word table of the ctx (the captured graph keeps its address)
+    int* d_err = reinterpret_cast<int*>(sipp_table_get(ctx, 101, 0, 0));
+    if (!d_err) {
+        uint64_t* t = nullptr;
+        SIPP_TRY(sipp_table_put(ctx, 101, 0, 0, std::vector<uint64_t>{0}, &t));
+        d_err = reinterpret_cast<int*>(t);
+    }
+    auto launch_all = [&]() -> hipError_t {
+        (void)hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream);
+        for (uint32_t l = 0; l < L; l++) {
+            const uint32_t r0 = sched->level_offsets[l], cnt = sched->level_offsets[l + 1] - r0;
+            if (cnt) {
+                LevelArgs a;
+                a.wires = d_wires; a.consts = d_constants; a.n = n; a.n_gens = (uint32_t)n_gens; a.rows = sched->d_rows + r0; a.count = cnt; a.err = d_err;
+                for (int q = 0; q < 4; q++) a.pih[q] = public_inputs_hash ? public_inputs_hash[q] : 0;
+                for (size_t q = 0; q < n_gens; q++) a.g[q] = gens[q];
+                hipLaunchKernelGGL(plonk_witness_level_kernel, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, a);
+            }
+            const uint32_t c0 = sched->copy_offsets[l], cc = sched->copy_offsets[l + 1] - c0;
+            if (cc)
+                hipLaunchKernelGGL(plonk_witness_copy_kernel, dim3((cc + 255) / 256), dim3(256), 0, ctx->stream, d_wires, sched->d_copy_src + c0,
+                                   sched->d_copy_dst + c0, cc, (uint64_t)num_wires << log_n, d_err);
+        }
+        return hipGetLastError();
+    };
+    const bool use_graph = !ctx->prof && !(ctx->kernel_routes & SIPP_ROUTE_WITNESS_NO_GRAPH);
+    if (!use_graph) {
+        ProfScope ps(ctx, "witness_levels");
+        SIPP_CHECK_HIP(ctx, launch_all());
+    } else {
+        // key: everything the captured kernel arguments hold
+        std::vector<uint64_t> key = {(uint64_t)(uintptr_t)d_wires, (uint64_t)(uintptr_t)d_constants, log_n, num_wires, num_constants, n_gens, L,
+                                     (uint64_t)(uintptr_t)sched->d_rows, (uint64_t)(uintptr_t)sched->d_copy_src, (uint64_t)(uintptr_t)sched->d_copy_dst};
+        for (int q = 0; q < 4; q++) key.push_back(public_inputs_hash ? public_inputs_hash[q] : 0);
+        for (size_t q = 0; q < n_gens; q++) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&gens[q]);
+            for (size_t x = 0; x < sizeof(sipp_plonk_generator) / 4; x++) key.push_back(w[x]);
+        }
+        for (uint32_t l = 0; l <= L; l++) key.push_back(((uint64_t)sched->level_offsets[l] << 32) | sched->copy_offsets[l]);
+        if (!ctx->wgraph.exec || ctx->wgraph.key != key) {
+            sipp_witness_graph_release(ctx);
+            SIPP_CHECK_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const hipError_t le = launch_all();
+            hipGraph_t g = nullptr;
+            const hipError_t ce = hipStreamEndCapture(ctx->stream, &g);
+            if (le != hipSuccess || ce != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                return sipp_fail(ctx, SIPP_E_HIP, "plonk witness: capturing the level launches as a hipGraph failed");
+            }
+            ctx->wgraph.graph = g;
+            if (hipGraphInstantiate(&ctx->wgraph.exec, g, nullptr, nullptr, 0) != hipSuccess) {
+                sipp_witness_graph_release(ctx);
+                return sipp_fail(ctx, SIPP_E_HIP, "plonk witness: hipGraphInstantiate failed");
+            }
+            ctx->wgraph.key = key;
+        }
+        SIPP_CHECK_HIP(ctx, hipGraphLaunch(ctx->wgraph.exec, ctx->stream));
+    }
+    int h_err = 0;
+    SIPP_CHECK_HIP(ctx, hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_err) return sipp_fail(ctx, SIPP_E_BADARG, "plonk witness: the schedule names a row or a cell outside the wire table");
     return SIPP_OK;
 }

@@ -640,6 +640,26 @@ def plonk_generate_witness(wires, consts, log_n, gens, pih, threads=None):
     return w
 
 
+def plonk_generate_witness_levels(wires, consts, log_n, gens, pih, sched):
+    """orc_plonk_generate_witness_levels on a COPY of wires; sched = tools/plonk_synth.chain_schedule(log_n, chain_len)"""
+    L = _plonk_lib()
+    u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+    L.orc_plonk_generate_witness_levels.argtypes = [u64p, u64p, C.c_uint, C.c_uint32, C.c_uint32, C.POINTER(OrcPlonkGenerator), C.c_size_t, u64p,
+                                                    C.c_uint32, u32p, u32p, u64p, u64p, u32p]
+    L.orc_plonk_generate_witness_levels.restype = C.c_int
+    w = np.ascontiguousarray(wires, dtype=np.uint64).copy()
+    k = np.ascontiguousarray(consts, dtype=np.uint64)
+    arr = (OrcPlonkGenerator * len(gens))(*[OrcPlonkGenerator(g[0], g[1], g[2], (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
+    a32 = lambda v: np.ascontiguousarray(v, dtype=np.uint32)
+    a64 = lambda v: np.ascontiguousarray(v if len(v) else [0], dtype=np.uint64)
+    rc = L.orc_plonk_generate_witness_levels(w.reshape(-1), k.reshape(-1), log_n, w.shape[0], k.shape[0], arr, len(gens),
+                                             np.asarray([int(x) for x in pih], dtype=np.uint64), int(sched["n_levels"]), a32(sched["rows"]),
+                                             a32(sched["level_offsets"]), a64(sched["copy_src"]), a64(sched["copy_dst"]), a32(sched["copy_offsets"]))
+    if rc:
+        raise RuntimeError("orc_plonk_generate_witness_levels: %d" % rc)
+    return w
+
+
 def plonk_gate_constraints_base(circ, wires_row, consts_row, pih):
     L = _plonk_gates_lib()
     cc = plonk_circuit(circ)

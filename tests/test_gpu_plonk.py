@@ -292,6 +292,60 @@ def test_witness_generators_match_the_oracle_and_feed_the_prover(ctx, log_n):
         ctx.plonk_generate_witness(d_w, d_cs[:K], log_n, [g for g in gens if g[0] == ps.GEN_PUBLIC_INPUT], None)
 
 
+@pytest.mark.parametrize("log_n,chain_len", [(10, 8), (14, 64)])
+def test_levelled_witness_generation_matches_the_oracle(ctx, log_n, chain_len):
+    """sipp_plonk_generate_witness_levels: the chained circuit's schedule (copy constraints from outputs to inputs of other rows) run level
+    by level on the device -- two launches per level, captured as a hipGraph and replayed; the one-by-one route (SIPP_ROUTE_WITNESS_NO_GRAPH)
+    and the replay give the oracle's table bit for bit, also after the inputs changed under the same graph; the proof of the generated
+    table is the oracle's word for word; a schedule that leaves the table is SIPP_E_BADARG"""
+    import sipp_amd
+    from tests.test_oracle_plonk import _synth
+    ps, circ, _w, _cs, _gate, pis, pih = _synth(log_n, 136, 80, seed=70 + log_n)
+    wires, cs, gate = ps.witness(circ, log_n, 70 + log_n, pih, chain_len=chain_len)
+    sc = ps.chain_schedule(log_n, chain_len)
+    K, gens = circ["num_constants"], ps.generators(circ)
+    blank = ps.blank_generated(circ, wires, gate, value=0xABCDEF, sched=sc)
+    ref = _oracle.plonk_generate_witness_levels(blank, cs[:K], log_n, gens, pih, sc)
+    assert (ref == wires).all()
+    d_cs, d_w = dev(cs), dev(blank)
+    sched = sipp_amd.PlonkSchedule.from_dict(sc)
+    L = sipp_amd.lib()
+    for route in (4, 0, 0):                                  # one by one, capture + replay, replay
+        assert L.sipp_ctx_set_kernel_routes(ctx.h, route) == 0
+        d_w.copy_(dev(blank))
+        ctx.plonk_generate_witness_levels(d_w, d_cs[:K], log_n, gens, pih, sched)
+        got = host(d_w)
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, "route %d: first mismatch wire %d row %d (gate %d)" % (route, bad[0][0], bad[0][1], gate[bad[0][1]])
+    # other inputs under the SAME graph (same buffers, same schedule): the replay computes from what the table holds now
+    blank2 = blank.copy()
+    blank2[5, np.flatnonzero(gate == 8)] ^= np.uint64(1)            # a free input of every Poseidon row
+    blank2[6, np.flatnonzero(gate == 1)] ^= np.uint64(2)            # an input of arithmetic op 1
+    ref2 = _oracle.plonk_generate_witness_levels(blank2, cs[:K], log_n, gens, pih, sc)
+    assert not (ref2 == ref).all()
+    d_w.copy_(dev(blank2))
+    ctx.plonk_generate_witness_levels(d_w, d_cs[:K], log_n, gens, pih, sched)
+    assert (host(d_w) == ref2).all()
+    if log_n == 10:
+        op, gp = _oracle.plonk_params(80, 8, 2), sipp_amd.PlonkParams(80, 8, 2)
+        ofp = fri(log_n, rate_bits=3, cap_height=2, nq=5, arity=4, fpb=3)
+        digest = (31, 32, 33, 34)
+        want = _oracle.plonk_prove_gates(wires, cs, log_n, op, ofp, circ, digest, pis)
+        d_w.copy_(dev(blank))
+        ctx.plonk_generate_witness_levels(d_w, d_cs[:K], log_n, gens, pih, sched)
+        pf = ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, to_params(ofp), sipp_amd.PlonkCircuit.from_dict(circ), digest, pis)
+        assert len(pf) == len(want) and (pf == want).all()
+        cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=2).cap
+        assert _verify.lib_plonk_verify(pf, cs_cap, op, ofp, circ, digest) == 0
+    for key, val in (("rows", 1 << log_n), ("copy_dst", 136 << log_n)):
+        bad_sc = dict(sc, **{key: sc[key].copy()})
+        bad_sc[key][3] = val
+        with pytest.raises(sipp_amd.SippError) as e:
+            ctx.plonk_generate_witness_levels(dev(blank), d_cs[:K], log_n, gens, pih, sipp_amd.PlonkSchedule.from_dict(bad_sc))
+        assert e.value.code == -1
+    assert L.sipp_ctx_set_kernel_routes(ctx.h, 0) == 0
+
+
 def test_bench_outer_plonk_leg_runs_and_verifies():
     """bench.py's `outer_plonk` leg (plonky2 prove() at the standard_ecc_config column counts, gates as data) at a small size: the leg
     proves, the oracle's verifier accepts the proof, and the object carries its own roofline entries"""

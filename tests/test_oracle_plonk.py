@@ -329,6 +329,43 @@ def test_witness_generators_fill_what_the_numpy_generator_fills():
             _oracle.plonk_generate_witness(blank, cs[:K], 8, [bad], pih)
 
 
+def test_levelled_witness_generation_follows_copy_constraints_from_outputs_to_inputs():
+    """the chained circuit (tools/plonk_synth.chain_schedule): Poseidon hash chains, arithmetic rows reading Poseidon outputs, reducing rows
+    reading arithmetic outputs -- copy constraints (2-cycles of sigma) from outputs to inputs of OTHER rows, so generators have an order.
+    oracle/plonk_witness.c runs the build-time schedule level by level and rebuilds the numpy generator's table bit for bit from the
+    inputs alone; the row-local pass cannot; every gate program and every copy constraint holds; the oracle proves and verifies the
+    circuit (sigma carries the new cycles: a proof exists only if the copies hold); a schedule that leaves the table is refused"""
+    log_n, cl = 8, 6
+    ps, circ, _w, _cs, _gate, pis, pih = _synth(log_n, 136, 80, seed=33)
+    wires, cs, gate = ps.witness(circ, log_n, 33, pih, chain_len=cl)
+    sc = ps.chain_schedule(log_n, cl)
+    K, n = circ["num_constants"], 1 << log_n
+    assert sc["n_levels"] >= cl and len(sc["copy_src"]) > 100 and sorted(sc["rows"].tolist()) == list(range(n))
+    flat = wires.reshape(-1)
+    assert (flat[sc["copy_src"].astype(np.int64)] == flat[sc["copy_dst"].astype(np.int64)]).all()
+    assert ps.check_rows(circ, wires, cs, pih, range(n))
+    blank = ps.blank_generated(circ, wires, gate, value=77, sched=sc)
+    gens = ps.generators(circ)
+    assert (_oracle.plonk_generate_witness_levels(blank, cs[:K], log_n, gens, pih, sc) == wires).all()
+    assert not (_oracle.plonk_generate_witness(blank, cs[:K], log_n, gens, pih) == wires).all()
+    w_in = ps.witness(circ, log_n, 33, pih, inputs_only=True, chain_len=cl)[0]
+    assert (_oracle.plonk_generate_witness_levels(w_in, cs[:K], log_n, gens, pih, sc) == wires).all()
+    p = _oracle.plonk_params(80, 8, 2)
+    fp = fri(log_n, rate_bits=3, cap_height=2, nq=4, arity=2, fpb=3)
+    digest = (5, 6, 7, 8)
+    pf = _oracle.plonk_prove_gates(wires, cs, log_n, p, fp, circ, digest, pis)
+    cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=2).cap
+    assert _oracle.plonk_verify_gates(pf, cs_cap, p, fp, circ, digest) == 0
+    # the witness of the row-local pass breaks copy constraints: its proof is refused
+    pf2 = _oracle.plonk_prove_gates(_oracle.plonk_generate_witness(blank, cs[:K], log_n, gens, pih), cs, log_n, p, fp, circ, digest, pis)
+    assert _oracle.plonk_verify_gates(pf2, cs_cap, p, fp, circ, digest) != 0
+    for key, val in (("rows", n), ("copy_dst", 136 * n)):
+        bad = dict(sc, **{key: sc[key].copy()})
+        bad[key][3] = val
+        with pytest.raises(RuntimeError):
+            _oracle.plonk_generate_witness_levels(blank, cs[:K], log_n, gens, pih, bad)
+
+
 def test_gates_as_data_prove_verify_and_reject():
     """orc_plonk_prove_gates / orc_plonk_verify_gates ("SIPPPLK3"): the whole outer flow with the gate set as data -- constants_sigmas
     (selectors, gate constants, sigmas), all wires, Z / partial products, quotient chunks with the gate terms, openings, FRI.  Accepted;

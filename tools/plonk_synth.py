@@ -360,32 +360,77 @@ def generated_wires(circ):
             7: list(range(4 + RED_K, 4 + 3 * RED_K)), 8: list(range(POS_OUT, POS_OUT + 12)) + list(range(POS_SBOX, POS_SBOX + 106))}
 
 
-def blank_generated(circ, wires, gate, value=0):
-    """a copy of the wire table with every generated cell overwritten (what the caller holds BEFORE witness generation)"""
+def blank_generated(circ, wires, gate, value=0, sched=None):
+    """a copy of the wire table with every generated cell overwritten (what the caller holds BEFORE witness generation); with a
+    chain_schedule() also the input cells that copy constraints feed from other rows' outputs"""
     out = wires.copy()
     for g, ws in generated_wires(circ).items():
         rows = np.flatnonzero(gate == g)
         for w in ws:
             out[w, rows] = np.uint64(value)
+    if sched:
+        out.reshape(-1)[sched["copy_dst"].astype(np.int64)] = np.uint64(value)
     return out
 
 
-def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False):
+def gate_rows(n):
+    """the gate of every row: the mix of a recursive verifier -- Poseidon 5 / 16, arithmetic 3 / 16, U32, random access and reducing
+    2 / 16 each, base sum, constant; row 0 the public-input row, a few no-ops"""
+    pattern = np.array([8, 1, 8, 5, 6, 8, 1, 7, 8, 2, 1, 5, 8, 6, 7, 4], dtype=np.int64)
+    gate = pattern[np.arange(n) % 16]
+    gate[0] = 3                                             # the public-input row
+    gate[1::64] = 0                                         # a few no-ops: rows whose routed wires are all free
+    return gate
+
+
+def chain_schedule(log_n, chain_len):
+    """COPY CONSTRAINTS FROM OUTPUTS TO INPUTS, and the order they force on the generators (what plonky2's generate_partial_witness finds
+    with its work list; here fixed at circuit-build time): the Poseidon rows form hash chains of `chain_len` links (a row's inputs 0 .. 3
+    are the outputs 0 .. 3 of the row `stride` Poseidon rows before it -- Merkle paths), the first multiplicand of arithmetic row t is
+    output 4 of Poseidon row t, the first coefficient of reducing row t is the first output of arithmetic row t.
+    -> dict: n_levels; row_level [N]; rows (all rows sorted by level, stable) + level_offsets [n_levels + 1]; copy_src / copy_dst (cell =
+    wire * N + row; the copy runs after its source's level) sorted by level + copy_offsets [n_levels + 1]"""
+    n = 1 << log_n
+    gate = gate_rows(n)
+    ip, ia, idr = (np.flatnonzero(gate == g) for g in (8, 1, 7))
+    stride = max(1, -(-len(ip) // chain_len))
+    lp = np.arange(len(ip)) // stride
+    la = lp[:len(ia)] + 1
+    lr = la[:len(idr)] + 1
+    row_level = np.zeros(n, dtype=np.uint32)
+    row_level[ip], row_level[ia], row_level[idr] = lp, la, lr
+    src, dst, lev = [], [], []
+    j = np.arange(stride, len(ip))
+    for q in range(4):
+        src.append((POS_OUT + q) * n + ip[j - stride]); dst.append((POS_IN + q) * n + ip[j]); lev.append(lp[j - stride])
+    t = np.arange(len(ia))
+    src.append((POS_OUT + 4) * n + ip[t]); dst.append(0 * n + ia); lev.append(lp[t])
+    t = np.arange(len(idr))
+    src.append(3 * n + ia[t]); dst.append(4 * n + idr); lev.append(la[t])
+    src, dst, lev = (np.concatenate(v).astype(np.int64) for v in (src, dst, lev))
+    o = np.argsort(lev, kind="stable")
+    src, dst, lev = src[o], dst[o], lev[o]
+    n_levels = int(row_level.max()) + 1
+    rows = np.argsort(row_level, kind="stable").astype(np.uint32)
+    level_offsets = np.searchsorted(row_level[rows], np.arange(n_levels + 1)).astype(np.uint32)
+    copy_offsets = np.searchsorted(lev, np.arange(n_levels + 1)).astype(np.uint32)
+    return {"n_levels": n_levels, "row_level": row_level, "rows": rows, "level_offsets": level_offsets, "copy_src": src.astype(np.uint64),
+            "copy_dst": dst.astype(np.uint64), "copy_offsets": copy_offsets, "chain_len": chain_len}
+
+
+def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False, chain_len=0):
     """inputs_only: the INPUT cells and the circuit's constants / sigmas only -- what a caller holds before generate_partial_witness; the
     field arithmetic of the generators (arithmetic, reducing, Poseidon rows) is skipped and their cells keep random words (same random
-    stream: every input cell equals the full witness')"""
+    stream: every input cell equals the full witness').  chain_len > 0: the circuit of chain_schedule() -- outputs wired to inputs of
+    other rows by copy constraints (2-cycles of the wire permutation), generated level by level"""
     rng = np.random.default_rng(seed)
     n = 1 << log_n
     Wn, R, n_ops = circ["num_wires"], circ["num_routed"], circ["n_arith_ops"]
-    rows = np.arange(n)
-    # the mix of a recursive verifier: Poseidon 5 / 16, arithmetic 3 / 16, U32, random access and reducing 2 / 16 each, base sum, constant
-    pattern = np.array([8, 1, 8, 5, 6, 8, 1, 7, 8, 2, 1, 5, 8, 6, 7, 4], dtype=np.int64)
-    gate = pattern[rows % 16]
-    gate[0] = 3                                             # the public-input row
-    gate[1::64] = 0                                         # a few no-ops: rows whose routed wires are all free
+    gate = gate_rows(n)
     wires = rand_field(rng, (Wn, n))
     c0, c1 = rand_field(rng, n), rand_field(rng, n)
     ix = {g: np.flatnonzero(gate == g) for g in range(9)}
+    sched = chain_schedule(log_n, chain_len) if chain_len else None
     # free (routable) cells: arithmetic inputs, Poseidon inputs, the random-access lists, the reducing coefficients, every routed wire of a noop row
     free = np.zeros((R, n), dtype=bool)
     for k in range(n_ops):
@@ -395,20 +440,43 @@ def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False):
         free[RA_STRIDE * j + 2:RA_STRIDE * j + 6, ix[6]] = True
     free[4:4 + RED_K, ix[7]] = True
     free[:, ix[0]] = True
+    if sched:                                               # a cell fed by another gate's output is not free
+        free.reshape(-1)[sched["copy_dst"].astype(np.int64)] = False
     cells = np.flatnonzero(free.reshape(-1)).astype(np.int64)
     order = rng.permutation(cells)
     order = order[:len(order) - len(order) % 3].reshape(-1, 3)
     perm = np.arange(R * n, dtype=np.int64)
     perm[order[:, 0]], perm[order[:, 1]], perm[order[:, 2]] = order[:, 1], order[:, 2], order[:, 0]
+    if sched:                                               # output cell <-> the input cell it feeds: a 2-cycle
+        cs_, cd_ = sched["copy_src"].astype(np.int64), sched["copy_dst"].astype(np.int64)
+        assert int(max(cs_.max(), cd_.max())) < R * n
+        perm[cs_], perm[cd_] = cd_, cs_
     vals = rand_field(rng, order.shape[0])
     flat = wires[:R].reshape(-1)
     for q in range(3):
         flat[order[:, q]] = vals
     wires[:R] = flat.reshape(R, n)
     # ---- outputs, gate by gate (on the rows of that gate only)
+    def gen_arith(r):
+        for k in range(n_ops):
+            wires[4 * k + 3, r] = gl_add(gl_mul(c0[r], gl_mul(wires[4 * k, r], wires[4 * k + 1, r])), gl_mul(c1[r], wires[4 * k + 2, r]))
+
+    def gen_reducing(r):
+        a0, a1 = wires[2, r], wires[3, r]
+        al0, al1 = wires[0, r], wires[1, r]
+        for i in range(RED_K):
+            n0 = gl_add(gl_add(gl_mul(a0, al0), gl_mul_small(gl_mul(a1, al1), EXT_W)), wires[4 + i, r])
+            n1 = gl_add(gl_mul(a0, al1), gl_mul(a1, al0))
+            wires[4 + RED_K + 2 * i, r], wires[5 + RED_K + 2 * i, r] = n0, n1
+            a0, a1 = n0, n1
+
+    def gen_poseidon(r):
+        out, sb = poseidon_rows(np.stack([wires[POS_IN + i, r] for i in range(12)]))
+        for i in range(12):
+            wires[POS_OUT + i, r] = out[i]
+        for w, v in sb.items():
+            wires[w, r] = v
     ia = ix[1]
-    for k in range(0 if inputs_only else n_ops):
-        wires[4 * k + 3, ia] = gl_add(gl_mul(c0[ia], gl_mul(wires[4 * k, ia], wires[4 * k + 1, ia])), gl_mul(c1[ia], wires[4 * k + 2, ia]))
     ibs = ix[2]
     bits = rng.integers(0, 2, size=(N_LIMBS, len(ibs)), dtype=np.uint64)
     total = np.zeros(len(ibs), dtype=np.uint64)
@@ -439,20 +507,20 @@ def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False):
         items = np.stack([wires[b + 2 + q, ir] for q in range(4)])
         wires[b + 1, ir] = items[idx.astype(np.int64), np.arange(len(ir))]
     idr = ix[7]
-    a0, a1 = wires[2, idr], wires[3, idr]
-    al0, al1 = wires[0, idr], wires[1, idr]
-    for i in range(0 if inputs_only else RED_K):
-        n0 = gl_add(gl_add(gl_mul(a0, al0), gl_mul_small(gl_mul(a1, al1), EXT_W)), wires[4 + i, idr])
-        n1 = gl_add(gl_mul(a0, al1), gl_mul(a1, al0))
-        wires[4 + RED_K + 2 * i, idr], wires[5 + RED_K + 2 * i, idr] = n0, n1
-        a0, a1 = n0, n1
     ip = ix[8]
-    if not inputs_only:
-        out, sb = poseidon_rows(np.stack([wires[POS_IN + i, ip] for i in range(12)]))
-        for i in range(12):
-            wires[POS_OUT + i, ip] = out[i]
-        for w, v in sb.items():
-            wires[w, ip] = v
+    if not inputs_only and not sched:
+        gen_arith(ia)
+        gen_reducing(idr)
+        gen_poseidon(ip)
+    elif not inputs_only:                                   # level by level: generators of the level, then the copies its outputs feed
+        rl, flat = sched["row_level"], wires.reshape(-1)
+        co, cs_, cd_ = sched["copy_offsets"], sched["copy_src"].astype(np.int64), sched["copy_dst"].astype(np.int64)
+        for lv in range(sched["n_levels"]):
+            for rows_g, gen in ((ip, gen_poseidon), (ia, gen_arith), (idr, gen_reducing)):
+                r = rows_g[rl[rows_g] == lv]
+                if len(r):
+                    gen(r)
+            flat[cd_[co[lv]:co[lv + 1]]] = flat[cs_[co[lv]:co[lv + 1]]]
     # ---- constants: three selector columns, the gates' constants; sigmas
     sels = [np.where((gate >= lo) & (gate < hi), gate, UNUSED).astype(np.uint64) for lo, hi in ((0, 5), (5, 8), (8, 9))]
     pw = powers(root_of_unity(log_n), n)
@@ -465,12 +533,12 @@ def witness_recursion_shaped(circ, log_n, seed, pih, inputs_only=False):
     return np.ascontiguousarray(wires), np.ascontiguousarray(cs), gate
 
 
-def witness(circ, log_n, seed, pih, inputs_only=False):
+def witness(circ, log_n, seed, pih, inputs_only=False, chain_len=0):
     """wires [num_wires][N], constants_sigmas [4 + num_routed][N] (VALUES, natural row order) satisfying every gate and a random wire
     permutation over the gates' free input cells (cycles of three cells, constant on a cycle); pih = hash_no_pad(public inputs)"""
     if circ.get("rich"):
-        return witness_recursion_shaped(circ, log_n, seed, pih, inputs_only)
-    assert not inputs_only
+        return witness_recursion_shaped(circ, log_n, seed, pih, inputs_only, chain_len)
+    assert not inputs_only and not chain_len
     rng = np.random.default_rng(seed)
     n = 1 << log_n
     Wn, R, n_ops = circ["num_wires"], circ["num_routed"], circ["n_arith_ops"]
