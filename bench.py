@@ -152,7 +152,9 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
     commitment, Z / partial products, the gate constraints interpreted inside the quotient kernel, quotient commitment, openings, FRI.
     constants_sigmas is committed once, outside the timing, as plonky2 does at circuit-build time.  A timed step is the WHOLE prove():
     witness generation on the device (sipp_plonk_generate_witness: the gates' generators, one lane per row, in place on the wire table
-    -- until round 6's last step a numpy generator on one host core, 2.3 s beside a 72 ms proof) and then everything below it.  What
+    -- until round 6's last step a numpy generator on one host core, 2.3 s beside a 72 ms proof; the circuit is CHAINED: Poseidon hash
+    chains of 64 links feeding arithmetic and reducing rows through copy constraints, so the generators run level by level as a build-time
+    schedule, two launches per level replayed from a hipGraph: sipp_plonk_generate_witness_levels) and then everything below it.  What
     stays on the host is what plonky2 does outside prove(): building the circuit and assigning the input cells (`host_circuit_and_inputs_s`).
     The C port of the generators (oracle/plonk_witness.c, OpenMP) runs once on the same inputs: its table must equal the device's
     (`witness_matches_cpu_port`) and its time is the CPU column of this step."""
@@ -175,12 +177,15 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         st = torch.zeros((1, 12), dtype=torch.int64, device="cuda")
         st[0, :len(pis)] = torch.tensor(pis, dtype=torch.int64)
         pih = [int(x) & 0xFFFFFFFFFFFFFFFF for x in ctx.poseidon_permute(st)[0, :4].tolist()]    # hash_n_to_hash_no_pad of <= 8 inputs
+        CHAIN = 64                                                                      # links of a Poseidon hash chain (Merkle-path-like)
         t0 = time.perf_counter()
-        wires, cs, _gate = ps.witness(circ, log_n, 2026, pih, inputs_only=True)       # input cells, constants, sigmas: the caller's side
+        wires, cs, _gate = ps.witness(circ, log_n, 2026, pih, inputs_only=True, chain_len=CHAIN)   # input cells, constants, sigmas: the caller's side
+        sc = ps.chain_schedule(log_n, CHAIN)                                          # circuit-build time: the generators' levels
         t_inputs = time.perf_counter() - t0
         gens = ps.generators(circ)
         d_w, d_cs = to_device(wires), to_device(cs)
         d_k = d_cs[:K]
+        sched = sipp_amd.PlonkSchedule.from_dict(sc)
         gp = sipp_amd.PlonkParams(R, D, CH)
         fp = sipp_amd.FriParams()
         fp.rate_bits, fp.cap_height, fp.pow_bits, fp.num_queries, fp.pow_rule, fp.hiding = rate_bits, cap_h, pow_bits, nq, 0, 0
@@ -188,23 +193,41 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         gc = sipp_amd.PlonkCircuit.from_dict(circ)
         digest = (0x53495050, 0x6f757465, 0x72706c6f, 0x6e6b3035)
         cs_or, cs_cap, keep = ctx.commit_ex(d_cs, log_n, rate_bits, cap_h)          # once per circuit
+
+        def generate():                                                              # in place; input cells are never written: repeatable
+            ctx.plonk_generate_witness_levels(d_w, d_k, log_n, gens, pih, sched)
+
         def prove():
-            ctx.plonk_generate_witness(d_w, d_k, log_n, gens, pih)             # in place; the input cells are not written: repeatable
+            generate()
             return ctx.plonk_prove_gates(d_w, d_cs, log_n, gp, fp, gc, digest, pis, cs_oracle=cs_or)
         prove()
-        ctx.profile(True)
-        ctx.profile_reset()
+        # witness generation alone: the captured hipGraph against the same launches one by one (the call ends with a stream sync)
+        wit = {}
+        for name, route in (("graph_replay_ms", 0), ("launch_by_launch_ms", 4)):
+            L.sipp_ctx_set_kernel_routes(ctx.h, route)
+            generate()
+            t0 = time.perf_counter()
+            for _ in range(4 * steps):
+                generate()
+            wit[name] = 1e3 * (time.perf_counter() - t0) / (4 * steps)
+        L.sipp_ctx_set_kernel_routes(ctx.h, 0)
+        wit_ms = wit["graph_replay_ms"]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps):                                                        # the timed steps: the whole prove(), profile off (graph route)
             pf = prove()
         ctx.sync()
         ms = 1e3 * (time.perf_counter() - t0) / steps
+        ctx.profile(True)                                                             # a second pass for the per-kernel breakdown
+        ctx.profile_reset()
+        for _ in range(steps):
+            prove()
+        ctx.sync()
         rep = {k: v["ms"] / steps for k, v in ctx.profile_report().items()}
         ctx.profile(False)
         del keep
-        wit_names = [k for k in rep if k.startswith("witness_")]
-        wit_ms = sum(rep[k] for k in wit_names)
+        wit.update({"levels": int(sc["n_levels"]), "launches": int(np.count_nonzero(np.diff(sc["level_offsets"])) + np.count_nonzero(np.diff(sc["copy_offsets"]))),
+                    "copies": int(len(sc["copy_src"])), "chain_len": CHAIN})
         ntt_names = [k for k in rep if k.startswith(("ntt_", "lde_", "bitrev"))]
         leaf_names = [k for k in rep if k.startswith("poseidon_leaves")]
         ntt_ms, leaf_ms = sum(rep[k] for k in ntt_names), sum(rep[k] for k in leaf_names)
@@ -221,8 +244,8 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
             from tests import _oracle
             from sipp_amd._lib import to_host
             t_c = time.perf_counter()
-            ref_w = _oracle.plonk_generate_witness(wires, cs[:K], log_n, gens, pih)
-            cpu_wit = {"cpu_witness_generation_s": time.perf_counter() - t_c, "cpu_witness_kind": "port (oracle/plonk_witness.c, OpenMP, incl. one copy of the table)",
+            ref_w = _oracle.plonk_generate_witness_levels(wires, cs[:K], log_n, gens, pih, sc)
+            cpu_wit = {"cpu_witness_generation_s": time.perf_counter() - t_c, "cpu_witness_kind": "port (oracle/plonk_witness.c, one thread, incl. one copy of the table)",
                        "cpu_cores": os.cpu_count(), "witness_matches_cpu_port": bool((to_host(d_w) == ref_w).all())}
             del ref_w
             ofp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_h, pow_bits=pow_bits, num_queries=nq, pow_rule=0, hiding=0, arity_bits=4,
@@ -244,7 +267,7 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                 **({"library_verifier_ms": lib_verify_ms} if verify else {}),
                 # HEADLINE, next to ms_per_proof (which contains it): witness generation now runs on the device (row-local generators; values
                 # that travel between rows through copy constraints are the caller's to order).  The host keeps what plonky2 does outside prove()
-                "witness_generation_s": wit_ms * 1e-3, "witness_generation_ms": wit_ms, "prove_below_witness_ms": ms - wit_ms,
+                "witness_generation_s": wit_ms * 1e-3, "witness_generation_ms": wit_ms, "prove_below_witness_ms": ms - wit_ms, "witness_generation": wit,
                 "end_to_end_s_per_proof": ms * 1e-3, "host_circuit_and_inputs_s": t_inputs, **cpu_wit,
                 "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
                 "roofline": {"transforms": {"bound": "hbm", "kernels": sorted(ntt_names), "algorithmic_bytes": ntt_bytes, "ms": ntt_ms,

@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(256) plonk_witness_kernel(GenArgs a) {
 
 // ---- level by level -------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t MAX_GENS = 16;
+constexpr uint32_t COOP_BELOW_ROWS = 16384;   // levels with fewer rows than this leave SIMDs empty with one lane per row
 struct LevelArgs {
     uint64_t* wires;
     const uint64_t* consts;
@@ -174,6 +175,63 @@ __global__ void __launch_bounds__(64) plonk_witness_level_kernel(LevelArgs a) {
     }
     for (uint32_t q = 0; q < a.n_gens; q++)
         if (a.consts[(size_t)a.g[q].selector_index * a.n + i] == a.g[q].row) run_generator(a.wires, a.consts, a.n, i, a.g[q], a.pih);
+}
+
+// THIN levels (a hash chain's link: a few hundred to a few thousand rows) are latency-bound -- one lane walking a whole permutation is
+// ~23 k dependent instructions.  Here a row gets SIXTEEN lanes (four rows per wave): lane l < 12 owns state element l of a Poseidon row,
+// S-boxes side by side, the MDS layer through LDS (every lane reads the twelve elements of its row and accumulates its own output from
+// exact 32-bit halves) -- ~3.5 k instructions deep; the short families run on lane 0 of their row's group.  pos = index of the Poseidon
+// generator in a.g, or -1.  One wave per block: the two barriers per round cost nothing.
+__global__ void __launch_bounds__(64) plonk_witness_level_coop_kernel(LevelArgs a, int pos) {
+    __shared__ uint64_t sh[4][12];
+    const uint32_t grp = threadIdx.x >> 4, l = threadIdx.x & 15, k = blockIdx.x * 4 + grp, n = a.n;
+    bool ok = k < a.count;
+    uint32_t i = ok ? a.rows[k] : 0;
+    if (ok && i >= n) {
+        if (l == 0) *a.err = 1;
+        ok = false;
+        i = 0;
+    }
+    bool is_pos = false;
+    if (ok) {
+        if (pos >= 0) is_pos = a.consts[(size_t)a.g[pos].selector_index * n + i] == a.g[pos].row;
+        if (l == 0)
+            for (uint32_t q = 0; q < a.n_gens; q++)
+                if ((int)q != pos && a.consts[(size_t)a.g[q].selector_index * n + i] == a.g[q].row) run_generator(a.wires, a.consts, n, i, a.g[q], a.pih);
+    }
+    if (pos < 0 || !__syncthreads_or(is_pos)) return;        // block-uniform: no Poseidon row among the four
+    const uint32_t in = a.g[pos].p[0], out = a.g[pos].p[1], sb = a.g[pos].p[2];
+    const uint32_t e = l < 12 ? l : 0;                        // lanes 12 .. 15 shadow element 0 and never store
+    const bool act = is_pos && l < 12;
+    uint32_t coef[12];                                        // this lane's row of the MDS matrix
+#pragma unroll
+    for (int c = 0; c < 12; c++) coef[c] = w_mds_circ[(c + 12 - e) % 12] + ((e == 0 && c == 0) ? MDS_DIAG0 : 0);
+    uint64_t s = act ? a.wires[(size_t)(in + e) * n + i] : 0;
+#pragma unroll 1
+    for (uint32_t rnd = 0; rnd < 30; rnd++) {
+        const bool full = rnd < 4 || rnd >= 26;
+        s = gl::add(s, w_rc[12 * rnd + e]);
+        if (full || e == 0) {
+            if (act && rnd) {
+                const uint32_t w = full ? (rnd < 4 ? sb + 12 * (rnd - 1) : sb + 58 + 12 * (rnd - 26)) + e : sb + 36 + (rnd - 4);
+                a.wires[(size_t)w * n + i] = s;
+            }
+            s = pow7(s);
+        }
+        if (l < 12) sh[grp][l] = s;
+        __syncthreads();
+        uint64_t al = 0, ah = 0;
+#pragma unroll
+        for (int c = 0; c < 12; c++) {
+            const uint64_t v = sh[grp][c];
+            al += (uint64_t)(uint32_t)v * coef[c];
+            ah += (v >> 32) * coef[c];
+        }
+        const uint64_t lo = al + (ah << 32);
+        s = gl::reduce96((uint32_t)(ah >> 32) + (lo < al ? 1u : 0u), lo);
+        __syncthreads();
+    }
+    if (act) a.wires[(size_t)(out + e) * n + i] = s;
 }
 
 __global__ void __launch_bounds__(256) plonk_witness_copy_kernel(uint64_t* wires, const uint64_t* src, const uint64_t* dst, uint32_t count,
@@ -285,6 +343,9 @@ extern "C" int sipp_plonk_generate_witness_levels(sipp_ctx* ctx, uint64_t* d_wir
         SIPP_TRY(sipp_table_put(ctx, 101, 0, 0, std::vector<uint64_t>{0}, &t));
         d_err = reinterpret_cast<int*>(t);
     }
+    int pos_gen = -1;
+    for (size_t q = 0; q < n_gens; q++)
+        if (gens[q].kind == SIPP_GEN_POSEIDON) pos_gen = (int)q;      // (two Poseidon layouts in one circuit: the last one gets the lanes)
     auto launch_all = [&]() -> hipError_t {
         (void)hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream);
         for (uint32_t l = 0; l < L; l++) {
@@ -294,7 +355,10 @@ extern "C" int sipp_plonk_generate_witness_levels(sipp_ctx* ctx, uint64_t* d_wir
                 a.wires = d_wires; a.consts = d_constants; a.n = n; a.n_gens = (uint32_t)n_gens; a.rows = sched->d_rows + r0; a.count = cnt; a.err = d_err;
                 for (int q = 0; q < 4; q++) a.pih[q] = public_inputs_hash ? public_inputs_hash[q] : 0;
                 for (size_t q = 0; q < n_gens; q++) a.g[q] = gens[q];
-                hipLaunchKernelGGL(plonk_witness_level_kernel, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, a);
+                if (cnt >= COOP_BELOW_ROWS)      // wide level: throughput, one lane per row
+                    hipLaunchKernelGGL(plonk_witness_level_kernel, dim3((cnt + 63) / 64), dim3(64), 0, ctx->stream, a);
+                else                             // thin level: latency, sixteen lanes per row
+                    hipLaunchKernelGGL(plonk_witness_level_coop_kernel, dim3((cnt + 3) / 4), dim3(64), 0, ctx->stream, a, pos_gen);
             }
             const uint32_t c0 = sched->copy_offsets[l], cc = sched->copy_offsets[l + 1] - c0;
             if (cc)

@@ -360,7 +360,9 @@ def test_bench_outer_plonk_leg_runs_and_verifies():
     assert r["shape"]["num_gate_constraints"] >= 100 and "Poseidon" in r["shape"]["gates"] and "U32MulAdd" in r["shape"]["gates"]
     # the last step of round 6: witness generation on the device, inside the timed step, equal to the C port's table
     assert 0 < r["witness_generation_s"] < 0.05 and abs(r["end_to_end_s_per_proof"] - r["ms_per_proof"] * 1e-3) < 1e-9
-    assert r["witness_matches_cpu_port"] is True and r["cpu_witness_generation_s"] > 0 and "witness_poseidon" in r["kernel_ms_per_proof"]
+    assert r["witness_matches_cpu_port"] is True and r["cpu_witness_generation_s"] > 0 and "witness_levels" in r["kernel_ms_per_proof"]
     assert abs(r["prove_below_witness_ms"] + r["witness_generation_ms"] - r["ms_per_proof"]) < 1e-6
+    w = r["witness_generation"]
+    assert w["levels"] >= 60 and w["launches"] >= 100 and w["graph_replay_ms"] > 0 and w["launch_by_launch_ms"] > 0
     q = r["roofline"]["plonk_quotient"]
     assert q["bound"] == "valu" and q["gate_products_per_point"] > 5000 and 0 < q["frac_valu_est"] < 1.5 and 0 < q["hbm"]["frac"] < 1

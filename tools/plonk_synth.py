@@ -388,7 +388,7 @@ def chain_schedule(log_n, chain_len):
     with its work list; here fixed at circuit-build time): the Poseidon rows form hash chains of `chain_len` links (a row's inputs 0 .. 3
     are the outputs 0 .. 3 of the row `stride` Poseidon rows before it -- Merkle paths), the first multiplicand of arithmetic row t is
     output 4 of Poseidon row t, the first coefficient of reducing row t is the first output of arithmetic row t.
-    -> dict: n_levels; row_level [N]; rows (all rows sorted by level, stable) + level_offsets [n_levels + 1]; copy_src / copy_dst (cell =
+    -> dict: n_levels; row_level [N]; rows (all rows sorted by level, then gate) + level_offsets [n_levels + 1]; copy_src / copy_dst (cell =
     wire * N + row; the copy runs after its source's level) sorted by level + copy_offsets [n_levels + 1]"""
     n = 1 << log_n
     gate = gate_rows(n)
@@ -411,7 +411,7 @@ def chain_schedule(log_n, chain_len):
     o = np.argsort(lev, kind="stable")
     src, dst, lev = src[o], dst[o], lev[o]
     n_levels = int(row_level.max()) + 1
-    rows = np.argsort(row_level, kind="stable").astype(np.uint32)
+    rows = np.lexsort((np.arange(n), gate, row_level)).astype(np.uint32)     # by level, then by gate: the rows of a family side by side
     level_offsets = np.searchsorted(row_level[rows], np.arange(n_levels + 1)).astype(np.uint32)
     copy_offsets = np.searchsorted(lev, np.arange(n_levels + 1)).astype(np.uint32)
     return {"n_levels": n_levels, "row_level": row_level, "rows": rows, "level_offsets": level_offsets, "copy_src": src.astype(np.uint64),
