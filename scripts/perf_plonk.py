@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The `outer_plonk` leg of bench.py alone (for rocprofv3 --kernel-trace --stats): plonky2's prove() below witness generation at the
-standard_ecc_config shape on a synthetic circuit with gates as data.  usage: perf_plonk.py [log2 rows = 18] [steps = 5]"""
+"""The `outer_plonk` leg of bench.py alone (for rocprofv3 --kernel-trace --stats): plonky2's whole prove() -- witness generation level by
+level on the device, then everything below it -- at the standard_ecc_config shape on the chained synthetic circuit with gates, generators
+and the level schedule as data.  usage: perf_plonk.py [log2 rows = 18] [steps = 5]"""
 import json
 import os
 import sys

@@ -88,7 +88,7 @@ def test_fallback_kernel_routes_give_the_same_proofs(ios4):
     L = sipp_amd.lib()
     c = sipp_amd.Ctx(workspace_bytes=L.sipp_workspace_bytes(2, 16))
     try:
-        assert L.sipp_ctx_set_kernel_routes(c.h, 4) == -1                 # unknown bit
+        assert L.sipp_ctx_set_kernel_routes(c.h, 8) == -1                 # unknown bit (4 = SIPP_ROUTE_WITNESS_NO_GRAPH: tests/test_gpu_plonk.py)
         assert L.sipp_ctx_set_kernel_routes(c.h, 3) == 0
         for kind in (0, 2):
             pf = c.prove(kind, ios4[kind])
