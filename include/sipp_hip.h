@@ -499,6 +499,39 @@ int sipp_plonk_generate_witness_levels(sipp_ctx *ctx, uint64_t *d_wires, const u
                                        uint32_t num_constants, const sipp_plonk_generator *gens, size_t n_gens,
                                        const uint64_t public_inputs_hash[4], const sipp_plonk_schedule *sched);
 
+/* ---- round 6: CIRCUIT DATA -- `builder.build()` / `data.prove(pw)` / `data.verify(proof)` with HOST pointers only -----------------------
+ * The reference builds its circuit once (src/verifier_circuit.rs:225 `builder.build::<C>()`), then proves and verifies through the
+ * CircuitData (:253 `data.prove(pw)`, :254 `data.verify(proof)`).  The entry points above take DEVICE buffers of the caller; a caller
+ * without HIP bindings of its own (the Rust shim) uses these instead: everything the circuit fixes -- the gate set, the generators
+ * with their level schedule, the constants_sigmas VALUES -- goes in once and stays on the device with its commitment; a proof takes the
+ * wire table with the INPUT cells set (plonky2's PartialWitness; every generated cell is overwritten) and the public inputs from host
+ * memory and returns the flat "SIPPPLK3" proof to host memory.  One proof at a time per circuit data; it belongs to its ctx (stream,
+ * arena >= sipp_circuit_workspace_bytes) and must be destroyed before it.
+ * circuit_digest: 4 words, or NULL = hash_no_pad(constants_sigmas cap || log_n, num_wires, num_routed_wires, num_constants,
+ * num_selectors, num_gates) (plonky2 hashes the cap and its common data the same way; the exact word list is this library's).
+ * sched may be NULL (row-local generators: sipp_plonk_generate_witness); its arrays are HOST arrays (copied). */
+typedef struct sipp_circuit_data sipp_circuit_data;
+typedef struct {
+    uint32_t n_levels;
+    const uint32_t *rows;
+    const uint32_t *level_offsets;
+    const uint64_t *copy_src;
+    const uint64_t *copy_dst;
+    const uint32_t *copy_offsets;
+} sipp_plonk_schedule_host;
+size_t sipp_circuit_workspace_bytes(uint32_t log_n, const sipp_plonk_params *p, const sipp_fri_params *fp, const sipp_plonk_circuit *c);
+int sipp_circuit_build(sipp_ctx *ctx, uint32_t log_n, const sipp_plonk_params *p, const sipp_fri_params *fp, const sipp_plonk_circuit *c,
+                       const uint64_t *constants_sigmas, const sipp_plonk_generator *gens, size_t n_gens,
+                       const sipp_plonk_schedule_host *sched, const uint64_t *circuit_digest, sipp_circuit_data **out);
+void sipp_circuit_destroy(sipp_circuit_data *cd);
+/* the verifier's half (VerifierOnlyCircuitData): cap_out 2^cap_height x 4 words, digest_out 4 words */
+int sipp_circuit_verifier_data(const sipp_circuit_data *cd, uint64_t *cap_out, uint64_t *digest_out);
+size_t sipp_circuit_proof_size(const sipp_circuit_data *cd, uint32_t n_public_inputs);
+/* wires: HOST [num_wires][N]; the proof's public inputs are bound through public_inputs_hash (PublicInput generator / gate) */
+int sipp_circuit_prove(sipp_circuit_data *cd, const uint64_t *wires, const uint64_t *public_inputs, uint32_t n_public_inputs,
+                       uint64_t *proof_out, size_t proof_cap, size_t *proof_len);
+int sipp_circuit_verify(const sipp_circuit_data *cd, const uint64_t *proof, size_t len, int *reason);
+
 /* ---- verification of the generic proofs (host code like sipp_stark_verify; stages in *reason, may be NULL) -------------------------
  * sipp_fri_verify_openings: PolynomialBatch::verify_openings over a proof of sipp_fri_prove_openings -- caps[o] = the cap of oracle o
  * (2^cap_height x 4 words), ncols / n_salt (may be NULL = 0) per oracle, the batches as proved; the caller's transcript goes in and

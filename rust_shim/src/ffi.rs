@@ -143,6 +143,24 @@ pub struct SippPlonkSchedule {
     pub copy_offsets: *const u32,
 }
 
+/// opaque: a built circuit (gate set, generators, schedule, constants_sigmas and its commitment on the device)
+#[repr(C)]
+pub struct SippCircuitDataOpaque {
+    _private: [u8; 0],
+}
+
+/// the level schedule as host arrays (sipp_circuit_build copies them)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct SippPlonkScheduleHost {
+    pub n_levels: u32,
+    pub rows: *const u32,
+    pub level_offsets: *const u32,
+    pub copy_src: *const u64,
+    pub copy_dst: *const u64,
+    pub copy_offsets: *const u32,
+}
+
 #[link(name = "sipp_hip")]
 extern "C" {
     pub fn sipp_default_config(cfg: *mut SippStarkConfig);
@@ -191,6 +209,16 @@ extern "C" {
     pub fn sipp_plonk_generate_witness_levels(ctx: *mut SippCtxOpaque, d_wires: *mut u64, d_constants: *const u64, log_n: u32, num_wires: u32,
                                               num_constants: u32, gens: *const SippPlonkGenerator, n_gens: usize, public_inputs_hash: *const u64,
                                               sched: *const SippPlonkSchedule) -> c_int;
+    pub fn sipp_circuit_workspace_bytes(log_n: u32, p: *const SippPlonkParams, fp: *const SippFriParams, c: *const SippPlonkCircuit) -> usize;
+    pub fn sipp_circuit_build(ctx: *mut SippCtxOpaque, log_n: u32, p: *const SippPlonkParams, fp: *const SippFriParams, c: *const SippPlonkCircuit,
+                              constants_sigmas: *const u64, gens: *const SippPlonkGenerator, n_gens: usize, sched: *const SippPlonkScheduleHost,
+                              circuit_digest: *const u64, out: *mut *mut SippCircuitDataOpaque) -> c_int;
+    pub fn sipp_circuit_destroy(cd: *mut SippCircuitDataOpaque);
+    pub fn sipp_circuit_verifier_data(cd: *const SippCircuitDataOpaque, cap_out: *mut u64, digest_out: *mut u64) -> c_int;
+    pub fn sipp_circuit_proof_size(cd: *const SippCircuitDataOpaque, n_public_inputs: u32) -> usize;
+    pub fn sipp_circuit_prove(cd: *mut SippCircuitDataOpaque, wires: *const u64, public_inputs: *const u64, n_public_inputs: u32,
+                              proof_out: *mut u64, proof_cap: usize, proof_len: *mut usize) -> c_int;
+    pub fn sipp_circuit_verify(cd: *const SippCircuitDataOpaque, proof: *const u64, len: usize, reason: *mut c_int) -> c_int;
     pub fn sipp_plonk_verify_gates(proof: *const u64, len: usize, constants_sigmas_cap: *const u64, p: *const SippPlonkParams, fp: *const SippFriParams,
                                    c: *const SippPlonkCircuit, circuit_digest: *const u64, reason: *mut c_int) -> c_int;
     pub fn sipp_proof_size(ctx: *const SippCtxOpaque, kind: c_int, num_io: usize) -> usize;

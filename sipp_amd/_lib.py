@@ -94,6 +94,23 @@ class PlonkSchedule(C.Structure):
         return s
 
 
+class PlonkScheduleHost(C.Structure):
+    """sipp_plonk_schedule_host: the level schedule as host arrays (sipp_circuit_build copies them)"""
+    _fields_ = [("n_levels", C.c_uint32), ("rows", C.POINTER(C.c_uint32)), ("level_offsets", C.POINTER(C.c_uint32)), ("copy_src", C.POINTER(C.c_uint64)),
+                ("copy_dst", C.POINTER(C.c_uint64)), ("copy_offsets", C.POINTER(C.c_uint32))]
+
+    @classmethod
+    def from_dict(cls, sched):
+        a32 = lambda v: np.ascontiguousarray(v, dtype=np.uint32)
+        a64 = lambda v: np.ascontiguousarray(v if len(v) else [0], dtype=np.uint64)
+        keep = (a32(sched["rows"]), a32(sched["level_offsets"]), a64(sched["copy_src"]), a64(sched["copy_dst"]), a32(sched["copy_offsets"]))
+        p32, p64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        s = cls(int(sched["n_levels"]), keep[0].ctypes.data_as(p32), keep[1].ctypes.data_as(p32), keep[2].ctypes.data_as(p64),
+                keep[3].ctypes.data_as(p64), keep[4].ctypes.data_as(p32))
+        s._keep = keep
+        return s
+
+
 class Challenger(C.Structure):
     _fields_ = [("state", C.c_uint64 * 12), ("in_buf", C.c_uint64 * 8), ("n_in", C.c_uint64), ("out_buf", C.c_uint64 * 8),
                 ("n_out", C.c_uint64)]
@@ -164,6 +181,14 @@ SIGNATURES = {
     "sipp_plonk_generate_witness": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PlonkGenerator), C.c_size_t, u64p]),
     "sipp_plonk_generate_witness_levels": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(PlonkGenerator), C.c_size_t, u64p,
                                                      C.POINTER(PlonkSchedule)]),
+    "sipp_circuit_workspace_bytes": (C.c_size_t, [C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), C.POINTER(PlonkCircuit)]),
+    "sipp_circuit_build": (C.c_int, [vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), C.POINTER(PlonkCircuit), vp, C.POINTER(PlonkGenerator),
+                                     C.c_size_t, C.POINTER(PlonkScheduleHost), u64p, C.POINTER(vp)]),
+    "sipp_circuit_destroy": (None, [vp]),
+    "sipp_circuit_verifier_data": (C.c_int, [vp, vp, vp]),
+    "sipp_circuit_proof_size": (C.c_size_t, [vp, C.c_uint32]),
+    "sipp_circuit_prove": (C.c_int, [vp, vp, u64p, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sipp_circuit_verify": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_int)]),
     "sipp_plonk_perm_prove": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(PlonkParams), C.POINTER(FriParams), u64p, u64p, vp, C.c_size_t,
                                         C.POINTER(C.c_size_t)]),
     "sipp_ntt_batch": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, C.c_uint32, C.c_int]),
@@ -739,6 +764,56 @@ class InstanceQueue:
         for s in self.slots:
             s.close()
         self.slots = []
+
+
+
+class CircuitData:
+    """plonky2's CircuitData for the outer proof over HOST arrays (sipp_circuit_build / _prove / _verify: reference
+    src/verifier_circuit.rs:225, :253, :254): the gate set, the generators with their level schedule and the constants_sigmas values go in
+    once; prove() takes the wire table with its input cells set and the public inputs, both numpy, and returns the flat proof."""
+
+    def __init__(self, ctx, log_n, params, fri, circuit, constants_sigmas, gens, sched=None, digest=None):
+        self.ctx, self.L = ctx, ctx.L                      # the ctx must outlive this object
+        self.circuit, self.params, self.fri = circuit, params, fri
+        cs = np.ascontiguousarray(constants_sigmas, dtype=np.uint64)
+        arr = (PlonkGenerator * max(1, len(gens)))(*[PlonkGenerator(int(g[0]), int(g[1]), int(g[2]), (C.c_uint32 * 5)(*[int(x) for x in g[3:8]])) for g in gens])
+        self._sched = None if sched is None else PlonkScheduleHost.from_dict(sched)
+        h = C.c_void_p()
+        rc = self.L.sipp_circuit_build(ctx.h, log_n, C.byref(params), C.byref(fri), C.byref(circuit), cs.ctypes.data, arr, len(gens),
+                                       None if self._sched is None else C.byref(self._sched),
+                                       None if digest is None else ctx._u64([int(x) for x in digest]), C.byref(h))
+        ctx._ck(rc, "circuit_build")
+        self.h, self.num_wires, self.n = h, circuit.num_wires, 1 << log_n
+        cap = np.zeros(((1 << min(fri.cap_height, log_n + fri.rate_bits)), 4), dtype=np.uint64)
+        dg = np.zeros(4, dtype=np.uint64)
+        ctx._ck(self.L.sipp_circuit_verifier_data(self.h, cap.ctypes.data, dg.ctypes.data), "circuit_verifier_data")
+        self.cap, self.digest = cap, dg
+
+    def prove(self, wires, public_inputs):
+        w = np.ascontiguousarray(wires, dtype=np.uint64)
+        if w.shape != (self.num_wires, self.n):
+            raise SippError(-1, "CircuitData.prove: wires must be [num_wires][N]")
+        pis = [int(x) for x in public_inputs]
+        cap = self.L.sipp_circuit_proof_size(self.h, len(pis))
+        if cap == 0:
+            raise SippError(-1, "sipp_circuit_proof_size")
+        out = np.zeros(cap, dtype=np.uint64)
+        n = C.c_size_t()
+        self.ctx._ck(self.L.sipp_circuit_prove(self.h, w.ctypes.data, self.ctx._u64(pis) if pis else None, len(pis), out.ctypes.data, cap, C.byref(n)),
+                     "circuit_prove")
+        return out[: n.value]
+
+    def verify(self, proof):
+        """-> (status, refusing stage): (0, 0) = accepted"""
+        pf = np.ascontiguousarray(proof, dtype=np.uint64)
+        reason = C.c_int(0)
+        rc = self.L.sipp_circuit_verify(self.h, pf.ctypes.data, len(pf), C.byref(reason))
+        return rc, reason.value
+
+    def close(self):
+        if self.h:
+            self.L.sipp_circuit_destroy(self.h)
+            self.h = None
 
 
 def io_shard(num_io, world, rank):

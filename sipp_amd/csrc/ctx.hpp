@@ -243,6 +243,7 @@ int sipp_k_poseidon_leaves(sipp_ctx* ctx, const uint64_t* d_lde, size_t col_stri
 int sipp_k_merkle_levels(sipp_ctx* ctx, uint64_t* d_tree, uint32_t log_leaves, uint32_t cap_height);
 int sipp_k_poseidon_permute(sipp_ctx* ctx, uint64_t* d_states, size_t n);
 void sipp_witness_graph_release(sipp_ctx* ctx);   // witness.hip
+int sipp_plonk_circuit_check(sipp_ctx* ctx, const sipp_plonk_circuit* c, const sipp_plonk_params* p);   // plonk.hip
 
 // ---- AIR layer (trace.hip / quotient.hip / stark.hip) -----------------------------------------
 #include "air_tables.h"

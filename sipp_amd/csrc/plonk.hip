@@ -441,6 +441,9 @@ int quotient_chunks_impl(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint6
 }
 }  // namespace
 
+// circuit_data.hip refuses a malformed gate set at build time
+int sipp_plonk_circuit_check(sipp_ctx* ctx, const sipp_plonk_circuit* c, const sipp_plonk_params* p) { return circuit_check(ctx, c, p); }
+
 // the flow of oracle/plonk.c::orc_plonk_perm_prove on the device: four PolynomialBatch commitments, the transcript on the host, one
 // opening proof at zeta / g zeta.  Flat proof: header[8] | wires cap | zs_partial_products cap | quotient cap | opening proof.
 namespace {

@@ -119,7 +119,8 @@ def test_host_poseidon_implementations_agree_with_the_oracle():
 _STRUCTS = {"sipp_ctx": "SippCtxOpaque", "sipp_stark_config": "SippStarkConfig", "sipp_fri_params": "SippFriParams",
             "sipp_oracle": "SippOracle", "sipp_poly_range": "SippPolyRange", "sipp_fri_batch": "SippFriBatch",
             "sipp_challenger": "SippChallenger", "sipp_plonk_params": "SippPlonkParams", "sipp_plonk_gate": "SippPlonkGate",
-            "sipp_plonk_circuit": "SippPlonkCircuit", "sipp_plonk_generator": "SippPlonkGenerator", "sipp_plonk_schedule": "SippPlonkSchedule"}
+            "sipp_plonk_circuit": "SippPlonkCircuit", "sipp_plonk_generator": "SippPlonkGenerator", "sipp_plonk_schedule": "SippPlonkSchedule", "sipp_plonk_schedule_host": "SippPlonkScheduleHost",
+            "sipp_circuit_data": "SippCircuitDataOpaque"}
 _SCALARS = {"int": "c_int", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "float": "f32", "char": "c_char", "void": "c_void"}
 
 
@@ -218,7 +219,7 @@ def test_rust_bindings_match_the_header():
     assert sorted(r_funcs) == sorted(c_funcs), (sorted(set(c_funcs) - set(r_funcs)), sorted(set(r_funcs) - set(c_funcs)))
     for name, (params, ret) in c_funcs.items():
         assert r_funcs[name] == (params, ret), (name, r_funcs[name], (params, ret))
-    assert len(c_structs) == 11
+    assert len(c_structs) == 12
     for cname, fields in c_structs.items():
         rfields = r_structs[_STRUCTS[cname]]
         want = [(n, t.replace("SIPP_FRI_MAX_ROUNDS", "SIPP_FRI_MAX_ROUNDS")) for n, t in fields]

@@ -346,6 +346,62 @@ def test_levelled_witness_generation_matches_the_oracle(ctx, log_n, chain_len):
     assert L.sipp_ctx_set_kernel_routes(ctx.h, 0) == 0
 
 
+@pytest.mark.parametrize("chain_len", [0, 16])
+def test_circuit_data_build_prove_verify_over_host_arrays(chain_len):
+    """sipp_circuit_build / _prove / _verify: `builder.build()`, `data.prove(pw)`, `data.verify(proof)` (reference src/verifier_circuit.rs:225,
+    :253, :254) for a caller with host memory only.  From the wire table with its INPUT cells alone the proof is the oracle's proof of the
+    full witness word for word -- row-local generators and the level schedule alike; the verifier data (cap, digest) equal the oracle's
+    commitment / the caller's digest; the data's own verify accepts it and refuses a forged public input; a second proof with other
+    public inputs under the same data verifies; a derived digest (NULL) is bound into the transcript; malformed builds are refused"""
+    import sipp_amd
+    from tests.test_oracle_plonk import _synth
+    log_n, pis = 11, [7, 8, 9, 10, 11]
+    ps, circ, _w, _cs, _gate, _pis, pih = _synth(log_n, 136, 80, seed=91, pis=pis)
+    wires, cs, gate = ps.witness(circ, log_n, 91, pih, chain_len=chain_len)
+    w_in = ps.witness(circ, log_n, 91, pih, inputs_only=True, chain_len=chain_len)[0]
+    sc = ps.chain_schedule(log_n, chain_len) if chain_len else None
+    op, gp = _oracle.plonk_params(80, 8, 2), sipp_amd.PlonkParams(80, 8, 2)
+    ofp = fri(log_n, rate_bits=3, cap_height=4, nq=8, arity=4, fpb=4)
+    gfp, gc = to_params(ofp), sipp_amd.PlonkCircuit.from_dict(circ)
+    digest = (41, 42, 43, 44)
+    L = sipp_amd.lib()
+    ws = L.sipp_circuit_workspace_bytes(log_n, C.byref(gp), C.byref(gfp), C.byref(gc))
+    assert ws > (4 << 30)
+    c = sipp_amd.Ctx(workspace_bytes=ws)
+    try:
+        data = sipp_amd.CircuitData(c, log_n, gp, gfp, gc, cs, ps.generators(circ), sched=sc, digest=digest)
+        cs_cap = _oracle.Batch(cs, log_n, rate_bits=3, cap_height=4).cap
+        assert (data.cap == cs_cap).all() and [int(x) for x in data.digest] == list(digest)
+        pf = data.prove(w_in, pis)
+        want = _oracle.plonk_prove_gates(wires, cs, log_n, op, ofp, circ, digest, pis)
+        assert len(pf) == len(want) and (pf == want).all()
+        assert data.verify(pf) == (0, 0) and _oracle.plonk_verify_gates(pf, cs_cap, op, ofp, circ, digest) == 0
+        forged = pf.copy()
+        forged[-1] ^= 1
+        assert data.verify(forged)[0] == -9
+        # other public inputs under the same data: the PublicInput row follows the new hash
+        pis2 = [1, 2, 3]
+        pf2 = data.prove(w_in, pis2)
+        assert data.verify(pf2) == (0, 0) and (pf2[-3:] == np.array(pis2, dtype=np.uint64)).all() and not (pf2[:64] == pf[:64]).all()
+        data.close()
+        # derived digest
+        d2 = sipp_amd.CircuitData(c, log_n, gp, gfp, gc, cs, ps.generators(circ), sched=sc)
+        assert d2.digest.any() and [int(x) for x in d2.digest] != list(digest)
+        pf3 = d2.prove(w_in, pis)
+        assert d2.verify(pf3) == (0, 0) and _oracle.plonk_verify_gates(pf3, cs_cap, op, ofp, circ, [int(x) for x in d2.digest]) == 0
+        assert _oracle.plonk_verify_gates(pf3, cs_cap, op, ofp, circ, digest) != 0
+        d2.close()
+        bad = dict(circ, programs=circ["programs"][:-3])
+        with pytest.raises(sipp_amd.SippError):
+            sipp_amd.CircuitData(c, log_n, gp, gfp, sipp_amd.PlonkCircuit.from_dict(bad), cs, ps.generators(circ), sched=sc)
+        if sc:
+            bad_sc = dict(sc, level_offsets=sc["level_offsets"][::-1].copy())
+            with pytest.raises(sipp_amd.SippError):
+                sipp_amd.CircuitData(c, log_n, gp, gfp, gc, cs, ps.generators(circ), sched=bad_sc)
+    finally:
+        c.close()
+
+
 def test_bench_outer_plonk_leg_runs_and_verifies():
     """bench.py's `outer_plonk` leg (plonky2 prove() at the standard_ecc_config column counts, gates as data) at a small size: the leg
     proves, the oracle's verifier accepts the proof, and the object carries its own roofline entries"""
