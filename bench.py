@@ -226,6 +226,24 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
         rep = {k: v["ms"] / steps for k, v in ctx.profile_report().items()}
         ctx.profile(False)
         del keep
+        # the same prove() through the HOST-pointer boundary (sipp_circuit_build once, then sipp_circuit_prove: the wire table with its input
+        # cells crosses PCIe on every proof -- 8 N num_wires bytes -- and the proof comes back to host memory): the PCIe-inclusive figure
+        host_to_host = None
+        try:
+            ctx.sync()
+            data = sipp_amd.CircuitData(ctx, log_n, gp, fp, gc, cs, gens, sched=sc, digest=digest)
+            try:
+                pf_h = data.prove(wires, pis)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pf_h = data.prove(wires, pis)
+                host_to_host = {"ms_per_proof": 1e3 * (time.perf_counter() - t0) / steps, "h2d_bytes_per_proof": int(wires.nbytes),
+                                "entry_points": "sipp_circuit_build, sipp_circuit_prove", "same_proof": bool(len(pf_h) == len(pf) and (pf_h == pf).all()),
+                                "verified": data.verify(pf_h) == (0, 0)}
+            finally:
+                data.close()
+        except Exception as e:                                                        # noqa: BLE001 -- a secondary figure
+            host_to_host = {"error": repr(e)}
         wit.update({"levels": int(sc["n_levels"]), "launches": int(np.count_nonzero(np.diff(sc["level_offsets"])) + np.count_nonzero(np.diff(sc["copy_offsets"]))),
                     "copies": int(len(sc["copy_src"])), "chain_len": CHAIN})
         ntt_names = [k for k in rep if k.startswith(("ntt_", "lde_", "bitrev"))]
@@ -268,7 +286,7 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                 # HEADLINE, next to ms_per_proof (which contains it): witness generation now runs on the device (row-local generators; values
                 # that travel between rows through copy constraints are the caller's to order).  The host keeps what plonky2 does outside prove()
                 "witness_generation_s": wit_ms * 1e-3, "witness_generation_ms": wit_ms, "prove_below_witness_ms": ms - wit_ms, "witness_generation": wit,
-                "end_to_end_s_per_proof": ms * 1e-3, "host_circuit_and_inputs_s": t_inputs, **cpu_wit,
+                "end_to_end_s_per_proof": ms * 1e-3, "host_circuit_and_inputs_s": t_inputs, "host_to_host": host_to_host, **cpu_wit,
                 "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
                 "roofline": {"transforms": {"bound": "hbm", "kernels": sorted(ntt_names), "algorithmic_bytes": ntt_bytes, "ms": ntt_ms,
                                             "achieved": ntt_bytes / (ntt_ms * 1e-3) / 1e9 if ntt_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

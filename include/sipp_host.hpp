@@ -288,6 +288,72 @@ struct StarkProofWithPublicInputs {
     }
 };
 
+// ---- the OUTER proof: plonky2's CircuitData (reference src/verifier_circuit.rs:225 `builder.build::<C>()`, :253 `data.prove(pw)`,
+// :254 `data.verify(proof)`) over sipp_circuit_build / _prove / _verify.  The circuit -- gate set, generators, level schedule,
+// constants_sigmas values -- is DATA the caller's circuit builder produced (the reference's own builder lives in un-vendored crates);
+// everything stays in host memory on this side.
+struct ProofWithPublicInputs {
+    std::vector<uint64_t> flat;            // "SIPPPLK3": header | caps | opening proof | public inputs
+    std::vector<uint64_t> public_inputs;   // the tail of `flat` (SIPPStatement::from_vec reads these back: verifier_circuit.rs:258-268)
+};
+class CircuitData {
+   public:
+    // degree_bits = log2 rows; constants_sigmas [num_constants + num_routed_wires][N] values; schedule may be null (row-local generators);
+    // digest may be null (derived from the constants_sigmas cap and the shape)
+    CircuitData(int device, uint32_t degree_bits, const sipp_plonk_params& params, const sipp_fri_params& fri, const sipp_plonk_circuit& circuit,
+                const std::vector<uint64_t>& constants_sigmas, const std::vector<sipp_plonk_generator>& generators,
+                const sipp_plonk_schedule_host* schedule = nullptr, const uint64_t* digest = nullptr)
+        : num_wires_(circuit.num_wires), n_((size_t)1 << degree_bits) {
+        if (constants_sigmas.size() != ((size_t)circuit.num_constants + params.num_routed_wires) * n_)
+            throw Error(SIPP_E_BADARG, "CircuitData: constants_sigmas must be [num_constants + num_routed_wires][N]");
+        int rc = sipp_ctx_create(&ctx_, device, nullptr, sipp_circuit_workspace_bytes(degree_bits, &params, &fri, &circuit));
+        if (rc != SIPP_OK) throw Error(rc, "CircuitData: sipp_ctx_create failed");
+        rc = sipp_circuit_build(ctx_, degree_bits, &params, &fri, &circuit, constants_sigmas.data(), generators.data(), generators.size(), schedule,
+                                digest, &data_);
+        if (rc != SIPP_OK) {
+            const std::string msg = std::string("sipp_circuit_build: ") + sipp_last_error(ctx_);
+            sipp_ctx_destroy(ctx_);
+            throw Error(rc, msg);
+        }
+        constants_sigmas_cap.assign((size_t)4 << std::min(fri.cap_height, degree_bits + fri.rate_bits), 0);
+        (void)sipp_circuit_verifier_data(data_, constants_sigmas_cap.data(), circuit_digest);
+    }
+    ~CircuitData() {
+        sipp_circuit_destroy(data_);
+        sipp_ctx_destroy(ctx_);
+    }
+    CircuitData(const CircuitData&) = delete;
+    CircuitData& operator=(const CircuitData&) = delete;
+
+    // `data.prove(pw)`: pw = the wire table [num_wires][N] with the input cells set (the generated cells are overwritten on the device)
+    ProofWithPublicInputs prove(const std::vector<uint64_t>& partial_witness, const std::vector<uint64_t>& public_inputs) {
+        if (partial_witness.size() != (size_t)num_wires_ * n_) throw Error(SIPP_E_BADARG, "CircuitData::prove: the witness must be [num_wires][N]");
+        ProofWithPublicInputs r;
+        const size_t cap = sipp_circuit_proof_size(data_, (uint32_t)public_inputs.size());
+        r.flat.assign(cap, 0);
+        size_t len = 0;
+        const int rc = sipp_circuit_prove(data_, partial_witness.data(), public_inputs.data(), (uint32_t)public_inputs.size(), r.flat.data(), cap, &len);
+        if (rc != SIPP_OK) throw Error(rc, std::string("sipp_circuit_prove: ") + sipp_last_error(ctx_));
+        r.flat.resize(len);
+        r.public_inputs.assign(r.flat.end() - (std::ptrdiff_t)public_inputs.size(), r.flat.end());
+        return r;
+    }
+    // `data.verify(proof)`: throws Error(SIPP_E_VERIFY) naming the refusing stage
+    void verify(const ProofWithPublicInputs& proof) const {
+        int reason = 0;
+        const int rc = sipp_circuit_verify(data_, proof.flat.data(), proof.flat.size(), &reason);
+        if (rc != SIPP_OK) throw Error(rc, "CircuitData::verify: refused at stage " + std::to_string(reason));
+    }
+    std::vector<uint64_t> constants_sigmas_cap;   // VerifierOnlyCircuitData
+    uint64_t circuit_digest[4] = {0, 0, 0, 0};
+
+   private:
+    sipp_ctx* ctx_ = nullptr;
+    sipp_circuit_data* data_ = nullptr;
+    uint32_t num_wires_;
+    size_t n_;
+};
+
 template <class Out>
 struct ExpCircuitResult {
     std::vector<Out> outputs;          // what g*_exp_circuit returns as targets, as values

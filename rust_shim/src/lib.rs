@@ -103,6 +103,52 @@ pub fn verify_plonk_proof(proof: &[u64], constants_sigmas_cap: &[u64], params: &
     if rc == 0 { Ok(()) } else { Err(anyhow::anyhow!("sipp_plonk_verify_gates: status {} at stage {}", rc, reason)) }
 }
 
+/// plonky2's `CircuitData` for the outer proof over `sipp_circuit_build` / `_prove` / `_verify` (reference src/verifier_circuit.rs:225
+/// `builder.build::<C>()`, :253 `data.prove(pw)`, :254 `data.verify(proof)`): host slices only; the ctx must outlive the data.
+pub struct CircuitData {
+    raw: *mut ffi::SippCircuitDataOpaque,
+}
+
+impl CircuitData {
+    /// constants_sigmas: [num_constants + num_routed_wires][N] values; sched / digest may be None (row-local generators / derived digest)
+    pub fn build(ctx: *mut ffi::SippCtxOpaque, degree_bits: u32, params: &ffi::SippPlonkParams, fri: &ffi::SippFriParams,
+                 circuit: &ffi::SippPlonkCircuit, constants_sigmas: &[u64], generators: &[ffi::SippPlonkGenerator],
+                 sched: Option<&ffi::SippPlonkScheduleHost>, digest: Option<&[u64; 4]>) -> Result<Self> {
+        let mut raw: *mut ffi::SippCircuitDataOpaque = std::ptr::null_mut();
+        let rc = unsafe {
+            ffi::sipp_circuit_build(ctx, degree_bits, params, fri, circuit, constants_sigmas.as_ptr(), generators.as_ptr(), generators.len(),
+                                    sched.map_or(std::ptr::null(), |s| s as *const _), digest.map_or(std::ptr::null(), |d| d.as_ptr()), &mut raw)
+        };
+        if rc == 0 { Ok(CircuitData { raw }) } else { Err(anyhow::anyhow!("sipp_circuit_build: status {}", rc)) }
+    }
+
+    /// `data.prove(pw)`: pw = the wire table [num_wires][N] with the input cells set; returns the flat proof, public inputs at its end
+    pub fn prove(&mut self, partial_witness: &[u64], public_inputs: &[u64]) -> Result<Vec<u64>> {
+        let cap = unsafe { ffi::sipp_circuit_proof_size(self.raw, public_inputs.len() as u32) };
+        let mut out = vec![0u64; cap];
+        let mut len = 0usize;
+        let rc = unsafe {
+            ffi::sipp_circuit_prove(self.raw, partial_witness.as_ptr(), public_inputs.as_ptr(), public_inputs.len() as u32, out.as_mut_ptr(), cap, &mut len)
+        };
+        if rc != 0 { return Err(anyhow::anyhow!("sipp_circuit_prove: status {}", rc)); }
+        out.truncate(len);
+        Ok(out)
+    }
+
+    /// `data.verify(proof)`
+    pub fn verify(&self, proof: &[u64]) -> Result<()> {
+        let mut reason: std::os::raw::c_int = 0;
+        let rc = unsafe { ffi::sipp_circuit_verify(self.raw, proof.as_ptr(), proof.len(), &mut reason) };
+        if rc == 0 { Ok(()) } else { Err(anyhow::anyhow!("sipp_circuit_verify: status {} at stage {}", rc, reason)) }
+    }
+}
+
+impl Drop for CircuitData {
+    fn drop(&mut self) {
+        unsafe { ffi::sipp_circuit_destroy(self.raw) }
+    }
+}
+
 pub fn io_shard(num_io: usize, world: u32, rank: u32) -> Result<std::ops::Range<usize>> {
     let (mut first, mut count) = (0usize, 0usize);
     let rc = unsafe { ffi::sipp_io_shard(num_io, world, rank, &mut first, &mut count) };

@@ -293,8 +293,88 @@ static int mapg2(const char* msgs_path, const char* out_prefix) {
     return 0;
 }
 
+// The tail of the reference's test (src/verifier_circuit.rs:225, :253-268) in its own terms: build the circuit data once, `data.prove(pw)`,
+// `data.verify(proof)`, read the public inputs back.  The circuit is DATA (fixture written by tests/test_host_cpp.py from
+// tools/plonk_synth.py: the recursion-shaped stand-in, chained): u64 words
+//   header[12] = degree_bits, num_wires, num_routed, num_constants, num_selectors, num_gates, program_words, n_gens, n_levels, n_copies,
+//                n_public_inputs, max_degree | fri params (7 + 32 words) | gates (6 words each) | programs | generators (8 words each)
+//   | rows (N) | level_offsets | copy_src | copy_dst | copy_offsets | constants_sigmas | wires (input cells set) | public inputs
+static int outer(const char* path, const char* out_path) {
+    const std::vector<uint64_t> w = read_u64(path);
+    size_t pos = 0;
+    auto next = [&](size_t count) -> const uint64_t* {
+        if (pos + count > w.size()) {
+            fprintf(stderr, "circuit fixture too short\n");
+            exit(2);
+        }
+        const uint64_t* q = w.data() + pos;
+        pos += count;
+        return q;
+    };
+    const uint64_t* h = next(12);
+    const uint32_t degree_bits = (uint32_t)h[0], n_gens = (uint32_t)h[7], n_levels = (uint32_t)h[8], n_copies = (uint32_t)h[9], n_pi = (uint32_t)h[10];
+    const size_t n = (size_t)1 << degree_bits;
+    sipp_plonk_params params{(uint32_t)h[2], (uint32_t)h[11], 2};
+    sipp_fri_params fri{};
+    const uint64_t* f = next(7 + SIPP_FRI_MAX_ROUNDS);
+    fri.rate_bits = (uint32_t)f[0]; fri.cap_height = (uint32_t)f[1]; fri.pow_bits = (uint32_t)f[2]; fri.num_queries = (uint32_t)f[3];
+    fri.pow_rule = (uint32_t)f[4]; fri.hiding = (uint32_t)f[5]; fri.n_rounds = (uint32_t)f[6];
+    for (uint32_t i = 0; i < SIPP_FRI_MAX_ROUNDS; i++) fri.arity_bits[i] = (uint32_t)f[7 + i];
+    std::vector<sipp_plonk_gate> gates(h[5]);
+    for (auto& g : gates) {
+        const uint64_t* q = next(6);
+        g = sipp_plonk_gate{(uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2], (uint32_t)q[3], (uint32_t)q[4], (uint32_t)q[5]};
+    }
+    const uint64_t* pr = next(h[6]);
+    std::vector<int64_t> programs(pr, pr + h[6]);
+    std::vector<sipp_plonk_generator> gens(n_gens);
+    for (auto& g : gens) {
+        const uint64_t* q = next(8);
+        g = sipp_plonk_generator{(uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2], {(uint32_t)q[3], (uint32_t)q[4], (uint32_t)q[5], (uint32_t)q[6], (uint32_t)q[7]}};
+    }
+    auto u32s = [&](size_t count) {
+        const uint64_t* q = next(count);
+        return std::vector<uint32_t>(q, q + count);
+    };
+    const std::vector<uint32_t> rows = u32s(n), level_offsets = u32s(n_levels + 1);
+    const uint64_t* cs_ = next(n_copies);
+    const uint64_t* cd_ = next(n_copies);
+    const std::vector<uint32_t> copy_offsets = u32s(n_levels + 1);
+    const sipp_plonk_schedule_host sched{n_levels, rows.data(), level_offsets.data(), cs_, cd_, copy_offsets.data()};
+    const size_t cs_words = (size_t)(h[3] + h[2]) * n, wire_words = (size_t)h[1] * n;
+    const uint64_t* q = next(cs_words);
+    const std::vector<uint64_t> constants_sigmas(q, q + cs_words);
+    q = next(wire_words);
+    const std::vector<uint64_t> pw(q, q + wire_words);
+    q = next(n_pi);
+    const std::vector<uint64_t> statement(q, q + n_pi);
+    CHECK(pos == w.size());
+    const sipp_plonk_circuit circuit{(uint32_t)h[1], (uint32_t)h[3], (uint32_t)h[4], (uint32_t)gates.size(), gates.data(), programs.data(),
+                                     (uint32_t)programs.size()};
+
+    sipp::CircuitData data(0, degree_bits, params, fri, circuit, constants_sigmas, gens, &sched);     // builder.build::<C>()
+    const sipp::ProofWithPublicInputs proof = data.prove(pw, statement);                              // data.prove(pw)
+    data.verify(proof);                                                                               // data.verify(proof)
+    CHECK(proof.public_inputs == statement);                      // SIPPStatement::from_vec(&proof.public_inputs) == statement (:258-268)
+    sipp::verify_plonk_proof(proof.flat, data.constants_sigmas_cap, params, fri, circuit, data.circuit_digest);   // ... from the verifier data alone
+    sipp::ProofWithPublicInputs forged = proof;
+    forged.flat.back() ^= 1;
+    try {
+        data.verify(forged);
+        CHECK(!"a proof with another statement was accepted");
+    } catch (const sipp::Error& e) {
+        CHECK(e.status() == SIPP_E_VERIFY);
+    }
+    std::ofstream o(out_path, std::ios::binary);
+    o.write(reinterpret_cast<const char*>(proof.flat.data()), (std::streamsize)(proof.flat.size() * 8));
+    o.write(reinterpret_cast<const char*>(data.circuit_digest), 32);
+    printf("outer proof ok: %zu words, %u public inputs, %u levels\n", proof.flat.size(), n_pi, n_levels);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
+        if (argc == 4 && std::string(argv[1]) == "outer") return outer(argv[2], argv[3]);
         if (argc >= 2 && std::string(argv[1]) == "layout") return layout(argc >= 3 ? argv[2] : nullptr);
         if (argc == 4 && std::string(argv[1]) == "prove") return prove(argv[2], argv[3]);
         if (argc == 4 && std::string(argv[1]) == "mapg2") return mapg2(argv[2], argv[3]);

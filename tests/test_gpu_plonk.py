@@ -418,6 +418,8 @@ def test_bench_outer_plonk_leg_runs_and_verifies():
     assert 0 < r["witness_generation_s"] < 0.05 and abs(r["end_to_end_s_per_proof"] - r["ms_per_proof"] * 1e-3) < 1e-9
     assert r["witness_matches_cpu_port"] is True and r["cpu_witness_generation_s"] > 0 and "witness_levels" in r["kernel_ms_per_proof"]
     assert abs(r["prove_below_witness_ms"] + r["witness_generation_ms"] - r["ms_per_proof"]) < 1e-6
+    hh = r["host_to_host"]
+    assert hh["same_proof"] is True and hh["verified"] is True and hh["ms_per_proof"] > 0 and hh["h2d_bytes_per_proof"] == 8 * 136 << 12
     w = r["witness_generation"]
     assert w["levels"] >= 60 and w["launches"] >= 100 and w["graph_replay_ms"] > 0 and w["launch_by_launch_ms"] > 0
     q = r["roofline"]["plonk_quotient"]

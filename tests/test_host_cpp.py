@@ -116,3 +116,41 @@ def test_bls_front_end_cpp(tmp_path):
     finally:
         ctx.close()
     assert len(got) == len(want) and (got == want).all()
+
+
+@pytest.mark.gpu
+def test_outer_circuit_data_cpp(tmp_path):
+    """sipp::CircuitData (include/sipp_host.hpp over sipp_circuit_build / _prove / _verify): the tail of the reference's test --
+    builder.build, data.prove(pw), data.verify(proof), public inputs read back as the SIPPStatement (src/verifier_circuit.rs:225, :253-268)
+    -- in C++ with host memory only, on the chained recursion-shaped stand-in circuit with the n = 4 fixture's statement as public
+    inputs; the proof the binary writes is the ORACLE's proof of the full numpy witness word for word"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import plonk_synth as ps
+    from tests import _oracle
+    from tests.test_oracle_plonk import fri
+    exe = build_host_test()
+    st = np.load(os.path.join(ROOT, "tests", "golden", "sipp_n4_ios.npz"))["statement"].astype(np.uint64)
+    log_n, chain = 10, 8
+    circ = ps.circuit(136, 80)
+    pih = [int(x) for x in _oracle.hash_no_pad(st)]
+    wires, cs, gate = ps.witness(circ, log_n, 17, pih, chain_len=chain)
+    w_in = ps.witness(circ, log_n, 17, pih, inputs_only=True, chain_len=chain)[0]
+    sc = ps.chain_schedule(log_n, chain)
+    ofp = fri(log_n, rate_bits=3, cap_height=4, nq=28, arity=4, fpb=5)
+    gens = ps.generators(circ)
+    u64 = lambda v: np.ascontiguousarray(v, dtype=np.uint64).reshape(-1)
+    head = [log_n, circ["num_wires"], circ["num_routed"], circ["num_constants"], circ["num_selectors"], len(circ["gates"]), len(circ["programs"]),
+            len(gens), sc["n_levels"], len(sc["copy_src"]), len(st), 8]
+    fp_words = [ofp.rate_bits, ofp.cap_height, ofp.pow_bits, ofp.num_queries, ofp.pow_rule, ofp.hiding, ofp.n_rounds] + [int(x) for x in ofp.arity_bits]
+    parts = [u64(head), u64(fp_words), u64([list(g) for g in circ["gates"]]), circ["programs"].astype(np.int64).view(np.uint64), u64([list(g) for g in gens]),
+             u64(sc["rows"]), u64(sc["level_offsets"]), u64(sc["copy_src"]), u64(sc["copy_dst"]), u64(sc["copy_offsets"]), u64(cs), u64(w_in), u64(st)]
+    with open(tmp_path / "circuit.bin", "wb") as f:
+        for a in parts:
+            f.write(a.tobytes())
+    out = subprocess.run([exe, "outer", str(tmp_path / "circuit.bin"), str(tmp_path / "outer.bin")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "outer proof ok" in out.stdout, out.stdout + out.stderr
+    got = np.fromfile(tmp_path / "outer.bin", dtype=np.uint64)
+    pf, digest = got[:-4], [int(x) for x in got[-4:]]
+    want = _oracle.plonk_prove_gates(wires, cs, log_n, _oracle.plonk_params(80, 8, 2), ofp, circ, digest, [int(x) for x in st])
+    assert len(pf) == len(want) and (pf == want).all()
