@@ -308,24 +308,42 @@ def plonk_quotient_roofline(circ, n, W, K, R, CH, D, zs_cols, ms):
     filter and the alpha fold of every challenge; ~26 wave instructions per product at one instruction per 4 cycles)"""
     if not ms:
         return None
+    # what the kernel runs since the last step of round 6 (plonk.hip compile_gates): per gate its DISTINCT monomials, each evaluated once
+    # (a pure power w^k by squaring, or ONE product when w^(k-1) came just before; a mixed monomial its factors) and weighted by one
+    # alpha-folded coefficient per challenge; `as_written` = the products the programs ask for constraint by constraint (rounds 5 - 6)
     prog = [int(x) for x in circ["programs"]]
-    products = 0
+    products = as_written = monomials = distinct = 0
     for (_si, _row, lo, hi, off, nc) in circ["gates"]:
         w = off
-        products += (hi - lo)                                # the gate's filter
+        products += (hi - lo) + CH                           # the gate's filter, filter x folded sum per challenge
+        as_written += (hi - lo)
+        seen = set()
         for _ in range(nc):
             nm = prog[w]
             w += 1
             for _m in range(nm):
                 coef, nf = prog[w], prog[w + 1]
+                seen.add(tuple(sorted((prog[w + 2 + 2 * i], prog[w + 3 + 2 * i]) for i in range(nf))))
                 w += 2 + 2 * nf
-                products += max(0, nf - 1) + (1 if abs(coef) != 1 and nf else 0)
-            products += 1 + CH                               # filter x constraint, one alpha fold per challenge
+                as_written += max(0, nf - 1) + (1 if abs(coef) != 1 and nf else 0)
+                monomials += 1
+            as_written += 1 + CH                             # filter x constraint, one alpha fold per challenge
+        distinct += len(seen)
+        pure = sorted((f[0], len(f)) for f in seen if f and f[0] == f[-1])
+        for i, (op, k) in enumerate(pure):
+            chained = i > 0 and pure[i - 1] == (op, k - 1)
+            products += 1 if chained and k > 1 else (k.bit_length() - 1) + bin(k).count("1") - 1
+        products += sum(len(f) - 1 for f in seen if f and f[0] != f[-1])
+        products += CH * len(seen)
     m = 8 * n
     bytes_alg = 8.0 * m * (K + R + W + zs_cols) + 8.0 * m * CH
     peak_products = 1024 * 64 * 2.2e9 / (4 * 26)             # lanes x clock / (cycles per instruction x instructions per product)
-    ach = products * m / (ms * 1e-3)
-    return {"bound": "valu", "ms": ms, "gate_products_per_point": products, "points": m, "achieved_products_per_s": ach,
+    chunks = (R + D - 1) // D
+    perm_products = CH * (4 * R + 2 * chunks + 2)            # the permutation terms beside the gates: per routed wire beta_k x, the numerator,
+    ach = (products + perm_products) * m / (ms * 1e-3)       # beta sigma and the denominator; per chunk the two sides of check_partial_products
+    return {"bound": "valu", "ms": ms, "gate_products_per_point": products, "gate_products_per_point_as_written": as_written,
+            "monomials": monomials, "distinct_monomials": distinct, "permutation_products_per_point": perm_products, "points": m,
+            "achieved_products_per_s": ach,
             "peak_products_per_s_est": peak_products, "frac_valu_est": ach / peak_products,
             "hbm": {"algorithmic_bytes": bytes_alg, "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}

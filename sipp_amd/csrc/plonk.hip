@@ -14,6 +14,8 @@
 // O(R) products per cell read -- integer VALU bound like the STARK quotient kernels.
 #include "ctx.hpp"
 #include "prover.hpp"
+#include <algorithm>
+#include <map>
 
 namespace {
 
@@ -117,9 +119,13 @@ struct QuotArgs {
     // gates as data (sipp_plonk_prove_gates): the circuit's gate set interpreted at every point of the quotient coset
     const uint64_t* cl;       // [num_constants][stride] constant columns (selectors first), leaf order; nullptr: no gate set
     const sipp_plonk_gate* gates;
-    const int64_t* prog;
-    const uint64_t* gapow;    // [C][n_gc]: alpha_c^(number of terms in front of gate constraint j)
-    uint32_t n_gates, many_sel, n_gc;
+    // the gate programs COMPILED for this proof (compile_gates below): per gate its DISTINCT monomials, each evaluated once per point and
+    // multiplied by ONE coefficient per challenge -- the alpha-folded sum of every place the monomial occurs in the gate's constraints
+    const int64_t* cprog;     // per gate: n_distinct, then per monomial: n_factors, (kind, index) x n_factors
+    const uint32_t* coff;     // [n_gates] word offset of a gate in cprog
+    const uint32_t* boff;     // [n_gates] index of a gate's first monomial in cB
+    const uint64_t* cB;       // [C][n_dist]
+    uint32_t n_gates, many_sel, n_dist;
     uint64_t pih[4];
 };
 
@@ -183,33 +189,32 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
             uint64_t part[MAX_CH];
 #pragma unroll
             for (uint32_t c = 0; c < MAX_CH; c++) part[c] = 0;
-            const int64_t* w = a.prog + ga.prog_offset;
+            // sum_j alpha^(n0 + j) c_{g,j} = sum over the gate's DISTINCT monomials d of  value_d(point) * B_d,  B_d = sum over the places
+            // (constraint j, coefficient) where d occurs of alpha^(n0 + j) * coefficient (host, per proof): the twelve constraints of a
+            // Poseidon round share their twelve S-box terms -- 2999 monomial instances of that gate are 309 distinct ones
+            const int64_t* w = a.cprog + a.coff[g];
+            const uint64_t* B = a.cB + a.boff[g];
+            const uint32_t nd_g = (uint32_t)*w++;
             int64_t pw_kind = -1, pw_idx = -1;                            // the last pure power evaluated: operand, exponent, value
             int pw_exp = 0;
             uint64_t pw_val = 0;
-            for (uint32_t j = 0; j < ga.num_constraints; j++) {
-                const int nm = (int)*w++;
-                uint64_t sum = 0;
-                for (int mo = 0; mo < nm; mo++) {
-                    const int64_t coef = w[0];
-                    const int nf = (int)w[1];
-                    w += 2;
-                    if (nf == 0) {
-                        sum = gl::add(sum, gl::from_i64(coef));
-                        continue;
-                    }
-                    // a monomial that is a pure POWER of one operand (the S-box terms of a Poseidon gate: w^7, and the binomial
-                    // expansion of (in + rc)^7: w, w^2, .. w^7 one after the other): one load, the power by squaring -- or ONE product
-                    // when the previous monomial was the next lower power of the same operand.  Wave-uniform decisions (program words).
+            for (uint32_t d = 0; d < nd_g; d++) {
+                const int nf = (int)*w++;
+                uint64_t t;
+                if (nf == 0) {
+                    t = 1;
+                } else {
+                    // a PURE POWER of one operand (w^7 of a Poseidon gate; w, w^2 .. w^7 of (in + rc)^7, adjacent after the compile step's
+                    // sort): one load, the power by squaring -- or ONE product when the previous monomial was the next lower power of the
+                    // same operand.  Wave-uniform decisions (program words).
                     const int64_t k0 = w[0], i0 = w[1];
-                    bool pure = nf > 1;
+                    bool pure = true;
                     for (int q = 1; q < nf && pure; q++) pure = w[2 * q] == k0 && w[2 * q + 1] == i0;
-                    uint64_t t;
                     if (pure) {
-                        const uint64_t x = operand(k0, i0);
                         if (k0 == pw_kind && i0 == pw_idx && nf == pw_exp + 1) {
-                            t = gl::mul(pw_val, x);
+                            t = gl::mul(pw_val, operand(k0, i0));
                         } else {
+                            const uint64_t x = operand(k0, i0);
                             t = x;
                             for (int bit = 30 - __builtin_clz((unsigned)nf); bit >= 0; bit--) {
                                 t = gl::mul(t, t);
@@ -222,15 +227,11 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(QuotArgs a) {
                         t = operand(k0, i0);
                         w += 2;
                         for (int q = 1; q < nf; q++, w += 2) t = gl::mul(t, operand(w[0], w[1]));
-                        if (nf == 1) { pw_kind = k0; pw_idx = i0; pw_exp = 1; pw_val = t; }
                     }
-                    if (coef == 1) sum = gl::add(sum, t);
-                    else if (coef == -1) sum = gl::sub(sum, t);
-                    else sum = gl::mad(gl::from_i64(coef), t, sum);
                 }
 #pragma unroll
                 for (uint32_t c = 0; c < MAX_CH; c++)
-                    if (c < C) part[c] = gl::mad(a.gapow[(size_t)c * a.n_gc + j], sum, part[c]);
+                    if (c < C) part[c] = gl::mad(B[(size_t)c * a.n_dist + d], t, part[c]);
             }
 #pragma unroll
             for (uint32_t c = 0; c < MAX_CH; c++)
@@ -333,6 +334,75 @@ int sipp_plonk_quotient_chunks_ex(sipp_ctx* ctx, const uint64_t* d_wires_lde, co
 }
 
 namespace {
+// The gate programs compiled for one proof.  A gate's constraints are sums of monomials over the row's wires / constants / public-inputs
+// hash, and the prover needs only  sum_j alpha^(n0 + j) constraint_j  per challenge: exchanging the sums, every DISTINCT monomial of a gate
+// is evaluated once per point and weighted by B = sum over its occurrences (constraint j, coefficient) of alpha^(n0 + j) coefficient.
+// Distinct = equal factor multisets.  Order inside a gate: pure powers first, by operand and ascending exponent (the kernel turns a run
+// w, w^2, .. into one product each), then the mixed monomials.  (circuit_check has validated the program words.)
+struct CompiledGates {
+    std::vector<int64_t> prog;     // per gate: n_distinct, then per monomial: n_factors, (kind, index) x n_factors
+    std::vector<uint32_t> coff, boff;
+    std::vector<uint64_t> B;       // [C][n_dist]
+    size_t n_dist = 0;
+};
+void compile_gates(const sipp_plonk_circuit* c, const std::vector<uint64_t>& gapow, uint32_t C, uint32_t n_gc, CompiledGates* out) {
+    using Factors = std::vector<std::pair<int64_t, int64_t>>;
+    struct Mono {
+        Factors f;
+        std::vector<uint64_t> b;   // per challenge
+    };
+    std::vector<std::vector<Mono>> per_gate(c->num_gates);
+    for (uint32_t g = 0; g < c->num_gates; g++) {
+        const sipp_plonk_gate& ga = c->gates[g];
+        std::map<Factors, size_t> index;
+        std::vector<Mono>& monos = per_gate[g];
+        size_t w = ga.prog_offset;
+        for (uint32_t j = 0; j < ga.num_constraints; j++) {
+            const int64_t nm = c->programs[w++];
+            for (int64_t m = 0; m < nm; m++) {
+                const uint64_t coef = gl::from_i64(c->programs[w]);
+                const int64_t nf = c->programs[w + 1];
+                w += 2;
+                Factors f;
+                for (int64_t q = 0; q < nf; q++, w += 2) f.emplace_back(c->programs[w], c->programs[w + 1]);
+                std::sort(f.begin(), f.end());
+                auto it = index.find(f);
+                if (it == index.end()) {
+                    it = index.emplace(f, monos.size()).first;
+                    monos.push_back(Mono{f, std::vector<uint64_t>(C, 0)});
+                }
+                for (uint32_t cc = 0; cc < C; cc++)
+                    monos[it->second].b[cc] = gl::add(monos[it->second].b[cc], gl::mul(gapow[(size_t)cc * n_gc + j], coef));
+            }
+        }
+        auto pure = [](const Factors& f) { return !f.empty() && f.front() == f.back(); };   // sorted: all factors equal
+        std::stable_sort(monos.begin(), monos.end(), [&](const Mono& x, const Mono& y) {
+            const bool px = pure(x.f), py = pure(y.f);
+            if (px != py) return px;
+            if (px) return std::make_pair(x.f.front(), x.f.size()) < std::make_pair(y.f.front(), y.f.size());
+            return false;
+        });
+        out->n_dist += monos.size();
+    }
+    out->B.assign((size_t)C * std::max<size_t>(1, out->n_dist), 0);
+    const size_t stride = std::max<size_t>(1, out->n_dist);
+    size_t base = 0;
+    for (uint32_t g = 0; g < c->num_gates; g++) {
+        out->coff.push_back((uint32_t)out->prog.size());
+        out->boff.push_back((uint32_t)base);
+        out->prog.push_back((int64_t)per_gate[g].size());
+        for (const Mono& m : per_gate[g]) {
+            out->prog.push_back((int64_t)m.f.size());
+            for (const auto& kv : m.f) {
+                out->prog.push_back(kv.first);
+                out->prog.push_back(kv.second);
+            }
+            for (uint32_t cc = 0; cc < C; cc++) out->B[(size_t)cc * stride + base] = m.b[cc];
+            base++;
+        }
+    }
+}
+
 uint32_t num_gate_constraints(const sipp_plonk_circuit* c) {
     uint32_t m = 0;
     for (uint32_t g = 0; g < c->num_gates; g++) m = std::max(m, c->gates[g].num_constraints);
@@ -408,27 +478,34 @@ int quotient_chunks_impl(sipp_ctx* ctx, const uint64_t* d_wires_lde, const uint6
     if (gs) {
         const sipp_plonk_circuit* c = gs->c;
         a.cl = gs->d_consts_lde;
-        a.n_gates = c->num_gates; a.many_sel = c->num_selectors > 1; a.n_gc = num_gate_constraints(c);
+        a.n_gates = c->num_gates; a.many_sel = c->num_selectors > 1;
+        const uint32_t n_gc = num_gate_constraints(c);
         for (int q = 0; q < 4; q++) a.pih[q] = gl::canon(gs->pih[q]);
         // alpha_c^(terms in front of gate constraint j): the permutation terms C + C m, then the caller's own terms
-        std::vector<uint64_t> gp((size_t)C * std::max(1u, a.n_gc));
+        std::vector<uint64_t> gp((size_t)C * std::max(1u, n_gc));
         for (uint32_t cc = 0; cc < C; cc++) {
             uint64_t x = gl::pow(a.alpha[cc], (uint64_t)C + (uint64_t)C * m + num_gate_terms);
-            for (uint32_t j = 0; j < a.n_gc; j++) {
-                gp[(size_t)cc * a.n_gc + j] = x;
+            for (uint32_t j = 0; j < n_gc; j++) {
+                gp[(size_t)cc * n_gc + j] = x;
                 x = gl::mul(x, a.alpha[cc]);
             }
         }
-        uint64_t* d_gp = arena_alloc_t<uint64_t>(ctx, gp.size());
+        CompiledGates cg;
+        compile_gates(c, gp, C, n_gc, &cg);
+        a.n_dist = (uint32_t)std::max<size_t>(1, cg.n_dist);
         sipp_plonk_gate* d_gates = arena_alloc_t<sipp_plonk_gate>(ctx, c->num_gates);
-        int64_t* d_prog = arena_alloc_t<int64_t>(ctx, std::max(1u, c->program_words));
-        if (!d_gp || !d_gates || !d_prog) return SIPP_E_NOMEM;
-        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_gp, gp.data(), gp.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        int64_t* d_cprog = arena_alloc_t<int64_t>(ctx, std::max<size_t>(1, cg.prog.size()));
+        uint32_t* d_off = arena_alloc_t<uint32_t>(ctx, 2 * (size_t)c->num_gates);
+        uint64_t* d_B = arena_alloc_t<uint64_t>(ctx, std::max<size_t>(1, cg.B.size()));
+        if (!d_gates || !d_cprog || !d_off || !d_B) return SIPP_E_NOMEM;
+        std::vector<uint32_t> off(cg.coff);
+        off.insert(off.end(), cg.boff.begin(), cg.boff.end());
         SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_gates, c->gates, (size_t)c->num_gates * sizeof(sipp_plonk_gate), hipMemcpyHostToDevice, ctx->stream));
-        if (c->program_words)
-            SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_prog, c->programs, (size_t)c->program_words * 8, hipMemcpyHostToDevice, ctx->stream));
-        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `gp` and the caller's arrays are host memory
-        a.gapow = d_gp; a.gates = d_gates; a.prog = d_prog;
+        if (!cg.prog.empty()) SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_cprog, cg.prog.data(), cg.prog.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (!cg.B.empty()) SIPP_CHECK_HIP(ctx, hipMemcpyAsync(d_B, cg.B.data(), cg.B.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        SIPP_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // the vectors above and the caller's arrays are host memory
+        a.gates = d_gates; a.cprog = d_cprog; a.coff = d_off; a.boff = d_off + c->num_gates; a.cB = d_B;
     }
     {
         ProfScope ps(ctx, "plonk_quotient");
