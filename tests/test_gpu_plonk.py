@@ -391,6 +391,14 @@ def test_circuit_data_build_prove_verify_over_host_arrays(chain_len):
         assert d2.verify(pf3) == (0, 0) and _oracle.plonk_verify_gates(pf3, cs_cap, op, ofp, circ, [int(x) for x in d2.digest]) == 0
         assert _oracle.plonk_verify_gates(pf3, cs_cap, op, ofp, circ, digest) != 0
         d2.close()
+        # build / destroy gives every byte back (constants_sigmas, its oracle, the wire table, the schedule: ~17 MB at this size)
+        from sipp_amd._lib import device_free_bytes
+        free0 = device_free_bytes(0)
+        for _ in range(4):
+            d3 = sipp_amd.CircuitData(c, log_n, gp, gfp, gc, cs, ps.generators(circ), sched=sc)
+            assert device_free_bytes(0) < free0 - (8 << 20)
+            d3.close()
+        assert abs(device_free_bytes(0) - free0) < (8 << 20)
         bad = dict(circ, programs=circ["programs"][:-3])
         with pytest.raises(sipp_amd.SippError):
             sipp_amd.CircuitData(c, log_n, gp, gfp, sipp_amd.PlonkCircuit.from_dict(bad), cs, ps.generators(circ), sched=sc)
