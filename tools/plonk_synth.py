@@ -156,12 +156,25 @@ def _i64(c):
     return c if c < (1 << 63) else c - P
 
 
+_POSEIDON_TABLES = None
+
+
 def _poseidon_tables():
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle.py import plonky2_generic as g
-    return g.ALL_ROUND_CONSTANTS, g.MDS_ROWS, g.poseidon
+    """(ALL_ROUND_CONSTANTS[360], MDS rows, None): the constants from data/poseidon_goldilocks_rc.txt (the file the product's and the oracle's
+    headers are generated from) and the circulant-plus-diagonal MDS matrix -- read here directly, so that building the stand-in circuit
+    (bench.py's outer_plonk leg) imports nothing from oracle/"""
+    global _POSEIDON_TABLES
+    if _POSEIDON_TABLES is None:
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        vals = []
+        for line in open(os.path.join(root, "data", "poseidon_goldilocks_rc.txt")):
+            vals += [int(t, 16) for t in line.split("#")[0].replace(",", " ").split()]
+        assert len(vals) == 360
+        circ, diag = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20], [8] + [0] * 11
+        rows = [tuple(circ[(c - r) % 12] + (diag[r] if c == r else 0) for c in range(12)) for r in range(12)]
+        _POSEIDON_TABLES = (vals, rows, None)
+    return _POSEIDON_TABLES
 
 
 def poseidon_sbox_wire(rnd, i):
