@@ -264,7 +264,7 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
             t_c = time.perf_counter()
             ref_w = _oracle.plonk_generate_witness_levels(wires, cs[:K], log_n, gens, pih, sc)
             cpu_wit = {"cpu_witness_generation_s": time.perf_counter() - t_c, "cpu_witness_kind": "port (oracle/plonk_witness.c, one thread, incl. one copy of the table)",
-                       "cpu_cores": os.cpu_count(), "witness_matches_cpu_port": bool((to_host(d_w) == ref_w).all())}
+                       "cpu_cores": 1, "witness_matches_cpu_port": bool((to_host(d_w) == ref_w).all())}
             del ref_w
             ofp = _oracle.fri_params(rate_bits=rate_bits, cap_height=cap_h, pow_bits=pow_bits, num_queries=nq, pow_rule=0, hiding=0, arity_bits=4,
                                      final_poly_bits=5, degree_bits=log_n)
