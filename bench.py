@@ -274,7 +274,7 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
             lib_ok = _verify.lib_plonk_verify(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0
             lib_verify_ms = round(1e3 * (time.perf_counter() - t_v), 2)
             verified = lib_ok and _oracle.plonk_verify_gates(pf, cs_cap, _oracle.plonk_params(R, D, CH), ofp, circ, digest) == 0 and cpu_wit["witness_matches_cpu_port"]
-        return {"what": "plonky2 prove() INCLUDING witness generation (sipp_plonk_generate_witness, then sipp_plonk_prove_gates) on a synthetic circuit with gates and generators as data",
+        return {"what": "plonky2 prove() INCLUDING witness generation (sipp_plonk_generate_witness_levels, then sipp_plonk_prove_gates) on a synthetic chained circuit with gates, generators and the level schedule as data",
                 "shape": {"degree_bits": log_n, "num_wires": W, "num_routed_wires": R, "num_constants": K, "num_challenges": CH, "quotient_degree_factor": D,
                           "rate_bits": rate_bits, "cap_height": cap_h, "num_queries": nq, "pow_bits": pow_bits, "arity": 16,
                           "gates": circ["gate_names"], "num_gate_constraints": circ["num_gate_constraints"], "program_words": int(len(circ["programs"])),
@@ -283,8 +283,8 @@ def outer_plonk_leg(device=0, log_n=18, steps=5, verify=True):
                               "(built by un-vendored crates): 2^%d rows here" % log_n,
                 "ms_per_proof": ms, "steps": steps, "proof_words": int(len(pf)), "verified": verified,
                 **({"library_verifier_ms": lib_verify_ms} if verify else {}),
-                # HEADLINE, next to ms_per_proof (which contains it): witness generation now runs on the device (row-local generators; values
-                # that travel between rows through copy constraints are the caller's to order).  The host keeps what plonky2 does outside prove()
+                # HEADLINE, next to ms_per_proof (which contains it): witness generation runs on the device, level by level (values that travel
+                # between rows through copy constraints follow the build-time schedule).  The host keeps what plonky2 does outside prove()
                 "witness_generation_s": wit_ms * 1e-3, "witness_generation_ms": wit_ms, "prove_below_witness_ms": ms - wit_ms, "witness_generation": wit,
                 "end_to_end_s_per_proof": ms * 1e-3, "host_circuit_and_inputs_s": t_inputs, "host_to_host": host_to_host, **cpu_wit,
                 "kernel_ms_per_proof": {k: round(v, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1])},
