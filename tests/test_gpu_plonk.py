@@ -410,6 +410,54 @@ def test_circuit_data_build_prove_verify_over_host_arrays(chain_len):
         c.close()
 
 
+def test_witness_schedule_edge_cases(ctx):
+    """the level schedule at its edges, device against oracle/plonk_witness.c: no generator at all (a no-op), ONE level without copies
+    (= the row-local pass), empty levels in the middle (offsets that repeat), a schedule that names only SOME rows (the others keep
+    their cells), the smallest table the entry point takes (2 rows)"""
+    import sipp_amd
+    from tests.test_oracle_plonk import _synth
+    log_n = 10
+    ps, circ, _w, _cs, _gate, pis, pih = _synth(log_n, 136, 80, seed=5)
+    wires, cs, gate = ps.witness(circ, log_n, 5, pih, chain_len=4)
+    sc = ps.chain_schedule(log_n, 4)
+    K, gens, n = circ["num_constants"], ps.generators(circ), 1 << log_n
+    blank = ps.blank_generated(circ, wires, gate, value=9, sched=sc)
+    d_cs = dev(cs)
+
+    def both(sched_dict, gs, table=blank):
+        ref = _oracle.plonk_generate_witness_levels(table, cs[:K], log_n, gs, pih, sched_dict)
+        d_w = dev(table)
+        ctx.plonk_generate_witness_levels(d_w, d_cs[:K], log_n, gs, pih, sipp_amd.PlonkSchedule.from_dict(sched_dict))
+        got = host(d_w)
+        assert (got == ref).all()
+        return got
+    assert (both(sc, []) [:, np.flatnonzero(gate != 0)] == _oracle.plonk_generate_witness_levels(blank, cs[:K], log_n, [], pih, sc)[:, np.flatnonzero(gate != 0)]).all()
+    one = {"n_levels": 1, "rows": np.arange(n, dtype=np.uint32), "level_offsets": np.array([0, n], dtype=np.uint32),
+           "copy_src": np.zeros(0, dtype=np.uint64), "copy_dst": np.zeros(0, dtype=np.uint64), "copy_offsets": np.array([0, 0], dtype=np.uint32)}
+    assert (both(one, gens) == _oracle.plonk_generate_witness(blank, cs[:K], log_n, gens, pih)).all()
+    # empty levels: every level of the schedule twice, the second time with no rows and no copies
+    lo, co = sc["level_offsets"], sc["copy_offsets"]
+    gaps = dict(sc, n_levels=2 * sc["n_levels"], level_offsets=np.repeat(lo, 2)[1:].astype(np.uint32), copy_offsets=np.repeat(co, 2)[1:].astype(np.uint32))
+    assert (both(gaps, gens) == wires).all()
+    # only the Poseidon rows scheduled: everything else keeps its blanked cells
+    rows8 = np.flatnonzero(gate == 8).astype(np.uint32)
+    lv = sc["row_level"][rows8]
+    o = np.argsort(lv, kind="stable")
+    part = dict(sc, rows=rows8[o], level_offsets=np.searchsorted(lv[o], np.arange(sc["n_levels"] + 1)).astype(np.uint32))
+    got = both(part, gens)
+    assert (got[:, np.flatnonzero(gate == 2)] == blank[:, np.flatnonzero(gate == 2)]).all() and (got[12:24, rows8] != blank[12:24, rows8]).any()
+    # two rows
+    tiny_c, tiny_w = np.zeros((K, 2), dtype=np.uint64), np.arange(136 * 2, dtype=np.uint64).reshape(136, 2)
+    tiny_c[0] = 1                                                               # two arithmetic rows
+    tiny = {"n_levels": 1, "rows": np.array([0, 1], dtype=np.uint32), "level_offsets": np.array([0, 2], dtype=np.uint32),
+            "copy_src": np.array([3 * 2 + 0], dtype=np.uint64), "copy_dst": np.array([0 * 2 + 1], dtype=np.uint64),
+            "copy_offsets": np.array([0, 1], dtype=np.uint32)}
+    ref = _oracle.plonk_generate_witness_levels(tiny_w, tiny_c, 1, gens[:1], pih, tiny)
+    d_t = dev(tiny_w)
+    ctx.plonk_generate_witness_levels(d_t, dev(tiny_c), 1, gens[:1], pih, sipp_amd.PlonkSchedule.from_dict(tiny))
+    assert (host(d_t) == ref).all() and int(ref[0, 1]) == int(ref[3, 0])
+
+
 def test_bench_outer_plonk_leg_runs_and_verifies():
     """bench.py's `outer_plonk` leg (plonky2 prove() at the standard_ecc_config column counts, gates as data) at a small size: the leg
     proves, the oracle's verifier accepts the proof, and the object carries its own roofline entries"""
